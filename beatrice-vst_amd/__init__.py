@@ -1,0 +1,245 @@
+"""beatrice-vst_amd -- MI355X-native Beatrice 2 (rc.0) per-hop voice-conversion path.
+
+The product is the C-ABI shared library ``csrc/libbeatrice_hip.so`` (hand-written HIP for gfx950,
+declared in ``include/beatrice_abi.h`` + ``include/beatrice_batch.h``).  This Python module is
+plumbing only: ctypes prototypes for that ABI, used by the tests, ``bench.py`` and
+``__graft_entry__.py``.  The directory name contains a hyphen, so import it by path:
+
+    import importlib.util, sys
+    spec = importlib.util.spec_from_file_location("beatrice_vst_amd", ".../beatrice-vst_amd/__init__.py")
+
+There is deliberately NO CPU fallback here: ``load_product()`` raises if the HIP library is
+missing or cannot be loaded.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+PRODUCT_LIB = os.path.join(HERE, "csrc", "libbeatrice_hip.so")
+
+IN_HOP, OUT_HOP = 160, 240
+PHONE_CH, HID, PITCH_BINS = 128, 256, 448
+CODEBOOK, KV_LEN, KV_CH, N_BLOCKS = 512, 384, 128, 4
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes) for the rc0 generation (include/beatrice_abi.h)
+_RC0 = {
+    "CreatePhoneExtractor": (_vp, []), "DestroyPhoneExtractor": (None, [_vp]),
+    "CreatePhoneContext1": (_vp, []), "DestroyPhoneContext1": (None, [_vp]),
+    "CreatePitchEstimator": (_vp, []), "DestroyPitchEstimator": (None, [_vp]),
+    "CreatePitchContext1": (_vp, []), "DestroyPitchContext1": (None, [_vp]),
+    "CreateWaveformGenerator": (_vp, []), "DestroyWaveformGenerator": (None, [_vp]),
+    "CreateWaveformContext1": (_vp, []), "DestroyWaveformContext1": (None, [_vp]),
+    "CreateEmbeddingSetter": (_vp, []), "DestroyEmbeddingSetter": (None, [_vp]),
+    "CreateEmbeddingContext": (_vp, []), "DestroyEmbeddingContext": (None, [_vp]),
+    "ReadPhoneExtractorParameters": (C.c_int, [_vp, C.c_char_p]),
+    "ReadPitchEstimatorParameters": (C.c_int, [_vp, C.c_char_p]),
+    "ReadWaveformGeneratorParameters": (C.c_int, [_vp, C.c_char_p]),
+    "ReadEmbeddingSetterParameters": (C.c_int, [_vp, C.c_char_p]),
+    "ReadNSpeakers": (C.c_int, [C.c_char_p, _i32p]),
+    "ReadSpeakerEmbeddings": (C.c_int, [C.c_char_p, _f32p, _f32p, _f32p, _f32p]),
+    "SetVQNumNeighbors": (None, [_vp, C.c_int]),
+    "SetMinQuantizedPitch": (None, [_vp, C.c_int]),
+    "SetMaxQuantizedPitch": (None, [_vp, C.c_int]),
+    "ExtractPhone1": (None, [_vp, _f32p, _f32p, _vp]),
+    "EstimatePitch1": (None, [_vp, _f32p, _i32p, _f32p, _vp]),
+    "GenerateWaveform1": (None, [_vp, _f32p, _i32p, _f32p, _f32p, _vp]),
+    "SetCodebook": (None, [_vp, _f32p]),
+    "SetAdditiveSpeakerEmbedding": (None, [_vp, _f32p, _vp, _vp]),
+    "SetFormantShiftEmbedding": (None, [_vp, _f32p, _vp, _vp]),
+    "RegisterKeyValueSpeakerEmbedding": (None, [_vp, _f32p, _vp]),
+    "SetKeyValueSpeakerEmbedding": (None, [_vp, C.c_int, _vp, _vp]),
+}
+ABI_SYMBOLS_RC0 = ["Beatrice20rc0_" + n for n in _RC0]
+_LEGACY = ["CreatePhoneExtractor", "DestroyPhoneExtractor", "CreatePhoneContext1",
+           "DestroyPhoneContext1", "CreatePitchEstimator", "DestroyPitchEstimator",
+           "CreatePitchContext1", "DestroyPitchContext1", "CreateWaveformGenerator",
+           "DestroyWaveformGenerator", "CreateWaveformContext1", "DestroyWaveformContext1",
+           "ReadPhoneExtractorParameters", "ReadPitchEstimatorParameters",
+           "ReadWaveformGeneratorParameters", "ReadNSpeakers", "ReadSpeakerEmbeddings",
+           "ExtractPhone1", "SetMinQuantizedPitch", "SetMaxQuantizedPitch", "EstimatePitch1",
+           "GenerateWaveform1"]
+ABI_SYMBOLS_LEGACY = [g + "_" + n for g in ("Beatrice20a2", "Beatrice20b1") for n in _LEGACY]
+
+
+def fptr(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_f32p)
+
+
+def iptr(a):
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_i32p)
+
+
+class Abi:
+    """Typed view of any shared library exporting the Beatrice20rc0_* C-ABI."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise FileNotFoundError("beatrice library not built: %s" % path)
+        self.path = path
+        self.lib = C.CDLL(path, mode=C.RTLD_LOCAL)
+        for name, (res, args) in _RC0.items():
+            fn = getattr(self.lib, "Beatrice20rc0_" + name)
+            fn.restype, fn.argtypes = res, args
+            setattr(self, name, fn)
+
+
+def load_product():
+    """The HIP library.  Raises (never falls back) when it is not built or not loadable."""
+    return Abi(PRODUCT_LIB)
+
+
+class SpeakerTables:
+    """Caller-owned embedding tables, shaped as the reference host keeps them
+    (reference src/common/processor_core_2.cc:335-351: n_speakers+1 slots, last = morph result)."""
+
+    def __init__(self, abi, model_dir):
+        path = os.path.join(model_dir, "speaker_embeddings.bin").encode()
+        n = C.c_int(0)
+        err = abi.ReadNSpeakers(path, C.byref(n))
+        if err:
+            raise RuntimeError("ReadNSpeakers error %d" % err)
+        self.n_speakers = n.value
+        s = self.n_speakers + 1
+        self.codebooks = np.zeros((s, CODEBOOK, PHONE_CH), np.float32)
+        self.additive = np.zeros((s, HID), np.float32)
+        self.formant = np.zeros((9, HID), np.float32)
+        self.kv = np.zeros((s, KV_LEN, KV_CH), np.float32)
+        err = abi.ReadSpeakerEmbeddings(path, fptr(self.codebooks), fptr(self.additive),
+                                        fptr(self.formant), fptr(self.kv))
+        if err:
+            raise RuntimeError("ReadSpeakerEmbeddings error %d" % err)
+
+
+class Models:
+    def __init__(self, abi, model_dir):
+        self.abi = abi
+        self.phone = abi.CreatePhoneExtractor()
+        self.pitch = abi.CreatePitchEstimator()
+        self.wave = abi.CreateWaveformGenerator()
+        self.embed = abi.CreateEmbeddingSetter()
+        for obj, fn, name in ((self.phone, abi.ReadPhoneExtractorParameters, "phone_extractor.bin"),
+                              (self.pitch, abi.ReadPitchEstimatorParameters, "pitch_estimator.bin"),
+                              (self.wave, abi.ReadWaveformGeneratorParameters, "waveform_generator.bin"),
+                              (self.embed, abi.ReadEmbeddingSetterParameters, "embedding_setter.bin")):
+            err = fn(obj, os.path.join(model_dir, name).encode())
+            if err:
+                raise RuntimeError("%s: Beatrice_ErrorCode %d" % (name, err))
+        self.tables = SpeakerTables(abi, model_dir)
+
+    def close(self):
+        a = self.abi
+        a.DestroyPhoneExtractor(self.phone)
+        a.DestroyPitchEstimator(self.pitch)
+        a.DestroyWaveformGenerator(self.wave)
+        a.DestroyEmbeddingSetter(self.embed)
+
+
+def pitch_transform(q, avg=52.0, intonation=1.0, shift=0.0, correction=0.0, ctype=0):
+    """Host pitch math between EstimatePitch1 and GenerateWaveform1, in double precision
+    (restates reference src/common/processor_core_2.cc:190-252)."""
+    import math
+    per = 8.0
+    t = avg + (float(q) - avg) * intonation + per * shift
+    if correction != 0.0:
+        if ctype == 0:
+            near = (math.floor(t / per) + 0.5) * per
+            d = (t - near) * (2.0 / per)
+            t = near if abs(d) < 1e-4 else near + d * math.pow(abs(d), -correction) * (per / 2.0)
+        else:
+            # C++ std::round: half away from zero
+            tt = t / per
+            near = (math.floor(tt + 0.5) if tt >= 0 else -math.floor(-tt + 0.5)) * per
+            d = (t - near) * (2.0 / per)
+            if correction > 1 - 1e-4:
+                t = near
+            elif d >= 0.0:
+                t = near + math.pow(d, 1.0 / (1.0 - correction)) * (per / 2.0)
+            else:
+                t = near - math.pow(-d, 1.0 / (1.0 - correction)) * (per / 2.0)
+    r = math.floor(t + 0.5) if t >= 0 else -math.floor(-t + 0.5)
+    return int(min(max(int(r), 1), PITCH_BINS - 1))
+
+
+class Stream1:
+    """One stream through the 1-stream C-ABI with the reference's per-hop call protocol
+    (reference src/common/processor_core_2.cc:181-255 and :431-466)."""
+
+    def __init__(self, models, speaker=0, formant_index=4, vq_k=0, min_q=1, max_q=383):
+        self.m, a = models, models.abi
+        self.a = a
+        self.pc, self.tc = a.CreatePhoneContext1(), a.CreatePitchContext1()
+        self.wc, self.ec = a.CreateWaveformContext1(), a.CreateEmbeddingContext()
+        self.kv_count = N_BLOCKS
+        self.pitch_params = {}
+        self.set_target_speaker(speaker)
+        while self.set_kv_block():
+            pass
+        self.set_formant_index(formant_index)
+        a.SetMinQuantizedPitch(self.tc, min_q)
+        a.SetMaxQuantizedPitch(self.tc, max_q)
+        a.SetVQNumNeighbors(self.pc, vq_k)
+
+    def set_target_speaker(self, s):
+        t, a = self.m.tables, self.a
+        a.SetCodebook(self.pc, fptr(t.codebooks[s]))
+        a.SetAdditiveSpeakerEmbedding(self.m.embed, fptr(t.additive[s]), self.ec, self.wc)
+        a.RegisterKeyValueSpeakerEmbedding(self.m.embed, fptr(t.kv[s]), self.ec)
+        self.kv_count = 0
+
+    def set_formant_index(self, idx):
+        self.a.SetFormantShiftEmbedding(self.m.embed, fptr(self.m.tables.formant[idx]), self.ec, self.wc)
+
+    def set_kv_block(self):
+        if self.kv_count < N_BLOCKS:
+            self.a.SetKeyValueSpeakerEmbedding(self.m.embed, self.kv_count, self.ec, self.wc)
+            self.kv_count += 1
+            return True
+        return False
+
+    def hop(self, x160, return_all=False):
+        a = self.a
+        x = np.ascontiguousarray(x160, np.float32)
+        self.set_kv_block()
+        phone = np.zeros(PHONE_CH, np.float32)
+        a.ExtractPhone1(self.m.phone, fptr(x), fptr(phone), self.pc)
+        q = np.zeros(1, np.int32)
+        feat = np.zeros(4, np.float32)
+        a.EstimatePitch1(self.m.pitch, fptr(x), iptr(q), fptr(feat), self.tc)
+        q2 = np.array([pitch_transform(int(q[0]), **self.pitch_params)], np.int32)
+        out = np.zeros(OUT_HOP, np.float32)
+        a.GenerateWaveform1(self.m.wave, fptr(phone), iptr(q2), fptr(feat), fptr(out), self.wc)
+        if return_all:
+            return out, phone, int(q[0]), feat, int(q2[0])
+        return out
+
+    def close(self):
+        a = self.a
+        a.DestroyPhoneContext1(self.pc)
+        a.DestroyPitchContext1(self.tc)
+        a.DestroyWaveformContext1(self.wc)
+        a.DestroyEmbeddingContext(self.ec)
+
+
+def synth_audio(n_samples, seed=0, sr=16000):
+    """Deterministic voiced-like test signal: gliding band-limited saw,
+    4 Hz syllable envelope, low-level noise."""
+    rng = np.random.Generator(np.random.PCG64(0xBEA7 + seed))
+    t = np.arange(n_samples) / sr
+    period = 2.0 + 2.0 * rng.random()
+    f0 = 90.0 * (400.0 / 90.0) ** (0.5 - 0.5 * np.cos(2 * np.pi * t / period + rng.random() * 6.28))
+    ph = 2 * np.pi * np.cumsum(f0) / sr
+    x = np.zeros(n_samples)
+    for h in range(1, 20):
+        x += np.sin(h * ph) / h * (h * f0 < 0.45 * sr)
+    env = 0.55 + 0.45 * np.sin(2 * np.pi * 4.0 * t + rng.random() * 6.28)
+    x = 0.3 * x / 1.8 * env + 0.0316 * 0.3 * rng.standard_normal(n_samples)
+    return x.astype(np.float32)
