@@ -1,0 +1,373 @@
+// abi.hip -- the 1-stream C-ABI of include/beatrice_abi.h on top of the HIP modules.
+//
+// Each entry point cites the reference declaration it replaces (reference
+// lib/beatricelib/beatrice.h) and the reference call site that defines its contract (reference
+// src/common/processor_core_2.cc).  Conventions of the boundary:
+//   * only the file readers can fail (Beatrice_ErrorCode); every other entry returns void and, on
+//     an internal HIP failure, leaves zeros in its outputs -- never throws, never blocks unboundedly;
+//   * per-hop calls are synchronous: outputs are valid on return (the host consumes them on the
+//     audio thread right away, processor_core_2.cc:184-255);
+//   * per-hop calls do not allocate: device state, pinned staging and the HIP stream are created in
+//     Create*Context1, which the host calls from non-real-time threads (processor_core_2.cc:259-266).
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "abi_objects.h"
+
+using namespace bhip;
+
+namespace bhip {
+
+// ---- model files (MODEL_SPEC section 5); error mapping = reference beatrice.h:30-37 -----------
+static const uint32_t kMagic = 0x43525442u, kVersion = 1u;
+
+Beatrice_ErrorCode parse_model_bytes(const unsigned char* bytes, size_t size, uint32_t kind, long expect_floats,
+                                     std::vector<float>* out) {
+  if (size < 16) return Beatrice_kFileTooSmall;
+  uint32_t hdr[4];
+  std::memcpy(hdr, bytes, 16);
+  if (hdr[0] != kMagic || hdr[1] != kind || hdr[2] != kVersion) return Beatrice_kInvalidFileSize;
+  const size_t payload = size - 16;
+  if (expect_floats >= 0) {
+    if (payload < (size_t)expect_floats * 4) return Beatrice_kFileTooSmall;
+    if (payload > (size_t)expect_floats * 4) return Beatrice_kFileTooLarge;
+  }
+  if (payload % 4 != 0 || (size_t)hdr[3] * 4 != payload) return Beatrice_kInvalidFileSize;
+  out->resize(payload / 4);
+  std::memcpy(out->data(), bytes + 16, payload);
+  return Beatrice_kSuccess;
+}
+
+Beatrice_ErrorCode read_model_file(const char* path, uint32_t kind, long expect_floats, std::vector<float>* out) {
+  std::ifstream f(path, std::ios::binary | std::ios::ate);
+  if (!f) return Beatrice_kFileOpenError;
+  const std::streamoff size = f.tellg();
+  if (size < 0) return Beatrice_kFileOpenError;
+  std::vector<unsigned char> bytes((size_t)size);
+  f.seekg(0);
+  if (size > 0 && !f.read(reinterpret_cast<char*>(bytes.data()), size)) return Beatrice_kFileOpenError;
+  return parse_model_bytes(bytes.data(), bytes.size(), kind, expect_floats, out);
+}
+
+template <class Obj>
+static Beatrice_ErrorCode install(Obj* m, const std::vector<float>& host) {
+  m->loaded = false;
+  if (!m->blob.upload(host.data(), host.size())) return Beatrice_kFileOpenError;  // device failure
+  m->w.bind(m->blob.d);
+  m->loaded = true;
+  return Beatrice_kSuccess;
+}
+
+bool make_stream(hipStream_t* s) { BHIP_TRY(hipStreamCreateWithFlags(s, hipStreamNonBlocking)); return true; }
+
+}  // namespace bhip
+
+extern "C" {
+
+// ================================ phone extractor ==============================================
+// ref beatrice.h:230-232
+Beatrice20rc0_PhoneExtractor* Beatrice20rc0_CreatePhoneExtractor(void) { return new Beatrice20rc0_PhoneExtractor(); }
+void Beatrice20rc0_DestroyPhoneExtractor(Beatrice20rc0_PhoneExtractor* m) {
+  if (!m) return;
+  m->blob.release();
+  delete m;
+}
+// ref beatrice.h:235-238; caller processor_core_2.cc:302-307
+Beatrice_ErrorCode Beatrice20rc0_ReadPhoneExtractorParameters(Beatrice20rc0_PhoneExtractor* m, const char* path) {
+  std::vector<float> host;
+  const Beatrice_ErrorCode e = read_model_file(path, KIND_PHONE, (long)PhoneWeights::n_floats(), &host);
+  return e ? e : install(m, host);
+}
+// ref beatrice.h:233-234; callers processor_core_2.h:36, processor_core_2.cc:263
+Beatrice20rc0_PhoneContext1* Beatrice20rc0_CreatePhoneContext1(void) {
+  auto* c = new Beatrice20rc0_PhoneContext1();
+  c->ok = make_stream(&c->stream) && c->st.create(1, nullptr) &&
+          hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(float) * (B_IN_HOP + B_PHONE_CH), hipHostMallocDefault),
+                 "hipHostMalloc");
+  return c;
+}
+void Beatrice20rc0_DestroyPhoneContext1(Beatrice20rc0_PhoneContext1* c) {
+  if (!c) return;
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto& e : c->cache) { (void)hipFree(e.d_cbT); (void)hipFree(e.d_cnorm); }
+  c->st.destroy();
+  if (c->h_io) (void)hipHostFree(c->h_io);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+// ref beatrice.h:239-242; caller processor_core_2.cc:585-590 (clamped there to 0..8)
+void Beatrice20rc0_SetVQNumNeighbors(Beatrice20rc0_PhoneContext1* ctx, int k) {
+  if (!ctx || !ctx->ok) return;
+  k = k < 0 ? 0 : (k > B_CODEBOOK ? B_CODEBOOK : k);
+  (void)hip_ok(hipMemcpy(ctx->st.d_vqk, &k, sizeof(int), hipMemcpyHostToDevice), "vq k");
+}
+// ref beatrice.h:318-322.  The host passes a pointer into its own table and, in morph mode, calls
+// this every hop (processor_core_2.cc:118-121), so it must be O(1) after first sight: the device
+// copy (transposed + norms) is cached per host pointer.  The table contents are assumed immutable
+// while cached, which holds for the reference host (tables are written once in LoadModel).
+void Beatrice20rc0_SetCodebook(Beatrice20rc0_PhoneContext1* ctx, const float* codebook) {
+  if (!ctx || !ctx->ok || !codebook) return;
+  const CodebookEntry* hit = nullptr;
+  for (const auto& e : ctx->cache) if (e.host == codebook) { hit = &e; break; }
+  if (!hit) {
+    CodebookEntry e{codebook, nullptr, nullptr};
+    float* d_raw = nullptr;
+    const size_t n = (size_t)B_CODEBOOK * B_PHONE_CH;
+    bool ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&d_raw), n * sizeof(float)), "cb raw") &&
+              hip_ok(hipMalloc(reinterpret_cast<void**>(&e.d_cbT), n * sizeof(float)), "cbT") &&
+              hip_ok(hipMalloc(reinterpret_cast<void**>(&e.d_cnorm), B_CODEBOOK * sizeof(float)), "cnorm") &&
+              hip_ok(hipMemcpy(d_raw, codebook, n * sizeof(float), hipMemcpyHostToDevice), "cb upload");
+    if (ok) {
+      codebook_prepare(d_raw, 1, e.d_cbT, e.d_cnorm, ctx->stream);
+      ok = hip_ok(hipStreamSynchronize(ctx->stream), "cb prep");
+    }
+    if (d_raw) (void)hipFree(d_raw);
+    if (!ok) { if (e.d_cbT) (void)hipFree(e.d_cbT); if (e.d_cnorm) (void)hipFree(e.d_cnorm); return; }
+    ctx->cache.push_back(e);
+    hit = &ctx->cache.back();
+  }
+  const float* ptrs[2] = {hit->d_cbT, hit->d_cnorm};
+  (void)hip_ok(hipMemcpy(ctx->st.d_cbT, &ptrs[0], sizeof(float*), hipMemcpyHostToDevice), "set cbT");
+  (void)hip_ok(hipMemcpy(ctx->st.d_cnorm, &ptrs[1], sizeof(float*), hipMemcpyHostToDevice), "set cnorm");
+}
+// ref beatrice.h:243-247; caller processor_core_2.cc:183-185
+void Beatrice20rc0_ExtractPhone1(const Beatrice20rc0_PhoneExtractor* m, const float* input, float* output,
+                                 Beatrice20rc0_PhoneContext1* ctx) {
+  std::memset(output, 0, sizeof(float) * B_PHONE_CH);
+  if (!m || !m->loaded || !ctx || !ctx->ok) return;
+  float* h_in = ctx->h_io;
+  float* h_out = ctx->h_io + B_IN_HOP;
+  std::memcpy(h_in, input, sizeof(float) * B_IN_HOP);
+  bool ok = hip_ok(hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * B_IN_HOP, hipMemcpyHostToDevice, ctx->stream), "in");
+  phone_forward(m->w, ctx->st, ctx->stream);
+  ok = ok && hip_ok(hipMemcpyAsync(h_out, ctx->st.d_phone, sizeof(float) * B_PHONE_CH, hipMemcpyDeviceToHost, ctx->stream), "out");
+  ok = hip_ok(hipStreamSynchronize(ctx->stream), "sync") && ok;
+  if (ok) std::memcpy(output, h_out, sizeof(float) * B_PHONE_CH);
+}
+
+// ================================ pitch estimator ==============================================
+// ref beatrice.h:249-251
+Beatrice20rc0_PitchEstimator* Beatrice20rc0_CreatePitchEstimator(void) { return new Beatrice20rc0_PitchEstimator(); }
+void Beatrice20rc0_DestroyPitchEstimator(Beatrice20rc0_PitchEstimator* m) {
+  if (!m) return;
+  m->blob.release();
+  delete m;
+}
+// ref beatrice.h:254-257; caller processor_core_2.cc:308-313
+Beatrice_ErrorCode Beatrice20rc0_ReadPitchEstimatorParameters(Beatrice20rc0_PitchEstimator* m, const char* path) {
+  std::vector<float> host;
+  const Beatrice_ErrorCode e = read_model_file(path, KIND_PITCH, (long)PitchWeights::n_floats(), &host);
+  return e ? e : install(m, host);
+}
+// ref beatrice.h:252-253
+Beatrice20rc0_PitchContext1* Beatrice20rc0_CreatePitchContext1(void) {
+  auto* c = new Beatrice20rc0_PitchContext1();
+  c->ok = make_stream(&c->stream) && c->st.create(1, nullptr, false) &&
+          hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(float) * (B_IN_HOP + 8), hipHostMallocDefault), "hipHostMalloc");
+  return c;
+}
+void Beatrice20rc0_DestroyPitchContext1(Beatrice20rc0_PitchContext1* c) {
+  if (!c) return;
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->st.destroy();
+  if (c->h_io) (void)hipHostFree(c->h_io);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+static int clamp_bin(int q) { return q < 1 ? 1 : (q > B_PITCH_BINS - 1 ? B_PITCH_BINS - 1 : q); }
+// ref beatrice.h:258-265; callers processor_core_2.cc:561-583
+void Beatrice20rc0_SetMinQuantizedPitch(Beatrice20rc0_PitchContext1* ctx, int q) {
+  if (!ctx || !ctx->ok) return;
+  q = clamp_bin(q);
+  (void)hip_ok(hipMemcpy(ctx->st.d_min_q, &q, sizeof(int), hipMemcpyHostToDevice), "min q");
+}
+void Beatrice20rc0_SetMaxQuantizedPitch(Beatrice20rc0_PitchContext1* ctx, int q) {
+  if (!ctx || !ctx->ok) return;
+  q = clamp_bin(q);
+  (void)hip_ok(hipMemcpy(ctx->st.d_max_q, &q, sizeof(int), hipMemcpyHostToDevice), "max q");
+}
+// ref beatrice.h:266-271; caller processor_core_2.cc:186-189
+void Beatrice20rc0_EstimatePitch1(const Beatrice20rc0_PitchEstimator* m, const float* input, int* out_q, float* out_feat,
+                                  Beatrice20rc0_PitchContext1* ctx) {
+  *out_q = 1;
+  std::memset(out_feat, 0, sizeof(float) * 4);
+  if (!m || !m->loaded || !ctx || !ctx->ok) return;
+  float* h_in = ctx->h_io;
+  float* h_feat = ctx->h_io + B_IN_HOP;
+  int* h_q = reinterpret_cast<int*>(ctx->h_io + B_IN_HOP + 4);
+  std::memcpy(h_in, input, sizeof(float) * B_IN_HOP);
+  bool ok = hip_ok(hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * B_IN_HOP, hipMemcpyHostToDevice, ctx->stream), "in");
+  pitch_forward(m->w, ctx->st, ctx->stream);
+  ok = ok && hip_ok(hipMemcpyAsync(h_feat, ctx->st.d_feat, sizeof(float) * 4, hipMemcpyDeviceToHost, ctx->stream), "feat");
+  ok = ok && hip_ok(hipMemcpyAsync(h_q, ctx->st.d_q_raw, sizeof(int), hipMemcpyDeviceToHost, ctx->stream), "q");
+  ok = hip_ok(hipStreamSynchronize(ctx->stream), "sync") && ok;
+  if (ok) { *out_q = *h_q; std::memcpy(out_feat, h_feat, sizeof(float) * 4); }
+}
+
+// ================================ waveform generator ===========================================
+// ref beatrice.h:292-294
+Beatrice20rc0_WaveformGenerator* Beatrice20rc0_CreateWaveformGenerator(void) { return new Beatrice20rc0_WaveformGenerator(); }
+void Beatrice20rc0_DestroyWaveformGenerator(Beatrice20rc0_WaveformGenerator* m) {
+  if (!m) return;
+  m->blob.release();
+  delete m;
+}
+// ref beatrice.h:297-300; caller processor_core_2.cc:314-319
+Beatrice_ErrorCode Beatrice20rc0_ReadWaveformGeneratorParameters(Beatrice20rc0_WaveformGenerator* m, const char* path) {
+  std::vector<float> host;
+  const Beatrice_ErrorCode e = read_model_file(path, KIND_WAVE, (long)WaveWeights::n_floats(), &host);
+  return e ? e : install(m, host);
+}
+// ref beatrice.h:295-296.  Inputs of one hop (phone 128 f32 | feat 4 f32 | bin 1 i32) are one
+// contiguous device block so GenerateWaveform1 needs a single host-to-device copy.
+Beatrice20rc0_WaveformContext1* Beatrice20rc0_CreateWaveformContext1(void) {
+  auto* c = new Beatrice20rc0_WaveformContext1();
+  const size_t in_floats = B_PHONE_CH + 4 + 1;
+  c->ok = make_stream(&c->stream) &&
+          hip_ok(hipMalloc(reinterpret_cast<void**>(&c->d_inputs), sizeof(float) * in_floats), "inputs") &&
+          hip_ok(hipMemset(c->d_inputs, 0, sizeof(float) * in_floats), "inputs0") &&
+          c->st.create(1, 1, 1, 1, c->d_inputs, reinterpret_cast<int*>(c->d_inputs + B_PHONE_CH + 4), c->d_inputs + B_PHONE_CH) &&
+          hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(float) * (in_floats + B_OUT_HOP), hipHostMallocDefault), "hipHostMalloc");
+  return c;
+}
+void Beatrice20rc0_DestroyWaveformContext1(Beatrice20rc0_WaveformContext1* c) {
+  if (!c) return;
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->st.destroy();
+  if (c->d_inputs) (void)hipFree(c->d_inputs);
+  if (c->h_io) (void)hipHostFree(c->h_io);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+// ref beatrice.h:301-307; caller processor_core_2.cc:253-255
+void Beatrice20rc0_GenerateWaveform1(const Beatrice20rc0_WaveformGenerator* m, const float* phone, const int* q,
+                                     const float* feat, float* output, Beatrice20rc0_WaveformContext1* ctx) {
+  std::memset(output, 0, sizeof(float) * B_OUT_HOP);
+  if (!m || !m->loaded || !ctx || !ctx->ok) return;
+  const size_t in_floats = B_PHONE_CH + 4 + 1;
+  float* h_in = ctx->h_io;
+  float* h_out = ctx->h_io + in_floats;
+  std::memcpy(h_in, phone, sizeof(float) * B_PHONE_CH);
+  std::memcpy(h_in + B_PHONE_CH, feat, sizeof(float) * 4);
+  std::memcpy(h_in + B_PHONE_CH + 4, q, sizeof(int));
+  bool ok = hip_ok(hipMemcpyAsync(ctx->d_inputs, h_in, sizeof(float) * in_floats, hipMemcpyHostToDevice, ctx->stream), "in");
+  wave_forward(m->w, ctx->st, ctx->stream);
+  ok = ok && hip_ok(hipMemcpyAsync(h_out, ctx->st.d_out, sizeof(float) * B_OUT_HOP, hipMemcpyDeviceToHost, ctx->stream), "out");
+  ok = hip_ok(hipStreamSynchronize(ctx->stream), "sync") && ok;
+  if (ok) std::memcpy(output, h_out, sizeof(float) * B_OUT_HOP);
+}
+
+// ================================ embedding setter =============================================
+// ref beatrice.h:309-311
+Beatrice20rc0_EmbeddingSetter* Beatrice20rc0_CreateEmbeddingSetter(void) { return new Beatrice20rc0_EmbeddingSetter(); }
+void Beatrice20rc0_DestroyEmbeddingSetter(Beatrice20rc0_EmbeddingSetter* m) {
+  if (!m) return;
+  m->blob.release();
+  delete m;
+}
+// ref beatrice.h:314-317; caller processor_core_2.cc:320-325
+Beatrice_ErrorCode Beatrice20rc0_ReadEmbeddingSetterParameters(Beatrice20rc0_EmbeddingSetter* m, const char* path) {
+  std::vector<float> host;
+  const Beatrice_ErrorCode e = read_model_file(path, KIND_EMBED, (long)EmbedWeights::n_floats(), &host);
+  return e ? e : install(m, host);
+}
+// ref beatrice.h:312-313
+Beatrice20rc0_EmbeddingContext* Beatrice20rc0_CreateEmbeddingContext(void) {
+  auto* c = new Beatrice20rc0_EmbeddingContext();
+  const size_t n = (size_t)B_KV_LEN * B_KV_CH + 4 * B_HID;
+  c->ok = make_stream(&c->stream) && hip_ok(hipMalloc(reinterpret_cast<void**>(&c->d_block), sizeof(float) * n), "embed ctx") &&
+          hip_ok(hipMemset(c->d_block, 0, sizeof(float) * n), "embed ctx0");
+  c->d_kv_raw = c->d_block;
+  c->d_tmp = c->d_block + (size_t)B_KV_LEN * B_KV_CH;
+  c->d_add = c->d_tmp + B_HID;
+  c->d_frm = c->d_add + B_HID;
+  return c;
+}
+void Beatrice20rc0_DestroyEmbeddingContext(Beatrice20rc0_EmbeddingContext* c) {
+  if (!c) return;
+  if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+  if (c->d_block) (void)hipFree(c->d_block);
+  delete c;
+}
+static void set_vector(const Beatrice20rc0_EmbeddingSetter* m, const float* w, const float* b, const float* embedding,
+                       Beatrice20rc0_EmbeddingContext* ec, float* d_ctx_vec, float* d_wave_row) {
+  if (!m || !m->loaded || !ec || !ec->ok || !embedding) return;
+  if (!hip_ok(hipMemcpy(ec->d_tmp, embedding, sizeof(float) * B_HID, hipMemcpyHostToDevice), "emb up")) return;
+  embed_project_rows(w, b, ec->d_tmp, d_ctx_vec, 1, ec->stream);
+  if (d_wave_row) (void)hip_ok(hipMemcpyAsync(d_wave_row, d_ctx_vec, sizeof(float) * B_HID, hipMemcpyDeviceToDevice, ec->stream), "emb d2d");
+  (void)hip_ok(hipStreamSynchronize(ec->stream), "emb sync");
+}
+// ref beatrice.h:323-327; callers processor_core_2.cc:137-141, 451-455
+void Beatrice20rc0_SetAdditiveSpeakerEmbedding(const Beatrice20rc0_EmbeddingSetter* m, const float* embedding,
+                                               Beatrice20rc0_EmbeddingContext* ec, Beatrice20rc0_WaveformContext1* wc) {
+  if (!m || !m->loaded) return;
+  set_vector(m, m->w.add_w, m->w.add_b, embedding, ec, ec ? ec->d_add : nullptr, (wc && wc->ok) ? wc->st.d_add_tab : nullptr);
+}
+// ref beatrice.h:328-332; caller processor_core_2.cc:475-479
+void Beatrice20rc0_SetFormantShiftEmbedding(const Beatrice20rc0_EmbeddingSetter* m, const float* embedding,
+                                            Beatrice20rc0_EmbeddingContext* ec, Beatrice20rc0_WaveformContext1* wc) {
+  if (!m || !m->loaded) return;
+  set_vector(m, m->w.frm_w, m->w.frm_b, embedding, ec, ec ? ec->d_frm : nullptr, (wc && wc->ok) ? wc->st.d_frm_tab : nullptr);
+}
+// ref beatrice.h:333-338; callers processor_core_2.cc:165-170, 456-462.  Copies: the host rewrites
+// its morph slot in place right after registering (processor_core_2.cc:158-170).
+void Beatrice20rc0_RegisterKeyValueSpeakerEmbedding(const Beatrice20rc0_EmbeddingSetter* m, const float* kv,
+                                                    Beatrice20rc0_EmbeddingContext* ec) {
+  (void)m;
+  if (!ec || !ec->ok || !kv) return;
+  (void)hip_ok(hipMemcpy(ec->d_kv_raw, kv, sizeof(float) * B_KV_LEN * B_KV_CH, hipMemcpyHostToDevice), "kv up");
+}
+// ref beatrice.h:339-343; caller processor_core_2.h:161-169 (one block per hop after a change)
+void Beatrice20rc0_SetKeyValueSpeakerEmbedding(const Beatrice20rc0_EmbeddingSetter* m, int block,
+                                               Beatrice20rc0_EmbeddingContext* ec, Beatrice20rc0_WaveformContext1* wc) {
+  if (!m || !m->loaded || !ec || !ec->ok || !wc || !wc->ok || block < 0 || block >= B_NBLOCKS) return;
+  embed_project_kv(m->w, block, ec->d_kv_raw, 1, wc->st.d_kt[block], wc->st.d_v[block], ec->stream);
+  (void)hip_ok(hipStreamSynchronize(ec->stream), "kv sync");
+}
+
+// ================================ speaker file =================================================
+static Beatrice_ErrorCode open_speakers(const char* path, std::vector<float>* host, int* n) {
+  const Beatrice_ErrorCode e = read_model_file(path, KIND_SPEAKERS, -1, host);
+  if (e) return e;
+  const long per = (long)B_CODEBOOK * B_PHONE_CH + B_HID + (long)B_KV_LEN * B_KV_CH;
+  const long body = (long)host->size() - 9L * B_HID;
+  if (body < per) return Beatrice_kFileTooSmall;
+  if (body % per != 0) return Beatrice_kInvalidFileSize;
+  *n = (int)(body / per);
+  return Beatrice_kSuccess;
+}
+// ref beatrice.h:273-275; caller processor_core_2.cc:328-333
+Beatrice_ErrorCode Beatrice20rc0_ReadNSpeakers(const char* path, int* output) {
+  std::vector<float> host;
+  int n = 0;
+  const Beatrice_ErrorCode e = open_speakers(path, &host, &n);
+  if (e) return e;
+  *output = n;
+  return Beatrice_kSuccess;
+}
+// ref beatrice.h:276-290; caller processor_core_2.cc:344-351
+Beatrice_ErrorCode Beatrice20rc0_ReadSpeakerEmbeddings(const char* path, float* codebook, float* additive, float* formant,
+                                                       float* kv) {
+  std::vector<float> host;
+  int n = 0;
+  const Beatrice_ErrorCode e = open_speakers(path, &host, &n);
+  if (e) return e;
+  const float* p = host.data();
+  std::memcpy(formant, p, sizeof(float) * 9 * B_HID);
+  p += 9 * B_HID;
+  for (int s = 0; s < n; ++s) {
+    std::memcpy(codebook + (size_t)s * B_CODEBOOK * B_PHONE_CH, p, sizeof(float) * B_CODEBOOK * B_PHONE_CH);
+    p += B_CODEBOOK * B_PHONE_CH;
+    std::memcpy(additive + (size_t)s * B_HID, p, sizeof(float) * B_HID);
+    p += B_HID;
+    std::memcpy(kv + (size_t)s * B_KV_LEN * B_KV_CH, p, sizeof(float) * B_KV_LEN * B_KV_CH);
+    p += B_KV_LEN * B_KV_CH;
+  }
+  return Beatrice_kSuccess;
+}
+
+}  // extern "C"

@@ -1,0 +1,177 @@
+// common.hip -- device memory plumbing shared by the modules: parameter blobs, ring arenas,
+// weight-pointer binding (tensor order of MODEL_SPEC section 5) and the set-time launchers.
+#include <cstdio>
+#include <cstdlib>
+
+#include "engine.h"
+
+namespace bhip {
+
+bool hip_ok(hipError_t e, const char* what) {
+  if (e == hipSuccess) return true;
+  static const bool verbose = std::getenv("BEATRICE_HIP_DEBUG") != nullptr;
+  if (verbose) std::fprintf(stderr, "[beatrice_hip] %s -> %s\n", what, hipGetErrorString(e));
+  (void)hipGetLastError();
+  return false;
+}
+
+bool DeviceBlob::upload(const float* host, size_t n) {
+  release();
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), n * sizeof(float)));
+  n_floats = n;
+  BHIP_TRY(hipMemcpy(d, host, n * sizeof(float), hipMemcpyHostToDevice));
+  return true;
+}
+void DeviceBlob::release() {
+  if (d) (void)hipFree(d);
+  d = nullptr;
+  n_floats = 0;
+}
+
+bool RingArena::build(int B_, const std::vector<RingSpec>& specs) {
+  release();
+  B = B_;
+  size_t total = 0;
+  for (const RingSpec& s : specs) total += ((size_t)B * s.C * s.n * s.m + 63) / 64 * 64;
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&base), total * sizeof(float)));
+  floats = total;
+  BHIP_TRY(hipMemset(base, 0, total * sizeof(float)));
+  size_t off = 0;
+  for (const RingSpec& s : specs) {
+    s.ring->base = base + off;
+    s.ring->C = s.C;
+    s.ring->n = s.n;
+    s.ring->m = s.m;
+    off += ((size_t)B * s.C * s.n * s.m + 63) / 64 * 64;
+    rings.push_back(s.ring);
+  }
+  return true;
+}
+bool RingArena::zero_all(hipStream_t s) const {
+  BHIP_TRY(hipMemsetAsync(base, 0, floats * sizeof(float), s));
+  return true;
+}
+bool RingArena::zero_stream(int b, hipStream_t s) const {
+  for (const Ring* r : rings) {
+    const size_t per = ring_stream_floats(*r);
+    BHIP_TRY(hipMemsetAsync(r->base + (size_t)b * per, 0, per * sizeof(float), s));
+  }
+  return true;
+}
+void RingArena::release() {
+  if (base) (void)hipFree(base);
+  base = nullptr;
+  floats = 0;
+  rings.clear();
+}
+
+// ---- weight binding: the tensor order of MODEL_SPEC section 5 --------------------------------
+static const int kPhoneF[5][4] = {{1, 64, 10, 5}, {64, 128, 8, 4}, {128, 256, 4, 2}, {256, 256, 4, 2}, {256, 256, 4, 2}};
+
+size_t PhoneWeights::n_floats() {
+  size_t n = 0;
+  for (auto& f : kPhoneF) n += (size_t)f[0] * f[2] * f[1] + f[1];
+  n += 4 * (5 * 256 * 256 + 256);
+  n += 2 * 256 * 768 + 2 * 768;
+  n += 256 * B_PHONE_CH + B_PHONE_CH;
+  return n;
+}
+void PhoneWeights::bind(const float* p) {
+  f1_w = p; p += 10 * 64;
+  f1_b = p; p += 64;
+  for (int i = 1; i < 5; ++i) {
+    f_w[i - 1] = p; p += (size_t)kPhoneF[i][0] * kPhoneF[i][2] * kPhoneF[i][1];
+    f_b[i - 1] = p; p += kPhoneF[i][1];
+  }
+  for (int i = 0; i < 4; ++i) { rb_w[i] = p; p += 5 * 256 * 256; rb_b[i] = p; p += 256; }
+  gru_wih = p; p += 256 * 768;
+  gru_whh = p; p += 256 * 768;
+  gru_bih = p; p += 768;
+  gru_bhh = p; p += 768;
+  out_w = p; p += 256 * B_PHONE_CH;
+  out_b = p; p += B_PHONE_CH;
+}
+
+size_t PitchWeights::n_floats() {
+  size_t n = 2 * B_FFT_N;
+  n += 3 * B_SPEC_BINS * 128 + 128 + 2 * (3 * 128 * 128 + 128);
+  n += 2 * 128 * 384 + 2 * 384;
+  n += 128 * B_PITCH_BINS + B_PITCH_BINS + 128 + 1;
+  return n;
+}
+void PitchWeights::bind(const float* p) {
+  window = p; p += B_FFT_N;
+  twiddle = p; p += B_FFT_N;
+  for (int i = 0; i < 3; ++i) {
+    const int cin = i == 0 ? B_SPEC_BINS : 128;
+    p_w[i] = p; p += 3 * cin * 128;
+    p_b[i] = p; p += 128;
+  }
+  gru_wih = p; p += 128 * 384;
+  gru_whh = p; p += 128 * 384;
+  gru_bih = p; p += 384;
+  gru_bhh = p; p += 384;
+  out_w = p; p += 128 * B_PITCH_BINS;
+  out_b = p; p += B_PITCH_BINS;
+  voi_w = p; p += 128;
+  voi_b = p; p += 1;
+}
+
+size_t EmbedWeights::n_floats() { return 2 * (B_HID * B_HID + B_HID) + B_NBLOCKS * 2 * (B_KV_CH * B_HID + B_HID); }
+void EmbedWeights::bind(const float* p) {
+  add_w = p; p += B_HID * B_HID; add_b = p; p += B_HID;
+  frm_w = p; p += B_HID * B_HID; frm_b = p; p += B_HID;
+  for (int b = 0; b < B_NBLOCKS; ++b) {
+    k_w[b] = p; p += B_KV_CH * B_HID; k_b[b] = p; p += B_HID;
+    v_w[b] = p; p += B_KV_CH * B_HID; v_b[b] = p; p += B_HID;
+  }
+}
+
+static const int kUpRate[4] = {5, 4, 4, 3};
+static const int kUpCh[5] = {256, 128, 64, 32, 16};
+size_t WaveWeights::n_floats() {
+  size_t n = B_PHONE_CH * B_HID + B_HID + B_PITCH_BINS * B_HID + 4 * B_HID;
+  n += B_NBLOCKS * ((3 * B_HID * B_HID + B_HID) + 3 * (B_HID * B_HID + B_HID));
+  for (int s = 0; s < 4; ++s) {
+    const size_t cin = kUpCh[s], cout = kUpCh[s + 1], r = kUpRate[s];
+    n += 2 * cin * r * cout + r * cout + 2 * (3 * cout * cout + cout);
+  }
+  n += 7 * 16 + 1;
+  return n;
+}
+void WaveWeights::bind(const float* p) {
+  inp_w = p; p += B_PHONE_CH * B_HID;
+  inp_b = p; p += B_HID;
+  pitch_emb = p; p += B_PITCH_BINS * B_HID;
+  feat_w = p; p += 4 * B_HID;
+  for (int b = 0; b < B_NBLOCKS; ++b) {
+    c1_w[b] = p; p += 3 * B_HID * B_HID; c1_b[b] = p; p += B_HID;
+    c2_w[b] = p; p += B_HID * B_HID; c2_b[b] = p; p += B_HID;
+    q_w[b] = p; p += B_HID * B_HID; q_b[b] = p; p += B_HID;
+    o_w[b] = p; p += B_HID * B_HID; o_b[b] = p; p += B_HID;
+  }
+  for (int s = 0; s < 4; ++s) {
+    const size_t cin = kUpCh[s], cout = kUpCh[s + 1], r = kUpRate[s];
+    up_w[s] = p; p += 2 * cin * r * cout; up_b[s] = p; p += r * cout;
+    ra_w[s] = p; p += 3 * cout * cout; ra_b[s] = p; p += cout;
+    rb_w[s] = p; p += 3 * cout * cout; rb_b[s] = p; p += cout;
+  }
+  fin_w = p; p += 7 * 16;
+  fin_b = p; p += 1;
+}
+
+// ---- set-time launchers ------------------------------------------------------------------------
+void embed_project_rows(const float* w, const float* b, const float* d_x, float* d_y, int rows, hipStream_t stream) {
+  const int total = rows * B_HID;
+  hipLaunchKernelGGL(dense_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, d_x, w, b, d_y, rows, B_HID, B_HID);
+}
+void embed_project_kv(const EmbedWeights& w, int block, const float* d_kv_raw, int slots, float* d_kt, float* d_v,
+                      hipStream_t stream) {
+  hipLaunchKernelGGL(kv_project_kernel, dim3(B_KV_LEN, slots), dim3(256), 0, stream, d_kv_raw, w.k_w[block], w.k_b[block],
+                     w.v_w[block], w.v_b[block], d_kt, d_v);
+}
+void codebook_prepare(const float* d_cb, int n, float* d_cbT, float* d_cnorm, hipStream_t stream) {
+  hipLaunchKernelGGL(codebook_prep_kernel, dim3(n), dim3(512), 0, stream, d_cb, d_cbT, d_cnorm);
+}
+
+}  // namespace bhip

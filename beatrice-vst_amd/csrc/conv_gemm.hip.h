@@ -1,0 +1,235 @@
+// conv_gemm.hip.h -- the workhorse kernel: causal (dilated / strided / polyphase-transposed)
+// Conv1d, 1x1 conv and linear layers as one LDS-staged FP32-MFMA GEMM over (stream, frame) rows.
+//
+//   A[(b,t)][(j,c)] = pre( in_ring[b][(t+1)*STRIDE-1-(KSZ-1-j)*DIL][c] )       M = B*T rows
+//   W[(j,c)][n]                                                                 K = KSZ*CIN
+//   out[(b,t)][n]   = res + act( epi(acc) )                                     N = NOUT
+//
+// Numerics (MODEL_SPEC 2.2): every output is ONE k-ascending float32 FMA chain starting at 0;
+// v_mfma_f32_16x16x4_f32 is exactly such a chain (4 k per instruction, in k order), the K loop
+// feeds it k-ascending and never splits K, so the kernel reproduces the scalar definition
+// bit for bit.  16x16x4 is used instead of 32x32x2 because the dependent-accumulator latency per
+// unit of K is 4x shorter (40 cycles per 4 k vs 64 per 2 k), which is what bounds the small-M
+// layers of a per-hop network.
+//
+// Tiling: a workgroup of LM x LN wavefronts, each wavefront owning WM x WN MFMA tiles of 16x16.
+// A tile rows are gathered from the ring in 16-byte pieces (a row's KC channels are contiguous),
+// W tiles are read as coalesced float4 rows; both go through padded LDS so that the MFMA operand
+// reads (ds_read_b32, lane -> [row l&15][k l>>4]) are bank-conflict free:
+//   A stride KC+2  -> banks 2*i + k   distinct over a 32-lane group
+//   W stride == 16 (mod 32) -> banks 16*k + j distinct over a 32-lane group
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ring.h"
+#include "spec_math.hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { PRE_NONE = 0, PRE_LRELU = 1 };
+enum { ACT_NONE = 0, ACT_GELU = 1 };
+enum { EPI_BIAS = 0, EPI_SCALE = 1, EPI_ROWSCALE = 2 };
+
+struct ConvArgs {
+  Ring in, out, res;
+  const float* w;
+  const float* bias;
+  const int* hop;
+  int B;
+  float scale;            // EPI_SCALE
+  const float* rowscale;  // EPI_ROWSCALE: one factor per stream
+  // grouped mode (rows gathered by stream index, W chosen per M-tile)
+  const int* perm;       // [n_tiles][MT] stream index or -1
+  const int* tile_slot;  // [n_tiles] weight slot or -1 (tile unused)
+  size_t w_slot_stride;  // floats between weight slots
+  int rel_shift;         // added to every input frame offset (-1: read the previous hop's frame)
+};
+
+template <int CIN_, int NOUT_, int KSZ_, int STRIDE_, int DIL_, int T_, int PRE_, int ACT_,
+          int EPI_, bool RES_, bool GROUPED_ = false>
+struct Layer {
+  static constexpr int CIN = CIN_, NOUT = NOUT_, KSZ = KSZ_, STRIDE = STRIDE_, DIL = DIL_, T = T_;
+  static constexpr int PRE = PRE_, ACT = ACT_, EPI = EPI_;
+  static constexpr bool RES = RES_, GROUPED = GROUPED_;
+  static constexpr int KC = CIN >= 32 ? 32 : CIN;
+  static_assert(CIN % KC == 0 && KC % 4 == 0, "channel chunking");
+};
+
+template <int WM_, int WN_, int LM_, int LN_>
+struct TileCfg {
+  static constexpr int WM = WM_, WN = WN_, LM = LM_, LN = LN_;
+  static constexpr int MT = 16 * WM * LM, NT = 16 * WN * LN, NTHR = 64 * LM * LN;
+  static constexpr int WS = NT + ((NT % 32 == 16) ? 0 : 16);
+};
+
+template <class L, class TC>
+__global__ __launch_bounds__(TC::NTHR) void conv_gemm_kernel(const ConvArgs a) {
+  constexpr int KC = L::KC, AS = KC + 2, WS = TC::WS, MT = TC::MT, NT = TC::NT, NTHR = TC::NTHR;
+  constexpr int A_F4_PER_ROW = KC / 4;
+  constexpr int A_SLOTS = (MT * A_F4_PER_ROW + NTHR - 1) / NTHR;
+  constexpr int W_F4_PER_ROW = NT / 4;
+  constexpr int W_SLOTS = (KC * W_F4_PER_ROW + NTHR - 1) / NTHR;
+  static_assert(L::NOUT % NT == 0, "N tile must divide NOUT");
+  static_assert(!L::GROUPED || L::T == 1, "grouped rows are streams");
+
+  __shared__ float As[MT * AS];
+  __shared__ float Ws[KC * WS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wave_m = (wave / TC::LN) * (16 * TC::WM), wave_n = (wave % TC::LN) * (16 * TC::WN);
+  const int m0 = blockIdx.x * MT, n0 = blockIdx.y * NT;
+  const int M = a.B * L::T;
+
+  const float* wbase = a.w;
+  if constexpr (L::GROUPED) {
+    const int slot = a.tile_slot[blockIdx.x];
+    if (slot < 0) return;
+    wbase += (size_t)slot * a.w_slot_stride;
+  }
+
+  const int hop = *a.hop;
+  const int pos_in = ring_pos(a.in, hop);
+
+  // per-thread A staging slots: which (stream, t) row and which 16-byte piece
+  int a_b[A_SLOTS], a_t[A_SLOTS];
+#pragma unroll
+  for (int s = 0; s < A_SLOTS; ++s) {
+    const int idx = tid + s * NTHR;
+    const int r = idx / A_F4_PER_ROW;
+    int b = -1, t = 0;
+    if (r < MT) {
+      if constexpr (L::GROUPED) {
+        b = a.perm[blockIdx.x * MT + r];
+      } else {
+        const int m = m0 + r;
+        if (m < M) { b = m / L::T; t = m % L::T; }
+      }
+    }
+    a_b[s] = b;
+    a_t[s] = t;
+  }
+
+  f32x4 acc[TC::WM][TC::WN];
+#pragma unroll
+  for (int i = 0; i < TC::WM; ++i)
+#pragma unroll
+    for (int j = 0; j < TC::WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int j = 0; j < L::KSZ; ++j) {
+    for (int c0 = 0; c0 < L::CIN; c0 += KC) {
+      // ---- stage A chunk: rows x KC channels of tap j
+#pragma unroll
+      for (int s = 0; s < A_SLOTS; ++s) {
+        const int idx = tid + s * NTHR;
+        const int r = idx / A_F4_PER_ROW, q = idx % A_F4_PER_ROW;
+        if (r < MT) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (a_b[s] >= 0) {
+            const int rel = (a_t[s] + 1) * L::STRIDE - 1 - (L::KSZ - 1 - j) * L::DIL + a.rel_shift;
+            const float* src = ring_frame(a.in, a_b[s], pos_in, rel) + c0 + 4 * q;
+            v = *reinterpret_cast<const float4*>(src);
+            if constexpr (L::PRE == PRE_LRELU) {
+              v.x = bsp::lrelu(v.x); v.y = bsp::lrelu(v.y); v.z = bsp::lrelu(v.z); v.w = bsp::lrelu(v.w);
+            }
+          }
+          float* dst = &As[r * AS + 4 * q];
+          dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+      }
+      // ---- stage W chunk: KC rows x NT columns
+      const float* wsrc = wbase + ((size_t)(j * L::CIN + c0)) * L::NOUT + n0;
+#pragma unroll
+      for (int s = 0; s < W_SLOTS; ++s) {
+        const int idx = tid + s * NTHR;
+        const int r = idx / W_F4_PER_ROW, q = idx % W_F4_PER_ROW;
+        if (r < KC) {
+          const float4 v = *reinterpret_cast<const float4*>(wsrc + (size_t)r * L::NOUT + 4 * q);
+          *reinterpret_cast<float4*>(&Ws[r * WS + 4 * q]) = v;
+        }
+      }
+      __syncthreads();
+      // ---- MFMA over the chunk, k ascending
+#pragma unroll
+      for (int ks = 0; ks < KC / 4; ++ks) {
+        float av[TC::WM], bv[TC::WN];
+#pragma unroll
+        for (int i = 0; i < TC::WM; ++i) av[i] = As[(wave_m + i * 16 + (lane & 15)) * AS + ks * 4 + (lane >> 4)];
+#pragma unroll
+        for (int jn = 0; jn < TC::WN; ++jn) bv[jn] = Ws[(ks * 4 + (lane >> 4)) * WS + wave_n + jn * 16 + (lane & 15)];
+#pragma unroll
+        for (int i = 0; i < TC::WM; ++i)
+#pragma unroll
+          for (int jn = 0; jn < TC::WN; ++jn)
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[jn], acc[i][jn], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: D layout of 16x16x4: row = (lane>>4)*4 + reg, col = lane&15
+  const int pos_out = ring_pos(a.out, hop);
+  const int R_out = a.out.n * a.out.m;
+  int pos_res = 0, R_res = 0;
+  if constexpr (L::RES) { pos_res = ring_pos(a.res, hop); R_res = a.res.n * a.res.m; }
+#pragma unroll
+  for (int i = 0; i < TC::WM; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = wave_m + i * 16 + (lane >> 4) * 4 + e;
+      int b, t = 0;
+      if constexpr (L::GROUPED) {
+        b = a.perm[blockIdx.x * MT + r];
+      } else {
+        const int m = m0 + r;
+        b = m < M ? m / L::T : -1;
+        t = m % L::T;
+      }
+      if (b < 0) continue;
+      float* orow = a.out.base + ((size_t)b * R_out + pos_out) * a.out.C + (size_t)t * L::NOUT;
+      const float* rrow = nullptr;
+      if constexpr (L::RES) rrow = a.res.base + ((size_t)b * R_res + pos_res) * a.res.C + (size_t)t * L::NOUT;
+      float rs = 1.0f;
+      if constexpr (L::EPI == EPI_ROWSCALE) rs = a.rowscale[b];
+#pragma unroll
+      for (int jn = 0; jn < TC::WN; ++jn) {
+        const int n = n0 + wave_n + jn * 16 + (lane & 15);
+        float v = acc[i][jn][e];
+        if constexpr (L::EPI == EPI_BIAS) v = v + a.bias[n];
+        if constexpr (L::EPI == EPI_SCALE) v = v * a.scale;
+        if constexpr (L::EPI == EPI_ROWSCALE) v = v * rs;
+        if constexpr (L::ACT == ACT_GELU) v = bsp::gelu(v);
+        if constexpr (L::RES) v = rrow[n] + v;
+        orow[n] = v;
+      }
+    }
+  }
+}
+
+template <class L, class TC>
+static inline void launch_conv(const ConvArgs& a, int n_group_tiles, hipStream_t stream) {
+  dim3 grid;
+  if (L::GROUPED) grid.x = n_group_tiles;
+  else grid.x = (a.B * L::T + TC::MT - 1) / TC::MT;
+  grid.y = L::NOUT / TC::NT;
+  hipLaunchKernelGGL((conv_gemm_kernel<L, TC>), grid, dim3(TC::NTHR), 0, stream, a);
+}
+
+// ---- launch helpers shared by the modules ------------------------------------------------------
+using TS = TileCfg<1, 1, 1, 4>;  // 16 x 64 (rows x cols): layers with M <= 32 rows
+using TL = TileCfg<2, 2, 2, 2>;  // 64 x 64
+
+template <class L>
+static inline void launch_auto(const ConvArgs& a, hipStream_t s) {
+  if (a.B * L::T <= 32) launch_conv<L, TS>(a, 0, s);
+  else launch_conv<L, TL>(a, 0, s);
+}
+
+static inline ConvArgs conv_args(const Ring& in, const Ring& out, const float* w, const float* b, const int* hop, int B) {
+  ConvArgs a{};
+  a.in = in; a.out = out; a.res = in;
+  a.w = w; a.bias = b; a.hop = hop; a.B = B;
+  a.scale = 1.0f; a.rowscale = nullptr; a.perm = nullptr; a.tile_slot = nullptr; a.w_slot_stride = 0;
+  a.rel_shift = 0;
+  return a;
+}

@@ -1,0 +1,146 @@
+// engine.h -- host-side model/state objects of libbeatrice_hip.
+//
+// Three per-hop modules mirror the reference's three per-hop ABI calls
+// (reference lib/beatricelib/beatrice.h:243-247, 266-271, 301-307).  Each module has
+//   *Weights : device pointers into the uploaded parameter blob (immutable, shareable),
+//   *State   : per-stream activation rings + per-stream settings for B streams,
+//   *_forward: enqueue the module's kernels on a HIP stream (no allocation, no sync -- the
+//              sequence is capturable into a hipGraph).
+// The 1-stream C-ABI (abi.hip) wraps these with B = 1; the batched ABI (batch.hip) with B = N.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <vector>
+
+#include "kernels_misc.hip.h"
+#include "ring.h"
+
+namespace bhip {
+
+// ---- error handling: never throw across the C-ABI; remember the first failure ---------------
+bool hip_ok(hipError_t e, const char* what);  // logs once per site when BEATRICE_HIP_DEBUG is set
+#define BHIP_TRY(expr)                                \
+  do {                                                \
+    if (!::bhip::hip_ok((expr), #expr)) return false; \
+  } while (0)
+
+// ---- device blob -----------------------------------------------------------------------------
+struct DeviceBlob {
+  float* d = nullptr;
+  size_t n_floats = 0;
+  bool upload(const float* host, size_t n);
+  void release();
+};
+
+// ---- ring arena --------------------------------------------------------------------------------
+struct RingSpec { Ring* ring; int C, n, m; };
+struct RingArena {
+  float* base = nullptr;
+  size_t floats = 0;
+  int B = 0;
+  std::vector<Ring*> rings;
+  bool build(int B, const std::vector<RingSpec>& specs);  // one hipMalloc, zero-filled
+  bool zero_all(hipStream_t s) const;
+  bool zero_stream(int b, hipStream_t s) const;
+  void release();
+};
+
+// ---- phone extractor ---------------------------------------------------------------------------
+struct PhoneWeights {
+  const float *f1_w, *f1_b;
+  const float *f_w[4], *f_b[4];    // F2..F5
+  const float *rb_w[4], *rb_b[4];  // residual blocks
+  const float *gru_wih, *gru_whh, *gru_bih, *gru_bhh, *out_w, *out_b;
+  static size_t n_floats();
+  void bind(const float* base);
+};
+struct PhoneState {
+  int B = 0;
+  RingArena arena;
+  Ring audio, f[5], rb[4], gi, gh, h, raw;
+  float* d_in = nullptr;     // [B][160]; owned unless shared
+  bool owns_in = false;
+  float* d_phone = nullptr;  // [B][128]
+  const float** d_cbT = nullptr;    // [B] device pointers
+  const float** d_cnorm = nullptr;  // [B]
+  int* d_vqk = nullptr;             // [B]
+  int* d_hop = nullptr;
+  bool create(int B, float* shared_in);
+  void destroy();
+};
+void phone_forward(const PhoneWeights& w, const PhoneState& s, hipStream_t stream);
+
+// ---- pitch estimator ---------------------------------------------------------------------------
+struct PitchWeights {
+  const float *window, *twiddle;
+  const float *p_w[3], *p_b[3];
+  const float *gru_wih, *gru_whh, *gru_bih, *gru_bhh, *out_w, *out_b, *voi_w, *voi_b;
+  static size_t n_floats();
+  void bind(const float* base);
+};
+struct PitchState {
+  int B = 0;
+  RingArena arena;
+  Ring audio, spec, p[3], gi, gh, h, logits;
+  float* d_in = nullptr;
+  bool owns_in = false;
+  int *d_min_q = nullptr, *d_max_q = nullptr, *d_prev_q = nullptr, *d_q_raw = nullptr, *d_q = nullptr;
+  float* d_feat = nullptr;             // [B][4]
+  PitchParams* d_params = nullptr;     // [B] or nullptr (1-stream ABI: host does the transform)
+  int* d_hop = nullptr;
+  bool create(int B, float* shared_in, bool with_params);
+  void destroy();
+};
+void pitch_forward(const PitchWeights& w, const PitchState& s, hipStream_t stream);
+
+// ---- embedding setter --------------------------------------------------------------------------
+struct EmbedWeights {
+  const float *add_w, *add_b, *frm_w, *frm_b;
+  const float *k_w[B_NBLOCKS], *k_b[B_NBLOCKS], *v_w[B_NBLOCKS], *v_b[B_NBLOCKS];
+  static size_t n_floats();
+  void bind(const float* base);
+};
+
+// ---- waveform generator ------------------------------------------------------------------------
+struct WaveWeights {
+  const float *inp_w, *inp_b, *pitch_emb, *feat_w;
+  const float *c1_w[B_NBLOCKS], *c1_b[B_NBLOCKS], *c2_w[B_NBLOCKS], *c2_b[B_NBLOCKS];
+  const float *q_w[B_NBLOCKS], *q_b[B_NBLOCKS], *o_w[B_NBLOCKS], *o_b[B_NBLOCKS];
+  const float *up_w[4], *up_b[4], *ra_w[4], *ra_b[4], *rb_w[4], *rb_b[4];
+  const float *fin_w, *fin_b;
+  static size_t n_floats();
+  void bind(const float* base);
+};
+struct WaveState {
+  int B = 0;
+  int n_slots = 0;      // K/V slots per block in the tables
+  int n_tiles_max = 0;  // attention M-tiles (16 streams each) upper bound
+  RingArena arena;
+  Ring e, x[B_NBLOCKS + 1], h1, xa, q, sc, o, ya[4], yb[4], yc[4];
+  float* d_inv = nullptr;  // [B]
+  // inputs (device): phone [B][128], q [B], feat [B][4]; owned unless shared with other modules
+  float* d_phone = nullptr; int* d_q = nullptr; float* d_feat = nullptr;
+  bool owns_inputs = false;
+  float* d_out = nullptr;  // [B][240]
+  // conditioning tables and per-stream selectors
+  float* d_add_tab = nullptr; int n_add = 0;  // [n_add][256] projected additive embeddings
+  float* d_frm_tab = nullptr; int n_frm = 0;  // [n_frm][256] projected formant embeddings
+  int *d_add_idx = nullptr, *d_frm_idx = nullptr;  // [B]
+  float* d_kt[B_NBLOCKS] = {nullptr, nullptr, nullptr, nullptr};  // [n_slots][256][384]
+  float* d_v[B_NBLOCKS] = {nullptr, nullptr, nullptr, nullptr};   // [n_slots][384][256]
+  int* d_perm[B_NBLOCKS] = {nullptr, nullptr, nullptr, nullptr};       // [n_tiles_max][16]
+  int* d_tile_slot[B_NBLOCKS] = {nullptr, nullptr, nullptr, nullptr};  // [n_tiles_max]
+  int* d_hop = nullptr;
+  bool create(int B, int n_slots, int n_add, int n_frm, float* shared_phone, int* shared_q, float* shared_feat);
+  void destroy();
+};
+void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t stream);
+
+// set-time projections (embedding setter)
+void embed_project_rows(const float* w, const float* b, const float* d_x, float* d_y, int rows, hipStream_t stream);
+void embed_project_kv(const EmbedWeights& w, int block, const float* d_kv_raw, int slots, float* d_kt, float* d_v,
+                      hipStream_t stream);
+void codebook_prepare(const float* d_cb, int n, float* d_cbT, float* d_cnorm, hipStream_t stream);
+
+}  // namespace bhip

@@ -1,0 +1,402 @@
+// kernels_misc.hip.h -- the non-GEMM kernels of the per-hop path (MODEL_SPEC section 4) and the
+// set-time kernels of the embedding setter.  All of them are HBM/LDS-bound elementwise, gather or
+// reduction work: one workgroup (or one wavefront) per stream, coalesced channel-last accesses,
+// cross-lane reductions through wavefront shuffles in the order the spec fixes.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ring.h"
+#include "spec_math.hip.h"
+
+#define B_IN_HOP 160
+#define B_OUT_HOP 240
+#define B_HID 256
+#define B_PHONE_CH 128
+#define B_PITCH_BINS 448
+#define B_CODEBOOK 512
+#define B_KV_LEN 384
+#define B_KV_CH 128
+#define B_NBLOCKS 4
+#define B_FFT_N 1024
+#define B_SPEC_BINS 512
+#define B_PITCH_HIST (B_FFT_N - B_IN_HOP)
+
+// ---------------------------------------------------------------------------------------------
+static __global__ void hop_advance_kernel(int* hop) { *hop = *hop + 1; }
+
+// ---------------------------------------------------------------------------------------------
+// Phone front-end layer 1 (MODEL_SPEC 4.1.1): Conv1d(1 -> 64, k=10, stride=5) + GELU.
+// K is only 10, so this is VALU work: one workgroup per stream, thread = (frame t, 8 channels).
+// Also appends the hop's 160 samples to the audio ring (5 samples of history are re-read).
+static __global__ __launch_bounds__(256) void phone_f1_kernel(const float* __restrict__ d_in, Ring audio,
+                                                       Ring out, const float* __restrict__ w,
+                                                       const float* __restrict__ bias,
+                                                       const int* hop_ptr) {
+  __shared__ float x[5 + B_IN_HOP];
+  __shared__ float ws[10 * 64];
+  const int b = blockIdx.x, tid = threadIdx.x, hop = *hop_ptr;
+  const int pos = ring_pos(audio, hop);
+  for (int i = tid; i < 10 * 64; i += 256) ws[i] = w[i];
+  if (tid < 5) x[tid] = *ring_frame(audio, b, pos, tid - 5);
+  if (tid < B_IN_HOP) {
+    const float v = d_in[(size_t)b * B_IN_HOP + tid];
+    x[5 + tid] = v;
+    *ring_frame(audio, b, pos, tid) = v;
+  }
+  __syncthreads();
+  const int t = tid >> 3, n0 = (tid & 7) * 8;
+  float acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 10; ++j) {
+    const float a = x[5 * t + j];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = bsp::fma(a, ws[j * 64 + n0 + u], acc[u]);
+  }
+  float* o = ring_frame(out, b, ring_pos(out, hop), t) + n0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) o[u] = bsp::gelu(acc[u] + bias[n0 + u]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GRU gate math (MODEL_SPEC 3.2).  gi/gh = the two gate GEMMs (+bias), computed by conv_gemm.
+// h ring: C = H, n = 1, m = 2 (previous state = frame -1).
+static __global__ void gru_gate_kernel(const float* __restrict__ gi, const float* __restrict__ gh, Ring h,
+                                int H, int B, const int* hop_ptr) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * H) return;
+  const int b = idx / H, j = idx % H;
+  const int hop = *hop_ptr, pos = ring_pos(h, hop);
+  const float* gib = gi + (size_t)b * 3 * H;
+  const float* ghb = gh + (size_t)b * 3 * H;
+  const float r = bsp::sigmoid(gib[j] + ghb[j]);
+  const float z = bsp::sigmoid(gib[H + j] + ghb[H + j]);
+  const float nn = bsp::tanh(bsp::fma(r, ghb[2 * H + j], gib[2 * H + j]));
+  const float hp = ring_frame(h, b, pos, -1)[j];
+  ring_frame(h, b, pos, 0)[j] = bsp::fma(z, hp - nn, nn);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k-nearest-neighbour codebook lookup (MODEL_SPEC 4.1.3).  One workgroup of 512 threads per
+// stream; thread j owns codebook row j.  cbT is the codebook transposed to [128][512] so the
+// distance loop reads coalesced rows.  Streams with k == 0 pass the raw vector through.
+struct VqArgs {
+  const float* raw;            // [B][128]
+  float* out;                  // [B][128]
+  const float* const* cbT;     // per stream: [128][512]
+  const float* const* cnorm;   // per stream: [512]
+  const int* k;                // per stream
+};
+static __global__ __launch_bounds__(512) void phone_vq_kernel(VqArgs a) {
+  __shared__ float x[B_PHONE_CH];
+  __shared__ float red_d[8];
+  __shared__ int red_j[8];
+  __shared__ int winner;
+  const int b = blockIdx.x, j = threadIdx.x, lane = j & 63, wave = j >> 6;
+  const int k = a.k[b];
+  const float* cbT = a.cbT[b];
+  if (j < B_PHONE_CH) x[j] = a.raw[(size_t)b * B_PHONE_CH + j];
+  if (k <= 0 || cbT == nullptr) {
+    if (j < B_PHONE_CH) a.out[(size_t)b * B_PHONE_CH + j] = x[j];
+    return;
+  }
+  __syncthreads();
+  float dot = 0.0f;
+#pragma unroll 8
+  for (int c = 0; c < B_PHONE_CH; ++c) dot = bsp::fma(x[c], cbT[c * B_CODEBOOK + j], dot);
+  float d = bsp::fma(-2.0f, dot, a.cnorm[b][j]);
+  float acc = 0.0f;
+  for (int r = 0; r < k; ++r) {
+    float bd = d;
+    int bj = j;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float od = __shfl_xor(bd, off, 64);
+      const int oj = __shfl_xor(bj, off, 64);
+      if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
+    }
+    if (lane == 0) { red_d[wave] = bd; red_j[wave] = bj; }
+    __syncthreads();
+    if (j == 0) {
+      float wd = red_d[0];
+      int wj = red_j[0];
+      for (int w = 1; w < 8; ++w)
+        if (red_d[w] < wd || (red_d[w] == wd && red_j[w] < wj)) { wd = red_d[w]; wj = red_j[w]; }
+      winner = wj;
+    }
+    __syncthreads();
+    const int wj = winner;
+    if (j == wj) d = __builtin_huge_valf();
+    if (j < B_PHONE_CH) acc = acc + cbT[j * B_CODEBOOK + wj];
+    __syncthreads();
+  }
+  if (j < B_PHONE_CH) a.out[(size_t)b * B_PHONE_CH + j] = acc / (float)k;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pitch front-end (MODEL_SPEC 4.2.1): window, 1024-point radix-2 DIT FFT in LDS, log power.
+// One workgroup of 256 threads per stream; each thread does 2 butterflies per stage.
+static __global__ __launch_bounds__(256) void pitch_fft_kernel(const float* __restrict__ d_in, Ring audio,
+                                                        Ring spec, const float* __restrict__ window,
+                                                        const float* __restrict__ twiddle,
+                                                        const int* hop_ptr) {
+  __shared__ float re[B_FFT_N], im[B_FFT_N];
+  __shared__ float tw[B_FFT_N];
+  const int b = blockIdx.x, tid = threadIdx.x, hop = *hop_ptr;
+  const int pos = ring_pos(audio, hop);
+  for (int i = tid; i < B_FFT_N; i += 256) {
+    tw[i] = twiddle[i];
+    float s;
+    if (i < B_PITCH_HIST) {
+      s = *ring_frame(audio, b, pos, i - B_PITCH_HIST);
+    } else {
+      s = d_in[(size_t)b * B_IN_HOP + (i - B_PITCH_HIST)];
+      *ring_frame(audio, b, pos, i - B_PITCH_HIST) = s;
+    }
+    const int rev = (int)(__brev((unsigned)i) >> 22);
+    re[rev] = s * window[i];
+    im[rev] = 0.0f;
+  }
+  __syncthreads();
+  for (int half = 1; half < B_FFT_N; half <<= 1) {
+    const int step = B_FFT_N / (2 * half);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int bf = tid + u * 256;
+      const int j = bf & (half - 1);
+      const int ia = ((bf - j) << 1) + j, ib = ia + half;
+      const float wr = tw[2 * (j * step)], wi = tw[2 * (j * step) + 1];
+      const float br = re[ib], bi = im[ib];
+      const float tr = bsp::fma(-wi, bi, wr * br);
+      const float ti = bsp::fma(wi, br, wr * bi);
+      const float ar = re[ia], ai = im[ia];
+      re[ia] = ar + tr; im[ia] = ai + ti;
+      re[ib] = ar - tr; im[ib] = ai - ti;
+    }
+    __syncthreads();
+  }
+  float* o = ring_frame(spec, b, ring_pos(spec, hop), 0);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int k = tid + u * 256;
+    const float pw = bsp::fma(im[k], im[k], re[k] * re[k]);
+    o[k] = 0.5f * bsp::log(pw + 1e-5f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pitch head (MODEL_SPEC 4.2.3): masked argmax + 4 features, one wavefront per stream; optional
+// per-stream pitch transform (double precision, restating reference
+// src/common/processor_core_2.cc:190-252) so that the batched path needs no host round trip.
+struct PitchParams {  // per stream
+  double average_source_pitch, intonation_intensity, pitch_shift, pitch_correction;
+  int pitch_correction_type, pad;
+};
+struct PitchHeadArgs {
+  const float* logits;  // [B][448]
+  Ring h;               // GRU state ring (C=128)
+  const float* d_in;    // [B][160]
+  const float* voi_w;   // [128]
+  const float* voi_b;   // [1]
+  const int* min_q;
+  const int* max_q;
+  int* prev_q;
+  int* q_raw;           // [B]
+  int* q_out;           // [B] (after transform; == q_raw when params == nullptr)
+  float* feat;          // [B][4]
+  const PitchParams* params;
+  const int* hop;
+};
+
+__device__ inline double pitch_round_half_away(double v) { return v >= 0.0 ? floor(v + 0.5) : -floor(-v + 0.5); }
+
+__device__ inline int pitch_transform_device(int q, const PitchParams& p) {
+  const double per = 8.0;
+  double t = p.average_source_pitch + ((double)q - p.average_source_pitch) * p.intonation_intensity + per * p.pitch_shift;
+  if (p.pitch_correction != 0.0) {
+    if (p.pitch_correction_type == 0) {
+      const double near = (floor(t / per) + 0.5) * per;
+      const double d = (t - near) * (2.0 / per);
+      if (fabs(d) < 1e-4) t = near;
+      else t = near + d * pow(fabs(d), -p.pitch_correction) * (per / 2.0);
+    } else {
+      const double near = pitch_round_half_away(t / per) * per;
+      const double d = (t - near) * (2.0 / per);
+      if (p.pitch_correction > 1 - 1e-4) t = near;
+      else if (d >= 0.0) t = near + pow(d, 1.0 / (1.0 - p.pitch_correction)) * (per / 2.0);
+      else t = near - pow(-d, 1.0 / (1.0 - p.pitch_correction)) * (per / 2.0);
+    }
+  }
+  // the reference converts to int first (static_cast<int>(std::round(t))) and clamps after
+  const double r = pitch_round_half_away(t);
+  int qi = r > 2147483647.0 ? 2147483647 : (r < -2147483648.0 ? (int)(-2147483647 - 1) : (int)r);
+  return qi < 1 ? 1 : (qi > B_PITCH_BINS - 1 ? B_PITCH_BINS - 1 : qi);
+}
+
+static __global__ __launch_bounds__(64) void pitch_head_kernel(PitchHeadArgs a) {
+  const int b = blockIdx.x, l = threadIdx.x;
+  const int hop = *a.hop;
+  const float* lg = a.logits + (size_t)b * B_PITCH_BINS;
+  float v[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) v[i] = lg[l + 64 * i];
+  int lo = a.min_q[b], hi = a.max_q[b];
+  if (hi < lo) hi = lo;
+  float bv = -__builtin_huge_valf();
+  int bj = 0x7fffffff;
+  float mx = v[0];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int j = l + 64 * i;
+    mx = fmaxf(mx, v[i]);
+    if (j >= lo && j <= hi && (bj == 0x7fffffff || v[i] > bv)) { bv = v[i]; bj = j; }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float ov = __shfl_xor(bv, off, 64);
+    const int oj = __shfl_xor(bj, off, 64);
+    if (oj != 0x7fffffff && (bj == 0x7fffffff || ov > bv || (ov == bv && oj < bj))) { bv = ov; bj = oj; }
+  }
+  const int q = bj;
+  mx = bsp::wmax64(mx);
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) s = s + bsp::exp(v[i] - mx);
+  const float f0 = bsp::exp(lg[q] - mx) / bsp::wsum64(s);
+  const float* x = a.d_in + (size_t)b * B_IN_HOP;
+  float en = 0.0f;
+  for (int i = l; i < B_IN_HOP; i += 64) en = bsp::fma(x[i], x[i], en);
+  const float f1 = 0.1f * bsp::log(bsp::fma(bsp::wsum64(en), 1.0f / 160.0f, 1e-8f));
+  const float* hv = ring_frame(a.h, b, ring_pos(a.h, hop), 0);
+  const float pv = bsp::fma(hv[l + 64], a.voi_w[l + 64], bsp::fma(hv[l], a.voi_w[l], 0.0f));
+  const float f3 = bsp::sigmoid(bsp::wsum64(pv) + a.voi_b[0]);
+  if (l == 0) {
+    float dq = (float)(q - a.prev_q[b]) * 0.125f;
+    dq = dq < -1.0f ? -1.0f : (dq > 1.0f ? 1.0f : dq);
+    a.prev_q[b] = q;
+    float* f = a.feat + (size_t)b * 4;
+    f[0] = f0; f[1] = f1; f[2] = dq; f[3] = f3;
+    a.q_raw[b] = q;
+    a.q_out[b] = a.params ? pitch_transform_device(q, a.params[b]) : q;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Waveform input mix, conditioning part (MODEL_SPEC 4.4.1):
+//   e[b][n] = (pitch_emb[q][n] + Wf.feat[b]) + (add_tab[add_idx[b]][n] + frm_tab[frm_idx[b]][n])
+struct CondArgs {
+  const int* q;        // [B]
+  const float* feat;   // [B][4]
+  const float* pitch_emb;
+  const float* feat_w; // [4][256]
+  const float* add_tab; const int* add_idx;
+  const float* frm_tab; const int* frm_idx;
+  float* e;            // [B][256]
+};
+static __global__ __launch_bounds__(256) void wave_cond_kernel(CondArgs a) {
+  const int b = blockIdx.x, n = threadIdx.x;
+  int q = a.q[b];
+  q = q < 0 ? 0 : (q > B_PITCH_BINS - 1 ? B_PITCH_BINS - 1 : q);
+  const float* f = a.feat + (size_t)b * 4;
+  float fp = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fp = bsp::fma(f[i], a.feat_w[i * B_HID + n], fp);
+  const float c = a.add_tab[(size_t)a.add_idx[b] * B_HID + n] + a.frm_tab[(size_t)a.frm_idx[b] * B_HID + n];
+  a.e[(size_t)b * B_HID + n] = (a.pitch_emb[(size_t)q * B_HID + n] + fp) + c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Attention softmax statistics (MODEL_SPEC 4.4.2): one wavefront per stream row of 384 scores;
+// rewrites the row as e_j = exp(s_j - max) and stores 1/sum.
+static __global__ __launch_bounds__(64) void attn_softmax_kernel(float* __restrict__ s, float* __restrict__ inv, int B) {
+  const int b = blockIdx.x, l = threadIdx.x;
+  if (b >= B) return;
+  float* row = s + (size_t)b * B_KV_LEN;
+  float v[6];
+  float mx = -__builtin_huge_valf();
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { v[i] = row[l + 64 * i]; mx = fmaxf(mx, v[i]); }
+  mx = bsp::wmax64(mx);
+  float a = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { v[i] = bsp::exp(v[i] - mx); a = a + v[i]; row[l + 64 * i] = v[i]; }
+  const float tot = bsp::wsum64(a);
+  if (l == 0) inv[b] = 1.0f / tot;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Output layer (MODEL_SPEC 4.4.3 last step): LeakyReLU -> Conv1d(16 -> 1, k=7) -> tanh.
+// N = 1, so VALU: one workgroup per stream, input frames staged through LDS, coalesced store of
+// the 240 output samples.
+static __global__ __launch_bounds__(256) void wave_final_kernel(Ring y, const float* __restrict__ w,
+                                                         const float* __restrict__ bias,
+                                                         float* __restrict__ d_out, const int* hop_ptr) {
+  __shared__ float ys[(B_OUT_HOP + 6) * 17];
+  __shared__ float ws[7 * 16];
+  const int b = blockIdx.x, tid = threadIdx.x, hop = *hop_ptr;
+  const int pos = ring_pos(y, hop);
+  if (tid < 7 * 16) ws[tid] = w[tid];
+  for (int i = tid; i < (B_OUT_HOP + 6) * 4; i += 256) {
+    const int fr = i >> 2, q = i & 3;
+    const float4 v = *reinterpret_cast<const float4*>(ring_frame(y, b, pos, fr - 6) + 4 * q);
+    float* d = &ys[fr * 17 + 4 * q];
+    d[0] = bsp::lrelu(v.x); d[1] = bsp::lrelu(v.y); d[2] = bsp::lrelu(v.z); d[3] = bsp::lrelu(v.w);
+  }
+  __syncthreads();
+  if (tid < B_OUT_HOP) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+#pragma unroll
+      for (int c = 0; c < 16; ++c) acc = bsp::fma(ys[(tid + j) * 17 + c], ws[j * 16 + c], acc);
+    d_out[(size_t)b * B_OUT_HOP + tid] = bsp::tanh(acc + bias[0]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Set-time kernels (embedding setter, MODEL_SPEC 4.3).  Not on the per-hop path.
+// y[row][n] = bias[n] + chain_c x[row][c] * w[c][n]
+static __global__ void dense_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                  const float* __restrict__ bias, float* __restrict__ y, int rows,
+                                  int cin, int cout) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * cout) return;
+  const int r = idx / cout, n = idx % cout;
+  float acc = 0.0f;
+  for (int c = 0; c < cin; ++c) acc = bsp::fma(x[(size_t)r * cin + c], w[(size_t)c * cout + n], acc);
+  y[idx] = acc + bias[n];
+}
+
+// K^T[c][j] and V[j][c] of one block for `slots` raw embeddings: grid (384, slots), 256 threads.
+static __global__ __launch_bounds__(256) void kv_project_kernel(const float* __restrict__ kv_raw,
+                                                         const float* __restrict__ kw, const float* __restrict__ kb,
+                                                         const float* __restrict__ vw, const float* __restrict__ vb,
+                                                         float* __restrict__ kt, float* __restrict__ v) {
+  __shared__ float row[B_KV_CH];
+  const int j = blockIdx.x, slot = blockIdx.y, c = threadIdx.x;
+  if (c < B_KV_CH) row[c] = kv_raw[((size_t)slot * B_KV_LEN + j) * B_KV_CH + c];
+  __syncthreads();
+  float ak = 0.0f, av = 0.0f;
+  for (int e = 0; e < B_KV_CH; ++e) {
+    ak = bsp::fma(row[e], kw[e * B_HID + c], ak);
+    av = bsp::fma(row[e], vw[e * B_HID + c], av);
+  }
+  kt[(size_t)slot * B_HID * B_KV_LEN + (size_t)c * B_KV_LEN + j] = ak + kb[c];
+  v[(size_t)slot * B_KV_LEN * B_HID + (size_t)j * B_HID + c] = av + vb[c];
+}
+
+// codebook [512][128] -> transposed [128][512] + squared norms; grid = n codebooks, 512 threads.
+static __global__ __launch_bounds__(512) void codebook_prep_kernel(const float* __restrict__ cb, float* __restrict__ cbT,
+                                                            float* __restrict__ cnorm) {
+  const int s = blockIdx.x, j = threadIdx.x;
+  const float* src = cb + ((size_t)s * B_CODEBOOK + j) * B_PHONE_CH;
+  float* dstT = cbT + (size_t)s * B_PHONE_CH * B_CODEBOOK;
+  float a = 0.0f;
+  for (int c = 0; c < B_PHONE_CH; ++c) {
+    const float x = src[c];
+    a = bsp::fma(x, x, a);
+    dstT[(size_t)c * B_CODEBOOK + j] = x;
+  }
+  cnorm[(size_t)s * B_CODEBOOK + j] = a;
+}

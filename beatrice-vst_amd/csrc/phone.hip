@@ -1,0 +1,75 @@
+// phone.hip -- content encoder forward pass (MODEL_SPEC 4.1), the body of
+// Beatrice20rc0_ExtractPhone1 (reference lib/beatricelib/beatrice.h:243-247) for B streams.
+#include "conv_gemm.hip.h"
+#include "engine.h"
+
+namespace bhip {
+
+bool PhoneState::create(int B_, float* shared_in) {
+  B = B_;
+  std::vector<RingSpec> specs = {
+      {&audio, 1, B_IN_HOP, 2},
+      {&f[0], 64, 32, 2}, {&f[1], 128, 8, 2}, {&f[2], 256, 4, 2}, {&f[3], 256, 2, 2}, {&f[4], 256, 1, 5},
+      {&rb[0], 256, 1, 5}, {&rb[1], 256, 1, 5}, {&rb[2], 256, 1, 5}, {&rb[3], 256, 1, 1},
+      {&gi, 768, 1, 1}, {&gh, 768, 1, 1}, {&h, 256, 1, 2}, {&raw, B_PHONE_CH, 1, 1},
+  };
+  if (!arena.build(B, specs)) return false;
+  if (shared_in) { d_in = shared_in; owns_in = false; }
+  else { BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_in), sizeof(float) * B * B_IN_HOP)); owns_in = true;
+         BHIP_TRY(hipMemset(d_in, 0, sizeof(float) * B * B_IN_HOP)); }
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_phone), sizeof(float) * B * B_PHONE_CH));
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cbT), sizeof(float*) * B));
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cnorm), sizeof(float*) * B));
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_vqk), sizeof(int) * B));
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hop), sizeof(int)));
+  BHIP_TRY(hipMemset(d_phone, 0, sizeof(float) * B * B_PHONE_CH));
+  BHIP_TRY(hipMemset(d_cbT, 0, sizeof(float*) * B));
+  BHIP_TRY(hipMemset(d_cnorm, 0, sizeof(float*) * B));
+  BHIP_TRY(hipMemset(d_vqk, 0, sizeof(int) * B));
+  BHIP_TRY(hipMemset(d_hop, 0, sizeof(int)));
+  return true;
+}
+void PhoneState::destroy() {
+  arena.release();
+  if (owns_in && d_in) (void)hipFree(d_in);
+  if (d_phone) (void)hipFree(d_phone);
+  if (d_cbT) (void)hipFree(d_cbT);
+  if (d_cnorm) (void)hipFree(d_cnorm);
+  if (d_vqk) (void)hipFree(d_vqk);
+  if (d_hop) (void)hipFree(d_hop);
+  d_in = d_phone = nullptr; d_cbT = d_cnorm = nullptr; d_vqk = d_hop = nullptr;
+}
+
+//                 CIN NOUT K  S  D  T  PRE       ACT       EPI       RES
+using F2 = Layer<64, 128, 8, 4, 1, 8, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
+using F3 = Layer<128, 256, 4, 2, 1, 4, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
+using F4 = Layer<256, 256, 4, 2, 1, 2, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
+using F5 = Layer<256, 256, 4, 2, 1, 1, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
+using RBL = Layer<256, 256, 5, 1, 1, 1, PRE_NONE, ACT_GELU, EPI_BIAS, true>;
+using GATE = Layer<256, 768, 1, 1, 1, 1, PRE_NONE, ACT_NONE, EPI_BIAS, false>;
+using OUTL = Layer<256, B_PHONE_CH, 1, 1, 1, 1, PRE_NONE, ACT_NONE, EPI_BIAS, false>;
+
+void phone_forward(const PhoneWeights& w, const PhoneState& s, hipStream_t st) {
+  const int B = s.B;
+  hipLaunchKernelGGL(phone_f1_kernel, dim3(B), dim3(256), 0, st, s.d_in, s.audio, s.f[0], w.f1_w, w.f1_b, s.d_hop);
+  launch_auto<F2>(conv_args(s.f[0], s.f[1], w.f_w[0], w.f_b[0], s.d_hop, B), st);
+  launch_auto<F3>(conv_args(s.f[1], s.f[2], w.f_w[1], w.f_b[1], s.d_hop, B), st);
+  launch_auto<F4>(conv_args(s.f[2], s.f[3], w.f_w[2], w.f_b[2], s.d_hop, B), st);
+  launch_auto<F5>(conv_args(s.f[3], s.f[4], w.f_w[3], w.f_b[3], s.d_hop, B), st);
+  const Ring* cur = &s.f[4];
+  for (int i = 0; i < 4; ++i) {
+    launch_auto<RBL>(conv_args(*cur, s.rb[i], w.rb_w[i], w.rb_b[i], s.d_hop, B), st);
+    cur = &s.rb[i];
+  }
+  launch_auto<GATE>(conv_args(*cur, s.gi, w.gru_wih, w.gru_bih, s.d_hop, B), st);
+  ConvArgs gh = conv_args(s.h, s.gh, w.gru_whh, w.gru_bhh, s.d_hop, B);
+  gh.rel_shift = -1;  // previous hidden state
+  launch_auto<GATE>(gh, st);
+  hipLaunchKernelGGL(gru_gate_kernel, dim3((B * 256 + 255) / 256), dim3(256), 0, st, s.gi.base, s.gh.base, s.h, 256, B, s.d_hop);
+  launch_auto<OUTL>(conv_args(s.h, s.raw, w.out_w, w.out_b, s.d_hop, B), st);
+  VqArgs v{s.raw.base, s.d_phone, s.d_cbT, s.d_cnorm, s.d_vqk};
+  hipLaunchKernelGGL(phone_vq_kernel, dim3(B), dim3(512), 0, st, v);
+  hipLaunchKernelGGL(hop_advance_kernel, dim3(1), dim3(1), 0, st, s.d_hop);
+}
+
+}  // namespace bhip

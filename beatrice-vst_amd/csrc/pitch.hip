@@ -1,0 +1,72 @@
+// pitch.hip -- pitch estimator forward pass (MODEL_SPEC 4.2), the body of
+// Beatrice20rc0_EstimatePitch1 (reference lib/beatricelib/beatrice.h:266-271) for B streams.
+#include "conv_gemm.hip.h"
+#include "engine.h"
+
+namespace bhip {
+
+bool PitchState::create(int B_, float* shared_in, bool with_params) {
+  B = B_;
+  std::vector<RingSpec> specs = {
+      {&audio, 1, B_IN_HOP, 7},
+      {&spec, B_SPEC_BINS, 1, 3}, {&p[0], 128, 1, 3}, {&p[1], 128, 1, 3}, {&p[2], 128, 1, 1},
+      {&gi, 384, 1, 1}, {&gh, 384, 1, 1}, {&h, 128, 1, 2}, {&logits, B_PITCH_BINS, 1, 1},
+  };
+  if (!arena.build(B, specs)) return false;
+  if (shared_in) { d_in = shared_in; owns_in = false; }
+  else {
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_in), sizeof(float) * B * B_IN_HOP));
+    BHIP_TRY(hipMemset(d_in, 0, sizeof(float) * B * B_IN_HOP));
+    owns_in = true;
+  }
+  int** ints[] = {&d_min_q, &d_max_q, &d_prev_q, &d_q_raw, &d_q};
+  for (int** p : ints) {
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(p), sizeof(int) * B));
+    BHIP_TRY(hipMemset(*p, 0, sizeof(int) * B));
+  }
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_feat), sizeof(float) * 4 * B));
+  BHIP_TRY(hipMemset(d_feat, 0, sizeof(float) * 4 * B));
+  std::vector<int> lo(B, 1), hi(B, B_PITCH_BINS - 1);
+  BHIP_TRY(hipMemcpy(d_min_q, lo.data(), sizeof(int) * B, hipMemcpyHostToDevice));
+  BHIP_TRY(hipMemcpy(d_max_q, hi.data(), sizeof(int) * B, hipMemcpyHostToDevice));
+  if (with_params) {
+    std::vector<PitchParams> pp(B, PitchParams{52.0, 1.0, 0.0, 0.0, 0, 0});
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_params), sizeof(PitchParams) * B));
+    BHIP_TRY(hipMemcpy(d_params, pp.data(), sizeof(PitchParams) * B, hipMemcpyHostToDevice));
+  }
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hop), sizeof(int)));
+  BHIP_TRY(hipMemset(d_hop, 0, sizeof(int)));
+  return true;
+}
+void PitchState::destroy() {
+  arena.release();
+  if (owns_in && d_in) (void)hipFree(d_in);
+  void* ptrs[] = {d_min_q, d_max_q, d_prev_q, d_q_raw, d_q, d_feat, d_params, d_hop};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  d_in = d_feat = nullptr; d_min_q = d_max_q = d_prev_q = d_q_raw = d_q = d_hop = nullptr; d_params = nullptr;
+}
+
+using P1 = Layer<B_SPEC_BINS, 128, 3, 1, 1, 1, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
+using P23 = Layer<128, 128, 3, 1, 1, 1, PRE_NONE, ACT_GELU, EPI_BIAS, true>;
+using PGATE = Layer<128, 384, 1, 1, 1, 1, PRE_NONE, ACT_NONE, EPI_BIAS, false>;
+using POUT = Layer<128, B_PITCH_BINS, 1, 1, 1, 1, PRE_NONE, ACT_NONE, EPI_BIAS, false>;
+
+void pitch_forward(const PitchWeights& w, const PitchState& s, hipStream_t st) {
+  const int B = s.B;
+  hipLaunchKernelGGL(pitch_fft_kernel, dim3(B), dim3(256), 0, st, s.d_in, s.audio, s.spec, w.window, w.twiddle, s.d_hop);
+  launch_auto<P1>(conv_args(s.spec, s.p[0], w.p_w[0], w.p_b[0], s.d_hop, B), st);
+  launch_auto<P23>(conv_args(s.p[0], s.p[1], w.p_w[1], w.p_b[1], s.d_hop, B), st);
+  launch_auto<P23>(conv_args(s.p[1], s.p[2], w.p_w[2], w.p_b[2], s.d_hop, B), st);
+  launch_auto<PGATE>(conv_args(s.p[2], s.gi, w.gru_wih, w.gru_bih, s.d_hop, B), st);
+  ConvArgs gh = conv_args(s.h, s.gh, w.gru_whh, w.gru_bhh, s.d_hop, B);
+  gh.rel_shift = -1;
+  launch_auto<PGATE>(gh, st);
+  hipLaunchKernelGGL(gru_gate_kernel, dim3((B * 128 + 255) / 256), dim3(256), 0, st, s.gi.base, s.gh.base, s.h, 128, B, s.d_hop);
+  launch_auto<POUT>(conv_args(s.h, s.logits, w.out_w, w.out_b, s.d_hop, B), st);
+  PitchHeadArgs a{s.logits.base, s.h, s.d_in, w.voi_w, w.voi_b, s.d_min_q, s.d_max_q, s.d_prev_q,
+                  s.d_q_raw, s.d_q, s.d_feat, s.d_params, s.d_hop};
+  hipLaunchKernelGGL(pitch_head_kernel, dim3(B), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(hop_advance_kernel, dim3(1), dim3(1), 0, st, s.d_hop);
+}
+
+}  // namespace bhip

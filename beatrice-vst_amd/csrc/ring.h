@@ -1,0 +1,32 @@
+// ring.h -- per-stream activation rings ("data layout in HBM").
+//
+// Every tensor that a causal layer must remember across hops lives in a ring:
+//   base[stream][frame][channel], frames per stream R = n * m,
+//   n = frames produced per hop, m = 1 + ceil(history / n) hop slots.
+// Hop h writes its n new frames contiguously at slot (h % m); a consumer reads the new frames
+// plus up to `history` older frames (wrapping backwards).  Producers write straight into the
+// consumer's ring, so state update costs no extra pass and the only per-hop state traffic is
+// "write each activation once, read it once per tap".
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct Ring {
+  float* base;
+  int C;  // channels per frame
+  int n;  // frames per hop
+  int m;  // hop slots
+};
+
+__host__ __device__ inline int ring_frames(const Ring& r) { return r.n * r.m; }
+__host__ __device__ inline size_t ring_stream_floats(const Ring& r) { return (size_t)r.n * r.m * r.C; }
+
+// first new frame of hop `hop`
+__device__ __forceinline__ int ring_pos(const Ring& r, int hop) { return (hop % r.m) * r.n; }
+
+// pointer to frame (pos + rel) of stream b; rel in [-history, n)
+__device__ __forceinline__ float* ring_frame(const Ring& r, int b, int pos, int rel) {
+  int f = pos + rel;
+  const int R = r.n * r.m;
+  if (f < 0) f += R;
+  return r.base + ((size_t)b * R + f) * r.C;
+}

@@ -1,0 +1,150 @@
+// wave.hip -- waveform generator forward pass (MODEL_SPEC 4.4), the body of
+// Beatrice20rc0_GenerateWaveform1 (reference lib/beatricelib/beatrice.h:301-307) for B streams.
+#include "conv_gemm.hip.h"
+#include "engine.h"
+
+namespace bhip {
+
+static const int kBlockDil[B_NBLOCKS] = {1, 2, 4, 8};
+static const int kUpT[5] = {1, 5, 20, 80, 240};
+static const int kUpC[5] = {256, 128, 64, 32, 16};
+
+bool WaveState::create(int B_, int n_slots_, int n_add_, int n_frm_, float* shared_phone, int* shared_q,
+                       float* shared_feat) {
+  B = B_; n_slots = n_slots_; n_add = n_add_; n_frm = n_frm_;
+  n_tiles_max = (B + 15) / 16 + n_slots;
+  std::vector<RingSpec> specs = {
+      {&e, B_HID, 1, 1},
+      {&x[0], B_HID, 1, 1 + 2 * kBlockDil[0]}, {&x[1], B_HID, 1, 1 + 2 * kBlockDil[1]},
+      {&x[2], B_HID, 1, 1 + 2 * kBlockDil[2]}, {&x[3], B_HID, 1, 1 + 2 * kBlockDil[3]}, {&x[4], B_HID, 1, 2},
+      {&h1, B_HID, 1, 1}, {&xa, B_HID, 1, 1}, {&q, B_HID, 1, 1}, {&sc, B_KV_LEN, 1, 1}, {&o, B_HID, 1, 1},
+  };
+  for (int s = 0; s < 4; ++s) {
+    const int n = kUpT[s + 1], c = kUpC[s + 1];
+    specs.push_back({&ya[s], c, n, 1 + (2 + n - 1) / n});
+    specs.push_back({&yb[s], c, n, 1 + (6 + n - 1) / n});
+    specs.push_back({&yc[s], c, n, s == 3 ? 1 + (6 + n - 1) / n : 1 + (1 + n - 1) / n});
+  }
+  if (!arena.build(B, specs)) return false;
+  if (shared_phone) { d_phone = shared_phone; d_q = shared_q; d_feat = shared_feat; owns_inputs = false; }
+  else {
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_phone), sizeof(float) * B * B_PHONE_CH));
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_q), sizeof(int) * B));
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_feat), sizeof(float) * B * 4));
+    BHIP_TRY(hipMemset(d_phone, 0, sizeof(float) * B * B_PHONE_CH));
+    BHIP_TRY(hipMemset(d_q, 0, sizeof(int) * B));
+    BHIP_TRY(hipMemset(d_feat, 0, sizeof(float) * B * 4));
+    owns_inputs = true;
+  }
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(float) * B * B_OUT_HOP));
+  BHIP_TRY(hipMemset(d_out, 0, sizeof(float) * B * B_OUT_HOP));
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_inv), sizeof(float) * B));
+  BHIP_TRY(hipMemset(d_inv, 0, sizeof(float) * B));
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_add_tab), sizeof(float) * n_add * B_HID));
+  BHIP_TRY(hipMemset(d_add_tab, 0, sizeof(float) * n_add * B_HID));
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_frm_tab), sizeof(float) * n_frm * B_HID));
+  BHIP_TRY(hipMemset(d_frm_tab, 0, sizeof(float) * n_frm * B_HID));
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_add_idx), sizeof(int) * B));
+  BHIP_TRY(hipMemset(d_add_idx, 0, sizeof(int) * B));
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_frm_idx), sizeof(int) * B));
+  BHIP_TRY(hipMemset(d_frm_idx, 0, sizeof(int) * B));
+  std::vector<int> perm((size_t)n_tiles_max * 16, -1), slot(n_tiles_max, -1);
+  for (int b = 0; b < B; ++b) perm[b] = b;
+  for (int t = 0; t < (B + 15) / 16; ++t) slot[t] = 0;
+  for (int blk = 0; blk < B_NBLOCKS; ++blk) {
+    const size_t kvf = (size_t)n_slots * B_HID * B_KV_LEN;
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_kt[blk]), sizeof(float) * kvf));
+    BHIP_TRY(hipMemset(d_kt[blk], 0, sizeof(float) * kvf));
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_v[blk]), sizeof(float) * kvf));
+    BHIP_TRY(hipMemset(d_v[blk], 0, sizeof(float) * kvf));
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_perm[blk]), sizeof(int) * perm.size()));
+    BHIP_TRY(hipMemcpy(d_perm[blk], perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice));
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_tile_slot[blk]), sizeof(int) * slot.size()));
+    BHIP_TRY(hipMemcpy(d_tile_slot[blk], slot.data(), sizeof(int) * slot.size(), hipMemcpyHostToDevice));
+  }
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hop), sizeof(int)));
+  BHIP_TRY(hipMemset(d_hop, 0, sizeof(int)));
+  return true;
+}
+void WaveState::destroy() {
+  arena.release();
+  if (owns_inputs) { if (d_phone) (void)hipFree(d_phone); if (d_q) (void)hipFree(d_q); if (d_feat) (void)hipFree(d_feat); }
+  void* ptrs[] = {d_out, d_inv, d_add_tab, d_frm_tab, d_add_idx, d_frm_idx, d_hop};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (int b = 0; b < B_NBLOCKS; ++b) {
+    void* q4[] = {d_kt[b], d_v[b], d_perm[b], d_tile_slot[b]};
+    for (void* p : q4) if (p) (void)hipFree(p);
+    d_kt[b] = d_v[b] = nullptr; d_perm[b] = d_tile_slot[b] = nullptr;
+  }
+  d_phone = d_feat = d_out = d_inv = d_add_tab = d_frm_tab = nullptr;
+  d_q = d_add_idx = d_frm_idx = d_hop = nullptr;
+}
+
+using INP = Layer<B_PHONE_CH, B_HID, 1, 1, 1, 1, PRE_NONE, ACT_NONE, EPI_BIAS, true>;
+template <int D> using C1 = Layer<B_HID, B_HID, 3, 1, D, 1, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
+using C2 = Layer<B_HID, B_HID, 1, 1, 1, 1, PRE_NONE, ACT_NONE, EPI_BIAS, true>;
+using QL = Layer<B_HID, B_HID, 1, 1, 1, 1, PRE_NONE, ACT_NONE, EPI_BIAS, false>;
+using SCORE = Layer<B_HID, B_KV_LEN, 1, 1, 1, 1, PRE_NONE, ACT_NONE, EPI_SCALE, false, true>;
+using PV = Layer<B_KV_LEN, B_HID, 1, 1, 1, 1, PRE_NONE, ACT_NONE, EPI_ROWSCALE, false, true>;
+template <int CIN, int COUT, int R, int TIN> using UP = Layer<CIN, R * COUT, 2, 1, 1, TIN, PRE_LRELU, ACT_NONE, EPI_BIAS, false>;
+template <int C, int D, int T> using RES = Layer<C, C, 3, 1, D, T, PRE_LRELU, ACT_NONE, EPI_BIAS, true>;
+using TG = TileCfg<1, 1, 1, 4>;     // grouped attention tiles: 16 streams x 64 columns
+using T32 = TileCfg<2, 2, 4, 1>;    // 128 x 32
+using T48 = TileCfg<1, 3, 4, 1>;    // 64 x 48
+using T16 = TileCfg<4, 1, 4, 1>;    // 256 x 16
+
+template <int D>
+static void launch_c1(const WaveWeights& w, const WaveState& s, int blk, hipStream_t st) {
+  launch_auto<C1<D>>(conv_args(s.x[blk], s.h1, w.c1_w[blk], w.c1_b[blk], s.d_hop, s.B), st);
+}
+
+void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t st) {
+  const int B = s.B;
+  CondArgs ca{s.d_q, s.d_feat, w.pitch_emb, w.feat_w, s.d_add_tab, s.d_add_idx, s.d_frm_tab, s.d_frm_idx, s.e.base};
+  hipLaunchKernelGGL(wave_cond_kernel, dim3(B), dim3(256), 0, st, ca);
+  const Ring phone_in{s.d_phone, B_PHONE_CH, 1, 1};
+  ConvArgs a = conv_args(phone_in, s.x[0], w.inp_w, w.inp_b, s.d_hop, B);
+  a.res = s.e;
+  launch_auto<INP>(a, st);
+  for (int blk = 0; blk < B_NBLOCKS; ++blk) {
+    switch (blk) {
+      case 0: launch_c1<1>(w, s, blk, st); break;
+      case 1: launch_c1<2>(w, s, blk, st); break;
+      case 2: launch_c1<4>(w, s, blk, st); break;
+      default: launch_c1<8>(w, s, blk, st); break;
+    }
+    a = conv_args(s.h1, s.xa, w.c2_w[blk], w.c2_b[blk], s.d_hop, B);
+    a.res = s.x[blk];
+    launch_auto<C2>(a, st);
+    launch_auto<QL>(conv_args(s.xa, s.q, w.q_w[blk], w.q_b[blk], s.d_hop, B), st);
+    a = conv_args(s.q, s.sc, s.d_kt[blk], nullptr, s.d_hop, B);
+    a.scale = 0.0625f; a.perm = s.d_perm[blk]; a.tile_slot = s.d_tile_slot[blk];
+    a.w_slot_stride = (size_t)B_HID * B_KV_LEN;
+    launch_conv<SCORE, TG>(a, s.n_tiles_max, st);
+    hipLaunchKernelGGL(attn_softmax_kernel, dim3(B), dim3(64), 0, st, s.sc.base, s.d_inv, B);
+    a = conv_args(s.sc, s.o, s.d_v[blk], nullptr, s.d_hop, B);
+    a.rowscale = s.d_inv; a.perm = s.d_perm[blk]; a.tile_slot = s.d_tile_slot[blk];
+    a.w_slot_stride = (size_t)B_KV_LEN * B_HID;
+    launch_conv<PV, TG>(a, s.n_tiles_max, st);
+    a = conv_args(s.o, s.x[blk + 1], w.o_w[blk], w.o_b[blk], s.d_hop, B);
+    a.res = s.xa;
+    launch_auto<C2>(a, st);
+  }
+  // upsampler: x[4] -> 5 -> 20 -> 80 -> 240 frames
+  launch_auto<UP<256, 128, 5, 1>>(conv_args(s.x[4], s.ya[0], w.up_w[0], w.up_b[0], s.d_hop, B), st);
+  launch_auto<RES<128, 1, 5>>(conv_args(s.ya[0], s.yb[0], w.ra_w[0], w.ra_b[0], s.d_hop, B), st);
+  launch_auto<RES<128, 3, 5>>(conv_args(s.yb[0], s.yc[0], w.rb_w[0], w.rb_b[0], s.d_hop, B), st);
+  launch_auto<UP<128, 64, 4, 5>>(conv_args(s.yc[0], s.ya[1], w.up_w[1], w.up_b[1], s.d_hop, B), st);
+  launch_auto<RES<64, 1, 20>>(conv_args(s.ya[1], s.yb[1], w.ra_w[1], w.ra_b[1], s.d_hop, B), st);
+  launch_auto<RES<64, 3, 20>>(conv_args(s.yb[1], s.yc[1], w.rb_w[1], w.rb_b[1], s.d_hop, B), st);
+  launch_auto<UP<64, 32, 4, 20>>(conv_args(s.yc[1], s.ya[2], w.up_w[2], w.up_b[2], s.d_hop, B), st);
+  launch_conv<RES<32, 1, 80>, T32>(conv_args(s.ya[2], s.yb[2], w.ra_w[2], w.ra_b[2], s.d_hop, B), 0, st);
+  launch_conv<RES<32, 3, 80>, T32>(conv_args(s.yb[2], s.yc[2], w.rb_w[2], w.rb_b[2], s.d_hop, B), 0, st);
+  launch_conv<UP<32, 16, 3, 80>, T48>(conv_args(s.yc[2], s.ya[3], w.up_w[3], w.up_b[3], s.d_hop, B), 0, st);
+  launch_conv<RES<16, 1, 240>, T16>(conv_args(s.ya[3], s.yb[3], w.ra_w[3], w.ra_b[3], s.d_hop, B), 0, st);
+  launch_conv<RES<16, 3, 240>, T16>(conv_args(s.yb[3], s.yc[3], w.rb_w[3], w.rb_b[3], s.d_hop, B), 0, st);
+  hipLaunchKernelGGL(wave_final_kernel, dim3(B), dim3(256), 0, st, s.yc[3], w.fin_w, w.fin_b, s.d_out, s.d_hop);
+  hipLaunchKernelGGL(hop_advance_kernel, dim3(1), dim3(1), 0, st, s.d_hop);
+}
+
+}  // namespace bhip

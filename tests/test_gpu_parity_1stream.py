@@ -1,0 +1,131 @@
+"""HIP vs oracle through the 1-stream C-ABI (include/beatrice_abi.h), module by module and end to
+end.  Tolerance: north_star asks <= 1e-4 max-abs on float32 PCM; the spec is written so that the two
+implementations are bit-identical, and the tests report the observed deviation."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _maxabs(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+def test_phone_module(bv, oracle, product, model_dir):
+    x = bv.synth_audio(160 * 40, seed=3)
+    res = {}
+    for name, abi in (("o", oracle), ("p", product)):
+        m = bv.Models(abi, model_dir)
+        pc = abi.CreatePhoneContext1()
+        outs = []
+        for i in range(40):
+            out = np.zeros(bv.PHONE_CH, np.float32)
+            abi.ExtractPhone1(m.phone, bv.fptr(np.ascontiguousarray(x[i * 160:(i + 1) * 160])), bv.fptr(out), pc)
+            outs.append(out)
+        abi.DestroyPhoneContext1(pc)
+        m.close()
+        res[name] = np.array(outs)
+    assert np.abs(res["o"]).max() > 0.1
+    d = _maxabs(res["o"], res["p"])
+    print("phone max-abs", d)
+    assert d <= TOL
+
+
+def test_phone_vq(bv, oracle, product, model_dir):
+    x = bv.synth_audio(160 * 12, seed=4)
+    for k in (1, 4, 8):
+        res = {}
+        for name, abi in (("o", oracle), ("p", product)):
+            m = bv.Models(abi, model_dir)
+            pc = abi.CreatePhoneContext1()
+            abi.SetCodebook(pc, bv.fptr(m.tables.codebooks[1]))
+            abi.SetVQNumNeighbors(pc, k)
+            outs = []
+            for i in range(12):
+                out = np.zeros(bv.PHONE_CH, np.float32)
+                abi.ExtractPhone1(m.phone, bv.fptr(np.ascontiguousarray(x[i * 160:(i + 1) * 160])), bv.fptr(out), pc)
+                outs.append(out)
+            abi.DestroyPhoneContext1(pc)
+            m.close()
+            res[name] = np.array(outs)
+        d = _maxabs(res["o"], res["p"])
+        print("vq k=%d max-abs %g" % (k, d))
+        assert d <= TOL
+
+
+def test_pitch_module(bv, oracle, product, model_dir):
+    x = bv.synth_audio(160 * 40, seed=5)
+    res = {}
+    for name, abi in (("o", oracle), ("p", product)):
+        m = bv.Models(abi, model_dir)
+        tc = abi.CreatePitchContext1()
+        abi.SetMinQuantizedPitch(tc, 1)
+        abi.SetMaxQuantizedPitch(tc, 383)
+        qs, fs = [], []
+        for i in range(40):
+            q = np.zeros(1, np.int32)
+            f = np.zeros(4, np.float32)
+            abi.EstimatePitch1(m.pitch, bv.fptr(np.ascontiguousarray(x[i * 160:(i + 1) * 160])), bv.iptr(q), bv.fptr(f), tc)
+            qs.append(int(q[0]))
+            fs.append(f)
+        abi.DestroyPitchContext1(tc)
+        m.close()
+        res[name] = (qs, np.array(fs))
+    assert res["o"][0] == res["p"][0], (res["o"][0], res["p"][0])
+    d = _maxabs(res["o"][1], res["p"][1])
+    print("pitch feat max-abs", d)
+    assert d <= TOL
+
+
+def test_waveform_module(bv, oracle, product, model_dir):
+    rng = np.random.default_rng(7)
+    phones = rng.standard_normal((30, bv.PHONE_CH)).astype(np.float32) * 0.7
+    qs = rng.integers(1, 447, size=30).astype(np.int32)
+    feats = rng.random((30, 4)).astype(np.float32)
+    res = {}
+    for name, abi in (("o", oracle), ("p", product)):
+        m = bv.Models(abi, model_dir)
+        wc, ec = abi.CreateWaveformContext1(), abi.CreateEmbeddingContext()
+        t = m.tables
+        abi.SetAdditiveSpeakerEmbedding(m.embed, bv.fptr(t.additive[1]), ec, wc)
+        abi.SetFormantShiftEmbedding(m.embed, bv.fptr(t.formant[5]), ec, wc)
+        abi.RegisterKeyValueSpeakerEmbedding(m.embed, bv.fptr(t.kv[1]), ec)
+        for blk in range(4):
+            abi.SetKeyValueSpeakerEmbedding(m.embed, blk, ec, wc)
+        outs = []
+        for i in range(30):
+            out = np.zeros(bv.OUT_HOP, np.float32)
+            abi.GenerateWaveform1(m.wave, bv.fptr(phones[i]), bv.iptr(qs[i:i + 1].copy()), bv.fptr(feats[i]), bv.fptr(out), wc)
+            outs.append(out)
+        abi.DestroyWaveformContext1(wc)
+        abi.DestroyEmbeddingContext(ec)
+        m.close()
+        res[name] = np.array(outs)
+    assert np.abs(res["o"]).max() > 0.05
+    d = _maxabs(res["o"], res["p"])
+    print("waveform max-abs", d)
+    assert d <= TOL
+
+
+def test_end_to_end_protocol(bv, oracle, product, model_dir):
+    """Reference call protocol (processor_core_2.cc:181-255) incl. a speaker switch mid-stream: the
+    four K/V blocks change one per hop."""
+    x = bv.synth_audio(160 * 60, seed=9)
+    res = {}
+    for name, abi in (("o", oracle), ("p", product)):
+        m = bv.Models(abi, model_dir)
+        s = bv.Stream1(m, speaker=0, vq_k=2)
+        outs = []
+        for i in range(60):
+            if i == 25:
+                s.set_target_speaker(2)
+            if i == 40:
+                s.set_formant_index(7)
+            outs.append(s.hop(x[i * 160:(i + 1) * 160]))
+        s.close()
+        m.close()
+        res[name] = np.array(outs)
+    d = _maxabs(res["o"], res["p"])
+    print("end-to-end max-abs", d, "bit-identical" if np.array_equal(res["o"], res["p"]) else "")
+    assert d <= TOL
