@@ -243,3 +243,124 @@ def synth_audio(n_samples, seed=0, sr=16000):
     env = 0.55 + 0.45 * np.sin(2 * np.pi * 4.0 * t + rng.random() * 6.28)
     x = 0.3 * x / 1.8 * env + 0.0316 * 0.3 * rng.standard_normal(n_samples)
     return x.astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+# Batched extension ABI (include/beatrice_batch.h)
+# ------------------------------------------------------------------------------------------------
+_BATCH = {
+    "BeatriceHip_LoadPhoneExtractorFromMemory": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "BeatriceHip_LoadPitchEstimatorFromMemory": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "BeatriceHip_LoadWaveformGeneratorFromMemory": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "BeatriceHip_LoadEmbeddingSetterFromMemory": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "BeatriceBatch_Create": (_vp, [_vp, _vp, _vp, _vp, C.c_int, C.c_int]),
+    "BeatriceBatch_Destroy": (None, [_vp]),
+    "BeatriceBatch_IsHealthy": (C.c_int, [_vp]),
+    "BeatriceBatch_NumStreams": (C.c_int, [_vp]),
+    "BeatriceBatch_SetSpeakerTables": (C.c_int, [_vp, C.c_int, _f32p, _f32p, _f32p, _f32p]),
+    "BeatriceBatch_UpdateSpeaker": (C.c_int, [_vp, C.c_int, _f32p, _f32p, _f32p]),
+    "BeatriceBatch_SetTargetSpeaker": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "BeatriceBatch_FlushSpeaker": (C.c_int, [_vp, C.c_int]),
+    "BeatriceBatch_SetFormantShift": (C.c_int, [_vp, C.c_int, C.c_double]),
+    "BeatriceBatch_SetVQNumNeighbors": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "BeatriceBatch_SetMinSourcePitch": (C.c_int, [_vp, C.c_int, C.c_double]),
+    "BeatriceBatch_SetMaxSourcePitch": (C.c_int, [_vp, C.c_int, C.c_double]),
+    "BeatriceBatch_SetPitchShift": (C.c_int, [_vp, C.c_int, C.c_double]),
+    "BeatriceBatch_SetAverageSourcePitch": (C.c_int, [_vp, C.c_int, C.c_double]),
+    "BeatriceBatch_SetIntonationIntensity": (C.c_int, [_vp, C.c_int, C.c_double]),
+    "BeatriceBatch_SetPitchCorrection": (C.c_int, [_vp, C.c_int, C.c_double]),
+    "BeatriceBatch_SetPitchCorrectionType": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "BeatriceBatch_ResetStream": (C.c_int, [_vp, C.c_int]),
+    "BeatriceBatch_ConvertFrames": (C.c_int, [_vp, _f32p, _f32p]),
+    "BeatriceBatch_ConvertFramesDevice": (C.c_int, [_vp, _vp, _vp]),
+    "BeatriceBatch_Synchronize": (C.c_int, [_vp]),
+    "BeatriceBatch_SetStream": (C.c_int, [_vp, _vp]),
+    "BeatriceBatch_GetStream": (_vp, [_vp]),
+    "BeatriceBatch_EnableGraph": (C.c_int, [_vp, C.c_int]),
+    "BeatriceBatch_DeviceInput": (_vp, [_vp]),
+    "BeatriceBatch_DeviceOutput": (_vp, [_vp]),
+    "BeatriceBatch_GetIntermediates": (C.c_int, [_vp, _f32p, _i32p, _i32p, _f32p]),
+    "BeatriceBatch_TimeSteps": (C.c_int, [_vp, C.c_int, _f32p]),
+    "BeatriceBatch_ProfileKernels": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p, _i32p,
+                                               C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+ABI_SYMBOLS_BATCH = list(_BATCH)
+
+
+def bind_batch(abi):
+    """Attach typed prototypes of the batched extension to an Abi (product library only)."""
+    if getattr(abi, "_batch_bound", False):
+        return abi
+    for name, (res, args) in _BATCH.items():
+        fn = getattr(abi.lib, name)
+        fn.restype, fn.argtypes = res, args
+        setattr(abi, name, fn)
+    abi._batch_bound = True
+    return abi
+
+
+class Batch:
+    """B concurrent streams on one GPU through include/beatrice_batch.h."""
+
+    def __init__(self, models, n_streams, max_speakers=None):
+        self.m = models
+        self.a = bind_batch(models.abi)
+        t = models.tables
+        self.B = n_streams
+        ms = max_speakers or (t.n_speakers + 1)
+        self.h = self.a.BeatriceBatch_Create(models.phone, models.pitch, models.wave, models.embed, n_streams, ms)
+        if not self.a.BeatriceBatch_IsHealthy(self.h):
+            raise RuntimeError("BeatriceBatch_Create failed (no GPU / HIP error)")
+        self._check(self.a.BeatriceBatch_SetSpeakerTables(self.h, t.n_speakers + 1, fptr(t.codebooks), fptr(t.additive),
+                                                          fptr(t.formant), fptr(t.kv)))
+        # reference host defaults (processor_core_2.h:103-113): speaker 0 with all K/V blocks installed
+        self._check(self.a.BeatriceBatch_SetTargetSpeaker(self.h, -1, 0))
+        self._check(self.a.BeatriceBatch_FlushSpeaker(self.h, -1))
+        self._check(self.a.BeatriceBatch_SetMinSourcePitch(self.h, -1, 33.125))
+        self._check(self.a.BeatriceBatch_SetMaxSourcePitch(self.h, -1, 80.875))
+
+    @staticmethod
+    def _check(rc):
+        if rc != 0:
+            raise RuntimeError("BeatriceBatch call failed: %d" % rc)
+
+    def convert(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        assert x.shape == (self.B, IN_HOP)
+        out = np.zeros((self.B, OUT_HOP), np.float32)
+        self._check(self.a.BeatriceBatch_ConvertFrames(self.h, fptr(x), fptr(out)))
+        return out
+
+    def intermediates(self):
+        phone = np.zeros((self.B, PHONE_CH), np.float32)
+        q_raw = np.zeros(self.B, np.int32)
+        q = np.zeros(self.B, np.int32)
+        feat = np.zeros((self.B, 4), np.float32)
+        self._check(self.a.BeatriceBatch_GetIntermediates(self.h, fptr(phone), iptr(q_raw), iptr(q), fptr(feat)))
+        return phone, q_raw, q, feat
+
+    def time_steps(self, steps):
+        ms = C.c_float(0)
+        self._check(self.a.BeatriceBatch_TimeSteps(self.h, steps, C.byref(ms)))
+        return ms.value
+
+    def profile_kernels(self, repeats=10, max_entries=96):
+        """[{name, launches, mean_us, flops, bytes}] for one hop (BeatriceBatch_ProfileKernels)."""
+        names = C.create_string_buffer(64 * max_entries)
+        launches = (C.c_int * max_entries)()
+        us = (C.c_double * max_entries)()
+        fl = (C.c_double * max_entries)()
+        by = (C.c_double * max_entries)()
+        n = self.a.BeatriceBatch_ProfileKernels(self.h, repeats, max_entries, names, launches, us, fl, by)
+        if n < 0:
+            raise RuntimeError("BeatriceBatch_ProfileKernels failed: %d" % n)
+        rows = []
+        for i in range(n):
+            nm = names.raw[64 * i:64 * (i + 1)].split(b"\0")[0].decode()
+            rows.append(dict(name=nm, launches=launches[i], mean_us=us[i], flops=fl[i], bytes=by[i]))
+        return rows
+
+    def close(self):
+        if self.h:
+            self.a.BeatriceBatch_Destroy(self.h)
+            self.h = None

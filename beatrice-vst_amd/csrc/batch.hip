@@ -1,0 +1,538 @@
+// batch.hip -- N-stream extension ABI (include/beatrice_batch.h).
+//
+// One BeatriceBatch = B independent streams advancing one hop per call, sharing the immutable model
+// objects.  Host-side it mirrors, per stream, the settings and the call protocol that the reference
+// host keeps per plugin instance (reference src/common/processor_core_2.cc; line references at each
+// function).  Device-side it is phone_forward -> pitch_forward -> wave_forward on one HIP stream,
+// replayed from a hipGraph (the chain has ~70 launches per hop; hop position is read from device
+// memory by the kernels, so one captured graph serves every hop).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "abi_objects.h"
+#include "beatrice_batch.h"
+
+using namespace bhip;
+
+namespace {
+
+struct StreamCfg {
+  int target_speaker = 0;
+  int kv_set_count = B_NBLOCKS;  // reference: key_value_speaker_embedding_set_count_ (processor_core_2.h:134)
+  int kv_slot[B_NBLOCKS] = {0, 0, 0, 0};
+  int codebook_speaker = 0;
+  int additive_speaker = 0;
+  int formant_index = 4;
+  int vq_k = 0;
+  int min_q = 1, max_q = B_PITCH_BINS - 1;
+  PitchParams pitch{52.0, 1.0, 0.0, 0.0, 0, 0};  // defaults: processor_core_2.h:105-110
+};
+
+template <class T>
+struct Mirror {  // pinned host copy of a small per-stream device array
+  T* h = nullptr;
+  T* d = nullptr;
+  size_t n = 0;
+  bool dirty = true;
+  bool alloc_host(size_t n_) {
+    n = n_;
+    BHIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h), sizeof(T) * n, hipHostMallocDefault));
+    std::memset(h, 0, sizeof(T) * n);
+    return true;
+  }
+  bool push(hipStream_t s) {
+    if (!dirty) return true;
+    BHIP_TRY(hipMemcpyAsync(d, h, sizeof(T) * n, hipMemcpyHostToDevice, s));
+    dirty = false;
+    return true;
+  }
+  void release() { if (h) (void)hipHostFree(h); h = nullptr; }
+};
+
+}  // namespace
+
+struct BeatriceBatch {
+  const Beatrice20rc0_PhoneExtractor* phone_m = nullptr;
+  const Beatrice20rc0_PitchEstimator* pitch_m = nullptr;
+  const Beatrice20rc0_WaveformGenerator* wave_m = nullptr;
+  const Beatrice20rc0_EmbeddingSetter* embed_m = nullptr;
+  int B = 0, max_speakers = 0, n_speakers = 0;
+  bool ok = false;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  PhoneState phone;
+  PitchState pitch;
+  WaveState wave;
+  float* d_in = nullptr;  // [B][160], shared by phone and pitch
+  // speaker tables on device
+  float *d_cb_raw = nullptr, *d_cbT = nullptr, *d_cnorm = nullptr, *d_add_raw = nullptr, *d_frm_raw = nullptr, *d_kv_raw = nullptr;
+  // per-stream settings
+  std::vector<StreamCfg> cfg;
+  Mirror<const float*> m_cbT, m_cnorm;
+  Mirror<int> m_vqk, m_min_q, m_max_q, m_add_idx, m_frm_idx;
+  Mirror<PitchParams> m_params;
+  Mirror<int> m_perm[B_NBLOCKS], m_tile_slot[B_NBLOCKS];
+  int pending_kv = 0;  // streams with kv_set_count < 4
+  bool inflight = false;  // an un-synchronised device-variant step may still read the pinned mirrors
+  // staging for the host variant
+  float *h_in = nullptr, *h_out = nullptr;
+  // graph
+  bool use_graph = true;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+// Pinned mirrors are read by asynchronous copies; before the host edits them again the previous
+// device-variant step must have consumed them.
+void settle(BeatriceBatch* b) {
+  if (b->inflight) { (void)hip_ok(hipStreamSynchronize(b->stream), "settle"); b->inflight = false; }
+}
+
+void rebuild_tiles(BeatriceBatch* b, int blk) {
+  // streams grouped by K/V slot, ascending slot then ascending stream, 16 per tile
+  const int nt = b->wave.n_tiles_max;
+  int* perm = b->m_perm[blk].h;
+  int* slot = b->m_tile_slot[blk].h;
+  std::fill(perm, perm + (size_t)nt * 16, -1);
+  std::fill(slot, slot + nt, -1);
+  std::vector<int> order(b->B);
+  for (int i = 0; i < b->B; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return b->cfg[x].kv_slot[blk] < b->cfg[y].kv_slot[blk]; });
+  int tile = -1, fill = 16, cur = -1;
+  for (int s : order) {
+    const int sl = b->cfg[s].kv_slot[blk];
+    if (sl != cur || fill == 16) { ++tile; fill = 0; cur = sl; slot[tile] = sl; }
+    perm[tile * 16 + fill++] = s;
+  }
+  b->m_perm[blk].dirty = true;
+  b->m_tile_slot[blk].dirty = true;
+}
+
+void sync_stream_arrays(BeatriceBatch* b, int s) {
+  const StreamCfg& c = b->cfg[s];
+  b->m_cbT.h[s] = b->d_cbT + (size_t)c.codebook_speaker * B_PHONE_CH * B_CODEBOOK;
+  b->m_cnorm.h[s] = b->d_cnorm + (size_t)c.codebook_speaker * B_CODEBOOK;
+  b->m_vqk.h[s] = c.vq_k;
+  b->m_min_q.h[s] = c.min_q;
+  b->m_max_q.h[s] = c.max_q;
+  b->m_add_idx.h[s] = c.additive_speaker;
+  b->m_frm_idx.h[s] = c.formant_index;
+  b->m_params.h[s] = c.pitch;
+  b->m_cbT.dirty = b->m_cnorm.dirty = b->m_vqk.dirty = b->m_min_q.dirty = b->m_max_q.dirty = true;
+  b->m_add_idx.dirty = b->m_frm_idx.dirty = b->m_params.dirty = true;
+}
+
+// One K/V block per stream per hop, as the reference host does before its three per-hop calls
+// (processor_core_2.cc:179-181, processor_core_2.h:161-169).
+void advance_kv(BeatriceBatch* b) {
+  if (b->pending_kv == 0) return;
+  settle(b);
+  bool dirty[B_NBLOCKS] = {false, false, false, false};
+  int still = 0;
+  for (StreamCfg& c : b->cfg) {
+    if (c.kv_set_count < B_NBLOCKS) {
+      c.kv_slot[c.kv_set_count] = c.target_speaker;
+      dirty[c.kv_set_count] = true;
+      ++c.kv_set_count;
+      if (c.kv_set_count < B_NBLOCKS) ++still;
+    }
+  }
+  b->pending_kv = still;
+  for (int blk = 0; blk < B_NBLOCKS; ++blk) if (dirty[blk]) rebuild_tiles(b, blk);
+}
+
+bool push_settings(BeatriceBatch* b) {
+  hipStream_t s = b->stream;
+  bool ok = b->m_cbT.push(s) && b->m_cnorm.push(s) && b->m_vqk.push(s) && b->m_min_q.push(s) && b->m_max_q.push(s) &&
+            b->m_add_idx.push(s) && b->m_frm_idx.push(s) && b->m_params.push(s);
+  for (int blk = 0; blk < B_NBLOCKS; ++blk) ok = ok && b->m_perm[blk].push(s) && b->m_tile_slot[blk].push(s);
+  return ok;
+}
+
+void enqueue_chain(BeatriceBatch* b) {
+  phone_forward(b->phone_m->w, b->phone, b->stream);
+  pitch_forward(b->pitch_m->w, b->pitch, b->stream);
+  wave_forward(b->wave_m->w, b->wave, b->stream);
+}
+
+void drop_graph(BeatriceBatch* b) {
+  if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
+  if (b->graph) (void)hipGraphDestroy(b->graph);
+  b->graph_exec = nullptr;
+  b->graph = nullptr;
+}
+
+bool run_chain(BeatriceBatch* b) {
+  if (!b->use_graph) { enqueue_chain(b); return hip_ok(hipGetLastError(), "chain launch"); }
+  if (!b->graph_exec) {
+    BHIP_TRY(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
+    enqueue_chain(b);
+    BHIP_TRY(hipStreamEndCapture(b->stream, &b->graph));
+    BHIP_TRY(hipGraphInstantiate(&b->graph_exec, b->graph, nullptr, nullptr, 0));
+  }
+  BHIP_TRY(hipGraphLaunch(b->graph_exec, b->stream));
+  return true;
+}
+
+bool step_device(BeatriceBatch* b, const float* d_in, float* d_out) {
+  advance_kv(b);
+  if (!push_settings(b)) return false;
+  if (d_in && d_in != b->d_in)
+    BHIP_TRY(hipMemcpyAsync(b->d_in, d_in, sizeof(float) * b->B * B_IN_HOP, hipMemcpyDeviceToDevice, b->stream));
+  if (!run_chain(b)) return false;
+  if (d_out && d_out != b->wave.d_out)
+    BHIP_TRY(hipMemcpyAsync(d_out, b->wave.d_out, sizeof(float) * b->B * B_OUT_HOP, hipMemcpyDeviceToDevice, b->stream));
+  b->inflight = true;
+  return true;
+}
+
+template <class F>
+int for_streams(BeatriceBatch* b, int stream, F f) {
+  if (!b || !b->ok) return -2;
+  if (stream < -1 || stream >= b->B) return -1;
+  settle(b);
+  const int lo = stream < 0 ? 0 : stream, hi = stream < 0 ? b->B : stream + 1;
+  for (int s = lo; s < hi; ++s) { f(b->cfg[s]); sync_stream_arrays(b, s); }
+  return 0;
+}
+
+int midi_to_bin(double note) {
+  // reference processor_core_2.cc:561-583: clamp note to [0,128], bin = round((note-33)*8), clamp 1..447
+  note = std::min(std::max(note, 0.0), 128.0);
+  const int q = (int)std::round((note - 33.0) * (BEATRICE_PITCH_BINS_PER_OCTAVE / 12.0));
+  return std::min(std::max(q, 1), B_PITCH_BINS - 1);
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- memory loaders ---------------------------------------------------------------------------
+#define BHIP_MEMORY_LOADER(Name, Obj, KIND, Weights)                                                        \
+  Beatrice_ErrorCode BeatriceHip_Load##Name##FromMemory(Obj* m, const void* bytes, size_t size) {           \
+    std::vector<float> host;                                                                                \
+    const Beatrice_ErrorCode e = parse_model_bytes(static_cast<const unsigned char*>(bytes), size, KIND,   \
+                                                   (long)Weights::n_floats(), &host);                       \
+    if (e) return e;                                                                                        \
+    m->loaded = false;                                                                                      \
+    if (!m->blob.upload(host.data(), host.size())) return Beatrice_kFileOpenError;                          \
+    m->w.bind(m->blob.d);                                                                                   \
+    m->loaded = true;                                                                                       \
+    return Beatrice_kSuccess;                                                                               \
+  }
+BHIP_MEMORY_LOADER(PhoneExtractor, Beatrice20rc0_PhoneExtractor, KIND_PHONE, PhoneWeights)
+BHIP_MEMORY_LOADER(PitchEstimator, Beatrice20rc0_PitchEstimator, KIND_PITCH, PitchWeights)
+BHIP_MEMORY_LOADER(WaveformGenerator, Beatrice20rc0_WaveformGenerator, KIND_WAVE, WaveWeights)
+BHIP_MEMORY_LOADER(EmbeddingSetter, Beatrice20rc0_EmbeddingSetter, KIND_EMBED, EmbedWeights)
+
+// ---- lifecycle ----------------------------------------------------------------------------------
+BeatriceBatch* BeatriceBatch_Create(const Beatrice20rc0_PhoneExtractor* phone, const Beatrice20rc0_PitchEstimator* pitch,
+                                    const Beatrice20rc0_WaveformGenerator* wave, const Beatrice20rc0_EmbeddingSetter* embed,
+                                    int n_streams, int max_speakers) {
+  auto* b = new BeatriceBatch();
+  if (!phone || !pitch || !wave || !embed || !phone->loaded || !pitch->loaded || !wave->loaded || !embed->loaded ||
+      n_streams < 1 || max_speakers < 1)
+    return b;  // unhealthy object; every call on it fails with -2
+  b->phone_m = phone; b->pitch_m = pitch; b->wave_m = wave; b->embed_m = embed;
+  b->B = n_streams; b->max_speakers = max_speakers;
+  const int B = n_streams, S = max_speakers;
+  bool ok = make_stream(&b->stream);
+  b->owns_stream = ok;
+  ok = ok && hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_in), sizeof(float) * B * B_IN_HOP), "d_in") &&
+       hip_ok(hipMemset(b->d_in, 0, sizeof(float) * B * B_IN_HOP), "d_in0");
+  ok = ok && b->phone.create(B, b->d_in) && b->pitch.create(B, b->d_in, true) &&
+       b->wave.create(B, S, S, 9, b->phone.d_phone, b->pitch.d_q, b->pitch.d_feat);
+  const size_t cbf = (size_t)S * B_CODEBOOK * B_PHONE_CH, kvf = (size_t)S * B_KV_LEN * B_KV_CH;
+  ok = ok && hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_cb_raw), sizeof(float) * cbf), "cb") &&
+       hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_cbT), sizeof(float) * cbf), "cbT") &&
+       hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_cnorm), sizeof(float) * S * B_CODEBOOK), "cnorm") &&
+       hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_add_raw), sizeof(float) * S * B_HID), "add") &&
+       hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_frm_raw), sizeof(float) * 9 * B_HID), "frm") &&
+       hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_kv_raw), sizeof(float) * kvf), "kv");
+  ok = ok && hip_ok(hipMemset(b->d_cbT, 0, sizeof(float) * cbf), "cbT0") && hip_ok(hipMemset(b->d_cnorm, 0, sizeof(float) * S * B_CODEBOOK), "cn0");
+  b->cfg.assign(B, StreamCfg());
+  ok = ok && b->m_cbT.alloc_host(B) && b->m_cnorm.alloc_host(B) && b->m_vqk.alloc_host(B) && b->m_min_q.alloc_host(B) &&
+       b->m_max_q.alloc_host(B) && b->m_add_idx.alloc_host(B) && b->m_frm_idx.alloc_host(B) && b->m_params.alloc_host(B);
+  if (ok) {
+    b->m_cbT.d = b->phone.d_cbT; b->m_cnorm.d = b->phone.d_cnorm; b->m_vqk.d = b->phone.d_vqk;
+    b->m_min_q.d = b->pitch.d_min_q; b->m_max_q.d = b->pitch.d_max_q; b->m_params.d = b->pitch.d_params;
+    b->m_add_idx.d = b->wave.d_add_idx; b->m_frm_idx.d = b->wave.d_frm_idx;
+    for (int blk = 0; blk < B_NBLOCKS && ok; ++blk) {
+      ok = b->m_perm[blk].alloc_host((size_t)b->wave.n_tiles_max * 16) && b->m_tile_slot[blk].alloc_host(b->wave.n_tiles_max);
+      b->m_perm[blk].d = b->wave.d_perm[blk];
+      b->m_tile_slot[blk].d = b->wave.d_tile_slot[blk];
+    }
+  }
+  ok = ok && hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_in), sizeof(float) * B * B_IN_HOP, hipHostMallocDefault), "h_in") &&
+       hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_out), sizeof(float) * B * B_OUT_HOP, hipHostMallocDefault), "h_out") &&
+       hip_ok(hipEventCreate(&b->ev0), "ev0") && hip_ok(hipEventCreate(&b->ev1), "ev1");
+  b->ok = ok;
+  if (ok) {
+    for (int s = 0; s < B; ++s) sync_stream_arrays(b, s);
+    for (int blk = 0; blk < B_NBLOCKS; ++blk) rebuild_tiles(b, blk);
+  }
+  return b;
+}
+
+void BeatriceBatch_Destroy(BeatriceBatch* b) {
+  if (!b) return;
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  drop_graph(b);
+  b->phone.destroy(); b->pitch.destroy(); b->wave.destroy();
+  void* dev[] = {b->d_in, b->d_cb_raw, b->d_cbT, b->d_cnorm, b->d_add_raw, b->d_frm_raw, b->d_kv_raw};
+  for (void* p : dev) if (p) (void)hipFree(p);
+  b->m_cbT.release(); b->m_cnorm.release(); b->m_vqk.release(); b->m_min_q.release(); b->m_max_q.release();
+  b->m_add_idx.release(); b->m_frm_idx.release(); b->m_params.release();
+  for (int blk = 0; blk < B_NBLOCKS; ++blk) { b->m_perm[blk].release(); b->m_tile_slot[blk].release(); }
+  if (b->h_in) (void)hipHostFree(b->h_in);
+  if (b->h_out) (void)hipHostFree(b->h_out);
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->owns_stream && b->stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+}
+
+int BeatriceBatch_IsHealthy(const BeatriceBatch* b) { return b && b->ok ? 1 : 0; }
+int BeatriceBatch_NumStreams(const BeatriceBatch* b) { return b ? b->B : 0; }
+
+// ---- speaker tables -----------------------------------------------------------------------------
+static bool project_speakers(BeatriceBatch* b, int first, int count) {
+  hipStream_t s = b->stream;
+  const EmbedWeights& w = b->embed_m->w;
+  codebook_prepare(b->d_cb_raw + (size_t)first * B_CODEBOOK * B_PHONE_CH, count,
+                   b->d_cbT + (size_t)first * B_PHONE_CH * B_CODEBOOK, b->d_cnorm + (size_t)first * B_CODEBOOK, s);
+  embed_project_rows(w.add_w, w.add_b, b->d_add_raw + (size_t)first * B_HID, b->wave.d_add_tab + (size_t)first * B_HID, count, s);
+  for (int blk = 0; blk < B_NBLOCKS; ++blk)
+    embed_project_kv(w, blk, b->d_kv_raw + (size_t)first * B_KV_LEN * B_KV_CH, count,
+                     b->wave.d_kt[blk] + (size_t)first * B_HID * B_KV_LEN, b->wave.d_v[blk] + (size_t)first * B_KV_LEN * B_HID, s);
+  return hip_ok(hipStreamSynchronize(s), "project speakers");
+}
+
+int BeatriceBatch_SetSpeakerTables(BeatriceBatch* b, int n, const float* codebooks, const float* additive, const float* formant,
+                                   const float* kv) {
+  if (!b || !b->ok) return -2;
+  if (n < 1 || n > b->max_speakers || !codebooks || !additive || !formant || !kv) return -1;
+  bool ok = hip_ok(hipStreamSynchronize(b->stream), "sync") &&
+            hip_ok(hipMemcpy(b->d_cb_raw, codebooks, sizeof(float) * n * B_CODEBOOK * B_PHONE_CH, hipMemcpyHostToDevice), "cb") &&
+            hip_ok(hipMemcpy(b->d_add_raw, additive, sizeof(float) * n * B_HID, hipMemcpyHostToDevice), "add") &&
+            hip_ok(hipMemcpy(b->d_frm_raw, formant, sizeof(float) * 9 * B_HID, hipMemcpyHostToDevice), "frm") &&
+            hip_ok(hipMemcpy(b->d_kv_raw, kv, sizeof(float) * n * B_KV_LEN * B_KV_CH, hipMemcpyHostToDevice), "kv");
+  if (!ok) return -2;
+  b->n_speakers = n;
+  const EmbedWeights& w = b->embed_m->w;
+  embed_project_rows(w.frm_w, w.frm_b, b->d_frm_raw, b->wave.d_frm_tab, 9, b->stream);
+  return project_speakers(b, 0, n) ? 0 : -2;
+}
+
+int BeatriceBatch_UpdateSpeaker(BeatriceBatch* b, int spk, const float* codebook, const float* additive, const float* kv) {
+  if (!b || !b->ok) return -2;
+  if (spk < 0 || spk >= b->max_speakers) return -1;
+  bool ok = hip_ok(hipStreamSynchronize(b->stream), "sync");
+  if (codebook) ok = ok && hip_ok(hipMemcpy(b->d_cb_raw + (size_t)spk * B_CODEBOOK * B_PHONE_CH, codebook, sizeof(float) * B_CODEBOOK * B_PHONE_CH, hipMemcpyHostToDevice), "cb1");
+  if (additive) ok = ok && hip_ok(hipMemcpy(b->d_add_raw + (size_t)spk * B_HID, additive, sizeof(float) * B_HID, hipMemcpyHostToDevice), "add1");
+  if (kv) ok = ok && hip_ok(hipMemcpy(b->d_kv_raw + (size_t)spk * B_KV_LEN * B_KV_CH, kv, sizeof(float) * B_KV_LEN * B_KV_CH, hipMemcpyHostToDevice), "kv1");
+  if (!ok) return -2;
+  if (spk >= b->n_speakers) b->n_speakers = spk + 1;
+  return project_speakers(b, spk, 1) ? 0 : -2;
+}
+
+// ---- per-stream settings (reference ProcessorCore2 setters) ------------------------------------
+// processor_core_2.cc:431-466: codebook + additive switch at once, K/V re-registered and installed
+// one block per following hop.
+int BeatriceBatch_SetTargetSpeaker(BeatriceBatch* b, int stream, int speaker) {
+  if (!b || !b->ok) return -2;
+  if (speaker < 0 || speaker >= b->max_speakers) return -1;
+  const int r = for_streams(b, stream, [&](StreamCfg& c) {
+    c.target_speaker = speaker; c.codebook_speaker = speaker; c.additive_speaker = speaker; c.kv_set_count = 0;
+  });
+  if (r == 0) { b->pending_kv = 0; for (const StreamCfg& c : b->cfg) if (c.kv_set_count < B_NBLOCKS) ++b->pending_kv; }
+  return r;
+}
+// processor_core_2.cc:270,414: `while (SetKeyValueSpeakerEmbedding());`
+int BeatriceBatch_FlushSpeaker(BeatriceBatch* b, int stream) {
+  const int r = for_streams(b, stream, [&](StreamCfg& c) {
+    for (; c.kv_set_count < B_NBLOCKS; ++c.kv_set_count) c.kv_slot[c.kv_set_count] = c.target_speaker;
+  });
+  if (r == 0) {
+    b->pending_kv = 0;
+    for (const StreamCfg& c : b->cfg) if (c.kv_set_count < B_NBLOCKS) ++b->pending_kv;
+    for (int blk = 0; blk < B_NBLOCKS; ++blk) rebuild_tiles(b, blk);
+  }
+  return r;
+}
+// processor_core_2.cc:468-481
+int BeatriceBatch_SetFormantShift(BeatriceBatch* b, int stream, double shift) {
+  shift = std::min(std::max(shift, -2.0), 2.0);
+  const int idx = (int)std::round(shift * 2.0 + 4.0);
+  return for_streams(b, stream, [&](StreamCfg& c) { c.formant_index = idx; });
+}
+// processor_core_2.cc:585-590
+int BeatriceBatch_SetVQNumNeighbors(BeatriceBatch* b, int stream, int k) {
+  k = std::min(std::max(k, 0), 8);
+  return for_streams(b, stream, [&](StreamCfg& c) { c.vq_k = k; });
+}
+int BeatriceBatch_SetMinSourcePitch(BeatriceBatch* b, int stream, double note) {
+  const int q = midi_to_bin(note);
+  return for_streams(b, stream, [&](StreamCfg& c) { c.min_q = q; });
+}
+int BeatriceBatch_SetMaxSourcePitch(BeatriceBatch* b, int stream, double note) {
+  const int q = midi_to_bin(note);
+  return for_streams(b, stream, [&](StreamCfg& c) { c.max_q = q; });
+}
+// processor_core_2.cc:483-486, 534-559
+int BeatriceBatch_SetPitchShift(BeatriceBatch* b, int stream, double v) {
+  v = std::min(std::max(v, -24.0), 24.0);
+  return for_streams(b, stream, [&](StreamCfg& c) { c.pitch.pitch_shift = v; });
+}
+int BeatriceBatch_SetAverageSourcePitch(BeatriceBatch* b, int stream, double v) {
+  v = std::min(std::max(v, 0.0), 128.0);
+  return for_streams(b, stream, [&](StreamCfg& c) { c.pitch.average_source_pitch = v; });
+}
+int BeatriceBatch_SetIntonationIntensity(BeatriceBatch* b, int stream, double v) {
+  return for_streams(b, stream, [&](StreamCfg& c) { c.pitch.intonation_intensity = v; });
+}
+int BeatriceBatch_SetPitchCorrection(BeatriceBatch* b, int stream, double v) {
+  v = std::min(std::max(v, 0.0), 1.0);
+  return for_streams(b, stream, [&](StreamCfg& c) { c.pitch.pitch_correction = v; });
+}
+int BeatriceBatch_SetPitchCorrectionType(BeatriceBatch* b, int stream, int type) {
+  if (type < 0 || type > 1) return -1;
+  return for_streams(b, stream, [&](StreamCfg& c) { c.pitch.pitch_correction_type = type; });
+}
+// processor_core_2.cc:258-291: fresh contexts, then speaker (all four blocks at once) and the other
+// settings re-applied -- here the settings persist per stream, only the state is zeroed.
+int BeatriceBatch_ResetStream(BeatriceBatch* b, int stream) {
+  if (!b || !b->ok) return -2;
+  if (stream < -1 || stream >= b->B) return -1;
+  const int lo = stream < 0 ? 0 : stream, hi = stream < 0 ? b->B : stream + 1;
+  bool ok = true;
+  for (int s = lo; s < hi && ok; ++s) {
+    ok = b->phone.arena.zero_stream(s, b->stream) && b->pitch.arena.zero_stream(s, b->stream) &&
+         b->wave.arena.zero_stream(s, b->stream) &&
+         hip_ok(hipMemsetAsync(b->pitch.d_prev_q + s, 0, sizeof(int), b->stream), "prev_q");
+  }
+  if (!ok) return -2;
+  return BeatriceBatch_FlushSpeaker(b, stream);
+}
+
+// ---- per-hop ------------------------------------------------------------------------------------
+int BeatriceBatch_ConvertFramesDevice(BeatriceBatch* b, const float* d_in, float* d_out) {
+  if (!b || !b->ok) return -2;
+  return step_device(b, d_in, d_out) ? 0 : -2;
+}
+int BeatriceBatch_ConvertFrames(BeatriceBatch* b, const float* in, float* out) {
+  if (!b || !b->ok) { if (b && out) std::memset(out, 0, sizeof(float) * b->B * B_OUT_HOP); return -2; }
+  std::memcpy(b->h_in, in, sizeof(float) * b->B * B_IN_HOP);
+  bool ok = hip_ok(hipMemcpyAsync(b->d_in, b->h_in, sizeof(float) * b->B * B_IN_HOP, hipMemcpyHostToDevice, b->stream), "in");
+  ok = ok && step_device(b, nullptr, nullptr);
+  ok = ok && hip_ok(hipMemcpyAsync(b->h_out, b->wave.d_out, sizeof(float) * b->B * B_OUT_HOP, hipMemcpyDeviceToHost, b->stream), "out");
+  ok = hip_ok(hipStreamSynchronize(b->stream), "sync") && ok;
+  b->inflight = false;
+  if (ok) std::memcpy(out, b->h_out, sizeof(float) * b->B * B_OUT_HOP);
+  else std::memset(out, 0, sizeof(float) * b->B * B_OUT_HOP);
+  return ok ? 0 : -2;
+}
+int BeatriceBatch_Synchronize(BeatriceBatch* b) {
+  if (!b || !b->ok) return -2;
+  b->inflight = false;
+  return hip_ok(hipStreamSynchronize(b->stream), "sync") ? 0 : -2;
+}
+
+int BeatriceBatch_SetStream(BeatriceBatch* b, void* hip_stream) {
+  if (!b || !b->ok) return -2;
+  (void)hipStreamSynchronize(b->stream);
+  drop_graph(b);
+  if (b->owns_stream) (void)hipStreamDestroy(b->stream);
+  b->stream = static_cast<hipStream_t>(hip_stream);
+  b->owns_stream = false;
+  return 0;
+}
+void* BeatriceBatch_GetStream(const BeatriceBatch* b) { return b ? b->stream : nullptr; }
+int BeatriceBatch_EnableGraph(BeatriceBatch* b, int enable) {
+  if (!b || !b->ok) return -2;
+  (void)hipStreamSynchronize(b->stream);
+  b->use_graph = enable != 0;
+  if (!b->use_graph) drop_graph(b);
+  return 0;
+}
+float* BeatriceBatch_DeviceInput(BeatriceBatch* b) { return b && b->ok ? b->d_in : nullptr; }
+float* BeatriceBatch_DeviceOutput(BeatriceBatch* b) { return b && b->ok ? b->wave.d_out : nullptr; }
+
+int BeatriceBatch_GetIntermediates(BeatriceBatch* b, float* phone, int* q_raw, int* q, float* feat) {
+  if (!b || !b->ok) return -2;
+  bool ok = hip_ok(hipStreamSynchronize(b->stream), "sync");
+  if (phone) ok = ok && hip_ok(hipMemcpy(phone, b->phone.d_phone, sizeof(float) * b->B * B_PHONE_CH, hipMemcpyDeviceToHost), "phone");
+  if (q_raw) ok = ok && hip_ok(hipMemcpy(q_raw, b->pitch.d_q_raw, sizeof(int) * b->B, hipMemcpyDeviceToHost), "q_raw");
+  if (q) ok = ok && hip_ok(hipMemcpy(q, b->pitch.d_q, sizeof(int) * b->B, hipMemcpyDeviceToHost), "q");
+  if (feat) ok = ok && hip_ok(hipMemcpy(feat, b->pitch.d_feat, sizeof(float) * b->B * 4, hipMemcpyDeviceToHost), "feat");
+  return ok ? 0 : -2;
+}
+
+namespace {
+struct KernelRow { std::string name; int launches = 0; double us = 0, flops = 0, bytes = 0; };
+struct ProfileHook : LaunchHook {
+  std::vector<KernelRow> rows;
+  int repeats = 1;
+  hipEvent_t e0, e1;
+  bool ok = true;
+  void on_launch(const LaunchInfo& info, hipStream_t stream, void (*thunk)(void*), void* ctx) override {
+    const int reps = std::strcmp(info.name, "hop_advance") == 0 ? 1 : repeats;  // the only non-idempotent launch
+    ok = ok && hip_ok(hipEventRecord(e0, stream), "p0");
+    for (int i = 0; i < reps; ++i) thunk(ctx);
+    float ms = 0.f;
+    ok = ok && hip_ok(hipEventRecord(e1, stream), "p1") && hip_ok(hipEventSynchronize(e1), "ps") &&
+         hip_ok(hipEventElapsedTime(&ms, e0, e1), "pe");
+    KernelRow* row = nullptr;
+    for (auto& r : rows) if (r.name == info.name) row = &r;
+    if (!row) { rows.push_back(KernelRow{info.name}); row = &rows.back(); }
+    row->launches += 1;
+    row->us += 1000.0 * ms / reps;
+    row->flops = info.flops;
+    row->bytes = info.bytes;
+  }
+};
+}  // namespace
+
+int BeatriceBatch_ProfileKernels(BeatriceBatch* b, int repeats, int max_entries, char* names, int* launches, double* mean_us,
+                                 double* flops, double* bytes) {
+  if (!b || !b->ok) return -2;
+  if (repeats < 1 || max_entries < 1 || !names || !launches || !mean_us || !flops || !bytes) return -1;
+  if (!hip_ok(hipStreamSynchronize(b->stream), "sync")) return -2;
+  advance_kv(b);
+  if (!push_settings(b)) return -2;
+  ProfileHook hook;
+  hook.repeats = repeats;
+  hook.e0 = b->ev0;
+  hook.e1 = b->ev1;
+  launch_hook() = &hook;
+  enqueue_chain(b);
+  launch_hook() = nullptr;
+  if (!hook.ok || !hip_ok(hipStreamSynchronize(b->stream), "sync")) return -2;
+  const int n = std::min<int>((int)hook.rows.size(), max_entries);
+  for (int i = 0; i < n; ++i) {
+    std::memset(names + 64 * i, 0, 64);
+    std::strncpy(names + 64 * i, hook.rows[i].name.c_str(), 63);
+    launches[i] = hook.rows[i].launches;
+    mean_us[i] = hook.rows[i].us / hook.rows[i].launches;
+    flops[i] = hook.rows[i].flops;
+    bytes[i] = hook.rows[i].bytes;
+  }
+  return n;
+}
+
+int BeatriceBatch_TimeSteps(BeatriceBatch* b, int steps, float* ms) {
+  if (!b || !b->ok || steps < 1 || !ms) return b && b->ok ? -1 : -2;
+  bool ok = hip_ok(hipEventRecord(b->ev0, b->stream), "ev0");
+  for (int i = 0; i < steps && ok; ++i) ok = step_device(b, nullptr, nullptr);
+  ok = ok && hip_ok(hipEventRecord(b->ev1, b->stream), "ev1") && hip_ok(hipEventSynchronize(b->ev1), "evsync") &&
+       hip_ok(hipEventElapsedTime(ms, b->ev0, b->ev1), "elapsed");
+  return ok ? 0 : -2;
+}
+
+}  // extern "C"

@@ -15,6 +15,11 @@ bool hip_ok(hipError_t e, const char* what) {
   return false;
 }
 
+LaunchHook*& launch_hook() {
+  static thread_local LaunchHook* hook = nullptr;
+  return hook;
+}
+
 bool DeviceBlob::upload(const float* host, size_t n) {
   release();
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), n * sizeof(float)));

@@ -21,6 +21,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "engine.h"
 #include "ring.h"
 #include "spec_math.hip.h"
 
@@ -207,12 +208,16 @@ __global__ __launch_bounds__(TC::NTHR) void conv_gemm_kernel(const ConvArgs a) {
 }
 
 template <class L, class TC>
-static inline void launch_conv(const ConvArgs& a, int n_group_tiles, hipStream_t stream) {
+static inline void launch_conv(const char* name, const ConvArgs& a, int n_group_tiles, hipStream_t stream) {
   dim3 grid;
   if (L::GROUPED) grid.x = n_group_tiles;
   else grid.x = (a.B * L::T + TC::MT - 1) / TC::MT;
   grid.y = L::NOUT / TC::NT;
-  hipLaunchKernelGGL((conv_gemm_kernel<L, TC>), grid, dim3(TC::NTHR), 0, stream, a);
+  // algorithmic work of this launch: 2*M*K*N flops; bytes = weights once + A rows once + output once
+  const double M = (double)a.B * L::T, K = (double)L::KSZ * L::CIN, N = L::NOUT;
+  const double in_rows = (double)a.B * (L::T * L::STRIDE + (L::KSZ - 1) * L::DIL - (L::STRIDE - 1));
+  const bhip::LaunchInfo info{name, 2.0 * M * K * N, 4.0 * (K * N + in_rows * L::CIN + M * N * (L::RES ? 2 : 1))};
+  bhip::launch_site(info, stream, [&] { hipLaunchKernelGGL((conv_gemm_kernel<L, TC>), grid, dim3(TC::NTHR), 0, stream, a); });
 }
 
 // ---- launch helpers shared by the modules ------------------------------------------------------
@@ -220,9 +225,9 @@ using TS = TileCfg<1, 1, 1, 4>;  // 16 x 64 (rows x cols): layers with M <= 32 r
 using TL = TileCfg<2, 2, 2, 2>;  // 64 x 64
 
 template <class L>
-static inline void launch_auto(const ConvArgs& a, hipStream_t s) {
-  if (a.B * L::T <= 32) launch_conv<L, TS>(a, 0, s);
-  else launch_conv<L, TL>(a, 0, s);
+static inline void launch_auto(const char* name, const ConvArgs& a, hipStream_t s) {
+  if (a.B * L::T <= 32) launch_conv<L, TS>(name, a, 0, s);
+  else launch_conv<L, TL>(name, a, 0, s);
 }
 
 static inline ConvArgs conv_args(const Ring& in, const Ring& out, const float* w, const float* b, const int* hop, int B) {

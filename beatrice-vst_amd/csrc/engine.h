@@ -25,6 +25,22 @@ bool hip_ok(hipError_t e, const char* what);  // logs once per site when BEATRIC
     if (!::bhip::hip_ok((expr), #expr)) return false; \
   } while (0)
 
+// ---- launch hook: every kernel launch of the per-hop chain goes through launch_site(), so a
+// profiler (batch.hip, BeatriceBatch_ProfileKernels) can bracket each launch with HIP events and
+// attach the launch's algorithmic FLOPs / bytes.  No hook = plain launch.
+struct LaunchInfo { const char* name; double flops; double bytes; };
+struct LaunchHook {
+  virtual ~LaunchHook() = default;
+  virtual void on_launch(const LaunchInfo& info, hipStream_t stream, void (*thunk)(void*), void* ctx) = 0;
+};
+LaunchHook*& launch_hook();  // thread-local
+template <class F>
+inline void launch_site(const LaunchInfo& info, hipStream_t stream, F&& fn) {
+  LaunchHook* h = launch_hook();
+  if (!h) { fn(); return; }
+  h->on_launch(info, stream, [](void* c) { (*static_cast<F*>(c))(); }, &fn);
+}
+
 // ---- device blob -----------------------------------------------------------------------------
 struct DeviceBlob {
   float* d = nullptr;

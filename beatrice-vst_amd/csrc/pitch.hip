@@ -51,22 +51,28 @@ using P23 = Layer<128, 128, 3, 1, 1, 1, PRE_NONE, ACT_GELU, EPI_BIAS, true>;
 using PGATE = Layer<128, 384, 1, 1, 1, 1, PRE_NONE, ACT_NONE, EPI_BIAS, false>;
 using POUT = Layer<128, B_PITCH_BINS, 1, 1, 1, 1, PRE_NONE, ACT_NONE, EPI_BIAS, false>;
 
+#define MISC_LAUNCH(NAME, FLOPS, BYTES, KERNEL, GRID, BLOCK, ...)                              \
+  launch_site(LaunchInfo{NAME, (double)(FLOPS), (double)(BYTES)}, st,                          \
+              [&] { hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, st, __VA_ARGS__); })
+
 void pitch_forward(const PitchWeights& w, const PitchState& s, hipStream_t st) {
   const int B = s.B;
-  hipLaunchKernelGGL(pitch_fft_kernel, dim3(B), dim3(256), 0, st, s.d_in, s.audio, s.spec, w.window, w.twiddle, s.d_hop);
-  launch_auto<P1>(conv_args(s.spec, s.p[0], w.p_w[0], w.p_b[0], s.d_hop, B), st);
-  launch_auto<P23>(conv_args(s.p[0], s.p[1], w.p_w[1], w.p_b[1], s.d_hop, B), st);
-  launch_auto<P23>(conv_args(s.p[1], s.p[2], w.p_w[2], w.p_b[2], s.d_hop, B), st);
-  launch_auto<PGATE>(conv_args(s.p[2], s.gi, w.gru_wih, w.gru_bih, s.d_hop, B), st);
+  MISC_LAUNCH("pitch.fft", B * (10.0 * 512 * 10 + 1024 * 2 + 512 * 30), 4.0 * B * (1024 + 160 + 512), pitch_fft_kernel, dim3(B),
+              dim3(256), s.d_in, s.audio, s.spec, w.window, w.twiddle, s.d_hop);
+  launch_auto<P1>("pitch.p1", conv_args(s.spec, s.p[0], w.p_w[0], w.p_b[0], s.d_hop, B), st);
+  launch_auto<P23>("pitch.p23", conv_args(s.p[0], s.p[1], w.p_w[1], w.p_b[1], s.d_hop, B), st);
+  launch_auto<P23>("pitch.p23", conv_args(s.p[1], s.p[2], w.p_w[2], w.p_b[2], s.d_hop, B), st);
+  launch_auto<PGATE>("pitch.gru_gi", conv_args(s.p[2], s.gi, w.gru_wih, w.gru_bih, s.d_hop, B), st);
   ConvArgs gh = conv_args(s.h, s.gh, w.gru_whh, w.gru_bhh, s.d_hop, B);
   gh.rel_shift = -1;
-  launch_auto<PGATE>(gh, st);
-  hipLaunchKernelGGL(gru_gate_kernel, dim3((B * 128 + 255) / 256), dim3(256), 0, st, s.gi.base, s.gh.base, s.h, 128, B, s.d_hop);
-  launch_auto<POUT>(conv_args(s.h, s.logits, w.out_w, w.out_b, s.d_hop, B), st);
+  launch_auto<PGATE>("pitch.gru_gh", gh, st);
+  MISC_LAUNCH("pitch.gru_gate", 30.0 * B * 128, 4.0 * B * 128 * 8, gru_gate_kernel, dim3((B * 128 + 255) / 256), dim3(256),
+              s.gi.base, s.gh.base, s.h, 128, B, s.d_hop);
+  launch_auto<POUT>("pitch.out", conv_args(s.h, s.logits, w.out_w, w.out_b, s.d_hop, B), st);
   PitchHeadArgs a{s.logits.base, s.h, s.d_in, w.voi_w, w.voi_b, s.d_min_q, s.d_max_q, s.d_prev_q,
                   s.d_q_raw, s.d_q, s.d_feat, s.d_params, s.d_hop};
-  hipLaunchKernelGGL(pitch_head_kernel, dim3(B), dim3(64), 0, st, a);
-  hipLaunchKernelGGL(hop_advance_kernel, dim3(1), dim3(1), 0, st, s.d_hop);
+  MISC_LAUNCH("pitch.head", 25.0 * B * 448, 4.0 * B * (448 + 160 + 128 + 8), pitch_head_kernel, dim3(B), dim3(64), a);
+  MISC_LAUNCH("hop_advance", 0, 4, hop_advance_kernel, dim3(1), dim3(1), s.d_hop);
 }
 
 }  // namespace bhip

@@ -93,19 +93,23 @@ using T32 = TileCfg<2, 2, 4, 1>;    // 128 x 32
 using T48 = TileCfg<1, 3, 4, 1>;    // 64 x 48
 using T16 = TileCfg<4, 1, 4, 1>;    // 256 x 16
 
+#define MISC_LAUNCH(NAME, FLOPS, BYTES, KERNEL, GRID, BLOCK, ...)                              \
+  launch_site(LaunchInfo{NAME, (double)(FLOPS), (double)(BYTES)}, st,                          \
+              [&] { hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, st, __VA_ARGS__); })
+
 template <int D>
 static void launch_c1(const WaveWeights& w, const WaveState& s, int blk, hipStream_t st) {
-  launch_auto<C1<D>>(conv_args(s.x[blk], s.h1, w.c1_w[blk], w.c1_b[blk], s.d_hop, s.B), st);
+  launch_auto<C1<D>>("wave.blk.c1", conv_args(s.x[blk], s.h1, w.c1_w[blk], w.c1_b[blk], s.d_hop, s.B), st);
 }
 
 void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t st) {
   const int B = s.B;
   CondArgs ca{s.d_q, s.d_feat, w.pitch_emb, w.feat_w, s.d_add_tab, s.d_add_idx, s.d_frm_tab, s.d_frm_idx, s.e.base};
-  hipLaunchKernelGGL(wave_cond_kernel, dim3(B), dim3(256), 0, st, ca);
+  MISC_LAUNCH("wave.cond", 11.0 * B * 256, 4.0 * B * 256 * 4, wave_cond_kernel, dim3(B), dim3(256), ca);
   const Ring phone_in{s.d_phone, B_PHONE_CH, 1, 1};
   ConvArgs a = conv_args(phone_in, s.x[0], w.inp_w, w.inp_b, s.d_hop, B);
   a.res = s.e;
-  launch_auto<INP>(a, st);
+  launch_auto<INP>("wave.inp", a, st);
   for (int blk = 0; blk < B_NBLOCKS; ++blk) {
     switch (blk) {
       case 0: launch_c1<1>(w, s, blk, st); break;
@@ -115,36 +119,37 @@ void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t st) {
     }
     a = conv_args(s.h1, s.xa, w.c2_w[blk], w.c2_b[blk], s.d_hop, B);
     a.res = s.x[blk];
-    launch_auto<C2>(a, st);
-    launch_auto<QL>(conv_args(s.xa, s.q, w.q_w[blk], w.q_b[blk], s.d_hop, B), st);
+    launch_auto<C2>("wave.blk.c2", a, st);
+    launch_auto<QL>("wave.blk.q", conv_args(s.xa, s.q, w.q_w[blk], w.q_b[blk], s.d_hop, B), st);
     a = conv_args(s.q, s.sc, s.d_kt[blk], nullptr, s.d_hop, B);
     a.scale = 0.0625f; a.perm = s.d_perm[blk]; a.tile_slot = s.d_tile_slot[blk];
     a.w_slot_stride = (size_t)B_HID * B_KV_LEN;
-    launch_conv<SCORE, TG>(a, s.n_tiles_max, st);
-    hipLaunchKernelGGL(attn_softmax_kernel, dim3(B), dim3(64), 0, st, s.sc.base, s.d_inv, B);
+    launch_conv<SCORE, TG>("wave.blk.attn_qk", a, s.n_tiles_max, st);
+    MISC_LAUNCH("wave.blk.softmax", 25.0 * B * 384, 8.0 * B * 384, attn_softmax_kernel, dim3(B), dim3(64), s.sc.base, s.d_inv, B);
     a = conv_args(s.sc, s.o, s.d_v[blk], nullptr, s.d_hop, B);
     a.rowscale = s.d_inv; a.perm = s.d_perm[blk]; a.tile_slot = s.d_tile_slot[blk];
     a.w_slot_stride = (size_t)B_KV_LEN * B_HID;
-    launch_conv<PV, TG>(a, s.n_tiles_max, st);
+    launch_conv<PV, TG>("wave.blk.attn_pv", a, s.n_tiles_max, st);
     a = conv_args(s.o, s.x[blk + 1], w.o_w[blk], w.o_b[blk], s.d_hop, B);
     a.res = s.xa;
-    launch_auto<C2>(a, st);
+    launch_auto<C2>("wave.blk.o", a, st);
   }
   // upsampler: x[4] -> 5 -> 20 -> 80 -> 240 frames
-  launch_auto<UP<256, 128, 5, 1>>(conv_args(s.x[4], s.ya[0], w.up_w[0], w.up_b[0], s.d_hop, B), st);
-  launch_auto<RES<128, 1, 5>>(conv_args(s.ya[0], s.yb[0], w.ra_w[0], w.ra_b[0], s.d_hop, B), st);
-  launch_auto<RES<128, 3, 5>>(conv_args(s.yb[0], s.yc[0], w.rb_w[0], w.rb_b[0], s.d_hop, B), st);
-  launch_auto<UP<128, 64, 4, 5>>(conv_args(s.yc[0], s.ya[1], w.up_w[1], w.up_b[1], s.d_hop, B), st);
-  launch_auto<RES<64, 1, 20>>(conv_args(s.ya[1], s.yb[1], w.ra_w[1], w.ra_b[1], s.d_hop, B), st);
-  launch_auto<RES<64, 3, 20>>(conv_args(s.yb[1], s.yc[1], w.rb_w[1], w.rb_b[1], s.d_hop, B), st);
-  launch_auto<UP<64, 32, 4, 20>>(conv_args(s.yc[1], s.ya[2], w.up_w[2], w.up_b[2], s.d_hop, B), st);
-  launch_conv<RES<32, 1, 80>, T32>(conv_args(s.ya[2], s.yb[2], w.ra_w[2], w.ra_b[2], s.d_hop, B), 0, st);
-  launch_conv<RES<32, 3, 80>, T32>(conv_args(s.yb[2], s.yc[2], w.rb_w[2], w.rb_b[2], s.d_hop, B), 0, st);
-  launch_conv<UP<32, 16, 3, 80>, T48>(conv_args(s.yc[2], s.ya[3], w.up_w[3], w.up_b[3], s.d_hop, B), 0, st);
-  launch_conv<RES<16, 1, 240>, T16>(conv_args(s.ya[3], s.yb[3], w.ra_w[3], w.ra_b[3], s.d_hop, B), 0, st);
-  launch_conv<RES<16, 3, 240>, T16>(conv_args(s.yb[3], s.yc[3], w.rb_w[3], w.rb_b[3], s.d_hop, B), 0, st);
-  hipLaunchKernelGGL(wave_final_kernel, dim3(B), dim3(256), 0, st, s.yc[3], w.fin_w, w.fin_b, s.d_out, s.d_hop);
-  hipLaunchKernelGGL(hop_advance_kernel, dim3(1), dim3(1), 0, st, s.d_hop);
+  launch_auto<UP<256, 128, 5, 1>>("wave.up1", conv_args(s.x[4], s.ya[0], w.up_w[0], w.up_b[0], s.d_hop, B), st);
+  launch_auto<RES<128, 1, 5>>("wave.res1a", conv_args(s.ya[0], s.yb[0], w.ra_w[0], w.ra_b[0], s.d_hop, B), st);
+  launch_auto<RES<128, 3, 5>>("wave.res1b", conv_args(s.yb[0], s.yc[0], w.rb_w[0], w.rb_b[0], s.d_hop, B), st);
+  launch_auto<UP<128, 64, 4, 5>>("wave.up2", conv_args(s.yc[0], s.ya[1], w.up_w[1], w.up_b[1], s.d_hop, B), st);
+  launch_auto<RES<64, 1, 20>>("wave.res2a", conv_args(s.ya[1], s.yb[1], w.ra_w[1], w.ra_b[1], s.d_hop, B), st);
+  launch_auto<RES<64, 3, 20>>("wave.res2b", conv_args(s.yb[1], s.yc[1], w.rb_w[1], w.rb_b[1], s.d_hop, B), st);
+  launch_auto<UP<64, 32, 4, 20>>("wave.up3", conv_args(s.yc[1], s.ya[2], w.up_w[2], w.up_b[2], s.d_hop, B), st);
+  launch_conv<RES<32, 1, 80>, T32>("wave.res3a", conv_args(s.ya[2], s.yb[2], w.ra_w[2], w.ra_b[2], s.d_hop, B), 0, st);
+  launch_conv<RES<32, 3, 80>, T32>("wave.res3b", conv_args(s.yb[2], s.yc[2], w.rb_w[2], w.rb_b[2], s.d_hop, B), 0, st);
+  launch_conv<UP<32, 16, 3, 80>, T48>("wave.up4", conv_args(s.yc[2], s.ya[3], w.up_w[3], w.up_b[3], s.d_hop, B), 0, st);
+  launch_conv<RES<16, 1, 240>, T16>("wave.res4a", conv_args(s.ya[3], s.yb[3], w.ra_w[3], w.ra_b[3], s.d_hop, B), 0, st);
+  launch_conv<RES<16, 3, 240>, T16>("wave.res4b", conv_args(s.yb[3], s.yc[3], w.rb_w[3], w.rb_b[3], s.d_hop, B), 0, st);
+  MISC_LAUNCH("wave.final", 2.0 * B * 240 * 112, 4.0 * B * (246 * 16 + 240), wave_final_kernel, dim3(B), dim3(256), s.yc[3],
+              w.fin_w, w.fin_b, s.d_out, s.d_hop);
+  MISC_LAUNCH("hop_advance", 0, 4, hop_advance_kernel, dim3(1), dim3(1), s.d_hop);
 }
 
 }  // namespace bhip

@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py -- headline measurement for the Beatrice 2 per-hop voice-conversion path on MI355X.
+
+One "step" = one 10 ms hop (160 samples @16 kHz in -> 240 samples @24 kHz out) for EVERY stream of
+the batch: ExtractPhone + EstimatePitch + pitch transform + GenerateWaveform
+(reference src/common/processor_core_2.cc:181-255), through the batched C-ABI
+(include/beatrice_batch.h).  Workload = BASELINE.json configs[2] ("batch 256 concurrent streams,
+1 speaker, 1xMI355X") per GPU; with --gpus N each rank runs its own 256 streams (weak scaling, no
+collective inside a hop; weights are broadcast from rank 0 over RCCL at load).  Inputs are resident
+in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      -- dominant kernel of the chain: algorithmic FLOP/s (or B/s) vs gfx950 peak, from
+                   HIP-event timing on the library's own stream (BeatriceBatch_ProfileKernels)
+  cpu_baseline  -- the CPU oracle (oracle/, a port of the frozen spec -- NOT the proprietary
+                   beatricelib, which has no Linux build) timed on this box's host cores.
+"""
+import argparse
+import ctypes
+import importlib.util
+import json
+import os
+import sys
+import tempfile
+import threading
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense f32 MFMA
+PEAK_HBM_GBS = 8000.0
+
+
+def load_pkg():
+    name = "beatrice_vst_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REPO, "beatrice-vst_amd", "__init__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def broadcast_bytes(data, rank, world, dist, torch):
+    """rank 0's bytes -> every rank, as one RCCL broadcast of a uint8 device tensor over xGMI."""
+    if world == 1:
+        return data
+    n = torch.tensor([len(data) if rank == 0 else 0], dtype=torch.int64, device="cuda")
+    dist.broadcast(n, 0)
+    if rank == 0:
+        buf = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    else:
+        buf = torch.empty(int(n.item()), dtype=torch.uint8, device="cuda")
+    dist.broadcast(buf, 0)
+    return buf.cpu().numpy().tobytes()
+
+
+def cpu_baseline(bv, model_dir, seconds):
+    """Oracle through the same per-hop protocol: 1 stream on 1 core, then 1 stream per core."""
+    oracle = bv.Abi(os.path.join(REPO, "oracle", "libbeatrice_oracle.so"))
+    m = bv.Models(oracle, model_dir)
+
+    def run(n_hops, seed, out):
+        s = bv.Stream1(m, speaker=0)
+        x = bv.synth_audio(160 * 64, seed=seed)
+        t0 = time.perf_counter()
+        for i in range(n_hops):
+            s.hop(x[(i % 64) * 160:(i % 64 + 1) * 160])
+        out.append(time.perf_counter() - t0)
+        s.close()
+
+    probe = []
+    run(50, 0, probe)
+    hops = max(100, int(seconds * 50 / probe[0]))
+    one = []
+    run(hops, 1, one)
+    single = hops / one[0]
+    cores = os.cpu_count() or 1
+    hops_mt = max(50, hops // 2)
+    outs, threads = [], []
+    t0 = time.perf_counter()
+    for c in range(cores):
+        th = threading.Thread(target=run, args=(hops_mt, 10 + c, outs))
+        th.start()
+        threads.append(th)
+    for th in threads:
+        th.join()
+    wall = time.perf_counter() - t0
+    m.close()
+    return {"value": round(single, 1), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d hops of 1 synthetic stream through the 1-stream C-ABI (oracle/libbeatrice_oracle.so, "
+                      "gcc -O3 -mavx2 -mfma); the proprietary reference beatricelib has no Linux build" % hops,
+            "all_cores": {"value": round(cores * hops_mt / wall, 1), "cores": cores,
+                          "sample": "%d hops x %d streams, one thread per core" % (hops_mt, cores)}}
+
+
+def latency_b1(bv, product, model_dir, hops=400):
+    """BASELINE.json configs[1]: 1 stream, 1 speaker, hop-synchronous 1-stream C-ABI."""
+    m = bv.Models(product, model_dir)
+    s = bv.Stream1(m, speaker=0)
+    x = bv.synth_audio(160 * 64, seed=5)
+    lat = []
+    for i in range(hops + 50):
+        t0 = time.perf_counter()
+        s.hop(x[(i % 64) * 160:(i % 64 + 1) * 160])
+        lat.append(time.perf_counter() - t0)
+    s.close()
+    m.close()
+    lat = np.array(lat[50:]) * 1e6
+    return {"workload": "configs[1]: 1 stream through ExtractPhone1/EstimatePitch1/GenerateWaveform1",
+            "p50_us": round(float(np.percentile(lat, 50)), 1), "p99_us": round(float(np.percentile(lat, 99)), 1),
+            "frames_per_s": round(1e6 / float(lat.mean()), 1), "x_realtime": round(1e4 / float(lat.mean()), 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
+    ap.add_argument("--speakers", type=int, default=1)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / B=1 latency / kernel profile")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    bv = load_pkg()
+    product = bv.bind_batch(bv.load_product())
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import make_model
+
+    B = a.streams
+    tmp = tempfile.TemporaryDirectory()
+    model_dir = tmp.name
+    files = ["phone_extractor.bin", "pitch_estimator.bin", "waveform_generator.bin", "embedding_setter.bin",
+             "speaker_embeddings.bin"]
+    if rank == 0:
+        make_model.make_model(model_dir, n_speakers=a.speakers)
+    blobs = {}
+    for f in files:
+        data = open(os.path.join(model_dir, f), "rb").read() if rank == 0 else b""
+        blobs[f] = broadcast_bytes(data, rank, world, dist, torch)
+    if rank != 0:  # the speaker file is parsed by the file reader of the C-ABI
+        with open(os.path.join(model_dir, "speaker_embeddings.bin"), "wb") as fh:
+            fh.write(blobs["speaker_embeddings.bin"])
+
+    class MemModels:  # model objects loaded from the broadcast bytes
+        pass
+    m = MemModels()
+    m.abi = product
+    m.phone, m.pitch = product.CreatePhoneExtractor(), product.CreatePitchEstimator()
+    m.wave, m.embed = product.CreateWaveformGenerator(), product.CreateEmbeddingSetter()
+    for obj, fn, f in ((m.phone, product.BeatriceHip_LoadPhoneExtractorFromMemory, files[0]),
+                       (m.pitch, product.BeatriceHip_LoadPitchEstimatorFromMemory, files[1]),
+                       (m.wave, product.BeatriceHip_LoadWaveformGeneratorFromMemory, files[2]),
+                       (m.embed, product.BeatriceHip_LoadEmbeddingSetterFromMemory, files[3])):
+        err = fn(obj, blobs[f], len(blobs[f]))
+        if err:
+            raise SystemExit("load %s: Beatrice_ErrorCode %d" % (f, err))
+    m.tables = bv.SpeakerTables(product, model_dir)
+
+    batch = bv.Batch(m, B)
+    if a.no_graph:
+        product.BeatriceBatch_EnableGraph(batch.h, 0)
+    for s in range(B):  # streams spread over the speakers of the table
+        product.BeatriceBatch_SetTargetSpeaker(batch.h, s, s % a.speakers)
+    product.BeatriceBatch_FlushSpeaker(batch.h, -1)
+
+    # synthetic audio, resident on the device: 64 hops x B streams, cycled
+    n_cycle = 64
+    audio = np.stack([bv.synth_audio(160 * n_cycle, seed=rank * 100000 + s) for s in range(B)])
+    audio = np.ascontiguousarray(audio.reshape(B, n_cycle, 160).transpose(1, 0, 2))
+    d_audio = torch.from_numpy(audio).cuda()
+    d_out = torch.empty((B, 240), dtype=torch.float32, device="cuda")
+    base, hop_bytes = d_audio.data_ptr(), B * 160 * 4
+
+    def step(i):
+        rc = product.BeatriceBatch_ConvertFramesDevice(batch.h, base + (i % n_cycle) * hop_bytes, d_out.data_ptr())
+        if rc:
+            raise SystemExit("ConvertFramesDevice failed: %d" % rc)
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    out_rms = float(d_out.float().pow(2).mean().sqrt().item())
+
+    if rank == 0:
+        frames = world * B * a.steps
+        res = {
+            "metric": "audio frames/sec (24 kHz out, 10 ms hop)", "value": round(frames / elapsed, 1), "unit": "frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: %d concurrent streams per GPU, %d speaker(s), 10 ms hop "
+                                   "(160 in @16 kHz -> 240 out @24 kHz), synthetic weights of MODEL_SPEC v1" % (B, a.speakers),
+                       "streams_per_gpu": B, "speakers": a.speakers, "hipgraph": not a.no_graph,
+                       "parallelism": "streams sharded over %d GPU(s), no per-hop collective" % world},
+            "x_realtime_per_stream": round(a.steps / elapsed / 100.0, 2), "output_rms": round(out_rms, 4),
+        }
+        if not a.no_extras:
+            # per-kernel timing with HIP events on the library's own stream (eager, 10 launches per bracket)
+            rows = batch.profile_kernels(repeats=10)
+            for r in rows:
+                r["total_us"] = r["mean_us"] * r["launches"]
+            total_us = sum(r["total_us"] for r in rows)
+            dom = max(rows, key=lambda r: r["total_us"])
+            t_mfma = dom["flops"] / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+            t_hbm = dom["bytes"] / (PEAK_HBM_GBS * 1e9)
+            if t_mfma >= t_hbm:
+                ach = dom["flops"] / (dom["mean_us"] * 1e-6) / 1e12
+                roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4)}
+            else:
+                ach = dom["bytes"] / (dom["mean_us"] * 1e-6) / 1e9
+                roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(ach / PEAK_HBM_GBS, 4)}
+            roof.update({"traffic": None, "kernel": dom["name"], "launches_per_hop": dom["launches"],
+                         "mean_us_per_launch": round(dom["mean_us"], 2),
+                         "share_of_chain": round(dom["total_us"] / total_us, 3)})
+            res["roofline"] = roof
+            chain_flops = sum(r["flops"] * r["launches"] for r in rows)
+            res["chain"] = {"launches_per_hop": sum(r["launches"] for r in rows),
+                            "sum_kernel_us": round(total_us, 1), "gflop_per_step": round(chain_flops / 1e9, 3),
+                            "tflops_end_to_end": round(chain_flops / (elapsed / a.steps) / 1e12, 2),
+                            "mfma_frac_end_to_end": round(chain_flops / (elapsed / a.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+            res["kernels"] = [{"name": r["name"], "n": r["launches"], "us": round(r["mean_us"], 2)}
+                              for r in sorted(rows, key=lambda r: -r["total_us"])[:12]]
+            if world == 1:
+                res["latency_b1"] = latency_b1(bv, product, model_dir)
+                res["cpu_baseline"] = cpu_baseline(bv, model_dir, a.cpu_seconds)
+        print(json.dumps(res))
+    batch.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

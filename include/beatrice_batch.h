@@ -1,0 +1,113 @@
+/*
+ * beatrice_batch.h -- batched extension of the beatrice C-ABI (this project's addition).
+ *
+ * The reference library is one-stream-per-context: one plugin instance = one stream = one thread
+ * (reference src/vst/processor.h:56-57, factory.cc:21 kManyInstances); its per-hop entry points
+ * carry the suffix "1" (ExtractPhone1 / EstimatePitch1 / GenerateWaveform1,
+ * reference lib/beatricelib/beatrice.h:243-247, 266-271, 301-307).  A GPU wants many streams per
+ * launch, so this header adds an N-stream object that runs the SAME three modules, in the same
+ * order, for B independent streams per call, and keeps the reference host's per-stream settings
+ * and call protocol (reference src/common/processor_core_2.cc):
+ *
+ *   reference ProcessorCore2 member            ->  batched entry point (per stream)
+ *   SetTargetSpeaker        (:431-466)             BeatriceBatch_SetTargetSpeaker
+ *     + one K/V block per hop (:179-181, .h:161)   (applied inside BeatriceBatch_ConvertFrames)
+ *   SetFormantShift         (:468-481)             BeatriceBatch_SetFormantShift
+ *   SetPitchShift / SetAverageSourcePitch /
+ *   SetIntonationIntensity / SetPitchCorrection /
+ *   SetPitchCorrectionType  (:483-559)             BeatriceBatch_SetPitch*   (math of :190-252 on device)
+ *   SetMinSourcePitch / SetMaxSourcePitch (:561-583) BeatriceBatch_SetMin/MaxSourcePitch
+ *   SetVQNumNeighbors       (:585-590)             BeatriceBatch_SetVQNumNeighbors
+ *   ResetContext            (:258-291)             BeatriceBatch_ResetStream
+ *   Process1                (:50-256)              BeatriceBatch_ConvertFrames (one hop, all streams)
+ *
+ * All functions return 0 on success and a negative value on error (bad argument -1, HIP failure -2);
+ * they never throw.  `stream` = -1 addresses every stream.  Plain C types only.
+ */
+#ifndef BEATRICE_BATCH_H_
+#define BEATRICE_BATCH_H_
+
+#include <stddef.h>
+
+#include "beatrice_abi.h"
+
+BEATRICE_ABI_BEGIN
+
+typedef struct BeatriceBatch BeatriceBatch;
+
+/* Parameter blobs that arrive over the wire (e.g. broadcast with RCCL from rank 0) instead of from
+ * a file: same validation and error codes as the Read*Parameters functions. */
+Beatrice_ErrorCode BeatriceHip_LoadPhoneExtractorFromMemory(Beatrice20rc0_PhoneExtractor* m, const void* bytes, size_t size);
+Beatrice_ErrorCode BeatriceHip_LoadPitchEstimatorFromMemory(Beatrice20rc0_PitchEstimator* m, const void* bytes, size_t size);
+Beatrice_ErrorCode BeatriceHip_LoadWaveformGeneratorFromMemory(Beatrice20rc0_WaveformGenerator* m, const void* bytes, size_t size);
+Beatrice_ErrorCode BeatriceHip_LoadEmbeddingSetterFromMemory(Beatrice20rc0_EmbeddingSetter* m, const void* bytes, size_t size);
+
+/* n_streams concurrent streams; speaker tables may hold up to max_speakers entries
+ * (n_speakers + 1 when the caller keeps the reference's extra "morph" slot). */
+BeatriceBatch* BeatriceBatch_Create(const Beatrice20rc0_PhoneExtractor* phone, const Beatrice20rc0_PitchEstimator* pitch,
+                                    const Beatrice20rc0_WaveformGenerator* wave, const Beatrice20rc0_EmbeddingSetter* embed,
+                                    int n_streams, int max_speakers);
+void BeatriceBatch_Destroy(BeatriceBatch* b);
+int BeatriceBatch_IsHealthy(const BeatriceBatch* b);
+int BeatriceBatch_NumStreams(const BeatriceBatch* b);
+
+/* Upload the four caller-owned tables exactly as Beatrice20rc0_ReadSpeakerEmbeddings fills them
+ * ([n][512][128], [n][256], [9][256], [n][384][128]); projects additive/formant vectors and the
+ * K/V of every (speaker, block) once, so that later speaker switches are index changes. */
+int BeatriceBatch_SetSpeakerTables(BeatriceBatch* b, int n_speakers, const float* codebooks, const float* additive,
+                                   const float* formant, const float* key_value);
+/* Replace one table entry (e.g. the morph slot after a spherical average on the host). */
+int BeatriceBatch_UpdateSpeaker(BeatriceBatch* b, int speaker, const float* codebook, const float* additive,
+                                const float* key_value);
+
+int BeatriceBatch_SetTargetSpeaker(BeatriceBatch* b, int stream, int speaker);
+int BeatriceBatch_FlushSpeaker(BeatriceBatch* b, int stream); /* install all pending K/V blocks now */
+int BeatriceBatch_SetFormantShift(BeatriceBatch* b, int stream, double formant_shift);
+int BeatriceBatch_SetVQNumNeighbors(BeatriceBatch* b, int stream, int k);
+int BeatriceBatch_SetMinSourcePitch(BeatriceBatch* b, int stream, double midi_note);
+int BeatriceBatch_SetMaxSourcePitch(BeatriceBatch* b, int stream, double midi_note);
+int BeatriceBatch_SetPitchShift(BeatriceBatch* b, int stream, double semitones);
+int BeatriceBatch_SetAverageSourcePitch(BeatriceBatch* b, int stream, double midi_note);
+int BeatriceBatch_SetIntonationIntensity(BeatriceBatch* b, int stream, double v);
+int BeatriceBatch_SetPitchCorrection(BeatriceBatch* b, int stream, double v);
+int BeatriceBatch_SetPitchCorrectionType(BeatriceBatch* b, int stream, int type);
+int BeatriceBatch_ResetStream(BeatriceBatch* b, int stream);
+
+/* One hop for every stream.  Host variant: in [B][160] @16 kHz, out [B][240] @24 kHz, synchronous.
+ * Device variant: pointers are device memory, work is enqueued on the batch's HIP stream and the
+ * call returns without waiting (BeatriceBatch_Synchronize to wait). */
+int BeatriceBatch_ConvertFrames(BeatriceBatch* b, const float* in, float* out);
+int BeatriceBatch_ConvertFramesDevice(BeatriceBatch* b, const float* d_in, float* d_out);
+int BeatriceBatch_Synchronize(BeatriceBatch* b);
+
+/* Execution control: use an externally owned hipStream_t (e.g. the framework's current stream);
+ * replay the per-hop kernel chain from a captured hipGraph (default on). */
+int BeatriceBatch_SetStream(BeatriceBatch* b, void* hip_stream);
+void* BeatriceBatch_GetStream(const BeatriceBatch* b);
+int BeatriceBatch_EnableGraph(BeatriceBatch* b, int enable);
+
+/* Resident buffers of the batch ([B][160] in, [B][240] out) for callers that produce / consume
+ * audio on the device. */
+float* BeatriceBatch_DeviceInput(BeatriceBatch* b);
+float* BeatriceBatch_DeviceOutput(BeatriceBatch* b);
+
+/* Test hook: copies the last hop's intermediate results (any pointer may be NULL):
+ * phone [B][128], raw bins [B], transformed bins [B], features [B][4]. */
+int BeatriceBatch_GetIntermediates(BeatriceBatch* b, float* phone, int* q_raw, int* q, float* feat);
+
+/* Measurement hook: runs `steps` hops on the resident input buffer, timed with HIP events recorded
+ * on the batch's own stream; returns total milliseconds in *ms. */
+int BeatriceBatch_TimeSteps(BeatriceBatch* b, int steps, float* ms);
+
+/* Per-kernel measurement hook: runs ONE hop eagerly (no graph) with every launch of the chain
+ * bracketed by HIP events on the batch's stream; each launch is issued `repeats` times back to back
+ * inside its bracket (all kernels of the chain are idempotent within a hop) and the bracket time is
+ * divided by `repeats`.  Launches with the same name are accumulated.  Fills up to max_entries rows:
+ * names (64 bytes each, NUL terminated), launches per hop, mean microseconds per launch, and the
+ * algorithmic FLOPs and bytes of one launch.  Returns the number of rows. */
+int BeatriceBatch_ProfileKernels(BeatriceBatch* b, int repeats, int max_entries, char* names, int* launches,
+                                 double* mean_us, double* flops, double* bytes);
+
+BEATRICE_ABI_END
+
+#endif /* BEATRICE_BATCH_H_ */
