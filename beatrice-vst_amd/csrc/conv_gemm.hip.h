@@ -5,10 +5,11 @@
 //   W[(j,c)][n]                                                                 K = KSZ*CIN
 //   out[(b,t)][n]   = res + act( epi(acc) )                                     N = NOUT
 //
-// Numerics (MODEL_SPEC 2.2): every output is ONE k-ascending float32 FMA chain starting at 0;
-// v_mfma_f32_16x16x4_f32 is exactly such a chain (4 k per instruction, in k order), the K loop
-// feeds it k-ascending and never splits K, so the kernel reproduces the scalar definition
-// bit for bit.  16x16x4 is used instead of 32x32x2 because the dependent-accumulator latency per
+// Numerics (MODEL_SPEC 2.2): an output is the ordered sum of P = ceil(K/256) segment results, each
+// segment ONE k-ascending float32 FMA chain starting at 0.  v_mfma_f32_16x16x4_f32 is exactly such
+// a chain (4 k per instruction, in k order); each segment lives in its own accumulator and the
+// segments are added ((s0+s1)+s2)+..., so the kernel reproduces the scalar definition bit for bit
+// while the segments run concurrently (separate wave groups, or interleaved accumulators).  16x16x4 is used instead of 32x32x2 because the dependent-accumulator latency per
 // unit of K is 4x shorter (40 cycles per 4 k vs 64 per 2 k), which is what bounds the small-M
 // layers of a per-hop network.
 //
@@ -52,35 +53,55 @@ struct Layer {
   static constexpr int CIN = CIN_, NOUT = NOUT_, KSZ = KSZ_, STRIDE = STRIDE_, DIL = DIL_, T = T_;
   static constexpr int PRE = PRE_, ACT = ACT_, EPI = EPI_;
   static constexpr bool RES = RES_, GROUPED = GROUPED_;
-  static constexpr int KC = CIN >= 32 ? 32 : CIN;
-  static_assert(CIN % KC == 0 && KC % 4 == 0, "channel chunking");
+  static constexpr int K = KSZ * CIN;
+  static constexpr int SEG = 256;                      // MODEL_SPEC 2.2: reduction segment length
+  static constexpr int P = (K + SEG - 1) / SEG;        // segments per output
+  static constexpr int KC = CIN >= 64 ? 64 : CIN;      // staged chunk (never straddles a tap or a segment)
+  static constexpr int NCHUNK = K / KC;
+  static constexpr int CHUNKS_PER_SEG = SEG / KC;
+  static_assert(CIN % KC == 0 && KC % 4 == 0 && SEG % KC == 0 && K % KC == 0, "channel chunking");
 };
 
-template <int WM_, int WN_, int LM_, int LN_>
+// A workgroup is LK "k-groups" of LM x LN wavefronts; each wavefront owns WM x WN MFMA tiles.
+// LK == 1: one group walks all segments into separate accumulators (throughput layers);
+// LK == P: group g owns segment g, partial tiles are combined through LDS in segment order
+//          (latency layers: the dependent MFMA chain is one segment, not K, long).
+template <int WM_, int WN_, int LM_, int LN_, int LK_ = 1>
 struct TileCfg {
-  static constexpr int WM = WM_, WN = WN_, LM = LM_, LN = LN_;
-  static constexpr int MT = 16 * WM * LM, NT = 16 * WN * LN, NTHR = 64 * LM * LN;
+  static constexpr int WM = WM_, WN = WN_, LM = LM_, LN = LN_, LK = LK_;
+  static constexpr int MT = 16 * WM * LM, NT = 16 * WN * LN;
+  static constexpr int GTHR = 64 * LM * LN;  // threads per k-group
+  static constexpr int NTHR = GTHR * LK;
   static constexpr int WS = NT + ((NT % 32 == 16) ? 0 : 16);
 };
 
 template <class L, class TC>
 __global__ __launch_bounds__(TC::NTHR) void conv_gemm_kernel(const ConvArgs a) {
-  constexpr int KC = L::KC, AS = KC + 2, WS = TC::WS, MT = TC::MT, NT = TC::NT, NTHR = TC::NTHR;
+  constexpr int KC = L::KC, AS = KC + 2, WS = TC::WS, MT = TC::MT, NT = TC::NT, GTHR = TC::GTHR, LK = TC::LK;
+  constexpr int P = L::P;
+  static_assert(LK == 1 || LK == P, "k-groups: one group for all segments, or one group per segment");
+  constexpr int PG = (P + LK - 1) / LK;  // segments (accumulator sets) per group
   constexpr int A_F4_PER_ROW = KC / 4;
-  constexpr int A_SLOTS = (MT * A_F4_PER_ROW + NTHR - 1) / NTHR;
+  constexpr int A_SLOTS = (MT * A_F4_PER_ROW + GTHR - 1) / GTHR;
   constexpr int W_F4_PER_ROW = NT / 4;
-  constexpr int W_SLOTS = (KC * W_F4_PER_ROW + NTHR - 1) / NTHR;
+  constexpr int W_SLOTS = (KC * W_F4_PER_ROW + GTHR - 1) / GTHR;
+  constexpr int STAGE_FLOATS = MT * AS + KC * WS;  // per k-group
+  constexpr int RED_FLOATS = LK > 1 ? P * MT * NT : 0;
+  constexpr int LDS_FLOATS = STAGE_FLOATS * LK > RED_FLOATS ? STAGE_FLOATS * LK : RED_FLOATS;
   static_assert(L::NOUT % NT == 0, "N tile must divide NOUT");
   static_assert(!L::GROUPED || L::T == 1, "grouped rows are streams");
+  static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 
-  __shared__ float As[MT * AS];
-  __shared__ float Ws[KC * WS];
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int grp = tid / GTHR, gtid = tid % GTHR;
+  const int lane = gtid & 63, wave = gtid >> 6;
   const int wave_m = (wave / TC::LN) * (16 * TC::WM), wave_n = (wave % TC::LN) * (16 * TC::WN);
   const int m0 = blockIdx.x * MT, n0 = blockIdx.y * NT;
   const int M = a.B * L::T;
+  float* As = lds + grp * STAGE_FLOATS;
+  float* Ws = As + MT * AS;
 
   const float* wbase = a.w;
   if constexpr (L::GROUPED) {
@@ -96,7 +117,7 @@ __global__ __launch_bounds__(TC::NTHR) void conv_gemm_kernel(const ConvArgs a) {
   int a_b[A_SLOTS], a_t[A_SLOTS];
 #pragma unroll
   for (int s = 0; s < A_SLOTS; ++s) {
-    const int idx = tid + s * NTHR;
+    const int idx = gtid + s * GTHR;
     const int r = idx / A_F4_PER_ROW;
     int b = -1, t = 0;
     if (r < MT) {
@@ -111,46 +132,77 @@ __global__ __launch_bounds__(TC::NTHR) void conv_gemm_kernel(const ConvArgs a) {
     a_t[s] = t;
   }
 
-  f32x4 acc[TC::WM][TC::WN];
+  f32x4 acc[PG][TC::WM][TC::WN];
 #pragma unroll
-  for (int i = 0; i < TC::WM; ++i)
+  for (int g = 0; g < PG; ++g)
 #pragma unroll
-    for (int j = 0; j < TC::WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < TC::WM; ++i)
+#pragma unroll
+      for (int j = 0; j < TC::WN; ++j) acc[g][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int j = 0; j < L::KSZ; ++j) {
-    for (int c0 = 0; c0 < L::CIN; c0 += KC) {
-      // ---- stage A chunk: rows x KC channels of tap j
+  float4 areg[A_SLOTS], wreg[W_SLOTS];
+  // chunk `it` of this group: LK == 1 -> global chunk it; LK == P -> chunk it of segment grp
+  auto load_chunk = [&](int it) {
+    const int ch = LK == 1 ? it : grp * L::CHUNKS_PER_SEG + it;
+    const bool live = ch < L::NCHUNK;
+    const int kk0 = ch * KC;
+    const int j = kk0 / L::CIN, c0 = kk0 % L::CIN;
 #pragma unroll
-      for (int s = 0; s < A_SLOTS; ++s) {
-        const int idx = tid + s * NTHR;
-        const int r = idx / A_F4_PER_ROW, q = idx % A_F4_PER_ROW;
-        if (r < MT) {
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (a_b[s] >= 0) {
-            const int rel = (a_t[s] + 1) * L::STRIDE - 1 - (L::KSZ - 1 - j) * L::DIL + a.rel_shift;
-            const float* src = ring_frame(a.in, a_b[s], pos_in, rel) + c0 + 4 * q;
-            v = *reinterpret_cast<const float4*>(src);
-            if constexpr (L::PRE == PRE_LRELU) {
-              v.x = bsp::lrelu(v.x); v.y = bsp::lrelu(v.y); v.z = bsp::lrelu(v.z); v.w = bsp::lrelu(v.w);
-            }
-          }
-          float* dst = &As[r * AS + 4 * q];
-          dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-        }
+    for (int s = 0; s < A_SLOTS; ++s) {
+      const int idx = gtid + s * GTHR;
+      const int r = idx / A_F4_PER_ROW, q = idx % A_F4_PER_ROW;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live && r < MT && a_b[s] >= 0) {
+        const int rel = (a_t[s] + 1) * L::STRIDE - 1 - (L::KSZ - 1 - j) * L::DIL + a.rel_shift;
+        v = *reinterpret_cast<const float4*>(ring_frame(a.in, a_b[s], pos_in, rel) + c0 + 4 * q);
       }
-      // ---- stage W chunk: KC rows x NT columns
-      const float* wsrc = wbase + ((size_t)(j * L::CIN + c0)) * L::NOUT + n0;
+      areg[s] = v;
+    }
+    const float* wsrc = wbase + (size_t)kk0 * L::NOUT + n0;
 #pragma unroll
-      for (int s = 0; s < W_SLOTS; ++s) {
-        const int idx = tid + s * NTHR;
-        const int r = idx / W_F4_PER_ROW, q = idx % W_F4_PER_ROW;
-        if (r < KC) {
-          const float4 v = *reinterpret_cast<const float4*>(wsrc + (size_t)r * L::NOUT + 4 * q);
-          *reinterpret_cast<float4*>(&Ws[r * WS + 4 * q]) = v;
+    for (int s = 0; s < W_SLOTS; ++s) {
+      const int idx = gtid + s * GTHR;
+      const int r = idx / W_F4_PER_ROW, q = idx % W_F4_PER_ROW;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live && r < KC) v = *reinterpret_cast<const float4*>(wsrc + (size_t)r * L::NOUT + 4 * q);
+      wreg[s] = v;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int s = 0; s < A_SLOTS; ++s) {
+      const int idx = gtid + s * GTHR;
+      const int r = idx / A_F4_PER_ROW, q = idx % A_F4_PER_ROW;
+      if (r < MT) {
+        float4 v = areg[s];
+        if constexpr (L::PRE == PRE_LRELU) {
+          v.x = bsp::lrelu(v.x); v.y = bsp::lrelu(v.y); v.z = bsp::lrelu(v.z); v.w = bsp::lrelu(v.w);
         }
+        float2* dst = reinterpret_cast<float2*>(&As[r * AS + 4 * q]);
+        dst[0] = make_float2(v.x, v.y);
+        dst[1] = make_float2(v.z, v.w);
       }
-      __syncthreads();
-      // ---- MFMA over the chunk, k ascending
+    }
+#pragma unroll
+    for (int s = 0; s < W_SLOTS; ++s) {
+      const int idx = gtid + s * GTHR;
+      const int r = idx / W_F4_PER_ROW, q = idx % W_F4_PER_ROW;
+      if (r < KC) *reinterpret_cast<float4*>(&Ws[r * WS + 4 * q]) = wreg[s];
+    }
+  };
+
+  constexpr int N_IT = LK == 1 ? L::NCHUNK : (L::CHUNKS_PER_SEG < L::NCHUNK ? L::CHUNKS_PER_SEG : L::NCHUNK);
+  load_chunk(0);
+#pragma unroll 1
+  for (int it = 0; it < N_IT; ++it) {
+    store_chunk();
+    __syncthreads();
+    if (it + 1 < N_IT) load_chunk(it + 1);  // global loads fly while the MFMAs below run
+    const int g = LK == 1 ? (it / L::CHUNKS_PER_SEG) : 0;
+    // accumulator set must be a compile-time index: dispatch over PG
+#pragma unroll
+    for (int gs = 0; gs < PG; ++gs) {
+      if (gs != g) continue;
 #pragma unroll
       for (int ks = 0; ks < KC / 4; ++ks) {
         float av[TC::WM], bv[TC::WN];
@@ -162,47 +214,64 @@ __global__ __launch_bounds__(TC::NTHR) void conv_gemm_kernel(const ConvArgs a) {
         for (int i = 0; i < TC::WM; ++i)
 #pragma unroll
           for (int jn = 0; jn < TC::WN; ++jn)
-            acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[jn], acc[i][jn], 0, 0, 0);
+            acc[gs][i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[jn], acc[gs][i][jn], 0, 0, 0);
       }
-      __syncthreads();
     }
+    __syncthreads();
   }
 
-  // ---- epilogue: D layout of 16x16x4: row = (lane>>4)*4 + reg, col = lane&15
+  // ---- combine segments in ascending order (MODEL_SPEC 2.2)
   const int pos_out = ring_pos(a.out, hop);
   const int R_out = a.out.n * a.out.m;
   int pos_res = 0, R_res = 0;
   if constexpr (L::RES) { pos_res = ring_pos(a.res, hop); R_res = a.res.n * a.res.m; }
+
+  auto finish = [&](int r, int n, float v) {  // r: row in tile, n: absolute column
+    int b, t = 0;
+    if constexpr (L::GROUPED) {
+      b = a.perm[blockIdx.x * MT + r];
+    } else {
+      const int m = m0 + r;
+      b = m < M ? m / L::T : -1;
+      t = m % L::T;
+    }
+    if (b < 0) return;
+    if constexpr (L::EPI == EPI_BIAS) v = v + a.bias[n];
+    if constexpr (L::EPI == EPI_SCALE) v = v * a.scale;
+    if constexpr (L::EPI == EPI_ROWSCALE) v = v * a.rowscale[b];
+    if constexpr (L::ACT == ACT_GELU) v = bsp::gelu(v);
+    if constexpr (L::RES) v = a.res.base[((size_t)b * R_res + pos_res) * a.res.C + (size_t)t * L::NOUT + n] + v;
+    a.out.base[((size_t)b * R_out + pos_out) * a.out.C + (size_t)t * L::NOUT + n] = v;
+  };
+
+  if constexpr (LK == 1) {
+    // D layout of 16x16x4: row = (lane>>4)*4 + reg, col = lane&15
 #pragma unroll
-  for (int i = 0; i < TC::WM; ++i) {
+    for (int i = 0; i < TC::WM; ++i)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int r = wave_m + i * 16 + (lane >> 4) * 4 + e;
-      int b, t = 0;
-      if constexpr (L::GROUPED) {
-        b = a.perm[blockIdx.x * MT + r];
-      } else {
-        const int m = m0 + r;
-        b = m < M ? m / L::T : -1;
-        t = m % L::T;
-      }
-      if (b < 0) continue;
-      float* orow = a.out.base + ((size_t)b * R_out + pos_out) * a.out.C + (size_t)t * L::NOUT;
-      const float* rrow = nullptr;
-      if constexpr (L::RES) rrow = a.res.base + ((size_t)b * R_res + pos_res) * a.res.C + (size_t)t * L::NOUT;
-      float rs = 1.0f;
-      if constexpr (L::EPI == EPI_ROWSCALE) rs = a.rowscale[b];
+      for (int jn = 0; jn < TC::WN; ++jn)
 #pragma unroll
-      for (int jn = 0; jn < TC::WN; ++jn) {
-        const int n = n0 + wave_n + jn * 16 + (lane & 15);
-        float v = acc[i][jn][e];
-        if constexpr (L::EPI == EPI_BIAS) v = v + a.bias[n];
-        if constexpr (L::EPI == EPI_SCALE) v = v * a.scale;
-        if constexpr (L::EPI == EPI_ROWSCALE) v = v * rs;
-        if constexpr (L::ACT == ACT_GELU) v = bsp::gelu(v);
-        if constexpr (L::RES) v = rrow[n] + v;
-        orow[n] = v;
-      }
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[0][i][jn][e];
+#pragma unroll
+          for (int g = 1; g < PG; ++g) v = v + acc[g][i][jn][e];
+          finish(wave_m + i * 16 + (lane >> 4) * 4 + e, n0 + wave_n + jn * 16 + (lane & 15), v);
+        }
+  } else {
+    float* red = lds;  // [P][MT][NT]; staging buffers are dead after the last barrier above
+#pragma unroll
+    for (int i = 0; i < TC::WM; ++i)
+#pragma unroll
+      for (int jn = 0; jn < TC::WN; ++jn)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          red[(grp * MT + wave_m + i * 16 + (lane >> 4) * 4 + e) * NT + wave_n + jn * 16 + (lane & 15)] = acc[0][i][jn][e];
+    __syncthreads();
+    for (int idx = tid; idx < MT * NT; idx += TC::NTHR) {
+      float v = red[idx];
+#pragma unroll
+      for (int g = 1; g < P; ++g) v = v + red[g * MT * NT + idx];
+      finish(idx / NT, n0 + idx % NT, v);
     }
   }
 }
@@ -221,12 +290,14 @@ static inline void launch_conv(const char* name, const ConvArgs& a, int n_group_
 }
 
 // ---- launch helpers shared by the modules ------------------------------------------------------
-using TS = TileCfg<1, 1, 1, 4>;  // 16 x 64 (rows x cols): layers with M <= 32 rows
-using TL = TileCfg<2, 2, 2, 2>;  // 64 x 64
+template <class L> using TLat = TileCfg<1, 1, 1, 2, L::P>;  // 16 x 32 tile, one 2-wave k-group per segment
+using TL = TileCfg<2, 2, 2, 2, 1>;                            // 64 x 64 tile, segments interleaved
 
+// Layers with few rows are bound by the dependent MFMA chain and by how many CUs get a tile: use
+// small tiles and one k-group per segment.  Layers with many rows are throughput-bound: 64 x 64.
 template <class L>
 static inline void launch_auto(const char* name, const ConvArgs& a, hipStream_t s) {
-  if (a.B * L::T <= 32) launch_conv<L, TS>(name, a, 0, s);
+  if (a.B * L::T <= 2048) launch_conv<L, TLat<L>>(name, a, 0, s);
   else launch_conv<L, TL>(name, a, 0, s);
 }
 

@@ -88,10 +88,11 @@ using SCORE = Layer<B_HID, B_KV_LEN, 1, 1, 1, 1, PRE_NONE, ACT_NONE, EPI_SCALE, 
 using PV = Layer<B_KV_LEN, B_HID, 1, 1, 1, 1, PRE_NONE, ACT_NONE, EPI_ROWSCALE, false, true>;
 template <int CIN, int COUT, int R, int TIN> using UP = Layer<CIN, R * COUT, 2, 1, 1, TIN, PRE_LRELU, ACT_NONE, EPI_BIAS, false>;
 template <int C, int D, int T> using RES = Layer<C, C, 3, 1, D, T, PRE_LRELU, ACT_NONE, EPI_BIAS, true>;
-using TG = TileCfg<1, 1, 1, 4>;     // grouped attention tiles: 16 streams x 64 columns
-using T32 = TileCfg<2, 2, 4, 1>;    // 128 x 32
-using T48 = TileCfg<1, 3, 4, 1>;    // 64 x 48
-using T16 = TileCfg<4, 1, 4, 1>;    // 256 x 16
+using TGQ = TileCfg<1, 1, 1, 2, 1>;  // grouped attention scores: 16 streams x 32 keys, K = 256 (one segment)
+using TGV = TileCfg<1, 1, 1, 2, 2>;  // grouped attention P.V: 16 streams x 32 channels, two k-groups (K = 384)
+using T32 = TileCfg<2, 2, 4, 1, 1>;  // 128 x 32
+using T48 = TileCfg<1, 3, 4, 1, 1>;  // 64 x 48
+using T16 = TileCfg<4, 1, 4, 1, 1>;  // 256 x 16
 
 #define MISC_LAUNCH(NAME, FLOPS, BYTES, KERNEL, GRID, BLOCK, ...)                              \
   launch_site(LaunchInfo{NAME, (double)(FLOPS), (double)(BYTES)}, st,                          \
@@ -124,12 +125,12 @@ void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t st) {
     a = conv_args(s.q, s.sc, s.d_kt[blk], nullptr, s.d_hop, B);
     a.scale = 0.0625f; a.perm = s.d_perm[blk]; a.tile_slot = s.d_tile_slot[blk];
     a.w_slot_stride = (size_t)B_HID * B_KV_LEN;
-    launch_conv<SCORE, TG>("wave.blk.attn_qk", a, s.n_tiles_max, st);
+    launch_conv<SCORE, TGQ>("wave.blk.attn_qk", a, s.n_tiles_max, st);
     MISC_LAUNCH("wave.blk.softmax", 25.0 * B * 384, 8.0 * B * 384, attn_softmax_kernel, dim3(B), dim3(64), s.sc.base, s.d_inv, B);
     a = conv_args(s.sc, s.o, s.d_v[blk], nullptr, s.d_hop, B);
     a.rowscale = s.d_inv; a.perm = s.d_perm[blk]; a.tile_slot = s.d_tile_slot[blk];
     a.w_slot_stride = (size_t)B_KV_LEN * B_HID;
-    launch_conv<PV, TG>("wave.blk.attn_pv", a, s.n_tiles_max, st);
+    launch_conv<PV, TGV>("wave.blk.attn_pv", a, s.n_tiles_max, st);
     a = conv_args(s.o, s.x[blk + 1], w.o_w[blk], w.o_b[blk], s.d_hop, B);
     a.res = s.xa;
     launch_auto<C2>("wave.blk.o", a, st);

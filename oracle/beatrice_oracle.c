@@ -15,8 +15,9 @@
  * The HIP implementation is checked against THIS file (<= 1e-4 max-abs, in practice bit-exact).
  *
  * Style: scalar, single-threaded, obviously-correct loops.  Every dot product is one k-ascending
- * fused-multiply-add chain in float32 (MODEL_SPEC section 2.2), written n-innermost so gcc can
- * vectorise across output channels without changing any per-output rounding.
+ * fused-multiply-add chain per 256-long segment of the reduction index, segments added in order
+ * (MODEL_SPEC section 2.2), written n-innermost so gcc can vectorise across output channels
+ * without changing any per-output rounding.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -37,6 +38,8 @@
 #define FFT_N 1024
 #define SPEC_BINS 512
 #define PITCH_HIST (FFT_N - IN_HOP)
+
+#define SPEC_SEG 256
 
 #define FILE_MAGIC 0x43525442u
 #define FILE_VERSION 1u
@@ -75,7 +78,11 @@ static Beatrice_ErrorCode read_file(const char* path, uint32_t kind, long expect
 
 /* ------------------------------------------------------------------------------------------ */
 /* Causal streaming convolution (MODEL_SPEC section 3.1).                                      */
-/* y[t][n] = bias[n] + chain_{j<k, c<cin} x[(t+1)*stride-1-(k-1-j)*dil][c] * w[j*cin+c][n]     */
+/* y[t][n] = bias[n] + SUM_{j<k, c<cin} x[(t+1)*stride-1-(k-1-j)*dil][c] * w[j*cin+c][n]       */
+/* The reduction over the flat index kk = j*cin+c is SEGMENTED (MODEL_SPEC 2.2): every run of   */
+/* SPEC_SEG = 256 consecutive kk is one fma chain started at 0; the segment results are added in */
+/* ascending order, ((s0 + s1) + s2) + ..., then the bias.  (Defined this way so that parallel   */
+/* hardware can evaluate the segments concurrently and still match bit for bit.)                 */
 /* `hist` holds the H = (k-1)*dil-(stride-1) frames preceding this hop (zeros at stream start).*/
 /* ------------------------------------------------------------------------------------------ */
 typedef struct {
@@ -92,34 +99,49 @@ static void conv_run(const Conv* c, float* hist, const float* xin, int n_in, int
   memcpy(ext, hist, sizeof(float) * (size_t)H * cin);
   memcpy(ext + (size_t)H * cin, xin, sizeof(float) * (size_t)n_in * cin);
   float* acc = (float*)malloc(sizeof(float) * cout);
+  float* sum = (float*)malloc(sizeof(float) * cout);
   for (int t = 0; t < T; ++t) {
-    for (int n = 0; n < cout; ++n) acc[n] = 0.0f;
+    int kk = 0; /* flat reduction index j*cin + ci; a new segment starts every SPEC_SEG indices */
     for (int j = 0; j < c->k; ++j) {
       const int frame = H + (t + 1) * c->stride - 1 - (c->k - 1 - j) * c->dil;
       const float* xr = ext + (size_t)frame * cin;
-      for (int ci = 0; ci < cin; ++ci) {
+      for (int ci = 0; ci < cin; ++ci, ++kk) {
+        if (kk % SPEC_SEG == 0) {
+          if (kk == SPEC_SEG) for (int n = 0; n < cout; ++n) sum[n] = acc[n];
+          else if (kk > SPEC_SEG) for (int n = 0; n < cout; ++n) sum[n] = sum[n] + acc[n];
+          for (int n = 0; n < cout; ++n) acc[n] = 0.0f;
+        }
         float a = xr[ci];
         if (pre_lrelu) a = sp_lrelu(a);
         const float* wr = c->w + ((size_t)j * cin + ci) * cout;
         for (int n = 0; n < cout; ++n) acc[n] = sp_fma(a, wr[n], acc[n]);
       }
     }
+    if (kk > SPEC_SEG) for (int n = 0; n < cout; ++n) acc[n] = sum[n] + acc[n];
     for (int n = 0; n < cout; ++n) y[(size_t)t * cout + n] = acc[n] + c->b[n];
   }
   memcpy(hist, ext + (size_t)n_in * cin, sizeof(float) * (size_t)H * cin);
+  free(sum);
   free(acc);
   free(ext);
 }
 
 /* y[n] = bias[n] + chain_c x[c]*w[c][n] */
 static void linear_run(const float* w, const float* b, int cin, int cout, const float* x, float* y) {
-  for (int n = 0; n < cout; ++n) y[n] = 0.0f;
+  float* sum = (float*)malloc(sizeof(float) * cout);
   for (int ci = 0; ci < cin; ++ci) {
+    if (ci % SPEC_SEG == 0) {
+      if (ci == SPEC_SEG) for (int n = 0; n < cout; ++n) sum[n] = y[n];
+      else if (ci > SPEC_SEG) for (int n = 0; n < cout; ++n) sum[n] = sum[n] + y[n];
+      for (int n = 0; n < cout; ++n) y[n] = 0.0f;
+    }
     const float a = x[ci];
     const float* wr = w + (size_t)ci * cout;
     for (int n = 0; n < cout; ++n) y[n] = sp_fma(a, wr[n], y[n]);
   }
+  if (cin > SPEC_SEG) for (int n = 0; n < cout; ++n) y[n] = sum[n] + y[n];
   if (b) for (int n = 0; n < cout; ++n) y[n] = y[n] + b[n];
+  free(sum);
 }
 
 /* GRU cell, PyTorch gate order r,z,n (MODEL_SPEC section 3.2).  h is updated in place. */
