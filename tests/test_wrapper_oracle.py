@@ -1,0 +1,75 @@
+"""The oracle's restatement of the open-source wrapper (oracle/wrapper_oracle.c) against
+  (a) the library built from the reference's own headers (oracle/_ref/libref_wrapper.so), live, and
+  (b) the golden vectors minted from that library (tests/golden/wrapper_*.npz).
+Bit-exact is required: both sides do the same float32 multiply-accumulate order."""
+import os
+
+import numpy as np
+import pytest
+
+import wrapperlib
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RATES = [16000, 22050, 24000, 32000, 44100, 48000, 88200, 96000, 192000]
+
+
+@pytest.fixture(scope="module")
+def wo(built):
+    if not os.path.exists(wrapperlib.ORACLE_WRAPPER):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(wrapperlib.REPO, "oracle"), "libwrapper_oracle.so"])
+    return wrapperlib.oracle_wrapper()
+
+
+@pytest.fixture(scope="module")
+def ref():
+    r = wrapperlib.ref_wrapper()
+    if r is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    return r
+
+
+@pytest.mark.parametrize("sr", RATES)
+def test_chain_matches_golden(wo, sr):
+    g = np.load(os.path.join(GOLD, "wrapper_chain.npz"))
+    x, want = g["in_%d" % sr], g["out_%d" % sr]
+    for block in (441, 64, 4096):  # streaming invariance: block size must not change a single sample
+        got = wo.run_chain(sr, x, block)
+        assert np.array_equal(got, want), "sr=%d block=%d max-abs %g" % (sr, block, np.abs(got - want).max())
+    # sanity pinned by the reference's structure: first 480 samples @48 kHz (10 ms) are the FIFO's zeros
+    assert np.all(want[: int(0.01 * sr) - 40] == 0.0)
+    assert np.abs(want).max() > 0.01
+
+
+def test_fraction_matches_golden(wo):
+    g = np.load(os.path.join(GOLD, "wrapper_fraction.npz"))
+    for r, (n, d) in zip(g["ratio"], g["frac"]):
+        assert wo.fraction(float(r)) == (int(n), int(d))
+    assert wo.fraction(48000 / 44100) == (160, 147)
+    assert wo.fraction(1.0) == (1, 1)
+
+
+def test_gain_matches_golden(wo):
+    g = np.load(os.path.join(GOLD, "wrapper_gain.npz"))
+    for sr in (16000, 48000, 96000):
+        ev = [(int(a), float(b)) for a, b in g["ev_%d" % sr]]
+        got = wo.gain_trace(sr, g["in_%d" % sr], ev)
+        assert np.array_equal(got, g["out_%d" % sr])
+    got = wo.run_chain(48000, g["chain_in"], 480, in_gain_events=[(0, -6.0), (2400, 3.0)], out_gain_events=[(960, 6.0)])
+    assert np.array_equal(got, g["chain_out"])
+
+
+@pytest.mark.parametrize("sr,block", [(44100, 1), (48000, 512), (22050, 480), (192000, 441), (32000, 37)])
+def test_chain_matches_reference_live(wo, ref, sr, block):
+    x = wrapperlib.test_signal(int(0.06 * sr), sr, seed=1000 + sr)
+    a = ref.run_chain(sr, x, block)
+    b = wo.run_chain(sr, x, block)
+    assert np.array_equal(a, b), "max-abs %g" % np.abs(a - b).max()
+
+
+def test_dc_gain_is_half(wo):
+    """Zero-stuffing 240 -> 480 has no make-up gain, so DC through an identity-like hop comes out at 0.5
+    (SURVEY.md appendix A.3)."""
+    x = np.full(48000 // 2, 0.25, np.float32)
+    y = wo.run_chain(48000, x, 480)
+    assert abs(float(y[-2000:].mean()) - 0.125) < 2e-3
