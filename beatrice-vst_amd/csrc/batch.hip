@@ -8,6 +8,7 @@
 // memory by the kernels, so one captured graph serves every hop).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -84,6 +85,8 @@ struct BeatriceBatch {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t side_stream = nullptr;  // pitch branch
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace {
@@ -155,9 +158,25 @@ bool push_settings(BeatriceBatch* b) {
   return ok;
 }
 
+// phone and pitch modules are independent (both only read the hop's audio) and CAN run as two
+// parallel branches (second HIP stream, fork/join events, captured as parallel graph branches).
+// Measured on ROCm 7.2 / MI355X (profiles/r01_notes.md): a hipGraph replays its kernel nodes one
+// after another whatever the branch structure, so forking buys nothing (421.7 vs 414.3 us per hop at
+// B = 256) and is off by default; BEATRICE_HIP_FORK=1 turns it on for experiments.
 void enqueue_chain(BeatriceBatch* b) {
+  static const bool want_fork = std::getenv("BEATRICE_HIP_FORK") != nullptr;
+  const bool fork = want_fork && b->side_stream != nullptr && launch_hook() == nullptr;
+  hipStream_t ps = fork ? b->side_stream : b->stream;
+  if (fork) {
+    (void)hip_ok(hipEventRecord(b->ev_fork, b->stream), "fork");
+    (void)hip_ok(hipStreamWaitEvent(ps, b->ev_fork, 0), "fork wait");
+  }
   phone_forward(b->phone_m->w, b->phone, b->stream);
-  pitch_forward(b->pitch_m->w, b->pitch, b->stream);
+  pitch_forward(b->pitch_m->w, b->pitch, ps);
+  if (fork) {
+    (void)hip_ok(hipEventRecord(b->ev_join, ps), "join");
+    (void)hip_ok(hipStreamWaitEvent(b->stream, b->ev_join, 0), "join wait");
+  }
   wave_forward(b->wave_m->w, b->wave, b->stream);
 }
 
@@ -271,7 +290,9 @@ BeatriceBatch* BeatriceBatch_Create(const Beatrice20rc0_PhoneExtractor* phone, c
   }
   ok = ok && hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_in), sizeof(float) * B * B_IN_HOP, hipHostMallocDefault), "h_in") &&
        hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_out), sizeof(float) * B * B_OUT_HOP, hipHostMallocDefault), "h_out") &&
-       hip_ok(hipEventCreate(&b->ev0), "ev0") && hip_ok(hipEventCreate(&b->ev1), "ev1");
+       hip_ok(hipEventCreate(&b->ev0), "ev0") && hip_ok(hipEventCreate(&b->ev1), "ev1") && make_stream(&b->side_stream) &&
+       hip_ok(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming), "evf") &&
+       hip_ok(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming), "evj");
   b->ok = ok;
   if (ok) {
     for (int s = 0; s < B; ++s) sync_stream_arrays(b, s);
@@ -294,6 +315,9 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   if (b->h_out) (void)hipHostFree(b->h_out);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+  if (b->ev_join) (void)hipEventDestroy(b->ev_join);
+  if (b->side_stream) { (void)hipStreamSynchronize(b->side_stream); (void)hipStreamDestroy(b->side_stream); }
   if (b->owns_stream && b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
 }

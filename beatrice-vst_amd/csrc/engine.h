@@ -133,7 +133,9 @@ struct WaveState {
   int n_slots = 0;      // K/V slots per block in the tables
   int n_tiles_max = 0;  // attention M-tiles (16 streams each) upper bound
   RingArena arena;
-  Ring e, x[B_NBLOCKS + 1], h1, xa, q, sc, o, ya[4], yb[4], yc[4];
+  Ring e, x[B_NBLOCKS + 1], h1, xa, q, sc, o;
+  Ring ya1, yb1, yc1, ya2;  // upsampler stage 1 and the stage-2 transposed conv output
+  Ring tail;                // per-stream history block of the fused upsampler tail (wave_tail.hip.h)
   float* d_inv = nullptr;  // [B]
   // inputs (device): phone [B][128], q [B], feat [B][4]; owned unless shared with other modules
   float* d_phone = nullptr; int* d_q = nullptr; float* d_feat = nullptr;

@@ -2,6 +2,7 @@
 // Beatrice20rc0_GenerateWaveform1 (reference lib/beatricelib/beatrice.h:301-307) for B streams.
 #include "conv_gemm.hip.h"
 #include "engine.h"
+#include "wave_tail.hip.h"
 
 namespace bhip {
 
@@ -19,12 +20,11 @@ bool WaveState::create(int B_, int n_slots_, int n_add_, int n_frm_, float* shar
       {&x[2], B_HID, 1, 1 + 2 * kBlockDil[2]}, {&x[3], B_HID, 1, 1 + 2 * kBlockDil[3]}, {&x[4], B_HID, 1, 2},
       {&h1, B_HID, 1, 1}, {&xa, B_HID, 1, 1}, {&q, B_HID, 1, 1}, {&sc, B_KV_LEN, 1, 1}, {&o, B_HID, 1, 1},
   };
-  for (int s = 0; s < 4; ++s) {
-    const int n = kUpT[s + 1], c = kUpC[s + 1];
-    specs.push_back({&ya[s], c, n, 1 + (2 + n - 1) / n});
-    specs.push_back({&yb[s], c, n, 1 + (6 + n - 1) / n});
-    specs.push_back({&yc[s], c, n, s == 3 ? 1 + (6 + n - 1) / n : 1 + (1 + n - 1) / n});
-  }
+  specs.push_back({&ya1, 128, 5, 2});   // history 2 (res1a, k3)
+  specs.push_back({&yb1, 128, 5, 3});   // history 6 (res1b, k3 dil 3)
+  specs.push_back({&yc1, 128, 5, 2});   // history 1 (up2)
+  specs.push_back({&ya2, 64, 20, 2});   // history 2 (first layer of the fused tail)
+  specs.push_back({&tail, TAIL_STATE_FLOATS, 1, 1});
   if (!arena.build(B, specs)) return false;
   if (shared_phone) { d_phone = shared_phone; d_q = shared_q; d_feat = shared_feat; owns_inputs = false; }
   else {
@@ -90,9 +90,6 @@ template <int CIN, int COUT, int R, int TIN> using UP = Layer<CIN, R * COUT, 2, 
 template <int C, int D, int T> using RES = Layer<C, C, 3, 1, D, T, PRE_LRELU, ACT_NONE, EPI_BIAS, true>;
 using TGQ = TileCfg<1, 1, 1, 2, 1>;  // grouped attention scores: 16 streams x 32 keys, K = 256 (one segment)
 using TGV = TileCfg<1, 1, 1, 2, 2>;  // grouped attention P.V: 16 streams x 32 channels, two k-groups (K = 384)
-using T32 = TileCfg<2, 2, 4, 1, 1>;  // 128 x 32
-using T48 = TileCfg<1, 3, 4, 1, 1>;  // 64 x 48
-using T16 = TileCfg<4, 1, 4, 1, 1>;  // 256 x 16
 
 #define MISC_LAUNCH(NAME, FLOPS, BYTES, KERNEL, GRID, BLOCK, ...)                              \
   launch_site(LaunchInfo{NAME, (double)(FLOPS), (double)(BYTES)}, st,                          \
@@ -125,31 +122,30 @@ void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t st) {
     a = conv_args(s.q, s.sc, s.d_kt[blk], nullptr, s.d_hop, B);
     a.scale = 0.0625f; a.perm = s.d_perm[blk]; a.tile_slot = s.d_tile_slot[blk];
     a.w_slot_stride = (size_t)B_HID * B_KV_LEN;
-    launch_conv<SCORE, TGQ>("wave.blk.attn_qk", a, s.n_tiles_max, st);
+    launch_lat<SCORE, 2>("wave.blk.attn_qk", a, s.n_tiles_max, st);
     MISC_LAUNCH("wave.blk.softmax", 25.0 * B * 384, 8.0 * B * 384, attn_softmax_kernel, dim3(B), dim3(64), s.sc.base, s.d_inv, B);
     a = conv_args(s.sc, s.o, s.d_v[blk], nullptr, s.d_hop, B);
     a.rowscale = s.d_inv; a.perm = s.d_perm[blk]; a.tile_slot = s.d_tile_slot[blk];
     a.w_slot_stride = (size_t)B_KV_LEN * B_HID;
-    launch_conv<PV, TGV>("wave.blk.attn_pv", a, s.n_tiles_max, st);
+    launch_lat<PV, 2>("wave.blk.attn_pv", a, s.n_tiles_max, st);
     a = conv_args(s.o, s.x[blk + 1], w.o_w[blk], w.o_b[blk], s.d_hop, B);
     a.res = s.xa;
     launch_auto<C2>("wave.blk.o", a, st);
   }
-  // upsampler: x[4] -> 5 -> 20 -> 80 -> 240 frames
-  launch_auto<UP<256, 128, 5, 1>>("wave.up1", conv_args(s.x[4], s.ya[0], w.up_w[0], w.up_b[0], s.d_hop, B), st);
-  launch_auto<RES<128, 1, 5>>("wave.res1a", conv_args(s.ya[0], s.yb[0], w.ra_w[0], w.ra_b[0], s.d_hop, B), st);
-  launch_auto<RES<128, 3, 5>>("wave.res1b", conv_args(s.yb[0], s.yc[0], w.rb_w[0], w.rb_b[0], s.d_hop, B), st);
-  launch_auto<UP<128, 64, 4, 5>>("wave.up2", conv_args(s.yc[0], s.ya[1], w.up_w[1], w.up_b[1], s.d_hop, B), st);
-  launch_auto<RES<64, 1, 20>>("wave.res2a", conv_args(s.ya[1], s.yb[1], w.ra_w[1], w.ra_b[1], s.d_hop, B), st);
-  launch_auto<RES<64, 3, 20>>("wave.res2b", conv_args(s.yb[1], s.yc[1], w.rb_w[1], w.rb_b[1], s.d_hop, B), st);
-  launch_auto<UP<64, 32, 4, 20>>("wave.up3", conv_args(s.yc[1], s.ya[2], w.up_w[2], w.up_b[2], s.d_hop, B), st);
-  launch_conv<RES<32, 1, 80>, T32>("wave.res3a", conv_args(s.ya[2], s.yb[2], w.ra_w[2], w.ra_b[2], s.d_hop, B), 0, st);
-  launch_conv<RES<32, 3, 80>, T32>("wave.res3b", conv_args(s.yb[2], s.yc[2], w.rb_w[2], w.rb_b[2], s.d_hop, B), 0, st);
-  launch_conv<UP<32, 16, 3, 80>, T48>("wave.up4", conv_args(s.yc[2], s.ya[3], w.up_w[3], w.up_b[3], s.d_hop, B), 0, st);
-  launch_conv<RES<16, 1, 240>, T16>("wave.res4a", conv_args(s.ya[3], s.yb[3], w.ra_w[3], w.ra_b[3], s.d_hop, B), 0, st);
-  launch_conv<RES<16, 3, 240>, T16>("wave.res4b", conv_args(s.yb[3], s.yc[3], w.rb_w[3], w.rb_b[3], s.d_hop, B), 0, st);
-  MISC_LAUNCH("wave.final", 2.0 * B * 240 * 112, 4.0 * B * (246 * 16 + 240), wave_final_kernel, dim3(B), dim3(256), s.yc[3],
-              w.fin_w, w.fin_b, s.d_out, s.d_hop);
+  // upsampler: stage 1 and the stage-2 transposed conv as batched GEMMs (few rows per stream, large
+  // weights), everything after that in one per-stream kernel
+  launch_auto<UP<256, 128, 5, 1>>("wave.up1", conv_args(s.x[4], s.ya1, w.up_w[0], w.up_b[0], s.d_hop, B), st);
+  launch_auto<RES<128, 1, 5>>("wave.res1a", conv_args(s.ya1, s.yb1, w.ra_w[0], w.ra_b[0], s.d_hop, B), st);
+  launch_auto<RES<128, 3, 5>>("wave.res1b", conv_args(s.yb1, s.yc1, w.rb_w[0], w.rb_b[0], s.d_hop, B), st);
+  launch_auto<UP<128, 64, 4, 5>>("wave.up2", conv_args(s.yc1, s.ya2, w.up_w[1], w.up_b[1], s.d_hop, B), st);
+  TailArgs ta{};
+  ta.in = s.ya2; ta.state = s.tail.base; ta.fin_w = w.fin_w; ta.fin_b = w.fin_b; ta.d_out = s.d_out; ta.hop = s.d_hop;
+  ta.w[0] = w.ra_w[1]; ta.b[0] = w.ra_b[1]; ta.w[1] = w.rb_w[1]; ta.b[1] = w.rb_b[1];
+  ta.w[2] = w.up_w[2]; ta.b[2] = w.up_b[2]; ta.w[3] = w.ra_w[2]; ta.b[3] = w.ra_b[2]; ta.w[4] = w.rb_w[2]; ta.b[4] = w.rb_b[2];
+  ta.w[5] = w.up_w[3]; ta.b[5] = w.up_b[3]; ta.w[6] = w.ra_w[3]; ta.b[6] = w.ra_b[3]; ta.w[7] = w.rb_w[3]; ta.b[7] = w.rb_b[3];
+  const double tail_macs = 2.0 * 20 * 192 * 64 + 20.0 * 128 * 128 + 2.0 * 80 * 96 * 32 + 80.0 * 64 * 48 + 2.0 * 240 * 48 * 16 + 240.0 * 112;
+  MISC_LAUNCH("wave.tail", 2.0 * B * tail_macs, 4.0 * (52000.0 + B * (22 * 64 + 2 * TAIL_STATE_FLOATS + 240)), wave_tail_kernel,
+              dim3(B), dim3(tail::NTHR), ta);
   MISC_LAUNCH("hop_advance", 0, 4, hop_advance_kernel, dim3(1), dim3(1), s.d_hop);
 }
 
