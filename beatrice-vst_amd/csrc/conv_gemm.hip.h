@@ -505,7 +505,11 @@ using TL = TileCfg<2, 2, 2, 2, 1>;                            // 64 x 64 tile, s
 // small tiles and one k-group per segment.  Layers with many rows are throughput-bound: 64 x 64.
 template <class L>
 static inline void launch_auto(const char* name, const ConvArgs& a, hipStream_t s) {
-  if (a.B * L::T <= 2048) launch_lat<L, 2>(name, a, 0, s);
+  // (lat_gemm_kernel measured slower than the chunk-pipelined kernel for these layers on MI355X --
+  //  7.2 vs 5.0 us for a 256->256 linear at B = 256, profiles/r01_notes.md -- because its 64 dword
+  //  W loads per lane serialise ahead of the MFMA chain; it stays for the grouped attention GEMMs and
+  //  as the base for a pre-packed-weights variant.)
+  if (a.B * L::T <= 2048) launch_conv<L, TLat<L>>(name, a, 0, s);
   else launch_conv<L, TL>(name, a, 0, s);
 }
 

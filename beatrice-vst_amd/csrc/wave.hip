@@ -122,12 +122,12 @@ void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t st) {
     a = conv_args(s.q, s.sc, s.d_kt[blk], nullptr, s.d_hop, B);
     a.scale = 0.0625f; a.perm = s.d_perm[blk]; a.tile_slot = s.d_tile_slot[blk];
     a.w_slot_stride = (size_t)B_HID * B_KV_LEN;
-    launch_lat<SCORE, 2>("wave.blk.attn_qk", a, s.n_tiles_max, st);
+    launch_conv<SCORE, TGQ>("wave.blk.attn_qk", a, s.n_tiles_max, st);
     MISC_LAUNCH("wave.blk.softmax", 25.0 * B * 384, 8.0 * B * 384, attn_softmax_kernel, dim3(B), dim3(64), s.sc.base, s.d_inv, B);
     a = conv_args(s.sc, s.o, s.d_v[blk], nullptr, s.d_hop, B);
     a.rowscale = s.d_inv; a.perm = s.d_perm[blk]; a.tile_slot = s.d_tile_slot[blk];
     a.w_slot_stride = (size_t)B_KV_LEN * B_HID;
-    launch_lat<PV, 2>("wave.blk.attn_pv", a, s.n_tiles_max, st);
+    launch_conv<PV, TGV>("wave.blk.attn_pv", a, s.n_tiles_max, st);
     a = conv_args(s.o, s.x[blk + 1], w.o_w[blk], w.o_b[blk], s.d_hop, B);
     a.res = s.xa;
     launch_auto<C2>("wave.blk.o", a, st);
