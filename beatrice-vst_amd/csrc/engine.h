@@ -81,7 +81,9 @@ struct PhoneState {
   const float** d_cbT = nullptr;    // [B] device pointers
   const float** d_cnorm = nullptr;  // [B]
   int* d_vqk = nullptr;             // [B]
-  int* d_hop = nullptr;
+  int* d_hop = nullptr;       // owned hop counter
+  int* hop = nullptr;         // counter the kernels read (== d_hop unless shared by a batch)
+  bool advance_hop = true;    // this module's forward ends with the counter increment
   bool create(int B, float* shared_in);
   void destroy();
 };
@@ -104,7 +106,9 @@ struct PitchState {
   int *d_min_q = nullptr, *d_max_q = nullptr, *d_prev_q = nullptr, *d_q_raw = nullptr, *d_q = nullptr;
   float* d_feat = nullptr;             // [B][4]
   PitchParams* d_params = nullptr;     // [B] or nullptr (1-stream ABI: host does the transform)
-  int* d_hop = nullptr;
+  int* d_hop = nullptr;       // owned hop counter
+  int* hop = nullptr;         // counter the kernels read (== d_hop unless shared by a batch)
+  bool advance_hop = true;    // this module's forward ends with the counter increment
   bool create(int B, float* shared_in, bool with_params);
   void destroy();
 };
@@ -149,7 +153,9 @@ struct WaveState {
   float* d_v[B_NBLOCKS] = {nullptr, nullptr, nullptr, nullptr};   // [n_slots][384][256]
   int* d_perm[B_NBLOCKS] = {nullptr, nullptr, nullptr, nullptr};       // [n_tiles_max][16]
   int* d_tile_slot[B_NBLOCKS] = {nullptr, nullptr, nullptr, nullptr};  // [n_tiles_max]
-  int* d_hop = nullptr;
+  int* d_hop = nullptr;       // owned hop counter
+  int* hop = nullptr;         // counter the kernels read (== d_hop unless shared by a batch)
+  bool advance_hop = true;    // this module's forward ends with the counter increment
   bool create(int B, int n_slots, int n_add, int n_frm, float* shared_phone, int* shared_q, float* shared_feat);
   void destroy();
 };

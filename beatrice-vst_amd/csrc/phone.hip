@@ -27,6 +27,7 @@ bool PhoneState::create(int B_, float* shared_in) {
   BHIP_TRY(hipMemset(d_cnorm, 0, sizeof(float*) * B));
   BHIP_TRY(hipMemset(d_vqk, 0, sizeof(int) * B));
   BHIP_TRY(hipMemset(d_hop, 0, sizeof(int)));
+  hop = d_hop;
   return true;
 }
 void PhoneState::destroy() {
@@ -56,26 +57,26 @@ using OUTL = Layer<256, B_PHONE_CH, 1, 1, 1, 1, PRE_NONE, ACT_NONE, EPI_BIAS, fa
 void phone_forward(const PhoneWeights& w, const PhoneState& s, hipStream_t st) {
   const int B = s.B;
   MISC_LAUNCH("phone.f1", 2.0 * B * 32 * 64 * 10, 4.0 * B * (160 + 32 * 64), phone_f1_kernel, dim3(B), dim3(256), s.d_in,
-              s.audio, s.f[0], w.f1_w, w.f1_b, s.d_hop);
-  launch_auto<F2>("phone.f2", conv_args(s.f[0], s.f[1], w.f_w[0], w.f_b[0], s.d_hop, B), st);
-  launch_auto<F3>("phone.f3", conv_args(s.f[1], s.f[2], w.f_w[1], w.f_b[1], s.d_hop, B), st);
-  launch_auto<F4>("phone.f4", conv_args(s.f[2], s.f[3], w.f_w[2], w.f_b[2], s.d_hop, B), st);
-  launch_auto<F5>("phone.f5", conv_args(s.f[3], s.f[4], w.f_w[3], w.f_b[3], s.d_hop, B), st);
+              s.audio, s.f[0], w.f1_w, w.f1_b, s.hop);
+  launch_auto<F2>("phone.f2", conv_args(s.f[0], s.f[1], w.f_w[0], w.f_b[0], s.hop, B), st);
+  launch_auto<F3>("phone.f3", conv_args(s.f[1], s.f[2], w.f_w[1], w.f_b[1], s.hop, B), st);
+  launch_auto<F4>("phone.f4", conv_args(s.f[2], s.f[3], w.f_w[2], w.f_b[2], s.hop, B), st);
+  launch_auto<F5>("phone.f5", conv_args(s.f[3], s.f[4], w.f_w[3], w.f_b[3], s.hop, B), st);
   const Ring* cur = &s.f[4];
   for (int i = 0; i < 4; ++i) {
-    launch_auto<RBL>("phone.rb", conv_args(*cur, s.rb[i], w.rb_w[i], w.rb_b[i], s.d_hop, B), st);
+    launch_auto<RBL>("phone.rb", conv_args(*cur, s.rb[i], w.rb_w[i], w.rb_b[i], s.hop, B), st);
     cur = &s.rb[i];
   }
-  launch_auto<GATE>("phone.gru_gi", conv_args(*cur, s.gi, w.gru_wih, w.gru_bih, s.d_hop, B), st);
-  ConvArgs gh = conv_args(s.h, s.gh, w.gru_whh, w.gru_bhh, s.d_hop, B);
+  launch_auto<GATE>("phone.gru_gi", conv_args(*cur, s.gi, w.gru_wih, w.gru_bih, s.hop, B), st);
+  ConvArgs gh = conv_args(s.h, s.gh, w.gru_whh, w.gru_bhh, s.hop, B);
   gh.rel_shift = -1;  // previous hidden state
   launch_auto<GATE>("phone.gru_gh", gh, st);
   MISC_LAUNCH("phone.gru_gate", 30.0 * B * 256, 4.0 * B * 256 * 8, gru_gate_kernel, dim3((B * 256 + 255) / 256), dim3(256),
-              s.gi.base, s.gh.base, s.h, 256, B, s.d_hop);
-  launch_auto<OUTL>("phone.out", conv_args(s.h, s.raw, w.out_w, w.out_b, s.d_hop, B), st);
+              s.gi.base, s.gh.base, s.h, 256, B, s.hop);
+  launch_auto<OUTL>("phone.out", conv_args(s.h, s.raw, w.out_w, w.out_b, s.hop, B), st);
   VqArgs v{s.raw.base, s.d_phone, s.d_cbT, s.d_cnorm, s.d_vqk};
   MISC_LAUNCH("phone.vq", 2.0 * B * 512 * 128, 4.0 * (B * 256 + 512 * 129), phone_vq_kernel, dim3(B), dim3(512), v);
-  MISC_LAUNCH("hop_advance", 0, 4, hop_advance_kernel, dim3(1), dim3(1), s.d_hop);
+  if (s.advance_hop) MISC_LAUNCH("hop_advance", 0, 4, hop_advance_kernel, dim3(1), dim3(1), s.hop);
 }
 
 }  // namespace bhip

@@ -36,6 +36,7 @@ bool PitchState::create(int B_, float* shared_in, bool with_params) {
   }
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hop), sizeof(int)));
   BHIP_TRY(hipMemset(d_hop, 0, sizeof(int)));
+  hop = d_hop;
   return true;
 }
 void PitchState::destroy() {
@@ -58,21 +59,21 @@ using POUT = Layer<128, B_PITCH_BINS, 1, 1, 1, 1, PRE_NONE, ACT_NONE, EPI_BIAS, 
 void pitch_forward(const PitchWeights& w, const PitchState& s, hipStream_t st) {
   const int B = s.B;
   MISC_LAUNCH("pitch.fft", B * (10.0 * 512 * 10 + 1024 * 2 + 512 * 30), 4.0 * B * (1024 + 160 + 512), pitch_fft_kernel, dim3(B),
-              dim3(256), s.d_in, s.audio, s.spec, w.window, w.twiddle, s.d_hop);
-  launch_auto<P1>("pitch.p1", conv_args(s.spec, s.p[0], w.p_w[0], w.p_b[0], s.d_hop, B), st);
-  launch_auto<P23>("pitch.p23", conv_args(s.p[0], s.p[1], w.p_w[1], w.p_b[1], s.d_hop, B), st);
-  launch_auto<P23>("pitch.p23", conv_args(s.p[1], s.p[2], w.p_w[2], w.p_b[2], s.d_hop, B), st);
-  launch_auto<PGATE>("pitch.gru_gi", conv_args(s.p[2], s.gi, w.gru_wih, w.gru_bih, s.d_hop, B), st);
-  ConvArgs gh = conv_args(s.h, s.gh, w.gru_whh, w.gru_bhh, s.d_hop, B);
+              dim3(256), s.d_in, s.audio, s.spec, w.window, w.twiddle, s.hop);
+  launch_auto<P1>("pitch.p1", conv_args(s.spec, s.p[0], w.p_w[0], w.p_b[0], s.hop, B), st);
+  launch_auto<P23>("pitch.p23", conv_args(s.p[0], s.p[1], w.p_w[1], w.p_b[1], s.hop, B), st);
+  launch_auto<P23>("pitch.p23", conv_args(s.p[1], s.p[2], w.p_w[2], w.p_b[2], s.hop, B), st);
+  launch_auto<PGATE>("pitch.gru_gi", conv_args(s.p[2], s.gi, w.gru_wih, w.gru_bih, s.hop, B), st);
+  ConvArgs gh = conv_args(s.h, s.gh, w.gru_whh, w.gru_bhh, s.hop, B);
   gh.rel_shift = -1;
   launch_auto<PGATE>("pitch.gru_gh", gh, st);
   MISC_LAUNCH("pitch.gru_gate", 30.0 * B * 128, 4.0 * B * 128 * 8, gru_gate_kernel, dim3((B * 128 + 255) / 256), dim3(256),
-              s.gi.base, s.gh.base, s.h, 128, B, s.d_hop);
-  launch_auto<POUT>("pitch.out", conv_args(s.h, s.logits, w.out_w, w.out_b, s.d_hop, B), st);
+              s.gi.base, s.gh.base, s.h, 128, B, s.hop);
+  launch_auto<POUT>("pitch.out", conv_args(s.h, s.logits, w.out_w, w.out_b, s.hop, B), st);
   PitchHeadArgs a{s.logits.base, s.h, s.d_in, w.voi_w, w.voi_b, s.d_min_q, s.d_max_q, s.d_prev_q,
-                  s.d_q_raw, s.d_q, s.d_feat, s.d_params, s.d_hop};
+                  s.d_q_raw, s.d_q, s.d_feat, s.d_params, s.hop};
   MISC_LAUNCH("pitch.head", 25.0 * B * 448, 4.0 * B * (448 + 160 + 128 + 8), pitch_head_kernel, dim3(B), dim3(64), a);
-  MISC_LAUNCH("hop_advance", 0, 4, hop_advance_kernel, dim3(1), dim3(1), s.d_hop);
+  if (s.advance_hop) MISC_LAUNCH("hop_advance", 0, 4, hop_advance_kernel, dim3(1), dim3(1), s.hop);
 }
 
 }  // namespace bhip

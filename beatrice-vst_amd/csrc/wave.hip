@@ -64,6 +64,7 @@ bool WaveState::create(int B_, int n_slots_, int n_add_, int n_frm_, float* shar
   }
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hop), sizeof(int)));
   BHIP_TRY(hipMemset(d_hop, 0, sizeof(int)));
+  hop = d_hop;
   return true;
 }
 void WaveState::destroy() {
@@ -97,7 +98,7 @@ using TGV = TileCfg<1, 1, 1, 2, 2>;  // grouped attention P.V: 16 streams x 32 c
 
 template <int D>
 static void launch_c1(const WaveWeights& w, const WaveState& s, int blk, hipStream_t st) {
-  launch_auto<C1<D>>("wave.blk.c1", conv_args(s.x[blk], s.h1, w.c1_w[blk], w.c1_b[blk], s.d_hop, s.B), st);
+  launch_auto<C1<D>>("wave.blk.c1", conv_args(s.x[blk], s.h1, w.c1_w[blk], w.c1_b[blk], s.hop, s.B), st);
 }
 
 void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t st) {
@@ -105,7 +106,7 @@ void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t st) {
   CondArgs ca{s.d_q, s.d_feat, w.pitch_emb, w.feat_w, s.d_add_tab, s.d_add_idx, s.d_frm_tab, s.d_frm_idx, s.e.base};
   MISC_LAUNCH("wave.cond", 11.0 * B * 256, 4.0 * B * 256 * 4, wave_cond_kernel, dim3(B), dim3(256), ca);
   const Ring phone_in{s.d_phone, B_PHONE_CH, 1, 1};
-  ConvArgs a = conv_args(phone_in, s.x[0], w.inp_w, w.inp_b, s.d_hop, B);
+  ConvArgs a = conv_args(phone_in, s.x[0], w.inp_w, w.inp_b, s.hop, B);
   a.res = s.e;
   launch_auto<INP>("wave.inp", a, st);
   for (int blk = 0; blk < B_NBLOCKS; ++blk) {
@@ -115,38 +116,38 @@ void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t st) {
       case 2: launch_c1<4>(w, s, blk, st); break;
       default: launch_c1<8>(w, s, blk, st); break;
     }
-    a = conv_args(s.h1, s.xa, w.c2_w[blk], w.c2_b[blk], s.d_hop, B);
+    a = conv_args(s.h1, s.xa, w.c2_w[blk], w.c2_b[blk], s.hop, B);
     a.res = s.x[blk];
     launch_auto<C2>("wave.blk.c2", a, st);
-    launch_auto<QL>("wave.blk.q", conv_args(s.xa, s.q, w.q_w[blk], w.q_b[blk], s.d_hop, B), st);
-    a = conv_args(s.q, s.sc, s.d_kt[blk], nullptr, s.d_hop, B);
+    launch_auto<QL>("wave.blk.q", conv_args(s.xa, s.q, w.q_w[blk], w.q_b[blk], s.hop, B), st);
+    a = conv_args(s.q, s.sc, s.d_kt[blk], nullptr, s.hop, B);
     a.scale = 0.0625f; a.perm = s.d_perm[blk]; a.tile_slot = s.d_tile_slot[blk];
     a.w_slot_stride = (size_t)B_HID * B_KV_LEN;
     launch_conv<SCORE, TGQ>("wave.blk.attn_qk", a, s.n_tiles_max, st);
     MISC_LAUNCH("wave.blk.softmax", 25.0 * B * 384, 8.0 * B * 384, attn_softmax_kernel, dim3(B), dim3(64), s.sc.base, s.d_inv, B);
-    a = conv_args(s.sc, s.o, s.d_v[blk], nullptr, s.d_hop, B);
+    a = conv_args(s.sc, s.o, s.d_v[blk], nullptr, s.hop, B);
     a.rowscale = s.d_inv; a.perm = s.d_perm[blk]; a.tile_slot = s.d_tile_slot[blk];
     a.w_slot_stride = (size_t)B_KV_LEN * B_HID;
     launch_conv<PV, TGV>("wave.blk.attn_pv", a, s.n_tiles_max, st);
-    a = conv_args(s.o, s.x[blk + 1], w.o_w[blk], w.o_b[blk], s.d_hop, B);
+    a = conv_args(s.o, s.x[blk + 1], w.o_w[blk], w.o_b[blk], s.hop, B);
     a.res = s.xa;
     launch_auto<C2>("wave.blk.o", a, st);
   }
   // upsampler: stage 1 and the stage-2 transposed conv as batched GEMMs (few rows per stream, large
   // weights), everything after that in one per-stream kernel
-  launch_auto<UP<256, 128, 5, 1>>("wave.up1", conv_args(s.x[4], s.ya1, w.up_w[0], w.up_b[0], s.d_hop, B), st);
-  launch_auto<RES<128, 1, 5>>("wave.res1a", conv_args(s.ya1, s.yb1, w.ra_w[0], w.ra_b[0], s.d_hop, B), st);
-  launch_auto<RES<128, 3, 5>>("wave.res1b", conv_args(s.yb1, s.yc1, w.rb_w[0], w.rb_b[0], s.d_hop, B), st);
-  launch_auto<UP<128, 64, 4, 5>>("wave.up2", conv_args(s.yc1, s.ya2, w.up_w[1], w.up_b[1], s.d_hop, B), st);
+  launch_auto<UP<256, 128, 5, 1>>("wave.up1", conv_args(s.x[4], s.ya1, w.up_w[0], w.up_b[0], s.hop, B), st);
+  launch_auto<RES<128, 1, 5>>("wave.res1a", conv_args(s.ya1, s.yb1, w.ra_w[0], w.ra_b[0], s.hop, B), st);
+  launch_auto<RES<128, 3, 5>>("wave.res1b", conv_args(s.yb1, s.yc1, w.rb_w[0], w.rb_b[0], s.hop, B), st);
+  launch_auto<UP<128, 64, 4, 5>>("wave.up2", conv_args(s.yc1, s.ya2, w.up_w[1], w.up_b[1], s.hop, B), st);
   TailArgs ta{};
-  ta.in = s.ya2; ta.state = s.tail.base; ta.fin_w = w.fin_w; ta.fin_b = w.fin_b; ta.d_out = s.d_out; ta.hop = s.d_hop;
+  ta.in = s.ya2; ta.state = s.tail.base; ta.fin_w = w.fin_w; ta.fin_b = w.fin_b; ta.d_out = s.d_out; ta.hop = s.hop;
   ta.w[0] = w.ra_w[1]; ta.b[0] = w.ra_b[1]; ta.w[1] = w.rb_w[1]; ta.b[1] = w.rb_b[1];
   ta.w[2] = w.up_w[2]; ta.b[2] = w.up_b[2]; ta.w[3] = w.ra_w[2]; ta.b[3] = w.ra_b[2]; ta.w[4] = w.rb_w[2]; ta.b[4] = w.rb_b[2];
   ta.w[5] = w.up_w[3]; ta.b[5] = w.up_b[3]; ta.w[6] = w.ra_w[3]; ta.b[6] = w.ra_b[3]; ta.w[7] = w.rb_w[3]; ta.b[7] = w.rb_b[3];
   const double tail_macs = 2.0 * 20 * 192 * 64 + 20.0 * 128 * 128 + 2.0 * 80 * 96 * 32 + 80.0 * 64 * 48 + 2.0 * 240 * 48 * 16 + 240.0 * 112;
   MISC_LAUNCH("wave.tail", 2.0 * B * tail_macs, 4.0 * (52000.0 + B * (22 * 64 + 2 * TAIL_STATE_FLOATS + 240)), wave_tail_kernel,
               dim3(B), dim3(tail::NTHR), ta);
-  MISC_LAUNCH("hop_advance", 0, 4, hop_advance_kernel, dim3(1), dim3(1), s.d_hop);
+  if (s.advance_hop) MISC_LAUNCH("hop_advance", 0, 4, hop_advance_kernel, dim3(1), dim3(1), s.hop);
 }
 
 }  // namespace bhip

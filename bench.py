@@ -43,18 +43,11 @@ def load_pkg():
     return mod
 
 
-def broadcast_bytes(data, rank, world, dist, torch):
-    """rank 0's bytes -> every rank, as one RCCL broadcast of a uint8 device tensor over xGMI."""
-    if world == 1:
-        return data
-    n = torch.tensor([len(data) if rank == 0 else 0], dtype=torch.int64, device="cuda")
-    dist.broadcast(n, 0)
-    if rank == 0:
-        buf = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
-    else:
-        buf = torch.empty(int(n.item()), dtype=torch.uint8, device="cuda")
-    dist.broadcast(buf, 0)
-    return buf.cpu().numpy().tobytes()
+def load_shard():
+    spec = importlib.util.spec_from_file_location("beatrice_shard", os.path.join(REPO, "beatrice-vst_amd", "shard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def cpu_baseline(bv, model_dir, seconds):
@@ -150,10 +143,8 @@ def main():
              "speaker_embeddings.bin"]
     if rank == 0:
         make_model.make_model(model_dir, n_speakers=a.speakers)
-    blobs = {}
-    for f in files:
-        data = open(os.path.join(model_dir, f), "rb").read() if rank == 0 else b""
-        blobs[f] = broadcast_bytes(data, rank, world, dist, torch)
+    shard = load_shard()
+    blobs = shard.broadcast_model(model_dir, rank, world, dist, torch, "cuda")  # RCCL broadcast of the weights
     if rank != 0:  # the speaker file is parsed by the file reader of the C-ABI
         with open(os.path.join(model_dir, "speaker_embeddings.bin"), "wb") as fh:
             fh.write(blobs["speaker_embeddings.bin"])
@@ -206,9 +197,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = shard.max_over_ranks(elapsed, world, dist, torch, "cuda")
     out_rms = float(d_out.float().pow(2).mean().sqrt().item())
 
     if rank == 0:

@@ -1,0 +1,95 @@
+"""The N > 1 path on CPU: two processes over gloo run the same broadcast / shard / reduce code that
+bench.py runs over RCCL, with the oracle standing in for the device library (no GPU here).
+Checks (1) every rank receives rank 0's model bytes, (2) sharded streams == the same streams run in one
+process (multi-GPU invariance), (3) the MAX-over-ranks reduction."""
+import hashlib
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOTAL_STREAMS, HOPS = 5, 6
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _run_streams(bv, model_dir, lo, hi):
+    oracle = bv.Abi(os.path.join(REPO, "oracle", "libbeatrice_oracle.so"))
+    m = bv.Models(oracle, model_dir)
+    out = {}
+    for s in range(lo, hi):
+        st = bv.Stream1(m, speaker=s % 2, vq_k=s % 3)
+        x = bv.synth_audio(160 * HOPS, seed=300 + s)
+        out[s] = np.stack([st.hop(x[i * 160:(i + 1) * 160]) for i in range(HOPS)])
+        st.close()
+    m.close()
+    return out
+
+
+def _worker(rank, world, port, src_dir, tmp_root, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bv = _load("beatrice_vst_amd", os.path.join(REPO, "beatrice-vst_amd", "__init__.py"))
+    shard = _load("beatrice_shard", os.path.join(REPO, "beatrice-vst_amd", "shard.py"))
+    blobs = shard.broadcast_model(src_dir if rank == 0 else "/nonexistent", rank, world, dist, torch, "cpu")
+    my_dir = os.path.join(tmp_root, "rank%d" % rank)
+    os.makedirs(my_dir, exist_ok=True)
+    for f, data in blobs.items():
+        with open(os.path.join(my_dir, f), "wb") as fh:
+            fh.write(data)
+    lo, hi = shard.stream_range(rank, world, TOTAL_STREAMS)
+    outs = _run_streams(bv, my_dir, lo, hi)
+    slowest = shard.max_over_ranks(float(rank + 1), world, dist, torch, "cpu")
+    digest = {f: hashlib.sha256(d).hexdigest() for f, d in blobs.items()}
+    q.put((rank, lo, hi, {s: o.tobytes() for s, o in outs.items()}, digest, slowest))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_matches_single_process(bv, built, model_dir, tmp_path):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, model_dir, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = _run_streams(bv, model_dir, 0, TOTAL_STREAMS)
+    want = {f: hashlib.sha256(open(os.path.join(model_dir, f), "rb").read()).hexdigest()
+            for f in ("phone_extractor.bin", "speaker_embeddings.bin")}
+    covered = set()
+    for rank, lo, hi, outs, digest, slowest in results:
+        assert slowest == 2.0
+        for f, h in want.items():
+            assert digest[f] == h, "rank %d received different bytes for %s" % (rank, f)
+        for s, raw in outs.items():
+            got = np.frombuffer(raw, np.float32).reshape(HOPS, 240)
+            assert np.array_equal(got, ref[s]), "stream %d differs when sharded" % s
+            covered.add(s)
+    assert covered == set(range(TOTAL_STREAMS))
+
+
+def test_stream_range_partitions():
+    shard = _load("beatrice_shard", os.path.join(REPO, "beatrice-vst_amd", "shard.py"))
+    for world in (1, 2, 3, 8):
+        for total in (0, 1, 7, 256, 2048, 2049):
+            spans = [shard.stream_range(r, world, total) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
