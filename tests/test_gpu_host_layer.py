@@ -1,0 +1,34 @@
+"""End to end through the C++ host layer: the product build (host layer + HIP library) against the
+same host source on the oracle core, at several host sample rates (BASELINE.json configs[0]/[1]
+plumbing: any-rate audio in, same-length audio out)."""
+import numpy as np
+import pytest
+
+import hostlib
+import wrapperlib
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("sr,block", [(24000, 240), (48000, 480), (44100, 512)])
+def test_host_layer_hip_matches_oracle(built, model_dir, sr, block):
+    x = wrapperlib.test_signal(block * max(4, int(0.25 * sr) // block), sr, seed=sr + 7)
+    outs = {}
+    for name, path in (("oracle", hostlib.HOST_ON_ORACLE), ("hip", hostlib.HOST_PRODUCT)):
+        h = hostlib.Host(path, sr)
+        assert h.load(model_dir) == 0
+        h.call("SetVQNumNeighbors", 2)
+        h.call("SetPitchShift", -2.0)
+        half = block * (len(x) // block // 2)
+        a, ca = h.process(x[:half], block)
+        h.call("SetTargetSpeaker", 1)
+        h.call("SetFormantShift", 1.0)
+        b, cb = h.process(x[half:], block)
+        assert set(ca + cb) == {0}
+        outs[name] = (np.concatenate([a, b]), h.pitch_trace())
+        h.close()
+    assert outs["hip"][1] == outs["oracle"][1]
+    dev = float(np.abs(outs["hip"][0] - outs["oracle"][0]).max())
+    print("host layer sr=%d max-abs %g" % (sr, dev))
+    assert np.abs(outs["hip"][0]).max() > 1e-3
+    assert dev <= 1e-4

@@ -1,0 +1,111 @@
+"""The C++ host layer (the reference's ProcessorCore2 counterpart) on CPU, compiled against the
+oracle core: its Process() chain must equal [oracle wrapper chain] o [oracle model hop] bit for bit,
+and its guards / error codes must be the reference's (processor_core_2.cc:24-48, 431-438, 552-556)."""
+import os
+
+import numpy as np
+import pytest
+
+import hostlib
+import wrapperlib
+
+
+@pytest.fixture(scope="module")
+def host_path(built):
+    if not os.path.exists(hostlib.HOST_ON_ORACLE):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(hostlib.REPO, "oracle"), "libhost_on_oracle.so"])
+    return hostlib.HOST_ON_ORACLE
+
+
+def _reference_chain(bv, oracle, model_dir, sr, x, block, events):
+    """oracle wrapper (pinned to the reference headers) driving the oracle model through the
+    reference's per-hop protocol."""
+    m = bv.Models(oracle, model_dir)
+    st = bv.Stream1(m, speaker=0, vq_k=0)
+    bins = []
+
+    def hop(in160, out240, _user):
+        o, _, _, _, q2 = st.hop(np.ctypeslib.as_array(in160, (160,)).copy(), return_all=True)
+        bins.append(q2)
+        for i in range(240):
+            out240[i] = o[i]
+
+    wo = wrapperlib.oracle_wrapper()
+    cb = wrapperlib.HOP_FN(hop)
+    p = wo.f_create(float(sr), cb, None)
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros_like(x)
+    for pos in range(0, len(x), block):
+        for at, fn in events:
+            if at == pos:
+                fn(st, wo, p)
+        n = min(block, len(x) - pos)
+        wo.f_process(p, x[pos:pos + n].ctypes.data_as(wrapperlib._f32p), out[pos:pos + n].ctypes.data_as(wrapperlib._f32p), n)
+    wo.f_destroy(p)
+    st.close()
+    m.close()
+    return out, bins
+
+
+@pytest.mark.parametrize("sr,block", [(48000, 480), (44100, 441), (24000, 64), (96000, 1024)])
+def test_process_matches_wrapper_oracle(bv, oracle, host_path, model_dir, sr, block):
+    x = wrapperlib.test_signal(block * max(2, int(0.12 * sr) // block), sr, seed=sr + 1)
+    switch_at = block * (len(x) // block // 2)
+
+    def ev_ref(st, wo, p):
+        st.set_target_speaker(2)
+        st.pitch_params = dict(shift=3.0, correction=0.5, ctype=1)
+        wo.f_out_gain(p, -6.0)
+
+    want, want_bins = _reference_chain(bv, oracle, model_dir, sr, x, block, [(switch_at, ev_ref)])
+    h = hostlib.Host(host_path, sr)
+    assert h.load(model_dir) == 0
+    out_a, codes = h.process(x[:switch_at], block)
+    assert h.call("SetTargetSpeaker", 2) == 0
+    h.call("SetPitchShift", 3.0); h.call("SetPitchCorrection", 0.5); h.call("SetPitchCorrectionType", 1)
+    h.call("SetOutputGain", -6.0)
+    out_b, codes_b = h.process(x[switch_at:], block)
+    got = np.concatenate([out_a, out_b])
+    assert set(codes + codes_b) == {0}
+    assert h.pitch_trace() == want_bins
+    assert np.array_equal(got, want), "max-abs %g" % np.abs(got - want).max()
+    assert np.abs(got).max() > 1e-3
+    h.close()
+
+
+def test_guards_and_error_codes(host_path, model_dir, tmp_path):
+    h = hostlib.Host(host_path, 48000)
+    x = np.ones(100, np.float32)
+    out, codes = h.process(x, 100)
+    assert codes == [9] and not out.any()                 # kModelNotLoaded -> zeros
+    assert h.call("SetTargetSpeaker", 0) == 9             # before LoadModel
+    assert h.call("LoadModel", str(tmp_path / "nothing" / "model.toml").encode()) == 1  # kFileOpenError
+    assert h.load(model_dir) == 0
+    assert h.call("SetTargetSpeaker", 4) == 7             # kSpeakerIDOutOfRange (3 speakers + morph slot 3 are valid)
+    assert h.call("SetTargetSpeaker", 3) == 0
+    assert h.call("SetPitchCorrectionType", 2) == 8       # kInvalidPitchCorrectionType
+    assert h.call("SetSampleRate", 0.0) == 0
+    out, codes = h.process(x, 100)
+    assert codes == [10] and not out.any()                # kResamplerNotReady
+    h.close()
+
+
+def test_reset_context_restarts_the_stream(host_path, model_dir):
+    sr, block = 48000, 480
+    x = wrapperlib.test_signal(block * 12, sr, seed=5)
+    h = hostlib.Host(host_path, sr)
+    assert h.load(model_dir) == 0
+    h.call("SetVQNumNeighbors", 3)
+    first, _ = h.process(x, block)
+    assert h.call("ResetContext") == 0
+    # model state is fresh but the wrapper's FIFO/resampler history is kept, like the reference:
+    # compare only after the wrapper history has been flushed by identical input
+    second, _ = h.process(x, block)
+    h2 = hostlib.Host(host_path, sr)
+    assert h2.load(model_dir) == 0
+    h2.call("SetVQNumNeighbors", 3)
+    fresh, _ = h2.process(x, block)
+    assert np.array_equal(first, fresh)
+    assert np.abs(second[4 * block:] - fresh[4 * block:]).max() < 0.5  # same model state; wrapper tails differ early
+    h.close(); h2.close()
