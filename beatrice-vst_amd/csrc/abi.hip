@@ -54,8 +54,9 @@ Beatrice_ErrorCode read_model_file(const char* path, uint32_t kind, long expect_
 }
 
 template <class Obj>
-static Beatrice_ErrorCode install(Obj* m, const std::vector<float>& host) {
+static Beatrice_ErrorCode install(Obj* m, std::vector<float>& host) {
   m->loaded = false;
+  decltype(m->w)::pack_host(host.data());  // GEMM tensors -> MFMA-fragment order
   if (!m->blob.upload(host.data(), host.size())) return Beatrice_kFileOpenError;  // device failure
   m->w.bind(m->blob.d);
   m->loaded = true;
@@ -281,6 +282,7 @@ Beatrice20rc0_EmbeddingContext* Beatrice20rc0_CreateEmbeddingContext(void) {
   const size_t n = (size_t)B_KV_LEN * B_KV_CH + 4 * B_HID;
   c->ok = make_stream(&c->stream) && hip_ok(hipMalloc(reinterpret_cast<void**>(&c->d_block), sizeof(float) * n), "embed ctx") &&
           hip_ok(hipMemset(c->d_block, 0, sizeof(float) * n), "embed ctx0");
+  (void)hipDeviceSynchronize();  // NULL-stream memset vs the context's non-blocking stream
   c->d_kv_raw = c->d_block;
   c->d_tmp = c->d_block + (size_t)B_KV_LEN * B_KV_CH;
   c->d_add = c->d_tmp + B_HID;

@@ -240,6 +240,7 @@ extern "C" {
                                                    (long)Weights::n_floats(), &host);                       \
     if (e) return e;                                                                                        \
     m->loaded = false;                                                                                      \
+    Weights::pack_host(host.data());                                                                        \
     if (!m->blob.upload(host.data(), host.size())) return Beatrice_kFileOpenError;                          \
     m->w.bind(m->blob.d);                                                                                   \
     m->loaded = true;                                                                                       \
@@ -296,6 +297,7 @@ BeatriceBatch* BeatriceBatch_Create(const Beatrice20rc0_PhoneExtractor* phone, c
        hip_ok(hipEventCreate(&b->ev0), "ev0") && hip_ok(hipEventCreate(&b->ev1), "ev1") && make_stream(&b->side_stream) &&
        hip_ok(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming), "evf") &&
        hip_ok(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming), "evj");
+  ok = ok && hip_ok(hipDeviceSynchronize(), "create sync");  // NULL-stream memsets vs the non-blocking stream
   b->ok = ok;
   if (ok) {
     for (int s = 0; s < B; ++s) sync_stream_arrays(b, s);
@@ -350,7 +352,7 @@ int BeatriceBatch_SetSpeakerTables(BeatriceBatch* b, int n, const float* codeboo
             hip_ok(hipMemcpy(b->d_add_raw, additive, sizeof(float) * n * B_HID, hipMemcpyHostToDevice), "add") &&
             hip_ok(hipMemcpy(b->d_frm_raw, formant, sizeof(float) * 9 * B_HID, hipMemcpyHostToDevice), "frm") &&
             hip_ok(hipMemcpy(b->d_kv_raw, kv, sizeof(float) * n * B_KV_LEN * B_KV_CH, hipMemcpyHostToDevice), "kv");
-  if (!ok) return -2;
+  if (!ok || !hip_ok(hipDeviceSynchronize(), "tables sync")) return -2;
   b->n_speakers = n;
   const EmbedWeights& w = b->embed_m->w;
   embed_project_rows(w.frm_w, w.frm_b, b->d_frm_raw, b->wave.d_frm_tab, 9, b->stream);
@@ -364,7 +366,7 @@ int BeatriceBatch_UpdateSpeaker(BeatriceBatch* b, int spk, const float* codebook
   if (codebook) ok = ok && hip_ok(hipMemcpy(b->d_cb_raw + (size_t)spk * B_CODEBOOK * B_PHONE_CH, codebook, sizeof(float) * B_CODEBOOK * B_PHONE_CH, hipMemcpyHostToDevice), "cb1");
   if (additive) ok = ok && hip_ok(hipMemcpy(b->d_add_raw + (size_t)spk * B_HID, additive, sizeof(float) * B_HID, hipMemcpyHostToDevice), "add1");
   if (kv) ok = ok && hip_ok(hipMemcpy(b->d_kv_raw + (size_t)spk * B_KV_LEN * B_KV_CH, kv, sizeof(float) * B_KV_LEN * B_KV_CH, hipMemcpyHostToDevice), "kv1");
-  if (!ok) return -2;
+  if (!ok || !hip_ok(hipDeviceSynchronize(), "speaker sync")) return -2;
   if (spk >= b->n_speakers) b->n_speakers = spk + 1;
   return project_speakers(b, spk, 1) ? 0 : -2;
 }

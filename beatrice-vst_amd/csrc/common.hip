@@ -1,8 +1,11 @@
 // common.hip -- device memory plumbing shared by the modules: parameter blobs, ring arenas,
 // weight-pointer binding (tensor order of MODEL_SPEC section 5) and the set-time launchers.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
+#include "conv_gemm.hip.h"
 #include "engine.h"
 
 namespace bhip {
@@ -25,6 +28,7 @@ bool DeviceBlob::upload(const float* host, size_t n) {
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), n * sizeof(float)));
   n_floats = n;
   BHIP_TRY(hipMemcpy(d, host, n * sizeof(float), hipMemcpyHostToDevice));
+  BHIP_TRY(hipDeviceSynchronize());
   return true;
 }
 void DeviceBlob::release() {
@@ -163,6 +167,49 @@ void WaveWeights::bind(const float* p) {
   }
   fin_w = p; p += 7 * 16;
   fin_b = p; p += 1;
+}
+
+// ---- host-side repack of GEMM weights into MFMA B-fragment order (conv_gemm.hip.h) -----------
+static void pack_kn(const float* w_const, int K, int N) {
+  float* w = const_cast<float*>(w_const);
+  std::vector<float> tmp((size_t)K * N);
+  for (int kk = 0; kk < K; ++kk)
+    for (int n = 0; n < N; ++n) tmp[packed_w_offset(K, kk, n)] = w[(size_t)kk * N + n];
+  std::copy(tmp.begin(), tmp.end(), w);
+}
+void PhoneWeights::pack_host(float* base) {
+  PhoneWeights w{};
+  w.bind(base);
+  for (int i = 1; i < 5; ++i) pack_kn(w.f_w[i - 1], kPhoneF[i][0] * kPhoneF[i][2], kPhoneF[i][1]);
+  for (int i = 0; i < 4; ++i) pack_kn(w.rb_w[i], 5 * 256, 256);
+  pack_kn(w.gru_wih, 256, 768);
+  pack_kn(w.gru_whh, 256, 768);
+  pack_kn(w.out_w, 256, B_PHONE_CH);
+}
+void PitchWeights::pack_host(float* base) {
+  PitchWeights w{};
+  w.bind(base);
+  pack_kn(w.p_w[0], 3 * B_SPEC_BINS, 128);
+  pack_kn(w.p_w[1], 3 * 128, 128);
+  pack_kn(w.p_w[2], 3 * 128, 128);
+  pack_kn(w.gru_wih, 128, 384);
+  pack_kn(w.gru_whh, 128, 384);
+  pack_kn(w.out_w, 128, B_PITCH_BINS);
+}
+void WaveWeights::pack_host(float* base) {
+  WaveWeights w{};
+  w.bind(base);
+  pack_kn(w.inp_w, B_PHONE_CH, B_HID);
+  for (int b = 0; b < B_NBLOCKS; ++b) {
+    pack_kn(w.c1_w[b], 3 * B_HID, B_HID);
+    pack_kn(w.c2_w[b], B_HID, B_HID);
+    pack_kn(w.q_w[b], B_HID, B_HID);
+    pack_kn(w.o_w[b], B_HID, B_HID);
+  }
+  pack_kn(w.up_w[0], 2 * 256, 5 * 128);
+  pack_kn(w.ra_w[0], 3 * 128, 128);
+  pack_kn(w.rb_w[0], 3 * 128, 128);
+  pack_kn(w.up_w[1], 2 * 128, 4 * 64);
 }
 
 // ---- set-time launchers ------------------------------------------------------------------------

@@ -16,17 +16,28 @@
 // Tiling: a workgroup of LM x LN wavefronts, each wavefront owning WM x WN MFMA tiles of 16x16.
 // A tile rows are gathered from the ring in 16-byte pieces (a row's KC channels are contiguous),
 // W tiles are read as coalesced float4 rows; both go through padded LDS so that the MFMA operand
-// reads (ds_read_b32, lane -> [row l&15][k l>>4]) are bank-conflict free:
-//   A stride KC+2  -> banks 2*i + k   distinct over a 32-lane group
-//   W stride == 16 (mod 32) -> banks 16*k + j distinct over a 32-lane group
+// reads (ds_read_b32, lane -> [row l&15][k l>>4]) are bank-conflict free (A stride KC+2 -> banks
+// 2*i + k distinct over a 32-lane group).  W never touches LDS: see "PRE-PACKED" below.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include "engine.h"
 #include "ring.h"
 #include "spec_math.hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// GEMM weights are stored on the device PRE-PACKED in MFMA B-fragment order (done once on the host
+// at Read*Parameters, csrc/common.hip pack_kn): for column tile nt (16 columns) and k-block kb
+// (16 reduction indices = four 16x16x4 steps) one 1 KiB record of 64 lanes x float4, where lane
+// (j = l&15, kq = l>>4) holds W[kb*16 + 4e + kq][nt*16 + j] for e = 0..3.  A wavefront therefore
+// fetches the B operands of four MFMA steps with ONE fully coalesced 16-byte-per-lane load straight
+// into registers: no LDS staging, no transposition, no bank conflicts for W.
+__host__ __device__ inline size_t packed_w_offset(int K, int kk, int n) {
+  return ((((size_t)(n >> 4) * (K >> 4) + (kk >> 4)) * 64 + ((kk & 3) << 4) + (n & 15)) << 2) + ((kk & 15) >> 2);
+}
 
 enum { PRE_NONE = 0, PRE_LRELU = 1 };
 enum { ACT_NONE = 0, ACT_GELU = 1 };
@@ -72,20 +83,19 @@ struct TileCfg {
   static constexpr int MT = 16 * WM * LM, NT = 16 * WN * LN;
   static constexpr int GTHR = 64 * LM * LN;  // threads per k-group
   static constexpr int NTHR = GTHR * LK;
-  static constexpr int WS = NT + ((NT % 32 == 16) ? 0 : 16);
 };
 
 template <class L, class TC>
 __global__ __launch_bounds__(TC::NTHR) void conv_gemm_kernel(const ConvArgs a) {
-  constexpr int KC = L::KC, AS = KC + 2, WS = TC::WS, MT = TC::MT, NT = TC::NT, GTHR = TC::GTHR, LK = TC::LK;
+  constexpr int KC = L::KC, AS = KC + 2, MT = TC::MT, NT = TC::NT, GTHR = TC::GTHR, LK = TC::LK;
   constexpr int P = L::P;
   static_assert(LK == 1 || LK == P, "k-groups: one group for all segments, or one group per segment");
   constexpr int PG = (P + LK - 1) / LK;  // segments (accumulator sets) per group
   constexpr int A_F4_PER_ROW = KC / 4;
   constexpr int A_SLOTS = (MT * A_F4_PER_ROW + GTHR - 1) / GTHR;
-  constexpr int W_F4_PER_ROW = NT / 4;
-  constexpr int W_SLOTS = (KC * W_F4_PER_ROW + GTHR - 1) / GTHR;
-  constexpr int STAGE_FLOATS = MT * AS + KC * WS;  // per k-group
+  constexpr int KB = KC / 16;               // packed k-blocks per chunk
+  constexpr int STAGE_FLOATS = MT * AS;     // per k-group (only A goes through LDS)
+  static_assert(KC % 16 == 0 && L::K % 16 == 0, "packed weights need K in blocks of 16");
   constexpr int RED_FLOATS = LK > 1 ? P * MT * NT : 0;
   constexpr int LDS_FLOATS = STAGE_FLOATS * LK > RED_FLOATS ? STAGE_FLOATS * LK : RED_FLOATS;
   static_assert(L::NOUT % NT == 0, "N tile must divide NOUT");
@@ -101,7 +111,6 @@ __global__ __launch_bounds__(TC::NTHR) void conv_gemm_kernel(const ConvArgs a) {
   const int m0 = blockIdx.x * MT, n0 = blockIdx.y * NT;
   const int M = a.B * L::T;
   float* As = lds + grp * STAGE_FLOATS;
-  float* Ws = As + MT * AS;
 
   const float* wbase = a.w;
   if constexpr (L::GROUPED) {
@@ -140,7 +149,9 @@ __global__ __launch_bounds__(TC::NTHR) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
       for (int j = 0; j < TC::WN; ++j) acc[g][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  float4 areg[A_SLOTS], wreg[W_SLOTS];
+  float4 areg[A_SLOTS];
+  float4 bnext[TC::WN][KB], bcur[TC::WN][KB];
+  const float4* wfrag = reinterpret_cast<const float4*>(wbase) + (size_t)((n0 + wave_n) >> 4) * (L::K >> 4) * 64 + lane;
   // chunk `it` of this group: LK == 1 -> global chunk it; LK == P -> chunk it of segment grp
   auto load_chunk = [&](int it) {
     const int ch = LK == 1 ? it : grp * L::CHUNKS_PER_SEG + it;
@@ -158,15 +169,14 @@ __global__ __launch_bounds__(TC::NTHR) void conv_gemm_kernel(const ConvArgs a) {
       }
       areg[s] = v;
     }
-    const float* wsrc = wbase + (size_t)kk0 * L::NOUT + n0;
 #pragma unroll
-    for (int s = 0; s < W_SLOTS; ++s) {
-      const int idx = gtid + s * GTHR;
-      const int r = idx / W_F4_PER_ROW, q = idx % W_F4_PER_ROW;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (live && r < KC) v = *reinterpret_cast<const float4*>(wsrc + (size_t)r * L::NOUT + 4 * q);
-      wreg[s] = v;
-    }
+    for (int jn = 0; jn < TC::WN; ++jn)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const int kbg = live ? (kk0 >> 4) + kb : 0;
+        const float4 f = wfrag[((size_t)jn * (L::K >> 4) + kbg) * 64];
+        bnext[jn][kb] = live ? f : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
   };
   auto store_chunk = [&]() {
 #pragma unroll
@@ -184,11 +194,9 @@ __global__ __launch_bounds__(TC::NTHR) void conv_gemm_kernel(const ConvArgs a) {
       }
     }
 #pragma unroll
-    for (int s = 0; s < W_SLOTS; ++s) {
-      const int idx = gtid + s * GTHR;
-      const int r = idx / W_F4_PER_ROW, q = idx % W_F4_PER_ROW;
-      if (r < KC) *reinterpret_cast<float4*>(&Ws[r * WS + 4 * q]) = wreg[s];
-    }
+    for (int jn = 0; jn < TC::WN; ++jn)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) bcur[jn][kb] = bnext[jn][kb];
   };
 
   constexpr int N_IT = LK == 1 ? L::NCHUNK : (L::CHUNKS_PER_SEG < L::NCHUNK ? L::CHUNKS_PER_SEG : L::NCHUNK);
@@ -209,7 +217,10 @@ __global__ __launch_bounds__(TC::NTHR) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < TC::WM; ++i) av[i] = As[(wave_m + i * 16 + (lane & 15)) * AS + ks * 4 + (lane >> 4)];
 #pragma unroll
-        for (int jn = 0; jn < TC::WN; ++jn) bv[jn] = Ws[(ks * 4 + (lane >> 4)) * WS + wave_n + jn * 16 + (lane & 15)];
+        for (int jn = 0; jn < TC::WN; ++jn) {
+          const float4 f = bcur[jn][ks >> 2];
+          bv[jn] = (ks & 3) == 0 ? f.x : ((ks & 3) == 1 ? f.y : ((ks & 3) == 2 ? f.z : f.w));
+        }
 #pragma unroll
         for (int i = 0; i < TC::WM; ++i)
 #pragma unroll
@@ -331,14 +342,16 @@ __global__ __launch_bounds__(64 * LN * L::P) void lat_gemm_kernel(const ConvArgs
     wbase += (size_t)slot * a.w_slot_stride;
   }
 
-  // ---- W fragment -> registers (independent of the hop counter)
+  // ---- W fragment -> registers (independent of the hop counter): 16 coalesced float4 loads
   float breg[SEG / 4];
   {
-    const float* wp = wbase + (size_t)(kk0 + (lane >> 4)) * L::NOUT + n0 + wave * 16 + (lane & 15);
+    const float4* wp = reinterpret_cast<const float4*>(wbase) + ((size_t)((n0 + wave * 16) >> 4) * (L::K >> 4) + (kk0 >> 4)) * 64 + lane;
 #pragma unroll
-    for (int ks = 0; ks < SEG / 4; ++ks) {
-      const bool live = kk0 + 4 * ks < L::K;
-      breg[ks] = (live && !(ABL & 1)) ? wp[(size_t)(4 * ks) * L::NOUT] : 0.0f;
+    for (int kb = 0; kb < SEG / 16; ++kb) {
+      const bool live = kk0 + 16 * kb < L::K && !(ABL & 1);
+      const float4 f = wp[(size_t)(live ? kb : 0) * 64];
+      breg[4 * kb + 0] = live ? f.x : 0.f; breg[4 * kb + 1] = live ? f.y : 0.f;
+      breg[4 * kb + 2] = live ? f.z : 0.f; breg[4 * kb + 3] = live ? f.w : 0.f;
     }
   }
 
@@ -509,8 +522,13 @@ static inline void launch_auto(const char* name, const ConvArgs& a, hipStream_t 
   //  7.2 vs 5.0 us for a 256->256 linear at B = 256, profiles/r01_notes.md -- because its 64 dword
   //  W loads per lane serialise ahead of the MFMA chain; it stays for the grouped attention GEMMs and
   //  as the base for a pre-packed-weights variant.)
-  if (a.B * L::T <= 2048) launch_conv<L, TLat<L>>(name, a, 0, s);
-  else launch_conv<L, TL>(name, a, 0, s);
+  static const bool single_shot = std::getenv("BEATRICE_HIP_LAT") != nullptr;  // A/B switch for experiments
+  if (a.B * L::T <= 2048) {
+    if (single_shot) launch_lat<L, 2>(name, a, 0, s);
+    else launch_conv<L, TLat<L>>(name, a, 0, s);
+  } else {
+    launch_conv<L, TL>(name, a, 0, s);
+  }
 }
 
 static inline ConvArgs conv_args(const Ring& in, const Ring& out, const float* w, const float* b, const int* hop, int B) {

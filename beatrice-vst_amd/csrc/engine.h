@@ -70,6 +70,7 @@ struct PhoneWeights {
   const float *gru_wih, *gru_whh, *gru_bih, *gru_bhh, *out_w, *out_b;
   static size_t n_floats();
   void bind(const float* base);
+  static void pack_host(float* base);  // GEMM tensors -> MFMA-fragment order (conv_gemm.hip.h), in place
 };
 struct PhoneState {
   int B = 0;
@@ -96,6 +97,7 @@ struct PitchWeights {
   const float *gru_wih, *gru_whh, *gru_bih, *gru_bhh, *out_w, *out_b, *voi_w, *voi_b;
   static size_t n_floats();
   void bind(const float* base);
+  static void pack_host(float* base);
 };
 struct PitchState {
   int B = 0;
@@ -120,6 +122,7 @@ struct EmbedWeights {
   const float *k_w[B_NBLOCKS], *k_b[B_NBLOCKS], *v_w[B_NBLOCKS], *v_b[B_NBLOCKS];
   static size_t n_floats();
   void bind(const float* base);
+  static void pack_host(float*) {}  // set-time kernels read plain [K][N]
 };
 
 // ---- waveform generator ------------------------------------------------------------------------
@@ -131,6 +134,7 @@ struct WaveWeights {
   const float *fin_w, *fin_b;
   static size_t n_floats();
   void bind(const float* base);
+  static void pack_host(float* base);  // layers run by conv_gemm only; the fused tail keeps [K][N]
 };
 struct WaveState {
   int B = 0;

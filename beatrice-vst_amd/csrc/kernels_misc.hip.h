@@ -368,7 +368,11 @@ static __global__ void dense_rows_kernel(const float* __restrict__ x, const floa
   y[idx] = acc + bias[n];
 }
 
-// K^T[c][j] and V[j][c] of one block for `slots` raw embeddings: grid (384, slots), 256 threads.
+__device__ __forceinline__ size_t packed_w_offset_dev(int K, int kk, int n) {
+  return ((((size_t)(n >> 4) * (K >> 4) + (kk >> 4)) * 64 + ((kk & 3) << 4) + (n & 15)) << 2) + ((kk & 15) >> 2);
+}
+// K^T (k = channel, n = token) and V (k = token, n = channel) of one block for `slots` raw embeddings:
+// grid (384, slots), 256 threads.
 static __global__ __launch_bounds__(256) void kv_project_kernel(const float* __restrict__ kv_raw,
                                                          const float* __restrict__ kw, const float* __restrict__ kb,
                                                          const float* __restrict__ vw, const float* __restrict__ vb,
@@ -382,8 +386,11 @@ static __global__ __launch_bounds__(256) void kv_project_kernel(const float* __r
     ak = bsp::fma(row[e], kw[e * B_HID + c], ak);
     av = bsp::fma(row[e], vw[e * B_HID + c], av);
   }
-  kt[(size_t)slot * B_HID * B_KV_LEN + (size_t)c * B_KV_LEN + j] = ak + kb[c];
-  v[(size_t)slot * B_KV_LEN * B_HID + (size_t)j * B_HID + c] = av + vb[c];
+  // both tables are GEMM "weights" of the attention products and are written in MFMA B-fragment
+  // order (conv_gemm.hip.h packed_w_offset): scores = q . K^T has (k = channel c, n = token j),
+  // P . V has (k = token j, n = channel c)
+  kt[(size_t)slot * B_HID * B_KV_LEN + packed_w_offset_dev(B_HID, c, j)] = ak + kb[c];
+  v[(size_t)slot * B_KV_LEN * B_HID + packed_w_offset_dev(B_KV_LEN, j, c)] = av + vb[c];
 }
 
 // codebook [512][128] -> transposed [128][512] + squared norms; grid = n codebooks, 512 threads.

@@ -28,6 +28,9 @@ bool PhoneState::create(int B_, float* shared_in) {
   BHIP_TRY(hipMemset(d_vqk, 0, sizeof(int) * B));
   BHIP_TRY(hipMemset(d_hop, 0, sizeof(int)));
   hop = d_hop;
+  // hipMemset is asynchronous and runs on the NULL stream, which the (non-blocking) compute streams
+  // do not wait for: make every initialisation above visible before the first kernel can start
+  BHIP_TRY(hipDeviceSynchronize());
   return true;
 }
 void PhoneState::destroy() {

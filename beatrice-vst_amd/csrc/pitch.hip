@@ -37,6 +37,9 @@ bool PitchState::create(int B_, float* shared_in, bool with_params) {
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hop), sizeof(int)));
   BHIP_TRY(hipMemset(d_hop, 0, sizeof(int)));
   hop = d_hop;
+  // hipMemset is asynchronous and runs on the NULL stream, which the (non-blocking) compute streams
+  // do not wait for: make every initialisation above visible before the first kernel can start
+  BHIP_TRY(hipDeviceSynchronize());
   return true;
 }
 void PitchState::destroy() {

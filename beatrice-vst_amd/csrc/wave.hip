@@ -65,6 +65,9 @@ bool WaveState::create(int B_, int n_slots_, int n_add_, int n_frm_, float* shar
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hop), sizeof(int)));
   BHIP_TRY(hipMemset(d_hop, 0, sizeof(int)));
   hop = d_hop;
+  // hipMemset is asynchronous and runs on the NULL stream, which the (non-blocking) compute streams
+  // do not wait for: make every initialisation above visible before the first kernel can start
+  BHIP_TRY(hipDeviceSynchronize());
   return true;
 }
 void WaveState::destroy() {
