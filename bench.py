@@ -70,8 +70,8 @@ def cpu_baseline(bv, model_dir, seconds):
     one = []
     run(hops, 1, one)
     single = hops / one[0]
-    cores = os.cpu_count() or 1
-    hops_mt = max(50, hops // 2)
+    cores = min(os.cpu_count() or 1, 32)  # python threads (ctypes releases the GIL inside the oracle); bounded
+    hops_mt = max(50, hops // 8)
     outs, threads = [], []
     t0 = time.perf_counter()
     for c in range(cores):
