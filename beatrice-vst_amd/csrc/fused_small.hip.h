@@ -1,0 +1,188 @@
+// fused_small.hip.h -- two launch-count reductions for the few-row part of the chain
+// (profiles/r01_notes.md: at B = 256 every launch costs >= ~4 us whatever it computes).
+//
+//  * gru_fused_kernel: both gate GEMMs (x.Wih, h.Whh) and the gate math of a GRU cell in one
+//    launch (was 3).  Workgroup = 16 streams x 16 hidden units, six wavefronts = {x,h} x {r,z,n};
+//    each wavefront runs one 16x16 MFMA chain over K <= 256 (a single MODEL_SPEC 2.2 segment) with
+//    B fragments straight from the pre-packed weights and A from an LDS tile; the six partial tiles
+//    meet in LDS and 256 threads apply the gates.
+//  * attn_pv_kernel: softmax statistics + P.V product + 1/sum scaling in one launch (was 2).
+//    Workgroup = 16 streams (one K/V slot) x 32 channels, two k-groups (keys 0..255 | 256..383);
+//    every workgroup recomputes the 16 x 384 exponentials of its rows (24 per thread) instead of
+//    reading them back from a separate launch.
+// Arithmetic and its order are exactly those of the unfused kernels (conv_gemm + gru_gate_kernel,
+// attn_softmax_kernel + conv_gemm<PV>), so results stay bit-identical to the oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "conv_gemm.hip.h"
+
+struct GruArgs {
+  Ring x, h;                  // x: C = IN, n = 1; h: C = H, n = 1, m = 2 (previous state = frame -1)
+  const float *wih, *whh;     // packed [IN][3H], [H][3H]
+  const float *bih, *bhh;     // [3H]
+  const int* hop;
+  int B;
+};
+
+template <int IN, int H>
+static __global__ __launch_bounds__(384) void gru_fused_kernel(const GruArgs a) {
+  constexpr int XS = IN + 2, HS = H + 2;
+  __shared__ __attribute__((aligned(16))) float lds[16 * XS + 16 * HS + 6 * 256];
+  float* xs = lds;
+  float* hs = lds + 16 * XS;
+  float* g6 = hs + 16 * HS;  // [src][gate][16][16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int src = wave / 3, gate = wave % 3;
+  const int b0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
+  constexpr int K = IN > H ? IN : H;
+  (void)K;
+
+  // B fragment of this wave: packed weights, column tile (gate*H + j0)/16, all k-blocks
+  constexpr int KB_X = IN / 16, KB_H = H / 16;
+  float4 bf[(KB_X > KB_H ? KB_X : KB_H)];
+  {
+    const int kbn = src == 0 ? KB_X : KB_H;
+    const float4* wp = reinterpret_cast<const float4*>(src == 0 ? a.wih : a.whh) + (size_t)((gate * H + j0) >> 4) * kbn * 64 + lane;
+#pragma unroll
+    for (int kb = 0; kb < (KB_X > KB_H ? KB_X : KB_H); ++kb) bf[kb] = wp[(size_t)(kb < kbn ? kb : 0) * 64];
+  }
+  const int hop = *a.hop;
+  const int px = ring_pos(a.x, hop), ph = ring_pos(a.h, hop);
+  // A tiles -> LDS
+  for (int e = tid; e < 16 * (IN / 4); e += 384) {
+    const int r = e / (IN / 4), q = e % (IN / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b0 + r < a.B) v = *reinterpret_cast<const float4*>(ring_frame(a.x, b0 + r, px, 0) + 4 * q);
+    float2* d = reinterpret_cast<float2*>(&xs[r * XS + 4 * q]);
+    d[0] = make_float2(v.x, v.y); d[1] = make_float2(v.z, v.w);
+  }
+  for (int e = tid; e < 16 * (H / 4); e += 384) {
+    const int r = e / (H / 4), q = e % (H / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b0 + r < a.B) v = *reinterpret_cast<const float4*>(ring_frame(a.h, b0 + r, ph, -1) + 4 * q);
+    float2* d = reinterpret_cast<float2*>(&hs[r * HS + 4 * q]);
+    d[0] = make_float2(v.x, v.y); d[1] = make_float2(v.z, v.w);
+  }
+  __syncthreads();
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (src == 0) {
+    const float* ap = xs + (lane & 15) * XS + (lane >> 4);
+#pragma unroll
+    for (int ks = 0; ks < IN / 4; ++ks) {
+      const float4 f = bf[ks >> 2];
+      const float bv = (ks & 3) == 0 ? f.x : ((ks & 3) == 1 ? f.y : ((ks & 3) == 2 ? f.z : f.w));
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * ks], bv, acc, 0, 0, 0);
+    }
+  } else {
+    const float* ap = hs + (lane & 15) * HS + (lane >> 4);
+#pragma unroll
+    for (int ks = 0; ks < H / 4; ++ks) {
+      const float4 f = bf[ks >> 2];
+      const float bv = (ks & 3) == 0 ? f.x : ((ks & 3) == 1 ? f.y : ((ks & 3) == 2 ? f.z : f.w));
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * ks], bv, acc, 0, 0, 0);
+    }
+  }
+  {
+    const float bias = (src == 0 ? a.bih : a.bhh)[gate * H + j0 + (lane & 15)];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g6[(wave * 16 + (lane >> 4) * 4 + e) * 16 + (lane & 15)] = acc[e] + bias;
+  }
+  __syncthreads();
+  if (tid < 256) {
+    const int r = tid >> 4, j = tid & 15;
+    if (b0 + r < a.B) {
+      const float gi_r = g6[(0 * 16 + r) * 16 + j], gi_z = g6[(1 * 16 + r) * 16 + j], gi_n = g6[(2 * 16 + r) * 16 + j];
+      const float gh_r = g6[(3 * 16 + r) * 16 + j], gh_z = g6[(4 * 16 + r) * 16 + j], gh_n = g6[(5 * 16 + r) * 16 + j];
+      const float rr = bsp::sigmoid(gi_r + gh_r);
+      const float zz = bsp::sigmoid(gi_z + gh_z);
+      const float nn = bsp::tanh(bsp::fma(rr, gh_n, gi_n));
+      const float hp = hs[r * HS + j0 + j];
+      ring_frame(a.h, b0 + r, ph, 0)[j0 + j] = bsp::fma(zz, hp - nn, nn);
+    }
+  }
+}
+
+template <int IN, int H>
+static inline void launch_gru(const char* name, const GruArgs& a, hipStream_t stream) {
+  const bhip::LaunchInfo info{name, 2.0 * a.B * (IN + H) * 3.0 * H, 4.0 * ((IN + H) * 3.0 * H + a.B * (IN + 2.0 * H))};
+  bhip::launch_site(info, stream, [&] {
+    hipLaunchKernelGGL((gru_fused_kernel<IN, H>), dim3((a.B + 15) / 16, H / 16), dim3(384), 0, stream, a);
+  });
+}
+
+// ---------------------------------------------------------------------------------------------
+struct AttnPvArgs {
+  const float* scores;   // [B][384], already scaled by 1/16
+  const float* v;        // packed V tables, slot stride 384*256
+  float* out;            // [B][256]
+  const int* perm;       // [n_tiles][16]
+  const int* tile_slot;  // [n_tiles]
+};
+
+static __global__ __launch_bounds__(256) void attn_pv_kernel(const AttnPvArgs a) {
+  constexpr int KL = B_KV_LEN, AS = KL + 2, NT = 32;
+  __shared__ __attribute__((aligned(16))) float lds[16 * AS + 16 + 2 * 16 * NT];
+  float* es = lds;               // exp(s - max), [16][386]
+  float* inv = lds + 16 * AS;    // [16]
+  float* red = inv + 16;         // [2][16][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 1, wn = wave & 1;
+  const int slot = a.tile_slot[blockIdx.x];
+  if (slot < 0) return;
+  const int n0 = blockIdx.y * NT;
+  // B fragments of this wave: segment grp (keys 0..255 or 256..383), column tile (n0 + wn*16)/16
+  float4 bf[16];
+  {
+    const float4* vp = reinterpret_cast<const float4*>(a.v + (size_t)slot * KL * B_HID) +
+                       ((size_t)((n0 + wn * 16) >> 4) * (KL >> 4) + grp * 16) * 64 + lane;
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) bf[kb] = vp[(size_t)((grp == 0 || kb < 8) ? kb : 0) * 64];
+  }
+  // softmax statistics, 4 rows per wavefront (MODEL_SPEC 4.4.2: same order as attn_softmax_kernel)
+#pragma unroll 1
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = wave * 4 + rr;
+    const int b = a.perm[blockIdx.x * 16 + r];
+    float v[6];
+    float mx = -__builtin_huge_valf();
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { v[i] = b >= 0 ? a.scores[(size_t)b * KL + lane + 64 * i] : 0.0f; mx = fmaxf(mx, v[i]); }
+    mx = bsp::wmax64(mx);
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { v[i] = bsp::exp(v[i] - mx); s = s + v[i]; es[r * AS + lane + 64 * i] = v[i]; }
+    const float tot = bsp::wsum64(s);
+    if (lane == 0) inv[r] = 1.0f / tot;
+  }
+  __syncthreads();
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  {
+    const float* ap = es + (lane & 15) * AS + grp * 256 + (lane >> 4);
+    if (grp == 0) {
+#pragma unroll
+      for (int ks = 0; ks < 64; ++ks) {
+        const float4 f = bf[ks >> 2];
+        const float bv = (ks & 3) == 0 ? f.x : ((ks & 3) == 1 ? f.y : ((ks & 3) == 2 ? f.z : f.w));
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * ks], bv, acc, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 32; ++ks) {
+        const float4 f = bf[ks >> 2];
+        const float bv = (ks & 3) == 0 ? f.x : ((ks & 3) == 1 ? f.y : ((ks & 3) == 2 ? f.z : f.w));
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * ks], bv, acc, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[(grp * 16 + (lane >> 4) * 4 + e) * NT + wn * 16 + (lane & 15)] = acc[e];
+  __syncthreads();
+  for (int idx = tid; idx < 16 * NT; idx += 256) {
+    const int r = idx / NT, n = n0 + idx % NT;
+    const int b = a.perm[blockIdx.x * 16 + r];
+    if (b < 0) continue;
+    const float v = red[idx] + red[16 * NT + idx];  // segment 0 + segment 1 (MODEL_SPEC 2.2)
+    a.out[(size_t)b * B_HID + n] = v * inv[r];
+  }
+}

@@ -2,6 +2,7 @@
 // Beatrice20rc0_ExtractPhone1 (reference lib/beatricelib/beatrice.h:243-247) for B streams.
 #include "conv_gemm.hip.h"
 #include "engine.h"
+#include "fused_small.hip.h"
 
 namespace bhip {
 
@@ -70,12 +71,8 @@ void phone_forward(const PhoneWeights& w, const PhoneState& s, hipStream_t st) {
     launch_auto<RBL>("phone.rb", conv_args(*cur, s.rb[i], w.rb_w[i], w.rb_b[i], s.hop, B), st);
     cur = &s.rb[i];
   }
-  launch_auto<GATE>("phone.gru_gi", conv_args(*cur, s.gi, w.gru_wih, w.gru_bih, s.hop, B), st);
-  ConvArgs gh = conv_args(s.h, s.gh, w.gru_whh, w.gru_bhh, s.hop, B);
-  gh.rel_shift = -1;  // previous hidden state
-  launch_auto<GATE>("phone.gru_gh", gh, st);
-  MISC_LAUNCH("phone.gru_gate", 30.0 * B * 256, 4.0 * B * 256 * 8, gru_gate_kernel, dim3((B * 256 + 255) / 256), dim3(256),
-              s.gi.base, s.gh.base, s.h, 256, B, s.hop);
+  GruArgs ga{*cur, s.h, w.gru_wih, w.gru_whh, w.gru_bih, w.gru_bhh, s.hop, B};
+  launch_gru<256, 256>("phone.gru", ga, st);
   launch_auto<OUTL>("phone.out", conv_args(s.h, s.raw, w.out_w, w.out_b, s.hop, B), st);
   VqArgs v{s.raw.base, s.d_phone, s.d_cbT, s.d_cnorm, s.d_vqk};
   MISC_LAUNCH("phone.vq", 2.0 * B * 512 * 128, 4.0 * (B * 256 + 512 * 129), phone_vq_kernel, dim3(B), dim3(512), v);

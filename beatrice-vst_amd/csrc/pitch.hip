@@ -2,6 +2,7 @@
 // Beatrice20rc0_EstimatePitch1 (reference lib/beatricelib/beatrice.h:266-271) for B streams.
 #include "conv_gemm.hip.h"
 #include "engine.h"
+#include "fused_small.hip.h"
 
 namespace bhip {
 
@@ -66,12 +67,8 @@ void pitch_forward(const PitchWeights& w, const PitchState& s, hipStream_t st) {
   launch_auto<P1>("pitch.p1", conv_args(s.spec, s.p[0], w.p_w[0], w.p_b[0], s.hop, B), st);
   launch_auto<P23>("pitch.p23", conv_args(s.p[0], s.p[1], w.p_w[1], w.p_b[1], s.hop, B), st);
   launch_auto<P23>("pitch.p23", conv_args(s.p[1], s.p[2], w.p_w[2], w.p_b[2], s.hop, B), st);
-  launch_auto<PGATE>("pitch.gru_gi", conv_args(s.p[2], s.gi, w.gru_wih, w.gru_bih, s.hop, B), st);
-  ConvArgs gh = conv_args(s.h, s.gh, w.gru_whh, w.gru_bhh, s.hop, B);
-  gh.rel_shift = -1;
-  launch_auto<PGATE>("pitch.gru_gh", gh, st);
-  MISC_LAUNCH("pitch.gru_gate", 30.0 * B * 128, 4.0 * B * 128 * 8, gru_gate_kernel, dim3((B * 128 + 255) / 256), dim3(256),
-              s.gi.base, s.gh.base, s.h, 128, B, s.hop);
+  GruArgs ga{s.p[2], s.h, w.gru_wih, w.gru_whh, w.gru_bih, w.gru_bhh, s.hop, B};
+  launch_gru<128, 128>("pitch.gru", ga, st);
   launch_auto<POUT>("pitch.out", conv_args(s.h, s.logits, w.out_w, w.out_b, s.hop, B), st);
   PitchHeadArgs a{s.logits.base, s.h, s.d_in, w.voi_w, w.voi_b, s.d_min_q, s.d_max_q, s.d_prev_q,
                   s.d_q_raw, s.d_q, s.d_feat, s.d_params, s.hop};

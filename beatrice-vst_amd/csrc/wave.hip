@@ -2,6 +2,7 @@
 // Beatrice20rc0_GenerateWaveform1 (reference lib/beatricelib/beatrice.h:301-307) for B streams.
 #include "conv_gemm.hip.h"
 #include "engine.h"
+#include "fused_small.hip.h"
 #include "wave_tail.hip.h"
 
 namespace bhip {
@@ -127,11 +128,9 @@ void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t st) {
     a.scale = 0.0625f; a.perm = s.d_perm[blk]; a.tile_slot = s.d_tile_slot[blk];
     a.w_slot_stride = (size_t)B_HID * B_KV_LEN;
     launch_conv<SCORE, TGQ>("wave.blk.attn_qk", a, s.n_tiles_max, st);
-    MISC_LAUNCH("wave.blk.softmax", 25.0 * B * 384, 8.0 * B * 384, attn_softmax_kernel, dim3(B), dim3(64), s.sc.base, s.d_inv, B);
-    a = conv_args(s.sc, s.o, s.d_v[blk], nullptr, s.hop, B);
-    a.rowscale = s.d_inv; a.perm = s.d_perm[blk]; a.tile_slot = s.d_tile_slot[blk];
-    a.w_slot_stride = (size_t)B_KV_LEN * B_HID;
-    launch_conv<PV, TGV>("wave.blk.attn_pv", a, s.n_tiles_max, st);
+    AttnPvArgs pa{s.sc.base, s.d_v[blk], s.o.base, s.d_perm[blk], s.d_tile_slot[blk]};
+    MISC_LAUNCH("wave.blk.attn_pv", 2.0 * B * 384 * 256 + 25.0 * B * 384 * 8, 4.0 * (384.0 * 256 + B * (384 * 8 + 256)), attn_pv_kernel,
+                dim3(s.n_tiles_max, B_HID / 32), dim3(256), pa);
     a = conv_args(s.o, s.x[blk + 1], w.o_w[blk], w.o_b[blk], s.hop, B);
     a.res = s.xa;
     launch_auto<C2>("wave.blk.o", a, st);
