@@ -50,6 +50,34 @@ def load_shard():
     return mod
 
 
+# launch name (BeatriceBatch_ProfileKernels) -> substring of the kernel symbol in the rocprofv3 PMC summary
+PMC_SYMBOL = {
+    "phone.rb": "Layer<256, 256, 5, 1, 1, 1, 0, 1, 0, true, false>",
+    "wave.tail": "wave_tail_kernel",
+    "phone.gru": "gru_fused_kernel<256, 256>",
+    "wave.blk.c1": "Layer<256, 256, 3, 1, 1, 1, 0, 1, 0, false, false>",
+    "wave.blk.attn_pv": "attn_pv_kernel",
+    "wave.up1": "Layer<256, 640, 2, 1, 1, 1, 1, 0, 0, false, false>",
+}
+
+
+def pmc_traffic(kernel_name, streams):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/r*_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this bench at B = 256,
+    FETCH_SIZE doubled per the gfx950 correction).  None when no matching measurement exists."""
+    if streams != 256 or kernel_name not in PMC_SYMBOL:
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    kernels = json.load(open(files[-1]))["kernels"]
+    for sym, rec in kernels.items():
+        if PMC_SYMBOL[kernel_name] in sym:
+            return rec["hbm_bytes_per_launch"]
+    return None
+
+
 def cpu_baseline(bv, model_dir, seconds):
     """Oracle through the same per-hop protocol: 1 stream on 1 core, then 1 stream per core."""
     oracle = bv.Abi(os.path.join(REPO, "oracle", "libbeatrice_oracle.so"))
@@ -229,7 +257,8 @@ def main():
                 ach = dom["bytes"] / (dom["mean_us"] * 1e-6) / 1e9
                 roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(ach / PEAK_HBM_GBS, 4)}
-            roof.update({"traffic": None, "kernel": dom["name"], "launches_per_hop": dom["launches"],
+            roof.update({"traffic": pmc_traffic(dom["name"], B), "traffic_unit": "bytes per launch (PMC, profiles/)",
+                         "algorithmic_bytes": int(dom["bytes"]), "algorithmic_flops": int(dom["flops"]), "kernel": dom["name"], "launches_per_hop": dom["launches"],
                          "mean_us_per_launch": round(dom["mean_us"], 2),
                          "share_of_chain": round(dom["total_us"] / total_us, 3)})
             res["roofline"] = roof
