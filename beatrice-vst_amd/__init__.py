@@ -273,6 +273,8 @@ _BATCH = {
     "BeatriceBatch_ResetStream": (C.c_int, [_vp, C.c_int]),
     "BeatriceBatch_ConvertFrames": (C.c_int, [_vp, _f32p, _f32p]),
     "BeatriceBatch_ConvertFramesDevice": (C.c_int, [_vp, _vp, _vp]),
+    "BeatriceBatch_ConvertBlocks48k": (C.c_int, [_vp, _f32p, _f32p, C.c_int]),
+    "BeatriceBatch_ConvertBlocks48kDevice": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "BeatriceBatch_Synchronize": (C.c_int, [_vp]),
     "BeatriceBatch_SetStream": (C.c_int, [_vp, _vp]),
     "BeatriceBatch_GetStream": (_vp, [_vp]),
@@ -329,6 +331,14 @@ class Batch:
         assert x.shape == (self.B, IN_HOP)
         out = np.zeros((self.B, OUT_HOP), np.float32)
         self._check(self.a.BeatriceBatch_ConvertFrames(self.h, fptr(x), fptr(out)))
+        return out
+
+    def convert48k(self, x, channels):
+        """x: [B][channels][480] planar float @48 kHz -> same shape (device-side wrapper, configs[4])."""
+        x = np.ascontiguousarray(x, np.float32)
+        assert x.shape == (self.B, channels, 480)
+        out = np.zeros_like(x)
+        self._check(self.a.BeatriceBatch_ConvertBlocks48k(self.h, fptr(x), fptr(out), channels))
         return out
 
     def intermediates(self):

@@ -86,6 +86,9 @@ struct BeatriceBatch {
   hipGraphExec_t graph_exec = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t side_stream = nullptr;  // pitch branch
+  // 48 kHz device wrapper (configs[4])
+  Wrap48State* d_w48 = nullptr;
+  float *d_coef_down = nullptr, *d_coef_up = nullptr, *d_io48 = nullptr, *h_io48 = nullptr;  // io: in [B][2][480] | out [B][2][480]
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
@@ -297,6 +300,26 @@ BeatriceBatch* BeatriceBatch_Create(const Beatrice20rc0_PhoneExtractor* phone, c
        hip_ok(hipEventCreate(&b->ev0), "ev0") && hip_ok(hipEventCreate(&b->ev1), "ev1") && make_stream(&b->side_stream) &&
        hip_ok(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming), "evf") &&
        hip_ok(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming), "evj");
+  {  // 48 kHz wrapper: 33-entry Hann-windowed sinc tables of the ratio-1/1 resampler pair
+    //   (reference resample.h:209-230 with cutoffs 0.99*16000/48000 in, 0.99*24000/48000 out, :412-417)
+    float cd[33], cu[33];
+    const double pi = 3.14159265358979323846, cut_d = 0.99 * 16000.0 / 48000.0, cut_u = 0.99 * 24000.0 / 48000.0;
+    auto sinc = [&](double x) { return std::abs(x) < 1e-8 ? 1.0 : std::sin(x * pi) / (x * pi); };
+    for (int i = 0; i < 33; ++i) {
+      const double x = static_cast<double>(i - 16) / 1.0;
+      const double hann = 0.5 - 0.5 * std::cos(pi * 2.0 / 32.0 * static_cast<double>(i));
+      cd[i] = static_cast<float>(cut_d * sinc(x * cut_d) * hann);
+      cu[i] = static_cast<float>(cut_u * sinc(x * cut_u) * hann);
+    }
+    ok = ok && hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_w48), sizeof(Wrap48State) * B), "w48") &&
+         hip_ok(hipMemset(b->d_w48, 0, sizeof(Wrap48State) * B), "w48 0") &&
+         hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_coef_down), sizeof(cd)), "cd") &&
+         hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_coef_up), sizeof(cu)), "cu") &&
+         hip_ok(hipMemcpy(b->d_coef_down, cd, sizeof(cd), hipMemcpyHostToDevice), "cd up") &&
+         hip_ok(hipMemcpy(b->d_coef_up, cu, sizeof(cu), hipMemcpyHostToDevice), "cu up") &&
+         hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_io48), sizeof(float) * B * 4 * 480), "io48") &&
+         hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_io48), sizeof(float) * B * 4 * 480, hipHostMallocDefault), "hio48");
+  }
   ok = ok && hip_ok(hipDeviceSynchronize(), "create sync");  // NULL-stream memsets vs the non-blocking stream
   b->ok = ok;
   if (ok) {
@@ -311,7 +334,9 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   drop_graph(b);
   b->phone.destroy(); b->pitch.destroy(); b->wave.destroy();
-  void* dev[] = {b->d_in, b->d_cb_raw, b->d_cbT, b->d_cnorm, b->d_add_raw, b->d_frm_raw, b->d_kv_raw};
+  void* dev[] = {b->d_in, b->d_cb_raw, b->d_cbT, b->d_cnorm, b->d_add_raw, b->d_frm_raw, b->d_kv_raw,
+                 b->d_w48, b->d_coef_down, b->d_coef_up, b->d_io48};
+  if (b->h_io48) (void)hipHostFree(b->h_io48);
   for (void* p : dev) if (p) (void)hipFree(p);
   b->m_cbT.release(); b->m_cnorm.release(); b->m_vqk.release(); b->m_min_q.release(); b->m_max_q.release();
   b->m_add_idx.release(); b->m_frm_idx.release(); b->m_params.release();
@@ -444,7 +469,8 @@ int BeatriceBatch_ResetStream(BeatriceBatch* b, int stream) {
   for (int s = lo; s < hi && ok; ++s) {
     ok = b->phone.arena.zero_stream(s, b->stream) && b->pitch.arena.zero_stream(s, b->stream) &&
          b->wave.arena.zero_stream(s, b->stream) &&
-         hip_ok(hipMemsetAsync(b->pitch.d_prev_q + s, 0, sizeof(int), b->stream), "prev_q");
+         hip_ok(hipMemsetAsync(b->pitch.d_prev_q + s, 0, sizeof(int), b->stream), "prev_q") &&
+         hip_ok(hipMemsetAsync(b->d_w48 + s, 0, sizeof(Wrap48State), b->stream), "w48 reset");
   }
   if (!ok) return -2;
   return BeatriceBatch_FlushSpeaker(b, stream);
@@ -467,6 +493,39 @@ int BeatriceBatch_ConvertFrames(BeatriceBatch* b, const float* in, float* out) {
   else std::memset(out, 0, sizeof(float) * b->B * B_OUT_HOP);
   return ok ? 0 : -2;
 }
+// ---- 48 kHz blocks with the wrapper on the device ----------------------------------------------
+static bool step_48k(BeatriceBatch* b, const float* d_in48, float* d_out48, int channels) {
+  // the FIFO of the reference emits the PREVIOUS block's model output first (resample.h:346-361)
+  hipLaunchKernelGGL(wrap48_post_kernel, dim3(b->B), dim3(256), 0, b->stream, b->d_w48, b->d_coef_up, d_out48, channels);
+  hipLaunchKernelGGL(wrap48_pre_kernel, dim3(b->B), dim3(256), 0, b->stream, d_in48, channels, b->d_w48, b->d_coef_down, b->d_in);
+  if (!step_device(b, nullptr, nullptr)) return false;
+  hipLaunchKernelGGL(wrap48_latch_kernel, dim3((b->B * 240 + 255) / 256), dim3(256), 0, b->stream, b->d_w48, b->wave.d_out, b->B);
+  return hip_ok(hipGetLastError(), "wrap48");
+}
+int BeatriceBatch_ConvertBlocks48kDevice(BeatriceBatch* b, const float* d_in, float* d_out, int channels) {
+  if (!b || !b->ok) return -2;
+  if (channels < 1 || channels > 2 || !d_in || !d_out) return -1;
+  return step_48k(b, d_in, d_out, channels) ? 0 : -2;
+}
+int BeatriceBatch_ConvertBlocks48k(BeatriceBatch* b, const float* in, float* out, int channels) {
+  if (!b || !b->ok) return -2;
+  if (channels < 1 || channels > 2 || !in || !out) return -1;
+  const size_t n = (size_t)b->B * channels * 480;
+  float* h_in = b->h_io48;
+  float* h_out = b->h_io48 + (size_t)b->B * 2 * 480;
+  float* d_in = b->d_io48;
+  float* d_out = b->d_io48 + (size_t)b->B * 2 * 480;
+  std::memcpy(h_in, in, sizeof(float) * n);
+  bool ok = hip_ok(hipMemcpyAsync(d_in, h_in, sizeof(float) * n, hipMemcpyHostToDevice, b->stream), "in48");
+  ok = ok && step_48k(b, d_in, d_out, channels);
+  ok = ok && hip_ok(hipMemcpyAsync(h_out, d_out, sizeof(float) * n, hipMemcpyDeviceToHost, b->stream), "out48");
+  ok = hip_ok(hipStreamSynchronize(b->stream), "sync") && ok;
+  b->inflight = false;
+  if (ok) std::memcpy(out, h_out, sizeof(float) * n);
+  else std::memset(out, 0, sizeof(float) * n);
+  return ok ? 0 : -2;
+}
+
 int BeatriceBatch_Synchronize(BeatriceBatch* b) {
   if (!b || !b->ok) return -2;
   b->inflight = false;

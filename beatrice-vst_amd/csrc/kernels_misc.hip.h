@@ -407,3 +407,70 @@ static __global__ __launch_bounds__(512) void codebook_prep_kernel(const float* 
   }
   cnorm[(size_t)s * B_CODEBOOK + j] = a;
 }
+
+// ---------------------------------------------------------------------------------------------
+// 48 kHz host-rate wrapper on the device (BASELINE.json configs[4]; reference chain for a 48 kHz
+// host: src/vst/processor.cc:183-192 downmix, src/common/resample.h Downsample/Upsample at ratio
+// 1/1, :343-363 block FIFO, :380-394 decimate by 3 / zero-stuff by 2).  Gains are the 0 dB identity
+// here (non-zero gains stay in the C++ host layer).  Accumulations are mul-then-add in the
+// reference's tap order, so results equal the host chain bit for bit.
+struct Wrap48State {   // per stream, floats
+  float hist_in[30];   // newest 30 mono input samples of the previous block
+  float ztail[16];     // last 16 model outputs of the block emitted one call earlier
+  float fpend[240];    // model output waiting in the 480-sample FIFO (emitted by the NEXT call)
+};
+
+// mono = (L + R) * 0.5 (or L), 31-tap low-pass evaluated only at the samples the decimator keeps
+static __global__ __launch_bounds__(256) void wrap48_pre_kernel(const float* __restrict__ in48, int channels,
+                                                                Wrap48State* __restrict__ st, const float* __restrict__ coef_down,
+                                                                float* __restrict__ in16) {
+  __shared__ float g[30 + 480];
+  __shared__ float cd[33];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* src = in48 + (size_t)b * channels * 480;
+  if (tid < 33) cd[tid] = coef_down[tid];
+  if (tid < 30) g[tid] = st[b].hist_in[tid];
+  for (int i = tid; i < 480; i += 256) {
+    float m = src[i];
+    if (channels >= 2) { m = m + src[480 + i]; m = m * 0.5f; }
+    g[30 + i] = m;
+  }
+  __syncthreads();
+  if (tid < 160) {
+    const int p = 3 * tid + 2;
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 31; ++i) acc = acc + g[30 + p - i] * cd[1 + i];
+    in16[(size_t)b * 160 + tid] = acc * 1.0f;
+  }
+  if (tid < 30) st[b].hist_in[tid] = g[480 + tid];
+}
+
+// zero-stuffed previous model output through the 32-tap low-pass; writes every channel
+static __global__ __launch_bounds__(256) void wrap48_post_kernel(Wrap48State* __restrict__ st, const float* __restrict__ coef_up,
+                                                                 float* __restrict__ out48, int channels) {
+  __shared__ float f[16 + 240];
+  __shared__ float cu[33];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < 33) cu[tid] = coef_up[tid];
+  if (tid < 16) f[tid] = st[b].ztail[tid];
+  if (tid < 240) f[16 + tid] = st[b].fpend[tid];
+  __syncthreads();
+  float* dst = out48 + (size_t)b * channels * 480;
+  for (int n = tid; n < 480; n += 256) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int m = n - i;                     // index into the zero-stuffed stream; odd positions are zero
+      if ((m & 1) == 0) acc = acc + f[16 + (m >> 1)] * cu[i];   // m >= -31 -> (m >> 1) >= -16
+    }
+    for (int c = 0; c < channels; ++c) dst[c * 480 + n] = acc;
+  }
+  __syncthreads();
+  if (tid < 16) st[b].ztail[tid] = f[16 + 224 + tid];
+}
+
+static __global__ void wrap48_latch_kernel(Wrap48State* __restrict__ st, const float* __restrict__ model_out, int B) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < B * 240) st[idx / 240].fpend[idx % 240] = model_out[idx];
+}

@@ -80,6 +80,18 @@ int BeatriceBatch_ConvertFrames(BeatriceBatch* b, const float* in, float* out);
 int BeatriceBatch_ConvertFramesDevice(BeatriceBatch* b, const float* d_in, float* d_out);
 int BeatriceBatch_Synchronize(BeatriceBatch* b);
 
+/* 48 kHz host-rate blocks with the reference's wrapper ON THE DEVICE (BASELINE.json configs[4]):
+ * per call one 10 ms block of every stream, planar float, `channels` = 1 or 2:
+ *   in [B][channels][480] @48 kHz -> out [B][channels][480] @48 kHz.
+ * Performs, per stream, what the reference host does around the model for a 48 kHz host at 0 dB gains:
+ * stereo downmix (L+R)*0.5 (reference src/vst/processor.cc:183-192), 31-tap low-pass + keep every 3rd
+ * sample (src/common/resample.h:130-159, 384-386), the 480-sample FIFO (:343-363, i.e. +10 ms), the
+ * model hop, zero-stuffing x2 (:390-393), 32-tap low-pass (:168-206), copy to every output channel
+ * (processor.cc:221-225).  Bit-identical to the host chain.  Other host rates and non-zero gains: use
+ * the C++ host layer (beatrice-vst_amd/host). */
+int BeatriceBatch_ConvertBlocks48k(BeatriceBatch* b, const float* in, float* out, int channels);
+int BeatriceBatch_ConvertBlocks48kDevice(BeatriceBatch* b, const float* d_in, float* d_out, int channels);
+
 /* Execution control: use an externally owned hipStream_t (e.g. the framework's current stream);
  * replay the per-hop kernel chain from a captured hipGraph (default on). */
 int BeatriceBatch_SetStream(BeatriceBatch* b, void* hip_stream);
