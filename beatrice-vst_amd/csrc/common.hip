@@ -210,6 +210,15 @@ void WaveWeights::pack_host(float* base) {
   pack_kn(w.ra_w[0], 3 * 128, 128);
   pack_kn(w.rb_w[0], 3 * 128, 128);
   pack_kn(w.up_w[1], 2 * 128, 4 * 64);
+  // fused tail (wave_tail.hip.h): res2a/b, up3, res3a/b, up4, res4a/b
+  pack_kn(w.ra_w[1], 3 * 64, 64);
+  pack_kn(w.rb_w[1], 3 * 64, 64);
+  pack_kn(w.up_w[2], 2 * 64, 4 * 32);
+  pack_kn(w.ra_w[2], 3 * 32, 32);
+  pack_kn(w.rb_w[2], 3 * 32, 32);
+  pack_kn(w.up_w[3], 2 * 32, 3 * 16);
+  pack_kn(w.ra_w[3], 3 * 16, 16);
+  pack_kn(w.rb_w[3], 3 * 16, 16);
 }
 
 // ---- set-time launchers ------------------------------------------------------------------------

@@ -134,7 +134,7 @@ struct WaveWeights {
   const float *fin_w, *fin_b;
   static size_t n_floats();
   void bind(const float* base);
-  static void pack_host(float* base);  // layers run by conv_gemm only; the fused tail keeps [K][N]
+  static void pack_host(float* base);  // every MFMA layer (conv_gemm and the fused tail); fin_w stays plain
 };
 struct WaveState {
   int B = 0;

@@ -9,12 +9,13 @@
 // stream fit in LDS.  As nine launches they cost ~80 us per hop at B = 256 (launch + fill/drain per
 // layer); as one workgroup per stream they are bound by the CU's own MFMA pipe (~2400 16x16x4 MFMAs).
 //
-// Layout: one 512-thread workgroup per stream.  Three LDS activation buffers rotate through the
-// layers, rows = [history | new frames], row stride C+2 floats (bank = 2*row + k: conflict-free A
-// operand reads).  Each layer's weights are staged whole in LDS; the NEXT layer's weights are
-// fetched into registers while the current layer computes (L2 latency off the critical path).
-// Cross-hop history (the last 1..6 frames of every intermediate) lives in a 960-float state block
-// per stream in HBM.  Numerics: every K here is <= 256, so each output is one k-ascending MFMA chain
+// Layout: one 512-thread workgroup per stream, 59 KB of LDS (two workgroups per CU).  Three LDS
+// activation buffers rotate through the layers, rows = [history | new frames], row stride C+2 floats
+// (bank = 2*row + k: conflict-free A operand reads).  Weights never touch LDS: every wavefront holds
+// the pre-packed B fragments of its column tile(s) in registers, fetched one layer ahead (L2 latency
+// off the critical path), and keeps up to 3 independent accumulators in flight.  Cross-hop history
+// (the last 1..6 frames of every intermediate, 960 floats per stream) is read into LDS once at the
+// start and written back once at the end.  Numerics: every K here is <= 256, so each output is one k-ascending MFMA chain
 // (MODEL_SPEC 2.2), residual added after bias -- identical bits to the layer-by-layer path.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -50,93 +51,136 @@ struct TailArgs {
 namespace tail {
 constexpr int NTHR = 512, NWAVE = 8;
 constexpr int BUF_FLOATS = (240 + 6) * 18;  // largest activation buffer (stage 4)
-constexpr int W_FLOATS = 128 * 128;         // largest weight matrix (up3)
+constexpr int BIAS_FLOATS = 64 + 64 + 128 + 32 + 32 + 48 + 16 + 16;
+// bias offsets inside the LDS bias block, per layer
+constexpr int BO[8] = {0, 64, 128, 256, 288, 320, 368, 384};
 
-// One layer as a small GEMM: rows = frames, K = KSZ*CIN, N = NOUT, operands from LDS.
+// Work split of one layer over the 8 wavefronts: NWN column groups x NWM row groups.  A wavefront owns
+// CT column tiles (1, or all of them when the tile count is not a power of two) and up to RT row
+// tiles, i.e. RT*CT independent accumulators sharing the B fragments it holds in registers.
+template <int T, int NOUT>
+struct Split {
+  static constexpr int MT = (T + 15) / 16, NTL = NOUT / 16;
+  static constexpr bool POW2 = (NTL & (NTL - 1)) == 0;
+  static constexpr int NWN = POW2 ? (NTL < 8 ? NTL : 8) : 1;
+  static constexpr int NWM = 8 / NWN;
+  static constexpr int CT = POW2 ? 1 : NTL;
+  static constexpr int RT = (MT + NWM - 1) / NWM;
+  static_assert(!POW2 || NTL <= 8, "at most 8 column groups");
+};
+
+// B fragments of one layer for this wavefront: CT column tiles x K/16 packed records (float4 each),
+// fetched from the pre-packed global weights (conv_gemm.hip.h) one layer ahead of their use.
+template <int K, int NOUT, int T>
+__device__ __forceinline__ void fetch_b(const float* __restrict__ wpacked, float4 (&bf)[Split<T, NOUT>::CT][K / 16], int wave, int lane) {
+  using S = Split<T, NOUT>;
+  const int wn = wave % S::NWN;
+#pragma unroll
+  for (int ct = 0; ct < S::CT; ++ct) {
+    const int nt = S::POW2 ? wn : ct;
+    const float4* p = reinterpret_cast<const float4*>(wpacked) + (size_t)nt * (K / 16) * 64 + lane;
+#pragma unroll
+    for (int kb = 0; kb < K / 16; ++kb) bf[ct][kb] = p[(size_t)kb * 64];
+  }
+}
+
+// One layer as a small GEMM: rows = frames, K = KSZ*CIN, N = NOUT; A from LDS, B from registers.
 //   conv  (UPR == 0): out[H_OUT + t][n]            = in[H_IN + t][n] + (acc + bias[n])       (residual)
 //   convT (UPR  > 0): out[H_OUT + t*UPR + n/COUT][n%COUT] = acc + bias[n],  COUT = NOUT / UPR
 template <int CIN, int NOUT, int KSZ, int DIL, int T, int H_IN, int H_OUT, int UPR>
-__device__ __forceinline__ void layer(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ wl,
+__device__ __forceinline__ void layer(const float* __restrict__ in, float* __restrict__ out,
+                                      const float4 (&bf)[Split<T, NOUT>::CT][KSZ * CIN / 16],
                                       const float* __restrict__ bias, int wave, int lane) {
+  using S = Split<T, NOUT>;
   constexpr int SI = CIN + 2;
   constexpr int COUT = UPR > 0 ? NOUT / UPR : NOUT;
   constexpr int SO = COUT + 2;
-  constexpr int MT = (T + 15) / 16, NTL = NOUT / 16, TILES = MT * NTL;
   const int i = lane & 15, kq = lane >> 4;
-  for (int tile = wave; tile < TILES; tile += NWAVE) {
-    const int mt = tile / NTL, nt = tile % NTL;
-    int row = mt * 16 + i;
-    if (row > T - 1) row = T - 1;  // padded rows recompute the last frame; never stored
-    tail_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int wn = wave % S::NWN, wm = wave / S::NWN;
+  tail_f32x4 acc[S::RT][S::CT];
+  int row[S::RT];
 #pragma unroll
-    for (int j = 0; j < KSZ; ++j) {
-      const float* arow = in + (H_IN + row - (KSZ - 1 - j) * DIL) * SI;
-      const float* wrow = wl + (size_t)(j * CIN) * NOUT + nt * 16 + i;
-#pragma unroll 4
-      for (int c = 0; c < CIN; c += 4) {
-        const float a = bsp::lrelu(arow[c + kq]);
-        const float b = wrow[(size_t)(c + kq) * NOUT];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+  for (int rt = 0; rt < S::RT; ++rt) {
+    int r = (wm + rt * S::NWM) * 16 + i;
+    row[rt] = r > T - 1 ? T - 1 : r;  // padded rows recompute the last frame; never stored
+#pragma unroll
+    for (int ct = 0; ct < S::CT; ++ct) acc[rt][ct] = tail_f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int j = 0; j < KSZ; ++j) {
+#pragma unroll
+    for (int c = 0; c < CIN; c += 4) {
+      constexpr int dummy = 0; (void)dummy;
+      const int ks = (j * CIN + c) / 4;  // MFMA step index within the layer's reduction
+      float av[S::RT];
+#pragma unroll
+      for (int rt = 0; rt < S::RT; ++rt) av[rt] = bsp::lrelu(in[(H_IN + row[rt] - (KSZ - 1 - j) * DIL) * SI + c + kq]);
+#pragma unroll
+      for (int ct = 0; ct < S::CT; ++ct) {
+        const float4 f = bf[ct][ks >> 2];
+        const float bv = (ks & 3) == 0 ? f.x : ((ks & 3) == 1 ? f.y : ((ks & 3) == 2 ? f.z : f.w));
+#pragma unroll
+        for (int rt = 0; rt < S::RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt], bv, acc[rt][ct], 0, 0, 0);
       }
     }
-    const int n = nt * 16 + i;
-    const float bn = bias[n];
+  }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int t = mt * 16 + kq * 4 + e;
-      if (t < T) {
-        float v = acc[e] + bn;
-        if constexpr (UPR == 0) {
-          v = in[(H_IN + t) * SI + n] + v;
-          out[(H_OUT + t) * SO + n] = v;
-        } else {
-          out[(H_OUT + t * UPR + n / COUT) * SO + (n % COUT)] = v;
+  for (int rt = 0; rt < S::RT; ++rt) {
+    const int mt = wm + rt * S::NWM;
+    if (mt >= S::MT) continue;
+#pragma unroll
+    for (int ct = 0; ct < S::CT; ++ct) {
+      const int n = (S::POW2 ? wn : ct) * 16 + i;
+      const float bn = bias[n];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int t = mt * 16 + kq * 4 + e;
+        if (t < T) {
+          float v = acc[rt][ct][e] + bn;
+          if constexpr (UPR == 0) {
+            v = in[(H_IN + t) * SI + n] + v;
+            out[(H_OUT + t) * SO + n] = v;
+          } else {
+            out[(H_OUT + t * UPR + n / COUT) * SO + (n % COUT)] = v;
+          }
         }
       }
     }
   }
 }
 
-// Weight prefetch: a [K][N] matrix (TOTAL4 float4s) is fetched into named float4 registers (no
-// arrays: hipcc keeps indexed private arrays in scratch/LDS here) and dropped into LDS one phase later.
-#define TAIL_F1(R, S, GPTR, TOTAL4)                                                              \
-  {                                                                                              \
-    const int idx_ = tid + (S) * tail::NTHR;                                                     \
-    R = reinterpret_cast<const float4*>(GPTR)[idx_ < (TOTAL4) ? idx_ : 0];                       \
-  }
-#define TAIL_S1(R, S, LPTR, TOTAL4)                                                              \
-  {                                                                                              \
-    const int idx_ = tid + (S) * tail::NTHR;                                                     \
-    if (idx_ < (TOTAL4)) reinterpret_cast<float4*>(LPTR)[idx_] = R;                              \
-  }
-
-// history rows: state block <-> LDS buffer rows
+// history rows: LDS state block <-> LDS activation buffer rows
 template <int C, int ROWS>
-__device__ __forceinline__ void hist_load(float* __restrict__ buf, const float* __restrict__ st, int tid) {
+__device__ __forceinline__ void hist_in(float* __restrict__ buf, const float* __restrict__ st, int tid) {
   for (int e = tid; e < ROWS * C; e += NTHR) buf[(e / C) * (C + 2) + (e % C)] = st[e];
 }
 template <int C, int ROWS>
-__device__ __forceinline__ void hist_save(float* __restrict__ st, const float* __restrict__ buf, int first_row, int tid) {
+__device__ __forceinline__ void hist_out(float* __restrict__ st, const float* __restrict__ buf, int first_row, int tid) {
   for (int e = tid; e < ROWS * C; e += NTHR) st[e] = buf[(first_row + e / C) * (C + 2) + (e % C)];
 }
 }  // namespace tail
 
-static __global__ __launch_bounds__(tail::NTHR) void wave_tail_kernel(const TailArgs a) {
+// 2 workgroups per CU (59 KB of LDS each): while one waits at a barrier the other computes
+static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const TailArgs a) {
   using namespace tail;
-  __shared__ __attribute__((aligned(16))) float lds[3 * BUF_FLOATS + W_FLOATS + 7 * 16 + 16];
+  __shared__ __attribute__((aligned(16))) float lds[3 * BUF_FLOATS + 2 * TAIL_STATE_FLOATS + BIAS_FLOATS + 7 * 16];
   float* R0 = lds;
   float* R1 = lds + BUF_FLOATS;
   float* R2 = lds + 2 * BUF_FLOATS;
-  float* W = lds + 3 * BUF_FLOATS;
-  float* FW = W + W_FLOATS;
+  float* SI_ = lds + 3 * BUF_FLOATS;         // state of the previous hop (read)
+  float* SO_ = SI_ + TAIL_STATE_FLOATS;      // state after this hop (written, stored at the end)
+  float* BIAS = SO_ + TAIL_STATE_FLOATS;
+  float* FW = BIAS + BIAS_FLOATS;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int hop = *a.hop;
   float* st = a.state + (size_t)b * TAIL_STATE_FLOATS;
 
-  float4 wr0, wr1, wr2, wr3, wr4, wr5, wr6, wr7;  // next layer's weights in flight (<= 128*128 floats / 512 threads)
+  // B fragments, one layer ahead (a.w[] are pre-packed)
+  float4 b_r2a[1][12], b_r2b[1][12], b_u3[1][8], b_r3a[1][6], b_r3b[1][6], b_u4[3][4], b_r4a[1][3], b_r4b[1][3];
+  fetch_b<192, 64, 20>(a.w[0], b_r2a, wave, lane);
+  fetch_b<192, 64, 20>(a.w[1], b_r2b, wave, lane);
 
-  // ---- prologue: weights of res2a, input frames (history 2 + 20 new, 64 ch) and output histories
-  TAIL_F1(wr0, 0, a.w[0], 3072) TAIL_F1(wr1, 1, a.w[0], 3072) TAIL_F1(wr2, 2, a.w[0], 3072) TAIL_F1(wr3, 3, a.w[0], 3072) TAIL_F1(wr4, 4, a.w[0], 3072) TAIL_F1(wr5, 5, a.w[0], 3072)
+  // ---- prologue: one round of global loads: input frames (history 2 + 20 new), state, biases
+  const int hop = *a.hop;
   {
     const int pos = ring_pos(a.in, hop);
     for (int e = tid; e < 22 * 16; e += NTHR) {
@@ -145,79 +189,71 @@ static __global__ __launch_bounds__(tail::NTHR) void wave_tail_kernel(const Tail
       float* d = R0 + fr * 66 + 4 * q;
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
-    hist_load<64, 6>(R1, st + TS_YB2, tid);
+    for (int e = tid; e < TAIL_STATE_FLOATS; e += NTHR) SI_[e] = st[e];
+    if (tid < BIAS_FLOATS) {
+      int l = 0;
+#pragma unroll
+      for (int k = 1; k < 8; ++k) l += tid >= BO[k] ? 1 : 0;
+      BIAS[tid] = a.b[l][tid - BO[l]];
+    }
     if (tid < 7 * 16) FW[tid] = a.fin_w[tid];
   }
-  TAIL_S1(wr0, 0, W, 3072) TAIL_S1(wr1, 1, W, 3072) TAIL_S1(wr2, 2, W, 3072) TAIL_S1(wr3, 3, W, 3072) TAIL_S1(wr4, 4, W, 3072) TAIL_S1(wr5, 5, W, 3072)
   __syncthreads();
+  hist_in<64, 6>(R1, SI_ + TS_YB2, tid);
+  // (R1's history rows are only read by res2b, after the next barrier)
 
   // ---- res2a: R0 (H 2) -> R1 (H 6)
-  TAIL_F1(wr0, 0, a.w[1], 3072) TAIL_F1(wr1, 1, a.w[1], 3072) TAIL_F1(wr2, 2, a.w[1], 3072) TAIL_F1(wr3, 3, a.w[1], 3072) TAIL_F1(wr4, 4, a.w[1], 3072) TAIL_F1(wr5, 5, a.w[1], 3072)
-  layer<64, 64, 3, 1, 20, 2, 6, 0>(R0, R1, W, a.b[0], wave, lane);
-  hist_load<64, 1>(R2, st + TS_YC2, tid);
+  fetch_b<128, 128, 20>(a.w[2], b_u3, wave, lane);
+  layer<64, 64, 3, 1, 20, 2, 6, 0>(R0, R1, b_r2a, BIAS + BO[0], wave, lane);
+  hist_in<64, 1>(R2, SI_ + TS_YC2, tid);
   __syncthreads();
-  TAIL_S1(wr0, 0, W, 3072) TAIL_S1(wr1, 1, W, 3072) TAIL_S1(wr2, 2, W, 3072) TAIL_S1(wr3, 3, W, 3072) TAIL_S1(wr4, 4, W, 3072) TAIL_S1(wr5, 5, W, 3072)
-  hist_save<64, 6>(st + TS_YB2, R1, 20, tid);
-  __syncthreads();
+  hist_out<64, 6>(SO_ + TS_YB2, R1, 20, tid);
 
   // ---- res2b (dil 3): R1 (H 6) -> R2 (H 1)
-  TAIL_F1(wr0, 0, a.w[2], 4096) TAIL_F1(wr1, 1, a.w[2], 4096) TAIL_F1(wr2, 2, a.w[2], 4096) TAIL_F1(wr3, 3, a.w[2], 4096) TAIL_F1(wr4, 4, a.w[2], 4096) TAIL_F1(wr5, 5, a.w[2], 4096) TAIL_F1(wr6, 6, a.w[2], 4096) TAIL_F1(wr7, 7, a.w[2], 4096)
-  layer<64, 64, 3, 3, 20, 6, 1, 0>(R1, R2, W, a.b[1], wave, lane);
-  hist_load<32, 2>(R0, st + TS_YA3, tid);
+  fetch_b<96, 32, 80>(a.w[3], b_r3a, wave, lane);
+  layer<64, 64, 3, 3, 20, 6, 1, 0>(R1, R2, b_r2b, BIAS + BO[1], wave, lane);
+  hist_in<32, 2>(R0, SI_ + TS_YA3, tid);
   __syncthreads();
-  TAIL_S1(wr0, 0, W, 4096) TAIL_S1(wr1, 1, W, 4096) TAIL_S1(wr2, 2, W, 4096) TAIL_S1(wr3, 3, W, 4096) TAIL_S1(wr4, 4, W, 4096) TAIL_S1(wr5, 5, W, 4096) TAIL_S1(wr6, 6, W, 4096) TAIL_S1(wr7, 7, W, 4096)
-  hist_save<64, 1>(st + TS_YC2, R2, 20, tid);
-  __syncthreads();
+  hist_out<64, 1>(SO_ + TS_YC2, R2, 20, tid);
 
   // ---- up3 (x4): R2 (H 1, 20 frames of 64) -> R0 (H 2, 80 frames of 32)
-  TAIL_F1(wr0, 0, a.w[3], 768) TAIL_F1(wr1, 1, a.w[3], 768)
-  layer<64, 128, 2, 1, 20, 1, 2, 4>(R2, R0, W, a.b[2], wave, lane);
-  hist_load<32, 6>(R1, st + TS_YB3, tid);
+  fetch_b<96, 32, 80>(a.w[4], b_r3b, wave, lane);
+  layer<64, 128, 2, 1, 20, 1, 2, 4>(R2, R0, b_u3, BIAS + BO[2], wave, lane);
+  hist_in<32, 6>(R1, SI_ + TS_YB3, tid);
   __syncthreads();
-  TAIL_S1(wr0, 0, W, 768) TAIL_S1(wr1, 1, W, 768)
-  hist_save<32, 2>(st + TS_YA3, R0, 80, tid);
-  __syncthreads();
+  hist_out<32, 2>(SO_ + TS_YA3, R0, 80, tid);
 
   // ---- res3a: R0 (H 2) -> R1 (H 6)
-  TAIL_F1(wr0, 0, a.w[4], 768) TAIL_F1(wr1, 1, a.w[4], 768)
-  layer<32, 32, 3, 1, 80, 2, 6, 0>(R0, R1, W, a.b[3], wave, lane);
-  hist_load<32, 1>(R2, st + TS_YC3, tid);
+  fetch_b<64, 48, 80>(a.w[5], b_u4, wave, lane);
+  layer<32, 32, 3, 1, 80, 2, 6, 0>(R0, R1, b_r3a, BIAS + BO[3], wave, lane);
+  hist_in<32, 1>(R2, SI_ + TS_YC3, tid);
   __syncthreads();
-  TAIL_S1(wr0, 0, W, 768) TAIL_S1(wr1, 1, W, 768)
-  hist_save<32, 6>(st + TS_YB3, R1, 80, tid);
-  __syncthreads();
+  hist_out<32, 6>(SO_ + TS_YB3, R1, 80, tid);
 
   // ---- res3b (dil 3): R1 (H 6) -> R2 (H 1)
-  TAIL_F1(wr0, 0, a.w[5], 768) TAIL_F1(wr1, 1, a.w[5], 768)
-  layer<32, 32, 3, 3, 80, 6, 1, 0>(R1, R2, W, a.b[4], wave, lane);
-  hist_load<16, 2>(R0, st + TS_YA4, tid);
+  fetch_b<48, 16, 240>(a.w[6], b_r4a, wave, lane);
+  layer<32, 32, 3, 3, 80, 6, 1, 0>(R1, R2, b_r3b, BIAS + BO[4], wave, lane);
+  hist_in<16, 2>(R0, SI_ + TS_YA4, tid);
   __syncthreads();
-  TAIL_S1(wr0, 0, W, 768) TAIL_S1(wr1, 1, W, 768)
-  hist_save<32, 1>(st + TS_YC3, R2, 80, tid);
-  __syncthreads();
+  hist_out<32, 1>(SO_ + TS_YC3, R2, 80, tid);
 
   // ---- up4 (x3): R2 (H 1, 80 frames of 32) -> R0 (H 2, 240 frames of 16)
-  TAIL_F1(wr0, 0, a.w[6], 192)
-  layer<32, 48, 2, 1, 80, 1, 2, 3>(R2, R0, W, a.b[5], wave, lane);
-  hist_load<16, 6>(R1, st + TS_YB4, tid);
+  fetch_b<48, 16, 240>(a.w[7], b_r4b, wave, lane);
+  layer<32, 48, 2, 1, 80, 1, 2, 3>(R2, R0, b_u4, BIAS + BO[5], wave, lane);
+  hist_in<16, 6>(R1, SI_ + TS_YB4, tid);
   __syncthreads();
-  TAIL_S1(wr0, 0, W, 192)
-  hist_save<16, 2>(st + TS_YA4, R0, 240, tid);
-  __syncthreads();
+  hist_out<16, 2>(SO_ + TS_YA4, R0, 240, tid);
 
   // ---- res4a: R0 (H 2) -> R1 (H 6)
-  TAIL_F1(wr0, 0, a.w[7], 192)
-  layer<16, 16, 3, 1, 240, 2, 6, 0>(R0, R1, W, a.b[6], wave, lane);
-  hist_load<16, 6>(R2, st + TS_YC4, tid);
+  layer<16, 16, 3, 1, 240, 2, 6, 0>(R0, R1, b_r4a, BIAS + BO[6], wave, lane);
+  hist_in<16, 6>(R2, SI_ + TS_YC4, tid);
   __syncthreads();
-  TAIL_S1(wr0, 0, W, 192)
-  hist_save<16, 6>(st + TS_YB4, R1, 240, tid);
-  __syncthreads();
+  hist_out<16, 6>(SO_ + TS_YB4, R1, 240, tid);
 
   // ---- res4b (dil 3): R1 (H 6) -> R2 (H 6)
-  layer<16, 16, 3, 3, 240, 6, 6, 0>(R1, R2, W, a.b[7], wave, lane);
+  layer<16, 16, 3, 3, 240, 6, 6, 0>(R1, R2, b_r4b, BIAS + BO[7], wave, lane);
   __syncthreads();
-  hist_save<16, 6>(st + TS_YC4, R2, 240, tid);
+  hist_out<16, 6>(SO_ + TS_YC4, R2, 240, tid);
 
   // ---- output conv: lrelu, Conv1d(16 -> 1, k7), tanh; one thread per sample, coalesced store
   if (tid < B_OUT_HOP) {
@@ -228,4 +264,6 @@ static __global__ __launch_bounds__(tail::NTHR) void wave_tail_kernel(const Tail
       for (int c = 0; c < 16; ++c) acc = bsp::fma(bsp::lrelu(R2[(tid + j) * 18 + c]), FW[j * 16 + c], acc);
     a.d_out[(size_t)b * B_OUT_HOP + tid] = bsp::tanh(acc + a.fin_b[0]);
   }
+  __syncthreads();
+  for (int e = tid; e < TAIL_STATE_FLOATS; e += NTHR) st[e] = SO_[e];
 }

@@ -141,7 +141,10 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
-    ap.add_argument("--speakers", type=int, default=1)
+    ap.add_argument("--speakers", type=int, default=None)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4),
+                    help="BASELINE.json configs index: 2 = 256 streams/GPU, 1 speaker (default, the headline); "
+                         "3 = 256 streams/GPU, 64 rotating speakers, VQ k=4; 4 = 64 streams/GPU, 48 kHz stereo, wrapper on the device")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / B=1 latency / kernel profile")
@@ -164,6 +167,10 @@ def main():
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import make_model
 
+    if a.config == 4 and a.streams == 256:
+        a.streams = 64   # batch 512 over 8 GPUs
+    if a.speakers is None:
+        a.speakers = 64 if a.config == 3 else 1
     B = a.streams
     tmp = tempfile.TemporaryDirectory()
     model_dir = tmp.name
@@ -198,6 +205,9 @@ def main():
     for s in range(B):  # streams spread over the speakers of the table
         product.BeatriceBatch_SetTargetSpeaker(batch.h, s, s % a.speakers)
     product.BeatriceBatch_FlushSpeaker(batch.h, -1)
+    if a.config == 3:
+        product.BeatriceBatch_SetVQNumNeighbors(batch.h, -1, 4)
+    current_speaker = [s % a.speakers for s in range(B)]
 
     # synthetic audio, resident on the device: 64 hops x B streams, cycled
     n_cycle = 64
@@ -207,10 +217,26 @@ def main():
     d_out = torch.empty((B, 240), dtype=torch.float32, device="cuda")
     base, hop_bytes = d_audio.data_ptr(), B * 160 * 4
 
+    if a.config == 4:  # 48 kHz stereo blocks, resident: [n_cycle][B][2][480]
+        a48 = np.stack([np.stack([bv.synth_audio(480 * n_cycle, seed=rank * 100000 + 2 * s + c, sr=48000) for c in range(2)])
+                        for s in range(B)])
+        a48 = np.ascontiguousarray(a48.reshape(B, 2, n_cycle, 480).transpose(2, 0, 1, 3))
+        d_audio48 = torch.from_numpy(a48).cuda()
+        d_out48 = torch.empty((B, 2, 480), dtype=torch.float32, device="cuda")
+        base48, blk_bytes = d_audio48.data_ptr(), B * 2 * 480 * 4
+
     def step(i):
-        rc = product.BeatriceBatch_ConvertFramesDevice(batch.h, base + (i % n_cycle) * hop_bytes, d_out.data_ptr())
+        if a.config == 3:  # every stream moves to the next speaker every 200 hops, staggered by stream index
+            for s in range(B):
+                if (i + s * 200 // B) % 200 == 0 and i > 0:
+                    current_speaker[s] = (current_speaker[s] + 1) % a.speakers
+                    product.BeatriceBatch_SetTargetSpeaker(batch.h, s, current_speaker[s])
+        if a.config == 4:
+            rc = product.BeatriceBatch_ConvertBlocks48kDevice(batch.h, base48 + (i % n_cycle) * blk_bytes, d_out48.data_ptr(), 2)
+        else:
+            rc = product.BeatriceBatch_ConvertFramesDevice(batch.h, base + (i % n_cycle) * hop_bytes, d_out.data_ptr())
         if rc:
-            raise SystemExit("ConvertFramesDevice failed: %d" % rc)
+            raise SystemExit("Convert* failed: %d" % rc)
 
     for i in range(a.warmup):
         step(i)
@@ -226,7 +252,7 @@ def main():
     if world > 1:
         dist.barrier()
         elapsed = shard.max_over_ranks(elapsed, world, dist, torch, "cuda")
-    out_rms = float(d_out.float().pow(2).mean().sqrt().item())
+    out_rms = float((d_out48 if a.config == 4 else d_out).float().pow(2).mean().sqrt().item())
 
     if rank == 0:
         frames = world * B * a.steps
@@ -234,8 +260,12 @@ def main():
             "metric": "audio frames/sec (24 kHz out, 10 ms hop)", "value": round(frames / elapsed, 1), "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2]: %d concurrent streams per GPU, %d speaker(s), 10 ms hop "
-                                   "(160 in @16 kHz -> 240 out @24 kHz), synthetic weights of MODEL_SPEC v1" % (B, a.speakers),
+            "config": {"workload": {2: "BASELINE.json configs[2]: %d concurrent streams per GPU, %d speaker(s), 10 ms hop "
+                                       "(160 in @16 kHz -> 240 out @24 kHz), synthetic weights of MODEL_SPEC v1" % (B, a.speakers),
+                                    3: "BASELINE.json configs[3] per-GPU share: %d streams, %d speakers, every stream switches "
+                                       "speaker every 200 hops (K/V blocks one per hop), VQ k=4" % (B, a.speakers),
+                                    4: "BASELINE.json configs[4] per-GPU share: %d streams of 48 kHz stereo, downmix + resample "
+                                       "wrapper on the device, 480-sample blocks" % B}[a.config],
                        "streams_per_gpu": B, "speakers": a.speakers, "hipgraph": not a.no_graph,
                        "parallelism": "streams sharded over %d GPU(s), no per-hop collective" % world},
             "x_realtime_per_stream": round(a.steps / elapsed / 100.0, 2), "output_rms": round(out_rms, 4),
