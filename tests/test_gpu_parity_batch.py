@@ -91,3 +91,74 @@ def test_batch_reset_stream(bv, oracle, product, model_dir):
     dev = float(np.abs(ref - got).max())
     print("reset max-abs", dev)
     assert dev <= TOL
+
+
+def test_full_size_batch_invariance(bv, oracle, product, model_dir):
+    """BASELINE.json configs[2] size (256 streams): a stream inside the full batch equals the same stream
+    run alone through the oracle (checked on a sample of streams), and every stream produces sound."""
+    B, hops = 256, 10
+    audio = np.stack([bv.synth_audio(160 * hops, seed=500 + s) for s in range(B)])
+    m = bv.Models(product, model_dir)
+    batch = bv.Batch(m, B)
+    for s in range(B):
+        batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, s, s % 3)
+        batch.a.BeatriceBatch_SetVQNumNeighbors(batch.h, s, (s // 3) % 9)
+    batch.a.BeatriceBatch_FlushSpeaker(batch.h, -1)
+    got = np.stack([batch.convert(audio[:, h * 160:(h + 1) * 160]) for h in range(hops)])
+    batch.close()
+    m.close()
+    assert np.all(np.abs(got).reshape(hops, B, -1).max(axis=(0, 2)) > 1e-3)
+    mo = bv.Models(oracle, model_dir)
+    for s in (0, 1, 15, 16, 17, 100, 254, 255):
+        st = bv.Stream1(mo, speaker=s % 3, vq_k=(s // 3) % 9)
+        want = np.stack([st.hop(audio[s, h * 160:(h + 1) * 160]) for h in range(hops)])
+        st.close()
+        assert np.array_equal(got[:, s], want), "stream %d max-abs %g" % (s, np.abs(got[:, s] - want).max())
+    mo.close()
+
+
+def test_pitch_range_and_correction_settings(bv, oracle, product, model_dir):
+    """Per-stream pitch search range (SetMin/MaxSourcePitch -> bins, processor_core_2.cc:561-583) and the
+    pitch-correction branch of the transform (:199-249, uses pow) on the device vs the host."""
+    B, hops = 6, 12
+    audio = np.stack([bv.synth_audio(160 * hops, seed=700 + s) for s in range(B)])
+    ranges = [(33.125, 80.875), (45.0, 60.0), (60.0, 45.0), (0.0, 128.0), (50.0, 50.0), (70.0, 88.0)]
+    corr = [(0.0, 0), (0.5, 0), (0.5, 1), (1.0, 1), (0.25, 0), (0.9, 1)]
+
+    def to_bin(note):
+        note = min(max(note, 0.0), 128.0)
+        r = (note - 33.0) * 8.0
+        q = int(np.floor(r + 0.5)) if r >= 0 else -int(np.floor(-r + 0.5))
+        return min(max(q, 1), 447)
+
+    mo = bv.Models(oracle, model_dir)
+    ref = np.zeros((hops, B, bv.OUT_HOP), np.float32)
+    ref_q = np.zeros((hops, B), np.int32)
+    for s in range(B):
+        st = bv.Stream1(mo, speaker=1, min_q=to_bin(ranges[s][0]), max_q=to_bin(ranges[s][1]))
+        st.pitch_params = dict(correction=corr[s][0], ctype=corr[s][1], shift=0.5 * s)
+        for h in range(hops):
+            o, _, _, _, q2 = st.hop(audio[s, h * 160:(h + 1) * 160], return_all=True)
+            ref[h, s], ref_q[h, s] = o, q2
+        st.close()
+    mo.close()
+    m = bv.Models(product, model_dir)
+    batch = bv.Batch(m, B)
+    a, hnd = batch.a, batch.h
+    a.BeatriceBatch_SetTargetSpeaker(hnd, -1, 1)
+    a.BeatriceBatch_FlushSpeaker(hnd, -1)
+    for s in range(B):
+        a.BeatriceBatch_SetMinSourcePitch(hnd, s, ranges[s][0])
+        a.BeatriceBatch_SetMaxSourcePitch(hnd, s, ranges[s][1])
+        a.BeatriceBatch_SetPitchCorrection(hnd, s, corr[s][0])
+        a.BeatriceBatch_SetPitchCorrectionType(hnd, s, corr[s][1])
+        a.BeatriceBatch_SetPitchShift(hnd, s, 0.5 * s)
+    got = np.zeros_like(ref)
+    got_q = np.zeros_like(ref_q)
+    for h in range(hops):
+        got[h] = batch.convert(audio[:, h * 160:(h + 1) * 160])
+        got_q[h] = batch.intermediates()[2]
+    batch.close()
+    m.close()
+    assert np.array_equal(got_q, ref_q)
+    assert float(np.abs(got - ref).max()) <= TOL
