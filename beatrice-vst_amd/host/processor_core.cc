@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <numeric>
 
 namespace beatrice_amd {
 
@@ -192,6 +193,7 @@ void ProcessorCore2::Block480(const float* in480, float* out480) {
 
 // one model hop (reference processor_core_2.cc:179-255, without the morph branch)
 void ProcessorCore2::Hop(const float* in160, float* out240) {
+  if (target_speaker_ == n_speakers_) MorphStep();
   InstallNextKeyValueBlock();  // at most one block per hop, :179-181
   alignas(64) float phone[BEATRICE_20RC0_PHONE_CHANNELS];
   Beatrice20rc0_ExtractPhone1(phone_extractor_, in160, phone, phone_context_);
@@ -251,10 +253,24 @@ ErrorCode ProcessorCore2::LoadModel(const std::filesystem::path& model_file) {
   BEATRICE_TRY_READ(Beatrice20rc0_ReadSpeakerEmbeddings(reinterpret_cast<const char*>(spk.c_str()), codebooks_.data(), additive_.data(),
                                                         formant_.data(), key_value_.data()))
 #undef BEATRICE_TRY_READ
+  {  // spherical-mean solvers over the speakers (reference processor_core_2.cc:384-406)
+    const int lim = std::min(n_speakers_, kSphAvgMaxNSpeakers);
+    mean_additive_.Initialize(n_speakers_, BEATRICE_WAVEFORM_GENERATOR_HIDDEN_CHANNELS, additive_.data(), lim);
+    mean_kv_.assign(BEATRICE_20RC0_KV_LENGTH, SphericalMean());
+    std::vector<float> token(static_cast<size_t>(n_speakers_) * BEATRICE_20RC0_KV_SPEAKER_EMBEDDING_CHANNELS);
+    for (int i = 0; i < BEATRICE_20RC0_KV_LENGTH; ++i) {
+      for (int j = 0; j < n_speakers_; ++j)
+        std::copy_n(key_value_.data() + (static_cast<size_t>(j) * BEATRICE_20RC0_KV_LENGTH + i) * BEATRICE_20RC0_KV_SPEAKER_EMBEDDING_CHANNELS,
+                    BEATRICE_20RC0_KV_SPEAKER_EMBEDDING_CHANNELS, token.data() + static_cast<size_t>(j) * BEATRICE_20RC0_KV_SPEAKER_EMBEDDING_CHANNELS);
+      mean_kv_[i].Initialize(n_speakers_, BEATRICE_20RC0_KV_SPEAKER_EMBEDDING_CHANNELS, token.data(), lim);
+    }
+    morph_counter_ = std::numeric_limits<int>::max();
+  }
   ready_to_set_speaker_ = true;
   if (const auto err = SetTargetSpeaker(0); err != ErrorCode::kSuccess) return err;
   while (InstallNextKeyValueBlock()) {}
   model_file_ = model_file;
+  ApplySpeakerMorphingWeights();
   // the reference's proxy re-syncs every parameter after a load (processor_proxy.h:95)
   SetFormantShift(formant_shift_);
   SetMinSourcePitch(min_source_pitch_);
@@ -345,6 +361,80 @@ ErrorCode ProcessorCore2::SetVQNumNeighbors(int k) {  // reference processor_cor
   return ErrorCode::kSuccess;
 }
 
+// ---- morphing ------------------------------------------------------------------------------------
+ErrorCode ProcessorCore2::SetSpeakerMorphingWeights(const std::array<float, kMaxNSpeakers>& weights) {
+  if (weights == morph_weights_) return ErrorCode::kSuccess;  // reference processor_core_2.cc:498-505
+  morph_weights_ = weights;
+  return ApplySpeakerMorphingWeights();
+}
+
+// weight preparation: overflow speakers folded into the last one, < 0.01 dropped (reference
+// voice_morph_state.h:87-104), then the 8 largest kept (processor_core_2.cc:507-532)
+ErrorCode ProcessorCore2::ApplySpeakerMorphingWeights() {
+  if (!ready_to_set_speaker_) return ErrorCode::kSuccess;
+  std::array<float, kMaxNSpeakers> w = morph_weights_;
+  if (n_speakers_ <= 0) {
+    w.fill(0.0f);
+  } else {
+    const int count = std::min(n_speakers_, kMaxNSpeakers);
+    for (int i = count; i < kMaxNSpeakers; ++i) w[count - 1] += w[i];
+    std::fill(w.begin() + count, w.end(), 0.0f);
+    for (int i = 0; i < count; ++i) if (w[i] < 0.01f) w[i] = 0.0f;
+  }
+  std::iota(morph_order_.data(), morph_order_.data() + n_speakers_, 0);
+  std::sort(morph_order_.data(), morph_order_.data() + n_speakers_, [&w](const int a, const int b) -> bool { return w[a] > w[b]; });
+  morph_pruned_.fill(0.0f);
+  const int keep = std::min(n_speakers_, kSphAvgMaxNSpeakers);
+  for (int i = 0; i < keep; ++i) morph_pruned_[morph_order_[i]] = w[morph_order_[i]];
+  morph_counter_ = 0;  // the averages are recomputed over the next hops, not here
+  return ErrorCode::kSuccess;
+}
+
+// the morph branch of one hop (reference processor_core_2.cc:51-177, lottery variant :94-121)
+void ProcessorCore2::MorphStep() {
+  const size_t cb = static_cast<size_t>(BEATRICE_20RC0_CODEBOOK_SIZE) * BEATRICE_20RC0_PHONE_CHANNELS;
+  const size_t hid = BEATRICE_WAVEFORM_GENERATOR_HIDDEN_CHANNELS;
+  const size_t kvc = BEATRICE_20RC0_KV_SPEAKER_EMBEDDING_CHANNELS, kvl = BEATRICE_20RC0_KV_LENGTH;
+  {  // codebook: one real speaker per hop, drawn with the morph weights as odds
+    const int n_weights = std::min(n_speakers_, kSphAvgMaxNSpeakers);
+    float sum = 0.0f;
+    for (int i = 0; i < n_weights; ++i) sum += morph_pruned_[morph_order_[i]];
+    int idx = morph_order_[0];
+    if (sum <= std::numeric_limits<float>::epsilon()) {
+      idx = std::uniform_int_distribution<int>(0, n_speakers_ - 1)(lottery_);
+    } else {
+      float r = std::uniform_real_distribution<float>(0.0f, sum)(lottery_);
+      for (int i = 0; i < n_weights; ++i) {
+        const int speaker = morph_order_[i];
+        r -= morph_pruned_[speaker];
+        if (r < 0.0f) { idx = speaker; break; }
+      }
+    }
+    Beatrice20rc0_SetCodebook(phone_context_, codebooks_.data() + static_cast<size_t>(idx) * cb);
+  }
+  if (morph_counter_ == 0) {  // additive embedding: in one go, on the hop after a weight change
+    mean_additive_.SetWeights(n_speakers_, morph_pruned_.data(), morph_order_.data());
+    for (int j = 0; j < kSphAvgMaxNUpdates; ++j) if (mean_additive_.Update()) break;
+    float* slot = additive_.data() + static_cast<size_t>(n_speakers_) * hid;
+    mean_additive_.Result(slot);
+    Beatrice20rc0_SetAdditiveSpeakerEmbedding(embedding_setter_, slot, embedding_context_, waveform_context_);
+  }
+  if (morph_counter_ < kSphAvgMaxNState) {  // key/value tokens: a quarter of them per hop
+    const int first = static_cast<int>(kvl) * morph_counter_ / kSphAvgMaxNState;
+    const int last = static_cast<int>(kvl) * (morph_counter_ + 1) / kSphAvgMaxNState;
+    for (int i = first; i < last; ++i) {
+      mean_kv_[i].SetWeights(n_speakers_, morph_pruned_.data(), morph_order_.data());
+      for (int j = 0; j < kSphAvgMaxNUpdates; ++j) if (mean_kv_[i].Update()) break;
+      mean_kv_[i].Result(key_value_.data() + (static_cast<size_t>(n_speakers_) * kvl + i) * kvc);
+    }
+  } else if (morph_counter_ == kSphAvgMaxNState) {
+    Beatrice20rc0_RegisterKeyValueSpeakerEmbedding(embedding_setter_, key_value_.data() + static_cast<size_t>(n_speakers_) * kvl * kvc,
+                                                   embedding_context_);
+    kv_blocks_set_ = 0;
+  }
+  if (morph_counter_ <= kSphAvgMaxNState) ++morph_counter_;
+}
+
 }  // namespace beatrice_amd
 
 // ---- plain-C view of the class for FFI callers and the tests ------------------------------------
@@ -368,6 +458,12 @@ int BeatriceHost_SetPitchCorrectionType(void* p, int v) { return static_cast<int
 int BeatriceHost_SetMinSourcePitch(void* p, double v) { return static_cast<int>(static_cast<ProcessorCore2*>(p)->SetMinSourcePitch(v)); }
 int BeatriceHost_SetMaxSourcePitch(void* p, double v) { return static_cast<int>(static_cast<ProcessorCore2*>(p)->SetMaxSourcePitch(v)); }
 int BeatriceHost_SetVQNumNeighbors(void* p, int v) { return static_cast<int>(static_cast<ProcessorCore2*>(p)->SetVQNumNeighbors(v)); }
+int BeatriceHost_SetSpeakerMorphingWeights(void* p, const float* weights, int n) {
+  std::array<float, ProcessorCore2::kMaxNSpeakers> w{};
+  for (int i = 0; i < n && i < ProcessorCore2::kMaxNSpeakers; ++i) w[i] = weights[i];
+  return static_cast<int>(static_cast<ProcessorCore2*>(p)->SetSpeakerMorphingWeights(w));
+}
+void BeatriceHost_SetMorphSeed(void* p, unsigned seed) { static_cast<ProcessorCore2*>(p)->SetMorphSeed(seed); }
 int BeatriceHost_NumSpeakers(void* p) { return static_cast<ProcessorCore2*>(p)->n_speakers(); }
 int BeatriceHost_TakePitchTrace(void* p, int* out, int cap) {
   const auto t = static_cast<ProcessorCore2*>(p)->TakePitchTrace();
@@ -375,4 +471,17 @@ int BeatriceHost_TakePitchTrace(void* p, int* out, int cap) {
   for (int i = 0; i < n; ++i) out[i] = t[i];
   return static_cast<int>(t.size());
 }
+}
+
+// weighted spherical mean as the morph branch computes it (Initialize -> SetWeights -> <= max_updates
+// Update -> Result); returns the number of updates performed
+extern "C" int BeatriceHost_SphericalMean(int dim, int n_points, const float* points, const float* weights, const int* order,
+                                          int limit, int max_updates, float* out) {
+  beatrice_amd::SphericalMean m;
+  m.Initialize(n_points, dim, points, limit);
+  m.SetWeights(n_points, weights, order);
+  int it = 0;
+  for (; it < max_updates; ++it) if (m.Update()) break;
+  m.Result(out);
+  return it;
 }

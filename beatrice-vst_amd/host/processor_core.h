@@ -10,14 +10,20 @@
 //   -> [one K/V block if pending] ExtractPhone1, EstimatePitch1, pitch transform, GenerateWaveform1
 //   -> zero-stuff 240 -> 480 -> 48 kHz to host rate -> output gain.
 // The three library calls go to whatever implements include/beatrice_abi.h at link time: the HIP
-// library in the product build (libbeatrice_host.so).  Speaker morphing (SetSpeakerMorphingWeights,
-// reference processor_core_2.cc:51-177) is not implemented yet.
+// library in the product build (libbeatrice_host.so).  Speaker morphing (target speaker == n_speakers:
+// SetSpeakerMorphingWeights, reference processor_core_2.cc:51-177, 498-532) runs on the host as in the
+// reference: spherical means of the additive and key/value embeddings spread over four hops, a weighted
+// lottery for the codebook; the only deviation is that the lottery seed can be fixed (SetMorphSeed).
 #pragma once
+#include <array>
 #include <cstdint>
 #include <filesystem>
+#include <limits>
+#include <random>
 #include <vector>
 
 #include "beatrice_abi.h"
+#include "spherical_mean.h"
 
 namespace beatrice_amd {
 
@@ -103,6 +109,10 @@ class ProcessorCore2 {
   ErrorCode SetMinSourcePitch(double min_source_pitch);
   ErrorCode SetMaxSourcePitch(double max_source_pitch);
   ErrorCode SetVQNumNeighbors(int vq_num_neighbors);
+  static constexpr int kMaxNSpeakers = 256;      // reference src/common/model_config.h:17
+  static constexpr int kSphAvgMaxNSpeakers = 8;  // reference processor_core_2.h:26
+  ErrorCode SetSpeakerMorphingWeights(const std::array<float, kMaxNSpeakers>& weights);
+  void SetMorphSeed(std::uint32_t seed) { lottery_.seed(seed); }  // the reference seeds from std::random_device
   int n_speakers() const { return n_speakers_; }
   // test hook: bins handed to GenerateWaveform1 since the last call (pitch transform output)
   std::vector<int> TakePitchTrace() { std::vector<int> t; t.swap(pitch_trace_); return t; }
@@ -114,6 +124,8 @@ class ProcessorCore2 {
   void Reblock(const float* in, float* out, int n);
   bool InstallNextKeyValueBlock();
   int TransformPitch(int q) const;
+  ErrorCode ApplySpeakerMorphingWeights();
+  void MorphStep();
 
   std::filesystem::path model_file_;
   double sample_rate_;
@@ -139,6 +151,14 @@ class ProcessorCore2 {
   Beatrice20rc0_EmbeddingContext* embedding_context_;
   // caller-owned tables, (n_speakers + 1) slots like the reference (last = morph result)
   std::vector<float> codebooks_, additive_, formant_, key_value_;
+  // morphing (reference processor_core_2.h:137-152)
+  static constexpr int kSphAvgMaxNUpdates = 4, kSphAvgMaxNState = 4;
+  std::array<float, kMaxNSpeakers> morph_weights_{}, morph_pruned_{};
+  std::array<int, kMaxNSpeakers> morph_order_{};
+  int morph_counter_ = std::numeric_limits<int>::max();
+  std::mt19937 lottery_{std::random_device{}()};
+  SphericalMean mean_additive_;
+  std::vector<SphericalMean> mean_kv_;
 };
 
 }  // namespace beatrice_amd

@@ -80,7 +80,9 @@ int ref_spherical_average(int dim, int n_points, const float* points, const floa
     s.SetWeights(n_points, weights, argsort);
     int it = 0;
     for (; it < max_updates; ++it) if (s.Update()) break;
-    s.GetResult(dim, out);
+    alignas(64) float tmp[128];
+    s.GetResult(dim, tmp);
+    std::memcpy(out, tmp, sizeof(tmp));
     return it;
   }
   if (dim == 256) {
@@ -89,7 +91,9 @@ int ref_spherical_average(int dim, int n_points, const float* points, const floa
     s.SetWeights(n_points, weights, argsort);
     int it = 0;
     for (; it < max_updates; ++it) if (s.Update()) break;
-    s.GetResult(dim, out);
+    alignas(64) float tmp[256];
+    s.GetResult(dim, tmp);
+    std::memcpy(out, tmp, sizeof(tmp));
     return it;
   }
   return -1;

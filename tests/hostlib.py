@@ -19,6 +19,7 @@ class Host:
         L.BeatriceHost_LoadModel.argtypes = [C.c_void_p, C.c_char_p]
         L.BeatriceHost_Process.argtypes = [C.c_void_p, _f32p, _f32p, C.c_int]
         L.BeatriceHost_ResetContext.argtypes = [C.c_void_p]
+        L.BeatriceHost_NumSpeakers.argtypes = [C.c_void_p]
         L.BeatriceHost_TakePitchTrace.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
         for name in ("SetSampleRate", "SetFormantShift", "SetPitchShift", "SetInputGain", "SetOutputGain", "SetAverageSourcePitch",
                      "SetIntonationIntensity", "SetPitchCorrection", "SetMinSourcePitch", "SetMaxSourcePitch"):

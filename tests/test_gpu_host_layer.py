@@ -32,3 +32,35 @@ def test_host_layer_hip_matches_oracle(built, model_dir, sr, block):
     print("host layer sr=%d max-abs %g" % (sr, dev))
     assert np.abs(outs["hip"][0]).max() > 1e-3
     assert dev <= 1e-4
+
+
+def test_host_layer_morph_hip_matches_oracle(built, model_dir):
+    """Morph mode (target speaker == n_speakers) end to end: spherical means on the host, lottery
+    codebook (fixed seed, VQ on), additive / K/V slot re-installed on the device library."""
+    import ctypes as C
+    sr, block = 48000, 480
+    x = wrapperlib.test_signal(block * 20, sr, seed=31)
+    w = np.zeros(256, np.float32)
+    w[:3] = (0.2, 0.5, 0.3)
+    f32p = C.POINTER(C.c_float)
+    outs = {}
+    for name, path in (("oracle", hostlib.HOST_ON_ORACLE), ("hip", hostlib.HOST_PRODUCT)):
+        h = hostlib.Host(path, sr)
+        h.lib.BeatriceHost_SetSpeakerMorphingWeights.argtypes = [C.c_void_p, f32p, C.c_int]
+        h.lib.BeatriceHost_SetMorphSeed.argtypes = [C.c_void_p, C.c_uint]
+        assert h.load(model_dir) == 0
+        h.lib.BeatriceHost_SetMorphSeed(h.h, 99)
+        h.call("SetVQNumNeighbors", 3)
+        assert h.call("SetTargetSpeaker", h.call("NumSpeakers")) == 0
+        assert h.lib.BeatriceHost_SetSpeakerMorphingWeights(h.h, w.ctypes.data_as(f32p), 256) == 0
+        a, _ = h.process(x[:block * 10], block)
+        w2 = w.copy()
+        w2[:3] = (0.6, 0.0, 0.4)
+        assert h.lib.BeatriceHost_SetSpeakerMorphingWeights(h.h, w2.ctypes.data_as(f32p), 256) == 0
+        b, _ = h.process(x[block * 10:], block)
+        outs[name] = np.concatenate([a, b])
+        h.close()
+    dev = float(np.abs(outs["hip"] - outs["oracle"]).max())
+    print("morph max-abs", dev)
+    assert np.abs(outs["hip"]).max() > 1e-3
+    assert dev <= 1e-4
