@@ -75,7 +75,7 @@ void phone_forward(const PhoneWeights& w, const PhoneState& s, hipStream_t st) {
   launch_gru<256, 256>("phone.gru", ga, st);
   launch_auto<OUTL>("phone.out", conv_args(s.h, s.raw, w.out_w, w.out_b, s.hop, B), st);
   VqArgs v{s.raw.base, s.d_phone, s.d_cbT, s.d_cnorm, s.d_vqk};
-  MISC_LAUNCH("phone.vq", 2.0 * B * 512 * 128, 4.0 * (B * 256 + 512 * 129), phone_vq_kernel, dim3(B), dim3(512), v);
+  MISC_LAUNCH("phone.vq", 0 /* k-dependent: 131 kFLOP per stream with k > 0, pass-through at k = 0 */, 4.0 * B * 256, phone_vq_kernel, dim3(B), dim3(512), v);
   if (s.advance_hop) MISC_LAUNCH("hop_advance", 0, 4, hop_advance_kernel, dim3(1), dim3(1), s.hop);
 }
 

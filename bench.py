@@ -117,6 +117,28 @@ def cpu_baseline(bv, model_dir, seconds):
                           "sample": "%d hops x %d streams, one thread per core" % (hops_mt, cores)}}
 
 
+def saturation(bv, models, product, streams=8192, steps=30):
+    """Same chain, same kernels, enough streams to leave the launch-latency regime (not the headline:
+    BASELINE.json's throughput config is 256 streams per GPU).  Reports end-to-end FLOP/s and the
+    roofline fraction of the dominant kernel at that batch size."""
+    batch = bv.Batch(models, streams)
+    product.BeatriceBatch_FlushSpeaker(batch.h, -1)
+    batch.time_steps(5)
+    ms = batch.time_steps(steps)
+    rows = batch.profile_kernels(repeats=3)
+    batch.close()
+    total_flops = sum(r["flops"] * r["launches"] for r in rows)
+    dom = max(rows, key=lambda r: r["mean_us"] * r["launches"])
+    step_s = ms * 1e-3 / steps
+    return {"streams": streams, "frames_per_s": round(streams / step_s, 1), "ms_per_step": round(step_s * 1e3, 4),
+            "tflops_end_to_end": round(total_flops / step_s / 1e12, 2),
+            "mfma_frac_end_to_end": round(total_flops / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+            "dominant_kernel": dom["name"], "dominant_share": round(dom["mean_us"] * dom["launches"] / sum(r["mean_us"] * r["launches"] for r in rows), 3),
+            "dominant_tflops": round(dom["flops"] / (dom["mean_us"] * 1e-6) / 1e12, 2),
+            "dominant_frac_of_mfma_peak": round(dom["flops"] / (dom["mean_us"] * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+            "best_gemm_tflops": round(max(r["flops"] / (r["mean_us"] * 1e-6) / 1e12 for r in rows), 2)}
+
+
 def latency_b1(bv, product, model_dir, hops=400):
     """BASELINE.json configs[1]: 1 stream, 1 speaker, hop-synchronous 1-stream C-ABI."""
     m = bv.Models(product, model_dir)
@@ -300,6 +322,7 @@ def main():
             res["kernels"] = [{"name": r["name"], "n": r["launches"], "us": round(r["mean_us"], 2)}
                               for r in sorted(rows, key=lambda r: -r["total_us"])[:12]]
             if world == 1:
+                res["saturation"] = saturation(bv, m, product)
                 res["latency_b1"] = latency_b1(bv, product, model_dir)
                 res["cpu_baseline"] = cpu_baseline(bv, model_dir, a.cpu_seconds)
         print(json.dumps(res))
