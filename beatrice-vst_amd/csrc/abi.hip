@@ -86,7 +86,7 @@ Beatrice_ErrorCode Beatrice20rc0_ReadPhoneExtractorParameters(Beatrice20rc0_Phon
 // ref beatrice.h:233-234; callers processor_core_2.h:36, processor_core_2.cc:263
 Beatrice20rc0_PhoneContext1* Beatrice20rc0_CreatePhoneContext1(void) {
   auto* c = new Beatrice20rc0_PhoneContext1();
-  c->ok = make_stream(&c->stream) && c->st.create(1, nullptr) &&
+  c->ok = make_stream(&c->stream) && c->st.create(1, 1, nullptr) &&
           hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(float) * (B_IN_HOP + B_PHONE_CH), hipHostMallocDefault),
                  "hipHostMalloc");
   return c;
@@ -167,7 +167,7 @@ Beatrice_ErrorCode Beatrice20rc0_ReadPitchEstimatorParameters(Beatrice20rc0_Pitc
 // ref beatrice.h:252-253
 Beatrice20rc0_PitchContext1* Beatrice20rc0_CreatePitchContext1(void) {
   auto* c = new Beatrice20rc0_PitchContext1();
-  c->ok = make_stream(&c->stream) && c->st.create(1, nullptr, false) &&
+  c->ok = make_stream(&c->stream) && c->st.create(1, 1, nullptr, false) &&
           hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(float) * (B_IN_HOP + 8), hipHostMallocDefault), "hipHostMalloc");
   return c;
 }
@@ -231,7 +231,7 @@ Beatrice20rc0_WaveformContext1* Beatrice20rc0_CreateWaveformContext1(void) {
   c->ok = make_stream(&c->stream) &&
           hip_ok(hipMalloc(reinterpret_cast<void**>(&c->d_inputs), sizeof(float) * in_floats), "inputs") &&
           hip_ok(hipMemset(c->d_inputs, 0, sizeof(float) * in_floats), "inputs0") &&
-          c->st.create(1, 1, 1, 1, c->d_inputs, reinterpret_cast<int*>(c->d_inputs + B_PHONE_CH + 4), c->d_inputs + B_PHONE_CH) &&
+          c->st.create(1, 1, 1, 1, 1, c->d_inputs, reinterpret_cast<int*>(c->d_inputs + B_PHONE_CH + 4), c->d_inputs + B_PHONE_CH) &&
           hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(float) * (in_floats + B_OUT_HOP), hipHostMallocDefault), "hipHostMalloc");
   return c;
 }

@@ -269,8 +269,8 @@ BeatriceBatch* BeatriceBatch_Create(const Beatrice20rc0_PhoneExtractor* phone, c
   b->owns_stream = ok;
   ok = ok && hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_in), sizeof(float) * B * B_IN_HOP), "d_in") &&
        hip_ok(hipMemset(b->d_in, 0, sizeof(float) * B * B_IN_HOP), "d_in0");
-  ok = ok && b->phone.create(B, b->d_in) && b->pitch.create(B, b->d_in, true) &&
-       b->wave.create(B, S, S, 9, b->phone.d_phone, b->pitch.d_q, b->pitch.d_feat);
+  ok = ok && b->phone.create(B, 1, b->d_in) && b->pitch.create(B, 1, b->d_in, true) &&
+       b->wave.create(B, 1, S, S, 9, b->phone.d_phone, b->pitch.d_q, b->pitch.d_feat);
   // the three modules advance in lockstep here: one shared hop counter, incremented once per step
   b->pitch.hop = b->phone.d_hop; b->wave.hop = b->phone.d_hop;
   b->phone.advance_hop = false; b->pitch.advance_hop = false; b->wave.advance_hop = true;

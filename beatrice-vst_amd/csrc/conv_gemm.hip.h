@@ -99,7 +99,6 @@ __global__ __launch_bounds__(TC::NTHR) void conv_gemm_kernel(const ConvArgs a) {
   constexpr int RED_FLOATS = LK > 1 ? P * MT * NT : 0;
   constexpr int LDS_FLOATS = STAGE_FLOATS * LK > RED_FLOATS ? STAGE_FLOATS * LK : RED_FLOATS;
   static_assert(L::NOUT % NT == 0, "N tile must divide NOUT");
-  static_assert(!L::GROUPED || L::T == 1, "grouped rows are streams");
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
@@ -130,8 +129,9 @@ __global__ __launch_bounds__(TC::NTHR) void conv_gemm_kernel(const ConvArgs a) {
     const int r = idx / A_F4_PER_ROW;
     int b = -1, t = 0;
     if (r < MT) {
-      if constexpr (L::GROUPED) {
-        b = a.perm[blockIdx.x * MT + r];
+      if constexpr (L::GROUPED) {  // grouped rows: perm holds row indices (stream * T + frame) or -1
+        const int m = a.perm[blockIdx.x * MT + r];
+        if (m >= 0) { b = m / L::T; t = m % L::T; }
       } else {
         const int m = m0 + r;
         if (m < M) { b = m / L::T; t = m % L::T; }
@@ -238,18 +238,18 @@ __global__ __launch_bounds__(TC::NTHR) void conv_gemm_kernel(const ConvArgs a) {
   if constexpr (L::RES) { pos_res = ring_pos(a.res, hop); R_res = a.res.n * a.res.m; }
 
   auto finish = [&](int r, int n, float v) {  // r: row in tile, n: absolute column
-    int b, t = 0;
+    int b = -1, t = 0;
     if constexpr (L::GROUPED) {
-      b = a.perm[blockIdx.x * MT + r];
+      const int m = a.perm[blockIdx.x * MT + r];
+      if (m >= 0) { b = m / L::T; t = m % L::T; }
     } else {
       const int m = m0 + r;
-      b = m < M ? m / L::T : -1;
-      t = m % L::T;
+      if (m < M) { b = m / L::T; t = m % L::T; }
     }
     if (b < 0) return;
     if constexpr (L::EPI == EPI_BIAS) v = v + a.bias[n];
     if constexpr (L::EPI == EPI_SCALE) v = v * a.scale;
-    if constexpr (L::EPI == EPI_ROWSCALE) v = v * a.rowscale[b];
+    if constexpr (L::EPI == EPI_ROWSCALE) v = v * a.rowscale[b * L::T + t];
     if constexpr (L::ACT == ACT_GELU) v = bsp::gelu(v);
     if constexpr (L::RES) v = a.res.base[((size_t)b * R_res + pos_res) * a.res.C + (size_t)t * L::NOUT + n] + v;
     a.out.base[((size_t)b * R_out + pos_out) * a.out.C + (size_t)t * L::NOUT + n] = v;
@@ -369,7 +369,8 @@ __global__ __launch_bounds__(64 * LN * L::P) void lat_gemm_kernel(const ConvArgs
     if (idx < A_F4 && kk < L::K && !(ABL & 2)) {
       int b = -1, t = 0;
       if constexpr (L::GROUPED) {
-        b = a.perm[blockIdx.x * MT + r];
+        const int m = a.perm[blockIdx.x * MT + r];
+        if (m >= 0) { b = m / L::T; t = m % L::T; }
       } else {
         const int m = m0 + r;
         if (m < M) { b = m / L::T; t = m % L::T; }
@@ -395,18 +396,18 @@ __global__ __launch_bounds__(64 * LN * L::P) void lat_gemm_kernel(const ConvArgs
     e_bias[s] = 0.f; e_res[s] = 0.f; e_rs[s] = 1.f;
     if (idx < MT * NT) {
       const int r = idx / NT, n = n0 + idx % NT;
-      int b, t = 0;
+      int b = -1, t = 0;
       if constexpr (L::GROUPED) {
-        b = a.perm[blockIdx.x * MT + r];
+        const int m = a.perm[blockIdx.x * MT + r];
+        if (m >= 0) { b = m / L::T; t = m % L::T; }
       } else {
         const int m = m0 + r;
-        b = m < M ? m / L::T : -1;
-        t = m % L::T;
+        if (m < M) { b = m / L::T; t = m % L::T; }
       }
       if (b >= 0) {
         e_dst[s] = a.out.base + ((size_t)b * R_out + pos_out) * a.out.C + (size_t)t * L::NOUT + n;
         if constexpr (L::EPI == EPI_BIAS && !(ABL & 8)) e_bias[s] = a.bias[n];
-        if constexpr (L::EPI == EPI_ROWSCALE) e_rs[s] = a.rowscale[b];
+        if constexpr (L::EPI == EPI_ROWSCALE) e_rs[s] = a.rowscale[b * L::T + t];
         if constexpr (L::RES && !(ABL & 8)) {
           const int R_res = a.res.n * a.res.m;
           e_res[s] = a.res.base[((size_t)b * R_res + ring_pos(a.res, hop)) * a.res.C + (size_t)t * L::NOUT + n];

@@ -74,18 +74,19 @@ struct PhoneWeights {
 };
 struct PhoneState {
   int B = 0;
+  int H = 1;  // hops per step (1 = real-time per-hop path; 2/4 = block mode for bulk conversion)
   RingArena arena;
-  Ring audio, f[5], rb[4], gi, gh, h, raw;
-  float* d_in = nullptr;     // [B][160]; owned unless shared
+  Ring audio, f[5], rb[4], h, raw;
+  float* d_in = nullptr;     // [B][H*160]; owned unless shared
   bool owns_in = false;
-  float* d_phone = nullptr;  // [B][128]
+  float* d_phone = nullptr;  // [B][H][128]
   const float** d_cbT = nullptr;    // [B] device pointers
   const float** d_cnorm = nullptr;  // [B]
   int* d_vqk = nullptr;             // [B]
   int* d_hop = nullptr;       // owned hop counter
   int* hop = nullptr;         // counter the kernels read (== d_hop unless shared by a batch)
   bool advance_hop = true;    // this module's forward ends with the counter increment
-  bool create(int B, float* shared_in);
+  bool create(int B, int H, float* shared_in);
   void destroy();
 };
 void phone_forward(const PhoneWeights& w, const PhoneState& s, hipStream_t stream);
@@ -101,17 +102,19 @@ struct PitchWeights {
 };
 struct PitchState {
   int B = 0;
+  int H = 1;  // hops per step
   RingArena arena;
-  Ring audio, spec, p[3], gi, gh, h, logits;
+  Ring audio, spec, p[3], h, logits;
   float* d_in = nullptr;
   bool owns_in = false;
-  int *d_min_q = nullptr, *d_max_q = nullptr, *d_prev_q = nullptr, *d_q_raw = nullptr, *d_q = nullptr;
-  float* d_feat = nullptr;             // [B][4]
+  int *d_min_q = nullptr, *d_max_q = nullptr, *d_prev_q = nullptr;  // [B]
+  int *d_q_raw = nullptr, *d_q = nullptr;                          // [B][H]
+  float* d_feat = nullptr;             // [B][H][4]
   PitchParams* d_params = nullptr;     // [B] or nullptr (1-stream ABI: host does the transform)
   int* d_hop = nullptr;       // owned hop counter
   int* hop = nullptr;         // counter the kernels read (== d_hop unless shared by a batch)
   bool advance_hop = true;    // this module's forward ends with the counter increment
-  bool create(int B, float* shared_in, bool with_params);
+  bool create(int B, int H, float* shared_in, bool with_params);
   void destroy();
 };
 void pitch_forward(const PitchWeights& w, const PitchState& s, hipStream_t stream);
@@ -138,17 +141,17 @@ struct WaveWeights {
 };
 struct WaveState {
   int B = 0;
+  int H = 1;            // hops per step; attention rows = (stream, hop in step)
   int n_slots = 0;      // K/V slots per block in the tables
-  int n_tiles_max = 0;  // attention M-tiles (16 streams each) upper bound
+  int n_tiles_max = 0;  // attention M-tiles (16 rows each) upper bound
   RingArena arena;
   Ring e, x[B_NBLOCKS + 1], h1, xa, q, sc, o;
   Ring ya1, yb1, yc1, ya2;  // upsampler stage 1 and the stage-2 transposed conv output
   Ring tail;                // per-stream history block of the fused upsampler tail (wave_tail.hip.h)
-  float* d_inv = nullptr;  // [B]
-  // inputs (device): phone [B][128], q [B], feat [B][4]; owned unless shared with other modules
+  // inputs (device): phone [B][H][128], q [B][H], feat [B][H][4]; owned unless shared with other modules
   float* d_phone = nullptr; int* d_q = nullptr; float* d_feat = nullptr;
   bool owns_inputs = false;
-  float* d_out = nullptr;  // [B][240]
+  float* d_out = nullptr;  // [B][H*240]
   // conditioning tables and per-stream selectors
   float* d_add_tab = nullptr; int n_add = 0;  // [n_add][256] projected additive embeddings
   float* d_frm_tab = nullptr; int n_frm = 0;  // [n_frm][256] projected formant embeddings
@@ -160,7 +163,7 @@ struct WaveState {
   int* d_hop = nullptr;       // owned hop counter
   int* hop = nullptr;         // counter the kernels read (== d_hop unless shared by a batch)
   bool advance_hop = true;    // this module's forward ends with the counter increment
-  bool create(int B, int n_slots, int n_add, int n_frm, float* shared_phone, int* shared_q, float* shared_feat);
+  bool create(int B, int H, int n_slots, int n_add, int n_frm, float* shared_phone, int* shared_q, float* shared_feat);
   void destroy();
 };
 void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t stream);

@@ -23,6 +23,7 @@ struct GruArgs {
   const float *bih, *bhh;     // [3H]
   const int* hop;
   int B;
+  int t;  // hop within the step: x frame t, previous state = h frame t-1, new state -> h frame t
 };
 
 template <int IN, int H>
@@ -53,14 +54,14 @@ static __global__ __launch_bounds__(384) void gru_fused_kernel(const GruArgs a) 
   for (int e = tid; e < 16 * (IN / 4); e += 384) {
     const int r = e / (IN / 4), q = e % (IN / 4);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (b0 + r < a.B) v = *reinterpret_cast<const float4*>(ring_frame(a.x, b0 + r, px, 0) + 4 * q);
+    if (b0 + r < a.B) v = *reinterpret_cast<const float4*>(ring_frame(a.x, b0 + r, px, a.t) + 4 * q);
     float2* d = reinterpret_cast<float2*>(&xs[r * XS + 4 * q]);
     d[0] = make_float2(v.x, v.y); d[1] = make_float2(v.z, v.w);
   }
   for (int e = tid; e < 16 * (H / 4); e += 384) {
     const int r = e / (H / 4), q = e % (H / 4);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (b0 + r < a.B) v = *reinterpret_cast<const float4*>(ring_frame(a.h, b0 + r, ph, -1) + 4 * q);
+    if (b0 + r < a.B) v = *reinterpret_cast<const float4*>(ring_frame(a.h, b0 + r, ph, a.t - 1) + 4 * q);
     float2* d = reinterpret_cast<float2*>(&hs[r * HS + 4 * q]);
     d[0] = make_float2(v.x, v.y); d[1] = make_float2(v.z, v.w);
   }
@@ -98,7 +99,7 @@ static __global__ __launch_bounds__(384) void gru_fused_kernel(const GruArgs a) 
       const float zz = bsp::sigmoid(gi_z + gh_z);
       const float nn = bsp::tanh(bsp::fma(rr, gh_n, gi_n));
       const float hp = hs[r * HS + j0 + j];
-      ring_frame(a.h, b0 + r, ph, 0)[j0 + j] = bsp::fma(zz, hp - nn, nn);
+      ring_frame(a.h, b0 + r, ph, a.t)[j0 + j] = bsp::fma(zz, hp - nn, nn);
     }
   }
 }
@@ -113,10 +114,10 @@ static inline void launch_gru(const char* name, const GruArgs& a, hipStream_t st
 
 // ---------------------------------------------------------------------------------------------
 struct AttnPvArgs {
-  const float* scores;   // [B][384], already scaled by 1/16
+  const float* scores;   // [rows][384], already scaled by 1/16; rows = (stream, hop)
   const float* v;        // packed V tables, slot stride 384*256
-  float* out;            // [B][256]
-  const int* perm;       // [n_tiles][16]
+  float* out;            // [rows][256]
+  const int* perm;       // [n_tiles][16] row indices or -1
   const int* tile_slot;  // [n_tiles]
 };
 

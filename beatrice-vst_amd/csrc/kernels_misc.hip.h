@@ -31,17 +31,22 @@ static __global__ void hop_advance_kernel(int* hop) { *hop = *hop + 1; }
 static __global__ __launch_bounds__(256) void phone_f1_kernel(const float* __restrict__ d_in, Ring audio,
                                                        Ring out, const float* __restrict__ w,
                                                        const float* __restrict__ bias,
-                                                       const int* hop_ptr) {
+                                                       const int* hop_ptr, int H) {
+  // grid (stream, hop-in-step).  Samples before the step come from the audio ring, the rest from d_in.
   __shared__ float x[5 + B_IN_HOP];
   __shared__ float ws[10 * 64];
-  const int b = blockIdx.x, tid = threadIdx.x, hop = *hop_ptr;
+  const int b = blockIdx.x, hh = blockIdx.y, tid = threadIdx.x, hop = *hop_ptr;
   const int pos = ring_pos(audio, hop);
+  const float* src = d_in + (size_t)b * H * B_IN_HOP;
   for (int i = tid; i < 10 * 64; i += 256) ws[i] = w[i];
-  if (tid < 5) x[tid] = *ring_frame(audio, b, pos, tid - 5);
+  if (tid < 5) {
+    const int i = hh * B_IN_HOP + tid - 5;
+    x[tid] = i < 0 ? *ring_frame(audio, b, pos, i) : src[i];
+  }
   if (tid < B_IN_HOP) {
-    const float v = d_in[(size_t)b * B_IN_HOP + tid];
+    const float v = src[hh * B_IN_HOP + tid];
     x[5 + tid] = v;
-    *ring_frame(audio, b, pos, tid) = v;
+    *ring_frame(audio, b, pos, hh * B_IN_HOP + tid) = v;
   }
   __syncthreads();
   const int t = tid >> 3, n0 = (tid & 7) * 8;
@@ -54,27 +59,9 @@ static __global__ __launch_bounds__(256) void phone_f1_kernel(const float* __res
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc[u] = bsp::fma(a, ws[j * 64 + n0 + u], acc[u]);
   }
-  float* o = ring_frame(out, b, ring_pos(out, hop), t) + n0;
+  float* o = ring_frame(out, b, ring_pos(out, hop), hh * 32 + t) + n0;
 #pragma unroll
   for (int u = 0; u < 8; ++u) o[u] = bsp::gelu(acc[u] + bias[n0 + u]);
-}
-
-// ---------------------------------------------------------------------------------------------
-// GRU gate math (MODEL_SPEC 3.2).  gi/gh = the two gate GEMMs (+bias), computed by conv_gemm.
-// h ring: C = H, n = 1, m = 2 (previous state = frame -1).
-static __global__ void gru_gate_kernel(const float* __restrict__ gi, const float* __restrict__ gh, Ring h,
-                                int H, int B, const int* hop_ptr) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= B * H) return;
-  const int b = idx / H, j = idx % H;
-  const int hop = *hop_ptr, pos = ring_pos(h, hop);
-  const float* gib = gi + (size_t)b * 3 * H;
-  const float* ghb = gh + (size_t)b * 3 * H;
-  const float r = bsp::sigmoid(gib[j] + ghb[j]);
-  const float z = bsp::sigmoid(gib[H + j] + ghb[H + j]);
-  const float nn = bsp::tanh(bsp::fma(r, ghb[2 * H + j], gib[2 * H + j]));
-  const float hp = ring_frame(h, b, pos, -1)[j];
-  ring_frame(h, b, pos, 0)[j] = bsp::fma(z, hp - nn, nn);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -82,8 +69,9 @@ static __global__ void gru_gate_kernel(const float* __restrict__ gi, const float
 // stream; thread j owns codebook row j.  cbT is the codebook transposed to [128][512] so the
 // distance loop reads coalesced rows.  Streams with k == 0 pass the raw vector through.
 struct VqArgs {
-  const float* raw;            // [B][128]
-  float* out;                  // [B][128]
+  int H;                       // hops per step: rows are (stream, hop), codebook per stream
+  const float* raw;            // [B][H][128]
+  float* out;                  // [B][H][128]
   const float* const* cbT;     // per stream: [128][512]
   const float* const* cnorm;   // per stream: [512]
   const int* k;                // per stream
@@ -93,12 +81,12 @@ static __global__ __launch_bounds__(512) void phone_vq_kernel(VqArgs a) {
   __shared__ float red_d[8];
   __shared__ int red_j[8];
   __shared__ int winner;
-  const int b = blockIdx.x, j = threadIdx.x, lane = j & 63, wave = j >> 6;
+  const int row = blockIdx.x, b = row / a.H, j = threadIdx.x, lane = j & 63, wave = j >> 6;
   const int k = a.k[b];
   const float* cbT = a.cbT[b];
-  if (j < B_PHONE_CH) x[j] = a.raw[(size_t)b * B_PHONE_CH + j];
+  if (j < B_PHONE_CH) x[j] = a.raw[(size_t)row * B_PHONE_CH + j];
   if (k <= 0 || cbT == nullptr) {
-    if (j < B_PHONE_CH) a.out[(size_t)b * B_PHONE_CH + j] = x[j];
+    if (j < B_PHONE_CH) a.out[(size_t)row * B_PHONE_CH + j] = x[j];
     return;
   }
   __syncthreads();
@@ -131,7 +119,7 @@ static __global__ __launch_bounds__(512) void phone_vq_kernel(VqArgs a) {
     if (j < B_PHONE_CH) acc = acc + cbT[j * B_CODEBOOK + wj];
     __syncthreads();
   }
-  if (j < B_PHONE_CH) a.out[(size_t)b * B_PHONE_CH + j] = acc / (float)k;
+  if (j < B_PHONE_CH) a.out[(size_t)row * B_PHONE_CH + j] = acc / (float)k;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -140,19 +128,21 @@ static __global__ __launch_bounds__(512) void phone_vq_kernel(VqArgs a) {
 static __global__ __launch_bounds__(256) void pitch_fft_kernel(const float* __restrict__ d_in, Ring audio,
                                                         Ring spec, const float* __restrict__ window,
                                                         const float* __restrict__ twiddle,
-                                                        const int* hop_ptr) {
+                                                        const int* hop_ptr, int H) {
   __shared__ float re[B_FFT_N], im[B_FFT_N];
   __shared__ float tw[B_FFT_N];
-  const int b = blockIdx.x, tid = threadIdx.x, hop = *hop_ptr;
+  const int b = blockIdx.x, hh = blockIdx.y, tid = threadIdx.x, hop = *hop_ptr;
   const int pos = ring_pos(audio, hop);
+  const float* src = d_in + (size_t)b * H * B_IN_HOP;
   for (int i = tid; i < B_FFT_N; i += 256) {
     tw[i] = twiddle[i];
+    const int si = hh * B_IN_HOP + i - B_PITCH_HIST;  // sample index relative to the start of the step
     float s;
-    if (i < B_PITCH_HIST) {
-      s = *ring_frame(audio, b, pos, i - B_PITCH_HIST);
+    if (si < 0) {
+      s = *ring_frame(audio, b, pos, si);
     } else {
-      s = d_in[(size_t)b * B_IN_HOP + (i - B_PITCH_HIST)];
-      *ring_frame(audio, b, pos, i - B_PITCH_HIST) = s;
+      s = src[si];
+      if (i >= B_PITCH_HIST) *ring_frame(audio, b, pos, si) = s;  // each hop block appends its own 160 samples
     }
     const int rev = (int)(__brev((unsigned)i) >> 22);
     re[rev] = s * window[i];
@@ -176,7 +166,7 @@ static __global__ __launch_bounds__(256) void pitch_fft_kernel(const float* __re
     }
     __syncthreads();
   }
-  float* o = ring_frame(spec, b, ring_pos(spec, hop), 0);
+  float* o = ring_frame(spec, b, ring_pos(spec, hop), hh);
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int k = tid + u * 256;
@@ -194,7 +184,8 @@ struct PitchParams {  // per stream
   int pitch_correction_type, pad;
 };
 struct PitchHeadArgs {
-  const float* logits;  // [B][448]
+  int H;                // hops per step; all per-hop arrays below are [B][H]...
+  const float* logits;  // [B][H][448]
   Ring h;               // GRU state ring (C=128)
   const float* d_in;    // [B][160]
   const float* voi_w;   // [128]
@@ -237,56 +228,62 @@ __device__ inline int pitch_transform_device(int q, const PitchParams& p) {
 static __global__ __launch_bounds__(64) void pitch_head_kernel(PitchHeadArgs a) {
   const int b = blockIdx.x, l = threadIdx.x;
   const int hop = *a.hop;
-  const float* lg = a.logits + (size_t)b * B_PITCH_BINS;
-  float v[7];
-#pragma unroll
-  for (int i = 0; i < 7; ++i) v[i] = lg[l + 64 * i];
   int lo = a.min_q[b], hi = a.max_q[b];
   if (hi < lo) hi = lo;
-  float bv = -__builtin_huge_valf();
-  int bj = 0x7fffffff;
-  float mx = v[0];
+  int prev = a.prev_q[b];
+  for (int hh = 0; hh < a.H; ++hh) {
+    const size_t row = (size_t)b * a.H + hh;
+    const float* lg = a.logits + row * B_PITCH_BINS;
+    float v[7];
 #pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    const int j = l + 64 * i;
-    mx = fmaxf(mx, v[i]);
-    if (j >= lo && j <= hi && (bj == 0x7fffffff || v[i] > bv)) { bv = v[i]; bj = j; }
-  }
+    for (int i = 0; i < 7; ++i) v[i] = lg[l + 64 * i];
+    float bv = -__builtin_huge_valf();
+    int bj = 0x7fffffff;
+    float mx = v[0];
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const float ov = __shfl_xor(bv, off, 64);
-    const int oj = __shfl_xor(bj, off, 64);
-    if (oj != 0x7fffffff && (bj == 0x7fffffff || ov > bv || (ov == bv && oj < bj))) { bv = ov; bj = oj; }
-  }
-  const int q = bj;
-  mx = bsp::wmax64(mx);
-  float s = 0.0f;
+    for (int i = 0; i < 7; ++i) {
+      const int j = l + 64 * i;
+      mx = fmaxf(mx, v[i]);
+      if (j >= lo && j <= hi && (bj == 0x7fffffff || v[i] > bv)) { bv = v[i]; bj = j; }
+    }
 #pragma unroll
-  for (int i = 0; i < 7; ++i) s = s + bsp::exp(v[i] - mx);
-  const float f0 = bsp::exp(lg[q] - mx) / bsp::wsum64(s);
-  const float* x = a.d_in + (size_t)b * B_IN_HOP;
-  float en = 0.0f;
-  for (int i = l; i < B_IN_HOP; i += 64) en = bsp::fma(x[i], x[i], en);
-  const float f1 = 0.1f * bsp::log(bsp::fma(bsp::wsum64(en), 1.0f / 160.0f, 1e-8f));
-  const float* hv = ring_frame(a.h, b, ring_pos(a.h, hop), 0);
-  const float pv = bsp::fma(hv[l + 64], a.voi_w[l + 64], bsp::fma(hv[l], a.voi_w[l], 0.0f));
-  const float f3 = bsp::sigmoid(bsp::wsum64(pv) + a.voi_b[0]);
-  if (l == 0) {
-    float dq = (float)(q - a.prev_q[b]) * 0.125f;
-    dq = dq < -1.0f ? -1.0f : (dq > 1.0f ? 1.0f : dq);
-    a.prev_q[b] = q;
-    float* f = a.feat + (size_t)b * 4;
-    f[0] = f0; f[1] = f1; f[2] = dq; f[3] = f3;
-    a.q_raw[b] = q;
-    a.q_out[b] = a.params ? pitch_transform_device(q, a.params[b]) : q;
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float ov = __shfl_xor(bv, off, 64);
+      const int oj = __shfl_xor(bj, off, 64);
+      if (oj != 0x7fffffff && (bj == 0x7fffffff || ov > bv || (ov == bv && oj < bj))) { bv = ov; bj = oj; }
+    }
+    const int q = bj;
+    mx = bsp::wmax64(mx);
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) s = s + bsp::exp(v[i] - mx);
+    const float f0 = bsp::exp(lg[q] - mx) / bsp::wsum64(s);
+    const float* x = a.d_in + row * B_IN_HOP;
+    float en = 0.0f;
+    for (int i = l; i < B_IN_HOP; i += 64) en = bsp::fma(x[i], x[i], en);
+    const float f1 = 0.1f * bsp::log(bsp::fma(bsp::wsum64(en), 1.0f / 160.0f, 1e-8f));
+    const float* hv = ring_frame(a.h, b, ring_pos(a.h, hop), hh);
+    const float pv = bsp::fma(hv[l + 64], a.voi_w[l + 64], bsp::fma(hv[l], a.voi_w[l], 0.0f));
+    const float f3 = bsp::sigmoid(bsp::wsum64(pv) + a.voi_b[0]);
+    if (l == 0) {
+      float dq = (float)(q - prev) * 0.125f;
+      dq = dq < -1.0f ? -1.0f : (dq > 1.0f ? 1.0f : dq);
+      float* f = a.feat + row * 4;
+      f[0] = f0; f[1] = f1; f[2] = dq; f[3] = f3;
+      a.q_raw[row] = q;
+      a.q_out[row] = a.params ? pitch_transform_device(q, a.params[b]) : q;
+    }
+    prev = q;
   }
+  if (l == 0) a.prev_q[b] = prev;
 }
 
 // ---------------------------------------------------------------------------------------------
 // Waveform input mix, conditioning part (MODEL_SPEC 4.4.1):
 //   e[b][n] = (pitch_emb[q][n] + Wf.feat[b]) + (add_tab[add_idx[b]][n] + frm_tab[frm_idx[b]][n])
 struct CondArgs {
-  const int* q;        // [B]
+  int H;               // hops per step; q/feat/e rows are (stream, hop)
+  const int* q;        // [B][H]
   const float* feat;   // [B][4]
   const float* pitch_emb;
   const float* feat_w; // [4][256]
@@ -295,63 +292,15 @@ struct CondArgs {
   float* e;            // [B][256]
 };
 static __global__ __launch_bounds__(256) void wave_cond_kernel(CondArgs a) {
-  const int b = blockIdx.x, n = threadIdx.x;
-  int q = a.q[b];
+  const int row = blockIdx.x, b = row / a.H, n = threadIdx.x;
+  int q = a.q[row];
   q = q < 0 ? 0 : (q > B_PITCH_BINS - 1 ? B_PITCH_BINS - 1 : q);
-  const float* f = a.feat + (size_t)b * 4;
+  const float* f = a.feat + (size_t)row * 4;
   float fp = 0.0f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) fp = bsp::fma(f[i], a.feat_w[i * B_HID + n], fp);
   const float c = a.add_tab[(size_t)a.add_idx[b] * B_HID + n] + a.frm_tab[(size_t)a.frm_idx[b] * B_HID + n];
-  a.e[(size_t)b * B_HID + n] = (a.pitch_emb[(size_t)q * B_HID + n] + fp) + c;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Attention softmax statistics (MODEL_SPEC 4.4.2): one wavefront per stream row of 384 scores;
-// rewrites the row as e_j = exp(s_j - max) and stores 1/sum.
-static __global__ __launch_bounds__(64) void attn_softmax_kernel(float* __restrict__ s, float* __restrict__ inv, int B) {
-  const int b = blockIdx.x, l = threadIdx.x;
-  if (b >= B) return;
-  float* row = s + (size_t)b * B_KV_LEN;
-  float v[6];
-  float mx = -__builtin_huge_valf();
-#pragma unroll
-  for (int i = 0; i < 6; ++i) { v[i] = row[l + 64 * i]; mx = fmaxf(mx, v[i]); }
-  mx = bsp::wmax64(mx);
-  float a = 0.0f;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) { v[i] = bsp::exp(v[i] - mx); a = a + v[i]; row[l + 64 * i] = v[i]; }
-  const float tot = bsp::wsum64(a);
-  if (l == 0) inv[b] = 1.0f / tot;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Output layer (MODEL_SPEC 4.4.3 last step): LeakyReLU -> Conv1d(16 -> 1, k=7) -> tanh.
-// N = 1, so VALU: one workgroup per stream, input frames staged through LDS, coalesced store of
-// the 240 output samples.
-static __global__ __launch_bounds__(256) void wave_final_kernel(Ring y, const float* __restrict__ w,
-                                                         const float* __restrict__ bias,
-                                                         float* __restrict__ d_out, const int* hop_ptr) {
-  __shared__ float ys[(B_OUT_HOP + 6) * 17];
-  __shared__ float ws[7 * 16];
-  const int b = blockIdx.x, tid = threadIdx.x, hop = *hop_ptr;
-  const int pos = ring_pos(y, hop);
-  if (tid < 7 * 16) ws[tid] = w[tid];
-  for (int i = tid; i < (B_OUT_HOP + 6) * 4; i += 256) {
-    const int fr = i >> 2, q = i & 3;
-    const float4 v = *reinterpret_cast<const float4*>(ring_frame(y, b, pos, fr - 6) + 4 * q);
-    float* d = &ys[fr * 17 + 4 * q];
-    d[0] = bsp::lrelu(v.x); d[1] = bsp::lrelu(v.y); d[2] = bsp::lrelu(v.z); d[3] = bsp::lrelu(v.w);
-  }
-  __syncthreads();
-  if (tid < B_OUT_HOP) {
-    float acc = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 7; ++j)
-#pragma unroll
-      for (int c = 0; c < 16; ++c) acc = bsp::fma(ys[(tid + j) * 17 + c], ws[j * 16 + c], acc);
-    d_out[(size_t)b * B_OUT_HOP + tid] = bsp::tanh(acc + bias[0]);
-  }
+  a.e[(size_t)row * B_HID + n] = (a.pitch_emb[(size_t)q * B_HID + n] + fp) + c;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,29 +1,35 @@
 // phone.hip -- content encoder forward pass (MODEL_SPEC 4.1), the body of
-// Beatrice20rc0_ExtractPhone1 (reference lib/beatricelib/beatrice.h:243-247) for B streams.
+// Beatrice20rc0_ExtractPhone1 (reference lib/beatricelib/beatrice.h:243-247) for B streams and H
+// consecutive hops per step (H = 1: the real-time per-hop path; H > 1: block mode, batch.hip).
 #include "conv_gemm.hip.h"
 #include "engine.h"
 #include "fused_small.hip.h"
 
 namespace bhip {
 
-bool PhoneState::create(int B_, float* shared_in) {
-  B = B_;
+bool PhoneState::create(int B_, int H_, float* shared_in) {
+  B = B_; H = H_;
+  auto slots = [&](int n0, int hist) { return 1 + (hist + n0 * H - 1) / (n0 * H); };
   std::vector<RingSpec> specs = {
-      {&audio, 1, B_IN_HOP, 2},
-      {&f[0], 64, 32, 2}, {&f[1], 128, 8, 2}, {&f[2], 256, 4, 2}, {&f[3], 256, 2, 2}, {&f[4], 256, 1, 5},
-      {&rb[0], 256, 1, 5}, {&rb[1], 256, 1, 5}, {&rb[2], 256, 1, 5}, {&rb[3], 256, 1, 1},
-      {&gi, 768, 1, 1}, {&gh, 768, 1, 1}, {&h, 256, 1, 2}, {&raw, B_PHONE_CH, 1, 1},
+      {&audio, 1, B_IN_HOP * H, slots(B_IN_HOP, 5)},
+      {&f[0], 64, 32 * H, slots(32, 4)}, {&f[1], 128, 8 * H, slots(8, 2)}, {&f[2], 256, 4 * H, slots(4, 2)},
+      {&f[3], 256, 2 * H, slots(2, 2)}, {&f[4], 256, H, slots(1, 4)},
+      {&rb[0], 256, H, slots(1, 4)}, {&rb[1], 256, H, slots(1, 4)}, {&rb[2], 256, H, slots(1, 4)}, {&rb[3], 256, H, 1},
+      {&h, 256, H, slots(1, 1)}, {&raw, B_PHONE_CH, H, 1},
   };
   if (!arena.build(B, specs)) return false;
   if (shared_in) { d_in = shared_in; owns_in = false; }
-  else { BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_in), sizeof(float) * B * B_IN_HOP)); owns_in = true;
-         BHIP_TRY(hipMemset(d_in, 0, sizeof(float) * B * B_IN_HOP)); }
-  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_phone), sizeof(float) * B * B_PHONE_CH));
+  else {
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_in), sizeof(float) * B * H * B_IN_HOP));
+    BHIP_TRY(hipMemset(d_in, 0, sizeof(float) * B * H * B_IN_HOP));
+    owns_in = true;
+  }
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_phone), sizeof(float) * B * H * B_PHONE_CH));
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cbT), sizeof(float*) * B));
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cnorm), sizeof(float*) * B));
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_vqk), sizeof(int) * B));
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hop), sizeof(int)));
-  BHIP_TRY(hipMemset(d_phone, 0, sizeof(float) * B * B_PHONE_CH));
+  BHIP_TRY(hipMemset(d_phone, 0, sizeof(float) * B * H * B_PHONE_CH));
   BHIP_TRY(hipMemset(d_cbT, 0, sizeof(float*) * B));
   BHIP_TRY(hipMemset(d_cnorm, 0, sizeof(float*) * B));
   BHIP_TRY(hipMemset(d_vqk, 0, sizeof(int) * B));
@@ -45,23 +51,22 @@ void PhoneState::destroy() {
   d_in = d_phone = nullptr; d_cbT = d_cnorm = nullptr; d_vqk = d_hop = nullptr;
 }
 
-//                 CIN NOUT K  S  D  T  PRE       ACT       EPI       RES
-using F2 = Layer<64, 128, 8, 4, 1, 8, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
-using F3 = Layer<128, 256, 4, 2, 1, 4, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
-using F4 = Layer<256, 256, 4, 2, 1, 2, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
-using F5 = Layer<256, 256, 4, 2, 1, 1, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
-using RBL = Layer<256, 256, 5, 1, 1, 1, PRE_NONE, ACT_GELU, EPI_BIAS, true>;
-using GATE = Layer<256, 768, 1, 1, 1, 1, PRE_NONE, ACT_NONE, EPI_BIAS, false>;
-using OUTL = Layer<256, B_PHONE_CH, 1, 1, 1, 1, PRE_NONE, ACT_NONE, EPI_BIAS, false>;
-
 #define MISC_LAUNCH(NAME, FLOPS, BYTES, KERNEL, GRID, BLOCK, ...)                              \
   launch_site(LaunchInfo{NAME, (double)(FLOPS), (double)(BYTES)}, st,                          \
               [&] { hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, st, __VA_ARGS__); })
 
-void phone_forward(const PhoneWeights& w, const PhoneState& s, hipStream_t st) {
+template <int H>
+static void phone_forward_h(const PhoneWeights& w, const PhoneState& s, hipStream_t st) {
+  //                 CIN NOUT K  S  D  T      PRE       ACT       EPI       RES
+  using F2 = Layer<64, 128, 8, 4, 1, 8 * H, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
+  using F3 = Layer<128, 256, 4, 2, 1, 4 * H, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
+  using F4 = Layer<256, 256, 4, 2, 1, 2 * H, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
+  using F5 = Layer<256, 256, 4, 2, 1, H, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
+  using RBL = Layer<256, 256, 5, 1, 1, H, PRE_NONE, ACT_GELU, EPI_BIAS, true>;
+  using OUTL = Layer<256, B_PHONE_CH, 1, 1, 1, H, PRE_NONE, ACT_NONE, EPI_BIAS, false>;
   const int B = s.B;
-  MISC_LAUNCH("phone.f1", 2.0 * B * 32 * 64 * 10, 4.0 * B * (160 + 32 * 64), phone_f1_kernel, dim3(B), dim3(256), s.d_in,
-              s.audio, s.f[0], w.f1_w, w.f1_b, s.hop);
+  MISC_LAUNCH("phone.f1", 2.0 * B * H * 32 * 64 * 10, 4.0 * B * H * (160 + 32 * 64), phone_f1_kernel, dim3(B, H), dim3(256), s.d_in,
+              s.audio, s.f[0], w.f1_w, w.f1_b, s.hop, H);
   launch_auto<F2>("phone.f2", conv_args(s.f[0], s.f[1], w.f_w[0], w.f_b[0], s.hop, B), st);
   launch_auto<F3>("phone.f3", conv_args(s.f[1], s.f[2], w.f_w[1], w.f_b[1], s.hop, B), st);
   launch_auto<F4>("phone.f4", conv_args(s.f[2], s.f[3], w.f_w[2], w.f_b[2], s.hop, B), st);
@@ -71,12 +76,23 @@ void phone_forward(const PhoneWeights& w, const PhoneState& s, hipStream_t st) {
     launch_auto<RBL>("phone.rb", conv_args(*cur, s.rb[i], w.rb_w[i], w.rb_b[i], s.hop, B), st);
     cur = &s.rb[i];
   }
-  GruArgs ga{*cur, s.h, w.gru_wih, w.gru_whh, w.gru_bih, w.gru_bhh, s.hop, B};
-  launch_gru<256, 256>("phone.gru", ga, st);
+  for (int t = 0; t < H; ++t) {  // the recurrence is sequential over the hops of the step
+    GruArgs ga{*cur, s.h, w.gru_wih, w.gru_whh, w.gru_bih, w.gru_bhh, s.hop, B, t};
+    launch_gru<256, 256>("phone.gru", ga, st);
+  }
   launch_auto<OUTL>("phone.out", conv_args(s.h, s.raw, w.out_w, w.out_b, s.hop, B), st);
-  VqArgs v{s.raw.base, s.d_phone, s.d_cbT, s.d_cnorm, s.d_vqk};
-  MISC_LAUNCH("phone.vq", 0 /* k-dependent: 131 kFLOP per stream with k > 0, pass-through at k = 0 */, 4.0 * B * 256, phone_vq_kernel, dim3(B), dim3(512), v);
+  VqArgs v{H, s.raw.base, s.d_phone, s.d_cbT, s.d_cnorm, s.d_vqk};
+  MISC_LAUNCH("phone.vq", 0 /* k-dependent: 131 kFLOP per stream-hop with k > 0, pass-through at k = 0 */, 4.0 * B * H * 256, phone_vq_kernel,
+              dim3(B * H), dim3(512), v);
   if (s.advance_hop) MISC_LAUNCH("hop_advance", 0, 4, hop_advance_kernel, dim3(1), dim3(1), s.hop);
+}
+
+void phone_forward(const PhoneWeights& w, const PhoneState& s, hipStream_t st) {
+  switch (s.H) {
+    case 1: phone_forward_h<1>(w, s, st); break;
+    case 2: phone_forward_h<2>(w, s, st); break;
+    default: phone_forward_h<4>(w, s, st); break;
+  }
 }
 
 }  // namespace bhip

@@ -8,39 +8,37 @@
 namespace bhip {
 
 static const int kBlockDil[B_NBLOCKS] = {1, 2, 4, 8};
-static const int kUpT[5] = {1, 5, 20, 80, 240};
-static const int kUpC[5] = {256, 128, 64, 32, 16};
 
-bool WaveState::create(int B_, int n_slots_, int n_add_, int n_frm_, float* shared_phone, int* shared_q,
+bool WaveState::create(int B_, int H_, int n_slots_, int n_add_, int n_frm_, float* shared_phone, int* shared_q,
                        float* shared_feat) {
-  B = B_; n_slots = n_slots_; n_add = n_add_; n_frm = n_frm_;
-  n_tiles_max = (B + 15) / 16 + n_slots;
+  B = B_; H = H_; n_slots = n_slots_; n_add = n_add_; n_frm = n_frm_;
+  const int rows = B * H;
+  n_tiles_max = (rows + 15) / 16 + n_slots;  // rows grouped by slot: at most one partial tile per slot
+  auto slots = [&](int n0, int hist) { return 1 + (hist + n0 * H - 1) / (n0 * H); };
   std::vector<RingSpec> specs = {
-      {&e, B_HID, 1, 1},
-      {&x[0], B_HID, 1, 1 + 2 * kBlockDil[0]}, {&x[1], B_HID, 1, 1 + 2 * kBlockDil[1]},
-      {&x[2], B_HID, 1, 1 + 2 * kBlockDil[2]}, {&x[3], B_HID, 1, 1 + 2 * kBlockDil[3]}, {&x[4], B_HID, 1, 2},
-      {&h1, B_HID, 1, 1}, {&xa, B_HID, 1, 1}, {&q, B_HID, 1, 1}, {&sc, B_KV_LEN, 1, 1}, {&o, B_HID, 1, 1},
+      {&e, B_HID, H, 1},
+      {&x[0], B_HID, H, slots(1, 2 * kBlockDil[0])}, {&x[1], B_HID, H, slots(1, 2 * kBlockDil[1])},
+      {&x[2], B_HID, H, slots(1, 2 * kBlockDil[2])}, {&x[3], B_HID, H, slots(1, 2 * kBlockDil[3])}, {&x[4], B_HID, H, slots(1, 1)},
+      {&h1, B_HID, H, 1}, {&xa, B_HID, H, 1}, {&q, B_HID, H, 1}, {&sc, B_KV_LEN, H, 1}, {&o, B_HID, H, 1},
   };
-  specs.push_back({&ya1, 128, 5, 2});   // history 2 (res1a, k3)
-  specs.push_back({&yb1, 128, 5, 3});   // history 6 (res1b, k3 dil 3)
-  specs.push_back({&yc1, 128, 5, 2});   // history 1 (up2)
-  specs.push_back({&ya2, 64, 20, 2});   // history 2 (first layer of the fused tail)
+  specs.push_back({&ya1, 128, 5 * H, slots(5, 2)});   // history 2 (res1a, k3)
+  specs.push_back({&yb1, 128, 5 * H, slots(5, 6)});   // history 6 (res1b, k3 dil 3)
+  specs.push_back({&yc1, 128, 5 * H, slots(5, 1)});   // history 1 (up2)
+  specs.push_back({&ya2, 64, 20 * H, slots(20, 2)});  // history 2 (first layer of the fused tail)
   specs.push_back({&tail, TAIL_STATE_FLOATS, 1, 1});
   if (!arena.build(B, specs)) return false;
   if (shared_phone) { d_phone = shared_phone; d_q = shared_q; d_feat = shared_feat; owns_inputs = false; }
   else {
-    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_phone), sizeof(float) * B * B_PHONE_CH));
-    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_q), sizeof(int) * B));
-    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_feat), sizeof(float) * B * 4));
-    BHIP_TRY(hipMemset(d_phone, 0, sizeof(float) * B * B_PHONE_CH));
-    BHIP_TRY(hipMemset(d_q, 0, sizeof(int) * B));
-    BHIP_TRY(hipMemset(d_feat, 0, sizeof(float) * B * 4));
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_phone), sizeof(float) * rows * B_PHONE_CH));
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_q), sizeof(int) * rows));
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_feat), sizeof(float) * rows * 4));
+    BHIP_TRY(hipMemset(d_phone, 0, sizeof(float) * rows * B_PHONE_CH));
+    BHIP_TRY(hipMemset(d_q, 0, sizeof(int) * rows));
+    BHIP_TRY(hipMemset(d_feat, 0, sizeof(float) * rows * 4));
     owns_inputs = true;
   }
-  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(float) * B * B_OUT_HOP));
-  BHIP_TRY(hipMemset(d_out, 0, sizeof(float) * B * B_OUT_HOP));
-  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_inv), sizeof(float) * B));
-  BHIP_TRY(hipMemset(d_inv, 0, sizeof(float) * B));
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(float) * rows * B_OUT_HOP));
+  BHIP_TRY(hipMemset(d_out, 0, sizeof(float) * rows * B_OUT_HOP));
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_add_tab), sizeof(float) * n_add * B_HID));
   BHIP_TRY(hipMemset(d_add_tab, 0, sizeof(float) * n_add * B_HID));
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_frm_tab), sizeof(float) * n_frm * B_HID));
@@ -50,8 +48,8 @@ bool WaveState::create(int B_, int n_slots_, int n_add_, int n_frm_, float* shar
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_frm_idx), sizeof(int) * B));
   BHIP_TRY(hipMemset(d_frm_idx, 0, sizeof(int) * B));
   std::vector<int> perm((size_t)n_tiles_max * 16, -1), slot(n_tiles_max, -1);
-  for (int b = 0; b < B; ++b) perm[b] = b;
-  for (int t = 0; t < (B + 15) / 16; ++t) slot[t] = 0;
+  for (int r = 0; r < rows; ++r) perm[r] = r;
+  for (int t = 0; t < (rows + 15) / 16; ++t) slot[t] = 0;
   for (int blk = 0; blk < B_NBLOCKS; ++blk) {
     const size_t kvf = (size_t)n_slots * B_HID * B_KV_LEN;
     BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_kt[blk]), sizeof(float) * kvf));
@@ -74,82 +72,90 @@ bool WaveState::create(int B_, int n_slots_, int n_add_, int n_frm_, float* shar
 void WaveState::destroy() {
   arena.release();
   if (owns_inputs) { if (d_phone) (void)hipFree(d_phone); if (d_q) (void)hipFree(d_q); if (d_feat) (void)hipFree(d_feat); }
-  void* ptrs[] = {d_out, d_inv, d_add_tab, d_frm_tab, d_add_idx, d_frm_idx, d_hop};
+  void* ptrs[] = {d_out, d_add_tab, d_frm_tab, d_add_idx, d_frm_idx, d_hop};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int b = 0; b < B_NBLOCKS; ++b) {
     void* q4[] = {d_kt[b], d_v[b], d_perm[b], d_tile_slot[b]};
     for (void* p : q4) if (p) (void)hipFree(p);
     d_kt[b] = d_v[b] = nullptr; d_perm[b] = d_tile_slot[b] = nullptr;
   }
-  d_phone = d_feat = d_out = d_inv = d_add_tab = d_frm_tab = nullptr;
+  d_phone = d_feat = d_out = d_add_tab = d_frm_tab = nullptr;
   d_q = d_add_idx = d_frm_idx = d_hop = nullptr;
 }
 
-using INP = Layer<B_PHONE_CH, B_HID, 1, 1, 1, 1, PRE_NONE, ACT_NONE, EPI_BIAS, true>;
-template <int D> using C1 = Layer<B_HID, B_HID, 3, 1, D, 1, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
-using C2 = Layer<B_HID, B_HID, 1, 1, 1, 1, PRE_NONE, ACT_NONE, EPI_BIAS, true>;
-using QL = Layer<B_HID, B_HID, 1, 1, 1, 1, PRE_NONE, ACT_NONE, EPI_BIAS, false>;
-using SCORE = Layer<B_HID, B_KV_LEN, 1, 1, 1, 1, PRE_NONE, ACT_NONE, EPI_SCALE, false, true>;
-using PV = Layer<B_KV_LEN, B_HID, 1, 1, 1, 1, PRE_NONE, ACT_NONE, EPI_ROWSCALE, false, true>;
+template <int H> using INP = Layer<B_PHONE_CH, B_HID, 1, 1, 1, H, PRE_NONE, ACT_NONE, EPI_BIAS, true>;
+template <int D, int H> using C1 = Layer<B_HID, B_HID, 3, 1, D, H, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
+template <int H> using C2 = Layer<B_HID, B_HID, 1, 1, 1, H, PRE_NONE, ACT_NONE, EPI_BIAS, true>;
+template <int H> using QL = Layer<B_HID, B_HID, 1, 1, 1, H, PRE_NONE, ACT_NONE, EPI_BIAS, false>;
+template <int H> using SCORE = Layer<B_HID, B_KV_LEN, 1, 1, 1, H, PRE_NONE, ACT_NONE, EPI_SCALE, false, true>;
 template <int CIN, int COUT, int R, int TIN> using UP = Layer<CIN, R * COUT, 2, 1, 1, TIN, PRE_LRELU, ACT_NONE, EPI_BIAS, false>;
 template <int C, int D, int T> using RES = Layer<C, C, 3, 1, D, T, PRE_LRELU, ACT_NONE, EPI_BIAS, true>;
-using TGQ = TileCfg<1, 1, 1, 2, 1>;  // grouped attention scores: 16 streams x 32 keys, K = 256 (one segment)
-using TGV = TileCfg<1, 1, 1, 2, 2>;  // grouped attention P.V: 16 streams x 32 channels, two k-groups (K = 384)
+using TGQ = TileCfg<1, 1, 1, 2, 1>;  // grouped attention scores: 16 rows x 32 keys, K = 256 (one segment)
 
 #define MISC_LAUNCH(NAME, FLOPS, BYTES, KERNEL, GRID, BLOCK, ...)                              \
   launch_site(LaunchInfo{NAME, (double)(FLOPS), (double)(BYTES)}, st,                          \
               [&] { hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, st, __VA_ARGS__); })
 
-template <int D>
+template <int D, int H>
 static void launch_c1(const WaveWeights& w, const WaveState& s, int blk, hipStream_t st) {
-  launch_auto<C1<D>>("wave.blk.c1", conv_args(s.x[blk], s.h1, w.c1_w[blk], w.c1_b[blk], s.hop, s.B), st);
+  launch_auto<C1<D, H>>("wave.blk.c1", conv_args(s.x[blk], s.h1, w.c1_w[blk], w.c1_b[blk], s.hop, s.B), st);
 }
 
-void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t st) {
-  const int B = s.B;
-  CondArgs ca{s.d_q, s.d_feat, w.pitch_emb, w.feat_w, s.d_add_tab, s.d_add_idx, s.d_frm_tab, s.d_frm_idx, s.e.base};
-  MISC_LAUNCH("wave.cond", 11.0 * B * 256, 4.0 * B * 256 * 4, wave_cond_kernel, dim3(B), dim3(256), ca);
-  const Ring phone_in{s.d_phone, B_PHONE_CH, 1, 1};
+template <int H>
+static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t st) {
+  const int B = s.B, rows = s.B * H;
+  CondArgs ca{H, s.d_q, s.d_feat, w.pitch_emb, w.feat_w, s.d_add_tab, s.d_add_idx, s.d_frm_tab, s.d_frm_idx, s.e.base};
+  MISC_LAUNCH("wave.cond", 11.0 * rows * 256, 4.0 * rows * 256 * 4, wave_cond_kernel, dim3(rows), dim3(256), ca);
+  const Ring phone_in{s.d_phone, B_PHONE_CH, H, 1};
   ConvArgs a = conv_args(phone_in, s.x[0], w.inp_w, w.inp_b, s.hop, B);
   a.res = s.e;
-  launch_auto<INP>("wave.inp", a, st);
+  launch_auto<INP<H>>("wave.inp", a, st);
   for (int blk = 0; blk < B_NBLOCKS; ++blk) {
     switch (blk) {
-      case 0: launch_c1<1>(w, s, blk, st); break;
-      case 1: launch_c1<2>(w, s, blk, st); break;
-      case 2: launch_c1<4>(w, s, blk, st); break;
-      default: launch_c1<8>(w, s, blk, st); break;
+      case 0: launch_c1<1, H>(w, s, blk, st); break;
+      case 1: launch_c1<2, H>(w, s, blk, st); break;
+      case 2: launch_c1<4, H>(w, s, blk, st); break;
+      default: launch_c1<8, H>(w, s, blk, st); break;
     }
     a = conv_args(s.h1, s.xa, w.c2_w[blk], w.c2_b[blk], s.hop, B);
     a.res = s.x[blk];
-    launch_auto<C2>("wave.blk.c2", a, st);
-    launch_auto<QL>("wave.blk.q", conv_args(s.xa, s.q, w.q_w[blk], w.q_b[blk], s.hop, B), st);
+    launch_auto<C2<H>>("wave.blk.c2", a, st);
+    launch_auto<QL<H>>("wave.blk.q", conv_args(s.xa, s.q, w.q_w[blk], w.q_b[blk], s.hop, B), st);
     a = conv_args(s.q, s.sc, s.d_kt[blk], nullptr, s.hop, B);
     a.scale = 0.0625f; a.perm = s.d_perm[blk]; a.tile_slot = s.d_tile_slot[blk];
     a.w_slot_stride = (size_t)B_HID * B_KV_LEN;
-    launch_conv<SCORE, TGQ>("wave.blk.attn_qk", a, s.n_tiles_max, st);
+    launch_conv<SCORE<H>, TGQ>("wave.blk.attn_qk", a, s.n_tiles_max, st);
     AttnPvArgs pa{s.sc.base, s.d_v[blk], s.o.base, s.d_perm[blk], s.d_tile_slot[blk]};
-    MISC_LAUNCH("wave.blk.attn_pv", 2.0 * B * 384 * 256 + 25.0 * B * 384 * 8, 4.0 * (384.0 * 256 + B * (384 * 8 + 256)), attn_pv_kernel,
-                dim3(s.n_tiles_max, B_HID / 32), dim3(256), pa);
+    MISC_LAUNCH("wave.blk.attn_pv", 2.0 * rows * 384 * 256 + 25.0 * rows * 384 * 8, 4.0 * (384.0 * 256 + rows * (384 * 8 + 256)),
+                attn_pv_kernel, dim3(s.n_tiles_max, B_HID / 32), dim3(256), pa);
     a = conv_args(s.o, s.x[blk + 1], w.o_w[blk], w.o_b[blk], s.hop, B);
     a.res = s.xa;
-    launch_auto<C2>("wave.blk.o", a, st);
+    launch_auto<C2<H>>("wave.blk.o", a, st);
   }
   // upsampler: stage 1 and the stage-2 transposed conv as batched GEMMs (few rows per stream, large
   // weights), everything after that in one per-stream kernel
-  launch_auto<UP<256, 128, 5, 1>>("wave.up1", conv_args(s.x[4], s.ya1, w.up_w[0], w.up_b[0], s.hop, B), st);
-  launch_auto<RES<128, 1, 5>>("wave.res1a", conv_args(s.ya1, s.yb1, w.ra_w[0], w.ra_b[0], s.hop, B), st);
-  launch_auto<RES<128, 3, 5>>("wave.res1b", conv_args(s.yb1, s.yc1, w.rb_w[0], w.rb_b[0], s.hop, B), st);
-  launch_auto<UP<128, 64, 4, 5>>("wave.up2", conv_args(s.yc1, s.ya2, w.up_w[1], w.up_b[1], s.hop, B), st);
+  launch_auto<UP<256, 128, 5, H>>("wave.up1", conv_args(s.x[4], s.ya1, w.up_w[0], w.up_b[0], s.hop, B), st);
+  launch_auto<RES<128, 1, 5 * H>>("wave.res1a", conv_args(s.ya1, s.yb1, w.ra_w[0], w.ra_b[0], s.hop, B), st);
+  launch_auto<RES<128, 3, 5 * H>>("wave.res1b", conv_args(s.yb1, s.yc1, w.rb_w[0], w.rb_b[0], s.hop, B), st);
+  launch_auto<UP<128, 64, 4, 5 * H>>("wave.up2", conv_args(s.yc1, s.ya2, w.up_w[1], w.up_b[1], s.hop, B), st);
   TailArgs ta{};
+  ta.H = H;
   ta.in = s.ya2; ta.state = s.tail.base; ta.fin_w = w.fin_w; ta.fin_b = w.fin_b; ta.d_out = s.d_out; ta.hop = s.hop;
   ta.w[0] = w.ra_w[1]; ta.b[0] = w.ra_b[1]; ta.w[1] = w.rb_w[1]; ta.b[1] = w.rb_b[1];
   ta.w[2] = w.up_w[2]; ta.b[2] = w.up_b[2]; ta.w[3] = w.ra_w[2]; ta.b[3] = w.ra_b[2]; ta.w[4] = w.rb_w[2]; ta.b[4] = w.rb_b[2];
   ta.w[5] = w.up_w[3]; ta.b[5] = w.up_b[3]; ta.w[6] = w.ra_w[3]; ta.b[6] = w.ra_b[3]; ta.w[7] = w.rb_w[3]; ta.b[7] = w.rb_b[3];
   const double tail_macs = 2.0 * 20 * 192 * 64 + 20.0 * 128 * 128 + 2.0 * 80 * 96 * 32 + 80.0 * 64 * 48 + 2.0 * 240 * 48 * 16 + 240.0 * 112;
-  MISC_LAUNCH("wave.tail", 2.0 * B * tail_macs, 4.0 * (52000.0 + B * (22 * 64 + 2 * TAIL_STATE_FLOATS + 240)), wave_tail_kernel,
+  MISC_LAUNCH("wave.tail", 2.0 * rows * tail_macs, 4.0 * (52000.0 + B * 2 * TAIL_STATE_FLOATS + rows * (22 * 64 + 240)), wave_tail_kernel,
               dim3(B), dim3(tail::NTHR), ta);
   if (s.advance_hop) MISC_LAUNCH("hop_advance", 0, 4, hop_advance_kernel, dim3(1), dim3(1), s.hop);
+}
+
+void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t st) {
+  switch (s.H) {
+    case 1: wave_forward_h<1>(w, s, st); break;
+    case 2: wave_forward_h<2>(w, s, st); break;
+    default: wave_forward_h<4>(w, s, st); break;
+  }
 }
 
 }  // namespace bhip

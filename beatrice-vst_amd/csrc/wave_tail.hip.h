@@ -40,7 +40,8 @@ enum {
 };
 
 struct TailArgs {
-  Ring in;       // output of up2: C = 64, n = 20, history 2
+  int H;         // hops per step (processed one after the other inside the kernel; state stays in LDS)
+  Ring in;       // output of up2: C = 64, n = 20*H, history 2
   float* state;  // [B][TAIL_STATE_FLOATS]
   const float *w[8], *b[8];  // res2a, res2b, up3, res3a, res3b, up4, res4a, res4b
   const float *fin_w, *fin_b;
@@ -194,30 +195,34 @@ static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const T
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* st = a.state + (size_t)b * TAIL_STATE_FLOATS;
 
+  // biases, output-conv taps and the stream's state block: one round of global loads
+  const int hop = *a.hop;
+  for (int e = tid; e < TAIL_STATE_FLOATS; e += NTHR) SI_[e] = st[e];
+  if (tid < BIAS_FLOATS) {
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) l += tid >= BO[k] ? 1 : 0;
+    BIAS[tid] = a.b[l][tid - BO[l]];
+  }
+  if (tid < 7 * 16) FW[tid] = a.fin_w[tid];
+
+#pragma unroll 1
+  for (int hh = 0; hh < a.H; ++hh) {
   // B fragments, one layer ahead (a.w[] are pre-packed)
   float4 b_r2a[1][12], b_r2b[1][12], b_u3[1][8], b_r3a[1][6], b_r3b[1][6], b_u4[3][4], b_r4a[1][3], b_r4b[1][3];
   fetch_b<192, 64, 20>(a.w[0], b_r2a, wave, lane);
   fetch_b<192, 64, 20>(a.w[1], b_r2b, wave, lane);
 
-  // ---- prologue: one round of global loads: input frames (history 2 + 20 new), state, biases
-  const int hop = *a.hop;
+  // ---- input frames of this hop (history 2 + 20 new, 64 channels), raw + activated
   {
     const int pos = ring_pos(a.in, hop);
     for (int e = tid; e < 22 * 16; e += NTHR) {
       const int fr = e >> 4, q = e & 15;
-      const float4 v = *reinterpret_cast<const float4*>(ring_frame(a.in, b, pos, fr - 2) + 4 * q);
+      const float4 v = *reinterpret_cast<const float4*>(ring_frame(a.in, b, pos, hh * 20 + fr - 2) + 4 * q);
       float* d = R0 + fr * row_stride(64) + 4 * q;
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
       d[64] = bsp::lrelu(v.x); d[65] = bsp::lrelu(v.y); d[66] = bsp::lrelu(v.z); d[67] = bsp::lrelu(v.w);
     }
-    for (int e = tid; e < TAIL_STATE_FLOATS; e += NTHR) SI_[e] = st[e];
-    if (tid < BIAS_FLOATS) {
-      int l = 0;
-#pragma unroll
-      for (int k = 1; k < 8; ++k) l += tid >= BO[k] ? 1 : 0;
-      BIAS[tid] = a.b[l][tid - BO[l]];
-    }
-    if (tid < 7 * 16) FW[tid] = a.fin_w[tid];
   }
   __syncthreads();
   hist_in<64, 6>(R1, SI_ + TS_YB2, tid);
@@ -283,8 +288,10 @@ static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const T
     for (int j = 0; j < 7; ++j)
 #pragma unroll
       for (int c = 0; c < 16; ++c) acc = bsp::fma(bsp::lrelu(R2[(tid + j) * 18 + c]), FW[j * 16 + c], acc);
-    a.d_out[(size_t)b * B_OUT_HOP + tid] = bsp::tanh(acc + a.fin_b[0]);
+    a.d_out[((size_t)b * a.H + hh) * B_OUT_HOP + tid] = bsp::tanh(acc + a.fin_b[0]);
   }
   __syncthreads();
-  for (int e = tid; e < TAIL_STATE_FLOATS; e += NTHR) st[e] = SO_[e];
+  { float* tmp = SI_; SI_ = SO_; SO_ = tmp; }  // this hop's histories are the next hop's state
+  }  // hops of the step
+  for (int e = tid; e < TAIL_STATE_FLOATS; e += NTHR) st[e] = SI_[e];
 }
