@@ -254,6 +254,8 @@ _BATCH = {
     "BeatriceHip_LoadWaveformGeneratorFromMemory": (C.c_int, [_vp, _vp, C.c_size_t]),
     "BeatriceHip_LoadEmbeddingSetterFromMemory": (C.c_int, [_vp, _vp, C.c_size_t]),
     "BeatriceBatch_Create": (_vp, [_vp, _vp, _vp, _vp, C.c_int, C.c_int]),
+    "BeatriceBatch_CreateBlock": (_vp, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int]),
+    "BeatriceBatch_HopsPerStep": (C.c_int, [_vp]),
     "BeatriceBatch_Destroy": (None, [_vp]),
     "BeatriceBatch_IsHealthy": (C.c_int, [_vp]),
     "BeatriceBatch_NumStreams": (C.c_int, [_vp]),
@@ -302,15 +304,23 @@ def bind_batch(abi):
 
 
 class Batch:
-    """B concurrent streams on one GPU through include/beatrice_batch.h."""
+    """B concurrent streams on one GPU through include/beatrice_batch.h.
 
-    def __init__(self, models, n_streams, max_speakers=None):
+    hops_per_step = 1: one 10 ms hop per step (real time).  2 or 4: block mode, every step converts that
+    many consecutive hops per stream (in [B][H*160] -> out [B][H*240]), same results as single hops."""
+
+    def __init__(self, models, n_streams, max_speakers=None, hops_per_step=1):
         self.m = models
         self.a = bind_batch(models.abi)
         t = models.tables
         self.B = n_streams
+        self.H = hops_per_step
         ms = max_speakers or (t.n_speakers + 1)
-        self.h = self.a.BeatriceBatch_Create(models.phone, models.pitch, models.wave, models.embed, n_streams, ms)
+        if hops_per_step == 1:
+            self.h = self.a.BeatriceBatch_Create(models.phone, models.pitch, models.wave, models.embed, n_streams, ms)
+        else:
+            self.h = self.a.BeatriceBatch_CreateBlock(models.phone, models.pitch, models.wave, models.embed, n_streams, ms,
+                                                      hops_per_step)
         if not self.a.BeatriceBatch_IsHealthy(self.h):
             raise RuntimeError("BeatriceBatch_Create failed (no GPU / HIP error)")
         self._check(self.a.BeatriceBatch_SetSpeakerTables(self.h, t.n_speakers + 1, fptr(t.codebooks), fptr(t.additive),
@@ -328,8 +338,8 @@ class Batch:
 
     def convert(self, x):
         x = np.ascontiguousarray(x, np.float32)
-        assert x.shape == (self.B, IN_HOP)
-        out = np.zeros((self.B, OUT_HOP), np.float32)
+        assert x.shape == (self.B, self.H * IN_HOP)
+        out = np.zeros((self.B, self.H * OUT_HOP), np.float32)
         self._check(self.a.BeatriceBatch_ConvertFrames(self.h, fptr(x), fptr(out)))
         return out
 
@@ -342,10 +352,11 @@ class Batch:
         return out
 
     def intermediates(self):
-        phone = np.zeros((self.B, PHONE_CH), np.float32)
-        q_raw = np.zeros(self.B, np.int32)
-        q = np.zeros(self.B, np.int32)
-        feat = np.zeros((self.B, 4), np.float32)
+        shape = (self.B,) if self.H == 1 else (self.B, self.H)
+        phone = np.zeros(shape + (PHONE_CH,), np.float32)
+        q_raw = np.zeros(shape, np.int32)
+        q = np.zeros(shape, np.int32)
+        feat = np.zeros(shape + (4,), np.float32)
         self._check(self.a.BeatriceBatch_GetIntermediates(self.h, fptr(phone), iptr(q_raw), iptr(q), fptr(feat)))
         return phone, q_raw, q, feat
 

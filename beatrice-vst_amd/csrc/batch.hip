@@ -61,13 +61,14 @@ struct BeatriceBatch {
   const Beatrice20rc0_WaveformGenerator* wave_m = nullptr;
   const Beatrice20rc0_EmbeddingSetter* embed_m = nullptr;
   int B = 0, max_speakers = 0, n_speakers = 0;
+  int H = 1;  // hops per step (block mode when > 1)
   bool ok = false;
   hipStream_t stream = nullptr;
   bool owns_stream = false;
   PhoneState phone;
   PitchState pitch;
   WaveState wave;
-  float* d_in = nullptr;  // [B][160], shared by phone and pitch
+  float* d_in = nullptr;  // [B][H*160], shared by phone and pitch
   // speaker tables on device
   float *d_cb_raw = nullptr, *d_cbT = nullptr, *d_cnorm = nullptr, *d_add_raw = nullptr, *d_frm_raw = nullptr, *d_kv_raw = nullptr;
   // per-stream settings
@@ -77,6 +78,8 @@ struct BeatriceBatch {
   Mirror<PitchParams> m_params;
   Mirror<int> m_perm[B_NBLOCKS], m_tile_slot[B_NBLOCKS];
   int pending_kv = 0;  // streams with kv_set_count < 4
+  std::vector<int> row_slot[B_NBLOCKS];  // [B*H] K/V slot of attention row (stream, hop in step)
+  bool kv_transient = false;  // rows of the last step's early hops still hold pre-switch slots (H > 1)
   bool inflight = false;  // an un-synchronised device-variant step may still read the pinned mirrors
   // staging for the host variant
   float *h_in = nullptr, *h_out = nullptr;
@@ -101,23 +104,29 @@ void settle(BeatriceBatch* b) {
 }
 
 void rebuild_tiles(BeatriceBatch* b, int blk) {
-  // streams grouped by K/V slot, ascending slot then ascending stream, 16 per tile
-  const int nt = b->wave.n_tiles_max;
+  // attention rows (stream, hop in step) grouped by K/V slot, ascending slot then ascending row, 16 per tile
+  const int nt = b->wave.n_tiles_max, rows = b->B * b->H;
   int* perm = b->m_perm[blk].h;
   int* slot = b->m_tile_slot[blk].h;
+  const std::vector<int>& rs = b->row_slot[blk];
   std::fill(perm, perm + (size_t)nt * 16, -1);
   std::fill(slot, slot + nt, -1);
-  std::vector<int> order(b->B);
-  for (int i = 0; i < b->B; ++i) order[i] = i;
-  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return b->cfg[x].kv_slot[blk] < b->cfg[y].kv_slot[blk]; });
+  std::vector<int> order(rows);
+  for (int i = 0; i < rows; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return rs[x] < rs[y]; });
   int tile = -1, fill = 16, cur = -1;
-  for (int s : order) {
-    const int sl = b->cfg[s].kv_slot[blk];
+  for (int r : order) {
+    const int sl = rs[r];
     if (sl != cur || fill == 16) { ++tile; fill = 0; cur = sl; slot[tile] = sl; }
-    perm[tile * 16 + fill++] = s;
+    perm[tile * 16 + fill++] = r;
   }
   b->m_perm[blk].dirty = true;
   b->m_tile_slot[blk].dirty = true;
+}
+
+void fill_row_slots(BeatriceBatch* b, int s) {
+  for (int blk = 0; blk < B_NBLOCKS; ++blk)
+    for (int hh = 0; hh < b->H; ++hh) b->row_slot[blk][(size_t)s * b->H + hh] = b->cfg[s].kv_slot[blk];
 }
 
 void sync_stream_arrays(BeatriceBatch* b, int s) {
@@ -137,19 +146,29 @@ void sync_stream_arrays(BeatriceBatch* b, int s) {
 // One K/V block per stream per hop, as the reference host does before its three per-hop calls
 // (processor_core_2.cc:179-181, processor_core_2.h:161-169).
 void advance_kv(BeatriceBatch* b) {
-  if (b->pending_kv == 0) return;
+  if (b->pending_kv == 0 && !b->kv_transient) return;
   settle(b);
   bool dirty[B_NBLOCKS] = {false, false, false, false};
-  int still = 0;
-  for (StreamCfg& c : b->cfg) {
-    if (c.kv_set_count < B_NBLOCKS) {
-      c.kv_slot[c.kv_set_count] = c.target_speaker;
-      dirty[c.kv_set_count] = true;
-      ++c.kv_set_count;
-      if (c.kv_set_count < B_NBLOCKS) ++still;
+  bool advanced = false;
+  const int H = b->H;
+  for (int s = 0; s < b->B; ++s) {
+    StreamCfg& c = b->cfg[s];
+    for (int hh = 0; hh < H; ++hh) {  // the hops of this step, each preceded by one block install
+      if (c.kv_set_count < B_NBLOCKS) {
+        c.kv_slot[c.kv_set_count] = c.target_speaker;
+        ++c.kv_set_count;
+        advanced = true;
+      }
+      for (int blk = 0; blk < B_NBLOCKS; ++blk) {
+        int& rs = b->row_slot[blk][(size_t)s * H + hh];
+        if (rs != c.kv_slot[blk]) { rs = c.kv_slot[blk]; dirty[blk] = true; }
+      }
     }
   }
+  int still = 0;
+  for (const StreamCfg& c : b->cfg) if (c.kv_set_count < B_NBLOCKS) ++still;
   b->pending_kv = still;
+  b->kv_transient = advanced && H > 1;
   for (int blk = 0; blk < B_NBLOCKS; ++blk) if (dirty[blk]) rebuild_tiles(b, blk);
 }
 
@@ -206,10 +225,10 @@ bool step_device(BeatriceBatch* b, const float* d_in, float* d_out) {
   advance_kv(b);
   if (!push_settings(b)) return false;
   if (d_in && d_in != b->d_in)
-    BHIP_TRY(hipMemcpyAsync(b->d_in, d_in, sizeof(float) * b->B * B_IN_HOP, hipMemcpyDeviceToDevice, b->stream));
+    BHIP_TRY(hipMemcpyAsync(b->d_in, d_in, sizeof(float) * b->B * b->H * B_IN_HOP, hipMemcpyDeviceToDevice, b->stream));
   if (!run_chain(b)) return false;
   if (d_out && d_out != b->wave.d_out)
-    BHIP_TRY(hipMemcpyAsync(d_out, b->wave.d_out, sizeof(float) * b->B * B_OUT_HOP, hipMemcpyDeviceToDevice, b->stream));
+    BHIP_TRY(hipMemcpyAsync(d_out, b->wave.d_out, sizeof(float) * b->B * b->H * B_OUT_HOP, hipMemcpyDeviceToDevice, b->stream));
   b->inflight = true;
   return true;
 }
@@ -258,19 +277,25 @@ BHIP_MEMORY_LOADER(EmbeddingSetter, Beatrice20rc0_EmbeddingSetter, KIND_EMBED, E
 BeatriceBatch* BeatriceBatch_Create(const Beatrice20rc0_PhoneExtractor* phone, const Beatrice20rc0_PitchEstimator* pitch,
                                     const Beatrice20rc0_WaveformGenerator* wave, const Beatrice20rc0_EmbeddingSetter* embed,
                                     int n_streams, int max_speakers) {
+  return BeatriceBatch_CreateBlock(phone, pitch, wave, embed, n_streams, max_speakers, 1);
+}
+
+BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* phone, const Beatrice20rc0_PitchEstimator* pitch,
+                                         const Beatrice20rc0_WaveformGenerator* wave, const Beatrice20rc0_EmbeddingSetter* embed,
+                                         int n_streams, int max_speakers, int hops_per_step) {
   auto* b = new BeatriceBatch();
   if (!phone || !pitch || !wave || !embed || !phone->loaded || !pitch->loaded || !wave->loaded || !embed->loaded ||
-      n_streams < 1 || max_speakers < 1)
+      n_streams < 1 || max_speakers < 1 || (hops_per_step != 1 && hops_per_step != 2 && hops_per_step != 4))
     return b;  // unhealthy object; every call on it fails with -2
   b->phone_m = phone; b->pitch_m = pitch; b->wave_m = wave; b->embed_m = embed;
-  b->B = n_streams; b->max_speakers = max_speakers;
-  const int B = n_streams, S = max_speakers;
+  b->B = n_streams; b->max_speakers = max_speakers; b->H = hops_per_step;
+  const int B = n_streams, S = max_speakers, H = hops_per_step;
   bool ok = make_stream(&b->stream);
   b->owns_stream = ok;
-  ok = ok && hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_in), sizeof(float) * B * B_IN_HOP), "d_in") &&
-       hip_ok(hipMemset(b->d_in, 0, sizeof(float) * B * B_IN_HOP), "d_in0");
-  ok = ok && b->phone.create(B, 1, b->d_in) && b->pitch.create(B, 1, b->d_in, true) &&
-       b->wave.create(B, 1, S, S, 9, b->phone.d_phone, b->pitch.d_q, b->pitch.d_feat);
+  ok = ok && hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_in), sizeof(float) * B * H * B_IN_HOP), "d_in") &&
+       hip_ok(hipMemset(b->d_in, 0, sizeof(float) * B * H * B_IN_HOP), "d_in0");
+  ok = ok && b->phone.create(B, H, b->d_in) && b->pitch.create(B, H, b->d_in, true) &&
+       b->wave.create(B, H, S, S, 9, b->phone.d_phone, b->pitch.d_q, b->pitch.d_feat);
   // the three modules advance in lockstep here: one shared hop counter, incremented once per step
   b->pitch.hop = b->phone.d_hop; b->wave.hop = b->phone.d_hop;
   b->phone.advance_hop = false; b->pitch.advance_hop = false; b->wave.advance_hop = true;
@@ -295,8 +320,8 @@ BeatriceBatch* BeatriceBatch_Create(const Beatrice20rc0_PhoneExtractor* phone, c
       b->m_tile_slot[blk].d = b->wave.d_tile_slot[blk];
     }
   }
-  ok = ok && hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_in), sizeof(float) * B * B_IN_HOP, hipHostMallocDefault), "h_in") &&
-       hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_out), sizeof(float) * B * B_OUT_HOP, hipHostMallocDefault), "h_out") &&
+  ok = ok && hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_in), sizeof(float) * B * H * B_IN_HOP, hipHostMallocDefault), "h_in") &&
+       hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_out), sizeof(float) * B * H * B_OUT_HOP, hipHostMallocDefault), "h_out") &&
        hip_ok(hipEventCreate(&b->ev0), "ev0") && hip_ok(hipEventCreate(&b->ev1), "ev1") && make_stream(&b->side_stream) &&
        hip_ok(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming), "evf") &&
        hip_ok(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming), "evj");
@@ -323,7 +348,8 @@ BeatriceBatch* BeatriceBatch_Create(const Beatrice20rc0_PhoneExtractor* phone, c
   ok = ok && hip_ok(hipDeviceSynchronize(), "create sync");  // NULL-stream memsets vs the non-blocking stream
   b->ok = ok;
   if (ok) {
-    for (int s = 0; s < B; ++s) sync_stream_arrays(b, s);
+    for (int blk = 0; blk < B_NBLOCKS; ++blk) b->row_slot[blk].assign((size_t)B * H, 0);
+    for (int s = 0; s < B; ++s) { sync_stream_arrays(b, s); fill_row_slots(b, s); }
     for (int blk = 0; blk < B_NBLOCKS; ++blk) rebuild_tiles(b, blk);
   }
   return b;
@@ -354,6 +380,7 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
 
 int BeatriceBatch_IsHealthy(const BeatriceBatch* b) { return b && b->ok ? 1 : 0; }
 int BeatriceBatch_NumStreams(const BeatriceBatch* b) { return b ? b->B : 0; }
+int BeatriceBatch_HopsPerStep(const BeatriceBatch* b) { return b ? b->H : 0; }
 
 // ---- speaker tables -----------------------------------------------------------------------------
 static bool project_speakers(BeatriceBatch* b, int first, int count) {
@@ -414,6 +441,7 @@ int BeatriceBatch_FlushSpeaker(BeatriceBatch* b, int stream) {
     for (; c.kv_set_count < B_NBLOCKS; ++c.kv_set_count) c.kv_slot[c.kv_set_count] = c.target_speaker;
   });
   if (r == 0) {
+    for (int s = (stream < 0 ? 0 : stream); s < (stream < 0 ? b->B : stream + 1); ++s) fill_row_slots(b, s);
     b->pending_kv = 0;
     for (const StreamCfg& c : b->cfg) if (c.kv_set_count < B_NBLOCKS) ++b->pending_kv;
     for (int blk = 0; blk < B_NBLOCKS; ++blk) rebuild_tiles(b, blk);
@@ -482,15 +510,16 @@ int BeatriceBatch_ConvertFramesDevice(BeatriceBatch* b, const float* d_in, float
   return step_device(b, d_in, d_out) ? 0 : -2;
 }
 int BeatriceBatch_ConvertFrames(BeatriceBatch* b, const float* in, float* out) {
-  if (!b || !b->ok) { if (b && out) std::memset(out, 0, sizeof(float) * b->B * B_OUT_HOP); return -2; }
-  std::memcpy(b->h_in, in, sizeof(float) * b->B * B_IN_HOP);
-  bool ok = hip_ok(hipMemcpyAsync(b->d_in, b->h_in, sizeof(float) * b->B * B_IN_HOP, hipMemcpyHostToDevice, b->stream), "in");
+  if (!b || !b->ok) { if (b && out) std::memset(out, 0, sizeof(float) * b->B * b->H * B_OUT_HOP); return -2; }
+  const size_t n_in = (size_t)b->B * b->H * B_IN_HOP, n_out = (size_t)b->B * b->H * B_OUT_HOP;
+  std::memcpy(b->h_in, in, sizeof(float) * n_in);
+  bool ok = hip_ok(hipMemcpyAsync(b->d_in, b->h_in, sizeof(float) * n_in, hipMemcpyHostToDevice, b->stream), "in");
   ok = ok && step_device(b, nullptr, nullptr);
-  ok = ok && hip_ok(hipMemcpyAsync(b->h_out, b->wave.d_out, sizeof(float) * b->B * B_OUT_HOP, hipMemcpyDeviceToHost, b->stream), "out");
+  ok = ok && hip_ok(hipMemcpyAsync(b->h_out, b->wave.d_out, sizeof(float) * n_out, hipMemcpyDeviceToHost, b->stream), "out");
   ok = hip_ok(hipStreamSynchronize(b->stream), "sync") && ok;
   b->inflight = false;
-  if (ok) std::memcpy(out, b->h_out, sizeof(float) * b->B * B_OUT_HOP);
-  else std::memset(out, 0, sizeof(float) * b->B * B_OUT_HOP);
+  if (ok) std::memcpy(out, b->h_out, sizeof(float) * n_out);
+  else std::memset(out, 0, sizeof(float) * n_out);
   return ok ? 0 : -2;
 }
 // ---- 48 kHz blocks with the wrapper on the device ----------------------------------------------
@@ -504,12 +533,12 @@ static bool step_48k(BeatriceBatch* b, const float* d_in48, float* d_out48, int 
 }
 int BeatriceBatch_ConvertBlocks48kDevice(BeatriceBatch* b, const float* d_in, float* d_out, int channels) {
   if (!b || !b->ok) return -2;
-  if (channels < 1 || channels > 2 || !d_in || !d_out) return -1;
+  if (channels < 1 || channels > 2 || !d_in || !d_out || b->H != 1) return -1;  // the wrapper is per 10 ms block
   return step_48k(b, d_in, d_out, channels) ? 0 : -2;
 }
 int BeatriceBatch_ConvertBlocks48k(BeatriceBatch* b, const float* in, float* out, int channels) {
   if (!b || !b->ok) return -2;
-  if (channels < 1 || channels > 2 || !in || !out) return -1;
+  if (channels < 1 || channels > 2 || !in || !out || b->H != 1) return -1;
   const size_t n = (size_t)b->B * channels * 480;
   float* h_in = b->h_io48;
   float* h_out = b->h_io48 + (size_t)b->B * 2 * 480;
@@ -555,10 +584,10 @@ float* BeatriceBatch_DeviceOutput(BeatriceBatch* b) { return b && b->ok ? b->wav
 int BeatriceBatch_GetIntermediates(BeatriceBatch* b, float* phone, int* q_raw, int* q, float* feat) {
   if (!b || !b->ok) return -2;
   bool ok = hip_ok(hipStreamSynchronize(b->stream), "sync");
-  if (phone) ok = ok && hip_ok(hipMemcpy(phone, b->phone.d_phone, sizeof(float) * b->B * B_PHONE_CH, hipMemcpyDeviceToHost), "phone");
-  if (q_raw) ok = ok && hip_ok(hipMemcpy(q_raw, b->pitch.d_q_raw, sizeof(int) * b->B, hipMemcpyDeviceToHost), "q_raw");
-  if (q) ok = ok && hip_ok(hipMemcpy(q, b->pitch.d_q, sizeof(int) * b->B, hipMemcpyDeviceToHost), "q");
-  if (feat) ok = ok && hip_ok(hipMemcpy(feat, b->pitch.d_feat, sizeof(float) * b->B * 4, hipMemcpyDeviceToHost), "feat");
+  if (phone) ok = ok && hip_ok(hipMemcpy(phone, b->phone.d_phone, sizeof(float) * b->B * b->H * B_PHONE_CH, hipMemcpyDeviceToHost), "phone");
+  if (q_raw) ok = ok && hip_ok(hipMemcpy(q_raw, b->pitch.d_q_raw, sizeof(int) * b->B * b->H, hipMemcpyDeviceToHost), "q_raw");
+  if (q) ok = ok && hip_ok(hipMemcpy(q, b->pitch.d_q, sizeof(int) * b->B * b->H, hipMemcpyDeviceToHost), "q");
+  if (feat) ok = ok && hip_ok(hipMemcpy(feat, b->pitch.d_feat, sizeof(float) * b->B * b->H * 4, hipMemcpyDeviceToHost), "feat");
   return ok ? 0 : -2;
 }
 

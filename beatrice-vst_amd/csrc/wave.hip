@@ -139,13 +139,12 @@ static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t
   launch_auto<RES<128, 3, 5 * H>>("wave.res1b", conv_args(s.yb1, s.yc1, w.rb_w[0], w.rb_b[0], s.hop, B), st);
   launch_auto<UP<128, 64, 4, 5 * H>>("wave.up2", conv_args(s.yc1, s.ya2, w.up_w[1], w.up_b[1], s.hop, B), st);
   TailArgs ta{};
-  ta.H = H;
   ta.in = s.ya2; ta.state = s.tail.base; ta.fin_w = w.fin_w; ta.fin_b = w.fin_b; ta.d_out = s.d_out; ta.hop = s.hop;
   ta.w[0] = w.ra_w[1]; ta.b[0] = w.ra_b[1]; ta.w[1] = w.rb_w[1]; ta.b[1] = w.rb_b[1];
   ta.w[2] = w.up_w[2]; ta.b[2] = w.up_b[2]; ta.w[3] = w.ra_w[2]; ta.b[3] = w.ra_b[2]; ta.w[4] = w.rb_w[2]; ta.b[4] = w.rb_b[2];
   ta.w[5] = w.up_w[3]; ta.b[5] = w.up_b[3]; ta.w[6] = w.ra_w[3]; ta.b[6] = w.ra_b[3]; ta.w[7] = w.rb_w[3]; ta.b[7] = w.rb_b[3];
   const double tail_macs = 2.0 * 20 * 192 * 64 + 20.0 * 128 * 128 + 2.0 * 80 * 96 * 32 + 80.0 * 64 * 48 + 2.0 * 240 * 48 * 16 + 240.0 * 112;
-  MISC_LAUNCH("wave.tail", 2.0 * rows * tail_macs, 4.0 * (52000.0 + B * 2 * TAIL_STATE_FLOATS + rows * (22 * 64 + 240)), wave_tail_kernel,
+  MISC_LAUNCH("wave.tail", 2.0 * rows * tail_macs, 4.0 * (52000.0 + B * 2 * TAIL_STATE_FLOATS + rows * (22 * 64 + 240)), wave_tail_kernel<H>,
               dim3(B), dim3(tail::NTHR), ta);
   if (s.advance_hop) MISC_LAUNCH("hop_advance", 0, 4, hop_advance_kernel, dim3(1), dim3(1), s.hop);
 }

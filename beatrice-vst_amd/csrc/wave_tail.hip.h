@@ -40,7 +40,6 @@ enum {
 };
 
 struct TailArgs {
-  int H;         // hops per step (processed one after the other inside the kernel; state stays in LDS)
   Ring in;       // output of up2: C = 64, n = 20*H, history 2
   float* state;  // [B][TAIL_STATE_FLOATS]
   const float *w[8], *b[8];  // res2a, res2b, up3, res3a, res3b, up4, res4a, res4b
@@ -182,6 +181,7 @@ __device__ __forceinline__ void hist_out(float* __restrict__ st, const float* __
 }  // namespace tail
 
 // 2 workgroups per CU (59 KB of LDS each): while one waits at a barrier the other computes
+template <int H>  // hops per step, compile time: H = 1 keeps the single-hop kernel free of loop state
 static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const TailArgs a) {
   using namespace tail;
   __shared__ __attribute__((aligned(16))) float lds[3 * BUF_FLOATS + 2 * TAIL_STATE_FLOATS + BIAS_FLOATS + 7 * 16];
@@ -207,7 +207,7 @@ static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const T
   if (tid < 7 * 16) FW[tid] = a.fin_w[tid];
 
 #pragma unroll 1
-  for (int hh = 0; hh < a.H; ++hh) {
+  for (int hh = 0; hh < H; ++hh) {
   // B fragments, one layer ahead (a.w[] are pre-packed)
   float4 b_r2a[1][12], b_r2b[1][12], b_u3[1][8], b_r3a[1][6], b_r3b[1][6], b_u4[3][4], b_r4a[1][3], b_r4b[1][3];
   fetch_b<192, 64, 20>(a.w[0], b_r2a, wave, lane);
@@ -288,7 +288,7 @@ static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const T
     for (int j = 0; j < 7; ++j)
 #pragma unroll
       for (int c = 0; c < 16; ++c) acc = bsp::fma(bsp::lrelu(R2[(tid + j) * 18 + c]), FW[j * 16 + c], acc);
-    a.d_out[((size_t)b * a.H + hh) * B_OUT_HOP + tid] = bsp::tanh(acc + a.fin_b[0]);
+    a.d_out[((size_t)b * H + hh) * B_OUT_HOP + tid] = bsp::tanh(acc + a.fin_b[0]);
   }
   __syncthreads();
   { float* tmp = SI_; SI_ = SO_; SO_ = tmp; }  // this hop's histories are the next hop's state

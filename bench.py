@@ -139,6 +139,21 @@ def saturation(bv, models, product, streams=8192, steps=30):
             "best_gemm_tflops": round(max(r["flops"] / (r["mean_us"] * 1e-6) / 1e12 for r in rows), 2)}
 
 
+def block_mode(bv, models, product, streams, steps=200):
+    """Bulk / utterance conversion (not the headline, which is one 10 ms hop per step): the same chain with
+    H = 2 and 4 consecutive hops per step (BeatriceBatch_CreateBlock), bit-identical results, launch cost
+    shared by H hops.  Same resident-input timing as the headline."""
+    out = {"streams": streams}
+    for H in (2, 4):
+        batch = bv.Batch(models, streams, hops_per_step=H)
+        product.BeatriceBatch_FlushSpeaker(batch.h, -1)
+        batch.time_steps(20)
+        ms = batch.time_steps(steps)
+        batch.close()
+        out["H%d" % H] = {"frames_per_s": round(streams * H * steps / (ms * 1e-3), 1), "ms_per_step": round(ms / steps, 4)}
+    return out
+
+
 def latency_b1(bv, product, model_dir, hops=400):
     """BASELINE.json configs[1]: 1 stream, 1 speaker, hop-synchronous 1-stream C-ABI."""
     m = bv.Models(product, model_dir)
@@ -323,6 +338,7 @@ def main():
                               for r in sorted(rows, key=lambda r: -r["total_us"])[:12]]
             if world == 1:
                 res["saturation"] = saturation(bv, m, product)
+                res["block_mode"] = block_mode(bv, m, product, B)
                 res["latency_b1"] = latency_b1(bv, product, model_dir)
                 res["cpu_baseline"] = cpu_baseline(bv, model_dir, a.cpu_seconds)
         print(json.dumps(res))

@@ -47,9 +47,18 @@ Beatrice_ErrorCode BeatriceHip_LoadEmbeddingSetterFromMemory(Beatrice20rc0_Embed
 BeatriceBatch* BeatriceBatch_Create(const Beatrice20rc0_PhoneExtractor* phone, const Beatrice20rc0_PitchEstimator* pitch,
                                     const Beatrice20rc0_WaveformGenerator* wave, const Beatrice20rc0_EmbeddingSetter* embed,
                                     int n_streams, int max_speakers);
+/* Block mode for offline / utterance conversion: every step converts `hops_per_step` (1, 2 or 4)
+ * consecutive hops of every stream, so the per-launch cost of the kernel chain is shared by H hops.
+ * Results are bit-identical to H single-hop steps (the recurrent layers still advance hop by hop
+ * inside the step; a pending speaker switch still installs one K/V block per hop).  Buffers become
+ * in [B][H*160], out [B][H*240].  hops_per_step = 1 is BeatriceBatch_Create (10 ms real-time steps). */
+BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* phone, const Beatrice20rc0_PitchEstimator* pitch,
+                                         const Beatrice20rc0_WaveformGenerator* wave, const Beatrice20rc0_EmbeddingSetter* embed,
+                                         int n_streams, int max_speakers, int hops_per_step);
 void BeatriceBatch_Destroy(BeatriceBatch* b);
 int BeatriceBatch_IsHealthy(const BeatriceBatch* b);
 int BeatriceBatch_NumStreams(const BeatriceBatch* b);
+int BeatriceBatch_HopsPerStep(const BeatriceBatch* b);
 
 /* Upload the four caller-owned tables exactly as Beatrice20rc0_ReadSpeakerEmbeddings fills them
  * ([n][512][128], [n][256], [9][256], [n][384][128]); projects additive/formant vectors and the
@@ -73,7 +82,8 @@ int BeatriceBatch_SetPitchCorrection(BeatriceBatch* b, int stream, double v);
 int BeatriceBatch_SetPitchCorrectionType(BeatriceBatch* b, int stream, int type);
 int BeatriceBatch_ResetStream(BeatriceBatch* b, int stream);
 
-/* One hop for every stream.  Host variant: in [B][160] @16 kHz, out [B][240] @24 kHz, synchronous.
+/* One step (H hops, H = 1 unless created with BeatriceBatch_CreateBlock) for every stream.
+ * Host variant: in [B][H*160] @16 kHz, out [B][H*240] @24 kHz, synchronous.
  * Device variant: pointers are device memory, work is enqueued on the batch's HIP stream and the
  * call returns without waiting (BeatriceBatch_Synchronize to wait). */
 int BeatriceBatch_ConvertFrames(BeatriceBatch* b, const float* in, float* out);
@@ -88,7 +98,7 @@ int BeatriceBatch_Synchronize(BeatriceBatch* b);
  * sample (src/common/resample.h:130-159, 384-386), the 480-sample FIFO (:343-363, i.e. +10 ms), the
  * model hop, zero-stuffing x2 (:390-393), 32-tap low-pass (:168-206), copy to every output channel
  * (processor.cc:221-225).  Bit-identical to the host chain.  Other host rates and non-zero gains: use
- * the C++ host layer (beatrice-vst_amd/host). */
+ * the C++ host layer (beatrice-vst_amd/host).  Per 10 ms block only: returns -1 on a block-mode batch (H > 1). */
 int BeatriceBatch_ConvertBlocks48k(BeatriceBatch* b, const float* in, float* out, int channels);
 int BeatriceBatch_ConvertBlocks48kDevice(BeatriceBatch* b, const float* d_in, float* d_out, int channels);
 
@@ -98,16 +108,16 @@ int BeatriceBatch_SetStream(BeatriceBatch* b, void* hip_stream);
 void* BeatriceBatch_GetStream(const BeatriceBatch* b);
 int BeatriceBatch_EnableGraph(BeatriceBatch* b, int enable);
 
-/* Resident buffers of the batch ([B][160] in, [B][240] out) for callers that produce / consume
+/* Resident buffers of the batch ([B][H*160] in, [B][H*240] out) for callers that produce / consume
  * audio on the device. */
 float* BeatriceBatch_DeviceInput(BeatriceBatch* b);
 float* BeatriceBatch_DeviceOutput(BeatriceBatch* b);
 
-/* Test hook: copies the last hop's intermediate results (any pointer may be NULL):
- * phone [B][128], raw bins [B], transformed bins [B], features [B][4]. */
+/* Test hook: copies the last step's intermediate results (any pointer may be NULL):
+ * phone [B][H][128], raw bins [B][H], transformed bins [B][H], features [B][H][4]. */
 int BeatriceBatch_GetIntermediates(BeatriceBatch* b, float* phone, int* q_raw, int* q, float* feat);
 
-/* Measurement hook: runs `steps` hops on the resident input buffer, timed with HIP events recorded
+/* Measurement hook: runs `steps` steps (H hops each) on the resident input buffer, timed with HIP events recorded
  * on the batch's own stream; returns total milliseconds in *ms. */
 int BeatriceBatch_TimeSteps(BeatriceBatch* b, int steps, float* ms);
 

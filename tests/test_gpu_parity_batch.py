@@ -162,3 +162,57 @@ def test_pitch_range_and_correction_settings(bv, oracle, product, model_dir):
     m.close()
     assert np.array_equal(got_q, ref_q)
     assert float(np.abs(got - ref).max()) <= TOL
+
+
+@pytest.mark.parametrize("B,H,graph", [(3, 2, 1), (21, 4, 1), (5, 4, 0)])
+def test_block_mode_matches_single_hops(bv, oracle, product, model_dir, B, H, graph):
+    """BeatriceBatch_CreateBlock: H hops per step == H single-hop steps of independent oracle streams,
+    including a speaker switch whose four K/V blocks install on consecutive hops INSIDE a step."""
+    hops = 32
+    audio = np.stack([bv.synth_audio(160 * hops, seed=300 + s) for s in range(B)])
+
+    def script(h, s, st, batch):  # settings change between steps only: every event hop is a multiple of 4
+        if h == 0:
+            if st is not None:
+                st.a.SetVQNumNeighbors(st.pc, (s + 1) % 3)
+                st.pitch_params = dict(shift=float(s % 3) - 1.0, correction=0.5 if s % 2 else 0.0)
+            else:
+                a, hnd = batch.a, batch.h
+                a.BeatriceBatch_SetVQNumNeighbors(hnd, s, (s + 1) % 3)
+                a.BeatriceBatch_SetPitchShift(hnd, s, float(s % 3) - 1.0)
+                a.BeatriceBatch_SetPitchCorrection(hnd, s, 0.5 if s % 2 else 0.0)
+        if h == 8 + 4 * (s % 3):
+            spk = 1 + (s % 2)
+            if st is not None:
+                st.set_target_speaker(spk)
+            else:
+                batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, s, spk)
+        if h == 20 and s % 2 == 1:
+            if st is not None:
+                st.set_formant_index(2)
+            else:
+                batch.a.BeatriceBatch_SetFormantShift(batch.h, s, -1.0)
+
+    ref = _oracle_streams(bv, oracle, model_dir, B, hops, audio, script)  # [hops][B][240]
+    m = bv.Models(product, model_dir)
+    batch = bv.Batch(m, B, hops_per_step=H)
+    assert batch.a.BeatriceBatch_HopsPerStep(batch.h) == H
+    batch.a.BeatriceBatch_EnableGraph(batch.h, graph)
+    got = np.zeros_like(ref)
+    for step in range(hops // H):
+        for h in range(step * H, (step + 1) * H):
+            for s in range(B):
+                script(h, s, None, batch)
+        y = batch.convert(audio[:, step * H * 160:(step + 1) * H * 160])  # [B][H*240]
+        got[step * H:(step + 1) * H] = y.reshape(B, H, bv.OUT_HOP).transpose(1, 0, 2)
+    phone, q_raw, q, feat = batch.intermediates()
+    assert phone.shape == (B, H, bv.PHONE_CH) and q.shape == (B, H)
+    # the 48 kHz wrapper is per 10 ms block: refused in block mode
+    z = np.zeros((B, 1, 480), np.float32)
+    assert batch.a.BeatriceBatch_ConvertBlocks48k(batch.h, bv.fptr(z), bv.fptr(z.copy()), 1) == -1
+    batch.close()
+    m.close()
+    dev = float(np.abs(ref - got).max())
+    print("B=%d H=%d graph=%d max-abs %g %s" % (B, H, graph, dev, "bit-identical" if np.array_equal(ref, got) else ""))
+    assert np.abs(got).max() > 0.05
+    assert dev <= TOL
