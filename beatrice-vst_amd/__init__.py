@@ -256,6 +256,7 @@ _BATCH = {
     "BeatriceBatch_Create": (_vp, [_vp, _vp, _vp, _vp, C.c_int, C.c_int]),
     "BeatriceBatch_CreateBlock": (_vp, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int]),
     "BeatriceBatch_HopsPerStep": (C.c_int, [_vp]),
+    "BeatriceBatch_StateBytes": (C.c_size_t, [_vp]),
     "BeatriceBatch_Destroy": (None, [_vp]),
     "BeatriceBatch_IsHealthy": (C.c_int, [_vp]),
     "BeatriceBatch_NumStreams": (C.c_int, [_vp]),

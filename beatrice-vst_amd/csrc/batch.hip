@@ -381,6 +381,9 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
 int BeatriceBatch_IsHealthy(const BeatriceBatch* b) { return b && b->ok ? 1 : 0; }
 int BeatriceBatch_NumStreams(const BeatriceBatch* b) { return b ? b->B : 0; }
 int BeatriceBatch_HopsPerStep(const BeatriceBatch* b) { return b ? b->H : 0; }
+size_t BeatriceBatch_StateBytes(const BeatriceBatch* b) {
+  return b && b->ok ? sizeof(float) * (b->phone.arena.floats + b->pitch.arena.floats + b->wave.arena.floats) : 0;
+}
 
 // ---- speaker tables -----------------------------------------------------------------------------
 static bool project_speakers(BeatriceBatch* b, int first, int count) {

@@ -333,7 +333,8 @@ def main():
             res["chain"] = {"launches_per_hop": sum(r["launches"] for r in rows),
                             "sum_kernel_us": round(total_us, 1), "gflop_per_step": round(chain_flops / 1e9, 3),
                             "tflops_end_to_end": round(chain_flops / (elapsed / a.steps) / 1e12, 2),
-                            "mfma_frac_end_to_end": round(chain_flops / (elapsed / a.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+                            "mfma_frac_end_to_end": round(chain_flops / (elapsed / a.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                            "state_bytes_per_stream": int(product.BeatriceBatch_StateBytes(batch.h)) // B}
             res["kernels"] = [{"name": r["name"], "n": r["launches"], "us": round(r["mean_us"], 2)}
                               for r in sorted(rows, key=lambda r: -r["total_us"])[:12]]
             if world == 1:

@@ -59,6 +59,8 @@ void BeatriceBatch_Destroy(BeatriceBatch* b);
 int BeatriceBatch_IsHealthy(const BeatriceBatch* b);
 int BeatriceBatch_NumStreams(const BeatriceBatch* b);
 int BeatriceBatch_HopsPerStep(const BeatriceBatch* b);
+/* bytes of per-stream activation history (all rings of all three modules) held for the n_streams streams */
+size_t BeatriceBatch_StateBytes(const BeatriceBatch* b);
 
 /* Upload the four caller-owned tables exactly as Beatrice20rc0_ReadSpeakerEmbeddings fills them
  * ([n][512][128], [n][256], [9][256], [n][384][128]); projects additive/formant vectors and the
