@@ -80,6 +80,7 @@ struct BeatriceBatch {
   int pending_kv = 0;  // streams with kv_set_count < 4
   std::vector<int> row_slot[B_NBLOCKS];  // [B*H] K/V slot of attention row (stream, hop in step)
   bool kv_transient = false;  // rows of the last step's early hops still hold pre-switch slots (H > 1)
+  bool vq_dirty = true;   // a VQ setting changed since the k-NN launch was last (de)selected
   bool inflight = false;  // an un-synchronised device-variant step may still read the pinned mirrors
   // staging for the host variant
   float *h_in = nullptr, *h_out = nullptr;
@@ -88,11 +89,10 @@ struct BeatriceBatch {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  hipStream_t side_stream = nullptr;  // pitch branch
+  int* d_hop_next = nullptr;  // step counter, double-buffered: first kernels read it, the last one writes it
   // 48 kHz device wrapper (configs[4])
   Wrap48State* d_w48 = nullptr;
   float *d_coef_down = nullptr, *d_coef_up = nullptr, *d_io48 = nullptr, *h_io48 = nullptr;  // io: in [B][2][480] | out [B][2][480]
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace {
@@ -180,26 +180,18 @@ bool push_settings(BeatriceBatch* b) {
   return ok;
 }
 
-// phone and pitch modules are independent (both only read the hop's audio) and CAN run as two
-// parallel branches (second HIP stream, fork/join events, captured as parallel graph branches).
-// Measured on ROCm 7.2 / MI355X (profiles/r01_notes.md): a hipGraph replays its kernel nodes one
-// after another whatever the branch structure, so forking buys nothing (421.7 vs 414.3 us per hop at
-// B = 256) and is off by default; BEATRICE_HIP_FORK=1 turns it on for experiments.
+// Latency-bound regime (one hop per step, a few hundred streams): the pitch estimator's launches are
+// paired into the content encoder's (front.hip).  Elsewhere the three modules run one after the other.
+// (Running them as parallel graph branches or on two HIP streams was measured and buys nothing on
+// ROCm 7.2 / MI355X, profiles/r01_notes.md.)
 void enqueue_chain(BeatriceBatch* b) {
-  static const bool want_fork = std::getenv("BEATRICE_HIP_FORK") != nullptr;
-  const bool fork = want_fork && b->side_stream != nullptr && launch_hook() == nullptr;
-  hipStream_t ps = fork ? b->side_stream : b->stream;
-  if (fork) {
-    (void)hip_ok(hipEventRecord(b->ev_fork, b->stream), "fork");
-    (void)hip_ok(hipStreamWaitEvent(ps, b->ev_fork, 0), "fork wait");
+  static const bool no_pairs = std::getenv("BEATRICE_HIP_NO_PAIRS") != nullptr;  // A/B switch for measurements
+  const bool paired = !no_pairs && front_forward(b->phone_m->w, b->phone, b->pitch_m->w, b->pitch, b->wave_m->w, b->wave, b->stream);
+  if (!paired) {
+    phone_forward(b->phone_m->w, b->phone, b->stream);
+    pitch_forward(b->pitch_m->w, b->pitch, b->stream);
   }
-  phone_forward(b->phone_m->w, b->phone, b->stream);
-  pitch_forward(b->pitch_m->w, b->pitch, ps);
-  if (fork) {
-    (void)hip_ok(hipEventRecord(b->ev_join, ps), "join");
-    (void)hip_ok(hipStreamWaitEvent(b->stream, b->ev_join, 0), "join wait");
-  }
-  wave_forward(b->wave_m->w, b->wave, b->stream);
+  wave_forward(b->wave_m->w, b->wave, b->stream, paired);
 }
 
 void drop_graph(BeatriceBatch* b) {
@@ -221,8 +213,16 @@ bool run_chain(BeatriceBatch* b) {
   return true;
 }
 
+// the k-NN launch is dropped while no stream uses the codebook (phone.out then writes the module output)
+void update_vq_mode(BeatriceBatch* b) {
+  bool none = true;
+  for (const StreamCfg& c : b->cfg) none = none && c.vq_k == 0;
+  if (none != b->phone.skip_vq) { settle(b); b->phone.skip_vq = none; drop_graph(b); }
+}
+
 bool step_device(BeatriceBatch* b, const float* d_in, float* d_out) {
   advance_kv(b);
+  if (b->vq_dirty) { update_vq_mode(b); b->vq_dirty = false; }
   if (!push_settings(b)) return false;
   if (d_in && d_in != b->d_in)
     BHIP_TRY(hipMemcpyAsync(b->d_in, d_in, sizeof(float) * b->B * b->H * B_IN_HOP, hipMemcpyDeviceToDevice, b->stream));
@@ -296,9 +296,16 @@ BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* pho
        hip_ok(hipMemset(b->d_in, 0, sizeof(float) * B * H * B_IN_HOP), "d_in0");
   ok = ok && b->phone.create(B, H, b->d_in) && b->pitch.create(B, H, b->d_in, true) &&
        b->wave.create(B, H, S, S, 9, b->phone.d_phone, b->pitch.d_q, b->pitch.d_feat);
-  // the three modules advance in lockstep here: one shared hop counter, incremented once per step
+  // the three modules advance in lockstep here: one step counter, double-buffered so that no launch is
+  // spent on incrementing it: the step's first kernels (phone.f1, pitch.fft) read d_hop_next, phone.f1
+  // publishes the value to phone.d_hop for every later kernel, the last kernel (wave.tail) stores
+  // value + 1 back to d_hop_next
+  ok = ok && hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_hop_next), sizeof(int)), "hop_next") &&
+       hip_ok(hipMemset(b->d_hop_next, 0, sizeof(int)), "hop_next0");
   b->pitch.hop = b->phone.d_hop; b->wave.hop = b->phone.d_hop;
-  b->phone.advance_hop = false; b->pitch.advance_hop = false; b->wave.advance_hop = true;
+  b->phone.hop_in = b->d_hop_next; b->pitch.hop_in = b->d_hop_next;
+  b->phone.hop_publish = b->phone.d_hop; b->wave.hop_next_out = b->d_hop_next;
+  b->phone.advance_hop = false; b->pitch.advance_hop = false; b->wave.advance_hop = false;
   const size_t cbf = (size_t)S * B_CODEBOOK * B_PHONE_CH, kvf = (size_t)S * B_KV_LEN * B_KV_CH;
   ok = ok && hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_cb_raw), sizeof(float) * cbf), "cb") &&
        hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_cbT), sizeof(float) * cbf), "cbT") &&
@@ -322,9 +329,7 @@ BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* pho
   }
   ok = ok && hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_in), sizeof(float) * B * H * B_IN_HOP, hipHostMallocDefault), "h_in") &&
        hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_out), sizeof(float) * B * H * B_OUT_HOP, hipHostMallocDefault), "h_out") &&
-       hip_ok(hipEventCreate(&b->ev0), "ev0") && hip_ok(hipEventCreate(&b->ev1), "ev1") && make_stream(&b->side_stream) &&
-       hip_ok(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming), "evf") &&
-       hip_ok(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming), "evj");
+       hip_ok(hipEventCreate(&b->ev0), "ev0") && hip_ok(hipEventCreate(&b->ev1), "ev1");
   {  // 48 kHz wrapper: 33-entry Hann-windowed sinc tables of the ratio-1/1 resampler pair
     //   (reference resample.h:209-230 with cutoffs 0.99*16000/48000 in, 0.99*24000/48000 out, :412-417)
     float cd[33], cu[33];
@@ -361,7 +366,7 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   drop_graph(b);
   b->phone.destroy(); b->pitch.destroy(); b->wave.destroy();
   void* dev[] = {b->d_in, b->d_cb_raw, b->d_cbT, b->d_cnorm, b->d_add_raw, b->d_frm_raw, b->d_kv_raw,
-                 b->d_w48, b->d_coef_down, b->d_coef_up, b->d_io48};
+                 b->d_w48, b->d_coef_down, b->d_coef_up, b->d_io48, b->d_hop_next};
   if (b->h_io48) (void)hipHostFree(b->h_io48);
   for (void* p : dev) if (p) (void)hipFree(p);
   b->m_cbT.release(); b->m_cnorm.release(); b->m_vqk.release(); b->m_min_q.release(); b->m_max_q.release();
@@ -371,9 +376,6 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   if (b->h_out) (void)hipHostFree(b->h_out);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
-  if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
-  if (b->ev_join) (void)hipEventDestroy(b->ev_join);
-  if (b->side_stream) { (void)hipStreamSynchronize(b->side_stream); (void)hipStreamDestroy(b->side_stream); }
   if (b->owns_stream && b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
 }
@@ -460,6 +462,7 @@ int BeatriceBatch_SetFormantShift(BeatriceBatch* b, int stream, double shift) {
 // processor_core_2.cc:585-590
 int BeatriceBatch_SetVQNumNeighbors(BeatriceBatch* b, int stream, int k) {
   k = std::min(std::max(k, 0), 8);
+  if (b) b->vq_dirty = true;
   return for_streams(b, stream, [&](StreamCfg& c) { c.vq_k = k; });
 }
 int BeatriceBatch_SetMinSourcePitch(BeatriceBatch* b, int stream, double note) {
@@ -625,6 +628,7 @@ int BeatriceBatch_ProfileKernels(BeatriceBatch* b, int repeats, int max_entries,
   if (repeats < 1 || max_entries < 1 || !names || !launches || !mean_us || !flops || !bytes) return -1;
   if (!hip_ok(hipStreamSynchronize(b->stream), "sync")) return -2;
   advance_kv(b);
+  if (b->vq_dirty) { update_vq_mode(b); b->vq_dirty = false; }
   if (!push_settings(b)) return -2;
   ProfileHook hook;
   hook.repeats = repeats;

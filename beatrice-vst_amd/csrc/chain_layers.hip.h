@@ -1,0 +1,58 @@
+// chain_layers.hip.h -- the layer table of the per-hop chain (MODEL_SPEC 4.1, 4.2, 4.4) as Layer<>
+// types, and the argument builders of the non-GEMM kernels; shared by the per-module forward passes
+// (phone.hip, pitch.hip, wave.hip) and the paired front end (front.hip).  H = hops per step.
+#pragma once
+#include "conv_gemm.hip.h"
+#include "engine.h"
+#include "fused_small.hip.h"
+
+namespace bhip {
+
+//                                  CIN NOUT K  S  D  T      PRE       ACT       EPI       RES
+template <int H>
+struct PhoneLayers {
+  using F2 = Layer<64, 128, 8, 4, 1, 8 * H, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
+  using F3 = Layer<128, 256, 4, 2, 1, 4 * H, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
+  using F4 = Layer<256, 256, 4, 2, 1, 2 * H, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
+  using F5 = Layer<256, 256, 4, 2, 1, H, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
+  using RBL = Layer<256, 256, 5, 1, 1, H, PRE_NONE, ACT_GELU, EPI_BIAS, true>;
+  using OUTL = Layer<256, B_PHONE_CH, 1, 1, 1, H, PRE_NONE, ACT_NONE, EPI_BIAS, false>;
+};
+template <int H>
+struct PitchLayers {
+  using P1 = Layer<B_SPEC_BINS, 128, 3, 1, 1, H, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
+  using P23 = Layer<128, 128, 3, 1, 1, H, PRE_NONE, ACT_GELU, EPI_BIAS, true>;
+  using POUT = Layer<128, B_PITCH_BINS, 1, 1, 1, H, PRE_NONE, ACT_NONE, EPI_BIAS, false>;
+};
+
+static inline F1Args f1_args(const PhoneWeights& w, const PhoneState& s) {
+  return F1Args{s.d_in, s.audio, s.f[0], w.f1_w, w.f1_b, s.hop_in, s.hop_publish, s.H};
+}
+static inline LaunchInfo f1_info(const PhoneState& s) {
+  return LaunchInfo{"phone.f1", 2.0 * s.B * s.H * 32 * 64 * 10, 4.0 * s.B * s.H * (160 + 32 * 64)};
+}
+static inline FftArgs fft_args(const PitchWeights& w, const PitchState& s) {
+  return FftArgs{s.d_in, s.audio, s.spec, w.window, w.twiddle, s.hop_in, s.H};
+}
+static inline LaunchInfo fft_info(const PitchState& s) {
+  return LaunchInfo{"pitch.fft", s.B * s.H * (10.0 * 512 * 10 + 1024 * 2 + 512 * 30), 4.0 * s.B * s.H * (1024 + 160 + 512)};
+}
+static inline PitchHeadArgs head_args(const PitchWeights& w, const PitchState& s) {
+  return PitchHeadArgs{s.H, s.logits.base, s.h, s.d_in, w.voi_w, w.voi_b, s.d_min_q, s.d_max_q, s.d_prev_q,
+                       s.d_q_raw, s.d_q, s.d_feat, s.d_params, s.hop};
+}
+static inline LaunchInfo head_info(const PitchState& s) {
+  return LaunchInfo{"pitch.head", 25.0 * s.B * s.H * 448, 4.0 * s.B * s.H * (448 + 160 + 128 + 8)};
+}
+static inline CondArgs cond_args(const WaveWeights& w, const WaveState& s) {
+  return CondArgs{s.H, s.d_q, s.d_feat, w.pitch_emb, w.feat_w, s.d_add_tab, s.d_add_idx, s.d_frm_tab, s.d_frm_idx, s.e.base};
+}
+static inline LaunchInfo cond_info(const WaveState& s) {
+  return LaunchInfo{"wave.cond", 11.0 * s.B * s.H * 256, 4.0 * s.B * s.H * 256 * 4};
+}
+
+// phone.out writes the 128-d vector either to the ring the k-NN kernel reads or, when no stream uses
+// the codebook (skip_vq), straight to the module's output
+static inline Ring phone_out_ring(const PhoneState& s) { return s.skip_vq ? Ring{s.d_phone, B_PHONE_CH, s.H, 1} : s.raw; }
+
+}  // namespace bhip

@@ -85,8 +85,10 @@ struct TileCfg {
   static constexpr int NTHR = GTHR * LK;
 };
 
+// The kernel body takes its workgroup coordinates as arguments so that two independent layers can share
+// one launch (pair.hip.h); conv_gemm_kernel below is the plain one-layer launch.
 template <class L, class TC>
-__global__ __launch_bounds__(TC::NTHR) void conv_gemm_kernel(const ConvArgs a) {
+__device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bx, const int by) {
   constexpr int KC = L::KC, AS = KC + 2, MT = TC::MT, NT = TC::NT, GTHR = TC::GTHR, LK = TC::LK;
   constexpr int P = L::P;
   static_assert(LK == 1 || LK == P, "k-groups: one group for all segments, or one group per segment");
@@ -107,13 +109,13 @@ __global__ __launch_bounds__(TC::NTHR) void conv_gemm_kernel(const ConvArgs a) {
   const int grp = tid / GTHR, gtid = tid % GTHR;
   const int lane = gtid & 63, wave = gtid >> 6;
   const int wave_m = (wave / TC::LN) * (16 * TC::WM), wave_n = (wave % TC::LN) * (16 * TC::WN);
-  const int m0 = blockIdx.x * MT, n0 = blockIdx.y * NT;
+  const int m0 = bx * MT, n0 = by * NT;
   const int M = a.B * L::T;
   float* As = lds + grp * STAGE_FLOATS;
 
   const float* wbase = a.w;
   if constexpr (L::GROUPED) {
-    const int slot = a.tile_slot[blockIdx.x];
+    const int slot = a.tile_slot[bx];
     if (slot < 0) return;
     wbase += (size_t)slot * a.w_slot_stride;
   }
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(TC::NTHR) void conv_gemm_kernel(const ConvArgs a) {
     int b = -1, t = 0;
     if (r < MT) {
       if constexpr (L::GROUPED) {  // grouped rows: perm holds row indices (stream * T + frame) or -1
-        const int m = a.perm[blockIdx.x * MT + r];
+        const int m = a.perm[bx * MT + r];
         if (m >= 0) { b = m / L::T; t = m % L::T; }
       } else {
         const int m = m0 + r;
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(TC::NTHR) void conv_gemm_kernel(const ConvArgs a) {
   auto finish = [&](int r, int n, float v) {  // r: row in tile, n: absolute column
     int b = -1, t = 0;
     if constexpr (L::GROUPED) {
-      const int m = a.perm[blockIdx.x * MT + r];
+      const int m = a.perm[bx * MT + r];
       if (m >= 0) { b = m / L::T; t = m % L::T; }
     } else {
       const int m = m0 + r;
@@ -288,16 +290,35 @@ __global__ __launch_bounds__(TC::NTHR) void conv_gemm_kernel(const ConvArgs a) {
 }
 
 template <class L, class TC>
+__global__ __launch_bounds__(TC::NTHR) void conv_gemm_kernel(const ConvArgs a) {
+  conv_gemm_body<L, TC>(a, blockIdx.x, blockIdx.y);
+}
+
+// launch geometry + algorithmic work of one layer, shared by the single and the paired launchers
+template <class L, class TC>
+struct ConvOp {
+  using Args = ConvArgs;
+  static constexpr int NTHR = TC::NTHR;
+  static inline dim3 grid(const ConvArgs& a, int n_group_tiles = 0) {
+    dim3 g;
+    g.x = L::GROUPED ? n_group_tiles : (a.B * L::T + TC::MT - 1) / TC::MT;
+    g.y = L::NOUT / TC::NT;
+    return g;
+  }
+  // 2*M*K*N flops; bytes = weights once + A rows once + output once
+  static inline bhip::LaunchInfo info(const char* name, const ConvArgs& a) {
+    const double M = (double)a.B * L::T, K = (double)L::KSZ * L::CIN, N = L::NOUT;
+    const double in_rows = (double)a.B * (L::T * L::STRIDE + (L::KSZ - 1) * L::DIL - (L::STRIDE - 1));
+    return bhip::LaunchInfo{name, 2.0 * M * K * N, 4.0 * (K * N + in_rows * L::CIN + M * N * (L::RES ? 2 : 1))};
+  }
+  __device__ static __forceinline__ void run(const ConvArgs& a, int bx, int by) { conv_gemm_body<L, TC>(a, bx, by); }
+};
+
+template <class L, class TC>
 static inline void launch_conv(const char* name, const ConvArgs& a, int n_group_tiles, hipStream_t stream) {
-  dim3 grid;
-  if (L::GROUPED) grid.x = n_group_tiles;
-  else grid.x = (a.B * L::T + TC::MT - 1) / TC::MT;
-  grid.y = L::NOUT / TC::NT;
-  // algorithmic work of this launch: 2*M*K*N flops; bytes = weights once + A rows once + output once
-  const double M = (double)a.B * L::T, K = (double)L::KSZ * L::CIN, N = L::NOUT;
-  const double in_rows = (double)a.B * (L::T * L::STRIDE + (L::KSZ - 1) * L::DIL - (L::STRIDE - 1));
-  const bhip::LaunchInfo info{name, 2.0 * M * K * N, 4.0 * (K * N + in_rows * L::CIN + M * N * (L::RES ? 2 : 1))};
-  bhip::launch_site(info, stream, [&] { hipLaunchKernelGGL((conv_gemm_kernel<L, TC>), grid, dim3(TC::NTHR), 0, stream, a); });
+  const dim3 grid = ConvOp<L, TC>::grid(a, n_group_tiles);
+  bhip::launch_site(ConvOp<L, TC>::info(name, a), stream,
+                    [&] { hipLaunchKernelGGL((conv_gemm_kernel<L, TC>), grid, dim3(TC::NTHR), 0, stream, a); });
 }
 
 // ---- launch helpers shared by the modules ------------------------------------------------------

@@ -85,7 +85,10 @@ struct PhoneState {
   int* d_vqk = nullptr;             // [B]
   int* d_hop = nullptr;       // owned hop counter
   int* hop = nullptr;         // counter the kernels read (== d_hop unless shared by a batch)
+  int* hop_in = nullptr;      // counter the FIRST kernel reads (== hop unless a batch double-buffers the counter)
+  int* hop_publish = nullptr; // batch: the first kernel copies *hop_in here (== hop) for the rest of the chain
   bool advance_hop = true;    // this module's forward ends with the counter increment
+  bool skip_vq = false;       // no stream uses the codebook: phone.out writes d_phone, no k-NN launch
   bool create(int B, int H, float* shared_in);
   void destroy();
 };
@@ -113,6 +116,7 @@ struct PitchState {
   PitchParams* d_params = nullptr;     // [B] or nullptr (1-stream ABI: host does the transform)
   int* d_hop = nullptr;       // owned hop counter
   int* hop = nullptr;         // counter the kernels read (== d_hop unless shared by a batch)
+  int* hop_in = nullptr;      // counter the first kernel (FFT) reads
   bool advance_hop = true;    // this module's forward ends with the counter increment
   bool create(int B, int H, float* shared_in, bool with_params);
   void destroy();
@@ -162,11 +166,20 @@ struct WaveState {
   int* d_tile_slot[B_NBLOCKS] = {nullptr, nullptr, nullptr, nullptr};  // [n_tiles_max]
   int* d_hop = nullptr;       // owned hop counter
   int* hop = nullptr;         // counter the kernels read (== d_hop unless shared by a batch)
+  int* hop_next_out = nullptr;  // batch: the last kernel stores counter + 1 here (read by the next step's first kernels)
   bool advance_hop = true;    // this module's forward ends with the counter increment
   bool create(int B, int H, int n_slots, int n_add, int n_frm, float* shared_phone, int* shared_q, float* shared_feat);
   void destroy();
 };
-void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t stream);
+void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t stream, bool cond_done = false);
+
+// content encoder + pitch estimator (+ the waveform generator's conditioning mix) with the pitch
+// estimator's launches paired into the content encoder's (pair.hip.h).  Returns false when the
+// configuration is outside the paired regime (H != 1 or too many rows): nothing was enqueued, the
+// caller runs phone_forward / pitch_forward / wave_forward(cond_done = false) instead.
+void phone_vq(const PhoneWeights& w, const PhoneState& s, hipStream_t stream);
+bool front_forward(const PhoneWeights& pw, const PhoneState& ps, const PitchWeights& qw, const PitchState& qs,
+                   const WaveWeights& ww, const WaveState& ws, hipStream_t stream);
 
 // set-time projections (embedding setter)
 void embed_project_rows(const float* w, const float* b, const float* d_x, float* d_y, int rows, hipStream_t stream);

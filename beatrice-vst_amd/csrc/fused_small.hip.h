@@ -27,7 +27,7 @@ struct GruArgs {
 };
 
 template <int IN, int H>
-static __global__ __launch_bounds__(384) void gru_fused_kernel(const GruArgs a) {
+__device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, const int by) {
   constexpr int XS = IN + 2, HS = H + 2;
   __shared__ __attribute__((aligned(16))) float lds[16 * XS + 16 * HS + 6 * 256];
   float* xs = lds;
@@ -35,7 +35,7 @@ static __global__ __launch_bounds__(384) void gru_fused_kernel(const GruArgs a) 
   float* g6 = hs + 16 * HS;  // [src][gate][16][16]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int src = wave / 3, gate = wave % 3;
-  const int b0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
+  const int b0 = bx * 16, j0 = by * 16;
   constexpr int K = IN > H ? IN : H;
   (void)K;
 
@@ -105,11 +105,24 @@ static __global__ __launch_bounds__(384) void gru_fused_kernel(const GruArgs a) 
 }
 
 template <int IN, int H>
+static __global__ __launch_bounds__(384) void gru_fused_kernel(const GruArgs a) { gru_fused_body<IN, H>(a, blockIdx.x, blockIdx.y); }
+
+template <int IN, int H>
+struct GruOp {
+  using Args = GruArgs;
+  static constexpr int NTHR = 384;
+  static inline dim3 grid(const GruArgs& a) { return dim3((a.B + 15) / 16, H / 16); }
+  static inline bhip::LaunchInfo info(const char* name, const GruArgs& a) {
+    return bhip::LaunchInfo{name, 2.0 * a.B * (IN + H) * 3.0 * H, 4.0 * ((IN + H) * 3.0 * H + a.B * (IN + 2.0 * H))};
+  }
+  __device__ static __forceinline__ void run(const GruArgs& a, int bx, int by) { gru_fused_body<IN, H>(a, bx, by); }
+};
+
+template <int IN, int H>
 static inline void launch_gru(const char* name, const GruArgs& a, hipStream_t stream) {
-  const bhip::LaunchInfo info{name, 2.0 * a.B * (IN + H) * 3.0 * H, 4.0 * ((IN + H) * 3.0 * H + a.B * (IN + 2.0 * H))};
-  bhip::launch_site(info, stream, [&] {
-    hipLaunchKernelGGL((gru_fused_kernel<IN, H>), dim3((a.B + 15) / 16, H / 16), dim3(384), 0, stream, a);
-  });
+  const dim3 grid = GruOp<IN, H>::grid(a);
+  bhip::launch_site(GruOp<IN, H>::info(name, a), stream,
+                    [&] { hipLaunchKernelGGL((gru_fused_kernel<IN, H>), grid, dim3(384), 0, stream, a); });
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -28,14 +28,25 @@ static __global__ void hop_advance_kernel(int* hop) { *hop = *hop + 1; }
 // Phone front-end layer 1 (MODEL_SPEC 4.1.1): Conv1d(1 -> 64, k=10, stride=5) + GELU.
 // K is only 10, so this is VALU work: one workgroup per stream, thread = (frame t, 8 channels).
 // Also appends the hop's 160 samples to the audio ring (5 samples of history are re-read).
-static __global__ __launch_bounds__(256) void phone_f1_kernel(const float* __restrict__ d_in, Ring audio,
-                                                       Ring out, const float* __restrict__ w,
-                                                       const float* __restrict__ bias,
-                                                       const int* hop_ptr, int H) {
-  // grid (stream, hop-in-step).  Samples before the step come from the audio ring, the rest from d_in.
+struct F1Args {
+  const float* d_in;   // [B][H*160]
+  Ring audio, out;
+  const float *w, *bias;
+  const int* hop;      // step counter this kernel reads
+  int* hop_publish;    // optional: workgroup (0,0) copies the counter here for the rest of the chain
+  int H;
+};
+// grid (stream, hop-in-step).  Samples before the step come from the audio ring, the rest from d_in.
+__device__ __forceinline__ void phone_f1_body(const F1Args& a, const int b, const int hh) {
   __shared__ float x[5 + B_IN_HOP];
   __shared__ float ws[10 * 64];
-  const int b = blockIdx.x, hh = blockIdx.y, tid = threadIdx.x, hop = *hop_ptr;
+  const int tid = threadIdx.x, hop = *a.hop, H = a.H;
+  if (a.hop_publish != nullptr && b == 0 && hh == 0 && tid == 0) *a.hop_publish = hop;
+  const Ring& audio = a.audio;
+  const Ring& out = a.out;
+  const float* __restrict__ d_in = a.d_in;
+  const float* __restrict__ w = a.w;
+  const float* __restrict__ bias = a.bias;
   const int pos = ring_pos(audio, hop);
   const float* src = d_in + (size_t)b * H * B_IN_HOP;
   for (int i = tid; i < 10 * 64; i += 256) ws[i] = w[i];
@@ -63,6 +74,12 @@ static __global__ __launch_bounds__(256) void phone_f1_kernel(const float* __res
 #pragma unroll
   for (int u = 0; u < 8; ++u) o[u] = bsp::gelu(acc[u] + bias[n0 + u]);
 }
+static __global__ __launch_bounds__(256) void phone_f1_kernel(const F1Args a) { phone_f1_body(a, blockIdx.x, blockIdx.y); }
+struct F1Op {
+  using Args = F1Args;
+  static constexpr int NTHR = 256;
+  __device__ static __forceinline__ void run(const Args& a, int bx, int by) { phone_f1_body(a, bx, by); }
+};
 
 // ---------------------------------------------------------------------------------------------
 // k-nearest-neighbour codebook lookup (MODEL_SPEC 4.1.3).  One workgroup of 512 threads per
@@ -125,13 +142,22 @@ static __global__ __launch_bounds__(512) void phone_vq_kernel(VqArgs a) {
 // ---------------------------------------------------------------------------------------------
 // Pitch front-end (MODEL_SPEC 4.2.1): window, 1024-point radix-2 DIT FFT in LDS, log power.
 // One workgroup of 256 threads per stream; each thread does 2 butterflies per stage.
-static __global__ __launch_bounds__(256) void pitch_fft_kernel(const float* __restrict__ d_in, Ring audio,
-                                                        Ring spec, const float* __restrict__ window,
-                                                        const float* __restrict__ twiddle,
-                                                        const int* hop_ptr, int H) {
+struct FftArgs {
+  const float* d_in;  // [B][H*160]
+  Ring audio, spec;
+  const float *window, *twiddle;
+  const int* hop;
+  int H;
+};
+__device__ __forceinline__ void pitch_fft_body(const FftArgs& a, const int b, const int hh) {
   __shared__ float re[B_FFT_N], im[B_FFT_N];
   __shared__ float tw[B_FFT_N];
-  const int b = blockIdx.x, hh = blockIdx.y, tid = threadIdx.x, hop = *hop_ptr;
+  const int tid = threadIdx.x, hop = *a.hop, H = a.H;
+  const Ring& audio = a.audio;
+  const Ring& spec = a.spec;
+  const float* __restrict__ d_in = a.d_in;
+  const float* __restrict__ window = a.window;
+  const float* __restrict__ twiddle = a.twiddle;
   const int pos = ring_pos(audio, hop);
   const float* src = d_in + (size_t)b * H * B_IN_HOP;
   for (int i = tid; i < B_FFT_N; i += 256) {
@@ -174,6 +200,12 @@ static __global__ __launch_bounds__(256) void pitch_fft_kernel(const float* __re
     o[k] = 0.5f * bsp::log(pw + 1e-5f);
   }
 }
+static __global__ __launch_bounds__(256) void pitch_fft_kernel(const FftArgs a) { pitch_fft_body(a, blockIdx.x, blockIdx.y); }
+struct FftOp {
+  using Args = FftArgs;
+  static constexpr int NTHR = 256;
+  __device__ static __forceinline__ void run(const Args& a, int bx, int by) { pitch_fft_body(a, bx, by); }
+};
 
 // ---------------------------------------------------------------------------------------------
 // Pitch head (MODEL_SPEC 4.2.3): masked argmax + 4 features, one wavefront per stream; optional
@@ -225,8 +257,8 @@ __device__ inline int pitch_transform_device(int q, const PitchParams& p) {
   return qi < 1 ? 1 : (qi > B_PITCH_BINS - 1 ? B_PITCH_BINS - 1 : qi);
 }
 
-static __global__ __launch_bounds__(64) void pitch_head_kernel(PitchHeadArgs a) {
-  const int b = blockIdx.x, l = threadIdx.x;
+__device__ __forceinline__ void pitch_head_body(const PitchHeadArgs& a, const int b) {
+  const int l = threadIdx.x;
   const int hop = *a.hop;
   int lo = a.min_q[b], hi = a.max_q[b];
   if (hi < lo) hi = lo;
@@ -277,6 +309,12 @@ static __global__ __launch_bounds__(64) void pitch_head_kernel(PitchHeadArgs a) 
   }
   if (l == 0) a.prev_q[b] = prev;
 }
+static __global__ __launch_bounds__(64) void pitch_head_kernel(const PitchHeadArgs a) { pitch_head_body(a, blockIdx.x); }
+struct HeadOp {
+  using Args = PitchHeadArgs;
+  static constexpr int NTHR = 64;
+  __device__ static __forceinline__ void run(const Args& a, int bx, int) { pitch_head_body(a, bx); }
+};
 
 // ---------------------------------------------------------------------------------------------
 // Waveform input mix, conditioning part (MODEL_SPEC 4.4.1):
@@ -291,8 +329,8 @@ struct CondArgs {
   const float* frm_tab; const int* frm_idx;
   float* e;            // [B][256]
 };
-static __global__ __launch_bounds__(256) void wave_cond_kernel(CondArgs a) {
-  const int row = blockIdx.x, b = row / a.H, n = threadIdx.x;
+__device__ __forceinline__ void wave_cond_body(const CondArgs& a, const int row) {
+  const int b = row / a.H, n = threadIdx.x;
   int q = a.q[row];
   q = q < 0 ? 0 : (q > B_PITCH_BINS - 1 ? B_PITCH_BINS - 1 : q);
   const float* f = a.feat + (size_t)row * 4;
@@ -302,6 +340,12 @@ static __global__ __launch_bounds__(256) void wave_cond_kernel(CondArgs a) {
   const float c = a.add_tab[(size_t)a.add_idx[b] * B_HID + n] + a.frm_tab[(size_t)a.frm_idx[b] * B_HID + n];
   a.e[(size_t)row * B_HID + n] = (a.pitch_emb[(size_t)q * B_HID + n] + fp) + c;
 }
+static __global__ __launch_bounds__(256) void wave_cond_kernel(const CondArgs a) { wave_cond_body(a, blockIdx.x); }
+struct CondOp {
+  using Args = CondArgs;
+  static constexpr int NTHR = 256;
+  __device__ static __forceinline__ void run(const Args& a, int bx, int) { wave_cond_body(a, bx); }
+};
 
 // ---------------------------------------------------------------------------------------------
 // Set-time kernels (embedding setter, MODEL_SPEC 4.3).  Not on the per-hop path.

@@ -1,9 +1,7 @@
 // phone.hip -- content encoder forward pass (MODEL_SPEC 4.1), the body of
 // Beatrice20rc0_ExtractPhone1 (reference lib/beatricelib/beatrice.h:243-247) for B streams and H
 // consecutive hops per step (H = 1: the real-time per-hop path; H > 1: block mode, batch.hip).
-#include "conv_gemm.hip.h"
-#include "engine.h"
-#include "fused_small.hip.h"
+#include "chain_layers.hip.h"
 
 namespace bhip {
 
@@ -34,7 +32,7 @@ bool PhoneState::create(int B_, int H_, float* shared_in) {
   BHIP_TRY(hipMemset(d_cnorm, 0, sizeof(float*) * B));
   BHIP_TRY(hipMemset(d_vqk, 0, sizeof(int) * B));
   BHIP_TRY(hipMemset(d_hop, 0, sizeof(int)));
-  hop = d_hop;
+  hop = d_hop; hop_in = d_hop;
   // hipMemset is asynchronous and runs on the NULL stream, which the (non-blocking) compute streams
   // do not wait for: make every initialisation above visible before the first kernel can start
   BHIP_TRY(hipDeviceSynchronize());
@@ -55,36 +53,38 @@ void PhoneState::destroy() {
   launch_site(LaunchInfo{NAME, (double)(FLOPS), (double)(BYTES)}, st,                          \
               [&] { hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, st, __VA_ARGS__); })
 
+// k-NN codebook lookup (skipped while no stream uses it) and the module's counter increment
+void phone_vq(const PhoneWeights&, const PhoneState& s, hipStream_t st) {
+  const int B = s.B, H = s.H;
+  if (!s.skip_vq) {
+    VqArgs v{H, s.raw.base, s.d_phone, s.d_cbT, s.d_cnorm, s.d_vqk};
+    MISC_LAUNCH("phone.vq", 0 /* k-dependent: 131 kFLOP per stream-hop with k > 0, pass-through at k = 0 */, 4.0 * B * H * 256,
+                phone_vq_kernel, dim3(B * H), dim3(512), v);
+  }
+  if (s.advance_hop) MISC_LAUNCH("hop_advance", 0, 4, hop_advance_kernel, dim3(1), dim3(1), s.hop);
+}
+
 template <int H>
 static void phone_forward_h(const PhoneWeights& w, const PhoneState& s, hipStream_t st) {
-  //                 CIN NOUT K  S  D  T      PRE       ACT       EPI       RES
-  using F2 = Layer<64, 128, 8, 4, 1, 8 * H, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
-  using F3 = Layer<128, 256, 4, 2, 1, 4 * H, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
-  using F4 = Layer<256, 256, 4, 2, 1, 2 * H, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
-  using F5 = Layer<256, 256, 4, 2, 1, H, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
-  using RBL = Layer<256, 256, 5, 1, 1, H, PRE_NONE, ACT_GELU, EPI_BIAS, true>;
-  using OUTL = Layer<256, B_PHONE_CH, 1, 1, 1, H, PRE_NONE, ACT_NONE, EPI_BIAS, false>;
+  using PL = PhoneLayers<H>;
   const int B = s.B;
-  MISC_LAUNCH("phone.f1", 2.0 * B * H * 32 * 64 * 10, 4.0 * B * H * (160 + 32 * 64), phone_f1_kernel, dim3(B, H), dim3(256), s.d_in,
-              s.audio, s.f[0], w.f1_w, w.f1_b, s.hop, H);
-  launch_auto<F2>("phone.f2", conv_args(s.f[0], s.f[1], w.f_w[0], w.f_b[0], s.hop, B), st);
-  launch_auto<F3>("phone.f3", conv_args(s.f[1], s.f[2], w.f_w[1], w.f_b[1], s.hop, B), st);
-  launch_auto<F4>("phone.f4", conv_args(s.f[2], s.f[3], w.f_w[2], w.f_b[2], s.hop, B), st);
-  launch_auto<F5>("phone.f5", conv_args(s.f[3], s.f[4], w.f_w[3], w.f_b[3], s.hop, B), st);
+  const F1Args fa = f1_args(w, s);
+  launch_site(f1_info(s), st, [&] { hipLaunchKernelGGL(phone_f1_kernel, dim3(B, H), dim3(256), 0, st, fa); });
+  launch_auto<typename PL::F2>("phone.f2", conv_args(s.f[0], s.f[1], w.f_w[0], w.f_b[0], s.hop, B), st);
+  launch_auto<typename PL::F3>("phone.f3", conv_args(s.f[1], s.f[2], w.f_w[1], w.f_b[1], s.hop, B), st);
+  launch_auto<typename PL::F4>("phone.f4", conv_args(s.f[2], s.f[3], w.f_w[2], w.f_b[2], s.hop, B), st);
+  launch_auto<typename PL::F5>("phone.f5", conv_args(s.f[3], s.f[4], w.f_w[3], w.f_b[3], s.hop, B), st);
   const Ring* cur = &s.f[4];
   for (int i = 0; i < 4; ++i) {
-    launch_auto<RBL>("phone.rb", conv_args(*cur, s.rb[i], w.rb_w[i], w.rb_b[i], s.hop, B), st);
+    launch_auto<typename PL::RBL>("phone.rb", conv_args(*cur, s.rb[i], w.rb_w[i], w.rb_b[i], s.hop, B), st);
     cur = &s.rb[i];
   }
   for (int t = 0; t < H; ++t) {  // the recurrence is sequential over the hops of the step
-    GruArgs ga{*cur, s.h, w.gru_wih, w.gru_whh, w.gru_bih, w.gru_bhh, s.hop, B, t};
+    GruArgs ga{s.rb[3], s.h, w.gru_wih, w.gru_whh, w.gru_bih, w.gru_bhh, s.hop, B, t};
     launch_gru<256, 256>("phone.gru", ga, st);
   }
-  launch_auto<OUTL>("phone.out", conv_args(s.h, s.raw, w.out_w, w.out_b, s.hop, B), st);
-  VqArgs v{H, s.raw.base, s.d_phone, s.d_cbT, s.d_cnorm, s.d_vqk};
-  MISC_LAUNCH("phone.vq", 0 /* k-dependent: 131 kFLOP per stream-hop with k > 0, pass-through at k = 0 */, 4.0 * B * H * 256, phone_vq_kernel,
-              dim3(B * H), dim3(512), v);
-  if (s.advance_hop) MISC_LAUNCH("hop_advance", 0, 4, hop_advance_kernel, dim3(1), dim3(1), s.hop);
+  launch_auto<typename PL::OUTL>("phone.out", conv_args(s.h, phone_out_ring(s), w.out_w, w.out_b, s.hop, B), st);
+  phone_vq(w, s, st);
 }
 
 void phone_forward(const PhoneWeights& w, const PhoneState& s, hipStream_t st) {

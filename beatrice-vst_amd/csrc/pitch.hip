@@ -1,9 +1,7 @@
 // pitch.hip -- pitch estimator forward pass (MODEL_SPEC 4.2), the body of
 // Beatrice20rc0_EstimatePitch1 (reference lib/beatricelib/beatrice.h:266-271) for B streams and H
 // consecutive hops per step.
-#include "conv_gemm.hip.h"
-#include "engine.h"
-#include "fused_small.hip.h"
+#include "chain_layers.hip.h"
 
 namespace bhip {
 
@@ -44,7 +42,7 @@ bool PitchState::create(int B_, int H_, float* shared_in, bool with_params) {
   }
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hop), sizeof(int)));
   BHIP_TRY(hipMemset(d_hop, 0, sizeof(int)));
-  hop = d_hop;
+  hop = d_hop; hop_in = d_hop;
   BHIP_TRY(hipDeviceSynchronize());  // NULL-stream memsets vs non-blocking compute streams
   return true;
 }
@@ -62,23 +60,20 @@ void PitchState::destroy() {
 
 template <int H>
 static void pitch_forward_h(const PitchWeights& w, const PitchState& s, hipStream_t st) {
-  using P1 = Layer<B_SPEC_BINS, 128, 3, 1, 1, H, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
-  using P23 = Layer<128, 128, 3, 1, 1, H, PRE_NONE, ACT_GELU, EPI_BIAS, true>;
-  using POUT = Layer<128, B_PITCH_BINS, 1, 1, 1, H, PRE_NONE, ACT_NONE, EPI_BIAS, false>;
+  using QL = PitchLayers<H>;
   const int B = s.B;
-  MISC_LAUNCH("pitch.fft", B * H * (10.0 * 512 * 10 + 1024 * 2 + 512 * 30), 4.0 * B * H * (1024 + 160 + 512), pitch_fft_kernel, dim3(B, H),
-              dim3(256), s.d_in, s.audio, s.spec, w.window, w.twiddle, s.hop, H);
-  launch_auto<P1>("pitch.p1", conv_args(s.spec, s.p[0], w.p_w[0], w.p_b[0], s.hop, B), st);
-  launch_auto<P23>("pitch.p23", conv_args(s.p[0], s.p[1], w.p_w[1], w.p_b[1], s.hop, B), st);
-  launch_auto<P23>("pitch.p23", conv_args(s.p[1], s.p[2], w.p_w[2], w.p_b[2], s.hop, B), st);
+  const FftArgs fa = fft_args(w, s);
+  launch_site(fft_info(s), st, [&] { hipLaunchKernelGGL(pitch_fft_kernel, dim3(B, H), dim3(256), 0, st, fa); });
+  launch_auto<typename QL::P1>("pitch.p1", conv_args(s.spec, s.p[0], w.p_w[0], w.p_b[0], s.hop, B), st);
+  launch_auto<typename QL::P23>("pitch.p23", conv_args(s.p[0], s.p[1], w.p_w[1], w.p_b[1], s.hop, B), st);
+  launch_auto<typename QL::P23>("pitch.p23", conv_args(s.p[1], s.p[2], w.p_w[2], w.p_b[2], s.hop, B), st);
   for (int t = 0; t < H; ++t) {
     GruArgs ga{s.p[2], s.h, w.gru_wih, w.gru_whh, w.gru_bih, w.gru_bhh, s.hop, B, t};
     launch_gru<128, 128>("pitch.gru", ga, st);
   }
-  launch_auto<POUT>("pitch.out", conv_args(s.h, s.logits, w.out_w, w.out_b, s.hop, B), st);
-  PitchHeadArgs a{H, s.logits.base, s.h, s.d_in, w.voi_w, w.voi_b, s.d_min_q, s.d_max_q, s.d_prev_q,
-                  s.d_q_raw, s.d_q, s.d_feat, s.d_params, s.hop};
-  MISC_LAUNCH("pitch.head", 25.0 * B * H * 448, 4.0 * B * H * (448 + 160 + 128 + 8), pitch_head_kernel, dim3(B), dim3(64), a);
+  launch_auto<typename QL::POUT>("pitch.out", conv_args(s.h, s.logits, w.out_w, w.out_b, s.hop, B), st);
+  const PitchHeadArgs a = head_args(w, s);
+  launch_site(head_info(s), st, [&] { hipLaunchKernelGGL(pitch_head_kernel, dim3(B), dim3(64), 0, st, a); });
   if (s.advance_hop) MISC_LAUNCH("hop_advance", 0, 4, hop_advance_kernel, dim3(1), dim3(1), s.hop);
 }
 

@@ -1,8 +1,6 @@
 // wave.hip -- waveform generator forward pass (MODEL_SPEC 4.4), the body of
 // Beatrice20rc0_GenerateWaveform1 (reference lib/beatricelib/beatrice.h:301-307) for B streams.
-#include "conv_gemm.hip.h"
-#include "engine.h"
-#include "fused_small.hip.h"
+#include "chain_layers.hip.h"
 #include "wave_tail.hip.h"
 
 namespace bhip {
@@ -102,10 +100,12 @@ static void launch_c1(const WaveWeights& w, const WaveState& s, int blk, hipStre
 }
 
 template <int H>
-static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t st) {
+static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t st, bool cond_done) {
   const int B = s.B, rows = s.B * H;
-  CondArgs ca{H, s.d_q, s.d_feat, w.pitch_emb, w.feat_w, s.d_add_tab, s.d_add_idx, s.d_frm_tab, s.d_frm_idx, s.e.base};
-  MISC_LAUNCH("wave.cond", 11.0 * rows * 256, 4.0 * rows * 256 * 4, wave_cond_kernel, dim3(rows), dim3(256), ca);
+  if (!cond_done) {
+    const CondArgs ca = cond_args(w, s);
+    launch_site(cond_info(s), st, [&] { hipLaunchKernelGGL(wave_cond_kernel, dim3(rows), dim3(256), 0, st, ca); });
+  }
   const Ring phone_in{s.d_phone, B_PHONE_CH, H, 1};
   ConvArgs a = conv_args(phone_in, s.x[0], w.inp_w, w.inp_b, s.hop, B);
   a.res = s.e;
@@ -139,7 +139,7 @@ static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t
   launch_auto<RES<128, 3, 5 * H>>("wave.res1b", conv_args(s.yb1, s.yc1, w.rb_w[0], w.rb_b[0], s.hop, B), st);
   launch_auto<UP<128, 64, 4, 5 * H>>("wave.up2", conv_args(s.yc1, s.ya2, w.up_w[1], w.up_b[1], s.hop, B), st);
   TailArgs ta{};
-  ta.in = s.ya2; ta.state = s.tail.base; ta.fin_w = w.fin_w; ta.fin_b = w.fin_b; ta.d_out = s.d_out; ta.hop = s.hop;
+  ta.in = s.ya2; ta.state = s.tail.base; ta.fin_w = w.fin_w; ta.fin_b = w.fin_b; ta.d_out = s.d_out; ta.hop = s.hop; ta.hop_next_out = s.hop_next_out;
   ta.w[0] = w.ra_w[1]; ta.b[0] = w.ra_b[1]; ta.w[1] = w.rb_w[1]; ta.b[1] = w.rb_b[1];
   ta.w[2] = w.up_w[2]; ta.b[2] = w.up_b[2]; ta.w[3] = w.ra_w[2]; ta.b[3] = w.ra_b[2]; ta.w[4] = w.rb_w[2]; ta.b[4] = w.rb_b[2];
   ta.w[5] = w.up_w[3]; ta.b[5] = w.up_b[3]; ta.w[6] = w.ra_w[3]; ta.b[6] = w.ra_b[3]; ta.w[7] = w.rb_w[3]; ta.b[7] = w.rb_b[3];
@@ -149,11 +149,11 @@ static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t
   if (s.advance_hop) MISC_LAUNCH("hop_advance", 0, 4, hop_advance_kernel, dim3(1), dim3(1), s.hop);
 }
 
-void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t st) {
+void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t st, bool cond_done) {
   switch (s.H) {
-    case 1: wave_forward_h<1>(w, s, st); break;
-    case 2: wave_forward_h<2>(w, s, st); break;
-    default: wave_forward_h<4>(w, s, st); break;
+    case 1: wave_forward_h<1>(w, s, st, cond_done); break;
+    case 2: wave_forward_h<2>(w, s, st, cond_done); break;
+    default: wave_forward_h<4>(w, s, st, cond_done); break;
   }
 }
 

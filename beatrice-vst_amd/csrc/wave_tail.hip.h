@@ -44,8 +44,9 @@ struct TailArgs {
   float* state;  // [B][TAIL_STATE_FLOATS]
   const float *w[8], *b[8];  // res2a, res2b, up3, res3a, res3b, up4, res4a, res4b
   const float *fin_w, *fin_b;
-  float* d_out;  // [B][240]
+  float* d_out;  // [B][H*240]
   const int* hop;
+  int* hop_next_out;  // optional: workgroup 0 stores hop + 1 here (a counter no kernel of this step reads)
 };
 
 namespace tail {
@@ -294,4 +295,5 @@ static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const T
   { float* tmp = SI_; SI_ = SO_; SO_ = tmp; }  // this hop's histories are the next hop's state
   }  // hops of the step
   for (int e = tid; e < TAIL_STATE_FLOATS; e += NTHR) st[e] = SI_[e];
+  if (a.hop_next_out != nullptr && b == 0 && tid == 0) *a.hop_next_out = hop + 1;
 }
