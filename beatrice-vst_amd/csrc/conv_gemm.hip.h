@@ -67,10 +67,12 @@ struct Layer {
   static constexpr int K = KSZ * CIN;
   static constexpr int SEG = 256;                      // MODEL_SPEC 2.2: reduction segment length
   static constexpr int P = (K + SEG - 1) / SEG;        // segments per output
-  static constexpr int KC = CIN >= 64 ? 64 : CIN;      // staged chunk (never straddles a tap or a segment)
-  static constexpr int NCHUNK = K / KC;
-  static constexpr int CHUNKS_PER_SEG = SEG / KC;
+  // staged k-chunk (never straddles a tap or a segment): 64 for the throughput tiling; the few-row
+  // tiling takes 128 where the channel count allows (half the barriers on its latency-bound chain)
+  static constexpr int KC = CIN >= 64 ? 64 : CIN;
+  static constexpr int KC_FEW = CIN % 128 == 0 ? 128 : KC;
   static_assert(CIN % KC == 0 && KC % 4 == 0 && SEG % KC == 0 && K % KC == 0, "channel chunking");
+  static_assert(CIN % KC_FEW == 0 && SEG % KC_FEW == 0 && K % KC_FEW == 0, "channel chunking (few-row tiling)");
 };
 
 // A workgroup is LK "k-groups" of LM x LN wavefronts; each wavefront owns WM x WN MFMA tiles.
@@ -89,7 +91,9 @@ struct TileCfg {
 // one launch (pair.hip.h); conv_gemm_kernel below is the plain one-layer launch.
 template <class L, class TC>
 __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bx, const int by) {
-  constexpr int KC = L::KC, AS = KC + 2, MT = TC::MT, NT = TC::NT, GTHR = TC::GTHR, LK = TC::LK;
+  constexpr int KC = TC::MT == 16 ? L::KC_FEW : L::KC;
+  constexpr int NCHUNK = L::K / KC, CHUNKS_PER_SEG = L::SEG / KC;
+  constexpr int AS = KC + 2, MT = TC::MT, NT = TC::NT, GTHR = TC::GTHR, LK = TC::LK;
   constexpr int P = L::P;
   static_assert(LK == 1 || LK == P, "k-groups: one group for all segments, or one group per segment");
   constexpr int PG = (P + LK - 1) / LK;  // segments (accumulator sets) per group
@@ -156,10 +160,20 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bx, 
   const float4* wfrag = reinterpret_cast<const float4*>(wbase) + (size_t)((n0 + wave_n) >> 4) * (L::K >> 4) * 64 + lane;
   // chunk `it` of this group: LK == 1 -> global chunk it; LK == P -> chunk it of segment grp
   auto load_chunk = [&](int it) {
-    const int ch = LK == 1 ? it : grp * L::CHUNKS_PER_SEG + it;
-    const bool live = ch < L::NCHUNK;
+    const int ch = LK == 1 ? it : grp * CHUNKS_PER_SEG + it;
+    const bool live = ch < NCHUNK;
     const int kk0 = ch * KC;
     const int j = kk0 / L::CIN, c0 = kk0 % L::CIN;
+    // weights first: their addresses do not depend on the step counter, so the loads are in flight
+    // while the scalar counter load that the ring addresses below wait for completes
+#pragma unroll
+    for (int jn = 0; jn < TC::WN; ++jn)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const int kbg = live ? (kk0 >> 4) + kb : 0;
+        const float4 f = wfrag[((size_t)jn * (L::K >> 4) + kbg) * 64];
+        bnext[jn][kb] = live ? f : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
 #pragma unroll
     for (int s = 0; s < A_SLOTS; ++s) {
       const int idx = gtid + s * GTHR;
@@ -171,14 +185,6 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bx, 
       }
       areg[s] = v;
     }
-#pragma unroll
-    for (int jn = 0; jn < TC::WN; ++jn)
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-        const int kbg = live ? (kk0 >> 4) + kb : 0;
-        const float4 f = wfrag[((size_t)jn * (L::K >> 4) + kbg) * 64];
-        bnext[jn][kb] = live ? f : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
   };
   auto store_chunk = [&]() {
 #pragma unroll
@@ -201,14 +207,14 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bx, 
       for (int kb = 0; kb < KB; ++kb) bcur[jn][kb] = bnext[jn][kb];
   };
 
-  constexpr int N_IT = LK == 1 ? L::NCHUNK : (L::CHUNKS_PER_SEG < L::NCHUNK ? L::CHUNKS_PER_SEG : L::NCHUNK);
+  constexpr int N_IT = LK == 1 ? NCHUNK : (CHUNKS_PER_SEG < NCHUNK ? CHUNKS_PER_SEG : NCHUNK);
   load_chunk(0);
 #pragma unroll 1
   for (int it = 0; it < N_IT; ++it) {
     store_chunk();
     __syncthreads();
     if (it + 1 < N_IT) load_chunk(it + 1);  // global loads fly while the MFMAs below run
-    const int g = LK == 1 ? (it / L::CHUNKS_PER_SEG) : 0;
+    const int g = LK == 1 ? (it / CHUNKS_PER_SEG) : 0;
     // accumulator set must be a compile-time index: dispatch over PG
 #pragma unroll
     for (int gs = 0; gs < PG; ++gs) {
