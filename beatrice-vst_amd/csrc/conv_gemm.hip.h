@@ -209,6 +209,63 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bx, 
 
   constexpr int N_IT = LK == 1 ? NCHUNK : (CHUNKS_PER_SEG < NCHUNK ? CHUNKS_PER_SEG : NCHUNK);
   load_chunk(0);
+
+  // ---- few-row tiling: the epilogue's operands (bias, residual, row scale) and output addresses are
+  // fetched now, behind the first chunk's loads, instead of after the MFMA chain (one global-memory
+  // latency less on the dependent path of a latency-bound launch)
+  constexpr bool PF = TC::MT == 16;
+  constexpr int E_SLOTS = LK == 1 ? 4 * TC::WM * TC::WN : (MT * NT + TC::NTHR - 1) / TC::NTHR;
+  int pf_dst[PF ? E_SLOTS : 1];
+  float pf_bias[PF ? E_SLOTS : 1], pf_res[PF ? E_SLOTS : 1], pf_rs[PF ? E_SLOTS : 1];
+  auto elem = [&](int slot, int& r, int& n) -> bool {  // output element `slot` of this thread
+    if constexpr (LK == 1) {
+      const int e = slot & 3, jn = (slot >> 2) % TC::WN, i = (slot >> 2) / TC::WN;
+      r = wave_m + i * 16 + (lane >> 4) * 4 + e;  // D layout of 16x16x4: row = (lane>>4)*4 + reg, col = lane&15
+      n = n0 + wave_n + jn * 16 + (lane & 15);
+      return true;
+    } else {
+      const int idx = tid + slot * TC::NTHR;
+      r = idx / NT;
+      n = n0 + idx % NT;
+      return idx < MT * NT;
+    }
+  };
+  if constexpr (PF) {
+    const int pos_out = ring_pos(a.out, hop), R_out = a.out.n * a.out.m;
+#pragma unroll
+    for (int sl = 0; sl < E_SLOTS; ++sl) {
+      int r, n, b = -1, t = 0;
+      pf_dst[sl] = -1; pf_bias[sl] = 0.f; pf_res[sl] = 0.f; pf_rs[sl] = 1.f;
+      if (elem(sl, r, n)) {
+        if constexpr (L::GROUPED) {
+          const int m = a.perm[bx * MT + r];
+          if (m >= 0) { b = m / L::T; t = m % L::T; }
+        } else {
+          const int m = m0 + r;
+          if (m < M) { b = m / L::T; t = m % L::T; }
+        }
+      }
+      if (b >= 0) {
+        pf_dst[sl] = (int)(((size_t)b * R_out + pos_out) * a.out.C + (size_t)t * L::NOUT + n);
+        if constexpr (L::EPI == EPI_BIAS) pf_bias[sl] = a.bias[n];
+        if constexpr (L::EPI == EPI_ROWSCALE) pf_rs[sl] = a.rowscale[b * L::T + t];
+        if constexpr (L::RES) {
+          const int R_res = a.res.n * a.res.m;
+          pf_res[sl] = a.res.base[((size_t)b * R_res + ring_pos(a.res, hop)) * a.res.C + (size_t)t * L::NOUT + n];
+        }
+      }
+    }
+  }
+  auto finish_pf = [&](int sl, float v) {
+    if (pf_dst[sl] < 0) return;
+    if constexpr (L::EPI == EPI_BIAS) v = v + pf_bias[sl];
+    if constexpr (L::EPI == EPI_SCALE) v = v * a.scale;
+    if constexpr (L::EPI == EPI_ROWSCALE) v = v * pf_rs[sl];
+    if constexpr (L::ACT == ACT_GELU) v = bsp::gelu(v);
+    if constexpr (L::RES) v = pf_res[sl] + v;
+    a.out.base[pf_dst[sl]] = v;
+  };
+
 #pragma unroll 1
   for (int it = 0; it < N_IT; ++it) {
     store_chunk();
@@ -264,18 +321,20 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bx, 
   };
 
   if constexpr (LK == 1) {
-    // D layout of 16x16x4: row = (lane>>4)*4 + reg, col = lane&15
 #pragma unroll
-    for (int i = 0; i < TC::WM; ++i)
+    for (int sl = 0; sl < 4 * TC::WM * TC::WN; ++sl) {
+      const int e = sl & 3, jn = (sl >> 2) % TC::WN, i = (sl >> 2) / TC::WN;
+      float v = acc[0][i][jn][e];
 #pragma unroll
-      for (int jn = 0; jn < TC::WN; ++jn)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = acc[0][i][jn][e];
-#pragma unroll
-          for (int g = 1; g < PG; ++g) v = v + acc[g][i][jn][e];
-          finish(wave_m + i * 16 + (lane >> 4) * 4 + e, n0 + wave_n + jn * 16 + (lane & 15), v);
-        }
+      for (int g = 1; g < PG; ++g) v = v + acc[g][i][jn][e];
+      if constexpr (PF) {
+        finish_pf(sl, v);
+      } else {
+        int r, n;
+        elem(sl, r, n);
+        finish(r, n, v);
+      }
+    }
   } else {
     float* red = lds;  // [P][MT][NT]; staging buffers are dead after the last barrier above
 #pragma unroll
@@ -286,11 +345,15 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bx, 
         for (int e = 0; e < 4; ++e)
           red[(grp * MT + wave_m + i * 16 + (lane >> 4) * 4 + e) * NT + wave_n + jn * 16 + (lane & 15)] = acc[0][i][jn][e];
     __syncthreads();
-    for (int idx = tid; idx < MT * NT; idx += TC::NTHR) {
+#pragma unroll
+    for (int sl = 0; sl < E_SLOTS; ++sl) {
+      const int idx = tid + sl * TC::NTHR;
+      if (idx >= MT * NT) break;
       float v = red[idx];
 #pragma unroll
       for (int g = 1; g < P; ++g) v = v + red[g * MT * NT + idx];
-      finish(idx / NT, n0 + idx % NT, v);
+      if constexpr (PF) finish_pf(sl, v);
+      else finish(idx / NT, n0 + idx % NT, v);
     }
   }
 }
