@@ -153,21 +153,29 @@ static __global__ __launch_bounds__(256) void attn_pv_kernel(const AttnPvArgs a)
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) bf[kb] = vp[(size_t)((grp == 0 || kb < 8) ? kb : 0) * 64];
   }
-  // softmax statistics, 4 rows per wavefront (MODEL_SPEC 4.4.2: same order as attn_softmax_kernel)
-#pragma unroll 1
-  for (int rr = 0; rr < 4; ++rr) {
-    const int r = wave * 4 + rr;
-    const int b = a.perm[blockIdx.x * 16 + r];
-    float v[6];
-    float mx = -__builtin_huge_valf();
+  // softmax statistics, 4 rows per wavefront (MODEL_SPEC 4.4.2); all 24 score loads of the wave are
+  // issued before the first reduction so that the rows do not pay one memory latency each
+  {
+    float v[4][6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { v[i] = b >= 0 ? a.scores[(size_t)b * KL + lane + 64 * i] : 0.0f; mx = fmaxf(mx, v[i]); }
-    mx = bsp::wmax64(mx);
-    float s = 0.0f;
+    for (int rr = 0; rr < 4; ++rr) {
+      const int b = a.perm[blockIdx.x * 16 + wave * 4 + rr];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { v[i] = bsp::exp(v[i] - mx); s = s + v[i]; es[r * AS + lane + 64 * i] = v[i]; }
-    const float tot = bsp::wsum64(s);
-    if (lane == 0) inv[r] = 1.0f / tot;
+      for (int i = 0; i < 6; ++i) v[rr][i] = b >= 0 ? a.scores[(size_t)b * KL + lane + 64 * i] : 0.0f;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = wave * 4 + rr;
+      float mx = -__builtin_huge_valf();
+#pragma unroll
+      for (int i = 0; i < 6; ++i) mx = fmaxf(mx, v[rr][i]);
+      mx = bsp::wmax64(mx);
+      float s = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { const float e = bsp::exp(v[rr][i] - mx); s = s + e; es[r * AS + lane + 64 * i] = e; }
+      const float tot = bsp::wsum64(s);
+      if (lane == 0) inv[r] = 1.0f / tot;
+    }
   }
   __syncthreads();
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
