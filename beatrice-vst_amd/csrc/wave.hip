@@ -96,7 +96,8 @@ using TGQ = TileCfg<1, 1, 1, 2, 1>;  // grouped attention scores: 16 rows x 32 k
 
 template <int D, int H>
 static void launch_c1(const WaveWeights& w, const WaveState& s, int blk, hipStream_t st) {
-  launch_auto<C1<D, H>>("wave.blk.c1", conv_args(s.x[blk], s.h1, w.c1_w[blk], w.c1_b[blk], s.hop, s.B), st);
+  static const char* const names[9] = {"", "wave.blk.c1.d1", "wave.blk.c1.d2", "", "wave.blk.c1.d4", "", "", "", "wave.blk.c1.d8"};
+  launch_auto<C1<D, H>>(names[D], conv_args(s.x[blk], s.h1, w.c1_w[blk], w.c1_b[blk], s.hop, s.B), st);
 }
 
 template <int H>
@@ -119,18 +120,18 @@ static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t
     }
     a = conv_args(s.h1, s.xa, w.c2_w[blk], w.c2_b[blk], s.hop, B);
     a.res = s.x[blk];
-    launch_auto<C2<H>>("wave.blk.c2", a, st);
+    launch_auto<C2<H>>("wave.blk.c2o", a, st);  // c2 and o are the same kernel symbol: one profile row
     launch_auto<QL<H>>("wave.blk.q", conv_args(s.xa, s.q, w.q_w[blk], w.q_b[blk], s.hop, B), st);
     a = conv_args(s.q, s.sc, s.d_kt[blk], nullptr, s.hop, B);
     a.scale = 0.0625f; a.perm = s.d_perm[blk]; a.tile_slot = s.d_tile_slot[blk];
     a.w_slot_stride = (size_t)B_HID * B_KV_LEN;
     launch_conv<SCORE<H>, TGQ>("wave.blk.attn_qk", a, s.n_tiles_max, st);
     AttnPvArgs pa{s.sc.base, s.d_v[blk], s.o.base, s.d_perm[blk], s.d_tile_slot[blk]};
-    MISC_LAUNCH("wave.blk.attn_pv", 2.0 * rows * 384 * 256 + 25.0 * rows * 384 * 8, 4.0 * (384.0 * 256 + rows * (384 * 8 + 256)),
+    MISC_LAUNCH("wave.blk.attn_pv", 2.0 * rows * 384 * 256 + 25.0 * rows * 384, 4.0 * (384.0 * 256 + rows * (384 + 256)),
                 attn_pv_kernel, dim3(s.n_tiles_max, B_HID / 32), dim3(256), pa);
     a = conv_args(s.o, s.x[blk + 1], w.o_w[blk], w.o_b[blk], s.hop, B);
     a.res = s.xa;
-    launch_auto<C2<H>>("wave.blk.o", a, st);
+    launch_auto<C2<H>>("wave.blk.c2o", a, st);
   }
   // upsampler: stage 1 and the stage-2 transposed conv as batched GEMMs (few rows per stream, large
   // weights), everything after that in one per-stream kernel

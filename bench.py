@@ -52,12 +52,13 @@ def load_shard():
 
 # launch name (BeatriceBatch_ProfileKernels) -> substring of the kernel symbol in the rocprofv3 PMC summary
 PMC_SYMBOL = {
-    "phone.rb": "Layer<256, 256, 5, 1, 1, 1, 0, 1, 0, true, false>",
-    "wave.tail": "wave_tail_kernel",
-    "phone.gru": "gru_fused_kernel<256, 256>",
-    "wave.blk.c1": "Layer<256, 256, 3, 1, 1, 1, 0, 1, 0, false, false>",
+    "wave.blk.c2o": "conv_gemm_kernel<Layer<256, 256, 1, 1, 1, 1, 0, 0, 0, true, false>",
+    "wave.blk.q": "conv_gemm_kernel<Layer<256, 256, 1, 1, 1, 1, 0, 0, 0, false, false>",
+    "wave.blk.attn_qk": "conv_gemm_kernel<Layer<256, 384, 1, 1, 1, 1, 0, 0, 1, false, true>",
     "wave.blk.attn_pv": "attn_pv_kernel",
-    "wave.up1": "Layer<256, 640, 2, 1, 1, 1, 1, 0, 0, false, false>",
+    "wave.tail": "wave_tail_kernel",
+    "phone.rb": "conv_gemm_kernel<Layer<256, 256, 5, 1, 1, 1, 0, 1, 0, true, false>",
+    "wave.up1": "conv_gemm_kernel<Layer<256, 640, 2, 1, 1, 1, 1, 0, 0, false, false>",
 }
 
 

@@ -1,0 +1,45 @@
+#!/bin/bash
+# Measurement recipe of one round (run on a GPU box from the repo root, e.g. through gpurun):
+#   tools/profile_round.sh r01_e
+# writes under gpurun_out/<tag>/: the bench line, the rocprofv3 kernel-trace/stats summary of the same
+# command, and two separate PMC passes (FETCH_SIZE, WRITE_SIZE) reduced to per-kernel means.  Copy what
+# is to be judged into profiles/.
+set -u
+TAG=${1:-round}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+
+python "$ROOT/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
+tail -c 400 "$OUT/bench.err"
+
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o k -- \
+  python "$ROOT/bench.py" --no-extras --steps 200 --warmup 20 > "$OUT/bench_under_rocprof.json" 2> /dev/null
+STATS=$(find "$OUT/prof" -name 'k_kernel_stats.csv' | head -1)
+[ -n "$STATS" ] && cp "$STATS" "$OUT/kernel_stats_B256.csv"
+
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- \
+    python "$ROOT/bench.py" --no-extras --steps 20 --warmup 5 > /dev/null 2>&1
+  CSV=$(find "$OUT/pmc_$C" -name 'pmc_counter_collection.csv' | head -1)
+  mkdir -p "$OUT/pmc_r1_$C"
+  [ -n "$CSV" ] && cp "$CSV" "$OUT/pmc_r1_$C/pmc_counter_collection.csv"
+done
+python "$ROOT/tools/pmc_summary.py" "$OUT" "$OUT/pmc_traffic.json"
+# keep the merge-back small: raw traces stay on the box
+rm -rf "$OUT/prof" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE"
+for C in FETCH_SIZE WRITE_SIZE; do
+  python - "$OUT/pmc_r1_$C/pmc_counter_collection.csv" "$C" <<'PY'
+import collections, csv, sys
+d = collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    d[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+w = csv.writer(open(sys.argv[1].replace("pmc_counter_collection.csv", "per_kernel_mean.csv"), "w"))
+w.writerow(["kernel", "launches", "mean_%s_KiB" % sys.argv[2]])
+for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
+    w.writerow([k, len(v), "%.2f" % (sum(v) / len(v))])
+PY
+  rm -f "$OUT/pmc_r1_$C/pmc_counter_collection.csv"
+done
+ls -la "$OUT"
