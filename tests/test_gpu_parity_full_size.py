@@ -1,0 +1,126 @@
+"""Parity at BASELINE.json's full per-GPU size (256 concurrent streams) and on the inputs that stress the
+discrete decisions of the path (silence: argmax ties; full-scale and DC: clamps and saturating tanh)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def model_dir8(tmp_path_factory):
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import make_model
+    d = str(tmp_path_factory.mktemp("model8"))
+    make_model.make_model(d, n_speakers=8)
+    return d
+
+
+def _oracle(bv, oracle, model_dir, audio, hops, setup, event):
+    m = bv.Models(oracle, model_dir)
+    B = audio.shape[0]
+    out = np.zeros((hops, B, bv.OUT_HOP), np.float32)
+    for s in range(B):  # stream after stream: the oracle streams are independent
+        st = bv.Stream1(m, speaker=0, vq_k=0)
+        setup(s, st, None)
+        for h in range(hops):
+            event(h, s, st, None)
+            out[h, s] = st.hop(audio[s, h * 160:(h + 1) * 160])
+        st.close()
+    m.close()
+    return out
+
+
+def test_256_streams_rotating_speakers_knn(bv, oracle, product, model_dir8):
+    """configs[2]/[3] shape on one GPU: 256 streams, 8 speakers, every stream switches speaker once (K/V blocks
+    one per hop), k-NN codebook lookup on; all 256 streams compared with independent oracle streams."""
+    B, hops = 256, 14
+    audio = np.stack([bv.synth_audio(160 * hops, seed=500 + s) for s in range(B)])
+
+    def setup(s, st, batch):
+        if st is not None:
+            st.set_target_speaker(s % 8)
+            while st.set_kv_block():
+                pass
+            st.a.SetVQNumNeighbors(st.pc, 4 if s % 4 else 0)
+        else:
+            a, h = batch.a, batch.h
+            a.BeatriceBatch_SetTargetSpeaker(h, s, s % 8)
+            a.BeatriceBatch_FlushSpeaker(h, s)
+            a.BeatriceBatch_SetVQNumNeighbors(h, s, 4 if s % 4 else 0)
+
+    def event(h, s, st, batch):
+        if h == 4 + (s % 5):
+            spk = (s + 3) % 8
+            if st is not None:
+                st.set_target_speaker(spk)
+            else:
+                batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, s, spk)
+
+    ref = _oracle(bv, oracle, model_dir8, audio, hops, setup, event)
+    m = bv.Models(product, model_dir8)
+    batch = bv.Batch(m, B)
+    for s in range(B):
+        setup(s, None, batch)
+    got = np.zeros_like(ref)
+    for h in range(hops):
+        for s in range(B):
+            event(h, s, None, batch)
+        got[h] = batch.convert(audio[:, h * 160:(h + 1) * 160])
+    batch.close()
+    m.close()
+    dev = float(np.abs(ref - got).max())
+    print("B=256 rotating speakers + k-NN: max-abs %g %s" % (dev, "bit-identical" if np.array_equal(ref, got) else ""))
+    assert np.abs(got).max() > 0.05
+    assert dev <= TOL
+
+
+@pytest.mark.parametrize("kind", ["silence", "full_scale_square", "dc", "impulses"])
+def test_stress_inputs(bv, oracle, product, model_dir, kind):
+    """Digital silence makes every logit of a frame depend on biases only (ties are broken towards the
+    lowest index on both sides); full-scale square waves and DC exercise the clamps."""
+    B, hops = 6, 20
+    n = 160 * hops
+    rng = np.random.Generator(np.random.PCG64(77))
+    if kind == "silence":
+        audio = np.zeros((B, n), np.float32)
+        audio[1, 160 * 10:] = bv.synth_audio(n, seed=1)[160 * 10:]      # speech after silence
+        audio[2, :160 * 8] = bv.synth_audio(n, seed=2)[:160 * 8]        # silence after speech
+    elif kind == "full_scale_square":
+        t = np.arange(n)
+        audio = np.stack([np.where((t // (20 + 7 * s)) % 2 == 0, 1.0, -1.0) for s in range(B)]).astype(np.float32)
+    elif kind == "dc":
+        audio = np.stack([np.full(n, v, np.float32) for v in (1.0, -1.0, 0.5, 1e-3, -1e-6, 0.25)])
+    else:
+        audio = np.zeros((B, n), np.float32)
+        for s in range(B):
+            audio[s, rng.integers(0, n, 12)] = rng.choice([-1.0, 1.0], 12)
+
+    def setup(s, st, batch):
+        k = (0, 1, 8)[s % 3]
+        if st is not None:
+            st.a.SetVQNumNeighbors(st.pc, k)
+        else:
+            batch.a.BeatriceBatch_SetVQNumNeighbors(batch.h, s, k)
+
+    ref = _oracle(bv, oracle, model_dir, audio, hops, setup, lambda *a: None)
+    m = bv.Models(product, model_dir)
+    batch = bv.Batch(m, B)
+    for s in range(B):
+        setup(s, None, batch)
+    got = np.zeros_like(ref)
+    q_trace = []
+    for h in range(hops):
+        got[h] = batch.convert(audio[:, h * 160:(h + 1) * 160])
+        q_trace.append(batch.intermediates()[1].copy())
+    batch.close()
+    m.close()
+    assert np.all(np.isfinite(got))
+    dev = float(np.abs(ref - got).max())
+    print("%s: max-abs %g %s; raw bins seen %s" % (kind, dev, "bit-identical" if np.array_equal(ref, got) else "",
+                                                  sorted(set(np.concatenate(q_trace).tolist()))[:8]))
+    assert dev <= TOL
