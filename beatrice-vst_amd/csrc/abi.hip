@@ -87,8 +87,12 @@ Beatrice_ErrorCode Beatrice20rc0_ReadPhoneExtractorParameters(Beatrice20rc0_Phon
 Beatrice20rc0_PhoneContext1* Beatrice20rc0_CreatePhoneContext1(void) {
   auto* c = new Beatrice20rc0_PhoneContext1();
   c->ok = make_stream(&c->stream) && c->st.create(1, 1, nullptr) &&
-          hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(float) * (B_IN_HOP + B_PHONE_CH), hipHostMallocDefault),
+          hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(float) * (B_IN_HOP + 1 + B_PHONE_CH), hipHostMallocDefault),
                  "hipHostMalloc");
+  // the kernels read the step counter from the mailbox behind the audio; it arrives with the input copy
+  c->st.hop = c->st.hop_in = c->st.hop_mailbox;
+  c->st.advance_hop = false;
+  c->st.skip_vq = true;  // k = 0 until SetVQNumNeighbors says otherwise
   return c;
 }
 void Beatrice20rc0_DestroyPhoneContext1(Beatrice20rc0_PhoneContext1* c) {
@@ -105,6 +109,7 @@ void Beatrice20rc0_SetVQNumNeighbors(Beatrice20rc0_PhoneContext1* ctx, int k) {
   if (!ctx || !ctx->ok) return;
   k = k < 0 ? 0 : (k > B_CODEBOOK ? B_CODEBOOK : k);
   (void)hip_ok(hipMemcpy(ctx->st.d_vqk, &k, sizeof(int), hipMemcpyHostToDevice), "vq k");
+  ctx->st.skip_vq = k == 0;  // no k-NN launch while the codebook is unused
 }
 // ref beatrice.h:318-322.  The host passes a pointer into its own table and, in morph mode, calls
 // this every hop (processor_core_2.cc:118-121), so it must be O(1) after first sight: the device
@@ -141,9 +146,11 @@ void Beatrice20rc0_ExtractPhone1(const Beatrice20rc0_PhoneExtractor* m, const fl
   std::memset(output, 0, sizeof(float) * B_PHONE_CH);
   if (!m || !m->loaded || !ctx || !ctx->ok) return;
   float* h_in = ctx->h_io;
-  float* h_out = ctx->h_io + B_IN_HOP;
+  float* h_out = ctx->h_io + B_IN_HOP + 1;
   std::memcpy(h_in, input, sizeof(float) * B_IN_HOP);
-  bool ok = hip_ok(hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * B_IN_HOP, hipMemcpyHostToDevice, ctx->stream), "in");
+  std::memcpy(h_in + B_IN_HOP, &ctx->hop_count, sizeof(int));
+  ctx->hop_count = hop_next(ctx->hop_count);
+  bool ok = hip_ok(hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * (B_IN_HOP + 1), hipMemcpyHostToDevice, ctx->stream), "in");
   phone_forward(m->w, ctx->st, ctx->stream);
   ok = ok && hip_ok(hipMemcpyAsync(h_out, ctx->st.d_phone, sizeof(float) * B_PHONE_CH, hipMemcpyDeviceToHost, ctx->stream), "out");
   ok = hip_ok(hipStreamSynchronize(ctx->stream), "sync") && ok;
@@ -168,7 +175,9 @@ Beatrice_ErrorCode Beatrice20rc0_ReadPitchEstimatorParameters(Beatrice20rc0_Pitc
 Beatrice20rc0_PitchContext1* Beatrice20rc0_CreatePitchContext1(void) {
   auto* c = new Beatrice20rc0_PitchContext1();
   c->ok = make_stream(&c->stream) && c->st.create(1, 1, nullptr, false) &&
-          hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(float) * (B_IN_HOP + 8), hipHostMallocDefault), "hipHostMalloc");
+          hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(float) * (B_IN_HOP + 1 + 8), hipHostMallocDefault), "hipHostMalloc");
+  c->st.hop = c->st.hop_in = c->st.hop_mailbox;  // step counter arrives with the input copy
+  c->st.advance_hop = false;
   return c;
 }
 void Beatrice20rc0_DestroyPitchContext1(Beatrice20rc0_PitchContext1* c) {
@@ -198,10 +207,12 @@ void Beatrice20rc0_EstimatePitch1(const Beatrice20rc0_PitchEstimator* m, const f
   std::memset(out_feat, 0, sizeof(float) * 4);
   if (!m || !m->loaded || !ctx || !ctx->ok) return;
   float* h_in = ctx->h_io;
-  float* h_feat = ctx->h_io + B_IN_HOP;
-  int* h_q = reinterpret_cast<int*>(ctx->h_io + B_IN_HOP + 4);
+  float* h_feat = ctx->h_io + B_IN_HOP + 1;
+  int* h_q = reinterpret_cast<int*>(ctx->h_io + B_IN_HOP + 1 + 4);
   std::memcpy(h_in, input, sizeof(float) * B_IN_HOP);
-  bool ok = hip_ok(hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * B_IN_HOP, hipMemcpyHostToDevice, ctx->stream), "in");
+  std::memcpy(h_in + B_IN_HOP, &ctx->hop_count, sizeof(int));
+  ctx->hop_count = hop_next(ctx->hop_count);
+  bool ok = hip_ok(hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * (B_IN_HOP + 1), hipMemcpyHostToDevice, ctx->stream), "in");
   pitch_forward(m->w, ctx->st, ctx->stream);
   ok = ok && hip_ok(hipMemcpyAsync(h_feat, ctx->st.d_feat, sizeof(float) * 4, hipMemcpyDeviceToHost, ctx->stream), "feat");
   ok = ok && hip_ok(hipMemcpyAsync(h_q, ctx->st.d_q_raw, sizeof(int), hipMemcpyDeviceToHost, ctx->stream), "q");
@@ -227,12 +238,14 @@ Beatrice_ErrorCode Beatrice20rc0_ReadWaveformGeneratorParameters(Beatrice20rc0_W
 // contiguous device block so GenerateWaveform1 needs a single host-to-device copy.
 Beatrice20rc0_WaveformContext1* Beatrice20rc0_CreateWaveformContext1(void) {
   auto* c = new Beatrice20rc0_WaveformContext1();
-  const size_t in_floats = B_PHONE_CH + 4 + 1;
+  const size_t in_floats = B_PHONE_CH + 4 + 1 + 1;  // ... | step counter
   c->ok = make_stream(&c->stream) &&
           hip_ok(hipMalloc(reinterpret_cast<void**>(&c->d_inputs), sizeof(float) * in_floats), "inputs") &&
           hip_ok(hipMemset(c->d_inputs, 0, sizeof(float) * in_floats), "inputs0") &&
           c->st.create(1, 1, 1, 1, 1, c->d_inputs, reinterpret_cast<int*>(c->d_inputs + B_PHONE_CH + 4), c->d_inputs + B_PHONE_CH) &&
           hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(float) * (in_floats + B_OUT_HOP), hipHostMallocDefault), "hipHostMalloc");
+  c->st.hop = reinterpret_cast<int*>(c->d_inputs + B_PHONE_CH + 4 + 1);
+  c->st.advance_hop = false;
   return c;
 }
 void Beatrice20rc0_DestroyWaveformContext1(Beatrice20rc0_WaveformContext1* c) {
@@ -249,12 +262,14 @@ void Beatrice20rc0_GenerateWaveform1(const Beatrice20rc0_WaveformGenerator* m, c
                                      const float* feat, float* output, Beatrice20rc0_WaveformContext1* ctx) {
   std::memset(output, 0, sizeof(float) * B_OUT_HOP);
   if (!m || !m->loaded || !ctx || !ctx->ok) return;
-  const size_t in_floats = B_PHONE_CH + 4 + 1;
+  const size_t in_floats = B_PHONE_CH + 4 + 1 + 1;
   float* h_in = ctx->h_io;
   float* h_out = ctx->h_io + in_floats;
   std::memcpy(h_in, phone, sizeof(float) * B_PHONE_CH);
   std::memcpy(h_in + B_PHONE_CH, feat, sizeof(float) * 4);
   std::memcpy(h_in + B_PHONE_CH + 4, q, sizeof(int));
+  std::memcpy(h_in + B_PHONE_CH + 5, &ctx->hop_count, sizeof(int));
+  ctx->hop_count = hop_next(ctx->hop_count);
   bool ok = hip_ok(hipMemcpyAsync(ctx->d_inputs, h_in, sizeof(float) * in_floats, hipMemcpyHostToDevice, ctx->stream), "in");
   wave_forward(m->w, ctx->st, ctx->stream);
   ok = ok && hip_ok(hipMemcpyAsync(h_out, ctx->st.d_out, sizeof(float) * B_OUT_HOP, hipMemcpyDeviceToHost, ctx->stream), "out");

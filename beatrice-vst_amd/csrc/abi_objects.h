@@ -26,21 +26,24 @@ struct Beatrice20rc0_EmbeddingSetter { bhip::DeviceBlob blob; bhip::EmbedWeights
 struct Beatrice20rc0_PhoneContext1 {
   bhip::PhoneState st;
   hipStream_t stream = nullptr;
-  float* h_io = nullptr;  // pinned: 160 in | 128 out
+  float* h_io = nullptr;  // pinned: 160 in | step counter | 128 out
+  int hop_count = 0;      // hops done; travels to the device with the input copy (no launch spent on counting)
   std::vector<bhip::CodebookEntry> cache;
   bool ok = false;
 };
 struct Beatrice20rc0_PitchContext1 {
   bhip::PitchState st;
   hipStream_t stream = nullptr;
-  float* h_io = nullptr;  // pinned: 160 in | 4 feat | 1 bin
+  float* h_io = nullptr;  // pinned: 160 in | step counter | 4 feat | 1 bin
+  int hop_count = 0;
   bool ok = false;
 };
 struct Beatrice20rc0_WaveformContext1 {
   bhip::WaveState st;
   hipStream_t stream = nullptr;
-  float* d_inputs = nullptr;  // device: 128 phone | 4 feat | 1 bin
+  float* d_inputs = nullptr;  // device: 128 phone | 4 feat | 1 bin | step counter
   float* h_io = nullptr;      // pinned: inputs | 240 out
+  int hop_count = 0;
   bool ok = false;
 };
 struct Beatrice20rc0_EmbeddingContext {

@@ -41,7 +41,10 @@ bool RingArena::build(int B_, const std::vector<RingSpec>& specs) {
   release();
   B = B_;
   size_t total = 0;
-  for (const RingSpec& s : specs) total += ((size_t)B * s.C * s.n * s.m + 63) / 64 * 64;
+  for (const RingSpec& s : specs) {
+    if (s.m < 1 || s.m > 17) return false;  // the step counter wraps at lcm(1..17) (B_HOP_WRAP)
+    total += ((size_t)B * s.C * s.n * s.m + 63) / 64 * 64;
+  }
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&base), total * sizeof(float)));
   floats = total;
   BHIP_TRY(hipMemset(base, 0, total * sizeof(float)));

@@ -79,6 +79,7 @@ struct PhoneState {
   Ring audio, f[5], rb[4], h, raw;
   float* d_in = nullptr;     // [B][H*160]; owned unless shared
   bool owns_in = false;
+  int* hop_mailbox = nullptr;  // owned d_in only: one int right behind the audio (counter sent with the input copy)
   float* d_phone = nullptr;  // [B][H][128]
   const float** d_cbT = nullptr;    // [B] device pointers
   const float** d_cnorm = nullptr;  // [B]
@@ -110,6 +111,7 @@ struct PitchState {
   Ring audio, spec, p[3], h, logits;
   float* d_in = nullptr;
   bool owns_in = false;
+  int* hop_mailbox = nullptr;  // owned d_in only: one int right behind the audio
   int *d_min_q = nullptr, *d_max_q = nullptr, *d_prev_q = nullptr;  // [B]
   int *d_q_raw = nullptr, *d_q = nullptr;                          // [B][H]
   float* d_feat = nullptr;             // [B][H][4]

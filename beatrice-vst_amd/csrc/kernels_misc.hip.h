@@ -22,7 +22,11 @@
 #define B_PITCH_HIST (B_FFT_N - B_IN_HOP)
 
 // ---------------------------------------------------------------------------------------------
-static __global__ void hop_advance_kernel(int* hop) { *hop = *hop + 1; }
+// The step counter only ever selects ring slots (counter mod m, m <= 17 slots): it wraps at lcm(1..17)
+// so that a stream can run forever without the modulus glitching at an integer overflow.
+#define B_HOP_WRAP 12252240
+__host__ __device__ inline int hop_next(int hop) { return hop + 1 >= B_HOP_WRAP ? 0 : hop + 1; }
+static __global__ void hop_advance_kernel(int* hop) { *hop = hop_next(*hop); }
 
 // ---------------------------------------------------------------------------------------------
 // Phone front-end layer 1 (MODEL_SPEC 4.1.1): Conv1d(1 -> 64, k=10, stride=5) + GELU.

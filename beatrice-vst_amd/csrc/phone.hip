@@ -18,9 +18,11 @@ bool PhoneState::create(int B_, int H_, float* shared_in) {
   if (!arena.build(B, specs)) return false;
   if (shared_in) { d_in = shared_in; owns_in = false; }
   else {
-    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_in), sizeof(float) * B * H * B_IN_HOP));
-    BHIP_TRY(hipMemset(d_in, 0, sizeof(float) * B * H * B_IN_HOP));
+    // one extra word behind the audio: a step-counter mailbox the 1-stream ABI fills with the same copy
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_in), sizeof(float) * (B * H * B_IN_HOP + 1)));
+    BHIP_TRY(hipMemset(d_in, 0, sizeof(float) * (B * H * B_IN_HOP + 1)));
     owns_in = true;
+    hop_mailbox = reinterpret_cast<int*>(d_in + (size_t)B * H * B_IN_HOP);
   }
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_phone), sizeof(float) * B * H * B_PHONE_CH));
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cbT), sizeof(float*) * B));

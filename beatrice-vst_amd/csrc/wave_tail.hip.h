@@ -295,5 +295,5 @@ static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const T
   { float* tmp = SI_; SI_ = SO_; SO_ = tmp; }  // this hop's histories are the next hop's state
   }  // hops of the step
   for (int e = tid; e < TAIL_STATE_FLOATS; e += NTHR) st[e] = SI_[e];
-  if (a.hop_next_out != nullptr && b == 0 && tid == 0) *a.hop_next_out = hop + 1;
+  if (a.hop_next_out != nullptr && b == 0 && tid == 0) *a.hop_next_out = hop_next(hop);
 }
