@@ -2,7 +2,7 @@
 // B = 256 rows): which part of the kernel costs what.  Chain of 64 launches in a hipGraph.
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "conv_gemm.hip.h"
+#include "lat_gemm.hip.h"
 namespace bhip { LaunchHook*& launch_hook() { static thread_local LaunchHook* h = nullptr; return h; } }
 using LQ = Layer<256, 256, 1, 1, 1, 1, PRE_NONE, ACT_NONE, EPI_BIAS, true>;
 using L5 = Layer<256, 256, 5, 1, 1, 1, PRE_NONE, ACT_GELU, EPI_BIAS, true>;
