@@ -262,6 +262,8 @@ _BATCH = {
     "BeatriceBatch_NumStreams": (C.c_int, [_vp]),
     "BeatriceBatch_SetSpeakerTables": (C.c_int, [_vp, C.c_int, _f32p, _f32p, _f32p, _f32p]),
     "BeatriceBatch_UpdateSpeaker": (C.c_int, [_vp, C.c_int, _f32p, _f32p, _f32p]),
+    "BeatriceBatch_MorphSpeaker": (C.c_int, [_vp, C.c_int, _f32p, C.c_int, C.c_uint]),
+    "BeatriceBatch_GetSpeakerEmbeddings": (C.c_int, [_vp, C.c_int, _f32p, _f32p]),
     "BeatriceBatch_SetTargetSpeaker": (C.c_int, [_vp, C.c_int, C.c_int]),
     "BeatriceBatch_FlushSpeaker": (C.c_int, [_vp, C.c_int]),
     "BeatriceBatch_SetFormantShift": (C.c_int, [_vp, C.c_int, C.c_double]),

@@ -10,6 +10,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
+#include <numeric>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -30,6 +33,17 @@ struct StreamCfg {
   int vq_k = 0;
   int min_q = 1, max_q = B_PITCH_BINS - 1;
   PitchParams pitch{52.0, 1.0, 0.0, 0.0, 0, 0};  // defaults: processor_core_2.h:105-110
+};
+
+// A table entry that is a morph of real speakers (BeatriceBatch_MorphSpeaker): what the per-hop codebook
+// lottery needs (reference processor_core_2.cc:94-121)
+struct MorphSlot {
+  bool active = false;
+  int n_speakers = 0;           // real speakers the weights refer to
+  int n_odds = 0;               // min(n_speakers, 8)
+  int order[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float odds[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // pruned weights in `order`
+  std::mt19937 rng;
 };
 
 template <class T>
@@ -73,6 +87,8 @@ struct BeatriceBatch {
   float *d_cb_raw = nullptr, *d_cbT = nullptr, *d_cnorm = nullptr, *d_add_raw = nullptr, *d_frm_raw = nullptr, *d_kv_raw = nullptr;
   // per-stream settings
   std::vector<StreamCfg> cfg;
+  std::vector<MorphSlot> morph;  // [max_speakers]
+  int n_morph_slots = 0;
   Mirror<const float*> m_cbT, m_cnorm;
   Mirror<int> m_vqk, m_min_q, m_max_q, m_add_idx, m_frm_idx;
   Mirror<PitchParams> m_params;
@@ -220,8 +236,36 @@ void update_vq_mode(BeatriceBatch* b) {
   if (none != b->phone.skip_vq) { settle(b); b->phone.skip_vq = none; drop_graph(b); }
 }
 
+// streams whose target is a morphed entry draw the codebook of ONE real speaker per step, with the
+// morph weights as odds (reference processor_core_2.cc:94-121: same draws, same order of operations)
+void draw_codebooks(BeatriceBatch* b) {
+  if (b->n_morph_slots == 0) return;
+  bool any = false;
+  for (int s = 0; s < b->B; ++s) {
+    StreamCfg& c = b->cfg[s];
+    MorphSlot& m = b->morph[c.target_speaker];
+    if (!m.active) continue;
+    if (!any) { settle(b); any = true; }
+    float sum = 0.0f;
+    for (int i = 0; i < m.n_odds; ++i) sum += m.odds[i];
+    int idx = m.order[0];
+    if (sum <= std::numeric_limits<float>::epsilon()) {
+      idx = std::uniform_int_distribution<int>(0, m.n_speakers - 1)(m.rng);
+    } else {
+      float r = std::uniform_real_distribution<float>(0.0f, sum)(m.rng);
+      for (int i = 0; i < m.n_odds; ++i) {
+        r -= m.odds[i];
+        if (r < 0.0f) { idx = m.order[i]; break; }
+      }
+    }
+    c.codebook_speaker = idx;
+    sync_stream_arrays(b, s);
+  }
+}
+
 bool step_device(BeatriceBatch* b, const float* d_in, float* d_out) {
   advance_kv(b);
+  draw_codebooks(b);
   if (b->vq_dirty) { update_vq_mode(b); b->vq_dirty = false; }
   if (!push_settings(b)) return false;
   if (d_in && d_in != b->d_in)
@@ -315,6 +359,7 @@ BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* pho
        hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_kv_raw), sizeof(float) * kvf), "kv");
   ok = ok && hip_ok(hipMemset(b->d_cbT, 0, sizeof(float) * cbf), "cbT0") && hip_ok(hipMemset(b->d_cnorm, 0, sizeof(float) * S * B_CODEBOOK), "cn0");
   b->cfg.assign(B, StreamCfg());
+  b->morph.assign(S, MorphSlot());
   ok = ok && b->m_cbT.alloc_host(B) && b->m_cnorm.alloc_host(B) && b->m_vqk.alloc_host(B) && b->m_min_q.alloc_host(B) &&
        b->m_max_q.alloc_host(B) && b->m_add_idx.alloc_host(B) && b->m_frm_idx.alloc_host(B) && b->m_params.alloc_host(B);
   if (ok) {
@@ -411,6 +456,8 @@ int BeatriceBatch_SetSpeakerTables(BeatriceBatch* b, int n, const float* codeboo
             hip_ok(hipMemcpy(b->d_kv_raw, kv, sizeof(float) * n * B_KV_LEN * B_KV_CH, hipMemcpyHostToDevice), "kv");
   if (!ok || !hip_ok(hipDeviceSynchronize(), "tables sync")) return -2;
   b->n_speakers = n;
+  for (MorphSlot& m : b->morph) m.active = false;
+  b->n_morph_slots = 0;
   const EmbedWeights& w = b->embed_m->w;
   embed_project_rows(w.frm_w, w.frm_b, b->d_frm_raw, b->wave.d_frm_tab, 9, b->stream);
   return project_speakers(b, 0, n) ? 0 : -2;
@@ -425,7 +472,63 @@ int BeatriceBatch_UpdateSpeaker(BeatriceBatch* b, int spk, const float* codebook
   if (kv) ok = ok && hip_ok(hipMemcpy(b->d_kv_raw + (size_t)spk * B_KV_LEN * B_KV_CH, kv, sizeof(float) * B_KV_LEN * B_KV_CH, hipMemcpyHostToDevice), "kv1");
   if (!ok || !hip_ok(hipDeviceSynchronize(), "speaker sync")) return -2;
   if (spk >= b->n_speakers) b->n_speakers = spk + 1;
+  if (b->morph[spk].active) { b->morph[spk].active = false; --b->n_morph_slots; }  // the caller's data replaces a morph
   return project_speakers(b, spk, 1) ? 0 : -2;
+}
+
+// ---- speaker morphing ----------------------------------------------------------------------------
+// Weight preparation as the reference host does it (voice_morph_state.h:87-104: entries below 0.01
+// dropped; processor_core_2.cc:507-532: the eight largest kept, in descending order), then the additive
+// and the 384 key/value embeddings of entry `slot` become weighted spherical means computed on the
+// device (morph.hip), and their projections are refreshed.
+int BeatriceBatch_MorphSpeaker(BeatriceBatch* b, int slot, const float* weights, int n_weights, unsigned seed) {
+  if (!b || !b->ok) return -2;
+  if (!weights || n_weights < 1 || n_weights > 256 || slot < n_weights || slot >= b->max_speakers || n_weights > b->n_speakers) return -1;
+  std::vector<float> w(weights, weights + n_weights);
+  for (float& v : w) if (v < 0.01f) v = 0.0f;
+  std::vector<int> order(n_weights);
+  std::iota(order.begin(), order.end(), 0);
+  std::sort(order.begin(), order.end(), [&w](const int x, const int y) -> bool { return w[x] > w[y]; });
+  const int keep = std::min(n_weights, 8);
+  // SphericalAverage::SetWeights (spherical_average.h:142-199): points in `order` until the first zero weight
+  int n_active = 0, spk[8];
+  float wn[8], sum = 0.0f;
+  for (int i = 0; i < keep; ++i) {
+    if (w[order[i]] == 0.0f) break;
+    spk[n_active] = order[i]; wn[n_active] = w[order[i]]; ++n_active;
+  }
+  for (int i = 0; i < n_active; ++i) sum += wn[i];
+  if (n_active > 0 && sum > 0.0f) { const float inv = 1.0f / sum; for (int i = 0; i < n_active; ++i) wn[i] *= inv; }
+  else n_active = 0;
+  settle(b);
+  bool ok = hip_ok(hipStreamSynchronize(b->stream), "sync");
+  ok = ok && spherical_mean_rows(b->d_add_raw, B_HID, 1, B_HID, n_active, spk, wn, b->d_add_raw + (size_t)slot * B_HID, b->stream);
+  ok = ok && spherical_mean_rows(b->d_kv_raw, (size_t)B_KV_LEN * B_KV_CH, B_KV_LEN, B_KV_CH, n_active, spk, wn,
+                                 b->d_kv_raw + (size_t)slot * B_KV_LEN * B_KV_CH, b->stream);
+  if (!ok) return -2;
+  if (slot >= b->n_speakers) b->n_speakers = slot + 1;
+  if (!project_speakers(b, slot, 1)) return -2;
+  MorphSlot& m = b->morph[slot];
+  if (!m.active) ++b->n_morph_slots;
+  m.active = true;
+  m.n_speakers = n_weights;
+  m.n_odds = keep;
+  for (int i = 0; i < 8; ++i) { m.order[i] = i < keep ? order[i] : 0; m.odds[i] = i < keep ? w[order[i]] : 0.0f; }
+  m.rng.seed(seed);
+  // streams already on this entry re-install its key/value blocks, one per hop, like after a speaker switch
+  for (StreamCfg& c : b->cfg) if (c.target_speaker == slot) c.kv_set_count = 0;
+  b->pending_kv = 0;
+  for (const StreamCfg& c : b->cfg) if (c.kv_set_count < B_NBLOCKS) ++b->pending_kv;
+  return 0;
+}
+// copies the morphed entry's raw embeddings back (test / inspection hook; any pointer may be NULL)
+int BeatriceBatch_GetSpeakerEmbeddings(BeatriceBatch* b, int speaker, float* additive, float* key_value) {
+  if (!b || !b->ok) return -2;
+  if (speaker < 0 || speaker >= b->max_speakers) return -1;
+  bool ok = hip_ok(hipStreamSynchronize(b->stream), "sync");
+  if (additive) ok = ok && hip_ok(hipMemcpy(additive, b->d_add_raw + (size_t)speaker * B_HID, sizeof(float) * B_HID, hipMemcpyDeviceToHost), "add");
+  if (key_value) ok = ok && hip_ok(hipMemcpy(key_value, b->d_kv_raw + (size_t)speaker * B_KV_LEN * B_KV_CH, sizeof(float) * B_KV_LEN * B_KV_CH, hipMemcpyDeviceToHost), "kv");
+  return ok ? 0 : -2;
 }
 
 // ---- per-stream settings (reference ProcessorCore2 setters) ------------------------------------

@@ -189,4 +189,9 @@ void embed_project_kv(const EmbedWeights& w, int block, const float* d_kv_raw, i
                       hipStream_t stream);
 void codebook_prepare(const float* d_cb, int n, float* d_cbT, float* d_cnorm, hipStream_t stream);
 
+// speaker morphing (morph.hip): out[row][:] = weighted spherical mean over table[speakers[n]][row][:],
+// n < n_active <= 8, weights normalised and descending; dim = 128 or 256; one wavefront per row
+bool spherical_mean_rows(const float* d_table, size_t speaker_stride, int rows, int dim, int n_active, const int* speakers,
+                         const float* weights, float* d_out, hipStream_t stream);
+
 }  // namespace bhip

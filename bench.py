@@ -155,6 +155,50 @@ def block_mode(bv, models, product, streams, steps=200):
     return out
 
 
+def morph_timing(bv, product, n_real=8):
+    """Speaker morphing: one BeatriceBatch_MorphSpeaker call = 385 spherical
+    means on the device + re-projection of the entry, against the same 385 solves by the host solver
+    (beatrice-vst_amd/host, the bit-exact counterpart of the reference's SphericalAverage) on one core."""
+    import ctypes as C
+    import tempfile
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import make_model
+    tmp = tempfile.TemporaryDirectory()
+    make_model.make_model(tmp.name, n_speakers=n_real)
+    models = bv.Models(product, tmp.name)
+    batch = bv.Batch(models, 4, max_speakers=n_real + 2)
+    w = np.zeros(n_real, np.float32)
+    w[:min(n_real, 4)] = (0.4, 0.3, 0.2, 0.1)[:min(n_real, 4)]
+    product.BeatriceBatch_MorphSpeaker(batch.h, n_real, bv.fptr(w), n_real, 1)
+    t0 = time.perf_counter()
+    reps = 20
+    for i in range(reps):
+        product.BeatriceBatch_MorphSpeaker(batch.h, n_real, bv.fptr(w), n_real, 1)
+    dev_ms = (time.perf_counter() - t0) * 1e3 / reps
+    batch.close()
+    out = {"device_ms_per_morph": round(dev_ms, 3), "solves": 385}
+    host_path = os.path.join(REPO, "oracle", "libhost_on_oracle.so")
+    if os.path.exists(host_path):
+        lib = C.CDLL(host_path)
+        f32p, i32p = C.POINTER(C.c_float), C.POINTER(C.c_int)
+        lib.BeatriceHost_SphericalMean.argtypes = [C.c_int, C.c_int, f32p, f32p, i32p, C.c_int, C.c_int, f32p]
+        t = models.tables
+        order = np.argsort(-w, kind="stable").astype(np.int32)
+        o256, o128 = np.zeros(256, np.float32), np.zeros(128, np.float32)
+        kvp = [np.ascontiguousarray(t.kv[:n_real, tok]) for tok in range(t.kv.shape[1])]
+        addp = np.ascontiguousarray(t.additive[:n_real])
+        t0 = time.perf_counter()
+        lib.BeatriceHost_SphericalMean(256, n_real, addp.ctypes.data_as(f32p), w.ctypes.data_as(f32p), order.ctypes.data_as(i32p), 8, 4,
+                                       o256.ctypes.data_as(f32p))
+        for pts in kvp:
+            lib.BeatriceHost_SphericalMean(128, n_real, pts.ctypes.data_as(f32p), w.ctypes.data_as(f32p), order.ctypes.data_as(i32p), 8, 4,
+                                           o128.ctypes.data_as(f32p))
+        out["host_ms_per_morph_1core"] = round((time.perf_counter() - t0) * 1e3, 3)
+    models.close()
+    tmp.cleanup()
+    return out
+
+
 def latency_b1(bv, product, model_dir, hops=400):
     """BASELINE.json configs[1]: 1 stream, 1 speaker, hop-synchronous 1-stream C-ABI."""
     m = bv.Models(product, model_dir)
@@ -341,6 +385,7 @@ def main():
             if world == 1:
                 res["saturation"] = saturation(bv, m, product)
                 res["block_mode"] = block_mode(bv, m, product, B)
+                res["morph"] = morph_timing(bv, product)
                 res["latency_b1"] = latency_b1(bv, product, model_dir)
                 res["cpu_baseline"] = cpu_baseline(bv, model_dir, a.cpu_seconds)
         print(json.dumps(res))

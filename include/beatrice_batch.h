@@ -71,6 +71,20 @@ int BeatriceBatch_SetSpeakerTables(BeatriceBatch* b, int n_speakers, const float
 int BeatriceBatch_UpdateSpeaker(BeatriceBatch* b, int speaker, const float* codebook, const float* additive,
                                 const float* key_value);
 
+/* Speaker morphing on the device (reference processor_core_2.cc:51-177, 498-532; spherical_average.h):
+ * table entry `slot` (n_weights <= slot < max_speakers, e.g. the reference's extra entry n_speakers)
+ * becomes the morph of the real speakers 0..n_weights-1 under `weights`: weights below 0.01 are dropped and
+ * the eight largest kept (as the reference prepares them), the additive embedding and the 384 key/value
+ * embeddings are weighted spherical means (one wavefront each, one launch), projections are refreshed.
+ * Streams whose target speaker is `slot` then (a) re-install the entry's key/value blocks one per hop and
+ * (b) use, at every step, the codebook of ONE real speaker drawn with the weights as odds from a
+ * std::mt19937 seeded with `seed` (the reference seeds from std::random_device).  Unlike the reference
+ * host, which spreads the means over five hops to bound its CPU time, the new embeddings are complete
+ * when the call returns.  Agreement with the host computation: float rounding (<= 1e-5), not bit-exact. */
+int BeatriceBatch_MorphSpeaker(BeatriceBatch* b, int slot, const float* weights, int n_weights, unsigned seed);
+/* Raw embeddings of a table entry as currently held on the device: additive [256], key_value [384][128]. */
+int BeatriceBatch_GetSpeakerEmbeddings(BeatriceBatch* b, int speaker, float* additive, float* key_value);
+
 int BeatriceBatch_SetTargetSpeaker(BeatriceBatch* b, int stream, int speaker);
 int BeatriceBatch_FlushSpeaker(BeatriceBatch* b, int stream); /* install all pending K/V blocks now */
 int BeatriceBatch_SetFormantShift(BeatriceBatch* b, int stream, double formant_shift);

@@ -1,0 +1,165 @@
+"""Speaker morphing on the device: BeatriceBatch_MorphSpeaker against the
+host computation (SphericalMean, which is pinned bit-exact to the reference's SphericalAverage by
+tests/test_morph.py), and end to end against oracle streams whose morph entry was filled by the host."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import hostlib
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_f32p, _i32p = C.POINTER(C.c_float), C.POINTER(C.c_int)
+
+
+@pytest.fixture(scope="module")
+def model_dir8(tmp_path_factory):
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import make_model
+    d = str(tmp_path_factory.mktemp("model8m"))
+    make_model.make_model(d, n_speakers=8)
+    return d
+
+
+@pytest.fixture(scope="module")
+def host_lib(built):
+    lib = C.CDLL(hostlib.HOST_ON_ORACLE)  # test infrastructure: the host solver, CPU only
+    lib.BeatriceHost_SphericalMean.argtypes = [C.c_int, C.c_int, _f32p, _f32p, _i32p, C.c_int, C.c_int, _f32p]
+    return lib
+
+
+def _prepare(weights):
+    """reference weight preparation: < 0.01 dropped, descending order, eight kept"""
+    w = np.array(weights, np.float32)
+    w[w < np.float32(0.01)] = 0
+    order = np.argsort(-w, kind="stable").astype(np.int32)
+    pruned = np.zeros_like(w)
+    pruned[order[:8]] = w[order[:8]]
+    return pruned, order
+
+
+def _host_mean(lib, pts, pruned, order):
+    pts = np.ascontiguousarray(pts, np.float32)
+    out = np.zeros(pts.shape[1], np.float32)
+    lib.BeatriceHost_SphericalMean(pts.shape[1], pts.shape[0], pts.ctypes.data_as(_f32p), pruned.ctypes.data_as(_f32p),
+                                   order.ctypes.data_as(_i32p), 8, 4, out.ctypes.data_as(_f32p))
+    return out
+
+
+def _host_entry(lib, tables, n, weights):
+    pruned, order = _prepare(weights)
+    add = _host_mean(lib, tables.additive[:n], pruned, order)
+    kv = np.stack([_host_mean(lib, tables.kv[:n, tok], pruned, order) for tok in range(tables.kv.shape[1])])
+    return add, kv, pruned, order
+
+
+@pytest.mark.parametrize("weights", [
+    [0.2, 0.5, 0.3, 0, 0, 0, 0, 0],
+    [0.05, 0.3, 0.005, 0.2, 0.1, 0.15, 0.1, 0.1],     # one weight below the 0.01 threshold
+    [0, 0, 0, 1.0, 0, 0, 0, 0],                       # a single speaker: the mean is that speaker
+    [0.125] * 8,
+])
+def test_morphed_embeddings_match_host(bv, product, host_lib, model_dir8, weights):
+    m = bv.Models(product, model_dir8)
+    t = m.tables
+    n = t.n_speakers
+    batch = bv.Batch(m, 2)
+    w = np.array(weights, np.float32)
+    assert batch.a.BeatriceBatch_MorphSpeaker(batch.h, n, bv.fptr(w), n, 7) == 0
+    add = np.zeros(256, np.float32)
+    kv = np.zeros((384, 128), np.float32)
+    assert batch.a.BeatriceBatch_GetSpeakerEmbeddings(batch.h, n, bv.fptr(add), bv.fptr(kv)) == 0
+    ref_add, ref_kv, _, _ = _host_entry(host_lib, t, n, weights)
+    batch.close()
+    m.close()
+    scale = max(float(np.abs(ref_add).max()), float(np.abs(ref_kv).max()))
+    dev = max(float(np.abs(add - ref_add).max()), float(np.abs(kv - ref_kv).max()))
+    print("weights %s: max-abs %g (embedding scale %.2f)" % (weights[:4], dev, scale))
+    assert scale > 0.1
+    assert dev <= 1e-5 * max(1.0, scale)
+    if weights[3] == 1.0:  # the degenerate morph reproduces the speaker (up to the normalise / de-normalise round trip)
+        assert np.abs(add - t.additive[3]).max() <= 1e-5 * scale
+
+
+def _mt_draws(seed):
+    """std::uniform_real_distribution<float>(0, s)(std::mt19937(seed)) as libstdc++ computes it"""
+    bg = np.random.MT19937()
+    bg._legacy_seeding(seed)
+    while True:
+        c = np.float32(np.float32(int(bg.random_raw())) / np.float32(4294967296.0))
+        if c >= np.float32(1.0):
+            c = np.nextafter(np.float32(1.0), np.float32(0.0))
+        yield c
+
+
+@pytest.mark.parametrize("vq_k", [0, 4])
+def test_morph_end_to_end(bv, oracle, product, host_lib, model_dir8, vq_k):
+    """Streams on a morphed entry: embeddings from the device solver, K/V blocks installed one per hop, and
+    (k > 0) a codebook drawn per hop with the weights as odds -- against oracle streams driven with the
+    host-computed entry and the same draws."""
+    weights = [0.1, 0.0, 0.45, 0.0, 0.25, 0.2, 0.0, 0.0]
+    seed, B, hops = 1234, 3, 18
+    audio = np.stack([bv.synth_audio(160 * hops, seed=900 + s) for s in range(B)])
+    switch_hop = {0: 0, 1: 6}                     # stream 2 never morphs
+
+    # ---- oracle side: the morph entry of the caller-owned tables filled by the host solver
+    mo = bv.Models(oracle, model_dir8)
+    t = mo.tables
+    n = t.n_speakers
+    add, kv, pruned, order = _host_entry(host_lib, t, n, weights)
+    t.additive[n] = add
+    t.kv[n] = kv
+    odds = pruned[order[:8]]
+    total = np.float32(0)
+    for v in odds:
+        total = np.float32(total + v)
+    draws = _mt_draws(seed)
+    streams = [bv.Stream1(mo, speaker=s, vq_k=vq_k) for s in range(B)]
+    ref = np.zeros((hops, B, bv.OUT_HOP), np.float32)
+    picks = []
+    for h in range(hops):
+        for s in range(B):
+            if switch_hop.get(s) == h:
+                streams[s].set_target_speaker(n)
+            if s in switch_hop and h >= switch_hop[s]:   # one draw per morphing stream and hop, stream order
+                r = np.float32(next(draws) * total)
+                idx = int(order[0])
+                for i in range(8):
+                    r = np.float32(r - odds[i])
+                    if r < 0:
+                        idx = int(order[i])
+                        break
+                picks.append(idx)
+                streams[s].a.SetCodebook(streams[s].pc, bv.fptr(t.codebooks[idx]))
+        for s in range(B):
+            ref[h, s] = streams[s].hop(audio[s, h * 160:(h + 1) * 160])
+    for st in streams:
+        st.close()
+    mo.close()
+
+    # ---- product side
+    m = bv.Models(product, model_dir8)
+    batch = bv.Batch(m, B)
+    a, hnd = batch.a, batch.h
+    w = np.array(weights, np.float32)
+    assert a.BeatriceBatch_MorphSpeaker(hnd, n, bv.fptr(w), n, seed) == 0
+    for s in range(B):
+        a.BeatriceBatch_SetTargetSpeaker(hnd, s, s)
+        a.BeatriceBatch_SetVQNumNeighbors(hnd, s, vq_k)
+    a.BeatriceBatch_FlushSpeaker(hnd, -1)
+    got = np.zeros_like(ref)
+    for h in range(hops):
+        for s in range(B):
+            if switch_hop.get(s) == h:
+                a.BeatriceBatch_SetTargetSpeaker(hnd, s, n)
+        got[h] = batch.convert(audio[:, h * 160:(h + 1) * 160])
+    batch.close()
+    m.close()
+    dev = float(np.abs(ref - got).max())
+    print("morph end to end k=%d: max-abs %g; codebook draws %s" % (vq_k, dev, picks[:10]))
+    assert len(set(picks)) > 1 and set(picks) <= {0, 2, 4, 5}
+    assert np.abs(got).max() > 0.05
+    assert dev <= 1e-4
