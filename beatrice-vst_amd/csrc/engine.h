@@ -177,7 +177,7 @@ void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t stream, 
 
 // content encoder + pitch estimator (+ the waveform generator's conditioning mix) with the pitch
 // estimator's launches paired into the content encoder's (pair.hip.h).  Returns false when the
-// configuration is outside the paired regime (H != 1 or too many rows): nothing was enqueued, the
+// configuration is outside the paired regime (more than 2048 rows in the paired layers): nothing was enqueued, the
 // caller runs phone_forward / pitch_forward / wave_forward(cond_done = false) instead.
 void phone_vq(const PhoneWeights& w, const PhoneState& s, hipStream_t stream);
 bool front_forward(const PhoneWeights& pw, const PhoneState& ps, const PitchWeights& qw, const PitchState& qs,
