@@ -329,7 +329,7 @@ BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* pho
                                          int n_streams, int max_speakers, int hops_per_step) {
   auto* b = new BeatriceBatch();
   if (!phone || !pitch || !wave || !embed || !phone->loaded || !pitch->loaded || !wave->loaded || !embed->loaded ||
-      n_streams < 1 || max_speakers < 1 || (hops_per_step != 1 && hops_per_step != 2 && hops_per_step != 4))
+      n_streams < 1 || max_speakers < 1 || (hops_per_step != 1 && hops_per_step != 2 && hops_per_step != 4 && hops_per_step != 8))
     return b;  // unhealthy object; every call on it fails with -2
   b->phone_m = phone; b->pitch_m = pitch; b->wave_m = wave; b->embed_m = embed;
   b->B = n_streams; b->max_speakers = max_speakers; b->H = hops_per_step;

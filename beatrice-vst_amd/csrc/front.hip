@@ -90,7 +90,8 @@ bool front_forward(const PhoneWeights& pw, const PhoneState& ps, const PitchWeig
   switch (ps.H) {
     case 1: front_forward_h<1>(pw, ps, qw, qs, ww, ws, st); break;
     case 2: front_forward_h<2>(pw, ps, qw, qs, ww, ws, st); break;
-    default: front_forward_h<4>(pw, ps, qw, qs, ww, ws, st); break;
+    case 4: front_forward_h<4>(pw, ps, qw, qs, ww, ws, st); break;
+    default: front_forward_h<8>(pw, ps, qw, qs, ww, ws, st); break;
   }
   return true;
 }

@@ -93,7 +93,8 @@ void phone_forward(const PhoneWeights& w, const PhoneState& s, hipStream_t st) {
   switch (s.H) {
     case 1: phone_forward_h<1>(w, s, st); break;
     case 2: phone_forward_h<2>(w, s, st); break;
-    default: phone_forward_h<4>(w, s, st); break;
+    case 4: phone_forward_h<4>(w, s, st); break;
+    default: phone_forward_h<8>(w, s, st); break;
   }
 }
 

@@ -82,7 +82,8 @@ void pitch_forward(const PitchWeights& w, const PitchState& s, hipStream_t st) {
   switch (s.H) {
     case 1: pitch_forward_h<1>(w, s, st); break;
     case 2: pitch_forward_h<2>(w, s, st); break;
-    default: pitch_forward_h<4>(w, s, st); break;
+    case 4: pitch_forward_h<4>(w, s, st); break;
+    default: pitch_forward_h<8>(w, s, st); break;
   }
 }
 

@@ -154,7 +154,8 @@ void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t st, bool
   switch (s.H) {
     case 1: wave_forward_h<1>(w, s, st, cond_done); break;
     case 2: wave_forward_h<2>(w, s, st, cond_done); break;
-    default: wave_forward_h<4>(w, s, st, cond_done); break;
+    case 4: wave_forward_h<4>(w, s, st, cond_done); break;
+    default: wave_forward_h<8>(w, s, st, cond_done); break;
   }
 }
 

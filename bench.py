@@ -142,10 +142,10 @@ def saturation(bv, models, product, streams=8192, steps=30):
 
 def block_mode(bv, models, product, streams, steps=200):
     """Bulk / utterance conversion (not the headline, which is one 10 ms hop per step): the same chain with
-    H = 2 and 4 consecutive hops per step (BeatriceBatch_CreateBlock), bit-identical results, launch cost
+    H = 2, 4 and 8 consecutive hops per step (BeatriceBatch_CreateBlock), bit-identical results, launch cost
     shared by H hops.  Same resident-input timing as the headline."""
     out = {"streams": streams}
-    for H in (2, 4):
+    for H in (2, 4, 8):
         batch = bv.Batch(models, streams, hops_per_step=H)
         product.BeatriceBatch_FlushSpeaker(batch.h, -1)
         batch.time_steps(20)

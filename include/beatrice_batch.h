@@ -47,7 +47,7 @@ Beatrice_ErrorCode BeatriceHip_LoadEmbeddingSetterFromMemory(Beatrice20rc0_Embed
 BeatriceBatch* BeatriceBatch_Create(const Beatrice20rc0_PhoneExtractor* phone, const Beatrice20rc0_PitchEstimator* pitch,
                                     const Beatrice20rc0_WaveformGenerator* wave, const Beatrice20rc0_EmbeddingSetter* embed,
                                     int n_streams, int max_speakers);
-/* Block mode for offline / utterance conversion: every step converts `hops_per_step` (1, 2 or 4)
+/* Block mode for offline / utterance conversion: every step converts `hops_per_step` (1, 2, 4 or 8)
  * consecutive hops of every stream, so the per-launch cost of the kernel chain is shared by H hops.
  * Results are bit-identical to H single-hop steps (the recurrent layers still advance hop by hop
  * inside the step; a pending speaker switch still installs one K/V block per hop).  Buffers become

@@ -164,14 +164,14 @@ def test_pitch_range_and_correction_settings(bv, oracle, product, model_dir):
     assert float(np.abs(got - ref).max()) <= TOL
 
 
-@pytest.mark.parametrize("B,H,graph", [(3, 2, 1), (21, 4, 1), (5, 4, 0)])
+@pytest.mark.parametrize("B,H,graph", [(3, 2, 1), (21, 4, 1), (5, 4, 0), (9, 8, 1)])
 def test_block_mode_matches_single_hops(bv, oracle, product, model_dir, B, H, graph):
     """BeatriceBatch_CreateBlock: H hops per step == H single-hop steps of independent oracle streams,
     including a speaker switch whose four K/V blocks install on consecutive hops INSIDE a step."""
     hops = 32
     audio = np.stack([bv.synth_audio(160 * hops, seed=300 + s) for s in range(B)])
 
-    def script(h, s, st, batch):  # settings change between steps only: every event hop is a multiple of 4
+    def script(h, s, st, batch):  # settings change between steps only: every event hop is a multiple of 8
         if h == 0:
             if st is not None:
                 st.a.SetVQNumNeighbors(st.pc, (s + 1) % 3)
@@ -181,13 +181,13 @@ def test_block_mode_matches_single_hops(bv, oracle, product, model_dir, B, H, gr
                 a.BeatriceBatch_SetVQNumNeighbors(hnd, s, (s + 1) % 3)
                 a.BeatriceBatch_SetPitchShift(hnd, s, float(s % 3) - 1.0)
                 a.BeatriceBatch_SetPitchCorrection(hnd, s, 0.5 if s % 2 else 0.0)
-        if h == 8 + 4 * (s % 3):
+        if h == 8 + 8 * (s % 3):
             spk = 1 + (s % 2)
             if st is not None:
                 st.set_target_speaker(spk)
             else:
                 batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, s, spk)
-        if h == 20 and s % 2 == 1:
+        if h == 16 and s % 2 == 1:
             if st is not None:
                 st.set_formant_index(2)
             else:
