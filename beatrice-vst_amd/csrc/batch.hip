@@ -14,6 +14,7 @@
 #include <numeric>
 #include <random>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "abi_objects.h"
@@ -46,25 +47,52 @@ struct MorphSlot {
   std::mt19937 rng;
 };
 
+// Pinned host copy of a small per-stream device array.  Double-buffered: push() sends the buffer the
+// host has been editing and flips to the other one (brought up to date first), so the host never writes
+// into memory an asynchronous copy may still be reading and no step has to wait for the previous one
+// just because a setting changed.  The flip only blocks if the copy issued TWO pushes ago is unfinished.
 template <class T>
-struct Mirror {  // pinned host copy of a small per-stream device array
-  T* h = nullptr;
+struct Mirror {
+  T* h = nullptr;  // the buffer being edited
   T* d = nullptr;
   size_t n = 0;
   bool dirty = true;
+  T* buf[2] = {nullptr, nullptr};
+  hipEvent_t sent[2] = {nullptr, nullptr};
+  bool pending[2] = {false, false};
+  int cur = 0;
   bool alloc_host(size_t n_) {
     n = n_;
-    BHIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h), sizeof(T) * n, hipHostMallocDefault));
-    std::memset(h, 0, sizeof(T) * n);
+    for (int i = 0; i < 2; ++i) {
+      BHIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&buf[i]), sizeof(T) * n, hipHostMallocDefault));
+      std::memset(buf[i], 0, sizeof(T) * n);
+      BHIP_TRY(hipEventCreateWithFlags(&sent[i], hipEventDisableTiming));
+    }
+    h = buf[0];
     return true;
   }
   bool push(hipStream_t s) {
     if (!dirty) return true;
-    BHIP_TRY(hipMemcpyAsync(d, h, sizeof(T) * n, hipMemcpyHostToDevice, s));
+    BHIP_TRY(hipMemcpyAsync(d, buf[cur], sizeof(T) * n, hipMemcpyHostToDevice, s));
+    BHIP_TRY(hipEventRecord(sent[cur], s));
+    pending[cur] = true;
+    const int nxt = cur ^ 1;
+    if (pending[nxt]) { BHIP_TRY(hipEventSynchronize(sent[nxt])); pending[nxt] = false; }
+    std::memcpy(buf[nxt], buf[cur], sizeof(T) * n);
+    cur = nxt;
+    h = buf[cur];
     dirty = false;
     return true;
   }
-  void release() { if (h) (void)hipHostFree(h); h = nullptr; }
+  void release() {
+    for (int i = 0; i < 2; ++i) {
+      if (pending[i]) (void)hipEventSynchronize(sent[i]);
+      if (buf[i]) (void)hipHostFree(buf[i]);
+      if (sent[i]) (void)hipEventDestroy(sent[i]);
+      buf[i] = nullptr; sent[i] = nullptr; pending[i] = false;
+    }
+    h = nullptr;
+  }
 };
 
 }  // namespace
@@ -89,15 +117,19 @@ struct BeatriceBatch {
   std::vector<StreamCfg> cfg;
   std::vector<MorphSlot> morph;  // [max_speakers]
   int n_morph_slots = 0;
-  Mirror<const float*> m_cbT, m_cnorm;
-  Mirror<int> m_vqk, m_min_q, m_max_q, m_add_idx, m_frm_idx;
-  Mirror<PitchParams> m_params;
-  Mirror<int> m_perm[B_NBLOCKS], m_tile_slot[B_NBLOCKS];
+  // every per-stream setting array the kernels read lives in ONE device block with one pinned mirror, so a
+  // step after any change costs a single small host-to-device copy (a dozen separate copies cost ~50 us of
+  // stream time per step with 64 rotating speakers)
+  Mirror<unsigned char> settings;
+  struct { size_t cbT, cnorm, vqk, min_q, max_q, add_idx, frm_idx, params, perm[B_NBLOCKS], tile_slot[B_NBLOCKS], bytes; } off{};
+  template <class T> T* host_view(size_t o) { return reinterpret_cast<T*>(settings.h + o); }
+  template <class T> T* dev_view(size_t o) { return reinterpret_cast<T*>(settings.d + o); }
+  void* module_owned[8 + 2 * B_NBLOCKS] = {};  // the modules' own (now unused) setting arrays, handed back before destroy()
   int pending_kv = 0;  // streams with kv_set_count < 4
   std::vector<int> row_slot[B_NBLOCKS];  // [B*H] K/V slot of attention row (stream, hop in step)
   bool kv_transient = false;  // rows of the last step's early hops still hold pre-switch slots (H > 1)
   bool vq_dirty = true;   // a VQ setting changed since the k-NN launch was last (de)selected
-  bool inflight = false;  // an un-synchronised device-variant step may still read the pinned mirrors
+  bool inflight = false;  // device-variant steps have been enqueued since the last synchronisation
   // staging for the host variant
   float *h_in = nullptr, *h_out = nullptr;
   // graph
@@ -113,8 +145,8 @@ struct BeatriceBatch {
 
 namespace {
 
-// Pinned mirrors are read by asynchronous copies; before the host edits them again the previous
-// device-variant step must have consumed them.
+// Waits for the steps enqueued so far (needed before the graph or a speaker table they use is replaced;
+// the pinned setting mirrors are double-buffered and do not need it).
 void settle(BeatriceBatch* b) {
   if (b->inflight) { (void)hip_ok(hipStreamSynchronize(b->stream), "settle"); b->inflight = false; }
 }
@@ -122,8 +154,8 @@ void settle(BeatriceBatch* b) {
 void rebuild_tiles(BeatriceBatch* b, int blk) {
   // attention rows (stream, hop in step) grouped by K/V slot, ascending slot then ascending row, 16 per tile
   const int nt = b->wave.n_tiles_max, rows = b->B * b->H;
-  int* perm = b->m_perm[blk].h;
-  int* slot = b->m_tile_slot[blk].h;
+  int* perm = b->host_view<int>(b->off.perm[blk]);
+  int* slot = b->host_view<int>(b->off.tile_slot[blk]);
   const std::vector<int>& rs = b->row_slot[blk];
   std::fill(perm, perm + (size_t)nt * 16, -1);
   std::fill(slot, slot + nt, -1);
@@ -136,8 +168,7 @@ void rebuild_tiles(BeatriceBatch* b, int blk) {
     if (sl != cur || fill == 16) { ++tile; fill = 0; cur = sl; slot[tile] = sl; }
     perm[tile * 16 + fill++] = r;
   }
-  b->m_perm[blk].dirty = true;
-  b->m_tile_slot[blk].dirty = true;
+  b->settings.dirty = true;
 }
 
 void fill_row_slots(BeatriceBatch* b, int s) {
@@ -147,23 +178,21 @@ void fill_row_slots(BeatriceBatch* b, int s) {
 
 void sync_stream_arrays(BeatriceBatch* b, int s) {
   const StreamCfg& c = b->cfg[s];
-  b->m_cbT.h[s] = b->d_cbT + (size_t)c.codebook_speaker * B_PHONE_CH * B_CODEBOOK;
-  b->m_cnorm.h[s] = b->d_cnorm + (size_t)c.codebook_speaker * B_CODEBOOK;
-  b->m_vqk.h[s] = c.vq_k;
-  b->m_min_q.h[s] = c.min_q;
-  b->m_max_q.h[s] = c.max_q;
-  b->m_add_idx.h[s] = c.additive_speaker;
-  b->m_frm_idx.h[s] = c.formant_index;
-  b->m_params.h[s] = c.pitch;
-  b->m_cbT.dirty = b->m_cnorm.dirty = b->m_vqk.dirty = b->m_min_q.dirty = b->m_max_q.dirty = true;
-  b->m_add_idx.dirty = b->m_frm_idx.dirty = b->m_params.dirty = true;
+  b->host_view<const float*>(b->off.cbT)[s] = b->d_cbT + (size_t)c.codebook_speaker * B_PHONE_CH * B_CODEBOOK;
+  b->host_view<const float*>(b->off.cnorm)[s] = b->d_cnorm + (size_t)c.codebook_speaker * B_CODEBOOK;
+  b->host_view<int>(b->off.vqk)[s] = c.vq_k;
+  b->host_view<int>(b->off.min_q)[s] = c.min_q;
+  b->host_view<int>(b->off.max_q)[s] = c.max_q;
+  b->host_view<int>(b->off.add_idx)[s] = c.additive_speaker;
+  b->host_view<int>(b->off.frm_idx)[s] = c.formant_index;
+  b->host_view<PitchParams>(b->off.params)[s] = c.pitch;
+  b->settings.dirty = true;
 }
 
 // One K/V block per stream per hop, as the reference host does before its three per-hop calls
 // (processor_core_2.cc:179-181, processor_core_2.h:161-169).
 void advance_kv(BeatriceBatch* b) {
   if (b->pending_kv == 0 && !b->kv_transient) return;
-  settle(b);
   bool dirty[B_NBLOCKS] = {false, false, false, false};
   bool advanced = false;
   const int H = b->H;
@@ -190,9 +219,7 @@ void advance_kv(BeatriceBatch* b) {
 
 bool push_settings(BeatriceBatch* b) {
   hipStream_t s = b->stream;
-  bool ok = b->m_cbT.push(s) && b->m_cnorm.push(s) && b->m_vqk.push(s) && b->m_min_q.push(s) && b->m_max_q.push(s) &&
-            b->m_add_idx.push(s) && b->m_frm_idx.push(s) && b->m_params.push(s);
-  for (int blk = 0; blk < B_NBLOCKS; ++blk) ok = ok && b->m_perm[blk].push(s) && b->m_tile_slot[blk].push(s);
+  const bool ok = b->settings.push(s);
   return ok;
 }
 
@@ -240,12 +267,10 @@ void update_vq_mode(BeatriceBatch* b) {
 // morph weights as odds (reference processor_core_2.cc:94-121: same draws, same order of operations)
 void draw_codebooks(BeatriceBatch* b) {
   if (b->n_morph_slots == 0) return;
-  bool any = false;
   for (int s = 0; s < b->B; ++s) {
     StreamCfg& c = b->cfg[s];
     MorphSlot& m = b->morph[c.target_speaker];
     if (!m.active) continue;
-    if (!any) { settle(b); any = true; }
     float sum = 0.0f;
     for (int i = 0; i < m.n_odds; ++i) sum += m.odds[i];
     int idx = m.order[0];
@@ -281,7 +306,6 @@ template <class F>
 int for_streams(BeatriceBatch* b, int stream, F f) {
   if (!b || !b->ok) return -2;
   if (stream < -1 || stream >= b->B) return -1;
-  settle(b);
   const int lo = stream < 0 ? 0 : stream, hi = stream < 0 ? b->B : stream + 1;
   for (int s = lo; s < hi; ++s) { f(b->cfg[s]); sync_stream_arrays(b, s); }
   return 0;
@@ -360,16 +384,33 @@ BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* pho
   ok = ok && hip_ok(hipMemset(b->d_cbT, 0, sizeof(float) * cbf), "cbT0") && hip_ok(hipMemset(b->d_cnorm, 0, sizeof(float) * S * B_CODEBOOK), "cn0");
   b->cfg.assign(B, StreamCfg());
   b->morph.assign(S, MorphSlot());
-  ok = ok && b->m_cbT.alloc_host(B) && b->m_cnorm.alloc_host(B) && b->m_vqk.alloc_host(B) && b->m_min_q.alloc_host(B) &&
-       b->m_max_q.alloc_host(B) && b->m_add_idx.alloc_host(B) && b->m_frm_idx.alloc_host(B) && b->m_params.alloc_host(B);
-  if (ok) {
-    b->m_cbT.d = b->phone.d_cbT; b->m_cnorm.d = b->phone.d_cnorm; b->m_vqk.d = b->phone.d_vqk;
-    b->m_min_q.d = b->pitch.d_min_q; b->m_max_q.d = b->pitch.d_max_q; b->m_params.d = b->pitch.d_params;
-    b->m_add_idx.d = b->wave.d_add_idx; b->m_frm_idx.d = b->wave.d_frm_idx;
-    for (int blk = 0; blk < B_NBLOCKS && ok; ++blk) {
-      ok = b->m_perm[blk].alloc_host((size_t)b->wave.n_tiles_max * 16) && b->m_tile_slot[blk].alloc_host(b->wave.n_tiles_max);
-      b->m_perm[blk].d = b->wave.d_perm[blk];
-      b->m_tile_slot[blk].d = b->wave.d_tile_slot[blk];
+  {  // layout of the settings block (256-byte aligned arrays)
+    size_t o = 0;
+    auto take = [&o](size_t bytes) { const size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
+    const size_t nt = ok ? (size_t)b->wave.n_tiles_max : 1;
+    b->off.cbT = take(sizeof(float*) * B); b->off.cnorm = take(sizeof(float*) * B); b->off.vqk = take(sizeof(int) * B);
+    b->off.min_q = take(sizeof(int) * B); b->off.max_q = take(sizeof(int) * B);
+    b->off.add_idx = take(sizeof(int) * B); b->off.frm_idx = take(sizeof(int) * B); b->off.params = take(sizeof(PitchParams) * B);
+    for (int blk = 0; blk < B_NBLOCKS; ++blk) { b->off.perm[blk] = take(sizeof(int) * nt * 16); b->off.tile_slot[blk] = take(sizeof(int) * nt); }
+    b->off.bytes = o;
+  }
+  ok = ok && b->settings.alloc_host(b->off.bytes) &&
+       hip_ok(hipMalloc(reinterpret_cast<void**>(&b->settings.d), b->off.bytes), "settings") &&
+       hip_ok(hipMemset(b->settings.d, 0, b->off.bytes), "settings0");
+  if (ok) {  // the kernels read the block instead of the modules' own arrays
+    void** keep = b->module_owned;
+    auto swap_in = [&keep](auto*& member, auto* view) { *keep++ = (void*)member; member = view; };
+    swap_in(b->phone.d_cbT, b->dev_view<const float*>(b->off.cbT));
+    swap_in(b->phone.d_cnorm, b->dev_view<const float*>(b->off.cnorm));
+    swap_in(b->phone.d_vqk, b->dev_view<int>(b->off.vqk));
+    swap_in(b->pitch.d_min_q, b->dev_view<int>(b->off.min_q));
+    swap_in(b->pitch.d_max_q, b->dev_view<int>(b->off.max_q));
+    swap_in(b->pitch.d_params, b->dev_view<PitchParams>(b->off.params));
+    swap_in(b->wave.d_add_idx, b->dev_view<int>(b->off.add_idx));
+    swap_in(b->wave.d_frm_idx, b->dev_view<int>(b->off.frm_idx));
+    for (int blk = 0; blk < B_NBLOCKS; ++blk) {
+      swap_in(b->wave.d_perm[blk], b->dev_view<int>(b->off.perm[blk]));
+      swap_in(b->wave.d_tile_slot[blk], b->dev_view<int>(b->off.tile_slot[blk]));
     }
   }
   ok = ok && hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_in), sizeof(float) * B * H * B_IN_HOP, hipHostMallocDefault), "h_in") &&
@@ -409,14 +450,21 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   if (!b) return;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   drop_graph(b);
+  if (b->module_owned[0]) {  // hand the modules their own arrays back so that destroy() frees what it allocated
+    void** keep = b->module_owned;
+    auto swap_out = [&keep](auto*& member) { member = static_cast<std::remove_reference_t<decltype(member)>>(*keep++); };
+    swap_out(b->phone.d_cbT); swap_out(b->phone.d_cnorm); swap_out(b->phone.d_vqk);
+    swap_out(b->pitch.d_min_q); swap_out(b->pitch.d_max_q); swap_out(b->pitch.d_params);
+    swap_out(b->wave.d_add_idx); swap_out(b->wave.d_frm_idx);
+    for (int blk = 0; blk < B_NBLOCKS; ++blk) { swap_out(b->wave.d_perm[blk]); swap_out(b->wave.d_tile_slot[blk]); }
+  }
   b->phone.destroy(); b->pitch.destroy(); b->wave.destroy();
   void* dev[] = {b->d_in, b->d_cb_raw, b->d_cbT, b->d_cnorm, b->d_add_raw, b->d_frm_raw, b->d_kv_raw,
                  b->d_w48, b->d_coef_down, b->d_coef_up, b->d_io48, b->d_hop_next};
   if (b->h_io48) (void)hipHostFree(b->h_io48);
   for (void* p : dev) if (p) (void)hipFree(p);
-  b->m_cbT.release(); b->m_cnorm.release(); b->m_vqk.release(); b->m_min_q.release(); b->m_max_q.release();
-  b->m_add_idx.release(); b->m_frm_idx.release(); b->m_params.release();
-  for (int blk = 0; blk < B_NBLOCKS; ++blk) { b->m_perm[blk].release(); b->m_tile_slot[blk].release(); }
+  b->settings.release();
+  if (b->settings.d) (void)hipFree(b->settings.d);
   if (b->h_in) (void)hipHostFree(b->h_in);
   if (b->h_out) (void)hipHostFree(b->h_out);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
