@@ -47,7 +47,15 @@ struct TailArgs {
   float* d_out;  // [B][H*240]
   const int* hop;
   int* hop_next_out;  // optional: workgroup 0 stores hop + 1 here (a counter no kernel of this step reads)
+#ifdef TAIL_TIMING
+  unsigned long long* stamps;  // tools/microbench/tail_timing.hip: [B][16] wall-clock stamps per phase
+#endif
 };
+#ifdef TAIL_TIMING
+#define TAIL_STAMP(i) do { if (tid == 0) a.stamps[b * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define TAIL_STAMP(i) do { } while (0)
+#endif
 
 namespace tail {
 constexpr int NTHR = 512, NWAVE = 8;
@@ -195,6 +203,7 @@ static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const T
   float* FW = BIAS + BIAS_FLOATS;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* st = a.state + (size_t)b * TAIL_STATE_FLOATS;
+  TAIL_STAMP(0);
 
   // biases, output-conv taps and the stream's state block: one round of global loads
   const int hop = *a.hop;
@@ -226,6 +235,7 @@ static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const T
     }
   }
   __syncthreads();
+  TAIL_STAMP(1);
   hist_in<64, 6>(R1, SI_ + TS_YB2, tid);
   // (R1's history rows are only read by res2b, after the next barrier)
 
@@ -235,6 +245,7 @@ static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const T
   hist_in<64, 1>(R2, SI_ + TS_YC2, tid);
   __syncthreads();
   hist_out<64, 6>(SO_ + TS_YB2, R1, 20, tid);
+  TAIL_STAMP(2);
 
   // ---- res2b (dil 3): R1 (H 6) -> R2 (H 1)
   fetch_b<96, 32, 80>(a.w[3], b_r3a, wave, lane);
@@ -242,6 +253,7 @@ static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const T
   hist_in<32, 2>(R0, SI_ + TS_YA3, tid);
   __syncthreads();
   hist_out<64, 1>(SO_ + TS_YC2, R2, 20, tid);
+  TAIL_STAMP(3);
 
   // ---- up3 (x4): R2 (H 1, 20 frames of 64) -> R0 (H 2, 80 frames of 32)
   fetch_b<96, 32, 80>(a.w[4], b_r3b, wave, lane);
@@ -249,6 +261,7 @@ static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const T
   hist_in<32, 6>(R1, SI_ + TS_YB3, tid);
   __syncthreads();
   hist_out<32, 2>(SO_ + TS_YA3, R0, 80, tid);
+  TAIL_STAMP(4);
 
   // ---- res3a: R0 (H 2) -> R1 (H 6)
   fetch_b<64, 48, 80>(a.w[5], b_u4, wave, lane);
@@ -256,6 +269,7 @@ static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const T
   hist_in<32, 1>(R2, SI_ + TS_YC3, tid);
   __syncthreads();
   hist_out<32, 6>(SO_ + TS_YB3, R1, 80, tid);
+  TAIL_STAMP(5);
 
   // ---- res3b (dil 3): R1 (H 6) -> R2 (H 1)
   fetch_b<48, 16, 240>(a.w[6], b_r4a, wave, lane);
@@ -263,6 +277,7 @@ static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const T
   hist_in<16, 2>(R0, SI_ + TS_YA4, tid);
   __syncthreads();
   hist_out<32, 1>(SO_ + TS_YC3, R2, 80, tid);
+  TAIL_STAMP(6);
 
   // ---- up4 (x3): R2 (H 1, 80 frames of 32) -> R0 (H 2, 240 frames of 16)
   fetch_b<48, 16, 240>(a.w[7], b_r4b, wave, lane);
@@ -270,17 +285,20 @@ static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const T
   hist_in<16, 6>(R1, SI_ + TS_YB4, tid);
   __syncthreads();
   hist_out<16, 2>(SO_ + TS_YA4, R0, 240, tid);
+  TAIL_STAMP(7);
 
   // ---- res4a: R0 (H 2) -> R1 (H 6)
   layer<16, 16, 3, 1, 240, 2, 6, 0>(R0, R1, b_r4a, BIAS + BO[6], wave, lane);
   hist_in<16, 6>(R2, SI_ + TS_YC4, tid);
   __syncthreads();
   hist_out<16, 6>(SO_ + TS_YB4, R1, 240, tid);
+  TAIL_STAMP(8);
 
   // ---- res4b (dil 3): R1 (H 6) -> R2 (H 6)
   layer<16, 16, 3, 3, 240, 6, 6, 0>(R1, R2, b_r4b, BIAS + BO[7], wave, lane);
   __syncthreads();
   hist_out<16, 6>(SO_ + TS_YC4, R2, 240, tid);
+  TAIL_STAMP(9);
 
   // ---- output conv: lrelu, Conv1d(16 -> 1, k7), tanh; one thread per sample, coalesced store
   if (tid < B_OUT_HOP) {
@@ -296,4 +314,5 @@ static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const T
   }  // hops of the step
   for (int e = tid; e < TAIL_STATE_FLOATS; e += NTHR) st[e] = SI_[e];
   if (a.hop_next_out != nullptr && b == 0 && tid == 0) *a.hop_next_out = hop_next(hop);
+  TAIL_STAMP(10);
 }

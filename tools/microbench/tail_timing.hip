@@ -13,7 +13,7 @@ int main() {
   TailArgs a{};
   a.in = Ring{ring, 64, 20, 2}; a.state = state; a.fin_w = w; a.fin_b = bias; a.d_out = out; a.hop = hop; a.stamps = st;
   for (int i = 0; i < 8; ++i) { a.w[i] = w + i * 20000; a.b[i] = bias; }
-  for (int it = 0; it < 5; ++it) hipLaunchKernelGGL(wave_tail_kernel, dim3(B), dim3(tail::NTHR), 0, 0, a);
+  for (int it = 0; it < 5; ++it) hipLaunchKernelGGL(wave_tail_kernel<1>, dim3(B), dim3(tail::NTHR), 0, 0, a);
   hipDeviceSynchronize();
   std::vector<unsigned long long> h(B * 16);
   hipMemcpy(h.data(), st, B * 16 * 8, hipMemcpyDeviceToHost);
