@@ -79,6 +79,20 @@ def pmc_traffic(kernel_name, streams):
     return None
 
 
+def pmc_mfma_busy(kernel_name, streams):
+    """SQ_VALU_MFMA_BUSY_CYCLES per launch of the dominant kernel (same committed PMC summary), or None."""
+    if streams != 256 or kernel_name not in PMC_SYMBOL:
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    for sym, rec in json.load(open(files[-1]))["kernels"].items():
+        if PMC_SYMBOL[kernel_name] in sym:
+            return rec.get("mfma_busy_cycles_per_launch")
+    return None
+
+
 def cpu_baseline(bv, model_dir, seconds):
     """Oracle through the same per-hop protocol: 1 stream on 1 core, then 1 stream per core."""
     oracle = bv.Abi(os.path.join(REPO, "oracle", "libbeatrice_oracle.so"))
@@ -369,6 +383,10 @@ def main():
                 ach = dom["bytes"] / (dom["mean_us"] * 1e-6) / 1e9
                 roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(ach / PEAK_HBM_GBS, 4)}
+            busy = pmc_mfma_busy(dom["name"], B)
+            if busy is not None:  # fraction of the chip's 1024 MFMA pipes kept busy over the launch (2.4 GHz)
+                roof["mfma_busy_cycles"] = busy
+                roof["mfma_pipe_busy_frac"] = round(busy / (dom["mean_us"] * 1e-6 * 2.4e9 * 1024), 4)
             roof.update({"traffic": pmc_traffic(dom["name"], B), "traffic_unit": "bytes per launch (PMC, profiles/)",
                          "algorithmic_bytes": int(dom["bytes"]), "algorithmic_flops": int(dom["flops"]), "kernel": dom["name"], "launches_per_hop": dom["launches"],
                          "mean_us_per_launch": round(dom["mean_us"], 2),

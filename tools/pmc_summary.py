@@ -26,6 +26,8 @@ def load(path):
 def main(root, out):
     f = load(os.path.join(root, "pmc_r1_FETCH_SIZE", "pmc_counter_collection.csv"))
     w = load(os.path.join(root, "pmc_r1_WRITE_SIZE", "pmc_counter_collection.csv"))
+    mfma_path = os.path.join(root, "pmc_r1_SQ_VALU_MFMA_BUSY_CYCLES", "pmc_counter_collection.csv")
+    mf = load(mfma_path) if os.path.exists(mfma_path) else {}
     res = {}
     for k, v in f.items():
         if k.startswith("__amd_rocclr"):
@@ -35,6 +37,8 @@ def main(root, out):
         write_kb = sum(wv) / len(wv)
         res[k] = {"launches": len(v), "fetch_size_kib_raw": round(fetch_kb, 1), "write_size_kib": round(write_kb, 1),
                   "hbm_bytes_per_launch": int(round((2.0 * fetch_kb + write_kb) * 1024))}
+        if k in mf:  # summed over the SIMDs that ran the kernel; one v_mfma_f32_16x16x4_f32 keeps a SIMD's pipe busy 32 cycles
+            res[k]["mfma_busy_cycles_per_launch"] = round(sum(mf[k]) / len(mf[k]), 1)
     json.dump({"note": "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; bench.py --no-extras --steps 20 --warmup 5, B=256",
                "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
     for k, r in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:12]:

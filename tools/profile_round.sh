@@ -2,7 +2,8 @@
 # Measurement recipe of one round (run on a GPU box from the repo root, e.g. through gpurun):
 #   tools/profile_round.sh r01_e
 # writes under gpurun_out/<tag>/: the bench line, the rocprofv3 kernel-trace/stats summary of the same
-# command, and two separate PMC passes (FETCH_SIZE, WRITE_SIZE) reduced to per-kernel means.  Copy what
+# command, and three separate PMC passes (FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES) reduced to
+# per-kernel means.  Copy what
 # is to be judged into profiles/.
 set -u
 TAG=${1:-round}
@@ -19,7 +20,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o k -- \
 STATS=$(find "$OUT/prof" -name 'k_kernel_stats.csv' | head -1)
 [ -n "$STATS" ] && cp "$STATS" "$OUT/kernel_stats_B256.csv"
 
-for C in FETCH_SIZE WRITE_SIZE; do
+for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- \
     python "$ROOT/bench.py" --no-extras --steps 20 --warmup 5 > /dev/null 2>&1
   CSV=$(find "$OUT/pmc_$C" -name 'pmc_counter_collection.csv' | head -1)
@@ -28,15 +29,15 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 python "$ROOT/tools/pmc_summary.py" "$OUT" "$OUT/pmc_traffic.json"
 # keep the merge-back small: raw traces stay on the box
-rm -rf "$OUT/prof" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE"
-for C in FETCH_SIZE WRITE_SIZE; do
+rm -rf "$OUT/prof" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES"
+for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   python - "$OUT/pmc_r1_$C/pmc_counter_collection.csv" "$C" <<'PY'
 import collections, csv, sys
 d = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
     d[r["Kernel_Name"]].append(float(r["Counter_Value"]))
 w = csv.writer(open(sys.argv[1].replace("pmc_counter_collection.csv", "per_kernel_mean.csv"), "w"))
-w.writerow(["kernel", "launches", "mean_%s_KiB" % sys.argv[2]])
+w.writerow(["kernel", "launches", "mean_%s%s" % (sys.argv[2], "_KiB" if sys.argv[2].endswith("SIZE") else "")])
 for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
     w.writerow([k, len(v), "%.2f" % (sum(v) / len(v))])
 PY
