@@ -157,15 +157,25 @@ def saturation(bv, models, product, streams=8192, steps=30):
 def block_mode(bv, models, product, streams, steps=200):
     """Bulk / utterance conversion (not the headline, which is one 10 ms hop per step): the same chain with
     H = 2, 4 and 8 consecutive hops per step (BeatriceBatch_CreateBlock), bit-identical results, launch cost
-    shared by H hops.  Same resident-input timing as the headline."""
+    shared by H hops.  Same resident-input timing as the headline; per-kernel roofline at the largest H."""
     out = {"streams": streams}
     for H in (2, 4, 8):
         batch = bv.Batch(models, streams, hops_per_step=H)
         product.BeatriceBatch_FlushSpeaker(batch.h, -1)
         batch.time_steps(20)
         ms = batch.time_steps(steps)
+        rec = {"frames_per_s": round(streams * H * steps / (ms * 1e-3), 1), "ms_per_step": round(ms / steps, 4)}
+        if H == 8:
+            rows = batch.profile_kernels(repeats=5)
+            flops = sum(r["flops"] * r["launches"] for r in rows)
+            dom = max(rows, key=lambda r: r["mean_us"] * r["launches"])
+            rec.update({"tflops_end_to_end": round(flops / (ms * 1e-3 / steps) / 1e12, 2),
+                        "mfma_frac_end_to_end": round(flops / (ms * 1e-3 / steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                        "dominant_kernel": dom["name"], "dominant_launches": dom["launches"],
+                        "dominant_us_per_launch": round(dom["mean_us"], 2),
+                        "dominant_frac_of_mfma_peak": round(dom["flops"] / (dom["mean_us"] * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)})
         batch.close()
-        out["H%d" % H] = {"frames_per_s": round(streams * H * steps / (ms * 1e-3), 1), "ms_per_step": round(ms / steps, 4)}
+        out["H%d" % H] = rec
     return out
 
 
