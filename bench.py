@@ -223,6 +223,25 @@ def morph_timing(bv, product, n_real=8):
     return out
 
 
+def host_buffer_rate(bv, models, product, streams, steps=200):
+    """The boundary's host-buffer variant (BeatriceBatch_ConvertFrames: pageable caller buffers -> pinned staging ->
+    PCIe -> chain -> PCIe -> caller buffer, synchronous per step).  PCIe-inclusive; never the headline `value`."""
+    batch = bv.Batch(models, streams)
+    product.BeatriceBatch_FlushSpeaker(batch.h, -1)
+    x = np.stack([bv.synth_audio(160 * 8, seed=s) for s in range(streams)]).reshape(streams, 8, 160)
+    xs = [np.ascontiguousarray(x[:, i]) for i in range(8)]
+    out = np.zeros((streams, 240), np.float32)
+    for i in range(20):
+        product.BeatriceBatch_ConvertFrames(batch.h, bv.fptr(xs[i % 8]), bv.fptr(out))
+    t0 = time.perf_counter()
+    for i in range(steps):
+        product.BeatriceBatch_ConvertFrames(batch.h, bv.fptr(xs[i % 8]), bv.fptr(out))
+    dt = time.perf_counter() - t0
+    batch.close()
+    return {"frames_per_s": round(streams * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4),
+            "bytes_over_pcie_per_step": streams * (160 + 240) * 4}
+
+
 def latency_b1(bv, product, model_dir, hops=400):
     """BASELINE.json configs[1]: 1 stream, 1 speaker, hop-synchronous 1-stream C-ABI."""
     m = bv.Models(product, model_dir)
@@ -414,6 +433,7 @@ def main():
                 res["saturation"] = saturation(bv, m, product)
                 res["block_mode"] = block_mode(bv, m, product, B)
                 res["morph"] = morph_timing(bv, product)
+                res["host_buffer_variant"] = host_buffer_rate(bv, m, product, B)
                 res["latency_b1"] = latency_b1(bv, product, model_dir)
                 res["cpu_baseline"] = cpu_baseline(bv, model_dir, a.cpu_seconds)
         print(json.dumps(res))
