@@ -281,6 +281,7 @@ _BATCH = {
     "BeatriceBatch_ConvertBlocks48k": (C.c_int, [_vp, _f32p, _f32p, C.c_int]),
     "BeatriceBatch_ConvertBlocks48kDevice": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "BeatriceBatch_Synchronize": (C.c_int, [_vp]),
+    "BeatriceBatch_BindResidentIO": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "BeatriceBatch_SetStream": (C.c_int, [_vp, _vp]),
     "BeatriceBatch_GetStream": (_vp, [_vp]),
     "BeatriceBatch_EnableGraph": (C.c_int, [_vp, C.c_int]),

@@ -137,7 +137,9 @@ struct BeatriceBatch {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  int* d_hop_next = nullptr;  // step counter, double-buffered: first kernels read it, the last one writes it
+  int* d_hop_next = nullptr;  // {step counter, resident-I/O slot}, double-buffered: first kernels read it, the last one writes it
+  float* own_d_out = nullptr; // the waveform module's output buffer while a resident output buffer is bound
+  int io_slots = 0;           // > 0: resident I/O bound (BeatriceBatch_BindResidentIO)
   // 48 kHz device wrapper (configs[4])
   Wrap48State* d_w48 = nullptr;
   float *d_coef_down = nullptr, *d_coef_up = nullptr, *d_io48 = nullptr, *h_io48 = nullptr;  // io: in [B][2][480] | out [B][2][480]
@@ -289,6 +291,7 @@ void draw_codebooks(BeatriceBatch* b) {
 }
 
 bool step_device(BeatriceBatch* b, const float* d_in, float* d_out) {
+  if (b->io_slots > 0 && (d_in || d_out)) return false;  // resident I/O is bound: the step reads and writes its slots
   advance_kv(b);
   draw_codebooks(b);
   if (b->vq_dirty) { update_vq_mode(b); b->vq_dirty = false; }
@@ -368,8 +371,8 @@ BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* pho
   // spent on incrementing it: the step's first kernels (phone.f1, pitch.fft) read d_hop_next, phone.f1
   // publishes the value to phone.d_hop for every later kernel, the last kernel (wave.tail) stores
   // value + 1 back to d_hop_next
-  ok = ok && hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_hop_next), sizeof(int)), "hop_next") &&
-       hip_ok(hipMemset(b->d_hop_next, 0, sizeof(int)), "hop_next0");
+  ok = ok && hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_hop_next), 2 * sizeof(int)), "hop_next") &&
+       hip_ok(hipMemset(b->d_hop_next, 0, 2 * sizeof(int)), "hop_next0");
   b->pitch.hop = b->phone.d_hop; b->wave.hop = b->phone.d_hop;
   b->phone.hop_in = b->d_hop_next; b->pitch.hop_in = b->d_hop_next;
   b->phone.hop_publish = b->phone.d_hop; b->wave.hop_next_out = b->d_hop_next;
@@ -450,6 +453,7 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   if (!b) return;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   drop_graph(b);
+  if (b->own_d_out) { b->wave.d_out = b->own_d_out; b->own_d_out = nullptr; }
   if (b->module_owned[0]) {  // hand the modules their own arrays back so that destroy() frees what it allocated
     void** keep = b->module_owned;
     auto swap_out = [&keep](auto*& member) { member = static_cast<std::remove_reference_t<decltype(member)>>(*keep++); };
@@ -666,8 +670,37 @@ int BeatriceBatch_ConvertFramesDevice(BeatriceBatch* b, const float* d_in, float
   if (!b || !b->ok) return -2;
   return step_device(b, d_in, d_out) ? 0 : -2;
 }
+// Resident I/O: the caller keeps n_slots steps of input and output on the device,
+//   d_in [n_slots][B][H*160], d_out [n_slots][B][H*240];
+// step k (BeatriceBatch_ConvertFramesDevice(b, NULL, NULL)) reads slot k mod n_slots and writes the same
+// slot of d_out, with no copy: the slot index lives next to the step counter in device memory and is
+// advanced by the last kernel, so the captured graph stays valid.  NULL pointers unbind.
+int BeatriceBatch_BindResidentIO(BeatriceBatch* b, const float* d_in, float* d_out, int n_slots) {
+  if (!b || !b->ok) return -2;
+  const bool bind = d_in != nullptr || d_out != nullptr;
+  if (bind && (!d_in || !d_out || n_slots < 1)) return -1;
+  settle(b);
+  if (!hip_ok(hipStreamSynchronize(b->stream), "sync")) return -2;
+  drop_graph(b);  // kernel arguments change
+  if (b->own_d_out) { b->wave.d_out = b->own_d_out; b->own_d_out = nullptr; }
+  b->phone.d_in = b->pitch.d_in = b->d_in;
+  b->phone.io_stride = b->pitch.io_stride = b->wave.io_stride = 0;
+  b->wave.io_slots = b->io_slots = 0;
+  if (bind) {
+    b->own_d_out = b->wave.d_out;
+    b->wave.d_out = d_out;
+    b->phone.d_in = b->pitch.d_in = const_cast<float*>(d_in);
+    b->phone.io_stride = b->pitch.io_stride = (size_t)b->B * b->H * B_IN_HOP;
+    b->wave.io_stride = (size_t)b->B * b->H * B_OUT_HOP;
+    b->wave.io_slots = b->io_slots = n_slots;
+  }
+  const int zero = 0;  // the next step starts at slot 0
+  return hip_ok(hipMemcpy(b->d_hop_next + 1, &zero, sizeof(int), hipMemcpyHostToDevice), "slot0") ? 0 : -2;
+}
+
 int BeatriceBatch_ConvertFrames(BeatriceBatch* b, const float* in, float* out) {
   if (!b || !b->ok) { if (b && out) std::memset(out, 0, sizeof(float) * b->B * b->H * B_OUT_HOP); return -2; }
+  if (b->io_slots > 0) return -1;  // resident I/O is bound
   const size_t n_in = (size_t)b->B * b->H * B_IN_HOP, n_out = (size_t)b->B * b->H * B_OUT_HOP;
   std::memcpy(b->h_in, in, sizeof(float) * n_in);
   bool ok = hip_ok(hipMemcpyAsync(b->d_in, b->h_in, sizeof(float) * n_in, hipMemcpyHostToDevice, b->stream), "in");
@@ -690,12 +723,12 @@ static bool step_48k(BeatriceBatch* b, const float* d_in48, float* d_out48, int 
 }
 int BeatriceBatch_ConvertBlocks48kDevice(BeatriceBatch* b, const float* d_in, float* d_out, int channels) {
   if (!b || !b->ok) return -2;
-  if (channels < 1 || channels > 2 || !d_in || !d_out || b->H != 1) return -1;  // the wrapper is per 10 ms block
+  if (channels < 1 || channels > 2 || !d_in || !d_out || b->H != 1 || b->io_slots > 0) return -1;  // the wrapper is per 10 ms block
   return step_48k(b, d_in, d_out, channels) ? 0 : -2;
 }
 int BeatriceBatch_ConvertBlocks48k(BeatriceBatch* b, const float* in, float* out, int channels) {
   if (!b || !b->ok) return -2;
-  if (channels < 1 || channels > 2 || !in || !out || b->H != 1) return -1;
+  if (channels < 1 || channels > 2 || !in || !out || b->H != 1 || b->io_slots > 0) return -1;
   const size_t n = (size_t)b->B * channels * 480;
   float* h_in = b->h_io48;
   float* h_out = b->h_io48 + (size_t)b->B * 2 * 480;

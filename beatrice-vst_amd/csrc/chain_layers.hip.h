@@ -26,20 +26,20 @@ struct PitchLayers {
 };
 
 static inline F1Args f1_args(const PhoneWeights& w, const PhoneState& s) {
-  return F1Args{s.d_in, s.audio, s.f[0], w.f1_w, w.f1_b, s.hop_in, s.hop_publish, s.H};
+  return F1Args{s.d_in, s.audio, s.f[0], w.f1_w, w.f1_b, s.hop_in, s.hop_publish, s.H, s.io_stride};
 }
 static inline LaunchInfo f1_info(const PhoneState& s) {
   return LaunchInfo{"phone.f1", 2.0 * s.B * s.H * 32 * 64 * 10, 4.0 * s.B * s.H * (160 + 32 * 64)};
 }
 static inline FftArgs fft_args(const PitchWeights& w, const PitchState& s) {
-  return FftArgs{s.d_in, s.audio, s.spec, w.window, w.twiddle, s.hop_in, s.H};
+  return FftArgs{s.d_in, s.audio, s.spec, w.window, w.twiddle, s.hop_in, s.H, s.io_stride};
 }
 static inline LaunchInfo fft_info(const PitchState& s) {
   return LaunchInfo{"pitch.fft", s.B * s.H * (10.0 * 512 * 10 + 1024 * 2 + 512 * 30), 4.0 * s.B * s.H * (1024 + 160 + 512)};
 }
 static inline PitchHeadArgs head_args(const PitchWeights& w, const PitchState& s) {
   return PitchHeadArgs{s.H, s.logits.base, s.h, s.d_in, w.voi_w, w.voi_b, s.d_min_q, s.d_max_q, s.d_prev_q,
-                       s.d_q_raw, s.d_q, s.d_feat, s.d_params, s.hop};
+                       s.d_q_raw, s.d_q, s.d_feat, s.d_params, s.hop, s.io_stride};
 }
 static inline LaunchInfo head_info(const PitchState& s) {
   return LaunchInfo{"pitch.head", 25.0 * s.B * s.H * 448, 4.0 * s.B * s.H * (448 + 160 + 128 + 8)};

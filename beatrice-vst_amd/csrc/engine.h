@@ -80,6 +80,7 @@ struct PhoneState {
   float* d_in = nullptr;     // [B][H*160]; owned unless shared
   bool owns_in = false;
   int* hop_mailbox = nullptr;  // owned d_in only: one int right behind the audio (counter sent with the input copy)
+  size_t io_stride = 0;        // batch, resident I/O: d_in holds several steps, this many floats apart (slot = hop[1])
   float* d_phone = nullptr;  // [B][H][128]
   const float** d_cbT = nullptr;    // [B] device pointers
   const float** d_cnorm = nullptr;  // [B]
@@ -112,6 +113,7 @@ struct PitchState {
   float* d_in = nullptr;
   bool owns_in = false;
   int* hop_mailbox = nullptr;  // owned d_in only: one int right behind the audio
+  size_t io_stride = 0;        // see PhoneState
   int *d_min_q = nullptr, *d_max_q = nullptr, *d_prev_q = nullptr;  // [B]
   int *d_q_raw = nullptr, *d_q = nullptr;                          // [B][H]
   float* d_feat = nullptr;             // [B][H][4]
@@ -169,6 +171,8 @@ struct WaveState {
   int* d_hop = nullptr;       // owned hop counter
   int* hop = nullptr;         // counter the kernels read (== d_hop unless shared by a batch)
   int* hop_next_out = nullptr;  // batch: the last kernel stores counter + 1 here (read by the next step's first kernels)
+  size_t io_stride = 0;         // batch, resident I/O: d_out holds io_slots steps, this many floats apart
+  int io_slots = 0;
   bool advance_hop = true;    // this module's forward ends with the counter increment
   bool create(int B, int H, int n_slots, int n_add, int n_frm, float* shared_phone, int* shared_q, float* shared_feat);
   void destroy();

@@ -36,19 +36,21 @@ struct F1Args {
   const float* d_in;   // [B][H*160]
   Ring audio, out;
   const float *w, *bias;
-  const int* hop;      // step counter this kernel reads
-  int* hop_publish;    // optional: workgroup (0,0) copies the counter here for the rest of the chain
+  const int* hop;      // step counter this kernel reads ([1] = resident-I/O slot, read only if io_stride != 0)
+  int* hop_publish;    // optional: workgroup (0,0) copies the counter (and the slot) here for the rest of the chain
   int H;
+  size_t io_stride;    // 0, or floats between the slots of a resident multi-step input buffer (batch.hip)
 };
 // grid (stream, hop-in-step).  Samples before the step come from the audio ring, the rest from d_in.
 __device__ __forceinline__ void phone_f1_body(const F1Args& a, const int b, const int hh) {
   __shared__ float x[5 + B_IN_HOP];
   __shared__ float ws[10 * 64];
   const int tid = threadIdx.x, hop = *a.hop, H = a.H;
-  if (a.hop_publish != nullptr && b == 0 && hh == 0 && tid == 0) *a.hop_publish = hop;
+  const int io = a.io_stride != 0 ? a.hop[1] : 0;
+  if (a.hop_publish != nullptr && b == 0 && hh == 0 && tid == 0) { a.hop_publish[0] = hop; a.hop_publish[1] = io; }
   const Ring& audio = a.audio;
   const Ring& out = a.out;
-  const float* __restrict__ d_in = a.d_in;
+  const float* __restrict__ d_in = a.d_in + (size_t)io * a.io_stride;
   const float* __restrict__ w = a.w;
   const float* __restrict__ bias = a.bias;
   const int pos = ring_pos(audio, hop);
@@ -152,6 +154,7 @@ struct FftArgs {
   const float *window, *twiddle;
   const int* hop;
   int H;
+  size_t io_stride;  // see F1Args
 };
 __device__ __forceinline__ void pitch_fft_body(const FftArgs& a, const int b, const int hh) {
   __shared__ float re[B_FFT_N], im[B_FFT_N];
@@ -159,7 +162,7 @@ __device__ __forceinline__ void pitch_fft_body(const FftArgs& a, const int b, co
   const int tid = threadIdx.x, hop = *a.hop, H = a.H;
   const Ring& audio = a.audio;
   const Ring& spec = a.spec;
-  const float* __restrict__ d_in = a.d_in;
+  const float* __restrict__ d_in = a.d_in + (a.io_stride != 0 ? (size_t)a.hop[1] * a.io_stride : 0);
   const float* __restrict__ window = a.window;
   const float* __restrict__ twiddle = a.twiddle;
   const int pos = ring_pos(audio, hop);
@@ -234,6 +237,7 @@ struct PitchHeadArgs {
   float* feat;          // [B][4]
   const PitchParams* params;
   const int* hop;
+  size_t io_stride;     // see F1Args (d_in is read for the frame energy)
 };
 
 __device__ inline double pitch_round_half_away(double v) { return v >= 0.0 ? floor(v + 0.5) : -floor(-v + 0.5); }
@@ -294,7 +298,7 @@ __device__ __forceinline__ void pitch_head_body(const PitchHeadArgs& a, const in
 #pragma unroll
     for (int i = 0; i < 7; ++i) s = s + bsp::exp(v[i] - mx);
     const float f0 = bsp::exp(lg[q] - mx) / bsp::wsum64(s);
-    const float* x = a.d_in + row * B_IN_HOP;
+    const float* x = a.d_in + (a.io_stride != 0 ? (size_t)a.hop[1] * a.io_stride : 0) + row * B_IN_HOP;
     float en = 0.0f;
     for (int i = l; i < B_IN_HOP; i += 64) en = bsp::fma(x[i], x[i], en);
     const float f1 = 0.1f * bsp::log(bsp::fma(bsp::wsum64(en), 1.0f / 160.0f, 1e-8f));

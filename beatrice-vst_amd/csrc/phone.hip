@@ -28,12 +28,12 @@ bool PhoneState::create(int B_, int H_, float* shared_in) {
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cbT), sizeof(float*) * B));
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cnorm), sizeof(float*) * B));
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_vqk), sizeof(int) * B));
-  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hop), sizeof(int)));
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hop), 2 * sizeof(int)));  // [0] step counter, [1] resident-I/O slot
   BHIP_TRY(hipMemset(d_phone, 0, sizeof(float) * B * H * B_PHONE_CH));
   BHIP_TRY(hipMemset(d_cbT, 0, sizeof(float*) * B));
   BHIP_TRY(hipMemset(d_cnorm, 0, sizeof(float*) * B));
   BHIP_TRY(hipMemset(d_vqk, 0, sizeof(int) * B));
-  BHIP_TRY(hipMemset(d_hop, 0, sizeof(int)));
+  BHIP_TRY(hipMemset(d_hop, 0, 2 * sizeof(int)));
   hop = d_hop; hop_in = d_hop;
   // hipMemset is asynchronous and runs on the NULL stream, which the (non-blocking) compute streams
   // do not wait for: make every initialisation above visible before the first kernel can start

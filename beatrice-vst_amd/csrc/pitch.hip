@@ -41,8 +41,8 @@ bool PitchState::create(int B_, int H_, float* shared_in, bool with_params) {
     BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_params), sizeof(PitchParams) * B));
     BHIP_TRY(hipMemcpy(d_params, pp.data(), sizeof(PitchParams) * B, hipMemcpyHostToDevice));
   }
-  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hop), sizeof(int)));
-  BHIP_TRY(hipMemset(d_hop, 0, sizeof(int)));
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hop), 2 * sizeof(int)));
+  BHIP_TRY(hipMemset(d_hop, 0, 2 * sizeof(int)));
   hop = d_hop; hop_in = d_hop;
   BHIP_TRY(hipDeviceSynchronize());  // NULL-stream memsets vs non-blocking compute streams
   return true;

@@ -59,8 +59,8 @@ bool WaveState::create(int B_, int H_, int n_slots_, int n_add_, int n_frm_, flo
     BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_tile_slot[blk]), sizeof(int) * slot.size()));
     BHIP_TRY(hipMemcpy(d_tile_slot[blk], slot.data(), sizeof(int) * slot.size(), hipMemcpyHostToDevice));
   }
-  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hop), sizeof(int)));
-  BHIP_TRY(hipMemset(d_hop, 0, sizeof(int)));
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hop), 2 * sizeof(int)));  // [0] step counter, [1] resident-I/O slot
+  BHIP_TRY(hipMemset(d_hop, 0, 2 * sizeof(int)));
   hop = d_hop;
   // hipMemset is asynchronous and runs on the NULL stream, which the (non-blocking) compute streams
   // do not wait for: make every initialisation above visible before the first kernel can start
@@ -140,7 +140,7 @@ static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t
   launch_auto<RES<128, 3, 5 * H>>("wave.res1b", conv_args(s.yb1, s.yc1, w.rb_w[0], w.rb_b[0], s.hop, B), st);
   launch_auto<UP<128, 64, 4, 5 * H>>("wave.up2", conv_args(s.yc1, s.ya2, w.up_w[1], w.up_b[1], s.hop, B), st);
   TailArgs ta{};
-  ta.in = s.ya2; ta.state = s.tail.base; ta.fin_w = w.fin_w; ta.fin_b = w.fin_b; ta.d_out = s.d_out; ta.hop = s.hop; ta.hop_next_out = s.hop_next_out;
+  ta.in = s.ya2; ta.state = s.tail.base; ta.fin_w = w.fin_w; ta.fin_b = w.fin_b; ta.d_out = s.d_out; ta.hop = s.hop; ta.hop_next_out = s.hop_next_out; ta.io_stride = s.io_stride; ta.io_slots = s.io_slots;
   ta.w[0] = w.ra_w[1]; ta.b[0] = w.ra_b[1]; ta.w[1] = w.rb_w[1]; ta.b[1] = w.rb_b[1];
   ta.w[2] = w.up_w[2]; ta.b[2] = w.up_b[2]; ta.w[3] = w.ra_w[2]; ta.b[3] = w.ra_b[2]; ta.w[4] = w.rb_w[2]; ta.b[4] = w.rb_b[2];
   ta.w[5] = w.up_w[3]; ta.b[5] = w.up_b[3]; ta.w[6] = w.ra_w[3]; ta.b[6] = w.ra_b[3]; ta.w[7] = w.rb_w[3]; ta.b[7] = w.rb_b[3];

@@ -47,6 +47,8 @@ struct TailArgs {
   float* d_out;  // [B][H*240]
   const int* hop;
   int* hop_next_out;  // optional: workgroup 0 stores hop + 1 here (a counter no kernel of this step reads)
+  size_t io_stride;   // 0, or floats between the slots of a resident multi-step output buffer (slot = hop[1])
+  int io_slots;       // number of slots; [1] of hop_next_out advances modulo this
 #ifdef TAIL_TIMING
   unsigned long long* stamps;  // tools/microbench/tail_timing.hip: [B][16] wall-clock stamps per phase
 #endif
@@ -207,6 +209,8 @@ static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const T
 
   // biases, output-conv taps and the stream's state block: one round of global loads
   const int hop = *a.hop;
+  const int io = a.io_stride != 0 ? a.hop[1] : 0;
+  float* __restrict__ d_out = a.d_out + (size_t)io * a.io_stride;
   for (int e = tid; e < TAIL_STATE_FLOATS; e += NTHR) SI_[e] = st[e];
   if (tid < BIAS_FLOATS) {
     int l = 0;
@@ -307,12 +311,15 @@ static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const T
     for (int j = 0; j < 7; ++j)
 #pragma unroll
       for (int c = 0; c < 16; ++c) acc = bsp::fma(bsp::lrelu(R2[(tid + j) * 18 + c]), FW[j * 16 + c], acc);
-    a.d_out[((size_t)b * H + hh) * B_OUT_HOP + tid] = bsp::tanh(acc + a.fin_b[0]);
+    d_out[((size_t)b * H + hh) * B_OUT_HOP + tid] = bsp::tanh(acc + a.fin_b[0]);
   }
   __syncthreads();
   { float* tmp = SI_; SI_ = SO_; SO_ = tmp; }  // this hop's histories are the next hop's state
   }  // hops of the step
   for (int e = tid; e < TAIL_STATE_FLOATS; e += NTHR) st[e] = SI_[e];
-  if (a.hop_next_out != nullptr && b == 0 && tid == 0) *a.hop_next_out = hop_next(hop);
+  if (a.hop_next_out != nullptr && b == 0 && tid == 0) {
+    a.hop_next_out[0] = hop_next(hop);
+    a.hop_next_out[1] = a.io_slots > 0 ? (io + 1 >= a.io_slots ? 0 : io + 1) : 0;
+  }
   TAIL_STAMP(10);
 }

@@ -272,6 +272,9 @@ def main():
                          "3 = 256 streams/GPU, 64 rotating speakers, VQ k=4; 4 = 64 streams/GPU, 48 kHz stereo, wrapper on the device")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--copy-io", action="store_true",
+                    help="device-to-device copy of each hop into / out of the library's own buffers instead of "
+                         "binding the resident audio buffers (BeatriceBatch_BindResidentIO)")
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / B=1 latency / kernel profile")
     a = ap.parse_args()
 
@@ -339,8 +342,12 @@ def main():
     audio = np.stack([bv.synth_audio(160 * n_cycle, seed=rank * 100000 + s) for s in range(B)])
     audio = np.ascontiguousarray(audio.reshape(B, n_cycle, 160).transpose(1, 0, 2))
     d_audio = torch.from_numpy(audio).cuda()
-    d_out = torch.empty((B, 240), dtype=torch.float32, device="cuda")
+    resident = a.config != 4 and not a.copy_io
+    d_out = torch.zeros((n_cycle if resident else 1, B, 240), dtype=torch.float32, device="cuda")
     base, hop_bytes = d_audio.data_ptr(), B * 160 * 4
+    if resident:  # the 64 resident hops are the slots: every step reads one and writes one, no copy
+        if product.BeatriceBatch_BindResidentIO(batch.h, d_audio.data_ptr(), d_out.data_ptr(), n_cycle):
+            raise SystemExit("BindResidentIO failed")
 
     if a.config == 4:  # 48 kHz stereo blocks, resident: [n_cycle][B][2][480]
         a48 = np.stack([np.stack([bv.synth_audio(480 * n_cycle, seed=rank * 100000 + 2 * s + c, sr=48000) for c in range(2)])
@@ -358,6 +365,8 @@ def main():
                     product.BeatriceBatch_SetTargetSpeaker(batch.h, s, current_speaker[s])
         if a.config == 4:
             rc = product.BeatriceBatch_ConvertBlocks48kDevice(batch.h, base48 + (i % n_cycle) * blk_bytes, d_out48.data_ptr(), 2)
+        elif resident:
+            rc = product.BeatriceBatch_ConvertFramesDevice(batch.h, None, None)
         else:
             rc = product.BeatriceBatch_ConvertFramesDevice(batch.h, base + (i % n_cycle) * hop_bytes, d_out.data_ptr())
         if rc:
@@ -392,6 +401,8 @@ def main():
                                     4: "BASELINE.json configs[4] per-GPU share: %d streams of 48 kHz stereo, downmix + resample "
                                        "wrapper on the device, 480-sample blocks" % B}[a.config],
                        "streams_per_gpu": B, "speakers": a.speakers, "hipgraph": not a.no_graph,
+                       "io": "resident device buffers, 64 hops per stream cycled, bound as I/O slots (no per-step copy)" if resident
+                             else "resident device buffers, one device-to-device copy in and out per step",
                        "parallelism": "streams sharded over %d GPU(s), no per-hop collective" % world},
             "x_realtime_per_stream": round(a.steps / elapsed / 100.0, 2), "output_rms": round(out_rms, 4),
         }

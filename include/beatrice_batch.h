@@ -106,6 +106,13 @@ int BeatriceBatch_ConvertFrames(BeatriceBatch* b, const float* in, float* out);
 int BeatriceBatch_ConvertFramesDevice(BeatriceBatch* b, const float* d_in, float* d_out);
 int BeatriceBatch_Synchronize(BeatriceBatch* b);
 
+/* Resident I/O (utterances or stream buffers that already live on the device): bind
+ *   d_in [n_slots][B][H*160] and d_out [n_slots][B][H*240];
+ * afterwards every BeatriceBatch_ConvertFramesDevice(b, NULL, NULL) converts the next slot (k mod n_slots) in
+ * place -- no per-step copy, same results.  While bound, the host-buffer and 48 kHz entry points return -1.
+ * NULL, NULL unbinds.  Re-binding restarts at slot 0. */
+int BeatriceBatch_BindResidentIO(BeatriceBatch* b, const float* d_in, float* d_out, int n_slots);
+
 /* 48 kHz host-rate blocks with the reference's wrapper ON THE DEVICE (BASELINE.json configs[4]):
  * per call one 10 ms block of every stream, planar float, `channels` = 1 or 2:
  *   in [B][channels][480] @48 kHz -> out [B][channels][480] @48 kHz.
