@@ -71,9 +71,18 @@ struct Mirror {
     h = buf[0];
     return true;
   }
+  // sends [off, off + len) of the edited buffer to dst (nullptr: d + off) for each part, then flips
+  bool push_parts(hipStream_t s, int n_parts, const size_t* off, const size_t* len, T* const* dst) {
+    for (int i = 0; i < n_parts; ++i)
+      BHIP_TRY(hipMemcpyAsync(dst[i] ? dst[i] : d + off[i], buf[cur] + off[i], sizeof(T) * len[i], hipMemcpyHostToDevice, s));
+    return flip(s);
+  }
   bool push(hipStream_t s) {
     if (!dirty) return true;
     BHIP_TRY(hipMemcpyAsync(d, buf[cur], sizeof(T) * n, hipMemcpyHostToDevice, s));
+    return flip(s);
+  }
+  bool flip(hipStream_t s) {
     BHIP_TRY(hipEventRecord(sent[cur], s));
     pending[cur] = true;
     const int nxt = cur ^ 1;
@@ -121,7 +130,11 @@ struct BeatriceBatch {
   // step after any change costs a single small host-to-device copy (a dozen separate copies cost ~50 us of
   // stream time per step with 64 rotating speakers)
   Mirror<unsigned char> settings;
-  struct { size_t cbT, cnorm, vqk, min_q, max_q, add_idx, frm_idx, params, perm[B_NBLOCKS], tile_slot[B_NBLOCKS], bytes; } off{};
+  // layout: [front part: arrays the front end reads][wave part: attention tile lists], and on the device the wave
+  // part twice -- the waveform generator of step t reads copy t & 1, so a change can be pushed for step t while the
+  // generator of step t-1 is still running (its copy is refreshed one step later)
+  struct { size_t cbT, cnorm, vqk, min_q, max_q, add_idx, frm_idx, params, perm[B_NBLOCKS], tile_slot[B_NBLOCKS], front_bytes, wave_bytes; } off{};
+  bool front_dirty = true, wave_dirty[2] = {true, true};
   template <class T> T* host_view(size_t o) { return reinterpret_cast<T*>(settings.h + o); }
   template <class T> T* dev_view(size_t o) { return reinterpret_cast<T*>(settings.d + o); }
   void* module_owned[8 + 2 * B_NBLOCKS] = {};  // the modules' own (now unused) setting arrays, handed back before destroy()
@@ -132,10 +145,22 @@ struct BeatriceBatch {
   bool inflight = false;  // device-variant steps have been enqueued since the last synchronisation
   // staging for the host variant
   float *h_in = nullptr, *h_out = nullptr;
-  // graph
+  // One step = front end (content encoder + pitch estimator + conditioning mix) then waveform generator.  The
+  // two halves are separate launches (graphs): with pipelining on they go to two HIP streams, so the front end
+  // of step t+1 overlaps the waveform generator of step t whenever the caller enqueues steps ahead of their
+  // completion (the halves of ONE step stay ordered by an event; outputs and timing of a step that is waited
+  // for before the next is enqueued do not change).  Off: both halves on `stream`, in order.
+  bool pipelined = false;
+  hipStream_t wave_stream_own = nullptr;
+  hipEvent_t ev_front = nullptr;            // front end of the current step enqueued/done
+  hipEvent_t ev_wave[2] = {nullptr, nullptr};  // waveform generator of step t done, at [t & 1]
+  long long steps_enqueued = 0;
+  int hop_host = 0;     // mirror of the device step counter (same increments, same wrap): its parity picks the slots
+  int last_parity = 0;  // parity of the last enqueued step
+  int* d_hop_wave = nullptr;  // int[2][2]: {counter, I/O slot} of the step the waveform generator works on, at [counter & 1]
   bool use_graph = true;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t graph_exec = nullptr;
+  hipGraph_t graph_front = nullptr, graph_wave[2] = {nullptr, nullptr};
+  hipGraphExec_t exec_front = nullptr, exec_wave[2] = {nullptr, nullptr};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int* d_hop_next = nullptr;  // {step counter, resident-I/O slot}, double-buffered: first kernels read it, the last one writes it
   float* own_d_out = nullptr; // the waveform module's output buffer while a resident output buffer is bound
@@ -149,8 +174,15 @@ namespace {
 
 // Waits for the steps enqueued so far (needed before the graph or a speaker table they use is replaced;
 // the pinned setting mirrors are double-buffered and do not need it).
+hipStream_t wave_stream(const BeatriceBatch* b) { return b->pipelined ? b->wave_stream_own : b->stream; }
+bool sync_all(BeatriceBatch* b) {
+  bool ok = hip_ok(hipStreamSynchronize(b->stream), "sync");
+  if (b->wave_stream_own) ok = hip_ok(hipStreamSynchronize(b->wave_stream_own), "sync wave") && ok;
+  b->inflight = false;
+  return ok;
+}
 void settle(BeatriceBatch* b) {
-  if (b->inflight) { (void)hip_ok(hipStreamSynchronize(b->stream), "settle"); b->inflight = false; }
+  if (b->inflight) (void)sync_all(b);
 }
 
 void rebuild_tiles(BeatriceBatch* b, int blk) {
@@ -158,6 +190,7 @@ void rebuild_tiles(BeatriceBatch* b, int blk) {
   const int nt = b->wave.n_tiles_max, rows = b->B * b->H;
   int* perm = b->host_view<int>(b->off.perm[blk]);
   int* slot = b->host_view<int>(b->off.tile_slot[blk]);
+  b->wave_dirty[0] = b->wave_dirty[1] = true;
   const std::vector<int>& rs = b->row_slot[blk];
   std::fill(perm, perm + (size_t)nt * 16, -1);
   std::fill(slot, slot + nt, -1);
@@ -170,7 +203,6 @@ void rebuild_tiles(BeatriceBatch* b, int blk) {
     if (sl != cur || fill == 16) { ++tile; fill = 0; cur = sl; slot[tile] = sl; }
     perm[tile * 16 + fill++] = r;
   }
-  b->settings.dirty = true;
 }
 
 void fill_row_slots(BeatriceBatch* b, int s) {
@@ -188,7 +220,7 @@ void sync_stream_arrays(BeatriceBatch* b, int s) {
   b->host_view<int>(b->off.add_idx)[s] = c.additive_speaker;
   b->host_view<int>(b->off.frm_idx)[s] = c.formant_index;
   b->host_view<PitchParams>(b->off.params)[s] = c.pitch;
-  b->settings.dirty = true;
+  b->front_dirty = true;
 }
 
 // One K/V block per stream per hop, as the reference host does before its three per-hop calls
@@ -219,42 +251,75 @@ void advance_kv(BeatriceBatch* b) {
   for (int blk = 0; blk < B_NBLOCKS; ++blk) if (dirty[blk]) rebuild_tiles(b, blk);
 }
 
-bool push_settings(BeatriceBatch* b) {
-  hipStream_t s = b->stream;
-  const bool ok = b->settings.push(s);
-  return ok;
+// what changed since the last step goes to the device: the front part as it is, the wave part into the copy the
+// waveform generator of THIS step (parity) will read
+bool push_settings(BeatriceBatch* b, int parity) {
+  size_t off[2], len[2];
+  unsigned char* dst[2];
+  int n = 0;
+  if (b->front_dirty) { off[n] = 0; len[n] = b->off.front_bytes; dst[n] = nullptr; ++n; }
+  if (b->wave_dirty[parity]) {
+    off[n] = b->off.front_bytes; len[n] = b->off.wave_bytes;
+    dst[n] = b->settings.d + b->off.front_bytes + (size_t)parity * b->off.wave_bytes; ++n;
+  }
+  if (n == 0) return true;
+  b->front_dirty = false;
+  b->wave_dirty[parity] = false;
+  return b->settings.push_parts(b->stream, n, off, len, dst);
 }
 
-// Latency-bound regime (one hop per step, a few hundred streams): the pitch estimator's launches are
-// paired into the content encoder's (front.hip).  Elsewhere the three modules run one after the other.
-// (Running them as parallel graph branches or on two HIP streams was measured and buys nothing on
-// ROCm 7.2 / MI355X, profiles/r01_notes.md.)
-void enqueue_chain(BeatriceBatch* b) {
+// Front end.  Latency-bound regime (a few hundred rows): the pitch estimator's launches are paired into the
+// content encoder's (front.hip); elsewhere the modules run one after the other.  (Running them as parallel
+// graph branches was measured and buys nothing on ROCm 7.2 / MI355X, profiles/r01_notes.md.)
+void enqueue_front(BeatriceBatch* b, hipStream_t st) {
   static const bool no_pairs = std::getenv("BEATRICE_HIP_NO_PAIRS") != nullptr;  // A/B switch for measurements
-  const bool paired = !no_pairs && front_forward(b->phone_m->w, b->phone, b->pitch_m->w, b->pitch, b->wave_m->w, b->wave, b->stream);
-  if (!paired) {
-    phone_forward(b->phone_m->w, b->phone, b->stream);
-    pitch_forward(b->pitch_m->w, b->pitch, b->stream);
+  if (!no_pairs && front_forward(b->phone_m->w, b->phone, b->pitch_m->w, b->pitch, b->wave_m->w, b->wave, st)) return;
+  phone_forward(b->phone_m->w, b->phone, st);
+  pitch_forward(b->pitch_m->w, b->pitch, st);
+  wave_cond(b->wave_m->w, b->wave, st);
+}
+void enqueue_wave(BeatriceBatch* b, int parity, hipStream_t st) {
+  b->wave.hop = b->d_hop_wave + 2 * parity;
+  for (int blk = 0; blk < B_NBLOCKS; ++blk) {  // this parity's copy of the attention tile lists
+    b->wave.d_perm[blk] = b->dev_view<int>(b->off.perm[blk] + (size_t)parity * b->off.wave_bytes);
+    b->wave.d_tile_slot[blk] = b->dev_view<int>(b->off.tile_slot[blk] + (size_t)parity * b->off.wave_bytes);
   }
-  wave_forward(b->wave_m->w, b->wave, b->stream, paired);
+  wave_forward(b->wave_m->w, b->wave, st, /*cond_done=*/true);
 }
 
 void drop_graph(BeatriceBatch* b) {
-  if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
-  if (b->graph) (void)hipGraphDestroy(b->graph);
-  b->graph_exec = nullptr;
-  b->graph = nullptr;
+  if (b->exec_front) (void)hipGraphExecDestroy(b->exec_front);
+  if (b->graph_front) (void)hipGraphDestroy(b->graph_front);
+  b->exec_front = nullptr; b->graph_front = nullptr;
+  for (int p = 0; p < 2; ++p) {
+    if (b->exec_wave[p]) (void)hipGraphExecDestroy(b->exec_wave[p]);
+    if (b->graph_wave[p]) (void)hipGraphDestroy(b->graph_wave[p]);
+    b->exec_wave[p] = nullptr; b->graph_wave[p] = nullptr;
+  }
 }
 
-bool run_chain(BeatriceBatch* b) {
-  if (!b->use_graph) { enqueue_chain(b); return hip_ok(hipGetLastError(), "chain launch"); }
-  if (!b->graph_exec) {
-    BHIP_TRY(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
-    enqueue_chain(b);
-    BHIP_TRY(hipStreamEndCapture(b->stream, &b->graph));
-    BHIP_TRY(hipGraphInstantiate(&b->graph_exec, b->graph, nullptr, nullptr, 0));
-  }
-  BHIP_TRY(hipGraphLaunch(b->graph_exec, b->stream));
+template <class F>
+bool capture(hipStream_t st, hipGraph_t* graph, hipGraphExec_t* exec, F enqueue) {
+  BHIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  enqueue();
+  BHIP_TRY(hipStreamEndCapture(st, graph));
+  BHIP_TRY(hipGraphInstantiate(exec, *graph, nullptr, nullptr, 0));
+  return true;
+}
+
+bool run_front(BeatriceBatch* b) {
+  if (!b->use_graph) { enqueue_front(b, b->stream); return hip_ok(hipGetLastError(), "front launch"); }
+  if (!b->exec_front && !capture(b->stream, &b->graph_front, &b->exec_front, [b] { enqueue_front(b, b->stream); })) return false;
+  BHIP_TRY(hipGraphLaunch(b->exec_front, b->stream));
+  return true;
+}
+bool run_wave(BeatriceBatch* b, int parity) {
+  hipStream_t st = wave_stream(b);
+  if (!b->use_graph) { enqueue_wave(b, parity, st); return hip_ok(hipGetLastError(), "wave launch"); }
+  if (!b->exec_wave[parity] &&
+      !capture(st, &b->graph_wave[parity], &b->exec_wave[parity], [b, parity, st] { enqueue_wave(b, parity, st); }))
+    return false;
+  BHIP_TRY(hipGraphLaunch(b->exec_wave[parity], st));
   return true;
 }
 
@@ -295,12 +360,25 @@ bool step_device(BeatriceBatch* b, const float* d_in, float* d_out) {
   advance_kv(b);
   draw_codebooks(b);
   if (b->vq_dirty) { update_vq_mode(b); b->vq_dirty = false; }
-  if (!push_settings(b)) return false;
+  hipStream_t fs = b->stream, ws = wave_stream(b);
+  const long long t = b->steps_enqueued;
+  const int parity = b->hop_host & 1;
+  // The front end of step t overwrites what the waveform generator of step t-2 read: the two-slot phone /
+  // conditioning buffers, the counter pair and the attention tile lists of this parity.
+  if (t >= 2) BHIP_TRY(hipStreamWaitEvent(fs, b->ev_wave[parity], 0));
+  if (!push_settings(b, parity)) return false;
   if (d_in && d_in != b->d_in)
-    BHIP_TRY(hipMemcpyAsync(b->d_in, d_in, sizeof(float) * b->B * b->H * B_IN_HOP, hipMemcpyDeviceToDevice, b->stream));
-  if (!run_chain(b)) return false;
+    BHIP_TRY(hipMemcpyAsync(b->d_in, d_in, sizeof(float) * b->B * b->H * B_IN_HOP, hipMemcpyDeviceToDevice, fs));
+  if (!run_front(b)) return false;
+  BHIP_TRY(hipEventRecord(b->ev_front, fs));
+  BHIP_TRY(hipStreamWaitEvent(ws, b->ev_front, 0));
+  if (!run_wave(b, parity)) return false;
   if (d_out && d_out != b->wave.d_out)
-    BHIP_TRY(hipMemcpyAsync(d_out, b->wave.d_out, sizeof(float) * b->B * b->H * B_OUT_HOP, hipMemcpyDeviceToDevice, b->stream));
+    BHIP_TRY(hipMemcpyAsync(d_out, b->wave.d_out, sizeof(float) * b->B * b->H * B_OUT_HOP, hipMemcpyDeviceToDevice, ws));
+  BHIP_TRY(hipEventRecord(b->ev_wave[parity], ws));
+  b->last_parity = parity;
+  b->hop_host = hop_next(b->hop_host);
+  b->steps_enqueued = t + 1;
   b->inflight = true;
   return true;
 }
@@ -365,18 +443,25 @@ BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* pho
   b->owns_stream = ok;
   ok = ok && hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_in), sizeof(float) * B * H * B_IN_HOP), "d_in") &&
        hip_ok(hipMemset(b->d_in, 0, sizeof(float) * B * H * B_IN_HOP), "d_in0");
-  ok = ok && b->phone.create(B, H, b->d_in) && b->pitch.create(B, H, b->d_in, true) &&
-       b->wave.create(B, H, S, S, 9, b->phone.d_phone, b->pitch.d_q, b->pitch.d_feat);
-  // the three modules advance in lockstep here: one step counter, double-buffered so that no launch is
-  // spent on incrementing it: the step's first kernels (phone.f1, pitch.fft) read d_hop_next, phone.f1
-  // publishes the value to phone.d_hop for every later kernel, the last kernel (wave.tail) stores
-  // value + 1 back to d_hop_next
+  // the front end's outputs (phone vector, conditioning mix) have two step slots: see `pipelined`
+  ok = ok && b->phone.create(B, H, b->d_in, 2) && b->pitch.create(B, H, b->d_in, true) &&
+       b->wave.create(B, H, S, S, 9, b->phone.d_phone, b->pitch.d_q, b->pitch.d_feat, 2);
+  // The modules advance in lockstep: one step counter, with no launch spent on incrementing it.  The step's
+  // first kernels (phone.f1, pitch.fft) read the pair {counter, I/O slot} from d_hop_next; phone.f1 publishes
+  // it to phone.d_hop for the rest of the front end and to d_hop_wave[counter & 1] for the waveform generator
+  // (which may lag one step behind); the front end's last body (wave.cond) stores the next pair to d_hop_next.
   ok = ok && hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_hop_next), 2 * sizeof(int)), "hop_next") &&
-       hip_ok(hipMemset(b->d_hop_next, 0, 2 * sizeof(int)), "hop_next0");
-  b->pitch.hop = b->phone.d_hop; b->wave.hop = b->phone.d_hop;
+       hip_ok(hipMemset(b->d_hop_next, 0, 2 * sizeof(int)), "hop_next0") &&
+       hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_hop_wave), 4 * sizeof(int)), "hop_wave") &&
+       hip_ok(hipMemset(b->d_hop_wave, 0, 4 * sizeof(int)), "hop_wave0");
+  b->pitch.hop = b->phone.d_hop; b->wave.hop = b->d_hop_wave;
   b->phone.hop_in = b->d_hop_next; b->pitch.hop_in = b->d_hop_next;
-  b->phone.hop_publish = b->phone.d_hop; b->wave.hop_next_out = b->d_hop_next;
+  b->phone.hop_publish = b->phone.d_hop; b->phone.hop_publish_wave = b->d_hop_wave;
+  b->wave.front_hop = b->phone.d_hop; b->wave.front_next_out = b->d_hop_next;
   b->phone.advance_hop = false; b->pitch.advance_hop = false; b->wave.advance_hop = false;
+  ok = ok && make_stream(&b->wave_stream_own) && hip_ok(hipEventCreateWithFlags(&b->ev_front, hipEventDisableTiming), "evf") &&
+       hip_ok(hipEventCreateWithFlags(&b->ev_wave[0], hipEventDisableTiming), "evw0") &&
+       hip_ok(hipEventCreateWithFlags(&b->ev_wave[1], hipEventDisableTiming), "evw1");
   const size_t cbf = (size_t)S * B_CODEBOOK * B_PHONE_CH, kvf = (size_t)S * B_KV_LEN * B_KV_CH;
   ok = ok && hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_cb_raw), sizeof(float) * cbf), "cb") &&
        hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_cbT), sizeof(float) * cbf), "cbT") &&
@@ -394,12 +479,14 @@ BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* pho
     b->off.cbT = take(sizeof(float*) * B); b->off.cnorm = take(sizeof(float*) * B); b->off.vqk = take(sizeof(int) * B);
     b->off.min_q = take(sizeof(int) * B); b->off.max_q = take(sizeof(int) * B);
     b->off.add_idx = take(sizeof(int) * B); b->off.frm_idx = take(sizeof(int) * B); b->off.params = take(sizeof(PitchParams) * B);
+    b->off.front_bytes = o;
     for (int blk = 0; blk < B_NBLOCKS; ++blk) { b->off.perm[blk] = take(sizeof(int) * nt * 16); b->off.tile_slot[blk] = take(sizeof(int) * nt); }
-    b->off.bytes = o;
+    b->off.wave_bytes = o - b->off.front_bytes;
   }
-  ok = ok && b->settings.alloc_host(b->off.bytes) &&
-       hip_ok(hipMalloc(reinterpret_cast<void**>(&b->settings.d), b->off.bytes), "settings") &&
-       hip_ok(hipMemset(b->settings.d, 0, b->off.bytes), "settings0");
+  const size_t dev_bytes = b->off.front_bytes + 2 * b->off.wave_bytes;
+  ok = ok && b->settings.alloc_host(b->off.front_bytes + b->off.wave_bytes) &&
+       hip_ok(hipMalloc(reinterpret_cast<void**>(&b->settings.d), dev_bytes), "settings") &&
+       hip_ok(hipMemset(b->settings.d, 0, dev_bytes), "settings0");
   if (ok) {  // the kernels read the block instead of the modules' own arrays
     void** keep = b->module_owned;
     auto swap_in = [&keep](auto*& member, auto* view) { *keep++ = (void*)member; member = view; };
@@ -451,7 +538,7 @@ BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* pho
 
 void BeatriceBatch_Destroy(BeatriceBatch* b) {
   if (!b) return;
-  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  if (b->stream) (void)sync_all(b);
   drop_graph(b);
   if (b->own_d_out) { b->wave.d_out = b->own_d_out; b->own_d_out = nullptr; }
   if (b->module_owned[0]) {  // hand the modules their own arrays back so that destroy() frees what it allocated
@@ -464,7 +551,7 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   }
   b->phone.destroy(); b->pitch.destroy(); b->wave.destroy();
   void* dev[] = {b->d_in, b->d_cb_raw, b->d_cbT, b->d_cnorm, b->d_add_raw, b->d_frm_raw, b->d_kv_raw,
-                 b->d_w48, b->d_coef_down, b->d_coef_up, b->d_io48, b->d_hop_next};
+                 b->d_w48, b->d_coef_down, b->d_coef_up, b->d_io48, b->d_hop_next, b->d_hop_wave};
   if (b->h_io48) (void)hipHostFree(b->h_io48);
   for (void* p : dev) if (p) (void)hipFree(p);
   b->settings.release();
@@ -473,6 +560,9 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   if (b->h_out) (void)hipHostFree(b->h_out);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->ev_front) (void)hipEventDestroy(b->ev_front);
+  for (hipEvent_t e : b->ev_wave) if (e) (void)hipEventDestroy(e);
+  if (b->wave_stream_own) (void)hipStreamDestroy(b->wave_stream_own);
   if (b->owns_stream && b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
 }
@@ -501,7 +591,7 @@ int BeatriceBatch_SetSpeakerTables(BeatriceBatch* b, int n, const float* codeboo
                                    const float* kv) {
   if (!b || !b->ok) return -2;
   if (n < 1 || n > b->max_speakers || !codebooks || !additive || !formant || !kv) return -1;
-  bool ok = hip_ok(hipStreamSynchronize(b->stream), "sync") &&
+  bool ok = sync_all(b) &&
             hip_ok(hipMemcpy(b->d_cb_raw, codebooks, sizeof(float) * n * B_CODEBOOK * B_PHONE_CH, hipMemcpyHostToDevice), "cb") &&
             hip_ok(hipMemcpy(b->d_add_raw, additive, sizeof(float) * n * B_HID, hipMemcpyHostToDevice), "add") &&
             hip_ok(hipMemcpy(b->d_frm_raw, formant, sizeof(float) * 9 * B_HID, hipMemcpyHostToDevice), "frm") &&
@@ -518,7 +608,7 @@ int BeatriceBatch_SetSpeakerTables(BeatriceBatch* b, int n, const float* codeboo
 int BeatriceBatch_UpdateSpeaker(BeatriceBatch* b, int spk, const float* codebook, const float* additive, const float* kv) {
   if (!b || !b->ok) return -2;
   if (spk < 0 || spk >= b->max_speakers) return -1;
-  bool ok = hip_ok(hipStreamSynchronize(b->stream), "sync");
+  bool ok = sync_all(b);
   if (codebook) ok = ok && hip_ok(hipMemcpy(b->d_cb_raw + (size_t)spk * B_CODEBOOK * B_PHONE_CH, codebook, sizeof(float) * B_CODEBOOK * B_PHONE_CH, hipMemcpyHostToDevice), "cb1");
   if (additive) ok = ok && hip_ok(hipMemcpy(b->d_add_raw + (size_t)spk * B_HID, additive, sizeof(float) * B_HID, hipMemcpyHostToDevice), "add1");
   if (kv) ok = ok && hip_ok(hipMemcpy(b->d_kv_raw + (size_t)spk * B_KV_LEN * B_KV_CH, kv, sizeof(float) * B_KV_LEN * B_KV_CH, hipMemcpyHostToDevice), "kv1");
@@ -552,8 +642,7 @@ int BeatriceBatch_MorphSpeaker(BeatriceBatch* b, int slot, const float* weights,
   for (int i = 0; i < n_active; ++i) sum += wn[i];
   if (n_active > 0 && sum > 0.0f) { const float inv = 1.0f / sum; for (int i = 0; i < n_active; ++i) wn[i] *= inv; }
   else n_active = 0;
-  settle(b);
-  bool ok = hip_ok(hipStreamSynchronize(b->stream), "sync");
+  bool ok = sync_all(b);
   ok = ok && spherical_mean_rows(b->d_add_raw, B_HID, 1, B_HID, n_active, spk, wn, b->d_add_raw + (size_t)slot * B_HID, b->stream);
   ok = ok && spherical_mean_rows(b->d_kv_raw, (size_t)B_KV_LEN * B_KV_CH, B_KV_LEN, B_KV_CH, n_active, spk, wn,
                                  b->d_kv_raw + (size_t)slot * B_KV_LEN * B_KV_CH, b->stream);
@@ -577,7 +666,7 @@ int BeatriceBatch_MorphSpeaker(BeatriceBatch* b, int slot, const float* weights,
 int BeatriceBatch_GetSpeakerEmbeddings(BeatriceBatch* b, int speaker, float* additive, float* key_value) {
   if (!b || !b->ok) return -2;
   if (speaker < 0 || speaker >= b->max_speakers) return -1;
-  bool ok = hip_ok(hipStreamSynchronize(b->stream), "sync");
+  bool ok = sync_all(b);
   if (additive) ok = ok && hip_ok(hipMemcpy(additive, b->d_add_raw + (size_t)speaker * B_HID, sizeof(float) * B_HID, hipMemcpyDeviceToHost), "add");
   if (key_value) ok = ok && hip_ok(hipMemcpy(key_value, b->d_kv_raw + (size_t)speaker * B_KV_LEN * B_KV_CH, sizeof(float) * B_KV_LEN * B_KV_CH, hipMemcpyDeviceToHost), "kv");
   return ok ? 0 : -2;
@@ -654,7 +743,7 @@ int BeatriceBatch_ResetStream(BeatriceBatch* b, int stream) {
   if (!b || !b->ok) return -2;
   if (stream < -1 || stream >= b->B) return -1;
   const int lo = stream < 0 ? 0 : stream, hi = stream < 0 ? b->B : stream + 1;
-  bool ok = true;
+  bool ok = !b->pipelined || sync_all(b);  // the waveform generator of the last step may still be running on its own stream
   for (int s = lo; s < hi && ok; ++s) {
     ok = b->phone.arena.zero_stream(s, b->stream) && b->pitch.arena.zero_stream(s, b->stream) &&
          b->wave.arena.zero_stream(s, b->stream) &&
@@ -679,8 +768,7 @@ int BeatriceBatch_BindResidentIO(BeatriceBatch* b, const float* d_in, float* d_o
   if (!b || !b->ok) return -2;
   const bool bind = d_in != nullptr || d_out != nullptr;
   if (bind && (!d_in || !d_out || n_slots < 1)) return -1;
-  settle(b);
-  if (!hip_ok(hipStreamSynchronize(b->stream), "sync")) return -2;
+  if (!sync_all(b)) return -2;
   drop_graph(b);  // kernel arguments change
   if (b->own_d_out) { b->wave.d_out = b->own_d_out; b->own_d_out = nullptr; }
   b->phone.d_in = b->pitch.d_in = b->d_in;
@@ -705,9 +793,8 @@ int BeatriceBatch_ConvertFrames(BeatriceBatch* b, const float* in, float* out) {
   std::memcpy(b->h_in, in, sizeof(float) * n_in);
   bool ok = hip_ok(hipMemcpyAsync(b->d_in, b->h_in, sizeof(float) * n_in, hipMemcpyHostToDevice, b->stream), "in");
   ok = ok && step_device(b, nullptr, nullptr);
-  ok = ok && hip_ok(hipMemcpyAsync(b->h_out, b->wave.d_out, sizeof(float) * n_out, hipMemcpyDeviceToHost, b->stream), "out");
-  ok = hip_ok(hipStreamSynchronize(b->stream), "sync") && ok;
-  b->inflight = false;
+  ok = ok && hip_ok(hipMemcpyAsync(b->h_out, b->wave.d_out, sizeof(float) * n_out, hipMemcpyDeviceToHost, wave_stream(b)), "out");
+  ok = sync_all(b) && ok;
   if (ok) std::memcpy(out, b->h_out, sizeof(float) * n_out);
   else std::memset(out, 0, sizeof(float) * n_out);
   return ok ? 0 : -2;
@@ -723,12 +810,12 @@ static bool step_48k(BeatriceBatch* b, const float* d_in48, float* d_out48, int 
 }
 int BeatriceBatch_ConvertBlocks48kDevice(BeatriceBatch* b, const float* d_in, float* d_out, int channels) {
   if (!b || !b->ok) return -2;
-  if (channels < 1 || channels > 2 || !d_in || !d_out || b->H != 1 || b->io_slots > 0) return -1;  // the wrapper is per 10 ms block
+  if (channels < 1 || channels > 2 || !d_in || !d_out || b->H != 1 || b->io_slots > 0 || b->pipelined) return -1;  // per 10 ms block, in order
   return step_48k(b, d_in, d_out, channels) ? 0 : -2;
 }
 int BeatriceBatch_ConvertBlocks48k(BeatriceBatch* b, const float* in, float* out, int channels) {
   if (!b || !b->ok) return -2;
-  if (channels < 1 || channels > 2 || !in || !out || b->H != 1 || b->io_slots > 0) return -1;
+  if (channels < 1 || channels > 2 || !in || !out || b->H != 1 || b->io_slots > 0 || b->pipelined) return -1;
   const size_t n = (size_t)b->B * channels * 480;
   float* h_in = b->h_io48;
   float* h_out = b->h_io48 + (size_t)b->B * 2 * 480;
@@ -747,13 +834,12 @@ int BeatriceBatch_ConvertBlocks48k(BeatriceBatch* b, const float* in, float* out
 
 int BeatriceBatch_Synchronize(BeatriceBatch* b) {
   if (!b || !b->ok) return -2;
-  b->inflight = false;
-  return hip_ok(hipStreamSynchronize(b->stream), "sync") ? 0 : -2;
+  return sync_all(b) ? 0 : -2;
 }
 
 int BeatriceBatch_SetStream(BeatriceBatch* b, void* hip_stream) {
   if (!b || !b->ok) return -2;
-  (void)hipStreamSynchronize(b->stream);
+  (void)sync_all(b);
   drop_graph(b);
   if (b->owns_stream) (void)hipStreamDestroy(b->stream);
   b->stream = static_cast<hipStream_t>(hip_stream);
@@ -763,18 +849,34 @@ int BeatriceBatch_SetStream(BeatriceBatch* b, void* hip_stream) {
 void* BeatriceBatch_GetStream(const BeatriceBatch* b) { return b ? b->stream : nullptr; }
 int BeatriceBatch_EnableGraph(BeatriceBatch* b, int enable) {
   if (!b || !b->ok) return -2;
-  (void)hipStreamSynchronize(b->stream);
+  (void)sync_all(b);
   b->use_graph = enable != 0;
   if (!b->use_graph) drop_graph(b);
   return 0;
 }
+// Throughput mode for callers that enqueue steps ahead (BeatriceBatch_ConvertFramesDevice without waiting,
+// resident I/O): the front end of step t+1 runs on the batch's stream while the waveform generator of step t
+// runs on a second stream.  Same results; a step's output is complete when BeatriceBatch_Synchronize returns
+// (or, stream-ordered, on BeatriceBatch_GetWaveStream).  Off by default: everything in order on one stream.
+int BeatriceBatch_EnablePipelining(BeatriceBatch* b, int enable) {
+  if (!b || !b->ok) return -2;
+  if (!sync_all(b)) return -2;
+  drop_graph(b);  // the waveform half is captured on the stream it will run on
+  b->pipelined = enable != 0;
+  return 0;
+}
+void* BeatriceBatch_GetWaveStream(const BeatriceBatch* b) { return b ? wave_stream(b) : nullptr; }
 float* BeatriceBatch_DeviceInput(BeatriceBatch* b) { return b && b->ok ? b->d_in : nullptr; }
 float* BeatriceBatch_DeviceOutput(BeatriceBatch* b) { return b && b->ok ? b->wave.d_out : nullptr; }
 
 int BeatriceBatch_GetIntermediates(BeatriceBatch* b, float* phone, int* q_raw, int* q, float* feat) {
   if (!b || !b->ok) return -2;
-  bool ok = hip_ok(hipStreamSynchronize(b->stream), "sync");
-  if (phone) ok = ok && hip_ok(hipMemcpy(phone, b->phone.d_phone, sizeof(float) * b->B * b->H * B_PHONE_CH, hipMemcpyDeviceToHost), "phone");
+  bool ok = sync_all(b);
+  if (phone) {  // the phone vectors of the last step sit in one of the two step slots of a per-stream ring
+    const size_t row = sizeof(float) * b->H * B_PHONE_CH;
+    ok = ok && hip_ok(hipMemcpy2D(phone, row, b->phone.d_phone + (size_t)b->last_parity * b->H * B_PHONE_CH, row * b->phone.out_slots, row,
+                                  b->B, hipMemcpyDeviceToHost), "phone");
+  }
   if (q_raw) ok = ok && hip_ok(hipMemcpy(q_raw, b->pitch.d_q_raw, sizeof(int) * b->B * b->H, hipMemcpyDeviceToHost), "q_raw");
   if (q) ok = ok && hip_ok(hipMemcpy(q, b->pitch.d_q, sizeof(int) * b->B * b->H, hipMemcpyDeviceToHost), "q");
   if (feat) ok = ok && hip_ok(hipMemcpy(feat, b->pitch.d_feat, sizeof(float) * b->B * b->H * 4, hipMemcpyDeviceToHost), "feat");
@@ -810,18 +912,22 @@ int BeatriceBatch_ProfileKernels(BeatriceBatch* b, int repeats, int max_entries,
                                  double* flops, double* bytes) {
   if (!b || !b->ok) return -2;
   if (repeats < 1 || max_entries < 1 || !names || !launches || !mean_us || !flops || !bytes) return -1;
-  if (!hip_ok(hipStreamSynchronize(b->stream), "sync")) return -2;
+  if (!sync_all(b)) return -2;
   advance_kv(b);
   if (b->vq_dirty) { update_vq_mode(b); b->vq_dirty = false; }
-  if (!push_settings(b)) return -2;
+  const int parity = b->hop_host & 1;
+  if (!push_settings(b, parity)) return -2;
   ProfileHook hook;
   hook.repeats = repeats;
   hook.e0 = b->ev0;
   hook.e1 = b->ev1;
   launch_hook() = &hook;
-  enqueue_chain(b);
+  enqueue_front(b, b->stream);  // one step, eagerly, both halves on the batch's stream
+  enqueue_wave(b, parity, b->stream);
   launch_hook() = nullptr;
-  if (!hook.ok || !hip_ok(hipStreamSynchronize(b->stream), "sync")) return -2;
+  b->last_parity = parity;
+  b->hop_host = hop_next(b->hop_host);
+  if (!hook.ok || !sync_all(b)) return -2;
   const int n = std::min<int>((int)hook.rows.size(), max_entries);
   for (int i = 0; i < n; ++i) {
     std::memset(names + 64 * i, 0, 64);
@@ -836,11 +942,11 @@ int BeatriceBatch_ProfileKernels(BeatriceBatch* b, int repeats, int max_entries,
 
 int BeatriceBatch_TimeSteps(BeatriceBatch* b, int steps, float* ms) {
   if (!b || !b->ok || steps < 1 || !ms) return b && b->ok ? -1 : -2;
-  bool ok = hip_ok(hipEventRecord(b->ev0, b->stream), "ev0");
+  bool ok = sync_all(b) && hip_ok(hipEventRecord(b->ev0, b->stream), "ev0");
   for (int i = 0; i < steps && ok; ++i) ok = step_device(b, nullptr, nullptr);
-  ok = ok && hip_ok(hipEventRecord(b->ev1, b->stream), "ev1") && hip_ok(hipEventSynchronize(b->ev1), "evsync") &&
+  ok = ok && hip_ok(hipEventRecord(b->ev1, wave_stream(b)), "ev1") && hip_ok(hipEventSynchronize(b->ev1), "evsync") &&
        hip_ok(hipEventElapsedTime(ms, b->ev0, b->ev1), "elapsed");
-  return ok ? 0 : -2;
+  return (sync_all(b) && ok) ? 0 : -2;
 }
 
 }  // extern "C"

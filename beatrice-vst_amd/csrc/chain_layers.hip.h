@@ -26,7 +26,7 @@ struct PitchLayers {
 };
 
 static inline F1Args f1_args(const PhoneWeights& w, const PhoneState& s) {
-  return F1Args{s.d_in, s.audio, s.f[0], w.f1_w, w.f1_b, s.hop_in, s.hop_publish, s.H, s.io_stride};
+  return F1Args{s.d_in, s.audio, s.f[0], w.f1_w, w.f1_b, s.hop_in, s.hop_publish, s.hop_publish_wave, s.H, s.io_stride};
 }
 static inline LaunchInfo f1_info(const PhoneState& s) {
   return LaunchInfo{"phone.f1", 2.0 * s.B * s.H * 32 * 64 * 10, 4.0 * s.B * s.H * (160 + 32 * 64)};
@@ -45,7 +45,8 @@ static inline LaunchInfo head_info(const PitchState& s) {
   return LaunchInfo{"pitch.head", 25.0 * s.B * s.H * 448, 4.0 * s.B * s.H * (448 + 160 + 128 + 8)};
 }
 static inline CondArgs cond_args(const WaveWeights& w, const WaveState& s) {
-  return CondArgs{s.H, s.d_q, s.d_feat, w.pitch_emb, w.feat_w, s.d_add_tab, s.d_add_idx, s.d_frm_tab, s.d_frm_idx, s.e.base};
+  return CondArgs{s.H, s.d_q, s.d_feat, w.pitch_emb, w.feat_w, s.d_add_tab, s.d_add_idx, s.d_frm_tab, s.d_frm_idx, s.e,
+                  s.front_hop ? s.front_hop : s.hop, s.front_next_out, s.io_slots};
 }
 static inline LaunchInfo cond_info(const WaveState& s) {
   return LaunchInfo{"wave.cond", 11.0 * s.B * s.H * 256, 4.0 * s.B * s.H * 256 * 4};
@@ -53,6 +54,7 @@ static inline LaunchInfo cond_info(const WaveState& s) {
 
 // phone.out writes the 128-d vector either to the ring the k-NN kernel reads or, when no stream uses
 // the codebook (skip_vq), straight to the module's output
-static inline Ring phone_out_ring(const PhoneState& s) { return s.skip_vq ? Ring{s.d_phone, B_PHONE_CH, s.H, 1} : s.raw; }
+static inline Ring phone_vector_ring(const PhoneState& s) { return Ring{s.d_phone, B_PHONE_CH, s.H, s.out_slots}; }
+static inline Ring phone_out_ring(const PhoneState& s) { return s.skip_vq ? phone_vector_ring(s) : s.raw; }
 
 }  // namespace bhip

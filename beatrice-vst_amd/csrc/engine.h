@@ -81,7 +81,8 @@ struct PhoneState {
   bool owns_in = false;
   int* hop_mailbox = nullptr;  // owned d_in only: one int right behind the audio (counter sent with the input copy)
   size_t io_stride = 0;        // batch, resident I/O: d_in holds several steps, this many floats apart (slot = hop[1])
-  float* d_phone = nullptr;  // [B][H][128]
+  float* d_phone = nullptr;  // ring [B][out_slots * H][128]: step t writes slot t mod out_slots
+  int out_slots = 1;         // 2 in a batch, so that the next step's front end may run while the waveform generator reads
   const float** d_cbT = nullptr;    // [B] device pointers
   const float** d_cnorm = nullptr;  // [B]
   int* d_vqk = nullptr;             // [B]
@@ -89,9 +90,10 @@ struct PhoneState {
   int* hop = nullptr;         // counter the kernels read (== d_hop unless shared by a batch)
   int* hop_in = nullptr;      // counter the FIRST kernel reads (== hop unless a batch double-buffers the counter)
   int* hop_publish = nullptr; // batch: the first kernel copies *hop_in here (== hop) for the rest of the chain
+  int* hop_publish_wave = nullptr;  // batch: ... and to the waveform generator's counter pair [counter & 1]
   bool advance_hop = true;    // this module's forward ends with the counter increment
   bool skip_vq = false;       // no stream uses the codebook: phone.out writes d_phone, no k-NN launch
-  bool create(int B, int H, float* shared_in);
+  bool create(int B, int H, float* shared_in, int out_slots = 1);
   void destroy();
 };
 void phone_forward(const PhoneWeights& w, const PhoneState& s, hipStream_t stream);
@@ -170,14 +172,20 @@ struct WaveState {
   int* d_tile_slot[B_NBLOCKS] = {nullptr, nullptr, nullptr, nullptr};  // [n_tiles_max]
   int* d_hop = nullptr;       // owned hop counter
   int* hop = nullptr;         // counter the kernels read (== d_hop unless shared by a batch)
-  int* hop_next_out = nullptr;  // batch: the last kernel stores counter + 1 here (read by the next step's first kernels)
   size_t io_stride = 0;         // batch, resident I/O: d_out holds io_slots steps, this many floats apart
   int io_slots = 0;
+  // the conditioning mix (wave.cond) belongs to the front end of a step: it reads the front end's counter and,
+  // in a batch, stores the next step's {counter, I/O slot} (no front-end kernel reads that pair after the first launch)
+  const int* front_hop = nullptr;  // nullptr: same counter as the rest of the module
+  int* front_next_out = nullptr;
+  int front_slots = 1;             // step slots of the front end's outputs (phone vector, conditioning e): 1, or 2 in a batch
   bool advance_hop = true;    // this module's forward ends with the counter increment
-  bool create(int B, int H, int n_slots, int n_add, int n_frm, float* shared_phone, int* shared_q, float* shared_feat);
+  bool create(int B, int H, int n_slots, int n_add, int n_frm, float* shared_phone, int* shared_q, float* shared_feat,
+              int front_slots = 1);
   void destroy();
 };
 void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t stream, bool cond_done = false);
+void wave_cond(const WaveWeights& w, const WaveState& s, hipStream_t stream);
 
 // content encoder + pitch estimator (+ the waveform generator's conditioning mix) with the pitch
 // estimator's launches paired into the content encoder's (pair.hip.h).  Returns false when the

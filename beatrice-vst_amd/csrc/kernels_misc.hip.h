@@ -38,6 +38,8 @@ struct F1Args {
   const float *w, *bias;
   const int* hop;      // step counter this kernel reads ([1] = resident-I/O slot, read only if io_stride != 0)
   int* hop_publish;    // optional: workgroup (0,0) copies the counter (and the slot) here for the rest of the chain
+  int* hop_publish_wave;  // optional, int[2][2]: the same pair again at [counter & 1], for the waveform generator's chain,
+                          // which may still be working on the previous step when the next one's front end starts
   int H;
   size_t io_stride;    // 0, or floats between the slots of a resident multi-step input buffer (batch.hip)
 };
@@ -47,7 +49,10 @@ __device__ __forceinline__ void phone_f1_body(const F1Args& a, const int b, cons
   __shared__ float ws[10 * 64];
   const int tid = threadIdx.x, hop = *a.hop, H = a.H;
   const int io = a.io_stride != 0 ? a.hop[1] : 0;
-  if (a.hop_publish != nullptr && b == 0 && hh == 0 && tid == 0) { a.hop_publish[0] = hop; a.hop_publish[1] = io; }
+  if (a.hop_publish != nullptr && b == 0 && hh == 0 && tid == 0) {
+    a.hop_publish[0] = hop; a.hop_publish[1] = io;
+    if (a.hop_publish_wave != nullptr) { a.hop_publish_wave[(hop & 1) * 2] = hop; a.hop_publish_wave[(hop & 1) * 2 + 1] = io; }
+  }
   const Ring& audio = a.audio;
   const Ring& out = a.out;
   const float* __restrict__ d_in = a.d_in + (size_t)io * a.io_stride;
@@ -94,7 +99,8 @@ struct F1Op {
 struct VqArgs {
   int H;                       // hops per step: rows are (stream, hop), codebook per stream
   const float* raw;            // [B][H][128]
-  float* out;                  // [B][H][128]
+  Ring out;                    // C = 128, n = H frames per step, m = 1 or 2 step slots
+  const int* hop;
   const float* const* cbT;     // per stream: [128][512]
   const float* const* cnorm;   // per stream: [512]
   const int* k;                // per stream
@@ -105,11 +111,12 @@ static __global__ __launch_bounds__(512) void phone_vq_kernel(VqArgs a) {
   __shared__ int red_j[8];
   __shared__ int winner;
   const int row = blockIdx.x, b = row / a.H, j = threadIdx.x, lane = j & 63, wave = j >> 6;
+  float* out = ring_frame(a.out, b, ring_pos(a.out, *a.hop), row % a.H);
   const int k = a.k[b];
   const float* cbT = a.cbT[b];
   if (j < B_PHONE_CH) x[j] = a.raw[(size_t)row * B_PHONE_CH + j];
   if (k <= 0 || cbT == nullptr) {
-    if (j < B_PHONE_CH) a.out[(size_t)row * B_PHONE_CH + j] = x[j];
+    if (j < B_PHONE_CH) out[j] = x[j];
     return;
   }
   __syncthreads();
@@ -142,7 +149,7 @@ static __global__ __launch_bounds__(512) void phone_vq_kernel(VqArgs a) {
     if (j < B_PHONE_CH) acc = acc + cbT[j * B_CODEBOOK + wj];
     __syncthreads();
   }
-  if (j < B_PHONE_CH) a.out[(size_t)row * B_PHONE_CH + j] = acc / (float)k;
+  if (j < B_PHONE_CH) out[j] = acc / (float)k;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -335,7 +342,11 @@ struct CondArgs {
   const float* feat_w; // [4][256]
   const float* add_tab; const int* add_idx;
   const float* frm_tab; const int* frm_idx;
-  float* e;            // [B][256]
+  Ring e;              // C = 256, n = H, m = 1 or 2 step slots
+  const int* hop;
+  int* hop_next_out;   // optional (batch): row 0 stores {counter + 1, next resident-I/O slot} for the next step's first kernels;
+                       // no kernel of this step's front end reads that pair after its first launch
+  int io_slots;
 };
 __device__ __forceinline__ void wave_cond_body(const CondArgs& a, const int row) {
   const int b = row / a.H, n = threadIdx.x;
@@ -346,7 +357,13 @@ __device__ __forceinline__ void wave_cond_body(const CondArgs& a, const int row)
 #pragma unroll
   for (int i = 0; i < 4; ++i) fp = bsp::fma(f[i], a.feat_w[i * B_HID + n], fp);
   const float c = a.add_tab[(size_t)a.add_idx[b] * B_HID + n] + a.frm_tab[(size_t)a.frm_idx[b] * B_HID + n];
-  a.e[(size_t)row * B_HID + n] = (a.pitch_emb[(size_t)q * B_HID + n] + fp) + c;
+  const int hop = *a.hop;
+  ring_frame(a.e, b, ring_pos(a.e, hop), row % a.H)[n] = (a.pitch_emb[(size_t)q * B_HID + n] + fp) + c;
+  if (a.hop_next_out != nullptr && row == 0 && n == 0) {
+    const int io = a.io_slots > 0 ? a.hop[1] : 0;
+    a.hop_next_out[0] = hop_next(hop);
+    a.hop_next_out[1] = a.io_slots > 0 ? (io + 1 >= a.io_slots ? 0 : io + 1) : 0;
+  }
 }
 static __global__ __launch_bounds__(256) void wave_cond_kernel(const CondArgs a) { wave_cond_body(a, blockIdx.x); }
 struct CondOp {

@@ -5,8 +5,8 @@
 
 namespace bhip {
 
-bool PhoneState::create(int B_, int H_, float* shared_in) {
-  B = B_; H = H_;
+bool PhoneState::create(int B_, int H_, float* shared_in, int out_slots_) {
+  B = B_; H = H_; out_slots = out_slots_;
   auto slots = [&](int n0, int hist) { return 1 + (hist + n0 * H - 1) / (n0 * H); };
   std::vector<RingSpec> specs = {
       {&audio, 1, B_IN_HOP * H, slots(B_IN_HOP, 5)},
@@ -24,12 +24,12 @@ bool PhoneState::create(int B_, int H_, float* shared_in) {
     owns_in = true;
     hop_mailbox = reinterpret_cast<int*>(d_in + (size_t)B * H * B_IN_HOP);
   }
-  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_phone), sizeof(float) * B * H * B_PHONE_CH));
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_phone), sizeof(float) * B * H * B_PHONE_CH * out_slots));
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cbT), sizeof(float*) * B));
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cnorm), sizeof(float*) * B));
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_vqk), sizeof(int) * B));
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hop), 2 * sizeof(int)));  // [0] step counter, [1] resident-I/O slot
-  BHIP_TRY(hipMemset(d_phone, 0, sizeof(float) * B * H * B_PHONE_CH));
+  BHIP_TRY(hipMemset(d_phone, 0, sizeof(float) * B * H * B_PHONE_CH * out_slots));
   BHIP_TRY(hipMemset(d_cbT, 0, sizeof(float*) * B));
   BHIP_TRY(hipMemset(d_cnorm, 0, sizeof(float*) * B));
   BHIP_TRY(hipMemset(d_vqk, 0, sizeof(int) * B));
@@ -59,7 +59,7 @@ void PhoneState::destroy() {
 void phone_vq(const PhoneWeights&, const PhoneState& s, hipStream_t st) {
   const int B = s.B, H = s.H;
   if (!s.skip_vq) {
-    VqArgs v{H, s.raw.base, s.d_phone, s.d_cbT, s.d_cnorm, s.d_vqk};
+    VqArgs v{H, s.raw.base, phone_vector_ring(s), s.hop, s.d_cbT, s.d_cnorm, s.d_vqk};
     MISC_LAUNCH("phone.vq", 0 /* k-dependent: 131 kFLOP per stream-hop with k > 0, pass-through at k = 0 */, 4.0 * B * H * 256,
                 phone_vq_kernel, dim3(B * H), dim3(512), v);
   }

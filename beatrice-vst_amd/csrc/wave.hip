@@ -8,13 +8,13 @@ namespace bhip {
 static const int kBlockDil[B_NBLOCKS] = {1, 2, 4, 8};
 
 bool WaveState::create(int B_, int H_, int n_slots_, int n_add_, int n_frm_, float* shared_phone, int* shared_q,
-                       float* shared_feat) {
-  B = B_; H = H_; n_slots = n_slots_; n_add = n_add_; n_frm = n_frm_;
+                       float* shared_feat, int front_slots_) {
+  B = B_; H = H_; n_slots = n_slots_; n_add = n_add_; n_frm = n_frm_; front_slots = front_slots_;
   const int rows = B * H;
   n_tiles_max = (rows + 15) / 16 + n_slots;  // rows grouped by slot: at most one partial tile per slot
   auto slots = [&](int n0, int hist) { return 1 + (hist + n0 * H - 1) / (n0 * H); };
   std::vector<RingSpec> specs = {
-      {&e, B_HID, H, 1},
+      {&e, B_HID, H, front_slots},
       {&x[0], B_HID, H, slots(1, 2 * kBlockDil[0])}, {&x[1], B_HID, H, slots(1, 2 * kBlockDil[1])},
       {&x[2], B_HID, H, slots(1, 2 * kBlockDil[2])}, {&x[3], B_HID, H, slots(1, 2 * kBlockDil[3])}, {&x[4], B_HID, H, slots(1, 1)},
       {&h1, B_HID, H, 1}, {&xa, B_HID, H, 1}, {&q, B_HID, H, 1}, {&sc, B_KV_LEN, H, 1}, {&o, B_HID, H, 1},
@@ -27,10 +27,10 @@ bool WaveState::create(int B_, int H_, int n_slots_, int n_add_, int n_frm_, flo
   if (!arena.build(B, specs)) return false;
   if (shared_phone) { d_phone = shared_phone; d_q = shared_q; d_feat = shared_feat; owns_inputs = false; }
   else {
-    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_phone), sizeof(float) * rows * B_PHONE_CH));
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_phone), sizeof(float) * rows * B_PHONE_CH * front_slots));
     BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_q), sizeof(int) * rows));
     BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_feat), sizeof(float) * rows * 4));
-    BHIP_TRY(hipMemset(d_phone, 0, sizeof(float) * rows * B_PHONE_CH));
+    BHIP_TRY(hipMemset(d_phone, 0, sizeof(float) * rows * B_PHONE_CH * front_slots));
     BHIP_TRY(hipMemset(d_q, 0, sizeof(int) * rows));
     BHIP_TRY(hipMemset(d_feat, 0, sizeof(float) * rows * 4));
     owns_inputs = true;
@@ -107,7 +107,7 @@ static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t
     const CondArgs ca = cond_args(w, s);
     launch_site(cond_info(s), st, [&] { hipLaunchKernelGGL(wave_cond_kernel, dim3(rows), dim3(256), 0, st, ca); });
   }
-  const Ring phone_in{s.d_phone, B_PHONE_CH, H, 1};
+  const Ring phone_in{s.d_phone, B_PHONE_CH, H, s.front_slots};
   ConvArgs a = conv_args(phone_in, s.x[0], w.inp_w, w.inp_b, s.hop, B);
   a.res = s.e;
   launch_auto<INP<H>>("wave.inp", a, st);
@@ -140,7 +140,7 @@ static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t
   launch_auto<RES<128, 3, 5 * H>>("wave.res1b", conv_args(s.yb1, s.yc1, w.rb_w[0], w.rb_b[0], s.hop, B), st);
   launch_auto<UP<128, 64, 4, 5 * H>>("wave.up2", conv_args(s.yc1, s.ya2, w.up_w[1], w.up_b[1], s.hop, B), st);
   TailArgs ta{};
-  ta.in = s.ya2; ta.state = s.tail.base; ta.fin_w = w.fin_w; ta.fin_b = w.fin_b; ta.d_out = s.d_out; ta.hop = s.hop; ta.hop_next_out = s.hop_next_out; ta.io_stride = s.io_stride; ta.io_slots = s.io_slots;
+  ta.in = s.ya2; ta.state = s.tail.base; ta.fin_w = w.fin_w; ta.fin_b = w.fin_b; ta.d_out = s.d_out; ta.hop = s.hop; ta.io_stride = s.io_stride;
   ta.w[0] = w.ra_w[1]; ta.b[0] = w.ra_b[1]; ta.w[1] = w.rb_w[1]; ta.b[1] = w.rb_b[1];
   ta.w[2] = w.up_w[2]; ta.b[2] = w.up_b[2]; ta.w[3] = w.ra_w[2]; ta.b[3] = w.ra_b[2]; ta.w[4] = w.rb_w[2]; ta.b[4] = w.rb_b[2];
   ta.w[5] = w.up_w[3]; ta.b[5] = w.up_b[3]; ta.w[6] = w.ra_w[3]; ta.b[6] = w.ra_b[3]; ta.w[7] = w.rb_w[3]; ta.b[7] = w.rb_b[3];
@@ -148,6 +148,12 @@ static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t
   MISC_LAUNCH("wave.tail", 2.0 * rows * tail_macs, 4.0 * (52000.0 + B * 2 * TAIL_STATE_FLOATS + rows * (22 * 64 + 240)), wave_tail_kernel<H>,
               dim3(B), dim3(tail::NTHR), ta);
   if (s.advance_hop) MISC_LAUNCH("hop_advance", 0, 4, hop_advance_kernel, dim3(1), dim3(1), s.hop);
+}
+
+// the conditioning mix alone (a batch runs it with the front end of the step)
+void wave_cond(const WaveWeights& w, const WaveState& s, hipStream_t st) {
+  const CondArgs ca = cond_args(w, s);
+  launch_site(cond_info(s), st, [&] { hipLaunchKernelGGL(wave_cond_kernel, dim3(s.B * s.H), dim3(256), 0, st, ca); });
 }
 
 void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t st, bool cond_done) {

@@ -46,9 +46,7 @@ struct TailArgs {
   const float *fin_w, *fin_b;
   float* d_out;  // [B][H*240]
   const int* hop;
-  int* hop_next_out;  // optional: workgroup 0 stores hop + 1 here (a counter no kernel of this step reads)
   size_t io_stride;   // 0, or floats between the slots of a resident multi-step output buffer (slot = hop[1])
-  int io_slots;       // number of slots; [1] of hop_next_out advances modulo this
 #ifdef TAIL_TIMING
   unsigned long long* stamps;  // tools/microbench/tail_timing.hip: [B][16] wall-clock stamps per phase
 #endif
@@ -317,9 +315,5 @@ static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const T
   { float* tmp = SI_; SI_ = SO_; SO_ = tmp; }  // this hop's histories are the next hop's state
   }  // hops of the step
   for (int e = tid; e < TAIL_STATE_FLOATS; e += NTHR) st[e] = SI_[e];
-  if (a.hop_next_out != nullptr && b == 0 && tid == 0) {
-    a.hop_next_out[0] = hop_next(hop);
-    a.hop_next_out[1] = a.io_slots > 0 ? (io + 1 >= a.io_slots ? 0 : io + 1) : 0;
-  }
   TAIL_STAMP(10);
 }

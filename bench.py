@@ -272,6 +272,9 @@ def main():
                          "3 = 256 streams/GPU, 64 rotating speakers, VQ k=4; 4 = 64 streams/GPU, 48 kHz stereo, wrapper on the device")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="keep both halves of a step on one HIP stream (default: BeatriceBatch_EnablePipelining, the front end "
+                         "of step t+1 overlaps the waveform generator of step t while steps are enqueued ahead)")
     ap.add_argument("--copy-io", action="store_true",
                     help="device-to-device copy of each hop into / out of the library's own buffers instead of "
                          "binding the resident audio buffers (BeatriceBatch_BindResidentIO)")
@@ -345,6 +348,9 @@ def main():
     resident = a.config != 4 and not a.copy_io
     d_out = torch.zeros((n_cycle if resident else 1, B, 240), dtype=torch.float32, device="cuda")
     base, hop_bytes = d_audio.data_ptr(), B * 160 * 4
+    pipelined = a.config != 4 and not a.no_pipeline
+    if pipelined and product.BeatriceBatch_EnablePipelining(batch.h, 1):
+        raise SystemExit("EnablePipelining failed")
     if resident:  # the 64 resident hops are the slots: every step reads one and writes one, no copy
         if product.BeatriceBatch_BindResidentIO(batch.h, d_audio.data_ptr(), d_out.data_ptr(), n_cycle):
             raise SystemExit("BindResidentIO failed")
@@ -374,6 +380,7 @@ def main():
 
     for i in range(a.warmup):
         step(i)
+    product.BeatriceBatch_Synchronize(batch.h)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -381,6 +388,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(a.warmup + i)
+    if product.BeatriceBatch_Synchronize(batch.h):  # both of the batch's streams (torch only knows its own)
+        raise SystemExit("Synchronize failed")
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -401,6 +410,8 @@ def main():
                                     4: "BASELINE.json configs[4] per-GPU share: %d streams of 48 kHz stereo, downmix + resample "
                                        "wrapper on the device, 480-sample blocks" % B}[a.config],
                        "streams_per_gpu": B, "speakers": a.speakers, "hipgraph": not a.no_graph,
+                       "pipelining": "front end of step t+1 overlaps the waveform generator of step t (two HIP streams), steps "
+                                     "enqueued without waiting" if pipelined else "off: one stream, halves in order",
                        "io": "resident device buffers, 64 hops per stream cycled, bound as I/O slots (no per-step copy)" if resident
                              else "resident device buffers, one device-to-device copy in and out per step",
                        "parallelism": "streams sharded over %d GPU(s), no per-hop collective" % world},

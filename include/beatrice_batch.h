@@ -130,6 +130,13 @@ int BeatriceBatch_ConvertBlocks48kDevice(BeatriceBatch* b, const float* d_in, fl
 int BeatriceBatch_SetStream(BeatriceBatch* b, void* hip_stream);
 void* BeatriceBatch_GetStream(const BeatriceBatch* b);
 int BeatriceBatch_EnableGraph(BeatriceBatch* b, int enable);
+/* Throughput mode for callers that enqueue steps ahead of their completion (BeatriceBatch_ConvertFramesDevice
+ * without waiting, resident I/O): the front end (content encoder, pitch estimator) of step t+1 runs on the
+ * batch's stream while the waveform generator of step t runs on a second, internal stream.  Same samples.
+ * A step's output is complete after BeatriceBatch_Synchronize, or in stream order on BeatriceBatch_GetWaveStream.
+ * Off by default (everything in order on the batch's stream); the 48 kHz entry points need it off. */
+int BeatriceBatch_EnablePipelining(BeatriceBatch* b, int enable);
+void* BeatriceBatch_GetWaveStream(const BeatriceBatch* b);
 
 /* Resident buffers of the batch ([B][H*160] in, [B][H*240] out) for callers that produce / consume
  * audio on the device. */

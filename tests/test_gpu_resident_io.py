@@ -28,8 +28,10 @@ class Hip:
         self.lib.hipFree(p)
 
 
-@pytest.mark.parametrize("B,H,slots,steps", [(7, 1, 5, 13), (4, 4, 3, 7)])
-def test_resident_io_matches_host_buffers(bv, product, model_dir, B, H, slots, steps):
+@pytest.mark.parametrize("B,H,slots,steps,pipelined", [(7, 1, 5, 13, 0), (4, 4, 3, 7, 0), (37, 1, 6, 18, 1), (5, 2, 4, 11, 1)])
+def test_resident_io_matches_host_buffers(bv, product, model_dir, B, H, slots, steps, pipelined):
+    """pipelined = 1: BeatriceBatch_EnablePipelining -- the front end of step t+1 overlaps the waveform generator
+    of step t on a second stream while steps are enqueued without waiting; settings keep changing in between."""
     hip = Hip()
     audio = np.stack([bv.synth_audio(160 * H * steps, seed=40 + s) for s in range(B)])  # [B][steps*H*160]
     m = bv.Models(product, model_dir)
@@ -40,10 +42,21 @@ def test_resident_io_matches_host_buffers(bv, product, model_dir, B, H, slots, s
             batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, s, s % 3)
         batch.a.BeatriceBatch_FlushSpeaker(batch.h, -1)
 
+    def change(batch, k):  # settings that change while earlier steps may still be in flight
+        if k % 3 == 1:
+            s = (5 * k) % B
+            batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, s, (k + s) % 3)
+            batch.a.BeatriceBatch_SetFormantShift(batch.h, (s + 1) % B, float(k % 5) - 2.0)
+            batch.a.BeatriceBatch_SetVQNumNeighbors(batch.h, (s + 2) % B, k % 4)
+
     # reference: the synchronous host-buffer entry point
     ref_batch = bv.Batch(m, B, hops_per_step=H)
     settings(ref_batch)
-    ref = np.stack([ref_batch.convert(audio[:, k * H * 160:(k + 1) * H * 160]) for k in range(steps)])  # [steps][B][H*240]
+    ref = []
+    for k in range(steps):
+        change(ref_batch, k)
+        ref.append(ref_batch.convert(audio[:, k * H * 160:(k + 1) * H * 160]))
+    ref = np.stack(ref)  # [steps][B][H*240]
     ref_batch.close()
 
     batch = bv.Batch(m, B, hops_per_step=H)
@@ -51,6 +64,7 @@ def test_resident_io_matches_host_buffers(bv, product, model_dir, B, H, slots, s
     a, h = batch.a, batch.h
     d_in, d_out = hip.malloc(slots * B * H * 160 * 4), hip.malloc(slots * B * H * 240 * 4)
     assert a.BeatriceBatch_BindResidentIO(h, d_in, d_out, slots) == 0
+    assert a.BeatriceBatch_EnablePipelining(h, pipelined) == 0
     x0 = np.zeros((B, H * 160), np.float32)
     assert a.BeatriceBatch_ConvertFrames(h, bv.fptr(x0), bv.fptr(np.zeros((B, H * 240), np.float32))) == -1  # bound
     got = np.zeros_like(ref)
@@ -61,6 +75,7 @@ def test_resident_io_matches_host_buffers(bv, product, model_dir, B, H, slots, s
             buf[(first + k) % slots] = audio[:, (first + k) * H * 160:(first + k + 1) * H * 160]
         hip.h2d(d_in, buf)
         for k in range(n):
+            change(batch, first + k)
             assert a.BeatriceBatch_ConvertFramesDevice(h, None, None) == 0
         assert a.BeatriceBatch_Synchronize(h) == 0
         out = np.zeros((slots, B, H * 240), np.float32)
@@ -74,7 +89,7 @@ def test_resident_io_matches_host_buffers(bv, product, model_dir, B, H, slots, s
     batch.close()
     m.close()
     hip.free(d_in); hip.free(d_out)
-    print("resident I/O B=%d H=%d slots=%d: %s" % (B, H, slots, "bit-identical" if np.array_equal(ref, got) else
+    print("resident I/O B=%d H=%d slots=%d pipelined=%d: %s" % (B, H, slots, pipelined, "bit-identical" if np.array_equal(ref, got) else
                                                    "max-abs %g" % np.abs(ref - got).max()))
     assert np.abs(got).max() > 0.05
     assert np.array_equal(ref, got)
