@@ -8,6 +8,7 @@
 // memory by the kernels, so one captured graph serves every hop).
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -131,10 +132,10 @@ struct BeatriceBatch {
   // stream time per step with 64 rotating speakers)
   Mirror<unsigned char> settings;
   // layout: [front part: arrays the front end reads][wave part: attention tile lists], and on the device the wave
-  // part twice -- the waveform generator of step t reads copy t & 1, so a change can be pushed for step t while the
-  // generator of step t-1 is still running (its copy is refreshed one step later)
+  // part four times -- the waveform generator of step t reads copy t & 3, so a change can be pushed for step t while
+  // the generator stages of steps t-1..t-3 are still running (their copies are refreshed when their slot comes up)
   struct { size_t cbT, cnorm, vqk, min_q, max_q, add_idx, frm_idx, params, perm[B_NBLOCKS], tile_slot[B_NBLOCKS], front_bytes, wave_bytes; } off{};
-  bool front_dirty = true, wave_dirty[2] = {true, true};
+  bool front_dirty = true, wave_dirty[4] = {true, true, true, true};  // [kSlots]
   template <class T> T* host_view(size_t o) { return reinterpret_cast<T*>(settings.h + o); }
   template <class T> T* dev_view(size_t o) { return reinterpret_cast<T*>(settings.d + o); }
   void* module_owned[8 + 2 * B_NBLOCKS] = {};  // the modules' own (now unused) setting arrays, handed back before destroy()
@@ -145,22 +146,31 @@ struct BeatriceBatch {
   bool inflight = false;  // device-variant steps have been enqueued since the last synchronisation
   // staging for the host variant
   float *h_in = nullptr, *h_out = nullptr;
-  // One step = front end (content encoder + pitch estimator + conditioning mix) then waveform generator.  The
-  // two halves are separate launches (graphs): with pipelining on they go to two HIP streams, so the front end
-  // of step t+1 overlaps the waveform generator of step t whenever the caller enqueues steps ahead of their
-  // completion (the halves of ONE step stay ordered by an event; outputs and timing of a step that is waited
-  // for before the next is enqueued do not change).  Off: both halves on `stream`, in order.
+  // One step = a chain of stages: stage 0 the front end (content encoder + pitch estimator + conditioning mix),
+  // stages 1.. consecutive parts of the waveform generator (WavePart).  Each stage is its own launch (graph).
+  // With pipelining off all stages go to `stream`, in order.  With a pipeline depth of n = 2..4 there are n
+  // stages on n HIP streams, and stage s of step t+1 overlaps stage s+1 of step t whenever the caller enqueues
+  // steps ahead of their completion: the chain is a string of ~40 launches that are each latency-bound and leave
+  // most of the chip idle, so several steps in flight at different depths of the chain fill it.  Ordering:
+  //   stage s of step t   after stage s-1 of step t        (data of the same step)
+  //   stage s of step t   after stage s+1 of step t-2      (buffers that cross a stage boundary hold two steps:
+  //                                                          two-slot phone / conditioning buffers, one spare slot
+  //                                                          on the rings x[], ya2; the stages' scratch is private)
+  //   stage 0 of step t   after the last stage of step t-4 (counter pairs and attention tile lists have 4 copies)
+  // Outputs are identical; a step that is waited for before the next is enqueued runs exactly as without pipelining.
+  static constexpr int kMaxStages = 4, kSlots = 4;
+  int n_stages = 2;      // stages of the current plan (2 when pipelining is off: front end, whole generator)
   bool pipelined = false;
-  hipStream_t wave_stream_own = nullptr;
-  hipEvent_t ev_front = nullptr;            // front end of the current step enqueued/done
-  hipEvent_t ev_wave[2] = {nullptr, nullptr};  // waveform generator of step t done, at [t & 1]
+  WavePart part[kMaxStages] = {};                 // [s], s >= 1
+  hipStream_t stage_stream_own[kMaxStages] = {};  // [s], s >= 1; stage 0 runs on `stream`
+  hipEvent_t ev_done[kMaxStages][kSlots] = {};    // stage s of step t enqueued/done, at [t & 3]
   long long steps_enqueued = 0;
-  int hop_host = 0;     // mirror of the device step counter (same increments, same wrap): its parity picks the slots
-  int last_parity = 0;  // parity of the last enqueued step
-  int* d_hop_wave = nullptr;  // int[2][2]: {counter, I/O slot} of the step the waveform generator works on, at [counter & 1]
+  int hop_host = 0;     // mirror of the device step counter (same increments, same wrap)
+  int last_parity = 0;  // parity of the last enqueued step (slot of its phone vectors)
+  int* d_hop_wave = nullptr;  // int[4][2]: {counter, I/O slot} of step t at [t & 3], for the waveform generator's stages
   bool use_graph = true;
-  hipGraph_t graph_front = nullptr, graph_wave[2] = {nullptr, nullptr};
-  hipGraphExec_t exec_front = nullptr, exec_wave[2] = {nullptr, nullptr};
+  hipGraph_t graph[kMaxStages][kSlots] = {};      // stage 0 uses [0][0] only
+  hipGraphExec_t exec[kMaxStages][kSlots] = {};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int* d_hop_next = nullptr;  // {step counter, resident-I/O slot}, double-buffered: first kernels read it, the last one writes it
   float* own_d_out = nullptr; // the waveform module's output buffer while a resident output buffer is bound
@@ -174,12 +184,45 @@ namespace {
 
 // Waits for the steps enqueued so far (needed before the graph or a speaker table they use is replaced;
 // the pinned setting mirrors are double-buffered and do not need it).
-hipStream_t wave_stream(const BeatriceBatch* b) { return b->pipelined ? b->wave_stream_own : b->stream; }
+hipStream_t stage_stream(const BeatriceBatch* b, int s) { return b->pipelined && s > 0 ? b->stage_stream_own[s] : b->stream; }
+hipStream_t wave_stream(const BeatriceBatch* b) { return stage_stream(b, b->n_stages - 1); }  // where a step's output appears
 bool sync_all(BeatriceBatch* b) {
   bool ok = hip_ok(hipStreamSynchronize(b->stream), "sync");
-  if (b->wave_stream_own) ok = hip_ok(hipStreamSynchronize(b->wave_stream_own), "sync wave") && ok;
+  for (int s = 1; s < BeatriceBatch::kMaxStages; ++s)
+    if (b->stage_stream_own[s]) ok = hip_ok(hipStreamSynchronize(b->stage_stream_own[s]), "sync stage") && ok;
   b->inflight = false;
   return ok;
+}
+// Experiment switch: BEATRICE_HIP_CUMASK="lo-hi;lo-hi;..." gives the stream of stage 0, 1, ... a CU mask (CU index
+// ranges), so that concurrently running stages do not land on the same CUs.
+bool make_stage_stream(hipStream_t* st, int stage) {
+  const char* spec = std::getenv("BEATRICE_HIP_CUMASK");
+  if (spec) {
+    std::string sp(spec);
+    size_t pos = 0;
+    for (int i = 0; i < stage && pos != std::string::npos; ++i) { pos = sp.find(';', pos); if (pos != std::string::npos) ++pos; }
+    if (pos != std::string::npos && pos < sp.size()) {
+      int lo = 0, hi = -1;
+      if (std::sscanf(sp.c_str() + pos, "%d-%d", &lo, &hi) == 2 && lo >= 0 && hi >= lo && hi < 512) {
+        uint32_t mask[16] = {};
+        for (int c = lo; c <= hi; ++c) mask[c >> 5] |= 1u << (c & 31);
+        return hip_ok(hipExtStreamCreateWithCUMask(st, 16, mask), "cu mask stream");
+      }
+    }
+  }
+  return make_stream(st);
+}
+
+// stage plans by pipeline depth (waveform parts: 1 input mix, 2..5 blocks, 6 upsampler GEMMs, 7 tail); the cuts
+// balance the measured stage times at 256 streams (front end 83 us, generator 200 us)
+void set_plan(BeatriceBatch* b, int depth) {
+  b->pipelined = depth >= 2;
+  b->n_stages = depth < 2 ? 2 : depth;
+  switch (b->n_stages) {
+    case 2: b->part[1] = WavePart{1, 7, 0}; break;
+    case 3: b->part[1] = WavePart{1, 4, 0}; b->part[2] = WavePart{5, 7, 1}; break;
+    default: b->part[1] = WavePart{1, 3, 0}; b->part[2] = WavePart{4, 5, 1}; b->part[3] = WavePart{6, 7, 2}; break;
+  }
 }
 void settle(BeatriceBatch* b) {
   if (b->inflight) (void)sync_all(b);
@@ -190,7 +233,7 @@ void rebuild_tiles(BeatriceBatch* b, int blk) {
   const int nt = b->wave.n_tiles_max, rows = b->B * b->H;
   int* perm = b->host_view<int>(b->off.perm[blk]);
   int* slot = b->host_view<int>(b->off.tile_slot[blk]);
-  b->wave_dirty[0] = b->wave_dirty[1] = true;
+  for (bool& d : b->wave_dirty) d = true;
   const std::vector<int>& rs = b->row_slot[blk];
   std::fill(perm, perm + (size_t)nt * 16, -1);
   std::fill(slot, slot + nt, -1);
@@ -253,7 +296,7 @@ void advance_kv(BeatriceBatch* b) {
 
 // what changed since the last step goes to the device: the front part as it is, the wave part into the copy the
 // waveform generator of THIS step (parity) will read
-bool push_settings(BeatriceBatch* b, int parity) {
+bool push_settings(BeatriceBatch* b, int parity /* slot: step & 3 */) {
   size_t off[2], len[2];
   unsigned char* dst[2];
   int n = 0;
@@ -278,24 +321,18 @@ void enqueue_front(BeatriceBatch* b, hipStream_t st) {
   pitch_forward(b->pitch_m->w, b->pitch, st);
   wave_cond(b->wave_m->w, b->wave, st);
 }
-void enqueue_wave(BeatriceBatch* b, int parity, hipStream_t st) {
-  b->wave.hop = b->d_hop_wave + 2 * parity;
-  for (int blk = 0; blk < B_NBLOCKS; ++blk) {  // this parity's copy of the attention tile lists
-    b->wave.d_perm[blk] = b->dev_view<int>(b->off.perm[blk] + (size_t)parity * b->off.wave_bytes);
-    b->wave.d_tile_slot[blk] = b->dev_view<int>(b->off.tile_slot[blk] + (size_t)parity * b->off.wave_bytes);
+void enqueue_wave(BeatriceBatch* b, int stage, int slot, hipStream_t st) {
+  b->wave.hop = b->d_hop_wave + 2 * slot;
+  for (int blk = 0; blk < B_NBLOCKS; ++blk) {  // this slot's copy of the attention tile lists
+    b->wave.d_perm[blk] = b->dev_view<int>(b->off.perm[blk] + (size_t)slot * b->off.wave_bytes);
+    b->wave.d_tile_slot[blk] = b->dev_view<int>(b->off.tile_slot[blk] + (size_t)slot * b->off.wave_bytes);
   }
-  wave_forward(b->wave_m->w, b->wave, st, /*cond_done=*/true);
+  wave_forward(b->wave_m->w, b->wave, st, /*cond_done=*/true, b->part[stage]);
 }
 
 void drop_graph(BeatriceBatch* b) {
-  if (b->exec_front) (void)hipGraphExecDestroy(b->exec_front);
-  if (b->graph_front) (void)hipGraphDestroy(b->graph_front);
-  b->exec_front = nullptr; b->graph_front = nullptr;
-  for (int p = 0; p < 2; ++p) {
-    if (b->exec_wave[p]) (void)hipGraphExecDestroy(b->exec_wave[p]);
-    if (b->graph_wave[p]) (void)hipGraphDestroy(b->graph_wave[p]);
-    b->exec_wave[p] = nullptr; b->graph_wave[p] = nullptr;
-  }
+  for (auto& per_stage : b->exec) for (hipGraphExec_t& e : per_stage) { if (e) (void)hipGraphExecDestroy(e); e = nullptr; }
+  for (auto& per_stage : b->graph) for (hipGraph_t& g : per_stage) { if (g) (void)hipGraphDestroy(g); g = nullptr; }
 }
 
 template <class F>
@@ -307,19 +344,13 @@ bool capture(hipStream_t st, hipGraph_t* graph, hipGraphExec_t* exec, F enqueue)
   return true;
 }
 
-bool run_front(BeatriceBatch* b) {
-  if (!b->use_graph) { enqueue_front(b, b->stream); return hip_ok(hipGetLastError(), "front launch"); }
-  if (!b->exec_front && !capture(b->stream, &b->graph_front, &b->exec_front, [b] { enqueue_front(b, b->stream); })) return false;
-  BHIP_TRY(hipGraphLaunch(b->exec_front, b->stream));
-  return true;
-}
-bool run_wave(BeatriceBatch* b, int parity) {
-  hipStream_t st = wave_stream(b);
-  if (!b->use_graph) { enqueue_wave(b, parity, st); return hip_ok(hipGetLastError(), "wave launch"); }
-  if (!b->exec_wave[parity] &&
-      !capture(st, &b->graph_wave[parity], &b->exec_wave[parity], [b, parity, st] { enqueue_wave(b, parity, st); }))
-    return false;
-  BHIP_TRY(hipGraphLaunch(b->exec_wave[parity], st));
+bool run_stage(BeatriceBatch* b, int stage, int slot) {
+  hipStream_t st = stage_stream(b, stage);
+  auto enqueue = [b, stage, slot, st] { if (stage == 0) enqueue_front(b, st); else enqueue_wave(b, stage, slot, st); };
+  if (!b->use_graph) { enqueue(); return hip_ok(hipGetLastError(), "stage launch"); }
+  const int g = stage == 0 ? 0 : slot;  // the front end reads its counter through one fixed pointer
+  if (!b->exec[stage][g] && !capture(st, &b->graph[stage][g], &b->exec[stage][g], enqueue)) return false;
+  BHIP_TRY(hipGraphLaunch(b->exec[stage][g], st));
   return true;
 }
 
@@ -360,23 +391,27 @@ bool step_device(BeatriceBatch* b, const float* d_in, float* d_out) {
   advance_kv(b);
   draw_codebooks(b);
   if (b->vq_dirty) { update_vq_mode(b); b->vq_dirty = false; }
-  hipStream_t fs = b->stream, ws = wave_stream(b);
   const long long t = b->steps_enqueued;
-  const int parity = b->hop_host & 1;
-  // The front end of step t overwrites what the waveform generator of step t-2 read: the two-slot phone /
-  // conditioning buffers, the counter pair and the attention tile lists of this parity.
-  if (t >= 2) BHIP_TRY(hipStreamWaitEvent(fs, b->ev_wave[parity], 0));
-  if (!push_settings(b, parity)) return false;
+  const int slot = b->hop_host & 3, slot2 = (slot + 2) & 3, last = b->n_stages - 1;
+  hipStream_t fs = b->stream;
+  // ordering rules: see the comment at BeatriceBatch::n_stages
+  if (t >= 2) BHIP_TRY(hipStreamWaitEvent(fs, b->ev_done[1][slot2], 0));
+  if (t >= 4) BHIP_TRY(hipStreamWaitEvent(fs, b->ev_done[last][slot], 0));
+  if (!push_settings(b, slot)) return false;
   if (d_in && d_in != b->d_in)
     BHIP_TRY(hipMemcpyAsync(b->d_in, d_in, sizeof(float) * b->B * b->H * B_IN_HOP, hipMemcpyDeviceToDevice, fs));
-  if (!run_front(b)) return false;
-  BHIP_TRY(hipEventRecord(b->ev_front, fs));
-  BHIP_TRY(hipStreamWaitEvent(ws, b->ev_front, 0));
-  if (!run_wave(b, parity)) return false;
-  if (d_out && d_out != b->wave.d_out)
-    BHIP_TRY(hipMemcpyAsync(d_out, b->wave.d_out, sizeof(float) * b->B * b->H * B_OUT_HOP, hipMemcpyDeviceToDevice, ws));
-  BHIP_TRY(hipEventRecord(b->ev_wave[parity], ws));
-  b->last_parity = parity;
+  if (!run_stage(b, 0, slot)) return false;
+  BHIP_TRY(hipEventRecord(b->ev_done[0][slot], fs));
+  for (int s = 1; s <= last; ++s) {
+    hipStream_t st = stage_stream(b, s);
+    BHIP_TRY(hipStreamWaitEvent(st, b->ev_done[s - 1][slot], 0));
+    if (s < last && t >= 2) BHIP_TRY(hipStreamWaitEvent(st, b->ev_done[s + 1][slot2], 0));
+    if (!run_stage(b, s, slot)) return false;
+    if (s == last && d_out && d_out != b->wave.d_out)
+      BHIP_TRY(hipMemcpyAsync(d_out, b->wave.d_out, sizeof(float) * b->B * b->H * B_OUT_HOP, hipMemcpyDeviceToDevice, st));
+    BHIP_TRY(hipEventRecord(b->ev_done[s][slot], st));
+  }
+  b->last_parity = b->hop_host & 1;
   b->hop_host = hop_next(b->hop_host);
   b->steps_enqueued = t + 1;
   b->inflight = true;
@@ -439,7 +474,7 @@ BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* pho
   b->phone_m = phone; b->pitch_m = pitch; b->wave_m = wave; b->embed_m = embed;
   b->B = n_streams; b->max_speakers = max_speakers; b->H = hops_per_step;
   const int B = n_streams, S = max_speakers, H = hops_per_step;
-  bool ok = make_stream(&b->stream);
+  bool ok = make_stage_stream(&b->stream, 0);
   b->owns_stream = ok;
   ok = ok && hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_in), sizeof(float) * B * H * B_IN_HOP), "d_in") &&
        hip_ok(hipMemset(b->d_in, 0, sizeof(float) * B * H * B_IN_HOP), "d_in0");
@@ -452,16 +487,18 @@ BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* pho
   // (which may lag one step behind); the front end's last body (wave.cond) stores the next pair to d_hop_next.
   ok = ok && hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_hop_next), 2 * sizeof(int)), "hop_next") &&
        hip_ok(hipMemset(b->d_hop_next, 0, 2 * sizeof(int)), "hop_next0") &&
-       hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_hop_wave), 4 * sizeof(int)), "hop_wave") &&
-       hip_ok(hipMemset(b->d_hop_wave, 0, 4 * sizeof(int)), "hop_wave0");
+       hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_hop_wave), 8 * sizeof(int)), "hop_wave") &&
+       hip_ok(hipMemset(b->d_hop_wave, 0, 8 * sizeof(int)), "hop_wave0");
   b->pitch.hop = b->phone.d_hop; b->wave.hop = b->d_hop_wave;
   b->phone.hop_in = b->d_hop_next; b->pitch.hop_in = b->d_hop_next;
   b->phone.hop_publish = b->phone.d_hop; b->phone.hop_publish_wave = b->d_hop_wave;
   b->wave.front_hop = b->phone.d_hop; b->wave.front_next_out = b->d_hop_next;
   b->phone.advance_hop = false; b->pitch.advance_hop = false; b->wave.advance_hop = false;
-  ok = ok && make_stream(&b->wave_stream_own) && hip_ok(hipEventCreateWithFlags(&b->ev_front, hipEventDisableTiming), "evf") &&
-       hip_ok(hipEventCreateWithFlags(&b->ev_wave[0], hipEventDisableTiming), "evw0") &&
-       hip_ok(hipEventCreateWithFlags(&b->ev_wave[1], hipEventDisableTiming), "evw1");
+  for (int s = 0; s < BeatriceBatch::kMaxStages && ok; ++s) {
+    if (s > 0) ok = make_stage_stream(&b->stage_stream_own[s], s);
+    for (int k = 0; k < BeatriceBatch::kSlots && ok; ++k) ok = hip_ok(hipEventCreateWithFlags(&b->ev_done[s][k], hipEventDisableTiming), "ev");
+  }
+  set_plan(b, 1);
   const size_t cbf = (size_t)S * B_CODEBOOK * B_PHONE_CH, kvf = (size_t)S * B_KV_LEN * B_KV_CH;
   ok = ok && hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_cb_raw), sizeof(float) * cbf), "cb") &&
        hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_cbT), sizeof(float) * cbf), "cbT") &&
@@ -483,7 +520,7 @@ BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* pho
     for (int blk = 0; blk < B_NBLOCKS; ++blk) { b->off.perm[blk] = take(sizeof(int) * nt * 16); b->off.tile_slot[blk] = take(sizeof(int) * nt); }
     b->off.wave_bytes = o - b->off.front_bytes;
   }
-  const size_t dev_bytes = b->off.front_bytes + 2 * b->off.wave_bytes;
+  const size_t dev_bytes = b->off.front_bytes + BeatriceBatch::kSlots * b->off.wave_bytes;
   ok = ok && b->settings.alloc_host(b->off.front_bytes + b->off.wave_bytes) &&
        hip_ok(hipMalloc(reinterpret_cast<void**>(&b->settings.d), dev_bytes), "settings") &&
        hip_ok(hipMemset(b->settings.d, 0, dev_bytes), "settings0");
@@ -560,9 +597,8 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   if (b->h_out) (void)hipHostFree(b->h_out);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
-  if (b->ev_front) (void)hipEventDestroy(b->ev_front);
-  for (hipEvent_t e : b->ev_wave) if (e) (void)hipEventDestroy(e);
-  if (b->wave_stream_own) (void)hipStreamDestroy(b->wave_stream_own);
+  for (auto& per_stage : b->ev_done) for (hipEvent_t e : per_stage) if (e) (void)hipEventDestroy(e);
+  for (hipStream_t st : b->stage_stream_own) if (st) (void)hipStreamDestroy(st);
   if (b->owns_stream && b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
 }
@@ -861,8 +897,9 @@ int BeatriceBatch_EnableGraph(BeatriceBatch* b, int enable) {
 int BeatriceBatch_EnablePipelining(BeatriceBatch* b, int enable) {
   if (!b || !b->ok) return -2;
   if (!sync_all(b)) return -2;
-  drop_graph(b);  // the waveform half is captured on the stream it will run on
-  b->pipelined = enable != 0;
+  if (enable < 0 || enable > BeatriceBatch::kMaxStages) return -1;
+  drop_graph(b);  // stages are captured on the streams they will run on
+  set_plan(b, enable == 1 ? 2 : enable);  // 1 = the default depth
   return 0;
 }
 void* BeatriceBatch_GetWaveStream(const BeatriceBatch* b) { return b ? wave_stream(b) : nullptr; }
@@ -915,17 +952,17 @@ int BeatriceBatch_ProfileKernels(BeatriceBatch* b, int repeats, int max_entries,
   if (!sync_all(b)) return -2;
   advance_kv(b);
   if (b->vq_dirty) { update_vq_mode(b); b->vq_dirty = false; }
-  const int parity = b->hop_host & 1;
-  if (!push_settings(b, parity)) return -2;
+  const int slot = b->hop_host & 3;
+  if (!push_settings(b, slot)) return -2;
   ProfileHook hook;
   hook.repeats = repeats;
   hook.e0 = b->ev0;
   hook.e1 = b->ev1;
   launch_hook() = &hook;
-  enqueue_front(b, b->stream);  // one step, eagerly, both halves on the batch's stream
-  enqueue_wave(b, parity, b->stream);
+  enqueue_front(b, b->stream);  // one step, eagerly, every stage on the batch's stream
+  for (int st = 1; st < b->n_stages; ++st) enqueue_wave(b, st, slot, b->stream);
   launch_hook() = nullptr;
-  b->last_parity = parity;
+  b->last_parity = b->hop_host & 1;
   b->hop_host = hop_next(b->hop_host);
   if (!hook.ok || !sync_all(b)) return -2;
   const int n = std::min<int>((int)hook.rows.size(), max_entries);

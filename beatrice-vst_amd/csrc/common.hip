@@ -42,7 +42,7 @@ bool RingArena::build(int B_, const std::vector<RingSpec>& specs) {
   B = B_;
   size_t total = 0;
   for (const RingSpec& s : specs) {
-    if (s.m < 1 || s.m > 17) return false;  // the step counter wraps at lcm(1..17) (B_HOP_WRAP)
+    if (s.m < 1 || B_HOP_WRAP % s.m != 0) return false;  // the step counter wraps at B_HOP_WRAP = lcm(1..17): every slot count must divide it
     total += ((size_t)B * s.C * s.n * s.m + 63) / 64 * 64;
   }
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&base), total * sizeof(float)));

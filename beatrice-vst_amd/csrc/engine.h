@@ -155,7 +155,12 @@ struct WaveState {
   int n_slots = 0;      // K/V slots per block in the tables
   int n_tiles_max = 0;  // attention M-tiles (16 rows each) upper bound
   RingArena arena;
-  Ring e, x[B_NBLOCKS + 1], h1, xa, q, sc, o;
+  Ring e, x[B_NBLOCKS + 1];
+  // scratch of one conditioned block (reused by every block); one set per pipeline stage so that blocks of
+  // different steps can be in flight at once (batch.hip)
+  static constexpr int kScratchSets = 4;
+  struct Scratch { Ring h1, xa, q, sc, o; } scr[kScratchSets];
+  int boundary_slots = 0;   // extra step slots on the rings a pipeline stage boundary may cut (x[], ya2): 0, or 1 in a batch
   Ring ya1, yb1, yc1, ya2;  // upsampler stage 1 and the stage-2 transposed conv output
   Ring tail;                // per-stream history block of the fused upsampler tail (wave_tail.hip.h)
   // inputs (device): phone [B][H][128], q [B][H], feat [B][H][4]; owned unless shared with other modules
@@ -184,7 +189,10 @@ struct WaveState {
               int front_slots = 1);
   void destroy();
 };
-void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t stream, bool cond_done = false);
+// parts of the module, for pipelines that cut it into stages: 1 = input mix, 2..5 = conditioned blocks 0..3,
+// 6 = upsampler GEMMs, 7 = fused tail
+struct WavePart { int first = 1, last = 7, scratch = 0; };
+void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t stream, bool cond_done = false, WavePart part = WavePart());
 void wave_cond(const WaveWeights& w, const WaveState& s, hipStream_t stream);
 
 // content encoder + pitch estimator (+ the waveform generator's conditioning mix) with the pitch

@@ -38,8 +38,8 @@ struct F1Args {
   const float *w, *bias;
   const int* hop;      // step counter this kernel reads ([1] = resident-I/O slot, read only if io_stride != 0)
   int* hop_publish;    // optional: workgroup (0,0) copies the counter (and the slot) here for the rest of the chain
-  int* hop_publish_wave;  // optional, int[2][2]: the same pair again at [counter & 1], for the waveform generator's chain,
-                          // which may still be working on the previous step when the next one's front end starts
+  int* hop_publish_wave;  // optional, int[4][2]: the same pair again at [counter & 3], for the waveform generator's stages,
+                          // which may still be working on earlier steps when the next one's front end starts
   int H;
   size_t io_stride;    // 0, or floats between the slots of a resident multi-step input buffer (batch.hip)
 };
@@ -51,7 +51,7 @@ __device__ __forceinline__ void phone_f1_body(const F1Args& a, const int b, cons
   const int io = a.io_stride != 0 ? a.hop[1] : 0;
   if (a.hop_publish != nullptr && b == 0 && hh == 0 && tid == 0) {
     a.hop_publish[0] = hop; a.hop_publish[1] = io;
-    if (a.hop_publish_wave != nullptr) { a.hop_publish_wave[(hop & 1) * 2] = hop; a.hop_publish_wave[(hop & 1) * 2 + 1] = io; }
+    if (a.hop_publish_wave != nullptr) { a.hop_publish_wave[(hop & 3) * 2] = hop; a.hop_publish_wave[(hop & 3) * 2 + 1] = io; }
   }
   const Ring& audio = a.audio;
   const Ring& out = a.out;

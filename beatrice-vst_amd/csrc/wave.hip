@@ -10,19 +10,25 @@ static const int kBlockDil[B_NBLOCKS] = {1, 2, 4, 8};
 bool WaveState::create(int B_, int H_, int n_slots_, int n_add_, int n_frm_, float* shared_phone, int* shared_q,
                        float* shared_feat, int front_slots_) {
   B = B_; H = H_; n_slots = n_slots_; n_add = n_add_; n_frm = n_frm_; front_slots = front_slots_;
+  boundary_slots = front_slots_ > 1 ? 1 : 0;  // a batch may cut the module into pipeline stages
+  const int xs = boundary_slots;
   const int rows = B * H;
   n_tiles_max = (rows + 15) / 16 + n_slots;  // rows grouped by slot: at most one partial tile per slot
   auto slots = [&](int n0, int hist) { return 1 + (hist + n0 * H - 1) / (n0 * H); };
   std::vector<RingSpec> specs = {
       {&e, B_HID, H, front_slots},
-      {&x[0], B_HID, H, slots(1, 2 * kBlockDil[0])}, {&x[1], B_HID, H, slots(1, 2 * kBlockDil[1])},
-      {&x[2], B_HID, H, slots(1, 2 * kBlockDil[2])}, {&x[3], B_HID, H, slots(1, 2 * kBlockDil[3])}, {&x[4], B_HID, H, slots(1, 1)},
-      {&h1, B_HID, H, 1}, {&xa, B_HID, H, 1}, {&q, B_HID, H, 1}, {&sc, B_KV_LEN, H, 1}, {&o, B_HID, H, 1},
+      {&x[0], B_HID, H, slots(1, 2 * kBlockDil[0]) + xs}, {&x[1], B_HID, H, slots(1, 2 * kBlockDil[1]) + xs},
+      {&x[2], B_HID, H, slots(1, 2 * kBlockDil[2]) + xs}, {&x[3], B_HID, H, slots(1, 2 * kBlockDil[3]) + xs},
+      {&x[4], B_HID, H, slots(1, 1) + xs},
   };
+  for (int i = 0; i < (boundary_slots ? kScratchSets : 1); ++i) {
+    specs.push_back({&scr[i].h1, B_HID, H, 1}); specs.push_back({&scr[i].xa, B_HID, H, 1}); specs.push_back({&scr[i].q, B_HID, H, 1});
+    specs.push_back({&scr[i].sc, B_KV_LEN, H, 1}); specs.push_back({&scr[i].o, B_HID, H, 1});
+  }
   specs.push_back({&ya1, 128, 5 * H, slots(5, 2)});   // history 2 (res1a, k3)
   specs.push_back({&yb1, 128, 5 * H, slots(5, 6)});   // history 6 (res1b, k3 dil 3)
   specs.push_back({&yc1, 128, 5 * H, slots(5, 1)});   // history 1 (up2)
-  specs.push_back({&ya2, 64, 20 * H, slots(20, 2)});  // history 2 (first layer of the fused tail)
+  specs.push_back({&ya2, 64, 20 * H, slots(20, 2) + xs});  // history 2 (first layer of the fused tail)
   specs.push_back({&tail, TAIL_STATE_FLOATS, 1, 1});
   if (!arena.build(B, specs)) return false;
   if (shared_phone) { d_phone = shared_phone; d_q = shared_q; d_feat = shared_feat; owns_inputs = false; }
@@ -95,50 +101,59 @@ using TGQ = TileCfg<1, 1, 1, 2, 1>;  // grouped attention scores: 16 rows x 32 k
               [&] { hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, st, __VA_ARGS__); })
 
 template <int D, int H>
-static void launch_c1(const WaveWeights& w, const WaveState& s, int blk, hipStream_t st) {
+static void launch_c1(const WaveWeights& w, const WaveState& s, int blk, const Ring& h1, hipStream_t st) {
   static const char* const names[9] = {"", "wave.blk.c1.d1", "wave.blk.c1.d2", "", "wave.blk.c1.d4", "", "", "", "wave.blk.c1.d8"};
-  launch_auto<C1<D, H>>(names[D], conv_args(s.x[blk], s.h1, w.c1_w[blk], w.c1_b[blk], s.hop, s.B), st);
+  launch_auto<C1<D, H>>(names[D], conv_args(s.x[blk], h1, w.c1_w[blk], w.c1_b[blk], s.hop, s.B), st);
 }
 
 template <int H>
-static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t st, bool cond_done) {
+static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t st, bool cond_done, WavePart part) {
   const int B = s.B, rows = s.B * H;
+  const WaveState::Scratch& k = s.scr[part.scratch];
+  auto in_part = [&part](int seg) { return seg >= part.first && seg <= part.last; };
+  ConvArgs a;
   if (!cond_done) {
     const CondArgs ca = cond_args(w, s);
     launch_site(cond_info(s), st, [&] { hipLaunchKernelGGL(wave_cond_kernel, dim3(rows), dim3(256), 0, st, ca); });
   }
-  const Ring phone_in{s.d_phone, B_PHONE_CH, H, s.front_slots};
-  ConvArgs a = conv_args(phone_in, s.x[0], w.inp_w, w.inp_b, s.hop, B);
-  a.res = s.e;
-  launch_auto<INP<H>>("wave.inp", a, st);
+  if (in_part(1)) {
+    const Ring phone_in{s.d_phone, B_PHONE_CH, H, s.front_slots};
+    a = conv_args(phone_in, s.x[0], w.inp_w, w.inp_b, s.hop, B);
+    a.res = s.e;
+    launch_auto<INP<H>>("wave.inp", a, st);
+  }
   for (int blk = 0; blk < B_NBLOCKS; ++blk) {
+    if (!in_part(2 + blk)) continue;
     switch (blk) {
-      case 0: launch_c1<1, H>(w, s, blk, st); break;
-      case 1: launch_c1<2, H>(w, s, blk, st); break;
-      case 2: launch_c1<4, H>(w, s, blk, st); break;
-      default: launch_c1<8, H>(w, s, blk, st); break;
+      case 0: launch_c1<1, H>(w, s, blk, k.h1, st); break;
+      case 1: launch_c1<2, H>(w, s, blk, k.h1, st); break;
+      case 2: launch_c1<4, H>(w, s, blk, k.h1, st); break;
+      default: launch_c1<8, H>(w, s, blk, k.h1, st); break;
     }
-    a = conv_args(s.h1, s.xa, w.c2_w[blk], w.c2_b[blk], s.hop, B);
+    a = conv_args(k.h1, k.xa, w.c2_w[blk], w.c2_b[blk], s.hop, B);
     a.res = s.x[blk];
     launch_auto<C2<H>>("wave.blk.c2o", a, st);  // c2 and o are the same kernel symbol: one profile row
-    launch_auto<QL<H>>("wave.blk.q", conv_args(s.xa, s.q, w.q_w[blk], w.q_b[blk], s.hop, B), st);
-    a = conv_args(s.q, s.sc, s.d_kt[blk], nullptr, s.hop, B);
+    launch_auto<QL<H>>("wave.blk.q", conv_args(k.xa, k.q, w.q_w[blk], w.q_b[blk], s.hop, B), st);
+    a = conv_args(k.q, k.sc, s.d_kt[blk], nullptr, s.hop, B);
     a.scale = 0.0625f; a.perm = s.d_perm[blk]; a.tile_slot = s.d_tile_slot[blk];
     a.w_slot_stride = (size_t)B_HID * B_KV_LEN;
     launch_conv<SCORE<H>, TGQ>("wave.blk.attn_qk", a, s.n_tiles_max, st);
-    AttnPvArgs pa{s.sc.base, s.d_v[blk], s.o.base, s.d_perm[blk], s.d_tile_slot[blk]};
+    AttnPvArgs pa{k.sc.base, s.d_v[blk], k.o.base, s.d_perm[blk], s.d_tile_slot[blk]};
     MISC_LAUNCH("wave.blk.attn_pv", 2.0 * rows * 384 * 256 + 25.0 * rows * 384, 4.0 * (384.0 * 256 + rows * (384 + 256)),
                 attn_pv_kernel, dim3(s.n_tiles_max, B_HID / 32), dim3(256), pa);
-    a = conv_args(s.o, s.x[blk + 1], w.o_w[blk], w.o_b[blk], s.hop, B);
-    a.res = s.xa;
+    a = conv_args(k.o, s.x[blk + 1], w.o_w[blk], w.o_b[blk], s.hop, B);
+    a.res = k.xa;
     launch_auto<C2<H>>("wave.blk.c2o", a, st);
   }
   // upsampler: stage 1 and the stage-2 transposed conv as batched GEMMs (few rows per stream, large
   // weights), everything after that in one per-stream kernel
-  launch_auto<UP<256, 128, 5, H>>("wave.up1", conv_args(s.x[4], s.ya1, w.up_w[0], w.up_b[0], s.hop, B), st);
-  launch_auto<RES<128, 1, 5 * H>>("wave.res1a", conv_args(s.ya1, s.yb1, w.ra_w[0], w.ra_b[0], s.hop, B), st);
-  launch_auto<RES<128, 3, 5 * H>>("wave.res1b", conv_args(s.yb1, s.yc1, w.rb_w[0], w.rb_b[0], s.hop, B), st);
-  launch_auto<UP<128, 64, 4, 5 * H>>("wave.up2", conv_args(s.yc1, s.ya2, w.up_w[1], w.up_b[1], s.hop, B), st);
+  if (in_part(6)) {
+    launch_auto<UP<256, 128, 5, H>>("wave.up1", conv_args(s.x[4], s.ya1, w.up_w[0], w.up_b[0], s.hop, B), st);
+    launch_auto<RES<128, 1, 5 * H>>("wave.res1a", conv_args(s.ya1, s.yb1, w.ra_w[0], w.ra_b[0], s.hop, B), st);
+    launch_auto<RES<128, 3, 5 * H>>("wave.res1b", conv_args(s.yb1, s.yc1, w.rb_w[0], w.rb_b[0], s.hop, B), st);
+    launch_auto<UP<128, 64, 4, 5 * H>>("wave.up2", conv_args(s.yc1, s.ya2, w.up_w[1], w.up_b[1], s.hop, B), st);
+  }
+  if (!in_part(7)) return;
   TailArgs ta{};
   ta.in = s.ya2; ta.state = s.tail.base; ta.fin_w = w.fin_w; ta.fin_b = w.fin_b; ta.d_out = s.d_out; ta.hop = s.hop; ta.io_stride = s.io_stride;
   ta.w[0] = w.ra_w[1]; ta.b[0] = w.ra_b[1]; ta.w[1] = w.rb_w[1]; ta.b[1] = w.rb_b[1];
@@ -156,12 +171,12 @@ void wave_cond(const WaveWeights& w, const WaveState& s, hipStream_t st) {
   launch_site(cond_info(s), st, [&] { hipLaunchKernelGGL(wave_cond_kernel, dim3(s.B * s.H), dim3(256), 0, st, ca); });
 }
 
-void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t st, bool cond_done) {
+void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t st, bool cond_done, WavePart part) {
   switch (s.H) {
-    case 1: wave_forward_h<1>(w, s, st, cond_done); break;
-    case 2: wave_forward_h<2>(w, s, st, cond_done); break;
-    case 4: wave_forward_h<4>(w, s, st, cond_done); break;
-    default: wave_forward_h<8>(w, s, st, cond_done); break;
+    case 1: wave_forward_h<1>(w, s, st, cond_done, part); break;
+    case 2: wave_forward_h<2>(w, s, st, cond_done, part); break;
+    case 4: wave_forward_h<4>(w, s, st, cond_done, part); break;
+    default: wave_forward_h<8>(w, s, st, cond_done, part); break;
   }
 }
 

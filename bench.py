@@ -272,9 +272,9 @@ def main():
                          "3 = 256 streams/GPU, 64 rotating speakers, VQ k=4; 4 = 64 streams/GPU, 48 kHz stereo, wrapper on the device")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-pipeline", action="store_true",
-                    help="keep both halves of a step on one HIP stream (default: BeatriceBatch_EnablePipelining, the front end "
-                         "of step t+1 overlaps the waveform generator of step t while steps are enqueued ahead)")
+    ap.add_argument("--pipeline-depth", type=int, default=3, choices=(0, 2, 3, 4),
+                    help="BeatriceBatch_EnablePipelining: stages of the per-hop chain that overlap across consecutive steps "
+                         "while steps are enqueued ahead (0 = off: one HIP stream, in order)")
     ap.add_argument("--copy-io", action="store_true",
                     help="device-to-device copy of each hop into / out of the library's own buffers instead of "
                          "binding the resident audio buffers (BeatriceBatch_BindResidentIO)")
@@ -348,8 +348,8 @@ def main():
     resident = a.config != 4 and not a.copy_io
     d_out = torch.zeros((n_cycle if resident else 1, B, 240), dtype=torch.float32, device="cuda")
     base, hop_bytes = d_audio.data_ptr(), B * 160 * 4
-    pipelined = a.config != 4 and not a.no_pipeline
-    if pipelined and product.BeatriceBatch_EnablePipelining(batch.h, 1):
+    pipelined = a.pipeline_depth if a.config != 4 else 0
+    if pipelined and product.BeatriceBatch_EnablePipelining(batch.h, pipelined):
         raise SystemExit("EnablePipelining failed")
     if resident:  # the 64 resident hops are the slots: every step reads one and writes one, no copy
         if product.BeatriceBatch_BindResidentIO(batch.h, d_audio.data_ptr(), d_out.data_ptr(), n_cycle):
@@ -388,6 +388,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(a.warmup + i)
+    enqueue_s = time.perf_counter() - t0   # host time to enqueue all steps (the GPU may lag behind)
     if product.BeatriceBatch_Synchronize(batch.h):  # both of the batch's streams (torch only knows its own)
         raise SystemExit("Synchronize failed")
     torch.cuda.synchronize()
@@ -410,12 +411,14 @@ def main():
                                     4: "BASELINE.json configs[4] per-GPU share: %d streams of 48 kHz stereo, downmix + resample "
                                        "wrapper on the device, 480-sample blocks" % B}[a.config],
                        "streams_per_gpu": B, "speakers": a.speakers, "hipgraph": not a.no_graph,
-                       "pipelining": "front end of step t+1 overlaps the waveform generator of step t (two HIP streams), steps "
-                                     "enqueued without waiting" if pipelined else "off: one stream, halves in order",
+                       "pipelining": ("%d stages of the chain on %d HIP streams; stage s of step t+1 overlaps stage s+1 of step t, "
+                                      "steps enqueued without waiting" % (pipelined, pipelined)) if pipelined
+                                     else "off: one stream, in order",
                        "io": "resident device buffers, 64 hops per stream cycled, bound as I/O slots (no per-step copy)" if resident
                              else "resident device buffers, one device-to-device copy in and out per step",
                        "parallelism": "streams sharded over %d GPU(s), no per-hop collective" % world},
             "x_realtime_per_stream": round(a.steps / elapsed / 100.0, 2), "output_rms": round(out_rms, 4),
+            "host_enqueue_ms_per_step": round(1e3 * enqueue_s / a.steps, 4),
         }
         if not a.no_extras:
             # per-kernel timing with HIP events on the library's own stream (eager, 10 launches per bracket)

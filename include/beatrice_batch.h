@@ -131,10 +131,12 @@ int BeatriceBatch_SetStream(BeatriceBatch* b, void* hip_stream);
 void* BeatriceBatch_GetStream(const BeatriceBatch* b);
 int BeatriceBatch_EnableGraph(BeatriceBatch* b, int enable);
 /* Throughput mode for callers that enqueue steps ahead of their completion (BeatriceBatch_ConvertFramesDevice
- * without waiting, resident I/O): the front end (content encoder, pitch estimator) of step t+1 runs on the
- * batch's stream while the waveform generator of step t runs on a second, internal stream.  Same samples.
- * A step's output is complete after BeatriceBatch_Synchronize, or in stream order on BeatriceBatch_GetWaveStream.
- * Off by default (everything in order on the batch's stream); the 48 kHz entry points need it off. */
+ * without waiting, resident I/O).  The per-hop chain is ~40 dependent, latency-bound launches that leave most of
+ * the chip idle; with a pipeline depth n = 2..4 it is cut into n stages (front end = content encoder + pitch
+ * estimator; the waveform generator in 1..3 parts) on n HIP streams, and stage s of step t+1 overlaps stage s+1 of
+ * step t.  Same samples (bit for bit).  enable: 0 = off (default: everything in order on the batch's stream),
+ * 1 = depth 2, 2..4 = that depth.  A step's output is complete after BeatriceBatch_Synchronize, or in stream order
+ * on BeatriceBatch_GetWaveStream.  The 48 kHz entry points need it off. */
 int BeatriceBatch_EnablePipelining(BeatriceBatch* b, int enable);
 void* BeatriceBatch_GetWaveStream(const BeatriceBatch* b);
 

@@ -28,10 +28,10 @@ class Hip:
         self.lib.hipFree(p)
 
 
-@pytest.mark.parametrize("B,H,slots,steps,pipelined", [(7, 1, 5, 13, 0), (4, 4, 3, 7, 0), (37, 1, 6, 18, 1), (5, 2, 4, 11, 1)])
+@pytest.mark.parametrize("B,H,slots,steps,pipelined", [(7, 1, 5, 13, 0), (4, 4, 3, 7, 0), (37, 1, 6, 18, 2), (5, 2, 4, 11, 3), (19, 1, 7, 23, 3), (40, 1, 9, 30, 4)])
 def test_resident_io_matches_host_buffers(bv, product, model_dir, B, H, slots, steps, pipelined):
-    """pipelined = 1: BeatriceBatch_EnablePipelining -- the front end of step t+1 overlaps the waveform generator
-    of step t on a second stream while steps are enqueued without waiting; settings keep changing in between."""
+    """pipelined = 2..4: BeatriceBatch_EnablePipelining with that many stages -- stage s of step t+1 overlaps stage s+1
+    of step t on separate streams while steps are enqueued without waiting; settings keep changing in between."""
     hip = Hip()
     audio = np.stack([bv.synth_audio(160 * H * steps, seed=40 + s) for s in range(B)])  # [B][steps*H*160]
     m = bv.Models(product, model_dir)

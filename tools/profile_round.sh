@@ -1,6 +1,8 @@
 #!/bin/bash
 # Measurement recipe of one round (run on a GPU box from the repo root, e.g. through gpurun):
 #   tools/profile_round.sh r01_e
+# (the profiled passes run the chain in order on one stream, --pipeline-depth 0, so that per-kernel durations are
+# those of the kernel alone, like the HIP-event timing inside bench.py; the headline line itself is pipelined)
 # writes under gpurun_out/<tag>/: the bench line, the rocprofv3 kernel-trace/stats summary of the same
 # command, and three separate PMC passes (FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES) reduced to
 # per-kernel means.  Copy what
@@ -16,13 +18,13 @@ python "$ROOT/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -c 400 "$OUT/bench.err"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o k -- \
-  python "$ROOT/bench.py" --no-extras --steps 200 --warmup 20 > "$OUT/bench_under_rocprof.json" 2> /dev/null
+  python "$ROOT/bench.py" --no-extras --pipeline-depth 0 --steps 200 --warmup 20 > "$OUT/bench_under_rocprof.json" 2> /dev/null
 STATS=$(find "$OUT/prof" -name 'k_kernel_stats.csv' | head -1)
 [ -n "$STATS" ] && cp "$STATS" "$OUT/kernel_stats_B256.csv"
 
 for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- \
-    python "$ROOT/bench.py" --no-extras --steps 20 --warmup 5 > /dev/null 2>&1
+    python "$ROOT/bench.py" --no-extras --pipeline-depth 0 --steps 20 --warmup 5 > /dev/null 2>&1
   CSV=$(find "$OUT/pmc_$C" -name 'pmc_counter_collection.csv' | head -1)
   mkdir -p "$OUT/pmc_r1_$C"
   [ -n "$CSV" ] && cp "$CSV" "$OUT/pmc_r1_$C/pmc_counter_collection.csv"
