@@ -169,7 +169,7 @@ struct BeatriceBatch {
   int last_parity = 0;  // parity of the last enqueued step (slot of its phone vectors)
   int* d_hop_wave = nullptr;  // int[4][2]: {counter, I/O slot} of step t at [t & 3], for the waveform generator's stages
   bool use_graph = true;
-  hipGraph_t graph[kMaxStages][kSlots] = {};      // stage 0 uses [0][0] only
+  hipGraph_t graph[kMaxStages][kSlots] = {};      // pipelined: stage 0 uses [0][0] only; in order: [0][slot] holds the whole step
   hipGraphExec_t exec[kMaxStages][kSlots] = {};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int* d_hop_next = nullptr;  // {step counter, resident-I/O slot}, double-buffered: first kernels read it, the last one writes it
@@ -344,6 +344,16 @@ bool capture(hipStream_t st, hipGraph_t* graph, hipGraphExec_t* exec, F enqueue)
   return true;
 }
 
+// pipelining off: the whole step as ONE launch on the batch's stream (a second graph launch per step costs ~15 us)
+bool run_step_in_order(BeatriceBatch* b, int slot) {
+  hipStream_t st = b->stream;
+  auto enqueue = [b, slot, st] { enqueue_front(b, st); for (int s = 1; s < b->n_stages; ++s) enqueue_wave(b, s, slot, st); };
+  if (!b->use_graph) { enqueue(); return hip_ok(hipGetLastError(), "step launch"); }
+  if (!b->exec[0][slot] && !capture(st, &b->graph[0][slot], &b->exec[0][slot], enqueue)) return false;
+  BHIP_TRY(hipGraphLaunch(b->exec[0][slot], st));
+  return true;
+}
+
 bool run_stage(BeatriceBatch* b, int stage, int slot) {
   hipStream_t st = stage_stream(b, stage);
   auto enqueue = [b, stage, slot, st] { if (stage == 0) enqueue_front(b, st); else enqueue_wave(b, stage, slot, st); };
@@ -394,6 +404,19 @@ bool step_device(BeatriceBatch* b, const float* d_in, float* d_out) {
   const long long t = b->steps_enqueued;
   const int slot = b->hop_host & 3, slot2 = (slot + 2) & 3, last = b->n_stages - 1;
   hipStream_t fs = b->stream;
+  if (!b->pipelined) {
+    if (!push_settings(b, slot)) return false;
+    if (d_in && d_in != b->d_in)
+      BHIP_TRY(hipMemcpyAsync(b->d_in, d_in, sizeof(float) * b->B * b->H * B_IN_HOP, hipMemcpyDeviceToDevice, fs));
+    if (!run_step_in_order(b, slot)) return false;
+    if (d_out && d_out != b->wave.d_out)
+      BHIP_TRY(hipMemcpyAsync(d_out, b->wave.d_out, sizeof(float) * b->B * b->H * B_OUT_HOP, hipMemcpyDeviceToDevice, fs));
+    b->last_parity = b->hop_host & 1;
+    b->hop_host = hop_next(b->hop_host);
+    b->steps_enqueued = t + 1;
+    b->inflight = true;
+    return true;
+  }
   // ordering rules: see the comment at BeatriceBatch::n_stages
   if (t >= 2) BHIP_TRY(hipStreamWaitEvent(fs, b->ev_done[1][slot2], 0));
   if (t >= 4) BHIP_TRY(hipStreamWaitEvent(fs, b->ev_done[last][slot], 0));

@@ -242,6 +242,18 @@ def host_buffer_rate(bv, models, product, streams, steps=200):
             "bytes_over_pcie_per_step": streams * (160 + 240) * 4}
 
 
+def hop_synchronous(bv, models, product, streams, steps=300):
+    """The same chain with pipelining off: every step complete before the next starts (what a real-time server that
+    receives one hop per stream every 10 ms runs); its step time is the latency of a 256-stream hop."""
+    batch = bv.Batch(models, streams)
+    product.BeatriceBatch_FlushSpeaker(batch.h, -1)
+    batch.time_steps(30)
+    ms = batch.time_steps(steps)
+    batch.close()
+    return {"frames_per_s": round(streams * steps / (ms * 1e-3), 1), "ms_per_step": round(ms / steps, 4),
+            "x_realtime_per_stream": round(10.0 / (ms / steps), 1)}
+
+
 def latency_b1(bv, product, model_dir, hops=400):
     """BASELINE.json configs[1]: 1 stream, 1 speaker, hop-synchronous 1-stream C-ABI."""
     m = bv.Models(product, model_dir)
@@ -455,6 +467,7 @@ def main():
             res["kernels"] = [{"name": r["name"], "n": r["launches"], "us": round(r["mean_us"], 2)}
                               for r in sorted(rows, key=lambda r: -r["total_us"])[:12]]
             if world == 1:
+                res["hop_synchronous"] = hop_synchronous(bv, m, product, B)
                 res["saturation"] = saturation(bv, m, product)
                 res["block_mode"] = block_mode(bv, m, product, B)
                 res["morph"] = morph_timing(bv, product)
