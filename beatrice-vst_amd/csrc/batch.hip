@@ -517,8 +517,7 @@ BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* pho
   b->phone.hop_publish = b->phone.d_hop; b->phone.hop_publish_wave = b->d_hop_wave;
   b->wave.front_hop = b->phone.d_hop; b->wave.front_next_out = b->d_hop_next;
   b->phone.advance_hop = false; b->pitch.advance_hop = false; b->wave.advance_hop = false;
-  for (int s = 0; s < BeatriceBatch::kMaxStages && ok; ++s) {
-    if (s > 0) ok = make_stage_stream(&b->stage_stream_own[s], s);
+  for (int s = 0; s < BeatriceBatch::kMaxStages && ok; ++s) {  // (stage streams are created when a pipeline depth asks for them)
     for (int k = 0; k < BeatriceBatch::kSlots && ok; ++k) ok = hip_ok(hipEventCreateWithFlags(&b->ev_done[s][k], hipEventDisableTiming), "ev");
   }
   set_plan(b, 1);
@@ -923,6 +922,8 @@ int BeatriceBatch_EnablePipelining(BeatriceBatch* b, int enable) {
   if (enable < 0 || enable > BeatriceBatch::kMaxStages) return -1;
   drop_graph(b);  // stages are captured on the streams they will run on
   set_plan(b, enable == 1 ? 2 : enable);  // 1 = the default depth
+  for (int s = 1; s < b->n_stages && b->pipelined; ++s)  // every stream takes a hardware queue: only those in use exist
+    if (!b->stage_stream_own[s] && !make_stage_stream(&b->stage_stream_own[s], s)) return -2;
   return 0;
 }
 void* BeatriceBatch_GetWaveStream(const BeatriceBatch* b) { return b ? wave_stream(b) : nullptr; }

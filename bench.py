@@ -15,6 +15,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
   cpu_baseline  -- the CPU oracle (oracle/, a port of the frozen spec -- NOT the proprietary
                    beatricelib, which has no Linux build) timed on this box's host cores.
 """
+import os as _os
+# A pipeline depth of 4 keeps four HIP streams busy; ROCm maps streams onto 4 hardware queues by default, and a
+# stream that shares a queue with another one waits for it.  Must be set before the HIP runtime initialises.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import argparse
 import ctypes
 import importlib.util
@@ -284,7 +288,7 @@ def main():
                          "3 = 256 streams/GPU, 64 rotating speakers, VQ k=4; 4 = 64 streams/GPU, 48 kHz stereo, wrapper on the device")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--pipeline-depth", type=int, default=3, choices=(0, 2, 3, 4),
+    ap.add_argument("--pipeline-depth", type=int, default=4, choices=(0, 2, 3, 4),
                     help="BeatriceBatch_EnablePipelining: stages of the per-hop chain that overlap across consecutive steps "
                          "while steps are enqueued ahead (0 = off: one HIP stream, in order)")
     ap.add_argument("--copy-io", action="store_true",
@@ -424,7 +428,7 @@ def main():
                                        "wrapper on the device, 480-sample blocks" % B}[a.config],
                        "streams_per_gpu": B, "speakers": a.speakers, "hipgraph": not a.no_graph,
                        "pipelining": ("%d stages of the chain on %d HIP streams; stage s of step t+1 overlaps stage s+1 of step t, "
-                                      "steps enqueued without waiting" % (pipelined, pipelined)) if pipelined
+                                      "steps enqueued without waiting; GPU_MAX_HW_QUEUES=%s" % (pipelined, pipelined, os.environ.get("GPU_MAX_HW_QUEUES"))) if pipelined
                                      else "off: one stream, in order",
                        "io": "resident device buffers, 64 hops per stream cycled, bound as I/O slots (no per-step copy)" if resident
                              else "resident device buffers, one device-to-device copy in and out per step",

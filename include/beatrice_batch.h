@@ -136,7 +136,9 @@ int BeatriceBatch_EnableGraph(BeatriceBatch* b, int enable);
  * estimator; the waveform generator in 1..3 parts) on n HIP streams, and stage s of step t+1 overlaps stage s+1 of
  * step t.  Same samples (bit for bit).  enable: 0 = off (default: everything in order on the batch's stream),
  * 1 = depth 2, 2..4 = that depth.  A step's output is complete after BeatriceBatch_Synchronize, or in stream order
- * on BeatriceBatch_GetWaveStream.  The 48 kHz entry points need it off. */
+ * on BeatriceBatch_GetWaveStream.  The 48 kHz entry points need it off.  Depth 4 needs more hardware queues than ROCm
+ * hands a process by default (environment GPU_MAX_HW_QUEUES=8, set before the HIP runtime starts): streams that
+ * share a queue do not overlap, and depth 4 then runs slower than depth 3. */
 int BeatriceBatch_EnablePipelining(BeatriceBatch* b, int enable);
 void* BeatriceBatch_GetWaveStream(const BeatriceBatch* b);
 
