@@ -153,9 +153,11 @@ struct BeatriceBatch {
   // steps ahead of their completion: the chain is a string of ~40 launches that are each latency-bound and leave
   // most of the chip idle, so several steps in flight at different depths of the chain fill it.  Ordering:
   //   stage s of step t   after stage s-1 of step t        (data of the same step)
-  //   stage s of step t   after stage s+1 of step t-2      (buffers that cross a stage boundary hold two steps:
-  //                                                          two-slot phone / conditioning buffers, one spare slot
-  //                                                          on the rings x[], ya2; the stages' scratch is private)
+  //   stage s of step t   after stage s+1 of step t-3      (buffers that cross a stage boundary hold three steps:
+  //                                                          three-slot phone / conditioning buffers, two spare slots
+  //                                                          on the rings x[], ya2; the stages' scratch is private.
+  //                                                          One step of slack keeps the ~20 us cross-stream hand-over
+  //                                                          off the critical path: +2 % over two-step buffers)
   //   stage 0 of step t   after the last stage of step t-4 (counter pairs and attention tile lists have 4 copies)
   // Outputs are identical; a step that is waited for before the next is enqueued runs exactly as without pipelining.
   static constexpr int kMaxStages = 4, kSlots = 4;
@@ -166,7 +168,7 @@ struct BeatriceBatch {
   hipEvent_t ev_done[kMaxStages][kSlots] = {};    // stage s of step t enqueued/done, at [t & 3]
   long long steps_enqueued = 0;
   int hop_host = 0;     // mirror of the device step counter (same increments, same wrap)
-  int last_parity = 0;  // parity of the last enqueued step (slot of its phone vectors)
+  int last_parity = 0;  // slot (step counter mod 3) of the last enqueued step's phone vectors
   int* d_hop_wave = nullptr;  // int[4][2]: {counter, I/O slot} of step t at [t & 3], for the waveform generator's stages
   bool use_graph = true;
   hipGraph_t graph[kMaxStages][kSlots] = {};      // pipelined: stage 0 uses [0][0] only; in order: [0][slot] holds the whole step
@@ -402,7 +404,7 @@ bool step_device(BeatriceBatch* b, const float* d_in, float* d_out) {
   draw_codebooks(b);
   if (b->vq_dirty) { update_vq_mode(b); b->vq_dirty = false; }
   const long long t = b->steps_enqueued;
-  const int slot = b->hop_host & 3, slot2 = (slot + 2) & 3, last = b->n_stages - 1;
+  const int slot = b->hop_host & 3, slot2 = (slot + 1) & 3 /* step t-3 */, last = b->n_stages - 1;
   hipStream_t fs = b->stream;
   if (!b->pipelined) {
     if (!push_settings(b, slot)) return false;
@@ -411,14 +413,14 @@ bool step_device(BeatriceBatch* b, const float* d_in, float* d_out) {
     if (!run_step_in_order(b, slot)) return false;
     if (d_out && d_out != b->wave.d_out)
       BHIP_TRY(hipMemcpyAsync(d_out, b->wave.d_out, sizeof(float) * b->B * b->H * B_OUT_HOP, hipMemcpyDeviceToDevice, fs));
-    b->last_parity = b->hop_host & 1;
+    b->last_parity = b->hop_host % 3;
     b->hop_host = hop_next(b->hop_host);
     b->steps_enqueued = t + 1;
     b->inflight = true;
     return true;
   }
   // ordering rules: see the comment at BeatriceBatch::n_stages
-  if (t >= 2) BHIP_TRY(hipStreamWaitEvent(fs, b->ev_done[1][slot2], 0));
+  if (t >= 3) BHIP_TRY(hipStreamWaitEvent(fs, b->ev_done[1][slot2], 0));
   if (t >= 4) BHIP_TRY(hipStreamWaitEvent(fs, b->ev_done[last][slot], 0));
   if (!push_settings(b, slot)) return false;
   if (d_in && d_in != b->d_in)
@@ -428,13 +430,13 @@ bool step_device(BeatriceBatch* b, const float* d_in, float* d_out) {
   for (int s = 1; s <= last; ++s) {
     hipStream_t st = stage_stream(b, s);
     BHIP_TRY(hipStreamWaitEvent(st, b->ev_done[s - 1][slot], 0));
-    if (s < last && t >= 2) BHIP_TRY(hipStreamWaitEvent(st, b->ev_done[s + 1][slot2], 0));
+    if (s < last && t >= 3) BHIP_TRY(hipStreamWaitEvent(st, b->ev_done[s + 1][slot2], 0));
     if (!run_stage(b, s, slot)) return false;
     if (s == last && d_out && d_out != b->wave.d_out)
       BHIP_TRY(hipMemcpyAsync(d_out, b->wave.d_out, sizeof(float) * b->B * b->H * B_OUT_HOP, hipMemcpyDeviceToDevice, st));
     BHIP_TRY(hipEventRecord(b->ev_done[s][slot], st));
   }
-  b->last_parity = b->hop_host & 1;
+  b->last_parity = b->hop_host % 3;
   b->hop_host = hop_next(b->hop_host);
   b->steps_enqueued = t + 1;
   b->inflight = true;
@@ -501,9 +503,9 @@ BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* pho
   b->owns_stream = ok;
   ok = ok && hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_in), sizeof(float) * B * H * B_IN_HOP), "d_in") &&
        hip_ok(hipMemset(b->d_in, 0, sizeof(float) * B * H * B_IN_HOP), "d_in0");
-  // the front end's outputs (phone vector, conditioning mix) have two step slots: see `pipelined`
-  ok = ok && b->phone.create(B, H, b->d_in, 2) && b->pitch.create(B, H, b->d_in, true) &&
-       b->wave.create(B, H, S, S, 9, b->phone.d_phone, b->pitch.d_q, b->pitch.d_feat, 2);
+  // the front end's outputs (phone vector, conditioning mix) have three step slots: see `pipelined`
+  ok = ok && b->phone.create(B, H, b->d_in, 3) && b->pitch.create(B, H, b->d_in, true) &&
+       b->wave.create(B, H, S, S, 9, b->phone.d_phone, b->pitch.d_q, b->pitch.d_feat, 3);
   // The modules advance in lockstep: one step counter, with no launch spent on incrementing it.  The step's
   // first kernels (phone.f1, pitch.fft) read the pair {counter, I/O slot} from d_hop_next; phone.f1 publishes
   // it to phone.d_hop for the rest of the front end and to d_hop_wave[counter & 1] for the waveform generator
@@ -933,7 +935,7 @@ float* BeatriceBatch_DeviceOutput(BeatriceBatch* b) { return b && b->ok ? b->wav
 int BeatriceBatch_GetIntermediates(BeatriceBatch* b, float* phone, int* q_raw, int* q, float* feat) {
   if (!b || !b->ok) return -2;
   bool ok = sync_all(b);
-  if (phone) {  // the phone vectors of the last step sit in one of the two step slots of a per-stream ring
+  if (phone) {  // the phone vectors of the last step sit in one of the three step slots of a per-stream ring
     const size_t row = sizeof(float) * b->H * B_PHONE_CH;
     ok = ok && hip_ok(hipMemcpy2D(phone, row, b->phone.d_phone + (size_t)b->last_parity * b->H * B_PHONE_CH, row * b->phone.out_slots, row,
                                   b->B, hipMemcpyDeviceToHost), "phone");
@@ -986,7 +988,7 @@ int BeatriceBatch_ProfileKernels(BeatriceBatch* b, int repeats, int max_entries,
   enqueue_front(b, b->stream);  // one step, eagerly, every stage on the batch's stream
   for (int st = 1; st < b->n_stages; ++st) enqueue_wave(b, st, slot, b->stream);
   launch_hook() = nullptr;
-  b->last_parity = b->hop_host & 1;
+  b->last_parity = b->hop_host % 3;
   b->hop_host = hop_next(b->hop_host);
   if (!hook.ok || !sync_all(b)) return -2;
   const int n = std::min<int>((int)hook.rows.size(), max_entries);

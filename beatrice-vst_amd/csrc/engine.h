@@ -82,7 +82,7 @@ struct PhoneState {
   int* hop_mailbox = nullptr;  // owned d_in only: one int right behind the audio (counter sent with the input copy)
   size_t io_stride = 0;        // batch, resident I/O: d_in holds several steps, this many floats apart (slot = hop[1])
   float* d_phone = nullptr;  // ring [B][out_slots * H][128]: step t writes slot t mod out_slots
-  int out_slots = 1;         // 2 in a batch, so that the next step's front end may run while the waveform generator reads
+  int out_slots = 1;         // 3 in a batch, so that the next steps' front end may run while the waveform generator reads
   const float** d_cbT = nullptr;    // [B] device pointers
   const float** d_cnorm = nullptr;  // [B]
   int* d_vqk = nullptr;             // [B]
@@ -160,7 +160,8 @@ struct WaveState {
   // different steps can be in flight at once (batch.hip)
   static constexpr int kScratchSets = 4;
   struct Scratch { Ring h1, xa, q, sc, o; } scr[kScratchSets];
-  int boundary_slots = 0;   // extra step slots on the rings a pipeline stage boundary may cut (x[], ya2): 0, or 1 in a batch
+  int boundary_slots = 0;   // extra step slots on the rings a pipeline stage boundary may cut (x[], ya2): 0, or 2 in a batch
+                            // (rounded up to a slot count that divides the step counter's wrap)
   Ring ya1, yb1, yc1, ya2;  // upsampler stage 1 and the stage-2 transposed conv output
   Ring tail;                // per-stream history block of the fused upsampler tail (wave_tail.hip.h)
   // inputs (device): phone [B][H][128], q [B][H], feat [B][H][4]; owned unless shared with other modules
@@ -183,7 +184,7 @@ struct WaveState {
   // in a batch, stores the next step's {counter, I/O slot} (no front-end kernel reads that pair after the first launch)
   const int* front_hop = nullptr;  // nullptr: same counter as the rest of the module
   int* front_next_out = nullptr;
-  int front_slots = 1;             // step slots of the front end's outputs (phone vector, conditioning e): 1, or 2 in a batch
+  int front_slots = 1;             // step slots of the front end's outputs (phone vector, conditioning e): 1, or 3 in a batch
   bool advance_hop = true;    // this module's forward ends with the counter increment
   bool create(int B, int H, int n_slots, int n_add, int n_frm, float* shared_phone, int* shared_q, float* shared_feat,
               int front_slots = 1);

@@ -10,16 +10,17 @@ static const int kBlockDil[B_NBLOCKS] = {1, 2, 4, 8};
 bool WaveState::create(int B_, int H_, int n_slots_, int n_add_, int n_frm_, float* shared_phone, int* shared_q,
                        float* shared_feat, int front_slots_) {
   B = B_; H = H_; n_slots = n_slots_; n_add = n_add_; n_frm = n_frm_; front_slots = front_slots_;
-  boundary_slots = front_slots_ > 1 ? 1 : 0;  // a batch may cut the module into pipeline stages
+  boundary_slots = front_slots_ > 1 ? 2 : 0;  // a batch may cut the module into pipeline stages
   const int xs = boundary_slots;
+  auto fit = [](int m) { while (B_HOP_WRAP % m != 0) ++m; return m; };
   const int rows = B * H;
   n_tiles_max = (rows + 15) / 16 + n_slots;  // rows grouped by slot: at most one partial tile per slot
   auto slots = [&](int n0, int hist) { return 1 + (hist + n0 * H - 1) / (n0 * H); };
   std::vector<RingSpec> specs = {
       {&e, B_HID, H, front_slots},
-      {&x[0], B_HID, H, slots(1, 2 * kBlockDil[0]) + xs}, {&x[1], B_HID, H, slots(1, 2 * kBlockDil[1]) + xs},
-      {&x[2], B_HID, H, slots(1, 2 * kBlockDil[2]) + xs}, {&x[3], B_HID, H, slots(1, 2 * kBlockDil[3]) + xs},
-      {&x[4], B_HID, H, slots(1, 1) + xs},
+      {&x[0], B_HID, H, fit(slots(1, 2 * kBlockDil[0]) + xs)}, {&x[1], B_HID, H, fit(slots(1, 2 * kBlockDil[1]) + xs)},
+      {&x[2], B_HID, H, fit(slots(1, 2 * kBlockDil[2]) + xs)}, {&x[3], B_HID, H, fit(slots(1, 2 * kBlockDil[3]) + xs)},
+      {&x[4], B_HID, H, fit(slots(1, 1) + xs)},
   };
   for (int i = 0; i < (boundary_slots ? kScratchSets : 1); ++i) {
     specs.push_back({&scr[i].h1, B_HID, H, 1}); specs.push_back({&scr[i].xa, B_HID, H, 1}); specs.push_back({&scr[i].q, B_HID, H, 1});
@@ -28,7 +29,7 @@ bool WaveState::create(int B_, int H_, int n_slots_, int n_add_, int n_frm_, flo
   specs.push_back({&ya1, 128, 5 * H, slots(5, 2)});   // history 2 (res1a, k3)
   specs.push_back({&yb1, 128, 5 * H, slots(5, 6)});   // history 6 (res1b, k3 dil 3)
   specs.push_back({&yc1, 128, 5 * H, slots(5, 1)});   // history 1 (up2)
-  specs.push_back({&ya2, 64, 20 * H, slots(20, 2) + xs});  // history 2 (first layer of the fused tail)
+  specs.push_back({&ya2, 64, 20 * H, fit(slots(20, 2) + xs)});  // history 2 (first layer of the fused tail)
   specs.push_back({&tail, TAIL_STATE_FLOATS, 1, 1});
   if (!arena.build(B, specs)) return false;
   if (shared_phone) { d_phone = shared_phone; d_q = shared_q; d_feat = shared_feat; owns_inputs = false; }
