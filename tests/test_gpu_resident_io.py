@@ -48,6 +48,8 @@ def test_resident_io_matches_host_buffers(bv, product, model_dir, B, H, slots, s
             batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, s, (k + s) % 3)
             batch.a.BeatriceBatch_SetFormantShift(batch.h, (s + 1) % B, float(k % 5) - 2.0)
             batch.a.BeatriceBatch_SetVQNumNeighbors(batch.h, (s + 2) % B, k % 4)
+        if k == 5:
+            assert batch.a.BeatriceBatch_ResetStream(batch.h, 1) == 0   # fresh state for one stream, mid-flight
 
     # reference: the synchronous host-buffer entry point
     ref_batch = bv.Batch(m, B, hops_per_step=H)

@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""frames/s over batch size x hops per step x pipeline depth (BeatriceBatch_TimeSteps on resident buffers).
+Run with GPU_MAX_HW_QUEUES=8 for depth 4."""
 import importlib.util, os, sys, tempfile
-REPO = "/root/repo" if os.path.exists("/root/repo/bench.py") else os.getcwd()
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 spec = importlib.util.spec_from_file_location("beatrice_vst_amd", os.path.join(REPO, "beatrice-vst_amd", "__init__.py"))
 bv = importlib.util.module_from_spec(spec); sys.modules["beatrice_vst_amd"] = bv; spec.loader.exec_module(bv)
 sys.path.insert(0, os.path.join(REPO, "tools"))
