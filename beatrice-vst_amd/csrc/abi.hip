@@ -65,6 +65,20 @@ static Beatrice_ErrorCode install(Obj* m, std::vector<float>& host) {
 
 bool make_stream(hipStream_t* s) { BHIP_TRY(hipStreamCreateWithFlags(s, hipStreamNonBlocking)); return true; }
 
+// Completion wait of the synchronous per-hop calls.  They run on the host's audio thread, which has nothing else
+// to do until the ~100 us of device work are done: polling the stream returns a few microseconds after the last
+// copy lands, a blocking hipStreamSynchronize only after the runtime's wake-up path (352 -> 328 us per hop of
+// three calls, profiles/r01_notes.md).  Falls back to the blocking wait if the work is unusually long.
+bool wait_stream(hipStream_t s) {
+  for (int spins = 0; spins < 200000; ++spins) {
+    const hipError_t e = hipStreamQuery(s);
+    if (e == hipSuccess) return true;
+    if (e != hipErrorNotReady) return hip_ok(e, "stream query");
+    __builtin_ia32_pause();
+  }
+  return hip_ok(hipStreamSynchronize(s), "sync");
+}
+
 }  // namespace bhip
 
 extern "C" {
@@ -153,7 +167,7 @@ void Beatrice20rc0_ExtractPhone1(const Beatrice20rc0_PhoneExtractor* m, const fl
   bool ok = hip_ok(hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * (B_IN_HOP + 1), hipMemcpyHostToDevice, ctx->stream), "in");
   phone_forward(m->w, ctx->st, ctx->stream);
   ok = ok && hip_ok(hipMemcpyAsync(h_out, ctx->st.d_phone, sizeof(float) * B_PHONE_CH, hipMemcpyDeviceToHost, ctx->stream), "out");
-  ok = hip_ok(hipStreamSynchronize(ctx->stream), "sync") && ok;
+  ok = wait_stream(ctx->stream) && ok;
   if (ok) std::memcpy(output, h_out, sizeof(float) * B_PHONE_CH);
 }
 
@@ -216,7 +230,7 @@ void Beatrice20rc0_EstimatePitch1(const Beatrice20rc0_PitchEstimator* m, const f
   pitch_forward(m->w, ctx->st, ctx->stream);
   ok = ok && hip_ok(hipMemcpyAsync(h_feat, ctx->st.d_feat, sizeof(float) * 4, hipMemcpyDeviceToHost, ctx->stream), "feat");
   ok = ok && hip_ok(hipMemcpyAsync(h_q, ctx->st.d_q_raw, sizeof(int), hipMemcpyDeviceToHost, ctx->stream), "q");
-  ok = hip_ok(hipStreamSynchronize(ctx->stream), "sync") && ok;
+  ok = wait_stream(ctx->stream) && ok;
   if (ok) { *out_q = *h_q; std::memcpy(out_feat, h_feat, sizeof(float) * 4); }
 }
 
@@ -273,7 +287,7 @@ void Beatrice20rc0_GenerateWaveform1(const Beatrice20rc0_WaveformGenerator* m, c
   bool ok = hip_ok(hipMemcpyAsync(ctx->d_inputs, h_in, sizeof(float) * in_floats, hipMemcpyHostToDevice, ctx->stream), "in");
   wave_forward(m->w, ctx->st, ctx->stream);
   ok = ok && hip_ok(hipMemcpyAsync(h_out, ctx->st.d_out, sizeof(float) * B_OUT_HOP, hipMemcpyDeviceToHost, ctx->stream), "out");
-  ok = hip_ok(hipStreamSynchronize(ctx->stream), "sync") && ok;
+  ok = wait_stream(ctx->stream) && ok;
   if (ok) std::memcpy(output, h_out, sizeof(float) * B_OUT_HOP);
 }
 
