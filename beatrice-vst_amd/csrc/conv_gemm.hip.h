@@ -231,11 +231,16 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bx, 
     }
   };
   if constexpr (PF) {
+    // addresses first (scalar ring arithmetic, integer division included), then every load back to back: a load
+    // issued in the middle of the address code made the compiler wait for ALL outstanding loads (s_waitcnt vmcnt(0))
     const int pos_out = ring_pos(a.out, hop), R_out = a.out.n * a.out.m;
+    int pos_res = 0, R_res = 0;
+    if constexpr (L::RES) { pos_res = ring_pos(a.res, hop); R_res = a.res.n * a.res.m; }
+    int src_res[E_SLOTS], src_rs[E_SLOTS], src_n[E_SLOTS];
 #pragma unroll
     for (int sl = 0; sl < E_SLOTS; ++sl) {
       int r, n, b = -1, t = 0;
-      pf_dst[sl] = -1; pf_bias[sl] = 0.f; pf_res[sl] = 0.f; pf_rs[sl] = 1.f;
+      pf_dst[sl] = -1; src_res[sl] = 0; src_rs[sl] = 0; src_n[sl] = 0;
       if (elem(sl, r, n)) {
         if constexpr (L::GROUPED) {
           const int m = a.perm[bx * MT + r];
@@ -246,14 +251,20 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bx, 
         }
       }
       if (b >= 0) {
-        pf_dst[sl] = (int)(((size_t)b * R_out + pos_out) * a.out.C + (size_t)t * L::NOUT + n);
-        if constexpr (L::EPI == EPI_BIAS) pf_bias[sl] = a.bias[n];
-        if constexpr (L::EPI == EPI_ROWSCALE) pf_rs[sl] = a.rowscale[b * L::T + t];
-        if constexpr (L::RES) {
-          const int R_res = a.res.n * a.res.m;
-          pf_res[sl] = a.res.base[((size_t)b * R_res + ring_pos(a.res, hop)) * a.res.C + (size_t)t * L::NOUT + n];
-        }
+        pf_dst[sl] = (b * R_out + pos_out) * a.out.C + t * L::NOUT + n;
+        src_n[sl] = n;
+        src_rs[sl] = b * L::T + t;
+        if constexpr (L::RES) src_res[sl] = (b * R_res + pos_res) * a.res.C + t * L::NOUT + n;
       }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int sl = 0; sl < E_SLOTS; ++sl) {
+      const bool live = pf_dst[sl] >= 0;
+      pf_bias[sl] = 0.f; pf_res[sl] = 0.f; pf_rs[sl] = 1.f;
+      if constexpr (L::EPI == EPI_BIAS) pf_bias[sl] = live ? a.bias[src_n[sl]] : 0.f;
+      if constexpr (L::EPI == EPI_ROWSCALE) pf_rs[sl] = live ? a.rowscale[src_rs[sl]] : 1.f;
+      if constexpr (L::RES) pf_res[sl] = live ? a.res.base[src_res[sl]] : 0.f;
     }
   }
   auto finish_pf = [&](int sl, float v) {
@@ -276,6 +287,25 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bx, 
 #pragma unroll
     for (int gs = 0; gs < PG; ++gs) {
       if (gs != g) continue;
+      if constexpr (TC::MT == 16) {
+        // few-row tiling: one wavefront per SIMD and a dependent MFMA chain, so what counts is the chain's latency.
+        // Left alone the compiler puts each ds_read next to the MFMA that uses it (ds_read, wait, 2 MFMAs, ...) and
+        // the chain pays the LDS latency after every second MFMA; fetch the chunk's whole A operand first instead.
+        float aop[KC / 4];
+#pragma unroll
+        for (int ks = 0; ks < KC / 4; ++ks) aop[ks] = As[(wave_m + (lane & 15)) * AS + ks * 4 + (lane >> 4)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KC / 4; ++ks) {
+#pragma unroll
+          for (int jn = 0; jn < TC::WN; ++jn) {
+            const float4 f = bcur[jn][ks >> 2];
+            const float bvv = (ks & 3) == 0 ? f.x : ((ks & 3) == 1 ? f.y : ((ks & 3) == 2 ? f.z : f.w));
+            acc[gs][0][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[ks], bvv, acc[gs][0][jn], 0, 0, 0);
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int ks = 0; ks < KC / 4; ++ks) {
         float av[TC::WM], bv[TC::WN];
