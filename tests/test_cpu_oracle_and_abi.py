@@ -207,3 +207,21 @@ def test_product_without_gpu_emits_silence_not_crash(bv, product, model_dir):
                     (ec, product.DestroyEmbeddingContext), (pe, product.DestroyPhoneExtractor), (pt, product.DestroyPitchEstimator),
                     (wg, product.DestroyWaveformGenerator), (es, product.DestroyEmbeddingSetter)):
         fn(obj)
+
+
+def test_model_toml_has_the_schema_the_reference_reader_asks_for(model_dir):
+    """model.toml next to the five .bin files: every key that reference src/common/model_config.h:73-136 looks up
+    (a missing one makes its reader throw), the rc0 version string (:25-35), voice ids contiguous from 0."""
+    import os
+    import tomli
+    with open(os.path.join(model_dir, "model.toml"), "rb") as f:
+        doc = tomli.load(f)
+    assert doc["model"]["version"] == "2.0.0-rc.0"
+    assert isinstance(doc["model"]["name"], str) and isinstance(doc["model"]["description"], str)
+    ids = sorted(int(k) for k in doc["voice"])
+    assert ids == list(range(len(ids))) and len(ids) >= 1
+    for k in ids:
+        v = doc["voice"][str(k)]
+        assert isinstance(v["name"], str) and v["name"] and isinstance(v["description"], str)
+        assert 0.0 <= float(v["average_pitch"]) <= 128.0
+        assert isinstance(v["portrait"]["path"], str) and isinstance(v["portrait"]["description"], str)

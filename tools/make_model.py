@@ -155,8 +155,11 @@ def make_model(out_dir, n_speakers=2, seed=0x20C0):
     with open(os.path.join(out_dir, "model.toml"), "w") as f:
         f.write('[model]\nversion = "2.0.0-rc.0"\nname = "synthetic-%x"\n' % seed)
         f.write('description = "deterministic synthetic weights for MODEL_SPEC v%d"\n' % VERSION)
+        # every key the reference's ModelConfig reader asks for (reference src/common/model_config.h:73-136):
+        # voice ids from 0, contiguous; name, description, average_pitch in [0, 128], portrait.path, portrait.description
         for s in range(n_speakers):
-            f.write('[voice.%d]\nname = "spk%d"\ndescription = ""\naverage_pitch = 52.0\n' % (s, s))
+            f.write('\n[voice.%d]\nname = "spk%d"\ndescription = "synthetic speaker %d"\naverage_pitch = 52.0\n' % (s, s, s))
+            f.write('[voice.%d.portrait]\npath = ""\ndescription = ""\n' % s)
     return sizes
 
 
