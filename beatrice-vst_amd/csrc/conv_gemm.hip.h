@@ -87,10 +87,18 @@ struct TileCfg {
   static constexpr int NTHR = GTHR * LK;
 };
 
-// The kernel body takes its workgroup coordinates as arguments so that two independent layers can share
-// one launch (pair.hip.h); conv_gemm_kernel below is the plain one-layer launch.
+// LDS the body needs (floats): the staged A chunk of every k-group, re-used for the segment combine
 template <class L, class TC>
-__device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bx, const int by) {
+constexpr int conv_lds_floats() {
+  constexpr int KC = TC::MT == 16 ? L::KC_FEW : L::KC;
+  constexpr int stage = TC::MT * (KC + 2) * TC::LK, red = TC::LK > 1 ? L::P * TC::MT * TC::NT : 0;
+  return stage > red ? stage : red;
+}
+
+// The kernel body takes its workgroup coordinates and its LDS as arguments so that independent layers can share
+// one launch (fuse.hip.h); conv_gemm_kernel below is the plain one-layer launch.
+template <class L, class TC>
+__device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bx, const int by, float* __restrict__ lds) {
   constexpr int KC = TC::MT == 16 ? L::KC_FEW : L::KC;
   constexpr int NCHUNK = L::K / KC, CHUNKS_PER_SEG = L::SEG / KC;
   constexpr int AS = KC + 2, MT = TC::MT, NT = TC::NT, GTHR = TC::GTHR, LK = TC::LK;
@@ -106,8 +114,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bx, 
   constexpr int LDS_FLOATS = STAGE_FLOATS * LK > RED_FLOATS ? STAGE_FLOATS * LK : RED_FLOATS;
   static_assert(L::NOUT % NT == 0, "N tile must divide NOUT");
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
-
-  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  static_assert(LDS_FLOATS == conv_lds_floats<L, TC>(), "LDS size");
 
   const int tid = threadIdx.x;
   const int grp = tid / GTHR, gtid = tid % GTHR;
@@ -390,7 +397,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bx, 
 
 template <class L, class TC>
 __global__ __launch_bounds__(TC::NTHR) void conv_gemm_kernel(const ConvArgs a) {
-  conv_gemm_body<L, TC>(a, blockIdx.x, blockIdx.y);
+  __shared__ __attribute__((aligned(16))) float lds[conv_lds_floats<L, TC>()];
+  conv_gemm_body<L, TC>(a, blockIdx.x, blockIdx.y, lds);
 }
 
 // launch geometry + algorithmic work of one layer, shared by the single and the paired launchers
@@ -398,6 +406,7 @@ template <class L, class TC>
 struct ConvOp {
   using Args = ConvArgs;
   static constexpr int NTHR = TC::NTHR;
+  static constexpr int LDS_FLOATS = conv_lds_floats<L, TC>();
   static inline dim3 grid(const ConvArgs& a, int n_group_tiles = 0) {
     dim3 g;
     g.x = L::GROUPED ? n_group_tiles : (a.B * L::T + TC::MT - 1) / TC::MT;
@@ -410,7 +419,7 @@ struct ConvOp {
     const double in_rows = (double)a.B * (L::T * L::STRIDE + (L::KSZ - 1) * L::DIL - (L::STRIDE - 1));
     return bhip::LaunchInfo{name, 2.0 * M * K * N, 4.0 * (K * N + in_rows * L::CIN + M * N * (L::RES ? 2 : 1))};
   }
-  __device__ static __forceinline__ void run(const ConvArgs& a, int bx, int by) { conv_gemm_body<L, TC>(a, bx, by); }
+  __device__ static __forceinline__ void run(const ConvArgs& a, int bx, int by, float* lds) { conv_gemm_body<L, TC>(a, bx, by, lds); }
 };
 
 template <class L, class TC>

@@ -197,7 +197,7 @@ void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t stream, 
 void wave_cond(const WaveWeights& w, const WaveState& s, hipStream_t stream);
 
 // content encoder + pitch estimator (+ the waveform generator's conditioning mix) with the pitch
-// estimator's launches paired into the content encoder's (pair.hip.h).  Returns false when the
+// estimator's launches paired into the content encoder's (fuse.hip.h).  Returns false when the
 // configuration is outside the paired regime (more than 2048 rows in the paired layers): nothing was enqueued, the
 // caller runs phone_forward / pitch_forward / wave_forward(cond_done = false) instead.
 void phone_vq(const PhoneWeights& w, const PhoneState& s, hipStream_t stream);

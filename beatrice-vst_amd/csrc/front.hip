@@ -1,5 +1,5 @@
 // front.hip -- content encoder and pitch estimator of one step as ONE chain of paired launches
-// (pair.hip.h): the two modules only share the hop's audio (reference processor_core_2.cc:181-189
+// (fuse.hip.h): the two modules only share the hop's audio (reference processor_core_2.cc:181-189
 // calls ExtractPhone1 and EstimatePitch1 back to back on the same 160 samples), so every launch of
 // the pitch estimator rides along with a launch of the content encoder, and the waveform generator's
 // conditioning mix (needs only the pitch head's output) rides with the next one:
@@ -15,7 +15,7 @@
 // layers are in the few-row tiling (B x H <= 2048 rows); elsewhere the modules run one after the other
 // (phone.hip, pitch.hip).
 #include "chain_layers.hip.h"
-#include "pair.hip.h"
+#include "fuse.hip.h"
 
 namespace bhip {
 
@@ -24,7 +24,7 @@ template <class LA, class LB>
 static void pair_conv(const char* na, const ConvArgs& a, const char* nb, const ConvArgs& b, hipStream_t st) {
   using OA = ConvOp<LA, TLat<LA>>;
   using OB = ConvOp<LB, TLat<LB>>;
-  launch_pair<OA, OB>(OA::info(na, a), a, OA::grid(a), OB::info(nb, b), b, OB::grid(b), st);
+  fuse::launch(st, fuse::part<OA>(OA::info(na, a), a, OA::grid(a)), fuse::part<OB>(OB::info(nb, b), b, OB::grid(b)));
 }
 
 template <int H>
@@ -39,7 +39,7 @@ static void front_forward_h(const PhoneWeights& pw, const PhoneState& ps, const 
   using QGRU = GruOp<128, 128>;
   const int B = ps.B;
 
-  launch_pair<F1Op, FftOp>(f1_info(ps), f1_args(pw, ps), dim3(B, H), fft_info(qs), fft_args(qw, qs), dim3(B, H), st);
+  fuse::launch(st, fuse::part<F1Op>(f1_info(ps), f1_args(pw, ps), dim3(B, H)), fuse::part<FftOp>(fft_info(qs), fft_args(qw, qs), dim3(B, H)));
   launch_auto<typename PL::F2>("phone.f2", conv_args(ps.f[0], ps.f[1], pw.f_w[0], pw.f_b[0], ps.hop, B), st);
   launch_auto<typename PL::F3>("phone.f3", conv_args(ps.f[1], ps.f[2], pw.f_w[1], pw.f_b[1], ps.hop, B), st);
   launch_auto<typename PL::F4>("phone.f4", conv_args(ps.f[2], ps.f[3], pw.f_w[2], pw.f_b[2], ps.hop, B), st);
@@ -64,20 +64,20 @@ static void front_forward_h(const PhoneWeights& pw, const PhoneState& ps, const 
     if (pk == 0 && qk == 0) {
       const ConvArgs& a = i == 0 ? rb2 : rb3;
       const GruArgs g = qgru(i);
-      launch_pair<RB, QGRU>(RB::info("phone.rb", a), a, RB::grid(a), QGRU::info("pitch.gru", g), g, QGRU::grid(g), st);
+      fuse::launch(st, fuse::part<RB>(RB::info("phone.rb", a), a, RB::grid(a)), fuse::part<QGRU>(QGRU::info("pitch.gru", g), g, QGRU::grid(g)));
     } else if (pk == 0 && qk == 1) {  // H = 1 only
-      launch_pair<RB, POUT>(RB::info("phone.rb", rb3), rb3, RB::grid(rb3), POUT::info("pitch.out", qout), qout, POUT::grid(qout), st);
+      fuse::launch(st, fuse::part<RB>(RB::info("phone.rb", rb3), rb3, RB::grid(rb3)), fuse::part<POUT>(POUT::info("pitch.out", qout), qout, POUT::grid(qout)));
     } else if (pk == 1 && qk == 0) {  // H = 4 only
       const GruArgs a = pgru(i - 2), g = qgru(i);
-      launch_pair<PGRU, QGRU>(PGRU::info("phone.gru", a), a, PGRU::grid(a), QGRU::info("pitch.gru", g), g, QGRU::grid(g), st);
+      fuse::launch(st, fuse::part<PGRU>(PGRU::info("phone.gru", a), a, PGRU::grid(a)), fuse::part<QGRU>(QGRU::info("pitch.gru", g), g, QGRU::grid(g)));
     } else if (pk == 1 && qk == 1) {
       const GruArgs a = pgru(i - 2);
-      launch_pair<PGRU, POUT>(PGRU::info("phone.gru", a), a, PGRU::grid(a), POUT::info("pitch.out", qout), qout, POUT::grid(qout), st);
+      fuse::launch(st, fuse::part<PGRU>(PGRU::info("phone.gru", a), a, PGRU::grid(a)), fuse::part<POUT>(POUT::info("pitch.out", qout), qout, POUT::grid(qout)));
     } else if (pk == 1 && qk == 2) {
       const GruArgs a = pgru(i - 2);
-      launch_pair<PGRU, HeadOp>(PGRU::info("phone.gru", a), a, PGRU::grid(a), head_info(qs), head_args(qw, qs), dim3(B, 1), st);
+      fuse::launch(st, fuse::part<PGRU>(PGRU::info("phone.gru", a), a, PGRU::grid(a)), fuse::part<HeadOp>(head_info(qs), head_args(qw, qs), dim3(B, 1)));
     } else {  // pk == 2 && qk == 3
-      launch_pair<OUT, CondOp>(OUT::info("phone.out", pout), pout, OUT::grid(pout), cond_info(ws), cond_args(ww, ws), dim3(B * H, 1), st);
+      fuse::launch(st, fuse::part<OUT>(OUT::info("phone.out", pout), pout, OUT::grid(pout)), fuse::part<CondOp>(cond_info(ws), cond_args(ww, ws), dim3(B * H, 1)));
     }
   }
   phone_vq(pw, ps, st);

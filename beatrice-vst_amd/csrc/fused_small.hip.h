@@ -27,9 +27,8 @@ struct GruArgs {
 };
 
 template <int IN, int H>
-__device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, const int by) {
-  constexpr int XS = IN + 2, HS = H + 2;
-  __shared__ __attribute__((aligned(16))) float lds[16 * XS + 16 * HS + 6 * 256];
+__device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, const int by, float* __restrict__ lds) {
+  constexpr int XS = IN + 2, HS = H + 2;  // lds: 16 * XS + 16 * HS + 6 * 256 floats
   float* xs = lds;
   float* hs = lds + 16 * XS;
   float* g6 = hs + 16 * HS;  // [src][gate][16][16]
@@ -105,17 +104,21 @@ __device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, c
 }
 
 template <int IN, int H>
-static __global__ __launch_bounds__(384) void gru_fused_kernel(const GruArgs a) { gru_fused_body<IN, H>(a, blockIdx.x, blockIdx.y); }
+static __global__ __launch_bounds__(384) void gru_fused_kernel(const GruArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[16 * (IN + 2) + 16 * (H + 2) + 6 * 256];
+  gru_fused_body<IN, H>(a, blockIdx.x, blockIdx.y, lds);
+}
 
 template <int IN, int H>
 struct GruOp {
   using Args = GruArgs;
   static constexpr int NTHR = 384;
+  static constexpr int LDS_FLOATS = 16 * (IN + 2) + 16 * (H + 2) + 6 * 256;
   static inline dim3 grid(const GruArgs& a) { return dim3((a.B + 15) / 16, H / 16); }
   static inline bhip::LaunchInfo info(const char* name, const GruArgs& a) {
     return bhip::LaunchInfo{name, 2.0 * a.B * (IN + H) * 3.0 * H, 4.0 * ((IN + H) * 3.0 * H + a.B * (IN + 2.0 * H))};
   }
-  __device__ static __forceinline__ void run(const GruArgs& a, int bx, int by) { gru_fused_body<IN, H>(a, bx, by); }
+  __device__ static __forceinline__ void run(const GruArgs& a, int bx, int by, float* lds) { gru_fused_body<IN, H>(a, bx, by, lds); }
 };
 
 template <int IN, int H>
@@ -134,17 +137,17 @@ struct AttnPvArgs {
   const int* tile_slot;  // [n_tiles]
 };
 
-static __global__ __launch_bounds__(256) void attn_pv_kernel(const AttnPvArgs a) {
+constexpr int kAttnPvLdsFloats = 16 * (B_KV_LEN + 2) + 16 + 2 * 16 * 32;
+__device__ __forceinline__ void attn_pv_body(const AttnPvArgs& a, const int bx, const int by, float* __restrict__ lds) {
   constexpr int KL = B_KV_LEN, AS = KL + 2, NT = 32;
-  __shared__ __attribute__((aligned(16))) float lds[16 * AS + 16 + 2 * 16 * NT];
   float* es = lds;               // exp(s - max), [16][386]
   float* inv = lds + 16 * AS;    // [16]
   float* red = inv + 16;         // [2][16][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = wave >> 1, wn = wave & 1;
-  const int slot = a.tile_slot[blockIdx.x];
+  const int slot = a.tile_slot[bx];
   if (slot < 0) return;
-  const int n0 = blockIdx.y * NT;
+  const int n0 = by * NT;
   // B fragments of this wave: segment grp (keys 0..255 or 256..383), column tile (n0 + wn*16)/16
   float4 bf[16];
   {
@@ -159,7 +162,7 @@ static __global__ __launch_bounds__(256) void attn_pv_kernel(const AttnPvArgs a)
     float v[4][6];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-      const int b = a.perm[blockIdx.x * 16 + wave * 4 + rr];
+      const int b = a.perm[bx * 16 + wave * 4 + rr];
 #pragma unroll
       for (int i = 0; i < 6; ++i) v[rr][i] = b >= 0 ? a.scores[(size_t)b * KL + lane + 64 * i] : 0.0f;
     }
@@ -202,9 +205,19 @@ static __global__ __launch_bounds__(256) void attn_pv_kernel(const AttnPvArgs a)
   __syncthreads();
   for (int idx = tid; idx < 16 * NT; idx += 256) {
     const int r = idx / NT, n = n0 + idx % NT;
-    const int b = a.perm[blockIdx.x * 16 + r];
+    const int b = a.perm[bx * 16 + r];
     if (b < 0) continue;
     const float v = red[idx] + red[16 * NT + idx];  // segment 0 + segment 1 (MODEL_SPEC 2.2)
     a.out[(size_t)b * B_HID + n] = v * inv[r];
   }
 }
+static __global__ __launch_bounds__(256) void attn_pv_kernel(const AttnPvArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[kAttnPvLdsFloats];
+  attn_pv_body(a, blockIdx.x, blockIdx.y, lds);
+}
+struct AttnPvOp {
+  using Args = AttnPvArgs;
+  static constexpr int NTHR = 256;
+  static constexpr int LDS_FLOATS = kAttnPvLdsFloats;
+  __device__ static __forceinline__ void run(const Args& a, int bx, int by, float* lds) { attn_pv_body(a, bx, by, lds); }
+};

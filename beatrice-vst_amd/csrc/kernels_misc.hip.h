@@ -44,9 +44,10 @@ struct F1Args {
   size_t io_stride;    // 0, or floats between the slots of a resident multi-step input buffer (batch.hip)
 };
 // grid (stream, hop-in-step).  Samples before the step come from the audio ring, the rest from d_in.
-__device__ __forceinline__ void phone_f1_body(const F1Args& a, const int b, const int hh) {
-  __shared__ float x[5 + B_IN_HOP];
-  __shared__ float ws[10 * 64];
+constexpr int kF1LdsFloats = 168 + 10 * 64;
+__device__ __forceinline__ void phone_f1_body(const F1Args& a, const int b, const int hh, float* __restrict__ lds) {
+  float* x = lds;         // [5 + 160]
+  float* ws = lds + 168;  // [10][64]
   const int tid = threadIdx.x, hop = *a.hop, H = a.H;
   const int io = a.io_stride != 0 ? a.hop[1] : 0;
   if (a.hop_publish != nullptr && b == 0 && hh == 0 && tid == 0) {
@@ -85,11 +86,15 @@ __device__ __forceinline__ void phone_f1_body(const F1Args& a, const int b, cons
 #pragma unroll
   for (int u = 0; u < 8; ++u) o[u] = bsp::gelu(acc[u] + bias[n0 + u]);
 }
-static __global__ __launch_bounds__(256) void phone_f1_kernel(const F1Args a) { phone_f1_body(a, blockIdx.x, blockIdx.y); }
+static __global__ __launch_bounds__(256) void phone_f1_kernel(const F1Args a) {
+  __shared__ __attribute__((aligned(16))) float lds[kF1LdsFloats];
+  phone_f1_body(a, blockIdx.x, blockIdx.y, lds);
+}
 struct F1Op {
   using Args = F1Args;
   static constexpr int NTHR = 256;
-  __device__ static __forceinline__ void run(const Args& a, int bx, int by) { phone_f1_body(a, bx, by); }
+  static constexpr int LDS_FLOATS = kF1LdsFloats;
+  __device__ static __forceinline__ void run(const Args& a, int bx, int by, float* lds) { phone_f1_body(a, bx, by, lds); }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -105,12 +110,13 @@ struct VqArgs {
   const float* const* cnorm;   // per stream: [512]
   const int* k;                // per stream
 };
-static __global__ __launch_bounds__(512) void phone_vq_kernel(VqArgs a) {
-  __shared__ float x[B_PHONE_CH];
-  __shared__ float red_d[8];
-  __shared__ int red_j[8];
-  __shared__ int winner;
-  const int row = blockIdx.x, b = row / a.H, j = threadIdx.x, lane = j & 63, wave = j >> 6;
+constexpr int kVqLdsFloats = B_PHONE_CH + 8 + 8 + 8;
+__device__ __forceinline__ void phone_vq_body(const VqArgs& a, const int row, float* __restrict__ lds) {
+  float* x = lds;                                               // [128]
+  float* red_d = lds + B_PHONE_CH;                              // [8]
+  int* red_j = reinterpret_cast<int*>(lds + B_PHONE_CH + 8);    // [8]
+  int& winner = *reinterpret_cast<int*>(lds + B_PHONE_CH + 16);
+  const int b = row / a.H, j = threadIdx.x, lane = j & 63, wave = j >> 6;
   float* out = ring_frame(a.out, b, ring_pos(a.out, *a.hop), row % a.H);
   const int k = a.k[b];
   const float* cbT = a.cbT[b];
@@ -151,6 +157,16 @@ static __global__ __launch_bounds__(512) void phone_vq_kernel(VqArgs a) {
   }
   if (j < B_PHONE_CH) out[j] = acc / (float)k;
 }
+static __global__ __launch_bounds__(512) void phone_vq_kernel(const VqArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[kVqLdsFloats];
+  phone_vq_body(a, blockIdx.x, lds);
+}
+struct VqOp {
+  using Args = VqArgs;
+  static constexpr int NTHR = 512;
+  static constexpr int LDS_FLOATS = kVqLdsFloats;
+  __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { phone_vq_body(a, bx, lds); }
+};
 
 // ---------------------------------------------------------------------------------------------
 // Pitch front-end (MODEL_SPEC 4.2.1): window, 1024-point radix-2 DIT FFT in LDS, log power.
@@ -163,9 +179,11 @@ struct FftArgs {
   int H;
   size_t io_stride;  // see F1Args
 };
-__device__ __forceinline__ void pitch_fft_body(const FftArgs& a, const int b, const int hh) {
-  __shared__ float re[B_FFT_N], im[B_FFT_N];
-  __shared__ float tw[B_FFT_N];
+constexpr int kFftLdsFloats = 3 * B_FFT_N;
+__device__ __forceinline__ void pitch_fft_body(const FftArgs& a, const int b, const int hh, float* __restrict__ lds) {
+  float* re = lds;
+  float* im = lds + B_FFT_N;
+  float* tw = lds + 2 * B_FFT_N;
   const int tid = threadIdx.x, hop = *a.hop, H = a.H;
   const Ring& audio = a.audio;
   const Ring& spec = a.spec;
@@ -214,11 +232,15 @@ __device__ __forceinline__ void pitch_fft_body(const FftArgs& a, const int b, co
     o[k] = 0.5f * bsp::log(pw + 1e-5f);
   }
 }
-static __global__ __launch_bounds__(256) void pitch_fft_kernel(const FftArgs a) { pitch_fft_body(a, blockIdx.x, blockIdx.y); }
+static __global__ __launch_bounds__(256) void pitch_fft_kernel(const FftArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[kFftLdsFloats];
+  pitch_fft_body(a, blockIdx.x, blockIdx.y, lds);
+}
 struct FftOp {
   using Args = FftArgs;
   static constexpr int NTHR = 256;
-  __device__ static __forceinline__ void run(const Args& a, int bx, int by) { pitch_fft_body(a, bx, by); }
+  static constexpr int LDS_FLOATS = kFftLdsFloats;
+  __device__ static __forceinline__ void run(const Args& a, int bx, int by, float* lds) { pitch_fft_body(a, bx, by, lds); }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -328,7 +350,8 @@ static __global__ __launch_bounds__(64) void pitch_head_kernel(const PitchHeadAr
 struct HeadOp {
   using Args = PitchHeadArgs;
   static constexpr int NTHR = 64;
-  __device__ static __forceinline__ void run(const Args& a, int bx, int) { pitch_head_body(a, bx); }
+  static constexpr int LDS_FLOATS = 0;
+  __device__ static __forceinline__ void run(const Args& a, int bx, int, float*) { pitch_head_body(a, bx); }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -369,7 +392,8 @@ static __global__ __launch_bounds__(256) void wave_cond_kernel(const CondArgs a)
 struct CondOp {
   using Args = CondArgs;
   static constexpr int NTHR = 256;
-  __device__ static __forceinline__ void run(const Args& a, int bx, int) { wave_cond_body(a, bx); }
+  static constexpr int LDS_FLOATS = 0;
+  __device__ static __forceinline__ void run(const Args& a, int bx, int, float*) { wave_cond_body(a, bx); }
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -190,10 +190,10 @@ __device__ __forceinline__ void hist_out(float* __restrict__ st, const float* __
 }  // namespace tail
 
 // 2 workgroups per CU (59 KB of LDS each): while one waits at a barrier the other computes
+constexpr int kTailLdsFloats = 3 * tail::BUF_FLOATS + 2 * TAIL_STATE_FLOATS + tail::BIAS_FLOATS + 7 * 16;
 template <int H>  // hops per step, compile time: H = 1 keeps the single-hop kernel free of loop state
-static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const TailArgs a) {
+__device__ __forceinline__ void wave_tail_body(const TailArgs& a, const int b, float* __restrict__ lds) {
   using namespace tail;
-  __shared__ __attribute__((aligned(16))) float lds[3 * BUF_FLOATS + 2 * TAIL_STATE_FLOATS + BIAS_FLOATS + 7 * 16];
   float* R0 = lds;
   float* R1 = lds + BUF_FLOATS;
   float* R2 = lds + 2 * BUF_FLOATS;
@@ -201,7 +201,7 @@ static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const T
   float* SO_ = SI_ + TAIL_STATE_FLOATS;      // state after this hop (written, stored at the end)
   float* BIAS = SO_ + TAIL_STATE_FLOATS;
   float* FW = BIAS + BIAS_FLOATS;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* st = a.state + (size_t)b * TAIL_STATE_FLOATS;
   TAIL_STAMP(0);
 
@@ -317,3 +317,16 @@ static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const T
   for (int e = tid; e < TAIL_STATE_FLOATS; e += NTHR) st[e] = SI_[e];
   TAIL_STAMP(10);
 }
+
+template <int H>
+static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const TailArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[kTailLdsFloats];
+  wave_tail_body<H>(a, blockIdx.x, lds);
+}
+template <int H>
+struct TailOp {
+  using Args = TailArgs;
+  static constexpr int NTHR = tail::NTHR;
+  static constexpr int LDS_FLOATS = kTailLdsFloats;
+  __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { wave_tail_body<H>(a, bx, lds); }
+};
