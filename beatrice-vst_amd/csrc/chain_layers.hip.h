@@ -25,6 +25,18 @@ struct PitchLayers {
   using POUT = Layer<128, B_PITCH_BINS, 1, 1, 1, H, PRE_NONE, ACT_NONE, EPI_BIAS, false>;
 };
 
+// waveform generator (MODEL_SPEC 4.4)
+namespace wave_layers {
+template <int H> using INP = Layer<B_PHONE_CH, B_HID, 1, 1, 1, H, PRE_NONE, ACT_NONE, EPI_BIAS, true>;
+template <int D, int H> using C1 = Layer<B_HID, B_HID, 3, 1, D, H, PRE_NONE, ACT_GELU, EPI_BIAS, false>;
+template <int H> using C2 = Layer<B_HID, B_HID, 1, 1, 1, H, PRE_NONE, ACT_NONE, EPI_BIAS, true>;
+template <int H> using QL = Layer<B_HID, B_HID, 1, 1, 1, H, PRE_NONE, ACT_NONE, EPI_BIAS, false>;
+template <int H> using SCORE = Layer<B_HID, B_KV_LEN, 1, 1, 1, H, PRE_NONE, ACT_NONE, EPI_SCALE, false, true>;
+template <int CIN, int COUT, int R, int TIN> using UP = Layer<CIN, R * COUT, 2, 1, 1, TIN, PRE_LRELU, ACT_NONE, EPI_BIAS, false>;
+template <int C, int D, int T> using RES = Layer<C, C, 3, 1, D, T, PRE_LRELU, ACT_NONE, EPI_BIAS, true>;
+using TGQ = TileCfg<1, 1, 1, 2, 1>;  // grouped attention scores: 16 rows x 32 keys, K = 256 (one segment)
+}  // namespace wave_layers
+
 static inline F1Args f1_args(const PhoneWeights& w, const PhoneState& s) {
   return F1Args{s.d_in, s.audio, s.f[0], w.f1_w, w.f1_b, s.hop_in, s.hop_publish, s.hop_publish_wave, s.H, s.io_stride};
 }
