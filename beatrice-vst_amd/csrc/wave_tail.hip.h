@@ -319,7 +319,7 @@ __device__ __forceinline__ void wave_tail_body(const TailArgs& a, const int b, f
 }
 
 template <int H>
-static __global__ __launch_bounds__(tail::NTHR, 2) void wave_tail_kernel(const TailArgs a) {
+static __global__ __launch_bounds__(tail::NTHR, 3) void wave_tail_kernel(const TailArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[kTailLdsFloats];
   wave_tail_body<H>(a, blockIdx.x, lds);
 }
