@@ -287,6 +287,7 @@ _BATCH = {
     "BeatriceBatch_EnableGraph": (C.c_int, [_vp, C.c_int]),
     "BeatriceBatch_EnablePipelining": (C.c_int, [_vp, C.c_int]),
     "BeatriceBatch_GetWaveStream": (_vp, [_vp]),
+    "BeatriceBatch_Prepare": (C.c_int, [_vp]),
     "BeatriceBatch_DeviceInput": (_vp, [_vp]),
     "BeatriceBatch_DeviceOutput": (_vp, [_vp]),
     "BeatriceBatch_GetIntermediates": (C.c_int, [_vp, _f32p, _i32p, _i32p, _f32p]),

@@ -349,19 +349,25 @@ bool capture(hipStream_t st, hipGraph_t* graph, hipGraphExec_t* exec, F enqueue)
 // pipelining off: the whole step as ONE launch on the batch's stream (a second graph launch per step costs ~15 us)
 bool run_step_in_order(BeatriceBatch* b, int slot) {
   hipStream_t st = b->stream;
-  auto enqueue = [b, slot, st] { enqueue_front(b, st); for (int s = 1; s < b->n_stages; ++s) enqueue_wave(b, s, slot, st); };
-  if (!b->use_graph) { enqueue(); return hip_ok(hipGetLastError(), "step launch"); }
-  if (!b->exec[0][slot] && !capture(st, &b->graph[0][slot], &b->exec[0][slot], enqueue)) return false;
+  auto enqueue_slot = [b, st](int sl) { enqueue_front(b, st); for (int s = 1; s < b->n_stages; ++s) enqueue_wave(b, s, sl, st); };
+  if (!b->use_graph) { if (slot >= 0) enqueue_slot(slot); return hip_ok(hipGetLastError(), "step launch"); }
+  if (slot < 0 || !b->exec[0][slot])  // first use: capture the variants of all four slots at once, so that no later step pays for a capture
+    for (int sl = 0; sl < BeatriceBatch::kSlots; ++sl)
+      if (!b->exec[0][sl] && !capture(st, &b->graph[0][sl], &b->exec[0][sl], [&] { enqueue_slot(sl); })) return false;
+  if (slot < 0) return true;  // capture only (BeatriceBatch_Prepare)
   BHIP_TRY(hipGraphLaunch(b->exec[0][slot], st));
   return true;
 }
 
 bool run_stage(BeatriceBatch* b, int stage, int slot) {
   hipStream_t st = stage_stream(b, stage);
-  auto enqueue = [b, stage, slot, st] { if (stage == 0) enqueue_front(b, st); else enqueue_wave(b, stage, slot, st); };
-  if (!b->use_graph) { enqueue(); return hip_ok(hipGetLastError(), "stage launch"); }
-  const int g = stage == 0 ? 0 : slot;  // the front end reads its counter through one fixed pointer
-  if (!b->exec[stage][g] && !capture(st, &b->graph[stage][g], &b->exec[stage][g], enqueue)) return false;
+  auto enqueue_slot = [b, stage, st](int sl) { if (stage == 0) enqueue_front(b, st); else enqueue_wave(b, stage, sl, st); };
+  if (!b->use_graph) { if (slot >= 0) enqueue_slot(slot); return hip_ok(hipGetLastError(), "stage launch"); }
+  const int g = stage == 0 || slot < 0 ? 0 : slot;  // the front end reads its counter through one fixed pointer
+  if (slot < 0 || !b->exec[stage][g])  // first use: every slot's variant of this stage at once (no capture inside a later step)
+    for (int sl = 0; sl < (stage == 0 ? 1 : BeatriceBatch::kSlots); ++sl)
+      if (!b->exec[stage][sl] && !capture(st, &b->graph[stage][sl], &b->exec[stage][sl], [&] { enqueue_slot(sl); })) return false;
+  if (slot < 0) return true;  // capture only (BeatriceBatch_Prepare)
   BHIP_TRY(hipGraphLaunch(b->exec[stage][g], st));
   return true;
 }
@@ -929,6 +935,16 @@ int BeatriceBatch_EnablePipelining(BeatriceBatch* b, int enable) {
   return 0;
 }
 void* BeatriceBatch_GetWaveStream(const BeatriceBatch* b) { return b ? wave_stream(b) : nullptr; }
+// Captures the hipGraphs of the current mode now (nothing is executed), so that the first steps do not pay for it.
+int BeatriceBatch_Prepare(BeatriceBatch* b) {
+  if (!b || !b->ok) return -2;
+  if (b->vq_dirty) { update_vq_mode(b); b->vq_dirty = false; }
+  if (!b->use_graph) return 0;
+  bool ok = true;
+  if (!b->pipelined) ok = run_step_in_order(b, -1);
+  else for (int s = 0; s < b->n_stages && ok; ++s) ok = run_stage(b, s, -1);
+  return ok ? 0 : -2;
+}
 float* BeatriceBatch_DeviceInput(BeatriceBatch* b) { return b && b->ok ? b->d_in : nullptr; }
 float* BeatriceBatch_DeviceOutput(BeatriceBatch* b) { return b && b->ok ? b->wave.d_out : nullptr; }
 

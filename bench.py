@@ -384,6 +384,9 @@ def main():
         d_out48 = torch.empty((B, 2, 480), dtype=torch.float32, device="cuda")
         base48, blk_bytes = d_audio48.data_ptr(), B * 2 * 480 * 4
 
+    if product.BeatriceBatch_Prepare(batch.h):  # graph capture now, not inside the first (possibly timed) steps
+        raise SystemExit("Prepare failed")
+
     def step(i):
         if a.config == 3:  # every stream moves to the next speaker every 200 hops, staggered by stream index
             for s in range(B):

@@ -141,6 +141,9 @@ int BeatriceBatch_EnableGraph(BeatriceBatch* b, int enable);
  * share a queue do not overlap, and depth 4 then runs slower than depth 3. */
 int BeatriceBatch_EnablePipelining(BeatriceBatch* b, int enable);
 void* BeatriceBatch_GetWaveStream(const BeatriceBatch* b);
+/* Optional: capture the hipGraphs of the current mode now (settings, I/O binding, pipelining as they stand; nothing
+ * runs), so that the first steps do not spend milliseconds on it.  Otherwise it happens inside the first step. */
+int BeatriceBatch_Prepare(BeatriceBatch* b);
 
 /* Resident buffers of the batch ([B][H*160] in, [B][H*240] out) for callers that produce / consume
  * audio on the device. */
