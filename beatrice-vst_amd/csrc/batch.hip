@@ -57,7 +57,6 @@ struct Mirror {
   T* h = nullptr;  // the buffer being edited
   T* d = nullptr;
   size_t n = 0;
-  bool dirty = true;
   T* buf[2] = {nullptr, nullptr};
   hipEvent_t sent[2] = {nullptr, nullptr};
   bool pending[2] = {false, false};
@@ -78,11 +77,6 @@ struct Mirror {
       BHIP_TRY(hipMemcpyAsync(dst[i] ? dst[i] : d + off[i], buf[cur] + off[i], sizeof(T) * len[i], hipMemcpyHostToDevice, s));
     return flip(s);
   }
-  bool push(hipStream_t s) {
-    if (!dirty) return true;
-    BHIP_TRY(hipMemcpyAsync(d, buf[cur], sizeof(T) * n, hipMemcpyHostToDevice, s));
-    return flip(s);
-  }
   bool flip(hipStream_t s) {
     BHIP_TRY(hipEventRecord(sent[cur], s));
     pending[cur] = true;
@@ -91,7 +85,6 @@ struct Mirror {
     std::memcpy(buf[nxt], buf[cur], sizeof(T) * n);
     cur = nxt;
     h = buf[cur];
-    dirty = false;
     return true;
   }
   void release() {
