@@ -124,3 +124,35 @@ def test_stress_inputs(bv, oracle, product, model_dir, kind):
     print("%s: max-abs %g %s; raw bins seen %s" % (kind, dev, "bit-identical" if np.array_equal(ref, got) else "",
                                                   sorted(set(np.concatenate(q_trace).tolist()))[:8]))
     assert dev <= TOL
+
+
+def test_batch_and_shard_invariance(bv, product, model_dir):
+    """A stream's output does not depend on the batch it runs in: the same 96 streams as one batch, as the three
+    shards that `shard.stream_range` gives three ranks, and one of them alone (B = 1) -- bit for bit.  This is the
+    single-GPU form of "sharded over N GPUs == one GPU" (streams never exchange anything)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("beatrice_shard", os.path.join(REPO, "beatrice-vst_amd", "shard.py"))
+    shard = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(shard)
+    B, hops = 96, 10
+    audio = np.stack([bv.synth_audio(160 * hops, seed=700 + s) for s in range(B)])
+    m = bv.Models(product, model_dir)
+
+    def run(lo, hi):
+        batch = bv.Batch(m, hi - lo)
+        for s in range(lo, hi):
+            batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, s - lo, s % 3)
+            batch.a.BeatriceBatch_SetVQNumNeighbors(batch.h, s - lo, s % 4)
+            batch.a.BeatriceBatch_SetPitchShift(batch.h, s - lo, float(s % 7) - 3.0)
+        batch.a.BeatriceBatch_FlushSpeaker(batch.h, -1)
+        out = np.stack([batch.convert(audio[lo:hi, h * 160:(h + 1) * 160]) for h in range(hops)])  # [hops][n][240]
+        batch.close()
+        return out
+
+    whole = run(0, B)
+    for rank in range(3):
+        lo, hi = shard.stream_range(rank, 3, B)
+        assert np.array_equal(run(lo, hi), whole[:, lo:hi]), "shard %d differs from the whole batch" % rank
+    assert np.array_equal(run(41, 42), whole[:, 41:42])
+    m.close()
+    assert np.abs(whole).max() > 0.05
