@@ -371,10 +371,13 @@ def main():
     base, hop_bytes = d_audio.data_ptr(), B * 160 * 4
     pipelined = a.pipeline_depth if a.config != 4 else 0
     if pipelined and product.BeatriceBatch_EnablePipelining(batch.h, pipelined):
-        raise SystemExit("EnablePipelining failed")
+        print("bench: EnablePipelining(%d) refused, running in order" % pipelined, file=sys.stderr)
+        pipelined = 0
     if resident:  # the 64 resident hops are the slots: every step reads one and writes one, no copy
         if product.BeatriceBatch_BindResidentIO(batch.h, d_audio.data_ptr(), d_out.data_ptr(), n_cycle):
-            raise SystemExit("BindResidentIO failed")
+            print("bench: BindResidentIO refused, copying each hop in and out", file=sys.stderr)
+            resident = False
+            d_out = torch.zeros((1, B, 240), dtype=torch.float32, device="cuda")
 
     if a.config == 4:  # 48 kHz stereo blocks, resident: [n_cycle][B][2][480]
         a48 = np.stack([np.stack([bv.synth_audio(480 * n_cycle, seed=rank * 100000 + 2 * s + c, sr=48000) for c in range(2)])
