@@ -253,6 +253,8 @@ _BATCH = {
     "BeatriceHip_LoadPitchEstimatorFromMemory": (C.c_int, [_vp, _vp, C.c_size_t]),
     "BeatriceHip_LoadWaveformGeneratorFromMemory": (C.c_int, [_vp, _vp, C.c_size_t]),
     "BeatriceHip_LoadEmbeddingSetterFromMemory": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "BeatriceHip_ModelBlob": (C.c_int, [C.c_int, _vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "BeatriceHip_ModelBlobReady": (C.c_int, [C.c_int, _vp]),
     "BeatriceBatch_Create": (_vp, [_vp, _vp, _vp, _vp, C.c_int, C.c_int]),
     "BeatriceBatch_CreateBlock": (_vp, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int]),
     "BeatriceBatch_HopsPerStep": (C.c_int, [_vp]),
@@ -261,7 +263,10 @@ _BATCH = {
     "BeatriceBatch_IsHealthy": (C.c_int, [_vp]),
     "BeatriceBatch_NumStreams": (C.c_int, [_vp]),
     "BeatriceBatch_SetSpeakerTables": (C.c_int, [_vp, C.c_int, _f32p, _f32p, _f32p, _f32p]),
+    "BeatriceBatch_SpeakerTablesDevice": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "BeatriceBatch_ProjectSpeakerTables": (C.c_int, [_vp, C.c_int]),
     "BeatriceBatch_UpdateSpeaker": (C.c_int, [_vp, C.c_int, _f32p, _f32p, _f32p]),
+    "BeatriceBatch_SeedLottery": (C.c_int, [_vp, C.c_int, C.c_uint]),
     "BeatriceBatch_MorphSpeaker": (C.c_int, [_vp, C.c_int, _f32p, C.c_int, C.c_uint]),
     "BeatriceBatch_GetSpeakerEmbeddings": (C.c_int, [_vp, C.c_int, _f32p, _f32p]),
     "BeatriceBatch_SetTargetSpeaker": (C.c_int, [_vp, C.c_int, C.c_int]),
@@ -316,10 +321,10 @@ class Batch:
     hops_per_step = 1: one 10 ms hop per step (real time).  2 or 4: block mode, every step converts that
     many consecutive hops per stream (in [B][H*160] -> out [B][H*240]), same results as single hops."""
 
-    def __init__(self, models, n_streams, max_speakers=None, hops_per_step=1):
+    def __init__(self, models, n_streams, max_speakers=None, hops_per_step=1, upload_tables=True):
         self.m = models
         self.a = bind_batch(models.abi)
-        t = models.tables
+        t = models.tables if upload_tables else None
         self.B = n_streams
         self.H = hops_per_step
         ms = max_speakers or (t.n_speakers + 1)
@@ -330,8 +335,13 @@ class Batch:
                                                       hops_per_step)
         if not self.a.BeatriceBatch_IsHealthy(self.h):
             raise RuntimeError("BeatriceBatch_Create failed (no GPU / HIP error)")
+        if not upload_tables:  # the caller fills the device tables itself (shard.share_speaker_tables)
+            return
         self._check(self.a.BeatriceBatch_SetSpeakerTables(self.h, t.n_speakers + 1, fptr(t.codebooks), fptr(t.additive),
                                                           fptr(t.formant), fptr(t.kv)))
+        self.apply_defaults()
+
+    def apply_defaults(self):
         # reference host defaults (processor_core_2.h:103-113): speaker 0 with all K/V blocks installed
         self._check(self.a.BeatriceBatch_SetTargetSpeaker(self.h, -1, 0))
         self._check(self.a.BeatriceBatch_FlushSpeaker(self.h, -1))

@@ -97,14 +97,31 @@ Beatrice_ErrorCode Beatrice20rc0_ReadPhoneExtractorParameters(Beatrice20rc0_Phon
   const Beatrice_ErrorCode e = read_model_file(path, KIND_PHONE, (long)PhoneWeights::n_floats(), &host);
   return e ? e : install(m, host);
 }
-// ref beatrice.h:233-234; callers processor_core_2.h:36, processor_core_2.cc:263
+// ref beatrice.h:233-234; callers processor_core_2.h:36, processor_core_2.cc:263 (non-real-time threads: everything a
+// hop or a setter may need later -- state, pinned staging, the codebook pool -- is allocated here)
 Beatrice20rc0_PhoneContext1* Beatrice20rc0_CreatePhoneContext1(void) {
   auto* c = new Beatrice20rc0_PhoneContext1();
+  constexpr size_t kCbFloats = (size_t)B_CODEBOOK * B_PHONE_CH, kSlotFloats = kCbFloats + B_CODEBOOK;
   c->ok = make_stream(&c->stream) && c->st.create(1, 1, nullptr) &&
-          hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(float) * (B_IN_HOP + 1 + B_PHONE_CH), hipHostMallocDefault),
-                 "hipHostMalloc");
-  // the kernels read the step counter from the mailbox behind the audio; it arrives with the input copy
-  c->st.hop = c->st.hop_in = c->st.hop_mailbox;
+          hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(float) * (B_IN_HOP + kMailboxWords + B_PHONE_CH), hipHostMallocDefault),
+                 "hipHostMalloc") &&
+          hip_ok(hipMalloc(reinterpret_cast<void**>(&c->d_pool), sizeof(float) * kSlotFloats * kCodebookPool), "cb pool") &&
+          hip_ok(hipMalloc(reinterpret_cast<void**>(&c->d_cb_stage), sizeof(float) * 2 * kCbFloats), "cb stage") &&
+          hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_cb_stage), sizeof(float) * 2 * kCbFloats, hipHostMallocDefault), "cb stage host") &&
+          hip_ok(hipEventCreateWithFlags(&c->stage_done[0], hipEventDisableTiming), "ev") &&
+          hip_ok(hipEventCreateWithFlags(&c->stage_done[1], hipEventDisableTiming), "ev");
+  if (c->ok) {
+    for (int i = 0; i < kCodebookPool; ++i) {
+      c->pool[i].d_cbT = c->d_pool + (size_t)i * kSlotFloats;
+      c->pool[i].d_cnorm = c->pool[i].d_cbT + kCbFloats;
+    }
+    // the kernels read the step counter and the k-NN selectors from the mailbox behind the audio; they arrive with the input copy
+    c->st.hop = c->st.hop_in = c->st.hop_mailbox;
+    c->own_sel[0] = c->st.d_vqk; c->own_sel[1] = (void*)c->st.d_cbT; c->own_sel[2] = (void*)c->st.d_cnorm;
+    c->st.d_vqk = c->st.hop_mailbox + 1;
+    c->st.d_cbT = reinterpret_cast<const float**>(c->st.hop_mailbox + 2);
+    c->st.d_cnorm = reinterpret_cast<const float**>(c->st.hop_mailbox + 4);
+  }
   c->st.advance_hop = false;
   c->st.skip_vq = true;  // k = 0 until SetVQNumNeighbors says otherwise
   return c;
@@ -112,47 +129,69 @@ Beatrice20rc0_PhoneContext1* Beatrice20rc0_CreatePhoneContext1(void) {
 void Beatrice20rc0_DestroyPhoneContext1(Beatrice20rc0_PhoneContext1* c) {
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (auto& e : c->cache) { (void)hipFree(e.d_cbT); (void)hipFree(e.d_cnorm); }
+  if (c->own_sel[0]) {
+    c->st.d_vqk = static_cast<int*>(c->own_sel[0]);
+    c->st.d_cbT = static_cast<const float**>(c->own_sel[1]);
+    c->st.d_cnorm = static_cast<const float**>(c->own_sel[2]);
+  }
   c->st.destroy();
+  if (c->d_pool) (void)hipFree(c->d_pool);
+  if (c->d_cb_stage) (void)hipFree(c->d_cb_stage);
+  if (c->h_cb_stage) (void)hipHostFree(c->h_cb_stage);
+  for (hipEvent_t e : c->stage_done) if (e) (void)hipEventDestroy(e);
   if (c->h_io) (void)hipHostFree(c->h_io);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
-// ref beatrice.h:239-242; caller processor_core_2.cc:585-590 (clamped there to 0..8)
+// ref beatrice.h:239-242; caller processor_core_2.cc:585-590 (clamped there to 0..8).  Host-side only: k travels to
+// the device with the next hop's input.
 void Beatrice20rc0_SetVQNumNeighbors(Beatrice20rc0_PhoneContext1* ctx, int k) {
   if (!ctx || !ctx->ok) return;
-  k = k < 0 ? 0 : (k > B_CODEBOOK ? B_CODEBOOK : k);
-  (void)hip_ok(hipMemcpy(ctx->st.d_vqk, &k, sizeof(int), hipMemcpyHostToDevice), "vq k");
-  ctx->st.skip_vq = k == 0;  // no k-NN launch while the codebook is unused
+  ctx->vq_k = k < 0 ? 0 : (k > B_CODEBOOK ? B_CODEBOOK : k);
+  ctx->st.skip_vq = ctx->vq_k == 0;  // no k-NN launch while the codebook is unused
 }
-// ref beatrice.h:318-322.  The host passes a pointer into its own table and, in morph mode, calls
-// this every hop (processor_core_2.cc:118-121), so it must be O(1) after first sight: the device
-// copy (transposed + norms) is cached per host pointer.  The table contents are assumed immutable
-// while cached, which holds for the reference host (tables are written once in LoadModel).
+// Fingerprint of a caller-owned codebook: 96 words sampled over the table.  Cheap enough for a per-hop call, and a
+// table rewritten in place by a model reload differs somewhere in the sample with overwhelming probability.
+static uint64_t codebook_print(const float* cb) {
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(cb);
+  constexpr size_t n = (size_t)B_CODEBOOK * B_PHONE_CH;
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&h](uint32_t v) { h = (h ^ v) * 1099511628211ull; };
+  for (size_t i = 0; i < 16; ++i) { mix(w[i]); mix(w[n - 1 - i]); }
+  for (size_t i = 0; i < 64; ++i) mix(w[(i * 1021 + 389) % n]);
+  return h;
+}
+// ref beatrice.h:318-322.  The host passes a pointer into its own table and, in morph mode, calls this every hop on
+// the audio thread (processor_core_2.cc:118-121): O(1) when the table is in the context's pool, otherwise ONE
+// stream-ordered upload (pinned staging -> device -> transpose + norms) into the least recently used slot -- no
+// allocation and no wait either way (the next ExtractPhone1 runs behind it on the context's stream).
 void Beatrice20rc0_SetCodebook(Beatrice20rc0_PhoneContext1* ctx, const float* codebook) {
   if (!ctx || !ctx->ok || !codebook) return;
-  const CodebookEntry* hit = nullptr;
-  for (const auto& e : ctx->cache) if (e.host == codebook) { hit = &e; break; }
-  if (!hit) {
-    CodebookEntry e{codebook, nullptr, nullptr};
-    float* d_raw = nullptr;
-    const size_t n = (size_t)B_CODEBOOK * B_PHONE_CH;
-    bool ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&d_raw), n * sizeof(float)), "cb raw") &&
-              hip_ok(hipMalloc(reinterpret_cast<void**>(&e.d_cbT), n * sizeof(float)), "cbT") &&
-              hip_ok(hipMalloc(reinterpret_cast<void**>(&e.d_cnorm), B_CODEBOOK * sizeof(float)), "cnorm") &&
-              hip_ok(hipMemcpy(d_raw, codebook, n * sizeof(float), hipMemcpyHostToDevice), "cb upload");
-    if (ok) {
-      codebook_prepare(d_raw, 1, e.d_cbT, e.d_cnorm, ctx->stream);
-      ok = hip_ok(hipStreamSynchronize(ctx->stream), "cb prep");
-    }
-    if (d_raw) (void)hipFree(d_raw);
-    if (!ok) { if (e.d_cbT) (void)hipFree(e.d_cbT); if (e.d_cnorm) (void)hipFree(e.d_cnorm); return; }
-    ctx->cache.push_back(e);
-    hit = &ctx->cache.back();
+  const uint64_t print = codebook_print(codebook);
+  CodebookEntry* hit = nullptr;
+  CodebookEntry* lru = &ctx->pool[0];
+  for (CodebookEntry& e : ctx->pool) {
+    if (e.host == codebook && e.print == print) { hit = &e; break; }
+    if (e.host == codebook) { lru = &e; break; }  // same storage, new contents: refresh this slot
+    if (e.last_use < lru->last_use) lru = &e;
   }
-  const float* ptrs[2] = {hit->d_cbT, hit->d_cnorm};
-  (void)hip_ok(hipMemcpy(ctx->st.d_cbT, &ptrs[0], sizeof(float*), hipMemcpyHostToDevice), "set cbT");
-  (void)hip_ok(hipMemcpy(ctx->st.d_cnorm, &ptrs[1], sizeof(float*), hipMemcpyHostToDevice), "set cnorm");
+  if (!hit) {
+    constexpr size_t n = (size_t)B_CODEBOOK * B_PHONE_CH;
+    const int sb = ctx->stage_next;
+    ctx->stage_next ^= 1;
+    if (ctx->stage_busy[sb]) { (void)hipEventSynchronize(ctx->stage_done[sb]); ctx->stage_busy[sb] = false; }  // two uploads ago: long done
+    std::memcpy(ctx->h_cb_stage + sb * n, codebook, n * sizeof(float));
+    float* d_raw = ctx->d_cb_stage + sb * n;
+    if (!hip_ok(hipMemcpyAsync(d_raw, ctx->h_cb_stage + sb * n, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream), "cb upload")) return;
+    codebook_prepare(d_raw, 1, lru->d_cbT, lru->d_cnorm, ctx->stream);
+    ctx->stage_busy[sb] = hip_ok(hipEventRecord(ctx->stage_done[sb], ctx->stream), "cb ev");
+    lru->host = codebook;
+    lru->print = print;
+    hit = lru;
+  }
+  hit->last_use = ++ctx->use_clock;
+  ctx->sel_cbT = hit->d_cbT;
+  ctx->sel_cnorm = hit->d_cnorm;
 }
 // ref beatrice.h:243-247; caller processor_core_2.cc:183-185
 void Beatrice20rc0_ExtractPhone1(const Beatrice20rc0_PhoneExtractor* m, const float* input, float* output,
@@ -160,11 +199,17 @@ void Beatrice20rc0_ExtractPhone1(const Beatrice20rc0_PhoneExtractor* m, const fl
   std::memset(output, 0, sizeof(float) * B_PHONE_CH);
   if (!m || !m->loaded || !ctx || !ctx->ok) return;
   float* h_in = ctx->h_io;
-  float* h_out = ctx->h_io + B_IN_HOP + 1;
+  float* h_out = ctx->h_io + B_IN_HOP + kMailboxWords;
   std::memcpy(h_in, input, sizeof(float) * B_IN_HOP);
-  std::memcpy(h_in + B_IN_HOP, &ctx->hop_count, sizeof(int));
+  {  // mailbox: counter | k | codebook pointers
+    int* mb = reinterpret_cast<int*>(h_in + B_IN_HOP);
+    mb[0] = ctx->hop_count;
+    mb[1] = ctx->sel_cbT ? ctx->vq_k : 0;
+    std::memcpy(mb + 2, &ctx->sel_cbT, sizeof(float*));
+    std::memcpy(mb + 4, &ctx->sel_cnorm, sizeof(float*));
+  }
   ctx->hop_count = hop_next(ctx->hop_count);
-  bool ok = hip_ok(hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * (B_IN_HOP + 1), hipMemcpyHostToDevice, ctx->stream), "in");
+  bool ok = hip_ok(hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * (B_IN_HOP + kMailboxWords), hipMemcpyHostToDevice, ctx->stream), "in");
   phone_forward(m->w, ctx->st, ctx->stream);
   ok = ok && hip_ok(hipMemcpyAsync(h_out, ctx->st.d_phone, sizeof(float) * B_PHONE_CH, hipMemcpyDeviceToHost, ctx->stream), "out");
   ok = wait_stream(ctx->stream) && ok;
@@ -189,14 +234,20 @@ Beatrice_ErrorCode Beatrice20rc0_ReadPitchEstimatorParameters(Beatrice20rc0_Pitc
 Beatrice20rc0_PitchContext1* Beatrice20rc0_CreatePitchContext1(void) {
   auto* c = new Beatrice20rc0_PitchContext1();
   c->ok = make_stream(&c->stream) && c->st.create(1, 1, nullptr, false) &&
-          hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(float) * (B_IN_HOP + 1 + 8), hipHostMallocDefault), "hipHostMalloc");
-  c->st.hop = c->st.hop_in = c->st.hop_mailbox;  // step counter arrives with the input copy
+          hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(float) * (B_IN_HOP + kMailboxWords + 8), hipHostMallocDefault), "hipHostMalloc");
+  if (c->ok) {  // step counter and bin range arrive with the input copy (mailbox behind the audio)
+    c->st.hop = c->st.hop_in = c->st.hop_mailbox;
+    c->own_sel[0] = c->st.d_min_q; c->own_sel[1] = c->st.d_max_q;
+    c->st.d_min_q = c->st.hop_mailbox + 1;
+    c->st.d_max_q = c->st.hop_mailbox + 2;
+  }
   c->st.advance_hop = false;
   return c;
 }
 void Beatrice20rc0_DestroyPitchContext1(Beatrice20rc0_PitchContext1* c) {
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->own_sel[0]) { c->st.d_min_q = static_cast<int*>(c->own_sel[0]); c->st.d_max_q = static_cast<int*>(c->own_sel[1]); }
   c->st.destroy();
   if (c->h_io) (void)hipHostFree(c->h_io);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -206,13 +257,11 @@ static int clamp_bin(int q) { return q < 1 ? 1 : (q > B_PITCH_BINS - 1 ? B_PITCH
 // ref beatrice.h:258-265; callers processor_core_2.cc:561-583
 void Beatrice20rc0_SetMinQuantizedPitch(Beatrice20rc0_PitchContext1* ctx, int q) {
   if (!ctx || !ctx->ok) return;
-  q = clamp_bin(q);
-  (void)hip_ok(hipMemcpy(ctx->st.d_min_q, &q, sizeof(int), hipMemcpyHostToDevice), "min q");
+  ctx->min_q = clamp_bin(q);  // host-side only: travels with the next hop's input
 }
 void Beatrice20rc0_SetMaxQuantizedPitch(Beatrice20rc0_PitchContext1* ctx, int q) {
   if (!ctx || !ctx->ok) return;
-  q = clamp_bin(q);
-  (void)hip_ok(hipMemcpy(ctx->st.d_max_q, &q, sizeof(int), hipMemcpyHostToDevice), "max q");
+  ctx->max_q = clamp_bin(q);
 }
 // ref beatrice.h:266-271; caller processor_core_2.cc:186-189
 void Beatrice20rc0_EstimatePitch1(const Beatrice20rc0_PitchEstimator* m, const float* input, int* out_q, float* out_feat,
@@ -221,12 +270,15 @@ void Beatrice20rc0_EstimatePitch1(const Beatrice20rc0_PitchEstimator* m, const f
   std::memset(out_feat, 0, sizeof(float) * 4);
   if (!m || !m->loaded || !ctx || !ctx->ok) return;
   float* h_in = ctx->h_io;
-  float* h_feat = ctx->h_io + B_IN_HOP + 1;
-  int* h_q = reinterpret_cast<int*>(ctx->h_io + B_IN_HOP + 1 + 4);
+  float* h_feat = ctx->h_io + B_IN_HOP + kMailboxWords;
+  int* h_q = reinterpret_cast<int*>(ctx->h_io + B_IN_HOP + kMailboxWords + 4);
   std::memcpy(h_in, input, sizeof(float) * B_IN_HOP);
-  std::memcpy(h_in + B_IN_HOP, &ctx->hop_count, sizeof(int));
+  {  // mailbox: counter | lowest bin | highest bin
+    int* mb = reinterpret_cast<int*>(h_in + B_IN_HOP);
+    mb[0] = ctx->hop_count; mb[1] = ctx->min_q; mb[2] = ctx->max_q;
+  }
   ctx->hop_count = hop_next(ctx->hop_count);
-  bool ok = hip_ok(hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * (B_IN_HOP + 1), hipMemcpyHostToDevice, ctx->stream), "in");
+  bool ok = hip_ok(hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * (B_IN_HOP + kMailboxWords), hipMemcpyHostToDevice, ctx->stream), "in");
   pitch_forward(m->w, ctx->st, ctx->stream);
   ok = ok && hip_ok(hipMemcpyAsync(h_feat, ctx->st.d_feat, sizeof(float) * 4, hipMemcpyDeviceToHost, ctx->stream), "feat");
   ok = ok && hip_ok(hipMemcpyAsync(h_q, ctx->st.d_q_raw, sizeof(int), hipMemcpyDeviceToHost, ctx->stream), "q");
@@ -305,59 +357,86 @@ Beatrice_ErrorCode Beatrice20rc0_ReadEmbeddingSetterParameters(Beatrice20rc0_Emb
   const Beatrice_ErrorCode e = read_model_file(path, KIND_EMBED, (long)EmbedWeights::n_floats(), &host);
   return e ? e : install(m, host);
 }
-// ref beatrice.h:312-313
+// ref beatrice.h:312-313.  Pinned staging for every setter is allocated here, so that the setters themselves (the
+// host calls SetAdditive / Register / SetKeyValue on its audio thread in morph mode, processor_core_2.cc:124-172)
+// neither allocate nor wait: uploads and projections are enqueued on HIP streams, ordered by events.
 Beatrice20rc0_EmbeddingContext* Beatrice20rc0_CreateEmbeddingContext(void) {
   auto* c = new Beatrice20rc0_EmbeddingContext();
-  const size_t n = (size_t)B_KV_LEN * B_KV_CH + 4 * B_HID;
+  const size_t n = (size_t)B_KV_LEN * B_KV_CH + 2 * 2 * B_HID + 2 * B_HID;
+  const size_t nh = (size_t)B_KV_LEN * B_KV_CH + 4 * B_HID;
   c->ok = make_stream(&c->stream) && hip_ok(hipMalloc(reinterpret_cast<void**>(&c->d_block), sizeof(float) * n), "embed ctx") &&
-          hip_ok(hipMemset(c->d_block, 0, sizeof(float) * n), "embed ctx0");
+          hip_ok(hipMemset(c->d_block, 0, sizeof(float) * n), "embed ctx0") &&
+          hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), sizeof(float) * nh, hipHostMallocDefault), "embed stage") &&
+          hip_ok(hipEventCreateWithFlags(&c->kv_uploaded, hipEventDisableTiming), "ev") &&
+          hip_ok(hipEventCreateWithFlags(&c->kv_projected, hipEventDisableTiming), "ev");
+  for (int i = 0; i < 4 && c->ok; ++i) c->ok = hip_ok(hipEventCreateWithFlags(&c->vec_sent[i], hipEventDisableTiming), "ev");
   (void)hipDeviceSynchronize();  // NULL-stream memset vs the context's non-blocking stream
   c->d_kv_raw = c->d_block;
-  c->d_tmp = c->d_block + (size_t)B_KV_LEN * B_KV_CH;
-  c->d_add = c->d_tmp + B_HID;
+  c->d_tmp = c->d_block + (size_t)B_KV_LEN * B_KV_CH;  // [4][256] upload slots: additive x2, formant x2
+  c->d_add = c->d_tmp + 4 * B_HID;
   c->d_frm = c->d_add + B_HID;
   return c;
 }
 void Beatrice20rc0_DestroyEmbeddingContext(Beatrice20rc0_EmbeddingContext* c) {
   if (!c) return;
-  if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+  (void)hipDeviceSynchronize();  // setter work may sit on waveform contexts' streams
+  if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->d_block) (void)hipFree(c->d_block);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
+  for (hipEvent_t e : c->vec_sent) if (e) (void)hipEventDestroy(e);
+  if (c->kv_uploaded) (void)hipEventDestroy(c->kv_uploaded);
+  if (c->kv_projected) (void)hipEventDestroy(c->kv_projected);
   delete c;
 }
-static void set_vector(const Beatrice20rc0_EmbeddingSetter* m, const float* w, const float* b, const float* embedding,
-                       Beatrice20rc0_EmbeddingContext* ec, float* d_ctx_vec, float* d_wave_row) {
+// kind 0 = additive, 1 = formant.  The work goes to the waveform context's stream when there is one, so it is ordered
+// before that context's next GenerateWaveform1 without a wait here.
+static void set_vector(const Beatrice20rc0_EmbeddingSetter* m, int kind, const float* w, const float* b, const float* embedding,
+                       Beatrice20rc0_EmbeddingContext* ec, float* d_ctx_vec, Beatrice20rc0_WaveformContext1* wc, float* d_wave_row) {
   if (!m || !m->loaded || !ec || !ec->ok || !embedding) return;
-  if (!hip_ok(hipMemcpy(ec->d_tmp, embedding, sizeof(float) * B_HID, hipMemcpyHostToDevice), "emb up")) return;
-  embed_project_rows(w, b, ec->d_tmp, d_ctx_vec, 1, ec->stream);
-  if (d_wave_row) (void)hip_ok(hipMemcpyAsync(d_wave_row, d_ctx_vec, sizeof(float) * B_HID, hipMemcpyDeviceToDevice, ec->stream), "emb d2d");
-  (void)hip_ok(hipStreamSynchronize(ec->stream), "emb sync");
+  const int slot = kind * 2 + (ec->vec_next[kind] ^= 1);
+  if (ec->vec_busy[slot]) { (void)hipEventSynchronize(ec->vec_sent[slot]); ec->vec_busy[slot] = false; }  // two calls ago
+  float* h = ec->h_stage + (size_t)B_KV_LEN * B_KV_CH + (size_t)slot * B_HID;
+  float* d = ec->d_tmp + (size_t)slot * B_HID;
+  std::memcpy(h, embedding, sizeof(float) * B_HID);
+  hipStream_t st = (wc && wc->ok) ? wc->stream : ec->stream;
+  if (!hip_ok(hipMemcpyAsync(d, h, sizeof(float) * B_HID, hipMemcpyHostToDevice, st), "emb up")) return;
+  ec->vec_busy[slot] = hip_ok(hipEventRecord(ec->vec_sent[slot], st), "emb ev");
+  embed_project_rows(w, b, d, d_ctx_vec, 1, st);
+  if (d_wave_row) (void)hip_ok(hipMemcpyAsync(d_wave_row, d_ctx_vec, sizeof(float) * B_HID, hipMemcpyDeviceToDevice, st), "emb d2d");
 }
 // ref beatrice.h:323-327; callers processor_core_2.cc:137-141, 451-455
 void Beatrice20rc0_SetAdditiveSpeakerEmbedding(const Beatrice20rc0_EmbeddingSetter* m, const float* embedding,
                                                Beatrice20rc0_EmbeddingContext* ec, Beatrice20rc0_WaveformContext1* wc) {
   if (!m || !m->loaded) return;
-  set_vector(m, m->w.add_w, m->w.add_b, embedding, ec, ec ? ec->d_add : nullptr, (wc && wc->ok) ? wc->st.d_add_tab : nullptr);
+  set_vector(m, 0, m->w.add_w, m->w.add_b, embedding, ec, ec ? ec->d_add : nullptr, wc, (wc && wc->ok) ? wc->st.d_add_tab : nullptr);
 }
 // ref beatrice.h:328-332; caller processor_core_2.cc:475-479
 void Beatrice20rc0_SetFormantShiftEmbedding(const Beatrice20rc0_EmbeddingSetter* m, const float* embedding,
                                             Beatrice20rc0_EmbeddingContext* ec, Beatrice20rc0_WaveformContext1* wc) {
   if (!m || !m->loaded) return;
-  set_vector(m, m->w.frm_w, m->w.frm_b, embedding, ec, ec ? ec->d_frm : nullptr, (wc && wc->ok) ? wc->st.d_frm_tab : nullptr);
+  set_vector(m, 1, m->w.frm_w, m->w.frm_b, embedding, ec, ec ? ec->d_frm : nullptr, wc, (wc && wc->ok) ? wc->st.d_frm_tab : nullptr);
 }
-// ref beatrice.h:333-338; callers processor_core_2.cc:165-170, 456-462.  Copies: the host rewrites
-// its morph slot in place right after registering (processor_core_2.cc:158-170).
+// ref beatrice.h:333-338; callers processor_core_2.cc:165-170, 456-462.  Copies before returning: the host rewrites
+// its morph slot in place right after registering (processor_core_2.cc:158-170).  The copy is host-side (pinned
+// staging); the upload is enqueued behind the projections that still read the previous registration.
 void Beatrice20rc0_RegisterKeyValueSpeakerEmbedding(const Beatrice20rc0_EmbeddingSetter* m, const float* kv,
                                                     Beatrice20rc0_EmbeddingContext* ec) {
   (void)m;
   if (!ec || !ec->ok || !kv) return;
-  (void)hip_ok(hipMemcpy(ec->d_kv_raw, kv, sizeof(float) * B_KV_LEN * B_KV_CH, hipMemcpyHostToDevice), "kv up");
+  if (ec->kv_busy) { (void)hipEventSynchronize(ec->kv_uploaded); ec->kv_busy = false; }  // previous upload still reads the staging
+  std::memcpy(ec->h_stage, kv, sizeof(float) * B_KV_LEN * B_KV_CH);
+  if (ec->kv_proj_pending) (void)hip_ok(hipStreamWaitEvent(ec->stream, ec->kv_projected, 0), "kv order");
+  if (!hip_ok(hipMemcpyAsync(ec->d_kv_raw, ec->h_stage, sizeof(float) * B_KV_LEN * B_KV_CH, hipMemcpyHostToDevice, ec->stream), "kv up")) return;
+  ec->kv_busy = hip_ok(hipEventRecord(ec->kv_uploaded, ec->stream), "kv ev");
 }
-// ref beatrice.h:339-343; caller processor_core_2.h:161-169 (one block per hop after a change)
+// ref beatrice.h:339-343; caller processor_core_2.h:161-169 (one block per hop after a change).  Projection on the
+// waveform context's stream, behind the upload: done before that context's next GenerateWaveform1, no wait here.
 void Beatrice20rc0_SetKeyValueSpeakerEmbedding(const Beatrice20rc0_EmbeddingSetter* m, int block,
                                                Beatrice20rc0_EmbeddingContext* ec, Beatrice20rc0_WaveformContext1* wc) {
   if (!m || !m->loaded || !ec || !ec->ok || !wc || !wc->ok || block < 0 || block >= B_NBLOCKS) return;
-  embed_project_kv(m->w, block, ec->d_kv_raw, 1, wc->st.d_kt[block], wc->st.d_v[block], ec->stream);
-  (void)hip_ok(hipStreamSynchronize(ec->stream), "kv sync");
+  if (ec->kv_busy) (void)hip_ok(hipStreamWaitEvent(wc->stream, ec->kv_uploaded, 0), "kv wait");
+  embed_project_kv(m->w, block, ec->d_kv_raw, 1, wc->st.d_kt[block], wc->st.d_v[block], wc->stream);
+  ec->kv_proj_pending = hip_ok(hipEventRecord(ec->kv_projected, wc->stream), "kv proj ev");
 }
 
 // ================================ speaker file =================================================

@@ -13,7 +13,11 @@ Beatrice_ErrorCode parse_model_bytes(const unsigned char* bytes, size_t size, ui
                                      std::vector<float>* out);
 Beatrice_ErrorCode read_model_file(const char* path, uint32_t kind, long expect_floats, std::vector<float>* out);
 bool make_stream(hipStream_t* s);
-struct CodebookEntry { const float* host; float* d_cbT; float* d_cnorm; };
+// One slot of a phone context's codebook pool (abi.hip, Beatrice20rc0_SetCodebook): the device form (transposed +
+// norms) of the caller's table at `host`; `print` fingerprints the caller's bytes so that a table rewritten in
+// place (a host that reloads a model into the same storage) is re-uploaded instead of served stale.
+struct CodebookEntry { const float* host = nullptr; uint64_t print = 0; unsigned long long last_use = 0; float* d_cbT = nullptr; float* d_cnorm = nullptr; };
+constexpr int kCodebookPool = 12;  // >= the 8 speakers a morph can draw from (reference processor_core_2.cc:515-525) + slack
 }  // namespace bhip
 
 // model objects: immutable after Read*Parameters, shareable between contexts and threads
@@ -26,16 +30,33 @@ struct Beatrice20rc0_EmbeddingSetter { bhip::DeviceBlob blob; bhip::EmbedWeights
 struct Beatrice20rc0_PhoneContext1 {
   bhip::PhoneState st;
   hipStream_t stream = nullptr;
-  float* h_io = nullptr;  // pinned: 160 in | step counter | 128 out
+  float* h_io = nullptr;  // pinned: 160 in | mailbox (step counter, k, codebook pointers) | 128 out
   int hop_count = 0;      // hops done; travels to the device with the input copy (no launch spent on counting)
-  std::vector<bhip::CodebookEntry> cache;
+  // k-NN settings travel with the input copy too (mailbox words behind the audio: counter | k | cbT* | cnorm*), so
+  // SetVQNumNeighbors / SetCodebook issue no device call of their own
+  int vq_k = 0;
+  const float* sel_cbT = nullptr;
+  const float* sel_cnorm = nullptr;
+  // codebook pool: every slot, the raw staging buffer and its pinned host twin are allocated in CreatePhoneContext1;
+  // a table seen for the first time is uploaded stream-ordered into the least recently used slot (no hipMalloc, no wait)
+  bhip::CodebookEntry pool[bhip::kCodebookPool];
+  float* d_pool = nullptr;     // [kCodebookPool][128*512 + 512]
+  float* d_cb_stage = nullptr; // [2][512*128] raw upload staging, alternating
+  float* h_cb_stage = nullptr; // pinned twin
+  hipEvent_t stage_done[2] = {nullptr, nullptr};
+  bool stage_busy[2] = {false, false};
+  int stage_next = 0;
+  unsigned long long use_clock = 0;
+  void* own_sel[3] = {nullptr, nullptr, nullptr};  // the state's own (unused) selector arrays, handed back before destroy()
   bool ok = false;
 };
 struct Beatrice20rc0_PitchContext1 {
   bhip::PitchState st;
   hipStream_t stream = nullptr;
-  float* h_io = nullptr;  // pinned: 160 in | step counter | 4 feat | 1 bin
+  float* h_io = nullptr;  // pinned: 160 in | mailbox (step counter, bin range) | 4 feat | 1 bin
   int hop_count = 0;
+  int min_q = 1, max_q = BEATRICE_20RC0_PITCH_BINS - 1;  // travel with the input copy
+  void* own_sel[2] = {nullptr, nullptr};
   bool ok = false;
 };
 struct Beatrice20rc0_WaveformContext1 {
@@ -50,5 +71,11 @@ struct Beatrice20rc0_EmbeddingContext {
   hipStream_t stream = nullptr;
   float* d_block = nullptr;
   float *d_kv_raw = nullptr, *d_tmp = nullptr, *d_add = nullptr, *d_frm = nullptr;
+  float* h_stage = nullptr;  // pinned: key/value registration [384][128] | 4 vector slots (additive x2, formant x2)
+  hipEvent_t vec_sent[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool vec_busy[4] = {false, false, false, false};
+  int vec_next[2] = {0, 0};
+  hipEvent_t kv_uploaded = nullptr, kv_projected = nullptr;
+  bool kv_busy = false, kv_proj_pending = false;
   bool ok = false;
 };

@@ -29,7 +29,8 @@ struct StreamCfg {
   int target_speaker = 0;
   int kv_set_count = B_NBLOCKS;  // reference: key_value_speaker_embedding_set_count_ (processor_core_2.h:134)
   int kv_slot[B_NBLOCKS] = {0, 0, 0, 0};
-  int codebook_speaker = 0;
+  int codebook_speaker = 0;       // after a step: the codebook of its last hop
+  int codebook_row[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // codebook of each hop of the step (a morphing stream draws one per hop)
   int additive_speaker = 0;
   int formant_index = 4;
   int vq_k = 0;
@@ -45,7 +46,6 @@ struct MorphSlot {
   int n_odds = 0;               // min(n_speakers, 8)
   int order[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   float odds[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // pruned weights in `order`
-  std::mt19937 rng;
 };
 
 // Pinned host copy of a small per-stream device array.  Double-buffered: push() sends the buffer the
@@ -120,6 +120,9 @@ struct BeatriceBatch {
   std::vector<StreamCfg> cfg;
   std::vector<MorphSlot> morph;  // [max_speakers]
   int n_morph_slots = 0;
+  // the codebook lottery's engine belongs to the stream, as the reference's belongs to the plugin instance
+  // (processor_core_2.h:48,145): a stream's draws do not depend on which other streams share its batch
+  std::vector<std::mt19937> lottery;  // [B]
   // every per-stream setting array the kernels read lives in ONE device block with one pinned mirror, so a
   // step after any change costs a single small host-to-device copy (a dozen separate copies cost ~50 us of
   // stream time per step with 64 rotating speakers)
@@ -250,8 +253,10 @@ void fill_row_slots(BeatriceBatch* b, int s) {
 
 void sync_stream_arrays(BeatriceBatch* b, int s) {
   const StreamCfg& c = b->cfg[s];
-  b->host_view<const float*>(b->off.cbT)[s] = b->d_cbT + (size_t)c.codebook_speaker * B_PHONE_CH * B_CODEBOOK;
-  b->host_view<const float*>(b->off.cnorm)[s] = b->d_cnorm + (size_t)c.codebook_speaker * B_CODEBOOK;
+  for (int hh = 0; hh < b->H; ++hh) {  // k-NN rows are (stream, hop in step)
+    b->host_view<const float*>(b->off.cbT)[(size_t)s * b->H + hh] = b->d_cbT + (size_t)c.codebook_row[hh] * B_PHONE_CH * B_CODEBOOK;
+    b->host_view<const float*>(b->off.cnorm)[(size_t)s * b->H + hh] = b->d_cnorm + (size_t)c.codebook_row[hh] * B_CODEBOOK;
+  }
   b->host_view<int>(b->off.vqk)[s] = c.vq_k;
   b->host_view<int>(b->off.min_q)[s] = c.min_q;
   b->host_view<int>(b->off.max_q)[s] = c.max_q;
@@ -372,27 +377,32 @@ void update_vq_mode(BeatriceBatch* b) {
   if (none != b->phone.skip_vq) { settle(b); b->phone.skip_vq = none; drop_graph(b); }
 }
 
-// streams whose target is a morphed entry draw the codebook of ONE real speaker per step, with the
-// morph weights as odds (reference processor_core_2.cc:94-121: same draws, same order of operations)
+// streams whose target is a morphed entry draw the codebook of ONE real speaker per hop, with the
+// morph weights as odds (reference processor_core_2.cc:94-121: same draws, same order of operations), from
+// the stream's own engine
 void draw_codebooks(BeatriceBatch* b) {
   if (b->n_morph_slots == 0) return;
   for (int s = 0; s < b->B; ++s) {
     StreamCfg& c = b->cfg[s];
     MorphSlot& m = b->morph[c.target_speaker];
     if (!m.active) continue;
+    std::mt19937& rng = b->lottery[s];
     float sum = 0.0f;
     for (int i = 0; i < m.n_odds; ++i) sum += m.odds[i];
-    int idx = m.order[0];
-    if (sum <= std::numeric_limits<float>::epsilon()) {
-      idx = std::uniform_int_distribution<int>(0, m.n_speakers - 1)(m.rng);
-    } else {
-      float r = std::uniform_real_distribution<float>(0.0f, sum)(m.rng);
-      for (int i = 0; i < m.n_odds; ++i) {
-        r -= m.odds[i];
-        if (r < 0.0f) { idx = m.order[i]; break; }
+    for (int hh = 0; hh < b->H; ++hh) {
+      int idx = m.order[0];
+      if (sum <= std::numeric_limits<float>::epsilon()) {
+        idx = std::uniform_int_distribution<int>(0, m.n_speakers - 1)(rng);
+      } else {
+        float r = std::uniform_real_distribution<float>(0.0f, sum)(rng);
+        for (int i = 0; i < m.n_odds; ++i) {
+          r -= m.odds[i];
+          if (r < 0.0f) { idx = m.order[i]; break; }
+        }
       }
+      c.codebook_row[hh] = idx;
     }
-    c.codebook_speaker = idx;
+    c.codebook_speaker = c.codebook_row[b->H - 1];
     sync_stream_arrays(b, s);
   }
 }
@@ -460,6 +470,35 @@ int midi_to_bin(double note) {
 
 }  // namespace
 
+// ---- device-resident parameter blobs (multi-GPU load) ------------------------
+// Rank 0 reads and packs a model file once; the other ranks allocate an empty blob of the same size, the caller
+// broadcasts device memory to device memory (RCCL over xGMI) and marks the model ready: what travels is exactly
+// what the kernels read (MFMA-fragment order), no host round trip and no repacking on the receivers.
+namespace {
+template <class Model, class Weights>
+int model_blob(Model* m, int allocate, void** d_ptr, size_t* n_bytes) {
+  if (!m || !d_ptr || !n_bytes) return -1;
+  const size_t n = Weights::n_floats();
+  if (allocate && !m->loaded && m->blob.n_floats != n) {
+    m->blob.release();
+    if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&m->blob.d), n * sizeof(float)), "blob alloc")) return -2;
+    m->blob.n_floats = n;
+  }
+  if (!m->blob.d || m->blob.n_floats != n) return -1;
+  *d_ptr = m->blob.d;
+  *n_bytes = n * sizeof(float);
+  return 0;
+}
+template <class Model>
+int model_ready(Model* m) {
+  if (!m || !m->blob.d) return -1;
+  if (!hip_ok(hipDeviceSynchronize(), "blob ready")) return -2;
+  m->w.bind(m->blob.d);
+  m->loaded = true;
+  return 0;
+}
+}  // namespace
+
 extern "C" {
 
 // ---- memory loaders ---------------------------------------------------------------------------
@@ -480,6 +519,25 @@ BHIP_MEMORY_LOADER(PhoneExtractor, Beatrice20rc0_PhoneExtractor, KIND_PHONE, Pho
 BHIP_MEMORY_LOADER(PitchEstimator, Beatrice20rc0_PitchEstimator, KIND_PITCH, PitchWeights)
 BHIP_MEMORY_LOADER(WaveformGenerator, Beatrice20rc0_WaveformGenerator, KIND_WAVE, WaveWeights)
 BHIP_MEMORY_LOADER(EmbeddingSetter, Beatrice20rc0_EmbeddingSetter, KIND_EMBED, EmbedWeights)
+
+int BeatriceHip_ModelBlob(int kind, void* model, int allocate, void** d_ptr, size_t* n_bytes) {
+  switch (kind) {
+    case KIND_PHONE: return model_blob<Beatrice20rc0_PhoneExtractor, PhoneWeights>(static_cast<Beatrice20rc0_PhoneExtractor*>(model), allocate, d_ptr, n_bytes);
+    case KIND_PITCH: return model_blob<Beatrice20rc0_PitchEstimator, PitchWeights>(static_cast<Beatrice20rc0_PitchEstimator*>(model), allocate, d_ptr, n_bytes);
+    case KIND_WAVE: return model_blob<Beatrice20rc0_WaveformGenerator, WaveWeights>(static_cast<Beatrice20rc0_WaveformGenerator*>(model), allocate, d_ptr, n_bytes);
+    case KIND_EMBED: return model_blob<Beatrice20rc0_EmbeddingSetter, EmbedWeights>(static_cast<Beatrice20rc0_EmbeddingSetter*>(model), allocate, d_ptr, n_bytes);
+    default: return -1;
+  }
+}
+int BeatriceHip_ModelBlobReady(int kind, void* model) {
+  switch (kind) {
+    case KIND_PHONE: return model_ready(static_cast<Beatrice20rc0_PhoneExtractor*>(model));
+    case KIND_PITCH: return model_ready(static_cast<Beatrice20rc0_PitchEstimator*>(model));
+    case KIND_WAVE: return model_ready(static_cast<Beatrice20rc0_WaveformGenerator*>(model));
+    case KIND_EMBED: return model_ready(static_cast<Beatrice20rc0_EmbeddingSetter*>(model));
+    default: return -1;
+  }
+}
 
 // ---- lifecycle ----------------------------------------------------------------------------------
 BeatriceBatch* BeatriceBatch_Create(const Beatrice20rc0_PhoneExtractor* phone, const Beatrice20rc0_PitchEstimator* pitch,
@@ -529,14 +587,19 @@ BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* pho
        hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_add_raw), sizeof(float) * S * B_HID), "add") &&
        hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_frm_raw), sizeof(float) * 9 * B_HID), "frm") &&
        hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_kv_raw), sizeof(float) * kvf), "kv");
-  ok = ok && hip_ok(hipMemset(b->d_cbT, 0, sizeof(float) * cbf), "cbT0") && hip_ok(hipMemset(b->d_cnorm, 0, sizeof(float) * S * B_CODEBOOK), "cn0");
+  ok = ok && hip_ok(hipMemset(b->d_cbT, 0, sizeof(float) * cbf), "cbT0") && hip_ok(hipMemset(b->d_cnorm, 0, sizeof(float) * S * B_CODEBOOK), "cn0") &&
+       // entries the caller never fills (a morph entry's codebook, speakers added later) project to zeros, not to garbage
+       hip_ok(hipMemset(b->d_cb_raw, 0, sizeof(float) * cbf), "cb0") && hip_ok(hipMemset(b->d_add_raw, 0, sizeof(float) * S * B_HID), "add0") &&
+       hip_ok(hipMemset(b->d_frm_raw, 0, sizeof(float) * 9 * B_HID), "frm0") && hip_ok(hipMemset(b->d_kv_raw, 0, sizeof(float) * kvf), "kv0");
   b->cfg.assign(B, StreamCfg());
   b->morph.assign(S, MorphSlot());
+  b->lottery.resize(B);
+  for (int s = 0; s < B; ++s) b->lottery[s].seed(5489u + (unsigned)s);
   {  // layout of the settings block (256-byte aligned arrays)
     size_t o = 0;
     auto take = [&o](size_t bytes) { const size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
     const size_t nt = ok ? (size_t)b->wave.n_tiles_max : 1;
-    b->off.cbT = take(sizeof(float*) * B); b->off.cnorm = take(sizeof(float*) * B); b->off.vqk = take(sizeof(int) * B);
+    b->off.cbT = take(sizeof(float*) * B * H); b->off.cnorm = take(sizeof(float*) * B * H); b->off.vqk = take(sizeof(int) * B);
     b->off.min_q = take(sizeof(int) * B); b->off.max_q = take(sizeof(int) * B);
     b->off.add_idx = take(sizeof(int) * B); b->off.frm_idx = take(sizeof(int) * B); b->off.params = take(sizeof(PitchParams) * B);
     b->off.front_bytes = o;
@@ -664,6 +727,31 @@ int BeatriceBatch_SetSpeakerTables(BeatriceBatch* b, int n, const float* codeboo
   return project_speakers(b, 0, n) ? 0 : -2;
 }
 
+// The four raw tables as they sit on the device, for callers that fill them device-to-device (a broadcast from the
+// rank that read the file): [0] codebooks [S][512][128], [1] additive [S][256], [2] formant [9][256], [3] key/value
+// [S][384][128]; then BeatriceBatch_ProjectSpeakerTables(b, n) does what SetSpeakerTables does after its upload.
+int BeatriceBatch_SpeakerTablesDevice(BeatriceBatch* b, void** d_ptrs, size_t* n_bytes) {
+  if (!b || !b->ok) return -2;
+  if (!d_ptrs || !n_bytes) return -1;
+  const size_t S = (size_t)b->max_speakers;
+  d_ptrs[0] = b->d_cb_raw; n_bytes[0] = sizeof(float) * S * B_CODEBOOK * B_PHONE_CH;
+  d_ptrs[1] = b->d_add_raw; n_bytes[1] = sizeof(float) * S * B_HID;
+  d_ptrs[2] = b->d_frm_raw; n_bytes[2] = sizeof(float) * 9 * B_HID;
+  d_ptrs[3] = b->d_kv_raw; n_bytes[3] = sizeof(float) * S * B_KV_LEN * B_KV_CH;
+  return 0;
+}
+int BeatriceBatch_ProjectSpeakerTables(BeatriceBatch* b, int n) {
+  if (!b || !b->ok) return -2;
+  if (n < 1 || n > b->max_speakers) return -1;
+  if (!sync_all(b) || !hip_ok(hipDeviceSynchronize(), "tables sync")) return -2;
+  b->n_speakers = n;
+  for (MorphSlot& m : b->morph) m.active = false;
+  b->n_morph_slots = 0;
+  const EmbedWeights& w = b->embed_m->w;
+  embed_project_rows(w.frm_w, w.frm_b, b->d_frm_raw, b->wave.d_frm_tab, 9, b->stream);
+  return project_speakers(b, 0, n) ? 0 : -2;
+}
+
 int BeatriceBatch_UpdateSpeaker(BeatriceBatch* b, int spk, const float* codebook, const float* additive, const float* kv) {
   if (!b || !b->ok) return -2;
   if (spk < 0 || spk >= b->max_speakers) return -1;
@@ -714,11 +802,19 @@ int BeatriceBatch_MorphSpeaker(BeatriceBatch* b, int slot, const float* weights,
   m.n_speakers = n_weights;
   m.n_odds = keep;
   for (int i = 0; i < 8; ++i) { m.order[i] = i < keep ? order[i] : 0; m.odds[i] = i < keep ? w[order[i]] : 0.0f; }
-  m.rng.seed(seed);
+  for (int st = 0; st < b->B; ++st) b->lottery[st].seed(seed + (unsigned)st);  // BeatriceBatch_SeedLottery for other seeds
   // streams already on this entry re-install its key/value blocks, one per hop, like after a speaker switch
   for (StreamCfg& c : b->cfg) if (c.target_speaker == slot) c.kv_set_count = 0;
   b->pending_kv = 0;
   for (const StreamCfg& c : b->cfg) if (c.kv_set_count < B_NBLOCKS) ++b->pending_kv;
+  return 0;
+}
+// the codebook lottery's engine of one stream (or of all, -1): std::mt19937(seed), e.g. a value derived from the
+// stream's global identity when streams are sharded over several batches / GPUs
+int BeatriceBatch_SeedLottery(BeatriceBatch* b, int stream, unsigned seed) {
+  if (!b || !b->ok) return -2;
+  if (stream < -1 || stream >= b->B) return -1;
+  for (int s = (stream < 0 ? 0 : stream); s < (stream < 0 ? b->B : stream + 1); ++s) b->lottery[s].seed(seed);
   return 0;
 }
 // copies the morphed entry's raw embeddings back (test / inspection hook; any pointer may be NULL)
@@ -739,6 +835,7 @@ int BeatriceBatch_SetTargetSpeaker(BeatriceBatch* b, int stream, int speaker) {
   if (speaker < 0 || speaker >= b->max_speakers) return -1;
   const int r = for_streams(b, stream, [&](StreamCfg& c) {
     c.target_speaker = speaker; c.codebook_speaker = speaker; c.additive_speaker = speaker; c.kv_set_count = 0;
+    for (int& cr : c.codebook_row) cr = speaker;
   });
   if (r == 0) { b->pending_kv = 0; for (const StreamCfg& c : b->cfg) if (c.kv_set_count < B_NBLOCKS) ++b->pending_kv; }
   return r;
@@ -963,7 +1060,11 @@ struct ProfileHook : LaunchHook {
   hipEvent_t e0, e1;
   bool ok = true;
   void on_launch(const LaunchInfo& info, hipStream_t stream, void (*thunk)(void*), void* ctx) override {
-    const int reps = std::strcmp(info.name, "hop_advance") == 0 ? 1 : repeats;  // the only non-idempotent launch
+    // launches that update state in place run once (the tail rewrites its history block, the pitch head its previous
+    // bin, the GRUs their state, hop_advance the counter); everything else only writes this step's ring slots
+    const bool once = std::strstr(info.name, "hop_advance") || std::strstr(info.name, "wave.tail") || std::strstr(info.name, "pitch.head") ||
+                      std::strstr(info.name, "gru");
+    const int reps = once ? 1 : repeats;
     ok = ok && hip_ok(hipEventRecord(e0, stream), "p0");
     for (int i = 0; i < reps; ++i) thunk(ctx);
     float ms = 0.f;
@@ -999,6 +1100,7 @@ int BeatriceBatch_ProfileKernels(BeatriceBatch* b, int repeats, int max_entries,
   launch_hook() = nullptr;
   b->last_parity = b->hop_host % 3;
   b->hop_host = hop_next(b->hop_host);
+  b->steps_enqueued += 1;
   if (!hook.ok || !sync_all(b)) return -2;
   const int n = std::min<int>((int)hook.rows.size(), max_entries);
   for (int i = 0; i < n; ++i) {

@@ -62,6 +62,11 @@ struct RingArena {
   void release();
 };
 
+// words behind a module-owned input buffer that travel with the 1-stream ABI's input copy (abi.hip):
+//   phone: [0] step counter, [1] k-NN k, [2..3] codebook^T pointer, [4..5] norms pointer
+//   pitch: [0] step counter, [1] lowest bin, [2] highest bin
+constexpr int kMailboxWords = 8;
+
 // ---- phone extractor ---------------------------------------------------------------------------
 struct PhoneWeights {
   const float *f1_w, *f1_b;
@@ -79,7 +84,7 @@ struct PhoneState {
   Ring audio, f[5], rb[4], h, raw;
   float* d_in = nullptr;     // [B][H*160]; owned unless shared
   bool owns_in = false;
-  int* hop_mailbox = nullptr;  // owned d_in only: one int right behind the audio (counter sent with the input copy)
+  int* hop_mailbox = nullptr;  // owned d_in only: kMailboxWords words right behind the audio (sent with the input copy)
   size_t io_stride = 0;        // batch, resident I/O: d_in holds several steps, this many floats apart (slot = hop[1])
   float* d_phone = nullptr;  // ring [B][out_slots * H][128]: step t writes slot t mod out_slots
   int out_slots = 1;         // 3 in a batch, so that the next steps' front end may run while the waveform generator reads
@@ -114,7 +119,7 @@ struct PitchState {
   Ring audio, spec, p[3], h, logits;
   float* d_in = nullptr;
   bool owns_in = false;
-  int* hop_mailbox = nullptr;  // owned d_in only: one int right behind the audio
+  int* hop_mailbox = nullptr;  // owned d_in only: kMailboxWords words right behind the audio
   size_t io_stride = 0;        // see PhoneState
   int *d_min_q = nullptr, *d_max_q = nullptr, *d_prev_q = nullptr;  // [B]
   int *d_q_raw = nullptr, *d_q = nullptr;                          // [B][H]

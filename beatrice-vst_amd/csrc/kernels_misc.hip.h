@@ -106,8 +106,8 @@ struct VqArgs {
   const float* raw;            // [B][H][128]
   Ring out;                    // C = 128, n = H frames per step, m = 1 or 2 step slots
   const int* hop;
-  const float* const* cbT;     // per stream: [128][512]
-  const float* const* cnorm;   // per stream: [512]
+  const float* const* cbT;     // per row (stream, hop): [128][512]
+  const float* const* cnorm;   // per row: [512]
   const int* k;                // per stream
 };
 constexpr int kVqLdsFloats = B_PHONE_CH + 8 + 8 + 8;
@@ -119,7 +119,7 @@ __device__ __forceinline__ void phone_vq_body(const VqArgs& a, const int row, fl
   const int b = row / a.H, j = threadIdx.x, lane = j & 63, wave = j >> 6;
   float* out = ring_frame(a.out, b, ring_pos(a.out, *a.hop), row % a.H);
   const int k = a.k[b];
-  const float* cbT = a.cbT[b];
+  const float* cbT = a.cbT[row];
   if (j < B_PHONE_CH) x[j] = a.raw[(size_t)row * B_PHONE_CH + j];
   if (k <= 0 || cbT == nullptr) {
     if (j < B_PHONE_CH) out[j] = x[j];
@@ -129,7 +129,7 @@ __device__ __forceinline__ void phone_vq_body(const VqArgs& a, const int row, fl
   float dot = 0.0f;
 #pragma unroll 8
   for (int c = 0; c < B_PHONE_CH; ++c) dot = bsp::fma(x[c], cbT[c * B_CODEBOOK + j], dot);
-  float d = bsp::fma(-2.0f, dot, a.cnorm[b][j]);
+  float d = bsp::fma(-2.0f, dot, a.cnorm[row][j]);
   float acc = 0.0f;
   for (int r = 0; r < k; ++r) {
     float bd = d;

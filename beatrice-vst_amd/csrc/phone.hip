@@ -18,20 +18,21 @@ bool PhoneState::create(int B_, int H_, float* shared_in, int out_slots_) {
   if (!arena.build(B, specs)) return false;
   if (shared_in) { d_in = shared_in; owns_in = false; }
   else {
-    // one extra word behind the audio: a step-counter mailbox the 1-stream ABI fills with the same copy
-    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_in), sizeof(float) * (B * H * B_IN_HOP + 1)));
-    BHIP_TRY(hipMemset(d_in, 0, sizeof(float) * (B * H * B_IN_HOP + 1)));
+    // eight extra words behind the audio: a mailbox the 1-stream ABI fills with the same copy as the audio
+    // (step counter | k-NN k | codebook pointers: abi.hip)
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_in), sizeof(float) * (B * H * B_IN_HOP + kMailboxWords)));
+    BHIP_TRY(hipMemset(d_in, 0, sizeof(float) * (B * H * B_IN_HOP + kMailboxWords)));
     owns_in = true;
     hop_mailbox = reinterpret_cast<int*>(d_in + (size_t)B * H * B_IN_HOP);
   }
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_phone), sizeof(float) * B * H * B_PHONE_CH * out_slots));
-  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cbT), sizeof(float*) * B));
-  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cnorm), sizeof(float*) * B));
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cbT), sizeof(float*) * B * H));
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cnorm), sizeof(float*) * B * H));
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_vqk), sizeof(int) * B));
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hop), 2 * sizeof(int)));  // [0] step counter, [1] resident-I/O slot
   BHIP_TRY(hipMemset(d_phone, 0, sizeof(float) * B * H * B_PHONE_CH * out_slots));
-  BHIP_TRY(hipMemset(d_cbT, 0, sizeof(float*) * B));
-  BHIP_TRY(hipMemset(d_cnorm, 0, sizeof(float*) * B));
+  BHIP_TRY(hipMemset(d_cbT, 0, sizeof(float*) * B * H));
+  BHIP_TRY(hipMemset(d_cnorm, 0, sizeof(float*) * B * H));
   BHIP_TRY(hipMemset(d_vqk, 0, sizeof(int) * B));
   BHIP_TRY(hipMemset(d_hop, 0, 2 * sizeof(int)));
   hop = d_hop; hop_in = d_hop;

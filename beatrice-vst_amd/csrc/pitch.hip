@@ -16,8 +16,8 @@ bool PitchState::create(int B_, int H_, float* shared_in, bool with_params) {
   if (!arena.build(B, specs)) return false;
   if (shared_in) { d_in = shared_in; owns_in = false; }
   else {
-    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_in), sizeof(float) * (B * H * B_IN_HOP + 1)));
-    BHIP_TRY(hipMemset(d_in, 0, sizeof(float) * (B * H * B_IN_HOP + 1)));
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_in), sizeof(float) * (B * H * B_IN_HOP + kMailboxWords)));
+    BHIP_TRY(hipMemset(d_in, 0, sizeof(float) * (B * H * B_IN_HOP + kMailboxWords)));
     owns_in = true;
     hop_mailbox = reinterpret_cast<int*>(d_in + (size_t)B * H * B_IN_HOP);  // see PhoneState::create
   }

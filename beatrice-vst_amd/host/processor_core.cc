@@ -235,6 +235,9 @@ bool ProcessorCore2::InstallNextKeyValueBlock() {  // reference processor_core_2
 ErrorCode ProcessorCore2::LoadModel(const std::filesystem::path& model_file) {
   model_file_.clear();
   ready_to_set_speaker_ = false;
+  // The reference builds a NEW core for every load (processor_proxy.h:55-70), so a loaded model always starts on
+  // fresh contexts: no audio history of the previous model, no device copy of its codebooks.
+  RecreateContexts();
   const auto dir = model_file.parent_path();
   auto path = [&](const char* name) { return (dir / name).u8string(); };
 #define BEATRICE_TRY_READ(call) \
@@ -280,7 +283,7 @@ ErrorCode ProcessorCore2::LoadModel(const std::filesystem::path& model_file) {
 }
 
 // reference processor_core_2.cc:258-291
-ErrorCode ProcessorCore2::ResetContext() {
+void ProcessorCore2::RecreateContexts() {
   Beatrice20rc0_DestroyPhoneContext1(phone_context_);
   Beatrice20rc0_DestroyPitchContext1(pitch_context_);
   Beatrice20rc0_DestroyWaveformContext1(waveform_context_);
@@ -289,6 +292,10 @@ ErrorCode ProcessorCore2::ResetContext() {
   pitch_context_ = Beatrice20rc0_CreatePitchContext1();
   waveform_context_ = Beatrice20rc0_CreateWaveformContext1();
   embedding_context_ = Beatrice20rc0_CreateEmbeddingContext();
+}
+
+ErrorCode ProcessorCore2::ResetContext() {
+  RecreateContexts();
   ErrorCode error = SetTargetSpeaker(target_speaker_);
   while (InstallNextKeyValueBlock()) {}
   for (const ErrorCode e : {SetFormantShift(formant_shift_), SetMinSourcePitch(min_source_pitch_),

@@ -123,6 +123,7 @@ class ProcessorCore2 {
   void Block480(const float* in480, float* out480);
   void Reblock(const float* in, float* out, int n);
   bool InstallNextKeyValueBlock();
+  void RecreateContexts();
   int TransformPitch(int q) const;
   ErrorCode ApplySpeakerMorphingWeights();
   void MorphStep();

@@ -37,6 +37,91 @@ def broadcast_model(model_dir, rank, world, dist, torch, device):
     return blobs
 
 
+class _DeviceView:
+    """Foreign device memory (a pointer handed out by the C-ABI) as something torch can alias without copying."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
+                                         "strides": None, "version": 2}
+
+
+def device_bytes(torch, ptr, nbytes, device="cuda"):
+    """uint8 tensor ALIASING [ptr, ptr + nbytes) of device memory owned by the library."""
+    return torch.as_tensor(_DeviceView(ptr, nbytes), device=device)
+
+
+def broadcast_inplace(buf, world, dist, src=0):
+    """One broadcast of `buf` (a tensor every rank holds with the same size): rank `src`'s contents land in the
+    other ranks' `buf`, device to device when the tensors are device memory (RCCL over xGMI)."""
+    if world > 1:
+        dist.broadcast(buf, src)
+    return buf
+
+
+KINDS = (("phone", 1, "ReadPhoneExtractorParameters", "phone_extractor.bin"),
+         ("pitch", 2, "ReadPitchEstimatorParameters", "pitch_estimator.bin"),
+         ("wave", 3, "ReadWaveformGeneratorParameters", "waveform_generator.bin"),
+         ("embed", 4, "ReadEmbeddingSetterParameters", "embedding_setter.bin"))
+
+
+def load_models_from_rank0(product, objs, model_dir, rank, world, dist, torch, device="cuda"):
+    """The four model objects of this rank (objs: name -> handle, freshly created).  Rank 0 reads and packs the files
+    (Read*Parameters); every other rank gets an empty device blob of the same size (BeatriceHip_ModelBlob) that
+    receives rank 0's PACKED blob by one broadcast each, device to device -- no file, no host copy, no repacking --
+    and is then marked ready.  Returns the bytes broadcast."""
+    import ctypes as C
+    moved = 0
+    for name, kind, reader, fname in KINDS:
+        if rank == 0:
+            err = getattr(product, reader)(objs[name], os.path.join(model_dir, fname).encode())
+            if err:
+                raise RuntimeError("%s: Beatrice_ErrorCode %d" % (fname, err))
+        if world == 1:
+            continue
+        ptr, nbytes = C.c_void_p(), C.c_size_t()
+        rc = product.BeatriceHip_ModelBlob(kind, objs[name], 0 if rank == 0 else 1, C.byref(ptr), C.byref(nbytes))
+        if rc:
+            raise RuntimeError("BeatriceHip_ModelBlob(%s): %d" % (name, rc))
+        broadcast_inplace(device_bytes(torch, ptr.value, nbytes.value, device), world, dist)
+        moved += nbytes.value
+        if rank != 0:
+            torch.cuda.synchronize()
+            rc = product.BeatriceHip_ModelBlobReady(kind, objs[name])
+            if rc:
+                raise RuntimeError("BeatriceHip_ModelBlobReady(%s): %d" % (name, rc))
+    return moved
+
+
+def share_speaker_tables(product, batch_handle, n_speakers, rank, world, dist, torch, device="cuda"):
+    """Rank 0 has uploaded its tables (BeatriceBatch_SetSpeakerTables); the raw device tables go to the other ranks
+    by four broadcasts and are projected there (BeatriceBatch_ProjectSpeakerTables)."""
+    import ctypes as C
+    if world == 1:
+        return 0
+    ptrs, sizes = (C.c_void_p * 4)(), (C.c_size_t * 4)()
+    rc = product.BeatriceBatch_SpeakerTablesDevice(batch_handle, ptrs, sizes)
+    if rc:
+        raise RuntimeError("BeatriceBatch_SpeakerTablesDevice: %d" % rc)
+    for i in range(4):
+        broadcast_inplace(device_bytes(torch, ptrs[i], sizes[i], device), world, dist)
+    if rank != 0:
+        torch.cuda.synchronize()
+        rc = product.BeatriceBatch_ProjectSpeakerTables(batch_handle, n_speakers)
+        if rc:
+            raise RuntimeError("BeatriceBatch_ProjectSpeakerTables: %d" % rc)
+    return int(sum(sizes))
+
+
+def affine_speaker(rank, world, local_stream, n_speakers):
+    """Speaker-affine placement: rank r starts its streams on the speakers congruent to r
+    modulo the world size, so a GPU keeps 1/world of the codebooks and K/V tables hot.  With fewer speakers than
+    ranks every rank cycles through all of them."""
+    if n_speakers < world:
+        return local_stream % n_speakers
+    per = n_speakers // world
+    return (rank + world * (local_stream % per)) % n_speakers
+
+
 def max_over_ranks(value, world, dist, torch, device):
     if world == 1:
         return value

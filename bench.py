@@ -300,18 +300,46 @@ def main():
                     help="device-to-device copy of each hop into / out of the library's own buffers instead of "
                          "binding the resident audio buffers (BeatriceBatch_BindResidentIO)")
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / B=1 latency / kernel profile")
+    ap.add_argument("--total-streams", type=int, default=None,
+                    help="strong scaling: this many streams in total, split evenly over the GPUs (default: --streams per GPU, weak scaling)")
+    ap.add_argument("--placement", choices=("round-robin", "speaker-affine"), default="round-robin",
+                    help="configs[3]: which speakers a rank's streams start on (speaker-affine: speaker mod world == rank)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, run one all-reduce over gloo and exit (CPU check that --gpus N launches N ranks)")
     a = ap.parse_args()
 
+    # --gpus N without a launcher: start N ranks of this script under torch.distributed.run (one process per GPU)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import subprocess
+        port = os.environ.get("MASTER_PORT") or str(29400 + os.getpid() % 2000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node equal to --gpus, or without a launcher)"
+                         % (a.gpus, world))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
     import torch
     import torch.distributed as dist
+    if a.rendezvous_only:
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.ones(1)
+        if world > 1:
+            dist.all_reduce(t)
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"rendezvous": "gloo", "n_gpus": a.gpus, "ranks_seen": int(t.item())}))
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     bv = load_pkg()
@@ -323,43 +351,46 @@ def main():
         a.streams = 64   # batch 512 over 8 GPUs
     if a.speakers is None:
         a.speakers = 64 if a.config == 3 else 1
+    scaling = "weak"
+    if a.total_streams:
+        if a.total_streams % world:
+            raise SystemExit("--total-streams must be a multiple of --gpus")
+        a.streams = a.total_streams // world
+        scaling = "strong"
     B = a.streams
     tmp = tempfile.TemporaryDirectory()
     model_dir = tmp.name
-    files = ["phone_extractor.bin", "pitch_estimator.bin", "waveform_generator.bin", "embedding_setter.bin",
-             "speaker_embeddings.bin"]
     if rank == 0:
         make_model.make_model(model_dir, n_speakers=a.speakers)
     shard = load_shard()
-    blobs = shard.broadcast_model(model_dir, rank, world, dist, torch, "cuda")  # RCCL broadcast of the weights
-    if rank != 0:  # the speaker file is parsed by the file reader of the C-ABI
-        with open(os.path.join(model_dir, "speaker_embeddings.bin"), "wb") as fh:
-            fh.write(blobs["speaker_embeddings.bin"])
 
-    class MemModels:  # model objects loaded from the broadcast bytes
+    # One file read, on rank 0; the packed parameter blobs and the raw speaker tables reach the other GPUs device to
+    # device (RCCL broadcast over xGMI), straight into the memory the kernels read.
+    class Loaded:
         pass
-    m = MemModels()
+    m = Loaded()
     m.abi = product
     m.phone, m.pitch = product.CreatePhoneExtractor(), product.CreatePitchEstimator()
     m.wave, m.embed = product.CreateWaveformGenerator(), product.CreateEmbeddingSetter()
-    for obj, fn, f in ((m.phone, product.BeatriceHip_LoadPhoneExtractorFromMemory, files[0]),
-                       (m.pitch, product.BeatriceHip_LoadPitchEstimatorFromMemory, files[1]),
-                       (m.wave, product.BeatriceHip_LoadWaveformGeneratorFromMemory, files[2]),
-                       (m.embed, product.BeatriceHip_LoadEmbeddingSetterFromMemory, files[3])):
-        err = fn(obj, blobs[f], len(blobs[f]))
-        if err:
-            raise SystemExit("load %s: Beatrice_ErrorCode %d" % (f, err))
-    m.tables = bv.SpeakerTables(product, model_dir)
-
-    batch = bv.Batch(m, B)
+    bcast_bytes = shard.load_models_from_rank0(product, {"phone": m.phone, "pitch": m.pitch, "wave": m.wave, "embed": m.embed},
+                                                model_dir, rank, world, dist, torch)
+    if rank == 0:
+        m.tables = bv.SpeakerTables(product, model_dir)
+    batch = bv.Batch(m, B, max_speakers=a.speakers + 1, upload_tables=(rank == 0))
+    bcast_bytes += shard.share_speaker_tables(product, batch.h, a.speakers + 1, rank, world, dist, torch)
+    if rank != 0:
+        batch.apply_defaults()
     if a.no_graph:
         product.BeatriceBatch_EnableGraph(batch.h, 0)
-    for s in range(B):  # streams spread over the speakers of the table
-        product.BeatriceBatch_SetTargetSpeaker(batch.h, s, s % a.speakers)
+    if a.placement == "speaker-affine":
+        current_speaker = [shard.affine_speaker(rank, world, s, a.speakers) for s in range(B)]
+    else:  # global stream index modulo the table size
+        current_speaker = [(rank * B + s) % a.speakers for s in range(B)]
+    for s in range(B):
+        product.BeatriceBatch_SetTargetSpeaker(batch.h, s, current_speaker[s])
     product.BeatriceBatch_FlushSpeaker(batch.h, -1)
     if a.config == 3:
         product.BeatriceBatch_SetVQNumNeighbors(batch.h, -1, 4)
-    current_speaker = [s % a.speakers for s in range(B)]
 
     # synthetic audio, resident on the device: 64 hops x B streams, cycled
     n_cycle = 64
@@ -430,7 +461,7 @@ def main():
         res = {
             "metric": "audio frames/sec (24 kHz out, 10 ms hop)", "value": round(frames / elapsed, 1), "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": {2: "BASELINE.json configs[2]: %d concurrent streams per GPU, %d speaker(s), 10 ms hop "
                                        "(160 in @16 kHz -> 240 out @24 kHz), synthetic weights of MODEL_SPEC v1" % (B, a.speakers),
                                     3: "BASELINE.json configs[3] per-GPU share: %d streams, %d speakers, every stream switches "
@@ -443,7 +474,9 @@ def main():
                                      else "off: one stream, in order",
                        "io": "resident device buffers, 64 hops per stream cycled, bound as I/O slots (no per-step copy)" if resident
                              else "resident device buffers, one device-to-device copy in and out per step",
-                       "parallelism": "streams sharded over %d GPU(s), no per-hop collective" % world},
+                       "parallelism": "streams sharded over %d GPU(s), no per-hop collective; load: one file read on rank 0, "
+                                      "%d bytes of packed parameters and speaker tables broadcast device to device" % (world, bcast_bytes),
+                       "placement": a.placement if a.config == 3 else "n/a"},
             "x_realtime_per_stream": round(a.steps / elapsed / 100.0, 2), "output_rms": round(out_rms, 4),
             "host_enqueue_ms_per_step": round(1e3 * enqueue_s / a.steps, 4),
         }

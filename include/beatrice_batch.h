@@ -42,6 +42,15 @@ Beatrice_ErrorCode BeatriceHip_LoadPitchEstimatorFromMemory(Beatrice20rc0_PitchE
 Beatrice_ErrorCode BeatriceHip_LoadWaveformGeneratorFromMemory(Beatrice20rc0_WaveformGenerator* m, const void* bytes, size_t size);
 Beatrice_ErrorCode BeatriceHip_LoadEmbeddingSetterFromMemory(Beatrice20rc0_EmbeddingSetter* m, const void* bytes, size_t size);
 
+/* Device-resident parameter blobs, for loading a model on several GPUs from ONE file read.
+ * kind: 1 phone extractor, 2 pitch estimator, 3 waveform generator, 4 embedding setter; `model` the matching object.
+ * BeatriceHip_ModelBlob returns the object's parameter blob as it sits on the device (already in the kernels' packed
+ * layout); with allocate != 0 an object that has not been loaded gets an empty blob of the right size.  The caller
+ * moves bytes device to device (e.g. a RCCL broadcast from the rank that called Read*Parameters) and then calls
+ * BeatriceHip_ModelBlobReady on the receiving objects.  0 on success, -1 bad argument / nothing to share, -2 HIP failure. */
+int BeatriceHip_ModelBlob(int kind, void* model, int allocate, void** d_ptr, size_t* n_bytes);
+int BeatriceHip_ModelBlobReady(int kind, void* model);
+
 /* n_streams concurrent streams; speaker tables may hold up to max_speakers entries
  * (n_speakers + 1 when the caller keeps the reference's extra "morph" slot). */
 BeatriceBatch* BeatriceBatch_Create(const Beatrice20rc0_PhoneExtractor* phone, const Beatrice20rc0_PitchEstimator* pitch,
@@ -67,6 +76,11 @@ size_t BeatriceBatch_StateBytes(const BeatriceBatch* b);
  * K/V of every (speaker, block) once, so that later speaker switches are index changes. */
 int BeatriceBatch_SetSpeakerTables(BeatriceBatch* b, int n_speakers, const float* codebooks, const float* additive,
                                    const float* formant, const float* key_value);
+/* The same tables filled device to device: d_ptrs[4] / n_bytes[4] receive the raw device tables (codebooks, additive,
+ * formant, key_value; sized for max_speakers entries); after writing n entries into them (e.g. by a broadcast),
+ * BeatriceBatch_ProjectSpeakerTables(b, n) runs the projections that BeatriceBatch_SetSpeakerTables runs after its upload. */
+int BeatriceBatch_SpeakerTablesDevice(BeatriceBatch* b, void** d_ptrs, size_t* n_bytes);
+int BeatriceBatch_ProjectSpeakerTables(BeatriceBatch* b, int n_speakers);
 /* Replace one table entry (e.g. the morph slot after a spherical average on the host). */
 int BeatriceBatch_UpdateSpeaker(BeatriceBatch* b, int speaker, const float* codebook, const float* additive,
                                 const float* key_value);
@@ -82,6 +96,14 @@ int BeatriceBatch_UpdateSpeaker(BeatriceBatch* b, int speaker, const float* code
  * host, which spreads the means over five hops to bound its CPU time, the new embeddings are complete
  * when the call returns.  Agreement with the host computation: float rounding (<= 1e-5), not bit-exact. */
 int BeatriceBatch_MorphSpeaker(BeatriceBatch* b, int slot, const float* weights, int n_weights, unsigned seed);
+/* The lottery engine is per stream, as the reference's is per plugin instance (processor_core_2.h:48,145):
+ * BeatriceBatch_MorphSpeaker(seed) seeds stream s with std::mt19937(seed + s); BeatriceBatch_SeedLottery re-seeds one
+ * stream (or all, -1) with std::mt19937(seed) -- e.g. from the stream's global identity when streams are sharded
+ * over batches or GPUs, so that a stream's draws do not depend on where it runs.  One draw per hop, also in block mode.
+ * The entry's key/value projections are replaced in place by BeatriceBatch_MorphSpeaker: streams already on the entry
+ * see all four blocks change at that step (the reference, which computes the means over four hops on the audio
+ * thread, installs them one block per hop). */
+int BeatriceBatch_SeedLottery(BeatriceBatch* b, int stream, unsigned seed);
 /* Raw embeddings of a table entry as currently held on the device: additive [256], key_value [384][128]. */
 int BeatriceBatch_GetSpeakerEmbeddings(BeatriceBatch* b, int speaker, float* additive, float* key_value);
 
@@ -160,8 +182,8 @@ int BeatriceBatch_TimeSteps(BeatriceBatch* b, int steps, float* ms);
 
 /* Per-kernel measurement hook: runs ONE hop eagerly (no graph) with every launch of the chain
  * bracketed by HIP events on the batch's stream; each launch is issued `repeats` times back to back
- * inside its bracket (all kernels of the chain are idempotent within a hop) and the bracket time is
- * divided by `repeats`.  Launches with the same name are accumulated.  Fills up to max_entries rows:
+ * inside its bracket and the bracket time is divided by `repeats` (launches that update state in place -- the GRUs,
+ * the pitch head, the upsampler tail -- are issued once, so the profiled hop is an ordinary hop of the stream).  Launches with the same name are accumulated.  Fills up to max_entries rows:
  * names (64 bytes each, NUL terminated), launches per hop, mean microseconds per launch, and the
  * algorithmic FLOPs and bytes of one launch.  Returns the number of rows. */
 int BeatriceBatch_ProfileKernels(BeatriceBatch* b, int repeats, int max_entries, char* names, int* launches,

@@ -225,3 +225,37 @@ def test_model_toml_has_the_schema_the_reference_reader_asks_for(model_dir):
         assert isinstance(v["name"], str) and v["name"] and isinstance(v["description"], str)
         assert 0.0 <= float(v["average_pitch"]) <= 128.0
         assert isinstance(v["portrait"]["path"], str) and isinstance(v["portrait"]["description"], str)
+
+
+@pytest.mark.parametrize("compiler,std", [("gcc", "-std=c11"), ("g++", "-std=c++20")])
+def test_prototypes_agree_with_reference_header(tmp_path, compiler, std):
+    """Types, not just names: the reference header and ours in ONE translation unit.  A C compiler rejects two
+    declarations of a function whose return or argument types differ ("conflicting types"), so a clean compile proves
+    all 77 prototypes and the constants agree.  Our copy goes in with its enum definition removed (the reference's is
+    in scope; its enumerator values are checked by static assertions).  Runs where the reference is mounted."""
+    ref = "/root/reference/lib/beatricelib/beatrice.h"
+    if not os.path.exists(ref):
+        pytest.skip("reference not mounted")
+    import subprocess
+    ours = open(os.path.join(REPO, "include", "beatrice_abi.h")).read()
+    stripped, n = re.subn(r"typedef enum Beatrice_ErrorCode \{.*?\} Beatrice_ErrorCode;", "", ours, flags=re.S)
+    assert n == 1
+    values = dict(re.findall(r"(Beatrice_k[A-Za-z]+) = (\d+)", ours))
+    assert len(values) == 5
+    (tmp_path / "ours_no_enum.h").write_text(stripped)
+    sa = "_Static_assert" if compiler == "gcc" else "static_assert"
+    tu = '#include "%s"\n#include "ours_no_enum.h"\n' % ref
+    tu += "".join('%s(%s == %s, "%s");\n' % (sa, k, v, k) for k, v in values.items())
+    tu += "int main(void) { return 0; }\n"
+    src = tmp_path / ("tu.c" if compiler == "gcc" else "tu.cc")
+    src.write_text(tu)
+    out = subprocess.run([compiler, std, "-fsyntax-only", "-Wall", "-Werror", "-I" + str(tmp_path), str(src)],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    # and the check has teeth: one changed argument type must be caught
+    broken = stripped.replace("void G##_SetMinQuantizedPitch(G##_PitchContext1* ctx, int min_quantized_pitch);",
+                              "void G##_SetMinQuantizedPitch(G##_PitchContext1* ctx, long min_quantized_pitch);")
+    assert broken != stripped
+    (tmp_path / "ours_no_enum.h").write_text(broken)
+    out = subprocess.run([compiler, std, "-fsyntax-only", "-I" + str(tmp_path), str(src)], capture_output=True, text=True)
+    assert out.returncode != 0

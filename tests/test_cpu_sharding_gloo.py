@@ -51,6 +51,10 @@ def _worker(rank, world, port, src_dir, tmp_root, q):
             fh.write(data)
     lo, hi = shard.stream_range(rank, world, TOTAL_STREAMS)
     outs = _run_streams(bv, my_dir, lo, hi)
+    # the in-place broadcast bench.py uses for the packed device blobs (here: host memory standing in for the blob)
+    blob = np.arange(4096, dtype=np.uint8) if rank == 0 else np.zeros(4096, np.uint8)
+    shard.broadcast_inplace(torch.from_numpy(blob), world, dist)
+    assert np.array_equal(blob, np.arange(4096, dtype=np.uint8)), "rank %d: in-place broadcast did not land" % rank
     slowest = shard.max_over_ranks(float(rank + 1), world, dist, torch, "cpu")
     digest = {f: hashlib.sha256(d).hexdigest() for f, d in blobs.items()}
     q.put((rank, lo, hi, {s: o.tobytes() for s, o in outs.items()}, digest, slowest))
@@ -93,3 +97,34 @@ def test_stream_range_partitions():
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself (checked over gloo: no GPU here);
+    a launcher whose world size disagrees with --gpus is refused."""
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_PORT=str(29300 + os.getpid() % 1000))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--rendezvous-only"],
+                         capture_output=True, text=True, timeout=600, cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2
+    bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--rendezvous-only"],
+                         capture_output=True, text=True, timeout=600, cwd=REPO, env=dict(env, WORLD_SIZE="1", RANK="0"))
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
+
+
+def test_speaker_affine_placement():
+    shard = _load("beatrice_shard", os.path.join(REPO, "beatrice-vst_amd", "shard.py"))
+    for world in (1, 2, 4, 8):
+        seen = set()
+        for rank in range(world):
+            mine = {shard.affine_speaker(rank, world, s, 64) for s in range(256)}
+            assert all(spk % world == rank for spk in mine)     # SURVEY.md 8e: gpu = speaker mod world
+            assert len(mine) == 64 // world
+            seen |= mine
+        assert seen == set(range(64))
+    assert {shard.affine_speaker(3, 8, s, 2) for s in range(16)} == {0, 1}   # fewer speakers than ranks

@@ -116,7 +116,7 @@ def test_morph_end_to_end(bv, oracle, product, host_lib, model_dir8, vq_k):
     total = np.float32(0)
     for v in odds:
         total = np.float32(total + v)
-    draws = _mt_draws(seed)
+    draws = {s: _mt_draws(seed + s) for s in range(B)}   # every stream owns its engine: std::mt19937(seed + stream)
     streams = [bv.Stream1(mo, speaker=s, vq_k=vq_k) for s in range(B)]
     ref = np.zeros((hops, B, bv.OUT_HOP), np.float32)
     picks = []
@@ -124,8 +124,8 @@ def test_morph_end_to_end(bv, oracle, product, host_lib, model_dir8, vq_k):
         for s in range(B):
             if switch_hop.get(s) == h:
                 streams[s].set_target_speaker(n)
-            if s in switch_hop and h >= switch_hop[s]:   # one draw per morphing stream and hop, stream order
-                r = np.float32(next(draws) * total)
+            if s in switch_hop and h >= switch_hop[s]:   # one draw per morphing stream and hop
+                r = np.float32(next(draws[s]) * total)
                 idx = int(order[0])
                 for i in range(8):
                     r = np.float32(r - odds[i])

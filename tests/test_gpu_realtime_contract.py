@@ -1,0 +1,78 @@
+"""Real-time contract of the 1-stream ABI: the per-hop calls and the setters the reference
+host issues on its audio thread (morph mode calls SetCodebook every hop, processor_core_2.cc:118-121) must not
+allocate device memory, and a codebook table rewritten in place must not be served from a stale device copy."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def model_dir8(tmp_path_factory):
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import make_model
+    d = str(tmp_path_factory.mktemp("model8rt"))
+    make_model.make_model(d, n_speakers=8)
+    return d
+
+
+def _free_bytes():
+    import torch
+    return torch.cuda.mem_get_info()[0]
+
+
+def test_setcodebook_per_hop_no_allocation_and_lru(bv, oracle, product, model_dir8):
+    """14 distinct codebook pointers cycled hop by hop (more than the context's pool of 12, so slots are recycled):
+    free device memory stays on a plateau once the contexts exist, and PCM equals the oracle's."""
+    hops = 40
+    x = bv.synth_audio(160 * hops, seed=31)
+    outs, free_trace = {}, []
+    for name, abi in (("oracle", oracle), ("hip", product)):
+        m = bv.Models(abi, model_dir8)
+        t = m.tables
+        books = [t.codebooks[i] for i in range(9)] + [np.ascontiguousarray(t.codebooks[i % 8][::-1].copy()) for i in range(5)]
+        st = bv.Stream1(m, speaker=1, vq_k=3)
+        out = np.zeros((hops, bv.OUT_HOP), np.float32)
+        for h in range(hops):
+            st.a.SetCodebook(st.pc, bv.fptr(books[(h * 5) % len(books)]))
+            if h % 9 == 4:   # the other audio-thread setters of morph mode
+                st.a.SetAdditiveSpeakerEmbedding(m.embed, bv.fptr(t.additive[h % 8]), st.ec, st.wc)
+                st.a.RegisterKeyValueSpeakerEmbedding(m.embed, bv.fptr(t.kv[h % 8]), st.ec)
+                st.kv_count = 0
+            out[h] = st.hop(x[h * 160:(h + 1) * 160])
+            if name == "hip":
+                free_trace.append(_free_bytes())
+        st.close()
+        m.close()
+        outs[name] = out
+    assert np.abs(outs["hip"]).max() > 0.01
+    assert np.array_equal(outs["oracle"], outs["hip"]), "max-abs %g" % np.abs(outs["oracle"] - outs["hip"]).max()
+    assert len(set(free_trace)) == 1, "free device memory moved during hops: %s" % sorted(set(free_trace))
+
+
+def test_codebook_rewritten_in_place_is_reuploaded(bv, oracle, product, model_dir8):
+    """Same host pointer, new contents (a host that reloads a model into the same storage): the next SetCodebook must
+    pick the new table up."""
+    hops = 12
+    x = bv.synth_audio(160 * hops, seed=32)
+    outs = {}
+    for name, abi in (("oracle", oracle), ("hip", product)):
+        m = bv.Models(abi, model_dir8)
+        t = m.tables
+        table = np.ascontiguousarray(t.codebooks[2].copy())
+        st = bv.Stream1(m, speaker=0, vq_k=2)
+        out = np.zeros((hops, bv.OUT_HOP), np.float32)
+        for h in range(hops):
+            if h == 6:
+                table[:] = t.codebooks[5]
+            st.a.SetCodebook(st.pc, bv.fptr(table))
+            out[h] = st.hop(x[h * 160:(h + 1) * 160])
+        st.close()
+        m.close()
+        outs[name] = out
+    assert np.array_equal(outs["oracle"], outs["hip"])
+    assert not np.array_equal(outs["hip"][5], outs["hip"][7])
