@@ -57,4 +57,13 @@ def oracle(bv, built):
 
 @pytest.fixture(scope="session")
 def product(bv, built):
+    # torch ships its own copy of the HIP runtime.  A process that uses both torch's GPU side and the product must let
+    # torch bring its runtime up FIRST (as bench.py does): the product's libamdhip64 dependency then resolves to the
+    # copy already loaded, and both see the GPU.  The other order leaves torch without a device.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     return bv.load_product()
