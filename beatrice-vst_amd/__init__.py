@@ -292,6 +292,8 @@ _BATCH = {
     "BeatriceBatch_EnableGraph": (C.c_int, [_vp, C.c_int]),
     "BeatriceBatch_EnablePipelining": (C.c_int, [_vp, C.c_int]),
     "BeatriceBatch_GetWaveStream": (_vp, [_vp]),
+    "BeatriceBatch_EnableTickPipeline": (C.c_int, [_vp, C.c_int]),
+    "BeatriceBatch_TickStages": (C.c_int, [_vp]),
     "BeatriceBatch_Prepare": (C.c_int, [_vp]),
     "BeatriceBatch_DeviceInput": (_vp, [_vp]),
     "BeatriceBatch_DeviceOutput": (_vp, [_vp]),

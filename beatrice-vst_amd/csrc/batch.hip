@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <numeric>
 #include <random>
 #include <string>
@@ -20,6 +21,7 @@
 
 #include "abi_objects.h"
 #include "beatrice_batch.h"
+#include "tick.hip.h"
 
 using namespace bhip;
 
@@ -173,6 +175,9 @@ struct BeatriceBatch {
   int* d_hop_next = nullptr;  // {step counter, resident-I/O slot}, double-buffered: first kernels read it, the last one writes it
   float* own_d_out = nullptr; // the waveform module's output buffer while a resident output buffer is bound
   int io_slots = 0;           // > 0: resident I/O bound (BeatriceBatch_BindResidentIO)
+  int io_host = 0;            // mirror of the device's resident-I/O slot counter
+  int last_hop = 0;           // step counter of the last enqueued step (selects the slot of the pitch head's outputs)
+  tick::State tk;             // tick pipelining (tick.hip.h)
   // 48 kHz device wrapper (configs[4])
   Wrap48State* d_w48 = nullptr;
   float *d_coef_down = nullptr, *d_coef_up = nullptr, *d_io48 = nullptr, *h_io48 = nullptr;  // io: in [B][2][480] | out [B][2][480]
@@ -184,8 +189,10 @@ namespace {
 // the pinned setting mirrors are double-buffered and do not need it).
 hipStream_t stage_stream(const BeatriceBatch* b, int s) { return b->pipelined && s > 0 ? b->stage_stream_own[s] : b->stream; }
 hipStream_t wave_stream(const BeatriceBatch* b) { return stage_stream(b, b->n_stages - 1); }  // where a step's output appears
+bool tick_drain(BeatriceBatch* b);
 bool sync_all(BeatriceBatch* b) {
-  bool ok = hip_ok(hipStreamSynchronize(b->stream), "sync");
+  bool ok = !b->tk.on || tick_drain(b);  // steps still inside the tick pipeline come out first
+  ok = hip_ok(hipStreamSynchronize(b->stream), "sync") && ok;
   for (int s = 1; s < BeatriceBatch::kMaxStages; ++s)
     if (b->stage_stream_own[s]) ok = hip_ok(hipStreamSynchronize(b->stage_stream_own[s]), "sync stage") && ok;
   b->inflight = false;
@@ -374,7 +381,7 @@ bool run_stage(BeatriceBatch* b, int stage, int slot) {
 void update_vq_mode(BeatriceBatch* b) {
   bool none = true;
   for (const StreamCfg& c : b->cfg) none = none && c.vq_k == 0;
-  if (none != b->phone.skip_vq) { settle(b); b->phone.skip_vq = none; drop_graph(b); }
+  if (none != b->phone.skip_vq) { settle(b); b->phone.skip_vq = none; drop_graph(b); b->tk.table_dirty = true; }
 }
 
 // streams whose target is a morphed entry draw the codebook of ONE real speaker per hop, with the
@@ -407,8 +414,10 @@ void draw_codebooks(BeatriceBatch* b) {
   }
 }
 
+bool tick_run(BeatriceBatch* b, bool feeding);
 bool step_device(BeatriceBatch* b, const float* d_in, float* d_out) {
   if (b->io_slots > 0 && (d_in || d_out)) return false;  // resident I/O is bound: the step reads and writes its slots
+  if (b->tk.on) return tick_run(b, true);
   advance_kv(b);
   draw_codebooks(b);
   if (b->vq_dirty) { update_vq_mode(b); b->vq_dirty = false; }
@@ -423,7 +432,9 @@ bool step_device(BeatriceBatch* b, const float* d_in, float* d_out) {
     if (d_out && d_out != b->wave.d_out)
       BHIP_TRY(hipMemcpyAsync(d_out, b->wave.d_out, sizeof(float) * b->B * b->H * B_OUT_HOP, hipMemcpyDeviceToDevice, fs));
     b->last_parity = b->hop_host % 3;
+    b->last_hop = b->hop_host;
     b->hop_host = hop_next(b->hop_host);
+    if (b->io_slots > 0) b->io_host = (b->io_host + 1) % b->io_slots;
     b->steps_enqueued = t + 1;
     b->inflight = true;
     return true;
@@ -446,10 +457,205 @@ bool step_device(BeatriceBatch* b, const float* d_in, float* d_out) {
     BHIP_TRY(hipEventRecord(b->ev_done[s][slot], st));
   }
   b->last_parity = b->hop_host % 3;
+  b->last_hop = b->hop_host;
   b->hop_host = hop_next(b->hop_host);
+  if (b->io_slots > 0) b->io_host = (b->io_host + 1) % b->io_slots;
   b->steps_enqueued = t + 1;
   b->inflight = true;
   return true;
+}
+
+// ---- tick pipelining (tick.hip.h) ---------------------------------------------------------------------------------
+bool tick_build_table(BeatriceBatch* b) {
+  using namespace tick;
+  State& k = b->tk;
+  auto tb = std::make_unique<Builder>();
+  const PhoneWeights& pw = b->phone_m->w;
+  const PitchWeights& qw = b->pitch_m->w;
+  const WaveWeights& ww = b->wave_m->w;
+  const PhoneState& ps = b->phone;
+  const PitchState& qs = b->pitch;
+  const WaveState& ws = b->wave;
+  const int B = b->B;
+  auto hp = [&](int stage) { return k.d_hops + 2 * stage; };
+  auto conv = [&](const Ring& in, const Ring& out, const float* w, const float* bias, int stage) { return conv_args(in, out, w, bias, hp(stage), B); };
+  // content encoder (the layers with the longest reductions first: they are the longest-running workgroups)
+  for (int i = 0; i < 4; ++i) {
+    const ConvArgs a = conv(i == 0 ? ps.f[4] : ps.rb[i - 1], ps.rb[i], pw.rb_w[i], pw.rb_b[i], S_RB0 + i);
+    tb->add<T_RB>(CT<PL::RBL>::info("phone.rb", a), a, CT<PL::RBL>::grid(a));
+  }
+  { const ConvArgs a = conv(qs.spec, qs.p[0], qw.p_w[0], qw.p_b[0], S_P1); tb->add<T_P1>(CT<QL1::P1>::info("pitch.p1", a), a, CT<QL1::P1>::grid(a)); }
+  { const ConvArgs a = conv(ps.f[2], ps.f[3], pw.f_w[2], pw.f_b[2], S_F4); tb->add<T_F4>(CT<PL::F4>::info("phone.f4", a), a, CT<PL::F4>::grid(a)); }
+  { const ConvArgs a = conv(ps.f[3], ps.f[4], pw.f_w[3], pw.f_b[3], S_F5); tb->add<T_F5>(CT<PL::F5>::info("phone.f5", a), a, CT<PL::F5>::grid(a)); }
+  { const ConvArgs a = conv(ps.f[0], ps.f[1], pw.f_w[0], pw.f_b[0], S_F2); tb->add<T_F2>(CT<PL::F2>::info("phone.f2", a), a, CT<PL::F2>::grid(a)); }
+  { const ConvArgs a = conv(ps.f[1], ps.f[2], pw.f_w[1], pw.f_b[1], S_F3); tb->add<T_F3>(CT<PL::F3>::info("phone.f3", a), a, CT<PL::F3>::grid(a)); }
+  { F1Args a = f1_args(pw, ps); a.hop = hp(S_F1); a.hop_publish = nullptr; a.hop_publish_wave = nullptr; tb->add<T_F1>(f1_info(ps), a, dim3(B, 1)); }
+  { FftArgs a = fft_args(qw, qs); a.hop = hp(S_FFT); tb->add<T_FFT>(fft_info(qs), a, dim3(B, 1)); }
+  for (int i = 0; i < 2; ++i) {
+    const ConvArgs a = conv(qs.p[i], qs.p[i + 1], qw.p_w[i + 1], qw.p_b[i + 1], S_P2 + i);
+    tb->add<T_P23>(CT<QL1::P23>::info("pitch.p23", a), a, CT<QL1::P23>::grid(a));
+  }
+  { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(S_QGRU), B, 0}; tb->add<T_QGRU>(GruOp<128, 128>::info("pitch.gru", g), g, GruOp<128, 128>::grid(g)); }
+  { const ConvArgs a = conv(qs.h, qs.logits, qw.out_w, qw.out_b, S_POUT); tb->add<T_POUT>(CT<QL1::POUT>::info("pitch.out", a), a, CT<QL1::POUT>::grid(a)); }
+  { const GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(S_PGRU), B, 0}; tb->add<T_PGRU>(GruOp<256, 256>::info("phone.gru", g), g, GruOp<256, 256>::grid(g)); }
+  { PitchHeadArgs a = head_args(qw, qs); a.hop = hp(S_HEAD); tb->add<T_HEAD>(head_info(qs), a, dim3(B, 1)); }
+  { const ConvArgs a = conv(ps.h, phone_out_ring(ps), pw.out_w, pw.out_b, S_OUT); tb->add<T_OUT>(CT<PL::OUTL>::info("phone.out", a), a, CT<PL::OUTL>::grid(a)); }
+  { CondArgs a = cond_args(ww, ws); a.hop = hp(S_COND); a.hop_next_out = nullptr; tb->add<T_COND>(cond_info(ws), a, dim3(B, 1)); }
+  { const VqArgs a{1, ps.raw, phone_vector_ring(ps), hp(S_VQ), ps.d_cbT, ps.d_cnorm, ps.d_vqk}; tb->add<T_VQ>(LaunchInfo{"phone.vq", 0, 4.0 * B * 256}, a, dim3(B, 1), !ps.skip_vq); }
+  // waveform generator
+  { const Ring phone_in{ws.d_phone, B_PHONE_CH, 1, ws.front_slots}; ConvArgs a = conv(phone_in, ws.x[0], ww.inp_w, ww.inp_b, S_INP); a.res = ws.e; tb->add<T_INP>(CT<INP<1>>::info("wave.inp", a), a, CT<INP<1>>::grid(a)); }
+  for (int blk = 0; blk < B_NBLOCKS; ++blk) {
+    const WaveState::Scratch& sc = ws.scr[blk];  // one scratch set per block: all four blocks are in flight at once
+    const int s0 = S_BLK0 + 6 * blk;
+    { const ConvArgs a = conv(ws.x[blk], sc.h1, ww.c1_w[blk], ww.c1_b[blk], s0);
+      switch (blk) {
+        case 0: tb->add<T_C1D1>(CT<C1<1, 1>>::info("wave.blk.c1", a), a, CT<C1<1, 1>>::grid(a)); break;
+        case 1: tb->add<T_C1D2>(CT<C1<2, 1>>::info("wave.blk.c1", a), a, CT<C1<2, 1>>::grid(a)); break;
+        case 2: tb->add<T_C1D4>(CT<C1<4, 1>>::info("wave.blk.c1", a), a, CT<C1<4, 1>>::grid(a)); break;
+        default: tb->add<T_C1D8>(CT<C1<8, 1>>::info("wave.blk.c1", a), a, CT<C1<8, 1>>::grid(a)); break;
+      } }
+    { ConvArgs a = conv(sc.h1, sc.xa, ww.c2_w[blk], ww.c2_b[blk], s0 + 1); a.res = ws.x[blk]; tb->add<T_C2>(CT<C2<1>>::info("wave.blk.c2o", a), a, CT<C2<1>>::grid(a)); }
+    { const ConvArgs a = conv(sc.xa, sc.q, ww.q_w[blk], ww.q_b[blk], s0 + 2); tb->add<T_Q>(CT<QL<1>>::info("wave.blk.q", a), a, CT<QL<1>>::grid(a)); }
+    // the two attention kernels read the tile lists: private copies 0 (scores) and 1 (softmax . V) of the block's lists
+    int* perm[2]; int* slot[2];
+    for (int c = 0; c < 2; ++c) {
+      perm[c] = b->dev_view<int>(b->off.perm[blk] + (size_t)c * b->off.wave_bytes);
+      slot[c] = b->dev_view<int>(b->off.tile_slot[blk] + (size_t)c * b->off.wave_bytes);
+    }
+    { ConvArgs a = conv(sc.q, sc.sc, ws.d_kt[blk], nullptr, s0 + 3); a.scale = 0.0625f; a.perm = perm[0]; a.tile_slot = slot[0]; a.w_slot_stride = (size_t)B_HID * B_KV_LEN;
+      tb->add<T_SCORE>(ConvOp<SCORE<1>, TGQ>::info("wave.blk.attn_qk", a), a, ConvOp<SCORE<1>, TGQ>::grid(a, ws.n_tiles_max)); }
+    { const AttnPvArgs a{sc.sc, ws.d_v[blk], sc.o, perm[1], slot[1], hp(s0 + 4)};
+      tb->add<T_PV>(LaunchInfo{"wave.blk.attn_pv", 2.0 * B * 384 * 256 + 25.0 * B * 384, 4.0 * (384.0 * 256 + B * (384 + 256))}, a, dim3(ws.n_tiles_max, B_HID / 32)); }
+    { ConvArgs a = conv(sc.o, ws.x[blk + 1], ww.o_w[blk], ww.o_b[blk], s0 + 5); a.res = sc.xa; tb->add<T_C2>(CT<C2<1>>::info("wave.blk.c2o", a), a, CT<C2<1>>::grid(a)); }
+  }
+  { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], S_UP1); tb->add<T_UP1>(CT<UP<256, 128, 5, 1>>::info("wave.up1", a), a, CT<UP<256, 128, 5, 1>>::grid(a)); }
+  { const ConvArgs a = conv(ws.ya1, ws.yb1, ww.ra_w[0], ww.ra_b[0], S_RES1A); tb->add<T_RES1A>(CT<RES<128, 1, 5>>::info("wave.res1a", a), a, CT<RES<128, 1, 5>>::grid(a)); }
+  { const ConvArgs a = conv(ws.yb1, ws.yc1, ww.rb_w[0], ww.rb_b[0], S_RES1B); tb->add<T_RES1B>(CT<RES<128, 3, 5>>::info("wave.res1b", a), a, CT<RES<128, 3, 5>>::grid(a)); }
+  { const ConvArgs a = conv(ws.yc1, ws.ya2, ww.up_w[1], ww.up_b[1], S_UP2); tb->add<T_UP2>(CT<UP<128, 64, 4, 5>>::info("wave.up2", a), a, CT<UP<128, 64, 4, 5>>::grid(a)); }
+  if (!tb->ok) return false;
+  BHIP_TRY(hipMemcpy(k.d_table, &tb->t, sizeof(Tab), hipMemcpyHostToDevice));
+  k.table_total = tb->t.total;
+  k.tail = tail_args(ww, ws);
+  k.tail.hop = hp(S_TAIL);
+  // who reads which part of the settings block, and where its private copy lives
+  k.consumers.clear();
+  unsigned char* d = b->settings.d;
+  k.consumers.push_back(Consumer{S_VQ, b->off.cbT, b->off.min_q - b->off.cbT, d + b->off.cbT, -1});
+  k.consumers.push_back(Consumer{S_HEAD, b->off.min_q, b->off.add_idx - b->off.min_q, d + b->off.min_q, -1});
+  k.consumers.push_back(Consumer{S_COND, b->off.add_idx, b->off.front_bytes - b->off.add_idx, d + b->off.add_idx, -1});
+  for (int blk = 0; blk < B_NBLOCKS; ++blk) {
+    const size_t lo = b->off.perm[blk], hi = blk + 1 < B_NBLOCKS ? b->off.perm[blk + 1] : b->off.front_bytes + b->off.wave_bytes;
+    for (int c = 0; c < 2; ++c)
+      k.consumers.push_back(Consumer{S_BLK0 + 6 * blk + 3 + c, lo, hi - lo, d + lo + (size_t)c * b->off.wave_bytes, -1});
+  }
+  k.table_dirty = false;
+  return true;
+}
+
+// One tick: every stage advances by one step; `feeding` = a new step enters at stage 0.
+bool tick_run(BeatriceBatch* b, bool feeding) {
+  using namespace tick;
+  State& k = b->tk;
+  if (feeding) {
+    advance_kv(b);
+    draw_codebooks(b);
+    if (b->vq_dirty) { update_vq_mode(b); b->vq_dirty = false; }   // (drains the pipeline if the k-NN stage comes or goes)
+  }
+  if (k.table_dirty && !tick_build_table(b)) return false;
+  hipStream_t st = b->stream;
+  if (feeding) {
+    bool dirty = b->front_dirty || k.snap_cur < 0;
+    for (bool w : b->wave_dirty) dirty = dirty || w;
+    if (dirty) {  // a new version of the settings: one upload into the next slot of the snapshot ring
+      const int serial = k.snap_next++;
+      const size_t off = 0, len = k.snap_bytes;
+      unsigned char* dst = k.d_snap + (size_t)(serial % kRing) * k.snap_bytes;
+      if (!b->settings.push_parts(st, 1, &off, &len, &dst)) return false;
+      k.snap_cur = serial;
+      b->front_dirty = false;
+      for (bool& w : b->wave_dirty) w = false;
+    }
+    const long long u = k.n_fed;
+    k.fed_step[k.tick % kRing] = u;
+    k.snap_of_step[u % kRing] = k.snap_cur;
+    k.hop_of_step[u % kRing] = b->hop_host;
+    k.io_of_step[u % kRing] = b->io_host;
+  } else {
+    k.fed_step[k.tick % kRing] = -1;
+  }
+  Prolog p{};
+  p.n_stages = S_COUNT;
+  auto step_at = [&k](int stage) -> long long {
+    const long long t2 = k.tick - stage;
+    return t2 >= 0 ? k.fed_step[t2 % kRing] : -1;
+  };
+  for (int s = 0; s < S_COUNT; ++s) {
+    const long long u = step_at(s);
+    p.hop[s] = u < 0 ? -1 : k.hop_of_step[u % kRing];
+    p.io[s] = u < 0 ? 0 : k.io_of_step[u % kRing];
+  }
+  for (Consumer& c : k.consumers) {
+    const long long u = step_at(c.stage);
+    if (u < 0) continue;
+    const int want = k.snap_of_step[u % kRing];
+    if (want == c.held) continue;
+    p.copy[p.n_copies++] = Copy{c.dst, k.d_snap + (size_t)(want % kRing) * k.snap_bytes + c.off, (int)c.bytes};
+    c.held = want;
+  }
+  hipLaunchKernelGGL(prologue_kernel, dim3(1 + p.n_copies), dim3(256), 0, st, k.d_hops, p);
+  fuse::launch_table(k.d_table, k.table_total, st);
+  hipLaunchKernelGGL(wave_tail_kernel<1>, dim3(b->B), dim3(tail::NTHR), 0, st, k.tail);
+  if (feeding) {
+    b->last_parity = b->hop_host % 3;
+    b->last_hop = b->hop_host;
+    b->hop_host = hop_next(b->hop_host);
+    b->io_host = (b->io_host + 1) % b->io_slots;
+    b->steps_enqueued += 1;
+    k.n_fed += 1;
+    k.last_feed_tick = k.tick;
+  }
+  k.tick += 1;
+  b->inflight = true;
+  return hip_ok(hipGetLastError(), "tick launch");
+}
+// ticks without new input until the last step fed has left the last stage
+bool tick_drain(BeatriceBatch* b) {
+  bool ok = true;
+  while (ok && b->tk.on && b->tk.tick <= b->tk.last_feed_tick + tick::S_COUNT - 1) ok = tick_run(b, false);
+  return ok;
+}
+int tick_enable(BeatriceBatch* b, bool on) {
+  using namespace tick;
+  State& k = b->tk;
+  if (on == k.on) return 0;
+  if (on) {
+    // one 10 ms hop per step, at most 256 streams (the few-row tilings of every layer), resident I/O with enough slots
+    // that a step's input is still there when the pitch head reads it nine ticks on and outputs have somewhere to land
+    if (b->H != 1 || b->B > 256 || b->io_slots < S_COUNT + 1) return -1;
+    if (!sync_all(b)) return -2;
+    if (b->pipelined) { drop_graph(b); set_plan(b, 1); }
+    k.snap_bytes = b->off.front_bytes + b->off.wave_bytes;
+    if (!k.d_hops) {
+      if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_hops), sizeof(int) * 2 * kMaxStages), "tick hops") ||
+          !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_table), sizeof(Tab)), "tick table") ||
+          !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_snap), k.snap_bytes * kRing), "tick snapshots"))
+        return -2;
+    }
+    if (!hip_ok(hipMemset(k.d_hops, 0xff, sizeof(int) * 2 * kMaxStages), "tick hops0") || !hip_ok(hipDeviceSynchronize(), "tick sync")) return -2;
+    k.tick = 0; k.n_fed = 0; k.last_feed_tick = -1000; k.snap_cur = -1; k.snap_next = 0;
+    for (long long& f : k.fed_step) f = -1;
+    k.table_dirty = true;
+    k.on = true;
+    return 0;
+  }
+  if (!sync_all(b)) return -2;  // drains
+  k.on = false;
+  // the in-order chain reads its counters from device memory: hand them the host's values
+  const int pair[2] = {b->hop_host, b->io_host};
+  if (!hip_ok(hipMemcpy(b->d_hop_next, pair, sizeof(pair), hipMemcpyHostToDevice), "tick leave")) return -2;
+  b->front_dirty = true;
+  for (bool& w : b->wave_dirty) w = true;
+  return 0;
 }
 
 template <class F>
@@ -561,8 +767,10 @@ BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* pho
   ok = ok && hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_in), sizeof(float) * B * H * B_IN_HOP), "d_in") &&
        hip_ok(hipMemset(b->d_in, 0, sizeof(float) * B * H * B_IN_HOP), "d_in0");
   // the front end's outputs (phone vector, conditioning mix) have three step slots: see `pipelined`
-  ok = ok && b->phone.create(B, H, b->d_in, 3) && b->pitch.create(B, H, b->d_in, true) &&
-       b->wave.create(B, H, S, S, 9, b->phone.d_phone, b->pitch.d_q, b->pitch.d_feat, 3);
+  const bool slack = H == 1;  // rings sized so that every layer can be its own pipeline stage (tick.hip.h)
+  ok = ok && b->phone.create(B, H, b->d_in, 3, slack) && b->pitch.create(B, H, b->d_in, true, slack) &&
+       b->wave.create(B, H, S, S, 9, b->phone.d_phone, b->pitch.d_q, b->pitch.d_feat, 3, slack);
+  b->wave.q_slots = b->pitch.q_slots;
   // The modules advance in lockstep: one step counter, with no launch spent on incrementing it.  The step's
   // first kernels (phone.f1, pitch.fft) read the pair {counter, I/O slot} from d_hop_next; phone.f1 publishes
   // it to phone.d_hop for the rest of the front end and to d_hop_wave[counter & 1] for the waveform generator
@@ -600,8 +808,9 @@ BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* pho
     auto take = [&o](size_t bytes) { const size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
     const size_t nt = ok ? (size_t)b->wave.n_tiles_max : 1;
     b->off.cbT = take(sizeof(float*) * B * H); b->off.cnorm = take(sizeof(float*) * B * H); b->off.vqk = take(sizeof(int) * B);
-    b->off.min_q = take(sizeof(int) * B); b->off.max_q = take(sizeof(int) * B);
-    b->off.add_idx = take(sizeof(int) * B); b->off.frm_idx = take(sizeof(int) * B); b->off.params = take(sizeof(PitchParams) * B);
+    // (grouped by consumer: k-NN | pitch head | conditioning mix -- tick mode copies a consumer's range as one piece)
+    b->off.min_q = take(sizeof(int) * B); b->off.max_q = take(sizeof(int) * B); b->off.params = take(sizeof(PitchParams) * B);
+    b->off.add_idx = take(sizeof(int) * B); b->off.frm_idx = take(sizeof(int) * B);
     b->off.front_bytes = o;
     for (int blk = 0; blk < B_NBLOCKS; ++blk) { b->off.perm[blk] = take(sizeof(int) * nt * 16); b->off.tile_slot[blk] = take(sizeof(int) * nt); }
     b->off.wave_bytes = o - b->off.front_bytes;
@@ -663,6 +872,7 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   if (!b) return;
   if (b->stream) (void)sync_all(b);
   drop_graph(b);
+  { void* tk[] = {b->tk.d_hops, b->tk.d_table, b->tk.d_snap}; for (void* p : tk) if (p) (void)hipFree(p); }
   if (b->own_d_out) { b->wave.d_out = b->own_d_out; b->own_d_out = nullptr; }
   if (b->module_owned[0]) {  // hand the modules their own arrays back so that destroy() frees what it allocated
     void** keep = b->module_owned;
@@ -924,7 +1134,9 @@ int BeatriceBatch_BindResidentIO(BeatriceBatch* b, const float* d_in, float* d_o
   if (!b || !b->ok) return -2;
   const bool bind = d_in != nullptr || d_out != nullptr;
   if (bind && (!d_in || !d_out || n_slots < 1)) return -1;
+  if (b->tk.on) return -1;  // leave tick mode first
   if (!sync_all(b)) return -2;
+  b->io_host = 0;
   drop_graph(b);  // kernel arguments change
   if (b->own_d_out) { b->wave.d_out = b->own_d_out; b->own_d_out = nullptr; }
   b->phone.d_in = b->pitch.d_in = b->d_in;
@@ -944,7 +1156,7 @@ int BeatriceBatch_BindResidentIO(BeatriceBatch* b, const float* d_in, float* d_o
 
 int BeatriceBatch_ConvertFrames(BeatriceBatch* b, const float* in, float* out) {
   if (!b || !b->ok) { if (b && out) std::memset(out, 0, sizeof(float) * b->B * b->H * B_OUT_HOP); return -2; }
-  if (b->io_slots > 0) return -1;  // resident I/O is bound
+  if (b->io_slots > 0 || b->tk.on) return -1;  // resident I/O is bound
   const size_t n_in = (size_t)b->B * b->H * B_IN_HOP, n_out = (size_t)b->B * b->H * B_OUT_HOP;
   std::memcpy(b->h_in, in, sizeof(float) * n_in);
   bool ok = hip_ok(hipMemcpyAsync(b->d_in, b->h_in, sizeof(float) * n_in, hipMemcpyHostToDevice, b->stream), "in");
@@ -966,12 +1178,12 @@ static bool step_48k(BeatriceBatch* b, const float* d_in48, float* d_out48, int 
 }
 int BeatriceBatch_ConvertBlocks48kDevice(BeatriceBatch* b, const float* d_in, float* d_out, int channels) {
   if (!b || !b->ok) return -2;
-  if (channels < 1 || channels > 2 || !d_in || !d_out || b->H != 1 || b->io_slots > 0 || b->pipelined) return -1;  // per 10 ms block, in order
+  if (channels < 1 || channels > 2 || !d_in || !d_out || b->H != 1 || b->io_slots > 0 || b->pipelined || b->tk.on) return -1;  // per 10 ms block, in order
   return step_48k(b, d_in, d_out, channels) ? 0 : -2;
 }
 int BeatriceBatch_ConvertBlocks48k(BeatriceBatch* b, const float* in, float* out, int channels) {
   if (!b || !b->ok) return -2;
-  if (channels < 1 || channels > 2 || !in || !out || b->H != 1 || b->io_slots > 0 || b->pipelined) return -1;
+  if (channels < 1 || channels > 2 || !in || !out || b->H != 1 || b->io_slots > 0 || b->pipelined || b->tk.on) return -1;
   const size_t n = (size_t)b->B * channels * 480;
   float* h_in = b->h_io48;
   float* h_out = b->h_io48 + (size_t)b->B * 2 * 480;
@@ -1014,8 +1226,14 @@ int BeatriceBatch_EnableGraph(BeatriceBatch* b, int enable) {
 // resident I/O): the front end of step t+1 runs on the batch's stream while the waveform generator of step t
 // runs on a second stream.  Same results; a step's output is complete when BeatriceBatch_Synchronize returns
 // (or, stream-ordered, on BeatriceBatch_GetWaveStream).  Off by default: everything in order on one stream.
+int BeatriceBatch_EnableTickPipeline(BeatriceBatch* b, int enable) {
+  if (!b || !b->ok) return -2;
+  return tick_enable(b, enable != 0);
+}
+int BeatriceBatch_TickStages(const BeatriceBatch*) { return tick::S_COUNT; }
 int BeatriceBatch_EnablePipelining(BeatriceBatch* b, int enable) {
   if (!b || !b->ok) return -2;
+  if (b->tk.on) return -1;
   if (!sync_all(b)) return -2;
   if (enable < 0 || enable > BeatriceBatch::kMaxStages) return -1;
   drop_graph(b);  // stages are captured on the streams they will run on
@@ -1046,9 +1264,10 @@ int BeatriceBatch_GetIntermediates(BeatriceBatch* b, float* phone, int* q_raw, i
     ok = ok && hip_ok(hipMemcpy2D(phone, row, b->phone.d_phone + (size_t)b->last_parity * b->H * B_PHONE_CH, row * b->phone.out_slots, row,
                                   b->B, hipMemcpyDeviceToHost), "phone");
   }
-  if (q_raw) ok = ok && hip_ok(hipMemcpy(q_raw, b->pitch.d_q_raw, sizeof(int) * b->B * b->H, hipMemcpyDeviceToHost), "q_raw");
-  if (q) ok = ok && hip_ok(hipMemcpy(q, b->pitch.d_q, sizeof(int) * b->B * b->H, hipMemcpyDeviceToHost), "q");
-  if (feat) ok = ok && hip_ok(hipMemcpy(feat, b->pitch.d_feat, sizeof(float) * b->B * b->H * 4, hipMemcpyDeviceToHost), "feat");
+  const size_t qo = (size_t)(b->last_hop % b->pitch.q_slots) * b->B * b->H;  // the pitch head's outputs are double-buffered by step
+  if (q_raw) ok = ok && hip_ok(hipMemcpy(q_raw, b->pitch.d_q_raw + qo, sizeof(int) * b->B * b->H, hipMemcpyDeviceToHost), "q_raw");
+  if (q) ok = ok && hip_ok(hipMemcpy(q, b->pitch.d_q + qo, sizeof(int) * b->B * b->H, hipMemcpyDeviceToHost), "q");
+  if (feat) ok = ok && hip_ok(hipMemcpy(feat, b->pitch.d_feat + qo * 4, sizeof(float) * b->B * b->H * 4, hipMemcpyDeviceToHost), "feat");
   return ok ? 0 : -2;
 }
 
@@ -1084,7 +1303,7 @@ struct ProfileHook : LaunchHook {
 int BeatriceBatch_ProfileKernels(BeatriceBatch* b, int repeats, int max_entries, char* names, int* launches, double* mean_us,
                                  double* flops, double* bytes) {
   if (!b || !b->ok) return -2;
-  if (repeats < 1 || max_entries < 1 || !names || !launches || !mean_us || !flops || !bytes) return -1;
+  if (repeats < 1 || max_entries < 1 || !names || !launches || !mean_us || !flops || !bytes || b->tk.on) return -1;
   if (!sync_all(b)) return -2;
   advance_kv(b);
   if (b->vq_dirty) { update_vq_mode(b); b->vq_dirty = false; }
@@ -1099,7 +1318,9 @@ int BeatriceBatch_ProfileKernels(BeatriceBatch* b, int repeats, int max_entries,
   for (int st = 1; st < b->n_stages; ++st) enqueue_wave(b, st, slot, b->stream);
   launch_hook() = nullptr;
   b->last_parity = b->hop_host % 3;
+  b->last_hop = b->hop_host;
   b->hop_host = hop_next(b->hop_host);
+  if (b->io_slots > 0) b->io_host = (b->io_host + 1) % b->io_slots;
   b->steps_enqueued += 1;
   if (!hook.ok || !sync_all(b)) return -2;
   const int n = std::min<int>((int)hook.rows.size(), max_entries);

@@ -5,6 +5,7 @@
 #include "conv_gemm.hip.h"
 #include "engine.h"
 #include "fused_small.hip.h"
+#include "wave_tail.hip.h"
 
 namespace bhip {
 
@@ -50,18 +51,32 @@ static inline LaunchInfo fft_info(const PitchState& s) {
   return LaunchInfo{"pitch.fft", s.B * s.H * (10.0 * 512 * 10 + 1024 * 2 + 512 * 30), 4.0 * s.B * s.H * (1024 + 160 + 512)};
 }
 static inline PitchHeadArgs head_args(const PitchWeights& w, const PitchState& s) {
-  return PitchHeadArgs{s.H, s.logits.base, s.h, s.d_in, w.voi_w, w.voi_b, s.d_min_q, s.d_max_q, s.d_prev_q,
-                       s.d_q_raw, s.d_q, s.d_feat, s.d_params, s.hop, s.io_stride};
+  return PitchHeadArgs{s.H, s.logits, s.h, s.d_in, w.voi_w, w.voi_b, s.d_min_q, s.d_max_q, s.d_prev_q,
+                       s.d_q_raw, s.d_q, s.d_feat, s.d_params, s.hop, s.io_stride, s.q_slots, s.B};
 }
 static inline LaunchInfo head_info(const PitchState& s) {
   return LaunchInfo{"pitch.head", 25.0 * s.B * s.H * 448, 4.0 * s.B * s.H * (448 + 160 + 128 + 8)};
 }
 static inline CondArgs cond_args(const WaveWeights& w, const WaveState& s) {
-  return CondArgs{s.H, s.d_q, s.d_feat, w.pitch_emb, w.feat_w, s.d_add_tab, s.d_add_idx, s.d_frm_tab, s.d_frm_idx, s.e,
+  return CondArgs{s.H, s.d_q, s.d_feat, s.q_slots, s.B, w.pitch_emb, w.feat_w, s.d_add_tab, s.d_add_idx, s.d_frm_tab, s.d_frm_idx, s.e,
                   s.front_hop ? s.front_hop : s.hop, s.front_next_out, s.io_slots};
 }
 static inline LaunchInfo cond_info(const WaveState& s) {
   return LaunchInfo{"wave.cond", 11.0 * s.B * s.H * 256, 4.0 * s.B * s.H * 256 * 4};
+}
+
+static inline TailArgs tail_args(const WaveWeights& w, const WaveState& s) {
+  TailArgs ta{};
+  ta.in = s.ya2; ta.state = s.tail.base; ta.fin_w = w.fin_w; ta.fin_b = w.fin_b; ta.d_out = s.d_out; ta.hop = s.hop; ta.io_stride = s.io_stride;
+  ta.w[0] = w.ra_w[1]; ta.b[0] = w.ra_b[1]; ta.w[1] = w.rb_w[1]; ta.b[1] = w.rb_b[1];
+  ta.w[2] = w.up_w[2]; ta.b[2] = w.up_b[2]; ta.w[3] = w.ra_w[2]; ta.b[3] = w.ra_b[2]; ta.w[4] = w.rb_w[2]; ta.b[4] = w.rb_b[2];
+  ta.w[5] = w.up_w[3]; ta.b[5] = w.up_b[3]; ta.w[6] = w.ra_w[3]; ta.b[6] = w.ra_b[3]; ta.w[7] = w.rb_w[3]; ta.b[7] = w.rb_b[3];
+  return ta;
+}
+static inline LaunchInfo tail_info(const WaveState& s) {
+  const double tail_macs = 2.0 * 20 * 192 * 64 + 20.0 * 128 * 128 + 2.0 * 80 * 96 * 32 + 80.0 * 64 * 48 + 2.0 * 240 * 48 * 16 + 240.0 * 112;
+  const int rows = s.B * s.H;
+  return LaunchInfo{"wave.tail", 2.0 * rows * tail_macs, 4.0 * (52000.0 + s.B * 2 * TAIL_STATE_FLOATS + rows * (22 * 64 + 240))};
 }
 
 // phone.out writes the 128-d vector either to the ring the k-NN kernel reads or, when no stream uses

@@ -132,6 +132,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bx, 
   }
 
   const int hop = *a.hop;
+  if (hop < 0) return;  // this stage has no step this tick (pipeline fill / drain, batch.hip tick mode)
   const int pos_in = ring_pos(a.in, hop);
 
   // per-thread A staging slots: which (stream, t) row and which 16-byte piece

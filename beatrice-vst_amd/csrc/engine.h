@@ -98,7 +98,9 @@ struct PhoneState {
   int* hop_publish_wave = nullptr;  // batch: ... and to the waveform generator's counter pair [counter & 1]
   bool advance_hop = true;    // this module's forward ends with the counter increment
   bool skip_vq = false;       // no stream uses the codebook: phone.out writes d_phone, no k-NN launch
-  bool create(int B, int H, float* shared_in, int out_slots = 1);
+  // pipe_slack: one more step slot on every ring a later layer reads, so that each LAYER may run as its own pipeline
+  // stage one step behind its producer (batch.hip, tick mode)
+  bool create(int B, int H, float* shared_in, int out_slots = 1, bool pipe_slack = false);
   void destroy();
 };
 void phone_forward(const PhoneWeights& w, const PhoneState& s, hipStream_t stream);
@@ -122,14 +124,15 @@ struct PitchState {
   int* hop_mailbox = nullptr;  // owned d_in only: kMailboxWords words right behind the audio
   size_t io_stride = 0;        // see PhoneState
   int *d_min_q = nullptr, *d_max_q = nullptr, *d_prev_q = nullptr;  // [B]
-  int *d_q_raw = nullptr, *d_q = nullptr;                          // [B][H]
-  float* d_feat = nullptr;             // [B][H][4]
+  int q_slots = 1;                                                 // step slots of the three outputs below (2 with pipe_slack)
+  int *d_q_raw = nullptr, *d_q = nullptr;                          // [q_slots][B][H]
+  float* d_feat = nullptr;             // [q_slots][B][H][4]
   PitchParams* d_params = nullptr;     // [B] or nullptr (1-stream ABI: host does the transform)
   int* d_hop = nullptr;       // owned hop counter
   int* hop = nullptr;         // counter the kernels read (== d_hop unless shared by a batch)
   int* hop_in = nullptr;      // counter the first kernel (FFT) reads
   bool advance_hop = true;    // this module's forward ends with the counter increment
-  bool create(int B, int H, float* shared_in, bool with_params);
+  bool create(int B, int H, float* shared_in, bool with_params, bool pipe_slack = false);
   void destroy();
 };
 void pitch_forward(const PitchWeights& w, const PitchState& s, hipStream_t stream);
@@ -171,6 +174,7 @@ struct WaveState {
   Ring tail;                // per-stream history block of the fused upsampler tail (wave_tail.hip.h)
   // inputs (device): phone [B][H][128], q [B][H], feat [B][H][4]; owned unless shared with other modules
   float* d_phone = nullptr; int* d_q = nullptr; float* d_feat = nullptr;
+  int q_slots = 1;  // step slots of d_q / d_feat (PitchState::q_slots when shared)
   bool owns_inputs = false;
   float* d_out = nullptr;  // [B][H*240]
   // conditioning tables and per-stream selectors
@@ -192,7 +196,7 @@ struct WaveState {
   int front_slots = 1;             // step slots of the front end's outputs (phone vector, conditioning e): 1, or 3 in a batch
   bool advance_hop = true;    // this module's forward ends with the counter increment
   bool create(int B, int H, int n_slots, int n_add, int n_frm, float* shared_phone, int* shared_q, float* shared_feat,
-              int front_slots = 1);
+              int front_slots = 1, bool pipe_slack = false);
   void destroy();
 };
 // parts of the module, for pipelines that cut it into stages: 1 = input mix, 2..5 = conditioned blocks 0..3,

@@ -97,4 +97,91 @@ static inline void launch(hipStream_t stream, const Part<Ops>&... parts) {
   });
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Table-driven variant: MANY bodies (a whole pipeline's worth, batch.hip tick mode) in one launch.  The arguments
+// live in device memory (a launch with ~50 argument blocks exceeds what a kernel-argument segment should carry, and
+// they are the same every launch); a workgroup finds its body with one vector load of the bodies' first-workgroup
+// indices + a ballot, then branches on the body's TYPE, so that a kernel body used by several layers (the eight
+// 256->256 linears of the conditioned blocks, say) is compiled into the launch once.
+template <class Op, int CAP>
+struct Many { using op = Op; static constexpr int cap = CAP; };
+struct Span { int first, gx, type, arg; };  // workgroups [first, next first) run body `type` with its argument block `arg`
+constexpr int kMaxSpans = 64;
+template <class... Ms> struct Banks;
+template <> struct Banks<> {};
+template <class M, class... Rest>
+struct Banks<M, Rest...> {
+  typename M::op::Args a[M::cap];
+  Banks<Rest...> rest;
+};
+template <class... Ms>
+struct Table {
+  int n_spans, total;
+  int first[kMaxSpans];
+  Span span[kMaxSpans];
+  Banks<Ms...> banks;
+};
+template <class... Ms> struct MaxM;
+template <class M> struct MaxM<M> { static constexpr int NTHR = M::op::NTHR, LDS = M::op::LDS_FLOATS; };
+template <class M, class... Rest>
+struct MaxM<M, Rest...> {
+  static constexpr int NTHR = M::op::NTHR > MaxM<Rest...>::NTHR ? M::op::NTHR : MaxM<Rest...>::NTHR;
+  static constexpr int LDS = M::op::LDS_FLOATS > MaxM<Rest...>::LDS ? M::op::LDS_FLOATS : MaxM<Rest...>::LDS;
+};
+
+template <int I, int NTHR, class M, class... Rest>
+__device__ __forceinline__ void run_type(const Banks<M, Rest...>& b, const Span& sp, int id, float* lds) {
+  if (sp.type == I) {
+    using Op = typename M::op;
+    if (Op::NTHR >= NTHR || (int)threadIdx.x < Op::NTHR) Op::run(b.a[sp.arg], id % sp.gx, id / sp.gx, lds);
+  } else {
+    if constexpr (sizeof...(Rest) > 0) run_type<I + 1, NTHR, Rest...>(b.rest, sp, id, lds);
+  }
+}
+
+template <class... Ms>
+__global__ __launch_bounds__(MaxM<Ms...>::NTHR) void table_kernel(const Table<Ms...>* __restrict__ t) {
+  __shared__ __attribute__((aligned(16))) float lds[MaxM<Ms...>::LDS > 0 ? MaxM<Ms...>::LDS : 1];
+  const int id = blockIdx.x, lane = threadIdx.x & 63;
+  const int f = lane < t->n_spans ? t->first[lane] : 0x7fffffff;
+  const int idx = __builtin_amdgcn_readfirstlane(__popcll(__ballot(f <= id)) - 1);
+  const Span sp = t->span[idx];
+  run_type<0, MaxM<Ms...>::NTHR, Ms...>(t->banks, sp, id - sp.first, lds);
+}
+
+template <class... Ms>
+static inline void launch_table(const Table<Ms...>* d_table, int total, hipStream_t stream) {
+  hipLaunchKernelGGL((table_kernel<Ms...>), dim3(total), dim3(MaxM<Ms...>::NTHR), 0, stream, d_table);
+}
+
+// host side: fill a Table<Ms...>.  add<I>() appends one body of type I (its index in Ms...); bodies run in the order added
+template <int I, class B> struct BankAt;
+template <class M, class... Rest> struct BankAt<0, Banks<M, Rest...>> {
+  static typename M::op::Args* get(Banks<M, Rest...>& b) { return b.a; }
+  static constexpr int cap = M::cap;
+};
+template <int I, class M, class... Rest> struct BankAt<I, Banks<M, Rest...>> {
+  static auto get(Banks<M, Rest...>& b) { return BankAt<I - 1, Banks<Rest...>>::get(b.rest); }
+  static constexpr int cap = BankAt<I - 1, Banks<Rest...>>::cap;
+};
+template <class... Ms>
+struct TableBuilder {
+  Table<Ms...> t{};
+  int used[sizeof...(Ms)] = {};
+  bool ok = true;
+  double flops = 0, bytes = 0;
+  template <int I, class Args>
+  void add(const bhip::LaunchInfo& info, const Args& a, dim3 grid, bool on = true) {
+    if (!on) return;
+    using BA = BankAt<I, Banks<Ms...>>;
+    if (t.n_spans >= kMaxSpans || used[I] >= BA::cap) { ok = false; return; }
+    BA::get(t.banks)[used[I]] = a;
+    Span& sp = t.span[t.n_spans];
+    sp.first = t.total; sp.gx = (int)grid.x > 0 ? (int)grid.x : 1; sp.type = I; sp.arg = used[I]++;
+    t.first[t.n_spans++] = t.total;
+    t.total += (int)(grid.x * grid.y);
+    flops += info.flops; bytes += info.bytes;
+  }
+};
+
 }  // namespace fuse

@@ -48,6 +48,7 @@ __device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, c
     for (int kb = 0; kb < (KB_X > KB_H ? KB_X : KB_H); ++kb) bf[kb] = wp[(size_t)(kb < kbn ? kb : 0) * 64];
   }
   const int hop = *a.hop;
+  if (hop < 0) return;
   const int px = ring_pos(a.x, hop), ph = ring_pos(a.h, hop);
   // A tiles -> LDS
   for (int e = tid; e < 16 * (IN / 4); e += 384) {
@@ -130,11 +131,12 @@ static inline void launch_gru(const char* name, const GruArgs& a, hipStream_t st
 
 // ---------------------------------------------------------------------------------------------
 struct AttnPvArgs {
-  const float* scores;   // [rows][384], already scaled by 1/16; rows = (stream, hop)
+  Ring scores;           // C = 384, n = H frames per step: scores of row (stream, hop), already scaled by 1/16
   const float* v;        // packed V tables, slot stride 384*256
-  float* out;            // [rows][256]
-  const int* perm;       // [n_tiles][16] row indices or -1
+  Ring out;              // C = 256, n = H
+  const int* perm;       // [n_tiles][16] row indices (stream * H + hop) or -1
   const int* tile_slot;  // [n_tiles]
+  const int* hop;
 };
 
 constexpr int kAttnPvLdsFloats = 16 * (B_KV_LEN + 2) + 16 + 2 * 16 * 32;
@@ -145,9 +147,12 @@ __device__ __forceinline__ void attn_pv_body(const AttnPvArgs& a, const int bx, 
   float* red = inv + 16;         // [2][16][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = wave >> 1, wn = wave & 1;
+  const int hop = *a.hop;
+  if (hop < 0) return;
   const int slot = a.tile_slot[bx];
   if (slot < 0) return;
   const int n0 = by * NT;
+  const int H = a.scores.n, pos_s = ring_pos(a.scores, hop), pos_o = ring_pos(a.out, hop);
   // B fragments of this wave: segment grp (keys 0..255 or 256..383), column tile (n0 + wn*16)/16
   float4 bf[16];
   {
@@ -163,8 +168,9 @@ __device__ __forceinline__ void attn_pv_body(const AttnPvArgs& a, const int bx, 
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int b = a.perm[bx * 16 + wave * 4 + rr];
+      const float* srow = b >= 0 ? ring_frame(a.scores, b / H, pos_s, b % H) : nullptr;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) v[rr][i] = b >= 0 ? a.scores[(size_t)b * KL + lane + 64 * i] : 0.0f;
+      for (int i = 0; i < 6; ++i) v[rr][i] = b >= 0 ? srow[lane + 64 * i] : 0.0f;
     }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -208,7 +214,7 @@ __device__ __forceinline__ void attn_pv_body(const AttnPvArgs& a, const int bx, 
     const int b = a.perm[bx * 16 + r];
     if (b < 0) continue;
     const float v = red[idx] + red[16 * NT + idx];  // segment 0 + segment 1 (MODEL_SPEC 2.2)
-    a.out[(size_t)b * B_HID + n] = v * inv[r];
+    ring_frame(a.out, b / H, pos_o, b % H)[n] = v * inv[r];
   }
 }
 static __global__ __launch_bounds__(256) void attn_pv_kernel(const AttnPvArgs a) {

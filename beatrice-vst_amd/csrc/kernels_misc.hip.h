@@ -49,6 +49,7 @@ __device__ __forceinline__ void phone_f1_body(const F1Args& a, const int b, cons
   float* x = lds;         // [5 + 160]
   float* ws = lds + 168;  // [10][64]
   const int tid = threadIdx.x, hop = *a.hop, H = a.H;
+  if (hop < 0) return;
   const int io = a.io_stride != 0 ? a.hop[1] : 0;
   if (a.hop_publish != nullptr && b == 0 && hh == 0 && tid == 0) {
     a.hop_publish[0] = hop; a.hop_publish[1] = io;
@@ -103,7 +104,7 @@ struct F1Op {
 // distance loop reads coalesced rows.  Streams with k == 0 pass the raw vector through.
 struct VqArgs {
   int H;                       // hops per step: rows are (stream, hop), codebook per stream
-  const float* raw;            // [B][H][128]
+  Ring raw;                    // C = 128, n = H: the encoder's output vectors
   Ring out;                    // C = 128, n = H frames per step, m = 1 or 2 step slots
   const int* hop;
   const float* const* cbT;     // per row (stream, hop): [128][512]
@@ -117,10 +118,12 @@ __device__ __forceinline__ void phone_vq_body(const VqArgs& a, const int row, fl
   int* red_j = reinterpret_cast<int*>(lds + B_PHONE_CH + 8);    // [8]
   int& winner = *reinterpret_cast<int*>(lds + B_PHONE_CH + 16);
   const int b = row / a.H, j = threadIdx.x, lane = j & 63, wave = j >> 6;
-  float* out = ring_frame(a.out, b, ring_pos(a.out, *a.hop), row % a.H);
+  const int hop = *a.hop;
+  if (hop < 0) return;
+  float* out = ring_frame(a.out, b, ring_pos(a.out, hop), row % a.H);
   const int k = a.k[b];
   const float* cbT = a.cbT[row];
-  if (j < B_PHONE_CH) x[j] = a.raw[(size_t)row * B_PHONE_CH + j];
+  if (j < B_PHONE_CH) x[j] = ring_frame(a.raw, b, ring_pos(a.raw, hop), row % a.H)[j];
   if (k <= 0 || cbT == nullptr) {
     if (j < B_PHONE_CH) out[j] = x[j];
     return;
@@ -185,6 +188,7 @@ __device__ __forceinline__ void pitch_fft_body(const FftArgs& a, const int b, co
   float* im = lds + B_FFT_N;
   float* tw = lds + 2 * B_FFT_N;
   const int tid = threadIdx.x, hop = *a.hop, H = a.H;
+  if (hop < 0) return;
   const Ring& audio = a.audio;
   const Ring& spec = a.spec;
   const float* __restrict__ d_in = a.d_in + (a.io_stride != 0 ? (size_t)a.hop[1] * a.io_stride : 0);
@@ -253,7 +257,7 @@ struct PitchParams {  // per stream
 };
 struct PitchHeadArgs {
   int H;                // hops per step; all per-hop arrays below are [B][H]...
-  const float* logits;  // [B][H][448]
+  Ring logits;          // C = 448, n = H
   Ring h;               // GRU state ring (C=128)
   const float* d_in;    // [B][160]
   const float* voi_w;   // [128]
@@ -261,12 +265,14 @@ struct PitchHeadArgs {
   const int* min_q;
   const int* max_q;
   int* prev_q;
-  int* q_raw;           // [B]
-  int* q_out;           // [B] (after transform; == q_raw when params == nullptr)
-  float* feat;          // [B][4]
+  int* q_raw;           // [q_slots][B][H]
+  int* q_out;           // [q_slots][B][H] (after transform; == q_raw when params == nullptr)
+  float* feat;          // [q_slots][B][H][4]
   const PitchParams* params;
   const int* hop;
   size_t io_stride;     // see F1Args (d_in is read for the frame energy)
+  int q_slots;          // step slots of the three outputs (step t -> slot t mod q_slots): 1, or 2 when the consumer may lag a step
+  int B;
 };
 
 __device__ inline double pitch_round_half_away(double v) { return v >= 0.0 ? floor(v + 0.5) : -floor(-v + 0.5); }
@@ -297,12 +303,15 @@ __device__ inline int pitch_transform_device(int q, const PitchParams& p) {
 __device__ __forceinline__ void pitch_head_body(const PitchHeadArgs& a, const int b) {
   const int l = threadIdx.x;
   const int hop = *a.hop;
+  if (hop < 0) return;
+  const size_t qoff = (size_t)(hop % a.q_slots) * a.B * a.H;
+  const int pos_l = ring_pos(a.logits, hop);
   int lo = a.min_q[b], hi = a.max_q[b];
   if (hi < lo) hi = lo;
   int prev = a.prev_q[b];
   for (int hh = 0; hh < a.H; ++hh) {
     const size_t row = (size_t)b * a.H + hh;
-    const float* lg = a.logits + row * B_PITCH_BINS;
+    const float* lg = ring_frame(a.logits, b, pos_l, hh);
     float v[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) v[i] = lg[l + 64 * i];
@@ -337,10 +346,10 @@ __device__ __forceinline__ void pitch_head_body(const PitchHeadArgs& a, const in
     if (l == 0) {
       float dq = (float)(q - prev) * 0.125f;
       dq = dq < -1.0f ? -1.0f : (dq > 1.0f ? 1.0f : dq);
-      float* f = a.feat + row * 4;
+      float* f = a.feat + (qoff + row) * 4;
       f[0] = f0; f[1] = f1; f[2] = dq; f[3] = f3;
-      a.q_raw[row] = q;
-      a.q_out[row] = a.params ? pitch_transform_device(q, a.params[b]) : q;
+      a.q_raw[qoff + row] = q;
+      a.q_out[qoff + row] = a.params ? pitch_transform_device(q, a.params[b]) : q;
     }
     prev = q;
   }
@@ -359,8 +368,9 @@ struct HeadOp {
 //   e[b][n] = (pitch_emb[q][n] + Wf.feat[b]) + (add_tab[add_idx[b]][n] + frm_tab[frm_idx[b]][n])
 struct CondArgs {
   int H;               // hops per step; q/feat/e rows are (stream, hop)
-  const int* q;        // [B][H]
-  const float* feat;   // [B][4]
+  const int* q;        // [q_slots][B][H]
+  const float* feat;   // [q_slots][B][H][4]
+  int q_slots, B;      // see PitchHeadArgs
   const float* pitch_emb;
   const float* feat_w; // [4][256]
   const float* add_tab; const int* add_idx;
@@ -373,14 +383,16 @@ struct CondArgs {
 };
 __device__ __forceinline__ void wave_cond_body(const CondArgs& a, const int row) {
   const int b = row / a.H, n = threadIdx.x;
-  int q = a.q[row];
+  const int hop = *a.hop;
+  if (hop < 0) return;
+  const size_t qoff = (size_t)(hop % a.q_slots) * a.B * a.H;
+  int q = a.q[qoff + row];
   q = q < 0 ? 0 : (q > B_PITCH_BINS - 1 ? B_PITCH_BINS - 1 : q);
-  const float* f = a.feat + (size_t)row * 4;
+  const float* f = a.feat + (qoff + row) * 4;
   float fp = 0.0f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) fp = bsp::fma(f[i], a.feat_w[i * B_HID + n], fp);
   const float c = a.add_tab[(size_t)a.add_idx[b] * B_HID + n] + a.frm_tab[(size_t)a.frm_idx[b] * B_HID + n];
-  const int hop = *a.hop;
   ring_frame(a.e, b, ring_pos(a.e, hop), row % a.H)[n] = (a.pitch_emb[(size_t)q * B_HID + n] + fp) + c;
   if (a.hop_next_out != nullptr && row == 0 && n == 0) {
     const int io = a.io_slots > 0 ? a.hop[1] : 0;

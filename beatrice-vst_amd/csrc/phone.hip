@@ -5,15 +5,16 @@
 
 namespace bhip {
 
-bool PhoneState::create(int B_, int H_, float* shared_in, int out_slots_) {
+bool PhoneState::create(int B_, int H_, float* shared_in, int out_slots_, bool pipe_slack) {
   B = B_; H = H_; out_slots = out_slots_;
+  const int x = pipe_slack ? 1 : 0;  // the reader of a ring may be one step behind its writer
   auto slots = [&](int n0, int hist) { return 1 + (hist + n0 * H - 1) / (n0 * H); };
   std::vector<RingSpec> specs = {
       {&audio, 1, B_IN_HOP * H, slots(B_IN_HOP, 5)},
-      {&f[0], 64, 32 * H, slots(32, 4)}, {&f[1], 128, 8 * H, slots(8, 2)}, {&f[2], 256, 4 * H, slots(4, 2)},
-      {&f[3], 256, 2 * H, slots(2, 2)}, {&f[4], 256, H, slots(1, 4)},
-      {&rb[0], 256, H, slots(1, 4)}, {&rb[1], 256, H, slots(1, 4)}, {&rb[2], 256, H, slots(1, 4)}, {&rb[3], 256, H, 1},
-      {&h, 256, H, slots(1, 1)}, {&raw, B_PHONE_CH, H, 1},
+      {&f[0], 64, 32 * H, slots(32, 4) + x}, {&f[1], 128, 8 * H, slots(8, 2) + x}, {&f[2], 256, 4 * H, slots(4, 2) + x},
+      {&f[3], 256, 2 * H, slots(2, 2) + x}, {&f[4], 256, H, slots(1, 4) + x},
+      {&rb[0], 256, H, slots(1, 4) + x}, {&rb[1], 256, H, slots(1, 4) + x}, {&rb[2], 256, H, slots(1, 4) + x}, {&rb[3], 256, H, 1 + x},
+      {&h, 256, H, slots(1, 1) + x}, {&raw, B_PHONE_CH, H, 1 + x},
   };
   if (!arena.build(B, specs)) return false;
   if (shared_in) { d_in = shared_in; owns_in = false; }
@@ -60,7 +61,7 @@ void PhoneState::destroy() {
 void phone_vq(const PhoneWeights&, const PhoneState& s, hipStream_t st) {
   const int B = s.B, H = s.H;
   if (!s.skip_vq) {
-    VqArgs v{H, s.raw.base, phone_vector_ring(s), s.hop, s.d_cbT, s.d_cnorm, s.d_vqk};
+    VqArgs v{H, s.raw, phone_vector_ring(s), s.hop, s.d_cbT, s.d_cnorm, s.d_vqk};
     MISC_LAUNCH("phone.vq", 0 /* k-dependent: 131 kFLOP per stream-hop with k > 0, pass-through at k = 0 */, 4.0 * B * H * 256,
                 phone_vq_kernel, dim3(B * H), dim3(512), v);
   }

@@ -5,13 +5,15 @@
 
 namespace bhip {
 
-bool PitchState::create(int B_, int H_, float* shared_in, bool with_params) {
+bool PitchState::create(int B_, int H_, float* shared_in, bool with_params, bool pipe_slack) {
   B = B_; H = H_;
+  const int x = pipe_slack ? 1 : 0;  // see PhoneState::create; the GRU state is also read by the pitch head, two stages on
+  q_slots = pipe_slack ? 2 : 1;
   auto slots = [&](int n0, int hist) { return 1 + (hist + n0 * H - 1) / (n0 * H); };
   std::vector<RingSpec> specs = {
       {&audio, 1, B_IN_HOP * H, slots(B_IN_HOP, B_PITCH_HIST)},
-      {&spec, B_SPEC_BINS, H, slots(1, 2)}, {&p[0], 128, H, slots(1, 2)}, {&p[1], 128, H, slots(1, 2)}, {&p[2], 128, H, 1},
-      {&h, 128, H, slots(1, 1)}, {&logits, B_PITCH_BINS, H, 1},
+      {&spec, B_SPEC_BINS, H, slots(1, 2) + x}, {&p[0], 128, H, slots(1, 2) + x}, {&p[1], 128, H, slots(1, 2) + x}, {&p[2], 128, H, 1 + x},
+      {&h, 128, H, slots(1, 1) + 2 * x}, {&logits, B_PITCH_BINS, H, 1 + x},
   };
   if (!arena.build(B, specs)) return false;
   if (shared_in) { d_in = shared_in; owns_in = false; }
@@ -28,11 +30,11 @@ bool PitchState::create(int B_, int H_, float* shared_in, bool with_params) {
   }
   int** per_row[] = {&d_q_raw, &d_q};
   for (int** p : per_row) {
-    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(p), sizeof(int) * B * H));
-    BHIP_TRY(hipMemset(*p, 0, sizeof(int) * B * H));
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(p), sizeof(int) * B * H * q_slots));
+    BHIP_TRY(hipMemset(*p, 0, sizeof(int) * B * H * q_slots));
   }
-  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_feat), sizeof(float) * 4 * B * H));
-  BHIP_TRY(hipMemset(d_feat, 0, sizeof(float) * 4 * B * H));
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_feat), sizeof(float) * 4 * B * H * q_slots));
+  BHIP_TRY(hipMemset(d_feat, 0, sizeof(float) * 4 * B * H * q_slots));
   std::vector<int> lo(B, 1), hi(B, B_PITCH_BINS - 1);
   BHIP_TRY(hipMemcpy(d_min_q, lo.data(), sizeof(int) * B, hipMemcpyHostToDevice));
   BHIP_TRY(hipMemcpy(d_max_q, hi.data(), sizeof(int) * B, hipMemcpyHostToDevice));

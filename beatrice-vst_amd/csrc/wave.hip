@@ -1,15 +1,15 @@
 // wave.hip -- waveform generator forward pass (MODEL_SPEC 4.4), the body of
 // Beatrice20rc0_GenerateWaveform1 (reference lib/beatricelib/beatrice.h:301-307) for B streams.
 #include "chain_layers.hip.h"
-#include "wave_tail.hip.h"
 
 namespace bhip {
 
 static const int kBlockDil[B_NBLOCKS] = {1, 2, 4, 8};
 
 bool WaveState::create(int B_, int H_, int n_slots_, int n_add_, int n_frm_, float* shared_phone, int* shared_q,
-                       float* shared_feat, int front_slots_) {
+                       float* shared_feat, int front_slots_, bool pipe_slack) {
   B = B_; H = H_; n_slots = n_slots_; n_add = n_add_; n_frm = n_frm_; front_slots = front_slots_;
+  const int ps = pipe_slack ? 1 : 0;  // every layer its own pipeline stage (tick mode): readers run a step behind
   boundary_slots = front_slots_ > 1 ? 2 : 0;  // a batch may cut the module into pipeline stages
   const int xs = boundary_slots;
   auto fit = [](int m) { while (B_HOP_WRAP % m != 0) ++m; return m; };
@@ -23,12 +23,13 @@ bool WaveState::create(int B_, int H_, int n_slots_, int n_add_, int n_frm_, flo
       {&x[4], B_HID, H, fit(slots(1, 1) + xs)},
   };
   for (int i = 0; i < (boundary_slots ? kScratchSets : 1); ++i) {
-    specs.push_back({&scr[i].h1, B_HID, H, 1}); specs.push_back({&scr[i].xa, B_HID, H, 1}); specs.push_back({&scr[i].q, B_HID, H, 1});
-    specs.push_back({&scr[i].sc, B_KV_LEN, H, 1}); specs.push_back({&scr[i].o, B_HID, H, 1});
+    // (xa is read again, as the residual, by the block's last layer: four stages after it is written)
+    specs.push_back({&scr[i].h1, B_HID, H, 1 + ps}); specs.push_back({&scr[i].xa, B_HID, H, 1 + 4 * ps}); specs.push_back({&scr[i].q, B_HID, H, 1 + ps});
+    specs.push_back({&scr[i].sc, B_KV_LEN, H, 1 + ps}); specs.push_back({&scr[i].o, B_HID, H, 1 + ps});
   }
-  specs.push_back({&ya1, 128, 5 * H, slots(5, 2)});   // history 2 (res1a, k3)
-  specs.push_back({&yb1, 128, 5 * H, slots(5, 6)});   // history 6 (res1b, k3 dil 3)
-  specs.push_back({&yc1, 128, 5 * H, slots(5, 1)});   // history 1 (up2)
+  specs.push_back({&ya1, 128, 5 * H, slots(5, 2) + ps});   // history 2 (res1a, k3)
+  specs.push_back({&yb1, 128, 5 * H, slots(5, 6) + ps});   // history 6 (res1b, k3 dil 3)
+  specs.push_back({&yc1, 128, 5 * H, slots(5, 1) + ps});   // history 1 (up2)
   specs.push_back({&ya2, 64, 20 * H, fit(slots(20, 2) + xs)});  // history 2 (first layer of the fused tail)
   specs.push_back({&tail, TAIL_STATE_FLOATS, 1, 1});
   if (!arena.build(B, specs)) return false;
@@ -132,7 +133,7 @@ static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t
     a.scale = 0.0625f; a.perm = s.d_perm[blk]; a.tile_slot = s.d_tile_slot[blk];
     a.w_slot_stride = (size_t)B_HID * B_KV_LEN;
     launch_conv<SCORE<H>, TGQ>("wave.blk.attn_qk", a, s.n_tiles_max, st);
-    AttnPvArgs pa{k.sc.base, s.d_v[blk], k.o.base, s.d_perm[blk], s.d_tile_slot[blk]};
+    AttnPvArgs pa{k.sc, s.d_v[blk], k.o, s.d_perm[blk], s.d_tile_slot[blk], s.hop};
     MISC_LAUNCH("wave.blk.attn_pv", 2.0 * rows * 384 * 256 + 25.0 * rows * 384, 4.0 * (384.0 * 256 + rows * (384 + 256)),
                 attn_pv_kernel, dim3(s.n_tiles_max, B_HID / 32), dim3(256), pa);
     a = conv_args(k.o, s.x[blk + 1], w.o_w[blk], w.o_b[blk], s.hop, B);
@@ -148,14 +149,8 @@ static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t
     launch_auto<UP<128, 64, 4, 5 * H>>("wave.up2", conv_args(s.yc1, s.ya2, w.up_w[1], w.up_b[1], s.hop, B), st);
   }
   if (!in_part(7)) return;
-  TailArgs ta{};
-  ta.in = s.ya2; ta.state = s.tail.base; ta.fin_w = w.fin_w; ta.fin_b = w.fin_b; ta.d_out = s.d_out; ta.hop = s.hop; ta.io_stride = s.io_stride;
-  ta.w[0] = w.ra_w[1]; ta.b[0] = w.ra_b[1]; ta.w[1] = w.rb_w[1]; ta.b[1] = w.rb_b[1];
-  ta.w[2] = w.up_w[2]; ta.b[2] = w.up_b[2]; ta.w[3] = w.ra_w[2]; ta.b[3] = w.ra_b[2]; ta.w[4] = w.rb_w[2]; ta.b[4] = w.rb_b[2];
-  ta.w[5] = w.up_w[3]; ta.b[5] = w.up_b[3]; ta.w[6] = w.ra_w[3]; ta.b[6] = w.ra_b[3]; ta.w[7] = w.rb_w[3]; ta.b[7] = w.rb_b[3];
-  const double tail_macs = 2.0 * 20 * 192 * 64 + 20.0 * 128 * 128 + 2.0 * 80 * 96 * 32 + 80.0 * 64 * 48 + 2.0 * 240 * 48 * 16 + 240.0 * 112;
-  MISC_LAUNCH("wave.tail", 2.0 * rows * tail_macs, 4.0 * (52000.0 + B * 2 * TAIL_STATE_FLOATS + rows * (22 * 64 + 240)), wave_tail_kernel<H>,
-              dim3(B), dim3(tail::NTHR), ta);
+  const TailArgs ta = tail_args(w, s);
+  launch_site(tail_info(s), st, [&] { hipLaunchKernelGGL(wave_tail_kernel<H>, dim3(B), dim3(tail::NTHR), 0, st, ta); });
   if (s.advance_hop) MISC_LAUNCH("hop_advance", 0, 4, hop_advance_kernel, dim3(1), dim3(1), s.hop);
 }
 

@@ -1,0 +1,111 @@
+"""Tick pipelining (BeatriceBatch_EnableTickPipeline): every layer of the chain its own pipeline stage, one launch per
+tick, ~40 steps in flight.  Must give the samples of the in-order chain bit for bit -- with per-stream settings
+changing between steps (speaker switches installing one K/V block per hop, k-NN on/off, pitch and formant
+settings), across pipeline drains, a stream reset in mid-flight, and the return to the in-order chain."""
+import numpy as np
+import pytest
+
+from test_gpu_resident_io import Hip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,steps,vq_from_start", [(24, 75, True), (5, 60, False), (256, 50, True)])
+def test_tick_pipeline_matches_in_order_chain(bv, product, model_dir, B, steps, vq_from_start):
+    hip = Hip()
+    m = bv.Models(product, model_dir)
+    bv.bind_batch(product)
+    audio = np.stack([bv.synth_audio(160 * steps, seed=8000 + s) for s in range(B)])  # [B][steps*160]
+    tail_steps = 4   # after the pipelined part: back to the in-order chain on the same streams
+
+    def settings(batch):
+        for s in range(B):
+            batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, s, s % 3)
+            if vq_from_start:
+                batch.a.BeatriceBatch_SetVQNumNeighbors(batch.h, s, s % 3)
+        batch.a.BeatriceBatch_FlushSpeaker(batch.h, -1)
+
+    def change(batch, k):
+        a, h = batch.a, batch.h
+        if k % 4 == 1:
+            s = (7 * k) % B
+            a.BeatriceBatch_SetTargetSpeaker(h, s, (k + s) % 3)            # K/V blocks follow, one per hop
+            a.BeatriceBatch_SetFormantShift(h, (s + 1) % B, float(k % 5) - 2.0)
+            a.BeatriceBatch_SetPitchShift(h, (s + 2) % B, float(k % 7) - 3.0)
+        if k % 9 == 5 and vq_from_start:
+            a.BeatriceBatch_SetVQNumNeighbors(h, (3 * k) % B, k % 5)
+        if k == 20 and not vq_from_start:
+            a.BeatriceBatch_SetVQNumNeighbors(h, 1 % B, 3)                    # the k-NN stage appears: pipeline drains, table rebuilt
+        if k == 33:
+            assert a.BeatriceBatch_ResetStream(h, 2 % B) == 0                 # fresh state for one stream
+        if k == 41:
+            a.BeatriceBatch_SetMinSourcePitch(h, 0, 50.0)
+            a.BeatriceBatch_SetPitchCorrection(h, 1 % B, 0.6)
+
+    total = steps + tail_steps
+    audio_all = np.concatenate([audio, audio[:, :160 * tail_steps]], axis=1)
+    ref_batch = bv.Batch(m, B)
+    settings(ref_batch)
+    ref = []
+    for k in range(total):
+        change(ref_batch, k)
+        ref.append(ref_batch.convert(audio_all[:, k * 160:(k + 1) * 160]))
+    ref = np.stack(ref)
+    ref_q = ref_batch.intermediates()[1].copy()
+    ref_batch.close()
+
+    batch = bv.Batch(m, B)
+    settings(batch)
+    a, h = batch.a, batch.h
+    stages = a.BeatriceBatch_TickStages(h)
+    slots = stages + 6
+    d_in, d_out = hip.malloc(slots * B * 160 * 4), hip.malloc(slots * B * 240 * 4)
+    assert a.BeatriceBatch_EnableTickPipeline(h, 1) == -1          # needs resident I/O
+    assert a.BeatriceBatch_BindResidentIO(h, d_in, d_out, slots) == 0
+    assert a.BeatriceBatch_EnableTickPipeline(h, 1) == 0
+    assert a.BeatriceBatch_EnablePipelining(h, 2) == -1
+    got = np.zeros_like(ref)
+    k0 = 0
+    for chunk in (slots, 7, slots - 3, 10 ** 9):     # fill slots, feed without waiting, drain, read back; wraps around
+        n = min(chunk, steps - k0)
+        if n <= 0:
+            break
+        buf = np.zeros((slots, B, 160), np.float32)
+        hip.d2h(buf, d_in)
+        for k in range(k0, k0 + n):
+            buf[k % slots] = audio_all[:, k * 160:(k + 1) * 160]
+        hip.h2d(d_in, buf)
+        for k in range(k0, k0 + n):
+            change(batch, k)
+            assert a.BeatriceBatch_ConvertFramesDevice(h, None, None) == 0
+        assert a.BeatriceBatch_Synchronize(h) == 0
+        out = np.zeros((slots, B, 240), np.float32)
+        hip.d2h(out, d_out)
+        for k in range(k0, k0 + n):
+            got[k] = out[k % slots]
+        k0 += n
+    assert k0 == steps
+    # back to the in-order chain: same streams, same slots, state carried over
+    assert a.BeatriceBatch_EnableTickPipeline(h, 0) == 0
+    buf = np.zeros((slots, B, 160), np.float32)
+    for k in range(steps, total):
+        buf[k % slots] = audio_all[:, k * 160:(k + 1) * 160]
+    hip.h2d(d_in, buf)
+    for k in range(steps, total):
+        change(batch, k)
+        assert a.BeatriceBatch_ConvertFramesDevice(h, None, None) == 0
+    assert a.BeatriceBatch_Synchronize(h) == 0
+    out = np.zeros((slots, B, 240), np.float32)
+    hip.d2h(out, d_out)
+    for k in range(steps, total):
+        got[k] = out[k % slots]
+    q = batch.intermediates()[1]
+    batch.close()
+    m.close()
+    hip.free(d_in); hip.free(d_out)
+    bad = [k for k in range(total) if not np.array_equal(ref[k], got[k])]
+    print("tick pipeline B=%d, %d stages, %d steps: %s" % (B, stages, steps, "bit-identical" if not bad else
+                                                          "steps that differ: %s, max-abs %g" % (bad[:12], np.abs(ref - got).max())))
+    assert np.abs(got).max() > 0.05
+    assert not bad
+    assert np.array_equal(q, ref_q)
