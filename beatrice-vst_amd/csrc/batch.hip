@@ -470,6 +470,7 @@ bool tick_build_table(BeatriceBatch* b) {
   using namespace tick;
   State& k = b->tk;
   auto tb = std::make_unique<Builder>();
+  auto ab = std::make_unique<AuxBuilder>();
   const PhoneWeights& pw = b->phone_m->w;
   const PitchWeights& qw = b->pitch_m->w;
   const WaveWeights& ww = b->wave_m->w;
@@ -477,64 +478,75 @@ bool tick_build_table(BeatriceBatch* b) {
   const PitchState& qs = b->pitch;
   const WaveState& ws = b->wave;
   const int B = b->B;
+  // measurement aid: BEATRICE_HIP_TICK_DROP=<bit mask> leaves groups of bodies out of the main launch (results are then
+  // meaningless; only the launch's duration is of interest): 1 content encoder convs, 2 pitch estimator, 4 block linears,
+  // 8 attention, 16 upsampler convs, 32 f1 / cond / inp
+  static const int drop = std::getenv("BEATRICE_HIP_TICK_DROP") ? std::atoi(std::getenv("BEATRICE_HIP_TICK_DROP")) : 0;
   auto hp = [&](int stage) { return k.d_hops + 2 * stage; };
   auto conv = [&](const Ring& in, const Ring& out, const float* w, const float* bias, int stage) { return conv_args(in, out, w, bias, hp(stage), B); };
   // content encoder (the layers with the longest reductions first: they are the longest-running workgroups)
-  for (int i = 0; i < 4; ++i) {
+  if (!(drop & 1)) for (int i = 0; i < 4; ++i) {
     const ConvArgs a = conv(i == 0 ? ps.f[4] : ps.rb[i - 1], ps.rb[i], pw.rb_w[i], pw.rb_b[i], S_RB0 + i);
-    tb->add<T_RB>(CT<PL::RBL>::info("phone.rb", a), a, CT<PL::RBL>::grid(a));
+    tb->add<T_RB>(CT<PL::RBL>::info("phone.rb", a), a, CT<PL::RBL>::grid(a), true, CT<PL::RBL>::wg_cost());
   }
-  { const ConvArgs a = conv(qs.spec, qs.p[0], qw.p_w[0], qw.p_b[0], S_P1); tb->add<T_P1>(CT<QL1::P1>::info("pitch.p1", a), a, CT<QL1::P1>::grid(a)); }
-  { const ConvArgs a = conv(ps.f[2], ps.f[3], pw.f_w[2], pw.f_b[2], S_F4); tb->add<T_F4>(CT<PL::F4>::info("phone.f4", a), a, CT<PL::F4>::grid(a)); }
-  { const ConvArgs a = conv(ps.f[3], ps.f[4], pw.f_w[3], pw.f_b[3], S_F5); tb->add<T_F5>(CT<PL::F5>::info("phone.f5", a), a, CT<PL::F5>::grid(a)); }
-  { const ConvArgs a = conv(ps.f[0], ps.f[1], pw.f_w[0], pw.f_b[0], S_F2); tb->add<T_F2>(CT<PL::F2>::info("phone.f2", a), a, CT<PL::F2>::grid(a)); }
-  { const ConvArgs a = conv(ps.f[1], ps.f[2], pw.f_w[1], pw.f_b[1], S_F3); tb->add<T_F3>(CT<PL::F3>::info("phone.f3", a), a, CT<PL::F3>::grid(a)); }
-  { F1Args a = f1_args(pw, ps); a.hop = hp(S_F1); a.hop_publish = nullptr; a.hop_publish_wave = nullptr; tb->add<T_F1>(f1_info(ps), a, dim3(B, 1)); }
-  { FftArgs a = fft_args(qw, qs); a.hop = hp(S_FFT); tb->add<T_FFT>(fft_info(qs), a, dim3(B, 1)); }
-  for (int i = 0; i < 2; ++i) {
+  if (!(drop & 2)) { const ConvArgs a = conv(qs.spec, qs.p[0], qw.p_w[0], qw.p_b[0], S_P1); tb->add<T_P1>(CT<QL1::P1>::info("pitch.p1", a), a, CT<QL1::P1>::grid(a), true, CT<QL1::P1>::wg_cost()); }
+  if (!(drop & 1)) { const ConvArgs a = conv(ps.f[2], ps.f[3], pw.f_w[2], pw.f_b[2], S_F4); tb->add<T_F4>(CT<PL::F4>::info("phone.f4", a), a, CT<PL::F4>::grid(a), true, CT<PL::F4>::wg_cost()); }
+  if (!(drop & 1)) { const ConvArgs a = conv(ps.f[3], ps.f[4], pw.f_w[3], pw.f_b[3], S_F5); tb->add<T_F5>(CT<PL::F5>::info("phone.f5", a), a, CT<PL::F5>::grid(a), true, CT<PL::F5>::wg_cost()); }
+  if (!(drop & 1)) { const ConvArgs a = conv(ps.f[0], ps.f[1], pw.f_w[0], pw.f_b[0], S_F2); tb->add<T_F2>(CT<PL::F2>::info("phone.f2", a), a, CT<PL::F2>::grid(a), true, CT<PL::F2>::wg_cost()); }
+  if (!(drop & 1)) { const ConvArgs a = conv(ps.f[1], ps.f[2], pw.f_w[1], pw.f_b[1], S_F3); tb->add<T_F3>(CT<PL::F3>::info("phone.f3", a), a, CT<PL::F3>::grid(a), true, CT<PL::F3>::wg_cost()); }
+  if (!(drop & 32)) { F1Args a = f1_args(pw, ps); a.hop = hp(S_F1); a.hop_publish = nullptr; a.hop_publish_wave = nullptr; tb->add<T_F1>(f1_info(ps), a, dim3(B, 1), true, 3.0); }
+  if (!(drop & 2)) { FftArgs a = fft_args(qw, qs); a.hop = hp(S_FFT); tb->add<T_FFT>(fft_info(qs), a, dim3(B, 1), true, 4.0); }
+  if (!(drop & 2)) for (int i = 0; i < 2; ++i) {
     const ConvArgs a = conv(qs.p[i], qs.p[i + 1], qw.p_w[i + 1], qw.p_b[i + 1], S_P2 + i);
-    tb->add<T_P23>(CT<QL1::P23>::info("pitch.p23", a), a, CT<QL1::P23>::grid(a));
+    tb->add<T_P23>(CT<QL1::P23>::info("pitch.p23", a), a, CT<QL1::P23>::grid(a), true, CT<QL1::P23>::wg_cost());
   }
-  { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(S_QGRU), B, 0}; tb->add<T_QGRU>(GruOp<128, 128>::info("pitch.gru", g), g, GruOp<128, 128>::grid(g)); }
-  { const ConvArgs a = conv(qs.h, qs.logits, qw.out_w, qw.out_b, S_POUT); tb->add<T_POUT>(CT<QL1::POUT>::info("pitch.out", a), a, CT<QL1::POUT>::grid(a)); }
-  { const GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(S_PGRU), B, 0}; tb->add<T_PGRU>(GruOp<256, 256>::info("phone.gru", g), g, GruOp<256, 256>::grid(g)); }
-  { PitchHeadArgs a = head_args(qw, qs); a.hop = hp(S_HEAD); tb->add<T_HEAD>(head_info(qs), a, dim3(B, 1)); }
-  { const ConvArgs a = conv(ps.h, phone_out_ring(ps), pw.out_w, pw.out_b, S_OUT); tb->add<T_OUT>(CT<PL::OUTL>::info("phone.out", a), a, CT<PL::OUTL>::grid(a)); }
-  { CondArgs a = cond_args(ww, ws); a.hop = hp(S_COND); a.hop_next_out = nullptr; tb->add<T_COND>(cond_info(ws), a, dim3(B, 1)); }
-  { const VqArgs a{1, ps.raw, phone_vector_ring(ps), hp(S_VQ), ps.d_cbT, ps.d_cnorm, ps.d_vqk}; tb->add<T_VQ>(LaunchInfo{"phone.vq", 0, 4.0 * B * 256}, a, dim3(B, 1), !ps.skip_vq); }
+  { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(S_QGRU), B, 0}; ab->add<A_QGRU>(GruOp<128, 128>::info("pitch.gru", g), g, GruOp<128, 128>::grid(g)); }
+  if (!(drop & 2)) { const ConvArgs a = conv(qs.h, qs.logits, qw.out_w, qw.out_b, S_POUT); tb->add<T_POUT>(CT<QL1::POUT>::info("pitch.out", a), a, CT<QL1::POUT>::grid(a), true, CT<QL1::POUT>::wg_cost()); }
+  { const GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(S_PGRU), B, 0}; ab->add<A_PGRU>(GruOp<256, 256>::info("phone.gru", g), g, GruOp<256, 256>::grid(g)); }
+  if (!(drop & 2)) { PitchHeadArgs a = head_args(qw, qs); a.hop = hp(S_HEAD); tb->add<T_HEAD>(head_info(qs), a, dim3(B, 1), true, 2.0); }
+  if (!(drop & 1)) { const ConvArgs a = conv(ps.h, phone_out_ring(ps), pw.out_w, pw.out_b, S_OUT); tb->add<T_OUT>(CT<PL::OUTL>::info("phone.out", a), a, CT<PL::OUTL>::grid(a), true, CT<PL::OUTL>::wg_cost()); }
+  if (!(drop & 32)) { CondArgs a = cond_args(ww, ws); a.hop = hp(S_COND); a.hop_next_out = nullptr; tb->add<T_COND>(cond_info(ws), a, dim3(B, 1), true, 2.0); }
+  { const VqArgs a{1, ps.raw, phone_vector_ring(ps), hp(S_VQ), ps.d_cbT, ps.d_cnorm, ps.d_vqk}; ab->add<A_VQ>(LaunchInfo{"phone.vq", 0, 4.0 * B * 256}, a, dim3(B, 1), !ps.skip_vq); }
   // waveform generator
-  { const Ring phone_in{ws.d_phone, B_PHONE_CH, 1, ws.front_slots}; ConvArgs a = conv(phone_in, ws.x[0], ww.inp_w, ww.inp_b, S_INP); a.res = ws.e; tb->add<T_INP>(CT<INP<1>>::info("wave.inp", a), a, CT<INP<1>>::grid(a)); }
+  if (!(drop & 32)) { const Ring phone_in{ws.d_phone, B_PHONE_CH, 1, ws.front_slots}; ConvArgs a = conv(phone_in, ws.x[0], ww.inp_w, ww.inp_b, S_INP); a.res = ws.e; tb->add<T_INP>(CT<INP<1>>::info("wave.inp", a), a, CT<INP<1>>::grid(a), true, CT<INP<1>>::wg_cost()); }
   for (int blk = 0; blk < B_NBLOCKS; ++blk) {
     const WaveState::Scratch& sc = ws.scr[blk];  // one scratch set per block: all four blocks are in flight at once
     const int s0 = S_BLK0 + 6 * blk;
-    { const ConvArgs a = conv(ws.x[blk], sc.h1, ww.c1_w[blk], ww.c1_b[blk], s0);
+    if (!(drop & 4)) { const ConvArgs a = conv(ws.x[blk], sc.h1, ww.c1_w[blk], ww.c1_b[blk], s0);
       switch (blk) {
-        case 0: tb->add<T_C1D1>(CT<C1<1, 1>>::info("wave.blk.c1", a), a, CT<C1<1, 1>>::grid(a)); break;
-        case 1: tb->add<T_C1D2>(CT<C1<2, 1>>::info("wave.blk.c1", a), a, CT<C1<2, 1>>::grid(a)); break;
-        case 2: tb->add<T_C1D4>(CT<C1<4, 1>>::info("wave.blk.c1", a), a, CT<C1<4, 1>>::grid(a)); break;
-        default: tb->add<T_C1D8>(CT<C1<8, 1>>::info("wave.blk.c1", a), a, CT<C1<8, 1>>::grid(a)); break;
+        case 0: tb->add<T_C1D1>(CT<C1<1, 1>>::info("wave.blk.c1", a), a, CT<C1<1, 1>>::grid(a), true, CT<C1<1, 1>>::wg_cost()); break;
+        case 1: tb->add<T_C1D2>(CT<C1<2, 1>>::info("wave.blk.c1", a), a, CT<C1<2, 1>>::grid(a), true, CT<C1<2, 1>>::wg_cost()); break;
+        case 2: tb->add<T_C1D4>(CT<C1<4, 1>>::info("wave.blk.c1", a), a, CT<C1<4, 1>>::grid(a), true, CT<C1<4, 1>>::wg_cost()); break;
+        default: tb->add<T_C1D8>(CT<C1<8, 1>>::info("wave.blk.c1", a), a, CT<C1<8, 1>>::grid(a), true, CT<C1<8, 1>>::wg_cost()); break;
       } }
-    { ConvArgs a = conv(sc.h1, sc.xa, ww.c2_w[blk], ww.c2_b[blk], s0 + 1); a.res = ws.x[blk]; tb->add<T_C2>(CT<C2<1>>::info("wave.blk.c2o", a), a, CT<C2<1>>::grid(a)); }
-    { const ConvArgs a = conv(sc.xa, sc.q, ww.q_w[blk], ww.q_b[blk], s0 + 2); tb->add<T_Q>(CT<QL<1>>::info("wave.blk.q", a), a, CT<QL<1>>::grid(a)); }
+    if (!(drop & 4)) { ConvArgs a = conv(sc.h1, sc.xa, ww.c2_w[blk], ww.c2_b[blk], s0 + 1); a.res = ws.x[blk]; tb->add<T_C2>(CT<C2<1>>::info("wave.blk.c2o", a), a, CT<C2<1>>::grid(a), true, CT<C2<1>>::wg_cost()); }
+    if (!(drop & 4)) { const ConvArgs a = conv(sc.xa, sc.q, ww.q_w[blk], ww.q_b[blk], s0 + 2); tb->add<T_Q>(CT<QL<1>>::info("wave.blk.q", a), a, CT<QL<1>>::grid(a), true, CT<QL<1>>::wg_cost()); }
     // the two attention kernels read the tile lists: private copies 0 (scores) and 1 (softmax . V) of the block's lists
     int* perm[2]; int* slot[2];
     for (int c = 0; c < 2; ++c) {
       perm[c] = b->dev_view<int>(b->off.perm[blk] + (size_t)c * b->off.wave_bytes);
       slot[c] = b->dev_view<int>(b->off.tile_slot[blk] + (size_t)c * b->off.wave_bytes);
     }
-    { ConvArgs a = conv(sc.q, sc.sc, ws.d_kt[blk], nullptr, s0 + 3); a.scale = 0.0625f; a.perm = perm[0]; a.tile_slot = slot[0]; a.w_slot_stride = (size_t)B_HID * B_KV_LEN;
-      tb->add<T_SCORE>(ConvOp<SCORE<1>, TGQ>::info("wave.blk.attn_qk", a), a, ConvOp<SCORE<1>, TGQ>::grid(a, ws.n_tiles_max)); }
-    { const AttnPvArgs a{sc.sc, ws.d_v[blk], sc.o, perm[1], slot[1], hp(s0 + 4)};
-      tb->add<T_PV>(LaunchInfo{"wave.blk.attn_pv", 2.0 * B * 384 * 256 + 25.0 * B * 384, 4.0 * (384.0 * 256 + B * (384 + 256))}, a, dim3(ws.n_tiles_max, B_HID / 32)); }
-    { ConvArgs a = conv(sc.o, ws.x[blk + 1], ww.o_w[blk], ww.o_b[blk], s0 + 5); a.res = sc.xa; tb->add<T_C2>(CT<C2<1>>::info("wave.blk.c2o", a), a, CT<C2<1>>::grid(a)); }
+    if (!(drop & 8)) { ConvArgs a = conv(sc.q, sc.sc, ws.d_kt[blk], nullptr, s0 + 3); a.scale = 0.0625f; a.perm = perm[0]; a.tile_slot = slot[0]; a.w_slot_stride = (size_t)B_HID * B_KV_LEN;
+      tb->add<T_SCORE>(CT<SCORE<1>>::info("wave.blk.attn_qk", a), a, CT<SCORE<1>>::grid(a, ws.n_tiles_max), true, CT<SCORE<1>>::wg_cost()); }
+    if (!(drop & 8)) { const AttnPvArgs a{sc.sc, ws.d_v[blk], sc.o, perm[1], slot[1], hp(s0 + 4)};
+      tb->add<T_PV>(LaunchInfo{"wave.blk.attn_pv", 2.0 * B * 384 * 256 + 25.0 * B * 384, 4.0 * (384.0 * 256 + B * (384 + 256))}, a, dim3(ws.n_tiles_max, B_HID / 32), true, 4.0); }
+    if (!(drop & 4)) { ConvArgs a = conv(sc.o, ws.x[blk + 1], ww.o_w[blk], ww.o_b[blk], s0 + 5); a.res = sc.xa; tb->add<T_C2>(CT<C2<1>>::info("wave.blk.c2o", a), a, CT<C2<1>>::grid(a), true, CT<C2<1>>::wg_cost()); }
   }
-  { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], S_UP1); tb->add<T_UP1>(CT<UP<256, 128, 5, 1>>::info("wave.up1", a), a, CT<UP<256, 128, 5, 1>>::grid(a)); }
-  { const ConvArgs a = conv(ws.ya1, ws.yb1, ww.ra_w[0], ww.ra_b[0], S_RES1A); tb->add<T_RES1A>(CT<RES<128, 1, 5>>::info("wave.res1a", a), a, CT<RES<128, 1, 5>>::grid(a)); }
-  { const ConvArgs a = conv(ws.yb1, ws.yc1, ww.rb_w[0], ww.rb_b[0], S_RES1B); tb->add<T_RES1B>(CT<RES<128, 3, 5>>::info("wave.res1b", a), a, CT<RES<128, 3, 5>>::grid(a)); }
-  { const ConvArgs a = conv(ws.yc1, ws.ya2, ww.up_w[1], ww.up_b[1], S_UP2); tb->add<T_UP2>(CT<UP<128, 64, 4, 5>>::info("wave.up2", a), a, CT<UP<128, 64, 4, 5>>::grid(a)); }
-  if (!tb->ok) return false;
+  if (!(drop & 16)) { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], S_UP1); tb->add<T_UP1>(CT<UP<256, 128, 5, 1>>::info("wave.up1", a), a, CT<UP<256, 128, 5, 1>>::grid(a), true, CT<UP<256, 128, 5, 1>>::wg_cost()); }
+  if (!(drop & 16)) { const ConvArgs a = conv(ws.ya1, ws.yb1, ww.ra_w[0], ww.ra_b[0], S_RES1A); tb->add<T_RES1A>(CT<RES<128, 1, 5>>::info("wave.res1a", a), a, CT<RES<128, 1, 5>>::grid(a), true, CT<RES<128, 1, 5>>::wg_cost()); }
+  if (!(drop & 16)) { const ConvArgs a = conv(ws.yb1, ws.yc1, ww.rb_w[0], ww.rb_b[0], S_RES1B); tb->add<T_RES1B>(CT<RES<128, 3, 5>>::info("wave.res1b", a), a, CT<RES<128, 3, 5>>::grid(a), true, CT<RES<128, 3, 5>>::wg_cost()); }
+  if (!(drop & 16)) { const ConvArgs a = conv(ws.yc1, ws.ya2, ww.up_w[1], ww.up_b[1], S_UP2); tb->add<T_UP2>(CT<UP<128, 64, 4, 5>>::info("wave.up2", a), a, CT<UP<128, 64, 4, 5>>::grid(a), true, CT<UP<128, 64, 4, 5>>::wg_cost()); }
+  if (!tb->ok || !ab->ok) return false;
+  // XCD-aware placement (every body's workgroups on ONE XCD, so that its weights stay in that XCD's L2) cuts the launch's
+  // memory-side traffic from 105 MB to 26 MB per tick (rocprofv3 FETCH_SIZE) but not its duration (0.114 vs 0.106 ms per
+  // tick: the launch is bound by per-workgroup latencies, and confining a body to 32 CUs lengthens the tail): off by default
+  static const bool by_xcd = std::getenv("BEATRICE_HIP_TICK_XCD") != nullptr;
+  if (by_xcd) tb->place_by_xcd();
   BHIP_TRY(hipMemcpy(k.d_table, &tb->t, sizeof(Tab), hipMemcpyHostToDevice));
+  BHIP_TRY(hipMemcpy(k.d_aux, &ab->t, sizeof(AuxTab), hipMemcpyHostToDevice));
   k.table_total = tb->t.total;
+  k.aux_total = ab->t.total;
   k.tail = tail_args(ww, ws);
   k.tail.hop = hp(S_TAIL);
   // who reads which part of the settings block, and where its private copy lives
@@ -604,6 +616,7 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
   }
   hipLaunchKernelGGL(prologue_kernel, dim3(1 + p.n_copies), dim3(256), 0, st, k.d_hops, p);
   fuse::launch_table(k.d_table, k.table_total, st);
+  fuse::launch_table(k.d_aux, k.aux_total, st);
   hipLaunchKernelGGL(wave_tail_kernel<1>, dim3(b->B), dim3(tail::NTHR), 0, st, k.tail);
   if (feeding) {
     b->last_parity = b->hop_host % 3;
@@ -638,6 +651,7 @@ int tick_enable(BeatriceBatch* b, bool on) {
     if (!k.d_hops) {
       if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_hops), sizeof(int) * 2 * kMaxStages), "tick hops") ||
           !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_table), sizeof(Tab)), "tick table") ||
+          !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_aux), sizeof(AuxTab)), "tick aux table") ||
           !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_snap), k.snap_bytes * kRing), "tick snapshots"))
         return -2;
     }
@@ -872,7 +886,7 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   if (!b) return;
   if (b->stream) (void)sync_all(b);
   drop_graph(b);
-  { void* tk[] = {b->tk.d_hops, b->tk.d_table, b->tk.d_snap}; for (void* p : tk) if (p) (void)hipFree(p); }
+  { void* tk[] = {b->tk.d_hops, b->tk.d_table, b->tk.d_aux, b->tk.d_snap}; for (void* p : tk) if (p) (void)hipFree(p); }
   if (b->own_d_out) { b->wave.d_out = b->own_d_out; b->own_d_out = nullptr; }
   if (b->module_owned[0]) {  // hand the modules their own arrays back so that destroy() frees what it allocated
     void** keep = b->module_owned;
@@ -1109,7 +1123,7 @@ int BeatriceBatch_ResetStream(BeatriceBatch* b, int stream) {
   if (!b || !b->ok) return -2;
   if (stream < -1 || stream >= b->B) return -1;
   const int lo = stream < 0 ? 0 : stream, hi = stream < 0 ? b->B : stream + 1;
-  bool ok = !b->pipelined || sync_all(b);  // the waveform generator of the last step may still be running on its own stream
+  bool ok = !(b->pipelined || b->tk.on) || sync_all(b);  // later stages of earlier steps may still be running (own streams / later ticks)
   for (int s = lo; s < hi && ok; ++s) {
     ok = b->phone.arena.zero_stream(s, b->stream) && b->pitch.arena.zero_stream(s, b->stream) &&
          b->wave.arena.zero_stream(s, b->stream) &&

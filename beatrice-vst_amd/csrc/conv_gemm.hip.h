@@ -79,9 +79,12 @@ struct Layer {
 // LK == 1: one group walks all segments into separate accumulators (throughput layers);
 // LK == P: group g owns segment g, partial tiles are combined through LDS in segment order
 //          (latency layers: the dependent MFMA chain is one segment, not K, long).
-template <int WM_, int WN_, int LM_, int LN_, int LK_ = 1>
+// KFEW_: the few-row tiling (MT == 16) stages 128-wide k-chunks where the layer allows (half the barriers on a
+// latency-bound chain); false = 64-wide chunks, which needs ~50 fewer registers (tick launches want occupancy instead)
+template <int WM_, int WN_, int LM_, int LN_, int LK_ = 1, bool KFEW_ = true>
 struct TileCfg {
   static constexpr int WM = WM_, WN = WN_, LM = LM_, LN = LN_, LK = LK_;
+  static constexpr bool KFEW = KFEW_;
   static constexpr int MT = 16 * WM * LM, NT = 16 * WN * LN;
   static constexpr int GTHR = 64 * LM * LN;  // threads per k-group
   static constexpr int NTHR = GTHR * LK;
@@ -90,7 +93,7 @@ struct TileCfg {
 // LDS the body needs (floats): the staged A chunk of every k-group, re-used for the segment combine
 template <class L, class TC>
 constexpr int conv_lds_floats() {
-  constexpr int KC = TC::MT == 16 ? L::KC_FEW : L::KC;
+  constexpr int KC = (TC::MT == 16 && TC::KFEW) ? L::KC_FEW : L::KC;
   constexpr int stage = TC::MT * (KC + 2) * TC::LK, red = TC::LK > 1 ? L::P * TC::MT * TC::NT : 0;
   return stage > red ? stage : red;
 }
@@ -99,7 +102,7 @@ constexpr int conv_lds_floats() {
 // one launch (fuse.hip.h); conv_gemm_kernel below is the plain one-layer launch.
 template <class L, class TC>
 __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bx, const int by, float* __restrict__ lds) {
-  constexpr int KC = TC::MT == 16 ? L::KC_FEW : L::KC;
+  constexpr int KC = (TC::MT == 16 && TC::KFEW) ? L::KC_FEW : L::KC;
   constexpr int NCHUNK = L::K / KC, CHUNKS_PER_SEG = L::SEG / KC;
   constexpr int AS = KC + 2, MT = TC::MT, NT = TC::NT, GTHR = TC::GTHR, LK = TC::LK;
   constexpr int P = L::P;
@@ -420,6 +423,8 @@ struct ConvOp {
     const double in_rows = (double)a.B * (L::T * L::STRIDE + (L::KSZ - 1) * L::DIL - (L::STRIDE - 1));
     return bhip::LaunchInfo{name, 2.0 * M * K * N, 4.0 * (K * N + in_rows * L::CIN + M * N * (L::RES ? 2 : 1))};
   }
+  // relative time of one workgroup: a fixed part (launch, operand latency) + its dependent MFMA chain (microseconds, roughly)
+  static constexpr double wg_cost() { return 2.0 + (double)(L::K / 4) * TC::WM * TC::WN / TC::LK * (40.0 / 2400.0); }
   __device__ static __forceinline__ void run(const ConvArgs& a, int bx, int by, float* lds) { conv_gemm_body<L, TC>(a, bx, by, lds); }
 };
 

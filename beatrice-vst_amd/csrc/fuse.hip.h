@@ -116,9 +116,8 @@ struct Banks<M, Rest...> {
 };
 template <class... Ms>
 struct Table {
-  int n_spans, total;
-  int first[kMaxSpans];
-  Span span[kMaxSpans];
+  int n_spans, total, per_xcd, pad;  // per_xcd > 0: XCD-aware layout, see TableBuilder::place_by_xcd
+  Span span[kMaxSpans];  // 16 bytes each: a wavefront fetches all of them with one load, lane i = body i
   Banks<Ms...> banks;
 };
 template <class... Ms> struct MaxM;
@@ -142,10 +141,17 @@ __device__ __forceinline__ void run_type(const Banks<M, Rest...>& b, const Span&
 template <class... Ms>
 __global__ __launch_bounds__(MaxM<Ms...>::NTHR) void table_kernel(const Table<Ms...>* __restrict__ t) {
   __shared__ __attribute__((aligned(16))) float lds[MaxM<Ms...>::LDS > 0 ? MaxM<Ms...>::LDS : 1];
-  const int id = blockIdx.x, lane = threadIdx.x & 63;
-  const int f = lane < t->n_spans ? t->first[lane] : 0x7fffffff;
-  const int idx = __builtin_amdgcn_readfirstlane(__popcll(__ballot(f <= id)) - 1);
-  const Span sp = t->span[idx];
+  const int lane = threadIdx.x & 63;
+  // XCD-aware layout: workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only), and the table gives
+  // every XCD its own contiguous run of body indices, so that a body's weights are fetched into ONE XCD's L2 and stay there
+  const int per = t->per_xcd;
+  const int id = per > 0 ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  // (unused entries hold first = INT_MAX)
+  const int4 mine = reinterpret_cast<const int4*>(t->span)[lane];
+  const int idx = __popcll(__ballot(mine.x <= id)) - 1;
+  Span sp;
+  sp.first = __builtin_amdgcn_readlane(mine.x, idx); sp.gx = __builtin_amdgcn_readlane(mine.y, idx);
+  sp.type = __builtin_amdgcn_readlane(mine.z, idx); sp.arg = __builtin_amdgcn_readlane(mine.w, idx);
   run_type<0, MaxM<Ms...>::NTHR, Ms...>(t->banks, sp, id - sp.first, lds);
 }
 
@@ -168,17 +174,64 @@ template <class... Ms>
 struct TableBuilder {
   Table<Ms...> t{};
   int used[sizeof...(Ms)] = {};
+  double cost[kMaxSpans] = {};  // estimated time of the body's workgroups (relative), for place_by_xcd
+  int n_wg[kMaxSpans] = {};
+  TableBuilder() { for (Span& sp : t.span) sp = Span{0x7fffffff, 1, -1, 0}; }
+  // Re-lays the bodies out for an 8-XCD chip: bodies are assigned whole to XCDs (longest first, to the XCD with the
+  // least work so far), XCD x owns the index range [x * per_xcd, (x + 1) * per_xcd), padded with indices that do
+  // nothing.  Launch 8 * per_xcd workgroups.  Every XCD then touches only its own bodies' weights.
+  void place_by_xcd() {
+    const int n = t.n_spans;
+    if (n == 0 || n + 8 > kMaxSpans) return;
+    int order[kMaxSpans];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    for (int i = 0; i < n; ++i)
+      for (int j = i + 1; j < n; ++j)
+        if (cost[order[j]] > cost[order[i]]) { const int x = order[i]; order[i] = order[j]; order[j] = x; }
+    double load[8] = {};
+    int len[8] = {}, owner[kMaxSpans];
+    for (int oi = 0; oi < n; ++oi) {
+      int best = 0;
+      for (int x = 1; x < 8; ++x) if (load[x] < load[best]) best = x;
+      owner[order[oi]] = best;
+      load[best] += cost[order[oi]];
+      len[best] += n_wg[order[oi]];
+    }
+    int per = 1;
+    for (int x = 0; x < 8; ++x) per = len[x] > per ? len[x] : per;
+    Span old[kMaxSpans];
+    for (int i = 0; i < n; ++i) old[i] = t.span[i];
+    int out = 0;
+    for (int x = 0; x < 8; ++x) {
+      int at = x * per;
+      for (int oi = 0; oi < n; ++oi) {   // longest bodies first inside an XCD too
+        const int i = order[oi];
+        if (owner[i] != x) continue;
+        t.span[out] = old[i];
+        t.span[out].first = at;
+        at += n_wg[i];
+        ++out;
+      }
+      if (at < (x + 1) * per) t.span[out++] = Span{at, 1, -1, 0};  // filler: these indices exit at once
+    }
+    for (int i = out; i < kMaxSpans; ++i) t.span[i] = Span{0x7fffffff, 1, -1, 0};
+    t.n_spans = out;
+    t.per_xcd = per;
+    t.total = 8 * per;
+  }
   bool ok = true;
   double flops = 0, bytes = 0;
   template <int I, class Args>
-  void add(const bhip::LaunchInfo& info, const Args& a, dim3 grid, bool on = true) {
+  void add(const bhip::LaunchInfo& info, const Args& a, dim3 grid, bool on = true, double wg_cost = 1.0) {
     if (!on) return;
     using BA = BankAt<I, Banks<Ms...>>;
     if (t.n_spans >= kMaxSpans || used[I] >= BA::cap) { ok = false; return; }
     BA::get(t.banks)[used[I]] = a;
     Span& sp = t.span[t.n_spans];
     sp.first = t.total; sp.gx = (int)grid.x > 0 ? (int)grid.x : 1; sp.type = I; sp.arg = used[I]++;
-    t.first[t.n_spans++] = t.total;
+    n_wg[t.n_spans] = (int)(grid.x * grid.y);
+    cost[t.n_spans] = wg_cost * n_wg[t.n_spans];
+    ++t.n_spans;
     t.total += (int)(grid.x * grid.y);
     flops += info.flops; bytes += info.bytes;
   }

@@ -50,36 +50,44 @@ static __global__ __launch_bounds__(256) void prologue_kernel(int* __restrict__ 
 
 using namespace bhip;
 using namespace wave_layers;
-// tilings of the tick launch: the few-row tiling with at most 512 threads per workgroup (one wavefront per
-// k-group where a layer has five or six reduction segments)
-template <class L> using TT = TileCfg<1, 1, 1, (L::P >= 5 ? 1 : 2), L::P>;
+// Tiling of the tick launches: 32 rows x 64 columns per workgroup, four wavefronts, each walking ALL reduction segments
+// of its column tile (one accumulator per segment, added in order): 256 threads and ~10-20 KB of LDS whatever the layer,
+// so several workgroups fit a CU at once -- a tick wants occupancy, not the shortest dependent chain.  Measured at 256
+// streams (ms per tick): 16x64 tiles 0.106, 32x64 0.104, 16x32 0.131, 128-wide k-chunks (152 VGPRs) 0.119.
+#ifndef TICK_KFEW
+#define TICK_KFEW false
+#endif
+#ifndef TICK_WM
+#define TICK_WM 2
+#endif
+#ifndef TICK_LN
+#define TICK_LN 4
+#endif
+template <class L> using TT = TileCfg<TICK_WM, 1, 1, TICK_LN, 1, TICK_KFEW>;
 template <class L> using CT = ConvOp<L, TT<L>>;
 using PL = PhoneLayers<1>;
 using QL1 = PitchLayers<1>;
 
+// main launch (256-thread workgroups)
 enum BodyType {
-  T_F1, T_FFT, T_F2, T_F3, T_F4, T_F5, T_P1, T_RB, T_P23, T_QGRU, T_POUT, T_PGRU, T_HEAD, T_OUT, T_COND, T_VQ, T_INP,
+  T_F1, T_FFT, T_F2, T_F3, T_F4, T_F5, T_P1, T_RB, T_P23, T_POUT, T_HEAD, T_OUT, T_COND, T_INP,
   T_C1D1, T_C1D2, T_C1D4, T_C1D8, T_C2, T_Q, T_SCORE, T_PV, T_UP1, T_RES1A, T_RES1B, T_UP2, T_COUNT
 };
-using Tab = fuse::Table<
-    fuse::Many<F1Op, 1>, fuse::Many<FftOp, 1>, fuse::Many<CT<PL::F2>, 1>, fuse::Many<CT<PL::F3>, 1>, fuse::Many<CT<PL::F4>, 1>,
-    fuse::Many<CT<PL::F5>, 1>, fuse::Many<CT<QL1::P1>, 1>, fuse::Many<CT<PL::RBL>, 4>, fuse::Many<CT<QL1::P23>, 2>,
-    fuse::Many<GruOp<128, 128>, 1>, fuse::Many<CT<QL1::POUT>, 1>, fuse::Many<GruOp<256, 256>, 1>, fuse::Many<HeadOp, 1>,
-    fuse::Many<CT<PL::OUTL>, 1>, fuse::Many<CondOp, 1>, fuse::Many<VqOp, 1>, fuse::Many<CT<INP<1>>, 1>,
-    fuse::Many<CT<C1<1, 1>>, 1>, fuse::Many<CT<C1<2, 1>>, 1>, fuse::Many<CT<C1<4, 1>>, 1>, fuse::Many<CT<C1<8, 1>>, 1>,
-    fuse::Many<CT<C2<1>>, 8>, fuse::Many<CT<QL<1>>, 4>, fuse::Many<ConvOp<SCORE<1>, TGQ>, 4>, fuse::Many<AttnPvOp, 4>,
-    fuse::Many<CT<UP<256, 128, 5, 1>>, 1>, fuse::Many<CT<RES<128, 1, 5>>, 1>, fuse::Many<CT<RES<128, 3, 5>>, 1>,
-    fuse::Many<CT<UP<128, 64, 4, 5>>, 1>>;
-using Builder = fuse::TableBuilder<
-    fuse::Many<F1Op, 1>, fuse::Many<FftOp, 1>, fuse::Many<CT<PL::F2>, 1>, fuse::Many<CT<PL::F3>, 1>, fuse::Many<CT<PL::F4>, 1>,
-    fuse::Many<CT<PL::F5>, 1>, fuse::Many<CT<QL1::P1>, 1>, fuse::Many<CT<PL::RBL>, 4>, fuse::Many<CT<QL1::P23>, 2>,
-    fuse::Many<GruOp<128, 128>, 1>, fuse::Many<CT<QL1::POUT>, 1>, fuse::Many<GruOp<256, 256>, 1>, fuse::Many<HeadOp, 1>,
-    fuse::Many<CT<PL::OUTL>, 1>, fuse::Many<CondOp, 1>, fuse::Many<VqOp, 1>, fuse::Many<CT<INP<1>>, 1>,
-    fuse::Many<CT<C1<1, 1>>, 1>, fuse::Many<CT<C1<2, 1>>, 1>, fuse::Many<CT<C1<4, 1>>, 1>, fuse::Many<CT<C1<8, 1>>, 1>,
-    fuse::Many<CT<C2<1>>, 8>, fuse::Many<CT<QL<1>>, 4>, fuse::Many<ConvOp<SCORE<1>, TGQ>, 4>, fuse::Many<AttnPvOp, 4>,
-    fuse::Many<CT<UP<256, 128, 5, 1>>, 1>, fuse::Many<CT<RES<128, 1, 5>>, 1>, fuse::Many<CT<RES<128, 3, 5>>, 1>,
-    fuse::Many<CT<UP<128, 64, 4, 5>>, 1>>;
-static_assert(sizeof(Tab) == sizeof(decltype(Builder::t)), "table types");
+#define TICK_MAIN_TYPES                                                                                                        \
+    fuse::Many<F1Op, 1>, fuse::Many<FftOp, 1>, fuse::Many<CT<PL::F2>, 1>, fuse::Many<CT<PL::F3>, 1>, fuse::Many<CT<PL::F4>, 1>, \
+    fuse::Many<CT<PL::F5>, 1>, fuse::Many<CT<QL1::P1>, 1>, fuse::Many<CT<PL::RBL>, 4>, fuse::Many<CT<QL1::P23>, 2>,            \
+    fuse::Many<CT<QL1::POUT>, 1>, fuse::Many<HeadOp, 1>, fuse::Many<CT<PL::OUTL>, 1>, fuse::Many<CondOp, 1>,                    \
+    fuse::Many<CT<INP<1>>, 1>, fuse::Many<CT<C1<1, 1>>, 1>, fuse::Many<CT<C1<2, 1>>, 1>, fuse::Many<CT<C1<4, 1>>, 1>,           \
+    fuse::Many<CT<C1<8, 1>>, 1>, fuse::Many<CT<C2<1>>, 8>, fuse::Many<CT<QL<1>>, 4>, fuse::Many<CT<SCORE<1>>, 4>,               \
+    fuse::Many<AttnPvOp, 4>, fuse::Many<CT<UP<256, 128, 5, 1>>, 1>, fuse::Many<CT<RES<128, 1, 5>>, 1>,                          \
+    fuse::Many<CT<RES<128, 3, 5>>, 1>, fuse::Many<CT<UP<128, 64, 4, 5>>, 1>
+using Tab = fuse::Table<TICK_MAIN_TYPES>;
+using Builder = fuse::TableBuilder<TICK_MAIN_TYPES>;
+// second launch: the bodies with larger workgroups (the two GRU cells: six wavefronts; k-NN: one thread per codebook row)
+enum AuxType { A_QGRU, A_PGRU, A_VQ };
+#define TICK_AUX_TYPES fuse::Many<GruOp<128, 128>, 1>, fuse::Many<GruOp<256, 256>, 1>, fuse::Many<VqOp, 1>
+using AuxTab = fuse::Table<TICK_AUX_TYPES>;
+using AuxBuilder = fuse::TableBuilder<TICK_AUX_TYPES>;
 
 // stage of each layer: the in-order chain's launch order, the pitch estimator zipped into the content encoder's
 // stages from the fourth launch on (its spectrum ring then has its reader one stage later, like every other ring)
@@ -101,7 +109,8 @@ struct State {
   bool on = false;
   int* d_hops = nullptr;            // [kMaxStages][2]
   Tab* d_table = nullptr;
-  int table_total = 0;
+  AuxTab* d_aux = nullptr;
+  int table_total = 0, aux_total = 0;
   bool table_dirty = true;
   unsigned char* d_snap = nullptr;  // [kRing][snap_bytes] settings snapshots
   size_t snap_bytes = 0;

@@ -296,6 +296,10 @@ def main():
     ap.add_argument("--pipeline-depth", type=int, default=4, choices=(0, 2, 3, 4),
                     help="BeatriceBatch_EnablePipelining: stages of the per-hop chain that overlap across consecutive steps "
                          "while steps are enqueued ahead (0 = off: one HIP stream, in order)")
+    ap.add_argument("--pipeline", choices=("tick", "stages", "off"), default="tick",
+                    help="how steps enqueued ahead of their completion overlap: tick = every layer its own pipeline stage, one "
+                         "launch per tick on one stream (BeatriceBatch_EnableTickPipeline); stages = --pipeline-depth stages on "
+                         "as many HIP streams; off = in order")
     ap.add_argument("--copy-io", action="store_true",
                     help="device-to-device copy of each hop into / out of the library's own buffers instead of "
                          "binding the resident audio buffers (BeatriceBatch_BindResidentIO)")
@@ -400,15 +404,21 @@ def main():
     resident = a.config != 4 and not a.copy_io
     d_out = torch.zeros((n_cycle if resident else 1, B, 240), dtype=torch.float32, device="cuda")
     base, hop_bytes = d_audio.data_ptr(), B * 160 * 4
-    pipelined = a.pipeline_depth if a.config != 4 else 0
-    if pipelined and product.BeatriceBatch_EnablePipelining(batch.h, pipelined):
-        print("bench: EnablePipelining(%d) refused, running in order" % pipelined, file=sys.stderr)
-        pipelined = 0
+    if a.config == 4 or a.pipeline == "off":
+        a.pipeline, a.pipeline_depth = "off", 0
+    pipelined = a.pipeline_depth if a.pipeline == "stages" else 0
     if resident:  # the 64 resident hops are the slots: every step reads one and writes one, no copy
         if product.BeatriceBatch_BindResidentIO(batch.h, d_audio.data_ptr(), d_out.data_ptr(), n_cycle):
             print("bench: BindResidentIO refused, copying each hop in and out", file=sys.stderr)
             resident = False
             d_out = torch.zeros((1, B, 240), dtype=torch.float32, device="cuda")
+    tick = a.pipeline == "tick"
+    if tick and (not resident or product.BeatriceBatch_EnableTickPipeline(batch.h, 1)):
+        print("bench: tick pipelining refused (needs resident I/O, <= 256 streams), using stage pipelining", file=sys.stderr)
+        tick, pipelined = False, a.pipeline_depth
+    if pipelined and product.BeatriceBatch_EnablePipelining(batch.h, pipelined):
+        print("bench: EnablePipelining(%d) refused, running in order" % pipelined, file=sys.stderr)
+        pipelined = 0
 
     if a.config == 4:  # 48 kHz stereo blocks, resident: [n_cycle][B][2][480]
         a48 = np.stack([np.stack([bv.synth_audio(480 * n_cycle, seed=rank * 100000 + 2 * s + c, sr=48000) for c in range(2)])
@@ -469,7 +479,10 @@ def main():
                                     4: "BASELINE.json configs[4] per-GPU share: %d streams of 48 kHz stereo, downmix + resample "
                                        "wrapper on the device, 480-sample blocks" % B}[a.config],
                        "streams_per_gpu": B, "speakers": a.speakers, "hipgraph": not a.no_graph,
-                       "pipelining": ("%d stages of the chain on %d HIP streams; stage s of step t+1 overlaps stage s+1 of step t, "
+                       "pipelining": ("tick: every layer of the chain its own pipeline stage (%d stages), one launch per tick on one HIP "
+                                      "stream, stage s works on the step fed s ticks earlier; steps enqueued without waiting; the timed "
+                                      "region includes the %d ticks that drain the pipeline" % (product.BeatriceBatch_TickStages(batch.h), product.BeatriceBatch_TickStages(batch.h) - 1)) if tick
+                                     else ("%d stages of the chain on %d HIP streams; stage s of step t+1 overlaps stage s+1 of step t, "
                                       "steps enqueued without waiting; GPU_MAX_HW_QUEUES=%s" % (pipelined, pipelined, os.environ.get("GPU_MAX_HW_QUEUES"))) if pipelined
                                      else "off: one stream, in order",
                        "io": "resident device buffers, 64 hops per stream cycled, bound as I/O slots (no per-step copy)" if resident
@@ -481,7 +494,9 @@ def main():
             "host_enqueue_ms_per_step": round(1e3 * enqueue_s / a.steps, 4),
         }
         if not a.no_extras:
-            # per-kernel timing with HIP events on the library's own stream (eager, 10 launches per bracket)
+            # per-kernel timing with HIP events on the library's own stream (eager, 10 launches per bracket), chain in order
+            if tick:
+                product.BeatriceBatch_EnableTickPipeline(batch.h, 0)
             rows = batch.profile_kernels(repeats=10)
             for r in rows:
                 r["total_us"] = r["mean_us"] * r["launches"]
