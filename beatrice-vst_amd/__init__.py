@@ -294,6 +294,7 @@ _BATCH = {
     "BeatriceBatch_GetWaveStream": (_vp, [_vp]),
     "BeatriceBatch_EnableTickPipeline": (C.c_int, [_vp, C.c_int]),
     "BeatriceBatch_TickStages": (C.c_int, [_vp]),
+    "BeatriceBatch_TimeTickLaunch": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "BeatriceBatch_Prepare": (C.c_int, [_vp]),
     "BeatriceBatch_DeviceInput": (_vp, [_vp]),
     "BeatriceBatch_DeviceOutput": (_vp, [_vp]),

@@ -470,7 +470,6 @@ bool tick_build_table(BeatriceBatch* b) {
   using namespace tick;
   State& k = b->tk;
   auto tb = std::make_unique<Builder>();
-  auto ab = std::make_unique<AuxBuilder>();
   const PhoneWeights& pw = b->phone_m->w;
   const PitchWeights& qw = b->pitch_m->w;
   const WaveWeights& ww = b->wave_m->w;
@@ -478,87 +477,82 @@ bool tick_build_table(BeatriceBatch* b) {
   const PitchState& qs = b->pitch;
   const WaveState& ws = b->wave;
   const int B = b->B;
-  // measurement aid: BEATRICE_HIP_TICK_DROP=<bit mask> leaves groups of bodies out of the main launch (results are then
-  // meaningless; only the launch's duration is of interest): 1 content encoder convs, 2 pitch estimator, 4 block linears,
-  // 8 attention, 16 upsampler convs, 32 f1 / cond / inp
-  static const int drop = std::getenv("BEATRICE_HIP_TICK_DROP") ? std::atoi(std::getenv("BEATRICE_HIP_TICK_DROP")) : 0;
+  const Plan pl = k.plan;
   auto hp = [&](int stage) { return k.d_hops + 2 * stage; };
   auto conv = [&](const Ring& in, const Ring& out, const float* w, const float* bias, int stage) { return conv_args(in, out, w, bias, hp(stage), B); };
-  // content encoder (the layers with the longest reductions first: they are the longest-running workgroups)
-  if (!(drop & 1)) for (int i = 0; i < 4; ++i) {
-    const ConvArgs a = conv(i == 0 ? ps.f[4] : ps.rb[i - 1], ps.rb[i], pw.rb_w[i], pw.rb_b[i], S_RB0 + i);
-    tb->add<T_RB>(CT<PL::RBL>::info("phone.rb", a), a, CT<PL::RBL>::grid(a), true, CT<PL::RBL>::wg_cost());
-  }
-  if (!(drop & 2)) { const ConvArgs a = conv(qs.spec, qs.p[0], qw.p_w[0], qw.p_b[0], S_P1); tb->add<T_P1>(CT<QL1::P1>::info("pitch.p1", a), a, CT<QL1::P1>::grid(a), true, CT<QL1::P1>::wg_cost()); }
-  if (!(drop & 1)) { const ConvArgs a = conv(ps.f[2], ps.f[3], pw.f_w[2], pw.f_b[2], S_F4); tb->add<T_F4>(CT<PL::F4>::info("phone.f4", a), a, CT<PL::F4>::grid(a), true, CT<PL::F4>::wg_cost()); }
-  if (!(drop & 1)) { const ConvArgs a = conv(ps.f[3], ps.f[4], pw.f_w[3], pw.f_b[3], S_F5); tb->add<T_F5>(CT<PL::F5>::info("phone.f5", a), a, CT<PL::F5>::grid(a), true, CT<PL::F5>::wg_cost()); }
-  if (!(drop & 1)) { const ConvArgs a = conv(ps.f[0], ps.f[1], pw.f_w[0], pw.f_b[0], S_F2); tb->add<T_F2>(CT<PL::F2>::info("phone.f2", a), a, CT<PL::F2>::grid(a), true, CT<PL::F2>::wg_cost()); }
-  if (!(drop & 1)) { const ConvArgs a = conv(ps.f[1], ps.f[2], pw.f_w[1], pw.f_b[1], S_F3); tb->add<T_F3>(CT<PL::F3>::info("phone.f3", a), a, CT<PL::F3>::grid(a), true, CT<PL::F3>::wg_cost()); }
-  if (!(drop & 32)) { F1Args a = f1_args(pw, ps); a.hop = hp(S_F1); a.hop_publish = nullptr; a.hop_publish_wave = nullptr; tb->add<T_F1>(f1_info(ps), a, dim3(B, 1), true, 3.0); }
-  if (!(drop & 2)) { FftArgs a = fft_args(qw, qs); a.hop = hp(S_FFT); tb->add<T_FFT>(fft_info(qs), a, dim3(B, 1), true, 4.0); }
-  if (!(drop & 2)) for (int i = 0; i < 2; ++i) {
-    const ConvArgs a = conv(qs.p[i], qs.p[i + 1], qw.p_w[i + 1], qw.p_b[i + 1], S_P2 + i);
-    tb->add<T_P23>(CT<QL1::P23>::info("pitch.p23", a), a, CT<QL1::P23>::grid(a), true, CT<QL1::P23>::wg_cost());
-  }
-  { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(S_QGRU), B, 0}; ab->add<A_QGRU>(GruOp<128, 128>::info("pitch.gru", g), g, GruOp<128, 128>::grid(g)); }
-  if (!(drop & 2)) { const ConvArgs a = conv(qs.h, qs.logits, qw.out_w, qw.out_b, S_POUT); tb->add<T_POUT>(CT<QL1::POUT>::info("pitch.out", a), a, CT<QL1::POUT>::grid(a), true, CT<QL1::POUT>::wg_cost()); }
-  { const GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(S_PGRU), B, 0}; ab->add<A_PGRU>(GruOp<256, 256>::info("phone.gru", g), g, GruOp<256, 256>::grid(g)); }
-  if (!(drop & 2)) { PitchHeadArgs a = head_args(qw, qs); a.hop = hp(S_HEAD); tb->add<T_HEAD>(head_info(qs), a, dim3(B, 1), true, 2.0); }
-  if (!(drop & 1)) { const ConvArgs a = conv(ps.h, phone_out_ring(ps), pw.out_w, pw.out_b, S_OUT); tb->add<T_OUT>(CT<PL::OUTL>::info("phone.out", a), a, CT<PL::OUTL>::grid(a), true, CT<PL::OUTL>::wg_cost()); }
-  if (!(drop & 32)) { CondArgs a = cond_args(ww, ws); a.hop = hp(S_COND); a.hop_next_out = nullptr; tb->add<T_COND>(cond_info(ws), a, dim3(B, 1), true, 2.0); }
-  { const VqArgs a{1, ps.raw, phone_vector_ring(ps), hp(S_VQ), ps.d_cbT, ps.d_cnorm, ps.d_vqk}; ab->add<A_VQ>(LaunchInfo{"phone.vq", 0, 4.0 * B * 256}, a, dim3(B, 1), !ps.skip_vq); }
-  // waveform generator
-  if (!(drop & 32)) { const Ring phone_in{ws.d_phone, B_PHONE_CH, 1, ws.front_slots}; ConvArgs a = conv(phone_in, ws.x[0], ww.inp_w, ww.inp_b, S_INP); a.res = ws.e; tb->add<T_INP>(CT<INP<1>>::info("wave.inp", a), a, CT<INP<1>>::grid(a), true, CT<INP<1>>::wg_cost()); }
+  // (workgroups are dispatched in this order: the longest-running bodies first)
+  // ---- conditioned blocks: two row-local chains each
   for (int blk = 0; blk < B_NBLOCKS; ++blk) {
     const WaveState::Scratch& sc = ws.scr[blk];  // one scratch set per block: all four blocks are in flight at once
-    const int s0 = S_BLK0 + 6 * blk;
-    if (!(drop & 4)) { const ConvArgs a = conv(ws.x[blk], sc.h1, ww.c1_w[blk], ww.c1_b[blk], s0);
-      switch (blk) {
-        case 0: tb->add<T_C1D1>(CT<C1<1, 1>>::info("wave.blk.c1", a), a, CT<C1<1, 1>>::grid(a), true, CT<C1<1, 1>>::wg_cost()); break;
-        case 1: tb->add<T_C1D2>(CT<C1<2, 1>>::info("wave.blk.c1", a), a, CT<C1<2, 1>>::grid(a), true, CT<C1<2, 1>>::wg_cost()); break;
-        case 2: tb->add<T_C1D4>(CT<C1<4, 1>>::info("wave.blk.c1", a), a, CT<C1<4, 1>>::grid(a), true, CT<C1<4, 1>>::wg_cost()); break;
-        default: tb->add<T_C1D8>(CT<C1<8, 1>>::info("wave.blk.c1", a), a, CT<C1<8, 1>>::grid(a), true, CT<C1<8, 1>>::wg_cost()); break;
-      } }
-    if (!(drop & 4)) { ConvArgs a = conv(sc.h1, sc.xa, ww.c2_w[blk], ww.c2_b[blk], s0 + 1); a.res = ws.x[blk]; tb->add<T_C2>(CT<C2<1>>::info("wave.blk.c2o", a), a, CT<C2<1>>::grid(a), true, CT<C2<1>>::wg_cost()); }
-    if (!(drop & 4)) { const ConvArgs a = conv(sc.xa, sc.q, ww.q_w[blk], ww.q_b[blk], s0 + 2); tb->add<T_Q>(CT<QL<1>>::info("wave.blk.q", a), a, CT<QL<1>>::grid(a), true, CT<QL<1>>::wg_cost()); }
-    // the two attention kernels read the tile lists: private copies 0 (scores) and 1 (softmax . V) of the block's lists
-    int* perm[2]; int* slot[2];
-    for (int c = 0; c < 2; ++c) {
-      perm[c] = b->dev_view<int>(b->off.perm[blk] + (size_t)c * b->off.wave_bytes);
-      slot[c] = b->dev_view<int>(b->off.tile_slot[blk] + (size_t)c * b->off.wave_bytes);
-    }
-    if (!(drop & 8)) { ConvArgs a = conv(sc.q, sc.sc, ws.d_kt[blk], nullptr, s0 + 3); a.scale = 0.0625f; a.perm = perm[0]; a.tile_slot = slot[0]; a.w_slot_stride = (size_t)B_HID * B_KV_LEN;
-      tb->add<T_SCORE>(CT<SCORE<1>>::info("wave.blk.attn_qk", a), a, CT<SCORE<1>>::grid(a, ws.n_tiles_max), true, CT<SCORE<1>>::wg_cost()); }
-    if (!(drop & 8)) { const AttnPvArgs a{sc.sc, ws.d_v[blk], sc.o, perm[1], slot[1], hp(s0 + 4)};
-      tb->add<T_PV>(LaunchInfo{"wave.blk.attn_pv", 2.0 * B * 384 * 256 + 25.0 * B * 384, 4.0 * (384.0 * 256 + B * (384 + 256))}, a, dim3(ws.n_tiles_max, B_HID / 32), true, 4.0); }
-    if (!(drop & 4)) { ConvArgs a = conv(sc.o, ws.x[blk + 1], ww.o_w[blk], ww.o_b[blk], s0 + 5); a.res = sc.xa; tb->add<T_C2>(CT<C2<1>>::info("wave.blk.c2o", a), a, CT<C2<1>>::grid(a), true, CT<C2<1>>::wg_cost()); }
+    const int s0 = pl.blk(blk);
+    const rc::BlockBArgs ba{sc.xa, ws.x[blk + 1], ww.q_w[blk], ww.q_b[blk], ww.o_w[blk], ww.o_b[blk], ws.d_kt[blk], ws.d_v[blk],
+                            b->dev_view<int>(b->off.perm[blk]), b->dev_view<int>(b->off.tile_slot[blk]), hp(s0 + 1)};
+    tb->add<T_BLKB>(LaunchInfo{"wave.blk.b", 2.0 * B * (256.0 * 256 * 2 + 256.0 * 384 * 2), 4.0 * (2.0 * 256 * 256 + 2.0 * 256 * 384 + B * 3.0 * 256)}, ba,
+                    dim3(ws.n_tiles_max, 1), true, 41.0);
   }
-  if (!(drop & 16)) { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], S_UP1); tb->add<T_UP1>(CT<UP<256, 128, 5, 1>>::info("wave.up1", a), a, CT<UP<256, 128, 5, 1>>::grid(a), true, CT<UP<256, 128, 5, 1>>::wg_cost()); }
-  if (!(drop & 16)) { const ConvArgs a = conv(ws.ya1, ws.yb1, ww.ra_w[0], ww.ra_b[0], S_RES1A); tb->add<T_RES1A>(CT<RES<128, 1, 5>>::info("wave.res1a", a), a, CT<RES<128, 1, 5>>::grid(a), true, CT<RES<128, 1, 5>>::wg_cost()); }
-  if (!(drop & 16)) { const ConvArgs a = conv(ws.yb1, ws.yc1, ww.rb_w[0], ww.rb_b[0], S_RES1B); tb->add<T_RES1B>(CT<RES<128, 3, 5>>::info("wave.res1b", a), a, CT<RES<128, 3, 5>>::grid(a), true, CT<RES<128, 3, 5>>::wg_cost()); }
-  if (!(drop & 16)) { const ConvArgs a = conv(ws.yc1, ws.ya2, ww.up_w[1], ww.up_b[1], S_UP2); tb->add<T_UP2>(CT<UP<128, 64, 4, 5>>::info("wave.up2", a), a, CT<UP<128, 64, 4, 5>>::grid(a), true, CT<UP<128, 64, 4, 5>>::wg_cost()); }
-  if (!tb->ok || !ab->ok) return false;
-  // XCD-aware placement (every body's workgroups on ONE XCD, so that its weights stay in that XCD's L2) cuts the launch's
-  // memory-side traffic from 105 MB to 26 MB per tick (rocprofv3 FETCH_SIZE) but not its duration (0.114 vs 0.106 ms per
-  // tick: the launch is bound by per-workgroup latencies, and confining a body to 32 CUs lengthens the tail): off by default
+  for (int blk = 0; blk < B_NBLOCKS; ++blk) {
+    const rc::BlockAArgs aa{ws.x[blk], ws.scr[blk].xa, ww.c1_w[blk], ww.c1_b[blk], ww.c2_w[blk], ww.c2_b[blk], hp(pl.blk(blk)), B};
+    switch (blk) {
+      case 0: tb->add<T_BLKA1>(rc::BlockAOp<1>::info(aa), aa, rc::BlockAOp<1>::grid(aa), true, 41); break;
+      case 1: tb->add<T_BLKA2>(rc::BlockAOp<2>::info(aa), aa, rc::BlockAOp<2>::grid(aa), true, 41); break;
+      case 2: tb->add<T_BLKA4>(rc::BlockAOp<4>::info(aa), aa, rc::BlockAOp<4>::grid(aa), true, 41); break;
+      default: tb->add<T_BLKA8>(rc::BlockAOp<8>::info(aa), aa, rc::BlockAOp<8>::grid(aa), true, 41); break;
+    }
+  }
+  // ---- the layers with long reductions, then the fused tail
+  { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], pl.up1()); tb->add<T_UP1>(OpUP1::info("wave.up1", a), a, OpUP1::grid(a), true, 36); }
+  for (int i = 0; i < 4; ++i) {
+    const ConvArgs a = conv(i == 0 ? ps.f[4] : ps.rb[i - 1], ps.rb[i], pw.rb_w[i], pw.rb_b[i], Plan::RB0 + i);
+    tb->add<T_RB>(OpRB::info("phone.rb", a), a, OpRB::grid(a), true, 46);
+  }
+  { const ConvArgs a = conv(qs.spec, qs.p[0], qw.p_w[0], qw.p_b[0], Plan::P1); tb->add<T_P1>(OpP1::info("pitch.p1", a), a, OpP1::grid(a), true, 34.5); }
+  { const ConvArgs a = conv(ps.f[2], ps.f[3], pw.f_w[2], pw.f_b[2], Plan::F4); tb->add<T_F4>(OpF4::info("phone.f4", a), a, OpF4::grid(a), true, 37.5); }
+  { const ConvArgs a = conv(ps.f[3], ps.f[4], pw.f_w[3], pw.f_b[3], Plan::F5); tb->add<T_F5>(OpF5::info("phone.f5", a), a, OpF5::grid(a), true, 47); }
+  { TailArgs ta = tail_args(ww, ws); ta.hop = hp(pl.tail()); tb->add<T_TAIL>(tail_info(ws), ta, dim3(B, 1), true, 41, true); }
+  { const ConvArgs a = conv(ps.f[0], ps.f[1], pw.f_w[0], pw.f_b[0], Plan::F2); tb->add<T_F2>(OpF2::info("phone.f2", a), a, OpF2::grid(a), true, 10); }
+  { const ConvArgs a = conv(ps.f[1], ps.f[2], pw.f_w[1], pw.f_b[1], Plan::F3); tb->add<T_F3>(OpF3::info("phone.f3", a), a, OpF3::grid(a), true, 18); }
+  { const ConvArgs a = conv(ws.ya1, ws.yb1, ww.ra_w[0], ww.ra_b[0], pl.up1() + 1); tb->add<T_RES1A>(OpRES1A::info("wave.res1a", a), a, OpRES1A::grid(a), true, 10); }
+  { const ConvArgs a = conv(ws.yb1, ws.yc1, ww.rb_w[0], ww.rb_b[0], pl.up1() + 2); tb->add<T_RES1B>(OpRES1B::info("wave.res1b", a), a, OpRES1B::grid(a), true, 10); }
+  { const ConvArgs a = conv(ws.yc1, ws.ya2, ww.up_w[1], ww.up_b[1], pl.up1() + 3); tb->add<T_UP2>(OpUP2::info("wave.up2", a), a, OpUP2::grid(a), true, 12); }
+  { const GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(Plan::PGRU), B, 0}; tb->add<T_PGRU>(GruOp<256, 256>::info("phone.gru", g), g, GruOp<256, 256>::grid(g), true, 7.6); }
+  { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, 0}; tb->add<T_QGRU>(GruOp<128, 128>::info("pitch.gru", g), g, GruOp<128, 128>::grid(g), true, 4.6); }
+  for (int i = 0; i < 2; ++i) {
+    const ConvArgs a = conv(qs.p[i], qs.p[i + 1], qw.p_w[i + 1], qw.p_b[i + 1], Plan::P2 + i);
+    tb->add<T_P23>(OpP23::info("pitch.p23", a), a, OpP23::grid(a), true, 8);
+  }
+  { const ConvArgs a = conv(qs.h, qs.logits, qw.out_w, qw.out_b, Plan::POUT); tb->add<T_POUT>(OpPOUT::info("pitch.out", a), a, OpPOUT::grid(a), true, 9.4); }
+  { const ConvArgs a = conv(ps.h, phone_out_ring(ps), pw.out_w, pw.out_b, Plan::OUT); tb->add<T_OUT>(OpOUT::info("phone.out", a), a, OpOUT::grid(a), true, 6); }
+  { const Ring phone_in{ws.d_phone, B_PHONE_CH, 1, ws.front_slots}; ConvArgs a = conv(phone_in, ws.x[0], ww.inp_w, ww.inp_b, Plan::INP); a.res = ws.e; tb->add<T_INP>(OpINP::info("wave.inp", a), a, OpINP::grid(a), true, 7.7); }
+  { const VqArgs a{1, ps.raw, phone_vector_ring(ps), hp(Plan::VQ), ps.d_cbT, ps.d_cnorm, ps.d_vqk}; tb->add<T_VQ>(LaunchInfo{"phone.vq", 0, 4.0 * B * 256}, a, dim3(B, 1), !ps.skip_vq, 6.0, true); }
+  { F1Args a = f1_args(pw, ps); a.hop = hp(Plan::F1); a.hop_publish = nullptr; a.hop_publish_wave = nullptr; tb->add<T_F1>(f1_info(ps), a, dim3(B, 1), true, 4.5); }
+  { FftArgs a = fft_args(qw, qs); a.hop = hp(Plan::FFT); tb->add<T_FFT>(fft_info(qs), a, dim3(B, 1), true, 6); }
+  { PitchHeadArgs a = head_args(qw, qs); a.hop = hp(Plan::HEAD); tb->add<T_HEAD>(head_info(qs), a, dim3(B, 1), true, 4.7); }
+  { CondArgs a = cond_args(ww, ws); a.hop = hp(Plan::COND); a.hop_next_out = nullptr; tb->add<T_COND>(cond_info(ws), a, dim3(B, 1), true, 1.3); }
+  if (!tb->ok) return false;
+  // XCD-aware placement (bodies with many weights pinned to one XCD each, so that the weights stay in that L2) was
+  // measured twice: it cuts the launch's memory-side traffic 4x (rocprofv3 FETCH_SIZE 105 -> 26 MB per tick) and the
+  // pinned workgroups run ~10-25 % shorter, but confining a body to 32 CUs costs more in makespan than that gains
+  // (0.096 vs 0.090 ms per tick): off by default
   static const bool by_xcd = std::getenv("BEATRICE_HIP_TICK_XCD") != nullptr;
   if (by_xcd) tb->place_by_xcd();
+  if (std::getenv("BEATRICE_HIP_TICK_TRACE")) {
+    if (k.d_trace) (void)hipFree(k.d_trace);
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&k.d_trace), sizeof(unsigned long long) * 3 * tb->t.total));
+    tb->t.trace = k.d_trace;
+  }
   BHIP_TRY(hipMemcpy(k.d_table, &tb->t, sizeof(Tab), hipMemcpyHostToDevice));
-  BHIP_TRY(hipMemcpy(k.d_aux, &ab->t, sizeof(AuxTab), hipMemcpyHostToDevice));
   k.table_total = tb->t.total;
-  k.aux_total = ab->t.total;
-  k.tail = tail_args(ww, ws);
-  k.tail.hop = hp(S_TAIL);
+  k.table_flops = tb->flops;
+  k.table_bytes = tb->bytes;
   // who reads which part of the settings block, and where its private copy lives
   k.consumers.clear();
   unsigned char* d = b->settings.d;
-  k.consumers.push_back(Consumer{S_VQ, b->off.cbT, b->off.min_q - b->off.cbT, d + b->off.cbT, -1});
-  k.consumers.push_back(Consumer{S_HEAD, b->off.min_q, b->off.add_idx - b->off.min_q, d + b->off.min_q, -1});
-  k.consumers.push_back(Consumer{S_COND, b->off.add_idx, b->off.front_bytes - b->off.add_idx, d + b->off.add_idx, -1});
+  k.consumers.push_back(Consumer{Plan::VQ, b->off.cbT, b->off.min_q - b->off.cbT, d + b->off.cbT, -1});
+  k.consumers.push_back(Consumer{Plan::HEAD, b->off.min_q, b->off.add_idx - b->off.min_q, d + b->off.min_q, -1});
+  k.consumers.push_back(Consumer{Plan::COND, b->off.add_idx, b->off.front_bytes - b->off.add_idx, d + b->off.add_idx, -1});
   for (int blk = 0; blk < B_NBLOCKS; ++blk) {
     const size_t lo = b->off.perm[blk], hi = blk + 1 < B_NBLOCKS ? b->off.perm[blk + 1] : b->off.front_bytes + b->off.wave_bytes;
-    for (int c = 0; c < 2; ++c)
-      k.consumers.push_back(Consumer{S_BLK0 + 6 * blk + 3 + c, lo, hi - lo, d + lo + (size_t)c * b->off.wave_bytes, -1});
+    k.consumers.push_back(Consumer{pl.blk(blk) + 1, lo, hi - lo, d + lo, -1});
   }
   k.table_dirty = false;
   return true;
@@ -596,12 +590,12 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
     k.fed_step[k.tick % kRing] = -1;
   }
   Prolog p{};
-  p.n_stages = S_COUNT;
+  p.n_stages = k.plan.count();
   auto step_at = [&k](int stage) -> long long {
     const long long t2 = k.tick - stage;
     return t2 >= 0 ? k.fed_step[t2 % kRing] : -1;
   };
-  for (int s = 0; s < S_COUNT; ++s) {
+  for (int s = 0; s < p.n_stages; ++s) {
     const long long u = step_at(s);
     p.hop[s] = u < 0 ? -1 : k.hop_of_step[u % kRing];
     p.io[s] = u < 0 ? 0 : k.io_of_step[u % kRing];
@@ -615,9 +609,9 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
     c.held = want;
   }
   hipLaunchKernelGGL(prologue_kernel, dim3(1 + p.n_copies), dim3(256), 0, st, k.d_hops, p);
-  fuse::launch_table(k.d_table, k.table_total, st);
-  fuse::launch_table(k.d_aux, k.aux_total, st);
-  hipLaunchKernelGGL(wave_tail_kernel<1>, dim3(b->B), dim3(tail::NTHR), 0, st, k.tail);
+  if (k.bracket) (void)hipEventRecord(k.bracket[k.bracket_at], st);
+  fuse::launch_table_w<4>(k.d_table, k.table_total, st);
+  if (k.bracket) (void)hipEventRecord(k.bracket[k.bracket_at + 1], st);
   if (feeding) {
     b->last_parity = b->hop_host % 3;
     b->last_hop = b->hop_host;
@@ -634,7 +628,17 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
 // ticks without new input until the last step fed has left the last stage
 bool tick_drain(BeatriceBatch* b) {
   bool ok = true;
-  while (ok && b->tk.on && b->tk.tick <= b->tk.last_feed_tick + tick::S_COUNT - 1) ok = tick_run(b, false);
+  if (b->tk.on && b->tk.d_trace && b->tk.last_feed_tick == b->tk.tick - 1 && b->tk.n_fed > b->tk.plan.count()) {
+    // measurement aid: the tick just enqueued had every stage busy; dump its per-workgroup timeline (100 MHz wall clock)
+    std::vector<unsigned long long> tr((size_t)3 * b->tk.table_total);
+    if (hip_ok(hipStreamSynchronize(b->stream), "trace sync") &&
+        hip_ok(hipMemcpy(tr.data(), b->tk.d_trace, tr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost), "trace copy"))
+      if (FILE* f = std::fopen(std::getenv("BEATRICE_HIP_TICK_TRACE"), "w")) {
+        for (size_t i = 0; i < tr.size(); i += 3) std::fprintf(f, "%llu %llu %llu\n", tr[i], tr[i + 1], tr[i + 2]);
+        std::fclose(f);
+      }
+  }
+  while (ok && b->tk.on && b->tk.tick <= b->tk.last_feed_tick + b->tk.plan.count() - 1) ok = tick_run(b, false);
   return ok;
 }
 int tick_enable(BeatriceBatch* b, bool on) {
@@ -644,14 +648,13 @@ int tick_enable(BeatriceBatch* b, bool on) {
   if (on) {
     // one 10 ms hop per step, at most 256 streams (the few-row tilings of every layer), resident I/O with enough slots
     // that a step's input is still there when the pitch head reads it nine ticks on and outputs have somewhere to land
-    if (b->H != 1 || b->B > 256 || b->io_slots < S_COUNT + 1) return -1;
+    if (b->H != 1 || b->B > 256 || b->io_slots < k.plan.count() + 1) return -1;
     if (!sync_all(b)) return -2;
     if (b->pipelined) { drop_graph(b); set_plan(b, 1); }
     k.snap_bytes = b->off.front_bytes + b->off.wave_bytes;
     if (!k.d_hops) {
       if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_hops), sizeof(int) * 2 * kMaxStages), "tick hops") ||
           !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_table), sizeof(Tab)), "tick table") ||
-          !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_aux), sizeof(AuxTab)), "tick aux table") ||
           !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_snap), k.snap_bytes * kRing), "tick snapshots"))
         return -2;
     }
@@ -886,7 +889,7 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   if (!b) return;
   if (b->stream) (void)sync_all(b);
   drop_graph(b);
-  { void* tk[] = {b->tk.d_hops, b->tk.d_table, b->tk.d_aux, b->tk.d_snap}; for (void* p : tk) if (p) (void)hipFree(p); }
+  { void* tk[] = {b->tk.d_hops, b->tk.d_table, b->tk.d_snap, b->tk.d_trace}; for (void* p : tk) if (p) (void)hipFree(p); }
   if (b->own_d_out) { b->wave.d_out = b->own_d_out; b->own_d_out = nullptr; }
   if (b->module_owned[0]) {  // hand the modules their own arrays back so that destroy() frees what it allocated
     void** keep = b->module_owned;
@@ -1244,7 +1247,29 @@ int BeatriceBatch_EnableTickPipeline(BeatriceBatch* b, int enable) {
   if (!b || !b->ok) return -2;
   return tick_enable(b, enable != 0);
 }
-int BeatriceBatch_TickStages(const BeatriceBatch*) { return tick::S_COUNT; }
+int BeatriceBatch_TickStages(const BeatriceBatch* b) { return b ? b->tk.plan.count() : 0; }
+// Measurement hook: `ticks` more ticks (each feeding a step from the resident slots), every tick's pipeline launch
+// bracketed by HIP events on the batch's stream; returns the mean duration of that launch and its algorithmic work.
+// Call with the pipeline full (at least BeatriceBatch_TickStages steps fed) for the steady-state figure.
+int BeatriceBatch_TimeTickLaunch(BeatriceBatch* b, int ticks, float* us_per_launch, double* flops, double* bytes) {
+  if (!b || !b->ok) return -2;
+  if (!b->tk.on || ticks < 1 || ticks > 64 || !us_per_launch) return -1;
+  std::vector<hipEvent_t> ev(2 * ticks);
+  bool ok = true;
+  for (hipEvent_t& e : ev) ok = ok && hip_ok(hipEventCreate(&e), "tick ev");
+  b->tk.bracket = ok ? ev.data() : nullptr;
+  for (int i = 0; i < ticks && ok; ++i) { b->tk.bracket_at = 2 * i; ok = tick_run(b, true); }
+  b->tk.bracket = nullptr;
+  ok = ok && hip_ok(hipStreamSynchronize(b->stream), "tick time sync");
+  double sum = 0;
+  for (int i = 0; i < ticks && ok; ++i) { float ms = 0; ok = hip_ok(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]), "tick elapsed"); sum += ms; }
+  for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+  if (!ok) return -2;
+  *us_per_launch = (float)(1000.0 * sum / ticks);
+  if (flops) *flops = b->tk.table_flops;
+  if (bytes) *bytes = b->tk.table_bytes;
+  return 0;
+}
 int BeatriceBatch_EnablePipelining(BeatriceBatch* b, int enable) {
   if (!b || !b->ok) return -2;
   if (b->tk.on) return -1;

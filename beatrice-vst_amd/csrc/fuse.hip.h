@@ -117,6 +117,7 @@ struct Banks<M, Rest...> {
 template <class... Ms>
 struct Table {
   int n_spans, total, per_xcd, pad;  // per_xcd > 0: XCD-aware layout, see TableBuilder::place_by_xcd
+  unsigned long long* trace;         // measurement aid (may be null): per workgroup {start, end} wall clock + body type
   Span span[kMaxSpans];  // 16 bytes each: a wavefront fetches all of them with one load, lane i = body i
   Banks<Ms...> banks;
 };
@@ -138,8 +139,16 @@ __device__ __forceinline__ void run_type(const Banks<M, Rest...>& b, const Span&
   }
 }
 
+template <int MINW, class... Ms>
+__device__ __forceinline__ void table_body(const Table<Ms...>* __restrict__ t);
 template <class... Ms>
-__global__ __launch_bounds__(MaxM<Ms...>::NTHR) void table_kernel(const Table<Ms...>* __restrict__ t) {
+__global__ __launch_bounds__(MaxM<Ms...>::NTHR) void table_kernel(const Table<Ms...>* __restrict__ t) { table_body<0, Ms...>(t); }
+// the same with a register budget: MINW = minimum wavefronts per SIMD the launch wants resident (HIP's second
+// __launch_bounds__ parameter): 4 with 512-thread workgroups = two workgroups per CU = at most 128 VGPRs
+template <int MINW, class... Ms>
+__global__ __launch_bounds__(MaxM<Ms...>::NTHR, MINW) void table_kernel_w(const Table<Ms...>* __restrict__ t) { table_body<MINW, Ms...>(t); }
+template <int MINW, class... Ms>
+__device__ __forceinline__ void table_body(const Table<Ms...>* __restrict__ t) {
   __shared__ __attribute__((aligned(16))) float lds[MaxM<Ms...>::LDS > 0 ? MaxM<Ms...>::LDS : 1];
   const int lane = threadIdx.x & 63;
   // XCD-aware layout: workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only), and the table gives
@@ -152,12 +161,25 @@ __global__ __launch_bounds__(MaxM<Ms...>::NTHR) void table_kernel(const Table<Ms
   Span sp;
   sp.first = __builtin_amdgcn_readlane(mine.x, idx); sp.gx = __builtin_amdgcn_readlane(mine.y, idx);
   sp.type = __builtin_amdgcn_readlane(mine.z, idx); sp.arg = __builtin_amdgcn_readlane(mine.w, idx);
-  run_type<0, MaxM<Ms...>::NTHR, Ms...>(t->banks, sp, id - sp.first, lds);
+  unsigned long long* const trace = t->trace;
+  const unsigned long long t0 = trace ? wall_clock64() : 0;
+  // (a body spread over the XCDs is eight spans; span k owns the body's workgroups k, k + 8, ...: arg bits 8-11 = k, bit 12 set)
+  const int local = id - sp.first;
+  const int body_wg = (sp.arg & 0x1000) ? local * 8 + ((sp.arg >> 8) & 15) : local;
+  sp.arg &= 0xff;
+  run_type<0, MaxM<Ms...>::NTHR, Ms...>(t->banks, sp, body_wg, lds);
+  if (trace && threadIdx.x == 0) {
+    trace[3 * (size_t)blockIdx.x] = t0; trace[3 * (size_t)blockIdx.x + 1] = wall_clock64(); trace[3 * (size_t)blockIdx.x + 2] = (unsigned long long)sp.type;
+  }
 }
 
 template <class... Ms>
 static inline void launch_table(const Table<Ms...>* d_table, int total, hipStream_t stream) {
   hipLaunchKernelGGL((table_kernel<Ms...>), dim3(total), dim3(MaxM<Ms...>::NTHR), 0, stream, d_table);
+}
+template <int MINW, class... Ms>
+static inline void launch_table_w(const Table<Ms...>* d_table, int total, hipStream_t stream) {
+  hipLaunchKernelGGL((table_kernel_w<MINW, Ms...>), dim3(total), dim3(MaxM<Ms...>::NTHR), 0, stream, d_table);
 }
 
 // host side: fill a Table<Ms...>.  add<I>() appends one body of type I (its index in Ms...); bodies run in the order added
@@ -177,12 +199,18 @@ struct TableBuilder {
   double cost[kMaxSpans] = {};  // estimated time of the body's workgroups (relative), for place_by_xcd
   int n_wg[kMaxSpans] = {};
   TableBuilder() { for (Span& sp : t.span) sp = Span{0x7fffffff, 1, -1, 0}; }
-  // Re-lays the bodies out for an 8-XCD chip: bodies are assigned whole to XCDs (longest first, to the XCD with the
-  // least work so far), XCD x owns the index range [x * per_xcd, (x + 1) * per_xcd), padded with indices that do
-  // nothing.  Launch 8 * per_xcd workgroups.  Every XCD then touches only its own bodies' weights.
+  bool ok = true;
+  double flops = 0, bytes = 0;
+  // Re-lays the bodies out for an 8-XCD chip.  A pinned body goes whole to ONE XCD (longest first, to the XCD with the
+  // least work so far), so that its weights are fetched into one L2 and stay there from tick to tick; a body marked
+  // `spread` (many workgroups, few weights) is dealt round-robin over all eight.  XCD x owns the index range
+  // [x * per_xcd, (x + 1) * per_xcd), padded with indices that do nothing.  Launch 8 * per_xcd workgroups.
+  bool spread[kMaxSpans] = {};
   void place_by_xcd() {
     const int n = t.n_spans;
-    if (n == 0 || n + 8 > kMaxSpans) return;
+    int n_out = 0;
+    for (int i = 0; i < n; ++i) n_out += spread[i] ? 8 : 1;
+    if (n == 0 || n_out + 8 > kMaxSpans) return;
     int order[kMaxSpans];
     for (int i = 0; i < n; ++i) order[i] = i;
     for (int i = 0; i < n; ++i)
@@ -190,27 +218,45 @@ struct TableBuilder {
         if (cost[order[j]] > cost[order[i]]) { const int x = order[i]; order[i] = order[j]; order[j] = x; }
     double load[8] = {};
     int len[8] = {}, owner[kMaxSpans];
+    for (int i = 0; i < n; ++i)
+      if (spread[i]) for (int x = 0; x < 8; ++x) { load[x] += cost[i] / 8; len[x] += (n_wg[i] - x + 7) / 8; }
     for (int oi = 0; oi < n; ++oi) {
+      const int i = order[oi];
+      if (spread[i]) continue;
       int best = 0;
       for (int x = 1; x < 8; ++x) if (load[x] < load[best]) best = x;
-      owner[order[oi]] = best;
-      load[best] += cost[order[oi]];
-      len[best] += n_wg[order[oi]];
+      owner[i] = best;
+      load[best] += cost[i];
+      len[best] += n_wg[i];
     }
     int per = 1;
     for (int x = 0; x < 8; ++x) per = len[x] > per ? len[x] : per;
     Span old[kMaxSpans];
     for (int i = 0; i < n; ++i) old[i] = t.span[i];
+    // inside an XCD: the bodies whose workgroups run longest first (they set the launch's makespan)
+    for (int i = 0; i < n; ++i) order[i] = i;
+    for (int i = 0; i < n; ++i)
+      for (int j = i + 1; j < n; ++j)
+        if (cost[order[j]] / n_wg[order[j]] > cost[order[i]] / n_wg[order[i]]) { const int x = order[i]; order[i] = order[j]; order[j] = x; }
     int out = 0;
     for (int x = 0; x < 8; ++x) {
       int at = x * per;
-      for (int oi = 0; oi < n; ++oi) {   // longest bodies first inside an XCD too
+      for (int oi = 0; oi < n; ++oi) {
         const int i = order[oi];
-        if (owner[i] != x) continue;
-        t.span[out] = old[i];
-        t.span[out].first = at;
-        at += n_wg[i];
-        ++out;
+        if (spread[i]) {
+          const int cnt = (n_wg[i] - x + 7) / 8;
+          if (cnt <= 0) continue;
+          t.span[out] = old[i];
+          t.span[out].first = at;
+          t.span[out].arg = old[i].arg | (x << 8) | 0x1000;
+          at += cnt;
+          ++out;
+        } else if (owner[i] == x) {
+          t.span[out] = old[i];
+          t.span[out].first = at;
+          at += n_wg[i];
+          ++out;
+        }
       }
       if (at < (x + 1) * per) t.span[out++] = Span{at, 1, -1, 0};  // filler: these indices exit at once
     }
@@ -219,10 +265,8 @@ struct TableBuilder {
     t.per_xcd = per;
     t.total = 8 * per;
   }
-  bool ok = true;
-  double flops = 0, bytes = 0;
   template <int I, class Args>
-  void add(const bhip::LaunchInfo& info, const Args& a, dim3 grid, bool on = true, double wg_cost = 1.0) {
+  void add(const bhip::LaunchInfo& info, const Args& a, dim3 grid, bool on = true, double wg_cost = 1.0, bool spread_over_xcds = false) {
     if (!on) return;
     using BA = BankAt<I, Banks<Ms...>>;
     if (t.n_spans >= kMaxSpans || used[I] >= BA::cap) { ok = false; return; }
@@ -231,6 +275,7 @@ struct TableBuilder {
     sp.first = t.total; sp.gx = (int)grid.x > 0 ? (int)grid.x : 1; sp.type = I; sp.arg = used[I]++;
     n_wg[t.n_spans] = (int)(grid.x * grid.y);
     cost[t.n_spans] = wg_cost * n_wg[t.n_spans];
+    spread[t.n_spans] = spread_over_xcds;
     ++t.n_spans;
     t.total += (int)(grid.x * grid.y);
     flops += info.flops; bytes += info.bytes;

@@ -1,0 +1,394 @@
+// rowchain.hip.h -- row-local chains of layers as ONE workgroup per 16 rows (stream-stationary kernels).
+//
+// In the conditioned blocks of the waveform generator (and the tail of the content encoder) every layer has one
+// frame per stream-hop, so a layer's output row depends only on the same row of its input: conv-k3 -> 1x1 + residual
+// and q -> q.K^T -> softmax.V -> output linear + residual need no exchange between rows.  A workgroup that owns 16
+// rows can therefore run the whole chain with the activations in LDS and only the weights streaming past
+// (pre-packed MFMA B fragments, conv_gemm.hip.h), instead of one launch per layer with every layer's rows spread over
+// the chip.  Per layer this trades parallelism (16 workgroups for 256 streams) for density (~4000-5000 back-to-back
+// MFMAs per workgroup and no launch / fill / drain per layer): the right trade inside the tick pipeline (tick.hip.h),
+// where ~40 stages of different steps share a launch and the chip is filled by stages, not by one layer's tiles.
+// In the in-order chain the per-layer launches win; BEATRICE_HIP_ROWCHAIN=1 runs these kernels
+// there for measurements and for the parity tests.
+//
+// Numerics are those of the per-layer kernels, operation for operation (MODEL_SPEC 2.2: every 256-long reduction
+// segment one k-ascending MFMA chain, segments added in order, then bias / scale / activation / residual in the same
+// order as conv_gemm's epilogue; softmax as attn_pv_kernel), so results are bit-identical.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "conv_gemm.hip.h"
+#include "kernels_misc.hip.h"
+#include "ring.h"
+#include "spec_math.hip.h"
+
+namespace rc {
+
+constexpr int NTHR = 512, NWAVE = 8;
+constexpr int AS = B_HID + 2;        // LDS row stride of a 256-channel tile: A-operand reads (row l&15, k l>>4) hit 32 distinct banks
+constexpr int TILE = 16 * AS;        // floats of one [16][256] tile
+constexpr int SS = B_KV_LEN + 2;     // row stride of the score tile
+constexpr int STILE = 16 * SS;
+
+// One reduction segment (KB k-blocks of 16) for CG column tiles of this wavefront: acc[c] += A[16 x 16 KB] . W.
+// `a` = this lane's A base in LDS (row l&15, k l>>4 of the segment's first k); `wf` = this lane's float4 of column
+// tile 0 / k-block 0 of the segment; consecutive column tiles of the wavefront are `tile_stride` float4 apart.
+// B fragments are fetched four k-blocks ahead of their use (an L2 round trip is ~200-500 cycles, a k-block is
+// 4 CG MFMAs = 128 CG cycles of the SIMD's matrix pipe; eight ahead measured 2 % better than four at two column tiles).
+template <int CG, int KB>
+__device__ __forceinline__ void mma_segment_p(f32x4 (&acc)[CG], const float* __restrict__ a, const float4* const (&wf)[CG]) {
+#ifndef RC_PREFETCH
+#define RC_PREFETCH 8
+#endif
+  constexpr int D = CG <= 2 ? RC_PREFETCH : (CG <= 3 ? 4 : 2);  // prefetch depth in k-blocks (registers: D * CG float4)
+  static_assert(KB % D == 0, "segment length");
+  float4 bq[D][CG];
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+#pragma unroll
+    for (int c = 0; c < CG; ++c) bq[d][c] = wf[c][(size_t)d * 64];
+#pragma unroll
+  for (int kb = 0; kb < KB; kb += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      float4 cur[CG];
+#pragma unroll
+      for (int c = 0; c < CG; ++c) cur[c] = bq[d][c];
+      if (kb + d + D < KB) {
+#pragma unroll
+        for (int c = 0; c < CG; ++c) bq[d][c] = wf[c][(size_t)(kb + d + D) * 64];
+      }
+      const float* ap = a + (kb + d) * 16;
+      const float a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
+#pragma unroll
+      for (int c = 0; c < CG; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, cur[c].x, acc[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < CG; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, cur[c].y, acc[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < CG; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, cur[c].z, acc[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < CG; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, cur[c].w, acc[c], 0, 0, 0);
+    }
+  }
+}
+template <int CG, int KB>
+__device__ __forceinline__ void mma_segment(f32x4 (&acc)[CG], const float* __restrict__ a, const float4* __restrict__ wf,
+                                            const size_t tile_stride) {
+  const float4* wfc[CG];
+#pragma unroll
+  for (int c = 0; c < CG; ++c) wfc[c] = wf + c * tile_stride;
+  mma_segment_p<CG, KB>(acc, a, wfc);
+}
+
+// A layer over 16 rows: K = NSEG segments of 256 (segment s read from LDS tile seg[s], row stride `as`), N = 16 * 8 * CG
+// columns; wavefront w owns column tiles w, w + 8, ...  epi(row, col, value) receives the ordered sum of the segments.
+template <int NSEG, int CG, class Epi>
+__device__ __forceinline__ void layer256(const float* const (&seg)[NSEG], const int as, const float* __restrict__ w_packed,
+                                         const int wave, const int lane, Epi epi) {
+  constexpr int K = NSEG * 256;
+  const float4* wf = reinterpret_cast<const float4*>(w_packed) + (size_t)wave * (K / 16) * 64 + lane;
+  const size_t tile_stride = (size_t)NWAVE * (K / 16) * 64;
+  f32x4 tot[CG];
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s) {
+    f32x4 acc[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mma_segment<CG, 16>(acc, seg[s] + (lane & 15) * as + (lane >> 4), wf + (size_t)s * 16 * 64, tile_stride);
+#pragma unroll
+    for (int c = 0; c < CG; ++c) {
+      if (s == 0) tot[c] = acc[c];
+      else { tot[c][0] = tot[c][0] + acc[c][0]; tot[c][1] = tot[c][1] + acc[c][1]; tot[c][2] = tot[c][2] + acc[c][2]; tot[c][3] = tot[c][3] + acc[c][3]; }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CG; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) epi((lane >> 4) * 4 + e, (wave + NWAVE * c) * 16 + (lane & 15), tot[c][e]);
+}
+
+// [16 rows][256 channels] from a ring into an LDS tile; row r = frame `rel` of stream sid[r] (zeros when sid[r] < 0)
+__device__ __forceinline__ void load_tile(float* __restrict__ dst, const Ring& ring, const int* sid /* LDS, [16] */, const int pos, const int rel,
+                                          const int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + i * NTHR, r = idx >> 6, q = idx & 63;
+    const int b = sid[r];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b >= 0) v = *reinterpret_cast<const float4*>(ring_frame(ring, b, pos, rel) + 4 * q);
+    float2* d = reinterpret_cast<float2*>(dst + r * AS + 4 * q);
+    d[0] = make_float2(v.x, v.y);
+    d[1] = make_float2(v.z, v.w);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// First half of a conditioned block (MODEL_SPEC 4.4.2): h = gelu(Conv(256->256, k3, dil D)(x)); xa = x + Linear(h).
+struct BlockAArgs {
+  Ring x, xa;                      // block input (history 2 D frames) and the scratch ring the second half reads
+  const float *c1_w, *c1_b, *c2_w, *c2_b;
+  const int* hop;
+  int B;
+};
+constexpr int kBlockALds = 4 * TILE + 16;
+template <int D>
+__device__ __forceinline__ void block_a_body(const BlockAArgs& a, const int g, float* __restrict__ lds) {
+  float* T[3] = {lds, lds + TILE, lds + 2 * TILE};  // taps t-2D, t-D, t
+  float* Hh = lds + 3 * TILE;
+  int* sid = reinterpret_cast<int*>(lds + 4 * TILE);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hop = *a.hop;
+  if (hop < 0) return;
+  if (tid < 16) sid[tid] = g * 16 + tid < a.B ? g * 16 + tid : -1;
+  __syncthreads();
+  const int pos = ring_pos(a.x, hop);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) load_tile(T[j], a.x, sid, pos, -(2 - j) * D, tid);
+  __syncthreads();
+  {
+    const float* const seg[3] = {T[0], T[1], T[2]};
+    const float* __restrict__ bias = a.c1_b;
+    layer256<3, 2>(seg, AS, a.c1_w, wave, lane, [&](int r, int n, float v) { Hh[r * AS + n] = bsp::gelu(v + bias[n]); });
+  }
+  __syncthreads();
+  {
+    const float* const seg[1] = {Hh};
+    const float* __restrict__ bias = a.c2_b;
+    const int pos_o = ring_pos(a.xa, hop);
+    layer256<1, 2>(seg, AS, a.c2_w, wave, lane, [&](int r, int n, float v) {
+      const int b = sid[r];
+      if (b >= 0) ring_frame(a.xa, b, pos_o, 0)[n] = T[2][r * AS + n] + (v + bias[n]);
+    });
+  }
+}
+template <int D>
+struct BlockAOp {
+  using Args = BlockAArgs;
+  static constexpr int NTHR = rc::NTHR;
+  static constexpr int LDS_FLOATS = kBlockALds;
+  static inline dim3 grid(const Args& a) { return dim3((a.B + 15) / 16, 1); }
+  static inline bhip::LaunchInfo info(const Args& a) {
+    return bhip::LaunchInfo{"wave.blk.a", 2.0 * a.B * (768.0 + 256.0) * 256.0, 4.0 * ((768.0 + 256.0) * 256.0 + a.B * 5.0 * 256.0)};
+  }
+  static constexpr double wg_cost() { return 20.0; }
+  __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { block_a_body<D>(a, bx, lds); }
+};
+template <int D>
+static __global__ __launch_bounds__(NTHR, 4) void block_a_kernel(const BlockAArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[kBlockALds];
+  block_a_body<D>(a, blockIdx.x, lds);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Second half: q = Linear(xa); s = (q . K^T) / 16; o = softmax(s) . V; x' = xa + Linear(o).  Rows are grouped by the
+// key/value slot they attend to (the same tile lists as the per-layer attention kernels).
+struct BlockBArgs {
+  Ring xa, out;                    // first half's output; the next block's input ring
+  const float *q_w, *q_b, *o_w, *o_b;
+  const float *kt, *v;             // packed per-slot tables, slot stride 256 * 384 floats
+  const int* perm;                 // [n_tiles][16] row (stream) indices or -1
+  const int* tile_slot;            // [n_tiles]
+  const int* hop;
+};
+constexpr int kBlockBLds = 2 * TILE + STILE + 32;
+__device__ __forceinline__ void block_b_body(const BlockBArgs& a, const int g, float* __restrict__ lds) {
+  float* XA = lds;
+  float* Q = lds + TILE;           // q, later o
+  float* S = lds + 2 * TILE;       // scores, then exp(s - max)
+  float* inv = S + STILE;
+  int* sid = reinterpret_cast<int*>(inv + 16);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hop = *a.hop;
+  if (hop < 0) return;
+  const int slot = a.tile_slot[g];
+  if (slot < 0) return;
+  if (tid < 16) sid[tid] = a.perm[g * 16 + tid];
+  __syncthreads();
+  load_tile(XA, a.xa, sid, ring_pos(a.xa, hop), 0, tid);
+  __syncthreads();
+  {
+    const float* const seg[1] = {XA};
+    const float* __restrict__ bias = a.q_b;
+    layer256<1, 2>(seg, AS, a.q_w, wave, lane, [&](int r, int n, float v) { Q[r * AS + n] = v + bias[n]; });
+  }
+  __syncthreads();
+  {
+    const float* const seg[1] = {Q};
+    layer256<1, 3>(seg, AS, a.kt + (size_t)slot * B_HID * B_KV_LEN, wave, lane, [&](int r, int n, float v) { S[r * SS + n] = v * 0.0625f; });
+  }
+  __syncthreads();
+  // softmax statistics, two rows per wavefront (MODEL_SPEC 4.4.2; same operations as attn_pv_kernel)
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const int r = wave * 2 + rr;
+    float v[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = S[r * SS + lane + 64 * i];
+    float mx = -__builtin_huge_valf();
+#pragma unroll
+    for (int i = 0; i < 6; ++i) mx = fmaxf(mx, v[i]);
+    mx = bsp::wmax64(mx);
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { const float e = bsp::exp(v[i] - mx); s = s + e; S[r * SS + lane + 64 * i] = e; }
+    const float tot = bsp::wsum64(s);
+    if (lane == 0) inv[r] = 1.0f / tot;
+  }
+  __syncthreads();
+  {  // o = (segment 0 + segment 1) * (1 / sum): K = 384 = 256 + 128, V packed [384][256]
+    const float4* wf = reinterpret_cast<const float4*>(a.v + (size_t)slot * B_KV_LEN * B_HID) + (size_t)wave * (B_KV_LEN / 16) * 64 + lane;
+    const size_t tile_stride = (size_t)NWAVE * (B_KV_LEN / 16) * 64;
+    const float* ap = S + (lane & 15) * SS + (lane >> 4);
+    f32x4 acc0[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, acc1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    mma_segment<2, 16>(acc0, ap, wf, tile_stride);
+    mma_segment<2, 8>(acc1, ap + 256, wf + (size_t)16 * 64, tile_stride);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = (lane >> 4) * 4 + e, n = (wave + NWAVE * c) * 16 + (lane & 15);
+        const float v = acc0[c][e] + acc1[c][e];
+        Q[r * AS + n] = v * inv[r];
+      }
+  }
+  __syncthreads();
+  {
+    const float* const seg[1] = {Q};
+    const float* __restrict__ bias = a.o_b;
+    const int pos_o = ring_pos(a.out, hop);
+    layer256<1, 2>(seg, AS, a.o_w, wave, lane, [&](int r, int n, float v) {
+      const int b = sid[r];
+      if (b >= 0) ring_frame(a.out, b, pos_o, 0)[n] = XA[r * AS + n] + (v + bias[n]);
+    });
+  }
+}
+struct BlockBOp {
+  using Args = BlockBArgs;
+  static constexpr int NTHR = rc::NTHR;
+  static constexpr int LDS_FLOATS = kBlockBLds;
+  static constexpr double wg_cost() { return 24.0; }
+  __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { block_b_body(a, bx, lds); }
+};
+static __global__ __launch_bounds__(NTHR, 4) void block_b_kernel(const BlockBArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[kBlockBLds];
+  block_b_body(a, blockIdx.x, lds);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Any conv_gemm Layer for ONE tile of 16 rows and ALL its output columns: the A operand streams through two LDS tiles
+// one 256-long reduction segment at a time (gathered from the input ring exactly as conv_gemm does, next segment's
+// loads in flight during the current segment's MFMAs, one barrier per segment), the eight wavefronts own the
+// column tiles w, w + 8, ...  Same results as conv_gemm_kernel<L, *> (same segments, same order, same epilogue).  Inside
+// a tick this replaces conv_gemm's 64-wide k-chunks (two barriers and an exposed load latency per 16 MFMA steps):
+// phone.rb (K = 1280): 65 -> 46 us per workgroup with two workgroups per CU.
+constexpr int kConvRowsLds = 2 * TILE + 32;
+// COLS = output columns per workgroup (0 = all): a wide layer can be cut into column slabs, one workgroup each (grid y).
+template <class L, int COLS = 0>
+__device__ __forceinline__ void conv_rows_body(const ConvArgs& a, const int bx, const int by, float* __restrict__ lds) {
+  constexpr int NCOL = COLS > 0 ? COLS : L::NOUT;
+  static_assert(L::NOUT % NCOL == 0 && NCOL % 16 == 0, "column slabs");
+  constexpr int K = L::K, P = L::P, NTL = NCOL / 16, CG = (NTL + NWAVE - 1) / NWAVE;
+  const int nt_base = by * NTL;  // first column tile of this workgroup's slab
+  constexpr int LAST = K - 256 * (P - 1);  // length of the last segment
+  static_assert(K % 16 == 0 && LAST % 64 == 0 && L::NOUT % 16 == 0 && !L::GROUPED, "layer shape");
+  float* slot[2] = {lds, lds + TILE};
+  int* rb_ = reinterpret_cast<int*>(lds + 2 * TILE);  // [16] stream, [16] frame of each row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hop = *a.hop;
+  if (hop < 0) return;
+  const int M = a.B * L::T;
+  if (tid < 16) {
+    const int m = bx * 16 + tid;
+    rb_[tid] = m < M ? m / L::T : -1;
+    rb_[16 + tid] = m < M ? m % L::T : 0;
+  }
+  __syncthreads();
+  const int pos_in = ring_pos(a.in, hop);
+  // this thread's two 16-byte pieces of a segment: rows r0 / r0 + 8, piece q
+  const int q = tid & 63, r0 = tid >> 6;
+  const int b0 = rb_[r0], t0 = rb_[16 + r0], b1 = rb_[r0 + 8], t1 = rb_[16 + r0 + 8];
+  float4 nx[2];
+  auto load_seg = [&](int s) {
+    const int kk = s * 256 + 4 * q;
+    const bool live = kk < K;
+    const int j = live ? kk / L::CIN : 0, c = live ? kk % L::CIN : 0;
+    nx[0] = nx[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live && b0 >= 0) nx[0] = *reinterpret_cast<const float4*>(ring_frame(a.in, b0, pos_in, (t0 + 1) * L::STRIDE - 1 - (L::KSZ - 1 - j) * L::DIL + a.rel_shift) + c);
+    if (live && b1 >= 0) nx[1] = *reinterpret_cast<const float4*>(ring_frame(a.in, b1, pos_in, (t1 + 1) * L::STRIDE - 1 - (L::KSZ - 1 - j) * L::DIL + a.rel_shift) + c);
+  };
+  auto store_seg = [&](float* dst) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float4 v = nx[i];
+      if constexpr (L::PRE == PRE_LRELU) { v.x = bsp::lrelu(v.x); v.y = bsp::lrelu(v.y); v.z = bsp::lrelu(v.z); v.w = bsp::lrelu(v.w); }
+      float2* d = reinterpret_cast<float2*>(dst + (r0 + 8 * i) * AS + 4 * q);
+      d[0] = make_float2(v.x, v.y);
+      d[1] = make_float2(v.z, v.w);
+    }
+  };
+  const float4* wfc[CG];
+#pragma unroll
+  for (int c = 0; c < CG; ++c) {
+    const int nt = wave + NWAVE * c < NTL ? wave + NWAVE * c : NTL - 1;  // surplus tiles of a ragged layer recompute the last one
+    wfc[c] = reinterpret_cast<const float4*>(a.w) + (size_t)(nt_base + nt) * (K / 16) * 64 + lane;
+  }
+  load_seg(0);
+  store_seg(slot[0]);
+  __syncthreads();
+  f32x4 tot[CG];
+#pragma unroll
+  for (int s = 0; s < P; ++s) {
+    if (s + 1 < P) load_seg(s + 1);
+    f32x4 acc[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float4* wfs[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) wfs[c] = wfc[c] + (size_t)s * 16 * 64;
+    const float* ap = slot[s & 1] + (lane & 15) * AS + (lane >> 4);
+    if (s + 1 < P) mma_segment_p<CG, 16>(acc, ap, wfs);
+    else mma_segment_p<CG, LAST / 16>(acc, ap, wfs);
+#pragma unroll
+    for (int c = 0; c < CG; ++c) {
+      if (s == 0) tot[c] = acc[c];
+      else { tot[c][0] = tot[c][0] + acc[c][0]; tot[c][1] = tot[c][1] + acc[c][1]; tot[c][2] = tot[c][2] + acc[c][2]; tot[c][3] = tot[c][3] + acc[c][3]; }
+    }
+    if (s + 1 < P) {
+      store_seg(slot[(s + 1) & 1]);
+      __syncthreads();
+    }
+  }
+  // epilogue: conv_gemm's, operation for operation
+  const int pos_out = ring_pos(a.out, hop), R_out = a.out.n * a.out.m;
+  int pos_res = 0, R_res = 0;
+  if constexpr (L::RES) { pos_res = ring_pos(a.res, hop); R_res = a.res.n * a.res.m; }
+#pragma unroll
+  for (int c = 0; c < CG; ++c) {
+    if (wave + NWAVE * c >= NTL) continue;
+    const int n = (nt_base + wave + NWAVE * c) * 16 + (lane & 15);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = (lane >> 4) * 4 + e;
+      const int b = rb_[r], t = rb_[16 + r];
+      if (b < 0) continue;
+      float v = tot[c][e];
+      if constexpr (L::EPI == EPI_BIAS) v = v + a.bias[n];
+      if constexpr (L::EPI == EPI_SCALE) v = v * a.scale;
+      if constexpr (L::EPI == EPI_ROWSCALE) v = v * a.rowscale[b * L::T + t];
+      if constexpr (L::ACT == ACT_GELU) v = bsp::gelu(v);
+      if constexpr (L::RES) v = a.res.base[((size_t)b * R_res + pos_res) * a.res.C + (size_t)t * L::NOUT + n] + v;
+      a.out.base[((size_t)b * R_out + pos_out) * a.out.C + (size_t)t * L::NOUT + n] = v;
+    }
+  }
+}
+template <class L, int COLS = 0>
+struct ConvRowsOp {
+  using Args = ConvArgs;
+  static constexpr int NTHR = rc::NTHR;
+  static constexpr int LDS_FLOATS = kConvRowsLds;
+  static inline dim3 grid(const ConvArgs& a) { return dim3((a.B * L::T + 15) / 16, COLS > 0 ? L::NOUT / COLS : 1); }
+  static inline bhip::LaunchInfo info(const char* name, const ConvArgs& a) { return ConvOp<L, TileCfg<1, 1, 1, 2, 1>>::info(name, a); }
+  __device__ static __forceinline__ void run(const ConvArgs& a, int bx, int by, float* lds) { conv_rows_body<L, COLS>(a, bx, by, lds); }
+};
+
+}  // namespace rc

@@ -23,10 +23,11 @@
 #pragma once
 #include "chain_layers.hip.h"
 #include "fuse.hip.h"
+#include "rowchain.hip.h"
 
 namespace tick {
 
-constexpr int kMaxStages = 48, kRing = 64, kMaxCopies = 16;
+constexpr int kMaxStages = 32, kRing = 64, kMaxCopies = 16;
 
 struct Copy { unsigned char* dst; const unsigned char* src; int bytes; };
 struct Prolog {
@@ -50,53 +51,59 @@ static __global__ __launch_bounds__(256) void prologue_kernel(int* __restrict__ 
 
 using namespace bhip;
 using namespace wave_layers;
-// Tiling of the tick launches: 32 rows x 64 columns per workgroup, four wavefronts, each walking ALL reduction segments
-// of its column tile (one accumulator per segment, added in order): 256 threads and ~10-20 KB of LDS whatever the layer,
-// so several workgroups fit a CU at once -- a tick wants occupancy, not the shortest dependent chain.  Measured at 256
-// streams (ms per tick): 16x64 tiles 0.106, 32x64 0.104, 16x32 0.131, 128-wide k-chunks (152 VGPRs) 0.119.
-#ifndef TICK_KFEW
-#define TICK_KFEW false
+// Tilings of the tick launch.  Everything runs in 512-thread workgroups, two per CU (<= 128 VGPRs, <= 78 KB of LDS): the
+// stream-stationary bodies (conditioned blocks as two row-local chains each, rowchain.hip.h; the fused upsampler tail)
+// and the remaining layers as rc::conv_rows_body: 16 rows x the layer's whole width per workgroup, the A operand streamed
+// through LDS one 256-long reduction segment at a time, weights prefetched four k-blocks ahead.  A tick wants MFMA density and occupancy, not the shortest dependent chain: per-layer launches with
+// 16x32 tiles and 128-wide k-chunks (the in-order chain's choice) measured 0.224 ms per tick at 256 streams, 16x64 tiles
+// in 256-thread workgroups 0.104, this layout see DESIGN.md.
+#ifndef TICK_RB_COLS
+#define TICK_RB_COLS 0
 #endif
-#ifndef TICK_WM
-#define TICK_WM 2
-#endif
-#ifndef TICK_LN
-#define TICK_LN 4
-#endif
-template <class L> using TT = TileCfg<TICK_WM, 1, 1, TICK_LN, 1, TICK_KFEW>;
-template <class L> using CT = ConvOp<L, TT<L>>;
 using PL = PhoneLayers<1>;
 using QL1 = PitchLayers<1>;
+using OpF2 = rc::ConvRowsOp<PL::F2>;
+using OpF3 = rc::ConvRowsOp<PL::F3>;
+using OpF4 = rc::ConvRowsOp<PL::F4, TICK_RB_COLS>;
+using OpF5 = rc::ConvRowsOp<PL::F5, TICK_RB_COLS>;
+using OpRB = rc::ConvRowsOp<PL::RBL, TICK_RB_COLS>;
+using OpOUT = rc::ConvRowsOp<PL::OUTL>;
+using OpP1 = rc::ConvRowsOp<QL1::P1>;
+using OpP23 = rc::ConvRowsOp<QL1::P23>;
+using OpPOUT = rc::ConvRowsOp<QL1::POUT>;
+using OpINP = rc::ConvRowsOp<INP<1>>;
+using OpUP1 = rc::ConvRowsOp<UP<256, 128, 5, 1>, 128>;   // 640 columns: five slabs
+using OpRES1A = rc::ConvRowsOp<RES<128, 1, 5>>;
+using OpRES1B = rc::ConvRowsOp<RES<128, 3, 5>>;
+using OpUP2 = rc::ConvRowsOp<UP<128, 64, 4, 5>>;
 
-// main launch (256-thread workgroups)
 enum BodyType {
-  T_F1, T_FFT, T_F2, T_F3, T_F4, T_F5, T_P1, T_RB, T_P23, T_POUT, T_HEAD, T_OUT, T_COND, T_INP,
-  T_C1D1, T_C1D2, T_C1D4, T_C1D8, T_C2, T_Q, T_SCORE, T_PV, T_UP1, T_RES1A, T_RES1B, T_UP2, T_COUNT
+  T_F1, T_FFT, T_F2, T_F3, T_F4, T_F5, T_P1, T_RB, T_P23, T_POUT, T_HEAD, T_OUT, T_COND, T_INP, T_UP1, T_RES1A, T_RES1B, T_UP2,
+  T_QGRU, T_PGRU, T_VQ, T_TAIL, T_BLKA1, T_BLKA2, T_BLKA4, T_BLKA8, T_BLKB, T_COUNT
 };
-#define TICK_MAIN_TYPES                                                                                                        \
-    fuse::Many<F1Op, 1>, fuse::Many<FftOp, 1>, fuse::Many<CT<PL::F2>, 1>, fuse::Many<CT<PL::F3>, 1>, fuse::Many<CT<PL::F4>, 1>, \
-    fuse::Many<CT<PL::F5>, 1>, fuse::Many<CT<QL1::P1>, 1>, fuse::Many<CT<PL::RBL>, 4>, fuse::Many<CT<QL1::P23>, 2>,            \
-    fuse::Many<CT<QL1::POUT>, 1>, fuse::Many<HeadOp, 1>, fuse::Many<CT<PL::OUTL>, 1>, fuse::Many<CondOp, 1>,                    \
-    fuse::Many<CT<INP<1>>, 1>, fuse::Many<CT<C1<1, 1>>, 1>, fuse::Many<CT<C1<2, 1>>, 1>, fuse::Many<CT<C1<4, 1>>, 1>,           \
-    fuse::Many<CT<C1<8, 1>>, 1>, fuse::Many<CT<C2<1>>, 8>, fuse::Many<CT<QL<1>>, 4>, fuse::Many<CT<SCORE<1>>, 4>,               \
-    fuse::Many<AttnPvOp, 4>, fuse::Many<CT<UP<256, 128, 5, 1>>, 1>, fuse::Many<CT<RES<128, 1, 5>>, 1>,                          \
-    fuse::Many<CT<RES<128, 3, 5>>, 1>, fuse::Many<CT<UP<128, 64, 4, 5>>, 1>
-using Tab = fuse::Table<TICK_MAIN_TYPES>;
-using Builder = fuse::TableBuilder<TICK_MAIN_TYPES>;
-// second launch: the bodies with larger workgroups (the two GRU cells: six wavefronts; k-NN: one thread per codebook row)
-enum AuxType { A_QGRU, A_PGRU, A_VQ };
-#define TICK_AUX_TYPES fuse::Many<GruOp<128, 128>, 1>, fuse::Many<GruOp<256, 256>, 1>, fuse::Many<VqOp, 1>
-using AuxTab = fuse::Table<TICK_AUX_TYPES>;
-using AuxBuilder = fuse::TableBuilder<TICK_AUX_TYPES>;
+#define TICK_TYPES                                                                                                            \
+    fuse::Many<F1Op, 1>, fuse::Many<FftOp, 1>, fuse::Many<OpF2, 1>, fuse::Many<OpF3, 1>, fuse::Many<OpF4, 1>, fuse::Many<OpF5, 1>, \
+    fuse::Many<OpP1, 1>, fuse::Many<OpRB, 4>, fuse::Many<OpP23, 2>, fuse::Many<OpPOUT, 1>, fuse::Many<HeadOp, 1>,                  \
+    fuse::Many<OpOUT, 1>, fuse::Many<CondOp, 1>, fuse::Many<OpINP, 1>, fuse::Many<OpUP1, 1>, fuse::Many<OpRES1A, 1>,               \
+    fuse::Many<OpRES1B, 1>, fuse::Many<OpUP2, 1>, fuse::Many<GruOp<128, 128>, 1>, fuse::Many<GruOp<256, 256>, 1>,                  \
+    fuse::Many<VqOp, 1>, fuse::Many<TailOp<1>, 1>, fuse::Many<rc::BlockAOp<1>, 1>, fuse::Many<rc::BlockAOp<2>, 1>,                 \
+    fuse::Many<rc::BlockAOp<4>, 1>, fuse::Many<rc::BlockAOp<8>, 1>, fuse::Many<rc::BlockBOp, 4>
+using Tab = fuse::Table<TICK_TYPES>;
+using Builder = fuse::TableBuilder<TICK_TYPES>;
 
-// stage of each layer: the in-order chain's launch order, the pitch estimator zipped into the content encoder's
-// stages from the fourth launch on (its spectrum ring then has its reader one stage later, like every other ring)
-enum Stage {
-  S_F1 = 0, S_F2 = 1, S_F3 = 2, S_F4 = 3, S_FFT = 3, S_F5 = 4, S_P1 = 4, S_RB0 = 5, S_P2 = 5, S_RB1 = 6, S_P3 = 6, S_RB2 = 7, S_QGRU = 7,
-  S_RB3 = 8, S_POUT = 8, S_PGRU = 9, S_HEAD = 9, S_OUT = 10, S_COND = 10, S_VQ = 11, S_INP = 12, S_BLK0 = 13 /* c1 c2 q qk pv o */,
-  S_UP1 = 37, S_RES1A = 38, S_RES1B = 39, S_UP2 = 40, S_TAIL = 41, S_COUNT = 42
+// Stage of each body.  Front end: the in-order chain's launch order, the pitch estimator zipped into the content
+// encoder's stages from the fourth launch on (its spectrum ring then has its reader one stage later, like every other
+// ring).  A conditioned block is two stages (rowchain.hip.h).
+struct Plan {
+  static constexpr int F1 = 0, F2 = 1, F3 = 2, F4 = 3, FFT = 3, F5 = 4, P1 = 4, RB0 = 5, P2 = 5, QGRU = 7, POUT = 8, PGRU = 9, HEAD = 9,
+                       OUT = 10, COND = 10, VQ = 11, INP = 12, BLK0 = 13;
+  static constexpr int per_block = 2;  // stages per conditioned block
+  int blk(int b) const { return BLK0 + per_block * b; }
+  int up1() const { return blk(B_NBLOCKS); }
+  int tail() const { return up1() + 4; }
+  int count() const { return tail() + 1; }
 };
-static_assert(S_COUNT <= kMaxStages && S_COUNT + 2 <= kRing, "stage bookkeeping");
+static_assert(Plan::BLK0 + Plan::per_block * B_NBLOCKS + 5 <= kMaxStages && kMaxStages + 2 <= kRing, "stage bookkeeping");
 
 struct Consumer {  // a kernel that reads per-stream settings: its private copy of a byte range of the settings block
   int stage;
@@ -109,8 +116,9 @@ struct State {
   bool on = false;
   int* d_hops = nullptr;            // [kMaxStages][2]
   Tab* d_table = nullptr;
-  AuxTab* d_aux = nullptr;
-  int table_total = 0, aux_total = 0;
+  int table_total = 0;
+  double table_flops = 0, table_bytes = 0;  // algorithmic work of one full tick (sum over the bodies)
+  unsigned long long* d_trace = nullptr;  // BEATRICE_HIP_TICK_TRACE=<file>: per-workgroup timeline of the last full tick
   bool table_dirty = true;
   unsigned char* d_snap = nullptr;  // [kRing][snap_bytes] settings snapshots
   size_t snap_bytes = 0;
@@ -119,7 +127,9 @@ struct State {
   int snap_of_step[kRing], hop_of_step[kRing], io_of_step[kRing];
   int snap_cur = -1, snap_next = 0;
   std::vector<Consumer> consumers;
-  TailArgs tail;
+  Plan plan;
+  hipEvent_t* bracket = nullptr;  // BeatriceBatch_TimeTickLaunch: events recorded around this tick's pipeline launch
+  int bracket_at = 0;
 };
 
 }  // namespace tick

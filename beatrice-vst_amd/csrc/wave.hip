@@ -1,6 +1,9 @@
 // wave.hip -- waveform generator forward pass (MODEL_SPEC 4.4), the body of
 // Beatrice20rc0_GenerateWaveform1 (reference lib/beatricelib/beatrice.h:301-307) for B streams.
+#include <cstdlib>
+
 #include "chain_layers.hip.h"
+#include "rowchain.hip.h"
 
 namespace bhip {
 
@@ -117,8 +120,28 @@ static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t
     a.res = s.e;
     launch_auto<INP<H>>("wave.inp", a, st);
   }
+  // BEATRICE_HIP_ROWCHAIN=1: the conditioned blocks as two stream-stationary kernels each (rowchain.hip.h) instead of six
+  // per-layer launches -- for measurements and parity tests; the in-order chain is faster with the per-layer launches
+  static const bool rowchain = std::getenv("BEATRICE_HIP_ROWCHAIN") != nullptr;
   for (int blk = 0; blk < B_NBLOCKS; ++blk) {
     if (!in_part(2 + blk)) continue;
+    if (rowchain && H == 1) {
+      const rc::BlockAArgs aa{s.x[blk], k.xa, w.c1_w[blk], w.c1_b[blk], w.c2_w[blk], w.c2_b[blk], s.hop, B};
+      const dim3 ga((B + 15) / 16);
+      launch_site(rc::BlockAOp<1>::info(aa), st, [&] {
+        switch (blk) {
+          case 0: hipLaunchKernelGGL(rc::block_a_kernel<1>, ga, dim3(rc::NTHR), 0, st, aa); break;
+          case 1: hipLaunchKernelGGL(rc::block_a_kernel<2>, ga, dim3(rc::NTHR), 0, st, aa); break;
+          case 2: hipLaunchKernelGGL(rc::block_a_kernel<4>, ga, dim3(rc::NTHR), 0, st, aa); break;
+          default: hipLaunchKernelGGL(rc::block_a_kernel<8>, ga, dim3(rc::NTHR), 0, st, aa); break;
+        }
+      });
+      const rc::BlockBArgs ba{k.xa, s.x[blk + 1], w.q_w[blk], w.q_b[blk], w.o_w[blk], w.o_b[blk], s.d_kt[blk], s.d_v[blk],
+                              s.d_perm[blk], s.d_tile_slot[blk], s.hop};
+      launch_site(LaunchInfo{"wave.blk.b", 2.0 * rows * (256.0 * 256 * 2 + 256.0 * 384 * 2), 4.0 * (2.0 * 256 * 256 + 2.0 * 256 * 384 + rows * 3.0 * 256)}, st,
+                  [&] { hipLaunchKernelGGL(rc::block_b_kernel, dim3(s.n_tiles_max), dim3(rc::NTHR), 0, st, ba); });
+      continue;
+    }
     switch (blk) {
       case 0: launch_c1<1, H>(w, s, blk, k.h1, st); break;
       case 1: launch_c1<2, H>(w, s, blk, k.h1, st); break;

@@ -164,9 +164,10 @@ int BeatriceBatch_EnableGraph(BeatriceBatch* b, int enable);
 int BeatriceBatch_EnablePipelining(BeatriceBatch* b, int enable);
 void* BeatriceBatch_GetWaveStream(const BeatriceBatch* b);
 /* Tick pipelining: the deepest form of the same idea, on ONE stream.  Every layer of the chain is its own pipeline
- * stage; each BeatriceBatch_ConvertFramesDevice(b, NULL, NULL) is one "tick" -- a single launch in which stage s works
- * on the step fed s ticks ago, so ~40 steps are in flight and their ~5000 independent workgroups fill the chip, with
- * the kernel boundary between ticks as the only synchronisation.  Same samples, bit for bit; a step's output lands
+ * stage (the conditioned blocks: two stages each, as row-local chains); each BeatriceBatch_ConvertFramesDevice(b, NULL, NULL)
+ * is one "tick" -- a single launch of 512-thread workgroups in which stage s works on the step fed s ticks ago, so ~26
+ * steps are in flight and their ~2600 independent workgroups fill the chip two per CU, with the kernel boundary between
+ * ticks as the only synchronisation.  Same samples, bit for bit; a step's output lands
  * in its resident-I/O slot BeatriceBatch_TickStages() - 1 ticks after its input was fed, and BeatriceBatch_Synchronize
  * drains the pipeline (that many ticks without new input).  Settings changed between steps apply to exactly the step
  * they precede.  Requirements (-1 otherwise): one hop per step, at most 256 streams, resident I/O bound with more slots
@@ -174,6 +175,9 @@ void* BeatriceBatch_GetWaveStream(const BeatriceBatch* b);
  * The host-buffer, 48 kHz and profiling entry points return -1 while it is on. */
 int BeatriceBatch_EnableTickPipeline(BeatriceBatch* b, int enable);
 int BeatriceBatch_TickStages(const BeatriceBatch* b);
+/* Measurement hook (tick mode on, pipeline full): `ticks` (<= 64) more ticks, each pipeline launch bracketed by HIP
+ * events on the batch's stream: mean microseconds per launch + the launch's algorithmic FLOPs and bytes. */
+int BeatriceBatch_TimeTickLaunch(BeatriceBatch* b, int ticks, float* us_per_launch, double* flops, double* bytes);
 /* Optional: capture the hipGraphs of the current mode now (settings, I/O binding, pipelining as they stand; nothing
  * runs), so that the first steps do not spend milliseconds on it.  Otherwise it happens inside the first step. */
 int BeatriceBatch_Prepare(BeatriceBatch* b);

@@ -58,6 +58,7 @@ def test_tick_pipeline_matches_in_order_chain(bv, product, model_dir, B, steps, 
     settings(batch)
     a, h = batch.a, batch.h
     stages = a.BeatriceBatch_TickStages(h)
+    assert 8 <= stages <= 48
     slots = stages + 6
     d_in, d_out = hip.malloc(slots * B * 160 * 4), hip.malloc(slots * B * 240 * 4)
     assert a.BeatriceBatch_EnableTickPipeline(h, 1) == -1          # needs resident I/O

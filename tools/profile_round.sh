@@ -1,8 +1,8 @@
 #!/bin/bash
 # Measurement recipe of one round (run on a GPU box from the repo root, e.g. through gpurun):
 #   tools/profile_round.sh r01_e
-# (the profiled passes run the chain in order on one stream, --pipeline-depth 0, so that per-kernel durations are
-# those of the kernel alone, like the HIP-event timing inside bench.py; the headline line itself is pipelined)
+# (two sets of profiled passes: the headline configuration -- tick pipelining, whose dominant kernel is the tick launch --
+# and the chain in order on one stream, --pipeline off, where a kernel's duration is that of the kernel alone)
 # writes under gpurun_out/<tag>/: the bench line, the rocprofv3 kernel-trace/stats summary of the same
 # command, and three separate PMC passes (FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES) reduced to
 # per-kernel means.  Copy what
@@ -18,13 +18,18 @@ python "$ROOT/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -c 400 "$OUT/bench.err"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o k -- \
-  python "$ROOT/bench.py" --no-extras --pipeline-depth 0 --steps 200 --warmup 20 > "$OUT/bench_under_rocprof.json" 2> /dev/null
+  python "$ROOT/bench.py" --no-extras --steps 300 --warmup 20 > "$OUT/bench_under_rocprof.json" 2> /dev/null
 STATS=$(find "$OUT/prof" -name 'k_kernel_stats.csv' | head -1)
-[ -n "$STATS" ] && cp "$STATS" "$OUT/kernel_stats_B256.csv"
+[ -n "$STATS" ] && cp "$STATS" "$OUT/kernel_stats_B256_tick.csv"
+rm -rf "$OUT/prof"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o k -- \
+  python "$ROOT/bench.py" --no-extras --pipeline off --steps 200 --warmup 20 > /dev/null 2>&1
+STATS=$(find "$OUT/prof" -name 'k_kernel_stats.csv' | head -1)
+[ -n "$STATS" ] && cp "$STATS" "$OUT/kernel_stats_B256_in_order.csv"
 
 for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- \
-    python "$ROOT/bench.py" --no-extras --pipeline-depth 0 --steps 20 --warmup 5 > /dev/null 2>&1
+    python "$ROOT/bench.py" --no-extras --steps 200 --warmup 5 > /dev/null 2>&1
   CSV=$(find "$OUT/pmc_$C" -name 'pmc_counter_collection.csv' | head -1)
   mkdir -p "$OUT/pmc_r1_$C"
   [ -n "$CSV" ] && cp "$CSV" "$OUT/pmc_r1_$C/pmc_counter_collection.csv"
@@ -39,9 +44,10 @@ d = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
     d[r["Kernel_Name"]].append(float(r["Counter_Value"]))
 w = csv.writer(open(sys.argv[1].replace("pmc_counter_collection.csv", "per_kernel_mean.csv"), "w"))
-w.writerow(["kernel", "launches", "mean_%s%s" % (sys.argv[2], "_KiB" if sys.argv[2].endswith("SIZE") else "")])
+w.writerow(["kernel", "launches", "mean_%s%s" % (sys.argv[2], "_KiB" if sys.argv[2].endswith("SIZE") else ""), "median", "max"])
 for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
-    w.writerow([k, len(v), "%.2f" % (sum(v) / len(v))])
+    v2 = sorted(v)
+    w.writerow([k[:160], len(v), "%.2f" % (sum(v) / len(v)), "%.2f" % v2[len(v2) // 2], "%.2f" % v2[-1]])
 PY
   rm -f "$OUT/pmc_r1_$C/pmc_counter_collection.csv"
 done
