@@ -1,0 +1,158 @@
+// processor_proxy.cc -- see processor_proxy.h.
+#include "processor_proxy.h"
+
+#include <cmath>
+#include <cstring>
+#include <exception>
+
+namespace beatrice_amd {
+
+ProcessorProxy::ProcessorProxy() { state_.SetDefaultValues(); }
+
+ErrorCode ProcessorProxy::SetSampleRate(double sr) {
+  sample_rate_ = sr;
+  return core_ ? core_->SetSampleRate(sr) : ErrorCode::kSuccess;  // reference ProcessorCoreUnloaded accepts every setter
+}
+
+ErrorCode ProcessorProxy::Process(const float* in, float* out, int n) {
+  if (core_) return core_->Process(in, out, n);
+  std::memset(out, 0, sizeof(float) * (size_t)(n > 0 ? n : 0));  // reference processor_core.h:99-103
+  return ErrorCode::kModelNotLoaded;
+}
+ErrorCode ProcessorProxy::ResetContext() { return core_ ? core_->ResetContext() : ErrorCode::kSuccess; }
+
+// reference processor_proxy.h:45-100
+ErrorCode ProcessorProxy::LoadModel(const std::filesystem::path& file) {
+  ErrorCode error = ErrorCode::kSuccess;
+  std::unique_ptr<ProcessorCore2> fresh;
+  if (file.empty()) {
+    core_.reset();
+    return error;  // an empty path unloads without an error (processor_proxy.h:47-49)
+  }
+  std::error_code ec;
+  if (!std::filesystem::exists(file, ec)) {
+    core_.reset();
+    return ErrorCode::kFileOpenError;
+  }
+  try {
+    const toml_subset::Value root = toml_subset::ParseFile(file.string());
+    const ModelConfig config = ReadModelConfig(root);
+    switch (config.model.VersionInt()) {
+      case 2: fresh = std::make_unique<ProcessorCore2>(sample_rate_); break;
+      case 0: case 1:
+        // legacy generations: their parameter readers decline in this library (csrc/legacy.hip), which is what the
+        // reference's ProcessorCore0/1::LoadModel would report first
+        error = ErrorCode::kFileOpenError;
+        break;
+      default: error = ErrorCode::kInvalidModelConfig; break;
+    }
+    if (fresh) {
+      error = fresh->LoadModel(file);
+      if (error == ErrorCode::kSuccess) config_ = config;
+    }
+  } catch (const toml_subset::FileError&) { error = ErrorCode::kFileOpenError;
+  } catch (const toml_subset::SyntaxError&) { error = ErrorCode::kTOMLSyntaxError;
+  } catch (const toml_subset::TypeError&) { error = ErrorCode::kInvalidModelConfig;
+  } catch (const std::invalid_argument&) { error = ErrorCode::kInvalidModelConfig;
+  } catch (const std::out_of_range&) { error = ErrorCode::kInvalidModelConfig;
+  } catch (const std::exception&) { error = ErrorCode::kUnknownError; }
+  if (error != ErrorCode::kSuccess) {
+    core_.reset();  // "unloaded": zeros out
+    return error;
+  }
+  core_ = std::move(fresh);
+  return SyncAllParameters(param_id::kModel);
+}
+
+ErrorCode ProcessorProxy::SetParameter(std::int16_t id, ParameterState::Value value) {
+  state_.Set(id, std::move(value));
+  return SyncParameter(id);
+}
+
+// the processor-side rules of reference parameter_schema.cc:51-477
+ErrorCode ProcessorProxy::SyncParameter(std::int16_t id) {
+  using namespace param_id;
+  const auto it = Schema().find(id);
+  if (it == Schema().end() || !state_.Has(id)) return ErrorCode::kUnknownError;
+  const ParameterState::Value& v = state_.Get(id);
+  if ((int)v.index() != (int)it->second.kind) return ErrorCode::kUnknownError;  // (the reference's std::get would throw)
+  if (id == kModel) return LoadModel(std::filesystem::path(std::get<std::string>(v)));
+  if (!core_) return ErrorCode::kSuccess;  // unloaded core: every setter succeeds and does nothing
+  auto num = [&v] { return std::get<double>(v); };
+  auto integer = [&v] { return std::get<int>(v); };
+  switch (id) {
+    case kVoice: return core_->SetTargetSpeaker(integer());
+    case kFormantShift: return core_->SetFormantShift(num());
+    case kPitchShift: return core_->SetPitchShift(num());
+    case kAverageSourcePitch: return core_->SetAverageSourcePitch(num());
+    case kLock: return ErrorCode::kSuccess;
+    case kInputGain: return core_->SetInputGain(num());
+    case kOutputGain: return core_->SetOutputGain(num());
+    case kIntonationIntensity: return core_->SetIntonationIntensity(num());
+    case kPitchCorrection: return core_->SetPitchCorrection(num());
+    case kPitchCorrectionType: return core_->SetPitchCorrectionType(integer());
+    case kMinSourcePitch: return core_->SetMinSourcePitch(num());
+    case kMaxSourcePitch: return core_->SetMaxSourcePitch(num());
+    case kVQNumNeighbors: return core_->SetVQNumNeighbors((int)std::round(num()));
+    default: break;
+  }
+  if (id >= kVoiceMorphCursorX && id < kVoiceMorphMarkerYBase + kMaxNVoiceMorphMarkers)
+    return core_->SetSpeakerMorphingWeights(VoiceMorphWeights(state_));
+  return ErrorCode::kSuccess;  // average target pitches: controller-side only
+}
+
+ErrorCode ProcessorProxy::SyncAllParameters(std::int16_t ignore) {  // reference processor_proxy.cc:45-56
+  ErrorCode error = ErrorCode::kSuccess;
+  for (const auto& [id, info] : Schema()) {
+    (void)info;
+    if (id == ignore) continue;
+    if (const ErrorCode e = SyncParameter(id); e != ErrorCode::kSuccess) error = e;
+  }
+  return error;
+}
+
+ErrorCode ProcessorProxy::Read(const unsigned char* blob, size_t n) {  // reference processor_proxy.cc:58-63
+  const ErrorCode read = state_.ReadOrSetDefault(blob, n);
+  const ErrorCode sync = SyncAllParameters(-1);
+  return read == ErrorCode::kSuccess ? sync : read;
+}
+
+}  // namespace beatrice_amd
+
+// ---- C view for tests and non-C++ hosts -------------------------------------------------------------------------------
+using beatrice_amd::ProcessorProxy;
+extern "C" {
+void* BeatriceProxy_Create(void) { return new ProcessorProxy(); }
+void BeatriceProxy_Destroy(void* p) { delete static_cast<ProcessorProxy*>(p); }
+int BeatriceProxy_SetSampleRate(void* p, double sr) { return (int)static_cast<ProcessorProxy*>(p)->SetSampleRate(sr); }
+int BeatriceProxy_LoadModel(void* p, const char* toml_path) { return (int)static_cast<ProcessorProxy*>(p)->LoadModel(toml_path ? toml_path : ""); }
+int BeatriceProxy_SetNumber(void* p, int id, double v) { return (int)static_cast<ProcessorProxy*>(p)->SetParameter((std::int16_t)id, v); }
+int BeatriceProxy_SetInt(void* p, int id, int v) { return (int)static_cast<ProcessorProxy*>(p)->SetParameter((std::int16_t)id, v); }
+int BeatriceProxy_SetString(void* p, int id, const char* s) { return (int)static_cast<ProcessorProxy*>(p)->SetParameter((std::int16_t)id, std::string(s ? s : "")); }
+int BeatriceProxy_Process(void* p, const float* in, float* out, int n) { return (int)static_cast<ProcessorProxy*>(p)->Process(in, out, n); }
+int BeatriceProxy_ResetContext(void* p) { return (int)static_cast<ProcessorProxy*>(p)->ResetContext(); }
+int BeatriceProxy_CoreVersion(void* p) { return static_cast<ProcessorProxy*>(p)->CoreVersion(); }
+int BeatriceProxy_VoiceCount(void* p) { const auto* c = static_cast<ProcessorProxy*>(p)->Config(); return c ? beatrice_amd::GetVoiceCount(*c) : 0; }
+// parameter read-back: kind 0 int / 1 number / 2 string, -1 unknown id
+int BeatriceProxy_GetKind(void* p, int id) { const auto& st = static_cast<ProcessorProxy*>(p)->GetParameterState(); return st.Has((std::int16_t)id) ? (int)st.Get((std::int16_t)id).index() : -1; }
+double BeatriceProxy_GetNumber(void* p, int id) { const auto& v = static_cast<ProcessorProxy*>(p)->GetParameter((std::int16_t)id); return v.index() == 1 ? std::get<double>(v) : (v.index() == 0 ? (double)std::get<int>(v) : 0.0); }
+int BeatriceProxy_GetString(void* p, int id, char* buf, int cap) {
+  const auto& v = static_cast<ProcessorProxy*>(p)->GetParameter((std::int16_t)id);
+  if (v.index() != 2) return -1;
+  const std::string& s = std::get<std::string>(v);
+  if (buf && cap > 0) { const int n = (int)s.size() < cap - 1 ? (int)s.size() : cap - 1; std::memcpy(buf, s.data(), (size_t)n); buf[n] = '\0'; }
+  return (int)s.size();
+}
+// state blob: returns the size; copies when the buffer is large enough
+int BeatriceProxy_WriteState(void* p, unsigned char* buf, int cap) {
+  const std::vector<unsigned char> b = static_cast<ProcessorProxy*>(p)->Write();
+  if (buf && cap >= (int)b.size()) std::memcpy(buf, b.data(), b.size());
+  return (int)b.size();
+}
+int BeatriceProxy_ReadState(void* p, const unsigned char* buf, int n) { return (int)static_cast<ProcessorProxy*>(p)->Read(buf, (size_t)(n > 0 ? n : 0)); }
+// morph weights the current parameters imply (test hook)
+void BeatriceProxy_MorphWeights(void* p, float* out256) {
+  const auto w = beatrice_amd::VoiceMorphWeights(static_cast<ProcessorProxy*>(p)->GetParameterState());
+  std::memcpy(out256, w.data(), sizeof(float) * w.size());
+}
+}

@@ -64,3 +64,35 @@ def test_host_layer_morph_hip_matches_oracle(built, model_dir):
     print("morph max-abs", dev)
     assert np.abs(outs["hip"]).max() > 1e-3
     assert dev <= 1e-4
+
+
+def test_proxy_loads_package_by_toml_on_the_product(built, model_dir):
+    """`load a package by its .toml` as a product feature: ProcessorProxy (TOML reader, version dispatch, parameter
+    fan-out, state blob) linked against the HIP library gives the samples of the same host code on the oracle core,
+    and a state blob written by one restores the other."""
+    import ctypes as C
+    from test_host_proxy import K_MODEL, K_PITCH_SHIFT, K_VOICE, K_VQ, Proxy
+    x = wrapperlib.test_signal(480 * 16, 48000, seed=77)
+    outs, blobs = {}, {}
+    for name, path in (("oracle", hostlib.HOST_ON_ORACLE), ("hip", hostlib.HOST_PRODUCT)):
+        hostlib_path = hostlib.HOST_ON_ORACLE
+        hostlib.HOST_ON_ORACLE = path   # Proxy binds whatever library this names
+        try:
+            p = Proxy()
+        finally:
+            hostlib.HOST_ON_ORACLE = hostlib_path
+        assert p.call("SetString", K_MODEL, (model_dir + "/model.toml").encode()) == 0
+        assert p.call("CoreVersion") == 2
+        p.call("SetInt", K_VOICE, 2)
+        p.call("SetNumber", K_VQ, 2.0)
+        p.call("SetNumber", K_PITCH_SHIFT, -1.5)
+        outs[name], codes = p.process(x)
+        assert set(codes) == {0}
+        blobs[name] = p.state()
+        assert p.call("LoadModel", b"/nonexistent.toml") == 1 and p.call("CoreVersion") == -1   # unloaded: zeros
+        z, _ = p.process(x[:960])
+        assert not z.any()
+        p.close()
+    assert blobs["hip"] == blobs["oracle"]
+    assert np.abs(outs["hip"]).max() > 1e-3
+    assert np.abs(outs["hip"] - outs["oracle"]).max() <= 1e-4
