@@ -285,6 +285,12 @@ _BATCH = {
     "BeatriceBatch_ConvertFramesDevice": (C.c_int, [_vp, _vp, _vp]),
     "BeatriceBatch_ConvertBlocks48k": (C.c_int, [_vp, _f32p, _f32p, C.c_int]),
     "BeatriceBatch_ConvertBlocks48kDevice": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "BeatriceBatch_ConfigureWrapper": (C.c_int, [_vp, C.c_double]),
+    "BeatriceBatch_SetInputGain": (C.c_int, [_vp, C.c_int, C.c_double]),
+    "BeatriceBatch_SetOutputGain": (C.c_int, [_vp, C.c_int, C.c_double]),
+    "BeatriceBatch_ProcessBlocks": (C.c_int, [_vp, _f32p, _f32p, C.c_int, C.c_int]),
+    "BeatriceBatch_ProcessBlocksDevice": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int]),
+    "BeatriceBatch_MaxWrapperBlock": (C.c_int, [_vp]),
     "BeatriceBatch_Synchronize": (C.c_int, [_vp]),
     "BeatriceBatch_BindResidentIO": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "BeatriceBatch_SetStream": (C.c_int, [_vp, _vp]),

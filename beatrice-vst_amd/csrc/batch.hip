@@ -22,6 +22,7 @@
 #include "abi_objects.h"
 #include "beatrice_batch.h"
 #include "tick.hip.h"
+#include "wrapper.hip.h"
 
 using namespace bhip;
 
@@ -178,6 +179,13 @@ struct BeatriceBatch {
   int io_host = 0;            // mirror of the device's resident-I/O slot counter
   int last_hop = 0;           // step counter of the last enqueued step (selects the slot of the pitch head's outputs)
   tick::State tk;             // tick pipelining (tick.hip.h)
+  // any-rate device wrapper (wrapper.hip.h): the reference host's gains, resampler pair and 480-sample FIFO for all streams
+  wrapn::WrapPlan wrap;
+  std::vector<wrapn::GainClock> gain_in, gain_out;  // [B]
+  wrapn::StreamState* d_wrap = nullptr;             // [B]
+  float *d_wrap_taps = nullptr, *d_wrap_inner = nullptr, *d_wrap_io = nullptr, *h_wrap_io = nullptr;  // taps: down | up; inner [B][kInnerStride]
+  Mirror<wrapn::GainSeg> wrap_gains;                // [2][B]: input | output segments of the current call
+  bool wrap_gains_constant = false;                 // the device copy holds constant segments that are still right
   // 48 kHz device wrapper (configs[4])
   Wrap48State* d_w48 = nullptr;
   float *d_coef_down = nullptr, *d_coef_up = nullptr, *d_io48 = nullptr, *h_io48 = nullptr;  // io: in [B][2][480] | out [B][2][480]
@@ -889,6 +897,9 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   if (!b) return;
   if (b->stream) (void)sync_all(b);
   drop_graph(b);
+  { void* wr[] = {b->d_wrap, b->d_wrap_taps, b->d_wrap_inner, b->d_wrap_io, b->wrap_gains.d}; for (void* p : wr) if (p) (void)hipFree(p); }
+  if (b->h_wrap_io) (void)hipHostFree(b->h_wrap_io);
+  b->wrap_gains.release();
   { void* tk[] = {b->tk.d_hops, b->tk.d_table, b->tk.d_snap, b->tk.d_trace}; for (void* p : tk) if (p) (void)hipFree(p); }
   if (b->own_d_out) { b->wave.d_out = b->own_d_out; b->own_d_out = nullptr; }
   if (b->module_owned[0]) {  // hand the modules their own arrays back so that destroy() frees what it allocated
@@ -1214,6 +1225,127 @@ int BeatriceBatch_ConvertBlocks48k(BeatriceBatch* b, const float* in, float* out
   b->inflight = false;
   if (ok) std::memcpy(out, h_out, sizeof(float) * n);
   else std::memset(out, 0, sizeof(float) * n);
+  return ok ? 0 : -2;
+}
+
+// ---- host-rate blocks with the whole wrapper on the device (wrapper.hip.h) -------------------------------------------
+namespace { constexpr int kInnerStride = wrapn::kMaxSamples + 64; }
+int BeatriceBatch_ConfigureWrapper(BeatriceBatch* b, double sample_rate) {
+  if (!b || !b->ok) return -2;
+  if (b->H != 1) return -1;
+  if (!sync_all(b)) return -2;
+  if (!b->wrap.configure(sample_rate)) return -1;  // rate <= 0, or a ratio whose filter history exceeds the state block
+  const int B = b->B;
+  const size_t nt = b->wrap.taps_down.size();
+  bool ok = true;
+  if (!b->d_wrap) {
+    ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_wrap), sizeof(wrapn::StreamState) * B), "wrap state") &&
+         hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_wrap_inner), sizeof(float) * B * kInnerStride), "wrap inner") &&
+         hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_wrap_io), sizeof(float) * B * 4 * wrapn::kMaxSamples), "wrap io") &&
+         hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_wrap_io), sizeof(float) * B * 4 * wrapn::kMaxSamples, hipHostMallocDefault), "wrap io host") &&
+         b->wrap_gains.alloc_host(2 * (size_t)B) &&
+         hip_ok(hipMalloc(reinterpret_cast<void**>(&b->wrap_gains.d), sizeof(wrapn::GainSeg) * 2 * B), "wrap gains");
+    b->gain_in.assign(B, wrapn::GainClock());
+    b->gain_out.assign(B, wrapn::GainClock());
+  }
+  if (b->d_wrap_taps) { (void)hipFree(b->d_wrap_taps); b->d_wrap_taps = nullptr; }
+  ok = ok && hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_wrap_taps), sizeof(float) * 2 * nt), "wrap taps") &&
+       hip_ok(hipMemcpy(b->d_wrap_taps, b->wrap.taps_down.data(), sizeof(float) * nt, hipMemcpyHostToDevice), "taps down") &&
+       hip_ok(hipMemcpy(b->d_wrap_taps + nt, b->wrap.taps_up.data(), sizeof(float) * nt, hipMemcpyHostToDevice), "taps up") &&
+       hip_ok(hipMemset(b->d_wrap, 0, sizeof(wrapn::StreamState) * B), "wrap state0") && hip_ok(hipDeviceSynchronize(), "wrap sync");
+  b->wrap_gains_constant = false;
+  // (a new rate restarts the resampler and the FIFO as the reference's SetSampleRate does; the gains keep their state,
+  //  now ramping at the new rate: reference processor_core_2.cc:421-429)
+  return ok ? 0 : -2;
+}
+// reference ProcessorCore2::SetInputGain / SetOutputGain (processor_core_2.cc:488-496): the target; the ramp follows at 2 dB/ms
+int BeatriceBatch_SetInputGain(BeatriceBatch* b, int stream, double db) {
+  if (!b || !b->ok) return -2;
+  if (stream < -1 || stream >= b->B || b->gain_in.empty()) return -1;
+  for (int s = (stream < 0 ? 0 : stream); s < (stream < 0 ? b->B : stream + 1); ++s) b->gain_in[s].target_db = db;
+  return 0;
+}
+int BeatriceBatch_SetOutputGain(BeatriceBatch* b, int stream, double db) {
+  if (!b || !b->ok) return -2;
+  if (stream < -1 || stream >= b->B || b->gain_out.empty()) return -1;
+  for (int s = (stream < 0 ? 0 : stream); s < (stream < 0 ? b->B : stream + 1); ++s) b->gain_out[s].target_db = db;
+  return 0;
+}
+static bool wrap_chunk(BeatriceBatch* b, const float* d_in, float* d_out, int channels, int n) {
+  using namespace wrapn;
+  const int B = b->B;
+  hipStream_t st = b->stream;
+  WrapPlan& w = b->wrap;
+  // gains: this call's segment per stream; the device copy is refreshed unless it already holds the same constants
+  bool all_constant = true;
+  GainSeg* seg = b->wrap_gains.h;
+  for (int s = 0; s < B; ++s) {
+    const GainSeg gi = b->gain_in[s].advance(n, w.rate), go = b->gain_out[s].advance(n, w.rate);
+    all_constant = all_constant && gi.step == 1.0 && go.step == 1.0 && seg[s].step == 1.0 && seg[B + s].step == 1.0 &&
+                   seg[s].amp0 == gi.amp0 && seg[B + s].amp0 == go.amp0;
+    seg[s] = gi;
+    seg[B + s] = go;
+  }
+  if (!(all_constant && b->wrap_gains_constant)) {
+    const size_t off = 0, len = 2 * (size_t)B;
+    GainSeg* dst = nullptr;
+    if (!b->wrap_gains.push_parts(st, 1, &off, &len, &dst)) return false;
+    b->wrap_gains_constant = all_constant;
+  }
+  const size_t nt = w.taps_down.size();
+  const Dir din = w.to_inner(n);
+  const int m = din.n_out;
+  if (m < 0 || m > kMaxSamples) return false;
+  hipLaunchKernelGGL(wrap_in_kernel, dim3(B), dim3(256), 0, st, d_in, channels, n, b->d_wrap, b->wrap_gains.d, b->d_wrap_taps + (din.decimate ? 0 : nt), din,
+                     b->d_wrap_inner, kInnerStride);
+  for (int at = 0; at < m;) {  // the exact-480 FIFO; a model hop every time it fills
+    const int take = std::min(kBlock - w.fill, m - at);
+    const int fires = w.fill + take == kBlock ? 1 : 0;
+    hipLaunchKernelGGL(wrap_fifo_kernel, dim3(B), dim3(256), 0, st, b->d_wrap_inner, kInnerStride, b->d_wrap, at, w.fill, take, fires, b->d_in);
+    if (fires) {
+      if (!step_device(b, nullptr, nullptr)) return false;
+      hipLaunchKernelGGL(wrap_refill_kernel, dim3((B * kBlock + 255) / 256), dim3(256), 0, st, b->d_wrap, b->wave.d_out, B);
+      w.fill = 0;
+    } else {
+      w.fill += take;
+    }
+    at += take;
+  }
+  const Dir dout = w.to_outer(m);
+  if (dout.n_out != n) return false;  // the two clocks are coupled so that a block comes back with its own length
+  hipLaunchKernelGGL(wrap_out_kernel, dim3(B), dim3(256), 0, st, b->d_wrap_inner, kInnerStride, b->d_wrap, b->wrap_gains.d + B,
+                     b->d_wrap_taps + (dout.decimate ? 0 : nt), dout, d_out, channels);
+  return hip_ok(hipGetLastError(), "wrapper launch");
+}
+static int wrap_max_chunk(const BeatriceBatch* b) {  // host samples per launch so that neither side exceeds the kernels' LDS buffers
+  const double r = b->wrap.rate / 48000.0;
+  return std::max(1, (int)std::floor((wrapn::kMaxSamples - 8) * std::min(1.0, r)));
+}
+// in / out: [B][channels][n] planar at the configured host rate; any n >= 1 (long blocks are processed in pieces)
+int BeatriceBatch_ProcessBlocksDevice(BeatriceBatch* b, const float* d_in, float* d_out, int channels, int n) {
+  if (!b || !b->ok) return -2;
+  if (!b->wrap.ready || channels < 1 || channels > 2 || !d_in || !d_out || n < 1 || b->H != 1 || b->io_slots > 0 || b->pipelined || b->tk.on) return -1;
+  const int piece = wrap_max_chunk(b);
+  if (n <= piece) return wrap_chunk(b, d_in, d_out, channels, n) ? 0 : -2;
+  return -1;  // the planar layout [B][channels][n] cannot be cut without copies: callers pass blocks of at most `piece` samples
+}
+int BeatriceBatch_MaxWrapperBlock(const BeatriceBatch* b) { return b && b->ok && b->wrap.ready ? wrap_max_chunk(b) : 0; }
+int BeatriceBatch_ProcessBlocks(BeatriceBatch* b, const float* in, float* out, int channels, int n) {
+  if (!b || !b->ok) return -2;
+  if (!b->wrap.ready || channels < 1 || channels > 2 || !in || !out || n < 1 || n > wrap_max_chunk(b) || b->H != 1 || b->io_slots > 0 || b->pipelined || b->tk.on) return -1;
+  const size_t cnt = (size_t)b->B * channels * n;
+  float* h_in = b->h_wrap_io;
+  float* h_out = b->h_wrap_io + (size_t)b->B * 2 * wrapn::kMaxSamples;
+  float* d_in = b->d_wrap_io;
+  float* d_out = b->d_wrap_io + (size_t)b->B * 2 * wrapn::kMaxSamples;
+  std::memcpy(h_in, in, sizeof(float) * cnt);
+  bool ok = hip_ok(hipMemcpyAsync(d_in, h_in, sizeof(float) * cnt, hipMemcpyHostToDevice, b->stream), "wrap in");
+  ok = ok && wrap_chunk(b, d_in, d_out, channels, n);
+  ok = ok && hip_ok(hipMemcpyAsync(h_out, d_out, sizeof(float) * cnt, hipMemcpyDeviceToHost, b->stream), "wrap out");
+  ok = hip_ok(hipStreamSynchronize(b->stream), "wrap sync") && ok;
+  b->inflight = false;
+  if (ok) std::memcpy(out, h_out, sizeof(float) * cnt);
+  else std::memset(out, 0, sizeof(float) * cnt);
   return ok ? 0 : -2;
 }
 

@@ -147,6 +147,23 @@ int BeatriceBatch_BindResidentIO(BeatriceBatch* b, const float* d_in, float* d_o
 int BeatriceBatch_ConvertBlocks48k(BeatriceBatch* b, const float* in, float* out, int channels);
 int BeatriceBatch_ConvertBlocks48kDevice(BeatriceBatch* b, const float* d_in, float* d_out, int channels);
 
+/* The same wrapper at ANY host rate and block size, with the dB-ramped gains (the whole of the reference's
+ * ProcessorCore2::Process, src/common/processor_core_2.cc:24-48, per stream on the device): input gain (gain.h:41-71,
+ * 2 dB/ms towards the target) -> host rate to 48 kHz (resample.h:130-237: Stern-Brocot ratio, Hann-windowed sinc tables) ->
+ * exact-480 FIFO -> every third sample -> model hop -> zero-stuffing -> 48 kHz to host rate -> output gain -> every channel.
+ * BeatriceBatch_ConfigureWrapper sets the host rate for the batch (restarting resampler and FIFO, like SetSampleRate);
+ * BeatriceBatch_ProcessBlocks[Device] converts one block of n samples per stream, [B][channels][n] planar, channels 1 or 2
+ * (stereo is down-mixed (L+R)*0.5 as src/vst/processor.cc:183-192 does); n may change from call to call, up to
+ * BeatriceBatch_MaxWrapperBlock(b) (4088 samples at the higher of the two rates).  A model hop runs whenever 480 samples
+ * at 48 kHz have accumulated (0, 1 or several times per call).  Bit-identical to the host chain.  One 10 ms hop per step
+ * batches only, pipelining off. */
+int BeatriceBatch_ConfigureWrapper(BeatriceBatch* b, double host_sample_rate);
+int BeatriceBatch_SetInputGain(BeatriceBatch* b, int stream, double gain_db);
+int BeatriceBatch_SetOutputGain(BeatriceBatch* b, int stream, double gain_db);
+int BeatriceBatch_ProcessBlocks(BeatriceBatch* b, const float* in, float* out, int channels, int n_samples);
+int BeatriceBatch_ProcessBlocksDevice(BeatriceBatch* b, const float* d_in, float* d_out, int channels, int n_samples);
+int BeatriceBatch_MaxWrapperBlock(const BeatriceBatch* b);
+
 /* Execution control: use an externally owned hipStream_t (e.g. the framework's current stream);
  * replay the per-hop kernel chain from a captured hipGraph (default on). */
 int BeatriceBatch_SetStream(BeatriceBatch* b, void* hip_stream);
