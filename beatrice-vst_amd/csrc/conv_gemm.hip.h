@@ -134,8 +134,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bx, 
     wbase += (size_t)slot * a.w_slot_stride;
   }
 
-  const int hop = *a.hop;
-  if (hop < 0) return;  // this stage has no step this tick (pipeline fill / drain, batch.hip tick mode)
+  const int hop = *a.hop;   // (-1: this stage has no step this tick -- pipeline fill / drain of the batch's tick mode; checked
+                            //  below, AFTER the first weight loads are issued, so that it costs the chain no extra latency)
   const int pos_in = ring_pos(a.in, hop);
 
   // per-thread A staging slots: which (stream, t) row and which 16-byte piece
@@ -170,13 +170,12 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bx, 
   float4 bnext[TC::WN][KB], bcur[TC::WN][KB];
   const float4* wfrag = reinterpret_cast<const float4*>(wbase) + (size_t)((n0 + wave_n) >> 4) * (L::K >> 4) * 64 + lane;
   // chunk `it` of this group: LK == 1 -> global chunk it; LK == P -> chunk it of segment grp
-  auto load_chunk = [&](int it) {
+  // weights first: their addresses do not depend on the step counter, so the loads are in flight
+  // while the scalar counter load that the ring addresses of the A operand wait for completes
+  auto load_w = [&](int it) {
     const int ch = LK == 1 ? it : grp * CHUNKS_PER_SEG + it;
     const bool live = ch < NCHUNK;
     const int kk0 = ch * KC;
-    const int j = kk0 / L::CIN, c0 = kk0 % L::CIN;
-    // weights first: their addresses do not depend on the step counter, so the loads are in flight
-    // while the scalar counter load that the ring addresses below wait for completes
 #pragma unroll
     for (int jn = 0; jn < TC::WN; ++jn)
 #pragma unroll
@@ -185,6 +184,12 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bx, 
         const float4 f = wfrag[((size_t)jn * (L::K >> 4) + kbg) * 64];
         bnext[jn][kb] = live ? f : make_float4(0.f, 0.f, 0.f, 0.f);
       }
+  };
+  auto load_a = [&](int it) {
+    const int ch = LK == 1 ? it : grp * CHUNKS_PER_SEG + it;
+    const bool live = ch < NCHUNK;
+    const int kk0 = ch * KC;
+    const int j = kk0 / L::CIN, c0 = kk0 % L::CIN;
 #pragma unroll
     for (int s = 0; s < A_SLOTS; ++s) {
       const int idx = gtid + s * GTHR;
@@ -218,8 +223,11 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bx, 
       for (int kb = 0; kb < KB; ++kb) bcur[jn][kb] = bnext[jn][kb];
   };
 
+  auto load_chunk = [&](int it) { load_w(it); load_a(it); };
   constexpr int N_IT = LK == 1 ? NCHUNK : (CHUNKS_PER_SEG < NCHUNK ? CHUNKS_PER_SEG : NCHUNK);
-  load_chunk(0);
+  load_w(0);
+  if (hop < 0) return;
+  load_a(0);
 
   // ---- few-row tiling: the epilogue's operands (bias, residual, row scale) and output addresses are
   // fetched now, behind the first chunk's loads, instead of after the MFMA chain (one global-memory

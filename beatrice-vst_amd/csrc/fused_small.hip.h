@@ -147,12 +147,10 @@ __device__ __forceinline__ void attn_pv_body(const AttnPvArgs& a, const int bx, 
   float* red = inv + 16;         // [2][16][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = wave >> 1, wn = wave & 1;
-  const int hop = *a.hop;
-  if (hop < 0) return;
+  const int hop = *a.hop;  // (checked after the V fragment loads are issued)
   const int slot = a.tile_slot[bx];
   if (slot < 0) return;
   const int n0 = by * NT;
-  const int H = a.scores.n, pos_s = ring_pos(a.scores, hop), pos_o = ring_pos(a.out, hop);
   // B fragments of this wave: segment grp (keys 0..255 or 256..383), column tile (n0 + wn*16)/16
   float4 bf[16];
   {
@@ -161,6 +159,8 @@ __device__ __forceinline__ void attn_pv_body(const AttnPvArgs& a, const int bx, 
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) bf[kb] = vp[(size_t)((grp == 0 || kb < 8) ? kb : 0) * 64];
   }
+  if (hop < 0) return;
+  const int H = a.scores.n, pos_s = ring_pos(a.scores, hop), pos_o = ring_pos(a.out, hop);
   // softmax statistics, 4 rows per wavefront (MODEL_SPEC 4.4.2); all 24 score loads of the wave are
   // issued before the first reduction so that the rows do not pay one memory latency each
   {
