@@ -10,6 +10,7 @@
 //   * per-hop calls do not allocate: device state, pinned staging and the HIP stream are created in
 //     Create*Context1, which the host calls from non-real-time threads (processor_core_2.cc:259-266).
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <mutex>
@@ -79,6 +80,25 @@ bool wait_stream(hipStream_t s) {
   return hip_ok(hipStreamSynchronize(s), "sync");
 }
 
+// Runs `enqueue` (copies + kernels on `s`) through the context's captured graph; captures it first when there is none for
+// this model / variant.  BEATRICE_HIP_NO_HOP_GRAPH=1: plain launches (measurements).
+template <class F>
+static bool run_hop(HopGraph& g, const void* model, int variant, hipStream_t s, F enqueue) {
+  static const bool eager = std::getenv("BEATRICE_HIP_NO_HOP_GRAPH") != nullptr;
+  if (eager) { enqueue(); return hip_ok(hipGetLastError(), "hop launch"); }
+  if (!g.exec || g.model != model || g.variant != variant) {
+    g.drop();
+    BHIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    enqueue();
+    BHIP_TRY(hipStreamEndCapture(s, &g.graph));
+    BHIP_TRY(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+    g.model = model;
+    g.variant = variant;
+  }
+  BHIP_TRY(hipGraphLaunch(g.exec, s));
+  return true;
+}
+
 }  // namespace bhip
 
 extern "C" {
@@ -129,6 +149,7 @@ Beatrice20rc0_PhoneContext1* Beatrice20rc0_CreatePhoneContext1(void) {
 void Beatrice20rc0_DestroyPhoneContext1(Beatrice20rc0_PhoneContext1* c) {
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->hop_graph.drop();
   if (c->own_sel[0]) {
     c->st.d_vqk = static_cast<int*>(c->own_sel[0]);
     c->st.d_cbT = static_cast<const float**>(c->own_sel[1]);
@@ -209,9 +230,11 @@ void Beatrice20rc0_ExtractPhone1(const Beatrice20rc0_PhoneExtractor* m, const fl
     std::memcpy(mb + 4, &ctx->sel_cnorm, sizeof(float*));
   }
   ctx->hop_count = hop_next(ctx->hop_count);
-  bool ok = hip_ok(hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * (B_IN_HOP + kMailboxWords), hipMemcpyHostToDevice, ctx->stream), "in");
-  phone_forward(m->w, ctx->st, ctx->stream);
-  ok = ok && hip_ok(hipMemcpyAsync(h_out, ctx->st.d_phone, sizeof(float) * B_PHONE_CH, hipMemcpyDeviceToHost, ctx->stream), "out");
+  bool ok = run_hop(ctx->hop_graph, m, ctx->st.skip_vq ? 0 : 1, ctx->stream, [&] {
+    (void)hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * (B_IN_HOP + kMailboxWords), hipMemcpyHostToDevice, ctx->stream);
+    phone_forward(m->w, ctx->st, ctx->stream);
+    (void)hipMemcpyAsync(h_out, ctx->st.d_phone, sizeof(float) * B_PHONE_CH, hipMemcpyDeviceToHost, ctx->stream);
+  });
   ok = wait_stream(ctx->stream) && ok;
   if (ok) std::memcpy(output, h_out, sizeof(float) * B_PHONE_CH);
 }
@@ -247,6 +270,7 @@ Beatrice20rc0_PitchContext1* Beatrice20rc0_CreatePitchContext1(void) {
 void Beatrice20rc0_DestroyPitchContext1(Beatrice20rc0_PitchContext1* c) {
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->hop_graph.drop();
   if (c->own_sel[0]) { c->st.d_min_q = static_cast<int*>(c->own_sel[0]); c->st.d_max_q = static_cast<int*>(c->own_sel[1]); }
   c->st.destroy();
   if (c->h_io) (void)hipHostFree(c->h_io);
@@ -278,10 +302,12 @@ void Beatrice20rc0_EstimatePitch1(const Beatrice20rc0_PitchEstimator* m, const f
     mb[0] = ctx->hop_count; mb[1] = ctx->min_q; mb[2] = ctx->max_q;
   }
   ctx->hop_count = hop_next(ctx->hop_count);
-  bool ok = hip_ok(hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * (B_IN_HOP + kMailboxWords), hipMemcpyHostToDevice, ctx->stream), "in");
-  pitch_forward(m->w, ctx->st, ctx->stream);
-  ok = ok && hip_ok(hipMemcpyAsync(h_feat, ctx->st.d_feat, sizeof(float) * 4, hipMemcpyDeviceToHost, ctx->stream), "feat");
-  ok = ok && hip_ok(hipMemcpyAsync(h_q, ctx->st.d_q_raw, sizeof(int), hipMemcpyDeviceToHost, ctx->stream), "q");
+  bool ok = run_hop(ctx->hop_graph, m, 0, ctx->stream, [&] {
+    (void)hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * (B_IN_HOP + kMailboxWords), hipMemcpyHostToDevice, ctx->stream);
+    pitch_forward(m->w, ctx->st, ctx->stream);
+    (void)hipMemcpyAsync(h_feat, ctx->st.d_feat, sizeof(float) * 4, hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipMemcpyAsync(h_q, ctx->st.d_q_raw, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+  });
   ok = wait_stream(ctx->stream) && ok;
   if (ok) { *out_q = *h_q; std::memcpy(out_feat, h_feat, sizeof(float) * 4); }
 }
@@ -317,6 +343,7 @@ Beatrice20rc0_WaveformContext1* Beatrice20rc0_CreateWaveformContext1(void) {
 void Beatrice20rc0_DestroyWaveformContext1(Beatrice20rc0_WaveformContext1* c) {
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->hop_graph.drop();
   c->st.destroy();
   if (c->d_inputs) (void)hipFree(c->d_inputs);
   if (c->h_io) (void)hipHostFree(c->h_io);
@@ -336,9 +363,11 @@ void Beatrice20rc0_GenerateWaveform1(const Beatrice20rc0_WaveformGenerator* m, c
   std::memcpy(h_in + B_PHONE_CH + 4, q, sizeof(int));
   std::memcpy(h_in + B_PHONE_CH + 5, &ctx->hop_count, sizeof(int));
   ctx->hop_count = hop_next(ctx->hop_count);
-  bool ok = hip_ok(hipMemcpyAsync(ctx->d_inputs, h_in, sizeof(float) * in_floats, hipMemcpyHostToDevice, ctx->stream), "in");
-  wave_forward(m->w, ctx->st, ctx->stream);
-  ok = ok && hip_ok(hipMemcpyAsync(h_out, ctx->st.d_out, sizeof(float) * B_OUT_HOP, hipMemcpyDeviceToHost, ctx->stream), "out");
+  bool ok = run_hop(ctx->hop_graph, m, 0, ctx->stream, [&] {
+    (void)hipMemcpyAsync(ctx->d_inputs, h_in, sizeof(float) * in_floats, hipMemcpyHostToDevice, ctx->stream);
+    wave_forward(m->w, ctx->st, ctx->stream);
+    (void)hipMemcpyAsync(h_out, ctx->st.d_out, sizeof(float) * B_OUT_HOP, hipMemcpyDeviceToHost, ctx->stream);
+  });
   ok = wait_stream(ctx->stream) && ok;
   if (ok) std::memcpy(output, h_out, sizeof(float) * B_OUT_HOP);
 }

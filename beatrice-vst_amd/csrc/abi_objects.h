@@ -26,6 +26,23 @@ struct Beatrice20rc0_PitchEstimator { bhip::DeviceBlob blob; bhip::PitchWeights 
 struct Beatrice20rc0_WaveformGenerator { bhip::DeviceBlob blob; bhip::WaveWeights w{}; bool loaded = false; };
 struct Beatrice20rc0_EmbeddingSetter { bhip::DeviceBlob blob; bhip::EmbedWeights w{}; bool loaded = false; };
 
+// One per-hop call = one hipGraph launch (input copy, the module's kernels, output copy), captured at the first hop of a
+// context with a given model (and again when the set of launches changes: k-NN on / off).  ~1-2 ms once, on the thread
+// that makes the first call; afterwards a call costs one graph launch of host time instead of 7-30 kernel launches.
+namespace bhip {
+struct HopGraph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  const void* model = nullptr;
+  int variant = -1;
+  void drop() {
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    exec = nullptr; graph = nullptr; model = nullptr; variant = -1;
+  }
+};
+}  // namespace bhip
+
 // per-stream contexts: device state for ONE stream + a private HIP stream + pinned staging
 struct Beatrice20rc0_PhoneContext1 {
   bhip::PhoneState st;
@@ -48,6 +65,7 @@ struct Beatrice20rc0_PhoneContext1 {
   int stage_next = 0;
   unsigned long long use_clock = 0;
   void* own_sel[3] = {nullptr, nullptr, nullptr};  // the state's own (unused) selector arrays, handed back before destroy()
+  bhip::HopGraph hop_graph;
   bool ok = false;
 };
 struct Beatrice20rc0_PitchContext1 {
@@ -57,6 +75,7 @@ struct Beatrice20rc0_PitchContext1 {
   int hop_count = 0;
   int min_q = 1, max_q = BEATRICE_20RC0_PITCH_BINS - 1;  // travel with the input copy
   void* own_sel[2] = {nullptr, nullptr};
+  bhip::HopGraph hop_graph;
   bool ok = false;
 };
 struct Beatrice20rc0_WaveformContext1 {
@@ -65,6 +84,7 @@ struct Beatrice20rc0_WaveformContext1 {
   float* d_inputs = nullptr;  // device: 128 phone | 4 feat | 1 bin | step counter
   float* h_io = nullptr;      // pinned: inputs | 240 out
   int hop_count = 0;
+  bhip::HopGraph hop_graph;
   bool ok = false;
 };
 struct Beatrice20rc0_EmbeddingContext {

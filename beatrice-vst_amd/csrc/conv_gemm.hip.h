@@ -447,13 +447,24 @@ static inline void launch_conv(const char* name, const ConvArgs& a, int n_group_
 template <class L> using TLat = TileCfg<1, 1, 1, 2, L::P>;  // 16 x 32 tile, one 2-wave k-group per segment
 using TL = TileCfg<2, 2, 2, 2, 1>;                            // 64 x 64 tile, segments interleaved
 
+#include "gemv.hip.h"  // (needs everything above; defines gemv::launch)
+
 // Layers with few rows are bound by the dependent MFMA chain and by how many CUs get a tile: use
-// small tiles and one k-group per segment.  Layers with many rows are throughput-bound: 64 x 64.
+// small tiles and one k-group per segment.  Layers with many rows are throughput-bound: 64 x 64.  A handful of rows
+// (the 1-stream C-ABI): one FMA chain per lane instead of a mostly empty MFMA tile (gemv.hip.h).
 template <class L>
 static inline void launch_auto(const char* name, const ConvArgs& a, hipStream_t s) {
   // (a single-shot variant that issues every load up front -- tools/microbench/lat_gemm.hip.h -- measured
   //  slower on MI355X: 5.5 vs 4.9 us for a 256->256 linear at 256 rows, profiles/r01_notes.md; overlapping
   //  the chunked loads with the MFMA chain wins)
+  // measured at one stream (us per launch, gemv vs few-row MFMA tiling): 256->256 linear 7.2 vs 5.0, k4 s2 convs 8.1-8.7 vs
+  // 6.5-6.8 -- a single 256-long chain per lane pays the same serial memory round trips as the MFMA kernel and has no
+  // second wavefront to hide them -- but layers with three or more reduction segments win (the segments run as
+  // parallel lanes): k5 residual blocks 5.8 vs 7.4, k3 dilated convs 5.5-6.0 vs 6.6-6.9, the pitch estimator's first layer 6.7 vs 7.8
+  static const bool no_gemv = std::getenv("BEATRICE_HIP_NO_GEMV") != nullptr;  // A/B switch for measurements
+  if constexpr (!L::GROUPED && L::P >= 3 && L::T == 1) {
+    if (!no_gemv && a.B <= 2) { gemv::launch<L>(name, a, s); return; }
+  }
   if (a.B * L::T <= 2048) launch_conv<L, TLat<L>>(name, a, 0, s);
   else launch_conv<L, TL>(name, a, 0, s);
 }

@@ -99,42 +99,40 @@ def pmc_mfma_busy(kernel_name, streams):
 
 
 def cpu_baseline(bv, model_dir, seconds):
-    """Oracle through the same per-hop protocol: 1 stream on 1 core, then 1 stream per core."""
-    oracle = bv.Abi(os.path.join(REPO, "oracle", "libbeatrice_oracle.so"))
-    m = bv.Models(oracle, model_dir)
-
-    def run(n_hops, seed, out):
-        s = bv.Stream1(m, speaker=0)
-        x = bv.synth_audio(160 * 64, seed=seed)
-        t0 = time.perf_counter()
-        for i in range(n_hops):
-            s.hop(x[(i % 64) * 160:(i % 64 + 1) * 160])
-        out.append(time.perf_counter() - t0)
-        s.close()
-
-    probe = []
-    run(50, 0, probe)
-    hops = max(100, int(seconds * 50 / probe[0]))
-    one = []
-    run(hops, 1, one)
-    single = hops / one[0]
-    cores = min(os.cpu_count() or 1, 32)  # python threads (ctypes releases the GIL inside the oracle); bounded
-    hops_mt = max(50, hops // 8)
-    outs, threads = [], []
-    t0 = time.perf_counter()
-    for c in range(cores):
-        th = threading.Thread(target=run, args=(hops_mt, 10 + c, outs))
-        th.start()
-        threads.append(th)
-    for th in threads:
-        th.join()
-    wall = time.perf_counter() - t0
-    m.close()
+    """The oracle (a port of the frozen spec; the proprietary beatricelib has no Linux build) on this box's host cores,
+    driven by a C loop (oracle/bench_driver.c: the reference's per-hop call sequence, one pthread per stream): 1 stream on
+    1 core -- how the plugin runs -- then one stream per core."""
+    lib = ctypes.CDLL(os.path.join(REPO, "oracle", "liboracle_bench.so"))
+    lib.oracle_bench_threads.restype = ctypes.c_double
+    lib.oracle_bench_threads.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+    probe = lib.oracle_bench_threads(model_dir.encode(), 1, 200)
+    if probe <= 0:
+        raise SystemExit("oracle bench driver failed: %g" % probe)
+    hops = max(500, int(seconds * probe))
+    single = lib.oracle_bench_threads(model_dir.encode(), 1, hops)
+    cores = os.cpu_count() or 1
+    hops_mt = max(200, int(0.5 * seconds * probe))
+    allc = lib.oracle_bench_threads(model_dir.encode(), cores, hops_mt)
     return {"value": round(single, 1), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d hops of 1 synthetic stream through the 1-stream C-ABI (oracle/libbeatrice_oracle.so, "
-                      "gcc -O3 -mavx2 -mfma); the proprietary reference beatricelib has no Linux build" % hops,
-            "all_cores": {"value": round(cores * hops_mt / wall, 1), "cores": cores,
-                          "sample": "%d hops x %d streams, one thread per core" % (hops_mt, cores)}}
+            "sample": "%d hops of 1 synthetic stream through the 1-stream C-ABI of oracle/libbeatrice_oracle.so (gcc -O3 -mavx2 -mfma), "
+                      "C driver loop; the proprietary reference beatricelib has no Linux build" % hops,
+            "all_cores": {"value": round(allc, 1), "cores": cores,
+                          "sample": "%d hops x %d streams, one pthread per core (oracle/bench_driver.c)" % (hops_mt, cores)}}
+
+
+def measured_peaks():
+    """What this box reaches on the two rooflines (tools/microbench/peaks.hip): float4 copy, dependency-free FP32 MFMA."""
+    path = os.path.join(REPO, "tools", "microbench", "libpeaks.so")
+    if not os.path.exists(path):
+        return None
+    lib = ctypes.CDLL(path)
+    lib.peaks_hbm_copy_gbs.restype = ctypes.c_double
+    lib.peaks_hbm_copy_gbs.argtypes = [ctypes.c_size_t, ctypes.c_int]
+    lib.peaks_mfma_f32_tflops.restype = ctypes.c_double
+    lib.peaks_mfma_f32_tflops.argtypes = [ctypes.c_int, ctypes.c_int]
+    return {"hbm_copy_GBs": round(lib.peaks_hbm_copy_gbs(1 << 30, 5), 1), "mfma_f32_TFLOPs": round(lib.peaks_mfma_f32_tflops(20000, 3), 1),
+            "spec": {"hbm_GBs": PEAK_HBM_GBS, "mfma_f32_TFLOPs": PEAK_FP32_MFMA_TFLOPS},
+            "how": "1 GiB float4 device-to-device copy (read + write); v_mfma_f32_16x16x4_f32 with 8 independent accumulators per wavefront, 32 wavefronts per CU"}
 
 
 def saturation(bv, models, product, streams=8192, steps=30):
@@ -264,20 +262,21 @@ def hop_synchronous(bv, models, product, streams, steps=300):
             "x_realtime_per_stream": round(10.0 / (ms / steps), 1)}
 
 
-def latency_b1(bv, product, model_dir, hops=400):
+def latency_b1(bv, product, model_dir, hops=10000, warm=500):
     """BASELINE.json configs[1]: 1 stream, 1 speaker, hop-synchronous 1-stream C-ABI."""
     m = bv.Models(product, model_dir)
     s = bv.Stream1(m, speaker=0)
     x = bv.synth_audio(160 * 64, seed=5)
     lat = []
-    for i in range(hops + 50):
+    for i in range(hops + warm):
         t0 = time.perf_counter()
         s.hop(x[(i % 64) * 160:(i % 64 + 1) * 160])
         lat.append(time.perf_counter() - t0)
     s.close()
     m.close()
-    lat = np.array(lat[50:]) * 1e6
-    return {"workload": "configs[1]: 1 stream through ExtractPhone1/EstimatePitch1/GenerateWaveform1",
+    lat = np.array(lat[warm:]) * 1e6
+    return {"workload": "configs[1]: 1 stream through ExtractPhone1/EstimatePitch1/GenerateWaveform1, %d hops after %d warm-up" % (hops, warm),
+            "max_us": round(float(lat.max()), 1),
             "p50_us": round(float(np.percentile(lat, 50)), 1), "p99_us": round(float(np.percentile(lat, 99)), 1),
             "frames_per_s": round(1e6 / float(lat.mean()), 1), "x_realtime": round(1e4 / float(lat.mean()), 1)}
 
@@ -574,6 +573,11 @@ def main():
                 res["host_buffer_variant"] = host_buffer_rate(bv, m, product, B)
                 res["latency_b1"] = latency_b1(bv, product, model_dir)
                 res["cpu_baseline"] = cpu_baseline(bv, model_dir, a.cpu_seconds)
+                peaks = measured_peaks()
+                if peaks:
+                    res["measured_peaks"] = peaks
+                    if res["roofline"]["bound"] == "mfma" and peaks["mfma_f32_TFLOPs"] > 0:
+                        res["roofline"]["frac_of_measured_peak"] = round(res["roofline"]["achieved"] / peaks["mfma_f32_TFLOPs"], 4)
         print(json.dumps(res))
     if batch is not None:
         batch.close()
