@@ -21,11 +21,29 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o k -- \
   python "$ROOT/bench.py" --no-extras --steps 300 --warmup 20 > "$OUT/bench_under_rocprof.json" 2> /dev/null
 STATS=$(find "$OUT/prof" -name 'k_kernel_stats.csv' | head -1)
 [ -n "$STATS" ] && cp "$STATS" "$OUT/kernel_stats_B256_tick.csv"
+# the stats average of the tick launch mixes full ticks with the partly filled ones of fill and drain: split them
+python - "$(find "$OUT/prof" -name 'k_kernel_trace.csv' | head -1)" > "$OUT/tick_launch_durations.txt" <<'PY'
+import csv, sys
+d = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(sys.argv[1])) if "table_kernel" in r["Kernel_Name"])
+full = [x for x in d if x >= 0.9 * d[-1]]
+print("tick launches %d: mean of all %.2f us; full ticks (>= 0.9 x max) %d: mean %.2f us, median %.2f us, max %.2f us; partly filled %d: mean %.2f us"
+      % (len(d), sum(d) / len(d) / 1e3, len(full), sum(full) / len(full) / 1e3, full[len(full) // 2] / 1e3, d[-1] / 1e3,
+         len(d) - len(full), (sum(d) - sum(full)) / max(1, len(d) - len(full)) / 1e3))
+PY
 rm -rf "$OUT/prof"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o k -- \
   python "$ROOT/bench.py" --no-extras --pipeline off --steps 200 --warmup 20 > /dev/null 2>&1
 STATS=$(find "$OUT/prof" -name 'k_kernel_stats.csv' | head -1)
 [ -n "$STATS" ] && cp "$STATS" "$OUT/kernel_stats_B256_in_order.csv"
+rm -rf "$OUT/prof"
+# the same chain with the conditioned blocks as two row-local kernels each (evidence for profiles/r02_notes.md)
+BEATRICE_HIP_ROWCHAIN=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o k -- \
+  python "$ROOT/bench.py" --no-extras --pipeline off --steps 200 --warmup 20 > "$OUT/bench_in_order_rowchain.json" 2> /dev/null
+STATS=$(find "$OUT/prof" -name 'k_kernel_stats.csv' | head -1)
+[ -n "$STATS" ] && cp "$STATS" "$OUT/kernel_stats_B256_in_order_rowchain.csv"
+rm -rf "$OUT/prof"
+# configs[1]: the 1-stream C-ABI, eager launches (rocprofv3 does not survive the per-call graphs)
+( cd "$ROOT" && bash tools/debug/b1_prof.sh "$TAG/b1" > /dev/null 2>&1 )
 
 for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- \
