@@ -1,0 +1,73 @@
+/* beatrice_host.h -- plain-C view of the host layer above the C-ABI (libbeatrice_host.so, beatrice-vst_amd/host/).
+ *
+ * The reference's host side is C++ classes (no C boundary of their own); these entry points exist so that FFI callers
+ * and the tests reach our mirrors of those classes.  Every function names the reference interface it stands for.
+ * Error codes are the reference's common::ErrorCode values as ints (src/common/error.h): 0 = success.
+ *
+ *   BeatriceHost_*   beatrice_amd::ProcessorCore2  == reference ProcessorCoreBase / ProcessorCore2
+ *                    (src/common/processor_core.h:22-92, processor_core_2.h:25-175, processor_core_2.cc:24-585):
+ *                    the per-stream wrapper around the three per-hop calls -- gains, any-rate resampler, 480-block FIFO,
+ *                    pitch arithmetic, speaker switching and morphing.
+ *   BeatriceProxy_*  beatrice_amd::ProcessorProxy  == reference ProcessorProxy (src/common/processor_proxy.h:25-147,
+ *                    processor_proxy.cc): owns the parameter state, reads the model package's TOML
+ *                    (src/common/model_config.h:20-138), picks the core by model version (processor_proxy.h:55-100; any
+ *                    failure leaves the silent "unloaded" core), replays every parameter into a new core, and reads /
+ *                    writes the preset blob (src/common/parameter_state.cc:68-147: [int16 id][int32 type][payload]).
+ */
+#ifndef BEATRICE_HOST_H_
+#define BEATRICE_HOST_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- ProcessorCore2 (processor_core.h:22-92) ---- */
+void* BeatriceHost_Create(double sample_rate);                               /* ctor, processor_core_2.h:28-51 */
+void BeatriceHost_Destroy(void* core);
+int BeatriceHost_LoadModel(void* core, const char* toml_path);               /* processor_core_2.cc:293-419 */
+int BeatriceHost_Process(void* core, const float* in, float* out, int n);    /* processor_core_2.cc:24-48 (any n, host rate) */
+int BeatriceHost_ResetContext(void* core);                                   /* :258-291 */
+int BeatriceHost_SetSampleRate(void* core, double v);                        /* :421-429 */
+int BeatriceHost_SetTargetSpeaker(void* core, int v);                        /* :431-466 */
+int BeatriceHost_SetFormantShift(void* core, double v);                      /* :468-481 */
+int BeatriceHost_SetPitchShift(void* core, double v);
+int BeatriceHost_SetInputGain(void* core, double v);                         /* gain.h:41-71 */
+int BeatriceHost_SetOutputGain(void* core, double v);
+int BeatriceHost_SetAverageSourcePitch(void* core, double v);
+int BeatriceHost_SetIntonationIntensity(void* core, double v);
+int BeatriceHost_SetPitchCorrection(void* core, double v);
+int BeatriceHost_SetPitchCorrectionType(void* core, int v);
+int BeatriceHost_SetMinSourcePitch(void* core, double v);                    /* :561-583 */
+int BeatriceHost_SetMaxSourcePitch(void* core, double v);
+int BeatriceHost_SetVQNumNeighbors(void* core, int v);
+int BeatriceHost_SetSpeakerMorphingWeights(void* core, const float* weights, int n);  /* :507-532 */
+void BeatriceHost_SetMorphSeed(void* core, unsigned seed);                   /* the reference seeds from random_device; tests need a fixed lottery */
+int BeatriceHost_NumSpeakers(void* core);
+int BeatriceHost_TakePitchTrace(void* core, int* out, int cap);              /* test hook: quantised pitch per hop */
+/* weighted spherical mean as the morph branch runs it (spherical_average.h:80-444); returns updates performed */
+int BeatriceHost_SphericalMean(int dim, int n_points, const float* points, const float* weights, const int* order, int limit,
+                               int max_updates, float* out);
+
+/* ---- ProcessorProxy (processor_proxy.h:25-147) ---- */
+void* BeatriceProxy_Create(void);
+void BeatriceProxy_Destroy(void* proxy);
+int BeatriceProxy_SetSampleRate(void* proxy, double sample_rate);
+int BeatriceProxy_LoadModel(void* proxy, const char* toml_path);             /* processor_proxy.h:55-100 */
+int BeatriceProxy_SetNumber(void* proxy, int id, double v);                  /* parameter ids: parameter_schema.h / host/parameter_state.h param_id */
+int BeatriceProxy_SetInt(void* proxy, int id, int v);
+int BeatriceProxy_SetString(void* proxy, int id, const char* s);
+int BeatriceProxy_Process(void* proxy, const float* in, float* out, int n);
+int BeatriceProxy_ResetContext(void* proxy);
+int BeatriceProxy_CoreVersion(void* proxy);                                  /* -1 = unloaded core */
+int BeatriceProxy_VoiceCount(void* proxy);                                   /* model_config.h voices with a non-empty description */
+int BeatriceProxy_GetKind(void* proxy, int id);                              /* 0 int, 1 number, 2 string, -1 unknown id */
+double BeatriceProxy_GetNumber(void* proxy, int id);
+int BeatriceProxy_GetString(void* proxy, int id, char* buf, int cap);        /* returns the length; -1 if not a string */
+int BeatriceProxy_WriteState(void* proxy, unsigned char* buf, int cap);      /* parameter_state.cc:111-147; returns the size */
+int BeatriceProxy_ReadState(void* proxy, const unsigned char* buf, int n);   /* parameter_state.cc:68-109 */
+void BeatriceProxy_MorphWeights(void* proxy, float* out256);                 /* voice_morph_state.h:87-104 (test hook) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEATRICE_HOST_H_ */

@@ -105,6 +105,21 @@ def test_product_exports_every_declared_symbol(bv, product):
     assert len(bv.ABI_SYMBOLS_RC0) == 33 and len(bv.ABI_SYMBOLS_LEGACY) == 44
 
 
+def test_host_library_exports_every_declared_symbol():
+    """include/beatrice_host.h (the C view of the ProcessorCore2 / ProcessorProxy mirrors) vs libbeatrice_host.so."""
+    text = open(os.path.join(REPO, "include", "beatrice_host.h")).read()
+    names = set(re.findall(r"\b(Beatrice(?:Host|Proxy)_[A-Za-z0-9]+)\s*\(", text))
+    assert len(names) >= 40
+    lib = C.CDLL(os.path.join(REPO, "beatrice-vst_amd", "host", "libbeatrice_host.so"))
+    missing = [s for s in sorted(names) if not hasattr(lib, s)]
+    assert not missing, missing
+    # and the other way round: no undeclared BeatriceHost_/BeatriceProxy_ export
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(REPO, "beatrice-vst_amd", "host", "libbeatrice_host.so")]).decode()
+    exported = set(re.findall(r"\b(Beatrice(?:Host|Proxy)_[A-Za-z0-9]+)\b", out))
+    assert exported == names, sorted(exported ^ names)
+
+
 def test_declarations_match_reference_header():
     """Every function name the reference header declares is declared by ours (runs only where the
     reference is mounted; the GPU box skips it)."""
