@@ -486,7 +486,11 @@ bool tick_build_table(BeatriceBatch* b) {
   const WaveState& ws = b->wave;
   const int B = b->B;
   const Plan pl = k.plan;
-  auto hp = [&](int stage) { return k.d_hops + 2 * stage; };
+  // measurement aid: BEATRICE_HIP_TICK_DROP=<bit mask> leaves groups of bodies out of the launch (results are then wrong)
+  static const int drop = std::getenv("BEATRICE_HIP_TICK_DROP") ? std::atoi(std::getenv("BEATRICE_HIP_TICK_DROP")) : 0;
+  auto keep = [](int group) { return ((drop >> group) & 1) == 0; };
+  // (every body takes its step counter from the launch's StepPairs -- a null counter pointer says so, ring.h stepc)
+  auto hp = [&](int) -> const int* { return nullptr; };
   auto conv = [&](const Ring& in, const Ring& out, const float* w, const float* bias, int stage) { return conv_args(in, out, w, bias, hp(stage), B); };
   // (workgroups are dispatched in this order: the longest-running bodies first)
   // ---- conditioned blocks: two row-local chains each
@@ -496,46 +500,46 @@ bool tick_build_table(BeatriceBatch* b) {
     const rc::BlockBArgs ba{sc.xa, ws.x[blk + 1], ww.q_w[blk], ww.q_b[blk], ww.o_w[blk], ww.o_b[blk], ws.d_kt[blk], ws.d_v[blk],
                             b->dev_view<int>(b->off.perm[blk]), b->dev_view<int>(b->off.tile_slot[blk]), hp(s0 + 1)};
     tb->add<T_BLKB>(LaunchInfo{"wave.blk.b", 2.0 * B * (256.0 * 256 * 2 + 256.0 * 384 * 2), 4.0 * (2.0 * 256 * 256 + 2.0 * 256 * 384 + B * 3.0 * 256)}, ba,
-                    dim3(ws.n_tiles_max, 1), true, 41.0);
+                    dim3(ws.n_tiles_max, 1), s0 + 1, keep(5), 41.0);
   }
   for (int blk = 0; blk < B_NBLOCKS; ++blk) {
     const rc::BlockAArgs aa{ws.x[blk], ws.scr[blk].xa, ww.c1_w[blk], ww.c1_b[blk], ww.c2_w[blk], ww.c2_b[blk], hp(pl.blk(blk)), B};
     switch (blk) {
-      case 0: tb->add<T_BLKA1>(rc::BlockAOp<1>::info(aa), aa, rc::BlockAOp<1>::grid(aa), true, 41); break;
-      case 1: tb->add<T_BLKA2>(rc::BlockAOp<2>::info(aa), aa, rc::BlockAOp<2>::grid(aa), true, 41); break;
-      case 2: tb->add<T_BLKA4>(rc::BlockAOp<4>::info(aa), aa, rc::BlockAOp<4>::grid(aa), true, 41); break;
-      default: tb->add<T_BLKA8>(rc::BlockAOp<8>::info(aa), aa, rc::BlockAOp<8>::grid(aa), true, 41); break;
+      case 0: tb->add<T_BLKA1>(rc::BlockAOp<1>::info(aa), aa, rc::BlockAOp<1>::grid(aa), pl.blk(blk), keep(5), 41); break;
+      case 1: tb->add<T_BLKA2>(rc::BlockAOp<2>::info(aa), aa, rc::BlockAOp<2>::grid(aa), pl.blk(blk), keep(5), 41); break;
+      case 2: tb->add<T_BLKA4>(rc::BlockAOp<4>::info(aa), aa, rc::BlockAOp<4>::grid(aa), pl.blk(blk), keep(5), 41); break;
+      default: tb->add<T_BLKA8>(rc::BlockAOp<8>::info(aa), aa, rc::BlockAOp<8>::grid(aa), pl.blk(blk), keep(5), 41); break;
     }
   }
   // ---- the layers with long reductions, then the fused tail
-  { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], pl.up1()); tb->add<T_UP1>(OpUP1::info("wave.up1", a), a, OpUP1::grid(a), true, 36); }
+  { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], pl.up1()); tb->add<T_UP1>(OpUP1::info("wave.up1", a), a, OpUP1::grid(a), pl.up1(), keep(7), 36); }
   for (int i = 0; i < 4; ++i) {
     const ConvArgs a = conv(i == 0 ? ps.f[4] : ps.rb[i - 1], ps.rb[i], pw.rb_w[i], pw.rb_b[i], Plan::RB0 + i);
-    tb->add<T_RB>(OpRB::info("phone.rb", a), a, OpRB::grid(a), true, 46);
+    tb->add<T_RB>(OpRB::info("phone.rb", a), a, OpRB::grid(a), Plan::RB0 + i, keep(6), 46);
   }
-  { const ConvArgs a = conv(qs.spec, qs.p[0], qw.p_w[0], qw.p_b[0], Plan::P1); tb->add<T_P1>(OpP1::info("pitch.p1", a), a, OpP1::grid(a), true, 34.5); }
-  { const ConvArgs a = conv(ps.f[2], ps.f[3], pw.f_w[2], pw.f_b[2], Plan::F4); tb->add<T_F4>(OpF4::info("phone.f4", a), a, OpF4::grid(a), true, 37.5); }
-  { const ConvArgs a = conv(ps.f[3], ps.f[4], pw.f_w[3], pw.f_b[3], Plan::F5); tb->add<T_F5>(OpF5::info("phone.f5", a), a, OpF5::grid(a), true, 47); }
-  { TailArgs ta = tail_args(ww, ws); ta.hop = hp(pl.tail()); tb->add<T_TAIL>(tail_info(ws), ta, dim3(B, 1), true, 41, true); }
-  { const ConvArgs a = conv(ps.f[0], ps.f[1], pw.f_w[0], pw.f_b[0], Plan::F2); tb->add<T_F2>(OpF2::info("phone.f2", a), a, OpF2::grid(a), true, 10); }
-  { const ConvArgs a = conv(ps.f[1], ps.f[2], pw.f_w[1], pw.f_b[1], Plan::F3); tb->add<T_F3>(OpF3::info("phone.f3", a), a, OpF3::grid(a), true, 18); }
-  { const ConvArgs a = conv(ws.ya1, ws.yb1, ww.ra_w[0], ww.ra_b[0], pl.up1() + 1); tb->add<T_RES1A>(OpRES1A::info("wave.res1a", a), a, OpRES1A::grid(a), true, 10); }
-  { const ConvArgs a = conv(ws.yb1, ws.yc1, ww.rb_w[0], ww.rb_b[0], pl.up1() + 2); tb->add<T_RES1B>(OpRES1B::info("wave.res1b", a), a, OpRES1B::grid(a), true, 10); }
-  { const ConvArgs a = conv(ws.yc1, ws.ya2, ww.up_w[1], ww.up_b[1], pl.up1() + 3); tb->add<T_UP2>(OpUP2::info("wave.up2", a), a, OpUP2::grid(a), true, 12); }
-  { const GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(Plan::PGRU), B, 0}; tb->add<T_PGRU>(GruOp<256, 256>::info("phone.gru", g), g, GruOp<256, 256>::grid(g), true, 7.6); }
-  { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, 0}; tb->add<T_QGRU>(GruOp<128, 128>::info("pitch.gru", g), g, GruOp<128, 128>::grid(g), true, 4.6); }
+  { const ConvArgs a = conv(qs.spec, qs.p[0], qw.p_w[0], qw.p_b[0], Plan::P1); tb->add<T_P1>(OpP1::info("pitch.p1", a), a, OpP1::grid(a), Plan::P1, keep(2), 34.5); }
+  { const ConvArgs a = conv(ps.f[2], ps.f[3], pw.f_w[2], pw.f_b[2], Plan::F4); tb->add<T_F4>(OpF4::info("phone.f4", a), a, OpF4::grid(a), Plan::F4, keep(6), 37.5); }
+  { const ConvArgs a = conv(ps.f[3], ps.f[4], pw.f_w[3], pw.f_b[3], Plan::F5); tb->add<T_F5>(OpF5::info("phone.f5", a), a, OpF5::grid(a), Plan::F5, keep(6), 47); }
+  { TailArgs ta = tail_args(ww, ws); ta.hop = hp(pl.tail()); tb->add<T_TAIL>(tail_info(ws), ta, dim3(B, 1), pl.tail(), keep(4), 41, true); }
+  { const ConvArgs a = conv(ps.f[0], ps.f[1], pw.f_w[0], pw.f_b[0], Plan::F2); tb->add<T_F2>(OpF2::info("phone.f2", a), a, OpF2::grid(a), Plan::F2, keep(6), 10); }
+  { const ConvArgs a = conv(ps.f[1], ps.f[2], pw.f_w[1], pw.f_b[1], Plan::F3); tb->add<T_F3>(OpF3::info("phone.f3", a), a, OpF3::grid(a), Plan::F3, keep(6), 18); }
+  { const ConvArgs a = conv(ws.ya1, ws.yb1, ww.ra_w[0], ww.ra_b[0], pl.up1() + 1); tb->add<T_RES1A>(OpRES1A::info("wave.res1a", a), a, OpRES1A::grid(a), pl.up1() + 1, keep(7), 10); }
+  { const ConvArgs a = conv(ws.yb1, ws.yc1, ww.rb_w[0], ww.rb_b[0], pl.up1() + 2); tb->add<T_RES1B>(OpRES1B::info("wave.res1b", a), a, OpRES1B::grid(a), pl.up1() + 2, keep(7), 10); }
+  { const ConvArgs a = conv(ws.yc1, ws.ya2, ww.up_w[1], ww.up_b[1], pl.up1() + 3); tb->add<T_UP2>(OpUP2::info("wave.up2", a), a, OpUP2::grid(a), pl.up1() + 3, keep(7), 12); }
+  { const GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(Plan::PGRU), B, 0}; tb->add<T_PGRU>(GruOp<256, 256>::info("phone.gru", g), g, GruOp<256, 256>::grid(g), Plan::PGRU, keep(1), 7.6); }
+  { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, 0}; tb->add<T_QGRU>(GruOp<128, 128>::info("pitch.gru", g), g, GruOp<128, 128>::grid(g), Plan::QGRU, keep(1), 4.6); }
   for (int i = 0; i < 2; ++i) {
     const ConvArgs a = conv(qs.p[i], qs.p[i + 1], qw.p_w[i + 1], qw.p_b[i + 1], Plan::P2 + i);
-    tb->add<T_P23>(OpP23::info("pitch.p23", a), a, OpP23::grid(a), true, 8);
+    tb->add<T_P23>(OpP23::info("pitch.p23", a), a, OpP23::grid(a), Plan::P2 + i, keep(2), 8);
   }
-  { const ConvArgs a = conv(qs.h, qs.logits, qw.out_w, qw.out_b, Plan::POUT); tb->add<T_POUT>(OpPOUT::info("pitch.out", a), a, OpPOUT::grid(a), true, 9.4); }
-  { const ConvArgs a = conv(ps.h, phone_out_ring(ps), pw.out_w, pw.out_b, Plan::OUT); tb->add<T_OUT>(OpOUT::info("phone.out", a), a, OpOUT::grid(a), true, 6); }
-  { const Ring phone_in{ws.d_phone, B_PHONE_CH, 1, ws.front_slots}; ConvArgs a = conv(phone_in, ws.x[0], ww.inp_w, ww.inp_b, Plan::INP); a.res = ws.e; tb->add<T_INP>(OpINP::info("wave.inp", a), a, OpINP::grid(a), true, 7.7); }
-  { const VqArgs a{1, ps.raw, phone_vector_ring(ps), hp(Plan::VQ), ps.d_cbT, ps.d_cnorm, ps.d_vqk}; tb->add<T_VQ>(LaunchInfo{"phone.vq", 0, 4.0 * B * 256}, a, dim3(B, 1), !ps.skip_vq, 6.0, true); }
-  { F1Args a = f1_args(pw, ps); a.hop = hp(Plan::F1); a.hop_publish = nullptr; a.hop_publish_wave = nullptr; tb->add<T_F1>(f1_info(ps), a, dim3(B, 1), true, 4.5); }
-  { FftArgs a = fft_args(qw, qs); a.hop = hp(Plan::FFT); tb->add<T_FFT>(fft_info(qs), a, dim3(B, 1), true, 6); }
-  { PitchHeadArgs a = head_args(qw, qs); a.hop = hp(Plan::HEAD); tb->add<T_HEAD>(head_info(qs), a, dim3(B, 1), true, 4.7); }
-  { CondArgs a = cond_args(ww, ws); a.hop = hp(Plan::COND); a.hop_next_out = nullptr; tb->add<T_COND>(cond_info(ws), a, dim3(B, 1), true, 1.3); }
+  { const ConvArgs a = conv(qs.h, qs.logits, qw.out_w, qw.out_b, Plan::POUT); tb->add<T_POUT>(OpPOUT::info("pitch.out", a), a, OpPOUT::grid(a), Plan::POUT, keep(2), 9.4); }
+  { const ConvArgs a = conv(ps.h, phone_out_ring(ps), pw.out_w, pw.out_b, Plan::OUT); tb->add<T_OUT>(OpOUT::info("phone.out", a), a, OpOUT::grid(a), Plan::OUT, keep(3), 6); }
+  { const Ring phone_in{ws.d_phone, B_PHONE_CH, 1, ws.front_slots}; ConvArgs a = conv(phone_in, ws.x[0], ww.inp_w, ww.inp_b, Plan::INP); a.res = ws.e; tb->add<T_INP>(OpINP::info("wave.inp", a), a, OpINP::grid(a), Plan::INP, keep(3), 7.7); }
+  { const VqArgs a{1, ps.raw, phone_vector_ring(ps), hp(Plan::VQ), ps.d_cbT, ps.d_cnorm, ps.d_vqk}; tb->add<T_VQ>(LaunchInfo{"phone.vq", 0, 4.0 * B * 256}, a, dim3(B, 1), Plan::VQ, !ps.skip_vq, 6.0, true); }
+  { F1Args a = f1_args(pw, ps); a.hop = hp(Plan::F1); a.hop_publish = nullptr; a.hop_publish_wave = nullptr; tb->add<T_F1>(f1_info(ps), F1Args2{a, B}, dim3((B + 1) / 2, 1), Plan::F1, keep(0), 4.5); }
+  { FftArgs a = fft_args(qw, qs); a.hop = hp(Plan::FFT); tb->add<T_FFT>(fft_info(qs), FftArgs2{a, B}, dim3((B + 1) / 2, 1), Plan::FFT, keep(0), 6); }
+  { PitchHeadArgs a = head_args(qw, qs); a.hop = hp(Plan::HEAD); tb->add<T_HEAD>(head_info(qs), a, dim3((B + 7) / 8, 1), Plan::HEAD, keep(0), 4.7); }
+  { CondArgs a = cond_args(ww, ws); a.hop = hp(Plan::COND); a.hop_next_out = nullptr; tb->add<T_COND>(cond_info(ws), a, dim3((B + 1) / 2, 1), Plan::COND, keep(0), 1.3); }
   if (!tb->ok) return false;
   // XCD-aware placement (bodies with many weights pinned to one XCD each, so that the weights stay in that L2) was
   // measured twice: it cuts the launch's memory-side traffic 4x (rocprofv3 FETCH_SIZE 105 -> 26 MB per tick) and the
@@ -616,9 +620,11 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
     p.copy[p.n_copies++] = Copy{c.dst, k.d_snap + (size_t)(want % kRing) * k.snap_bytes + c.off, (int)c.bytes};
     c.held = want;
   }
-  hipLaunchKernelGGL(prologue_kernel, dim3(1 + p.n_copies), dim3(256), 0, st, k.d_hops, p);
+  if (p.n_copies > 0) hipLaunchKernelGGL(prologue_kernel, dim3(p.n_copies), dim3(256), 0, st, p);  // (only on ticks where a settings change arrives at a consumer)
   if (k.bracket) (void)hipEventRecord(k.bracket[k.bracket_at], st);
-  fuse::launch_table_w<4>(k.d_table, k.table_total, st);
+  fuse::StepPairs pairs;
+  for (int s = 0; s < fuse::kMaxStepPairs; ++s) { pairs.hop[s] = s < p.n_stages ? p.hop[s] : -1; pairs.io[s] = s < p.n_stages ? p.io[s] : 0; }
+  fuse::launch_table_w<4>(k.d_table, k.table_total, st, pairs);
   if (k.bracket) (void)hipEventRecord(k.bracket[k.bracket_at + 1], st);
   if (feeding) {
     b->last_parity = b->hop_host % 3;
@@ -654,19 +660,18 @@ int tick_enable(BeatriceBatch* b, bool on) {
   State& k = b->tk;
   if (on == k.on) return 0;
   if (on) {
-    // one 10 ms hop per step, at most 256 streams (the few-row tilings of every layer), resident I/O with enough slots
+    // one 10 ms hop per step, resident I/O with enough slots
     // that a step's input is still there when the pitch head reads it nine ticks on and outputs have somewhere to land
-    if (b->H != 1 || b->B > 256 || b->io_slots < k.plan.count() + 1) return -1;
+    if (b->H != 1 || b->B > 4096 || b->io_slots < k.plan.count() + 1) return -1;
     if (!sync_all(b)) return -2;
     if (b->pipelined) { drop_graph(b); set_plan(b, 1); }
     k.snap_bytes = b->off.front_bytes + b->off.wave_bytes;
-    if (!k.d_hops) {
-      if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_hops), sizeof(int) * 2 * kMaxStages), "tick hops") ||
-          !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_table), sizeof(Tab)), "tick table") ||
+    if (!k.d_table) {
+      if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_table), sizeof(Tab)), "tick table") ||
           !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_snap), k.snap_bytes * kRing), "tick snapshots"))
         return -2;
     }
-    if (!hip_ok(hipMemset(k.d_hops, 0xff, sizeof(int) * 2 * kMaxStages), "tick hops0") || !hip_ok(hipDeviceSynchronize(), "tick sync")) return -2;
+    if (!hip_ok(hipDeviceSynchronize(), "tick sync")) return -2;
     k.tick = 0; k.n_fed = 0; k.last_feed_tick = -1000; k.snap_cur = -1; k.snap_next = 0;
     for (long long& f : k.fed_step) f = -1;
     k.table_dirty = true;
@@ -900,7 +905,7 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   { void* wr[] = {b->d_wrap, b->d_wrap_taps, b->d_wrap_inner, b->d_wrap_io, b->wrap_gains.d}; for (void* p : wr) if (p) (void)hipFree(p); }
   if (b->h_wrap_io) (void)hipHostFree(b->h_wrap_io);
   b->wrap_gains.release();
-  { void* tk[] = {b->tk.d_hops, b->tk.d_table, b->tk.d_snap, b->tk.d_trace}; for (void* p : tk) if (p) (void)hipFree(p); }
+  { void* tk[] = {b->tk.d_table, b->tk.d_snap, b->tk.d_trace}; for (void* p : tk) if (p) (void)hipFree(p); }
   if (b->own_d_out) { b->wave.d_out = b->own_d_out; b->own_d_out = nullptr; }
   if (b->module_owned[0]) {  // hand the modules their own arrays back so that destroy() frees what it allocated
     void** keep = b->module_owned;

@@ -134,7 +134,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int bx, 
     wbase += (size_t)slot * a.w_slot_stride;
   }
 
-  const int hop = *a.hop;   // (-1: this stage has no step this tick -- pipeline fill / drain of the batch's tick mode; checked
+  const int hop = stepc::step(a.hop);   // (-1: this stage has no step this tick -- pipeline fill / drain of the batch's tick mode; checked
                             //  below, AFTER the first weight loads are issued, so that it costs the chain no extra latency)
   const int pos_in = ring_pos(a.in, hop);
 

@@ -13,9 +13,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <string>
 
 #include "engine.h"
+#include "ring.h"
 
 namespace fuse {
 
@@ -107,6 +110,12 @@ template <class Op, int CAP>
 struct Many { using op = Op; static constexpr int cap = CAP; };
 struct Span { int first, gx, type, arg; };  // workgroups [first, next first) run body `type` with its argument block `arg`
 constexpr int kMaxSpans = 64;
+// (bits 16-23 of Span::arg: the body's pipeline stage, see StepPairs)
+// Step counter and I/O slot of every pipeline stage for ONE launch, passed to the table kernel by value (kernel arguments):
+// a workgroup looks its body's stage up and leaves the pair in LDS for the body (stepc, ring.h); a stage whose counter is
+// negative has no step in this launch and its workgroups leave at once.
+constexpr int kMaxStepPairs = 32;
+struct StepPairs { int hop[kMaxStepPairs], io[kMaxStepPairs]; };
 template <class... Ms> struct Banks;
 template <> struct Banks<> {};
 template <class M, class... Rest>
@@ -140,15 +149,15 @@ __device__ __forceinline__ void run_type(const Banks<M, Rest...>& b, const Span&
 }
 
 template <int MINW, class... Ms>
-__device__ __forceinline__ void table_body(const Table<Ms...>* __restrict__ t);
+__device__ __forceinline__ void table_body(const Table<Ms...>* __restrict__ t, const StepPairs& pairs);
 template <class... Ms>
-__global__ __launch_bounds__(MaxM<Ms...>::NTHR) void table_kernel(const Table<Ms...>* __restrict__ t) { table_body<0, Ms...>(t); }
+__global__ __launch_bounds__(MaxM<Ms...>::NTHR) void table_kernel(const Table<Ms...>* __restrict__ t, const StepPairs pairs) { table_body<0, Ms...>(t, pairs); }
 // the same with a register budget: MINW = minimum wavefronts per SIMD the launch wants resident (HIP's second
 // __launch_bounds__ parameter): 4 with 512-thread workgroups = two workgroups per CU = at most 128 VGPRs
 template <int MINW, class... Ms>
-__global__ __launch_bounds__(MaxM<Ms...>::NTHR, MINW) void table_kernel_w(const Table<Ms...>* __restrict__ t) { table_body<MINW, Ms...>(t); }
+__global__ __launch_bounds__(MaxM<Ms...>::NTHR, MINW) void table_kernel_w(const Table<Ms...>* __restrict__ t, const StepPairs pairs) { table_body<MINW, Ms...>(t, pairs); }
 template <int MINW, class... Ms>
-__device__ __forceinline__ void table_body(const Table<Ms...>* __restrict__ t) {
+__device__ __forceinline__ void table_body(const Table<Ms...>* __restrict__ t, const StepPairs& pairs) {
   __shared__ __attribute__((aligned(16))) float lds[MaxM<Ms...>::LDS > 0 ? MaxM<Ms...>::LDS : 1];
   const int lane = threadIdx.x & 63;
   // XCD-aware layout: workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only), and the table gives
@@ -161,6 +170,12 @@ __device__ __forceinline__ void table_body(const Table<Ms...>* __restrict__ t) {
   Span sp;
   sp.first = __builtin_amdgcn_readlane(mine.x, idx); sp.gx = __builtin_amdgcn_readlane(mine.y, idx);
   sp.type = __builtin_amdgcn_readlane(mine.z, idx); sp.arg = __builtin_amdgcn_readlane(mine.w, idx);
+  if (sp.type < 0) return;  // filler index
+  const int stage = (sp.arg >> 16) & 0xff;
+  const int step = pairs.hop[stage];
+  if (step < 0) return;    // fill / drain: this stage has no step in this launch
+  if (threadIdx.x == 0) { stepc::pair[0] = step; stepc::pair[1] = pairs.io[stage]; }
+  __syncthreads();
   unsigned long long* const trace = t->trace;
   const unsigned long long t0 = trace ? wall_clock64() : 0;
   // (a body spread over the XCDs is eight spans; span k owns the body's workgroups k, k + 8, ...: arg bits 8-11 = k, bit 12 set)
@@ -174,12 +189,14 @@ __device__ __forceinline__ void table_body(const Table<Ms...>* __restrict__ t) {
 }
 
 template <class... Ms>
-static inline void launch_table(const Table<Ms...>* d_table, int total, hipStream_t stream) {
-  hipLaunchKernelGGL((table_kernel<Ms...>), dim3(total), dim3(MaxM<Ms...>::NTHR), 0, stream, d_table);
+static inline void launch_table(const Table<Ms...>* d_table, int total, hipStream_t stream, const StepPairs& pairs) {
+  hipLaunchKernelGGL((table_kernel<Ms...>), dim3(total), dim3(MaxM<Ms...>::NTHR), 0, stream, d_table, pairs);
 }
 template <int MINW, class... Ms>
-static inline void launch_table_w(const Table<Ms...>* d_table, int total, hipStream_t stream) {
-  hipLaunchKernelGGL((table_kernel_w<MINW, Ms...>), dim3(total), dim3(MaxM<Ms...>::NTHR), 0, stream, d_table);
+static inline void launch_table_w(const Table<Ms...>* d_table, int total, hipStream_t stream, const StepPairs& pairs) {
+  // measurement aid: BEATRICE_HIP_TICK_PAD_LDS=<bytes> of dynamic LDS on top of the static block (e.g. to allow one workgroup per CU only)
+  static const int pad = std::getenv("BEATRICE_HIP_TICK_PAD_LDS") ? std::atoi(std::getenv("BEATRICE_HIP_TICK_PAD_LDS")) : 0;
+  hipLaunchKernelGGL((table_kernel_w<MINW, Ms...>), dim3(total), dim3(MaxM<Ms...>::NTHR), pad, stream, d_table, pairs);
 }
 
 // host side: fill a Table<Ms...>.  add<I>() appends one body of type I (its index in Ms...); bodies run in the order added
@@ -266,13 +283,13 @@ struct TableBuilder {
     t.total = 8 * per;
   }
   template <int I, class Args>
-  void add(const bhip::LaunchInfo& info, const Args& a, dim3 grid, bool on = true, double wg_cost = 1.0, bool spread_over_xcds = false) {
+  void add(const bhip::LaunchInfo& info, const Args& a, dim3 grid, int stage, bool on = true, double wg_cost = 1.0, bool spread_over_xcds = false) {
     if (!on) return;
     using BA = BankAt<I, Banks<Ms...>>;
     if (t.n_spans >= kMaxSpans || used[I] >= BA::cap) { ok = false; return; }
     BA::get(t.banks)[used[I]] = a;
     Span& sp = t.span[t.n_spans];
-    sp.first = t.total; sp.gx = (int)grid.x > 0 ? (int)grid.x : 1; sp.type = I; sp.arg = used[I]++;
+    sp.first = t.total; sp.gx = (int)grid.x > 0 ? (int)grid.x : 1; sp.type = I; sp.arg = used[I]++ | (stage << 16);
     n_wg[t.n_spans] = (int)(grid.x * grid.y);
     cost[t.n_spans] = wg_cost * n_wg[t.n_spans];
     spread[t.n_spans] = spread_over_xcds;

@@ -47,7 +47,7 @@ __device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, c
 #pragma unroll
     for (int kb = 0; kb < (KB_X > KB_H ? KB_X : KB_H); ++kb) bf[kb] = wp[(size_t)(kb < kbn ? kb : 0) * 64];
   }
-  const int hop = *a.hop;
+  const int hop = stepc::step(a.hop);
   if (hop < 0) return;
   const int px = ring_pos(a.x, hop), ph = ring_pos(a.h, hop);
   // A tiles -> LDS
@@ -147,7 +147,7 @@ __device__ __forceinline__ void attn_pv_body(const AttnPvArgs& a, const int bx, 
   float* red = inv + 16;         // [2][16][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = wave >> 1, wn = wave & 1;
-  const int hop = *a.hop;  // (checked after the V fragment loads are issued)
+  const int hop = stepc::step(a.hop);  // (checked after the V fragment loads are issued)
   const int slot = a.tile_slot[bx];
   if (slot < 0) return;
   const int n0 = by * NT;

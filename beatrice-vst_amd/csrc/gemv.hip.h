@@ -27,7 +27,7 @@ __device__ __forceinline__ void gemv_body(const ConvArgs& a, const int nt, float
   const int pairs = M * P;
   float* xs = lds;                             // [M][K] input rows (pre-activation applied)
   float* part = lds + M * K;                   // [pairs][16] segment results
-  const int hop = *a.hop;
+  const int hop = stepc::step(a.hop);
   if (hop < 0) return;
   const int pos_in = ring_pos(a.in, hop);
   for (int e = tid; e < M * (K / 4); e += NTHR) {

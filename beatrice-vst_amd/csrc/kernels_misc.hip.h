@@ -45,12 +45,18 @@ struct F1Args {
 };
 // grid (stream, hop-in-step).  Samples before the step come from the audio ring, the rest from d_in.
 constexpr int kF1LdsFloats = 168 + 10 * 64;
-__device__ __forceinline__ void phone_f1_body(const F1Args& a, const int b, const int hh, float* __restrict__ lds) {
-  float* x = lds;         // [5 + 160]
-  float* ws = lds + 168;  // [10][64]
-  const int tid = threadIdx.x, hop = *a.hop, H = a.H;
+// PACK streams per workgroup, 256 threads each (the tick launch runs 512-thread workgroups: two streams share one).
+// n_streams bounds the stream index when PACK > 1 (every thread still reaches the barrier).
+template <int PACK>
+__device__ __forceinline__ void phone_f1_body_t(const F1Args& a, const int bx, const int hh, float* __restrict__ lds, const int n_streams) {
+  const int tid = threadIdx.x & 255, part = PACK > 1 ? (int)(threadIdx.x >> 8) : 0;
+  float* x = lds + 168 * part;     // [5 + 160] per stream
+  float* ws = lds + 168 * PACK;    // [10][64], shared
+  const int b = bx * PACK + part;
+  const bool live = PACK == 1 || b < n_streams;
+  const int hop = stepc::step(a.hop), H = a.H;
   if (hop < 0) return;
-  const int io = a.io_stride != 0 ? a.hop[1] : 0;
+  const int io = a.io_stride != 0 ? stepc::slot(a.hop) : 0;
   if (a.hop_publish != nullptr && b == 0 && hh == 0 && tid == 0) {
     a.hop_publish[0] = hop; a.hop_publish[1] = io;
     if (a.hop_publish_wave != nullptr) { a.hop_publish_wave[(hop & 3) * 2] = hop; a.hop_publish_wave[(hop & 3) * 2 + 1] = io; }
@@ -62,17 +68,18 @@ __device__ __forceinline__ void phone_f1_body(const F1Args& a, const int b, cons
   const float* __restrict__ bias = a.bias;
   const int pos = ring_pos(audio, hop);
   const float* src = d_in + (size_t)b * H * B_IN_HOP;
-  for (int i = tid; i < 10 * 64; i += 256) ws[i] = w[i];
-  if (tid < 5) {
+  for (int i = threadIdx.x; i < 10 * 64; i += 256 * PACK) ws[i] = w[i];
+  if (live && tid < 5) {
     const int i = hh * B_IN_HOP + tid - 5;
     x[tid] = i < 0 ? *ring_frame(audio, b, pos, i) : src[i];
   }
-  if (tid < B_IN_HOP) {
+  if (live && tid < B_IN_HOP) {
     const float v = src[hh * B_IN_HOP + tid];
     x[5 + tid] = v;
     *ring_frame(audio, b, pos, hh * B_IN_HOP + tid) = v;
   }
   __syncthreads();
+  if (!live) return;
   const int t = tid >> 3, n0 = (tid & 7) * 8;
   float acc[8];
 #pragma unroll
@@ -87,6 +94,9 @@ __device__ __forceinline__ void phone_f1_body(const F1Args& a, const int b, cons
 #pragma unroll
   for (int u = 0; u < 8; ++u) o[u] = bsp::gelu(acc[u] + bias[n0 + u]);
 }
+__device__ __forceinline__ void phone_f1_body(const F1Args& a, const int b, const int hh, float* __restrict__ lds) {
+  phone_f1_body_t<1>(a, b, hh, lds, 0);
+}
 static __global__ __launch_bounds__(256) void phone_f1_kernel(const F1Args a) {
   __shared__ __attribute__((aligned(16))) float lds[kF1LdsFloats];
   phone_f1_body(a, blockIdx.x, blockIdx.y, lds);
@@ -96,6 +106,14 @@ struct F1Op {
   static constexpr int NTHR = 256;
   static constexpr int LDS_FLOATS = kF1LdsFloats;
   __device__ static __forceinline__ void run(const Args& a, int bx, int by, float* lds) { phone_f1_body(a, bx, by, lds); }
+};
+// two streams per 512-thread workgroup (H = 1): grid ((n_streams + 1) / 2, 1)
+struct F1Args2 { F1Args a; int n_streams; };
+struct F1Op2 {
+  using Args = F1Args2;
+  static constexpr int NTHR = 512;
+  static constexpr int LDS_FLOATS = 2 * 168 + 10 * 64;
+  __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { phone_f1_body_t<2>(a.a, bx, 0, lds, a.n_streams); }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -118,7 +136,7 @@ __device__ __forceinline__ void phone_vq_body(const VqArgs& a, const int row, fl
   int* red_j = reinterpret_cast<int*>(lds + B_PHONE_CH + 8);    // [8]
   int& winner = *reinterpret_cast<int*>(lds + B_PHONE_CH + 16);
   const int b = row / a.H, j = threadIdx.x, lane = j & 63, wave = j >> 6;
-  const int hop = *a.hop;
+  const int hop = stepc::step(a.hop);
   if (hop < 0) return;
   float* out = ring_frame(a.out, b, ring_pos(a.out, hop), row % a.H);
   const int k = a.k[b];
@@ -183,51 +201,60 @@ struct FftArgs {
   size_t io_stride;  // see F1Args
 };
 constexpr int kFftLdsFloats = 3 * B_FFT_N;
-__device__ __forceinline__ void pitch_fft_body(const FftArgs& a, const int b, const int hh, float* __restrict__ lds) {
-  float* re = lds;
-  float* im = lds + B_FFT_N;
-  float* tw = lds + 2 * B_FFT_N;
-  const int tid = threadIdx.x, hop = *a.hop, H = a.H;
+// PACK streams per workgroup, 256 threads each (see phone_f1_body_t); the twiddle table is shared
+template <int PACK>
+__device__ __forceinline__ void pitch_fft_body_t(const FftArgs& a, const int bx, const int hh, float* __restrict__ lds, const int n_streams) {
+  const int tid = threadIdx.x & 255, part = PACK > 1 ? (int)(threadIdx.x >> 8) : 0;
+  float* re = lds + 2 * B_FFT_N * part;
+  float* im = re + B_FFT_N;
+  float* tw = lds + 2 * B_FFT_N * PACK;
+  const int b = bx * PACK + part;
+  const bool live = PACK == 1 || b < n_streams;
+  const int hop = stepc::step(a.hop), H = a.H;
   if (hop < 0) return;
   const Ring& audio = a.audio;
   const Ring& spec = a.spec;
-  const float* __restrict__ d_in = a.d_in + (a.io_stride != 0 ? (size_t)a.hop[1] * a.io_stride : 0);
+  const float* __restrict__ d_in = a.d_in + (a.io_stride != 0 ? (size_t)stepc::slot(a.hop) * a.io_stride : 0);
   const float* __restrict__ window = a.window;
   const float* __restrict__ twiddle = a.twiddle;
   const int pos = ring_pos(audio, hop);
   const float* src = d_in + (size_t)b * H * B_IN_HOP;
-  for (int i = tid; i < B_FFT_N; i += 256) {
-    tw[i] = twiddle[i];
-    const int si = hh * B_IN_HOP + i - B_PITCH_HIST;  // sample index relative to the start of the step
-    float s;
-    if (si < 0) {
-      s = *ring_frame(audio, b, pos, si);
-    } else {
-      s = src[si];
-      if (i >= B_PITCH_HIST) *ring_frame(audio, b, pos, si) = s;  // each hop block appends its own 160 samples
+  for (int i = threadIdx.x; i < B_FFT_N; i += 256 * PACK) tw[i] = twiddle[i];
+  if (live)
+    for (int i = tid; i < B_FFT_N; i += 256) {
+      const int si = hh * B_IN_HOP + i - B_PITCH_HIST;  // sample index relative to the start of the step
+      float s;
+      if (si < 0) {
+        s = *ring_frame(audio, b, pos, si);
+      } else {
+        s = src[si];
+        if (i >= B_PITCH_HIST) *ring_frame(audio, b, pos, si) = s;  // each hop block appends its own 160 samples
+      }
+      const int rev = (int)(__brev((unsigned)i) >> 22);
+      re[rev] = s * window[i];
+      im[rev] = 0.0f;
     }
-    const int rev = (int)(__brev((unsigned)i) >> 22);
-    re[rev] = s * window[i];
-    im[rev] = 0.0f;
-  }
   __syncthreads();
   for (int half = 1; half < B_FFT_N; half <<= 1) {
     const int step = B_FFT_N / (2 * half);
+    if (live) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int bf = tid + u * 256;
-      const int j = bf & (half - 1);
-      const int ia = ((bf - j) << 1) + j, ib = ia + half;
-      const float wr = tw[2 * (j * step)], wi = tw[2 * (j * step) + 1];
-      const float br = re[ib], bi = im[ib];
-      const float tr = bsp::fma(-wi, bi, wr * br);
-      const float ti = bsp::fma(wi, br, wr * bi);
-      const float ar = re[ia], ai = im[ia];
-      re[ia] = ar + tr; im[ia] = ai + ti;
-      re[ib] = ar - tr; im[ib] = ai - ti;
+      for (int u = 0; u < 2; ++u) {
+        const int bf = tid + u * 256;
+        const int j = bf & (half - 1);
+        const int ia = ((bf - j) << 1) + j, ib = ia + half;
+        const float wr = tw[2 * (j * step)], wi = tw[2 * (j * step) + 1];
+        const float br = re[ib], bi = im[ib];
+        const float tr = bsp::fma(-wi, bi, wr * br);
+        const float ti = bsp::fma(wi, br, wr * bi);
+        const float ar = re[ia], ai = im[ia];
+        re[ia] = ar + tr; im[ia] = ai + ti;
+        re[ib] = ar - tr; im[ib] = ai - ti;
+      }
     }
     __syncthreads();
   }
+  if (!live) return;
   float* o = ring_frame(spec, b, ring_pos(spec, hop), hh);
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
@@ -235,6 +262,9 @@ __device__ __forceinline__ void pitch_fft_body(const FftArgs& a, const int b, co
     const float pw = bsp::fma(im[k], im[k], re[k] * re[k]);
     o[k] = 0.5f * bsp::log(pw + 1e-5f);
   }
+}
+__device__ __forceinline__ void pitch_fft_body(const FftArgs& a, const int b, const int hh, float* __restrict__ lds) {
+  pitch_fft_body_t<1>(a, b, hh, lds, 0);
 }
 static __global__ __launch_bounds__(256) void pitch_fft_kernel(const FftArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[kFftLdsFloats];
@@ -245,6 +275,13 @@ struct FftOp {
   static constexpr int NTHR = 256;
   static constexpr int LDS_FLOATS = kFftLdsFloats;
   __device__ static __forceinline__ void run(const Args& a, int bx, int by, float* lds) { pitch_fft_body(a, bx, by, lds); }
+};
+struct FftArgs2 { FftArgs a; int n_streams; };
+struct FftOp2 {  // two streams per 512-thread workgroup (H = 1): grid ((n_streams + 1) / 2, 1)
+  using Args = FftArgs2;
+  static constexpr int NTHR = 512;
+  static constexpr int LDS_FLOATS = 5 * B_FFT_N;
+  __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { pitch_fft_body_t<2>(a.a, bx, 0, lds, a.n_streams); }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -300,9 +337,8 @@ __device__ inline int pitch_transform_device(int q, const PitchParams& p) {
   return qi < 1 ? 1 : (qi > B_PITCH_BINS - 1 ? B_PITCH_BINS - 1 : qi);
 }
 
-__device__ __forceinline__ void pitch_head_body(const PitchHeadArgs& a, const int b) {
-  const int l = threadIdx.x;
-  const int hop = *a.hop;
+__device__ __forceinline__ void pitch_head_body(const PitchHeadArgs& a, const int b, const int l = threadIdx.x) {
+  const int hop = stepc::step(a.hop);
   if (hop < 0) return;
   const size_t qoff = (size_t)(hop % a.q_slots) * a.B * a.H;
   const int pos_l = ring_pos(a.logits, hop);
@@ -336,7 +372,7 @@ __device__ __forceinline__ void pitch_head_body(const PitchHeadArgs& a, const in
 #pragma unroll
     for (int i = 0; i < 7; ++i) s = s + bsp::exp(v[i] - mx);
     const float f0 = bsp::exp(lg[q] - mx) / bsp::wsum64(s);
-    const float* x = a.d_in + (a.io_stride != 0 ? (size_t)a.hop[1] * a.io_stride : 0) + row * B_IN_HOP;
+    const float* x = a.d_in + (a.io_stride != 0 ? (size_t)stepc::slot(a.hop) * a.io_stride : 0) + row * B_IN_HOP;
     float en = 0.0f;
     for (int i = l; i < B_IN_HOP; i += 64) en = bsp::fma(x[i], x[i], en);
     const float f1 = 0.1f * bsp::log(bsp::fma(bsp::wsum64(en), 1.0f / 160.0f, 1e-8f));
@@ -362,6 +398,15 @@ struct HeadOp {
   static constexpr int LDS_FLOATS = 0;
   __device__ static __forceinline__ void run(const Args& a, int bx, int, float*) { pitch_head_body(a, bx); }
 };
+struct HeadOp8 {  // one wavefront per stream, eight streams per 512-thread workgroup: grid ((B + 7) / 8, 1)
+  using Args = PitchHeadArgs;
+  static constexpr int NTHR = 512;
+  static constexpr int LDS_FLOATS = 0;
+  __device__ static __forceinline__ void run(const Args& a, int bx, int, float*) {
+    const int b = bx * 8 + (int)(threadIdx.x >> 6);
+    if (b < a.B) pitch_head_body(a, b, (int)(threadIdx.x & 63));
+  }
+};
 
 // ---------------------------------------------------------------------------------------------
 // Waveform input mix, conditioning part (MODEL_SPEC 4.4.1):
@@ -381,9 +426,9 @@ struct CondArgs {
                        // no kernel of this step's front end reads that pair after its first launch
   int io_slots;
 };
-__device__ __forceinline__ void wave_cond_body(const CondArgs& a, const int row) {
-  const int b = row / a.H, n = threadIdx.x;
-  const int hop = *a.hop;
+__device__ __forceinline__ void wave_cond_body(const CondArgs& a, const int row, const int n = threadIdx.x) {
+  const int b = row / a.H;
+  const int hop = stepc::step(a.hop);
   if (hop < 0) return;
   const size_t qoff = (size_t)(hop % a.q_slots) * a.B * a.H;
   int q = a.q[qoff + row];
@@ -395,7 +440,7 @@ __device__ __forceinline__ void wave_cond_body(const CondArgs& a, const int row)
   const float c = a.add_tab[(size_t)a.add_idx[b] * B_HID + n] + a.frm_tab[(size_t)a.frm_idx[b] * B_HID + n];
   ring_frame(a.e, b, ring_pos(a.e, hop), row % a.H)[n] = (a.pitch_emb[(size_t)q * B_HID + n] + fp) + c;
   if (a.hop_next_out != nullptr && row == 0 && n == 0) {
-    const int io = a.io_slots > 0 ? a.hop[1] : 0;
+    const int io = a.io_slots > 0 ? stepc::slot(a.hop) : 0;
     a.hop_next_out[0] = hop_next(hop);
     a.hop_next_out[1] = a.io_slots > 0 ? (io + 1 >= a.io_slots ? 0 : io + 1) : 0;
   }
@@ -406,6 +451,15 @@ struct CondOp {
   static constexpr int NTHR = 256;
   static constexpr int LDS_FLOATS = 0;
   __device__ static __forceinline__ void run(const Args& a, int bx, int, float*) { wave_cond_body(a, bx); }
+};
+struct CondOp2 {  // two rows per 512-thread workgroup: grid ((rows + 1) / 2, 1), rows = B * H
+  using Args = CondArgs;
+  static constexpr int NTHR = 512;
+  static constexpr int LDS_FLOATS = 0;
+  __device__ static __forceinline__ void run(const Args& a, int bx, int, float*) {
+    const int row = bx * 2 + (int)(threadIdx.x >> 8);
+    if (row < a.B * a.H) wave_cond_body(a, row, (int)(threadIdx.x & 255));
+  }
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -30,3 +30,13 @@ __device__ __forceinline__ float* ring_frame(const Ring& r, int b, int pos, int 
   if (f < 0) f += R;
   return r.base + ((size_t)b * R + f) * r.C;
 }
+
+// The step counter a kernel works on, and the slot of resident I/O buffers that belongs to it.  Ordinary launches read
+// the pair from device memory (args.hop); in the batch's tick launch (tick.hip.h) the table kernel takes every stage's
+// pair from its kernel arguments and leaves it in LDS for the body it dispatches to -- no dependent global load at the
+// start of a workgroup, no separate launch to publish the counters: there args.hop is null.
+namespace stepc {
+__shared__ int pair[2];
+__device__ __forceinline__ int step(const int* p) { return p != nullptr ? *p : pair[0]; }
+__device__ __forceinline__ int slot(const int* p) { return p != nullptr ? p[1] : pair[1]; }
+}  // namespace stepc

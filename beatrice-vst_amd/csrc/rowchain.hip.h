@@ -137,7 +137,7 @@ __device__ __forceinline__ void block_a_body(const BlockAArgs& a, const int g, f
   float* Hh = lds + 3 * TILE;
   int* sid = reinterpret_cast<int*>(lds + 4 * TILE);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int hop = *a.hop;
+  const int hop = stepc::step(a.hop);
   if (hop < 0) return;
   if (tid < 16) sid[tid] = g * 16 + tid < a.B ? g * 16 + tid : -1;
   __syncthreads();
@@ -198,7 +198,7 @@ __device__ __forceinline__ void block_b_body(const BlockBArgs& a, const int g, f
   float* inv = S + STILE;
   int* sid = reinterpret_cast<int*>(inv + 16);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int hop = *a.hop;
+  const int hop = stepc::step(a.hop);
   if (hop < 0) return;
   const int slot = a.tile_slot[g];
   if (slot < 0) return;
@@ -294,7 +294,7 @@ __device__ __forceinline__ void conv_rows_body(const ConvArgs& a, const int bx, 
   float* slot[2] = {lds, lds + TILE};
   int* rb_ = reinterpret_cast<int*>(lds + 2 * TILE);  // [16] stream, [16] frame of each row
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int hop = *a.hop;
+  const int hop = stepc::step(a.hop);
   if (hop < 0) return;
   const int M = a.B * L::T;
   if (tid < 16) {

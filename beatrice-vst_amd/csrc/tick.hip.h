@@ -4,8 +4,7 @@
 // Why: at a few hundred streams a step is a string of ~40 dependent, latency-bound launches, each using a fraction of
 // the chip for 4-9 us.  Streams never exchange data and every mutable thing is per-stream
 // state, so consecutive steps can overlap as long as stage s of step t+1 runs after stage s of step t.  A tick is ONE
-// launch (plus the fused upsampler tail, whose LDS footprint would cap the occupancy of everything else) in which
-// stage s works on step (tick - s): ~5000 independent workgroups of 40 different steps fill the chip, and the only
+// launch in which stage s works on step (tick - s): ~2500 independent workgroups of 26 different steps fill the chip, and the only
 // synchronisation is the kernel boundary between ticks.  Outputs are bit-identical to the in-order chain: the same
 // kernel bodies run on the same data, only later.  A step's output appears n_stages - 1 ticks after its input was
 // fed; BeatriceBatch_Synchronize drains the pipeline.  For callers that enqueue steps ahead of their completion
@@ -15,8 +14,10 @@
 //   * every ring a LATER stage reads holds one more step slot than the in-order chain needs (State::create with
 //     pipe_slack; the block scratch xa, read again four stages on, holds five), the small non-ring outputs of the pitch
 //     head are double-buffered by step parity;
-//   * each stage reads its own {step counter, I/O slot} pair (d_hops[stage]), written by a small prologue launch from
-//     values the host computes (the host knows which step every stage is at); -1 = "no step this tick" (fill, drain);
+//   * each stage has its own {step counter, I/O slot} pair, computed by the host (which knows the step every stage is
+//     at) and passed to the launch BY VALUE (fuse::StepPairs in the kernel arguments; a workgroup leaves its body's pair
+//     in LDS, ring.h stepc): no launch to publish counters, no dependent global load at the start of a workgroup;
+//     -1 = "no step this tick" (fill, drain);
 //   * per-stream settings are versioned: a change is uploaded once into a slot of a snapshot ring, and the prologue
 //     copies the snapshot into a consumer's private arrays at the tick that consumer reaches the step the change
 //     belongs to (consumers: k-NN, pitch head, conditioning mix, the two attention kernels of each block).
@@ -36,14 +37,10 @@ struct Prolog {
   int n_copies;
   Copy copy[kMaxCopies];
 };
-// workgroup 0 writes the stages' counters, workgroup 1 + c performs settings copy c (16-byte granules)
-static __global__ __launch_bounds__(256) void prologue_kernel(int* __restrict__ hops, const Prolog p) {
+// workgroup c performs settings copy c (16-byte granules); launched only on ticks that have copies
+static __global__ __launch_bounds__(256) void prologue_kernel(const Prolog p) {
   const int tid = threadIdx.x;
-  if (blockIdx.x == 0) {
-    for (int s = tid; s < p.n_stages; s += 256) { hops[2 * s] = p.hop[s]; hops[2 * s + 1] = p.io[s]; }
-    return;
-  }
-  const Copy c = p.copy[blockIdx.x - 1];
+  const Copy c = p.copy[blockIdx.x];
   const uint4* src = reinterpret_cast<const uint4*>(c.src);
   uint4* dst = reinterpret_cast<uint4*>(c.dst);
   for (int i = tid; i < c.bytes / 16; i += 256) dst[i] = src[i];
@@ -82,9 +79,9 @@ enum BodyType {
   T_QGRU, T_PGRU, T_VQ, T_TAIL, T_BLKA1, T_BLKA2, T_BLKA4, T_BLKA8, T_BLKB, T_COUNT
 };
 #define TICK_TYPES                                                                                                            \
-    fuse::Many<F1Op, 1>, fuse::Many<FftOp, 1>, fuse::Many<OpF2, 1>, fuse::Many<OpF3, 1>, fuse::Many<OpF4, 1>, fuse::Many<OpF5, 1>, \
-    fuse::Many<OpP1, 1>, fuse::Many<OpRB, 4>, fuse::Many<OpP23, 2>, fuse::Many<OpPOUT, 1>, fuse::Many<HeadOp, 1>,                  \
-    fuse::Many<OpOUT, 1>, fuse::Many<CondOp, 1>, fuse::Many<OpINP, 1>, fuse::Many<OpUP1, 1>, fuse::Many<OpRES1A, 1>,               \
+    fuse::Many<F1Op2, 1>, fuse::Many<FftOp2, 1>, fuse::Many<OpF2, 1>, fuse::Many<OpF3, 1>, fuse::Many<OpF4, 1>, fuse::Many<OpF5, 1>, \
+    fuse::Many<OpP1, 1>, fuse::Many<OpRB, 4>, fuse::Many<OpP23, 2>, fuse::Many<OpPOUT, 1>, fuse::Many<HeadOp8, 1>,                  \
+    fuse::Many<OpOUT, 1>, fuse::Many<CondOp2, 1>, fuse::Many<OpINP, 1>, fuse::Many<OpUP1, 1>, fuse::Many<OpRES1A, 1>,               \
     fuse::Many<OpRES1B, 1>, fuse::Many<OpUP2, 1>, fuse::Many<GruOp<128, 128>, 1>, fuse::Many<GruOp<256, 256>, 1>,                  \
     fuse::Many<VqOp, 1>, fuse::Many<TailOp<1>, 1>, fuse::Many<rc::BlockAOp<1>, 1>, fuse::Many<rc::BlockAOp<2>, 1>,                 \
     fuse::Many<rc::BlockAOp<4>, 1>, fuse::Many<rc::BlockAOp<8>, 1>, fuse::Many<rc::BlockBOp, 4>
@@ -103,7 +100,7 @@ struct Plan {
   int tail() const { return up1() + 4; }
   int count() const { return tail() + 1; }
 };
-static_assert(Plan::BLK0 + Plan::per_block * B_NBLOCKS + 5 <= kMaxStages && kMaxStages + 2 <= kRing, "stage bookkeeping");
+static_assert(Plan::BLK0 + Plan::per_block * B_NBLOCKS + 5 <= kMaxStages && kMaxStages + 2 <= kRing && kMaxStages <= fuse::kMaxStepPairs, "stage bookkeeping");
 
 struct Consumer {  // a kernel that reads per-stream settings: its private copy of a byte range of the settings block
   int stage;
@@ -114,7 +111,6 @@ struct Consumer {  // a kernel that reads per-stream settings: its private copy 
 
 struct State {
   bool on = false;
-  int* d_hops = nullptr;            // [kMaxStages][2]
   Tab* d_table = nullptr;
   int table_total = 0;
   double table_flops = 0, table_bytes = 0;  // algorithmic work of one full tick (sum over the bodies)

@@ -206,9 +206,9 @@ __device__ __forceinline__ void wave_tail_body(const TailArgs& a, const int b, f
   TAIL_STAMP(0);
 
   // biases, output-conv taps and the stream's state block: one round of global loads
-  const int hop = *a.hop;
+  const int hop = stepc::step(a.hop);
   if (hop < 0) return;
-  const int io = a.io_stride != 0 ? a.hop[1] : 0;
+  const int io = a.io_stride != 0 ? stepc::slot(a.hop) : 0;
   float* __restrict__ d_out = a.d_out + (size_t)io * a.io_stride;
   for (int e = tid; e < TAIL_STATE_FLOATS; e += NTHR) SI_[e] = st[e];
   if (tid < BIAS_FLOATS) {

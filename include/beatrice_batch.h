@@ -183,11 +183,11 @@ void* BeatriceBatch_GetWaveStream(const BeatriceBatch* b);
 /* Tick pipelining: the deepest form of the same idea, on ONE stream.  Every layer of the chain is its own pipeline
  * stage (the conditioned blocks: two stages each, as row-local chains); each BeatriceBatch_ConvertFramesDevice(b, NULL, NULL)
  * is one "tick" -- a single launch of 512-thread workgroups in which stage s works on the step fed s ticks ago, so ~26
- * steps are in flight and their ~2600 independent workgroups fill the chip two per CU, with the kernel boundary between
+ * steps are in flight and their ~1900 independent workgroups (at 256 streams) fill the chip two per CU, with the kernel boundary between
  * ticks as the only synchronisation.  Same samples, bit for bit; a step's output lands
  * in its resident-I/O slot BeatriceBatch_TickStages() - 1 ticks after its input was fed, and BeatriceBatch_Synchronize
  * drains the pipeline (that many ticks without new input).  Settings changed between steps apply to exactly the step
- * they precede.  Requirements (-1 otherwise): one hop per step, at most 256 streams, resident I/O bound with more slots
+ * they precede.  Requirements (-1 otherwise): one hop per step, at most 4096 streams (tested to 600, measured to 4096), resident I/O bound with more slots
  * than stages, and the caller must leave a step's INPUT slot untouched for BeatriceBatch_TickStages() further steps.
  * The host-buffer, 48 kHz and profiling entry points return -1 while it is on. */
 int BeatriceBatch_EnableTickPipeline(BeatriceBatch* b, int enable);

@@ -12,3 +12,13 @@ for t in sorted(set(typ.tolist())):
     m = typ == t
     name = NAMES[t] if 0 <= t < len(NAMES) else "idle"
     print("  %-6s n %4d  dur mean %6.1f max %6.1f  first start %6.1f  last end %6.1f" % (name, m.sum(), (end - start)[m].mean(), (end - start)[m].max(), start[m].min(), end[m].max()))
+# residency over time: workgroups resident per 5 us bin, split heavy (mean duration >= 25 us) / other
+dur = end - start
+heavy_types = {t for t in set(typ.tolist()) if dur[typ == t].mean() >= 25.0}
+edges = np.arange(0, end.max() + 5, 5.0)
+print("  t(us)   resident  heavy  other")
+for lo in edges[:-1]:
+    mid = lo + 2.5
+    live = (start <= mid) & (end > mid)
+    h = sum(int((live & (typ == t)).sum()) for t in heavy_types)
+    print("  %5.1f   %6d   %5d  %5d" % (mid, live.sum(), h, live.sum() - h))

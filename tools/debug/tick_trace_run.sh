@@ -1,0 +1,5 @@
+#!/bin/bash
+# per-workgroup timeline of a full tick: tools/debug/tick_trace_run.sh [DROP mask]
+export BEATRICE_HIP_TICK_DROP=${1:-0}
+BEATRICE_HIP_TICK_TRACE=/tmp/tick_trace.txt python bench.py --steps 100 --warmup 30 --no-extras > /dev/null 2>&1
+python tools/debug/tick_trace.py /tmp/tick_trace.txt
