@@ -18,7 +18,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
-PRODUCT_LIB = os.path.join(HERE, "csrc", "libbeatrice_hip.so")
+# (BEATRICE_HIP_LIB: another build of the same library, for A/B measurements of kernel variants)
+PRODUCT_LIB = os.environ.get("BEATRICE_HIP_LIB") or os.path.join(HERE, "csrc", "libbeatrice_hip.so")
 
 IN_HOP, OUT_HOP = 160, 240
 PHONE_CH, HID, PITCH_BINS = 128, 256, 448
@@ -263,6 +264,10 @@ _BATCH = {
     "BeatriceBatch_IsHealthy": (C.c_int, [_vp]),
     "BeatriceBatch_NumStreams": (C.c_int, [_vp]),
     "BeatriceBatch_SetSpeakerTables": (C.c_int, [_vp, C.c_int, _f32p, _f32p, _f32p, _f32p]),
+    "BeatriceBatch_EnableHostStreaming": (C.c_int, [_vp, C.c_int]),
+    "BeatriceBatch_HostStreamDelay": (C.c_int, [_vp]),
+    "BeatriceBatch_StreamFrames": (C.c_int, [_vp, _f32p, _f32p]),
+    "BeatriceBatch_StreamFlush": (C.c_int, [_vp, _f32p]),
     "BeatriceBatch_SpeakerTablesDevice": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "BeatriceBatch_ProjectSpeakerTables": (C.c_int, [_vp, C.c_int]),
     "BeatriceBatch_UpdateSpeaker": (C.c_int, [_vp, C.c_int, _f32p, _f32p, _f32p]),

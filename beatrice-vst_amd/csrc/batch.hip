@@ -17,6 +17,7 @@
 #include <random>
 #include <string>
 #include <type_traits>
+#include <deque>
 #include <vector>
 
 #include "abi_objects.h"
@@ -179,6 +180,20 @@ struct BeatriceBatch {
   int io_host = 0;            // mirror of the device's resident-I/O slot counter
   int last_hop = 0;           // step counter of the last enqueued step (selects the slot of the pitch head's outputs)
   tick::State tk;             // tick pipelining (tick.hip.h)
+  // host streaming (BeatriceBatch_EnableHostStreaming): tick pipelining fed from / drained to HOST buffers, the copies
+  // on their own streams beside the ticks
+  struct HostStream {
+    bool on = false;
+    int n_slots = 0;
+    float *d_in = nullptr, *d_out = nullptr;   // [n_slots][B][160], [n_slots][B][240]: the resident I/O the ticks use
+    float *h_in = nullptr, *h_out = nullptr;   // pinned mirrors
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    std::vector<hipEvent_t> ev_in, ev_out;     // per slot: upload done / download done
+    std::vector<hipEvent_t> ev_tick;           // ring over ticks: tick launched (recorded on the batch's stream)
+    struct Pending { long long step; int slot; long long done_tick; bool fetched; };
+    std::deque<Pending> pending;               // steps fed and not yet handed back, oldest first
+    long long fed = 0;
+  } hs;
   // any-rate device wrapper (wrapper.hip.h): the reference host's gains, resampler pair and 480-sample FIFO for all streams
   wrapn::WrapPlan wrap;
   std::vector<wrapn::GainClock> gain_in, gain_out;  // [B]
@@ -198,6 +213,7 @@ namespace {
 hipStream_t stage_stream(const BeatriceBatch* b, int s) { return b->pipelined && s > 0 ? b->stage_stream_own[s] : b->stream; }
 hipStream_t wave_stream(const BeatriceBatch* b) { return stage_stream(b, b->n_stages - 1); }  // where a step's output appears
 bool tick_drain(BeatriceBatch* b);
+void host_stream_free(BeatriceBatch* b);
 bool sync_all(BeatriceBatch* b) {
   bool ok = !b->tk.on || tick_drain(b);  // steps still inside the tick pipeline come out first
   ok = hip_ok(hipStreamSynchronize(b->stream), "sync") && ok;
@@ -906,6 +922,7 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   if (b->h_wrap_io) (void)hipHostFree(b->h_wrap_io);
   b->wrap_gains.release();
   { void* tk[] = {b->tk.d_table, b->tk.d_snap, b->tk.d_trace}; for (void* p : tk) if (p) (void)hipFree(p); }
+  host_stream_free(b);
   if (b->own_d_out) { b->wave.d_out = b->own_d_out; b->own_d_out = nullptr; }
   if (b->module_owned[0]) {  // hand the modules their own arrays back so that destroy() frees what it allocated
     void** keep = b->module_owned;
@@ -1376,6 +1393,127 @@ int BeatriceBatch_EnableGraph(BeatriceBatch* b, int enable) {
   if (!b->use_graph) drop_graph(b);
   return 0;
 }
+// ---- host streaming: the tick pipeline with HOST buffers on either side -----------------------------------------------------
+// Call k uploads its input on a copy stream (after tick k-2, by when every reader of the slot it re-uses is done), the
+// batch's stream waits for that upload and launches tick k, a second copy stream downloads the step that tick k
+// completed, and the call hands back the step whose download was enqueued two calls earlier -- so uploads, ticks and
+// downloads of neighbouring steps overlap and the host only ever waits for work that is long finished.
+static void host_stream_fetch(BeatriceBatch* b) {  // enqueue the download of every step the ticks run so far have completed
+  BeatriceBatch::HostStream& h = b->hs;
+  const long long last_tick = b->tk.tick - 1;
+  const size_t n_out = (size_t)b->B * B_OUT_HOP;
+  for (auto& p : h.pending) {
+    if (p.fetched || p.done_tick > last_tick) continue;
+    (void)hipStreamWaitEvent(h.s_out, h.ev_tick[p.done_tick % h.ev_tick.size()], 0);
+    (void)hipMemcpyAsync(h.h_out + p.slot * n_out, h.d_out + p.slot * n_out, sizeof(float) * n_out, hipMemcpyDeviceToHost, h.s_out);
+    (void)hipEventRecord(h.ev_out[p.slot], h.s_out);
+    p.fetched = true;
+  }
+}
+static bool host_stream_tick(BeatriceBatch* b, bool feeding) {
+  BeatriceBatch::HostStream& h = b->hs;
+  const long long t = b->tk.tick;
+  if (!tick_run(b, feeding)) return false;
+  (void)hipEventRecord(h.ev_tick[t % h.ev_tick.size()], b->stream);
+  host_stream_fetch(b);
+  return true;
+}
+}  // extern "C"
+namespace {
+void host_stream_free(BeatriceBatch* b) {
+  BeatriceBatch::HostStream& h = b->hs;
+  for (hipEvent_t e : h.ev_in) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h.ev_out) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h.ev_tick) if (e) (void)hipEventDestroy(e);
+  h.ev_in.clear(); h.ev_out.clear(); h.ev_tick.clear();
+  if (h.s_in) (void)hipStreamDestroy(h.s_in);
+  if (h.s_out) (void)hipStreamDestroy(h.s_out);
+  if (h.d_in) (void)hipFree(h.d_in);
+  if (h.d_out) (void)hipFree(h.d_out);
+  if (h.h_in) (void)hipHostFree(h.h_in);
+  if (h.h_out) (void)hipHostFree(h.h_out);
+  h = BeatriceBatch::HostStream{};
+}
+}  // namespace
+extern "C" {
+int BeatriceBatch_EnableHostStreaming(BeatriceBatch* b, int enable) {
+  if (!b || !b->ok) return -2;
+  BeatriceBatch::HostStream& h = b->hs;
+  if ((enable != 0) == h.on) return 0;
+  if (!enable) {
+    if (!sync_all(b)) return -2;
+    (void)hipStreamSynchronize(h.s_in); (void)hipStreamSynchronize(h.s_out);
+    const int rc = tick_enable(b, false);
+    if (rc) return rc;
+    const int rb = BeatriceBatch_BindResidentIO(b, nullptr, nullptr, 0);
+    host_stream_free(b);
+    return rb;
+  }
+  if (b->H != 1 || b->io_slots > 0 || b->tk.on || b->pipelined) return -1;  // one hop per step; no other binding or pipelining
+  h.n_slots = b->tk.plan.count() + 8;
+  const size_t n_in = (size_t)b->B * B_IN_HOP, n_out = (size_t)b->B * B_OUT_HOP;
+  bool ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&h.d_in), sizeof(float) * n_in * h.n_slots), "hs d_in") &&
+            hip_ok(hipMalloc(reinterpret_cast<void**>(&h.d_out), sizeof(float) * n_out * h.n_slots), "hs d_out") &&
+            hip_ok(hipHostMalloc(reinterpret_cast<void**>(&h.h_in), sizeof(float) * n_in * h.n_slots, hipHostMallocDefault), "hs h_in") &&
+            hip_ok(hipHostMalloc(reinterpret_cast<void**>(&h.h_out), sizeof(float) * n_out * h.n_slots, hipHostMallocDefault), "hs h_out") &&
+            hip_ok(hipMemset(h.d_in, 0, sizeof(float) * n_in * h.n_slots), "hs zero") &&
+            hip_ok(hipStreamCreateWithFlags(&h.s_in, hipStreamNonBlocking), "hs s_in") &&
+            hip_ok(hipStreamCreateWithFlags(&h.s_out, hipStreamNonBlocking), "hs s_out");
+  h.ev_in.assign(h.n_slots, nullptr); h.ev_out.assign(h.n_slots, nullptr); h.ev_tick.assign(tick::kRing, nullptr);
+  for (auto* v : {&h.ev_in, &h.ev_out, &h.ev_tick})
+    for (hipEvent_t& e : *v) ok = ok && hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hs event");
+  ok = ok && BeatriceBatch_BindResidentIO(b, h.d_in, h.d_out, h.n_slots) == 0 && tick_enable(b, true) == 0;
+  if (!ok) { (void)tick_enable(b, false); (void)BeatriceBatch_BindResidentIO(b, nullptr, nullptr, 0); host_stream_free(b); return -2; }
+  h.pending.clear();
+  h.fed = 0;
+  h.on = true;
+  return 0;
+}
+int BeatriceBatch_HostStreamDelay(const BeatriceBatch* b) { return b ? b->tk.plan.count() + 1 : 0; }
+// in: [B][160] host; out: [B][240] host.  Returns 1 when `out` received the samples of the step fed
+// BeatriceBatch_HostStreamDelay() calls ago, 0 while the pipeline is still filling (out untouched), < 0 on error.
+int BeatriceBatch_StreamFrames(BeatriceBatch* b, const float* in, float* out) {
+  if (!b || !b->ok) return -2;
+  BeatriceBatch::HostStream& h = b->hs;
+  if (!h.on || !in || !out) return -1;
+  const size_t n_in = (size_t)b->B * B_IN_HOP, n_out = (size_t)b->B * B_OUT_HOP;
+  const int slot = b->io_host;  // the slot the tick about to be fed reads and, pipeline depth later, writes
+  const long long t = b->tk.tick;
+  if (!hip_ok(hipEventSynchronize(h.ev_in[slot]), "hs in reuse")) return -2;  // the upload that last used this pinned slot (long done)
+  std::memcpy(h.h_in + slot * n_in, in, sizeof(float) * n_in);
+  if (t >= 2) (void)hipStreamWaitEvent(h.s_in, h.ev_tick[(t - 2) % h.ev_tick.size()], 0);   // every reader of the device slot's old contents is done
+  bool ok = hip_ok(hipMemcpyAsync(h.d_in + slot * n_in, h.h_in + slot * n_in, sizeof(float) * n_in, hipMemcpyHostToDevice, h.s_in), "hs upload");
+  (void)hipEventRecord(h.ev_in[slot], h.s_in);
+  (void)hipStreamWaitEvent(b->stream, h.ev_in[slot], 0);
+  (void)hipStreamWaitEvent(b->stream, h.ev_out[slot], 0);  // the output slot this step will overwrite has been downloaded
+  h.pending.push_back({h.fed, slot, t + b->tk.plan.count() - 1, false});
+  h.fed += 1;
+  ok = ok && host_stream_tick(b, true);
+  if (!ok) return -2;
+  const BeatriceBatch::HostStream::Pending& f = h.pending.front();
+  if (!f.fetched || f.done_tick > t - 2) return 0;   // hand back only what was enqueued for download two ticks ago
+  if (!hip_ok(hipEventSynchronize(h.ev_out[f.slot]), "hs download")) return -2;
+  std::memcpy(out, h.h_out + f.slot * n_out, sizeof(float) * n_out);
+  h.pending.pop_front();
+  return 1;
+}
+// After the last StreamFrames: hands back the next step still inside the pipeline (running ticks without input as
+// needed); returns 1 with `out` filled, 0 when nothing is pending.
+int BeatriceBatch_StreamFlush(BeatriceBatch* b, float* out) {
+  if (!b || !b->ok) return -2;
+  BeatriceBatch::HostStream& h = b->hs;
+  if (!h.on || !out) return -1;
+  if (h.pending.empty()) return 0;
+  const size_t n_out = (size_t)b->B * B_OUT_HOP;
+  while (!h.pending.front().fetched)
+    if (!host_stream_tick(b, false)) return -2;
+  const BeatriceBatch::HostStream::Pending f = h.pending.front();
+  if (!hip_ok(hipEventSynchronize(h.ev_out[f.slot]), "hs flush")) return -2;
+  std::memcpy(out, h.h_out + f.slot * n_out, sizeof(float) * n_out);
+  h.pending.pop_front();
+  return 1;
+}
+
 // Throughput mode for callers that enqueue steps ahead (BeatriceBatch_ConvertFramesDevice without waiting,
 // resident I/O): the front end of step t+1 runs on the batch's stream while the waveform generator of step t
 // runs on a second stream.  Same results; a step's output is complete when BeatriceBatch_Synchronize returns

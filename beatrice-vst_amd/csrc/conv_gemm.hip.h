@@ -445,7 +445,10 @@ static inline void launch_conv(const char* name, const ConvArgs& a, int n_group_
 
 // ---- launch helpers shared by the modules ------------------------------------------------------
 template <class L> using TLat = TileCfg<1, 1, 1, 2, L::P>;  // 16 x 32 tile, one 2-wave k-group per segment
-using TL = TileCfg<2, 2, 2, 2, 1>;                            // 64 x 64 tile, segments interleaved
+#ifndef BEATRICE_TL
+#define BEATRICE_TL 2, 2, 2, 2, 1
+#endif
+using TL = TileCfg<BEATRICE_TL>;                              // 64 x 64 tile, segments interleaved (BEATRICE_TL: A/B builds)
 
 #include "gemv.hip.h"  // (needs everything above; defines gemv::launch)
 

@@ -64,13 +64,27 @@ KINDS = (("phone", 1, "ReadPhoneExtractorParameters", "phone_extractor.bin"),
          ("embed", 4, "ReadEmbeddingSetterParameters", "embedding_setter.bin"))
 
 
+def all_ranks_ok(ok, world, dist, torch, device):
+    """True only if `ok` is true on every rank (MIN all-reduce): ranks must take the same branch before a collective."""
+    if world == 1:
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+LOADERS = {"phone": "BeatriceHip_LoadPhoneExtractorFromMemory", "pitch": "BeatriceHip_LoadPitchEstimatorFromMemory",
+           "wave": "BeatriceHip_LoadWaveformGeneratorFromMemory", "embed": "BeatriceHip_LoadEmbeddingSetterFromMemory"}
+
+
 def load_models_from_rank0(product, objs, model_dir, rank, world, dist, torch, device="cuda"):
     """The four model objects of this rank (objs: name -> handle, freshly created).  Rank 0 reads and packs the files
     (Read*Parameters); every other rank gets an empty device blob of the same size (BeatriceHip_ModelBlob) that
     receives rank 0's PACKED blob by one broadcast each, device to device -- no file, no host copy, no repacking --
-    and is then marked ready.  Returns the bytes broadcast."""
+    and is then marked ready.  If any rank cannot expose its blobs to torch, ALL ranks agree (all_ranks_ok) to ship
+    the file bytes instead (broadcast_bytes + BeatriceHip_Load*FromMemory).  Returns (bytes broadcast, path taken)."""
     import ctypes as C
-    moved = 0
+    views, ok = {}, True
     for name, kind, reader, fname in KINDS:
         if rank == 0:
             err = getattr(product, reader)(objs[name], os.path.join(model_dir, fname).encode())
@@ -78,38 +92,86 @@ def load_models_from_rank0(product, objs, model_dir, rank, world, dist, torch, d
                 raise RuntimeError("%s: Beatrice_ErrorCode %d" % (fname, err))
         if world == 1:
             continue
-        ptr, nbytes = C.c_void_p(), C.c_size_t()
-        rc = product.BeatriceHip_ModelBlob(kind, objs[name], 0 if rank == 0 else 1, C.byref(ptr), C.byref(nbytes))
+        try:
+            ptr, nbytes = C.c_void_p(), C.c_size_t()
+            rc = product.BeatriceHip_ModelBlob(kind, objs[name], 0 if rank == 0 else 1, C.byref(ptr), C.byref(nbytes))
+            if rc:
+                raise RuntimeError("BeatriceHip_ModelBlob(%s): %d" % (name, rc))
+            views[name] = device_bytes(torch, ptr.value, nbytes.value, device)
+        except Exception as e:  # noqa: BLE001 -- any failure means "take the other path", decided collectively below
+            print("shard: rank %d cannot share the %s blob in place (%s)" % (rank, name, e))
+            ok = False
+    if world == 1:
+        return 0, "file"
+    if all_ranks_ok(ok, world, dist, torch, device):
+        moved = 0
+        for name, kind, _, _ in KINDS:
+            broadcast_inplace(views[name], world, dist)
+            moved += views[name].numel()
+            if rank != 0:
+                torch.cuda.synchronize()
+                rc = product.BeatriceHip_ModelBlobReady(kind, objs[name])
+                if rc:
+                    raise RuntimeError("BeatriceHip_ModelBlobReady(%s): %d" % (name, rc))
+        return moved, "device blobs, in place"
+    moved = 0
+    for name, kind, _, fname in KINDS:
+        data = open(os.path.join(model_dir, fname), "rb").read() if rank == 0 else b""
+        data = broadcast_bytes(data, rank, world, dist, torch, device)
+        moved += len(data)
+        if rank != 0:
+            fn = getattr(product.lib, LOADERS[name])
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+            err = fn(objs[name], data, len(data))
+            if err:
+                raise RuntimeError("%s: Beatrice_ErrorCode %d" % (LOADERS[name], err))
+    return moved, "file bytes, repacked per rank"
+
+
+def share_speaker_tables(product, batch_handle, n_speakers, rank, world, dist, torch, device="cuda", host_tables=None):
+    """Rank 0 has uploaded its tables (BeatriceBatch_SetSpeakerTables); the raw device tables go to the other ranks
+    by four broadcasts and are projected there (BeatriceBatch_ProjectSpeakerTables).  Fallback, agreed by all ranks:
+    rank 0's host arrays (host_tables: the SpeakerTables object, rank 0 only) are broadcast and every other rank calls
+    BeatriceBatch_SetSpeakerTables itself.  Returns (bytes broadcast, path taken)."""
+    import ctypes as C
+    import numpy as np
+    if world == 1:
+        return 0, "file"
+    views, ok = [], True
+    try:
+        ptrs, sizes = (C.c_void_p * 4)(), (C.c_size_t * 4)()
+        rc = product.BeatriceBatch_SpeakerTablesDevice(batch_handle, ptrs, sizes)
         if rc:
-            raise RuntimeError("BeatriceHip_ModelBlob(%s): %d" % (name, rc))
-        broadcast_inplace(device_bytes(torch, ptr.value, nbytes.value, device), world, dist)
-        moved += nbytes.value
+            raise RuntimeError("BeatriceBatch_SpeakerTablesDevice: %d" % rc)
+        views = [device_bytes(torch, ptrs[i], sizes[i], device) for i in range(4)]
+    except Exception as e:  # noqa: BLE001
+        print("shard: rank %d cannot share its speaker tables in place (%s)" % (rank, e))
+        ok = False
+    if all_ranks_ok(ok, world, dist, torch, device):
+        for v in views:
+            broadcast_inplace(v, world, dist)
         if rank != 0:
             torch.cuda.synchronize()
-            rc = product.BeatriceHip_ModelBlobReady(kind, objs[name])
+            rc = product.BeatriceBatch_ProjectSpeakerTables(batch_handle, n_speakers)
             if rc:
-                raise RuntimeError("BeatriceHip_ModelBlobReady(%s): %d" % (name, rc))
-    return moved
-
-
-def share_speaker_tables(product, batch_handle, n_speakers, rank, world, dist, torch, device="cuda"):
-    """Rank 0 has uploaded its tables (BeatriceBatch_SetSpeakerTables); the raw device tables go to the other ranks
-    by four broadcasts and are projected there (BeatriceBatch_ProjectSpeakerTables)."""
-    import ctypes as C
-    if world == 1:
-        return 0
-    ptrs, sizes = (C.c_void_p * 4)(), (C.c_size_t * 4)()
-    rc = product.BeatriceBatch_SpeakerTablesDevice(batch_handle, ptrs, sizes)
-    if rc:
-        raise RuntimeError("BeatriceBatch_SpeakerTablesDevice: %d" % rc)
-    for i in range(4):
-        broadcast_inplace(device_bytes(torch, ptrs[i], sizes[i], device), world, dist)
+                raise RuntimeError("BeatriceBatch_ProjectSpeakerTables: %d" % rc)
+        return int(sum(v.numel() for v in views)), "device tables, in place"
+    shapes = ((n_speakers, 512, 128), (n_speakers, 256), (9, 256), (n_speakers, 384, 128))  # codebooks, additive, formant, kv
+    arrays, moved = [], 0
+    for i, shape in enumerate(shapes):
+        src = (host_tables.codebooks, host_tables.additive, host_tables.formant, host_tables.kv)[i] if rank == 0 else None
+        t = torch.from_numpy(np.ascontiguousarray(src, dtype=np.float32)).to(device) if rank == 0 else \
+            torch.empty(shape, dtype=torch.float32, device=device)
+        dist.broadcast(t, 0)
+        arrays.append(np.ascontiguousarray(t.cpu().numpy()))
+        moved += t.numel() * 4
     if rank != 0:
-        torch.cuda.synchronize()
-        rc = product.BeatriceBatch_ProjectSpeakerTables(batch_handle, n_speakers)
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+        rc = product.BeatriceBatch_SetSpeakerTables(batch_handle, n_speakers, fp(arrays[0]), fp(arrays[1]), fp(arrays[2]), fp(arrays[3]))
         if rc:
-            raise RuntimeError("BeatriceBatch_ProjectSpeakerTables: %d" % rc)
-    return int(sum(sizes))
+            raise RuntimeError("BeatriceBatch_SetSpeakerTables: %d" % rc)
+    return moved, "host tables, projected per rank"
 
 
 def affine_speaker(rank, world, local_stream, n_speakers):

@@ -272,9 +272,26 @@ def host_buffer_rate(bv, models, product, streams, steps=200):
     for i in range(steps):
         product.BeatriceBatch_ConvertFrames(batch.h, bv.fptr(xs[i % 8]), bv.fptr(out))
     dt = time.perf_counter() - t0
+    res = {"frames_per_s": round(streams * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4),
+           "bytes_over_pcie_per_step": streams * (160 + 240) * 4}
+    # the same host buffers through the tick pipeline (BeatriceBatch_StreamFrames): uploads, ticks and downloads of
+    # neighbouring steps on three HIP streams; fill and flush inside the timed region
+    if product.BeatriceBatch_EnableHostStreaming(batch.h, 1) == 0:
+        n = 600
+        for timed in (False, True):
+            t0 = time.perf_counter()
+            got = 0
+            for i in range(n):
+                got += product.BeatriceBatch_StreamFrames(batch.h, bv.fptr(xs[i % 8]), bv.fptr(out))
+            while product.BeatriceBatch_StreamFlush(batch.h, bv.fptr(out)) == 1:
+                got += 1
+            dt = time.perf_counter() - t0
+        res["streamed_through_tick_pipeline"] = {"frames_per_s": round(streams * n / dt, 1), "ms_per_step": round(dt / n * 1e3, 4),
+                                                 "steps": n, "steps_returned": got,
+                                                 "delay_steps": int(product.BeatriceBatch_HostStreamDelay(batch.h))}
+        product.BeatriceBatch_EnableHostStreaming(batch.h, 0)
     batch.close()
-    return {"frames_per_s": round(streams * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4),
-            "bytes_over_pcie_per_step": streams * (160 + 240) * 4}
+    return res
 
 
 def hop_synchronous(bv, models, product, streams, steps=300):
@@ -403,12 +420,14 @@ def main():
     m.abi = product
     m.phone, m.pitch = product.CreatePhoneExtractor(), product.CreatePitchEstimator()
     m.wave, m.embed = product.CreateWaveformGenerator(), product.CreateEmbeddingSetter()
-    bcast_bytes = shard.load_models_from_rank0(product, {"phone": m.phone, "pitch": m.pitch, "wave": m.wave, "embed": m.embed},
-                                                model_dir, rank, world, dist, torch)
+    bcast_bytes, load_path = shard.load_models_from_rank0(product, {"phone": m.phone, "pitch": m.pitch, "wave": m.wave, "embed": m.embed},
+                                                           model_dir, rank, world, dist, torch)
     if rank == 0:
         m.tables = bv.SpeakerTables(product, model_dir)
     batch = bv.Batch(m, B, max_speakers=a.speakers + 1, upload_tables=(rank == 0))
-    bcast_bytes += shard.share_speaker_tables(product, batch.h, a.speakers + 1, rank, world, dist, torch)
+    table_bytes, table_path = shard.share_speaker_tables(product, batch.h, a.speakers + 1, rank, world, dist, torch,
+                                                         host_tables=m.tables if rank == 0 else None)
+    bcast_bytes += table_bytes
     if rank != 0:
         batch.apply_defaults()
     if a.no_graph:
@@ -515,7 +534,7 @@ def main():
                        "io": "resident device buffers, 64 hops per stream cycled, bound as I/O slots (no per-step copy)" if resident
                              else "resident device buffers, one device-to-device copy in and out per step",
                        "parallelism": "streams sharded over %d GPU(s), no per-hop collective; load: one file read on rank 0, "
-                                      "%d bytes of packed parameters and speaker tables broadcast device to device" % (world, bcast_bytes),
+                                      "%d bytes of parameters (%s) and speaker tables (%s) broadcast over RCCL" % (world, bcast_bytes, load_path, table_path),
                        "placement": a.placement if a.config == 3 else "n/a"},
             "x_realtime_per_stream": round(a.steps / elapsed / 100.0, 2), "output_rms": round(out_rms, 4),
             "host_enqueue_ms_per_step": round(1e3 * enqueue_s / a.steps, 4),

@@ -192,6 +192,19 @@ void* BeatriceBatch_GetWaveStream(const BeatriceBatch* b);
  * The host-buffer, 48 kHz and profiling entry points return -1 while it is on. */
 int BeatriceBatch_EnableTickPipeline(BeatriceBatch* b, int enable);
 int BeatriceBatch_TickStages(const BeatriceBatch* b);
+/* Host streaming: tick pipelining for callers whose audio lives in HOST memory (offline conversion of files, a network
+ * front end).  BeatriceBatch_EnableHostStreaming(b, 1) gives the batch its own resident slots + pinned mirrors and turns
+ * tick mode on (requirements as above, nothing else bound); every BeatriceBatch_StreamFrames(b, in, out) then takes one
+ * hop of every stream ([B][160] in) and -- once the pipeline is full -- returns 1 with `out` ([B][240]) holding the samples
+ * of the step fed BeatriceBatch_HostStreamDelay() calls earlier (0 while filling: `out` untouched).  Uploads, ticks and
+ * downloads of neighbouring steps run on three HIP streams, so the PCIe copies hide behind the ticks.  After the last
+ * input, BeatriceBatch_StreamFlush(b, out) returns the remaining steps one per call (1, then 0 when none is left).
+ * Same samples as BeatriceBatch_ConvertFrames, bit for bit.  This is the host-buffer form of what src/common's
+ * ProcessorCore2::Process does per stream (processor_core_2.cc:24-48: in -> model hop -> out), for a whole batch. */
+int BeatriceBatch_EnableHostStreaming(BeatriceBatch* b, int enable);
+int BeatriceBatch_HostStreamDelay(const BeatriceBatch* b);
+int BeatriceBatch_StreamFrames(BeatriceBatch* b, const float* in, float* out);
+int BeatriceBatch_StreamFlush(BeatriceBatch* b, float* out);
 /* Measurement hook (tick mode on, pipeline full): `ticks` (<= 64) more ticks, each pipeline launch bracketed by HIP
  * events on the batch's stream: mean microseconds per launch + the launch's algorithmic FLOPs and bytes. */
 int BeatriceBatch_TimeTickLaunch(BeatriceBatch* b, int ticks, float* us_per_launch, double* flops, double* bytes);

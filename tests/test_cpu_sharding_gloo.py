@@ -89,6 +89,33 @@ def test_two_rank_sharding_matches_single_process(bv, built, model_dir, tmp_path
     assert covered == set(range(TOTAL_STREAMS))
 
 
+def _agree_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shard = _load("beatrice_shard", os.path.join(REPO, "beatrice-vst_amd", "shard.py"))
+    # only rank 1 fails: every rank must learn it, so that all of them take the fallback branch together
+    q.put((rank, shard.all_ranks_ok(rank != 1, world, dist, torch, "cpu"), shard.all_ranks_ok(True, world, dist, torch, "cpu")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_the_load_path():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 27500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_agree_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [(0, False, True), (1, False, True)]
+
+
 def test_stream_range_partitions():
     shard = _load("beatrice_shard", os.path.join(REPO, "beatrice-vst_amd", "shard.py"))
     for world in (1, 2, 3, 8):

