@@ -637,11 +637,9 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
     c.held = want;
   }
   if (p.n_copies > 0) hipLaunchKernelGGL(prologue_kernel, dim3(p.n_copies), dim3(256), 0, st, p);  // (only on ticks where a settings change arrives at a consumer)
-  if (k.bracket) (void)hipEventRecord(k.bracket[k.bracket_at], st);
   fuse::StepPairs pairs;
   for (int s = 0; s < fuse::kMaxStepPairs; ++s) { pairs.hop[s] = s < p.n_stages ? p.hop[s] : -1; pairs.io[s] = s < p.n_stages ? p.io[s] : 0; }
   fuse::launch_table_w<4>(k.d_table, k.table_total, st, pairs);
-  if (k.bracket) (void)hipEventRecord(k.bracket[k.bracket_at + 1], st);
   if (feeding) {
     b->last_parity = b->hop_host % 3;
     b->last_hop = b->hop_host;
@@ -1524,23 +1522,24 @@ int BeatriceBatch_EnableTickPipeline(BeatriceBatch* b, int enable) {
 }
 int BeatriceBatch_TickStages(const BeatriceBatch* b) { return b ? b->tk.plan.count() : 0; }
 // Measurement hook: `ticks` more ticks (each feeding a step from the resident slots), every tick's pipeline launch
-// bracketed by HIP events on the batch's stream; returns the mean duration of that launch and its algorithmic work.
+// between one pair of HIP events on the batch's stream; returns the mean duration per launch and its algorithmic work.
 // Call with the pipeline full (at least BeatriceBatch_TickStages steps fed) for the steady-state figure.
 int BeatriceBatch_TimeTickLaunch(BeatriceBatch* b, int ticks, float* us_per_launch, double* flops, double* bytes) {
   if (!b || !b->ok) return -2;
   if (!b->tk.on || ticks < 1 || ticks > 64 || !us_per_launch) return -1;
-  std::vector<hipEvent_t> ev(2 * ticks);
-  bool ok = true;
-  for (hipEvent_t& e : ev) ok = ok && hip_ok(hipEventCreate(&e), "tick ev");
-  b->tk.bracket = ok ? ev.data() : nullptr;
-  for (int i = 0; i < ticks && ok; ++i) { b->tk.bracket_at = 2 * i; ok = tick_run(b, true); }
-  b->tk.bracket = nullptr;
-  ok = ok && hip_ok(hipStreamSynchronize(b->stream), "tick time sync");
-  double sum = 0;
-  for (int i = 0; i < ticks && ok; ++i) { float ms = 0; ok = hip_ok(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]), "tick elapsed"); sum += ms; }
+  // ONE pair of events around `ticks` back-to-back launches (an event pair per launch adds two commands between
+  // consecutive launches and reads ~5 us long against rocprofv3's kernel durations); the figure includes the boundary
+  // between two ticks, which belongs to the launch's cost
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  bool ok = hip_ok(hipEventCreate(&ev[0]), "tick ev") && hip_ok(hipEventCreate(&ev[1]), "tick ev");
+  ok = ok && hip_ok(hipEventRecord(ev[0], b->stream), "tick ev0");
+  for (int i = 0; i < ticks && ok; ++i) ok = tick_run(b, true);
+  ok = ok && hip_ok(hipEventRecord(ev[1], b->stream), "tick ev1") && hip_ok(hipStreamSynchronize(b->stream), "tick time sync");
+  float ms = 0;
+  ok = ok && hip_ok(hipEventElapsedTime(&ms, ev[0], ev[1]), "tick elapsed");
   for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
   if (!ok) return -2;
-  *us_per_launch = (float)(1000.0 * sum / ticks);
+  *us_per_launch = (float)(1000.0 * ms / ticks);
   if (flops) *flops = b->tk.table_flops;
   if (bytes) *bytes = b->tk.table_bytes;
   return 0;

@@ -124,8 +124,6 @@ struct State {
   int snap_cur = -1, snap_next = 0;
   std::vector<Consumer> consumers;
   Plan plan;
-  hipEvent_t* bracket = nullptr;  // BeatriceBatch_TimeTickLaunch: events recorded around this tick's pipeline launch
-  int bracket_at = 0;
 };
 
 }  // namespace tick

@@ -205,8 +205,9 @@ int BeatriceBatch_EnableHostStreaming(BeatriceBatch* b, int enable);
 int BeatriceBatch_HostStreamDelay(const BeatriceBatch* b);
 int BeatriceBatch_StreamFrames(BeatriceBatch* b, const float* in, float* out);
 int BeatriceBatch_StreamFlush(BeatriceBatch* b, float* out);
-/* Measurement hook (tick mode on, pipeline full): `ticks` (<= 64) more ticks, each pipeline launch bracketed by HIP
- * events on the batch's stream: mean microseconds per launch + the launch's algorithmic FLOPs and bytes. */
+/* Measurement hook (tick mode on, pipeline full): `ticks` (<= 64) more ticks back to back between one pair of HIP events
+ * on the batch's stream: mean microseconds per launch (boundary to the next launch included) + the launch's algorithmic
+ * FLOPs and bytes. */
 int BeatriceBatch_TimeTickLaunch(BeatriceBatch* b, int ticks, float* us_per_launch, double* flops, double* bytes);
 /* Optional: capture the hipGraphs of the current mode now (settings, I/O binding, pipelining as they stand; nothing
  * runs), so that the first steps do not spend milliseconds on it.  Otherwise it happens inside the first step. */

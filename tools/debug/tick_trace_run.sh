@@ -1,5 +1,6 @@
 #!/bin/bash
-# per-workgroup timeline of a full tick: tools/debug/tick_trace_run.sh [DROP mask]
+# per-workgroup timeline of a full tick: tools/debug/tick_trace_run.sh [DROP mask] [extra bench.py arguments...]
 export BEATRICE_HIP_TICK_DROP=${1:-0}
-BEATRICE_HIP_TICK_TRACE=/tmp/tick_trace.txt python bench.py --steps 100 --warmup 30 --no-extras > /dev/null 2>&1
+shift
+BEATRICE_HIP_TICK_TRACE=/tmp/tick_trace.txt python bench.py --steps 100 --warmup 30 --no-extras "$@" > /dev/null 2>&1
 python tools/debug/tick_trace.py /tmp/tick_trace.txt
