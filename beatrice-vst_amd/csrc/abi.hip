@@ -80,12 +80,18 @@ bool wait_stream(hipStream_t s) {
   return hip_ok(hipStreamSynchronize(s), "sync");
 }
 
+// BEATRICE_HIP_HOP_IMMEDIATE=1: the step counter of a call travels in the kernels' arguments (stepc::immediate) instead of
+// the mailbox in device memory; the launches are then plain ones (arguments change every call).
+static bool hop_immediate() {
+  static const bool on = std::getenv("BEATRICE_HIP_HOP_IMMEDIATE") != nullptr;
+  return on;
+}
 // Runs `enqueue` (copies + kernels on `s`) through the context's captured graph; captures it first when there is none for
 // this model / variant.  BEATRICE_HIP_NO_HOP_GRAPH=1: plain launches (measurements).
 template <class F>
 static bool run_hop(HopGraph& g, const void* model, int variant, hipStream_t s, F enqueue) {
   static const bool eager = std::getenv("BEATRICE_HIP_NO_HOP_GRAPH") != nullptr;
-  if (eager) { enqueue(); return hip_ok(hipGetLastError(), "hop launch"); }
+  if (eager || hop_immediate()) { enqueue(); return hip_ok(hipGetLastError(), "hop launch"); }
   if (!g.exec || g.model != model || g.variant != variant) {
     g.drop();
     BHIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -229,6 +235,7 @@ void Beatrice20rc0_ExtractPhone1(const Beatrice20rc0_PhoneExtractor* m, const fl
     std::memcpy(mb + 2, &ctx->sel_cbT, sizeof(float*));
     std::memcpy(mb + 4, &ctx->sel_cnorm, sizeof(float*));
   }
+  if (hop_immediate()) ctx->st.hop = ctx->st.hop_in = const_cast<int*>(stepc::immediate(ctx->hop_count));
   ctx->hop_count = hop_next(ctx->hop_count);
   bool ok = run_hop(ctx->hop_graph, m, ctx->st.skip_vq ? 0 : 1, ctx->stream, [&] {
     (void)hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * (B_IN_HOP + kMailboxWords), hipMemcpyHostToDevice, ctx->stream);
@@ -301,6 +308,7 @@ void Beatrice20rc0_EstimatePitch1(const Beatrice20rc0_PitchEstimator* m, const f
     int* mb = reinterpret_cast<int*>(h_in + B_IN_HOP);
     mb[0] = ctx->hop_count; mb[1] = ctx->min_q; mb[2] = ctx->max_q;
   }
+  if (hop_immediate()) ctx->st.hop = ctx->st.hop_in = const_cast<int*>(stepc::immediate(ctx->hop_count));
   ctx->hop_count = hop_next(ctx->hop_count);
   bool ok = run_hop(ctx->hop_graph, m, 0, ctx->stream, [&] {
     (void)hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * (B_IN_HOP + kMailboxWords), hipMemcpyHostToDevice, ctx->stream);
@@ -362,6 +370,7 @@ void Beatrice20rc0_GenerateWaveform1(const Beatrice20rc0_WaveformGenerator* m, c
   std::memcpy(h_in + B_PHONE_CH, feat, sizeof(float) * 4);
   std::memcpy(h_in + B_PHONE_CH + 4, q, sizeof(int));
   std::memcpy(h_in + B_PHONE_CH + 5, &ctx->hop_count, sizeof(int));
+  if (hop_immediate()) ctx->st.hop = const_cast<int*>(stepc::immediate(ctx->hop_count));
   ctx->hop_count = hop_next(ctx->hop_count);
   bool ok = run_hop(ctx->hop_graph, m, 0, ctx->stream, [&] {
     (void)hipMemcpyAsync(ctx->d_inputs, h_in, sizeof(float) * in_floats, hipMemcpyHostToDevice, ctx->stream);

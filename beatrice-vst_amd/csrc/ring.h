@@ -35,8 +35,18 @@ __device__ __forceinline__ float* ring_frame(const Ring& r, int b, int pos, int 
 // the pair from device memory (args.hop); in the batch's tick launch (tick.hip.h) the table kernel takes every stage's
 // pair from its kernel arguments and leaves it in LDS for the body it dispatches to -- no dependent global load at the
 // start of a workgroup, no separate launch to publish the counters: there args.hop is null.
+// Third form, for the 1-stream calls whose host tracks the counter: the VALUE travels in the pointer bits
+// (stepc::immediate(hop); addresses below kImmediateTop are never mapped), again without a dependent load.
 namespace stepc {
 __shared__ int pair[2];
-__device__ __forceinline__ int step(const int* p) { return p != nullptr ? *p : pair[0]; }
-__device__ __forceinline__ int slot(const int* p) { return p != nullptr ? p[1] : pair[1]; }
+constexpr unsigned long long kImmediateTop = 1ull << 28;
+inline const int* immediate(int hop) { return reinterpret_cast<const int*>(static_cast<unsigned long long>(hop + 2)); }
+__device__ __forceinline__ int step(const int* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  return v == 0 ? pair[0] : (v < kImmediateTop ? (int)v - 2 : *p);
+}
+__device__ __forceinline__ int slot(const int* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  return v == 0 ? pair[1] : (v < kImmediateTop ? 0 : p[1]);
+}
 }  // namespace stepc
