@@ -264,6 +264,7 @@ _BATCH = {
     "BeatriceBatch_IsHealthy": (C.c_int, [_vp]),
     "BeatriceBatch_NumStreams": (C.c_int, [_vp]),
     "BeatriceBatch_SetSpeakerTables": (C.c_int, [_vp, C.c_int, _f32p, _f32p, _f32p, _f32p]),
+    "BeatriceBatch_BindResidentIO48k": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int]),
     "BeatriceBatch_EnableHostStreaming": (C.c_int, [_vp, C.c_int]),
     "BeatriceBatch_HostStreamDelay": (C.c_int, [_vp]),
     "BeatriceBatch_StreamFrames": (C.c_int, [_vp, _f32p, _f32p]),

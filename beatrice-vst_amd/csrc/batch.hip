@@ -203,6 +203,14 @@ struct BeatriceBatch {
   bool wrap_gains_constant = false;                 // the device copy holds constant segments that are still right
   // 48 kHz device wrapper (configs[4])
   Wrap48State* d_w48 = nullptr;
+  // the same wrapper around the TICK pipeline (BeatriceBatch_BindResidentIO48k): resident 48 kHz slots, own 16 / 24 kHz slots between
+  struct Resident48 {
+    bool on = false;
+    int channels = 0, n_slots = 0;
+    const float* d_in48 = nullptr;   // [n_slots][B][channels][480]
+    float* d_out48 = nullptr;        // [n_slots][B][channels][480]
+    float *d_in16 = nullptr, *d_out24 = nullptr;  // [n_slots][B][160], [n_slots][B][240]: the resident I/O of the ticks
+  } r48;
   float *d_coef_down = nullptr, *d_coef_up = nullptr, *d_io48 = nullptr, *h_io48 = nullptr;  // io: in [B][2][480] | out [B][2][480]
 };
 
@@ -637,9 +645,24 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
     c.held = want;
   }
   if (p.n_copies > 0) hipLaunchKernelGGL(prologue_kernel, dim3(p.n_copies), dim3(256), 0, st, p);  // (only on ticks where a settings change arrives at a consumer)
+  if (b->r48.on && feeding) {  // 48 kHz block of the step entering the pipeline -> its 16 kHz hop, straight into the resident slot
+    const BeatriceBatch::Resident48& r = b->r48;
+    hipLaunchKernelGGL(wrap48_pre_kernel, dim3(b->B), dim3(256), 0, st, r.d_in48 + (size_t)b->io_host * b->B * r.channels * 480, r.channels,
+                       b->d_w48, b->d_coef_down, r.d_in16 + (size_t)b->io_host * b->B * B_IN_HOP);
+  }
   fuse::StepPairs pairs;
   for (int s = 0; s < fuse::kMaxStepPairs; ++s) { pairs.hop[s] = s < p.n_stages ? p.hop[s] : -1; pairs.io[s] = s < p.n_stages ? p.io[s] : 0; }
   fuse::launch_table_w<4>(k.d_table, k.table_total, st, pairs);
+  if (b->r48.on) {  // the step this tick completed leaves through the up-sampler and the 480-sample FIFO (resample.h:346-361: the
+                    // block emitted for step j carries the model output of step j - 1), into the 48 kHz slot of step j
+    const long long u = step_at(k.plan.count() - 1);
+    if (u >= 0) {
+      const BeatriceBatch::Resident48& r = b->r48;
+      const int slot = k.io_of_step[u % kRing];
+      hipLaunchKernelGGL(wrap48_post_kernel, dim3(b->B), dim3(256), 0, st, b->d_w48, b->d_coef_up, r.d_out48 + (size_t)slot * b->B * r.channels * 480, r.channels);
+      hipLaunchKernelGGL(wrap48_latch_kernel, dim3((b->B * 240 + 255) / 256), dim3(256), 0, st, b->d_w48, r.d_out24 + (size_t)slot * b->B * B_OUT_HOP, b->B);
+    }
+  }
   if (feeding) {
     b->last_parity = b->hop_host % 3;
     b->last_hop = b->hop_host;
@@ -921,6 +944,8 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   b->wrap_gains.release();
   { void* tk[] = {b->tk.d_table, b->tk.d_snap, b->tk.d_trace}; for (void* p : tk) if (p) (void)hipFree(p); }
   host_stream_free(b);
+  if (b->r48.d_in16) (void)hipFree(b->r48.d_in16);
+  if (b->r48.d_out24) (void)hipFree(b->r48.d_out24);
   if (b->own_d_out) { b->wave.d_out = b->own_d_out; b->own_d_out = nullptr; }
   if (b->module_owned[0]) {  // hand the modules their own arrays back so that destroy() frees what it allocated
     void** keep = b->module_owned;
@@ -1224,8 +1249,44 @@ static bool step_48k(BeatriceBatch* b, const float* d_in48, float* d_out48, int 
   hipLaunchKernelGGL(wrap48_latch_kernel, dim3((b->B * 240 + 255) / 256), dim3(256), 0, b->stream, b->d_w48, b->wave.d_out, b->B);
   return hip_ok(hipGetLastError(), "wrap48");
 }
+// Throughput form of the 48 kHz wrapper: n_slots resident 48 kHz blocks per direction, the tick pipeline between them.
+// Block k (BeatriceBatch_ConvertBlocks48kDevice(b, NULL, NULL, channels)) is read from slot k mod n_slots; its converted
+// block lands in the same slot of d_out48 BeatriceBatch_TickStages() - 1 calls later (or after BeatriceBatch_Synchronize).
+// Same samples as the in-order BeatriceBatch_ConvertBlocks48kDevice.  NULL pointers unbind.
+int BeatriceBatch_BindResidentIO48k(BeatriceBatch* b, const float* d_in48, float* d_out48, int channels, int n_slots) {
+  if (!b || !b->ok) return -2;
+  BeatriceBatch::Resident48& r = b->r48;
+  if (r.on) {
+    if (!sync_all(b)) return -2;
+    const int rc = tick_enable(b, false);
+    if (rc) return rc;
+    (void)BeatriceBatch_BindResidentIO(b, nullptr, nullptr, 0);
+    if (r.d_in16) (void)hipFree(r.d_in16);
+    if (r.d_out24) (void)hipFree(r.d_out24);
+    r = BeatriceBatch::Resident48{};
+  }
+  if (!d_in48 && !d_out48) return 0;
+  if (!d_in48 || !d_out48 || channels < 1 || channels > 2 || n_slots < b->tk.plan.count() + 1 || b->H != 1 || b->io_slots > 0 || b->pipelined ||
+      b->tk.on || b->hs.on)
+    return -1;
+  bool ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_in16), sizeof(float) * n_slots * b->B * B_IN_HOP), "r48 in16") &&
+            hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_out24), sizeof(float) * n_slots * b->B * B_OUT_HOP), "r48 out24") &&
+            hip_ok(hipMemset(r.d_in16, 0, sizeof(float) * n_slots * b->B * B_IN_HOP), "r48 zero");
+  ok = ok && BeatriceBatch_BindResidentIO(b, r.d_in16, r.d_out24, n_slots) == 0 && tick_enable(b, true) == 0;
+  if (!ok) {
+    (void)tick_enable(b, false);
+    (void)BeatriceBatch_BindResidentIO(b, nullptr, nullptr, 0);
+    if (r.d_in16) (void)hipFree(r.d_in16);
+    if (r.d_out24) (void)hipFree(r.d_out24);
+    r = BeatriceBatch::Resident48{};
+    return -2;
+  }
+  r.d_in48 = d_in48; r.d_out48 = d_out48; r.channels = channels; r.n_slots = n_slots; r.on = true;
+  return 0;
+}
 int BeatriceBatch_ConvertBlocks48kDevice(BeatriceBatch* b, const float* d_in, float* d_out, int channels) {
   if (!b || !b->ok) return -2;
+  if (b->r48.on) return (!d_in && !d_out && channels == b->r48.channels) ? (tick_run(b, true) ? 0 : -2) : -1;
   if (channels < 1 || channels > 2 || !d_in || !d_out || b->H != 1 || b->io_slots > 0 || b->pipelined || b->tk.on) return -1;  // per 10 ms block, in order
   return step_48k(b, d_in, d_out, channels) ? 0 : -2;
 }

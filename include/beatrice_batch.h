@@ -146,6 +146,12 @@ int BeatriceBatch_BindResidentIO(BeatriceBatch* b, const float* d_in, float* d_o
  * the C++ host layer (beatrice-vst_amd/host).  Per 10 ms block only: returns -1 on a block-mode batch (H > 1). */
 int BeatriceBatch_ConvertBlocks48k(BeatriceBatch* b, const float* in, float* out, int channels);
 int BeatriceBatch_ConvertBlocks48kDevice(BeatriceBatch* b, const float* d_in, float* d_out, int channels);
+/* Throughput form: n_slots (> BeatriceBatch_TickStages()) resident 48 kHz blocks per direction, [n_slots][B][channels][480], with
+ * the tick pipeline between them (the batch allocates its own 16 / 24 kHz slots).  While bound, block k --
+ * BeatriceBatch_ConvertBlocks48kDevice(b, NULL, NULL, channels) -- is taken from slot k mod n_slots, and its converted block
+ * appears in the same slot of d_out48 BeatriceBatch_TickStages() - 1 calls later or after BeatriceBatch_Synchronize: the
+ * samples of the in-order call, later.  NULL, NULL unbinds (and leaves tick mode). */
+int BeatriceBatch_BindResidentIO48k(BeatriceBatch* b, const float* d_in48, float* d_out48, int channels, int n_slots);
 
 /* The same wrapper at ANY host rate and block size, with the dB-ramped gains (the whole of the reference's
  * ProcessorCore2::Process, src/common/processor_core_2.cc:24-48, per stream on the device): input gain (gain.h:41-71,

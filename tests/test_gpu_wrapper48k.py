@@ -52,3 +52,65 @@ def test_device_wrapper_48k_matches_host_chain(bv, oracle, product, model_dir, B
     if channels == 2:
         assert np.array_equal(got[:, 0], got[:, 1])
     assert dev <= 1e-4
+
+
+@pytest.mark.parametrize("B,channels,blocks", [(5, 2, 70), (64, 2, 45)])
+def test_48k_wrapper_around_the_tick_pipeline_matches_in_order(bv, product, model_dir, B, channels, blocks):
+    """BeatriceBatch_BindResidentIO48k: resident 48 kHz slots, the tick pipeline in between; block k's converted samples
+    land in slot k mod n_slots (pipeline depth later).  Must equal the in-order device wrapper block for block, across a
+    wrap of the slot ring and a drain in the middle."""
+    from test_gpu_resident_io import Hip
+    hip = Hip()
+    x = np.stack([np.stack([wrapperlib.test_signal(480 * blocks, 48000, seed=300 + 7 * s + c) for c in range(channels)])
+                  for s in range(B)]).astype(np.float32)                      # [B][ch][blocks*480]
+    m = bv.Models(product, model_dir)
+
+    def settings(batch):
+        for s in range(B):
+            batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, s, s % 3)
+            batch.a.BeatriceBatch_SetVQNumNeighbors(batch.h, s, s % 2)
+        batch.a.BeatriceBatch_FlushSpeaker(batch.h, -1)
+
+    ref_batch = bv.Batch(m, B)
+    settings(ref_batch)
+    want = [ref_batch.convert48k(np.ascontiguousarray(x[:, :, 480 * k:480 * (k + 1)]), channels).copy() for k in range(blocks)]
+    ref_batch.close()
+
+    batch = bv.Batch(m, B)
+    settings(batch)
+    a, h = batch.a, batch.h
+    stages = a.BeatriceBatch_TickStages(h)
+    slots = stages + 5
+    blk = B * channels * 480
+    d_in, d_out = hip.malloc(slots * blk * 4), hip.malloc(slots * blk * 4)
+    assert a.BeatriceBatch_BindResidentIO48k(h, d_in, d_out, channels, stages) == -1     # too few slots
+    assert a.BeatriceBatch_BindResidentIO48k(h, d_in, d_out, channels, slots) == 0
+    assert a.BeatriceBatch_ConvertBlocks48kDevice(h, d_in, d_out, channels) == -1        # bound: NULL, NULL only
+    got = [None] * blocks
+    k0 = 0
+    for chunk in (slots, 9, 10 ** 9):         # each chunk: upload its blocks, run them, drain, read them back
+        n = min(chunk, blocks - k0, slots)
+        while n > 0:
+            buf = np.zeros((slots, B, channels, 480), np.float32)
+            for k in range(k0, k0 + n):
+                buf[k % slots] = x[:, :, 480 * k:480 * (k + 1)]
+            hip.h2d(d_in, buf)
+            for k in range(k0, k0 + n):
+                assert a.BeatriceBatch_ConvertBlocks48kDevice(h, None, None, channels) == 0
+            assert a.BeatriceBatch_Synchronize(h) == 0
+            out = np.zeros((slots, B, channels, 480), np.float32)
+            hip.d2h(out, d_out)
+            for k in range(k0, k0 + n):
+                got[k] = out[k % slots].copy()
+            k0 += n
+            n = min(chunk, blocks - k0, slots) if chunk > slots else 0
+    assert k0 == blocks
+    for k in range(blocks):
+        assert np.array_equal(got[k], want[k]), "block %d differs" % k
+    assert a.BeatriceBatch_BindResidentIO48k(h, None, None, 0, 0) == 0
+    # in order again on the same streams (wrapper and model state carried over)
+    y = batch.convert48k(np.ascontiguousarray(x[:, :, :480]), channels)
+    assert np.isfinite(y).all()
+    hip.free(d_in); hip.free(d_out)
+    batch.close()
+    m.close()
