@@ -193,6 +193,7 @@ struct BeatriceBatch {
     struct Pending { long long step; int slot; long long done_tick; bool fetched; };
     std::deque<Pending> pending;               // steps fed and not yet handed back, oldest first
     long long fed = 0;
+    long long rec[2] = {-1, -1};               // ticks whose events were recorded last and second to last
   } hs;
   // any-rate device wrapper (wrapper.hip.h): the reference host's gains, resampler pair and 480-sample FIFO for all streams
   wrapn::WrapPlan wrap;
@@ -1463,7 +1464,9 @@ static void host_stream_fetch(BeatriceBatch* b) {  // enqueue the download of ev
   const size_t n_out = (size_t)b->B * B_OUT_HOP;
   for (auto& p : h.pending) {
     if (p.fetched || p.done_tick > last_tick) continue;
-    (void)hipStreamWaitEvent(h.s_out, h.ev_tick[p.done_tick % h.ev_tick.size()], 0);
+    // (the event recorded behind the tick just launched: it is at or after the tick that completed this step, also when
+    //  ticks were run by a drain in between, which records none)
+    (void)hipStreamWaitEvent(h.s_out, h.ev_tick[h.rec[0] % h.ev_tick.size()], 0);
     (void)hipMemcpyAsync(h.h_out + p.slot * n_out, h.d_out + p.slot * n_out, sizeof(float) * n_out, hipMemcpyDeviceToHost, h.s_out);
     (void)hipEventRecord(h.ev_out[p.slot], h.s_out);
     p.fetched = true;
@@ -1471,9 +1474,10 @@ static void host_stream_fetch(BeatriceBatch* b) {  // enqueue the download of ev
 }
 static bool host_stream_tick(BeatriceBatch* b, bool feeding) {
   BeatriceBatch::HostStream& h = b->hs;
-  const long long t = b->tk.tick;
-  if (!tick_run(b, feeding)) return false;
+  if (!tick_run(b, feeding)) return false;   // (may run a whole drain first: a stage that comes or goes)
+  const long long t = b->tk.tick - 1;        // the tick just launched
   (void)hipEventRecord(h.ev_tick[t % h.ev_tick.size()], b->stream);
+  h.rec[1] = h.rec[0]; h.rec[0] = t;
   host_stream_fetch(b);
   return true;
 }
@@ -1525,6 +1529,7 @@ int BeatriceBatch_EnableHostStreaming(BeatriceBatch* b, int enable) {
   if (!ok) { (void)tick_enable(b, false); (void)BeatriceBatch_BindResidentIO(b, nullptr, nullptr, 0); host_stream_free(b); return -2; }
   h.pending.clear();
   h.fed = 0;
+  h.rec[0] = h.rec[1] = -1;
   h.on = true;
   return 0;
 }
@@ -1537,20 +1542,21 @@ int BeatriceBatch_StreamFrames(BeatriceBatch* b, const float* in, float* out) {
   if (!h.on || !in || !out) return -1;
   const size_t n_in = (size_t)b->B * B_IN_HOP, n_out = (size_t)b->B * B_OUT_HOP;
   const int slot = b->io_host;  // the slot the tick about to be fed reads and, pipeline depth later, writes
-  const long long t = b->tk.tick;
   if (!hip_ok(hipEventSynchronize(h.ev_in[slot]), "hs in reuse")) return -2;  // the upload that last used this pinned slot (long done)
   std::memcpy(h.h_in + slot * n_in, in, sizeof(float) * n_in);
-  if (t >= 2) (void)hipStreamWaitEvent(h.s_in, h.ev_tick[(t - 2) % h.ev_tick.size()], 0);   // every reader of the device slot's old contents is done
+  // every reader of the device slot's old contents is done once the tick before the previous one is (the slot ring is
+  // longer than the deepest reader's stage by more than that)
+  if (h.rec[1] >= 0) (void)hipStreamWaitEvent(h.s_in, h.ev_tick[h.rec[1] % h.ev_tick.size()], 0);
   bool ok = hip_ok(hipMemcpyAsync(h.d_in + slot * n_in, h.h_in + slot * n_in, sizeof(float) * n_in, hipMemcpyHostToDevice, h.s_in), "hs upload");
   (void)hipEventRecord(h.ev_in[slot], h.s_in);
   (void)hipStreamWaitEvent(b->stream, h.ev_in[slot], 0);
   (void)hipStreamWaitEvent(b->stream, h.ev_out[slot], 0);  // the output slot this step will overwrite has been downloaded
-  h.pending.push_back({h.fed, slot, t + b->tk.plan.count() - 1, false});
-  h.fed += 1;
   ok = ok && host_stream_tick(b, true);
   if (!ok) return -2;
+  h.pending.push_back({h.fed, slot, b->tk.last_feed_tick + b->tk.plan.count() - 1, false});  // leaves the last stage that many ticks on
+  h.fed += 1;
   const BeatriceBatch::HostStream::Pending& f = h.pending.front();
-  if (!f.fetched || f.done_tick > t - 2) return 0;   // hand back only what was enqueued for download two ticks ago
+  if (!f.fetched || f.done_tick > b->tk.last_feed_tick - 2) return 0;   // hand back only what was enqueued for download two ticks ago
   if (!hip_ok(hipEventSynchronize(h.ev_out[f.slot]), "hs download")) return -2;
   std::memcpy(out, h.h_out + f.slot * n_out, sizeof(float) * n_out);
   h.pending.pop_front();
@@ -1579,6 +1585,7 @@ int BeatriceBatch_StreamFlush(BeatriceBatch* b, float* out) {
 // (or, stream-ordered, on BeatriceBatch_GetWaveStream).  Off by default: everything in order on one stream.
 int BeatriceBatch_EnableTickPipeline(BeatriceBatch* b, int enable) {
   if (!b || !b->ok) return -2;
+  if (b->hs.on || b->r48.on) return -1;  // those modes own the tick pipeline: leave them instead
   return tick_enable(b, enable != 0);
 }
 int BeatriceBatch_TickStages(const BeatriceBatch* b) { return b ? b->tk.plan.count() : 0; }

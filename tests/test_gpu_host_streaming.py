@@ -6,8 +6,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("B,steps", [(7, 90), (256, 70)])
-def test_streamed_host_buffers_match_in_order_chain(bv, product, model_dir, B, steps):
+@pytest.mark.parametrize("B,steps,vq_from_start", [(7, 90, True), (256, 70, True), (6, 80, False)])
+def test_streamed_host_buffers_match_in_order_chain(bv, product, model_dir, B, steps, vq_from_start):
     m = bv.Models(product, model_dir)
     bv.bind_batch(product)
     audio = np.stack([bv.synth_audio(160 * steps, seed=4100 + s) for s in range(B)]).reshape(B, steps, 160)
@@ -15,13 +15,18 @@ def test_streamed_host_buffers_match_in_order_chain(bv, product, model_dir, B, s
     def settings(batch):
         for s in range(B):
             batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, s, s % 3)
-            batch.a.BeatriceBatch_SetVQNumNeighbors(batch.h, s, s % 4)
+            if vq_from_start:
+                batch.a.BeatriceBatch_SetVQNumNeighbors(batch.h, s, s % 4)
         batch.a.BeatriceBatch_FlushSpeaker(batch.h, -1)
 
     def change(batch, k):
         if k % 11 == 3:
             batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, (5 * k) % B, (k + 1) % 3)
             batch.a.BeatriceBatch_SetPitchShift(batch.h, (3 * k) % B, float(k % 5) - 2.0)
+        if k == 31 and not vq_from_start:
+            batch.a.BeatriceBatch_SetVQNumNeighbors(batch.h, 1 % B, 3)     # the k-NN stage appears: the pipeline drains in mid-stream
+        if k == 44:
+            assert batch.a.BeatriceBatch_ResetStream(batch.h, 2 % B) == 0   # drains, too
 
     ref_batch = bv.Batch(m, B)
     settings(ref_batch)
@@ -37,7 +42,7 @@ def test_streamed_host_buffers_match_in_order_chain(bv, product, model_dir, B, s
     out = np.zeros((B, 240), np.float32)
     assert a.BeatriceBatch_StreamFrames(h, bv.fptr(np.ascontiguousarray(audio[:, 0])), bv.fptr(out)) == -1   # not enabled
     assert a.BeatriceBatch_EnableHostStreaming(h, 1) == 0
-    assert a.BeatriceBatch_EnableTickPipeline(h, 0) == 0 or True
+    assert a.BeatriceBatch_EnableTickPipeline(h, 0) == -1      # owned by the host streaming mode while that is on
     delay = a.BeatriceBatch_HostStreamDelay(h)
     assert 8 <= delay <= 64
     got = []
@@ -57,8 +62,8 @@ def test_streamed_host_buffers_match_in_order_chain(bv, product, model_dir, B, s
             break
         got.append(out.copy())
     assert len(got) == steps
-    for k in range(steps):
-        assert np.array_equal(got[k], ref[k]), "step %d differs" % k
+    bad = [(k, int(s_)) for k in range(steps) for s_ in np.nonzero(np.abs(got[k] - ref[k]).max(axis=1))[0]]
+    assert not bad, "differing (step, stream): %s" % bad[:40]
     # back to the in-order chain on the same streams: state carried over
     assert a.BeatriceBatch_EnableHostStreaming(h, 0) == 0
     batch.close()
