@@ -17,6 +17,7 @@
 #include <random>
 #include <string>
 #include <type_traits>
+#include <chrono>
 #include <deque>
 #include <vector>
 
@@ -596,16 +597,36 @@ bool tick_build_table(BeatriceBatch* b) {
 }
 
 // One tick: every stage advances by one step; `feeding` = a new step enters at stage 0.
+// BEATRICE_HIP_TICK_HOSTPROF=1: host time of tick_run by section, printed when the process ends (measurement aid)
+struct HostProf {
+  static constexpr int N = 5;
+  static bool on() { static const bool v = std::getenv("BEATRICE_HIP_TICK_HOSTPROF") != nullptr; return v; }
+  struct Totals { double us[N] = {}; long long calls = 0; ~Totals() { if (calls) std::fprintf(stderr, "tick_run host us per call: settings/kv %.1f, table %.1f, snapshot upload %.1f, copies %.1f, launch %.1f (%lld calls)\n", us[0] / calls, us[1] / calls, us[2] / calls, us[3] / calls, us[4] / calls, calls); } };
+  static Totals& totals() { static Totals t; return t; }
+  std::chrono::steady_clock::time_point t0;
+  HostProf() { if (on()) { t0 = std::chrono::steady_clock::now(); totals().calls += 1; } }
+  void lap(int i) {
+    if (!on()) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    totals().us[i] += std::chrono::duration<double, std::micro>(t1 - t0).count();
+    t0 = t1;
+  }
+};
 bool tick_run(BeatriceBatch* b, bool feeding) {
   using namespace tick;
   State& k = b->tk;
+  HostProf prof;
   if (feeding) {
     advance_kv(b);
     draw_codebooks(b);
     if (b->vq_dirty) { update_vq_mode(b); b->vq_dirty = false; }   // (drains the pipeline if the k-NN stage comes or goes)
   }
+  prof.lap(0);
   if (k.table_dirty && !tick_build_table(b)) return false;
+  prof.lap(1);
   hipStream_t st = b->stream;
+  Copy upload{nullptr, nullptr, 0};
+  int upload_stage = -1;
   if (feeding) {
     bool dirty = b->front_dirty || k.snap_cur < 0;
     for (bool w : b->wave_dirty) dirty = dirty || w;
@@ -613,7 +634,15 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
       const int serial = k.snap_next++;
       const size_t off = 0, len = k.snap_bytes;
       unsigned char* dst = k.d_snap + (size_t)(serial % kRing) * k.snap_bytes;
-      if (!b->settings.push_parts(st, 1, &off, &len, &dst)) return false;
+      // through a ring of pinned staging copies, so that the host may run several settings changes ahead of the device
+      // (the batch's two-deep mirror would make every second change wait for the copy of the change before it); the
+      // tick's prologue kernel reads the staging copy straight from host memory (tick.hip.h)
+      const int si = serial % State::kStaging;
+      if (k.stage_pending[si]) { if (!hip_ok(hipEventSynchronize(k.stage_ev[si]), "tick settings staging")) return false; }
+      unsigned char* src = k.h_stage + (size_t)si * k.snap_bytes;
+      std::memcpy(src, b->settings.h + off, len);
+      upload = Copy{dst, src, (int)len};
+      upload_stage = si;
       k.snap_cur = serial;
       b->front_dirty = false;
       for (bool& w : b->wave_dirty) w = false;
@@ -626,6 +655,7 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
   } else {
     k.fed_step[k.tick % kRing] = -1;
   }
+  prof.lap(2);
   Prolog p{};
   p.n_stages = k.plan.count();
   auto step_at = [&k](int stage) -> long long {
@@ -645,12 +675,27 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
     p.copy[p.n_copies++] = Copy{c.dst, k.d_snap + (size_t)(want % kRing) * k.snap_bytes + c.off, (int)c.bytes};
     c.held = want;
   }
-  if (p.n_copies > 0) hipLaunchKernelGGL(prologue_kernel, dim3(p.n_copies), dim3(256), 0, st, p);  // (only on ticks where a settings change arrives at a consumer)
+  if (upload.bytes > 0) {  // first, so that entry order = age; (a consumer never needs the snapshot uploaded in its own tick: none sits at stage 0)
+    for (int i = p.n_copies; i > 0; --i) p.copy[i] = p.copy[i - 1];
+    p.copy[0] = upload;
+    p.n_copies += 1;
+  }
+  if (p.n_copies > 0) {  // (only on ticks where the settings changed or a change arrives at a consumer)
+    int chunks = 0;
+    for (int i = 0; i < p.n_copies; ++i) { p.first_chunk[i] = chunks; chunks += (p.copy[i].bytes + kCopyChunk - 1) / kCopyChunk; }
+    p.first_chunk[p.n_copies] = chunks;
+    hipLaunchKernelGGL(prologue_kernel, dim3(chunks), dim3(256), 0, st, p);
+    if (upload_stage >= 0) {
+      if (!hip_ok(hipEventRecord(k.stage_ev[upload_stage], st), "tick settings event")) return false;
+      k.stage_pending[upload_stage] = true;
+    }
+  }
   if (b->r48.on && feeding) {  // 48 kHz block of the step entering the pipeline -> its 16 kHz hop, straight into the resident slot
     const BeatriceBatch::Resident48& r = b->r48;
     hipLaunchKernelGGL(wrap48_pre_kernel, dim3(b->B), dim3(256), 0, st, r.d_in48 + (size_t)b->io_host * b->B * r.channels * 480, r.channels,
                        b->d_w48, b->d_coef_down, r.d_in16 + (size_t)b->io_host * b->B * B_IN_HOP);
   }
+  prof.lap(3);
   fuse::StepPairs pairs;
   for (int s = 0; s < fuse::kMaxStepPairs; ++s) { pairs.hop[s] = s < p.n_stages ? p.hop[s] : -1; pairs.io[s] = s < p.n_stages ? p.io[s] : 0; }
   fuse::launch_table_w<4>(k.d_table, k.table_total, st, pairs);
@@ -673,6 +718,7 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
     k.n_fed += 1;
     k.last_feed_tick = k.tick;
   }
+  prof.lap(4);
   k.tick += 1;
   b->inflight = true;
   return hip_ok(hipGetLastError(), "tick launch");
@@ -706,8 +752,10 @@ int tick_enable(BeatriceBatch* b, bool on) {
     k.snap_bytes = b->off.front_bytes + b->off.wave_bytes;
     if (!k.d_table) {
       if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_table), sizeof(Tab)), "tick table") ||
-          !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_snap), k.snap_bytes * kRing), "tick snapshots"))
+          !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_snap), k.snap_bytes * kRing), "tick snapshots") ||
+          !hip_ok(hipHostMalloc(reinterpret_cast<void**>(&k.h_stage), k.snap_bytes * State::kStaging, hipHostMallocDefault), "tick staging"))
         return -2;
+      for (hipEvent_t& e : k.stage_ev) if (!hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "tick staging event")) return -2;
     }
     if (!hip_ok(hipDeviceSynchronize(), "tick sync")) return -2;
     k.tick = 0; k.n_fed = 0; k.last_feed_tick = -1000; k.snap_cur = -1; k.snap_next = 0;
@@ -944,6 +992,8 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   if (b->h_wrap_io) (void)hipHostFree(b->h_wrap_io);
   b->wrap_gains.release();
   { void* tk[] = {b->tk.d_table, b->tk.d_snap, b->tk.d_trace}; for (void* p : tk) if (p) (void)hipFree(p); }
+  if (b->tk.h_stage) (void)hipHostFree(b->tk.h_stage);
+  for (hipEvent_t e : b->tk.stage_ev) if (e) (void)hipEventDestroy(e);
   host_stream_free(b);
   if (b->r48.d_in16) (void)hipFree(b->r48.d_in16);
   if (b->r48.d_out24) (void)hipFree(b->r48.d_out24);

@@ -28,22 +28,27 @@
 
 namespace tick {
 
-constexpr int kMaxStages = 32, kRing = 64, kMaxCopies = 16;
+constexpr int kMaxStages = 32, kRing = 64, kMaxCopies = 16;  // (copies: 7 consumers + the snapshot upload)
 
 struct Copy { unsigned char* dst; const unsigned char* src; int bytes; };
+constexpr int kCopyChunk = 4096;  // bytes one workgroup moves (256 lanes x 16 bytes, one round trip)
 struct Prolog {
   int n_stages;
   int hop[kMaxStages], io[kMaxStages];
   int n_copies;
   Copy copy[kMaxCopies];
+  int first_chunk[kMaxCopies + 1];  // workgroups [first_chunk[c], first_chunk[c + 1]) perform copy c
 };
-// workgroup c performs settings copy c (16-byte granules); launched only on ticks that have copies
+// Settings traffic of a tick, one launch (only on ticks that have any): entry 0 may be the upload of a new snapshot --
+// its source is PINNED HOST memory, read by the kernel itself over PCIe (a copy command in the stream costs a switch to the
+// copy engine and back, ~40 us per tick when settings change every step) -- the others move a consumer stage's byte range
+// from an OLDER snapshot slot into that stage's private copy.  One workgroup per 4 KB.
 static __global__ __launch_bounds__(256) void prologue_kernel(const Prolog p) {
-  const int tid = threadIdx.x;
-  const Copy c = p.copy[blockIdx.x];
-  const uint4* src = reinterpret_cast<const uint4*>(c.src);
-  uint4* dst = reinterpret_cast<uint4*>(c.dst);
-  for (int i = tid; i < c.bytes / 16; i += 256) dst[i] = src[i];
+  int c = 0;
+  while (c + 1 < p.n_copies && (int)blockIdx.x >= p.first_chunk[c + 1]) ++c;
+  const Copy cp = p.copy[c];
+  const int at = ((int)blockIdx.x - p.first_chunk[c]) * kCopyChunk + (int)threadIdx.x * 16;
+  if (at + 16 <= cp.bytes) *reinterpret_cast<uint4*>(cp.dst + at) = *reinterpret_cast<const uint4*>(cp.src + at);  // (ranges are multiples of 16 bytes)
 }
 
 using namespace bhip;
@@ -117,6 +122,10 @@ struct State {
   unsigned long long* d_trace = nullptr;  // BEATRICE_HIP_TICK_TRACE=<file>: per-workgroup timeline of the last full tick
   bool table_dirty = true;
   unsigned char* d_snap = nullptr;  // [kRing][snap_bytes] settings snapshots
+  static constexpr int kStaging = 16;
+  unsigned char* h_stage = nullptr; // [kStaging][snap_bytes] pinned: a snapshot on its way to the device
+  hipEvent_t stage_ev[kStaging] = {};
+  bool stage_pending[kStaging] = {};
   size_t snap_bytes = 0;
   long long tick = 0, n_fed = 0, last_feed_tick = -1000;
   long long fed_step[kRing];        // step fed at tick (index tick % kRing), -1 none

@@ -481,12 +481,15 @@ def main():
     if product.BeatriceBatch_Prepare(batch.h):  # graph capture now, not inside the first (possibly timed) steps
         raise SystemExit("Prepare failed")
 
+    # (schedule of configs[3]'s speaker switches, worked out before the timed loop: stream s switches at steps congruent to
+    #  -(s * 200 // B) modulo 200)
+    switchers = [[s for s in range(B) if (r + s * 200 // B) % 200 == 0] for r in range(200)]
+
     def step(i):
-        if a.config == 3:  # every stream moves to the next speaker every 200 hops, staggered by stream index
-            for s in range(B):
-                if (i + s * 200 // B) % 200 == 0 and i > 0:
-                    current_speaker[s] = (current_speaker[s] + 1) % a.speakers
-                    product.BeatriceBatch_SetTargetSpeaker(batch.h, s, current_speaker[s])
+        if a.config == 3 and i > 0:  # every stream moves to the next speaker every 200 hops, staggered by stream index
+            for s in switchers[i % 200]:
+                current_speaker[s] = (current_speaker[s] + 1) % a.speakers
+                product.BeatriceBatch_SetTargetSpeaker(batch.h, s, current_speaker[s])
         if a.config == 4 and tick48:
             rc = product.BeatriceBatch_ConvertBlocks48kDevice(batch.h, None, None, 2)
         elif a.config == 4:
