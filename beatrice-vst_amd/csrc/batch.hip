@@ -195,6 +195,8 @@ struct BeatriceBatch {
     std::deque<Pending> pending;               // steps fed and not yet handed back, oldest first
     long long fed = 0;
     long long rec[2] = {-1, -1};               // ticks whose events were recorded last and second to last
+    bool mapped = false;                       // the ticks read and write the pinned mirrors themselves (no copies, no copy streams)
+    std::vector<long long> tick_of_ev;         // which tick the event in ev_tick[i] was recorded behind
   } hs;
   // any-rate device wrapper (wrapper.hip.h): the reference host's gains, resampler pair and 480-sample FIFO for all streams
   wrapn::WrapPlan wrap;
@@ -1504,16 +1506,20 @@ int BeatriceBatch_EnableGraph(BeatriceBatch* b, int enable) {
   return 0;
 }
 // ---- host streaming: the tick pipeline with HOST buffers on either side -----------------------------------------------------
-// Call k uploads its input on a copy stream (after tick k-2, by when every reader of the slot it re-uses is done), the
-// batch's stream waits for that upload and launches tick k, a second copy stream downloads the step that tick k
-// completed, and the call hands back the step whose download was enqueued two calls earlier -- so uploads, ticks and
-// downloads of neighbouring steps overlap and the host only ever waits for work that is long finished.
+// The resident I/O slots of the ticks are the batch's PINNED HOST mirrors: the stages that read a hop (f1, fft, pitch head)
+// and the one that writes samples (the tail) go over PCIe themselves -- 160 + 240 KB per tick at 256 streams, spread over
+// hundreds of workgroups that have plenty to overlap it with -- so a call is: memcpy the hop into its slot, launch the
+// tick, record an event, and hand back the step whose tick finished at least two ticks ago (the host then never waits
+// for the device's current work, and two ticks stay queued).  3.07 M frames/s from and to host memory at 256 streams
+// against 3.2 M with resident device buffers.  BEATRICE_HIP_HS_COPIES=1 (A/B): device slots with an upload and a
+// download stream beside the ticks instead -- 2.36 M: copy commands and cross-stream waits cost more than PCIe loads.
 static void host_stream_fetch(BeatriceBatch* b) {  // enqueue the download of every step the ticks run so far have completed
   BeatriceBatch::HostStream& h = b->hs;
   const long long last_tick = b->tk.tick - 1;
   const size_t n_out = (size_t)b->B * B_OUT_HOP;
   for (auto& p : h.pending) {
     if (p.fetched || p.done_tick > last_tick) continue;
+    if (h.mapped) { p.fetched = true; continue; }  // nothing to download: the last stage wrote host memory
     // (the event recorded behind the tick just launched: it is at or after the tick that completed this step, also when
     //  ticks were run by a drain in between, which records none)
     (void)hipStreamWaitEvent(h.s_out, h.ev_tick[h.rec[0] % h.ev_tick.size()], 0);
@@ -1527,9 +1533,19 @@ static bool host_stream_tick(BeatriceBatch* b, bool feeding) {
   if (!tick_run(b, feeding)) return false;   // (may run a whole drain first: a stage that comes or goes)
   const long long t = b->tk.tick - 1;        // the tick just launched
   (void)hipEventRecord(h.ev_tick[t % h.ev_tick.size()], b->stream);
+  h.tick_of_ev[t % h.ev_tick.size()] = t;
   h.rec[1] = h.rec[0]; h.rec[0] = t;
   host_stream_fetch(b);
   return true;
+}
+// the samples of pending step f are in the pinned output mirror
+static bool host_stream_wait(BeatriceBatch* b, const BeatriceBatch::HostStream::Pending& f) {
+  BeatriceBatch::HostStream& h = b->hs;
+  if (!h.mapped) return hip_ok(hipEventSynchronize(h.ev_out[f.slot]), "hs download");
+  const size_t n = h.ev_tick.size();
+  for (long long t = f.done_tick; t <= h.rec[0]; ++t)   // the first event recorded at or behind the tick that completed it
+    if (h.tick_of_ev[t % n] == t) return hip_ok(hipEventSynchronize(h.ev_tick[t % n]), "hs tick done");
+  return false;
 }
 }  // extern "C"
 namespace {
@@ -1575,7 +1591,10 @@ int BeatriceBatch_EnableHostStreaming(BeatriceBatch* b, int enable) {
   h.ev_in.assign(h.n_slots, nullptr); h.ev_out.assign(h.n_slots, nullptr); h.ev_tick.assign(tick::kRing, nullptr);
   for (auto* v : {&h.ev_in, &h.ev_out, &h.ev_tick})
     for (hipEvent_t& e : *v) ok = ok && hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hs event");
-  ok = ok && BeatriceBatch_BindResidentIO(b, h.d_in, h.d_out, h.n_slots) == 0 && tick_enable(b, true) == 0;
+  h.tick_of_ev.assign(tick::kRing, -1);
+  h.mapped = std::getenv("BEATRICE_HIP_HS_COPIES") == nullptr;   // A/B switch: copies on two more streams instead
+  if (ok && h.mapped) std::memset(h.h_in, 0, sizeof(float) * n_in * h.n_slots);
+  ok = ok && BeatriceBatch_BindResidentIO(b, h.mapped ? h.h_in : h.d_in, h.mapped ? h.h_out : h.d_out, h.n_slots) == 0 && tick_enable(b, true) == 0;
   if (!ok) { (void)tick_enable(b, false); (void)BeatriceBatch_BindResidentIO(b, nullptr, nullptr, 0); host_stream_free(b); return -2; }
   h.pending.clear();
   h.fed = 0;
@@ -1592,6 +1611,20 @@ int BeatriceBatch_StreamFrames(BeatriceBatch* b, const float* in, float* out) {
   if (!h.on || !in || !out) return -1;
   const size_t n_in = (size_t)b->B * B_IN_HOP, n_out = (size_t)b->B * B_OUT_HOP;
   const int slot = b->io_host;  // the slot the tick about to be fed reads and, pipeline depth later, writes
+  if (h.mapped) {
+    // the slot's last readers (stage 9 of the step fed n_slots calls ago) are done: every call since the pipeline filled
+    // has waited for a tick later than theirs before handing back its output
+    std::memcpy(h.h_in + slot * n_in, in, sizeof(float) * n_in);
+    if (!host_stream_tick(b, true)) return -2;
+    h.pending.push_back({h.fed, slot, b->tk.last_feed_tick + b->tk.plan.count() - 1, false});
+    h.fed += 1;
+    const BeatriceBatch::HostStream::Pending& f = h.pending.front();
+    if (!f.fetched || f.done_tick > b->tk.last_feed_tick - 2) return 0;   // keep two ticks queued on the device while the host waits
+    if (!host_stream_wait(b, f)) return -2;
+    std::memcpy(out, h.h_out + f.slot * n_out, sizeof(float) * n_out);
+    h.pending.pop_front();
+    return 1;
+  }
   if (!hip_ok(hipEventSynchronize(h.ev_in[slot]), "hs in reuse")) return -2;  // the upload that last used this pinned slot (long done)
   std::memcpy(h.h_in + slot * n_in, in, sizeof(float) * n_in);
   // every reader of the device slot's old contents is done once the tick before the previous one is (the slot ring is
@@ -1623,7 +1656,7 @@ int BeatriceBatch_StreamFlush(BeatriceBatch* b, float* out) {
   while (!h.pending.front().fetched)
     if (!host_stream_tick(b, false)) return -2;
   const BeatriceBatch::HostStream::Pending f = h.pending.front();
-  if (!hip_ok(hipEventSynchronize(h.ev_out[f.slot]), "hs flush")) return -2;
+  if (!host_stream_wait(b, f)) return -2;
   std::memcpy(out, h.h_out + f.slot * n_out, sizeof(float) * n_out);
   h.pending.pop_front();
   return 1;

@@ -202,8 +202,9 @@ int BeatriceBatch_TickStages(const BeatriceBatch* b);
  * front end).  BeatriceBatch_EnableHostStreaming(b, 1) gives the batch its own resident slots + pinned mirrors and turns
  * tick mode on (requirements as above, nothing else bound); every BeatriceBatch_StreamFrames(b, in, out) then takes one
  * hop of every stream ([B][160] in) and -- once the pipeline is full -- returns 1 with `out` ([B][240]) holding the samples
- * of the step fed BeatriceBatch_HostStreamDelay() calls earlier (0 while filling: `out` untouched).  Uploads, ticks and
- * downloads of neighbouring steps run on three HIP streams, so the PCIe copies hide behind the ticks.  After the last
+ * of the step fed BeatriceBatch_HostStreamDelay() calls earlier (0 while filling: `out` untouched).  The resident slots ARE
+ * the pinned host mirrors: the first stages read their hop and the last stage writes its samples over PCIe themselves, so
+ * there is no copy command and no second stream, and the transfers hide among the tick's workgroups.  After the last
  * input, BeatriceBatch_StreamFlush(b, out) returns the remaining steps one per call (1, then 0 when none is left).
  * Same samples as BeatriceBatch_ConvertFrames, bit for bit.  This is the host-buffer form of what src/common's
  * ProcessorCore2::Process does per stream (processor_core_2.cc:24-48: in -> model hop -> out), for a whole batch. */
