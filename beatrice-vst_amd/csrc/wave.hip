@@ -120,9 +120,14 @@ static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t
     a.res = s.e;
     launch_auto<INP<H>>("wave.inp", a, st);
   }
-  // BEATRICE_HIP_ROWCHAIN=1: the conditioned blocks as two stream-stationary kernels each (rowchain.hip.h) instead of six
-  // per-layer launches -- for measurements and parity tests; the in-order chain is faster with the per-layer launches
-  static const bool rowchain = std::getenv("BEATRICE_HIP_ROWCHAIN") != nullptr;
+  // The conditioned blocks as two stream-stationary kernels each (rowchain.hip.h) instead of six per-layer launches: the
+  // per-layer launches win while a launch cannot fill the chip (256 streams: 0.293 vs 0.413 ms per step), the row-local
+  // kernels once 16 streams per workgroup do (8192 streams: 84-89 TFLOP/s per block half against 34-61 for the six
+  // layers; 3.40 -> 3.82 M frames/s); even at 2048.  BEATRICE_HIP_ROWCHAIN=1 / =0 forces one or the other (measurements, parity tests).
+  static const char* const rc_env = std::getenv("BEATRICE_HIP_ROWCHAIN");
+  const bool rowchain = rc_env != nullptr ? rc_env[0] != '0' : B >= 2048;
+  // (the upsampler convolutions as 16-row full-width workgroups, rc::conv_rows_body, measured the same as the 64 x 64 tiling
+  //  at 8192 streams: 56-75 vs 57-74 us per launch)
   for (int blk = 0; blk < B_NBLOCKS; ++blk) {
     if (!in_part(2 + blk)) continue;
     if (rowchain && H == 1) {

@@ -156,3 +156,35 @@ def test_batch_and_shard_invariance(bv, product, model_dir):
     assert np.array_equal(run(41, 42), whole[:, 41:42])
     m.close()
     assert np.abs(whole).max() > 0.05
+
+
+def test_large_batch_chain_matches_small_batches(bv, product, model_dir):
+    """From 2048 streams on the in-order chain runs the conditioned blocks as row-local kernels (wave.hip); below that as
+    six launches per block.  Same streams either way, bit for bit: 2048 streams in one batch against slices of them in
+    batches of 300, with speakers and k-NN settings varied (per-speaker attention tiles) and a switch in mid-run."""
+    B, hops = 2048, 6
+    base = np.stack([bv.synth_audio(160 * hops, seed=5200 + s) for s in range(64)])
+    audio = np.concatenate([np.roll(base, 37 * r, axis=1) * np.float32(1.0 - 0.01 * r) for r in range(B // 64)], axis=0)
+    m = bv.Models(product, model_dir)
+
+    def run(lo, hi):
+        batch = bv.Batch(m, hi - lo)
+        for s in range(lo, hi):
+            batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, s - lo, s % 3)
+            batch.a.BeatriceBatch_SetVQNumNeighbors(batch.h, s - lo, (s // 3) % 3)
+        batch.a.BeatriceBatch_FlushSpeaker(batch.h, -1)
+        out = []
+        for h in range(hops):
+            if h == 2:
+                for s in range(lo, hi):
+                    if s % 5 == 0:
+                        batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, s - lo, (s + 1) % 3)   # K/V blocks follow one per hop
+            out.append(batch.convert(np.ascontiguousarray(audio[lo:hi, h * 160:(h + 1) * 160])))
+        batch.close()
+        return np.stack(out)
+
+    whole = run(0, B)
+    assert np.abs(whole).max() > 0.05
+    for lo in (0, 900, 1748):
+        assert np.array_equal(run(lo, lo + 300), whole[:, lo:lo + 300]), "streams %d.. differ between the two chains" % lo
+    m.close()
