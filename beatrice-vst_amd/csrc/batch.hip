@@ -214,6 +214,7 @@ struct BeatriceBatch {
     const float* d_in48 = nullptr;   // [n_slots][B][channels][480]
     float* d_out48 = nullptr;        // [n_slots][B][channels][480]
     float *d_in16 = nullptr, *d_out24 = nullptr;  // [n_slots][B][160], [n_slots][B][240]: the resident I/O of the ticks
+    int deferred_slot = -1;                       // step completed by the last tick, its 48 kHz block not yet produced
   } r48;
   float *d_coef_down = nullptr, *d_coef_up = nullptr, *d_io48 = nullptr, *h_io48 = nullptr;  // io: in [B][2][480] | out [B][2][480]
 };
@@ -692,24 +693,33 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
       k.stage_pending[upload_stage] = true;
     }
   }
-  if (b->r48.on && feeding) {  // 48 kHz block of the step entering the pipeline -> its 16 kHz hop, straight into the resident slot
-    const BeatriceBatch::Resident48& r = b->r48;
-    hipLaunchKernelGGL(wrap48_pre_kernel, dim3(b->B), dim3(256), 0, st, r.d_in48 + (size_t)b->io_host * b->B * r.channels * 480, r.channels,
-                       b->d_w48, b->d_coef_down, r.d_in16 + (size_t)b->io_host * b->B * B_IN_HOP);
+  if (b->r48.on && (feeding || b->r48.deferred_slot >= 0)) {
+    // one launch for both ends of the 48 kHz wrapper: the block entering the pipeline -> its 16 kHz hop, straight into the
+    // resident slot; and the step the PREVIOUS tick completed leaves through the up-sampler and the 480-sample FIFO
+    // (resample.h:346-361: the block emitted for step j carries the model output of step j - 1) into the 48 kHz slot of step j
+    BeatriceBatch::Resident48& r = b->r48;
+    Wrap48TickArgs wa{};
+    wa.channels = r.channels; wa.st = b->d_w48; wa.coef_down = b->d_coef_down; wa.coef_up = b->d_coef_up;
+    if (feeding) {
+      wa.n_pre = b->B;
+      wa.in48 = r.d_in48 + (size_t)b->io_host * b->B * r.channels * 480;
+      wa.in16 = r.d_in16 + (size_t)b->io_host * b->B * B_IN_HOP;
+    }
+    if (r.deferred_slot >= 0) {
+      wa.n_post = b->B;
+      wa.out48 = r.d_out48 + (size_t)r.deferred_slot * b->B * r.channels * 480;
+      wa.model_out = r.d_out24 + (size_t)r.deferred_slot * b->B * B_OUT_HOP;
+      r.deferred_slot = -1;
+    }
+    hipLaunchKernelGGL(wrap48_tick_kernel, dim3(wa.n_pre + wa.n_post), dim3(256), 0, st, wa);
   }
   prof.lap(3);
   fuse::StepPairs pairs;
   for (int s = 0; s < fuse::kMaxStepPairs; ++s) { pairs.hop[s] = s < p.n_stages ? p.hop[s] : -1; pairs.io[s] = s < p.n_stages ? p.io[s] : 0; }
   fuse::launch_table_w<4>(k.d_table, k.table_total, st, pairs);
-  if (b->r48.on) {  // the step this tick completed leaves through the up-sampler and the 480-sample FIFO (resample.h:346-361: the
-                    // block emitted for step j carries the model output of step j - 1), into the 48 kHz slot of step j
+  if (b->r48.on) {  // the step this tick completed: its 48 kHz block is produced by the wrapper launch of the next tick (or of the drain)
     const long long u = step_at(k.plan.count() - 1);
-    if (u >= 0) {
-      const BeatriceBatch::Resident48& r = b->r48;
-      const int slot = k.io_of_step[u % kRing];
-      hipLaunchKernelGGL(wrap48_post_kernel, dim3(b->B), dim3(256), 0, st, b->d_w48, b->d_coef_up, r.d_out48 + (size_t)slot * b->B * r.channels * 480, r.channels);
-      hipLaunchKernelGGL(wrap48_latch_kernel, dim3((b->B * 240 + 255) / 256), dim3(256), 0, st, b->d_w48, r.d_out24 + (size_t)slot * b->B * B_OUT_HOP, b->B);
-    }
+    if (u >= 0) b->r48.deferred_slot = k.io_of_step[u % kRing];
   }
   if (feeding) {
     b->last_parity = b->hop_host % 3;
@@ -739,6 +749,17 @@ bool tick_drain(BeatriceBatch* b) {
       }
   }
   while (ok && b->tk.on && b->tk.tick <= b->tk.last_feed_tick + b->tk.plan.count() - 1) ok = tick_run(b, false);
+  if (ok && b->r48.on && b->r48.deferred_slot >= 0) {  // the 48 kHz block of the step the last tick completed
+    BeatriceBatch::Resident48& r = b->r48;
+    Wrap48TickArgs wa{};
+    wa.channels = r.channels; wa.st = b->d_w48; wa.coef_down = b->d_coef_down; wa.coef_up = b->d_coef_up;
+    wa.n_post = b->B;
+    wa.out48 = r.d_out48 + (size_t)r.deferred_slot * b->B * r.channels * 480;
+    wa.model_out = r.d_out24 + (size_t)r.deferred_slot * b->B * B_OUT_HOP;
+    r.deferred_slot = -1;
+    hipLaunchKernelGGL(wrap48_tick_kernel, dim3(wa.n_post), dim3(256), 0, b->stream, wa);
+    ok = hip_ok(hipGetLastError(), "wrap48 flush");
+  }
   return ok;
 }
 int tick_enable(BeatriceBatch* b, bool on) {

@@ -529,12 +529,11 @@ struct Wrap48State {   // per stream, floats
 };
 
 // mono = (L + R) * 0.5 (or L), 31-tap low-pass evaluated only at the samples the decimator keeps
-static __global__ __launch_bounds__(256) void wrap48_pre_kernel(const float* __restrict__ in48, int channels,
-                                                                Wrap48State* __restrict__ st, const float* __restrict__ coef_down,
-                                                                float* __restrict__ in16) {
-  __shared__ float g[30 + 480];
-  __shared__ float cd[33];
-  const int b = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void wrap48_pre_body(const int b, const float* __restrict__ in48, int channels, Wrap48State* __restrict__ st,
+                                                const float* __restrict__ coef_down, float* __restrict__ in16, float* __restrict__ lds) {
+  float* g = lds;        // [30 + 480]
+  float* cd = lds + 512; // [33]
+  const int tid = threadIdx.x;
   const float* src = in48 + (size_t)b * channels * 480;
   if (tid < 33) cd[tid] = coef_down[tid];
   if (tid < 30) g[tid] = st[b].hist_in[tid];
@@ -553,13 +552,21 @@ static __global__ __launch_bounds__(256) void wrap48_pre_kernel(const float* __r
   }
   if (tid < 30) st[b].hist_in[tid] = g[480 + tid];
 }
+static __global__ __launch_bounds__(256) void wrap48_pre_kernel(const float* __restrict__ in48, int channels,
+                                                                Wrap48State* __restrict__ st, const float* __restrict__ coef_down,
+                                                                float* __restrict__ in16) {
+  __shared__ float lds[512 + 33];
+  wrap48_pre_body(blockIdx.x, in48, channels, st, coef_down, in16, lds);
+}
 
-// zero-stuffed previous model output through the 32-tap low-pass; writes every channel
-static __global__ __launch_bounds__(256) void wrap48_post_kernel(Wrap48State* __restrict__ st, const float* __restrict__ coef_up,
-                                                                 float* __restrict__ out48, int channels) {
-  __shared__ float f[16 + 240];
-  __shared__ float cu[33];
-  const int b = blockIdx.x, tid = threadIdx.x;
+// zero-stuffed previous model output through the 32-tap low-pass; writes every channel.  latch != nullptr: the model
+// output of this step ([B][240]) then takes the FIFO's place for the next block (what wrap48_latch_kernel does).
+__device__ __forceinline__ void wrap48_post_body(const int b, Wrap48State* __restrict__ st, const float* __restrict__ coef_up,
+                                                 float* __restrict__ out48, int channels, const float* __restrict__ latch,
+                                                 float* __restrict__ lds) {
+  float* f = lds;         // [16 + 240]
+  float* cu = lds + 256;  // [33]
+  const int tid = threadIdx.x;
   if (tid < 33) cu[tid] = coef_up[tid];
   if (tid < 16) f[tid] = st[b].ztail[tid];
   if (tid < 240) f[16 + tid] = st[b].fpend[tid];
@@ -576,9 +583,32 @@ static __global__ __launch_bounds__(256) void wrap48_post_kernel(Wrap48State* __
   }
   __syncthreads();
   if (tid < 16) st[b].ztail[tid] = f[16 + 224 + tid];
+  if (latch != nullptr && tid < 240) st[b].fpend[tid] = latch[(size_t)b * 240 + tid];
+}
+static __global__ __launch_bounds__(256) void wrap48_post_kernel(Wrap48State* __restrict__ st, const float* __restrict__ coef_up,
+                                                                 float* __restrict__ out48, int channels) {
+  __shared__ float lds[256 + 33];
+  wrap48_post_body(blockIdx.x, st, coef_up, out48, channels, nullptr, lds);
 }
 
 static __global__ void wrap48_latch_kernel(Wrap48State* __restrict__ st, const float* __restrict__ model_out, int B) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < B * 240) st[idx / 240].fpend[idx % 240] = model_out[idx];
+}
+
+// Both ends of the wrapper around one tick of the pipelined batch, one launch: workgroups [0, n_pre) turn the 48 kHz block
+// entering the pipeline into its 16 kHz hop, workgroups [n_pre, n_pre + n_post) emit the 48 kHz block of the step that
+// left the pipeline one tick earlier and latch its model output (they touch disjoint parts of Wrap48State).
+struct Wrap48TickArgs {
+  int n_pre, n_post, channels;
+  Wrap48State* st;
+  const float *coef_down, *coef_up;
+  const float* in48; float* in16;          // pre: slot of the step fed by this tick
+  float* out48; const float* model_out;    // post: slot of the step completed by the previous tick
+};
+static __global__ __launch_bounds__(256) void wrap48_tick_kernel(const Wrap48TickArgs a) {
+  __shared__ float lds[512 + 33];
+  const int w = blockIdx.x;
+  if (w < a.n_pre) wrap48_pre_body(w, a.in48, a.channels, a.st, a.coef_down, a.in16, lds);
+  else wrap48_post_body(w - a.n_pre, a.st, a.coef_up, a.out48, a.channels, a.model_out, lds);
 }
