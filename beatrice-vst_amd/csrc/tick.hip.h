@@ -4,8 +4,8 @@
 // Why: at a few hundred streams a step is a string of ~40 dependent, latency-bound launches, each using a fraction of
 // the chip for 4-9 us.  Streams never exchange data and every mutable thing is per-stream
 // state, so consecutive steps can overlap as long as stage s of step t+1 runs after stage s of step t.  A tick is ONE
-// launch in which stage s works on step (tick - s): ~2500 independent workgroups of 26 different steps fill the chip, and the only
-// synchronisation is the kernel boundary between ticks.  Outputs are bit-identical to the in-order chain: the same
+// launch in which stage s works on step (tick - s): ~1900 independent workgroups of 26 different steps fill the chip, and
+// the only synchronisation is the kernel boundary between ticks.  Outputs are bit-identical to the in-order chain: the same
 // kernel bodies run on the same data, only later.  A step's output appears n_stages - 1 ticks after its input was
 // fed; BeatriceBatch_Synchronize drains the pipeline.  For callers that enqueue steps ahead of their completion
 // (resident audio); a server that needs each hop back before the next runs the in-order chain.
@@ -18,9 +18,10 @@
 //     at) and passed to the launch BY VALUE (fuse::StepPairs in the kernel arguments; a workgroup leaves its body's pair
 //     in LDS, ring.h stepc): no launch to publish counters, no dependent global load at the start of a workgroup;
 //     -1 = "no step this tick" (fill, drain);
-//   * per-stream settings are versioned: a change is uploaded once into a slot of a snapshot ring, and the prologue
-//     copies the snapshot into a consumer's private arrays at the tick that consumer reaches the step the change
-//     belongs to (consumers: k-NN, pitch head, conditioning mix, the two attention kernels of each block).
+//   * per-stream settings are versioned: a change goes once into a slot of a snapshot ring on the device (staged in a
+//     ring of pinned host copies and fetched by the prologue kernel itself), and the same prologue kernel copies the
+//     byte range a consumer stage reads from its step's snapshot into that stage's private arrays at the tick the step
+//     arrives there (consumers: k-NN, pitch head, conditioning mix, the attention half of each block).
 #pragma once
 #include "chain_layers.hip.h"
 #include "fuse.hip.h"

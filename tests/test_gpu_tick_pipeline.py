@@ -1,5 +1,5 @@
 """Tick pipelining (BeatriceBatch_EnableTickPipeline): every layer of the chain its own pipeline stage, one launch per
-tick, ~40 steps in flight.  Must give the samples of the in-order chain bit for bit -- with per-stream settings
+tick, 26 steps in flight.  Must give the samples of the in-order chain bit for bit -- with per-stream settings
 changing between steps (speaker switches installing one K/V block per hop, k-NN on/off, pitch and formant
 settings), across pipeline drains, a stream reset in mid-flight, and the return to the in-order chain."""
 import numpy as np
