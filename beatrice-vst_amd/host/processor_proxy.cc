@@ -117,6 +117,22 @@ ErrorCode ProcessorProxy::Read(const unsigned char* blob, size_t n) {  // refere
   return read == ErrorCode::kSuccess ? sync : read;
 }
 
+ErrorCode ProcessorProxy::ProcessChannels(const float* in0, const float* in1, float* out0, float* out1, int n, bool* silent) {
+  if (silent) *silent = true;
+  if (!in0 || !out0 || n < 0) return ErrorCode::kUnknownError;
+  std::memmove(out0, in0, sizeof(float) * (size_t)n);          // processor.cc:183-185
+  if (in1) {
+    for (int i = 0; i < n; ++i) { out0[i] += in1[i]; out0[i] *= 0.5f; }   // :186-192 (two roundings, as there)
+  }
+  bool sil = true;                                              // :204-211
+  for (int i = 0; i < n; ++i) if (out0[i] != 0.0f) { sil = false; break; }
+  ErrorCode rc = ErrorCode::kSuccess;
+  if (!sil) rc = Process(out0, out0, n);                        // :212-219 (the shell ignores the code; we hand it on)
+  if (silent) *silent = sil;
+  if (out1) std::memcpy(out1, out0, sizeof(float) * (size_t)n);  // :221-225
+  return rc;
+}
+
 }  // namespace beatrice_amd
 
 // ---- C view for tests and non-C++ hosts -------------------------------------------------------------------------------
@@ -130,6 +146,12 @@ int BeatriceProxy_SetNumber(void* p, int id, double v) { return (int)static_cast
 int BeatriceProxy_SetInt(void* p, int id, int v) { return (int)static_cast<ProcessorProxy*>(p)->SetParameter((std::int16_t)id, v); }
 int BeatriceProxy_SetString(void* p, int id, const char* s) { return (int)static_cast<ProcessorProxy*>(p)->SetParameter((std::int16_t)id, std::string(s ? s : "")); }
 int BeatriceProxy_Process(void* p, const float* in, float* out, int n) { return (int)static_cast<ProcessorProxy*>(p)->Process(in, out, n); }
+// returns 1 when the block was silent (not converted), 0 when it was converted, < 0: -(error code)
+int BeatriceProxy_ProcessChannels(void* p, const float* in0, const float* in1, float* out0, float* out1, int n) {
+  bool silent = true;
+  const int rc = (int)static_cast<ProcessorProxy*>(p)->ProcessChannels(in0, in1, out0, out1, n, &silent);
+  return rc != 0 ? -rc : (silent ? 1 : 0);
+}
 int BeatriceProxy_ResetContext(void* p) { return (int)static_cast<ProcessorProxy*>(p)->ResetContext(); }
 int BeatriceProxy_CoreVersion(void* p) { return static_cast<ProcessorProxy*>(p)->CoreVersion(); }
 int BeatriceProxy_VoiceCount(void* p) { const auto* c = static_cast<ProcessorProxy*>(p)->Config(); return c ? beatrice_amd::GetVoiceCount(*c) : 0; }

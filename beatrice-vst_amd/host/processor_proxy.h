@@ -37,6 +37,12 @@ class ProcessorProxy {
   const ParameterState& GetParameterState() const { return state_; }
   // the core's Process (reference ProcessorCoreBase::Process); zeros while no model is loaded
   ErrorCode Process(const float* in, float* out, int n);
+  // One audio block as the VST shell hands it to the core (reference src/vst/processor.cc:183-225): channel 0 of the
+  // output receives the input, down-mixed (L + R) * 0.5 when there are two input channels; a block whose down-mix is
+  // all zeros is NOT converted -- the core is not called, its state and its 10 ms FIFO stand still, the output is that
+  // silence (the reference marks this TODO(bug); reproduced as it is) -- otherwise Process runs in place; a second output
+  // channel is a copy of the first.  in1 / out1 may be null.  *silent reports which of the two happened.
+  ErrorCode ProcessChannels(const float* in0, const float* in1, float* out0, float* out1, int n, bool* silent);
   ErrorCode ResetContext();
   bool IsLoaded() const { return core_ != nullptr; }
   int CoreVersion() const { return core_ ? 2 : -1; }           // reference ProcessorCoreBase::GetVersion; -1 = unloaded

@@ -159,7 +159,9 @@ int BeatriceBatch_BindResidentIO48k(BeatriceBatch* b, const float* d_in48, float
  * exact-480 FIFO -> every third sample -> model hop -> zero-stuffing -> 48 kHz to host rate -> output gain -> every channel.
  * BeatriceBatch_ConfigureWrapper sets the host rate for the batch (restarting resampler and FIFO, like SetSampleRate);
  * BeatriceBatch_ProcessBlocks[Device] converts one block of n samples per stream, [B][channels][n] planar, channels 1 or 2
- * (stereo is down-mixed (L+R)*0.5 as src/vst/processor.cc:183-192 does); n may change from call to call, up to
+ * (stereo is down-mixed (L+R)*0.5 as src/vst/processor.cc:183-192 does; the shell's skip of an all-zero block, :204-214,
+ * is NOT applied per stream -- the streams of a batch advance together, a silent stream is converted like any other; the
+ * one-stream form of that rule is ProcessorProxy::ProcessChannels, beatrice_host.h); n may change from call to call, up to
  * BeatriceBatch_MaxWrapperBlock(b) (4088 samples at the higher of the two rates).  A model hop runs whenever 480 samples
  * at 48 kHz have accumulated (0, 1 or several times per call).  Bit-identical to the host chain.  One 10 ms hop per step
  * batches only, pipelining off. */

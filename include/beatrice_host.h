@@ -57,6 +57,10 @@ int BeatriceProxy_SetNumber(void* proxy, int id, double v);                  /* 
 int BeatriceProxy_SetInt(void* proxy, int id, int v);
 int BeatriceProxy_SetString(void* proxy, int id, const char* s);
 int BeatriceProxy_Process(void* proxy, const float* in, float* out, int n);
+/* one block as the VST shell hands it over (src/vst/processor.cc:183-225): (L + R) * 0.5 down-mix, an all-zero block is
+ * not converted (core state stands still), second output channel = copy.  in1 / out1 may be NULL.
+ * Returns 1 = silent block, 0 = converted, < 0 = -(error code). */
+int BeatriceProxy_ProcessChannels(void* proxy, const float* in0, const float* in1, float* out0, float* out1, int n);
 int BeatriceProxy_ResetContext(void* proxy);
 int BeatriceProxy_CoreVersion(void* proxy);                                  /* -1 = unloaded core */
 int BeatriceProxy_VoiceCount(void* proxy);                                   /* model_config.h voices with a non-empty description */

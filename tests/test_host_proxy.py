@@ -30,7 +30,7 @@ class Proxy:
                            ("SetInt", [C.c_int, C.c_int]), ("SetString", [C.c_int, C.c_char_p]), ("Process", [_f32p, _f32p, C.c_int]),
                            ("ResetContext", []), ("CoreVersion", []), ("VoiceCount", []), ("GetKind", [C.c_int]), ("GetNumber", [C.c_int]),
                            ("GetString", [C.c_int, C.c_char_p, C.c_int]), ("WriteState", [C.c_char_p, C.c_int]), ("ReadState", [C.c_char_p, C.c_int]),
-                           ("MorphWeights", [_f32p])):
+                           ("MorphWeights", [_f32p]), ("ProcessChannels", [_f32p, _f32p, _f32p, _f32p, C.c_int])):
             getattr(L, "BeatriceProxy_" + name).argtypes = [C.c_void_p] + args
         L.BeatriceProxy_GetNumber.restype = C.c_double
         self.h = L.BeatriceProxy_Create()
@@ -239,3 +239,49 @@ def test_morph_weights_formula(built):
     p.call("MorphWeights", got.ctypes.data_as(_f32p))
     assert got[0] == f(0.25) and got[1] == f(0.5) and got[2] == f(0.25)
     p.close()
+
+
+def test_vst_shell_block_handling(built, model_dir):
+    """ProcessChannels = the block handling of the reference's VST shell (src/vst/processor.cc:183-225): stereo is
+    down-mixed (L + R) * 0.5, an all-zero block is not converted at all -- the core's state and its 10 ms FIFO stand
+    still, so the remaining blocks come out as if the silent block had never been there -- and a second output channel
+    is a copy.  Known answers: the same proxy driven through Process with the equivalent mono input."""
+    rng = np.random.default_rng(11)
+    n, blocks = 512, 9
+    L_ = (0.2 * rng.standard_normal(n * blocks)).astype(np.float32)
+    R_ = (0.2 * rng.standard_normal(n * blocks)).astype(np.float32)
+    silent_at = {3, 4, 7}
+    for k in silent_at:
+        L_[k * n:(k + 1) * n] = 0.0
+        R_[k * n:(k + 1) * n] = 0.0
+    mono = ((L_ + R_) * np.float32(0.5)).astype(np.float32)      # (float add, float multiply: the shell's two roundings)
+
+    def fresh():
+        p = Proxy(44100.0)
+        assert p.call("LoadModel", os.path.join(model_dir, "model.toml").encode()) == OK
+        return p
+
+    p = fresh()
+    out0 = np.full(n * blocks, 5.0, np.float32)
+    out1 = np.full(n * blocks, 6.0, np.float32)
+    flags = []
+    for k in range(blocks):
+        sl = slice(k * n, (k + 1) * n)
+        flags.append(p.call("ProcessChannels", L_[sl].ctypes.data_as(_f32p), R_[sl].ctypes.data_as(_f32p),
+                            out0[sl].ctypes.data_as(_f32p), out1[sl].ctypes.data_as(_f32p), n))
+    assert flags == [1 if k in silent_at else 0 for k in range(blocks)]
+    assert np.array_equal(out0, out1)
+    for k in silent_at:
+        assert not out0[k * n:(k + 1) * n].any()
+    # reference run: only the non-silent blocks, through Process, mono
+    q = fresh()
+    keep = [k for k in range(blocks) if k not in silent_at]
+    want, codes = q.process(np.concatenate([mono[k * n:(k + 1) * n] for k in keep]), block=n)
+    assert all(c == OK for c in codes)
+    got = np.concatenate([out0[k * n:(k + 1) * n] for k in keep])
+    assert np.abs(want).max() > 1e-3 and np.array_equal(got, want)
+    # mono input, no second output channel
+    r = fresh()
+    o = np.zeros(n, np.float32)
+    assert r.call("ProcessChannels", mono[:n].ctypes.data_as(_f32p), None, o.ctypes.data_as(_f32p), None, n) == 0
+    assert np.array_equal(o, want[:n])
