@@ -230,9 +230,10 @@ class Stream1:
         a.DestroyEmbeddingContext(self.ec)
 
 
-def synth_audio(n_samples, seed=0, sr=16000):
+def synth_audio(n_samples, seed=0, sr=16000, silence_gap=False):
     """Deterministic voiced-like test signal: gliding band-limited saw,
-    4 Hz syllable envelope, low-level noise."""
+    4 Hz syllable envelope, low-level noise.  silence_gap: 0.5 s of digital silence from 0.1 s on (the survey's
+    "10 % of the streams contain 0.5 s digital silence gaps"; the harness converts them like anything else)."""
     rng = np.random.Generator(np.random.PCG64(0xBEA7 + seed))
     t = np.arange(n_samples) / sr
     period = 2.0 + 2.0 * rng.random()
@@ -243,6 +244,8 @@ def synth_audio(n_samples, seed=0, sr=16000):
         x += np.sin(h * ph) / h * (h * f0 < 0.45 * sr)
     env = 0.55 + 0.45 * np.sin(2 * np.pi * 4.0 * t + rng.random() * 6.28)
     x = 0.3 * x / 1.8 * env + 0.0316 * 0.3 * rng.standard_normal(n_samples)
+    if silence_gap:
+        x[int(0.1 * sr):int(0.6 * sr)] = 0.0
     return x.astype(np.float32)
 
 

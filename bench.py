@@ -444,7 +444,7 @@ def main():
 
     # synthetic audio, resident on the device: 64 hops x B streams, cycled
     n_cycle = 64
-    audio = np.stack([bv.synth_audio(160 * n_cycle, seed=rank * 100000 + s) for s in range(B)])
+    audio = np.stack([bv.synth_audio(160 * n_cycle, seed=rank * 100000 + s, silence_gap=(s % 10 == 3)) for s in range(B)])  # (every tenth stream: 0.5 s of digital silence)
     audio = np.ascontiguousarray(audio.reshape(B, n_cycle, 160).transpose(1, 0, 2))
     d_audio = torch.from_numpy(audio).cuda()
     resident = a.config != 4 and not a.copy_io
