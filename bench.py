@@ -553,13 +553,16 @@ def main():
         if tick48:  # configs[4]: the wrapper kernels run beside each tick launch; per-kernel figures below are of the chain in order
             product.BeatriceBatch_BindResidentIO48k(batch.h, None, None, 0, 0)
         if tick:
-            # the dominant kernel of the headline IS the tick launch: refill the pipeline, then time 48 more launches with
-            # HIP events on the batch's stream (BeatriceBatch_TimeTickLaunch)
+            # the dominant kernel of the headline IS the tick launch: refill the pipeline, then time 64 more launches between
+            # one pair of HIP events on the batch's stream (BeatriceBatch_TimeTickLaunch)
             stages = product.BeatriceBatch_TickStages(batch.h)
             for i in range(stages + 2):
                 step(a.warmup + a.steps + i)
             us, fl, by = ctypes.c_float(0), ctypes.c_double(0), ctypes.c_double(0)
-            if product.BeatriceBatch_TimeTickLaunch(batch.h, 48, ctypes.byref(us), ctypes.byref(fl), ctypes.byref(by)) == 0:
+            # (the first call after a refill reads ~5 % long -- 83 -> 81 -> 79 -> 77 us over four calls, tools/debug/time_tick.py:
+            #  clocks and caches settle over a few hundred ticks -- so one call is thrown away)
+            product.BeatriceBatch_TimeTickLaunch(batch.h, 64, ctypes.byref(us), ctypes.byref(fl), ctypes.byref(by))
+            if product.BeatriceBatch_TimeTickLaunch(batch.h, 64, ctypes.byref(us), ctypes.byref(fl), ctypes.byref(by)) == 0:
                 ach = fl.value / (us.value * 1e-6) / 1e12
                 tick_roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),

@@ -1,0 +1,30 @@
+"""BeatriceBatch_TimeTickLaunch called repeatedly (is its figure stable, does it match the loop's period?)"""
+import ctypes, importlib, os, sys, tempfile, time
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tools"))
+import numpy as np
+import torch
+torch.cuda.init()
+import make_model
+bv = importlib.import_module("beatrice-vst_amd")
+product = bv.bind_batch(bv.load_product())
+tmp = tempfile.TemporaryDirectory(); make_model.make_model(tmp.name, n_speakers=1)
+m = bv.Models(product, tmp.name)
+B, n = 256, 64
+batch = bv.Batch(m, B)
+d_in = torch.randn((n, B, 160), device="cuda") * 0.1
+d_out = torch.zeros((n, B, 240), device="cuda")
+assert product.BeatriceBatch_BindResidentIO(batch.h, d_in.data_ptr(), d_out.data_ptr(), n) == 0
+assert product.BeatriceBatch_EnableTickPipeline(batch.h, 1) == 0
+for _ in range(60):
+    product.BeatriceBatch_ConvertFramesDevice(batch.h, None, None)
+us, fl, by = ctypes.c_float(0), ctypes.c_double(0), ctypes.c_double(0)
+for ticks in (48, 48, 64, 64, 16):
+    product.BeatriceBatch_TimeTickLaunch(batch.h, ticks, ctypes.byref(us), ctypes.byref(fl), ctypes.byref(by))
+    print("TimeTickLaunch(%d): %.2f us" % (ticks, us.value))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(400):
+    product.BeatriceBatch_ConvertFramesDevice(batch.h, None, None)
+torch.cuda.synchronize()
+print("loop without drain: %.2f us per tick" % ((time.perf_counter() - t0) / 400 * 1e6))
