@@ -347,6 +347,9 @@ def main():
     ap.add_argument("--copy-io", action="store_true",
                     help="device-to-device copy of each hop into / out of the library's own buffers instead of "
                          "binding the resident audio buffers (BeatriceBatch_BindResidentIO)")
+    ap.add_argument("--device-warm-ms", type=float, default=250.0,
+                    help="milliseconds of unrelated GPU work (torch matmuls) before the warm-up steps, so that a run of a few milliseconds "
+                         "does not execute at an idle device's clocks (+5 %% at 20 and at 300 steps); 0 = off; stated in config")
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / B=1 latency / kernel profile")
     ap.add_argument("--total-streams", type=int, default=None,
                     help="strong scaling: this many streams in total, split evenly over the GPUs (default: --streams per GPU, weak scaling)")
@@ -501,6 +504,15 @@ def main():
         if rc:
             raise SystemExit("Convert* failed: %d" % rc)
 
+    if a.device_warm_ms > 0:  # bring the GPU out of its idle power state with unrelated work (stated in `config`): a run of
+        # a few milliseconds otherwise executes at the clocks of an idle device (tools/debug/time_tick.py)
+        wa = torch.randn((2048, 2048), device="cuda")
+        t_end = time.perf_counter() + a.device_warm_ms * 1e-3
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                wa = (wa @ wa).clamp_(-1.0, 1.0)
+            torch.cuda.synchronize()
+        del wa
     for i in range(a.warmup):
         step(i)
     product.BeatriceBatch_Synchronize(batch.h)
@@ -533,7 +545,7 @@ def main():
                                        "speaker every 200 hops (K/V blocks one per hop), VQ k=4" % (B, a.speakers),
                                     4: "BASELINE.json configs[4] per-GPU share: %d streams of 48 kHz stereo, downmix + resample "
                                        "wrapper on the device, 480-sample blocks" % B}[a.config],
-                       "streams_per_gpu": B, "speakers": a.speakers, "hipgraph": not a.no_graph,
+                       "streams_per_gpu": B, "speakers": a.speakers, "hipgraph": not a.no_graph, "device_warm_ms": a.device_warm_ms,
                        "pipelining": ("tick: every layer of the chain its own pipeline stage (%d stages), one launch per tick on one HIP "
                                       "stream, stage s works on the step fed s ticks earlier; steps enqueued without waiting; the timed "
                                       "region includes the %d ticks that drain the pipeline" % (product.BeatriceBatch_TickStages(batch.h), product.BeatriceBatch_TickStages(batch.h) - 1)) if (tick or tick48)
