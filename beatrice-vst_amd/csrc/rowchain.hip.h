@@ -71,6 +71,54 @@ __device__ __forceinline__ void mma_segment_p(f32x4 (&acc)[CG], const float* __r
     }
   }
 }
+// The same for RT row tiles of 16 that share every B fragment (a1 = a0 + one LDS tile): acc[t][c] += A_t . W_c.
+// A fragment then feeds RT MFMAs: half the weight traffic per multiply-add at RT = 2.
+template <int RT, int CG, int KB>
+__device__ __forceinline__ void mma_segment_rt(f32x4 (&acc)[RT][CG], const float* __restrict__ a, const int a_tile_stride,
+                                               const float4* const (&wf)[CG]) {
+  constexpr int D = RT * CG <= 2 ? 8 : 4;  // prefetch depth in k-blocks (registers: D * CG float4)
+  static_assert(KB % D == 0, "segment length");
+  float4 bq[D][CG];
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+#pragma unroll
+    for (int c = 0; c < CG; ++c) bq[d][c] = wf[c][(size_t)d * 64];
+#pragma unroll
+  for (int kb = 0; kb < KB; kb += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      float4 cur[CG];
+#pragma unroll
+      for (int c = 0; c < CG; ++c) cur[c] = bq[d][c];
+      if (kb + d + D < KB) {
+#pragma unroll
+        for (int c = 0; c < CG; ++c) bq[d][c] = wf[c][(size_t)(kb + d + D) * 64];
+      }
+      float av[RT][4];
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        const float* ap = a + t * a_tile_stride + (kb + d) * 16;
+        av[t][0] = ap[0]; av[t][1] = ap[4]; av[t][2] = ap[8]; av[t][3] = ap[12];
+      }
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int c = 0; c < CG; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][0], cur[c].x, acc[t][c], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int c = 0; c < CG; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][1], cur[c].y, acc[t][c], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int c = 0; c < CG; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][2], cur[c].z, acc[t][c], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int c = 0; c < CG; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][3], cur[c].w, acc[t][c], 0, 0, 0);
+    }
+  }
+}
 template <int CG, int KB>
 __device__ __forceinline__ void mma_segment(f32x4 (&acc)[CG], const float* __restrict__ a, const float4* __restrict__ wf,
                                             const size_t tile_stride) {
@@ -282,46 +330,54 @@ static __global__ __launch_bounds__(NTHR, 4) void block_b_kernel(const BlockBArg
 // a tick this replaces conv_gemm's 64-wide k-chunks (two barriers and an exposed load latency per 16 MFMA steps):
 // phone.rb (K = 1280): 65 -> 46 us per workgroup with two workgroups per CU.
 constexpr int kConvRowsLds = 2 * TILE + 32;
+template <int RT> constexpr int conv_rows_lds() { return 2 * RT * TILE + 32 * RT; }
 // COLS = output columns per workgroup (0 = all): a wide layer can be cut into column slabs, one workgroup each (grid y).
-template <class L, int COLS = 0>
+// RT = row tiles of 16 per workgroup: at 2 every weight fragment feeds two MFMAs (half the weight traffic per row).
+template <class L, int COLS = 0, int RT = 1>
 __device__ __forceinline__ void conv_rows_body(const ConvArgs& a, const int bx, const int by, float* __restrict__ lds) {
   constexpr int NCOL = COLS > 0 ? COLS : L::NOUT;
   static_assert(L::NOUT % NCOL == 0 && NCOL % 16 == 0, "column slabs");
   constexpr int K = L::K, P = L::P, NTL = NCOL / 16, CG = (NTL + NWAVE - 1) / NWAVE;
+  constexpr int ROWS = 16 * RT;
   const int nt_base = by * NTL;  // first column tile of this workgroup's slab
   constexpr int LAST = K - 256 * (P - 1);  // length of the last segment
   static_assert(K % 16 == 0 && LAST % 64 == 0 && L::NOUT % 16 == 0 && !L::GROUPED, "layer shape");
-  float* slot[2] = {lds, lds + TILE};
-  int* rb_ = reinterpret_cast<int*>(lds + 2 * TILE);  // [16] stream, [16] frame of each row
+  float* slot[2] = {lds, lds + RT * TILE};   // a slot = RT tiles of [16][256], one after the other
+  int* rb_ = reinterpret_cast<int*>(lds + 2 * RT * TILE);  // [ROWS] stream, [ROWS] frame of each row
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hop = stepc::step(a.hop);
   if (hop < 0) return;
   const int M = a.B * L::T;
-  if (tid < 16) {
-    const int m = bx * 16 + tid;
+  if (tid < ROWS) {
+    const int m = bx * ROWS + tid;
     rb_[tid] = m < M ? m / L::T : -1;
-    rb_[16 + tid] = m < M ? m % L::T : 0;
+    rb_[ROWS + tid] = m < M ? m % L::T : 0;
   }
   __syncthreads();
   const int pos_in = ring_pos(a.in, hop);
-  // this thread's two 16-byte pieces of a segment: rows r0 / r0 + 8, piece q
+  // this thread's 2 RT 16-byte pieces of a segment: rows r0 + 8 i, piece q
   const int q = tid & 63, r0 = tid >> 6;
-  const int b0 = rb_[r0], t0 = rb_[16 + r0], b1 = rb_[r0 + 8], t1 = rb_[16 + r0 + 8];
-  float4 nx[2];
+  int pb[2 * RT], pt[2 * RT];
+#pragma unroll
+  for (int i = 0; i < 2 * RT; ++i) { pb[i] = rb_[r0 + 8 * i]; pt[i] = rb_[ROWS + r0 + 8 * i]; }
+  float4 nx[2 * RT];
   auto load_seg = [&](int s) {
     const int kk = s * 256 + 4 * q;
     const bool live = kk < K;
     const int j = live ? kk / L::CIN : 0, c = live ? kk % L::CIN : 0;
-    nx[0] = nx[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live && b0 >= 0) nx[0] = *reinterpret_cast<const float4*>(ring_frame(a.in, b0, pos_in, (t0 + 1) * L::STRIDE - 1 - (L::KSZ - 1 - j) * L::DIL + a.rel_shift) + c);
-    if (live && b1 >= 0) nx[1] = *reinterpret_cast<const float4*>(ring_frame(a.in, b1, pos_in, (t1 + 1) * L::STRIDE - 1 - (L::KSZ - 1 - j) * L::DIL + a.rel_shift) + c);
+#pragma unroll
+    for (int i = 0; i < 2 * RT; ++i) {
+      nx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live && pb[i] >= 0)
+        nx[i] = *reinterpret_cast<const float4*>(ring_frame(a.in, pb[i], pos_in, (pt[i] + 1) * L::STRIDE - 1 - (L::KSZ - 1 - j) * L::DIL + a.rel_shift) + c);
+    }
   };
   auto store_seg = [&](float* dst) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2 * RT; ++i) {
       float4 v = nx[i];
       if constexpr (L::PRE == PRE_LRELU) { v.x = bsp::lrelu(v.x); v.y = bsp::lrelu(v.y); v.z = bsp::lrelu(v.z); v.w = bsp::lrelu(v.w); }
-      float2* d = reinterpret_cast<float2*>(dst + (r0 + 8 * i) * AS + 4 * q);
+      float2* d = reinterpret_cast<float2*>(dst + (r0 + 8 * i) * AS + 4 * q);   // (row 16 t + r of the slot = row r of its tile t: tiles are contiguous)
       d[0] = make_float2(v.x, v.y);
       d[1] = make_float2(v.z, v.w);
     }
@@ -335,24 +391,33 @@ __device__ __forceinline__ void conv_rows_body(const ConvArgs& a, const int bx, 
   load_seg(0);
   store_seg(slot[0]);
   __syncthreads();
-  f32x4 tot[CG];
+  f32x4 tot[RT][CG];
 #pragma unroll
   for (int s = 0; s < P; ++s) {
     if (s + 1 < P) load_seg(s + 1);
-    f32x4 acc[CG];
+    f32x4 acc[RT][CG];
 #pragma unroll
-    for (int c = 0; c < CG; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int c = 0; c < CG; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float4* wfs[CG];
 #pragma unroll
     for (int c = 0; c < CG; ++c) wfs[c] = wfc[c] + (size_t)s * 16 * 64;
     const float* ap = slot[s & 1] + (lane & 15) * AS + (lane >> 4);
-    if (s + 1 < P) mma_segment_p<CG, 16>(acc, ap, wfs);
-    else mma_segment_p<CG, LAST / 16>(acc, ap, wfs);
-#pragma unroll
-    for (int c = 0; c < CG; ++c) {
-      if (s == 0) tot[c] = acc[c];
-      else { tot[c][0] = tot[c][0] + acc[c][0]; tot[c][1] = tot[c][1] + acc[c][1]; tot[c][2] = tot[c][2] + acc[c][2]; tot[c][3] = tot[c][3] + acc[c][3]; }
+    if constexpr (RT == 1) {
+      if (s + 1 < P) mma_segment_p<CG, 16>(acc[0], ap, wfs);
+      else mma_segment_p<CG, LAST / 16>(acc[0], ap, wfs);
+    } else {
+      if (s + 1 < P) mma_segment_rt<RT, CG, 16>(acc, ap, TILE, wfs);
+      else mma_segment_rt<RT, CG, LAST / 16>(acc, ap, TILE, wfs);
     }
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int c = 0; c < CG; ++c) {
+        if (s == 0) tot[t][c] = acc[t][c];
+        else { tot[t][c][0] = tot[t][c][0] + acc[t][c][0]; tot[t][c][1] = tot[t][c][1] + acc[t][c][1]; tot[t][c][2] = tot[t][c][2] + acc[t][c][2]; tot[t][c][3] = tot[t][c][3] + acc[t][c][3]; }
+      }
     if (s + 1 < P) {
       store_seg(slot[(s + 1) & 1]);
       __syncthreads();
@@ -363,32 +428,34 @@ __device__ __forceinline__ void conv_rows_body(const ConvArgs& a, const int bx, 
   int pos_res = 0, R_res = 0;
   if constexpr (L::RES) { pos_res = ring_pos(a.res, hop); R_res = a.res.n * a.res.m; }
 #pragma unroll
-  for (int c = 0; c < CG; ++c) {
-    if (wave + NWAVE * c >= NTL) continue;
-    const int n = (nt_base + wave + NWAVE * c) * 16 + (lane & 15);
+  for (int t = 0; t < RT; ++t)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int r = (lane >> 4) * 4 + e;
-      const int b = rb_[r], t = rb_[16 + r];
-      if (b < 0) continue;
-      float v = tot[c][e];
-      if constexpr (L::EPI == EPI_BIAS) v = v + a.bias[n];
-      if constexpr (L::EPI == EPI_SCALE) v = v * a.scale;
-      if constexpr (L::EPI == EPI_ROWSCALE) v = v * a.rowscale[b * L::T + t];
-      if constexpr (L::ACT == ACT_GELU) v = bsp::gelu(v);
-      if constexpr (L::RES) v = a.res.base[((size_t)b * R_res + pos_res) * a.res.C + (size_t)t * L::NOUT + n] + v;
-      a.out.base[((size_t)b * R_out + pos_out) * a.out.C + (size_t)t * L::NOUT + n] = v;
+    for (int c = 0; c < CG; ++c) {
+      if (wave + NWAVE * c >= NTL) continue;
+      const int n = (nt_base + wave + NWAVE * c) * 16 + (lane & 15);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 16 * t + (lane >> 4) * 4 + e;
+        const int b = rb_[r], fr = rb_[ROWS + r];
+        if (b < 0) continue;
+        float v = tot[t][c][e];
+        if constexpr (L::EPI == EPI_BIAS) v = v + a.bias[n];
+        if constexpr (L::EPI == EPI_SCALE) v = v * a.scale;
+        if constexpr (L::EPI == EPI_ROWSCALE) v = v * a.rowscale[b * L::T + fr];
+        if constexpr (L::ACT == ACT_GELU) v = bsp::gelu(v);
+        if constexpr (L::RES) v = a.res.base[((size_t)b * R_res + pos_res) * a.res.C + (size_t)fr * L::NOUT + n] + v;
+        a.out.base[((size_t)b * R_out + pos_out) * a.out.C + (size_t)fr * L::NOUT + n] = v;
+      }
     }
-  }
 }
-template <class L, int COLS = 0>
+template <class L, int COLS = 0, int RT = 1>
 struct ConvRowsOp {
   using Args = ConvArgs;
   static constexpr int NTHR = rc::NTHR;
-  static constexpr int LDS_FLOATS = kConvRowsLds;
-  static inline dim3 grid(const ConvArgs& a) { return dim3((a.B * L::T + 15) / 16, COLS > 0 ? L::NOUT / COLS : 1); }
+  static constexpr int LDS_FLOATS = conv_rows_lds<RT>();
+  static inline dim3 grid(const ConvArgs& a) { return dim3((a.B * L::T + 16 * RT - 1) / (16 * RT), COLS > 0 ? L::NOUT / COLS : 1); }
   static inline bhip::LaunchInfo info(const char* name, const ConvArgs& a) { return ConvOp<L, TileCfg<1, 1, 1, 2, 1>>::info(name, a); }
-  __device__ static __forceinline__ void run(const ConvArgs& a, int bx, int by, float* lds) { conv_rows_body<L, COLS>(a, bx, by, lds); }
+  __device__ static __forceinline__ void run(const ConvArgs& a, int bx, int by, float* lds) { conv_rows_body<L, COLS, RT>(a, bx, by, lds); }
 };
 
 }  // namespace rc

@@ -56,29 +56,38 @@ using namespace bhip;
 using namespace wave_layers;
 // Tilings of the tick launch.  Everything runs in 512-thread workgroups, two per CU (<= 128 VGPRs, <= 78 KB of LDS): the
 // stream-stationary bodies (conditioned blocks as two row-local chains each, rowchain.hip.h; the fused upsampler tail)
-// and the remaining layers as rc::conv_rows_body: 16 rows x the layer's whole width per workgroup, the A operand streamed
-// through LDS one 256-long reduction segment at a time, weights prefetched four k-blocks ahead.  A tick wants MFMA density and occupancy, not the shortest dependent chain: per-layer launches with
-// 16x32 tiles and 128-wide k-chunks (the in-order chain's choice) measured 0.224 ms per tick at 256 streams, 16x64 tiles
-// in 256-thread workgroups 0.104, this layout see DESIGN.md.
+// and the remaining layers as rc::conv_rows_body: 32 rows (two MFMA row tiles sharing every weight fragment) x the layer's
+// width (the three 256-column layers with long reductions: 128-column slabs) per workgroup, the A operand streamed through
+// LDS one 256-long reduction segment at a time, weights prefetched four to eight k-blocks ahead.  A tick wants MFMA density
+// and occupancy, not the shortest dependent chain: per-layer launches with 16x32 tiles and 128-wide k-chunks (the in-order
+// chain's choice) measured 0.224 ms per tick at 256 streams, 16x64 tiles in 256-thread workgroups 0.104, this layout 0.078.
+// (A/B build switches; measured at 256 / 1024 streams: one row tile, full width 3.18 / 3.83 M frames/s; the three long
+//  layers as 32 rows x 128 columns 3.27 / 3.85; every conv_rows body with two row tiles 3.29 / 3.98)
 #ifndef TICK_RB_COLS
-#define TICK_RB_COLS 0
+#define TICK_RB_COLS 128
 #endif
 using PL = PhoneLayers<1>;
 using QL1 = PitchLayers<1>;
-using OpF2 = rc::ConvRowsOp<PL::F2>;
-using OpF3 = rc::ConvRowsOp<PL::F3>;
-using OpF4 = rc::ConvRowsOp<PL::F4, TICK_RB_COLS>;
-using OpF5 = rc::ConvRowsOp<PL::F5, TICK_RB_COLS>;
-using OpRB = rc::ConvRowsOp<PL::RBL, TICK_RB_COLS>;
+#ifndef TICK_MID_RT
+#define TICK_MID_RT 2
+#endif
+using OpF2 = rc::ConvRowsOp<PL::F2, 0, TICK_MID_RT>;
+using OpF3 = rc::ConvRowsOp<PL::F3, 0, TICK_MID_RT>;
+#ifndef TICK_RB_RT
+#define TICK_RB_RT 2
+#endif
+using OpF4 = rc::ConvRowsOp<PL::F4, TICK_RB_COLS, TICK_RB_RT>;
+using OpF5 = rc::ConvRowsOp<PL::F5, TICK_RB_COLS, TICK_RB_RT>;
+using OpRB = rc::ConvRowsOp<PL::RBL, TICK_RB_COLS, TICK_RB_RT>;
 using OpOUT = rc::ConvRowsOp<PL::OUTL>;
-using OpP1 = rc::ConvRowsOp<QL1::P1>;
+using OpP1 = rc::ConvRowsOp<QL1::P1, 0, TICK_MID_RT>;
 using OpP23 = rc::ConvRowsOp<QL1::P23>;
 using OpPOUT = rc::ConvRowsOp<QL1::POUT>;
 using OpINP = rc::ConvRowsOp<INP<1>>;
-using OpUP1 = rc::ConvRowsOp<UP<256, 128, 5, 1>, 128>;   // 640 columns: five slabs
-using OpRES1A = rc::ConvRowsOp<RES<128, 1, 5>>;
-using OpRES1B = rc::ConvRowsOp<RES<128, 3, 5>>;
-using OpUP2 = rc::ConvRowsOp<UP<128, 64, 4, 5>>;
+using OpUP1 = rc::ConvRowsOp<UP<256, 128, 5, 1>, 128, TICK_MID_RT>;   // 640 columns: five slabs
+using OpRES1A = rc::ConvRowsOp<RES<128, 1, 5>, 0, TICK_MID_RT>;
+using OpRES1B = rc::ConvRowsOp<RES<128, 3, 5>, 0, TICK_MID_RT>;
+using OpUP2 = rc::ConvRowsOp<UP<128, 64, 4, 5>, 0, TICK_MID_RT>;
 
 enum BodyType {
   T_F1, T_FFT, T_F2, T_F3, T_F4, T_F5, T_P1, T_RB, T_P23, T_POUT, T_HEAD, T_OUT, T_COND, T_INP, T_UP1, T_RES1A, T_RES1B, T_UP2,
