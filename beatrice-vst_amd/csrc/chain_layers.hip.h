@@ -6,6 +6,7 @@
 #include "engine.h"
 #include "fused_small.hip.h"
 #include "wave_tail.hip.h"
+#include "rowchain.hip.h"  // launch_auto's many-row branch
 
 namespace bhip {
 

@@ -453,8 +453,12 @@ using TL = TileCfg<BEATRICE_TL>;                              // 64 x 64 tile, s
 #include "gemv.hip.h"  // (needs everything above; defines gemv::launch)
 
 // Layers with few rows are bound by the dependent MFMA chain and by how many CUs get a tile: use
-// small tiles and one k-group per segment.  Layers with many rows are throughput-bound: 64 x 64.  A handful of rows
+// small tiles and one k-group per segment.  Layers with many rows are throughput-bound: 32 rows x the layer's width per
+// workgroup with the A operand streamed by reduction segment (rc::conv_rows_body), or 64 x 64 tiles where that body does not apply.  A handful of rows
 // (the 1-stream C-ABI): one FMA chain per lane instead of a mostly empty MFMA tile (gemv.hip.h).
+// many-row layers (defined in rowchain.hip.h, which every user of launch_auto includes through chain_layers.hip.h)
+template <class L>
+static inline void launch_many_rows(const char* name, const ConvArgs& a, hipStream_t s);
 template <class L>
 static inline void launch_auto(const char* name, const ConvArgs& a, hipStream_t s) {
   // (a single-shot variant that issues every load up front -- tools/microbench/lat_gemm.hip.h -- measured
@@ -469,7 +473,7 @@ static inline void launch_auto(const char* name, const ConvArgs& a, hipStream_t 
     if (!no_gemv && a.B <= 2) { gemv::launch<L>(name, a, s); return; }
   }
   if (a.B * L::T <= 2048) launch_conv<L, TLat<L>>(name, a, 0, s);
-  else launch_conv<L, TL>(name, a, 0, s);
+  else launch_many_rows<L>(name, a, s);
 }
 
 static inline ConvArgs conv_args(const Ring& in, const Ring& out, const float* w, const float* b, const int* hop, int B) {

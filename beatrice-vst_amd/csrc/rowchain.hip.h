@@ -17,6 +17,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "conv_gemm.hip.h"
 #include "kernels_misc.hip.h"
 #include "ring.h"
@@ -458,4 +460,35 @@ struct ConvRowsOp {
   __device__ static __forceinline__ void run(const ConvArgs& a, int bx, int by, float* lds) { conv_rows_body<L, COLS, RT>(a, bx, by, lds); }
 };
 
+// the same body as a launch of its own (the in-order chain at large batches, wave.hip)
+template <class L, int COLS, int RT>
+static __global__ __launch_bounds__(NTHR, 4) void conv_rows_kernel(const ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[conv_rows_lds<RT>()];
+  conv_rows_body<L, COLS, RT>(a, blockIdx.x, blockIdx.y, lds);
+}
+template <class L, int COLS = 0, int RT = 2>
+static inline void launch_conv_rows(const char* name, const ConvArgs& a, hipStream_t stream) {
+  using Op = ConvRowsOp<L, COLS, RT>;
+  bhip::launch_site(Op::info(name, a), stream, [&] { hipLaunchKernelGGL((conv_rows_kernel<L, COLS, RT>), Op::grid(a), dim3(NTHR), 0, stream, a); });
+}
+
 }  // namespace rc
+
+// launch_auto's many-row branch (conv_gemm.hip.h): 32 rows x the layer's width per workgroup where conv_rows_body applies
+// -- at 8192 streams 8-13 % faster per launch than the 64 x 64 tiling (wave.up2 74 -> 64 us, up1 63 -> 59, res1b 58 -> 54):
+// a weight fragment feeds two MFMAs and there is one barrier per 256-long segment instead of two per 64 columns of K.
+// BEATRICE_HIP_NO_CONVROWS=1: the 64 x 64 tiling (A/B measurements).
+template <class L>
+static inline void launch_many_rows(const char* name, const ConvArgs& a, hipStream_t s) {
+  constexpr int LAST = L::K - 256 * (L::P - 1);
+  constexpr bool ok = !L::GROUPED && L::K % 16 == 0 && LAST % 64 == 0 && L::NOUT % 16 == 0;
+  if constexpr (ok) {
+    static const bool off = std::getenv("BEATRICE_HIP_NO_CONVROWS") != nullptr;
+    if (!off) {
+      constexpr int COLS = (L::NOUT % 128 == 0 && (L::NOUT > 256 || (L::NOUT == 256 && L::K >= 768))) ? 128 : 0;
+      rc::launch_conv_rows<L, COLS, 2>(name, a, s);
+      return;
+    }
+  }
+  launch_conv<L, TL>(name, a, 0, s);
+}

@@ -126,8 +126,6 @@ static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t
   // layers; 3.40 -> 3.82 M frames/s); even at 2048.  BEATRICE_HIP_ROWCHAIN=1 / =0 forces one or the other (measurements, parity tests).
   static const char* const rc_env = std::getenv("BEATRICE_HIP_ROWCHAIN");
   const bool rowchain = rc_env != nullptr ? rc_env[0] != '0' : B >= 2048;
-  // (the upsampler convolutions as 16-row full-width workgroups, rc::conv_rows_body, measured the same as the 64 x 64 tiling
-  //  at 8192 streams: 56-75 vs 57-74 us per launch)
   for (int blk = 0; blk < B_NBLOCKS; ++blk) {
     if (!in_part(2 + blk)) continue;
     if (rowchain && H == 1) {
