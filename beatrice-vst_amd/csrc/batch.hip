@@ -555,8 +555,8 @@ bool tick_build_table(BeatriceBatch* b) {
   { const ConvArgs a = conv(ws.ya1, ws.yb1, ww.ra_w[0], ww.ra_b[0], pl.up1() + 1); tb->add<T_RES1A>(OpRES1A::info("wave.res1a", a), a, OpRES1A::grid(a), pl.up1() + 1, keep(7), 10); }
   { const ConvArgs a = conv(ws.yb1, ws.yc1, ww.rb_w[0], ww.rb_b[0], pl.up1() + 2); tb->add<T_RES1B>(OpRES1B::info("wave.res1b", a), a, OpRES1B::grid(a), pl.up1() + 2, keep(7), 10); }
   { const ConvArgs a = conv(ws.yc1, ws.ya2, ww.up_w[1], ww.up_b[1], pl.up1() + 3); tb->add<T_UP2>(OpUP2::info("wave.up2", a), a, OpUP2::grid(a), pl.up1() + 3, keep(7), 12); }
-  { const GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(Plan::PGRU), B, 0}; tb->add<T_PGRU>(GruOp<256, 256>::info("phone.gru", g), g, GruOp<256, 256>::grid(g), Plan::PGRU, keep(1), 7.6); }
-  { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, 0}; tb->add<T_QGRU>(GruOp<128, 128>::info("pitch.gru", g), g, GruOp<128, 128>::grid(g), Plan::QGRU, keep(1), 4.6); }
+  { const GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(Plan::PGRU), B, 0}; tb->add<T_PGRU>(GruOp<256, 256, TICK_GRU_RT>::info("phone.gru", g), g, GruOp<256, 256, TICK_GRU_RT>::grid(g), Plan::PGRU, keep(1), 7.6); }
+  { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, 0}; tb->add<T_QGRU>(GruOp<128, 128, TICK_GRU_RT>::info("pitch.gru", g), g, GruOp<128, 128, TICK_GRU_RT>::grid(g), Plan::QGRU, keep(1), 4.6); }
   for (int i = 0; i < 2; ++i) {
     const ConvArgs a = conv(qs.p[i], qs.p[i + 1], qw.p_w[i + 1], qw.p_b[i + 1], Plan::P2 + i);
     tb->add<T_P23>(OpP23::info("pitch.p23", a), a, OpP23::grid(a), Plan::P2 + i, keep(2), 8);

@@ -26,17 +26,18 @@ struct GruArgs {
   int t;  // hop within the step: x frame t, previous state = h frame t-1, new state -> h frame t
 };
 
-template <int IN, int H>
+// RT = row tiles of 16 streams per workgroup: at 2 the wavefront's weight fragments (held in registers for the whole
+// reduction) feed two independent MFMA chains -- half the weight traffic per stream and twice the work per dependent step.
+template <int IN, int H, int RT = 1>
 __device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, const int by, float* __restrict__ lds) {
-  constexpr int XS = IN + 2, HS = H + 2;  // lds: 16 * XS + 16 * HS + 6 * 256 floats
+  constexpr int XS = IN + 2, HS = H + 2;  // lds: 16 RT * XS + 16 RT * HS + RT * 6 * 256 floats
+  constexpr int ROWS = 16 * RT;
   float* xs = lds;
-  float* hs = lds + 16 * XS;
-  float* g6 = hs + 16 * HS;  // [src][gate][16][16]
+  float* hs = lds + ROWS * XS;
+  float* g6 = hs + ROWS * HS;  // [tile][src][gate][16][16]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int src = wave / 3, gate = wave % 3;
-  const int b0 = bx * 16, j0 = by * 16;
-  constexpr int K = IN > H ? IN : H;
-  (void)K;
+  const int b0 = bx * ROWS, j0 = by * 16;
 
   // B fragment of this wave: packed weights, column tile (gate*H + j0)/16, all k-blocks
   constexpr int KB_X = IN / 16, KB_H = H / 16;
@@ -51,14 +52,14 @@ __device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, c
   if (hop < 0) return;
   const int px = ring_pos(a.x, hop), ph = ring_pos(a.h, hop);
   // A tiles -> LDS
-  for (int e = tid; e < 16 * (IN / 4); e += 384) {
+  for (int e = tid; e < ROWS * (IN / 4); e += 384) {
     const int r = e / (IN / 4), q = e % (IN / 4);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (b0 + r < a.B) v = *reinterpret_cast<const float4*>(ring_frame(a.x, b0 + r, px, a.t) + 4 * q);
     float2* d = reinterpret_cast<float2*>(&xs[r * XS + 4 * q]);
     d[0] = make_float2(v.x, v.y); d[1] = make_float2(v.z, v.w);
   }
-  for (int e = tid; e < 16 * (H / 4); e += 384) {
+  for (int e = tid; e < ROWS * (H / 4); e += 384) {
     const int r = e / (H / 4), q = e % (H / 4);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (b0 + r < a.B) v = *reinterpret_cast<const float4*>(ring_frame(a.h, b0 + r, ph, a.t - 1) + 4 * q);
@@ -66,14 +67,17 @@ __device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, c
     d[0] = make_float2(v.x, v.y); d[1] = make_float2(v.z, v.w);
   }
   __syncthreads();
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (src == 0) {
     const float* ap = xs + (lane & 15) * XS + (lane >> 4);
 #pragma unroll
     for (int ks = 0; ks < IN / 4; ++ks) {
       const float4 f = bf[ks >> 2];
       const float bv = (ks & 3) == 0 ? f.x : ((ks & 3) == 1 ? f.y : ((ks & 3) == 2 ? f.z : f.w));
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * ks], bv, acc, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[t * 16 * XS + 4 * ks], bv, acc[t], 0, 0, 0);
     }
   } else {
     const float* ap = hs + (lane & 15) * HS + (lane >> 4);
@@ -81,20 +85,24 @@ __device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, c
     for (int ks = 0; ks < H / 4; ++ks) {
       const float4 f = bf[ks >> 2];
       const float bv = (ks & 3) == 0 ? f.x : ((ks & 3) == 1 ? f.y : ((ks & 3) == 2 ? f.z : f.w));
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * ks], bv, acc, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[t * 16 * HS + 4 * ks], bv, acc[t], 0, 0, 0);
     }
   }
   {
     const float bias = (src == 0 ? a.bih : a.bhh)[gate * H + j0 + (lane & 15)];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) g6[(wave * 16 + (lane >> 4) * 4 + e) * 16 + (lane & 15)] = acc[e] + bias;
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g6[t * 6 * 256 + (wave * 16 + (lane >> 4) * 4 + e) * 16 + (lane & 15)] = acc[t][e] + bias;
   }
   __syncthreads();
-  if (tid < 256) {
-    const int r = tid >> 4, j = tid & 15;
+  for (int idx = tid; idx < ROWS * 16; idx += 384) {
+    const int r = idx >> 4, j = idx & 15, t = r >> 4, rr_ = r & 15;
     if (b0 + r < a.B) {
-      const float gi_r = g6[(0 * 16 + r) * 16 + j], gi_z = g6[(1 * 16 + r) * 16 + j], gi_n = g6[(2 * 16 + r) * 16 + j];
-      const float gh_r = g6[(3 * 16 + r) * 16 + j], gh_z = g6[(4 * 16 + r) * 16 + j], gh_n = g6[(5 * 16 + r) * 16 + j];
+      const float* g = g6 + t * 6 * 256;
+      const float gi_r = g[(0 * 16 + rr_) * 16 + j], gi_z = g[(1 * 16 + rr_) * 16 + j], gi_n = g[(2 * 16 + rr_) * 16 + j];
+      const float gh_r = g[(3 * 16 + rr_) * 16 + j], gh_z = g[(4 * 16 + rr_) * 16 + j], gh_n = g[(5 * 16 + rr_) * 16 + j];
       const float rr = bsp::sigmoid(gi_r + gh_r);
       const float zz = bsp::sigmoid(gi_z + gh_z);
       const float nn = bsp::tanh(bsp::fma(rr, gh_n, gi_n));
@@ -104,24 +112,27 @@ __device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, c
   }
 }
 
-template <int IN, int H>
+template <int IN, int H, int RT = 1>
 static __global__ __launch_bounds__(384) void gru_fused_kernel(const GruArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[16 * (IN + 2) + 16 * (H + 2) + 6 * 256];
-  gru_fused_body<IN, H>(a, blockIdx.x, blockIdx.y, lds);
+  __shared__ __attribute__((aligned(16))) float lds[RT * (16 * (IN + 2) + 16 * (H + 2) + 6 * 256)];
+  gru_fused_body<IN, H, RT>(a, blockIdx.x, blockIdx.y, lds);
 }
 
-template <int IN, int H>
+template <int IN, int H, int RT = 1>
 struct GruOp {
   using Args = GruArgs;
   static constexpr int NTHR = 384;
-  static constexpr int LDS_FLOATS = 16 * (IN + 2) + 16 * (H + 2) + 6 * 256;
-  static inline dim3 grid(const GruArgs& a) { return dim3((a.B + 15) / 16, H / 16); }
+  static constexpr int LDS_FLOATS = RT * (16 * (IN + 2) + 16 * (H + 2) + 6 * 256);
+  static inline dim3 grid(const GruArgs& a) { return dim3((a.B + 16 * RT - 1) / (16 * RT), H / 16); }
   static inline bhip::LaunchInfo info(const char* name, const GruArgs& a) {
     return bhip::LaunchInfo{name, 2.0 * a.B * (IN + H) * 3.0 * H, 4.0 * ((IN + H) * 3.0 * H + a.B * (IN + 2.0 * H))};
   }
-  __device__ static __forceinline__ void run(const GruArgs& a, int bx, int by, float* lds) { gru_fused_body<IN, H>(a, bx, by, lds); }
+  __device__ static __forceinline__ void run(const GruArgs& a, int bx, int by, float* lds) { gru_fused_body<IN, H, RT>(a, bx, by, lds); }
 };
 
+// (RT = 2 as a launch of its own measured slower at 8192 streams -- 140 vs 113 us: 78 KB of LDS leave two workgroups
+//  per CU where the one-tile form has four; inside the tick launch, where two per CU is the rule anyway, it is the
+//  better one: 1024 streams 3.98 -> 4.04 M frames/s)
 template <int IN, int H>
 static inline void launch_gru(const char* name, const GruArgs& a, hipStream_t stream) {
   const dim3 grid = GruOp<IN, H>::grid(a);

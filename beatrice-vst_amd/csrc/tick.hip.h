@@ -68,6 +68,9 @@ using namespace wave_layers;
 #endif
 using PL = PhoneLayers<1>;
 using QL1 = PitchLayers<1>;
+#ifndef TICK_GRU_RT
+#define TICK_GRU_RT 2
+#endif
 #ifndef TICK_MID_RT
 #define TICK_MID_RT 2
 #endif
@@ -97,7 +100,7 @@ enum BodyType {
     fuse::Many<F1Op2, 1>, fuse::Many<FftOp2, 1>, fuse::Many<OpF2, 1>, fuse::Many<OpF3, 1>, fuse::Many<OpF4, 1>, fuse::Many<OpF5, 1>, \
     fuse::Many<OpP1, 1>, fuse::Many<OpRB, 4>, fuse::Many<OpP23, 2>, fuse::Many<OpPOUT, 1>, fuse::Many<HeadOp8, 1>,                  \
     fuse::Many<OpOUT, 1>, fuse::Many<CondOp2, 1>, fuse::Many<OpINP, 1>, fuse::Many<OpUP1, 1>, fuse::Many<OpRES1A, 1>,               \
-    fuse::Many<OpRES1B, 1>, fuse::Many<OpUP2, 1>, fuse::Many<GruOp<128, 128>, 1>, fuse::Many<GruOp<256, 256>, 1>,                  \
+    fuse::Many<OpRES1B, 1>, fuse::Many<OpUP2, 1>, fuse::Many<GruOp<128, 128, TICK_GRU_RT>, 1>, fuse::Many<GruOp<256, 256, TICK_GRU_RT>, 1>,                  \
     fuse::Many<VqOp, 1>, fuse::Many<TailOp<1>, 1>, fuse::Many<rc::BlockAOp<1>, 1>, fuse::Many<rc::BlockAOp<2>, 1>,                 \
     fuse::Many<rc::BlockAOp<4>, 1>, fuse::Many<rc::BlockAOp<8>, 1>, fuse::Many<rc::BlockBOp, 4>
 using Tab = fuse::Table<TICK_TYPES>;
