@@ -522,7 +522,15 @@ bool tick_build_table(BeatriceBatch* b) {
   auto hp = [&](int) -> const int* { return nullptr; };
   auto conv = [&](const Ring& in, const Ring& out, const float* w, const float* bias, int stage) { return conv_args(in, out, w, bias, hp(stage), B); };
   // (workgroups are dispatched in this order: the longest-running bodies first)
-  // ---- conditioned blocks: two row-local chains each
+  // ---- longest workgroups first (measured, two per CU): f5 48 us, p1 46, f4 45, rb 42, block halves 41 / 38, tail 36
+  { const ConvArgs a = conv(ps.f[3], ps.f[4], pw.f_w[3], pw.f_b[3], Plan::F5); tb->add<T_F5>(OpF5::info("phone.f5", a), a, OpF5::grid(a), Plan::F5, keep(6), 47); }
+  { const ConvArgs a = conv(qs.spec, qs.p[0], qw.p_w[0], qw.p_b[0], Plan::P1); tb->add<T_P1>(OpP1::info("pitch.p1", a), a, OpP1::grid(a), Plan::P1, keep(2), 34.5); }
+  { const ConvArgs a = conv(ps.f[2], ps.f[3], pw.f_w[2], pw.f_b[2], Plan::F4); tb->add<T_F4>(OpF4::info("phone.f4", a), a, OpF4::grid(a), Plan::F4, keep(6), 37.5); }
+  for (int i = 0; i < 4; ++i) {
+    const ConvArgs a = conv(i == 0 ? ps.f[4] : ps.rb[i - 1], ps.rb[i], pw.rb_w[i], pw.rb_b[i], Plan::RB0 + i);
+    tb->add<T_RB>(OpRB::info("phone.rb", a), a, OpRB::grid(a), Plan::RB0 + i, keep(6), 46);
+  }
+  // conditioned blocks: two row-local chains each
   for (int blk = 0; blk < B_NBLOCKS; ++blk) {
     const WaveState::Scratch& sc = ws.scr[blk];  // one scratch set per block: all four blocks are in flight at once
     const int s0 = pl.blk(blk);
@@ -540,34 +548,27 @@ bool tick_build_table(BeatriceBatch* b) {
       default: tb->add<T_BLKA8>(rc::BlockAOp<8>::info(aa), aa, rc::BlockAOp<8>::grid(aa), pl.blk(blk), keep(5), 41); break;
     }
   }
-  // ---- the layers with long reductions, then the fused tail
-  { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], pl.up1()); tb->add<T_UP1>(OpUP1::info("wave.up1", a), a, OpUP1::grid(a), pl.up1(), keep(7), 36); }
-  for (int i = 0; i < 4; ++i) {
-    const ConvArgs a = conv(i == 0 ? ps.f[4] : ps.rb[i - 1], ps.rb[i], pw.rb_w[i], pw.rb_b[i], Plan::RB0 + i);
-    tb->add<T_RB>(OpRB::info("phone.rb", a), a, OpRB::grid(a), Plan::RB0 + i, keep(6), 46);
-  }
-  { const ConvArgs a = conv(qs.spec, qs.p[0], qw.p_w[0], qw.p_b[0], Plan::P1); tb->add<T_P1>(OpP1::info("pitch.p1", a), a, OpP1::grid(a), Plan::P1, keep(2), 34.5); }
-  { const ConvArgs a = conv(ps.f[2], ps.f[3], pw.f_w[2], pw.f_b[2], Plan::F4); tb->add<T_F4>(OpF4::info("phone.f4", a), a, OpF4::grid(a), Plan::F4, keep(6), 37.5); }
-  { const ConvArgs a = conv(ps.f[3], ps.f[4], pw.f_w[3], pw.f_b[3], Plan::F5); tb->add<T_F5>(OpF5::info("phone.f5", a), a, OpF5::grid(a), Plan::F5, keep(6), 47); }
   { TailArgs ta = tail_args(ww, ws); ta.hop = hp(pl.tail()); tb->add<T_TAIL>(tail_info(ws), ta, dim3(B, 1), pl.tail(), keep(4), 41, true); }
-  { const ConvArgs a = conv(ps.f[0], ps.f[1], pw.f_w[0], pw.f_b[0], Plan::F2); tb->add<T_F2>(OpF2::info("phone.f2", a), a, OpF2::grid(a), Plan::F2, keep(6), 10); }
+  // ---- everything else, longest workgroups first (they start when the heavy ones above leave their slots)
   { const ConvArgs a = conv(ps.f[1], ps.f[2], pw.f_w[1], pw.f_b[1], Plan::F3); tb->add<T_F3>(OpF3::info("phone.f3", a), a, OpF3::grid(a), Plan::F3, keep(6), 18); }
-  { const ConvArgs a = conv(ws.ya1, ws.yb1, ww.ra_w[0], ww.ra_b[0], pl.up1() + 1); tb->add<T_RES1A>(OpRES1A::info("wave.res1a", a), a, OpRES1A::grid(a), pl.up1() + 1, keep(7), 10); }
+  { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], pl.up1()); tb->add<T_UP1>(OpUP1::info("wave.up1", a), a, OpUP1::grid(a), pl.up1(), keep(7), 36); }
   { const ConvArgs a = conv(ws.yb1, ws.yc1, ww.rb_w[0], ww.rb_b[0], pl.up1() + 2); tb->add<T_RES1B>(OpRES1B::info("wave.res1b", a), a, OpRES1B::grid(a), pl.up1() + 2, keep(7), 10); }
+  { const ConvArgs a = conv(ws.ya1, ws.yb1, ww.ra_w[0], ww.ra_b[0], pl.up1() + 1); tb->add<T_RES1A>(OpRES1A::info("wave.res1a", a), a, OpRES1A::grid(a), pl.up1() + 1, keep(7), 10); }
   { const ConvArgs a = conv(ws.yc1, ws.ya2, ww.up_w[1], ww.up_b[1], pl.up1() + 3); tb->add<T_UP2>(OpUP2::info("wave.up2", a), a, OpUP2::grid(a), pl.up1() + 3, keep(7), 12); }
+  { const ConvArgs a = conv(ps.f[0], ps.f[1], pw.f_w[0], pw.f_b[0], Plan::F2); tb->add<T_F2>(OpF2::info("phone.f2", a), a, OpF2::grid(a), Plan::F2, keep(6), 10); }
   { const GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(Plan::PGRU), B, 0}; tb->add<T_PGRU>(GruOp<256, 256, TICK_GRU_RT>::info("phone.gru", g), g, GruOp<256, 256, TICK_GRU_RT>::grid(g), Plan::PGRU, keep(1), 7.6); }
-  { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, 0}; tb->add<T_QGRU>(GruOp<128, 128, TICK_GRU_RT>::info("pitch.gru", g), g, GruOp<128, 128, TICK_GRU_RT>::grid(g), Plan::QGRU, keep(1), 4.6); }
+  { const ConvArgs a = conv(qs.h, qs.logits, qw.out_w, qw.out_b, Plan::POUT); tb->add<T_POUT>(OpPOUT::info("pitch.out", a), a, OpPOUT::grid(a), Plan::POUT, keep(2), 9.4); }
   for (int i = 0; i < 2; ++i) {
     const ConvArgs a = conv(qs.p[i], qs.p[i + 1], qw.p_w[i + 1], qw.p_b[i + 1], Plan::P2 + i);
     tb->add<T_P23>(OpP23::info("pitch.p23", a), a, OpP23::grid(a), Plan::P2 + i, keep(2), 8);
   }
-  { const ConvArgs a = conv(qs.h, qs.logits, qw.out_w, qw.out_b, Plan::POUT); tb->add<T_POUT>(OpPOUT::info("pitch.out", a), a, OpPOUT::grid(a), Plan::POUT, keep(2), 9.4); }
-  { const ConvArgs a = conv(ps.h, phone_out_ring(ps), pw.out_w, pw.out_b, Plan::OUT); tb->add<T_OUT>(OpOUT::info("phone.out", a), a, OpOUT::grid(a), Plan::OUT, keep(3), 6); }
   { const Ring phone_in{ws.d_phone, B_PHONE_CH, 1, ws.front_slots}; ConvArgs a = conv(phone_in, ws.x[0], ww.inp_w, ww.inp_b, Plan::INP); a.res = ws.e; tb->add<T_INP>(OpINP::info("wave.inp", a), a, OpINP::grid(a), Plan::INP, keep(3), 7.7); }
-  { const VqArgs a{1, ps.raw, phone_vector_ring(ps), hp(Plan::VQ), ps.d_cbT, ps.d_cnorm, ps.d_vqk}; tb->add<T_VQ>(LaunchInfo{"phone.vq", 0, 4.0 * B * 256}, a, dim3(B, 1), Plan::VQ, !ps.skip_vq, 6.0, true); }
-  { F1Args a = f1_args(pw, ps); a.hop = hp(Plan::F1); a.hop_publish = nullptr; a.hop_publish_wave = nullptr; tb->add<T_F1>(f1_info(ps), F1Args2{a, B}, dim3((B + 1) / 2, 1), Plan::F1, keep(0), 4.5); }
+  { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, 0}; tb->add<T_QGRU>(GruOp<128, 128, TICK_GRU_RT>::info("pitch.gru", g), g, GruOp<128, 128, TICK_GRU_RT>::grid(g), Plan::QGRU, keep(1), 4.6); }
   { FftArgs a = fft_args(qw, qs); a.hop = hp(Plan::FFT); tb->add<T_FFT>(fft_info(qs), FftArgs2{a, B}, dim3((B + 1) / 2, 1), Plan::FFT, keep(0), 6); }
+  { const ConvArgs a = conv(ps.h, phone_out_ring(ps), pw.out_w, pw.out_b, Plan::OUT); tb->add<T_OUT>(OpOUT::info("phone.out", a), a, OpOUT::grid(a), Plan::OUT, keep(3), 6); }
+  { const VqArgs a{1, ps.raw, phone_vector_ring(ps), hp(Plan::VQ), ps.d_cbT, ps.d_cnorm, ps.d_vqk}; tb->add<T_VQ>(LaunchInfo{"phone.vq", 0, 4.0 * B * 256}, a, dim3(B, 1), Plan::VQ, !ps.skip_vq, 6.0, true); }
   { PitchHeadArgs a = head_args(qw, qs); a.hop = hp(Plan::HEAD); tb->add<T_HEAD>(head_info(qs), a, dim3((B + 7) / 8, 1), Plan::HEAD, keep(0), 4.7); }
+  { F1Args a = f1_args(pw, ps); a.hop = hp(Plan::F1); a.hop_publish = nullptr; a.hop_publish_wave = nullptr; tb->add<T_F1>(f1_info(ps), F1Args2{a, B}, dim3((B + 1) / 2, 1), Plan::F1, keep(0), 4.5); }
   { CondArgs a = cond_args(ww, ws); a.hop = hp(Plan::COND); a.hop_next_out = nullptr; tb->add<T_COND>(cond_info(ws), a, dim3((B + 1) / 2, 1), Plan::COND, keep(0), 1.3); }
   if (!tb->ok) return false;
   // XCD-aware placement (bodies with many weights pinned to one XCD each, so that the weights stay in that L2) was
