@@ -75,7 +75,12 @@ using QL1 = PitchLayers<1>;
 #define TICK_MID_RT 2
 #endif
 using OpF2 = rc::ConvRowsOp<PL::F2, 0, TICK_MID_RT>;
-using OpF3 = rc::ConvRowsOp<PL::F3, 0, TICK_MID_RT>;
+// (phone.f3 with ONE row tile: it runs in the launch's second round, where short workgroups matter more than traffic --
+//  32 workgroups of 28 us end the launch later than 64 of 18 us: 3.45 -> 3.55 M frames/s at 256 streams)
+#ifndef TICK_F3_RT
+#define TICK_F3_RT 1
+#endif
+using OpF3 = rc::ConvRowsOp<PL::F3, 0, TICK_F3_RT>;
 #ifndef TICK_RB_RT
 #define TICK_RB_RT 2
 #endif

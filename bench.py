@@ -347,7 +347,7 @@ def main():
     ap.add_argument("--copy-io", action="store_true",
                     help="device-to-device copy of each hop into / out of the library's own buffers instead of "
                          "binding the resident audio buffers (BeatriceBatch_BindResidentIO)")
-    ap.add_argument("--device-warm-ms", type=float, default=250.0,
+    ap.add_argument("--device-warm-ms", type=float, default=1000.0,
                     help="milliseconds of unrelated GPU work (torch matmuls) before the warm-up steps, so that a run of a few milliseconds "
                          "does not execute at an idle device's clocks (+5 %% at 20 and at 300 steps); 0 = off; stated in config")
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / B=1 latency / kernel profile")
