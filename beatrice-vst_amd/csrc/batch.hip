@@ -1532,8 +1532,8 @@ int BeatriceBatch_EnableGraph(BeatriceBatch* b, int enable) {
 // and the one that writes samples (the tail) go over PCIe themselves -- 160 + 240 KB per tick at 256 streams, spread over
 // hundreds of workgroups that have plenty to overlap it with -- so a call is: memcpy the hop into its slot, launch the
 // tick, record an event, and hand back the step whose tick finished at least two ticks ago (the host then never waits
-// for the device's current work, and two ticks stay queued).  3.07 M frames/s from and to host memory at 256 streams
-// against 3.2 M with resident device buffers.  BEATRICE_HIP_HS_COPIES=1 (A/B): device slots with an upload and a
+// for the device's current work, and two ticks stay queued).  3.07-3.16 M frames/s from and to host memory at 256 streams
+// against 3.2-3.55 M with resident device buffers (before / after the last changes of the tick bodies).  BEATRICE_HIP_HS_COPIES=1 (A/B): device slots with an upload and a
 // download stream beside the ticks instead -- 2.36 M: copy commands and cross-stream waits cost more than PCIe loads.
 static void host_stream_fetch(BeatriceBatch* b) {  // enqueue the download of every step the ticks run so far have completed
   BeatriceBatch::HostStream& h = b->hs;
