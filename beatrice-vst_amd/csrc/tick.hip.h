@@ -88,7 +88,10 @@ using OpF4 = rc::ConvRowsOp<PL::F4, TICK_RB_COLS, TICK_RB_RT>;
 using OpF5 = rc::ConvRowsOp<PL::F5, TICK_RB_COLS, TICK_RB_RT>;
 using OpRB = rc::ConvRowsOp<PL::RBL, TICK_RB_COLS, TICK_RB_RT>;
 using OpOUT = rc::ConvRowsOp<PL::OUTL>;
-using OpP1 = rc::ConvRowsOp<QL1::P1, 0, TICK_MID_RT>;
+#ifndef TICK_P1_RT
+#define TICK_P1_RT TICK_MID_RT
+#endif
+using OpP1 = rc::ConvRowsOp<QL1::P1, 0, TICK_P1_RT>;
 using OpP23 = rc::ConvRowsOp<QL1::P23>;
 using OpPOUT = rc::ConvRowsOp<QL1::POUT>;
 using OpINP = rc::ConvRowsOp<INP<1>>;
