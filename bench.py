@@ -353,8 +353,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / B=1 latency / kernel profile")
     ap.add_argument("--total-streams", type=int, default=None,
                     help="strong scaling: this many streams in total, split evenly over the GPUs (default: --streams per GPU, weak scaling)")
-    ap.add_argument("--placement", choices=("round-robin", "speaker-affine"), default="round-robin",
-                    help="configs[3]: which speakers a rank's streams start on (speaker-affine: speaker mod world == rank)")
+    ap.add_argument("--placement", choices=("round-robin", "speaker-affine"), default=None,
+                    help="configs[3]: which speakers a rank's streams start on (speaker-affine: speaker mod world == rank; the default "
+                         "when there are several ranks and at least as many speakers, SURVEY.md 8e; round-robin otherwise)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="start the ranks, run one all-reduce over gloo and exit (CPU check that --gpus N launches N ranks)")
     a = ap.parse_args()
@@ -435,6 +436,8 @@ def main():
         batch.apply_defaults()
     if a.no_graph:
         product.BeatriceBatch_EnableGraph(batch.h, 0)
+    if a.placement is None:
+        a.placement = "speaker-affine" if (world > 1 and a.speakers >= world) else "round-robin"
     if a.placement == "speaker-affine":
         current_speaker = [shard.affine_speaker(rank, world, s, a.speakers) for s in range(B)]
     else:  # global stream index modulo the table size
