@@ -178,6 +178,9 @@ struct BeatriceBatch {
   int* d_hop_next = nullptr;  // {step counter, resident-I/O slot}, double-buffered: first kernels read it, the last one writes it
   float* own_d_out = nullptr; // the waveform module's output buffer while a resident output buffer is bound
   int io_slots = 0;           // > 0: resident I/O bound (BeatriceBatch_BindResidentIO)
+  bool io_mapped = false;     // BeatriceBatch_ConvertFrames: the chain reads the pinned input mirror and writes the pinned output mirror itself
+  bool want_mapped = false;   // (set around the step ConvertFrames enqueues)
+  float* dev_d_out = nullptr; // the waveform module's device output buffer while io_mapped
   int io_host = 0;            // mirror of the device's resident-I/O slot counter
   int last_hop = 0;           // step counter of the last enqueued step (selects the slot of the pitch head's outputs)
   tick::State tk;             // tick pipelining (tick.hip.h)
@@ -452,8 +455,30 @@ void draw_codebooks(BeatriceBatch* b) {
 }
 
 bool tick_run(BeatriceBatch* b, bool feeding);
+// Host-buffer steps (BeatriceBatch_ConvertFrames) let the kernels read the pinned input mirror and write the pinned output
+// mirror directly: two copy commands around the chain cost a switch to the copy engine and back each (0.35 -> 0.31 ms per
+// step at 256 streams); every other kind of step uses the device buffers.
+bool set_io_mapped(BeatriceBatch* b, bool on) {
+  if (on == b->io_mapped) return true;
+  if (on && (b->io_slots > 0 || b->tk.on || b->pipelined)) return true;   // not applicable: ConvertFrames copies as before
+  if (!sync_all(b)) return false;
+  drop_graph(b);  // kernel arguments change
+  if (on) {
+    b->dev_d_out = b->wave.d_out;
+    b->phone.d_in = b->pitch.d_in = b->h_in;
+    b->wave.d_out = b->h_out;
+  } else {
+    b->phone.d_in = b->pitch.d_in = b->d_in;
+    b->wave.d_out = b->dev_d_out;
+    b->dev_d_out = nullptr;
+  }
+  b->io_mapped = on;
+  return true;
+}
+
 bool step_device(BeatriceBatch* b, const float* d_in, float* d_out) {
   if (b->io_slots > 0 && (d_in || d_out)) return false;  // resident I/O is bound: the step reads and writes its slots
+  if (b->io_mapped != b->want_mapped && !set_io_mapped(b, b->want_mapped)) return false;
   if (b->tk.on) return tick_run(b, true);
   advance_kv(b);
   draw_codebooks(b);
@@ -1022,6 +1047,7 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   if (b->r48.d_in16) (void)hipFree(b->r48.d_in16);
   if (b->r48.d_out24) (void)hipFree(b->r48.d_out24);
   if (b->own_d_out) { b->wave.d_out = b->own_d_out; b->own_d_out = nullptr; }
+  if (b->io_mapped) { b->wave.d_out = b->dev_d_out; b->phone.d_in = b->pitch.d_in = b->d_in; b->io_mapped = false; }  // (the modules free what they allocated)
   if (b->module_owned[0]) {  // hand the modules their own arrays back so that destroy() frees what it allocated
     void** keep = b->module_owned;
     auto swap_out = [&keep](auto*& member) { member = static_cast<std::remove_reference_t<decltype(member)>>(*keep++); };
@@ -1283,7 +1309,7 @@ int BeatriceBatch_BindResidentIO(BeatriceBatch* b, const float* d_in, float* d_o
   const bool bind = d_in != nullptr || d_out != nullptr;
   if (bind && (!d_in || !d_out || n_slots < 1)) return -1;
   if (b->tk.on) return -1;  // leave tick mode first
-  if (!sync_all(b)) return -2;
+  if (!set_io_mapped(b, false) || !sync_all(b)) return -2;
   b->io_host = 0;
   drop_graph(b);  // kernel arguments change
   if (b->own_d_out) { b->wave.d_out = b->own_d_out; b->own_d_out = nullptr; }
@@ -1306,10 +1332,13 @@ int BeatriceBatch_ConvertFrames(BeatriceBatch* b, const float* in, float* out) {
   if (!b || !b->ok) { if (b && out) std::memset(out, 0, sizeof(float) * b->B * b->H * B_OUT_HOP); return -2; }
   if (b->io_slots > 0 || b->tk.on) return -1;  // resident I/O is bound
   const size_t n_in = (size_t)b->B * b->H * B_IN_HOP, n_out = (size_t)b->B * b->H * B_OUT_HOP;
+  b->want_mapped = true;
+  bool ok = set_io_mapped(b, true);
   std::memcpy(b->h_in, in, sizeof(float) * n_in);
-  bool ok = hip_ok(hipMemcpyAsync(b->d_in, b->h_in, sizeof(float) * n_in, hipMemcpyHostToDevice, b->stream), "in");
+  if (!b->io_mapped) ok = ok && hip_ok(hipMemcpyAsync(b->d_in, b->h_in, sizeof(float) * n_in, hipMemcpyHostToDevice, b->stream), "in");
   ok = ok && step_device(b, nullptr, nullptr);
-  ok = ok && hip_ok(hipMemcpyAsync(b->h_out, b->wave.d_out, sizeof(float) * n_out, hipMemcpyDeviceToHost, wave_stream(b)), "out");
+  if (!b->io_mapped) ok = ok && hip_ok(hipMemcpyAsync(b->h_out, b->wave.d_out, sizeof(float) * n_out, hipMemcpyDeviceToHost, wave_stream(b)), "out");
+  b->want_mapped = false;
   ok = sync_all(b) && ok;
   if (ok) std::memcpy(out, b->h_out, sizeof(float) * n_out);
   else std::memset(out, 0, sizeof(float) * n_out);
@@ -1720,7 +1749,7 @@ int BeatriceBatch_TimeTickLaunch(BeatriceBatch* b, int ticks, float* us_per_laun
 int BeatriceBatch_EnablePipelining(BeatriceBatch* b, int enable) {
   if (!b || !b->ok) return -2;
   if (b->tk.on) return -1;
-  if (!sync_all(b)) return -2;
+  if (!set_io_mapped(b, false) || !sync_all(b)) return -2;
   if (enable < 0 || enable > BeatriceBatch::kMaxStages) return -1;
   drop_graph(b);  // stages are captured on the streams they will run on
   set_plan(b, enable == 1 ? 2 : enable);  // 1 = the default depth
@@ -1740,7 +1769,7 @@ int BeatriceBatch_Prepare(BeatriceBatch* b) {
   return ok ? 0 : -2;
 }
 float* BeatriceBatch_DeviceInput(BeatriceBatch* b) { return b && b->ok ? b->d_in : nullptr; }
-float* BeatriceBatch_DeviceOutput(BeatriceBatch* b) { return b && b->ok ? b->wave.d_out : nullptr; }
+float* BeatriceBatch_DeviceOutput(BeatriceBatch* b) { return b && b->ok && set_io_mapped(b, false) ? b->wave.d_out : nullptr; }
 
 int BeatriceBatch_GetIntermediates(BeatriceBatch* b, float* phone, int* q_raw, int* q, float* feat) {
   if (!b || !b->ok) return -2;
