@@ -356,6 +356,9 @@ def main():
     ap.add_argument("--placement", choices=("round-robin", "speaker-affine"), default=None,
                     help="configs[3]: which speakers a rank's streams start on (speaker-affine: speaker mod world == rank; the default "
                          "when there are several ranks and at least as many speakers, SURVEY.md 8e; round-robin otherwise)")
+    ap.add_argument("--collectives", choices=("nccl", "gloo"), default="nccl",
+                    help="nccl = RCCL over xGMI, one GPU per rank (the product path); gloo = test hook: the same flow with several ranks "
+                         "sharing the GPUs of a smaller box (tests/test_gpu_two_ranks_load_path.py)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="start the ranks, run one all-reduce over gloo and exit (CPU check that --gpus N launches N ranks)")
     a = ap.parse_args()
@@ -390,9 +393,14 @@ def main():
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if a.collectives == "gloo":  # test hook: several ranks on however many GPUs the box has (RCCL wants one device per rank)
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.collectives == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     bv = load_pkg()
     product = bv.bind_batch(bv.load_product())

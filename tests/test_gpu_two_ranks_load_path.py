@@ -96,3 +96,21 @@ def test_two_ranks_share_packed_blobs_and_tables_in_place(bv, product, model_dir
         assert moved > 20e6 and tmoved > 1e6      # the packed parameters (22 MB) and the raw tables really travelled
         covered += hi - lo
     assert covered == TOTAL
+
+
+def test_bench_with_two_ranks_on_this_box():
+    """`python bench.py --gpus 2` end to end (rank spawn, load path, sharded timing, one JSON line from rank 0), with gloo
+    carrying the collectives so that both ranks can share this box's GPU."""
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_PORT=str(28300 + os.getpid() % 1000))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--collectives", "gloo", "--streams", "64",
+                          "--steps", "40", "--warmup", "5", "--no-extras", "--device-warm-ms", "0"],
+                         capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["streams_per_gpu"] == 64
+    assert line["value"] > 1e4 and line["output_rms"] > 0.01
+    assert "device blobs, in place" in line["config"]["parallelism"]
