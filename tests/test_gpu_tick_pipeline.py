@@ -110,3 +110,51 @@ def test_tick_pipeline_matches_in_order_chain(bv, product, model_dir, B, steps, 
     assert np.abs(got).max() > 0.05
     assert not bad
     assert np.array_equal(q, ref_q)
+
+
+def test_tick_pipeline_with_a_morph_slot(bv, product, model_dir):
+    """A morphed speaker draws a codebook per stream and step (processor_core_2.cc:94-121).  In tick mode the draw is made
+    when the step is fed and must reach the k-NN stage eleven ticks later with THAT step -- through the settings snapshot
+    of the step, not through whatever the host has drawn since.  Same seeds, same draws: tick == in order, bit for bit."""
+    hip = Hip()
+    m = bv.Models(product, model_dir)
+    bv.bind_batch(product)
+    B, steps = 12, 48
+    n = m.tables.n_speakers
+    audio = np.stack([bv.synth_audio(160 * steps, seed=9300 + s) for s in range(B)])
+    w = np.zeros(n, np.float32)
+    w[:3] = (0.5, 0.3, 0.2)
+
+    def setup(batch):
+        a, h = batch.a, batch.h
+        assert a.BeatriceBatch_MorphSpeaker(h, n, bv.fptr(w), n, 1234) == 0          # entry n = the morph slot, lottery seeded
+        for s in range(B):
+            a.BeatriceBatch_SetTargetSpeaker(h, s, n if s % 2 == 0 else s % n)       # half the streams on the morph
+            a.BeatriceBatch_SetVQNumNeighbors(h, s, 1 + s % 3)                        # k-NN on: the drawn codebook matters
+        a.BeatriceBatch_FlushSpeaker(h, -1)
+
+    ref_batch = bv.Batch(m, B)
+    setup(ref_batch)
+    ref = np.stack([ref_batch.convert(np.ascontiguousarray(audio[:, k * 160:(k + 1) * 160])) for k in range(steps)])
+    ref_batch.close()
+
+    batch = bv.Batch(m, B)
+    setup(batch)
+    a, h = batch.a, batch.h
+    slots = steps   # every step has its own slot: no wrap to think about here
+    d_in, d_out = hip.malloc(slots * B * 160 * 4), hip.malloc(slots * B * 240 * 4)
+    hip.h2d(d_in, np.ascontiguousarray(audio.reshape(B, steps, 160).transpose(1, 0, 2)))
+    assert a.BeatriceBatch_BindResidentIO(h, d_in, d_out, slots) == 0
+    assert a.BeatriceBatch_EnableTickPipeline(h, 1) == 0
+    for k in range(steps):
+        assert a.BeatriceBatch_ConvertFramesDevice(h, None, None) == 0
+    assert a.BeatriceBatch_Synchronize(h) == 0
+    got = np.zeros((slots, B, 240), np.float32)
+    hip.d2h(got, d_out)
+    bad = [(k, int(s_)) for k in range(steps) for s_ in np.nonzero(np.abs(got[k] - ref[k]).max(axis=1))[0]]
+    assert not bad, "differing (step, stream): %s" % bad[:30]
+    # the draws did vary (otherwise this test shows nothing): the morph streams differ from what a fixed codebook gives
+    assert np.abs(ref).max() > 0.05
+    hip.free(d_in); hip.free(d_out)
+    batch.close()
+    m.close()

@@ -71,9 +71,19 @@ def test_48k_wrapper_around_the_tick_pipeline_matches_in_order(bv, product, mode
             batch.a.BeatriceBatch_SetVQNumNeighbors(batch.h, s, s % 2)
         batch.a.BeatriceBatch_FlushSpeaker(batch.h, -1)
 
+    def change(batch, k):   # settings moving while blocks are in flight; a stream reset (drains the pipeline, restarts its wrapper)
+        if k % 7 == 3:
+            batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, (3 * k) % B, (k + 1) % 3)
+            batch.a.BeatriceBatch_SetPitchShift(batch.h, (5 * k) % B, float(k % 5) - 2.0)
+        if k == 31:
+            assert batch.a.BeatriceBatch_ResetStream(batch.h, 1 % B) == 0
+
     ref_batch = bv.Batch(m, B)
     settings(ref_batch)
-    want = [ref_batch.convert48k(np.ascontiguousarray(x[:, :, 480 * k:480 * (k + 1)]), channels).copy() for k in range(blocks)]
+    want = []
+    for k in range(blocks):
+        change(ref_batch, k)
+        want.append(ref_batch.convert48k(np.ascontiguousarray(x[:, :, 480 * k:480 * (k + 1)]), channels).copy())
     ref_batch.close()
 
     batch = bv.Batch(m, B)
@@ -96,6 +106,7 @@ def test_48k_wrapper_around_the_tick_pipeline_matches_in_order(bv, product, mode
                 buf[k % slots] = x[:, :, 480 * k:480 * (k + 1)]
             hip.h2d(d_in, buf)
             for k in range(k0, k0 + n):
+                change(batch, k)
                 assert a.BeatriceBatch_ConvertBlocks48kDevice(h, None, None, channels) == 0
             assert a.BeatriceBatch_Synchronize(h) == 0
             out = np.zeros((slots, B, channels, 480), np.float32)
