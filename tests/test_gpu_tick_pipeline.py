@@ -10,7 +10,7 @@ from test_gpu_resident_io import Hip
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("B,steps,vq_from_start", [(24, 75, True), (5, 60, False), (256, 50, True), (600, 45, True), (1, 40, True), (17, 40, False), (33, 36, True)])
+@pytest.mark.parametrize("B,steps,vq_from_start", [(24, 75, True), (5, 60, False), (256, 50, True), (600, 45, True), (1, 40, True), (17, 40, False), (33, 36, True), (40, 420, True)])
 def test_tick_pipeline_matches_in_order_chain(bv, product, model_dir, B, steps, vq_from_start):
     hip = Hip()
     m = bv.Models(product, model_dir)
