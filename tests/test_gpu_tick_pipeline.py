@@ -67,8 +67,9 @@ def test_tick_pipeline_matches_in_order_chain(bv, product, model_dir, B, steps, 
     assert a.BeatriceBatch_EnablePipelining(h, 2) == -1
     got = np.zeros_like(ref)
     k0 = 0
-    for chunk in (slots, 7, slots - 3, 10 ** 9):     # fill slots, feed without waiting, drain, read back; wraps around
-        n = min(chunk, steps - k0)
+    import itertools
+    for chunk in itertools.cycle((slots, 7, slots - 3)):     # fill slots, feed without waiting, drain, read back; wraps around
+        n = min(chunk, steps - k0)                             # (never more steps at once than there are slots)
         if n <= 0:
             break
         buf = np.zeros((slots, B, 160), np.float32)
