@@ -6,7 +6,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("B,steps,vq_from_start", [(7, 90, True), (256, 70, True), (6, 80, False)])
+@pytest.mark.parametrize("B,steps,vq_from_start", [(7, 90, True), (256, 70, True), (6, 80, False), (9, 330, True)])
 def test_streamed_host_buffers_match_in_order_chain(bv, product, model_dir, B, steps, vq_from_start):
     m = bv.Models(product, model_dir)
     bv.bind_batch(product)
