@@ -345,6 +345,8 @@ class Batch:
         t = models.tables if upload_tables else None
         self.B = n_streams
         self.H = hops_per_step
+        if t is None and max_speakers is None:
+            raise ValueError("Batch(upload_tables=False) needs max_speakers: without host tables the table size is unknown")
         ms = max_speakers or (t.n_speakers + 1)
         if hops_per_step == 1:
             self.h = self.a.BeatriceBatch_Create(models.phone, models.pitch, models.wave, models.embed, n_streams, ms)

@@ -86,21 +86,38 @@ static bool hop_immediate() {
   static const bool on = std::getenv("BEATRICE_HIP_HOP_IMMEDIATE") != nullptr;
   return on;
 }
-// Runs `enqueue` (copies + kernels on `s`) through the context's captured graph; captures it first when there is none for
-// this model / variant.  BEATRICE_HIP_NO_HOP_GRAPH=1: plain launches (measurements).
+// Captures `enqueue` (copies + kernels on `s`) into g for this parameter blob / variant; nothing runs.  On any failure the
+// capture is ended, the graph dropped and the pair remembered as "eager", so that the stream is never left in capture
+// state and later hops fall back to plain launches instead of returning zeros.
 template <class F>
-static bool run_hop(HopGraph& g, const void* model, int variant, hipStream_t s, F enqueue) {
+static void capture_hop(HopGraph& g, const void* blob, int variant, hipStream_t s, F& enqueue) {
+  g.drop();
+  g.blob = blob;
+  g.variant = variant;
+  bool ok = hip_ok(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal), "begin capture");
+  if (ok) {
+    enqueue();
+    ok = hip_ok(hipStreamEndCapture(s, &g.graph), "end capture") && g.graph != nullptr;   // (also leaves capture mode after a failed node)
+    ok = ok && hip_ok(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0), "instantiate");
+  }
+  if (!ok) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+    g.exec = nullptr; g.graph = nullptr;
+    g.eager = true;
+    (void)hipGetLastError();  // the failure is handled: do not let it fail the eager launches that follow
+  }
+}
+// Runs `enqueue` through the context's captured graph; captures it first when there is none for this parameter blob /
+// variant.  The key is the DEVICE BLOB the captured kernels read (not the model object's address): Read*Parameters on the
+// same object frees and re-allocates the blob, and a graph holding the old pointers must not be replayed.
+// BEATRICE_HIP_NO_HOP_GRAPH=1: plain launches (measurements).
+template <class F>
+static bool run_hop(HopGraph& g, const void* blob, int variant, hipStream_t s, F enqueue) {
   static const bool eager = std::getenv("BEATRICE_HIP_NO_HOP_GRAPH") != nullptr;
   if (eager || hop_immediate()) { enqueue(); return hip_ok(hipGetLastError(), "hop launch"); }
-  if (!g.exec || g.model != model || g.variant != variant) {
-    g.drop();
-    BHIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    enqueue();
-    BHIP_TRY(hipStreamEndCapture(s, &g.graph));
-    BHIP_TRY(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
-    g.model = model;
-    g.variant = variant;
-  }
+  if (g.blob != blob || g.variant != variant || (!g.exec && !g.eager)) capture_hop(g, blob, variant, s, enqueue);
+  if (!g.exec) { enqueue(); return hip_ok(hipGetLastError(), "hop launch"); }
   BHIP_TRY(hipGraphLaunch(g.exec, s));
   return true;
 }
@@ -155,7 +172,7 @@ Beatrice20rc0_PhoneContext1* Beatrice20rc0_CreatePhoneContext1(void) {
 void Beatrice20rc0_DestroyPhoneContext1(Beatrice20rc0_PhoneContext1* c) {
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  c->hop_graph.drop();
+  for (HopGraph& g : c->hop_graph) g.drop();
   if (c->own_sel[0]) {
     c->st.d_vqk = static_cast<int*>(c->own_sel[0]);
     c->st.d_cbT = static_cast<const float**>(c->own_sel[1]);
@@ -237,11 +254,22 @@ void Beatrice20rc0_ExtractPhone1(const Beatrice20rc0_PhoneExtractor* m, const fl
   }
   if (hop_immediate()) ctx->st.hop = ctx->st.hop_in = const_cast<int*>(stepc::immediate(ctx->hop_count));
   ctx->hop_count = hop_next(ctx->hop_count);
-  bool ok = run_hop(ctx->hop_graph, m, ctx->st.skip_vq ? 0 : 1, ctx->stream, [&] {
+  auto enqueue = [&] {
     (void)hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * (B_IN_HOP + kMailboxWords), hipMemcpyHostToDevice, ctx->stream);
     phone_forward(m->w, ctx->st, ctx->stream);
     (void)hipMemcpyAsync(h_out, ctx->st.d_phone, sizeof(float) * B_PHONE_CH, hipMemcpyDeviceToHost, ctx->stream);
-  });
+  };
+  const int variant = ctx->st.skip_vq ? 0 : 1;
+  // Both variants (k-NN launch present / absent) are captured at the first hop with a given parameter blob, so that a
+  // later SetVQNumNeighbors toggle on the audio thread finds its graph ready instead of spending 1-2 ms on a capture.
+  HopGraph& other = ctx->hop_graph[variant ^ 1];
+  if (other.blob != m->blob.d && !hop_immediate() && std::getenv("BEATRICE_HIP_NO_HOP_GRAPH") == nullptr) {
+    const bool keep = ctx->st.skip_vq;
+    ctx->st.skip_vq = !keep;
+    capture_hop(other, m->blob.d, variant ^ 1, ctx->stream, enqueue);
+    ctx->st.skip_vq = keep;
+  }
+  bool ok = run_hop(ctx->hop_graph[variant], m->blob.d, variant, ctx->stream, enqueue);
   ok = wait_stream(ctx->stream) && ok;
   if (ok) std::memcpy(output, h_out, sizeof(float) * B_PHONE_CH);
 }
@@ -310,7 +338,7 @@ void Beatrice20rc0_EstimatePitch1(const Beatrice20rc0_PitchEstimator* m, const f
   }
   if (hop_immediate()) ctx->st.hop = ctx->st.hop_in = const_cast<int*>(stepc::immediate(ctx->hop_count));
   ctx->hop_count = hop_next(ctx->hop_count);
-  bool ok = run_hop(ctx->hop_graph, m, 0, ctx->stream, [&] {
+  bool ok = run_hop(ctx->hop_graph, m->blob.d, 0, ctx->stream, [&] {
     (void)hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * (B_IN_HOP + kMailboxWords), hipMemcpyHostToDevice, ctx->stream);
     pitch_forward(m->w, ctx->st, ctx->stream);
     (void)hipMemcpyAsync(h_feat, ctx->st.d_feat, sizeof(float) * 4, hipMemcpyDeviceToHost, ctx->stream);
@@ -372,7 +400,7 @@ void Beatrice20rc0_GenerateWaveform1(const Beatrice20rc0_WaveformGenerator* m, c
   std::memcpy(h_in + B_PHONE_CH + 5, &ctx->hop_count, sizeof(int));
   if (hop_immediate()) ctx->st.hop = const_cast<int*>(stepc::immediate(ctx->hop_count));
   ctx->hop_count = hop_next(ctx->hop_count);
-  bool ok = run_hop(ctx->hop_graph, m, 0, ctx->stream, [&] {
+  bool ok = run_hop(ctx->hop_graph, m->blob.d, 0, ctx->stream, [&] {
     (void)hipMemcpyAsync(ctx->d_inputs, h_in, sizeof(float) * in_floats, hipMemcpyHostToDevice, ctx->stream);
     wave_forward(m->w, ctx->st, ctx->stream);
     (void)hipMemcpyAsync(h_out, ctx->st.d_out, sizeof(float) * B_OUT_HOP, hipMemcpyDeviceToHost, ctx->stream);
@@ -438,9 +466,12 @@ static void set_vector(const Beatrice20rc0_EmbeddingSetter* m, int kind, const f
   std::memcpy(h, embedding, sizeof(float) * B_HID);
   hipStream_t st = (wc && wc->ok) ? wc->stream : ec->stream;
   if (!hip_ok(hipMemcpyAsync(d, h, sizeof(float) * B_HID, hipMemcpyHostToDevice, st), "emb up")) return;
-  ec->vec_busy[slot] = hip_ok(hipEventRecord(ec->vec_sent[slot], st), "emb ev");
   embed_project_rows(w, b, d, d_ctx_vec, 1, st);
   if (d_wave_row) (void)hip_ok(hipMemcpyAsync(d_wave_row, d_ctx_vec, sizeof(float) * B_HID, hipMemcpyDeviceToDevice, st), "emb d2d");
+  // The slot (pinned staging AND the device slot `d`) is free again only when the projection that reads `d` is done: the
+  // event is recorded behind it, and the call that re-uses the slot waits for it above -- whatever stream that call is on
+  // (one embedding context may serve several waveform contexts, or none).
+  ec->vec_busy[slot] = hip_ok(hipEventRecord(ec->vec_sent[slot], st), "emb ev");
 }
 // ref beatrice.h:323-327; callers processor_core_2.cc:137-141, 451-455
 void Beatrice20rc0_SetAdditiveSpeakerEmbedding(const Beatrice20rc0_EmbeddingSetter* m, const float* embedding,
@@ -473,8 +504,12 @@ void Beatrice20rc0_SetKeyValueSpeakerEmbedding(const Beatrice20rc0_EmbeddingSett
                                                Beatrice20rc0_EmbeddingContext* ec, Beatrice20rc0_WaveformContext1* wc) {
   if (!m || !m->loaded || !ec || !ec->ok || !wc || !wc->ok || block < 0 || block >= B_NBLOCKS) return;
   if (ec->kv_busy) (void)hip_ok(hipStreamWaitEvent(wc->stream, ec->kv_uploaded, 0), "kv wait");
+  // kv_projected is ONE event: when the previous projection ran on another waveform context's stream, chain behind it
+  // first, so that the event recorded below covers every projection that still reads the registration
+  if (ec->kv_proj_pending && ec->kv_proj_stream != wc->stream) (void)hip_ok(hipStreamWaitEvent(wc->stream, ec->kv_projected, 0), "kv chain");
   embed_project_kv(m->w, block, ec->d_kv_raw, 1, wc->st.d_kt[block], wc->st.d_v[block], wc->stream);
   ec->kv_proj_pending = hip_ok(hipEventRecord(ec->kv_projected, wc->stream), "kv proj ev");
+  ec->kv_proj_stream = wc->stream;
 }
 
 // ================================ speaker file =================================================

@@ -33,12 +33,13 @@ namespace bhip {
 struct HopGraph {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
-  const void* model = nullptr;
+  const void* blob = nullptr;  // the device parameter blob the captured kernels read (a reload re-allocates it)
   int variant = -1;
+  bool eager = false;          // capture or instantiation failed for (blob, variant): plain launches instead
   void drop() {
     if (exec) (void)hipGraphExecDestroy(exec);
     if (graph) (void)hipGraphDestroy(graph);
-    exec = nullptr; graph = nullptr; model = nullptr; variant = -1;
+    exec = nullptr; graph = nullptr; blob = nullptr; variant = -1; eager = false;
   }
 };
 }  // namespace bhip
@@ -65,7 +66,7 @@ struct Beatrice20rc0_PhoneContext1 {
   int stage_next = 0;
   unsigned long long use_clock = 0;
   void* own_sel[3] = {nullptr, nullptr, nullptr};  // the state's own (unused) selector arrays, handed back before destroy()
-  bhip::HopGraph hop_graph;
+  bhip::HopGraph hop_graph[2];  // [k-NN launch present]: both captured at the first hop with a given parameter blob
   bool ok = false;
 };
 struct Beatrice20rc0_PitchContext1 {
@@ -97,5 +98,6 @@ struct Beatrice20rc0_EmbeddingContext {
   int vec_next[2] = {0, 0};
   hipEvent_t kv_uploaded = nullptr, kv_projected = nullptr;
   bool kv_busy = false, kv_proj_pending = false;
+  hipStream_t kv_proj_stream = nullptr;  // where kv_projected was recorded last
   bool ok = false;
 };

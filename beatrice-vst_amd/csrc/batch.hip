@@ -128,6 +128,7 @@ struct BeatriceBatch {
   // the codebook lottery's engine belongs to the stream, as the reference's belongs to the plugin instance
   // (processor_core_2.h:48,145): a stream's draws do not depend on which other streams share its batch
   std::vector<std::mt19937> lottery;  // [B]
+  bool lottery_seeded = false;        // a caller's seed has been applied (first BeatriceBatch_MorphSpeaker, or BeatriceBatch_SeedLottery)
   // every per-stream setting array the kernels read lives in ONE device block with one pinned mirror, so a
   // step after any change costs a single small host-to-device copy (a dozen separate copies cost ~50 us of
   // stream time per step with 64 rotating speakers)
@@ -1186,7 +1187,14 @@ int BeatriceBatch_MorphSpeaker(BeatriceBatch* b, int slot, const float* weights,
   m.n_speakers = n_weights;
   m.n_odds = keep;
   for (int i = 0; i < 8; ++i) { m.order[i] = i < keep ? order[i] : 0; m.odds[i] = i < keep ? w[order[i]] : 0.0f; }
-  for (int st = 0; st < b->B; ++st) b->lottery[st].seed(seed + (unsigned)st);  // BeatriceBatch_SeedLottery for other seeds
+  // The engines are seeded ONCE per batch, as the reference seeds its engine once per instance (processor_core_2.h:48,145) and
+  // never again when morph weights move (:94-121): only the first morph of the batch's life applies `seed`; a caller that
+  // moves weights every step keeps each stream's draw SEQUENCE running, and a morph on one entry leaves the draws of the
+  // streams on other entries alone.  BeatriceBatch_SeedLottery re-seeds explicitly.
+  if (!b->lottery_seeded) {
+    for (int st = 0; st < b->B; ++st) b->lottery[st].seed(seed + (unsigned)st);
+    b->lottery_seeded = true;
+  }
   // streams already on this entry re-install its key/value blocks, one per hop, like after a speaker switch
   for (StreamCfg& c : b->cfg) if (c.target_speaker == slot) c.kv_set_count = 0;
   b->pending_kv = 0;
@@ -1199,6 +1207,7 @@ int BeatriceBatch_SeedLottery(BeatriceBatch* b, int stream, unsigned seed) {
   if (!b || !b->ok) return -2;
   if (stream < -1 || stream >= b->B) return -1;
   for (int s = (stream < 0 ? 0 : stream); s < (stream < 0 ? b->B : stream + 1); ++s) b->lottery[s].seed(seed);
+  b->lottery_seeded = true;  // a later BeatriceBatch_MorphSpeaker keeps these engines
   return 0;
 }
 // copies the morphed entry's raw embeddings back (test / inspection hook; any pointer may be NULL)

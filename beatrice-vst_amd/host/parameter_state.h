@@ -7,7 +7,9 @@
 // A VST host wraps it as int32 size + blob (reference src/vst/processor.cc:233-268): FrameState / UnframeState.
 // Reading starts from the defaults and overwrites what the stream holds (ReadOrSetDefault, :128-133); a truncated
 // record is ErrorCode::kFileTooSmall, an unknown type ErrorCode::kUnknownError; ids the table does not know are kept
-// (the reference keeps them too: SetValue inserts).
+// (the reference keeps them too: SetValue inserts).  A record of a KNOWN id whose type is not the schema's is dropped (the
+// default stays): state blobs are untrusted input, and a wrongly typed value would make every later typed read of that
+// id throw (the reference's std::get would) -- here nothing typed is ever stored for an id of another kind.
 #pragma once
 #include <array>
 #include <cstdint>
@@ -87,8 +89,25 @@ class ParameterState {
       else values_[id] = std::string();
     }
   }
-  void Set(std::int16_t id, Value v) { values_[id] = std::move(v); }
-  const Value& Get(std::int16_t id) const { return values_.at(id); }
+  // false (nothing stored) when `id` is in the schema with another kind
+  bool Set(std::int16_t id, Value v) {
+    if (!KindOk(id, v)) return false;
+    values_[id] = std::move(v);
+    return true;
+  }
+  static bool KindOk(std::int16_t id, const Value& v) {
+    const auto it = Schema().find(id);
+    return it == Schema().end() || (int)v.index() == (int)it->second.kind;
+  }
+  // nullptr for an id that holds nothing
+  const Value* Find(std::int16_t id) const { const auto it = values_.find(id); return it == values_.end() ? nullptr : &it->second; }
+  const Value& Get(std::int16_t id) const { return values_.at(id); }   // (throws for an unknown id: callers inside try blocks only)
+  // typed reads that never throw: the stored value when it has that type, else the schema default, else `fallback`
+  double Number(std::int16_t id, double fallback = 0.0) const {
+    if (const Value* v = Find(id)) if (const double* d = std::get_if<double>(v)) return *d;
+    const auto it = Schema().find(id);
+    return it != Schema().end() && it->second.kind == ParameterInfo::kNumber ? it->second.def : fallback;
+  }
   bool Has(std::int16_t id) const { return values_.count(id) != 0; }
   const std::map<std::int16_t, Value>& all() const { return values_; }
 
@@ -115,12 +134,12 @@ class ParameterState {
       std::int16_t id;
       std::int32_t type;
       if (!take(&id, 2) || !take(&type, 4)) return ErrorCode::kFileTooSmall;   // (an EMPTY stream is too small as well, like the reference)
-      if (type == 0) { std::int32_t v; if (!take(&v, 4)) return ErrorCode::kFileTooSmall; values_[id] = (int)v; }
-      else if (type == 1) { double v; if (!take(&v, 8)) return ErrorCode::kFileTooSmall; values_[id] = v; }
+      if (type == 0) { std::int32_t v; if (!take(&v, 4)) return ErrorCode::kFileTooSmall; (void)Set(id, (int)v); }
+      else if (type == 1) { double v; if (!take(&v, 8)) return ErrorCode::kFileTooSmall; (void)Set(id, v); }
       else if (type == 2) {
         std::int32_t len;
         if (!take(&len, 4) || len < 0 || at + (size_t)len > n) return ErrorCode::kFileTooSmall;
-        values_[id] = std::string(reinterpret_cast<const char*>(p + at), (size_t)len);
+        (void)Set(id, std::string(reinterpret_cast<const char*>(p + at), (size_t)len));
         at += (size_t)len;
       } else return ErrorCode::kUnknownError;
       if (at == n) return ErrorCode::kSuccess;
@@ -153,7 +172,7 @@ inline bool UnframeState(const unsigned char* p, size_t n, const unsigned char**
 // voice_morph_state.h:50-85 CalculateMarkerWeights / CalculateWeights), float arithmetic as in the reference
 inline std::array<float, kMaxNSpeakers> VoiceMorphWeights(const ParameterState& st) {
   using namespace param_id;
-  auto num = [&st](std::int16_t id) { return std::get<double>(st.Get(id)); };
+  auto num = [&st](std::int16_t id) { return st.Number(id); };
   const float cx = (float)std::clamp(num(kVoiceMorphCursorX), 0.0, 1.0), cy = (float)std::clamp(num(kVoiceMorphCursorY), 0.0, 1.0);
   const float falloff = std::clamp((float)num(kVoiceMorphFalloff), 0.0f, 4.0f);
   const int count = std::clamp((int)std::round(num(kVoiceMorphMarkerCount)), 1, kMaxNVoiceMorphMarkers);

@@ -65,7 +65,7 @@ ErrorCode ProcessorProxy::LoadModel(const std::filesystem::path& file) {
 }
 
 ErrorCode ProcessorProxy::SetParameter(std::int16_t id, ParameterState::Value value) {
-  state_.Set(id, std::move(value));
+  if (!state_.Set(id, std::move(value))) return ErrorCode::kUnknownError;  // wrong type for a known id: nothing changes
   return SyncParameter(id);
 }
 
@@ -137,44 +137,67 @@ ErrorCode ProcessorProxy::ProcessChannels(const float* in0, const float* in1, fl
 
 // ---- C view for tests and non-C++ hosts -------------------------------------------------------------------------------
 using beatrice_amd::ProcessorProxy;
+namespace {
+// Nothing may leave an extern "C" function by exception (std::terminate): run f, return `on_error` when anything is thrown
+// (kUnknownError = 1 for the entry points that hand back an ErrorCode).
+template <class F, class R>
+R guarded(R on_error, F&& f) noexcept {
+  try { return f(); } catch (...) { return on_error; }
+}
+constexpr int kThrown = (int)beatrice_amd::ErrorCode::kUnknownError;
+ProcessorProxy* proxy(void* p) { return static_cast<ProcessorProxy*>(p); }
+}  // namespace
 extern "C" {
-void* BeatriceProxy_Create(void) { return new ProcessorProxy(); }
-void BeatriceProxy_Destroy(void* p) { delete static_cast<ProcessorProxy*>(p); }
-int BeatriceProxy_SetSampleRate(void* p, double sr) { return (int)static_cast<ProcessorProxy*>(p)->SetSampleRate(sr); }
-int BeatriceProxy_LoadModel(void* p, const char* toml_path) { return (int)static_cast<ProcessorProxy*>(p)->LoadModel(toml_path ? toml_path : ""); }
-int BeatriceProxy_SetNumber(void* p, int id, double v) { return (int)static_cast<ProcessorProxy*>(p)->SetParameter((std::int16_t)id, v); }
-int BeatriceProxy_SetInt(void* p, int id, int v) { return (int)static_cast<ProcessorProxy*>(p)->SetParameter((std::int16_t)id, v); }
-int BeatriceProxy_SetString(void* p, int id, const char* s) { return (int)static_cast<ProcessorProxy*>(p)->SetParameter((std::int16_t)id, std::string(s ? s : "")); }
-int BeatriceProxy_Process(void* p, const float* in, float* out, int n) { return (int)static_cast<ProcessorProxy*>(p)->Process(in, out, n); }
+void* BeatriceProxy_Create(void) { return guarded((void*)nullptr, []() -> void* { return new ProcessorProxy(); }); }
+void BeatriceProxy_Destroy(void* p) { delete proxy(p); }
+int BeatriceProxy_SetSampleRate(void* p, double sr) { return guarded(kThrown, [&] { return (int)proxy(p)->SetSampleRate(sr); }); }
+int BeatriceProxy_LoadModel(void* p, const char* toml_path) { return guarded(kThrown, [&] { return (int)proxy(p)->LoadModel(toml_path ? toml_path : ""); }); }
+int BeatriceProxy_SetNumber(void* p, int id, double v) { return guarded(kThrown, [&] { return (int)proxy(p)->SetParameter((std::int16_t)id, v); }); }
+int BeatriceProxy_SetInt(void* p, int id, int v) { return guarded(kThrown, [&] { return (int)proxy(p)->SetParameter((std::int16_t)id, v); }); }
+int BeatriceProxy_SetString(void* p, int id, const char* s) { return guarded(kThrown, [&] { return (int)proxy(p)->SetParameter((std::int16_t)id, std::string(s ? s : "")); }); }
+int BeatriceProxy_Process(void* p, const float* in, float* out, int n) { return guarded(kThrown, [&] { return (int)proxy(p)->Process(in, out, n); }); }
 // returns 1 when the block was silent (not converted), 0 when it was converted, < 0: -(error code)
 int BeatriceProxy_ProcessChannels(void* p, const float* in0, const float* in1, float* out0, float* out1, int n) {
-  bool silent = true;
-  const int rc = (int)static_cast<ProcessorProxy*>(p)->ProcessChannels(in0, in1, out0, out1, n, &silent);
-  return rc != 0 ? -rc : (silent ? 1 : 0);
+  return guarded(-kThrown, [&] {
+    bool silent = true;
+    const int rc = (int)proxy(p)->ProcessChannels(in0, in1, out0, out1, n, &silent);
+    return rc != 0 ? -rc : (silent ? 1 : 0);
+  });
 }
-int BeatriceProxy_ResetContext(void* p) { return (int)static_cast<ProcessorProxy*>(p)->ResetContext(); }
-int BeatriceProxy_CoreVersion(void* p) { return static_cast<ProcessorProxy*>(p)->CoreVersion(); }
-int BeatriceProxy_VoiceCount(void* p) { const auto* c = static_cast<ProcessorProxy*>(p)->Config(); return c ? beatrice_amd::GetVoiceCount(*c) : 0; }
+int BeatriceProxy_ResetContext(void* p) { return guarded(kThrown, [&] { return (int)proxy(p)->ResetContext(); }); }
+int BeatriceProxy_CoreVersion(void* p) { return proxy(p)->CoreVersion(); }
+int BeatriceProxy_VoiceCount(void* p) { return guarded(0, [&] { const auto* c = proxy(p)->Config(); return c ? beatrice_amd::GetVoiceCount(*c) : 0; }); }
 // parameter read-back: kind 0 int / 1 number / 2 string, -1 unknown id
-int BeatriceProxy_GetKind(void* p, int id) { const auto& st = static_cast<ProcessorProxy*>(p)->GetParameterState(); return st.Has((std::int16_t)id) ? (int)st.Get((std::int16_t)id).index() : -1; }
-double BeatriceProxy_GetNumber(void* p, int id) { const auto& v = static_cast<ProcessorProxy*>(p)->GetParameter((std::int16_t)id); return v.index() == 1 ? std::get<double>(v) : (v.index() == 0 ? (double)std::get<int>(v) : 0.0); }
-int BeatriceProxy_GetString(void* p, int id, char* buf, int cap) {
-  const auto& v = static_cast<ProcessorProxy*>(p)->GetParameter((std::int16_t)id);
-  if (v.index() != 2) return -1;
-  const std::string& s = std::get<std::string>(v);
-  if (buf && cap > 0) { const int n = (int)s.size() < cap - 1 ? (int)s.size() : cap - 1; std::memcpy(buf, s.data(), (size_t)n); buf[n] = '\0'; }
-  return (int)s.size();
+int BeatriceProxy_GetKind(void* p, int id) { const auto* v = proxy(p)->FindParameter((std::int16_t)id); return v ? (int)v->index() : -1; }
+double BeatriceProxy_GetNumber(void* p, int id) {   // 0 for an unknown id or a string
+  const auto* v = proxy(p)->FindParameter((std::int16_t)id);
+  if (!v) return 0.0;
+  if (const double* d = std::get_if<double>(v)) return *d;
+  if (const int* i = std::get_if<int>(v)) return (double)*i;
+  return 0.0;
+}
+int BeatriceProxy_GetString(void* p, int id, char* buf, int cap) {   // -1 for an unknown id or a non-string
+  const auto* v = proxy(p)->FindParameter((std::int16_t)id);
+  const std::string* s = v ? std::get_if<std::string>(v) : nullptr;
+  if (!s) return -1;
+  if (buf && cap > 0) { const int n = (int)s->size() < cap - 1 ? (int)s->size() : cap - 1; std::memcpy(buf, s->data(), (size_t)n); buf[n] = '\0'; }
+  return (int)s->size();
 }
 // state blob: returns the size; copies when the buffer is large enough
 int BeatriceProxy_WriteState(void* p, unsigned char* buf, int cap) {
-  const std::vector<unsigned char> b = static_cast<ProcessorProxy*>(p)->Write();
-  if (buf && cap >= (int)b.size()) std::memcpy(buf, b.data(), b.size());
-  return (int)b.size();
+  return guarded(-1, [&] {
+    const std::vector<unsigned char> b = proxy(p)->Write();
+    if (buf && cap >= (int)b.size()) std::memcpy(buf, b.data(), b.size());
+    return (int)b.size();
+  });
 }
-int BeatriceProxy_ReadState(void* p, const unsigned char* buf, int n) { return (int)static_cast<ProcessorProxy*>(p)->Read(buf, (size_t)(n > 0 ? n : 0)); }
+int BeatriceProxy_ReadState(void* p, const unsigned char* buf, int n) { return guarded(kThrown, [&] { return (int)proxy(p)->Read(buf, (size_t)(n > 0 ? n : 0)); }); }
 // morph weights the current parameters imply (test hook)
 void BeatriceProxy_MorphWeights(void* p, float* out256) {
-  const auto w = beatrice_amd::VoiceMorphWeights(static_cast<ProcessorProxy*>(p)->GetParameterState());
-  std::memcpy(out256, w.data(), sizeof(float) * w.size());
+  (void)guarded(0, [&] {
+    const auto w = beatrice_amd::VoiceMorphWeights(proxy(p)->GetParameterState());
+    std::memcpy(out256, w.data(), sizeof(float) * w.size());
+    return 0;
+  });
 }
 }

@@ -30,7 +30,7 @@ class ProcessorProxy {
   double GetSampleRate() const { return sample_rate_; }
   ErrorCode SetSampleRate(double sr);
   ErrorCode SetParameter(std::int16_t id, ParameterState::Value value);
-  const ParameterState::Value& GetParameter(std::int16_t id) const { return state_.Get(id); }
+  const ParameterState::Value* FindParameter(std::int16_t id) const { return state_.Find(id); }   // nullptr: unknown id
   ErrorCode LoadModel(const std::filesystem::path& file);
   ErrorCode Read(const unsigned char* blob, size_t n);
   std::vector<unsigned char> Write() const { return state_.Write(); }

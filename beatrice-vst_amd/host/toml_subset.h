@@ -272,7 +272,16 @@ class Parser {
     ++p_;
     return out;
   }
+  // Arrays and inline tables nest by recursion: a cap keeps a hostile file ("[[[[[[...") from overflowing the stack.
+  static constexpr int kMaxNesting = 64;
+  int depth_ = 0;
+  struct DepthGuard {
+    Parser& p;
+    explicit DepthGuard(Parser& p_) : p(p_) { if (++p.depth_ > kMaxNesting) p.Fail("values nested too deeply"); }
+    ~DepthGuard() { --p.depth_; }
+  };
   Value ParseValue() {
+    const DepthGuard guard(*this);
     Value v;
     const char c = Peek();
     if (c == '"') { v.kind = Value::kString; v.s = BasicString(); return v; }

@@ -92,14 +92,17 @@ int BeatriceBatch_UpdateSpeaker(BeatriceBatch* b, int speaker, const float* code
  * embeddings are weighted spherical means (one wavefront each, one launch), projections are refreshed.
  * Streams whose target speaker is `slot` then (a) re-install the entry's key/value blocks one per hop and
  * (b) use, at every step, the codebook of ONE real speaker drawn with the weights as odds from a
- * std::mt19937 seeded with `seed` (the reference seeds from std::random_device).  Unlike the reference
+ * std::mt19937 seeded with `seed` the first time (the reference seeds once, from std::random_device).  Unlike the reference
  * host, which spreads the means over five hops to bound its CPU time, the new embeddings are complete
  * when the call returns.  Agreement with the host computation: float rounding (<= 1e-5), not bit-exact. */
 int BeatriceBatch_MorphSpeaker(BeatriceBatch* b, int slot, const float* weights, int n_weights, unsigned seed);
-/* The lottery engine is per stream, as the reference's is per plugin instance (processor_core_2.h:48,145):
- * BeatriceBatch_MorphSpeaker(seed) seeds stream s with std::mt19937(seed + s); BeatriceBatch_SeedLottery re-seeds one
- * stream (or all, -1) with std::mt19937(seed) -- e.g. from the stream's global identity when streams are sharded
- * over batches or GPUs, so that a stream's draws do not depend on where it runs.  One draw per hop, also in block mode.
+/* The lottery engine is per stream, as the reference's is per plugin instance (processor_core_2.h:48,145), and like the
+ * reference's it is seeded ONCE: the first BeatriceBatch_MorphSpeaker of a batch's life seeds stream s with
+ * std::mt19937(seed + s); later calls (weights moving, other entries) leave every engine running, so a caller that moves
+ * morph weights every step still gets a per-hop lottery and a morph on one entry does not restart the draws of streams on
+ * another.  BeatriceBatch_SeedLottery re-seeds one stream (or all, -1) with std::mt19937(seed) at any time -- e.g. from the
+ * stream's global identity when streams are sharded over batches or GPUs, so that a stream's draws do not depend on where it
+ * runs -- and a later BeatriceBatch_MorphSpeaker keeps those engines.  One draw per hop, also in block mode.
  * The entry's key/value projections are replaced in place by BeatriceBatch_MorphSpeaker: streams already on the entry
  * see all four blocks change at that step (the reference, which computes the means over four hops on the audio
  * thread, installs them one block per hop). */

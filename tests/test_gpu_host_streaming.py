@@ -7,7 +7,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("B,steps,vq_from_start", [(7, 90, True), (256, 70, True), (6, 80, False), (9, 330, True)])
-def test_streamed_host_buffers_match_in_order_chain(bv, product, model_dir, B, steps, vq_from_start):
+def test_streamed_host_buffers_match_in_order_chain(bv, oracle, product, model_dir, B, steps, vq_from_start):
     m = bv.Models(product, model_dir)
     bv.bind_batch(product)
     audio = np.stack([bv.synth_audio(160 * steps, seed=4100 + s) for s in range(B)]).reshape(B, steps, 160)
@@ -64,6 +64,13 @@ def test_streamed_host_buffers_match_in_order_chain(bv, product, model_dir, B, s
     assert len(got) == steps
     bad = [(k, int(s_)) for k in range(steps) for s_ in np.nonzero(np.abs(got[k] - ref[k]).max(axis=1))[0]]
     assert not bad, "differing (step, stream): %s" % bad[:40]
+    # the ORACLE leg: sampled streams as independent oracle streams under the same script (reference protocol)
+    from oracle_batch import oracle_leg, pick_streams, scripted_streams
+    sample = sorted(set(pick_streams(B, 6)) | set(scripted_streams(B, steps, change, 6)))
+    sample, want = oracle_leg(bv, oracle, model_dir, B, lambda k: audio[:, k], steps, settings, change, sample)
+    dev = float(np.abs(np.stack(got)[:, sample] - want).max())
+    print("host streaming vs ORACLE, streams %s, %d steps: max-abs %g" % (sample, steps, dev))
+    assert dev <= 1e-4
     # back to the in-order chain on the same streams: state carried over
     assert a.BeatriceBatch_EnableHostStreaming(h, 0) == 0
     batch.close()

@@ -163,3 +163,41 @@ def test_morph_end_to_end(bv, oracle, product, host_lib, model_dir8, vq_k):
     assert len(set(picks)) > 1 and set(picks) <= {0, 2, 4, 5}
     assert np.abs(got).max() > 0.05
     assert dev <= 1e-4
+
+
+def test_moving_morph_weights_does_not_restart_the_lottery(bv, product, model_dir8):
+    """The reference seeds its lottery engine once per instance and never when morph weights change
+    (processor_core_2.h:48,145, .cc:94-121).  A caller that re-sends the (same) weights before every step must therefore
+    get exactly the samples of a caller that sent them once -- the draw sequence runs on -- and a morph on a second entry
+    must not restart the draws of the streams on the first."""
+    B, hops = 6, 16
+    audio = np.stack([bv.synth_audio(160 * hops, seed=1500 + s) for s in range(B)])
+    m = bv.Models(product, model_dir8)
+    n = m.tables.n_speakers
+    w = np.array([0.1, 0.0, 0.45, 0.0, 0.25, 0.2, 0.0, 0.0], np.float32)
+    w2 = np.array([0.5, 0.5, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0], np.float32)
+
+    def run(resend, second_entry_at=None):
+        batch = bv.Batch(m, B, max_speakers=n + 2)
+        a, h = batch.a, batch.h
+        assert a.BeatriceBatch_MorphSpeaker(h, n, bv.fptr(w), n, 99) == 0
+        a.BeatriceBatch_SetTargetSpeaker(h, -1, n)
+        a.BeatriceBatch_SetVQNumNeighbors(h, -1, 2)
+        a.BeatriceBatch_FlushSpeaker(h, -1)
+        out = []
+        for k in range(hops):
+            if resend and k > 0:
+                assert a.BeatriceBatch_MorphSpeaker(h, n, bv.fptr(w), n, 99) == 0
+                a.BeatriceBatch_FlushSpeaker(h, -1)
+            if second_entry_at == k:
+                assert a.BeatriceBatch_MorphSpeaker(h, n + 1, bv.fptr(w2), n, 5) == 0
+            out.append(batch.convert(np.ascontiguousarray(audio[:, k * 160:(k + 1) * 160])))
+        batch.close()
+        return np.stack(out)
+
+    once = run(False)
+    assert np.array_equal(run(True), once), "re-sending the weights restarted the draw sequences"
+    assert np.array_equal(run(False, second_entry_at=7), once), "a morph on another entry restarted the draw sequences"
+    # and the lottery does draw: with a frozen first variate every hop would use one codebook; compare with k-NN off
+    m.close()
+    assert np.abs(once).max() > 0.05

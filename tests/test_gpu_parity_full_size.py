@@ -159,7 +159,7 @@ def test_batch_and_shard_invariance(bv, product, model_dir):
 
 
 @pytest.mark.parametrize("B", [2048, 2091])
-def test_large_batch_chain_matches_small_batches(bv, product, model_dir, B):
+def test_large_batch_chain_matches_small_batches(bv, oracle, product, model_dir, B):
     """From 2048 streams on the in-order chain runs the conditioned blocks as row-local kernels (wave.hip); below that as
     six launches per block.  Same streams either way, bit for bit: 2048 streams in one batch against slices of them in
     batches of 300, with speakers and k-NN settings varied (per-speaker attention tiles) and a switch in mid-run."""
@@ -189,3 +189,24 @@ def test_large_batch_chain_matches_small_batches(bv, product, model_dir, B):
     for lo in (0, 900, B - 300):
         assert np.array_equal(run(lo, lo + 300), whole[:, lo:lo + 300]), "streams %d.. differ between the two chains" % lo
     m.close()
+    # the ORACLE leg: a sample of the large batch's streams (tile corners, the ragged end, switching streams) as independent
+    # oracle streams under the same settings and the same mid-run switch
+    from oracle_batch import OracleBatch
+    sample = [0, 5, 15, 16, 31, 32, 1000, 1023, 1024, B - 65, B - 33, B - 6, B - 1]
+    sample = sorted(set(sample) | {s for s in range(B - 12, B) if s % 5 == 0})
+    ob = OracleBatch(bv, oracle, model_dir, B, sample=sample)
+    for s in ob.sample:
+        ob.a.BeatriceBatch_SetTargetSpeaker(None, s, s % 3)
+        ob.a.BeatriceBatch_SetVQNumNeighbors(None, s, (s // 3) % 3)
+    ob.a.BeatriceBatch_FlushSpeaker(None, -1)
+    dev = 0.0
+    for h in range(hops):
+        if h == 2:
+            for s in ob.sample:
+                if s % 5 == 0:
+                    ob.a.BeatriceBatch_SetTargetSpeaker(None, s, (s + 1) % 3)
+        want = ob.convert_rows(audio[:, h * 160:(h + 1) * 160])
+        dev = max(dev, float(np.abs(whole[h][ob.sample] - want).max()))
+    ob.close()
+    print("B=%d in-order chain (row-local block kernels) vs ORACLE, streams %s: max-abs %g" % (B, ob.sample, dev))
+    assert dev <= TOL

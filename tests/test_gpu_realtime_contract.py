@@ -76,3 +76,46 @@ def test_codebook_rewritten_in_place_is_reuploaded(bv, oracle, product, model_di
         outs[name] = out
     assert np.array_equal(outs["oracle"], outs["hip"])
     assert not np.array_equal(outs["hip"][5], outs["hip"][7])
+
+
+def test_reloading_parameters_into_the_same_model_objects(bv, oracle, product, model_dir, tmp_path):
+    """Read*Parameters on model objects that contexts have already run with (the device blobs are freed and re-allocated):
+    the contexts' captured hop graphs are keyed on the blob, so the next hop re-captures instead of replaying kernels that
+    read freed memory, and a k-NN toggle afterwards finds its variant captured already.  Same calls on the oracle."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import make_model
+    d2 = str(tmp_path / "other")
+    make_model.make_model(d2, n_speakers=3, seed=0x51C0)
+    hops = 18
+    x = bv.synth_audio(160 * hops, seed=77)
+    outs = {}
+    for name, abi in (("oracle", oracle), ("hip", product)):
+        m = bv.Models(abi, model_dir)
+        st = bv.Stream1(m, speaker=1, vq_k=2)
+        out = []
+        for h in range(hops):
+            if h == 6:   # new parameters into the SAME objects; tables and conditioning re-applied as a host does after LoadModel
+                for obj, fn, fname in ((m.phone, abi.ReadPhoneExtractorParameters, "phone_extractor.bin"),
+                                       (m.pitch, abi.ReadPitchEstimatorParameters, "pitch_estimator.bin"),
+                                       (m.wave, abi.ReadWaveformGeneratorParameters, "waveform_generator.bin"),
+                                       (m.embed, abi.ReadEmbeddingSetterParameters, "embedding_setter.bin")):
+                    assert fn(obj, os.path.join(d2, fname).encode()) == 0
+                m.tables = bv.SpeakerTables(abi, d2)
+                st.set_target_speaker(2)
+                while st.set_kv_block():
+                    pass
+                st.set_formant_index(4)
+            if h == 11:
+                abi.SetVQNumNeighbors(st.pc, 0)     # the other graph variant
+            if h == 14:
+                abi.SetVQNumNeighbors(st.pc, 3)
+            out.append(st.hop(x[h * 160:(h + 1) * 160]))
+        outs[name] = np.stack(out)
+        st.close()
+        m.close()
+    dev = float(np.abs(outs["hip"] - outs["oracle"]).max())
+    print("parameters reloaded into live model objects: max-abs %g" % dev)
+    assert np.abs(outs["hip"][7:]).max() > 1e-3
+    assert dev <= 1e-4

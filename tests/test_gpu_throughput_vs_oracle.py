@@ -1,0 +1,87 @@
+"""The throughput mode the bench times (tick pipelining over resident I/O) against the ORACLE directly -- not against the
+in-order HIP chain -- on the bench's own workload and over runs long enough for every ring of the pipeline to wrap many
+times (the deepest ring of a stage boundary holds ~30 step slots; the resident I/O ring 32-64)."""
+import numpy as np
+import pytest
+
+from oracle_batch import oracle_leg
+from tick_driver import run_tick
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4   # north_star's bound on output PCM; observed 0.0
+
+
+def test_bench_workload_in_tick_mode_matches_oracle(bv, oracle, product, model_dir):
+    """bench.py's headline: BASELINE.json configs[2] -- 256 streams, 1 speaker, k-NN 0, every tenth stream with 0.5 s of
+    digital silence, 64 resident hops per stream cycled as I/O slots, steps enqueued without waiting.  100 steps (the slot
+    ring wraps), a sample of 12 streams (silence-gap streams 3, 13, 253 among them) against independent oracle streams."""
+    B, n_cycle, steps = 256, 64, 100
+    audio = np.stack([bv.synth_audio(160 * n_cycle, seed=s, silence_gap=(s % 10 == 3)) for s in range(B)]).reshape(B, n_cycle, 160)
+
+    def settings(batch):
+        batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, -1, 0)
+        batch.a.BeatriceBatch_FlushSpeaker(batch.h, -1)
+
+    def hop_input(k):
+        return audio[:, k % n_cycle]
+
+    m = bv.Models(product, model_dir)
+    batch = bv.Batch(m, B)
+    settings(batch)
+    got = run_tick(bv, batch, steps, hop_input, slots=n_cycle)
+    batch.close()
+    m.close()
+    assert np.all(np.abs(got).reshape(steps, B, -1).max(axis=(0, 2)) > 1e-3)     # every stream produces sound
+    sample = [0, 3, 13, 15, 16, 31, 32, 127, 128, 253, 254, 255]
+    sample, want = oracle_leg(bv, oracle, model_dir, B, hop_input, steps, settings, lambda b, k: None, sample)
+    dev = float(np.abs(got[:, sample] - want).max())
+    print("bench workload, tick mode vs ORACLE: %d streams x %d steps, max-abs %g %s"
+          % (len(sample), steps, dev, "bit-identical" if np.array_equal(got[:, sample], want) else ""))
+    assert dev <= TOL
+
+
+@pytest.mark.parametrize("B,steps", [(8, 330)])
+def test_tick_soak_vs_oracle(bv, oracle, product, model_dir, B, steps):
+    """Soak: every stream of a small batch for 330 hops in tick mode against independent oracle streams driven through the
+    reference protocol (processor_core_2.cc:50-256; a switch installs one K/V block per hop, :179-181): speaker switches
+    throughout, k-NN on / off / changed, formant and pitch settings, pitch range, two stream resets -- early, in the middle and
+    near the end, so that every ring of the pipeline has wrapped several times when they arrive."""
+    audio = np.stack([bv.synth_audio(160 * steps, seed=7700 + s, silence_gap=(s == 5)) for s in range(B)]).reshape(B, steps, 160)
+
+    def settings(batch):
+        for s in range(B):
+            batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, s, s % 3)
+            batch.a.BeatriceBatch_SetVQNumNeighbors(batch.h, s, (0, 1, 4)[s % 3])
+        batch.a.BeatriceBatch_FlushSpeaker(batch.h, -1)
+
+    def change(batch, k):
+        a, h = batch.a, batch.h
+        if k % 23 == 7:
+            a.BeatriceBatch_SetTargetSpeaker(h, (k // 23) % B, (k // 23 + 1) % 3)      # K/V blocks follow, one per hop
+        if k % 31 == 11:
+            a.BeatriceBatch_SetVQNumNeighbors(h, (k // 31 + 2) % B, (k // 31) % 9)    # 0 turns the codebook off
+        if k % 41 == 13:
+            a.BeatriceBatch_SetFormantShift(h, (k // 41 + 3) % B, float(k % 5) - 2.0)
+            a.BeatriceBatch_SetPitchShift(h, (k // 41 + 4) % B, float(k % 9) - 4.0)
+        if k in (61, 211):
+            assert a.BeatriceBatch_ResetStream(h, 6 if k == 61 else 1) == 0
+        if k == 150:
+            a.BeatriceBatch_SetMinSourcePitch(h, 0, 48.0)
+            a.BeatriceBatch_SetMaxSourcePitch(h, 0, 70.0)
+            a.BeatriceBatch_SetPitchCorrection(h, 2, 0.6)
+            a.BeatriceBatch_SetPitchCorrectionType(h, 2, 1)
+        if k == 300:
+            a.BeatriceBatch_SetTargetSpeaker(h, -1, 2)                                # everyone, near the end
+
+    m = bv.Models(product, model_dir)
+    batch = bv.Batch(m, B)
+    settings(batch)
+    got = run_tick(bv, batch, steps, lambda k: audio[:, k], change, chunk=29)          # (chunks of 29: drains land everywhere)
+    batch.close()
+    m.close()
+    sample, want = oracle_leg(bv, oracle, model_dir, B, lambda k: audio[:, k], steps, settings, change, list(range(B)))
+    bad = sorted({int(k) for k in np.nonzero(np.abs(got - want).reshape(steps, -1).max(axis=1) > TOL)[0]})
+    dev = float(np.abs(got - want).max())
+    print("tick soak vs ORACLE: %d streams x %d steps, max-abs %g %s" % (B, steps, dev, "bit-identical" if np.array_equal(got, want) else ""))
+    assert np.abs(got).max() > 0.05
+    assert not bad, "steps beyond tolerance: %s" % bad[:20]

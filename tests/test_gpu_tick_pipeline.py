@@ -5,13 +5,14 @@ settings), across pipeline drains, a stream reset in mid-flight, and the return 
 import numpy as np
 import pytest
 
+from oracle_batch import oracle_leg, pick_streams, scripted_streams
 from test_gpu_resident_io import Hip
 
 pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("B,steps,vq_from_start", [(24, 75, True), (5, 60, False), (256, 50, True), (600, 45, True), (1, 40, True), (17, 40, False), (33, 36, True), (40, 420, True)])
-def test_tick_pipeline_matches_in_order_chain(bv, product, model_dir, B, steps, vq_from_start):
+def test_tick_pipeline_matches_in_order_chain(bv, oracle, product, model_dir, B, steps, vq_from_start):
     hip = Hip()
     m = bv.Models(product, model_dir)
     bv.bind_batch(product)
@@ -111,6 +112,13 @@ def test_tick_pipeline_matches_in_order_chain(bv, product, model_dir, B, steps, 
     assert np.abs(got).max() > 0.05
     assert not bad
     assert np.array_equal(q, ref_q)
+    # the ORACLE leg: a sample of the streams (tile corners + the streams the script addresses) as independent oracle
+    # streams driven by the same script through the reference protocol -- the tick pipeline against the oracle directly
+    sample = sorted(set(pick_streams(B, 6)) | set(scripted_streams(B, total, change, 6)))
+    sample, want = oracle_leg(bv, oracle, model_dir, B, lambda k: audio_all[:, k * 160:(k + 1) * 160], total, settings, change, sample)
+    dev = float(np.abs(got[:, sample] - want).max())
+    print("tick pipeline vs ORACLE, streams %s, %d steps: max-abs %g" % (sample, total, dev))
+    assert dev <= 1e-4
 
 
 def test_tick_pipeline_with_a_morph_slot(bv, product, model_dir):

@@ -55,7 +55,7 @@ def test_device_wrapper_48k_matches_host_chain(bv, oracle, product, model_dir, B
 
 
 @pytest.mark.parametrize("B,channels,blocks", [(5, 2, 70), (64, 2, 45)])
-def test_48k_wrapper_around_the_tick_pipeline_matches_in_order(bv, product, model_dir, B, channels, blocks):
+def test_48k_wrapper_around_the_tick_pipeline_matches_in_order(bv, oracle, product, model_dir, B, channels, blocks):
     """BeatriceBatch_BindResidentIO48k: resident 48 kHz slots, the tick pipeline in between; block k's converted samples
     land in slot k mod n_slots (pipeline depth later).  Must equal the in-order device wrapper block for block, across a
     wrap of the slot ring and a drain in the middle."""
@@ -119,6 +119,56 @@ def test_48k_wrapper_around_the_tick_pipeline_matches_in_order(bv, product, mode
     for k in range(blocks):
         assert np.array_equal(got[k], want[k]), "block %d differs" % k
     assert a.BeatriceBatch_BindResidentIO48k(h, None, None, 0, 0) == 0
+    # the ORACLE leg: a sample of the streams as the host chain -- the ref-pinned wrapper oracle around an independent oracle
+    # stream, the same script applied before each block; a reset restarts the stream's wrapper too (SetSampleRate semantics)
+    import ctypes as C
+    from oracle_batch import OracleBatch, pick_streams, scripted_streams
+    sample = sorted(set(pick_streams(B, 4)) | set(scripted_streams(B, blocks, change, 4)))
+    ob = OracleBatch(bv, oracle, model_dir, B, sample=sample)
+    settings(ob)
+    wl = wrapperlib.oracle_wrapper()
+    wrappers, callbacks = {}, {}
+
+    def make_wrapper(s):
+        def hop(in160, out240, _u, s=s):
+            o = ob.st[s]["s1"].hop(np.ctypeslib.as_array(in160, (160,)).copy())
+            C.memmove(out240, o.ctypes.data, 240 * 4)
+        if s in wrappers:
+            wl.f_destroy(wrappers[s])
+        callbacks[s] = wrapperlib.HOP_FN(hop)
+        wrappers[s] = wl.f_create(48000.0, callbacks[s], None)
+
+    class Script:   # what `change` sees: the oracle streams, plus the wrapper restart that goes with a stream reset
+        def __init__(self):
+            self.h, self.a = None, self
+
+        def BeatriceBatch_ResetStream(self, h_, stream):
+            rc = ob.a.BeatriceBatch_ResetStream(h_, stream)
+            if stream in wrappers:
+                make_wrapper(stream)
+            return rc
+
+        def __getattr__(self, name):
+            return getattr(ob.a, name)
+
+    script = Script()
+    for s_ in ob.sample:
+        make_wrapper(s_)
+    dev = 0.0
+    for k in range(blocks):
+        change(script, k)
+        for s_ in ob.sample:
+            blk_in = x[s_, :, 480 * k:480 * (k + 1)]
+            mono = np.ascontiguousarray(blk_in[0] if channels == 1 else ((blk_in[0] + blk_in[1]) * np.float32(0.5)).astype(np.float32))
+            y = np.zeros(480, np.float32)
+            assert wl.f_process(wrappers[s_], bv.fptr(mono), bv.fptr(y), 480) == 0
+            for c in range(channels):
+                dev = max(dev, float(np.abs(got[k][s_, c] - y).max()))
+    for s_ in ob.sample:
+        wl.f_destroy(wrappers[s_])
+    ob.close()
+    print("48k wrapper around the tick pipeline vs ORACLE host chain, streams %s, %d blocks: max-abs %g" % (ob.sample, blocks, dev))
+    assert dev <= 1e-4
     # in order again on the same streams (wrapper and model state carried over)
     y = batch.convert48k(np.ascontiguousarray(x[:, :, :480]), channels)
     assert np.isfinite(y).all()

@@ -285,3 +285,61 @@ def test_vst_shell_block_handling(built, model_dir):
     o = np.zeros(n, np.float32)
     assert r.call("ProcessChannels", mono[:n].ctypes.data_as(_f32p), None, o.ctypes.data_as(_f32p), None, n) == 0
     assert np.array_equal(o, want[:n])
+
+
+def test_wrongly_typed_state_records_cannot_poison_the_table(built, model_dir):
+    """A state blob is untrusted input.  Records of KNOWN ids whose type differs from the schema's (a morph cursor typed
+    int, a marker typed string, the voice typed float64) are dropped -- the defaults stay -- so no later typed read can
+    throw across the C boundary; unknown ids keep whatever they carry; the typed setters refuse a wrong kind."""
+    p = Proxy()
+    assert p.call("LoadModel", _toml(model_dir)) == OK
+    path = _toml(model_dir)
+    blob = b"".join([
+        struct.pack("<hii", K_MODEL, 2, len(path)) + path,             # (a state without the model path unloads the core)
+        struct.pack("<hii", K_VOICE, 0, 2),                            # fine: voice 2
+        struct.pack("<hid", K_VOICE, 1, 1.0),                          # wrong: the voice is an int (dropped; 2 stays)
+        struct.pack("<hii", K_CURSOR_X, 0, 1),                         # wrong: a morph number typed int
+        struct.pack("<hii", K_MARKER_X0 + 1, 2, 3) + b"abc",           # wrong: a morph number typed string
+        struct.pack("<hid", K_FALLOFF, 1, 3.0),                        # fine, and its sync reads ALL the morph ids
+        struct.pack("<hii", 777, 2, 2) + b"zz",                        # unknown id: kept
+    ])
+    assert p.call("ReadState", blob, len(blob)) == OK
+    assert p.call("GetKind", K_VOICE) == 0 and p.call("GetNumber", K_VOICE) == 2.0
+    assert p.call("GetKind", K_CURSOR_X) == 1 and p.call("GetNumber", K_CURSOR_X) == 0.5
+    assert p.call("GetKind", K_MARKER_X0 + 1) == 1 and abs(p.call("GetNumber", K_MARKER_X0 + 1) - 0.82) < 1e-6
+    assert p.call("GetNumber", K_FALLOFF) == 3.0
+    buf = C.create_string_buffer(8)
+    assert p.call("GetString", 777, buf, 8) == 2 and buf.value == b"zz"
+    w = np.zeros(256, np.float32)
+    p.call("MorphWeights", w.ctypes.data_as(_f32p))                    # used to terminate the process on a poisoned table
+    assert abs(float(w.sum()) - 1.0) < 1e-5
+    # getters on ids that hold nothing: no throw, neutral answers
+    assert p.call("GetKind", 9999) == -1 and p.call("GetNumber", 9999) == 0.0 and p.call("GetString", 9999, buf, 8) == -1
+    # the typed setters refuse the wrong kind for a known id and leave the value alone
+    assert p.call("SetInt", K_CURSOR_X, 1) == UNKNOWN and p.call("GetNumber", K_CURSOR_X) == 0.5
+    assert p.call("SetNumber", K_VOICE, 1.0) == UNKNOWN and p.call("GetNumber", K_VOICE) == 2.0
+    assert p.call("SetString", K_FORMANT, b"x") == UNKNOWN
+    assert p.call("SetNumber", K_CURSOR_X, 0.25) == OK
+    x = _signal(480 * 4)
+    out, codes = p.process(x)
+    assert set(codes) == {OK} and np.isfinite(out).all()
+    p.close()
+
+
+def test_deeply_nested_toml_is_a_syntax_error_not_a_crash(built, model_dir, tmp_path):
+    """toml_subset parses arrays and inline tables by recursion; a hostile model.toml must end as kTOMLSyntaxError (the
+    silent unloaded core), not as a stack overflow."""
+    import shutil
+    d = tmp_path / "deep"
+    shutil.copytree(model_dir, d)
+    text = open(os.path.join(model_dir, "model.toml")).read()
+    for opener, closer in (("[", "]"), ("{ a = ", " }")):
+        (d / "model.toml").write_text(text + "\nevil = " + opener * 200000 + "1" + closer * 200000 + "\n")
+        p = Proxy()
+        assert p.call("LoadModel", str(d / "model.toml").encode()) == TOML_SYNTAX
+        assert p.call("CoreVersion") == -1
+        p.close()
+    (d / "model.toml").write_text(text + "\nfine = " + "[" * 40 + "1" + "]" * 40 + "\n")      # 40 levels are fine
+    p = Proxy()
+    assert p.call("LoadModel", str(d / "model.toml").encode()) == OK
+    p.close()
