@@ -574,7 +574,21 @@ bool tick_build_table(BeatriceBatch* b) {
       default: tb->add<T_BLKA8>(rc::BlockAOp<8>::info(aa), aa, rc::BlockAOp<8>::grid(aa), pl.blk(blk), keep(5), 41); break;
     }
   }
-  { TailArgs ta = tail_args(ww, ws); ta.hop = hp(pl.tail()); tb->add<T_TAIL>(tail_info(ws), ta, dim3(B, 1), pl.tail(), keep(4), 41, true); }
+  if (!pl.split_tail) {
+    TailArgs ta = tail_args(ww, ws); ta.hop = hp(pl.tail()); tb->add<T_TAIL>(tail_info(ws), ta, dim3(B, 1), pl.tail(), keep(4), 41, true);
+  } else {
+    // the tail as three stages, several streams per workgroup (tail_stages.hip.h); same weights, same state block
+    tst::StageArgs t1{}, t2{}, t3{};
+    t1.in = ws.ya2; t1.out = ws.ya3; t2.in = ws.ya3; t2.out = ws.ya4; t3.in = ws.ya4;
+    for (tst::StageArgs* t : {&t1, &t2, &t3}) { t->state = ws.tail.base; t->hop = nullptr; t->B = B; }
+    t1.w[0] = ww.ra_w[1]; t1.b[0] = ww.ra_b[1]; t1.w[1] = ww.rb_w[1]; t1.b[1] = ww.rb_b[1]; t1.w[2] = ww.up_w[2]; t1.b[2] = ww.up_b[2];
+    t2.w[0] = ww.ra_w[2]; t2.b[0] = ww.ra_b[2]; t2.w[1] = ww.rb_w[2]; t2.b[1] = ww.rb_b[2]; t2.w[2] = ww.up_w[3]; t2.b[2] = ww.up_b[3];
+    t3.w[0] = ww.ra_w[3]; t3.b[0] = ww.ra_b[3]; t3.w[1] = ww.rb_w[3]; t3.b[1] = ww.rb_b[3];
+    t3.fin_w = ww.fin_w; t3.fin_b = ww.fin_b; t3.d_out = ws.d_out; t3.io_stride = ws.io_stride;
+    tb->add<T_TAIL1>(tst::T1Op::info(t1), t1, tst::T1Op::grid(t1), pl.tail(), keep(4), 30, true);
+    tb->add<T_TAIL2>(tst::T2Op::info(t2), t2, tst::T2Op::grid(t2), pl.tail() + 1, keep(4), 28, true);
+    tb->add<T_TAIL3>(tst::T3Op::info(t3), t3, tst::T3Op::grid(t3), pl.tail() + 2, keep(4), 16, true);
+  }
   // ---- everything else, longest workgroups first (they start when the heavy ones above leave their slots)
   { const ConvArgs a = conv(ps.f[1], ps.f[2], pw.f_w[1], pw.f_b[1], Plan::F3); tb->add<T_F3>(OpF3::info("phone.f3", a), a, OpF3::grid(a), Plan::F3, keep(6), 18); }
   { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], pl.up1()); tb->add<T_UP1>(OpUP1::info("wave.up1", a), a, OpUP1::grid(a), pl.up1(), keep(7), 36); }

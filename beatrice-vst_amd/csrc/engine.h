@@ -172,6 +172,8 @@ struct WaveState {
                             // (rounded up to a slot count that divides the step counter's wrap)
   Ring ya1, yb1, yc1, ya2;  // upsampler stage 1 and the stage-2 transposed conv output
   Ring tail;                // per-stream history block of the fused upsampler tail (wave_tail.hip.h)
+  Ring ya3, ya4;            // batch with pipeline slack only: the frames between the three tail stages of the tick launch
+                            // (tail_stages.hip.h): 32 ch x 80 and 16 ch x 240 frames per step, two step slots each
   // inputs (device): phone [B][H][128], q [B][H], feat [B][H][4]; owned unless shared with other modules
   float* d_phone = nullptr; int* d_q = nullptr; float* d_feat = nullptr;
   int q_slots = 1;  // step slots of d_q / d_feat (PitchState::q_slots when shared)

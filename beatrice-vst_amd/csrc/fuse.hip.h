@@ -178,13 +178,14 @@ __device__ __forceinline__ void table_body(const Table<Ms...>* __restrict__ t, c
   __syncthreads();
   unsigned long long* const trace = t->trace;
   const unsigned long long t0 = trace ? wall_clock64() : 0;
+  const unsigned long long c0 = trace ? __builtin_readcyclecounter() : 0;   // shader clock (the wall clock is 100 MHz): their ratio = the clock the launch ran at
   // (a body spread over the XCDs is eight spans; span k owns the body's workgroups k, k + 8, ...: arg bits 8-11 = k, bit 12 set)
   const int local = id - sp.first;
   const int body_wg = (sp.arg & 0x1000) ? local * 8 + ((sp.arg >> 8) & 15) : local;
   sp.arg &= 0xff;
   run_type<0, MaxM<Ms...>::NTHR, Ms...>(t->banks, sp, body_wg, lds);
   if (trace && threadIdx.x == 0) {
-    trace[3 * (size_t)blockIdx.x] = t0; trace[3 * (size_t)blockIdx.x + 1] = wall_clock64(); trace[3 * (size_t)blockIdx.x + 2] = (unsigned long long)sp.type;
+    trace[3 * (size_t)blockIdx.x] = t0; trace[3 * (size_t)blockIdx.x + 1] = wall_clock64(); trace[3 * (size_t)blockIdx.x + 2] = (unsigned long long)sp.type | ((__builtin_readcyclecounter() - c0) << 8);
   }
 }
 

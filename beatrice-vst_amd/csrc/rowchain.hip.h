@@ -24,6 +24,15 @@
 #include "ring.h"
 #include "spec_math.hip.h"
 
+// Measurement aid (tools/debug/build_variant.sh ... -DABL_WEIGHTS_HOT): every weight-fragment prefetch re-reads the segment's
+// first k-blocks, so the weight stream hits the CU's L1 -- results are WRONG; the build exists to time the launch without
+// its L2 / Infinity Cache weight traffic.  Never defined in the product build.
+#ifdef ABL_WEIGHTS_HOT
+#define ABL_KB(x) ((x) & 1)
+#else
+#define ABL_KB(x) (x)
+#endif
+
 namespace rc {
 
 constexpr int NTHR = 512, NWAVE = 8;
@@ -37,6 +46,20 @@ constexpr int STILE = 16 * SS;
 // tile 0 / k-block 0 of the segment; consecutive column tiles of the wavefront are `tile_stride` float4 apart.
 // B fragments are fetched four k-blocks ahead of their use (an L2 round trip is ~200-500 cycles, a k-block is
 // 4 CG MFMAs = 128 CG cycles of the SIMD's matrix pipe; eight ahead measured 2 % better than four at two column tiles).
+// Software pipeline, pinned: left alone the compiler SINKS the prefetch loads to just in front of their first use (to save
+// registers), so that every k-block waits a full L2 round trip -- the ISA of round 2's build showed `global_load ... ;
+// s_waitcnt vmcnt(0); v_mfma` throughout, and a wavefront's MFMA density was ~27 %.  A __builtin_amdgcn_sched_barrier(0)
+// between "issue the loads of k-block i + D (weights) and i + 1 (A operand)" and "the MFMAs of k-block i" forbids that: loads
+// may still float among the MFMAs of the PREVIOUS k-block, never behind the ones that were meant to hide them.
+#ifndef RC_PIN_PIPELINE
+#define RC_PIN_PIPELINE 1
+#endif
+__device__ __forceinline__ void pin_pipeline() {
+#if RC_PIN_PIPELINE
+  asm volatile("" ::: "memory");        // IR level: optimisation passes hoist invariant weight loads across a bare sched_barrier call
+  __builtin_amdgcn_sched_barrier(0);    // machine scheduler: nothing crosses
+#endif
+}
 template <int CG, int KB>
 __device__ __forceinline__ void mma_segment_p(f32x4 (&acc)[CG], const float* __restrict__ a, const float4* const (&wf)[CG]) {
 #ifndef RC_PREFETCH
@@ -45,10 +68,12 @@ __device__ __forceinline__ void mma_segment_p(f32x4 (&acc)[CG], const float* __r
   constexpr int D = CG <= 2 ? RC_PREFETCH : (CG <= 3 ? 4 : 2);  // prefetch depth in k-blocks (registers: D * CG float4)
   static_assert(KB % D == 0, "segment length");
   float4 bq[D][CG];
+  pin_pipeline();   // (the segment's first loads stay behind what precedes it: hoisted over an epilogue they only add register pressure)
 #pragma unroll
   for (int d = 0; d < D; ++d)
 #pragma unroll
     for (int c = 0; c < CG; ++c) bq[d][c] = wf[c][(size_t)d * 64];
+  float an[4] = {a[0], a[4], a[8], a[12]};   // A operand of the k-block to come (one k-block ahead: LDS latency behind 4 CG MFMAs)
 #pragma unroll
   for (int kb = 0; kb < KB; kb += D) {
 #pragma unroll
@@ -56,12 +81,16 @@ __device__ __forceinline__ void mma_segment_p(f32x4 (&acc)[CG], const float* __r
       float4 cur[CG];
 #pragma unroll
       for (int c = 0; c < CG; ++c) cur[c] = bq[d][c];
+      const float a0 = an[0], a1 = an[1], a2 = an[2], a3 = an[3];
       if (kb + d + D < KB) {
 #pragma unroll
-        for (int c = 0; c < CG; ++c) bq[d][c] = wf[c][(size_t)(kb + d + D) * 64];
+        for (int c = 0; c < CG; ++c) bq[d][c] = wf[c][(size_t)ABL_KB(kb + d + D) * 64];
       }
-      const float* ap = a + (kb + d) * 16;
-      const float a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
+      if (kb + d + 1 < KB) {
+        const float* ap = a + (kb + d + 1) * 16;
+        an[0] = ap[0]; an[1] = ap[4]; an[2] = ap[8]; an[3] = ap[12];
+      }
+      pin_pipeline();
 #pragma unroll
       for (int c = 0; c < CG; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, cur[c].x, acc[c], 0, 0, 0);
 #pragma unroll
@@ -81,10 +110,17 @@ __device__ __forceinline__ void mma_segment_rt(f32x4 (&acc)[RT][CG], const float
   constexpr int D = RT * CG <= 2 ? 8 : 4;  // prefetch depth in k-blocks (registers: D * CG float4)
   static_assert(KB % D == 0, "segment length");
   float4 bq[D][CG];
+  pin_pipeline();
 #pragma unroll
   for (int d = 0; d < D; ++d)
 #pragma unroll
     for (int c = 0; c < CG; ++c) bq[d][c] = wf[c][(size_t)d * 64];
+  float an[RT][4];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    const float* ap = a + t * a_tile_stride;
+    an[t][0] = ap[0]; an[t][1] = ap[4]; an[t][2] = ap[8]; an[t][3] = ap[12];
+  }
 #pragma unroll
   for (int kb = 0; kb < KB; kb += D) {
 #pragma unroll
@@ -92,16 +128,21 @@ __device__ __forceinline__ void mma_segment_rt(f32x4 (&acc)[RT][CG], const float
       float4 cur[CG];
 #pragma unroll
       for (int c = 0; c < CG; ++c) cur[c] = bq[d][c];
-      if (kb + d + D < KB) {
-#pragma unroll
-        for (int c = 0; c < CG; ++c) bq[d][c] = wf[c][(size_t)(kb + d + D) * 64];
-      }
       float av[RT][4];
 #pragma unroll
-      for (int t = 0; t < RT; ++t) {
-        const float* ap = a + t * a_tile_stride + (kb + d) * 16;
-        av[t][0] = ap[0]; av[t][1] = ap[4]; av[t][2] = ap[8]; av[t][3] = ap[12];
+      for (int t = 0; t < RT; ++t) { av[t][0] = an[t][0]; av[t][1] = an[t][1]; av[t][2] = an[t][2]; av[t][3] = an[t][3]; }
+      if (kb + d + D < KB) {
+#pragma unroll
+        for (int c = 0; c < CG; ++c) bq[d][c] = wf[c][(size_t)ABL_KB(kb + d + D) * 64];
       }
+      if (kb + d + 1 < KB) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          const float* ap = a + t * a_tile_stride + (kb + d + 1) * 16;
+          an[t][0] = ap[0]; an[t][1] = ap[4]; an[t][2] = ap[8]; an[t][3] = ap[12];
+        }
+      }
+      pin_pipeline();
 #pragma unroll
       for (int t = 0; t < RT; ++t)
 #pragma unroll

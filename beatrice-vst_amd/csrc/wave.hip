@@ -35,6 +35,10 @@ bool WaveState::create(int B_, int H_, int n_slots_, int n_add_, int n_frm_, flo
   specs.push_back({&yc1, 128, 5 * H, slots(5, 1) + ps});   // history 1 (up2)
   specs.push_back({&ya2, 64, 20 * H, fit(slots(20, 2) + xs)});  // history 2 (first layer of the fused tail)
   specs.push_back({&tail, TAIL_STATE_FLOATS, 1, 1});
+  if (pipe_slack) {  // the tail as three pipeline stages (tail_stages.hip.h): writer and reader are one tick apart
+    specs.push_back({&ya3, 32, 80 * H, 2});
+    specs.push_back({&ya4, 16, 240 * H, 2});
+  }
   if (!arena.build(B, specs)) return false;
   if (shared_phone) { d_phone = shared_phone; d_q = shared_q; d_feat = shared_feat; owns_inputs = false; }
   else {

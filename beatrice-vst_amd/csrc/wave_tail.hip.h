@@ -53,8 +53,13 @@ struct TailArgs {
 };
 #ifdef TAIL_TIMING
 #define TAIL_STAMP(i) do { if (tid == 0) a.stamps[b * 16 + (i)] = wall_clock64(); } while (0)
+// finer split, accumulated over the layers by wavefront 0 (tools/microbench/tail_timing.hip): k = 0 MFMA loop, 1 epilogue,
+// 2 history rows in + barrier wait, 3 history rows out (shader cycles)
+namespace tail { __shared__ unsigned long long sub_acc[4]; __shared__ unsigned long long sub_t; }
+#define TAIL_SUB(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); tail::sub_acc[k] += now_ - tail::sub_t; tail::sub_t = now_; } } while (0)
 #else
 #define TAIL_STAMP(i) do { } while (0)
+#define TAIL_SUB(k) do { } while (0)
 #endif
 
 namespace tail {
@@ -145,6 +150,7 @@ __device__ __forceinline__ void layer(const float* __restrict__ in, float* __res
       }
     }
   }
+  TAIL_SUB(0);
 #pragma unroll
   for (int rt = 0; rt < S::RT; ++rt) {
     const int mt = wm + rt * S::NWM;
@@ -171,6 +177,7 @@ __device__ __forceinline__ void layer(const float* __restrict__ in, float* __res
       }
     }
   }
+  TAIL_SUB(1);
 }
 
 // history rows: LDS state block <-> LDS activation buffer rows
@@ -204,6 +211,9 @@ __device__ __forceinline__ void wave_tail_body(const TailArgs& a, const int b, f
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* st = a.state + (size_t)b * TAIL_STATE_FLOATS;
   TAIL_STAMP(0);
+#ifdef TAIL_SETPRIO
+  __builtin_amdgcn_s_setprio(TAIL_SETPRIO);   // experiment: issue priority over the co-resident workgroup's wavefronts
+#endif
 
   // biases, output-conv taps and the stream's state block: one round of global loads
   const int hop = stepc::step(a.hop);
@@ -239,6 +249,9 @@ __device__ __forceinline__ void wave_tail_body(const TailArgs& a, const int b, f
   }
   __syncthreads();
   TAIL_STAMP(1);
+#ifdef TAIL_TIMING
+  if (tid == 0) { for (int k = 0; k < 4; ++k) tail::sub_acc[k] = 0; tail::sub_t = __builtin_readcyclecounter(); }
+#endif
   hist_in<64, 6>(R1, SI_ + TS_YB2, tid);
   // (R1's history rows are only read by res2b, after the next barrier)
 
@@ -247,7 +260,9 @@ __device__ __forceinline__ void wave_tail_body(const TailArgs& a, const int b, f
   layer<64, 64, 3, 1, 20, 2, 6, 0>(R0, R1, b_r2a, BIAS + BO[0], wave, lane);
   hist_in<64, 1>(R2, SI_ + TS_YC2, tid);
   __syncthreads();
+  TAIL_SUB(2);
   hist_out<64, 6>(SO_ + TS_YB2, R1, 20, tid);
+  TAIL_SUB(3);
   TAIL_STAMP(2);
 
   // ---- res2b (dil 3): R1 (H 6) -> R2 (H 1)
@@ -255,7 +270,9 @@ __device__ __forceinline__ void wave_tail_body(const TailArgs& a, const int b, f
   layer<64, 64, 3, 3, 20, 6, 1, 0>(R1, R2, b_r2b, BIAS + BO[1], wave, lane);
   hist_in<32, 2>(R0, SI_ + TS_YA3, tid);
   __syncthreads();
+  TAIL_SUB(2);
   hist_out<64, 1>(SO_ + TS_YC2, R2, 20, tid);
+  TAIL_SUB(3);
   TAIL_STAMP(3);
 
   // ---- up3 (x4): R2 (H 1, 20 frames of 64) -> R0 (H 2, 80 frames of 32)
@@ -263,7 +280,9 @@ __device__ __forceinline__ void wave_tail_body(const TailArgs& a, const int b, f
   layer<64, 128, 2, 1, 20, 1, 2, 4>(R2, R0, b_u3, BIAS + BO[2], wave, lane);
   hist_in<32, 6>(R1, SI_ + TS_YB3, tid);
   __syncthreads();
+  TAIL_SUB(2);
   hist_out<32, 2>(SO_ + TS_YA3, R0, 80, tid);
+  TAIL_SUB(3);
   TAIL_STAMP(4);
 
   // ---- res3a: R0 (H 2) -> R1 (H 6)
@@ -271,7 +290,9 @@ __device__ __forceinline__ void wave_tail_body(const TailArgs& a, const int b, f
   layer<32, 32, 3, 1, 80, 2, 6, 0>(R0, R1, b_r3a, BIAS + BO[3], wave, lane);
   hist_in<32, 1>(R2, SI_ + TS_YC3, tid);
   __syncthreads();
+  TAIL_SUB(2);
   hist_out<32, 6>(SO_ + TS_YB3, R1, 80, tid);
+  TAIL_SUB(3);
   TAIL_STAMP(5);
 
   // ---- res3b (dil 3): R1 (H 6) -> R2 (H 1)
@@ -279,7 +300,9 @@ __device__ __forceinline__ void wave_tail_body(const TailArgs& a, const int b, f
   layer<32, 32, 3, 3, 80, 6, 1, 0>(R1, R2, b_r3b, BIAS + BO[4], wave, lane);
   hist_in<16, 2>(R0, SI_ + TS_YA4, tid);
   __syncthreads();
+  TAIL_SUB(2);
   hist_out<32, 1>(SO_ + TS_YC3, R2, 80, tid);
+  TAIL_SUB(3);
   TAIL_STAMP(6);
 
   // ---- up4 (x3): R2 (H 1, 80 frames of 32) -> R0 (H 2, 240 frames of 16)
@@ -287,20 +310,26 @@ __device__ __forceinline__ void wave_tail_body(const TailArgs& a, const int b, f
   layer<32, 48, 2, 1, 80, 1, 2, 3>(R2, R0, b_u4, BIAS + BO[5], wave, lane);
   hist_in<16, 6>(R1, SI_ + TS_YB4, tid);
   __syncthreads();
+  TAIL_SUB(2);
   hist_out<16, 2>(SO_ + TS_YA4, R0, 240, tid);
+  TAIL_SUB(3);
   TAIL_STAMP(7);
 
   // ---- res4a: R0 (H 2) -> R1 (H 6)
   layer<16, 16, 3, 1, 240, 2, 6, 0>(R0, R1, b_r4a, BIAS + BO[6], wave, lane);
   hist_in<16, 6>(R2, SI_ + TS_YC4, tid);
   __syncthreads();
+  TAIL_SUB(2);
   hist_out<16, 6>(SO_ + TS_YB4, R1, 240, tid);
+  TAIL_SUB(3);
   TAIL_STAMP(8);
 
   // ---- res4b (dil 3): R1 (H 6) -> R2 (H 6)
   layer<16, 16, 3, 3, 240, 6, 6, 0>(R1, R2, b_r4b, BIAS + BO[7], wave, lane);
   __syncthreads();
+  TAIL_SUB(2);
   hist_out<16, 6>(SO_ + TS_YC4, R2, 240, tid);
+  TAIL_SUB(3);
   TAIL_STAMP(9);
 
   // ---- output conv: lrelu, Conv1d(16 -> 1, k7), tanh; one thread per sample, coalesced store
@@ -317,6 +346,9 @@ __device__ __forceinline__ void wave_tail_body(const TailArgs& a, const int b, f
   }  // hops of the step
   for (int e = tid; e < TAIL_STATE_FLOATS; e += NTHR) st[e] = SI_[e];
   TAIL_STAMP(10);
+#ifdef TAIL_TIMING
+  if (tid == 0) for (int k = 0; k < 4; ++k) a.stamps[b * 16 + 11 + k] = tail::sub_acc[k];
+#endif
 }
 
 template <int H>

@@ -1,11 +1,15 @@
 """Summarise a BEATRICE_HIP_TICK_TRACE dump: per body type, workgroup count and duration; makespan; slot utilisation."""
 import sys
 import numpy as np
-NAMES = "f1 fft f2 f3 f4 f5 p1 rb p23 pout head out cond inp up1 res1a res1b up2 qgru pgru vq tail blkA1 blkA2 blkA4 blkA8 blkB".split()
-d = np.loadtxt(sys.argv[1], dtype=np.int64)
+NAMES = "f1 fft f2 f3 f4 f5 p1 rb p23 pout head out cond inp up1 res1a res1b up2 qgru pgru vq tail tail1 tail2 tail3 blkA1 blkA2 blkA4 blkA8 blkB".split()
+d = np.loadtxt(sys.argv[1], dtype=np.uint64).astype(np.int64)
 d = d[d[:, 1] > 0]
 t0 = d[:, 0].min()
-start, end, typ = (d[:, 0] - t0) / 100.0, (d[:, 1] - t0) / 100.0, d[:, 2]   # 100 MHz -> us
+start, end, typ = (d[:, 0] - t0) / 100.0, (d[:, 1] - t0) / 100.0, d[:, 2] & 255   # 100 MHz -> us
+cyc = d[:, 2] >> 8
+long_ = (end - start) > 5.0
+if long_.any() and cyc[long_].sum() > 0:
+    print("shader clock over the workgroups longer than 5 us: %.0f MHz (shader cycles / wall time)" % (cyc[long_].sum() / (end - start)[long_].sum()))
 print("workgroups %d, makespan %.1f us, sum of workgroup time %.0f us -> %.1f workgroups resident on average" %
       (len(d), end.max(), (end - start).sum(), (end - start).sum() / end.max()))
 for t in sorted(set(typ.tolist())):

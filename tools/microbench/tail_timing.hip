@@ -2,10 +2,11 @@
 #define TAIL_TIMING
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include "wave_tail.hip.h"
-int main() {
-  const int B = 256;
+int main(int argc, char** argv) {
+  const int B = argc > 1 ? atoi(argv[1]) : 256;   // 256 = one workgroup per CU; 512 = two (as inside a tick launch)
   float *ring, *state, *w, *bias, *out; int* hop; unsigned long long* st;
   hipMalloc(&ring, B * 40 * 64 * 4); hipMalloc(&state, B * TAIL_STATE_FLOATS * 4); hipMalloc(&w, 1 << 20); hipMalloc(&bias, 4096);
   hipMalloc(&out, B * 240 * 4); hipMalloc(&hop, 4); hipMalloc(&st, B * 16 * 8);
@@ -24,5 +25,10 @@ int main() {
   }
   double tot = 0; for (int b = 0; b < B; ++b) tot += (double)(h[b * 16 + 10] - h[b * 16]);
   printf("total        %.2f us\n", tot / B * 0.01);
+  const char* sub[4] = {"MFMA loops", "epilogues", "history in + barrier wait", "history out"};
+  for (int k = 0; k < 4; ++k) {
+    double s = 0; for (int b = 0; b < B; ++b) s += (double)h[b * 16 + 11 + k];
+    printf("  wavefront 0, layers res2a..res4b: %-26s %.0f shader cycles\n", sub[k], s / B);
+  }
   return 0;
 }
