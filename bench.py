@@ -136,7 +136,7 @@ def measured_peaks():
     lib.peaks_mfma_f32_tflops.argtypes = [ctypes.c_int, ctypes.c_int]
     return {"hbm_copy_GBs": round(lib.peaks_hbm_copy_gbs(1 << 30, 5), 1), "mfma_f32_TFLOPs": round(lib.peaks_mfma_f32_tflops(20000, 3), 1),
             "spec": {"hbm_GBs": PEAK_HBM_GBS, "mfma_f32_TFLOPs": PEAK_FP32_MFMA_TFLOPS},
-            "how": "1 GiB float4 device-to-device copy (read + write); v_mfma_f32_16x16x4_f32 with 8 independent accumulators per wavefront, 32 wavefronts per CU"}
+            "how": "1 GiB non-temporal float4 device-to-device copy (read + write); v_mfma_f32_16x16x4_f32 with 2 independent accumulators per wavefront, 16 wavefronts per CU"}
 
 
 def saturation(bv, models, product, streams=8192, steps=30):
