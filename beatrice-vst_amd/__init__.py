@@ -257,6 +257,9 @@ _BATCH = {
     "BeatriceHip_LoadPitchEstimatorFromMemory": (C.c_int, [_vp, _vp, C.c_size_t]),
     "BeatriceHip_LoadWaveformGeneratorFromMemory": (C.c_int, [_vp, _vp, C.c_size_t]),
     "BeatriceHip_LoadEmbeddingSetterFromMemory": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "BeatriceHip_SetDevice": (C.c_int, [C.c_int]),
+    "BeatriceHip_GetDevice": (C.c_int, []),
+    "BeatriceBatch_Device": (C.c_int, [_vp]),
     "BeatriceHip_ModelBlob": (C.c_int, [C.c_int, _vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "BeatriceHip_ModelBlobReady": (C.c_int, [C.c_int, _vp]),
     "BeatriceBatch_Create": (_vp, [_vp, _vp, _vp, _vp, C.c_int, C.c_int]),

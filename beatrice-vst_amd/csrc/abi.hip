@@ -56,6 +56,7 @@ Beatrice_ErrorCode read_model_file(const char* path, uint32_t kind, long expect_
 
 template <class Obj>
 static Beatrice_ErrorCode install(Obj* m, std::vector<float>& host) {
+  const DeviceScope dev_(m->device);
   m->loaded = false;
   decltype(m->w)::pack_host(host.data());  // GEMM tensors -> MFMA-fragment order
   if (!m->blob.upload(host.data(), host.size())) return Beatrice_kFileOpenError;  // device failure
@@ -63,6 +64,14 @@ static Beatrice_ErrorCode install(Obj* m, std::vector<float>& host) {
   m->loaded = true;
   return Beatrice_kSuccess;
 }
+
+namespace { thread_local int t_target_device = -1; }
+int target_device() {
+  if (t_target_device >= 0) return t_target_device;
+  int cur = 0;
+  return hipGetDevice(&cur) == hipSuccess ? cur : -1;   // (-1: no usable GPU; the object is created unhealthy)
+}
+void set_target_device(int d) { t_target_device = d; }
 
 bool make_stream(hipStream_t* s) { BHIP_TRY(hipStreamCreateWithFlags(s, hipStreamNonBlocking)); return true; }
 
@@ -131,6 +140,7 @@ extern "C" {
 Beatrice20rc0_PhoneExtractor* Beatrice20rc0_CreatePhoneExtractor(void) { return new Beatrice20rc0_PhoneExtractor(); }
 void Beatrice20rc0_DestroyPhoneExtractor(Beatrice20rc0_PhoneExtractor* m) {
   if (!m) return;
+  const DeviceScope dev_(m->device);
   m->blob.release();
   delete m;
 }
@@ -144,6 +154,7 @@ Beatrice_ErrorCode Beatrice20rc0_ReadPhoneExtractorParameters(Beatrice20rc0_Phon
 // hop or a setter may need later -- state, pinned staging, the codebook pool -- is allocated here)
 Beatrice20rc0_PhoneContext1* Beatrice20rc0_CreatePhoneContext1(void) {
   auto* c = new Beatrice20rc0_PhoneContext1();
+  const DeviceScope dev_(c->device);
   constexpr size_t kCbFloats = (size_t)B_CODEBOOK * B_PHONE_CH, kSlotFloats = kCbFloats + B_CODEBOOK;
   c->ok = make_stream(&c->stream) && c->st.create(1, 1, nullptr) &&
           hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(float) * (B_IN_HOP + kMailboxWords + B_PHONE_CH), hipHostMallocDefault),
@@ -171,6 +182,7 @@ Beatrice20rc0_PhoneContext1* Beatrice20rc0_CreatePhoneContext1(void) {
 }
 void Beatrice20rc0_DestroyPhoneContext1(Beatrice20rc0_PhoneContext1* c) {
   if (!c) return;
+  const DeviceScope dev_(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (HopGraph& g : c->hop_graph) g.drop();
   if (c->own_sel[0]) {
@@ -211,6 +223,7 @@ static uint64_t codebook_print(const float* cb) {
 // allocation and no wait either way (the next ExtractPhone1 runs behind it on the context's stream).
 void Beatrice20rc0_SetCodebook(Beatrice20rc0_PhoneContext1* ctx, const float* codebook) {
   if (!ctx || !ctx->ok || !codebook) return;
+  const DeviceScope dev_(ctx->device);
   const uint64_t print = codebook_print(codebook);
   CodebookEntry* hit = nullptr;
   CodebookEntry* lru = &ctx->pool[0];
@@ -241,7 +254,8 @@ void Beatrice20rc0_SetCodebook(Beatrice20rc0_PhoneContext1* ctx, const float* co
 void Beatrice20rc0_ExtractPhone1(const Beatrice20rc0_PhoneExtractor* m, const float* input, float* output,
                                  Beatrice20rc0_PhoneContext1* ctx) {
   std::memset(output, 0, sizeof(float) * B_PHONE_CH);
-  if (!m || !m->loaded || !ctx || !ctx->ok) return;
+  if (!m || !m->loaded || !ctx || !ctx->ok || m->device != ctx->device) return;   // (model and context must live on one GPU)
+  const DeviceScope dev_(ctx->device);
   float* h_in = ctx->h_io;
   float* h_out = ctx->h_io + B_IN_HOP + kMailboxWords;
   std::memcpy(h_in, input, sizeof(float) * B_IN_HOP);
@@ -279,6 +293,7 @@ void Beatrice20rc0_ExtractPhone1(const Beatrice20rc0_PhoneExtractor* m, const fl
 Beatrice20rc0_PitchEstimator* Beatrice20rc0_CreatePitchEstimator(void) { return new Beatrice20rc0_PitchEstimator(); }
 void Beatrice20rc0_DestroyPitchEstimator(Beatrice20rc0_PitchEstimator* m) {
   if (!m) return;
+  const DeviceScope dev_(m->device);
   m->blob.release();
   delete m;
 }
@@ -291,6 +306,7 @@ Beatrice_ErrorCode Beatrice20rc0_ReadPitchEstimatorParameters(Beatrice20rc0_Pitc
 // ref beatrice.h:252-253
 Beatrice20rc0_PitchContext1* Beatrice20rc0_CreatePitchContext1(void) {
   auto* c = new Beatrice20rc0_PitchContext1();
+  const DeviceScope dev_(c->device);
   c->ok = make_stream(&c->stream) && c->st.create(1, 1, nullptr, false) &&
           hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(float) * (B_IN_HOP + kMailboxWords + 8), hipHostMallocDefault), "hipHostMalloc");
   if (c->ok) {  // step counter and bin range arrive with the input copy (mailbox behind the audio)
@@ -304,6 +320,7 @@ Beatrice20rc0_PitchContext1* Beatrice20rc0_CreatePitchContext1(void) {
 }
 void Beatrice20rc0_DestroyPitchContext1(Beatrice20rc0_PitchContext1* c) {
   if (!c) return;
+  const DeviceScope dev_(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->hop_graph.drop();
   if (c->own_sel[0]) { c->st.d_min_q = static_cast<int*>(c->own_sel[0]); c->st.d_max_q = static_cast<int*>(c->own_sel[1]); }
@@ -327,7 +344,8 @@ void Beatrice20rc0_EstimatePitch1(const Beatrice20rc0_PitchEstimator* m, const f
                                   Beatrice20rc0_PitchContext1* ctx) {
   *out_q = 1;
   std::memset(out_feat, 0, sizeof(float) * 4);
-  if (!m || !m->loaded || !ctx || !ctx->ok) return;
+  if (!m || !m->loaded || !ctx || !ctx->ok || m->device != ctx->device) return;
+  const DeviceScope dev_(ctx->device);
   float* h_in = ctx->h_io;
   float* h_feat = ctx->h_io + B_IN_HOP + kMailboxWords;
   int* h_q = reinterpret_cast<int*>(ctx->h_io + B_IN_HOP + kMailboxWords + 4);
@@ -353,6 +371,7 @@ void Beatrice20rc0_EstimatePitch1(const Beatrice20rc0_PitchEstimator* m, const f
 Beatrice20rc0_WaveformGenerator* Beatrice20rc0_CreateWaveformGenerator(void) { return new Beatrice20rc0_WaveformGenerator(); }
 void Beatrice20rc0_DestroyWaveformGenerator(Beatrice20rc0_WaveformGenerator* m) {
   if (!m) return;
+  const DeviceScope dev_(m->device);
   m->blob.release();
   delete m;
 }
@@ -366,6 +385,7 @@ Beatrice_ErrorCode Beatrice20rc0_ReadWaveformGeneratorParameters(Beatrice20rc0_W
 // contiguous device block so GenerateWaveform1 needs a single host-to-device copy.
 Beatrice20rc0_WaveformContext1* Beatrice20rc0_CreateWaveformContext1(void) {
   auto* c = new Beatrice20rc0_WaveformContext1();
+  const DeviceScope dev_(c->device);
   const size_t in_floats = B_PHONE_CH + 4 + 1 + 1;  // ... | step counter
   c->ok = make_stream(&c->stream) &&
           hip_ok(hipMalloc(reinterpret_cast<void**>(&c->d_inputs), sizeof(float) * in_floats), "inputs") &&
@@ -378,6 +398,7 @@ Beatrice20rc0_WaveformContext1* Beatrice20rc0_CreateWaveformContext1(void) {
 }
 void Beatrice20rc0_DestroyWaveformContext1(Beatrice20rc0_WaveformContext1* c) {
   if (!c) return;
+  const DeviceScope dev_(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->hop_graph.drop();
   c->st.destroy();
@@ -390,7 +411,8 @@ void Beatrice20rc0_DestroyWaveformContext1(Beatrice20rc0_WaveformContext1* c) {
 void Beatrice20rc0_GenerateWaveform1(const Beatrice20rc0_WaveformGenerator* m, const float* phone, const int* q,
                                      const float* feat, float* output, Beatrice20rc0_WaveformContext1* ctx) {
   std::memset(output, 0, sizeof(float) * B_OUT_HOP);
-  if (!m || !m->loaded || !ctx || !ctx->ok) return;
+  if (!m || !m->loaded || !ctx || !ctx->ok || m->device != ctx->device) return;
+  const DeviceScope dev_(ctx->device);
   const size_t in_floats = B_PHONE_CH + 4 + 1 + 1;
   float* h_in = ctx->h_io;
   float* h_out = ctx->h_io + in_floats;
@@ -414,6 +436,7 @@ void Beatrice20rc0_GenerateWaveform1(const Beatrice20rc0_WaveformGenerator* m, c
 Beatrice20rc0_EmbeddingSetter* Beatrice20rc0_CreateEmbeddingSetter(void) { return new Beatrice20rc0_EmbeddingSetter(); }
 void Beatrice20rc0_DestroyEmbeddingSetter(Beatrice20rc0_EmbeddingSetter* m) {
   if (!m) return;
+  const DeviceScope dev_(m->device);
   m->blob.release();
   delete m;
 }
@@ -428,6 +451,7 @@ Beatrice_ErrorCode Beatrice20rc0_ReadEmbeddingSetterParameters(Beatrice20rc0_Emb
 // neither allocate nor wait: uploads and projections are enqueued on HIP streams, ordered by events.
 Beatrice20rc0_EmbeddingContext* Beatrice20rc0_CreateEmbeddingContext(void) {
   auto* c = new Beatrice20rc0_EmbeddingContext();
+  const DeviceScope dev_(c->device);
   const size_t n = (size_t)B_KV_LEN * B_KV_CH + 2 * 2 * B_HID + 2 * B_HID;
   const size_t nh = (size_t)B_KV_LEN * B_KV_CH + 4 * B_HID;
   c->ok = make_stream(&c->stream) && hip_ok(hipMalloc(reinterpret_cast<void**>(&c->d_block), sizeof(float) * n), "embed ctx") &&
@@ -445,6 +469,7 @@ Beatrice20rc0_EmbeddingContext* Beatrice20rc0_CreateEmbeddingContext(void) {
 }
 void Beatrice20rc0_DestroyEmbeddingContext(Beatrice20rc0_EmbeddingContext* c) {
   if (!c) return;
+  const DeviceScope dev_(c->device);
   (void)hipDeviceSynchronize();  // setter work may sit on waveform contexts' streams
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->d_block) (void)hipFree(c->d_block);
@@ -458,7 +483,8 @@ void Beatrice20rc0_DestroyEmbeddingContext(Beatrice20rc0_EmbeddingContext* c) {
 // before that context's next GenerateWaveform1 without a wait here.
 static void set_vector(const Beatrice20rc0_EmbeddingSetter* m, int kind, const float* w, const float* b, const float* embedding,
                        Beatrice20rc0_EmbeddingContext* ec, float* d_ctx_vec, Beatrice20rc0_WaveformContext1* wc, float* d_wave_row) {
-  if (!m || !m->loaded || !ec || !ec->ok || !embedding) return;
+  if (!m || !m->loaded || !ec || !ec->ok || !embedding || m->device != ec->device || (wc && wc->ok && wc->device != ec->device)) return;
+  const DeviceScope dev_(ec->device);
   const int slot = kind * 2 + (ec->vec_next[kind] ^= 1);
   if (ec->vec_busy[slot]) { (void)hipEventSynchronize(ec->vec_sent[slot]); ec->vec_busy[slot] = false; }  // two calls ago
   float* h = ec->h_stage + (size_t)B_KV_LEN * B_KV_CH + (size_t)slot * B_HID;
@@ -492,6 +518,7 @@ void Beatrice20rc0_RegisterKeyValueSpeakerEmbedding(const Beatrice20rc0_Embeddin
                                                     Beatrice20rc0_EmbeddingContext* ec) {
   (void)m;
   if (!ec || !ec->ok || !kv) return;
+  const DeviceScope dev_(ec->device);
   if (ec->kv_busy) { (void)hipEventSynchronize(ec->kv_uploaded); ec->kv_busy = false; }  // previous upload still reads the staging
   std::memcpy(ec->h_stage, kv, sizeof(float) * B_KV_LEN * B_KV_CH);
   if (ec->kv_proj_pending) (void)hip_ok(hipStreamWaitEvent(ec->stream, ec->kv_projected, 0), "kv order");
@@ -503,6 +530,8 @@ void Beatrice20rc0_RegisterKeyValueSpeakerEmbedding(const Beatrice20rc0_Embeddin
 void Beatrice20rc0_SetKeyValueSpeakerEmbedding(const Beatrice20rc0_EmbeddingSetter* m, int block,
                                                Beatrice20rc0_EmbeddingContext* ec, Beatrice20rc0_WaveformContext1* wc) {
   if (!m || !m->loaded || !ec || !ec->ok || !wc || !wc->ok || block < 0 || block >= B_NBLOCKS) return;
+  if (m->device != ec->device || wc->device != ec->device) return;
+  const DeviceScope dev_(ec->device);
   if (ec->kv_busy) (void)hip_ok(hipStreamWaitEvent(wc->stream, ec->kv_uploaded, 0), "kv wait");
   // kv_projected is ONE event: when the previous projection ran on another waveform context's stream, chain behind it
   // first, so that the event recorded below covers every projection that still reads the registration

@@ -13,6 +13,24 @@ Beatrice_ErrorCode parse_model_bytes(const unsigned char* bytes, size_t size, ui
                                      std::vector<float>* out);
 Beatrice_ErrorCode read_model_file(const char* path, uint32_t kind, long expect_floats, std::vector<float>* out);
 bool make_stream(hipStream_t* s);
+
+// ---- devices.  One process may drive several GPUs (a C++ host with one thread per GPU, examples/node_convert.cc; the
+// reference runs many plugin instances per process, src/vst/factory.cc:21): every object remembers the device it was created
+// on -- the calling thread's target, BeatriceHip_SetDevice, else its current HIP device -- and every entry point makes that
+// device current for its own duration (DeviceScope), whatever the calling thread had selected.
+int target_device();              // device for objects this thread creates next
+void set_target_device(int d);    // -1: follow the thread's current HIP device again
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceScope(int device) {
+    int cur = -1;
+    if (device >= 0 && hipGetDevice(&cur) == hipSuccess && cur != device) { prev = cur; switched = hipSetDevice(device) == hipSuccess; }
+  }
+  ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
 // One slot of a phone context's codebook pool (abi.hip, Beatrice20rc0_SetCodebook): the device form (transposed +
 // norms) of the caller's table at `host`; `print` fingerprints the caller's bytes so that a table rewritten in
 // place (a host that reloads a model into the same storage) is re-uploaded instead of served stale.
@@ -21,10 +39,10 @@ constexpr int kCodebookPool = 12;  // >= the 8 speakers a morph can draw from (r
 }  // namespace bhip
 
 // model objects: immutable after Read*Parameters, shareable between contexts and threads
-struct Beatrice20rc0_PhoneExtractor { bhip::DeviceBlob blob; bhip::PhoneWeights w{}; bool loaded = false; };
-struct Beatrice20rc0_PitchEstimator { bhip::DeviceBlob blob; bhip::PitchWeights w{}; bool loaded = false; };
-struct Beatrice20rc0_WaveformGenerator { bhip::DeviceBlob blob; bhip::WaveWeights w{}; bool loaded = false; };
-struct Beatrice20rc0_EmbeddingSetter { bhip::DeviceBlob blob; bhip::EmbedWeights w{}; bool loaded = false; };
+struct Beatrice20rc0_PhoneExtractor { int device = bhip::target_device(); bhip::DeviceBlob blob; bhip::PhoneWeights w{}; bool loaded = false; };
+struct Beatrice20rc0_PitchEstimator { int device = bhip::target_device(); bhip::DeviceBlob blob; bhip::PitchWeights w{}; bool loaded = false; };
+struct Beatrice20rc0_WaveformGenerator { int device = bhip::target_device(); bhip::DeviceBlob blob; bhip::WaveWeights w{}; bool loaded = false; };
+struct Beatrice20rc0_EmbeddingSetter { int device = bhip::target_device(); bhip::DeviceBlob blob; bhip::EmbedWeights w{}; bool loaded = false; };
 
 // One per-hop call = one hipGraph launch (input copy, the module's kernels, output copy), captured at the first hop of a
 // context with a given model (and again when the set of launches changes: k-NN on / off).  ~1-2 ms once, on the thread
@@ -46,6 +64,7 @@ struct HopGraph {
 
 // per-stream contexts: device state for ONE stream + a private HIP stream + pinned staging
 struct Beatrice20rc0_PhoneContext1 {
+  int device = bhip::target_device();
   bhip::PhoneState st;
   hipStream_t stream = nullptr;
   float* h_io = nullptr;  // pinned: 160 in | mailbox (step counter, k, codebook pointers) | 128 out
@@ -70,6 +89,7 @@ struct Beatrice20rc0_PhoneContext1 {
   bool ok = false;
 };
 struct Beatrice20rc0_PitchContext1 {
+  int device = bhip::target_device();
   bhip::PitchState st;
   hipStream_t stream = nullptr;
   float* h_io = nullptr;  // pinned: 160 in | mailbox (step counter, bin range) | 4 feat | 1 bin
@@ -80,6 +100,7 @@ struct Beatrice20rc0_PitchContext1 {
   bool ok = false;
 };
 struct Beatrice20rc0_WaveformContext1 {
+  int device = bhip::target_device();
   bhip::WaveState st;
   hipStream_t stream = nullptr;
   float* d_inputs = nullptr;  // device: 128 phone | 4 feat | 1 bin | step counter
@@ -89,6 +110,7 @@ struct Beatrice20rc0_WaveformContext1 {
   bool ok = false;
 };
 struct Beatrice20rc0_EmbeddingContext {
+  int device = bhip::target_device();
   hipStream_t stream = nullptr;
   float* d_block = nullptr;
   float *d_kv_raw = nullptr, *d_tmp = nullptr, *d_add = nullptr, *d_frm = nullptr;

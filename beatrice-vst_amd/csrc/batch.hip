@@ -111,6 +111,7 @@ struct BeatriceBatch {
   const Beatrice20rc0_WaveformGenerator* wave_m = nullptr;
   const Beatrice20rc0_EmbeddingSetter* embed_m = nullptr;
   int B = 0, max_speakers = 0, n_speakers = 0;
+  int device = -1;  // the GPU of the model objects the batch was created from; every entry point runs with it current (DeviceScope)
   int H = 1;  // hops per step (block mode when > 1)
   bool ok = false;
   hipStream_t stream = nullptr;
@@ -864,6 +865,7 @@ namespace {
 template <class Model, class Weights>
 int model_blob(Model* m, int allocate, void** d_ptr, size_t* n_bytes) {
   if (!m || !d_ptr || !n_bytes) return -1;
+  const DeviceScope dev_(m->device);
   const size_t n = Weights::n_floats();
   if (allocate && !m->loaded && m->blob.n_floats != n) {
     m->blob.release();
@@ -878,6 +880,7 @@ int model_blob(Model* m, int allocate, void** d_ptr, size_t* n_bytes) {
 template <class Model>
 int model_ready(Model* m) {
   if (!m || !m->blob.d) return -1;
+  const DeviceScope dev_(m->device);
   if (!hip_ok(hipDeviceSynchronize(), "blob ready")) return -2;
   m->w.bind(m->blob.d);
   m->loaded = true;
@@ -894,6 +897,7 @@ extern "C" {
     const Beatrice_ErrorCode e = parse_model_bytes(static_cast<const unsigned char*>(bytes), size, KIND,   \
                                                    (long)Weights::n_floats(), &host);                       \
     if (e) return e;                                                                                        \
+    const DeviceScope dev_(m->device);                                                                      \
     m->loaded = false;                                                                                      \
     Weights::pack_host(host.data());                                                                        \
     if (!m->blob.upload(host.data(), host.size())) return Beatrice_kFileOpenError;                          \
@@ -905,6 +909,15 @@ BHIP_MEMORY_LOADER(PhoneExtractor, Beatrice20rc0_PhoneExtractor, KIND_PHONE, Pho
 BHIP_MEMORY_LOADER(PitchEstimator, Beatrice20rc0_PitchEstimator, KIND_PITCH, PitchWeights)
 BHIP_MEMORY_LOADER(WaveformGenerator, Beatrice20rc0_WaveformGenerator, KIND_WAVE, WaveWeights)
 BHIP_MEMORY_LOADER(EmbeddingSetter, Beatrice20rc0_EmbeddingSetter, KIND_EMBED, EmbedWeights)
+
+int BeatriceHip_SetDevice(int ordinal) {
+  int n = 0;
+  if (ordinal < -1 || (ordinal >= 0 && (hipGetDeviceCount(&n) != hipSuccess || ordinal >= n))) return -1;
+  set_target_device(ordinal);
+  return 0;
+}
+int BeatriceHip_GetDevice(void) { return target_device(); }
+int BeatriceBatch_Device(const BeatriceBatch* b) { return b ? b->device : -1; }
 
 int BeatriceHip_ModelBlob(int kind, void* model, int allocate, void** d_ptr, size_t* n_bytes) {
   switch (kind) {
@@ -939,6 +952,9 @@ BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* pho
   if (!phone || !pitch || !wave || !embed || !phone->loaded || !pitch->loaded || !wave->loaded || !embed->loaded ||
       n_streams < 1 || max_speakers < 1 || (hops_per_step != 1 && hops_per_step != 2 && hops_per_step != 4 && hops_per_step != 8))
     return b;  // unhealthy object; every call on it fails with -2
+  if (pitch->device != phone->device || wave->device != phone->device || embed->device != phone->device) return b;  // one GPU per batch
+  b->device = phone->device;
+  const DeviceScope dev_(b->device);
   b->phone_m = phone; b->pitch_m = pitch; b->wave_m = wave; b->embed_m = embed;
   b->B = n_streams; b->max_speakers = max_speakers; b->H = hops_per_step;
   const int B = n_streams, S = max_speakers, H = hops_per_step;
@@ -1049,6 +1065,7 @@ BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* pho
 }
 
 void BeatriceBatch_Destroy(BeatriceBatch* b) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b) return;
   if (b->stream) (void)sync_all(b);
   drop_graph(b);
@@ -1092,6 +1109,7 @@ int BeatriceBatch_IsHealthy(const BeatriceBatch* b) { return b && b->ok ? 1 : 0;
 int BeatriceBatch_NumStreams(const BeatriceBatch* b) { return b ? b->B : 0; }
 int BeatriceBatch_HopsPerStep(const BeatriceBatch* b) { return b ? b->H : 0; }
 size_t BeatriceBatch_StateBytes(const BeatriceBatch* b) {
+  const DeviceScope dev_(b ? b->device : -1);
   return b && b->ok ? sizeof(float) * (b->phone.arena.floats + b->pitch.arena.floats + b->wave.arena.floats) : 0;
 }
 
@@ -1110,6 +1128,7 @@ static bool project_speakers(BeatriceBatch* b, int first, int count) {
 
 int BeatriceBatch_SetSpeakerTables(BeatriceBatch* b, int n, const float* codebooks, const float* additive, const float* formant,
                                    const float* kv) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (n < 1 || n > b->max_speakers || !codebooks || !additive || !formant || !kv) return -1;
   bool ok = sync_all(b) &&
@@ -1130,6 +1149,7 @@ int BeatriceBatch_SetSpeakerTables(BeatriceBatch* b, int n, const float* codeboo
 // rank that read the file): [0] codebooks [S][512][128], [1] additive [S][256], [2] formant [9][256], [3] key/value
 // [S][384][128]; then BeatriceBatch_ProjectSpeakerTables(b, n) does what SetSpeakerTables does after its upload.
 int BeatriceBatch_SpeakerTablesDevice(BeatriceBatch* b, void** d_ptrs, size_t* n_bytes) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (!d_ptrs || !n_bytes) return -1;
   const size_t S = (size_t)b->max_speakers;
@@ -1140,6 +1160,7 @@ int BeatriceBatch_SpeakerTablesDevice(BeatriceBatch* b, void** d_ptrs, size_t* n
   return 0;
 }
 int BeatriceBatch_ProjectSpeakerTables(BeatriceBatch* b, int n) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (n < 1 || n > b->max_speakers) return -1;
   if (!sync_all(b) || !hip_ok(hipDeviceSynchronize(), "tables sync")) return -2;
@@ -1152,6 +1173,7 @@ int BeatriceBatch_ProjectSpeakerTables(BeatriceBatch* b, int n) {
 }
 
 int BeatriceBatch_UpdateSpeaker(BeatriceBatch* b, int spk, const float* codebook, const float* additive, const float* kv) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (spk < 0 || spk >= b->max_speakers) return -1;
   bool ok = sync_all(b);
@@ -1170,6 +1192,7 @@ int BeatriceBatch_UpdateSpeaker(BeatriceBatch* b, int spk, const float* codebook
 // and the 384 key/value embeddings of entry `slot` become weighted spherical means computed on the
 // device (morph.hip), and their projections are refreshed.
 int BeatriceBatch_MorphSpeaker(BeatriceBatch* b, int slot, const float* weights, int n_weights, unsigned seed) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (!weights || n_weights < 1 || n_weights > 256 || slot < n_weights || slot >= b->max_speakers || n_weights > b->n_speakers) return -1;
   std::vector<float> w(weights, weights + n_weights);
@@ -1218,6 +1241,7 @@ int BeatriceBatch_MorphSpeaker(BeatriceBatch* b, int slot, const float* weights,
 // the codebook lottery's engine of one stream (or of all, -1): std::mt19937(seed), e.g. a value derived from the
 // stream's global identity when streams are sharded over several batches / GPUs
 int BeatriceBatch_SeedLottery(BeatriceBatch* b, int stream, unsigned seed) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (stream < -1 || stream >= b->B) return -1;
   for (int s = (stream < 0 ? 0 : stream); s < (stream < 0 ? b->B : stream + 1); ++s) b->lottery[s].seed(seed);
@@ -1226,6 +1250,7 @@ int BeatriceBatch_SeedLottery(BeatriceBatch* b, int stream, unsigned seed) {
 }
 // copies the morphed entry's raw embeddings back (test / inspection hook; any pointer may be NULL)
 int BeatriceBatch_GetSpeakerEmbeddings(BeatriceBatch* b, int speaker, float* additive, float* key_value) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (speaker < 0 || speaker >= b->max_speakers) return -1;
   bool ok = sync_all(b);
@@ -1238,6 +1263,7 @@ int BeatriceBatch_GetSpeakerEmbeddings(BeatriceBatch* b, int speaker, float* add
 // processor_core_2.cc:431-466: codebook + additive switch at once, K/V re-registered and installed
 // one block per following hop.
 int BeatriceBatch_SetTargetSpeaker(BeatriceBatch* b, int stream, int speaker) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (speaker < 0 || speaker >= b->max_speakers) return -1;
   const int r = for_streams(b, stream, [&](StreamCfg& c) {
@@ -1249,6 +1275,7 @@ int BeatriceBatch_SetTargetSpeaker(BeatriceBatch* b, int stream, int speaker) {
 }
 // processor_core_2.cc:270,414: `while (SetKeyValueSpeakerEmbedding());`
 int BeatriceBatch_FlushSpeaker(BeatriceBatch* b, int stream) {
+  const DeviceScope dev_(b ? b->device : -1);
   const int r = for_streams(b, stream, [&](StreamCfg& c) {
     for (; c.kv_set_count < B_NBLOCKS; ++c.kv_set_count) c.kv_slot[c.kv_set_count] = c.target_speaker;
   });
@@ -1262,47 +1289,57 @@ int BeatriceBatch_FlushSpeaker(BeatriceBatch* b, int stream) {
 }
 // processor_core_2.cc:468-481
 int BeatriceBatch_SetFormantShift(BeatriceBatch* b, int stream, double shift) {
+  const DeviceScope dev_(b ? b->device : -1);
   shift = std::min(std::max(shift, -2.0), 2.0);
   const int idx = (int)std::round(shift * 2.0 + 4.0);
   return for_streams(b, stream, [&](StreamCfg& c) { c.formant_index = idx; });
 }
 // processor_core_2.cc:585-590
 int BeatriceBatch_SetVQNumNeighbors(BeatriceBatch* b, int stream, int k) {
+  const DeviceScope dev_(b ? b->device : -1);
   k = std::min(std::max(k, 0), 8);
   if (b) b->vq_dirty = true;
   return for_streams(b, stream, [&](StreamCfg& c) { c.vq_k = k; });
 }
 int BeatriceBatch_SetMinSourcePitch(BeatriceBatch* b, int stream, double note) {
+  const DeviceScope dev_(b ? b->device : -1);
   const int q = midi_to_bin(note);
   return for_streams(b, stream, [&](StreamCfg& c) { c.min_q = q; });
 }
 int BeatriceBatch_SetMaxSourcePitch(BeatriceBatch* b, int stream, double note) {
+  const DeviceScope dev_(b ? b->device : -1);
   const int q = midi_to_bin(note);
   return for_streams(b, stream, [&](StreamCfg& c) { c.max_q = q; });
 }
 // processor_core_2.cc:483-486, 534-559
 int BeatriceBatch_SetPitchShift(BeatriceBatch* b, int stream, double v) {
+  const DeviceScope dev_(b ? b->device : -1);
   v = std::min(std::max(v, -24.0), 24.0);
   return for_streams(b, stream, [&](StreamCfg& c) { c.pitch.pitch_shift = v; });
 }
 int BeatriceBatch_SetAverageSourcePitch(BeatriceBatch* b, int stream, double v) {
+  const DeviceScope dev_(b ? b->device : -1);
   v = std::min(std::max(v, 0.0), 128.0);
   return for_streams(b, stream, [&](StreamCfg& c) { c.pitch.average_source_pitch = v; });
 }
 int BeatriceBatch_SetIntonationIntensity(BeatriceBatch* b, int stream, double v) {
+  const DeviceScope dev_(b ? b->device : -1);
   return for_streams(b, stream, [&](StreamCfg& c) { c.pitch.intonation_intensity = v; });
 }
 int BeatriceBatch_SetPitchCorrection(BeatriceBatch* b, int stream, double v) {
+  const DeviceScope dev_(b ? b->device : -1);
   v = std::min(std::max(v, 0.0), 1.0);
   return for_streams(b, stream, [&](StreamCfg& c) { c.pitch.pitch_correction = v; });
 }
 int BeatriceBatch_SetPitchCorrectionType(BeatriceBatch* b, int stream, int type) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (type < 0 || type > 1) return -1;
   return for_streams(b, stream, [&](StreamCfg& c) { c.pitch.pitch_correction_type = type; });
 }
 // processor_core_2.cc:258-291: fresh contexts, then speaker (all four blocks at once) and the other
 // settings re-applied -- here the settings persist per stream, only the state is zeroed.
 int BeatriceBatch_ResetStream(BeatriceBatch* b, int stream) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (stream < -1 || stream >= b->B) return -1;
   const int lo = stream < 0 ? 0 : stream, hi = stream < 0 ? b->B : stream + 1;
@@ -1319,6 +1356,7 @@ int BeatriceBatch_ResetStream(BeatriceBatch* b, int stream) {
 
 // ---- per-hop ------------------------------------------------------------------------------------
 int BeatriceBatch_ConvertFramesDevice(BeatriceBatch* b, const float* d_in, float* d_out) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   return step_device(b, d_in, d_out) ? 0 : -2;
 }
@@ -1328,6 +1366,7 @@ int BeatriceBatch_ConvertFramesDevice(BeatriceBatch* b, const float* d_in, float
 // slot of d_out, with no copy: the slot index lives next to the step counter in device memory and is
 // advanced by the last kernel, so the captured graph stays valid.  NULL pointers unbind.
 int BeatriceBatch_BindResidentIO(BeatriceBatch* b, const float* d_in, float* d_out, int n_slots) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   const bool bind = d_in != nullptr || d_out != nullptr;
   if (bind && (!d_in || !d_out || n_slots < 1)) return -1;
@@ -1352,6 +1391,7 @@ int BeatriceBatch_BindResidentIO(BeatriceBatch* b, const float* d_in, float* d_o
 }
 
 int BeatriceBatch_ConvertFrames(BeatriceBatch* b, const float* in, float* out) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) { if (b && out) std::memset(out, 0, sizeof(float) * b->B * b->H * B_OUT_HOP); return -2; }
   if (b->io_slots > 0 || b->tk.on) return -1;  // resident I/O is bound
   const size_t n_in = (size_t)b->B * b->H * B_IN_HOP, n_out = (size_t)b->B * b->H * B_OUT_HOP;
@@ -1381,6 +1421,7 @@ static bool step_48k(BeatriceBatch* b, const float* d_in48, float* d_out48, int 
 // block lands in the same slot of d_out48 BeatriceBatch_TickStages() - 1 calls later (or after BeatriceBatch_Synchronize).
 // Same samples as the in-order BeatriceBatch_ConvertBlocks48kDevice.  NULL pointers unbind.
 int BeatriceBatch_BindResidentIO48k(BeatriceBatch* b, const float* d_in48, float* d_out48, int channels, int n_slots) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   BeatriceBatch::Resident48& r = b->r48;
   if (r.on) {
@@ -1412,12 +1453,14 @@ int BeatriceBatch_BindResidentIO48k(BeatriceBatch* b, const float* d_in48, float
   return 0;
 }
 int BeatriceBatch_ConvertBlocks48kDevice(BeatriceBatch* b, const float* d_in, float* d_out, int channels) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (b->r48.on) return (!d_in && !d_out && channels == b->r48.channels) ? (tick_run(b, true) ? 0 : -2) : -1;
   if (channels < 1 || channels > 2 || !d_in || !d_out || b->H != 1 || b->io_slots > 0 || b->pipelined || b->tk.on) return -1;  // per 10 ms block, in order
   return step_48k(b, d_in, d_out, channels) ? 0 : -2;
 }
 int BeatriceBatch_ConvertBlocks48k(BeatriceBatch* b, const float* in, float* out, int channels) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (channels < 1 || channels > 2 || !in || !out || b->H != 1 || b->io_slots > 0 || b->pipelined || b->tk.on) return -1;
   const size_t n = (size_t)b->B * channels * 480;
@@ -1439,6 +1482,7 @@ int BeatriceBatch_ConvertBlocks48k(BeatriceBatch* b, const float* in, float* out
 // ---- host-rate blocks with the whole wrapper on the device (wrapper.hip.h) -------------------------------------------
 namespace { constexpr int kInnerStride = wrapn::kMaxSamples + 64; }
 int BeatriceBatch_ConfigureWrapper(BeatriceBatch* b, double sample_rate) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (b->H != 1) return -1;
   if (!sync_all(b)) return -2;
@@ -1468,12 +1512,14 @@ int BeatriceBatch_ConfigureWrapper(BeatriceBatch* b, double sample_rate) {
 }
 // reference ProcessorCore2::SetInputGain / SetOutputGain (processor_core_2.cc:488-496): the target; the ramp follows at 2 dB/ms
 int BeatriceBatch_SetInputGain(BeatriceBatch* b, int stream, double db) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (stream < -1 || stream >= b->B || b->gain_in.empty()) return -1;
   for (int s = (stream < 0 ? 0 : stream); s < (stream < 0 ? b->B : stream + 1); ++s) b->gain_in[s].target_db = db;
   return 0;
 }
 int BeatriceBatch_SetOutputGain(BeatriceBatch* b, int stream, double db) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (stream < -1 || stream >= b->B || b->gain_out.empty()) return -1;
   for (int s = (stream < 0 ? 0 : stream); s < (stream < 0 ? b->B : stream + 1); ++s) b->gain_out[s].target_db = db;
@@ -1531,6 +1577,7 @@ static int wrap_max_chunk(const BeatriceBatch* b) {  // host samples per launch 
 }
 // in / out: [B][channels][n] planar at the configured host rate; any n >= 1 (long blocks are processed in pieces)
 int BeatriceBatch_ProcessBlocksDevice(BeatriceBatch* b, const float* d_in, float* d_out, int channels, int n) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (!b->wrap.ready || channels < 1 || channels > 2 || !d_in || !d_out || n < 1 || b->H != 1 || b->io_slots > 0 || b->pipelined || b->tk.on) return -1;
   const int piece = wrap_max_chunk(b);
@@ -1539,6 +1586,7 @@ int BeatriceBatch_ProcessBlocksDevice(BeatriceBatch* b, const float* d_in, float
 }
 int BeatriceBatch_MaxWrapperBlock(const BeatriceBatch* b) { return b && b->ok && b->wrap.ready ? wrap_max_chunk(b) : 0; }
 int BeatriceBatch_ProcessBlocks(BeatriceBatch* b, const float* in, float* out, int channels, int n) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (!b->wrap.ready || channels < 1 || channels > 2 || !in || !out || n < 1 || n > wrap_max_chunk(b) || b->H != 1 || b->io_slots > 0 || b->pipelined || b->tk.on) return -1;
   const size_t cnt = (size_t)b->B * channels * n;
@@ -1558,11 +1606,13 @@ int BeatriceBatch_ProcessBlocks(BeatriceBatch* b, const float* in, float* out, i
 }
 
 int BeatriceBatch_Synchronize(BeatriceBatch* b) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   return sync_all(b) ? 0 : -2;
 }
 
 int BeatriceBatch_SetStream(BeatriceBatch* b, void* hip_stream) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   (void)sync_all(b);
   drop_graph(b);
@@ -1573,6 +1623,7 @@ int BeatriceBatch_SetStream(BeatriceBatch* b, void* hip_stream) {
 }
 void* BeatriceBatch_GetStream(const BeatriceBatch* b) { return b ? b->stream : nullptr; }
 int BeatriceBatch_EnableGraph(BeatriceBatch* b, int enable) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   (void)sync_all(b);
   b->use_graph = enable != 0;
@@ -1640,6 +1691,7 @@ void host_stream_free(BeatriceBatch* b) {
 }  // namespace
 extern "C" {
 int BeatriceBatch_EnableHostStreaming(BeatriceBatch* b, int enable) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   BeatriceBatch::HostStream& h = b->hs;
   if ((enable != 0) == h.on) return 0;
@@ -1680,6 +1732,7 @@ int BeatriceBatch_HostStreamDelay(const BeatriceBatch* b) { return b ? b->tk.pla
 // in: [B][160] host; out: [B][240] host.  Returns 1 when `out` received the samples of the step fed
 // BeatriceBatch_HostStreamDelay() calls ago, 0 while the pipeline is still filling (out untouched), < 0 on error.
 int BeatriceBatch_StreamFrames(BeatriceBatch* b, const float* in, float* out) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   BeatriceBatch::HostStream& h = b->hs;
   if (!h.on || !in || !out) return -1;
@@ -1722,6 +1775,7 @@ int BeatriceBatch_StreamFrames(BeatriceBatch* b, const float* in, float* out) {
 // After the last StreamFrames: hands back the next step still inside the pipeline (running ticks without input as
 // needed); returns 1 with `out` filled, 0 when nothing is pending.
 int BeatriceBatch_StreamFlush(BeatriceBatch* b, float* out) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   BeatriceBatch::HostStream& h = b->hs;
   if (!h.on || !out) return -1;
@@ -1741,6 +1795,7 @@ int BeatriceBatch_StreamFlush(BeatriceBatch* b, float* out) {
 // runs on a second stream.  Same results; a step's output is complete when BeatriceBatch_Synchronize returns
 // (or, stream-ordered, on BeatriceBatch_GetWaveStream).  Off by default: everything in order on one stream.
 int BeatriceBatch_EnableTickPipeline(BeatriceBatch* b, int enable) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (b->hs.on || b->r48.on) return -1;  // those modes own the tick pipeline: leave them instead
   return tick_enable(b, enable != 0);
@@ -1750,6 +1805,7 @@ int BeatriceBatch_TickStages(const BeatriceBatch* b) { return b ? b->tk.plan.cou
 // between one pair of HIP events on the batch's stream; returns the mean duration per launch and its algorithmic work.
 // Call with the pipeline full (at least BeatriceBatch_TickStages steps fed) for the steady-state figure.
 int BeatriceBatch_TimeTickLaunch(BeatriceBatch* b, int ticks, float* us_per_launch, double* flops, double* bytes) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (!b->tk.on || ticks < 1 || ticks > 64 || !us_per_launch) return -1;
   // ONE pair of events around `ticks` back-to-back launches (an event pair per launch adds two commands between
@@ -1770,6 +1826,7 @@ int BeatriceBatch_TimeTickLaunch(BeatriceBatch* b, int ticks, float* us_per_laun
   return 0;
 }
 int BeatriceBatch_EnablePipelining(BeatriceBatch* b, int enable) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (b->tk.on) return -1;
   if (!set_io_mapped(b, false) || !sync_all(b)) return -2;
@@ -1783,6 +1840,7 @@ int BeatriceBatch_EnablePipelining(BeatriceBatch* b, int enable) {
 void* BeatriceBatch_GetWaveStream(const BeatriceBatch* b) { return b ? wave_stream(b) : nullptr; }
 // Captures the hipGraphs of the current mode now (nothing is executed), so that the first steps do not pay for it.
 int BeatriceBatch_Prepare(BeatriceBatch* b) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (b->vq_dirty) { update_vq_mode(b); b->vq_dirty = false; }
   if (!b->use_graph) return 0;
@@ -1792,9 +1850,13 @@ int BeatriceBatch_Prepare(BeatriceBatch* b) {
   return ok ? 0 : -2;
 }
 float* BeatriceBatch_DeviceInput(BeatriceBatch* b) { return b && b->ok ? b->d_in : nullptr; }
-float* BeatriceBatch_DeviceOutput(BeatriceBatch* b) { return b && b->ok && set_io_mapped(b, false) ? b->wave.d_out : nullptr; }
+float* BeatriceBatch_DeviceOutput(BeatriceBatch* b) {
+  const DeviceScope dev_(b ? b->device : -1);
+  return b && b->ok && set_io_mapped(b, false) ? b->wave.d_out : nullptr;
+}
 
 int BeatriceBatch_GetIntermediates(BeatriceBatch* b, float* phone, int* q_raw, int* q, float* feat) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   bool ok = sync_all(b);
   if (phone) {  // the phone vectors of the last step sit in one of the three step slots of a per-stream ring
@@ -1840,6 +1902,7 @@ struct ProfileHook : LaunchHook {
 
 int BeatriceBatch_ProfileKernels(BeatriceBatch* b, int repeats, int max_entries, char* names, int* launches, double* mean_us,
                                  double* flops, double* bytes) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (repeats < 1 || max_entries < 1 || !names || !launches || !mean_us || !flops || !bytes || b->tk.on) return -1;
   if (!sync_all(b)) return -2;
@@ -1874,6 +1937,7 @@ int BeatriceBatch_ProfileKernels(BeatriceBatch* b, int repeats, int max_entries,
 }
 
 int BeatriceBatch_TimeSteps(BeatriceBatch* b, int steps, float* ms) {
+  const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok || steps < 1 || !ms) return b && b->ok ? -1 : -2;
   bool ok = sync_all(b) && hip_ok(hipEventRecord(b->ev0, b->stream), "ev0");
   for (int i = 0; i < steps && ok; ++i) ok = step_device(b, nullptr, nullptr);

@@ -180,8 +180,10 @@ def affine_speaker(rank, world, local_stream, n_speakers):
     ranks every rank cycles through all of them."""
     if n_speakers < world:
         return local_stream % n_speakers
-    per = n_speakers // world
-    return (rank + world * (local_stream % per)) % n_speakers
+    # the speakers congruent to `rank`: rank, rank + world, ... below n_speakers -- ceil((n_speakers - rank) / world) of
+    # them, so that the ranks' sets PARTITION the table for any n_speakers (64 over 3 ranks: 22 + 21 + 21)
+    mine = (n_speakers - rank + world - 1) // world
+    return rank + world * (local_stream % mine)
 
 
 def max_over_ranks(value, world, dist, torch, device):

@@ -42,6 +42,18 @@ Beatrice_ErrorCode BeatriceHip_LoadPitchEstimatorFromMemory(Beatrice20rc0_PitchE
 Beatrice_ErrorCode BeatriceHip_LoadWaveformGeneratorFromMemory(Beatrice20rc0_WaveformGenerator* m, const void* bytes, size_t size);
 Beatrice_ErrorCode BeatriceHip_LoadEmbeddingSetterFromMemory(Beatrice20rc0_EmbeddingSetter* m, const void* bytes, size_t size);
 
+/* Several GPUs in one process (a C++ host with one thread per GPU, examples/node_convert.cc; the reference runs many plugin
+ * instances per process, src/vst/factory.cc:21).  Every object of this library -- model objects, contexts, batches --
+ * lives on ONE device, fixed when it is created: the calling thread's target device, BeatriceHip_SetDevice(ordinal)
+ * (thread-local; -1 = follow the thread's current HIP device, the default), and every entry point makes its object's
+ * device current for its own duration and restores the caller's, so a thread may own objects on several GPUs and a host
+ * framework's own device selection is left alone.  Objects of different devices cannot be combined (a context with a
+ * model object of another GPU emits zeros; BeatriceBatch_Create returns an unhealthy batch).  0, or -1 for an ordinal the
+ * runtime does not have. */
+int BeatriceHip_SetDevice(int ordinal);
+int BeatriceHip_GetDevice(void);
+int BeatriceBatch_Device(const BeatriceBatch* b);
+
 /* Device-resident parameter blobs, for loading a model on several GPUs from ONE file read.
  * kind: 1 phone extractor, 2 pitch estimator, 3 waveform generator, 4 embedding setter; `model` the matching object.
  * BeatriceHip_ModelBlob returns the object's parameter blob as it sits on the device (already in the kernels' packed

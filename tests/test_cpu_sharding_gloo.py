@@ -155,3 +155,8 @@ def test_speaker_affine_placement():
             seen |= mine
         assert seen == set(range(64))
     assert {shard.affine_speaker(3, 8, s, 2) for s in range(16)} == {0, 1}   # fewer speakers than ranks
+    # a table size the world does not divide: the ranks' sets still partition it, every speaker congruent to its rank
+    for world, n in ((3, 64), (5, 64), (7, 10), (8, 9)):
+        sets = [{shard.affine_speaker(rank, world, s, n) for s in range(4 * n)} for rank in range(world)]
+        assert sorted(x for st in sets for x in st) == list(range(n)), (world, n)
+        assert all(x % world == rank for rank, st in enumerate(sets) for x in st)

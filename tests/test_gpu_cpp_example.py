@@ -31,3 +31,58 @@ def test_cpp_host_program_matches_python_driven_chain(bv, product, model_dir, tm
     m.close()
     assert np.abs(want).max() > 0.05
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("speaker,k,placement", [(2, 3, "range"), (-1, 2, "range"), (-1, 0, "speaker")])
+def test_node_host_program_matches_single_batch(bv, product, model_dir, tmp_path, speaker, k, placement):
+    """examples/node_convert: the C++ host of one node (one thread + one batch per GPU, model read once on GPU 0, parameter
+    blobs and speaker tables by ncclBroadcast on librccl directly, frame counters all-reduced).  The test box has one GPU, so
+    N = 1 here: the whole flow runs -- communicator, in-place broadcasts, device-scoped objects, the all-reduce -- and its
+    output must equal the Python-driven in-order chain's bit for bit, with a fixed target speaker and with per-stream
+    speakers (speaker = stream mod n_speakers: the speaker-affine placement's input)."""
+    import json
+    exe = os.path.join(REPO, "examples", "node_convert")
+    assert os.path.exists(exe), "examples/node_convert was not built (make -C beatrice-vst_amd)"
+    B, hops = 24, 40
+    audio = np.stack([bv.synth_audio(160 * hops, seed=6400 + s) for s in range(B)]).reshape(B, hops, 160)
+    x = np.ascontiguousarray(audio.transpose(1, 0, 2))            # [hops][B][160]
+    fin, fout = str(tmp_path / "in.f32"), str(tmp_path / "out.f32")
+    x.tofile(fin)
+    r = subprocess.run([exe, model_dir, "1", str(B), str(hops), fin, fout, str(speaker), str(k), placement], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["frames"] == B * hops and line["gpus"] == 1 and line["streams_per_gpu"] == [B] and line["broadcast_bytes"] > 20e6
+    got = np.fromfile(fout, np.float32).reshape(hops, B, 240)
+    m = bv.Models(product, model_dir)
+    n = m.tables.n_speakers
+    batch = bv.Batch(m, B)
+    for s in range(B):
+        batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, s, speaker if speaker >= 0 else s % n)
+    batch.a.BeatriceBatch_FlushSpeaker(batch.h, -1)
+    batch.a.BeatriceBatch_SetVQNumNeighbors(batch.h, -1, k)
+    want = np.stack([batch.convert(np.ascontiguousarray(x[h])) for h in range(hops)])
+    batch.close()
+    m.close()
+    assert np.abs(want).max() > 0.05
+    assert np.array_equal(got, want)
+    # more GPUs than the box has: refused with a message, not a crash
+    r = subprocess.run([exe, model_dir, "64", str(B), str(hops), fin, fout], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "devices" in r.stderr
+
+
+def test_objects_carry_their_device(bv, product, model_dir):
+    """BeatriceHip_SetDevice: objects are created on the calling thread's target device and every entry point runs there.
+    With one GPU: ordinal 0 is accepted and everything works while ANOTHER thread-current HIP device cannot be selected
+    (there is none); an ordinal the runtime does not have is refused and leaves the target alone."""
+    a = bv.bind_batch(product)
+    assert a.BeatriceHip_SetDevice(0) == 0 and a.BeatriceHip_GetDevice() == 0
+    assert a.BeatriceHip_SetDevice(10 ** 6) == -1 and a.BeatriceHip_GetDevice() == 0
+    m = bv.Models(product, model_dir)
+    batch = bv.Batch(m, 3)
+    assert a.BeatriceBatch_Device(batch.h) == 0
+    x = np.stack([bv.synth_audio(160, seed=s) for s in range(3)])
+    y = batch.convert(x)
+    assert np.isfinite(y).all()
+    batch.close()
+    m.close()
+    assert a.BeatriceHip_SetDevice(-1) == 0      # back to "the thread's current HIP device"
