@@ -69,6 +69,29 @@ _LEGACY = ["CreatePhoneExtractor", "DestroyPhoneExtractor", "CreatePhoneContext1
 ABI_SYMBOLS_LEGACY = [g + "_" + n for g in ("Beatrice20a2", "Beatrice20b1") for n in _LEGACY]
 
 
+# legacy generations (include/beatrice_abi.h: Beatrice20a2_*, Beatrice20b1_*): 256-d phone vector, 384 pitch bins, the speaker
+# vector handed to GenerateWaveform1 per hop (reference lib/beatricelib/beatrice.h:39-203)
+LEGACY_PHONE_CH, LEGACY_PITCH_BINS = 256, 384
+_LEGACY_SIG = {
+    "CreatePhoneExtractor": (_vp, []), "DestroyPhoneExtractor": (None, [_vp]),
+    "CreatePhoneContext1": (_vp, []), "DestroyPhoneContext1": (None, [_vp]),
+    "CreatePitchEstimator": (_vp, []), "DestroyPitchEstimator": (None, [_vp]),
+    "CreatePitchContext1": (_vp, []), "DestroyPitchContext1": (None, [_vp]),
+    "CreateWaveformGenerator": (_vp, []), "DestroyWaveformGenerator": (None, [_vp]),
+    "CreateWaveformContext1": (_vp, []), "DestroyWaveformContext1": (None, [_vp]),
+    "ReadPhoneExtractorParameters": (C.c_int, [_vp, C.c_char_p]),
+    "ReadPitchEstimatorParameters": (C.c_int, [_vp, C.c_char_p]),
+    "ReadWaveformGeneratorParameters": (C.c_int, [_vp, C.c_char_p]),
+    "ReadNSpeakers": (C.c_int, [C.c_char_p, _i32p]),
+    "ReadSpeakerEmbeddings": (C.c_int, [C.c_char_p, _f32p]),
+    "ExtractPhone1": (None, [_vp, _f32p, _f32p, _vp]),
+    "SetMinQuantizedPitch": (None, [_vp, C.c_int]),
+    "SetMaxQuantizedPitch": (None, [_vp, C.c_int]),
+    "EstimatePitch1": (None, [_vp, _f32p, _i32p, _f32p, _vp]),
+    "GenerateWaveform1": (None, [_vp, _f32p, _i32p, _f32p, _f32p, _f32p, _vp]),
+}
+
+
 def fptr(a):
     assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(_f32p)
@@ -91,6 +114,89 @@ class Abi:
             fn = getattr(self.lib, "Beatrice20rc0_" + name)
             fn.restype, fn.argtypes = res, args
             setattr(self, name, fn)
+
+
+class AbiLegacy:
+    """Typed view of a library's Beatrice20a2_* or Beatrice20b1_* entry points (generation = "20a2" | "20b1")."""
+
+    def __init__(self, path, generation="20b1"):
+        if not os.path.exists(path):
+            raise FileNotFoundError("beatrice library not built: %s" % path)
+        self.path, self.generation = path, generation
+        self.lib = C.CDLL(path, mode=C.RTLD_LOCAL)
+        for name, (res, args) in _LEGACY_SIG.items():
+            fn = getattr(self.lib, "Beatrice%s_%s" % (generation, name))
+            fn.restype, fn.argtypes = res, args
+            setattr(self, name, fn)
+
+
+class ModelsLegacy:
+    """The five files of a legacy package, read as the reference's ProcessorCore0 / 1 read them
+    (reference src/common/processor_core_1.cc:165-216)."""
+
+    def __init__(self, abi, model_dir):
+        self.abi = abi
+        self.phone, self.pitch, self.wave = abi.CreatePhoneExtractor(), abi.CreatePitchEstimator(), abi.CreateWaveformGenerator()
+        for obj, fn, name in ((self.phone, abi.ReadPhoneExtractorParameters, "phone_extractor.bin"),
+                              (self.pitch, abi.ReadPitchEstimatorParameters, "pitch_estimator.bin"),
+                              (self.wave, abi.ReadWaveformGeneratorParameters, "waveform_generator.bin")):
+            err = fn(obj, os.path.join(model_dir, name).encode())
+            if err:
+                raise RuntimeError("%s: Beatrice_ErrorCode %d" % (name, err))
+        n = C.c_int(0)
+        path = os.path.join(model_dir, "speaker_embeddings.bin").encode()
+        err = abi.ReadNSpeakers(path, C.byref(n))
+        if err:
+            raise RuntimeError("ReadNSpeakers error %d" % err)
+        self.n_speakers = n.value
+        self.speakers = np.zeros((self.n_speakers + 1, HID), np.float32)      # + the morph slot, as the reference keeps it
+        err = abi.ReadSpeakerEmbeddings(path, fptr(self.speakers))
+        self.formant = np.zeros((9, HID), np.float32)
+        err = err or abi.ReadSpeakerEmbeddings(os.path.join(model_dir, "formant_shift_embeddings.bin").encode(), fptr(self.formant))
+        if err:
+            raise RuntimeError("ReadSpeakerEmbeddings error %d" % err)
+
+    def close(self):
+        a = self.abi
+        a.DestroyPhoneExtractor(self.phone)
+        a.DestroyPitchEstimator(self.pitch)
+        a.DestroyWaveformGenerator(self.wave)
+
+
+class StreamLegacy:
+    """One stream through a legacy generation's per-hop protocol (reference src/common/processor_core_1.cc:50-143):
+    phone, pitch, the host's pitch transform (clamped to [1, 383]), speaker vector = speaker + formant-shift row."""
+
+    def __init__(self, models, speaker=0, formant_index=4, min_q=1, max_q=LEGACY_PITCH_BINS - 1):
+        self.m, self.a = models, models.abi
+        a = self.a
+        self.pc, self.tc, self.wc = a.CreatePhoneContext1(), a.CreatePitchContext1(), a.CreateWaveformContext1()
+        self.speaker, self.formant_index = speaker, formant_index
+        self.pitch_params = {}
+        a.SetMinQuantizedPitch(self.tc, min_q)
+        a.SetMaxQuantizedPitch(self.tc, max_q)
+
+    def hop(self, x160, return_all=False):
+        a, m = self.a, self.m
+        x = np.ascontiguousarray(x160, np.float32)
+        phone = np.zeros(LEGACY_PHONE_CH, np.float32)
+        a.ExtractPhone1(m.phone, fptr(x), fptr(phone), self.pc)
+        q = np.zeros(1, np.int32)
+        feat = np.zeros(4, np.float32)
+        a.EstimatePitch1(m.pitch, fptr(x), iptr(q), fptr(feat), self.tc)
+        q2 = np.array([min(pitch_transform(int(q[0]), **self.pitch_params), LEGACY_PITCH_BINS - 1)], np.int32)
+        spk = np.ascontiguousarray(m.speakers[self.speaker] + m.formant[self.formant_index])      # float32 add, as the host does
+        out = np.zeros(OUT_HOP, np.float32)
+        a.GenerateWaveform1(m.wave, fptr(phone), iptr(q2), fptr(feat), fptr(spk), fptr(out), self.wc)
+        if return_all:
+            return out, phone, int(q[0]), feat, int(q2[0]), spk
+        return out
+
+    def close(self):
+        a = self.a
+        a.DestroyPhoneContext1(self.pc)
+        a.DestroyPitchContext1(self.tc)
+        a.DestroyWaveformContext1(self.wc)
 
 
 def load_product():

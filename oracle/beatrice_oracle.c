@@ -723,35 +723,301 @@ Beatrice_ErrorCode Beatrice20rc0_ReadSpeakerEmbeddings(const char* path, float* 
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* Legacy generations (reference beatrice.h:39-203): link-compatible stubs, out of scope for   */
-/* kernels.  Readers fail so a host falls back to "unloaded".         */
+/* Legacy generations 2.0.0-alpha.2 / 2.0.0-beta.1 (boundary: reference beatrice.h:39-203;      */
+/* callers: reference src/common/processor_core_0.cc, processor_core_1.cc).  Arithmetic:       */
+/* MODEL_SPEC section 6 -- the rc.0 modules with a 256-d phone vector and no codebook, 384      */
+/* pitch bins, and a waveform generator conditioned by ONE additive vector handed over per hop  */
+/* (no key/value attention).  Both generations share it; PARITY UNPINNED like the rc.0 core.    */
 /* ------------------------------------------------------------------------------------------ */
-#define LEGACY_STUBS(G, PH)                                                                      \
-  struct G##_PhoneExtractor { int u; }; struct G##_PhoneContext1 { int u; };                     \
-  struct G##_PitchEstimator { int u; }; struct G##_PitchContext1 { int u; };                     \
-  struct G##_WaveformGenerator { int u; }; struct G##_WaveformContext1 { int u; };               \
-  G##_PhoneExtractor* G##_CreatePhoneExtractor(void) { return (G##_PhoneExtractor*)calloc(1, 4); } \
-  void G##_DestroyPhoneExtractor(G##_PhoneExtractor* o) { free(o); }                             \
-  G##_PhoneContext1* G##_CreatePhoneContext1(void) { return (G##_PhoneContext1*)calloc(1, 4); }  \
-  void G##_DestroyPhoneContext1(G##_PhoneContext1* o) { free(o); }                               \
-  G##_PitchEstimator* G##_CreatePitchEstimator(void) { return (G##_PitchEstimator*)calloc(1, 4); } \
-  void G##_DestroyPitchEstimator(G##_PitchEstimator* o) { free(o); }                             \
-  G##_PitchContext1* G##_CreatePitchContext1(void) { return (G##_PitchContext1*)calloc(1, 4); }  \
-  void G##_DestroyPitchContext1(G##_PitchContext1* o) { free(o); }                               \
-  G##_WaveformGenerator* G##_CreateWaveformGenerator(void) { return (G##_WaveformGenerator*)calloc(1, 4); } \
-  void G##_DestroyWaveformGenerator(G##_WaveformGenerator* o) { free(o); }                       \
-  G##_WaveformContext1* G##_CreateWaveformContext1(void) { return (G##_WaveformContext1*)calloc(1, 4); } \
-  void G##_DestroyWaveformContext1(G##_WaveformContext1* o) { free(o); }                         \
-  Beatrice_ErrorCode G##_ReadPhoneExtractorParameters(G##_PhoneExtractor* m, const char* p) { (void)m; (void)p; return Beatrice_kFileOpenError; } \
-  Beatrice_ErrorCode G##_ReadPitchEstimatorParameters(G##_PitchEstimator* m, const char* p) { (void)m; (void)p; return Beatrice_kFileOpenError; } \
-  Beatrice_ErrorCode G##_ReadWaveformGeneratorParameters(G##_WaveformGenerator* m, const char* p) { (void)m; (void)p; return Beatrice_kFileOpenError; } \
-  Beatrice_ErrorCode G##_ReadNSpeakers(const char* p, int* o) { (void)p; (void)o; return Beatrice_kFileOpenError; } \
-  Beatrice_ErrorCode G##_ReadSpeakerEmbeddings(const char* p, float* o) { (void)p; (void)o; return Beatrice_kFileOpenError; } \
-  void G##_ExtractPhone1(const G##_PhoneExtractor* m, const float* in, float* out, G##_PhoneContext1* c) { (void)m; (void)in; (void)c; memset(out, 0, sizeof(float) * PH); } \
-  void G##_SetMinQuantizedPitch(G##_PitchContext1* c, int q) { (void)c; (void)q; }               \
-  void G##_SetMaxQuantizedPitch(G##_PitchContext1* c, int q) { (void)c; (void)q; }               \
-  void G##_EstimatePitch1(const G##_PitchEstimator* m, const float* in, int* q, float* f, G##_PitchContext1* c) { (void)m; (void)in; (void)c; *q = 1; memset(f, 0, 16); } \
-  void G##_GenerateWaveform1(const G##_WaveformGenerator* m, const float* ph, const int* q, const float* f, const float* s, float* out, G##_WaveformContext1* c) { (void)m; (void)ph; (void)q; (void)f; (void)s; (void)c; memset(out, 0, sizeof(float) * OUT_HOP); }
+#define L_PHONE_CH BEATRICE_20B1_PHONE_CHANNELS
+#define L_PITCH_BINS BEATRICE_20B1_PITCH_BINS
+enum { KIND_L_PHONE = 11, KIND_L_PITCH = 12, KIND_L_WAVE = 13, KIND_L_ROWS = 15 };
 
-LEGACY_STUBS(Beatrice20a2, BEATRICE_20A2_PHONE_CHANNELS)
-LEGACY_STUBS(Beatrice20b1, BEATRICE_20B1_PHONE_CHANNELS)
+typedef struct {
+  float* blob;
+  Conv f[5], rb[4];
+  const float *gru_wih, *gru_whh, *gru_bih, *gru_bhh, *out_w, *out_b;
+} LPhone;
+typedef struct { float* fh[5]; float* rbh[4]; float h[256]; } LPhoneCtx;
+static long lphone_n_floats(void) { return phone_n_floats() - (256L * PHONE_CH + PHONE_CH) + (256L * L_PHONE_CH + L_PHONE_CH); }
+static Beatrice_ErrorCode lphone_read(LPhone* m, const char* path) {
+  float* blob; long n;
+  const Beatrice_ErrorCode e = read_file(path, KIND_L_PHONE, lphone_n_floats(), &blob, &n);
+  if (e) return e;
+  free(m->blob);
+  m->blob = blob;
+  const float* p = blob;
+  for (int i = 0; i < 5; ++i) {
+    Conv* c = &m->f[i];
+    c->cin = kPhoneF[i][0]; c->cout = kPhoneF[i][1]; c->k = kPhoneF[i][2]; c->stride = kPhoneF[i][3]; c->dil = 1;
+    c->w = p; p += (long)c->cin * c->k * c->cout;
+    c->b = p; p += c->cout;
+  }
+  for (int i = 0; i < 4; ++i) {
+    Conv* c = &m->rb[i];
+    c->cin = 256; c->cout = 256; c->k = 5; c->stride = 1; c->dil = 1;
+    c->w = p; p += 5L * 256 * 256;
+    c->b = p; p += 256;
+  }
+  m->gru_wih = p; p += 256L * 768; m->gru_whh = p; p += 256L * 768; m->gru_bih = p; p += 768; m->gru_bhh = p; p += 768;
+  m->out_w = p; p += 256L * L_PHONE_CH; m->out_b = p; p += L_PHONE_CH;
+  return Beatrice_kSuccess;
+}
+static void lphone_ctx_init(LPhoneCtx* c) {
+  for (int i = 0; i < 5; ++i) c->fh[i] = (float*)calloc((size_t)((kPhoneF[i][2] - 1) - (kPhoneF[i][3] - 1)) * kPhoneF[i][0], sizeof(float));
+  for (int i = 0; i < 4; ++i) c->rbh[i] = (float*)calloc(4 * 256, sizeof(float));
+}
+static void lphone_ctx_free(LPhoneCtx* c) { for (int i = 0; i < 5; ++i) free(c->fh[i]); for (int i = 0; i < 4; ++i) free(c->rbh[i]); }
+/* MODEL_SPEC 6.1: section 4.1 steps 1-2 with Linear(256 -> 256); no codebook step */
+static void lphone_run(const LPhone* m, const float* input, float* output, LPhoneCtx* ctx) {
+  if (!m->blob) { memset(output, 0, sizeof(float) * L_PHONE_CH); return; }
+  float bufa[32 * 64], bufb[32 * 64];
+  const float* cur = input;
+  int n_in = IN_HOP;
+  float* dst = bufa;
+  for (int i = 0; i < 5; ++i) {
+    conv_run(&m->f[i], ctx->fh[i], cur, n_in, 0, dst);
+    n_in /= m->f[i].stride;
+    for (int e = 0; e < n_in * m->f[i].cout; ++e) dst[e] = sp_gelu(dst[e]);
+    cur = dst;
+    dst = (dst == bufa) ? bufb : bufa;
+  }
+  float x[256], y[256];
+  memcpy(x, cur, sizeof(x));
+  for (int i = 0; i < 4; ++i) {
+    conv_run(&m->rb[i], ctx->rbh[i], x, 1, 0, y);
+    for (int n = 0; n < 256; ++n) x[n] = x[n] + sp_gelu(y[n]);
+  }
+  gru_run(m->gru_wih, m->gru_whh, m->gru_bih, m->gru_bhh, 256, 256, x, ctx->h);
+  linear_run(m->out_w, m->out_b, 256, L_PHONE_CH, ctx->h, output);
+}
+
+typedef struct {
+  float* blob;
+  const float *window, *twiddle;
+  Conv p[3];
+  const float *gru_wih, *gru_whh, *gru_bih, *gru_bhh, *out_w, *out_b, *voi_w, *voi_b;
+} LPitch;
+typedef struct { float audio[PITCH_HIST]; float* ph[3]; float h[128]; int min_q, max_q, prev_q; } LPitchCtx;
+static long lpitch_n_floats(void) { return pitch_n_floats() - (128L * PITCH_BINS + PITCH_BINS) + (128L * L_PITCH_BINS + L_PITCH_BINS); }
+static Beatrice_ErrorCode lpitch_read(LPitch* m, const char* path) {
+  float* blob; long n;
+  const Beatrice_ErrorCode e = read_file(path, KIND_L_PITCH, lpitch_n_floats(), &blob, &n);
+  if (e) return e;
+  free(m->blob);
+  m->blob = blob;
+  const float* p = blob;
+  m->window = p; p += FFT_N;
+  m->twiddle = p; p += FFT_N;
+  for (int i = 0; i < 3; ++i) {
+    Conv* c = &m->p[i];
+    c->cin = i == 0 ? SPEC_BINS : 128; c->cout = 128; c->k = 3; c->stride = 1; c->dil = 1;
+    c->w = p; p += 3L * c->cin * 128;
+    c->b = p; p += 128;
+  }
+  m->gru_wih = p; p += 128L * 384; m->gru_whh = p; p += 128L * 384; m->gru_bih = p; p += 384; m->gru_bhh = p; p += 384;
+  m->out_w = p; p += 128L * L_PITCH_BINS; m->out_b = p; p += L_PITCH_BINS;
+  m->voi_w = p; p += 128; m->voi_b = p; p += 1;
+  return Beatrice_kSuccess;
+}
+static int lclamp_bin(int q) { return q < 1 ? 1 : (q > L_PITCH_BINS - 1 ? L_PITCH_BINS - 1 : q); }
+/* MODEL_SPEC 6.2: section 4.2 with 384 logits, bins in [1, 383] */
+static void lpitch_run(const LPitch* m, const float* input, int* out_q, float* out_feat, LPitchCtx* ctx) {
+  if (!m->blob) { *out_q = 1; memset(out_feat, 0, 4 * sizeof(float)); return; }
+  static _Thread_local float re[FFT_N], im[FFT_N];
+  float frame[FFT_N];
+  memcpy(frame, ctx->audio, sizeof(float) * PITCH_HIST);
+  memcpy(frame + PITCH_HIST, input, sizeof(float) * IN_HOP);
+  memcpy(ctx->audio, frame + IN_HOP, sizeof(float) * PITCH_HIST);
+  for (int i = 0; i < FFT_N; ++i) { re[i] = frame[i] * m->window[i]; im[i] = 0.0f; }
+  fft1024(m->twiddle, re, im);
+  float spec[SPEC_BINS];
+  for (int k = 0; k < SPEC_BINS; ++k) spec[k] = 0.5f * sp_log(sp_fma(im[k], im[k], re[k] * re[k]) + 1e-5f);
+  float x[128], y[128];
+  conv_run(&m->p[0], ctx->ph[0], spec, 1, 0, y);
+  for (int n = 0; n < 128; ++n) x[n] = sp_gelu(y[n]);
+  for (int i = 1; i < 3; ++i) {
+    conv_run(&m->p[i], ctx->ph[i], x, 1, 0, y);
+    for (int n = 0; n < 128; ++n) x[n] = x[n] + sp_gelu(y[n]);
+  }
+  gru_run(m->gru_wih, m->gru_whh, m->gru_bih, m->gru_bhh, 128, 128, x, ctx->h);
+  float logit[L_PITCH_BINS];
+  linear_run(m->out_w, m->out_b, 128, L_PITCH_BINS, ctx->h, logit);
+  int lo = ctx->min_q, hi = ctx->max_q;
+  if (hi < lo) hi = lo;
+  int q = lo;
+  for (int j = lo + 1; j <= hi; ++j) if (logit[j] > logit[q]) q = j;
+  float mx = logit[0];
+  for (int j = 1; j < L_PITCH_BINS; ++j) mx = logit[j] > mx ? logit[j] : mx;
+  float part[64];
+  for (int l = 0; l < 64; ++l) {
+    float a = 0.0f;
+    for (int j = l; j < L_PITCH_BINS; j += 64) a = a + sp_exp(logit[j] - mx);
+    part[l] = a;
+  }
+  out_feat[0] = sp_exp(logit[q] - mx) / sp_wsum64(part);
+  for (int l = 0; l < 64; ++l) {
+    float a = 0.0f;
+    for (int i = l; i < IN_HOP; i += 64) a = sp_fma(input[i], input[i], a);
+    part[l] = a;
+  }
+  out_feat[1] = 0.1f * sp_log(sp_fma(sp_wsum64(part), 1.0f / 160.0f, 1e-8f));
+  float dq = (float)(q - ctx->prev_q) * 0.125f;
+  out_feat[2] = dq < -1.0f ? -1.0f : (dq > 1.0f ? 1.0f : dq);
+  ctx->prev_q = q;
+  for (int l = 0; l < 64; ++l) part[l] = sp_fma(ctx->h[l + 64], m->voi_w[l + 64], sp_fma(ctx->h[l], m->voi_w[l], 0.0f));
+  out_feat[3] = sp_sigmoid(sp_wsum64(part) + m->voi_b[0]);
+  *out_q = q;
+}
+
+typedef struct {
+  float* blob;
+  const float *inp_w, *inp_b, *pitch_emb, *feat_w;
+  Conv c1[N_BLOCKS];
+  const float *c2_w[N_BLOCKS], *c2_b[N_BLOCKS];
+  Conv up[4], ra[4], rb[4], fin;
+} LWave;
+typedef struct { float* c1h[N_BLOCKS]; float* uph[4]; float* rah[4]; float* rbh[4]; float finh[6 * 16]; } LWaveCtx;
+static long lwave_n_floats(void) {
+  long n = L_PHONE_CH * (long)HID + HID + L_PITCH_BINS * (long)HID + 4 * HID;
+  n += N_BLOCKS * ((3L * HID * HID + HID) + (HID * (long)HID + HID));
+  for (int s = 0; s < 4; ++s) {
+    const long cin = kUpCh[s], cout = kUpCh[s + 1], r = kUpRate[s];
+    n += 2 * cin * r * cout + r * cout + 2 * (3 * cout * cout + cout);
+  }
+  return n + 7 * 16 + 1;
+}
+static Beatrice_ErrorCode lwave_read(LWave* m, const char* path) {
+  float* blob; long n;
+  const Beatrice_ErrorCode e = read_file(path, KIND_L_WAVE, lwave_n_floats(), &blob, &n);
+  if (e) return e;
+  free(m->blob);
+  m->blob = blob;
+  const float* p = blob;
+  m->inp_w = p; p += L_PHONE_CH * (long)HID; m->inp_b = p; p += HID;
+  m->pitch_emb = p; p += L_PITCH_BINS * (long)HID;
+  m->feat_w = p; p += 4 * HID;
+  for (int b = 0; b < N_BLOCKS; ++b) {
+    Conv* c = &m->c1[b];
+    c->cin = HID; c->cout = HID; c->k = 3; c->stride = 1; c->dil = kBlockDil[b];
+    c->w = p; p += 3L * HID * HID; c->b = p; p += HID;
+    m->c2_w[b] = p; p += HID * (long)HID; m->c2_b[b] = p; p += HID;
+  }
+  for (int s = 0; s < 4; ++s) {
+    const int cin = kUpCh[s], cout = kUpCh[s + 1], r = kUpRate[s];
+    Conv* u = &m->up[s];
+    u->cin = cin; u->cout = r * cout; u->k = 2; u->stride = 1; u->dil = 1;
+    u->w = p; p += 2L * cin * r * cout; u->b = p; p += r * cout;
+    Conv* a = &m->ra[s];
+    a->cin = cout; a->cout = cout; a->k = 3; a->stride = 1; a->dil = 1;
+    a->w = p; p += 3L * cout * cout; a->b = p; p += cout;
+    Conv* bb = &m->rb[s];
+    bb->cin = cout; bb->cout = cout; bb->k = 3; bb->stride = 1; bb->dil = 3;
+    bb->w = p; p += 3L * cout * cout; bb->b = p; p += cout;
+  }
+  m->fin.cin = 16; m->fin.cout = 1; m->fin.k = 7; m->fin.stride = 1; m->fin.dil = 1;
+  m->fin.w = p; p += 7 * 16; m->fin.b = p; p += 1;
+  return Beatrice_kSuccess;
+}
+static void lwave_ctx_init(LWaveCtx* c) {
+  for (int b = 0; b < N_BLOCKS; ++b) c->c1h[b] = (float*)calloc((size_t)2 * kBlockDil[b] * HID, sizeof(float));
+  for (int s = 0; s < 4; ++s) {
+    c->uph[s] = (float*)calloc((size_t)kUpCh[s], sizeof(float));
+    c->rah[s] = (float*)calloc((size_t)2 * kUpCh[s + 1], sizeof(float));
+    c->rbh[s] = (float*)calloc((size_t)6 * kUpCh[s + 1], sizeof(float));
+  }
+}
+static void lwave_ctx_free(LWaveCtx* c) {
+  for (int b = 0; b < N_BLOCKS; ++b) free(c->c1h[b]);
+  for (int s = 0; s < 4; ++s) { free(c->uph[s]); free(c->rah[s]); free(c->rbh[s]); }
+}
+/* MODEL_SPEC 6.3: e = (PitchEmb[bin] + W_f.feat) + s;  x = Linear(256 -> 256)(phone) + e;  four blocks
+ * x <- x + Linear(gelu(Conv(k3, dil d_b)(x)));  the upsampler of section 4.4.3 */
+static void lwave_run(const LWave* m, const float* phone, const int* qp, const float* feat, const float* spk, float* output, LWaveCtx* ctx) {
+  if (!m->blob) { memset(output, 0, sizeof(float) * OUT_HOP); return; }
+  int q = *qp;
+  q = q < 0 ? 0 : (q > L_PITCH_BINS - 1 ? L_PITCH_BINS - 1 : q);
+  float x[HID], t0[HID], t1[HID];
+  linear_run(m->feat_w, NULL, 4, HID, feat, t0);
+  linear_run(m->inp_w, m->inp_b, L_PHONE_CH, HID, phone, t1);
+  for (int n = 0; n < HID; ++n) x[n] = t1[n] + ((m->pitch_emb[(size_t)q * HID + n] + t0[n]) + spk[n]);
+  for (int b = 0; b < N_BLOCKS; ++b) {
+    float h1[HID];
+    conv_run(&m->c1[b], ctx->c1h[b], x, 1, 0, t0);
+    for (int n = 0; n < HID; ++n) h1[n] = sp_gelu(t0[n]);
+    linear_run(m->c2_w[b], m->c2_b[b], HID, HID, h1, t0);
+    for (int n = 0; n < HID; ++n) x[n] = x[n] + t0[n];
+  }
+  static _Thread_local float ya[OUT_HOP * 16 > 5 * 128 ? OUT_HOP * 16 : 5 * 128], yb[OUT_HOP * 16], yc[OUT_HOP * 16];
+  const float* cur = x;
+  int T = 1;
+  for (int s = 0; s < 4; ++s) {
+    const int cout = kUpCh[s + 1];
+    conv_run(&m->up[s], ctx->uph[s], cur, T, 1, ya);
+    T *= kUpRate[s];
+    conv_run(&m->ra[s], ctx->rah[s], ya, T, 1, yb);
+    for (int e = 0; e < T * cout; ++e) yb[e] = ya[e] + yb[e];
+    conv_run(&m->rb[s], ctx->rbh[s], yb, T, 1, yc);
+    for (int e = 0; e < T * cout; ++e) yc[e] = yb[e] + yc[e];
+    cur = yc;
+  }
+  float fin[OUT_HOP];
+  conv_run(&m->fin, ctx->finh, cur, T, 1, fin);
+  for (int i = 0; i < OUT_HOP; ++i) output[i] = sp_tanh(fin[i]);
+}
+/* embedding rows: [n][256]; the same reader serves speaker_embeddings.bin and formant_shift_embeddings.bin
+ * (reference processor_core_1.cc:189-216) */
+static Beatrice_ErrorCode lrows_open(const char* path, float** blob, int* rows) {
+  long n;
+  const Beatrice_ErrorCode e = read_file(path, KIND_L_ROWS, -1, blob, &n);
+  if (e) return e;
+  if (n < HID) { free(*blob); return Beatrice_kFileTooSmall; }
+  if (n % HID != 0) { free(*blob); return Beatrice_kInvalidFileSize; }
+  *rows = (int)(n / HID);
+  return Beatrice_kSuccess;
+}
+
+#define LEGACY_GENERATION(G)                                                                                     \
+  struct G##_PhoneExtractor { LPhone m; }; struct G##_PhoneContext1 { LPhoneCtx c; };                            \
+  struct G##_PitchEstimator { LPitch m; }; struct G##_PitchContext1 { LPitchCtx c; };                            \
+  struct G##_WaveformGenerator { LWave m; }; struct G##_WaveformContext1 { LWaveCtx c; };                        \
+  G##_PhoneExtractor* G##_CreatePhoneExtractor(void) { return (G##_PhoneExtractor*)calloc(1, sizeof(G##_PhoneExtractor)); } \
+  void G##_DestroyPhoneExtractor(G##_PhoneExtractor* o) { if (o) { free(o->m.blob); free(o); } }                \
+  G##_PhoneContext1* G##_CreatePhoneContext1(void) { G##_PhoneContext1* o = (G##_PhoneContext1*)calloc(1, sizeof(*o)); lphone_ctx_init(&o->c); return o; } \
+  void G##_DestroyPhoneContext1(G##_PhoneContext1* o) { if (o) { lphone_ctx_free(&o->c); free(o); } }           \
+  G##_PitchEstimator* G##_CreatePitchEstimator(void) { return (G##_PitchEstimator*)calloc(1, sizeof(G##_PitchEstimator)); } \
+  void G##_DestroyPitchEstimator(G##_PitchEstimator* o) { if (o) { free(o->m.blob); free(o); } }                \
+  G##_PitchContext1* G##_CreatePitchContext1(void) {                                                             \
+    G##_PitchContext1* o = (G##_PitchContext1*)calloc(1, sizeof(*o));                                            \
+    o->c.ph[0] = (float*)calloc(2 * SPEC_BINS, sizeof(float)); o->c.ph[1] = (float*)calloc(2 * 128, sizeof(float)); \
+    o->c.ph[2] = (float*)calloc(2 * 128, sizeof(float)); o->c.min_q = 1; o->c.max_q = L_PITCH_BINS - 1;          \
+    return o;                                                                                                    \
+  }                                                                                                              \
+  void G##_DestroyPitchContext1(G##_PitchContext1* o) { if (o) { for (int i = 0; i < 3; ++i) free(o->c.ph[i]); free(o); } } \
+  G##_WaveformGenerator* G##_CreateWaveformGenerator(void) { return (G##_WaveformGenerator*)calloc(1, sizeof(G##_WaveformGenerator)); } \
+  void G##_DestroyWaveformGenerator(G##_WaveformGenerator* o) { if (o) { free(o->m.blob); free(o); } }          \
+  G##_WaveformContext1* G##_CreateWaveformContext1(void) { G##_WaveformContext1* o = (G##_WaveformContext1*)calloc(1, sizeof(*o)); lwave_ctx_init(&o->c); return o; } \
+  void G##_DestroyWaveformContext1(G##_WaveformContext1* o) { if (o) { lwave_ctx_free(&o->c); free(o); } }      \
+  Beatrice_ErrorCode G##_ReadPhoneExtractorParameters(G##_PhoneExtractor* m, const char* p) { return lphone_read(&m->m, p); } \
+  Beatrice_ErrorCode G##_ReadPitchEstimatorParameters(G##_PitchEstimator* m, const char* p) { return lpitch_read(&m->m, p); } \
+  Beatrice_ErrorCode G##_ReadWaveformGeneratorParameters(G##_WaveformGenerator* m, const char* p) { return lwave_read(&m->m, p); } \
+  Beatrice_ErrorCode G##_ReadNSpeakers(const char* p, int* o) {                                                  \
+    float* blob; int rows;                                                                                       \
+    const Beatrice_ErrorCode e = lrows_open(p, &blob, &rows);                                                    \
+    if (e) return e;                                                                                             \
+    free(blob); *o = rows; return Beatrice_kSuccess;                                                             \
+  }                                                                                                              \
+  Beatrice_ErrorCode G##_ReadSpeakerEmbeddings(const char* p, float* o) {                                        \
+    float* blob; int rows;                                                                                       \
+    const Beatrice_ErrorCode e = lrows_open(p, &blob, &rows);                                                    \
+    if (e) return e;                                                                                             \
+    memcpy(o, blob, sizeof(float) * (size_t)rows * HID); free(blob); return Beatrice_kSuccess;                   \
+  }                                                                                                              \
+  void G##_ExtractPhone1(const G##_PhoneExtractor* m, const float* in, float* out, G##_PhoneContext1* c) { lphone_run(&m->m, in, out, &c->c); } \
+  void G##_SetMinQuantizedPitch(G##_PitchContext1* c, int q) { c->c.min_q = lclamp_bin(q); }                     \
+  void G##_SetMaxQuantizedPitch(G##_PitchContext1* c, int q) { c->c.max_q = lclamp_bin(q); }                     \
+  void G##_EstimatePitch1(const G##_PitchEstimator* m, const float* in, int* q, float* f, G##_PitchContext1* c) { lpitch_run(&m->m, in, q, f, &c->c); } \
+  void G##_GenerateWaveform1(const G##_WaveformGenerator* m, const float* ph, const int* q, const float* f, const float* s, float* out, G##_WaveformContext1* c) { lwave_run(&m->m, ph, q, f, s, out, &c->c); }
+
+LEGACY_GENERATION(Beatrice20a2)
+LEGACY_GENERATION(Beatrice20b1)

@@ -90,12 +90,12 @@ def gru(xs, wih, whh, bih, bhh):
 class PhoneExtractor:
     FRONT = ((10, 1, 64, 5), (8, 64, 128, 4), (4, 128, 256, 2), (4, 256, 256, 2), (4, 256, 256, 2))
 
-    def __init__(self, model_dir):
-        c = _Cursor(_read(os.path.join(model_dir, "phone_extractor.bin"), 1))
+    def __init__(self, model_dir, out_ch=PHONE_CH, kind=1):   # (legacy generations, MODEL_SPEC 6.1: out_ch 256, file kind 11)
+        c = _Cursor(_read(os.path.join(model_dir, "phone_extractor.bin"), kind))
         self.front = [(c.take(k * cin, cout), c.take(cout), k, s) for k, cin, cout, s in self.FRONT]
         self.res = [(c.take(5 * 256, 256), c.take(256)) for _ in range(4)]
         self.wih, self.whh, self.bih, self.bhh = c.take(256, 768), c.take(256, 768), c.take(768), c.take(768)
-        self.wo, self.bo = c.take(256, PHONE_CH), c.take(PHONE_CH)
+        self.wo, self.bo = c.take(256, out_ch), c.take(out_ch)
         c.done()
 
     def __call__(self, audio, codebook=None, k=0):
@@ -115,17 +115,20 @@ class PhoneExtractor:
 
 # ---- MODEL_SPEC 4.2 --------------------------------------------------------------------------------------------
 class PitchEstimator:
-    def __init__(self, model_dir):
-        c = _Cursor(_read(os.path.join(model_dir, "pitch_estimator.bin"), 2))
+    def __init__(self, model_dir, bins=BINS, kind=2):   # (legacy generations, MODEL_SPEC 6.2: 384 bins, file kind 12)
+        self.bins = bins
+        c = _Cursor(_read(os.path.join(model_dir, "pitch_estimator.bin"), kind))
         self.window, self.twiddle = c.take(FFT_N), c.take(FFT_N // 2, 2)
         self.p1 = (c.take(3 * 512, 128), c.take(128))
         self.res = [(c.take(3 * 128, 128), c.take(128)) for _ in range(2)]
         self.wih, self.whh, self.bih, self.bhh = c.take(128, 384), c.take(128, 384), c.take(384), c.take(384)
-        self.wo, self.bo = c.take(128, BINS), c.take(BINS)
+        self.wo, self.bo = c.take(128, bins), c.take(bins)
         self.v, self.vb = c.take(128), c.take(1)
         c.done()
 
-    def __call__(self, audio, lo=1, hi=BINS - 1):
+    def __call__(self, audio, lo=1, hi=None):
+        BINS = self.bins
+        hi = BINS - 1 if hi is None else hi
         audio = np.asarray(audio, np.float64)
         n = audio.size // IN_HOP
         padded = np.concatenate([np.zeros(FFT_N - IN_HOP), audio])
@@ -193,3 +196,38 @@ class WaveformGenerator:
             y = y + conv(y, *st["a"], 3, dil=1, pre=lrelu)
             y = y + conv(y, *st["b"], 3, dil=3, pre=lrelu)
         return np.tanh(conv(y, self.wfin, self.bfin, 7, pre=lrelu))[:, 0]
+
+
+# ---- MODEL_SPEC 6.3: the waveform generator of the legacy generations ------------------------------------------------
+class LegacyWaveformGenerator:
+    def __init__(self, model_dir):
+        c = _Cursor(_read(os.path.join(model_dir, "waveform_generator.bin"), 13))
+        self.wi, self.bi = c.take(256, HID), c.take(HID)
+        self.pitch_emb, self.wf = c.take(384, HID), c.take(4, HID)
+        self.blocks = [dict(c1=(c.take(3 * HID, HID), c.take(HID)), c2=(c.take(HID, HID), c.take(HID))) for _ in range(N_BLOCKS)]
+        self.up = []
+        for cin, cout, r in WaveformGenerator.UP:
+            self.up.append(dict(t=(c.take(2 * cin, r * cout), c.take(r * cout)), a=(c.take(3 * cout, cout), c.take(cout)),
+                                b=(c.take(3 * cout, cout), c.take(cout)), r=r))
+        self.wfin, self.bfin = c.take(7 * 16, 1), c.take(1)
+        c.done()
+
+    def __call__(self, phone, bins, feat, speaker):
+        """speaker: [frames][256] (the vector the host hands over per hop: speaker + formant-shift embedding)"""
+        phone, feat = np.asarray(phone, np.float64), np.asarray(feat, np.float64)
+        e = (self.pitch_emb[np.asarray(bins)] + feat @ self.wf) + np.asarray(speaker, np.float64)
+        x = (phone @ self.wi + self.bi) + e
+        for blk, d in zip(self.blocks, (1, 2, 4, 8)):
+            h = gelu(conv(x, *blk["c1"], 3, dil=d))
+            x = x + (h @ blk["c2"][0] + blk["c2"][1])
+        y = x
+        for st in self.up:
+            y = conv_transpose(y, *st["t"], st["r"], pre=lrelu)
+            y = y + conv(y, *st["a"], 3, dil=1, pre=lrelu)
+            y = y + conv(y, *st["b"], 3, dil=3, pre=lrelu)
+        return np.tanh(conv(y, self.wfin, self.bfin, 7, pre=lrelu))[:, 0]
+
+
+def read_rows(path):
+    """[n][256] embedding rows of a legacy package (speaker_embeddings.bin, formant_shift_embeddings.bin)"""
+    return _read(path, 15).reshape(-1, HID)

@@ -141,6 +141,73 @@ def speaker_embeddings(rs, n_speakers):
     return t
 
 
+# ---- legacy generations (MODEL_SPEC section 6): 2.0.0-beta.1 (Beatrice20b1_*) and 2.0.0-alpha.2 (Beatrice20a2_*) ----------
+LEGACY_PHONE_CH, LEGACY_PITCH_BINS = 256, 384
+LEGACY_KIND = {"phone_extractor": 11, "pitch_estimator": 12, "waveform_generator": 13, "embedding_rows": 15}
+LEGACY_VERSION = {"2.0.0-beta.1": 1, "2.0.0-alpha.2": 0}
+
+
+def legacy_phone_extractor(rs):
+    t = phone_extractor(rs)[:-2]                                      # front end, residual blocks, GRU as rc.0
+    t += [dense(rs, 256, LEGACY_PHONE_CH, 1.5), bias(rs, LEGACY_PHONE_CH)]
+    return t
+
+
+def legacy_pitch_estimator(rs):
+    t = pitch_estimator(rs)
+    head = [dense(rs, 128, LEGACY_PITCH_BINS, 6.0), bias(rs, LEGACY_PITCH_BINS, 0.5)]
+    return t[:-4] + head + t[-2:]                                     # logits over 384 bins; voicing vector as rc.0
+
+
+def legacy_waveform_generator(rs):
+    t = [dense(rs, LEGACY_PHONE_CH, HID, 1.0), bias(rs, HID)]
+    t += [(rs.uniform(LEGACY_PITCH_BINS * HID) * np.float32(0.5)).astype(np.float32)]
+    t += [dense(rs, 4, HID, 0.5)]
+    for _ in range(N_BLOCKS):
+        t += [dense(rs, 3 * HID, HID, 1.4), bias(rs, HID)]            # dilated conv
+        t += [dense(rs, HID, HID, 0.7), bias(rs, HID)]                # 1x1 (no attention half in these generations)
+    for s in range(4):
+        cin, cout, r = UP_CH[s], UP_CH[s + 1], UP_RATES[s]
+        t += [dense(rs, 2 * cin, r * cout, 1.0), np.tile(bias(rs, cout), r)]
+        t += [dense(rs, 3 * cout, cout, 0.7), bias(rs, cout)]
+        t += [dense(rs, 3 * cout, cout, 0.7), bias(rs, cout)]
+    t += [dense(rs, 7 * 16, 1, 0.45), bias(rs, 1, 0.0)]
+    return t
+
+
+def write_legacy_file(path, kind, tensors):
+    payload = np.concatenate([np.asarray(t, dtype=np.float32).ravel() for t in tensors])
+    with open(path, "wb") as f:
+        f.write(struct.pack("<IIII", MAGIC, LEGACY_KIND[kind], VERSION, payload.size))
+        f.write(payload.astype("<f4").tobytes())
+    return payload.size
+
+
+def make_model_legacy(out_dir, n_speakers=2, seed=0x20B1, version="2.0.0-beta.1"):
+    """A model package of a legacy generation: the five files the reference's ProcessorCore0 / ProcessorCore1 read
+    (reference src/common/processor_core_1.cc:165-216): phone_extractor.bin, pitch_estimator.bin, waveform_generator.bin,
+    speaker_embeddings.bin ([n][256]) and formant_shift_embeddings.bin ([9][256], read with the same reader)."""
+    assert version in LEGACY_VERSION
+    os.makedirs(out_dir, exist_ok=True)
+    sizes = {}
+    for name, fn in (("phone_extractor", legacy_phone_extractor), ("pitch_estimator", legacy_pitch_estimator),
+                     ("waveform_generator", legacy_waveform_generator)):
+        rs = Stream(seed + LEGACY_KIND[name])
+        sizes[name] = write_legacy_file(os.path.join(out_dir, name + ".bin"), name, fn(rs))
+    rs = Stream(seed + LEGACY_KIND["embedding_rows"])
+    sizes["speaker_embeddings"] = write_legacy_file(os.path.join(out_dir, "speaker_embeddings.bin"), "embedding_rows",
+                                                    [unit_rows(rs, n_speakers, HID)])
+    sizes["formant_shift_embeddings"] = write_legacy_file(os.path.join(out_dir, "formant_shift_embeddings.bin"), "embedding_rows",
+                                                          [unit_rows(rs, 9, HID) * np.float32(0.25)])
+    with open(os.path.join(out_dir, "model.toml"), "w") as f:
+        f.write('[model]\nversion = "%s"\nname = "synthetic-legacy-%x"\n' % (version, seed))
+        f.write('description = "deterministic synthetic weights for MODEL_SPEC section 6"\n')
+        for s in range(n_speakers):
+            f.write('\n[voice.%d]\nname = "spk%d"\ndescription = "synthetic speaker %d"\naverage_pitch = 52.0\n' % (s, s, s))
+            f.write('[voice.%d.portrait]\npath = ""\ndescription = ""\n' % s)
+    return sizes
+
+
 def make_model(out_dir, n_speakers=2, seed=0x20C0):
     os.makedirs(out_dir, exist_ok=True)
     sizes = {}
@@ -168,6 +235,8 @@ if __name__ == "__main__":
     ap.add_argument("out_dir")
     ap.add_argument("--speakers", type=int, default=2)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x20C0)
+    ap.add_argument("--legacy", choices=sorted(LEGACY_VERSION), default=None, help="write a legacy-generation package instead")
     a = ap.parse_args()
-    for k, v in make_model(a.out_dir, a.speakers, a.seed).items():
+    sizes = make_model_legacy(a.out_dir, a.speakers, a.seed, a.legacy) if a.legacy else make_model(a.out_dir, a.speakers, a.seed)
+    for k, v in sizes.items():
         print("%-20s %9d floats" % (k, v))
