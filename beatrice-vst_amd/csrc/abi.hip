@@ -131,6 +131,11 @@ static bool run_hop(HopGraph& g, const void* blob, int variant, hipStream_t s, F
   return true;
 }
 
+// the same for callers in other translation units (legacy.hip)
+bool run_hop_graph(HopGraph& g, const void* blob, int variant, hipStream_t s, void (*enqueue)(void*), void* ctx) {
+  return run_hop(g, blob, variant, s, [&] { enqueue(ctx); });
+}
+
 }  // namespace bhip
 
 extern "C" {

@@ -59,8 +59,8 @@ static inline LaunchInfo head_info(const PitchState& s) {
   return LaunchInfo{"pitch.head", 25.0 * s.B * s.H * 448, 4.0 * s.B * s.H * (448 + 160 + 128 + 8)};
 }
 static inline CondArgs cond_args(const WaveWeights& w, const WaveState& s) {
-  return CondArgs{s.H, s.d_q, s.d_feat, s.q_slots, s.B, w.pitch_emb, w.feat_w, s.d_add_tab, s.d_add_idx, s.d_frm_tab, s.d_frm_idx, s.e,
-                  s.front_hop ? s.front_hop : s.hop, s.front_next_out, s.io_slots};
+  return CondArgs{s.H, s.d_q, s.d_feat, s.q_slots, s.B, w.pitch_emb, w.feat_w, s.d_add_tab, s.d_add_idx, s.legacy ? nullptr : s.d_frm_tab, s.d_frm_idx, s.e,
+                  s.front_hop ? s.front_hop : s.hop, s.front_next_out, s.io_slots, s.legacy ? 384 : B_PITCH_BINS};
 }
 static inline LaunchInfo cond_info(const WaveState& s) {
   return LaunchInfo{"wave.cond", 11.0 * s.B * s.H * 256, 4.0 * s.B * s.H * 256 * 4};
@@ -82,7 +82,7 @@ static inline LaunchInfo tail_info(const WaveState& s) {
 
 // phone.out writes the 128-d vector either to the ring the k-NN kernel reads or, when no stream uses
 // the codebook (skip_vq), straight to the module's output
-static inline Ring phone_vector_ring(const PhoneState& s) { return Ring{s.d_phone, B_PHONE_CH, s.H, s.out_slots}; }
+static inline Ring phone_vector_ring(const PhoneState& s) { return Ring{s.d_phone, s.out_ch, s.H, s.out_slots}; }
 static inline Ring phone_out_ring(const PhoneState& s) { return s.skip_vq ? phone_vector_ring(s) : s.raw; }
 
 }  // namespace bhip

@@ -80,15 +80,15 @@ void RingArena::release() {
 // ---- weight binding: the tensor order of MODEL_SPEC section 5 --------------------------------
 static const int kPhoneF[5][4] = {{1, 64, 10, 5}, {64, 128, 8, 4}, {128, 256, 4, 2}, {256, 256, 4, 2}, {256, 256, 4, 2}};
 
-size_t PhoneWeights::n_floats() {
+size_t PhoneWeights::n_floats(int out_ch) {
   size_t n = 0;
   for (auto& f : kPhoneF) n += (size_t)f[0] * f[2] * f[1] + f[1];
   n += 4 * (5 * 256 * 256 + 256);
   n += 2 * 256 * 768 + 2 * 768;
-  n += 256 * B_PHONE_CH + B_PHONE_CH;
+  n += 256 * out_ch + out_ch;
   return n;
 }
-void PhoneWeights::bind(const float* p) {
+void PhoneWeights::bind(const float* p, int out_ch) {
   f1_w = p; p += 10 * 64;
   f1_b = p; p += 64;
   for (int i = 1; i < 5; ++i) {
@@ -100,18 +100,18 @@ void PhoneWeights::bind(const float* p) {
   gru_whh = p; p += 256 * 768;
   gru_bih = p; p += 768;
   gru_bhh = p; p += 768;
-  out_w = p; p += 256 * B_PHONE_CH;
-  out_b = p; p += B_PHONE_CH;
+  out_w = p; p += 256 * out_ch;
+  out_b = p; p += out_ch;
 }
 
-size_t PitchWeights::n_floats() {
+size_t PitchWeights::n_floats(int bins) {
   size_t n = 2 * B_FFT_N;
   n += 3 * B_SPEC_BINS * 128 + 128 + 2 * (3 * 128 * 128 + 128);
   n += 2 * 128 * 384 + 2 * 384;
-  n += 128 * B_PITCH_BINS + B_PITCH_BINS + 128 + 1;
+  n += 128 * bins + bins + 128 + 1;
   return n;
 }
-void PitchWeights::bind(const float* p) {
+void PitchWeights::bind(const float* p, int bins) {
   window = p; p += B_FFT_N;
   twiddle = p; p += B_FFT_N;
   for (int i = 0; i < 3; ++i) {
@@ -123,8 +123,8 @@ void PitchWeights::bind(const float* p) {
   gru_whh = p; p += 128 * 384;
   gru_bih = p; p += 384;
   gru_bhh = p; p += 384;
-  out_w = p; p += 128 * B_PITCH_BINS;
-  out_b = p; p += B_PITCH_BINS;
+  out_w = p; p += 128 * bins;
+  out_b = p; p += bins;
   voi_w = p; p += 128;
   voi_b = p; p += 1;
 }
@@ -141,9 +141,10 @@ void EmbedWeights::bind(const float* p) {
 
 static const int kUpRate[4] = {5, 4, 4, 3};
 static const int kUpCh[5] = {256, 128, 64, 32, 16};
-size_t WaveWeights::n_floats() {
-  size_t n = B_PHONE_CH * B_HID + B_HID + B_PITCH_BINS * B_HID + 4 * B_HID;
-  n += B_NBLOCKS * ((3 * B_HID * B_HID + B_HID) + 3 * (B_HID * B_HID + B_HID));
+size_t WaveWeights::n_floats(bool legacy) {
+  const size_t phone_ch = legacy ? 256 : B_PHONE_CH, bins = legacy ? 384 : B_PITCH_BINS;
+  size_t n = phone_ch * B_HID + B_HID + bins * B_HID + 4 * B_HID;
+  n += B_NBLOCKS * ((3 * B_HID * B_HID + B_HID) + (legacy ? 1 : 3) * (B_HID * B_HID + B_HID));
   for (int s = 0; s < 4; ++s) {
     const size_t cin = kUpCh[s], cout = kUpCh[s + 1], r = kUpRate[s];
     n += 2 * cin * r * cout + r * cout + 2 * (3 * cout * cout + cout);
@@ -151,14 +152,15 @@ size_t WaveWeights::n_floats() {
   n += 7 * 16 + 1;
   return n;
 }
-void WaveWeights::bind(const float* p) {
-  inp_w = p; p += B_PHONE_CH * B_HID;
+void WaveWeights::bind(const float* p, bool legacy) {
+  inp_w = p; p += (legacy ? 256 : B_PHONE_CH) * B_HID;
   inp_b = p; p += B_HID;
-  pitch_emb = p; p += B_PITCH_BINS * B_HID;
+  pitch_emb = p; p += (legacy ? 384 : B_PITCH_BINS) * B_HID;
   feat_w = p; p += 4 * B_HID;
   for (int b = 0; b < B_NBLOCKS; ++b) {
     c1_w[b] = p; p += 3 * B_HID * B_HID; c1_b[b] = p; p += B_HID;
     c2_w[b] = p; p += B_HID * B_HID; c2_b[b] = p; p += B_HID;
+    if (legacy) { q_w[b] = q_b[b] = o_w[b] = o_b[b] = nullptr; continue; }
     q_w[b] = p; p += B_HID * B_HID; q_b[b] = p; p += B_HID;
     o_w[b] = p; p += B_HID * B_HID; o_b[b] = p; p += B_HID;
   }
@@ -180,32 +182,33 @@ static void pack_kn(const float* w_const, int K, int N) {
     for (int n = 0; n < N; ++n) tmp[packed_w_offset(K, kk, n)] = w[(size_t)kk * N + n];
   std::copy(tmp.begin(), tmp.end(), w);
 }
-void PhoneWeights::pack_host(float* base) {
+void PhoneWeights::pack_host(float* base, int out_ch) {
   PhoneWeights w{};
-  w.bind(base);
+  w.bind(base, out_ch);
   for (int i = 1; i < 5; ++i) pack_kn(w.f_w[i - 1], kPhoneF[i][0] * kPhoneF[i][2], kPhoneF[i][1]);
   for (int i = 0; i < 4; ++i) pack_kn(w.rb_w[i], 5 * 256, 256);
   pack_kn(w.gru_wih, 256, 768);
   pack_kn(w.gru_whh, 256, 768);
-  pack_kn(w.out_w, 256, B_PHONE_CH);
+  pack_kn(w.out_w, 256, out_ch);
 }
-void PitchWeights::pack_host(float* base) {
+void PitchWeights::pack_host(float* base, int bins) {
   PitchWeights w{};
-  w.bind(base);
+  w.bind(base, bins);
   pack_kn(w.p_w[0], 3 * B_SPEC_BINS, 128);
   pack_kn(w.p_w[1], 3 * 128, 128);
   pack_kn(w.p_w[2], 3 * 128, 128);
   pack_kn(w.gru_wih, 128, 384);
   pack_kn(w.gru_whh, 128, 384);
-  pack_kn(w.out_w, 128, B_PITCH_BINS);
+  pack_kn(w.out_w, 128, bins);
 }
-void WaveWeights::pack_host(float* base) {
+void WaveWeights::pack_host(float* base, bool legacy) {
   WaveWeights w{};
-  w.bind(base);
-  pack_kn(w.inp_w, B_PHONE_CH, B_HID);
+  w.bind(base, legacy);
+  pack_kn(w.inp_w, legacy ? 256 : B_PHONE_CH, B_HID);
   for (int b = 0; b < B_NBLOCKS; ++b) {
     pack_kn(w.c1_w[b], 3 * B_HID, B_HID);
     pack_kn(w.c2_w[b], B_HID, B_HID);
+    if (legacy) continue;
     pack_kn(w.q_w[b], B_HID, B_HID);
     pack_kn(w.o_w[b], B_HID, B_HID);
   }

@@ -73,9 +73,15 @@ struct PhoneWeights {
   const float *f_w[4], *f_b[4];    // F2..F5
   const float *rb_w[4], *rb_b[4];  // residual blocks
   const float *gru_wih, *gru_whh, *gru_bih, *gru_bhh, *out_w, *out_b;
-  static size_t n_floats();
-  void bind(const float* base);
-  static void pack_host(float* base);  // GEMM tensors -> MFMA-fragment order (conv_gemm.hip.h), in place
+  // out_ch: width of the phone vector -- 128 (rc.0) or 256 (the legacy generations, MODEL_SPEC 6.1)
+  static size_t n_floats(int out_ch = B_PHONE_CH);
+  void bind(const float* base, int out_ch = B_PHONE_CH);
+  static void pack_host(float* base, int out_ch = B_PHONE_CH);  // GEMM tensors -> MFMA-fragment order (conv_gemm.hip.h), in place
+};
+struct PhoneWeightsLegacy : PhoneWeights {   // the same tensors with a 256-wide output layer
+  static size_t n_floats() { return PhoneWeights::n_floats(256); }
+  void bind(const float* base) { PhoneWeights::bind(base, 256); }
+  static void pack_host(float* base) { PhoneWeights::pack_host(base, 256); }
 };
 struct PhoneState {
   int B = 0;
@@ -98,9 +104,10 @@ struct PhoneState {
   int* hop_publish_wave = nullptr;  // batch: ... and to the waveform generator's counter pair [counter & 1]
   bool advance_hop = true;    // this module's forward ends with the counter increment
   bool skip_vq = false;       // no stream uses the codebook: phone.out writes d_phone, no k-NN launch
+  int out_ch = B_PHONE_CH;    // width of the phone vector (256: legacy generations, which have no codebook step)
   // pipe_slack: one more step slot on every ring a later layer reads, so that each LAYER may run as its own pipeline
   // stage one step behind its producer (batch.hip, tick mode)
-  bool create(int B, int H, float* shared_in, int out_slots = 1, bool pipe_slack = false);
+  bool create(int B, int H, float* shared_in, int out_slots = 1, bool pipe_slack = false, int out_ch = B_PHONE_CH);
   void destroy();
 };
 void phone_forward(const PhoneWeights& w, const PhoneState& s, hipStream_t stream);
@@ -110,9 +117,15 @@ struct PitchWeights {
   const float *window, *twiddle;
   const float *p_w[3], *p_b[3];
   const float *gru_wih, *gru_whh, *gru_bih, *gru_bhh, *out_w, *out_b, *voi_w, *voi_b;
-  static size_t n_floats();
-  void bind(const float* base);
-  static void pack_host(float* base);
+  // bins: pitch classes -- 448 (rc.0) or 384 (the legacy generations, MODEL_SPEC 6.2)
+  static size_t n_floats(int bins = B_PITCH_BINS);
+  void bind(const float* base, int bins = B_PITCH_BINS);
+  static void pack_host(float* base, int bins = B_PITCH_BINS);
+};
+struct PitchWeightsLegacy : PitchWeights {
+  static size_t n_floats() { return PitchWeights::n_floats(384); }
+  void bind(const float* base) { PitchWeights::bind(base, 384); }
+  static void pack_host(float* base) { PitchWeights::pack_host(base, 384); }
 };
 struct PitchState {
   int B = 0;
@@ -132,7 +145,8 @@ struct PitchState {
   int* hop = nullptr;         // counter the kernels read (== d_hop unless shared by a batch)
   int* hop_in = nullptr;      // counter the first kernel (FFT) reads
   bool advance_hop = true;    // this module's forward ends with the counter increment
-  bool create(int B, int H, float* shared_in, bool with_params, bool pipe_slack = false);
+  int bins = B_PITCH_BINS;    // pitch classes (384: legacy generations)
+  bool create(int B, int H, float* shared_in, bool with_params, bool pipe_slack = false, int bins = B_PITCH_BINS);
   void destroy();
 };
 void pitch_forward(const PitchWeights& w, const PitchState& s, hipStream_t stream);
@@ -153,9 +167,15 @@ struct WaveWeights {
   const float *q_w[B_NBLOCKS], *q_b[B_NBLOCKS], *o_w[B_NBLOCKS], *o_b[B_NBLOCKS];
   const float *up_w[4], *up_b[4], *ra_w[4], *ra_b[4], *rb_w[4], *rb_b[4];
   const float *fin_w, *fin_b;
-  static size_t n_floats();
-  void bind(const float* base);
-  static void pack_host(float* base);  // every MFMA layer (conv_gemm and the fused tail); fin_w stays plain
+  // legacy (MODEL_SPEC 6.3): phone vector 256 wide, 384 pitch embeddings, blocks without the attention half (no q / o tensors)
+  static size_t n_floats(bool legacy = false);
+  void bind(const float* base, bool legacy = false);
+  static void pack_host(float* base, bool legacy = false);  // every MFMA layer (conv_gemm and the fused tail); fin_w stays plain
+};
+struct WaveWeightsLegacy : WaveWeights {
+  static size_t n_floats() { return WaveWeights::n_floats(true); }
+  void bind(const float* base) { WaveWeights::bind(base, true); }
+  static void pack_host(float* base) { WaveWeights::pack_host(base, true); }
 };
 struct WaveState {
   int B = 0;
@@ -197,8 +217,11 @@ struct WaveState {
   int* front_next_out = nullptr;
   int front_slots = 1;             // step slots of the front end's outputs (phone vector, conditioning e): 1, or 3 in a batch
   bool advance_hop = true;    // this module's forward ends with the counter increment
+  // legacy generations (MODEL_SPEC 6.3, 1-stream ABI only): the phone vector is 256 wide, the pitch embedding has 384 rows, the
+  // conditioning vector is ONE additive row handed over per hop (n_frm = 0: no formant table), blocks are c1 + c2 only
+  bool legacy = false;
   bool create(int B, int H, int n_slots, int n_add, int n_frm, float* shared_phone, int* shared_q, float* shared_feat,
-              int front_slots = 1, bool pipe_slack = false);
+              int front_slots = 1, bool pipe_slack = false, bool legacy = false);
   void destroy();
 };
 // parts of the module, for pipelines that cut it into stages: 1 = input mix, 2..5 = conditioned blocks 0..3,

@@ -348,14 +348,16 @@ __device__ __forceinline__ void pitch_head_body(const PitchHeadArgs& a, const in
   for (int hh = 0; hh < a.H; ++hh) {
     const size_t row = (size_t)b * a.H + hh;
     const float* lg = ring_frame(a.logits, b, pos_l, hh);
+    const int n_slot = a.logits.C >> 6;   // logits per lane: 7 (448 bins) or 6 (384 bins, the legacy generations)
     float v[7];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) v[i] = lg[l + 64 * i];
+    for (int i = 0; i < 7; ++i) v[i] = i < n_slot ? lg[l + 64 * i] : 0.0f;
     float bv = -__builtin_huge_valf();
     int bj = 0x7fffffff;
     float mx = v[0];
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
+      if (i >= n_slot) break;
       const int j = l + 64 * i;
       mx = fmaxf(mx, v[i]);
       if (j >= lo && j <= hi && (bj == 0x7fffffff || v[i] > bv)) { bv = v[i]; bj = j; }
@@ -370,7 +372,7 @@ __device__ __forceinline__ void pitch_head_body(const PitchHeadArgs& a, const in
     mx = bsp::wmax64(mx);
     float s = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) s = s + bsp::exp(v[i] - mx);
+    for (int i = 0; i < 7; ++i) if (i < n_slot) s = s + bsp::exp(v[i] - mx);
     const float f0 = bsp::exp(lg[q] - mx) / bsp::wsum64(s);
     const float* x = a.d_in + (a.io_stride != 0 ? (size_t)stepc::slot(a.hop) * a.io_stride : 0) + row * B_IN_HOP;
     float en = 0.0f;
@@ -425,6 +427,8 @@ struct CondArgs {
   int* hop_next_out;   // optional (batch): row 0 stores {counter + 1, next resident-I/O slot} for the next step's first kernels;
                        // no kernel of this step's front end reads that pair after its first launch
   int io_slots;
+  int n_bins;          // rows of pitch_emb: 448, or 384 in the legacy generations -- which also have no formant table
+                       // (frm_tab == nullptr): their conditioning is the ONE row add_tab[add_idx] the host hands over per hop
 };
 __device__ __forceinline__ void wave_cond_body(const CondArgs& a, const int row, const int n = threadIdx.x) {
   const int b = row / a.H;
@@ -432,12 +436,13 @@ __device__ __forceinline__ void wave_cond_body(const CondArgs& a, const int row,
   if (hop < 0) return;
   const size_t qoff = (size_t)(hop % a.q_slots) * a.B * a.H;
   int q = a.q[qoff + row];
-  q = q < 0 ? 0 : (q > B_PITCH_BINS - 1 ? B_PITCH_BINS - 1 : q);
+  q = q < 0 ? 0 : (q > a.n_bins - 1 ? a.n_bins - 1 : q);
   const float* f = a.feat + (qoff + row) * 4;
   float fp = 0.0f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) fp = bsp::fma(f[i], a.feat_w[i * B_HID + n], fp);
-  const float c = a.add_tab[(size_t)a.add_idx[b] * B_HID + n] + a.frm_tab[(size_t)a.frm_idx[b] * B_HID + n];
+  float c = a.add_tab[(size_t)a.add_idx[b] * B_HID + n];
+  if (a.frm_tab != nullptr) c = c + a.frm_tab[(size_t)a.frm_idx[b] * B_HID + n];
   ring_frame(a.e, b, ring_pos(a.e, hop), row % a.H)[n] = (a.pitch_emb[(size_t)q * B_HID + n] + fp) + c;
   if (a.hop_next_out != nullptr && row == 0 && n == 0) {
     const int io = a.io_slots > 0 ? stepc::slot(a.hop) : 0;

@@ -5,8 +5,8 @@
 
 namespace bhip {
 
-bool PhoneState::create(int B_, int H_, float* shared_in, int out_slots_, bool pipe_slack) {
-  B = B_; H = H_; out_slots = out_slots_;
+bool PhoneState::create(int B_, int H_, float* shared_in, int out_slots_, bool pipe_slack, int out_ch_) {
+  B = B_; H = H_; out_slots = out_slots_; out_ch = out_ch_;
   const int x = pipe_slack ? 1 : 0;  // the reader of a ring may be one step behind its writer
   auto slots = [&](int n0, int hist) { return 1 + (hist + n0 * H - 1) / (n0 * H); };
   std::vector<RingSpec> specs = {
@@ -14,7 +14,7 @@ bool PhoneState::create(int B_, int H_, float* shared_in, int out_slots_, bool p
       {&f[0], 64, 32 * H, slots(32, 4) + x}, {&f[1], 128, 8 * H, slots(8, 2) + x}, {&f[2], 256, 4 * H, slots(4, 2) + x},
       {&f[3], 256, 2 * H, slots(2, 2) + x}, {&f[4], 256, H, slots(1, 4) + x},
       {&rb[0], 256, H, slots(1, 4) + x}, {&rb[1], 256, H, slots(1, 4) + x}, {&rb[2], 256, H, slots(1, 4) + x}, {&rb[3], 256, H, 1 + x},
-      {&h, 256, H, slots(1, 1) + x}, {&raw, B_PHONE_CH, H, 1 + x},
+      {&h, 256, H, slots(1, 1) + x}, {&raw, out_ch, H, 1 + x},
   };
   if (!arena.build(B, specs)) return false;
   if (shared_in) { d_in = shared_in; owns_in = false; }
@@ -26,12 +26,12 @@ bool PhoneState::create(int B_, int H_, float* shared_in, int out_slots_, bool p
     owns_in = true;
     hop_mailbox = reinterpret_cast<int*>(d_in + (size_t)B * H * B_IN_HOP);
   }
-  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_phone), sizeof(float) * B * H * B_PHONE_CH * out_slots));
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_phone), sizeof(float) * B * H * out_ch * out_slots));
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cbT), sizeof(float*) * B * H));
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cnorm), sizeof(float*) * B * H));
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_vqk), sizeof(int) * B));
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hop), 2 * sizeof(int)));  // [0] step counter, [1] resident-I/O slot
-  BHIP_TRY(hipMemset(d_phone, 0, sizeof(float) * B * H * B_PHONE_CH * out_slots));
+  BHIP_TRY(hipMemset(d_phone, 0, sizeof(float) * B * H * out_ch * out_slots));
   BHIP_TRY(hipMemset(d_cbT, 0, sizeof(float*) * B * H));
   BHIP_TRY(hipMemset(d_cnorm, 0, sizeof(float*) * B * H));
   BHIP_TRY(hipMemset(d_vqk, 0, sizeof(int) * B));
@@ -87,7 +87,11 @@ static void phone_forward_h(const PhoneWeights& w, const PhoneState& s, hipStrea
     GruArgs ga{s.rb[3], s.h, w.gru_wih, w.gru_whh, w.gru_bih, w.gru_bhh, s.hop, B, t};
     launch_gru<256, 256>("phone.gru", ga, st);
   }
-  launch_auto<typename PL::OUTL>("phone.out", conv_args(s.h, phone_out_ring(s), w.out_w, w.out_b, s.hop, B), st);
+  if (s.out_ch == 256) {  // the legacy generations' 256-wide phone vector (MODEL_SPEC 6.1); they have no codebook step
+    launch_auto<Layer<256, 256, 1, 1, 1, H, PRE_NONE, ACT_NONE, EPI_BIAS, false>>("phone.out", conv_args(s.h, phone_out_ring(s), w.out_w, w.out_b, s.hop, B), st);
+  } else {
+    launch_auto<typename PL::OUTL>("phone.out", conv_args(s.h, phone_out_ring(s), w.out_w, w.out_b, s.hop, B), st);
+  }
   phone_vq(w, s, st);
 }
 

@@ -5,15 +5,15 @@
 
 namespace bhip {
 
-bool PitchState::create(int B_, int H_, float* shared_in, bool with_params, bool pipe_slack) {
-  B = B_; H = H_;
+bool PitchState::create(int B_, int H_, float* shared_in, bool with_params, bool pipe_slack, int bins_) {
+  B = B_; H = H_; bins = bins_;
   const int x = pipe_slack ? 1 : 0;  // see PhoneState::create; the GRU state is also read by the pitch head, two stages on
   q_slots = pipe_slack ? 2 : 1;
   auto slots = [&](int n0, int hist) { return 1 + (hist + n0 * H - 1) / (n0 * H); };
   std::vector<RingSpec> specs = {
       {&audio, 1, B_IN_HOP * H, slots(B_IN_HOP, B_PITCH_HIST)},
       {&spec, B_SPEC_BINS, H, slots(1, 2) + x}, {&p[0], 128, H, slots(1, 2) + x}, {&p[1], 128, H, slots(1, 2) + x}, {&p[2], 128, H, 1 + x},
-      {&h, 128, H, slots(1, 1) + 2 * x}, {&logits, B_PITCH_BINS, H, 1 + x},
+      {&h, 128, H, slots(1, 1) + 2 * x}, {&logits, bins, H, 1 + x},
   };
   if (!arena.build(B, specs)) return false;
   if (shared_in) { d_in = shared_in; owns_in = false; }
@@ -35,7 +35,7 @@ bool PitchState::create(int B_, int H_, float* shared_in, bool with_params, bool
   }
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_feat), sizeof(float) * 4 * B * H * q_slots));
   BHIP_TRY(hipMemset(d_feat, 0, sizeof(float) * 4 * B * H * q_slots));
-  std::vector<int> lo(B, 1), hi(B, B_PITCH_BINS - 1);
+  std::vector<int> lo(B, 1), hi(B, bins - 1);
   BHIP_TRY(hipMemcpy(d_min_q, lo.data(), sizeof(int) * B, hipMemcpyHostToDevice));
   BHIP_TRY(hipMemcpy(d_max_q, hi.data(), sizeof(int) * B, hipMemcpyHostToDevice));
   if (with_params) {
@@ -74,7 +74,11 @@ static void pitch_forward_h(const PitchWeights& w, const PitchState& s, hipStrea
     GruArgs ga{s.p[2], s.h, w.gru_wih, w.gru_whh, w.gru_bih, w.gru_bhh, s.hop, B, t};
     launch_gru<128, 128>("pitch.gru", ga, st);
   }
-  launch_auto<typename QL::POUT>("pitch.out", conv_args(s.h, s.logits, w.out_w, w.out_b, s.hop, B), st);
+  if (s.bins == 384) {  // the legacy generations' 384 pitch classes (MODEL_SPEC 6.2)
+    launch_auto<Layer<128, 384, 1, 1, 1, H, PRE_NONE, ACT_NONE, EPI_BIAS, false>>("pitch.out", conv_args(s.h, s.logits, w.out_w, w.out_b, s.hop, B), st);
+  } else {
+    launch_auto<typename QL::POUT>("pitch.out", conv_args(s.h, s.logits, w.out_w, w.out_b, s.hop, B), st);
+  }
   const PitchHeadArgs a = head_args(w, s);
   launch_site(head_info(s), st, [&] { hipLaunchKernelGGL(pitch_head_kernel, dim3(B), dim3(64), 0, st, a); });
   if (s.advance_hop) MISC_LAUNCH("hop_advance", 0, 4, hop_advance_kernel, dim3(1), dim3(1), s.hop);

@@ -10,8 +10,8 @@ namespace bhip {
 static const int kBlockDil[B_NBLOCKS] = {1, 2, 4, 8};
 
 bool WaveState::create(int B_, int H_, int n_slots_, int n_add_, int n_frm_, float* shared_phone, int* shared_q,
-                       float* shared_feat, int front_slots_, bool pipe_slack) {
-  B = B_; H = H_; n_slots = n_slots_; n_add = n_add_; n_frm = n_frm_; front_slots = front_slots_;
+                       float* shared_feat, int front_slots_, bool pipe_slack, bool legacy_) {
+  B = B_; H = H_; n_slots = n_slots_; n_add = n_add_; n_frm = n_frm_; front_slots = front_slots_; legacy = legacy_;
   const int ps = pipe_slack ? 1 : 0;  // every layer its own pipeline stage (tick mode): readers run a step behind
   boundary_slots = front_slots_ > 1 ? 2 : 0;  // a batch may cut the module into pipeline stages
   const int xs = boundary_slots;
@@ -119,10 +119,11 @@ static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t
     launch_site(cond_info(s), st, [&] { hipLaunchKernelGGL(wave_cond_kernel, dim3(rows), dim3(256), 0, st, ca); });
   }
   if (in_part(1)) {
-    const Ring phone_in{s.d_phone, B_PHONE_CH, H, s.front_slots};
+    const Ring phone_in{s.d_phone, s.legacy ? 256 : B_PHONE_CH, H, s.front_slots};
     a = conv_args(phone_in, s.x[0], w.inp_w, w.inp_b, s.hop, B);
     a.res = s.e;
-    launch_auto<INP<H>>("wave.inp", a, st);
+    if (s.legacy) launch_auto<Layer<256, B_HID, 1, 1, 1, H, PRE_NONE, ACT_NONE, EPI_BIAS, true>>("wave.inp", a, st);
+    else launch_auto<INP<H>>("wave.inp", a, st);
   }
   // The conditioned blocks as two stream-stationary kernels each (rowchain.hip.h) instead of six per-layer launches: the
   // per-layer launches win while a launch cannot fill the chip (256 streams: 0.293 vs 0.413 ms per step), the row-local
@@ -132,7 +133,7 @@ static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t
   const bool rowchain = rc_env != nullptr ? rc_env[0] != '0' : B >= 2048;
   for (int blk = 0; blk < B_NBLOCKS; ++blk) {
     if (!in_part(2 + blk)) continue;
-    if (rowchain && H == 1) {
+    if (rowchain && H == 1 && !s.legacy) {
       const rc::BlockAArgs aa{s.x[blk], k.xa, w.c1_w[blk], w.c1_b[blk], w.c2_w[blk], w.c2_b[blk], s.hop, B};
       const dim3 ga((B + 15) / 16);
       launch_site(rc::BlockAOp<1>::info(aa), st, [&] {
@@ -154,6 +155,12 @@ static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t
       case 1: launch_c1<2, H>(w, s, blk, k.h1, st); break;
       case 2: launch_c1<4, H>(w, s, blk, k.h1, st); break;
       default: launch_c1<8, H>(w, s, blk, k.h1, st); break;
+    }
+    if (s.legacy) {  // MODEL_SPEC 6.3: the block ends here -- x' = x + Linear(h), no attention half
+      a = conv_args(k.h1, s.x[blk + 1], w.c2_w[blk], w.c2_b[blk], s.hop, B);
+      a.res = s.x[blk];
+      launch_auto<C2<H>>("wave.blk.c2o", a, st);
+      continue;
     }
     a = conv_args(k.h1, k.xa, w.c2_w[blk], w.c2_b[blk], s.hop, B);
     a.res = s.x[blk];
