@@ -124,14 +124,17 @@ static void ConfigureBridge(RateBridge& b, double sr) {
   b.Configure(sr, 48000.0, 0.99 * 16000.0 / std::clamp(sr, 16000.0, 48000.0), 0.99 * 24000.0 / std::clamp(sr, 24000.0, 48000.0));
 }
 
+StreamingCore::StreamingCore(double sample_rate, int pitch_bins)
+    : sample_rate_(sample_rate), pitch_bins_(pitch_bins), gain_in_(sample_rate), gain_out_(sample_rate), fifo_(kBlock, 0.0f) {
+  ConfigureBridge(bridge_, sample_rate);
+}
+
 ProcessorCore2::ProcessorCore2(double sample_rate)
-    : sample_rate_(sample_rate), gain_in_(sample_rate), gain_out_(sample_rate), fifo_(kBlock, 0.0f),
+    : StreamingCore(sample_rate, BEATRICE_20RC0_PITCH_BINS),
       phone_extractor_(Beatrice20rc0_CreatePhoneExtractor()), pitch_estimator_(Beatrice20rc0_CreatePitchEstimator()),
       waveform_generator_(Beatrice20rc0_CreateWaveformGenerator()), embedding_setter_(Beatrice20rc0_CreateEmbeddingSetter()),
       phone_context_(Beatrice20rc0_CreatePhoneContext1()), pitch_context_(Beatrice20rc0_CreatePitchContext1()),
-      waveform_context_(Beatrice20rc0_CreateWaveformContext1()), embedding_context_(Beatrice20rc0_CreateEmbeddingContext()) {
-  ConfigureBridge(bridge_, sample_rate);
-}
+      waveform_context_(Beatrice20rc0_CreateWaveformContext1()), embedding_context_(Beatrice20rc0_CreateEmbeddingContext()) {}
 
 ProcessorCore2::~ProcessorCore2() {
   Beatrice20rc0_DestroyPhoneExtractor(phone_extractor_);
@@ -145,11 +148,12 @@ ProcessorCore2::~ProcessorCore2() {
 }
 
 // guards and chain: reference processor_core_2.cc:24-48
-ErrorCode ProcessorCore2::Process(const float* input, float* output, int n_samples) {
+ErrorCode StreamingCore::Process(const float* input, float* output, int n_samples) {
   auto silence = [&](ErrorCode e) { std::memset(output, 0, sizeof(float) * n_samples); return e; };
   if (!IsLoaded()) return silence(ErrorCode::kModelNotLoaded);
   if (!bridge_.IsReady()) return silence(ErrorCode::kResamplerNotReady);
   if (!gain_in_.IsReady() || !gain_out_.IsReady()) return silence(ErrorCode::kGainNotReady);
+  if (const ErrorCode e = Preflight(); e != ErrorCode::kSuccess) return silence(e);
   if (pitch_correction_type_ < 0 || pitch_correction_type_ > 1) return silence(ErrorCode::kInvalidPitchCorrectionType);
   io_.resize(n_samples);
   gain_in_.Apply(input, io_.data(), n_samples);
@@ -164,7 +168,7 @@ ErrorCode ProcessorCore2::Process(const float* input, float* output, int n_sampl
 }
 
 // exact-480 FIFO, emits the previous block's result (reference resample.h:343-363)
-void ProcessorCore2::Reblock(const float* in, float* out, int n) {
+void StreamingCore::Reblock(const float* in, float* out, int n) {
   int done = 0;
   while (done < n) {
     const int take = std::min(kBlock - fifo_fill_, n - done);
@@ -182,7 +186,7 @@ void ProcessorCore2::Reblock(const float* in, float* out, int n) {
 }
 
 // 480 @48 kHz -> every third sample -> model hop -> zero-stuffed 480 (reference resample.h:380-394)
-void ProcessorCore2::Block480(const float* in480, float* out480) {
+void StreamingCore::Block480(const float* in480, float* out480) {
   alignas(64) float in160[BEATRICE_IN_HOP_LENGTH];
   alignas(64) float out240[BEATRICE_OUT_HOP_LENGTH];
   for (int i = 0; i < BEATRICE_IN_HOP_LENGTH; ++i) in160[i] = in480[3 * i + 2];
@@ -206,7 +210,7 @@ void ProcessorCore2::Hop(const float* in160, float* out240) {
 }
 
 // pitch shift, intonation, correction, clamp (reference processor_core_2.cc:190-252)
-int ProcessorCore2::TransformPitch(int q) const {
+int StreamingCore::TransformPitch(int q) const {
   double t = average_source_pitch_ + (static_cast<double>(q) - average_source_pitch_) * intonation_intensity_ +
              kBinsPerSemitone * pitch_shift_;
   if (pitch_correction_ != 0.0) {
@@ -222,7 +226,7 @@ int ProcessorCore2::TransformPitch(int q) const {
       else t = anchor - std::pow(-d, 1.0 / (1.0 - pitch_correction_)) * (kBinsPerSemitone / 2.0);
     }
   }
-  return std::clamp(static_cast<int>(std::round(t)), 1, BEATRICE_20RC0_PITCH_BINS - 1);
+  return std::clamp(static_cast<int>(std::round(t)), 1, pitch_bins_ - 1);
 }
 
 bool ProcessorCore2::InstallNextKeyValueBlock() {  // reference processor_core_2.h:161-169
@@ -304,7 +308,7 @@ ErrorCode ProcessorCore2::ResetContext() {
   return error;
 }
 
-ErrorCode ProcessorCore2::SetSampleRate(double sr) {  // reference processor_core_2.cc:421-429
+ErrorCode StreamingCore::SetSampleRate(double sr) {  // reference processor_core_2.cc:421-429
   if (sr == sample_rate_) return ErrorCode::kSuccess;
   sample_rate_ = sr;
   ConfigureBridge(bridge_, sr);
@@ -337,20 +341,20 @@ ErrorCode ProcessorCore2::SetFormantShift(double v) {  // reference processor_co
                                          embedding_context_, waveform_context_);
   return ErrorCode::kSuccess;
 }
-ErrorCode ProcessorCore2::SetPitchShift(double v) { pitch_shift_ = std::clamp(v, -24.0, 24.0); return ErrorCode::kSuccess; }
-ErrorCode ProcessorCore2::SetInputGain(double db) { gain_in_.SetTargetGain(db); return ErrorCode::kSuccess; }
-ErrorCode ProcessorCore2::SetOutputGain(double db) { gain_out_.SetTargetGain(db); return ErrorCode::kSuccess; }
-ErrorCode ProcessorCore2::SetAverageSourcePitch(double v) { average_source_pitch_ = std::clamp(v, 0.0, 128.0); return ErrorCode::kSuccess; }
-ErrorCode ProcessorCore2::SetIntonationIntensity(double v) { intonation_intensity_ = v; return ErrorCode::kSuccess; }
-ErrorCode ProcessorCore2::SetPitchCorrection(double v) { pitch_correction_ = std::clamp(v, 0.0, 1.0); return ErrorCode::kSuccess; }
-ErrorCode ProcessorCore2::SetPitchCorrectionType(int type) {
+ErrorCode StreamingCore::SetPitchShift(double v) { pitch_shift_ = std::clamp(v, -24.0, 24.0); return ErrorCode::kSuccess; }
+ErrorCode StreamingCore::SetInputGain(double db) { gain_in_.SetTargetGain(db); return ErrorCode::kSuccess; }
+ErrorCode StreamingCore::SetOutputGain(double db) { gain_out_.SetTargetGain(db); return ErrorCode::kSuccess; }
+ErrorCode StreamingCore::SetAverageSourcePitch(double v) { average_source_pitch_ = std::clamp(v, 0.0, 128.0); return ErrorCode::kSuccess; }
+ErrorCode StreamingCore::SetIntonationIntensity(double v) { intonation_intensity_ = v; return ErrorCode::kSuccess; }
+ErrorCode StreamingCore::SetPitchCorrection(double v) { pitch_correction_ = std::clamp(v, 0.0, 1.0); return ErrorCode::kSuccess; }
+ErrorCode StreamingCore::SetPitchCorrectionType(int type) {
   if (type < 0 || type > 1) return ErrorCode::kInvalidPitchCorrectionType;
   pitch_correction_type_ = type;
   return ErrorCode::kSuccess;
 }
-static int NoteToBin(double note) {  // reference processor_core_2.cc:561-583
+int StreamingCore::NoteToBin(double note) const {  // reference processor_core_2.cc:561-583
   const int q = static_cast<int>(std::round((note - 33.0) * kBinsPerSemitone));
-  return std::clamp(q, 1, BEATRICE_20RC0_PITCH_BINS - 1);
+  return std::clamp(q, 1, pitch_bins_ - 1);
 }
 ErrorCode ProcessorCore2::SetMinSourcePitch(double v) {
   min_source_pitch_ = std::clamp(v, 0.0, 128.0);
@@ -369,6 +373,15 @@ ErrorCode ProcessorCore2::SetVQNumNeighbors(int k) {  // reference processor_cor
 }
 
 // ---- morphing ------------------------------------------------------------------------------------
+std::array<float, kMaxNSpeakers> PrepareVoiceMorphWeights(std::array<float, kMaxNSpeakers> w, int speaker_count) {
+  if (speaker_count <= 0) return {};
+  const int count = std::min(speaker_count, kMaxNSpeakers);
+  for (int i = count; i < kMaxNSpeakers; ++i) w[count - 1] += w[i];
+  std::fill(w.begin() + count, w.end(), 0.0f);
+  for (int i = 0; i < count; ++i) if (w[i] < 0.01f) w[i] = 0.0f;
+  return w;
+}
+
 ErrorCode ProcessorCore2::SetSpeakerMorphingWeights(const std::array<float, kMaxNSpeakers>& weights) {
   if (weights == morph_weights_) return ErrorCode::kSuccess;  // reference processor_core_2.cc:498-505
   morph_weights_ = weights;
@@ -379,15 +392,7 @@ ErrorCode ProcessorCore2::SetSpeakerMorphingWeights(const std::array<float, kMax
 // voice_morph_state.h:87-104), then the 8 largest kept (processor_core_2.cc:507-532)
 ErrorCode ProcessorCore2::ApplySpeakerMorphingWeights() {
   if (!ready_to_set_speaker_) return ErrorCode::kSuccess;
-  std::array<float, kMaxNSpeakers> w = morph_weights_;
-  if (n_speakers_ <= 0) {
-    w.fill(0.0f);
-  } else {
-    const int count = std::min(n_speakers_, kMaxNSpeakers);
-    for (int i = count; i < kMaxNSpeakers; ++i) w[count - 1] += w[i];
-    std::fill(w.begin() + count, w.end(), 0.0f);
-    for (int i = 0; i < count; ++i) if (w[i] < 0.01f) w[i] = 0.0f;
-  }
+  const std::array<float, kMaxNSpeakers> w = PrepareVoiceMorphWeights(morph_weights_, n_speakers_);
   std::iota(morph_order_.data(), morph_order_.data() + n_speakers_, 0);
   std::sort(morph_order_.data(), morph_order_.data() + n_speakers_, [&w](const int a, const int b) -> bool { return w[a] > w[b]; });
   morph_pruned_.fill(0.0f);
@@ -444,36 +449,49 @@ void ProcessorCore2::MorphStep() {
 
 }  // namespace beatrice_amd
 
-// ---- plain-C view of the class for FFI callers and the tests ------------------------------------
-using beatrice_amd::ProcessorCore2;
-extern "C" {
-void* BeatriceHost_Create(double sample_rate) { return new ProcessorCore2(sample_rate); }
-void BeatriceHost_Destroy(void* p) { delete static_cast<ProcessorCore2*>(p); }
-int BeatriceHost_LoadModel(void* p, const char* toml_path) { return static_cast<int>(static_cast<ProcessorCore2*>(p)->LoadModel(toml_path)); }
-int BeatriceHost_Process(void* p, const float* in, float* out, int n) { return static_cast<int>(static_cast<ProcessorCore2*>(p)->Process(in, out, n)); }
-int BeatriceHost_ResetContext(void* p) { return static_cast<int>(static_cast<ProcessorCore2*>(p)->ResetContext()); }
-int BeatriceHost_SetSampleRate(void* p, double v) { return static_cast<int>(static_cast<ProcessorCore2*>(p)->SetSampleRate(v)); }
-int BeatriceHost_SetTargetSpeaker(void* p, int v) { return static_cast<int>(static_cast<ProcessorCore2*>(p)->SetTargetSpeaker(v)); }
-int BeatriceHost_SetFormantShift(void* p, double v) { return static_cast<int>(static_cast<ProcessorCore2*>(p)->SetFormantShift(v)); }
-int BeatriceHost_SetPitchShift(void* p, double v) { return static_cast<int>(static_cast<ProcessorCore2*>(p)->SetPitchShift(v)); }
-int BeatriceHost_SetInputGain(void* p, double v) { return static_cast<int>(static_cast<ProcessorCore2*>(p)->SetInputGain(v)); }
-int BeatriceHost_SetOutputGain(void* p, double v) { return static_cast<int>(static_cast<ProcessorCore2*>(p)->SetOutputGain(v)); }
-int BeatriceHost_SetAverageSourcePitch(void* p, double v) { return static_cast<int>(static_cast<ProcessorCore2*>(p)->SetAverageSourcePitch(v)); }
-int BeatriceHost_SetIntonationIntensity(void* p, double v) { return static_cast<int>(static_cast<ProcessorCore2*>(p)->SetIntonationIntensity(v)); }
-int BeatriceHost_SetPitchCorrection(void* p, double v) { return static_cast<int>(static_cast<ProcessorCore2*>(p)->SetPitchCorrection(v)); }
-int BeatriceHost_SetPitchCorrectionType(void* p, int v) { return static_cast<int>(static_cast<ProcessorCore2*>(p)->SetPitchCorrectionType(v)); }
-int BeatriceHost_SetMinSourcePitch(void* p, double v) { return static_cast<int>(static_cast<ProcessorCore2*>(p)->SetMinSourcePitch(v)); }
-int BeatriceHost_SetMaxSourcePitch(void* p, double v) { return static_cast<int>(static_cast<ProcessorCore2*>(p)->SetMaxSourcePitch(v)); }
-int BeatriceHost_SetVQNumNeighbors(void* p, int v) { return static_cast<int>(static_cast<ProcessorCore2*>(p)->SetVQNumNeighbors(v)); }
-int BeatriceHost_SetSpeakerMorphingWeights(void* p, const float* weights, int n) {
-  std::array<float, ProcessorCore2::kMaxNSpeakers> w{};
-  for (int i = 0; i < n && i < ProcessorCore2::kMaxNSpeakers; ++i) w[i] = weights[i];
-  return static_cast<int>(static_cast<ProcessorCore2*>(p)->SetSpeakerMorphingWeights(w));
+// ---- plain-C view of the classes for FFI callers and the tests ----------------------------------
+using beatrice_amd::ProcessorCoreBase;
+namespace beatrice_amd {
+std::unique_ptr<ProcessorCoreBase> MakeProcessorCore(int version, double sample_rate) {  // reference processor_proxy.h:57-70
+  switch (version) {
+    case 0: case 1: return std::make_unique<ProcessorCoreLegacy>(sample_rate, version);
+    case 2: return std::make_unique<ProcessorCore2>(sample_rate);
+    default: return nullptr;
+  }
 }
-void BeatriceHost_SetMorphSeed(void* p, unsigned seed) { static_cast<ProcessorCore2*>(p)->SetMorphSeed(seed); }
-int BeatriceHost_NumSpeakers(void* p) { return static_cast<ProcessorCore2*>(p)->n_speakers(); }
+}  // namespace beatrice_amd
+static ProcessorCoreBase* core(void* p) { return static_cast<ProcessorCoreBase*>(p); }
+extern "C" {
+void* BeatriceHost_Create(double sample_rate) { return beatrice_amd::MakeProcessorCore(2, sample_rate).release(); }
+// version: 0 = 2.0.0-alpha.2, 1 = 2.0.0-beta.1, 2 = 2.0.0-rc.0; null for anything else
+void* BeatriceHost_CreateVersion(double sample_rate, int version) { return beatrice_amd::MakeProcessorCore(version, sample_rate).release(); }
+void BeatriceHost_Destroy(void* p) { delete core(p); }
+int BeatriceHost_GetVersion(void* p) { return core(p)->GetVersion(); }
+int BeatriceHost_LoadModel(void* p, const char* toml_path) { return static_cast<int>(core(p)->LoadModel(toml_path)); }
+int BeatriceHost_Process(void* p, const float* in, float* out, int n) { return static_cast<int>(core(p)->Process(in, out, n)); }
+int BeatriceHost_ResetContext(void* p) { return static_cast<int>(core(p)->ResetContext()); }
+int BeatriceHost_SetSampleRate(void* p, double v) { return static_cast<int>(core(p)->SetSampleRate(v)); }
+int BeatriceHost_SetTargetSpeaker(void* p, int v) { return static_cast<int>(core(p)->SetTargetSpeaker(v)); }
+int BeatriceHost_SetFormantShift(void* p, double v) { return static_cast<int>(core(p)->SetFormantShift(v)); }
+int BeatriceHost_SetPitchShift(void* p, double v) { return static_cast<int>(core(p)->SetPitchShift(v)); }
+int BeatriceHost_SetInputGain(void* p, double v) { return static_cast<int>(core(p)->SetInputGain(v)); }
+int BeatriceHost_SetOutputGain(void* p, double v) { return static_cast<int>(core(p)->SetOutputGain(v)); }
+int BeatriceHost_SetAverageSourcePitch(void* p, double v) { return static_cast<int>(core(p)->SetAverageSourcePitch(v)); }
+int BeatriceHost_SetIntonationIntensity(void* p, double v) { return static_cast<int>(core(p)->SetIntonationIntensity(v)); }
+int BeatriceHost_SetPitchCorrection(void* p, double v) { return static_cast<int>(core(p)->SetPitchCorrection(v)); }
+int BeatriceHost_SetPitchCorrectionType(void* p, int v) { return static_cast<int>(core(p)->SetPitchCorrectionType(v)); }
+int BeatriceHost_SetMinSourcePitch(void* p, double v) { return static_cast<int>(core(p)->SetMinSourcePitch(v)); }
+int BeatriceHost_SetMaxSourcePitch(void* p, double v) { return static_cast<int>(core(p)->SetMaxSourcePitch(v)); }
+int BeatriceHost_SetVQNumNeighbors(void* p, int v) { return static_cast<int>(core(p)->SetVQNumNeighbors(v)); }
+int BeatriceHost_SetSpeakerMorphingWeights(void* p, const float* weights, int n) {
+  std::array<float, beatrice_amd::kMaxNSpeakers> w{};
+  for (int i = 0; i < n && i < beatrice_amd::kMaxNSpeakers; ++i) w[i] = weights[i];
+  return static_cast<int>(core(p)->SetSpeakerMorphingWeights(w));
+}
+void BeatriceHost_SetMorphSeed(void* p, unsigned seed) { core(p)->SetMorphSeed(seed); }
+int BeatriceHost_NumSpeakers(void* p) { return core(p)->n_speakers(); }
 int BeatriceHost_TakePitchTrace(void* p, int* out, int cap) {
-  const auto t = static_cast<ProcessorCore2*>(p)->TakePitchTrace();
+  const auto t = core(p)->TakePitchTrace();
   const int n = static_cast<int>(t.size()) < cap ? static_cast<int>(t.size()) : cap;
   for (int i = 0; i < n; ++i) out[i] = t[i];
   return static_cast<int>(t.size());

@@ -19,10 +19,12 @@
 #include <cstdint>
 #include <filesystem>
 #include <limits>
+#include <memory>
 #include <random>
 #include <vector>
 
 #include "beatrice_abi.h"
+#include "model_config.h"  // kMaxNSpeakers
 #include "spherical_mean.h"
 
 namespace beatrice_amd {
@@ -84,63 +86,111 @@ class RateBridge {
   History hist_high_, hist_low_;
 };
 
-class ProcessorCore2 {
+// What the proxy drives (reference ProcessorCoreBase, src/common/processor_core.h:22-92): every setter a core does
+// not have succeeds and does nothing.
+class ProcessorCoreBase {
  public:
-  explicit ProcessorCore2(double sample_rate);
-  ~ProcessorCore2();
-  ProcessorCore2(const ProcessorCore2&) = delete;
-  ProcessorCore2& operator=(const ProcessorCore2&) = delete;
-
-  int GetVersion() const { return 2; }
-  ErrorCode Process(const float* input, float* output, int n_samples);
-  ErrorCode ResetContext();
+  ProcessorCoreBase() = default;
+  ProcessorCoreBase(const ProcessorCoreBase&) = delete;
+  ProcessorCoreBase& operator=(const ProcessorCoreBase&) = delete;
+  virtual ~ProcessorCoreBase() = default;
+  virtual int GetVersion() const = 0;
+  virtual ErrorCode Process(const float* input, float* output, int n_samples) = 0;
+  virtual ErrorCode ResetContext() { return ErrorCode::kSuccess; }
   // `model_file` is the package's .toml path; as in the reference only its directory is used
-  ErrorCode LoadModel(const std::filesystem::path& model_file);
-  ErrorCode SetSampleRate(double sample_rate);
-  ErrorCode SetTargetSpeaker(int target_speaker);
-  ErrorCode SetFormantShift(double formant_shift);
-  ErrorCode SetPitchShift(double pitch_shift);
-  ErrorCode SetInputGain(double db);
-  ErrorCode SetOutputGain(double db);
-  ErrorCode SetAverageSourcePitch(double average_pitch);
-  ErrorCode SetIntonationIntensity(double intonation_intensity);
-  ErrorCode SetPitchCorrection(double pitch_correction);
-  ErrorCode SetPitchCorrectionType(int pitch_correction_type);
-  ErrorCode SetMinSourcePitch(double min_source_pitch);
-  ErrorCode SetMaxSourcePitch(double max_source_pitch);
-  ErrorCode SetVQNumNeighbors(int vq_num_neighbors);
-  static constexpr int kMaxNSpeakers = 256;      // reference src/common/model_config.h:17
-  static constexpr int kSphAvgMaxNSpeakers = 8;  // reference processor_core_2.h:26
-  ErrorCode SetSpeakerMorphingWeights(const std::array<float, kMaxNSpeakers>& weights);
-  void SetMorphSeed(std::uint32_t seed) { lottery_.seed(seed); }  // the reference seeds from std::random_device
-  int n_speakers() const { return n_speakers_; }
-  // test hook: bins handed to GenerateWaveform1 since the last call (pitch transform output)
-  std::vector<int> TakePitchTrace() { std::vector<int> t; t.swap(pitch_trace_); return t; }
+  virtual ErrorCode LoadModel(const std::filesystem::path& /*model_file*/) { return ErrorCode::kSuccess; }
+  virtual ErrorCode SetSampleRate(double) { return ErrorCode::kSuccess; }
+  virtual ErrorCode SetTargetSpeaker(int) { return ErrorCode::kSuccess; }
+  virtual ErrorCode SetFormantShift(double) { return ErrorCode::kSuccess; }
+  virtual ErrorCode SetPitchShift(double) { return ErrorCode::kSuccess; }
+  virtual ErrorCode SetInputGain(double) { return ErrorCode::kSuccess; }
+  virtual ErrorCode SetOutputGain(double) { return ErrorCode::kSuccess; }
+  virtual ErrorCode SetAverageSourcePitch(double) { return ErrorCode::kSuccess; }
+  virtual ErrorCode SetIntonationIntensity(double) { return ErrorCode::kSuccess; }
+  virtual ErrorCode SetPitchCorrection(double) { return ErrorCode::kSuccess; }
+  virtual ErrorCode SetPitchCorrectionType(int) { return ErrorCode::kSuccess; }
+  virtual ErrorCode SetMinSourcePitch(double) { return ErrorCode::kSuccess; }
+  virtual ErrorCode SetMaxSourcePitch(double) { return ErrorCode::kSuccess; }
+  virtual ErrorCode SetVQNumNeighbors(int) { return ErrorCode::kSuccess; }
+  virtual ErrorCode SetSpeakerMorphingWeights(const std::array<float, kMaxNSpeakers>&) { return ErrorCode::kSuccess; }
+  // not in the reference: the lottery seed of rc.0 morphing, and two test hooks
+  virtual void SetMorphSeed(std::uint32_t) {}
+  virtual int n_speakers() const { return 0; }
+  virtual std::vector<int> TakePitchTrace() { return {}; }
+};
 
- private:
+// The part every generation's core shares (reference processor_core_{0,1,2}.cc hold three copies of it): the guards of
+// Process(), input gain -> host rate to 48 kHz -> 480-sample FIFO -> every 3rd sample -> Hop() of the generation ->
+// zero-stuffed 480 -> host rate -> output gain, and the pitch parameters with their transform.
+class StreamingCore : public ProcessorCoreBase {
+ public:
+  explicit StreamingCore(double sample_rate, int pitch_bins);
+  ErrorCode Process(const float* input, float* output, int n_samples) final;
+  ErrorCode SetSampleRate(double sample_rate) override;
+  ErrorCode SetPitchShift(double pitch_shift) override;
+  ErrorCode SetInputGain(double db) override;
+  ErrorCode SetOutputGain(double db) override;
+  ErrorCode SetAverageSourcePitch(double average_pitch) override;
+  ErrorCode SetIntonationIntensity(double intonation_intensity) override;
+  ErrorCode SetPitchCorrection(double pitch_correction) override;
+  ErrorCode SetPitchCorrectionType(int pitch_correction_type) override;
+  int n_speakers() const override { return n_speakers_; }
+  // test hook: bins handed to GenerateWaveform1 since the last call (pitch transform output)
+  std::vector<int> TakePitchTrace() override { std::vector<int> t; t.swap(pitch_trace_); return t; }
+
+ protected:
   bool IsLoaded() const { return !model_file_.empty(); }
-  void Hop(const float* in160, float* out240);
-  void Block480(const float* in480, float* out480);
-  void Reblock(const float* in, float* out, int n);
-  bool InstallNextKeyValueBlock();
-  void RecreateContexts();
-  int TransformPitch(int q) const;
-  ErrorCode ApplySpeakerMorphingWeights();
-  void MorphStep();
+  virtual void Hop(const float* in160, float* out240) = 0;
+  // generation-specific guard of Process() behind the common ones (kSuccess = go on)
+  virtual ErrorCode Preflight() const { return ErrorCode::kSuccess; }
+  int TransformPitch(int q) const;   // shift, intonation, correction, clamp to [1, pitch_bins - 1]
+  int NoteToBin(double note) const;  // MIDI note -> bin, same clamp
 
   std::filesystem::path model_file_;
   double sample_rate_;
-  int target_speaker_ = 0, n_speakers_ = 0, pitch_correction_type_ = 0, vq_num_neighbors_ = 0, kv_blocks_set_ = 0;
+  const int pitch_bins_;
+  int target_speaker_ = 0, n_speakers_ = 0, pitch_correction_type_ = 0;
   double formant_shift_ = 0.0, pitch_shift_ = 0.0, average_source_pitch_ = 52.0, intonation_intensity_ = 1.0;
   double pitch_correction_ = 0.0, min_source_pitch_ = 33.125, max_source_pitch_ = 80.875;
-  bool ready_to_set_speaker_ = false;
+  std::vector<int> pitch_trace_;
 
+ private:
+  void Block480(const float* in480, float* out480);
+  void Reblock(const float* in, float* out, int n);
   RateBridge bridge_;
   GainRamp gain_in_, gain_out_;
   std::vector<float> fifo_;  // 480-sample block adapter
   int fifo_fill_ = 0;
   std::vector<float> io_, work_, scratch_;
-  std::vector<int> pitch_trace_;
+};
+
+class ProcessorCore2 final : public StreamingCore {
+ public:
+  explicit ProcessorCore2(double sample_rate);
+  ~ProcessorCore2() override;
+
+  int GetVersion() const override { return 2; }
+  ErrorCode ResetContext() override;
+  ErrorCode LoadModel(const std::filesystem::path& model_file) override;
+  ErrorCode SetTargetSpeaker(int target_speaker) override;
+  ErrorCode SetFormantShift(double formant_shift) override;
+  ErrorCode SetMinSourcePitch(double min_source_pitch) override;
+  ErrorCode SetMaxSourcePitch(double max_source_pitch) override;
+  ErrorCode SetVQNumNeighbors(int vq_num_neighbors) override;
+  static constexpr int kMaxNSpeakers = beatrice_amd::kMaxNSpeakers;
+  static constexpr int kSphAvgMaxNSpeakers = 8;  // reference processor_core_2.h:26
+  ErrorCode SetSpeakerMorphingWeights(const std::array<float, kMaxNSpeakers>& weights) override;
+  void SetMorphSeed(std::uint32_t seed) override { lottery_.seed(seed); }  // the reference seeds from std::random_device
+
+ private:
+  void Hop(const float* in160, float* out240) override;
+  bool InstallNextKeyValueBlock();
+  void RecreateContexts();
+  ErrorCode ApplySpeakerMorphingWeights();
+  void MorphStep();
+
+  int vq_num_neighbors_ = 0, kv_blocks_set_ = 0;
+  bool ready_to_set_speaker_ = false;
 
   Beatrice20rc0_PhoneExtractor* phone_extractor_;
   Beatrice20rc0_PitchEstimator* pitch_estimator_;
@@ -161,5 +211,46 @@ class ProcessorCore2 {
   SphericalMean mean_additive_;
   std::vector<SphericalMean> mean_kv_;
 };
+
+// weight preparation of morphing: overflow speakers folded into the last one, < 0.01 dropped (reference
+// voice_morph_state.h:87-104)
+std::array<float, kMaxNSpeakers> PrepareVoiceMorphWeights(std::array<float, kMaxNSpeakers> weights, int speaker_count);
+
+// The two older generations (reference src/common/processor_core_{0,1}.{h,cc}; the two files differ in the prefix of the
+// library calls and GetVersion() only).  What differs from ProcessorCore2: no codebook, no key/value embeddings; the
+// waveform generator takes ONE 256-float speaker vector per hop = speaker_embeddings[target] + formant_shift_embeddings[
+// round(2 shift + 4)]; morphing (target == n_speakers) is the spherical mean of the speaker vectors over ALL speakers
+// with a non-zero prepared weight, advanced one update per hop and written to slot n_speakers while it has not
+// converged (processor_core_1.cc:121-130, 258-270); SetTargetSpeaker only rejects negative ids and Process() answers
+// kSpeakerIDOutOfRange with zeros for an id beyond n_speakers (:35-40); ResetContext re-applies the source pitch
+// range only (:145-163).  `Lib` names the generation's entry points (processor_core_legacy.cc).
+struct LegacyLib;
+class ProcessorCoreLegacy final : public StreamingCore {
+ public:
+  ProcessorCoreLegacy(double sample_rate, int version);  // version 0 = 2.0.0-alpha.2, 1 = 2.0.0-beta.1
+  ~ProcessorCoreLegacy() override;
+  int GetVersion() const override { return version_; }
+  ErrorCode ResetContext() override;
+  ErrorCode LoadModel(const std::filesystem::path& model_file) override;
+  ErrorCode SetTargetSpeaker(int target_speaker) override;
+  ErrorCode SetFormantShift(double formant_shift) override;
+  ErrorCode SetMinSourcePitch(double min_source_pitch) override;
+  ErrorCode SetMaxSourcePitch(double max_source_pitch) override;
+  ErrorCode SetSpeakerMorphingWeights(const std::array<float, kMaxNSpeakers>& weights) override;
+
+ private:
+  void Hop(const float* in160, float* out240) override;
+  ErrorCode Preflight() const override;
+  ErrorCode ApplySpeakerMorphingWeights();
+  const int version_;
+  const LegacyLib& lib_;
+  void *phone_extractor_, *pitch_estimator_, *waveform_generator_, *phone_context_, *pitch_context_, *waveform_context_;
+  std::vector<float> speaker_embeddings_, formant_shift_embeddings_;  // (n_speakers + 1) x 256; 9 x 256
+  std::array<float, kMaxNSpeakers> morph_weights_{};
+  SphericalMean mean_;
+};
+
+// version of a package's `model.version` -> a core on this library; nullptr for a version this library does not know
+std::unique_ptr<ProcessorCoreBase> MakeProcessorCore(int version, double sample_rate);
 
 }  // namespace beatrice_amd

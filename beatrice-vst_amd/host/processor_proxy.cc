@@ -24,7 +24,7 @@ ErrorCode ProcessorProxy::ResetContext() { return core_ ? core_->ResetContext() 
 // reference processor_proxy.h:45-100
 ErrorCode ProcessorProxy::LoadModel(const std::filesystem::path& file) {
   ErrorCode error = ErrorCode::kSuccess;
-  std::unique_ptr<ProcessorCore2> fresh;
+  std::unique_ptr<ProcessorCoreBase> fresh;
   if (file.empty()) {
     core_.reset();
     return error;  // an empty path unloads without an error (processor_proxy.h:47-49)
@@ -37,16 +37,11 @@ ErrorCode ProcessorProxy::LoadModel(const std::filesystem::path& file) {
   try {
     const toml_subset::Value root = toml_subset::ParseFile(file.string());
     const ModelConfig config = ReadModelConfig(root);
-    switch (config.model.VersionInt()) {
-      case 2: fresh = std::make_unique<ProcessorCore2>(sample_rate_); break;
-      case 0: case 1:
-        // legacy generations: their parameter readers decline in this library (csrc/legacy.hip), which is what the
-        // reference's ProcessorCore0/1::LoadModel would report first
-        error = ErrorCode::kFileOpenError;
-        break;
-      default: error = ErrorCode::kInvalidModelConfig; break;
-    }
-    if (fresh) {
+    // the package's generation picks the core: 0 / 1 = ProcessorCoreLegacy, 2 = ProcessorCore2 (processor_proxy.h:57-70)
+    fresh = MakeProcessorCore(config.model.VersionInt(), sample_rate_);
+    if (!fresh) {
+      error = ErrorCode::kInvalidModelConfig;
+    } else {
       error = fresh->LoadModel(file);
       if (error == ErrorCode::kSuccess) config_ = config;
     }

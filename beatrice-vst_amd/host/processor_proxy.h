@@ -3,11 +3,9 @@
 // (reference src/common/processor_proxy.{h,cc}).
 //
 //   * LoadModel(path): parse the TOML (toml_subset.h), read the ModelConfig (model_config.h), pick the core by
-//     `model.version` (processor_proxy.h:55-70).  "2.0.0-rc.0" builds a ProcessorCore2 (processor_core.h) on the
-//     HIP library.  "2.0.0-alpha.2" / "2.0.0-beta.1" select the legacy generations, whose readers in this
-//     library decline (csrc/legacy.hip): the load fails with kFileOpenError exactly as
-//     the reference's ProcessorCore0/1::LoadModel would fail on a declining reader.  ANY failure leaves the
-//     "unloaded" core in place, whose Process() writes zeros (processor_proxy.h:97-99, processor_core.h:95-104).
+//     `model.version` (processor_proxy.h:55-70): "2.0.0-rc.0" builds a ProcessorCore2, "2.0.0-alpha.2" / "2.0.0-beta.1" a
+//     ProcessorCoreLegacy on the Beatrice20a2_* / Beatrice20b1_* entry points (processor_core.h), all on the HIP
+//     library.  ANY failure leaves the "unloaded" core in place, whose Process() writes zeros (processor_proxy.h:97-99, processor_core.h:95-104).
 //   * SetParameter(id, value): store, then apply (SyncParameter, processor_proxy.cc:23-43) through the processor-side
 //     rule of the parameter table (parameter_schema.cc: the `ProcessorSetValue` lambdas).
 //   * Read / Write: the TLV state blob (parameter_state.h); Read re-applies every parameter, which reloads the
@@ -45,16 +43,16 @@ class ProcessorProxy {
   ErrorCode ProcessChannels(const float* in0, const float* in1, float* out0, float* out1, int n, bool* silent);
   ErrorCode ResetContext();
   bool IsLoaded() const { return core_ != nullptr; }
-  int CoreVersion() const { return core_ ? 2 : -1; }           // reference ProcessorCoreBase::GetVersion; -1 = unloaded
+  int CoreVersion() const { return core_ ? core_->GetVersion() : -1; }           // reference ProcessorCoreBase::GetVersion; -1 = unloaded
   const ModelConfig* Config() const { return core_ ? &config_ : nullptr; }
-  ProcessorCore2* core() { return core_.get(); }
+  ProcessorCoreBase* core() { return core_.get(); }
 
  private:
   ErrorCode SyncParameter(std::int16_t id);
   ErrorCode SyncAllParameters(std::int16_t ignore);
   double sample_rate_ = 0.0;
   ParameterState state_;
-  std::unique_ptr<ProcessorCore2> core_;  // null = the reference's ProcessorCoreUnloaded
+  std::unique_ptr<ProcessorCoreBase> core_;  // null = the reference's ProcessorCoreUnloaded
   ModelConfig config_;
 };
 

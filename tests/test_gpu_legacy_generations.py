@@ -103,3 +103,47 @@ def test_legacy_objects_do_not_leak_and_unloaded_objects_stay_silent(bv, product
     assert not out.any()
     hip.DestroyPhoneContext1(pc)
     hip.DestroyPhoneExtractor(pe)
+
+
+@pytest.mark.parametrize("version,gen_version", [(1, "2.0.0-beta.1"), (0, "2.0.0-alpha.2")])
+def test_proxy_runs_a_legacy_package_on_the_product(built, tmp_path, version, gen_version):
+    """a `2.0.0-beta.1` (and `2.0.0-alpha.2`) package through ProcessorProxy -> ProcessorCoreLegacy ->
+    Beatrice20b1_* (Beatrice20a2_*) on the HIP library = the same host source on the oracle core, with a speaker change,
+    a formant row, the morph slot and a context reset on the way."""
+    import ctypes as C
+    import os
+    import sys
+    import hostlib
+    import wrapperlib
+    from test_host_proxy import K_FORMANT, K_MODEL, K_PITCH_SHIFT, K_VOICE, Proxy
+    sys.path.insert(0, os.path.join(hostlib.REPO, "tools"))
+    import make_model
+    pkg = str(tmp_path / "pkg")
+    os.makedirs(pkg)
+    make_model.make_model_legacy(pkg, n_speakers=3, version=gen_version)
+    sr, block = 44100, 441
+    x = wrapperlib.test_signal(block * 40, sr, seed=17 + version)
+    outs = {}
+    for name, path in (("oracle", hostlib.HOST_ON_ORACLE), ("hip", hostlib.HOST_PRODUCT)):
+        keep = hostlib.HOST_ON_ORACLE
+        hostlib.HOST_ON_ORACLE = path   # Proxy binds whatever library this names
+        try:
+            p = Proxy(sr)
+        finally:
+            hostlib.HOST_ON_ORACLE = keep
+        assert p.call("SetString", K_MODEL, (pkg + "/model.toml").encode()) == 0
+        assert p.call("CoreVersion") == version
+        parts = []
+        o, codes = p.process(x[:block * 10], block); parts.append(o)
+        assert set(codes) == {0}
+        p.call("SetInt", K_VOICE, 2); p.call("SetNumber", K_FORMANT, 1.5); p.call("SetNumber", K_PITCH_SHIFT, 7.0)
+        o, _ = p.process(x[block * 10:block * 20], block); parts.append(o)
+        p.call("SetInt", K_VOICE, 3)                                  # morph slot: the proxy's default markers give the weights
+        o, _ = p.process(x[block * 20:block * 30], block); parts.append(o)
+        assert p.call("ResetContext") == 0
+        p.call("SetInt", K_VOICE, 1)
+        o, _ = p.process(x[block * 30:], block); parts.append(o)
+        outs[name] = np.concatenate(parts)
+        p.close()
+    assert np.abs(outs["hip"]).max() > 1e-3
+    assert np.array_equal(outs["hip"], outs["oracle"]), "max-abs %g" % np.abs(outs["hip"] - outs["oracle"]).max()

@@ -107,8 +107,8 @@ def _write_pkg(tmp_path, model_dir, text):
 @pytest.mark.parametrize("edit,want", [
     (lambda t: t, OK),
     (lambda t: t.replace('version = "2.0.0-rc.0"', 'version = "9.9.9"'), INVALID_CONFIG),            # unknown generation
-    (lambda t: t.replace('version = "2.0.0-rc.0"', 'version = "2.0.0-beta.1"'), FILE_OPEN),           # legacy readers decline
-    (lambda t: t.replace('version = "2.0.0-rc.0"', 'version = "2.0.0-alpha.2"'), FILE_OPEN),
+    (lambda t: t.replace('version = "2.0.0-rc.0"', 'version = "2.0.0-beta.1"'), 4),                   # a legacy core on rc.0 files: kInvalidFileSize
+    (lambda t: t.replace('version = "2.0.0-rc.0"', 'version = "2.0.0-alpha.2"'), 4),
     (lambda t: t.replace("average_pitch = 52.0", "average_pitch = 52", 1), INVALID_CONFIG),           # integer is not a float
     (lambda t: t.replace("average_pitch = 52.0", "average_pitch = 200.0", 1), INVALID_CONFIG),
     (lambda t: t.replace("average_pitch = 52.0", "average_pitch = nan", 1), INVALID_CONFIG),
