@@ -137,7 +137,7 @@ struct BeatriceBatch {
   // layout: [front part: arrays the front end reads][wave part: attention tile lists], and on the device the wave
   // part four times -- the waveform generator of step t reads copy t & 3, so a change can be pushed for step t while
   // the generator stages of steps t-1..t-3 are still running (their copies are refreshed when their slot comes up)
-  struct { size_t cbT, cnorm, vqk, min_q, max_q, add_idx, frm_idx, params, perm[B_NBLOCKS], tile_slot[B_NBLOCKS], front_bytes, wave_bytes; } off{};
+  struct { size_t cbT, cnorm, vqk, min_q, max_q, add_idx, frm_idx, params, perm[B_NBLOCKS], tile_slot[B_NBLOCKS], qperm[B_NBLOCKS], qslot[B_NBLOCKS], front_bytes, wave_bytes; } off{};
   bool front_dirty = true, wave_dirty[4] = {true, true, true, true};  // [kSlots]
   template <class T> T* host_view(size_t o) { return reinterpret_cast<T*>(settings.h + o); }
   template <class T> T* dev_view(size_t o) { return reinterpret_cast<T*>(settings.d + o); }
@@ -275,6 +275,12 @@ void settle(BeatriceBatch* b) {
   if (b->inflight) (void)sync_all(b);
 }
 
+// Tick mode splits the attention rows of a step between two kinds of workgroup (rowchain.hip.h): 16-row tiles that share a
+// K/V slot (block_b_body) and quads of <= 4 rows (block_bq_body).  BEATRICE_HIP_TICK_NO_QUADS: A/B switch for measurements.
+bool quads_on(const BeatriceBatch* b) {
+  static const bool no_quads = std::getenv("BEATRICE_HIP_TICK_NO_QUADS") != nullptr;
+  return b->tk.on && b->wave.d_ktp[0] != nullptr && !no_quads;
+}
 void rebuild_tiles(BeatriceBatch* b, int blk) {
   // attention rows (stream, hop in step) grouped by K/V slot, ascending slot then ascending row, 16 per tile
   const int nt = b->wave.n_tiles_max, rows = b->B * b->H;
@@ -287,11 +293,33 @@ void rebuild_tiles(BeatriceBatch* b, int blk) {
   std::vector<int> order(rows);
   for (int i = 0; i < rows; ++i) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return rs[x] < rs[y]; });
-  int tile = -1, fill = 16, cur = -1;
-  for (int r : order) {
-    const int sl = rs[r];
-    if (sl != cur || fill == 16) { ++tile; fill = 0; cur = sl; slot[tile] = sl; }
-    perm[tile * 16 + fill++] = r;
+  // In-order modes: every row in a tile of its slot (at most one partial tile per slot).  Tick mode: a slot's rows fill whole
+  // tiles first; a remainder of >= 8 rows is one more (padded) tile, a smaller one goes to the quad list -- with 64 speakers
+  // on 256 streams that is 64 quads instead of 64 tiles with 12 of 16 rows empty.
+  const bool quads = quads_on(b);
+  int* qperm = b->host_view<int>(b->off.qperm[blk]);
+  int* qslot = b->host_view<int>(b->off.qslot[blk]);
+  std::fill(qperm, qperm + (size_t)nt * 16, -1);
+  std::fill(qslot, qslot + (size_t)nt * 4, -1);
+  int tile = 0, quad = 0;
+  for (int i = 0; i < rows;) {
+    const int sl = rs[order[i]];
+    int n = 1;
+    while (i + n < rows && rs[order[i + n]] == sl) ++n;
+    int at = 0;
+    while (n - at >= (quads ? 8 : 1)) {
+      const int take = std::min(16, n - at);
+      slot[tile] = sl;
+      for (int e = 0; e < take; ++e) perm[tile * 16 + e] = order[i + at + e];
+      ++tile; at += take;
+    }
+    while (at < n) {
+      const int take = std::min(4, n - at);
+      qslot[quad] = sl;
+      for (int e = 0; e < take; ++e) qperm[quad * 4 + e] = order[i + at + e];
+      ++quad; at += take;
+    }
+    i += n;
   }
 }
 
@@ -565,6 +593,12 @@ bool tick_build_table(BeatriceBatch* b) {
                             b->dev_view<int>(b->off.perm[blk]), b->dev_view<int>(b->off.tile_slot[blk]), hp(s0 + 1)};
     tb->add<T_BLKB>(LaunchInfo{"wave.blk.b", 2.0 * B * (256.0 * 256 * 2 + 256.0 * 384 * 2), 4.0 * (2.0 * 256 * 256 + 2.0 * 256 * 384 + B * 3.0 * 256)}, ba,
                     dim3(ws.n_tiles_max, 1), s0 + 1, keep(5), 41.0);
+    if (quads_on(b)) {  // rows without 15 neighbours on their K/V slot: one workgroup per quad (rebuild_tiles decides which rows)
+      const rc::BlockBqArgs bq{sc.xa, ws.x[blk + 1], ww.q_w[blk], ww.q_b[blk], ww.o_w[blk], ww.o_b[blk], ws.d_ktp[blk], ws.d_vp[blk],
+                               b->dev_view<int>(b->off.qperm[blk]), b->dev_view<int>(b->off.qslot[blk]), hp(s0 + 1)};
+      // (a slot leaves at most 7 rows = 2 quads to this list: <= n_slots workgroups of two quads)
+      tb->add<T_BLKBQ>(LaunchInfo{"wave.blk.bq", 0.0, 0.0}, bq, dim3(std::min(2 * ws.n_tiles_max, ws.n_slots), 1), s0 + 1, keep(5), 42.0);
+    }
   }
   for (int blk = 0; blk < B_NBLOCKS; ++blk) {
     const rc::BlockAArgs aa{ws.x[blk], ws.scr[blk].xa, ww.c1_w[blk], ww.c1_b[blk], ww.c2_w[blk], ww.c2_b[blk], hp(pl.blk(blk)), B};
@@ -827,10 +861,12 @@ int tick_enable(BeatriceBatch* b, bool on) {
     for (long long& f : k.fed_step) f = -1;
     k.table_dirty = true;
     k.on = true;
+    for (int blk = 0; blk < B_NBLOCKS; ++blk) rebuild_tiles(b, blk);  // (tick mode cuts the attention rows into tiles AND quads)
     return 0;
   }
   if (!sync_all(b)) return -2;  // drains
   k.on = false;
+  for (int blk = 0; blk < B_NBLOCKS; ++blk) rebuild_tiles(b, blk);
   // the in-order chain reads its counters from device memory: hand them the host's values
   const int pair[2] = {b->hop_host, b->io_host};
   if (!hip_ok(hipMemcpy(b->d_hop_next, pair, sizeof(pair), hipMemcpyHostToDevice), "tick leave")) return -2;
@@ -1008,7 +1044,11 @@ BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* pho
     b->off.min_q = take(sizeof(int) * B); b->off.max_q = take(sizeof(int) * B); b->off.params = take(sizeof(PitchParams) * B);
     b->off.add_idx = take(sizeof(int) * B); b->off.frm_idx = take(sizeof(int) * B);
     b->off.front_bytes = o;
-    for (int blk = 0; blk < B_NBLOCKS; ++blk) { b->off.perm[blk] = take(sizeof(int) * nt * 16); b->off.tile_slot[blk] = take(sizeof(int) * nt); }
+    for (int blk = 0; blk < B_NBLOCKS; ++blk) {
+      b->off.perm[blk] = take(sizeof(int) * nt * 16); b->off.tile_slot[blk] = take(sizeof(int) * nt);
+      // tick mode: the same rows as quads of <= 4 rows per K/V slot, four quads to a tile (rowchain.hip.h block_b_body)
+      b->off.qperm[blk] = take(sizeof(int) * nt * 16); b->off.qslot[blk] = take(sizeof(int) * nt * 4);
+    }
     b->off.wave_bytes = o - b->off.front_bytes;
   }
   const size_t dev_bytes = b->off.front_bytes + BeatriceBatch::kSlots * b->off.wave_bytes;
@@ -1122,7 +1162,9 @@ static bool project_speakers(BeatriceBatch* b, int first, int count) {
   embed_project_rows(w.add_w, w.add_b, b->d_add_raw + (size_t)first * B_HID, b->wave.d_add_tab + (size_t)first * B_HID, count, s);
   for (int blk = 0; blk < B_NBLOCKS; ++blk)
     embed_project_kv(w, blk, b->d_kv_raw + (size_t)first * B_KV_LEN * B_KV_CH, count,
-                     b->wave.d_kt[blk] + (size_t)first * B_HID * B_KV_LEN, b->wave.d_v[blk] + (size_t)first * B_KV_LEN * B_HID, s);
+                     b->wave.d_kt[blk] + (size_t)first * B_HID * B_KV_LEN, b->wave.d_v[blk] + (size_t)first * B_KV_LEN * B_HID, s,
+                     b->wave.d_ktp[blk] ? b->wave.d_ktp[blk] + (size_t)first * B_HID * B_KV_LEN : nullptr,
+                     b->wave.d_vp[blk] ? b->wave.d_vp[blk] + (size_t)first * B_KV_LEN * B_HID : nullptr);
   return hip_ok(hipStreamSynchronize(s), "project speakers");
 }
 

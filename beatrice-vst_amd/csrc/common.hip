@@ -233,9 +233,9 @@ void embed_project_rows(const float* w, const float* b, const float* d_x, float*
   hipLaunchKernelGGL(dense_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, d_x, w, b, d_y, rows, B_HID, B_HID);
 }
 void embed_project_kv(const EmbedWeights& w, int block, const float* d_kv_raw, int slots, float* d_kt, float* d_v,
-                      hipStream_t stream) {
+                      hipStream_t stream, float* d_kt_plain, float* d_v_plain) {
   hipLaunchKernelGGL(kv_project_kernel, dim3(B_KV_LEN, slots), dim3(256), 0, stream, d_kv_raw, w.k_w[block], w.k_b[block],
-                     w.v_w[block], w.v_b[block], d_kt, d_v);
+                     w.v_w[block], w.v_b[block], d_kt, d_v, d_kt_plain, d_v_plain);
 }
 void codebook_prepare(const float* d_cb, int n, float* d_cbT, float* d_cnorm, hipStream_t stream) {
   hipLaunchKernelGGL(codebook_prep_kernel, dim3(n), dim3(512), 0, stream, d_cb, d_cbT, d_cnorm);

@@ -205,6 +205,10 @@ struct WaveState {
   int *d_add_idx = nullptr, *d_frm_idx = nullptr;  // [B]
   float* d_kt[B_NBLOCKS] = {nullptr, nullptr, nullptr, nullptr};  // [n_slots][256][384]
   float* d_v[B_NBLOCKS] = {nullptr, nullptr, nullptr, nullptr};   // [n_slots][384][256]
+  // the same tables in plain row-major order (K^T [256][384], V [384][256]) for the 4x4x1 multi-block MFMAs of rows whose
+  // neighbours attend to other slots (rowchain.hip.h, quad path); tick-mode batches only, null elsewhere
+  float* d_ktp[B_NBLOCKS] = {nullptr, nullptr, nullptr, nullptr};
+  float* d_vp[B_NBLOCKS] = {nullptr, nullptr, nullptr, nullptr};
   int* d_perm[B_NBLOCKS] = {nullptr, nullptr, nullptr, nullptr};       // [n_tiles_max][16]
   int* d_tile_slot[B_NBLOCKS] = {nullptr, nullptr, nullptr, nullptr};  // [n_tiles_max]
   int* d_hop = nullptr;       // owned hop counter
@@ -240,8 +244,9 @@ bool front_forward(const PhoneWeights& pw, const PhoneState& ps, const PitchWeig
 
 // set-time projections (embedding setter)
 void embed_project_rows(const float* w, const float* b, const float* d_x, float* d_y, int rows, hipStream_t stream);
+// (d_kt_plain / d_v_plain: optional second copies in plain row-major order, WaveState::d_ktp / d_vp)
 void embed_project_kv(const EmbedWeights& w, int block, const float* d_kv_raw, int slots, float* d_kt, float* d_v,
-                      hipStream_t stream);
+                      hipStream_t stream, float* d_kt_plain = nullptr, float* d_v_plain = nullptr);
 void codebook_prepare(const float* d_cb, int n, float* d_cbT, float* d_cnorm, hipStream_t stream);
 
 // speaker morphing (morph.hip): out[row][:] = weighted spherical mean over table[speakers[n]][row][:],

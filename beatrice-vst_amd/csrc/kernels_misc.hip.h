@@ -489,7 +489,8 @@ __device__ __forceinline__ size_t packed_w_offset_dev(int K, int kk, int n) {
 static __global__ __launch_bounds__(256) void kv_project_kernel(const float* __restrict__ kv_raw,
                                                          const float* __restrict__ kw, const float* __restrict__ kb,
                                                          const float* __restrict__ vw, const float* __restrict__ vb,
-                                                         float* __restrict__ kt, float* __restrict__ v) {
+                                                         float* __restrict__ kt, float* __restrict__ v,
+                                                         float* __restrict__ kt_plain, float* __restrict__ v_plain) {
   __shared__ float row[B_KV_CH];
   const int j = blockIdx.x, slot = blockIdx.y, c = threadIdx.x;
   if (c < B_KV_CH) row[c] = kv_raw[((size_t)slot * B_KV_LEN + j) * B_KV_CH + c];
@@ -504,6 +505,9 @@ static __global__ __launch_bounds__(256) void kv_project_kernel(const float* __r
   // P . V has (k = token j, n = channel c)
   kt[(size_t)slot * B_HID * B_KV_LEN + packed_w_offset_dev(B_HID, c, j)] = ak + kb[c];
   v[(size_t)slot * B_KV_LEN * B_HID + packed_w_offset_dev(B_KV_LEN, j, c)] = av + vb[c];
+  // the same values in plain order for the multi-block (4x4x1) attention path: K^T [channel][token], V [token][channel]
+  if (kt_plain) kt_plain[(size_t)slot * B_HID * B_KV_LEN + (size_t)c * B_KV_LEN + j] = ak + kb[c];
+  if (v_plain) v_plain[(size_t)slot * B_KV_LEN * B_HID + (size_t)j * B_HID + c] = av + vb[c];
 }
 
 // codebook [512][128] -> transposed [128][512] + squared norms; grid = n codebooks, 512 threads.

@@ -33,6 +33,14 @@
 #define ABL_KB(x) (x)
 #endif
 
+// per-phase cycle stamps of the attention bodies for tools/microbench/blockb_timing.hip (never defined in the product build)
+#ifdef RC_TIMING
+__device__ unsigned long long* g_rc_stamps;   // [workgroups][16]
+#define RC_STAMP(i) do { if (threadIdx.x == 0) g_rc_stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RC_STAMP(i) do { } while (0)
+#endif
+
 namespace rc {
 
 constexpr int NTHR = 512, NWAVE = 8;
@@ -293,6 +301,7 @@ __device__ __forceinline__ void block_b_body(const BlockBArgs& a, const int g, f
   if (hop < 0) return;
   const int slot = a.tile_slot[g];
   if (slot < 0) return;
+  RC_STAMP(0);
   if (tid < 16) sid[tid] = a.perm[g * 16 + tid];
   __syncthreads();
   load_tile(XA, a.xa, sid, ring_pos(a.xa, hop), 0, tid);
@@ -300,14 +309,17 @@ __device__ __forceinline__ void block_b_body(const BlockBArgs& a, const int g, f
   {
     const float* const seg[1] = {XA};
     const float* __restrict__ bias = a.q_b;
+    RC_STAMP(1);
     layer256<1, 2>(seg, AS, a.q_w, wave, lane, [&](int r, int n, float v) { Q[r * AS + n] = v + bias[n]; });
   }
   __syncthreads();
+  RC_STAMP(2);
   {
     const float* const seg[1] = {Q};
     layer256<1, 3>(seg, AS, a.kt + (size_t)slot * B_HID * B_KV_LEN, wave, lane, [&](int r, int n, float v) { S[r * SS + n] = v * 0.0625f; });
   }
   __syncthreads();
+  RC_STAMP(3);
   // softmax statistics, two rows per wavefront (MODEL_SPEC 4.4.2; same operations as attn_pv_kernel)
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr) {
@@ -326,6 +338,7 @@ __device__ __forceinline__ void block_b_body(const BlockBArgs& a, const int g, f
     if (lane == 0) inv[r] = 1.0f / tot;
   }
   __syncthreads();
+  RC_STAMP(4);
   {  // o = (segment 0 + segment 1) * (1 / sum): K = 384 = 256 + 128, V packed [384][256]
     const float4* wf = reinterpret_cast<const float4*>(a.v + (size_t)slot * B_KV_LEN * B_HID) + (size_t)wave * (B_KV_LEN / 16) * 64 + lane;
     const size_t tile_stride = (size_t)NWAVE * (B_KV_LEN / 16) * 64;
@@ -343,6 +356,7 @@ __device__ __forceinline__ void block_b_body(const BlockBArgs& a, const int g, f
       }
   }
   __syncthreads();
+  RC_STAMP(5);
   {
     const float* const seg[1] = {Q};
     const float* __restrict__ bias = a.o_b;
@@ -352,6 +366,7 @@ __device__ __forceinline__ void block_b_body(const BlockBArgs& a, const int g, f
       if (b >= 0) ring_frame(a.out, b, pos_o, 0)[n] = XA[r * AS + n] + (v + bias[n]);
     });
   }
+  RC_STAMP(6);
 }
 struct BlockBOp {
   using Args = BlockBArgs;
@@ -365,6 +380,178 @@ static __global__ __launch_bounds__(NTHR, 4) void block_b_kernel(const BlockBArg
   block_b_body(a, blockIdx.x, lds);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The attention half for rows that do NOT share their K/V slot with 15 neighbours (many speakers per GPU, BASELINE.json
+// configs[3]): one workgroup per PAIR OF QUADS, a quad = up to four rows of one slot; q and the output layer as above on
+// the 8-row tile, the two products against the slots' own K / V on v_mfma_f32_4x4x1_16b_f32.
+//
+// The multi-block form runs 16 independent [4 x 1] . [1 x 4] products per instruction: A = lane 4 b + i -> row i of block b,
+// B = lane 4 b + j -> column j of block b, D = register r of lane 4 b + j -> (row r, column j).  Here every block gets the
+// SAME four rows (lane l supplies row l & 3) and its own four columns, so one instruction is a rank-1 update of
+// [4 rows] x [64 columns] without padded rows (a 16 x 16 x 4 tile would spend 12 of its 16 rows on nothing -- round 2 ran
+// 324 such tiles per tick at 64 speakers), and a lane's B operand is simply "its column at reduction index k" of a plain
+// row-major matrix: NV adjacent columns per lane come from one load and feed NV instructions.  Arithmetic as everywhere:
+// one k-ascending fma chain per output from 0, bit-identical to the 16 x 16 x 4 chain (tools/microbench/mfma_4x4.hip:
+// layout and bits against fmaf; ~10.7 cycles per instruction).
+// What bounds it is not the matrix pipe.  Nothing re-reads a K/V table within a tick, so the 786 KB per (quad, block) come
+// from HBM / the Infinity Cache, and ONE compute unit pulls ~35 bytes per cycle through its L1 whatever the kernel does
+// (tools/microbench/blockb_timing.hip; profiles/r03_notes.md section 4): the stream has to be spread over all CUs (four
+// quads per workgroup took 125-150 us per workgroup) with enough bytes in flight per workgroup (one quad per workgroup on
+// four wavefronts: 70 us inside the tick, latency-bound).
+template <int NV> struct QuadVec;
+template <> struct QuadVec<1> { using T = float; };
+template <> struct QuadVec<2> { using T = float2; };
+template <> struct QuadVec<4> { using T = float4; };
+__device__ __forceinline__ float quad_elem(const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+__device__ __forceinline__ float quad_elem(const float2& v, int c) { return c == 0 ? v.x : v.y; }
+__device__ __forceinline__ float quad_elem(const float& v, int) { return v; }
+// acc[c] += A[4 x KLEN] . B[KLEN x (this lane's column c)]: `a` = this lane's row in LDS (8-byte aligned, first k of the
+// segment), `bp` = this lane's first column in row-major B (row stride LDB floats), first k of the segment.  Rows of B are
+// fetched D ahead: 64 registers of rows in flight per lane (32 at NV = 1) are what fits under the launch's 128.
+template <int NV, int KLEN, int LDB>
+__device__ __forceinline__ void quad_segment(f32x4 (&acc)[NV], const float* __restrict__ a, const float* __restrict__ bp) {
+  using V = typename QuadVec<NV>::T;
+  constexpr int D = NV == 1 ? 32 : 64 / NV;  // k rows in flight
+  constexpr int G = 8;                       // A operand: float2 reads, one group of G k ahead
+  static_assert(KLEN % D == 0 && D % G == 0, "segment length");
+  V bq[D];
+  float2 an[G / 2];
+  pin_pipeline();
+#pragma unroll
+  for (int d = 0; d < D; ++d) bq[d] = *reinterpret_cast<const V*>(bp + (size_t)d * LDB);
+#pragma unroll
+  for (int d = 0; d < G / 2; ++d) an[d] = *reinterpret_cast<const float2*>(a + 2 * d);
+#pragma unroll 1
+  for (int k = 0; k < KLEN; k += D) {
+    const bool more = k + D < KLEN;
+#pragma unroll
+    for (int g = 0; g < D; g += G) {
+      float2 ac[G / 2];
+#pragma unroll
+      for (int d = 0; d < G / 2; ++d) ac[d] = an[d];
+      if (k + g + G < KLEN) {
+#pragma unroll
+        for (int d = 0; d < G / 2; ++d) an[d] = *reinterpret_cast<const float2*>(a + k + g + G + 2 * d);
+      }
+      V cur[G];
+#pragma unroll
+      for (int d = 0; d < G; ++d) cur[d] = bq[g + d];
+      if (more) {
+#pragma unroll
+        for (int d = 0; d < G; ++d) bq[g + d] = *reinterpret_cast<const V*>(bp + (size_t)(k + g + d + D) * LDB);
+      }
+      pin_pipeline();
+#pragma unroll
+      for (int d = 0; d < G; ++d)
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+          acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32((d & 1) ? ac[d / 2].y : ac[d / 2].x, quad_elem(cur[d], c), acc[c], 0, 0, 0);
+    }
+  }
+}
+struct BlockBqArgs {
+  Ring xa, out;
+  const float *q_w, *q_b, *o_w, *o_b;    // as BlockBArgs (MFMA-fragment order)
+  const float *ktp, *vp;                 // plain per-slot tables: K^T [256][384], V [384][256]
+  const int* qperm;                      // [n_quads][4] row (stream) indices or -1
+  const int* qslot;                      // [n_quads] slot or -1 (quad unused)
+  const int* hop;
+};
+constexpr int kBlockBqLds = kBlockBLds;
+__device__ __forceinline__ void block_bq_body(const BlockBqArgs& a, const int g, float* __restrict__ lds) {
+  float* XA = lds;
+  float* Q = lds + TILE;           // q, later o
+  float* S = lds + 2 * TILE;       // scores, then exp(s - max)
+  float* inv = S + STILE;
+  int* sid = reinterpret_cast<int*>(inv + 16);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int hop = stepc::step(a.hop);
+  if (hop < 0) return;
+  const int2 qs = *reinterpret_cast<const int2*>(a.qslot + 2 * g);
+  if (qs.x < 0 && qs.y < 0) return;
+  // These workgroups are the longest of the launch (two K/V tables through one CU's L1) and end it: issue priority over the
+  // co-resident workgroup (zero-sum for the SIMD, profiles/r03_notes.md section 2, but it shortens the launch's tail).
+  __builtin_amdgcn_s_setprio(3);
+  RC_STAMP(0);
+  if (tid < 16) sid[tid] = tid < 8 ? a.qperm[g * 8 + tid] : -1;   // rows 8..15 of the tile stay empty
+  __syncthreads();
+  load_tile(XA, a.xa, sid, ring_pos(a.xa, hop), 0, tid);
+  __syncthreads();
+  {
+    const float* const seg[1] = {XA};
+    const float* __restrict__ bias = a.q_b;
+    RC_STAMP(1);
+    layer256<1, 2>(seg, AS, a.q_w, wave, lane, [&](int r, int n, float v) { Q[r * AS + n] = v + bias[n]; });
+  }
+  __syncthreads();
+  RC_STAMP(2);
+  const int quad = wave_u >> 2, part = wave_u & 3;   // four wavefronts per quad
+  const int my_slot = quad == 0 ? qs.x : qs.y;
+  const int arow = quad * 4 + (lane & 3);            // the row this lane supplies as the A operand
+  if (part < 3) {  // s = (q . K^T) / 16: three wavefronts x 128 keys, two per lane
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const int j = part * 128 + 2 * lane;
+    if (my_slot >= 0) quad_segment<2, B_HID, B_KV_LEN>(acc, Q + arow * AS, a.ktp + (size_t)my_slot * B_HID * B_KV_LEN + j);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) S[(quad * 4 + r) * SS + j + c] = acc[c][r] * 0.0625f;
+  }
+  __syncthreads();
+  RC_STAMP(3);
+  {  // softmax statistics, one row per wavefront (MODEL_SPEC 4.4.2; same operations as block_b_body)
+    const int r = wave;
+    float v[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = S[r * SS + lane + 64 * i];
+    float mx = -__builtin_huge_valf();
+#pragma unroll
+    for (int i = 0; i < 6; ++i) mx = fmaxf(mx, v[i]);
+    mx = bsp::wmax64(mx);
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { const float e = bsp::exp(v[i] - mx); s = s + e; S[r * SS + lane + 64 * i] = e; }
+    const float tot = bsp::wsum64(s);
+    if (lane == 0) inv[r] = 1.0f / tot;
+  }
+  __syncthreads();
+  RC_STAMP(4);
+  {  // o = (segment 0 + segment 1) * (1 / sum): four wavefronts x 64 channels
+    const int n = part * 64 + lane;
+    f32x4 acc0[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, acc1[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (my_slot >= 0) {
+      const float* vp = a.vp + (size_t)my_slot * B_KV_LEN * B_HID + n;
+      quad_segment<1, 256, B_HID>(acc0, S + arow * SS, vp);
+      quad_segment<1, 128, B_HID>(acc1, S + arow * SS + 256, vp + (size_t)256 * B_HID);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = acc0[0][r] + acc1[0][r];
+      Q[(quad * 4 + r) * AS + n] = v * inv[quad * 4 + r];
+    }
+  }
+  __syncthreads();
+  RC_STAMP(5);
+  {
+    const float* const seg[1] = {Q};
+    const float* __restrict__ bias = a.o_b;
+    const int pos_o = ring_pos(a.out, hop);
+    layer256<1, 2>(seg, AS, a.o_w, wave, lane, [&](int r, int n, float v) {
+      const int b = sid[r];
+      if (b >= 0) ring_frame(a.out, b, pos_o, 0)[n] = XA[r * AS + n] + (v + bias[n]);
+    });
+  }
+  __builtin_amdgcn_s_setprio(0);
+  RC_STAMP(6);
+}
+struct BlockBqOp {
+  using Args = BlockBqArgs;
+  static constexpr int NTHR = rc::NTHR;
+  static constexpr int LDS_FLOATS = kBlockBqLds;
+  static constexpr double wg_cost() { return 30.0; }
+  __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { block_bq_body(a, bx, lds); }
+};
 // ---------------------------------------------------------------------------------------------------------------------
 // Any conv_gemm Layer for ONE tile of 16 rows and ALL its output columns: the A operand streams through two LDS tiles
 // one 256-long reduction segment at a time (gathered from the input ring exactly as conv_gemm does, next segment's

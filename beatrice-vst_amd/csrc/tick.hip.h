@@ -103,7 +103,7 @@ using OpUP2 = rc::ConvRowsOp<UP<128, 64, 4, 5>, 0, TICK_MID_RT>;
 
 enum BodyType {
   T_F1, T_FFT, T_F2, T_F3, T_F4, T_F5, T_P1, T_RB, T_P23, T_POUT, T_HEAD, T_OUT, T_COND, T_INP, T_UP1, T_RES1A, T_RES1B, T_UP2,
-  T_QGRU, T_PGRU, T_VQ, T_TAIL, T_TAIL1, T_TAIL2, T_TAIL3, T_BLKA1, T_BLKA2, T_BLKA4, T_BLKA8, T_BLKB, T_COUNT
+  T_QGRU, T_PGRU, T_VQ, T_TAIL, T_TAIL1, T_TAIL2, T_TAIL3, T_BLKA1, T_BLKA2, T_BLKA4, T_BLKA8, T_BLKB, T_BLKBQ, T_COUNT
 };
 #define TICK_TYPES                                                                                                            \
     fuse::Many<F1Op2, 1>, fuse::Many<FftOp2, 1>, fuse::Many<OpF2, 1>, fuse::Many<OpF3, 1>, fuse::Many<OpF4, 1>, fuse::Many<OpF5, 1>, \
@@ -111,7 +111,7 @@ enum BodyType {
     fuse::Many<OpOUT, 1>, fuse::Many<CondOp2, 1>, fuse::Many<OpINP, 1>, fuse::Many<OpUP1, 1>, fuse::Many<OpRES1A, 1>,               \
     fuse::Many<OpRES1B, 1>, fuse::Many<OpUP2, 1>, fuse::Many<GruOp<128, 128, TICK_GRU_RT>, 1>, fuse::Many<GruOp<256, 256, TICK_GRU_RT>, 1>,                  \
     fuse::Many<VqOp, 1>, fuse::Many<TailOp<1>, 1>, fuse::Many<tst::T1Op, 1>, fuse::Many<tst::T2Op, 1>, fuse::Many<tst::T3Op, 1>, fuse::Many<rc::BlockAOp<1>, 1>, fuse::Many<rc::BlockAOp<2>, 1>,                 \
-    fuse::Many<rc::BlockAOp<4>, 1>, fuse::Many<rc::BlockAOp<8>, 1>, fuse::Many<rc::BlockBOp, 4>
+    fuse::Many<rc::BlockAOp<4>, 1>, fuse::Many<rc::BlockAOp<8>, 1>, fuse::Many<rc::BlockBOp, 4>, fuse::Many<rc::BlockBqOp, 4>
 using Tab = fuse::Table<TICK_TYPES>;
 using Builder = fuse::TableBuilder<TICK_TYPES>;
 

@@ -69,6 +69,12 @@ bool WaveState::create(int B_, int H_, int n_slots_, int n_add_, int n_frm_, flo
     BHIP_TRY(hipMemset(d_kt[blk], 0, sizeof(float) * kvf));
     BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_v[blk]), sizeof(float) * kvf));
     BHIP_TRY(hipMemset(d_v[blk], 0, sizeof(float) * kvf));
+    if (pipe_slack && !legacy) {
+      BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_ktp[blk]), sizeof(float) * kvf));
+      BHIP_TRY(hipMemset(d_ktp[blk], 0, sizeof(float) * kvf));
+      BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_vp[blk]), sizeof(float) * kvf));
+      BHIP_TRY(hipMemset(d_vp[blk], 0, sizeof(float) * kvf));
+    }
     BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_perm[blk]), sizeof(int) * perm.size()));
     BHIP_TRY(hipMemcpy(d_perm[blk], perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice));
     BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_tile_slot[blk]), sizeof(int) * slot.size()));
@@ -88,9 +94,9 @@ void WaveState::destroy() {
   void* ptrs[] = {d_out, d_add_tab, d_frm_tab, d_add_idx, d_frm_idx, d_hop};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int b = 0; b < B_NBLOCKS; ++b) {
-    void* q4[] = {d_kt[b], d_v[b], d_perm[b], d_tile_slot[b]};
+    void* q4[] = {d_kt[b], d_v[b], d_perm[b], d_tile_slot[b], d_ktp[b], d_vp[b]};
     for (void* p : q4) if (p) (void)hipFree(p);
-    d_kt[b] = d_v[b] = nullptr; d_perm[b] = d_tile_slot[b] = nullptr;
+    d_kt[b] = d_v[b] = d_ktp[b] = d_vp[b] = nullptr; d_perm[b] = d_tile_slot[b] = nullptr;
   }
   d_phone = d_feat = d_out = d_add_tab = d_frm_tab = nullptr;
   d_q = d_add_idx = d_frm_idx = d_hop = nullptr;
