@@ -23,6 +23,10 @@ extern "C" {
 
 /* ---- ProcessorCore2 (processor_core.h:22-92) ---- */
 void* BeatriceHost_Create(double sample_rate);                               /* ctor, processor_core_2.h:28-51 */
+/* the core of a package generation: 0 = 2.0.0-alpha.2, 1 = 2.0.0-beta.1 (ProcessorCore0 / ProcessorCore1, processor_core_1.h:22-118),
+ * 2 = 2.0.0-rc.0 (= BeatriceHost_Create); NULL for any other value.  Dispatch as processor_proxy.h:57-70. */
+void* BeatriceHost_CreateVersion(double sample_rate, int version);
+int BeatriceHost_GetVersion(void* core);                                            /* ProcessorCoreBase::GetVersion */
 void BeatriceHost_Destroy(void* core);
 int BeatriceHost_LoadModel(void* core, const char* toml_path);               /* processor_core_2.cc:293-419 */
 int BeatriceHost_Process(void* core, const float* in, float* out, int n);    /* processor_core_2.cc:24-48 (any n, host rate) */
