@@ -570,8 +570,14 @@ bool tick_build_table(BeatriceBatch* b) {
   const WaveState& ws = b->wave;
   const int B = b->B;
   const Plan pl = k.plan;
-  // measurement aid: BEATRICE_HIP_TICK_DROP=<bit mask> leaves groups of bodies out of the launch (results are then wrong)
+  // measurement aid, MEASUREMENT BUILDS ONLY (tools/debug/build_variant.sh <name> -DBEATRICE_HIP_MEASUREMENT_BUILD; the
+  // product library has no switch that changes results): BEATRICE_HIP_TICK_DROP=<bit mask> leaves groups of bodies out of
+  // the launch
+#ifdef BEATRICE_HIP_MEASUREMENT_BUILD
   static const int drop = std::getenv("BEATRICE_HIP_TICK_DROP") ? std::atoi(std::getenv("BEATRICE_HIP_TICK_DROP")) : 0;
+#else
+  constexpr int drop = 0;
+#endif
   auto keep = [](int group) { return ((drop >> group) & 1) == 0; };
   // (every body takes its step counter from the launch's StepPairs -- a null counter pointer says so, ring.h stepc)
   auto hp = [&](int) -> const int* { return nullptr; };

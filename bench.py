@@ -67,17 +67,40 @@ PMC_SYMBOL = {
 }
 
 
-def pmc_traffic(kernel_name, streams):
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/r*_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this bench at B = 256,
-    FETCH_SIZE doubled per the gfx950 correction).  None when no matching measurement exists."""
-    if streams != 256 or kernel_name not in PMC_SYMBOL:
-        return None
+def csrc_sha1():
+    """Fingerprint of the kernel sources (beatrice-vst_amd/csrc): the PMC summaries under profiles/ carry the one they were
+    measured at (tools/pmc_summary.py), and a summary taken at other sources is not quoted."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for path in sorted(glob.glob(os.path.join(REPO, "beatrice-vst_amd", "csrc", "*.hip")) + glob.glob(os.path.join(REPO, "beatrice-vst_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
+def pmc_summary_file():
+    """The newest committed PMC summary IF it was measured at the present kernel sources, else None."""
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")))
     if not files:
         return None
-    kernels = json.load(open(files[-1]))["kernels"]
+    rec = json.load(open(files[-1]))
+    if rec.get("csrc_sha1") != csrc_sha1():
+        return None   # stale: the tick table (or a kernel) changed since the PMC passes
+    return rec
+
+
+def pmc_traffic(kernel_name, streams):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/r*_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this bench at B = 256,
+    FETCH_SIZE doubled per the gfx950 correction).  None when no measurement of the present sources exists."""
+    if streams != 256 or kernel_name not in PMC_SYMBOL:
+        return None
+    rec = pmc_summary_file()
+    if rec is None:
+        return None
+    kernels = rec["kernels"]
     for sym, rec in kernels.items():
         if PMC_SYMBOL[kernel_name] in sym:
             return rec["hbm_bytes_per_launch"]
@@ -88,11 +111,10 @@ def pmc_mfma_busy(kernel_name, streams):
     """SQ_VALU_MFMA_BUSY_CYCLES per launch of the dominant kernel (same committed PMC summary), or None."""
     if streams != 256 or kernel_name not in PMC_SYMBOL:
         return None
-    import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")))
-    if not files:
+    summary = pmc_summary_file()
+    if summary is None:
         return None
-    for sym, rec in json.load(open(files[-1]))["kernels"].items():
+    for sym, rec in summary["kernels"].items():
         if PMC_SYMBOL[kernel_name] in sym:
             return rec.get("mfma_busy_cycles_per_launch")
     return None
@@ -599,6 +621,9 @@ def main():
                                        "chain, %d stages each on its own step)" % stages,
                              "launches_per_hop": 1, "mean_us_per_launch": round(us.value, 2),
                              "share_of_chain": round(us.value * 1e-3 / (1e3 * elapsed / a.steps), 3) if a.steps >= 200 else None}
+                summary = pmc_summary_file()
+                tick_roof["traffic_measured_at"] = ({"csrc_sha1": summary["csrc_sha1"], "commit": summary.get("commit")} if summary else
+                                                    "no PMC pass at the present kernel sources (csrc_sha1 %s): traffic not quoted" % csrc_sha1()[:12])
                 busy = pmc_mfma_busy("tick", B)
                 if busy is not None:
                     tick_roof["mfma_busy_cycles"] = busy

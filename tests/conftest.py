@@ -35,9 +35,9 @@ def built():
     """Build the oracle and the product if their shared objects are missing (no-op on the GPU box,
     where the prebuilt .so files travel with the snapshot)."""
     if not os.path.exists(os.path.join(REPO, "oracle", "libbeatrice_oracle.so")):
-        subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle"), "libbeatrice_oracle.so"])
+        subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle"), "libbeatrice_oracle.so"], env={k: v for k, v in os.environ.items() if k != "LD_PRELOAD"})
     if not os.path.exists(os.path.join(REPO, "beatrice-vst_amd", "csrc", "libbeatrice_hip.so")):
-        subprocess.check_call(["make", "-C", os.path.join(REPO, "beatrice-vst_amd"), "-j8"])
+        subprocess.check_call(["make", "-C", os.path.join(REPO, "beatrice-vst_amd"), "-j8"], env={k: v for k, v in os.environ.items() if k != "LD_PRELOAD"})
     return True
 
 

@@ -23,7 +23,7 @@ _i32p = C.POINTER(C.c_int)
 @pytest.fixture(scope="module")
 def host_path(built):
     import subprocess
-    subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle"), "libhost_on_oracle.so"])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle"), "libhost_on_oracle.so"], env={k: v for k, v in os.environ.items() if k != "LD_PRELOAD"})
     return hostlib.HOST_ON_ORACLE
 
 

@@ -30,7 +30,7 @@ def _mean(lib, fn, pts, w, order, limit, updates):
 def host_lib(built):
     if not os.path.exists(hostlib.HOST_ON_ORACLE):
         import subprocess
-        subprocess.check_call(["make", "-C", os.path.join(hostlib.REPO, "oracle"), "libhost_on_oracle.so"])
+        subprocess.check_call(["make", "-C", os.path.join(hostlib.REPO, "oracle"), "libhost_on_oracle.so"], env={k: v for k, v in os.environ.items() if k != "LD_PRELOAD"})
     return C.CDLL(hostlib.HOST_ON_ORACLE)
 
 

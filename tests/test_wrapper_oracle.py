@@ -17,7 +17,7 @@ RATES = [16000, 22050, 24000, 32000, 44100, 48000, 88200, 96000, 192000]
 def wo(built):
     if not os.path.exists(wrapperlib.ORACLE_WRAPPER):
         import subprocess
-        subprocess.check_call(["make", "-C", os.path.join(wrapperlib.REPO, "oracle"), "libwrapper_oracle.so"])
+        subprocess.check_call(["make", "-C", os.path.join(wrapperlib.REPO, "oracle"), "libwrapper_oracle.so"], env={k: v for k, v in os.environ.items() if k != "LD_PRELOAD"})
     return wrapperlib.oracle_wrapper()
 
 

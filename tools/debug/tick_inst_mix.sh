@@ -1,6 +1,9 @@
 #!/bin/bash
 # instruction mix of the tick launch per group of bodies: the launch with one group left out (BEATRICE_HIP_TICK_DROP),
 # differences = that group's instructions per full tick.  -> gpurun_out/tick_inst_mix.txt
+# (BEATRICE_HIP_TICK_DROP exists in measurement builds only: first `tools/debug/build_variant.sh meas -DBEATRICE_HIP_MEASUREMENT_BUILD`;
+#  this script then runs on build_variants/lib_meas.so)
+[ -f "$(dirname "$0")/../../build_variants/lib_meas.so" ] && export BEATRICE_HIP_LIB="$(cd "$(dirname "$0")/../.." && pwd)/build_variants/lib_meas.so"
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/tick_inst_mix.txt

@@ -49,7 +49,11 @@ def main(root, out):
                   "hbm_bytes_per_launch": int(round((2.0 * fetch_kb + write_kb) * 1024))}
         if k in mf:  # summed over the SIMDs that ran the kernel; one v_mfma_f32_16x16x4_f32 keeps a SIMD's pipe busy 32 cycles
             res[k]["mfma_busy_cycles_per_launch"] = round(per_launch(mf[k], k), 1)
-    json.dump({"note": "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; bench.py --no-extras, B=256; tick launch: mean over full ticks",
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench   # csrc_sha1: the sources these passes ran on; bench.py quotes the summary only while they are unchanged
+    commit = os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % os.path.dirname(os.path.abspath(bench.__file__))).read().strip()
+    json.dump({"csrc_sha1": bench.csrc_sha1(), "commit": commit or "(no .git on the GPU box: see csrc_sha1)",
+               "note": "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; bench.py --no-extras, B=256; tick launch: mean over full ticks",
                "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
     for k, r in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:12]:
         print("%8.2f MB  %s" % (r["hbm_bytes_per_launch"] / 1e6, k[:120]))
