@@ -34,6 +34,7 @@ struct StreamCfg {
   int target_speaker = 0;
   int kv_set_count = B_NBLOCKS;  // reference: key_value_speaker_embedding_set_count_ (processor_core_2.h:134)
   int kv_slot[B_NBLOCKS] = {0, 0, 0, 0};
+  int kv_delay = 0;               // hops before the pending blocks start to install (staged morph: the reference computes the means first)
   int codebook_speaker = 0;       // after a step: the codebook of its last hop
   int codebook_row[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // codebook of each hop of the step (a morphing stream draws one per hop)
   int additive_speaker = 0;
@@ -353,7 +354,9 @@ void advance_kv(BeatriceBatch* b) {
   for (int s = 0; s < b->B; ++s) {
     StreamCfg& c = b->cfg[s];
     for (int hh = 0; hh < H; ++hh) {  // the hops of this step, each preceded by one block install
-      if (c.kv_set_count < B_NBLOCKS) {
+      if (c.kv_delay > 0) {
+        --c.kv_delay;
+      } else if (c.kv_set_count < B_NBLOCKS) {
         c.kv_slot[c.kv_set_count] = c.target_speaker;
         ++c.kv_set_count;
         advanced = true;
@@ -1239,9 +1242,7 @@ int BeatriceBatch_UpdateSpeaker(BeatriceBatch* b, int spk, const float* codebook
 // dropped; processor_core_2.cc:507-532: the eight largest kept, in descending order), then the additive
 // and the 384 key/value embeddings of entry `slot` become weighted spherical means computed on the
 // device (morph.hip), and their projections are refreshed.
-int BeatriceBatch_MorphSpeaker(BeatriceBatch* b, int slot, const float* weights, int n_weights, unsigned seed) {
-  const DeviceScope dev_(b ? b->device : -1);
-  if (!b || !b->ok) return -2;
+static int morph_into(BeatriceBatch* b, int slot, const float* weights, int n_weights, unsigned seed) {
   if (!weights || n_weights < 1 || n_weights > 256 || slot < n_weights || slot >= b->max_speakers || n_weights > b->n_speakers) return -1;
   std::vector<float> w(weights, weights + n_weights);
   for (float& v : w) if (v < 0.01f) v = 0.0f;
@@ -1280,8 +1281,44 @@ int BeatriceBatch_MorphSpeaker(BeatriceBatch* b, int slot, const float* weights,
     for (int st = 0; st < b->B; ++st) b->lottery[st].seed(seed + (unsigned)st);
     b->lottery_seeded = true;
   }
+  return 0;
+}
+int BeatriceBatch_MorphSpeaker(BeatriceBatch* b, int slot, const float* weights, int n_weights, unsigned seed) {
+  const DeviceScope dev_(b ? b->device : -1);
+  if (!b || !b->ok) return -2;
+  if (const int rc = morph_into(b, slot, weights, n_weights, seed)) return rc;
   // streams already on this entry re-install its key/value blocks, one per hop, like after a speaker switch
-  for (StreamCfg& c : b->cfg) if (c.target_speaker == slot) c.kv_set_count = 0;
+  for (StreamCfg& c : b->cfg) if (c.target_speaker == slot) { c.kv_set_count = 0; c.kv_delay = 0; }
+  b->pending_kv = 0;
+  for (const StreamCfg& c : b->cfg) if (c.kv_set_count < B_NBLOCKS) ++b->pending_kv;
+  return 0;
+}
+// The reference's timeline of a weight change for streams that are ALREADY morphing (processor_core_2.cc:51-177): on the next
+// hop h0 the new additive embedding is in force and the codebook lottery draws with the new odds; the key/value means are
+// computed a quarter per hop over h0 .. h0+3 while the OLD key/value blocks keep playing; at h0+4 the new embeddings are
+// registered and installed one block per hop, h0+4 .. h0+7.  In place that cannot be done (BeatriceBatch_MorphSpeaker
+// overwrites the entry every stream on it is reading), so the new morph goes into ANOTHER table entry `slot` and the streams
+// on `from_slot` move over: additive embedding and lottery at once, key/value blocks after four hops.  `slot` must not be an
+// entry whose key/value blocks some stream still has installed (-3: use a third entry, as a caller that moves the weights
+// faster than every eight hops needs anyway -- the reference never installs new blocks while the weights keep moving, and
+// neither do streams here: each call restarts their four-hop wait).
+int BeatriceBatch_MorphSpeakerStaged(BeatriceBatch* b, int slot, int from_slot, const float* weights, int n_weights, unsigned seed) {
+  const DeviceScope dev_(b ? b->device : -1);
+  if (!b || !b->ok) return -2;
+  if (from_slot < 0 || from_slot >= b->max_speakers || from_slot == slot) return -1;
+  if (slot >= 0 && slot < b->max_speakers)
+    for (const StreamCfg& c : b->cfg)
+      for (int blk = 0; blk < B_NBLOCKS; ++blk) if (c.kv_slot[blk] == slot) return -3;
+  if (const int rc = morph_into(b, slot, weights, n_weights, seed)) return rc;
+  for (int s = 0; s < b->B; ++s) {
+    StreamCfg& c = b->cfg[s];
+    if (c.target_speaker != from_slot) continue;
+    c.target_speaker = slot;
+    c.additive_speaker = slot;
+    c.kv_set_count = 0;
+    c.kv_delay = 4;
+    sync_stream_arrays(b, s);
+  }
   b->pending_kv = 0;
   for (const StreamCfg& c : b->cfg) if (c.kv_set_count < B_NBLOCKS) ++b->pending_kv;
   return 0;
@@ -1315,7 +1352,7 @@ int BeatriceBatch_SetTargetSpeaker(BeatriceBatch* b, int stream, int speaker) {
   if (!b || !b->ok) return -2;
   if (speaker < 0 || speaker >= b->max_speakers) return -1;
   const int r = for_streams(b, stream, [&](StreamCfg& c) {
-    c.target_speaker = speaker; c.codebook_speaker = speaker; c.additive_speaker = speaker; c.kv_set_count = 0;
+    c.target_speaker = speaker; c.codebook_speaker = speaker; c.additive_speaker = speaker; c.kv_set_count = 0; c.kv_delay = 0;
     for (int& cr : c.codebook_row) cr = speaker;
   });
   if (r == 0) { b->pending_kv = 0; for (const StreamCfg& c : b->cfg) if (c.kv_set_count < B_NBLOCKS) ++b->pending_kv; }
@@ -1325,6 +1362,7 @@ int BeatriceBatch_SetTargetSpeaker(BeatriceBatch* b, int stream, int speaker) {
 int BeatriceBatch_FlushSpeaker(BeatriceBatch* b, int stream) {
   const DeviceScope dev_(b ? b->device : -1);
   const int r = for_streams(b, stream, [&](StreamCfg& c) {
+    c.kv_delay = 0;
     for (; c.kv_set_count < B_NBLOCKS; ++c.kv_set_count) c.kv_slot[c.kv_set_count] = c.target_speaker;
   });
   if (r == 0) {

@@ -119,6 +119,15 @@ int BeatriceBatch_MorphSpeaker(BeatriceBatch* b, int slot, const float* weights,
  * see all four blocks change at that step (the reference, which computes the means over four hops on the audio
  * thread, installs them one block per hop). */
 int BeatriceBatch_SeedLottery(BeatriceBatch* b, int stream, unsigned seed);
+/* The reference's own timeline of a weight change for streams that are already morphing (processor_core_2.cc:51-177,
+ * 144-172): on the next hop h0 the new additive embedding and the new lottery odds are in force, the OLD key/value blocks keep
+ * playing over h0 .. h0+3 (the reference computes a quarter of the key/value means per hop), the new ones are installed one
+ * block per hop over h0+4 .. h0+7.  The new morph is computed into ANOTHER table entry `slot` (same rules as
+ * BeatriceBatch_MorphSpeaker) and every stream whose target speaker is `from_slot` moves to it on that timeline.  -3: some
+ * stream still has key/value blocks of `slot` installed (rotate over three entries when the weights move faster than every
+ * eight hops; as in the reference, new blocks are then never installed while the weights keep moving: each call restarts the
+ * four-hop wait). */
+int BeatriceBatch_MorphSpeakerStaged(BeatriceBatch* b, int slot, int from_slot, const float* weights, int n_weights, unsigned seed);
 /* Raw embeddings of a table entry as currently held on the device: additive [256], key_value [384][128]. */
 int BeatriceBatch_GetSpeakerEmbeddings(BeatriceBatch* b, int speaker, float* additive, float* key_value);
 

@@ -201,3 +201,69 @@ def test_moving_morph_weights_does_not_restart_the_lottery(bv, product, model_di
     # and the lottery does draw: with a frozen first variate every hop would use one codebook; compare with k-NN off
     m.close()
     assert np.abs(once).max() > 0.05
+
+
+def test_staged_morph_follows_the_reference_timeline(bv, oracle, product, model_dir8):
+    """the reference-faithful install of a weight change for streams that are already morphing
+    (processor_core_2.cc:51-177): additive embedding on the next hop, the OLD key/value blocks for four more hops, the new ones
+    one block per hop after that.  Oracle streams are driven through exactly that protocol with the embeddings the device
+    solver produced (read back), so the comparison is bit for bit; k-NN off (no lottery in the way)."""
+    B, hops, change_at = 3, 24, 7
+    audio = np.stack([bv.synth_audio(160 * hops, seed=700 + s) for s in range(B)])
+    w1 = np.array([0.5, 0.0, 0.3, 0.2, 0.0, 0.0, 0.0, 0.0], np.float32)
+    w2 = np.array([0.0, 0.6, 0.0, 0.0, 0.1, 0.3, 0.0, 0.0], np.float32)
+    m = bv.Models(product, model_dir8)
+    batch = bv.Batch(m, B, max_speakers=m.tables.n_speakers + 3)   # room for two morph entries
+    a, hnd = batch.a, batch.h
+    n = m.tables.n_speakers
+    e1, e2 = n, n + 1
+    assert a.BeatriceBatch_MorphSpeaker(hnd, e1, bv.fptr(w1), n, 5) == 0
+    a.BeatriceBatch_SetTargetSpeaker(hnd, 0, e1)
+    a.BeatriceBatch_SetTargetSpeaker(hnd, 1, e1)
+    a.BeatriceBatch_SetTargetSpeaker(hnd, 2, 1)           # a stream that is not morphing keeps out of it
+    a.BeatriceBatch_FlushSpeaker(hnd, -1)
+    emb = {}
+
+    def read_entry(e):
+        add, kv = np.zeros(bv.HID, np.float32), np.zeros((bv.KV_LEN, bv.KV_CH), np.float32)
+        assert a.BeatriceBatch_GetSpeakerEmbeddings(hnd, e, bv.fptr(add), bv.fptr(kv)) == 0
+        return add, kv
+
+    emb[e1] = read_entry(e1)
+    got = np.zeros((hops, B, bv.OUT_HOP), np.float32)
+    for h in range(hops):
+        if h == change_at:
+            assert a.BeatriceBatch_MorphSpeakerStaged(hnd, e1, e1, bv.fptr(w2), n, 5) == -1       # in place is what MorphSpeaker does
+            assert a.BeatriceBatch_MorphSpeakerStaged(hnd, e2, e1, bv.fptr(w2), n, 5) == 0
+            emb[e2] = read_entry(e2)
+        if h == change_at + 2:
+            assert a.BeatriceBatch_MorphSpeakerStaged(hnd, e1, e2, bv.fptr(w1), n, 5) == -3       # e1's blocks are still installed
+        got[h] = batch.convert(audio[:, h * 160:(h + 1) * 160])
+    batch.close()
+    m.close()
+
+    mo = bv.Models(oracle, model_dir8)
+    t = mo.tables
+    want = np.zeros_like(got)
+    for s in range(B):
+        st = bv.Stream1(mo, speaker=1 if s == 2 else 0, vq_k=0)
+        if s < 2:   # onto the first morph, all blocks at once (FlushSpeaker)
+            st.a.SetAdditiveSpeakerEmbedding(mo.embed, bv.fptr(emb[e1][0]), st.ec, st.wc)
+            st.a.RegisterKeyValueSpeakerEmbedding(mo.embed, bv.fptr(emb[e1][1]), st.ec)
+            st.kv_count = 0
+            while st.set_kv_block():
+                pass
+        for h in range(hops):
+            if s < 2 and h == change_at:          # morph_counter_ == 0: the additive embedding at once
+                st.a.SetAdditiveSpeakerEmbedding(mo.embed, bv.fptr(emb[e2][0]), st.ec, st.wc)
+            if s < 2 and h == change_at + 4:      # morph_counter_ == 4: register; Stream1.hop installs one block per hop from here
+                st.a.RegisterKeyValueSpeakerEmbedding(mo.embed, bv.fptr(emb[e2][1]), st.ec)
+                st.kv_count = 0
+            want[h, s] = st.hop(audio[s, h * 160:(h + 1) * 160])
+        st.close()
+    mo.close()
+    assert np.abs(got).max() > 0.05
+    for h in range(hops):
+        assert np.array_equal(got[h], want[h]), "hop %d max-abs %g" % (h, np.abs(got[h] - want[h]).max())
+    # the change is audible where the protocol says: nothing before h0, and the streams differ from an "all at once" install
+    assert not np.array_equal(got[change_at:, :2], 0 * got[change_at:, :2])
