@@ -13,6 +13,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <deque>
 #include <numeric>
 #include <random>
 #include <string>
@@ -223,6 +224,20 @@ struct BeatriceBatch {
     int deferred_slot = -1;                       // step completed by the last tick, its 48 kHz block not yet produced
   } r48;
   float *d_coef_down = nullptr, *d_coef_up = nullptr, *d_io48 = nullptr, *h_io48 = nullptr;  // io: in [B][2][480] | out [B][2][480]
+  // The any-rate wrapper around the tick pipeline (BeatriceBatch_BindResidentBlocks): host-rate blocks resident on the device,
+  // the input half of the chain in front of the ticks, the output half `delay` calls later (wrapper.hip.h wrap_post_kernel)
+  struct ResidentBlocks {
+    bool on = false;
+    int channels = 0, n = 0, n_slots = 0, io_slots = 0, delay = 0, ring = 0;
+    const float* d_in = nullptr;   // [n_slots][B][channels][n]
+    float* d_out = nullptr;        // [n_slots][B][channels][n]
+    float *d_in16 = nullptr, *d_out24 = nullptr;   // [io_slots][B][160], [io_slots][B][240]: the resident I/O of the ticks
+    wrapn::GainSeg *d_gains = nullptr, *h_gains = nullptr;   // [ring][2][B]: a call's input | output segments, until its output half has run
+    hipEvent_t* gain_ev = nullptr;                           // [ring]: upload of ring entry done
+    long long calls = 0, t48 = 0;                            // calls so far; 48 kHz samples fed so far
+    struct Job { long long call, t0; wrapn::Dir dout; };
+    std::deque<Job> jobs;                                    // calls whose output half is still to run, oldest first
+  } rb;
 };
 
 namespace {
@@ -821,6 +836,17 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
   return hip_ok(hipGetLastError(), "tick launch");
 }
 // ticks without new input until the last step fed has left the last stage
+// output half of one call of the any-rate wrapper around the ticks (BeatriceBatch_BindResidentBlocks): its block's inner
+// samples gathered from the resident model outputs, second resampling direction, output gain, into the call's slot
+bool rb_post(BeatriceBatch* b, const BeatriceBatch::ResidentBlocks::Job& j) {
+  BeatriceBatch::ResidentBlocks& r = b->rb;
+  const size_t nt = b->wrap.taps_down.size();
+  const int slot = (int)(j.call % r.n_slots), ge = (int)(j.call % r.ring);
+  hipLaunchKernelGGL(wrapn::wrap_post_kernel, dim3(b->B), dim3(256), 0, b->stream, r.d_out24, r.io_slots, b->B, j.t0, b->d_wrap,
+                     r.d_gains + (size_t)ge * 2 * b->B + b->B, b->d_wrap_taps + (j.dout.decimate ? 0 : nt), j.dout,
+                     r.d_out + (size_t)slot * b->B * r.channels * r.n, r.channels);
+  return hip_ok(hipGetLastError(), "wrapper output half");
+}
 bool tick_drain(BeatriceBatch* b) {
   bool ok = true;
   if (b->tk.on && b->tk.d_trace && b->tk.last_feed_tick == b->tk.tick - 1 && b->tk.n_fed > b->tk.plan.count()) {
@@ -844,6 +870,10 @@ bool tick_drain(BeatriceBatch* b) {
     r.deferred_slot = -1;
     hipLaunchKernelGGL(wrap48_tick_kernel, dim3(wa.n_post), dim3(256), 0, b->stream, wa);
     ok = hip_ok(hipGetLastError(), "wrap48 flush");
+  }
+  while (ok && b->rb.on && !b->rb.jobs.empty()) {  // every model hop has left the pipeline: the output halves still owed, in order
+    ok = rb_post(b, b->rb.jobs.front());
+    b->rb.jobs.pop_front();
   }
   return ok;
 }
@@ -934,6 +964,8 @@ int model_ready(Model* m) {
 }  // namespace
 
 extern "C" {
+static bool rb_step(BeatriceBatch* b);
+static void rb_release(BeatriceBatch* b);
 
 // ---- memory loaders ---------------------------------------------------------------------------
 #define BHIP_MEMORY_LOADER(Name, Obj, KIND, Weights)                                                        \
@@ -1127,6 +1159,7 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   host_stream_free(b);
   if (b->r48.d_in16) (void)hipFree(b->r48.d_in16);
   if (b->r48.d_out24) (void)hipFree(b->r48.d_out24);
+  rb_release(b);
   if (b->own_d_out) { b->wave.d_out = b->own_d_out; b->own_d_out = nullptr; }
   if (b->io_mapped) { b->wave.d_out = b->dev_d_out; b->phone.d_in = b->pitch.d_in = b->d_in; b->io_mapped = false; }  // (the modules free what they allocated)
   if (b->module_owned[0]) {  // hand the modules their own arrays back so that destroy() frees what it allocated
@@ -1665,12 +1698,128 @@ static int wrap_max_chunk(const BeatriceBatch* b) {  // host samples per launch 
 int BeatriceBatch_ProcessBlocksDevice(BeatriceBatch* b, const float* d_in, float* d_out, int channels, int n) {
   const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
+  if (b->rb.on) return (!d_in && !d_out && channels == b->rb.channels && n == b->rb.n) ? (rb_step(b) ? 0 : -2) : -1;
   if (!b->wrap.ready || channels < 1 || channels > 2 || !d_in || !d_out || n < 1 || b->H != 1 || b->io_slots > 0 || b->pipelined || b->tk.on) return -1;
   const int piece = wrap_max_chunk(b);
   if (n <= piece) return wrap_chunk(b, d_in, d_out, channels, n) ? 0 : -2;
   return -1;  // the planar layout [B][channels][n] cannot be cut without copies: callers pass blocks of at most `piece` samples
 }
 int BeatriceBatch_MaxWrapperBlock(const BeatriceBatch* b) { return b && b->ok && b->wrap.ready ? wrap_max_chunk(b) : 0; }
+
+// ---- the same wrapper around the TICK pipeline (throughput form, resident blocks) ------------------------------------------------
+// One call = one host-rate block per stream from slot `call mod n_slots` of d_in: gains and the first resampling direction, the
+// 480-sample accumulation, a model hop into the tick pipeline every time it fills (one tick per hop, at least one tick per
+// call so that a hop is out of the pipeline TickStages() - 1 calls after it went in); then the output half of the call made
+// `delay` = TickStages() - 1 calls ago, into ITS slot of d_out.  Everything that is control is on the host, as in wrap_chunk.
+static void rb_release(BeatriceBatch* b) {
+  BeatriceBatch::ResidentBlocks& r = b->rb;
+  if (r.d_in16) (void)hipFree(r.d_in16);
+  if (r.d_out24) (void)hipFree(r.d_out24);
+  if (r.d_gains) (void)hipFree(r.d_gains);
+  if (r.h_gains) (void)hipHostFree(r.h_gains);
+  if (r.gain_ev) { for (int i = 0; i < r.ring; ++i) if (r.gain_ev[i]) (void)hipEventDestroy(r.gain_ev[i]); delete[] r.gain_ev; }
+  r = BeatriceBatch::ResidentBlocks{};
+}
+static bool rb_step(BeatriceBatch* b) {
+  using namespace wrapn;
+  BeatriceBatch::ResidentBlocks& r = b->rb;
+  const int B = b->B, n = r.n;
+  hipStream_t st = b->stream;
+  WrapPlan& w = b->wrap;
+  const long long call = r.calls;
+  const int ge = (int)(call % r.ring);
+  // this call's gain segments: input half now, output half when its job runs
+  if (call >= r.ring && !hip_ok(hipEventSynchronize(r.gain_ev[ge]), "wrapper gain ring")) return false;
+  GainSeg* seg = r.h_gains + (size_t)ge * 2 * B;
+  for (int s = 0; s < B; ++s) { seg[s] = b->gain_in[s].advance(n, w.rate); seg[B + s] = b->gain_out[s].advance(n, w.rate); }
+  GainSeg* dseg = r.d_gains + (size_t)ge * 2 * B;
+  BHIP_TRY(hipMemcpyAsync(dseg, seg, sizeof(GainSeg) * 2 * B, hipMemcpyHostToDevice, st));
+  BHIP_TRY(hipEventRecord(r.gain_ev[ge], st));
+  const size_t nt = w.taps_down.size();
+  const Dir din = w.to_inner(n);
+  const int m = din.n_out;
+  if (m < 0 || m > kMaxSamples) return false;
+  const Dir dout = w.to_outer(m);
+  if (dout.n_out != n) return false;
+  const float* src = r.d_in + (size_t)(call % r.n_slots) * B * r.channels * n;
+  hipLaunchKernelGGL(wrap_in_kernel, dim3(B), dim3(256), 0, st, src, r.channels, n, b->d_wrap, dseg, b->d_wrap_taps + (din.decimate ? 0 : nt), din,
+                     b->d_wrap_inner, kInnerStride);
+  int ticks = 0;
+  for (int at = 0; at < m;) {  // the 480-sample accumulation; a model hop every time it fills (the per-stream FIFO array holds it)
+    const int take = std::min(kBlock - w.fill, m - at);
+    const int fires = w.fill + take == kBlock ? 1 : 0;
+    hipLaunchKernelGGL(wrap_fifo_kernel, dim3(B), dim3(256), 0, st, b->d_wrap_inner, kInnerStride, b->d_wrap, at, w.fill, take, fires,
+                       r.d_in16 + (size_t)b->io_host * B * B_IN_HOP);
+    if (fires) {
+      if (!tick_run(b, true)) return false;
+      ++ticks;
+      w.fill = 0;
+    } else {
+      w.fill += take;
+    }
+    at += take;
+  }
+  if (ticks == 0 && !tick_run(b, false)) return false;   // the pipeline advances with every call
+  r.jobs.push_back(BeatriceBatch::ResidentBlocks::Job{call, r.t48, dout});
+  r.t48 += m;
+  r.calls = call + 1;
+  bool ok = true;
+  while (ok && !r.jobs.empty() && r.jobs.front().call + r.delay <= call) {
+    ok = rb_post(b, r.jobs.front());
+    r.jobs.pop_front();
+  }
+  b->inflight = true;
+  return ok;
+}
+// d_in / d_out: [n_slots][B][channels][n] planar blocks at the configured host rate (BeatriceBatch_ConfigureWrapper first).
+// Call k (BeatriceBatch_ProcessBlocksDevice(b, NULL, NULL, channels, n)) reads slot k mod n_slots; its output block is in the
+// same slot of d_out BeatriceBatch_ResidentBlocksDelay() calls later (or after BeatriceBatch_Synchronize).  Same samples as
+// the in-order BeatriceBatch_ProcessBlocksDevice.  n_slots > delay + 1.  NULL pointers unbind.
+int BeatriceBatch_BindResidentBlocks(BeatriceBatch* b, const float* d_in, float* d_out, int channels, int n, int n_slots) {
+  const DeviceScope dev_(b ? b->device : -1);
+  if (!b || !b->ok) return -2;
+  BeatriceBatch::ResidentBlocks& r = b->rb;
+  if (r.on) {
+    if (!sync_all(b)) return -2;
+    const int rc = tick_enable(b, false);
+    if (rc) return rc;
+    (void)BeatriceBatch_BindResidentIO(b, nullptr, nullptr, 0);
+    rb_release(b);
+  }
+  if (!d_in && !d_out) return 0;
+  const int stages = b->tk.plan.count();
+  if (!b->wrap.ready || !d_in || !d_out || channels < 1 || channels > 2 || n < 1 || n > wrap_max_chunk(b) || n_slots < stages + 1 || b->H != 1 ||
+      b->io_slots > 0 || b->pipelined || b->tk.on || b->hs.on || b->r48.on)
+    return -1;
+  if (!sync_all(b)) return -2;
+  // model hops a call can fire: ceil(inner samples / 480) + 1; a hop's resident output is read until `delay` calls after the
+  // call in which the NEXT hop fired
+  const int m_max = (int)std::ceil(n * 48000.0 / b->wrap.rate) + 2, hops_per_call = (m_max + wrapn::kBlock - 1) / wrapn::kBlock + 1;
+  r.delay = stages - 1;
+  r.ring = r.delay + 3;
+  r.io_slots = std::max(stages + 1, (r.delay + 2) * hops_per_call + 2);
+  const int B = b->B;
+  bool ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_in16), sizeof(float) * r.io_slots * B * B_IN_HOP), "rb in16") &&
+            hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_out24), sizeof(float) * r.io_slots * B * B_OUT_HOP), "rb out24") &&
+            hip_ok(hipMemset(r.d_in16, 0, sizeof(float) * r.io_slots * B * B_IN_HOP), "rb zero") &&
+            hip_ok(hipMemset(r.d_out24, 0, sizeof(float) * r.io_slots * B * B_OUT_HOP), "rb zero") &&
+            hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_gains), sizeof(wrapn::GainSeg) * r.ring * 2 * B), "rb gains") &&
+            hip_ok(hipHostMalloc(reinterpret_cast<void**>(&r.h_gains), sizeof(wrapn::GainSeg) * r.ring * 2 * B, hipHostMallocDefault), "rb gains host");
+  if (ok) {
+    r.gain_ev = new hipEvent_t[r.ring]();
+    for (int i = 0; i < r.ring && ok; ++i) ok = hip_ok(hipEventCreateWithFlags(&r.gain_ev[i], hipEventDisableTiming), "rb event");
+  }
+  ok = ok && hip_ok(hipDeviceSynchronize(), "rb sync") && BeatriceBatch_BindResidentIO(b, r.d_in16, r.d_out24, r.io_slots) == 0 && tick_enable(b, true) == 0;
+  if (!ok) {
+    (void)tick_enable(b, false);
+    (void)BeatriceBatch_BindResidentIO(b, nullptr, nullptr, 0);
+    rb_release(b);
+    return -2;
+  }
+  r.d_in = d_in; r.d_out = d_out; r.channels = channels; r.n = n; r.n_slots = n_slots; r.on = true;
+  return 0;
+}
+int BeatriceBatch_ResidentBlocksDelay(const BeatriceBatch* b) { return b && b->ok && b->rb.on ? b->rb.delay : -1; }
 int BeatriceBatch_ProcessBlocks(BeatriceBatch* b, const float* in, float* out, int channels, int n) {
   const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;

@@ -134,6 +134,46 @@ static __global__ __launch_bounds__(256) void wrap_out_kernel(const float* __res
   for (int i = tid; i < d.hist; i += 256) hist[i] = x[d.n_in + i];
 }
 
+// The output half of the chain for a batch whose model hops run in the tick pipeline (BeatriceBatch_BindResidentBlocks): the
+// 480-sample FIFO only DELAYS -- 48 kHz sample t of the stream leaving it is sample t % 480 of the zero-stuffed output of
+// model hop t / 480 - 1 (zeros before the first hop; reference resample.h:343-363, 380-394) -- so the block's inner samples
+// [t0, t0 + m) are gathered straight from the resident model outputs (hop k in slot k mod io_slots) once those hops have
+// left the pipeline, and go through the second resampling direction and the output gain exactly as in wrap_out_kernel.
+static __global__ __launch_bounds__(256) void wrap_post_kernel(const float* __restrict__ out24 /* [io_slots][B][240] */, const int io_slots, const int B,
+                                                               const long long t0, StreamState* __restrict__ st, const GainSeg* __restrict__ gain,
+                                                               const float* __restrict__ taps, const Dir d, float* __restrict__ out, const int channels) {
+  __shared__ float x[kMaxHist + kMaxSamples];
+  __shared__ double amp[kMaxSamples];
+  const int b = blockIdx.x, tid = threadIdx.x, n = d.n_out;
+  float* hist = d.decimate ? st[b].hist_high_out : st[b].hist_low_out;
+  const GainSeg g = gain[b];
+  if (tid == 0 && g.step != 1.0) {
+    double a = g.amp0;
+    for (int i = 0; i < n; ++i) {
+      if (g.step > 1.0) { if (a < g.goal) a = fmin(a * g.step, g.goal); }
+      else if (a > g.goal) a = fmax(a * g.step, g.goal);
+      amp[i] = a;
+    }
+  }
+  for (int i = tid; i < d.hist; i += 256) x[i] = hist[i];
+  for (int i = tid; i < d.n_in; i += 256) {
+    const long long t = t0 + i;
+    const long long k = t / kBlock - 1;
+    const int off = (int)(t % kBlock);
+    x[d.hist + i] = (k < 0 || (off & 1)) ? 0.0f : out24[((size_t)(k % io_slots) * B + b) * 240 + (off >> 1)];
+  }
+  __syncthreads();
+  float* dst = out + (size_t)b * channels * n;
+  for (int o = tid; o < n; o += 256) {
+    const float y = resample_one(d, x, taps, o);
+    const double a = g.step != 1.0 ? amp[o] : g.amp0;
+    const float v = (float)(y * a);
+    for (int c = 0; c < channels; ++c) dst[c * n + o] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < d.hist; i += 256) hist[i] = x[d.n_in + i];
+}
+
 // The exact-480 FIFO (reference resample.h:343-363): samples [at, at + take) of the 48 kHz stream swap places with
 // FIFO positions [fill, fill + take) -- the stream gets what the previous block left there (its processed output), the
 // FIFO gets the new input.  When that completes the block (fires != 0) every third sample goes to the model's input.

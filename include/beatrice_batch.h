@@ -195,6 +195,14 @@ int BeatriceBatch_SetOutputGain(BeatriceBatch* b, int stream, double gain_db);
 int BeatriceBatch_ProcessBlocks(BeatriceBatch* b, const float* in, float* out, int channels, int n_samples);
 int BeatriceBatch_ProcessBlocksDevice(BeatriceBatch* b, const float* d_in, float* d_out, int channels, int n_samples);
 int BeatriceBatch_MaxWrapperBlock(const BeatriceBatch* b);
+/* Throughput form of the any-rate wrapper: the TICK pipeline between resident host-rate blocks (as BeatriceBatch_BindResidentIO48k
+ * is for 48 kHz / 0 dB).  d_in / d_out: [n_slots][B][channels][n_samples] planar, at the rate of BeatriceBatch_ConfigureWrapper.
+ * Call k = BeatriceBatch_ProcessBlocksDevice(b, NULL, NULL, channels, n_samples) reads slot k mod n_slots; its output block is in
+ * the same slot of d_out BeatriceBatch_ResidentBlocksDelay() (= TickStages() - 1) calls later, or after BeatriceBatch_Synchronize.
+ * Gains (BeatriceBatch_SetInputGain / SetOutputGain) and every per-stream setting apply to the call that follows them, as in
+ * order.  Same samples as BeatriceBatch_ProcessBlocksDevice in order.  n_slots >= TickStages() + 1.  NULL pointers unbind. */
+int BeatriceBatch_BindResidentBlocks(BeatriceBatch* b, const float* d_in, float* d_out, int channels, int n_samples, int n_slots);
+int BeatriceBatch_ResidentBlocksDelay(const BeatriceBatch* b);
 
 /* Execution control: use an externally owned hipStream_t (e.g. the framework's current stream);
  * replay the per-hop kernel chain from a captured hipGraph (default on). */
