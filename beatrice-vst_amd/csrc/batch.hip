@@ -575,344 +575,7 @@ bool step_device(BeatriceBatch* b, const float* d_in, float* d_out) {
   return true;
 }
 
-// ---- tick pipelining (tick.hip.h) ---------------------------------------------------------------------------------
-bool tick_build_table(BeatriceBatch* b) {
-  using namespace tick;
-  State& k = b->tk;
-  auto tb = std::make_unique<Builder>();
-  const PhoneWeights& pw = b->phone_m->w;
-  const PitchWeights& qw = b->pitch_m->w;
-  const WaveWeights& ww = b->wave_m->w;
-  const PhoneState& ps = b->phone;
-  const PitchState& qs = b->pitch;
-  const WaveState& ws = b->wave;
-  const int B = b->B;
-  const Plan pl = k.plan;
-  // measurement aid, MEASUREMENT BUILDS ONLY (tools/debug/build_variant.sh <name> -DBEATRICE_HIP_MEASUREMENT_BUILD; the
-  // product library has no switch that changes results): BEATRICE_HIP_TICK_DROP=<bit mask> leaves groups of bodies out of
-  // the launch
-#ifdef BEATRICE_HIP_MEASUREMENT_BUILD
-  static const int drop = std::getenv("BEATRICE_HIP_TICK_DROP") ? std::atoi(std::getenv("BEATRICE_HIP_TICK_DROP")) : 0;
-#else
-  constexpr int drop = 0;
-#endif
-  auto keep = [](int group) { return ((drop >> group) & 1) == 0; };
-  // (every body takes its step counter from the launch's StepPairs -- a null counter pointer says so, ring.h stepc)
-  auto hp = [&](int) -> const int* { return nullptr; };
-  auto conv = [&](const Ring& in, const Ring& out, const float* w, const float* bias, int stage) { return conv_args(in, out, w, bias, hp(stage), B); };
-  // (workgroups are dispatched in this order: the longest-running bodies first)
-  // ---- longest workgroups first (measured, two per CU): f5 48 us, p1 46, f4 45, rb 42, block halves 41 / 38, tail 36
-  { const ConvArgs a = conv(ps.f[3], ps.f[4], pw.f_w[3], pw.f_b[3], Plan::F5); tb->add<T_F5>(OpF5::info("phone.f5", a), a, OpF5::grid(a), Plan::F5, keep(6), 47); }
-  { const ConvArgs a = conv(qs.spec, qs.p[0], qw.p_w[0], qw.p_b[0], Plan::P1); tb->add<T_P1>(OpP1::info("pitch.p1", a), a, OpP1::grid(a), Plan::P1, keep(2), 34.5); }
-  { const ConvArgs a = conv(ps.f[2], ps.f[3], pw.f_w[2], pw.f_b[2], Plan::F4); tb->add<T_F4>(OpF4::info("phone.f4", a), a, OpF4::grid(a), Plan::F4, keep(6), 37.5); }
-  for (int i = 0; i < 4; ++i) {
-    const ConvArgs a = conv(i == 0 ? ps.f[4] : ps.rb[i - 1], ps.rb[i], pw.rb_w[i], pw.rb_b[i], Plan::RB0 + i);
-    tb->add<T_RB>(OpRB::info("phone.rb", a), a, OpRB::grid(a), Plan::RB0 + i, keep(6), 46);
-  }
-  // conditioned blocks: two row-local chains each
-  for (int blk = 0; blk < B_NBLOCKS; ++blk) {
-    const WaveState::Scratch& sc = ws.scr[blk];  // one scratch set per block: all four blocks are in flight at once
-    const int s0 = pl.blk(blk);
-    const rc::BlockBArgs ba{sc.xa, ws.x[blk + 1], ww.q_w[blk], ww.q_b[blk], ww.o_w[blk], ww.o_b[blk], ws.d_kt[blk], ws.d_v[blk],
-                            b->dev_view<int>(b->off.perm[blk]), b->dev_view<int>(b->off.tile_slot[blk]), hp(s0 + 1)};
-    tb->add<T_BLKB>(LaunchInfo{"wave.blk.b", 2.0 * B * (256.0 * 256 * 2 + 256.0 * 384 * 2), 4.0 * (2.0 * 256 * 256 + 2.0 * 256 * 384 + B * 3.0 * 256)}, ba,
-                    dim3(ws.n_tiles_max, 1), s0 + 1, keep(5), 41.0);
-    if (quads_on(b)) {  // rows without 15 neighbours on their K/V slot: one workgroup per quad (rebuild_tiles decides which rows)
-      const rc::BlockBqArgs bq{sc.xa, ws.x[blk + 1], ww.q_w[blk], ww.q_b[blk], ww.o_w[blk], ww.o_b[blk], ws.d_ktp[blk], ws.d_vp[blk],
-                               b->dev_view<int>(b->off.qperm[blk]), b->dev_view<int>(b->off.qslot[blk]), hp(s0 + 1)};
-      // (a slot leaves at most 7 rows = 2 quads to this list: <= n_slots workgroups of two quads)
-      tb->add<T_BLKBQ>(LaunchInfo{"wave.blk.bq", 0.0, 0.0}, bq, dim3(std::min(2 * ws.n_tiles_max, ws.n_slots), 1), s0 + 1, keep(5), 42.0);
-    }
-  }
-  for (int blk = 0; blk < B_NBLOCKS; ++blk) {
-    const rc::BlockAArgs aa{ws.x[blk], ws.scr[blk].xa, ww.c1_w[blk], ww.c1_b[blk], ww.c2_w[blk], ww.c2_b[blk], hp(pl.blk(blk)), B};
-    switch (blk) {
-      case 0: tb->add<T_BLKA1>(rc::BlockAOp<1>::info(aa), aa, rc::BlockAOp<1>::grid(aa), pl.blk(blk), keep(5), 41); break;
-      case 1: tb->add<T_BLKA2>(rc::BlockAOp<2>::info(aa), aa, rc::BlockAOp<2>::grid(aa), pl.blk(blk), keep(5), 41); break;
-      case 2: tb->add<T_BLKA4>(rc::BlockAOp<4>::info(aa), aa, rc::BlockAOp<4>::grid(aa), pl.blk(blk), keep(5), 41); break;
-      default: tb->add<T_BLKA8>(rc::BlockAOp<8>::info(aa), aa, rc::BlockAOp<8>::grid(aa), pl.blk(blk), keep(5), 41); break;
-    }
-  }
-  if (!pl.split_tail) {
-    TailArgs ta = tail_args(ww, ws); ta.hop = hp(pl.tail()); tb->add<T_TAIL>(tail_info(ws), ta, dim3(B, 1), pl.tail(), keep(4), 41, true);
-  } else {
-    // the tail as three stages, several streams per workgroup (tail_stages.hip.h); same weights, same state block
-    tst::StageArgs t1{}, t2{}, t3{};
-    t1.in = ws.ya2; t1.out = ws.ya3; t2.in = ws.ya3; t2.out = ws.ya4; t3.in = ws.ya4;
-    for (tst::StageArgs* t : {&t1, &t2, &t3}) { t->state = ws.tail.base; t->hop = nullptr; t->B = B; }
-    t1.w[0] = ww.ra_w[1]; t1.b[0] = ww.ra_b[1]; t1.w[1] = ww.rb_w[1]; t1.b[1] = ww.rb_b[1]; t1.w[2] = ww.up_w[2]; t1.b[2] = ww.up_b[2];
-    t2.w[0] = ww.ra_w[2]; t2.b[0] = ww.ra_b[2]; t2.w[1] = ww.rb_w[2]; t2.b[1] = ww.rb_b[2]; t2.w[2] = ww.up_w[3]; t2.b[2] = ww.up_b[3];
-    t3.w[0] = ww.ra_w[3]; t3.b[0] = ww.ra_b[3]; t3.w[1] = ww.rb_w[3]; t3.b[1] = ww.rb_b[3];
-    t3.fin_w = ww.fin_w; t3.fin_b = ww.fin_b; t3.d_out = ws.d_out; t3.io_stride = ws.io_stride;
-    tb->add<T_TAIL1>(tst::T1Op::info(t1), t1, tst::T1Op::grid(t1), pl.tail(), keep(4), 30, true);
-    tb->add<T_TAIL2>(tst::T2Op::info(t2), t2, tst::T2Op::grid(t2), pl.tail() + 1, keep(4), 28, true);
-    tb->add<T_TAIL3>(tst::T3Op::info(t3), t3, tst::T3Op::grid(t3), pl.tail() + 2, keep(4), 16, true);
-  }
-  // ---- everything else, longest workgroups first (they start when the heavy ones above leave their slots)
-  { const ConvArgs a = conv(ps.f[1], ps.f[2], pw.f_w[1], pw.f_b[1], Plan::F3); tb->add<T_F3>(OpF3::info("phone.f3", a), a, OpF3::grid(a), Plan::F3, keep(6), 18); }
-  { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], pl.up1()); tb->add<T_UP1>(OpUP1::info("wave.up1", a), a, OpUP1::grid(a), pl.up1(), keep(7), 36); }
-  { const ConvArgs a = conv(ws.yb1, ws.yc1, ww.rb_w[0], ww.rb_b[0], pl.up1() + 2); tb->add<T_RES1B>(OpRES1B::info("wave.res1b", a), a, OpRES1B::grid(a), pl.up1() + 2, keep(7), 10); }
-  { const ConvArgs a = conv(ws.ya1, ws.yb1, ww.ra_w[0], ww.ra_b[0], pl.up1() + 1); tb->add<T_RES1A>(OpRES1A::info("wave.res1a", a), a, OpRES1A::grid(a), pl.up1() + 1, keep(7), 10); }
-  { const ConvArgs a = conv(ws.yc1, ws.ya2, ww.up_w[1], ww.up_b[1], pl.up1() + 3); tb->add<T_UP2>(OpUP2::info("wave.up2", a), a, OpUP2::grid(a), pl.up1() + 3, keep(7), 12); }
-  { const ConvArgs a = conv(ps.f[0], ps.f[1], pw.f_w[0], pw.f_b[0], Plan::F2); tb->add<T_F2>(OpF2::info("phone.f2", a), a, OpF2::grid(a), Plan::F2, keep(6), 10); }
-  { const GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(Plan::PGRU), B, 0}; tb->add<T_PGRU>(GruOp<256, 256, TICK_GRU_RT>::info("phone.gru", g), g, GruOp<256, 256, TICK_GRU_RT>::grid(g), Plan::PGRU, keep(1), 7.6); }
-  { const ConvArgs a = conv(qs.h, qs.logits, qw.out_w, qw.out_b, Plan::POUT); tb->add<T_POUT>(OpPOUT::info("pitch.out", a), a, OpPOUT::grid(a), Plan::POUT, keep(2), 9.4); }
-  for (int i = 0; i < 2; ++i) {
-    const ConvArgs a = conv(qs.p[i], qs.p[i + 1], qw.p_w[i + 1], qw.p_b[i + 1], Plan::P2 + i);
-    tb->add<T_P23>(OpP23::info("pitch.p23", a), a, OpP23::grid(a), Plan::P2 + i, keep(2), 8);
-  }
-  { const Ring phone_in{ws.d_phone, B_PHONE_CH, 1, ws.front_slots}; ConvArgs a = conv(phone_in, ws.x[0], ww.inp_w, ww.inp_b, Plan::INP); a.res = ws.e; tb->add<T_INP>(OpINP::info("wave.inp", a), a, OpINP::grid(a), Plan::INP, keep(3), 7.7); }
-  { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, 0}; tb->add<T_QGRU>(GruOp<128, 128, TICK_GRU_RT>::info("pitch.gru", g), g, GruOp<128, 128, TICK_GRU_RT>::grid(g), Plan::QGRU, keep(1), 4.6); }
-  { FftArgs a = fft_args(qw, qs); a.hop = hp(Plan::FFT); tb->add<T_FFT>(fft_info(qs), FftArgs2{a, B}, dim3((B + 1) / 2, 1), Plan::FFT, keep(0), 6); }
-  { const ConvArgs a = conv(ps.h, phone_out_ring(ps), pw.out_w, pw.out_b, Plan::OUT); tb->add<T_OUT>(OpOUT::info("phone.out", a), a, OpOUT::grid(a), Plan::OUT, keep(3), 6); }
-  { const VqArgs a{1, ps.raw, phone_vector_ring(ps), hp(Plan::VQ), ps.d_cbT, ps.d_cnorm, ps.d_vqk}; tb->add<T_VQ>(LaunchInfo{"phone.vq", 0, 4.0 * B * 256}, a, dim3(B, 1), Plan::VQ, !ps.skip_vq, 6.0, true); }
-  { PitchHeadArgs a = head_args(qw, qs); a.hop = hp(Plan::HEAD); tb->add<T_HEAD>(head_info(qs), a, dim3((B + 7) / 8, 1), Plan::HEAD, keep(0), 4.7); }
-  { F1Args a = f1_args(pw, ps); a.hop = hp(Plan::F1); a.hop_publish = nullptr; a.hop_publish_wave = nullptr; tb->add<T_F1>(f1_info(ps), F1Args2{a, B}, dim3((B + 1) / 2, 1), Plan::F1, keep(0), 4.5); }
-  { CondArgs a = cond_args(ww, ws); a.hop = hp(Plan::COND); a.hop_next_out = nullptr; tb->add<T_COND>(cond_info(ws), a, dim3((B + 1) / 2, 1), Plan::COND, keep(0), 1.3); }
-  if (!tb->ok) return false;
-  // XCD-aware placement (bodies with many weights pinned to one XCD each, so that the weights stay in that L2) was
-  // measured twice: it cuts the launch's memory-side traffic 4x (rocprofv3 FETCH_SIZE 105 -> 26 MB per tick) and the
-  // pinned workgroups run ~10-25 % shorter, but confining a body to 32 CUs costs more in makespan than that gains
-  // (0.096 vs 0.090 ms per tick): off by default
-  static const bool by_xcd = std::getenv("BEATRICE_HIP_TICK_XCD") != nullptr;
-  if (by_xcd) tb->place_by_xcd();
-  if (std::getenv("BEATRICE_HIP_TICK_TRACE")) {
-    if (k.d_trace) (void)hipFree(k.d_trace);
-    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&k.d_trace), sizeof(unsigned long long) * 3 * tb->t.total));
-    tb->t.trace = k.d_trace;
-  }
-  BHIP_TRY(hipMemcpy(k.d_table, &tb->t, sizeof(Tab), hipMemcpyHostToDevice));
-  k.table_total = tb->t.total;
-  k.table_flops = tb->flops;
-  k.table_bytes = tb->bytes;
-  // who reads which part of the settings block, and where its private copy lives
-  k.consumers.clear();
-  unsigned char* d = b->settings.d;
-  k.consumers.push_back(Consumer{Plan::VQ, b->off.cbT, b->off.min_q - b->off.cbT, d + b->off.cbT, -1});
-  k.consumers.push_back(Consumer{Plan::HEAD, b->off.min_q, b->off.add_idx - b->off.min_q, d + b->off.min_q, -1});
-  k.consumers.push_back(Consumer{Plan::COND, b->off.add_idx, b->off.front_bytes - b->off.add_idx, d + b->off.add_idx, -1});
-  for (int blk = 0; blk < B_NBLOCKS; ++blk) {
-    const size_t lo = b->off.perm[blk], hi = blk + 1 < B_NBLOCKS ? b->off.perm[blk + 1] : b->off.front_bytes + b->off.wave_bytes;
-    k.consumers.push_back(Consumer{pl.blk(blk) + 1, lo, hi - lo, d + lo, -1});
-  }
-  k.table_dirty = false;
-  return true;
-}
-
-// One tick: every stage advances by one step; `feeding` = a new step enters at stage 0.
-// BEATRICE_HIP_TICK_HOSTPROF=1: host time of tick_run by section, printed when the process ends (measurement aid)
-struct HostProf {
-  static constexpr int N = 5;
-  static bool on() { static const bool v = std::getenv("BEATRICE_HIP_TICK_HOSTPROF") != nullptr; return v; }
-  struct Totals { double us[N] = {}; long long calls = 0; ~Totals() { if (calls) std::fprintf(stderr, "tick_run host us per call: settings/kv %.1f, table %.1f, snapshot upload %.1f, copies %.1f, launch %.1f (%lld calls)\n", us[0] / calls, us[1] / calls, us[2] / calls, us[3] / calls, us[4] / calls, calls); } };
-  static Totals& totals() { static Totals t; return t; }
-  std::chrono::steady_clock::time_point t0;
-  HostProf() { if (on()) { t0 = std::chrono::steady_clock::now(); totals().calls += 1; } }
-  void lap(int i) {
-    if (!on()) return;
-    const auto t1 = std::chrono::steady_clock::now();
-    totals().us[i] += std::chrono::duration<double, std::micro>(t1 - t0).count();
-    t0 = t1;
-  }
-};
-bool tick_run(BeatriceBatch* b, bool feeding) {
-  using namespace tick;
-  State& k = b->tk;
-  HostProf prof;
-  if (feeding) {
-    advance_kv(b);
-    draw_codebooks(b);
-    if (b->vq_dirty) { update_vq_mode(b); b->vq_dirty = false; }   // (drains the pipeline if the k-NN stage comes or goes)
-  }
-  prof.lap(0);
-  if (k.table_dirty && !tick_build_table(b)) return false;
-  prof.lap(1);
-  hipStream_t st = b->stream;
-  Copy upload{nullptr, nullptr, 0};
-  int upload_stage = -1;
-  if (feeding) {
-    bool dirty = b->front_dirty || k.snap_cur < 0;
-    for (bool w : b->wave_dirty) dirty = dirty || w;
-    if (dirty) {  // a new version of the settings: one upload into the next slot of the snapshot ring
-      const int serial = k.snap_next++;
-      const size_t off = 0, len = k.snap_bytes;
-      unsigned char* dst = k.d_snap + (size_t)(serial % kRing) * k.snap_bytes;
-      // through a ring of pinned staging copies, so that the host may run several settings changes ahead of the device
-      // (the batch's two-deep mirror would make every second change wait for the copy of the change before it); the
-      // tick's prologue kernel reads the staging copy straight from host memory (tick.hip.h)
-      const int si = serial % State::kStaging;
-      if (k.stage_pending[si]) { if (!hip_ok(hipEventSynchronize(k.stage_ev[si]), "tick settings staging")) return false; }
-      unsigned char* src = k.h_stage + (size_t)si * k.snap_bytes;
-      std::memcpy(src, b->settings.h + off, len);
-      upload = Copy{dst, src, (int)len};
-      upload_stage = si;
-      k.snap_cur = serial;
-      b->front_dirty = false;
-      for (bool& w : b->wave_dirty) w = false;
-    }
-    const long long u = k.n_fed;
-    k.fed_step[k.tick % kRing] = u;
-    k.snap_of_step[u % kRing] = k.snap_cur;
-    k.hop_of_step[u % kRing] = b->hop_host;
-    k.io_of_step[u % kRing] = b->io_host;
-  } else {
-    k.fed_step[k.tick % kRing] = -1;
-  }
-  prof.lap(2);
-  Prolog p{};
-  p.n_stages = k.plan.count();
-  auto step_at = [&k](int stage) -> long long {
-    const long long t2 = k.tick - stage;
-    return t2 >= 0 ? k.fed_step[t2 % kRing] : -1;
-  };
-  for (int s = 0; s < p.n_stages; ++s) {
-    const long long u = step_at(s);
-    p.hop[s] = u < 0 ? -1 : k.hop_of_step[u % kRing];
-    p.io[s] = u < 0 ? 0 : k.io_of_step[u % kRing];
-  }
-  for (Consumer& c : k.consumers) {
-    const long long u = step_at(c.stage);
-    if (u < 0) continue;
-    const int want = k.snap_of_step[u % kRing];
-    if (want == c.held) continue;
-    p.copy[p.n_copies++] = Copy{c.dst, k.d_snap + (size_t)(want % kRing) * k.snap_bytes + c.off, (int)c.bytes};
-    c.held = want;
-  }
-  if (upload.bytes > 0) {  // first, so that entry order = age; (a consumer never needs the snapshot uploaded in its own tick: none sits at stage 0)
-    for (int i = p.n_copies; i > 0; --i) p.copy[i] = p.copy[i - 1];
-    p.copy[0] = upload;
-    p.n_copies += 1;
-  }
-  if (p.n_copies > 0) {  // (only on ticks where the settings changed or a change arrives at a consumer)
-    int chunks = 0;
-    for (int i = 0; i < p.n_copies; ++i) { p.first_chunk[i] = chunks; chunks += (p.copy[i].bytes + kCopyChunk - 1) / kCopyChunk; }
-    p.first_chunk[p.n_copies] = chunks;
-    hipLaunchKernelGGL(prologue_kernel, dim3(chunks), dim3(256), 0, st, p);
-    if (upload_stage >= 0) {
-      if (!hip_ok(hipEventRecord(k.stage_ev[upload_stage], st), "tick settings event")) return false;
-      k.stage_pending[upload_stage] = true;
-    }
-  }
-  if (b->r48.on && (feeding || b->r48.deferred_slot >= 0)) {
-    // one launch for both ends of the 48 kHz wrapper: the block entering the pipeline -> its 16 kHz hop, straight into the
-    // resident slot; and the step the PREVIOUS tick completed leaves through the up-sampler and the 480-sample FIFO
-    // (resample.h:346-361: the block emitted for step j carries the model output of step j - 1) into the 48 kHz slot of step j
-    BeatriceBatch::Resident48& r = b->r48;
-    Wrap48TickArgs wa{};
-    wa.channels = r.channels; wa.st = b->d_w48; wa.coef_down = b->d_coef_down; wa.coef_up = b->d_coef_up;
-    if (feeding) {
-      wa.n_pre = b->B;
-      wa.in48 = r.d_in48 + (size_t)b->io_host * b->B * r.channels * 480;
-      wa.in16 = r.d_in16 + (size_t)b->io_host * b->B * B_IN_HOP;
-    }
-    if (r.deferred_slot >= 0) {
-      wa.n_post = b->B;
-      wa.out48 = r.d_out48 + (size_t)r.deferred_slot * b->B * r.channels * 480;
-      wa.model_out = r.d_out24 + (size_t)r.deferred_slot * b->B * B_OUT_HOP;
-      r.deferred_slot = -1;
-    }
-    hipLaunchKernelGGL(wrap48_tick_kernel, dim3(wa.n_pre + wa.n_post), dim3(256), 0, st, wa);
-  }
-  prof.lap(3);
-  fuse::StepPairs pairs;
-  for (int s = 0; s < fuse::kMaxStepPairs; ++s) { pairs.hop[s] = s < p.n_stages ? p.hop[s] : -1; pairs.io[s] = s < p.n_stages ? p.io[s] : 0; }
-  fuse::launch_table_w<4>(k.d_table, k.table_total, st, pairs);
-  if (b->r48.on) {  // the step this tick completed: its 48 kHz block is produced by the wrapper launch of the next tick (or of the drain)
-    const long long u = step_at(k.plan.count() - 1);
-    if (u >= 0) b->r48.deferred_slot = k.io_of_step[u % kRing];
-  }
-  if (feeding) {
-    b->last_parity = b->hop_host % 3;
-    b->last_hop = b->hop_host;
-    b->hop_host = hop_next(b->hop_host);
-    b->io_host = (b->io_host + 1) % b->io_slots;
-    b->steps_enqueued += 1;
-    k.n_fed += 1;
-    k.last_feed_tick = k.tick;
-  }
-  prof.lap(4);
-  k.tick += 1;
-  b->inflight = true;
-  return hip_ok(hipGetLastError(), "tick launch");
-}
-// ticks without new input until the last step fed has left the last stage
-// output half of one call of the any-rate wrapper around the ticks (BeatriceBatch_BindResidentBlocks): its block's inner
-// samples gathered from the resident model outputs, second resampling direction, output gain, into the call's slot
-bool rb_post(BeatriceBatch* b, const BeatriceBatch::ResidentBlocks::Job& j) {
-  BeatriceBatch::ResidentBlocks& r = b->rb;
-  const size_t nt = b->wrap.taps_down.size();
-  const int slot = (int)(j.call % r.n_slots), ge = (int)(j.call % r.ring);
-  hipLaunchKernelGGL(wrapn::wrap_post_kernel, dim3(b->B), dim3(256), 0, b->stream, r.d_out24, r.io_slots, b->B, j.t0, b->d_wrap,
-                     r.d_gains + (size_t)ge * 2 * b->B + b->B, b->d_wrap_taps + (j.dout.decimate ? 0 : nt), j.dout,
-                     r.d_out + (size_t)slot * b->B * r.channels * r.n, r.channels);
-  return hip_ok(hipGetLastError(), "wrapper output half");
-}
-bool tick_drain(BeatriceBatch* b) {
-  bool ok = true;
-  if (b->tk.on && b->tk.d_trace && b->tk.last_feed_tick == b->tk.tick - 1 && b->tk.n_fed > b->tk.plan.count()) {
-    // measurement aid: the tick just enqueued had every stage busy; dump its per-workgroup timeline (100 MHz wall clock)
-    std::vector<unsigned long long> tr((size_t)3 * b->tk.table_total);
-    if (hip_ok(hipStreamSynchronize(b->stream), "trace sync") &&
-        hip_ok(hipMemcpy(tr.data(), b->tk.d_trace, tr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost), "trace copy"))
-      if (FILE* f = std::fopen(std::getenv("BEATRICE_HIP_TICK_TRACE"), "w")) {
-        for (size_t i = 0; i < tr.size(); i += 3) std::fprintf(f, "%llu %llu %llu\n", tr[i], tr[i + 1], tr[i + 2]);
-        std::fclose(f);
-      }
-  }
-  while (ok && b->tk.on && b->tk.tick <= b->tk.last_feed_tick + b->tk.plan.count() - 1) ok = tick_run(b, false);
-  if (ok && b->r48.on && b->r48.deferred_slot >= 0) {  // the 48 kHz block of the step the last tick completed
-    BeatriceBatch::Resident48& r = b->r48;
-    Wrap48TickArgs wa{};
-    wa.channels = r.channels; wa.st = b->d_w48; wa.coef_down = b->d_coef_down; wa.coef_up = b->d_coef_up;
-    wa.n_post = b->B;
-    wa.out48 = r.d_out48 + (size_t)r.deferred_slot * b->B * r.channels * 480;
-    wa.model_out = r.d_out24 + (size_t)r.deferred_slot * b->B * B_OUT_HOP;
-    r.deferred_slot = -1;
-    hipLaunchKernelGGL(wrap48_tick_kernel, dim3(wa.n_post), dim3(256), 0, b->stream, wa);
-    ok = hip_ok(hipGetLastError(), "wrap48 flush");
-  }
-  while (ok && b->rb.on && !b->rb.jobs.empty()) {  // every model hop has left the pipeline: the output halves still owed, in order
-    ok = rb_post(b, b->rb.jobs.front());
-    b->rb.jobs.pop_front();
-  }
-  return ok;
-}
-int tick_enable(BeatriceBatch* b, bool on) {
-  using namespace tick;
-  State& k = b->tk;
-  if (on == k.on) return 0;
-  if (on) {
-    // one 10 ms hop per step, resident I/O with enough slots
-    // that a step's input is still there when the pitch head reads it nine ticks on and outputs have somewhere to land
-    if (b->H != 1 || b->B > 4096 || b->io_slots < k.plan.count() + 1) return -1;
-    if (!sync_all(b)) return -2;
-    if (b->pipelined) { drop_graph(b); set_plan(b, 1); }
-    k.snap_bytes = b->off.front_bytes + b->off.wave_bytes;
-    if (!k.d_table) {
-      if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_table), sizeof(Tab)), "tick table") ||
-          !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_snap), k.snap_bytes * kRing), "tick snapshots") ||
-          !hip_ok(hipHostMalloc(reinterpret_cast<void**>(&k.h_stage), k.snap_bytes * State::kStaging, hipHostMallocDefault), "tick staging"))
-        return -2;
-      for (hipEvent_t& e : k.stage_ev) if (!hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "tick staging event")) return -2;
-    }
-    if (!hip_ok(hipDeviceSynchronize(), "tick sync")) return -2;
-    k.tick = 0; k.n_fed = 0; k.last_feed_tick = -1000; k.snap_cur = -1; k.snap_next = 0;
-    for (long long& f : k.fed_step) f = -1;
-    k.table_dirty = true;
-    k.on = true;
-    for (int blk = 0; blk < B_NBLOCKS; ++blk) rebuild_tiles(b, blk);  // (tick mode cuts the attention rows into tiles AND quads)
-    return 0;
-  }
-  if (!sync_all(b)) return -2;  // drains
-  k.on = false;
-  for (int blk = 0; blk < B_NBLOCKS; ++blk) rebuild_tiles(b, blk);
-  // the in-order chain reads its counters from device memory: hand them the host's values
-  const int pair[2] = {b->hop_host, b->io_host};
-  if (!hip_ok(hipMemcpy(b->d_hop_next, pair, sizeof(pair), hipMemcpyHostToDevice), "tick leave")) return -2;
-  b->front_dirty = true;
-  for (bool& w : b->wave_dirty) w = true;
-  return 0;
-}
+#include "batch_tick.hip.h"      // tick mode: table, per-tick host work, drain, enable
 
 template <class F>
 int for_streams(BeatriceBatch* b, int stream, F f) {
@@ -1526,319 +1189,7 @@ int BeatriceBatch_ConvertFrames(BeatriceBatch* b, const float* in, float* out) {
   else std::memset(out, 0, sizeof(float) * n_out);
   return ok ? 0 : -2;
 }
-// ---- 48 kHz blocks with the wrapper on the device ----------------------------------------------
-static bool step_48k(BeatriceBatch* b, const float* d_in48, float* d_out48, int channels) {
-  // the FIFO of the reference emits the PREVIOUS block's model output first (resample.h:346-361)
-  hipLaunchKernelGGL(wrap48_post_kernel, dim3(b->B), dim3(256), 0, b->stream, b->d_w48, b->d_coef_up, d_out48, channels);
-  hipLaunchKernelGGL(wrap48_pre_kernel, dim3(b->B), dim3(256), 0, b->stream, d_in48, channels, b->d_w48, b->d_coef_down, b->d_in);
-  if (!step_device(b, nullptr, nullptr)) return false;
-  hipLaunchKernelGGL(wrap48_latch_kernel, dim3((b->B * 240 + 255) / 256), dim3(256), 0, b->stream, b->d_w48, b->wave.d_out, b->B);
-  return hip_ok(hipGetLastError(), "wrap48");
-}
-// Throughput form of the 48 kHz wrapper: n_slots resident 48 kHz blocks per direction, the tick pipeline between them.
-// Block k (BeatriceBatch_ConvertBlocks48kDevice(b, NULL, NULL, channels)) is read from slot k mod n_slots; its converted
-// block lands in the same slot of d_out48 BeatriceBatch_TickStages() - 1 calls later (or after BeatriceBatch_Synchronize).
-// Same samples as the in-order BeatriceBatch_ConvertBlocks48kDevice.  NULL pointers unbind.
-int BeatriceBatch_BindResidentIO48k(BeatriceBatch* b, const float* d_in48, float* d_out48, int channels, int n_slots) {
-  const DeviceScope dev_(b ? b->device : -1);
-  if (!b || !b->ok) return -2;
-  BeatriceBatch::Resident48& r = b->r48;
-  if (r.on) {
-    if (!sync_all(b)) return -2;
-    const int rc = tick_enable(b, false);
-    if (rc) return rc;
-    (void)BeatriceBatch_BindResidentIO(b, nullptr, nullptr, 0);
-    if (r.d_in16) (void)hipFree(r.d_in16);
-    if (r.d_out24) (void)hipFree(r.d_out24);
-    r = BeatriceBatch::Resident48{};
-  }
-  if (!d_in48 && !d_out48) return 0;
-  if (!d_in48 || !d_out48 || channels < 1 || channels > 2 || n_slots < b->tk.plan.count() + 1 || b->H != 1 || b->io_slots > 0 || b->pipelined ||
-      b->tk.on || b->hs.on)
-    return -1;
-  bool ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_in16), sizeof(float) * n_slots * b->B * B_IN_HOP), "r48 in16") &&
-            hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_out24), sizeof(float) * n_slots * b->B * B_OUT_HOP), "r48 out24") &&
-            hip_ok(hipMemset(r.d_in16, 0, sizeof(float) * n_slots * b->B * B_IN_HOP), "r48 zero");
-  ok = ok && BeatriceBatch_BindResidentIO(b, r.d_in16, r.d_out24, n_slots) == 0 && tick_enable(b, true) == 0;
-  if (!ok) {
-    (void)tick_enable(b, false);
-    (void)BeatriceBatch_BindResidentIO(b, nullptr, nullptr, 0);
-    if (r.d_in16) (void)hipFree(r.d_in16);
-    if (r.d_out24) (void)hipFree(r.d_out24);
-    r = BeatriceBatch::Resident48{};
-    return -2;
-  }
-  r.d_in48 = d_in48; r.d_out48 = d_out48; r.channels = channels; r.n_slots = n_slots; r.on = true;
-  return 0;
-}
-int BeatriceBatch_ConvertBlocks48kDevice(BeatriceBatch* b, const float* d_in, float* d_out, int channels) {
-  const DeviceScope dev_(b ? b->device : -1);
-  if (!b || !b->ok) return -2;
-  if (b->r48.on) return (!d_in && !d_out && channels == b->r48.channels) ? (tick_run(b, true) ? 0 : -2) : -1;
-  if (channels < 1 || channels > 2 || !d_in || !d_out || b->H != 1 || b->io_slots > 0 || b->pipelined || b->tk.on) return -1;  // per 10 ms block, in order
-  return step_48k(b, d_in, d_out, channels) ? 0 : -2;
-}
-int BeatriceBatch_ConvertBlocks48k(BeatriceBatch* b, const float* in, float* out, int channels) {
-  const DeviceScope dev_(b ? b->device : -1);
-  if (!b || !b->ok) return -2;
-  if (channels < 1 || channels > 2 || !in || !out || b->H != 1 || b->io_slots > 0 || b->pipelined || b->tk.on) return -1;
-  const size_t n = (size_t)b->B * channels * 480;
-  float* h_in = b->h_io48;
-  float* h_out = b->h_io48 + (size_t)b->B * 2 * 480;
-  float* d_in = b->d_io48;
-  float* d_out = b->d_io48 + (size_t)b->B * 2 * 480;
-  std::memcpy(h_in, in, sizeof(float) * n);
-  bool ok = hip_ok(hipMemcpyAsync(d_in, h_in, sizeof(float) * n, hipMemcpyHostToDevice, b->stream), "in48");
-  ok = ok && step_48k(b, d_in, d_out, channels);
-  ok = ok && hip_ok(hipMemcpyAsync(h_out, d_out, sizeof(float) * n, hipMemcpyDeviceToHost, b->stream), "out48");
-  ok = hip_ok(hipStreamSynchronize(b->stream), "sync") && ok;
-  b->inflight = false;
-  if (ok) std::memcpy(out, h_out, sizeof(float) * n);
-  else std::memset(out, 0, sizeof(float) * n);
-  return ok ? 0 : -2;
-}
-
-// ---- host-rate blocks with the whole wrapper on the device (wrapper.hip.h) -------------------------------------------
-namespace { constexpr int kInnerStride = wrapn::kMaxSamples + 64; }
-int BeatriceBatch_ConfigureWrapper(BeatriceBatch* b, double sample_rate) {
-  const DeviceScope dev_(b ? b->device : -1);
-  if (!b || !b->ok) return -2;
-  if (b->H != 1) return -1;
-  if (!sync_all(b)) return -2;
-  if (!b->wrap.configure(sample_rate)) return -1;  // rate <= 0, or a ratio whose filter history exceeds the state block
-  const int B = b->B;
-  const size_t nt = b->wrap.taps_down.size();
-  bool ok = true;
-  if (!b->d_wrap) {
-    ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_wrap), sizeof(wrapn::StreamState) * B), "wrap state") &&
-         hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_wrap_inner), sizeof(float) * B * kInnerStride), "wrap inner") &&
-         hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_wrap_io), sizeof(float) * B * 4 * wrapn::kMaxSamples), "wrap io") &&
-         hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_wrap_io), sizeof(float) * B * 4 * wrapn::kMaxSamples, hipHostMallocDefault), "wrap io host") &&
-         b->wrap_gains.alloc_host(2 * (size_t)B) &&
-         hip_ok(hipMalloc(reinterpret_cast<void**>(&b->wrap_gains.d), sizeof(wrapn::GainSeg) * 2 * B), "wrap gains");
-    b->gain_in.assign(B, wrapn::GainClock());
-    b->gain_out.assign(B, wrapn::GainClock());
-  }
-  if (b->d_wrap_taps) { (void)hipFree(b->d_wrap_taps); b->d_wrap_taps = nullptr; }
-  ok = ok && hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_wrap_taps), sizeof(float) * 2 * nt), "wrap taps") &&
-       hip_ok(hipMemcpy(b->d_wrap_taps, b->wrap.taps_down.data(), sizeof(float) * nt, hipMemcpyHostToDevice), "taps down") &&
-       hip_ok(hipMemcpy(b->d_wrap_taps + nt, b->wrap.taps_up.data(), sizeof(float) * nt, hipMemcpyHostToDevice), "taps up") &&
-       hip_ok(hipMemset(b->d_wrap, 0, sizeof(wrapn::StreamState) * B), "wrap state0") && hip_ok(hipDeviceSynchronize(), "wrap sync");
-  b->wrap_gains_constant = false;
-  // (a new rate restarts the resampler and the FIFO as the reference's SetSampleRate does; the gains keep their state,
-  //  now ramping at the new rate: reference processor_core_2.cc:421-429)
-  return ok ? 0 : -2;
-}
-// reference ProcessorCore2::SetInputGain / SetOutputGain (processor_core_2.cc:488-496): the target; the ramp follows at 2 dB/ms
-int BeatriceBatch_SetInputGain(BeatriceBatch* b, int stream, double db) {
-  const DeviceScope dev_(b ? b->device : -1);
-  if (!b || !b->ok) return -2;
-  if (stream < -1 || stream >= b->B || b->gain_in.empty()) return -1;
-  for (int s = (stream < 0 ? 0 : stream); s < (stream < 0 ? b->B : stream + 1); ++s) b->gain_in[s].target_db = db;
-  return 0;
-}
-int BeatriceBatch_SetOutputGain(BeatriceBatch* b, int stream, double db) {
-  const DeviceScope dev_(b ? b->device : -1);
-  if (!b || !b->ok) return -2;
-  if (stream < -1 || stream >= b->B || b->gain_out.empty()) return -1;
-  for (int s = (stream < 0 ? 0 : stream); s < (stream < 0 ? b->B : stream + 1); ++s) b->gain_out[s].target_db = db;
-  return 0;
-}
-static bool wrap_chunk(BeatriceBatch* b, const float* d_in, float* d_out, int channels, int n) {
-  using namespace wrapn;
-  const int B = b->B;
-  hipStream_t st = b->stream;
-  WrapPlan& w = b->wrap;
-  // gains: this call's segment per stream; the device copy is refreshed unless it already holds the same constants
-  bool all_constant = true;
-  GainSeg* seg = b->wrap_gains.h;
-  for (int s = 0; s < B; ++s) {
-    const GainSeg gi = b->gain_in[s].advance(n, w.rate), go = b->gain_out[s].advance(n, w.rate);
-    all_constant = all_constant && gi.step == 1.0 && go.step == 1.0 && seg[s].step == 1.0 && seg[B + s].step == 1.0 &&
-                   seg[s].amp0 == gi.amp0 && seg[B + s].amp0 == go.amp0;
-    seg[s] = gi;
-    seg[B + s] = go;
-  }
-  if (!(all_constant && b->wrap_gains_constant)) {
-    const size_t off = 0, len = 2 * (size_t)B;
-    GainSeg* dst = nullptr;
-    if (!b->wrap_gains.push_parts(st, 1, &off, &len, &dst)) return false;
-    b->wrap_gains_constant = all_constant;
-  }
-  const size_t nt = w.taps_down.size();
-  const Dir din = w.to_inner(n);
-  const int m = din.n_out;
-  if (m < 0 || m > kMaxSamples) return false;
-  hipLaunchKernelGGL(wrap_in_kernel, dim3(B), dim3(256), 0, st, d_in, channels, n, b->d_wrap, b->wrap_gains.d, b->d_wrap_taps + (din.decimate ? 0 : nt), din,
-                     b->d_wrap_inner, kInnerStride);
-  for (int at = 0; at < m;) {  // the exact-480 FIFO; a model hop every time it fills
-    const int take = std::min(kBlock - w.fill, m - at);
-    const int fires = w.fill + take == kBlock ? 1 : 0;
-    hipLaunchKernelGGL(wrap_fifo_kernel, dim3(B), dim3(256), 0, st, b->d_wrap_inner, kInnerStride, b->d_wrap, at, w.fill, take, fires, b->d_in);
-    if (fires) {
-      if (!step_device(b, nullptr, nullptr)) return false;
-      hipLaunchKernelGGL(wrap_refill_kernel, dim3((B * kBlock + 255) / 256), dim3(256), 0, st, b->d_wrap, b->wave.d_out, B);
-      w.fill = 0;
-    } else {
-      w.fill += take;
-    }
-    at += take;
-  }
-  const Dir dout = w.to_outer(m);
-  if (dout.n_out != n) return false;  // the two clocks are coupled so that a block comes back with its own length
-  hipLaunchKernelGGL(wrap_out_kernel, dim3(B), dim3(256), 0, st, b->d_wrap_inner, kInnerStride, b->d_wrap, b->wrap_gains.d + B,
-                     b->d_wrap_taps + (dout.decimate ? 0 : nt), dout, d_out, channels);
-  return hip_ok(hipGetLastError(), "wrapper launch");
-}
-static int wrap_max_chunk(const BeatriceBatch* b) {  // host samples per launch so that neither side exceeds the kernels' LDS buffers
-  const double r = b->wrap.rate / 48000.0;
-  return std::max(1, (int)std::floor((wrapn::kMaxSamples - 8) * std::min(1.0, r)));
-}
-// in / out: [B][channels][n] planar at the configured host rate; any n >= 1 (long blocks are processed in pieces)
-int BeatriceBatch_ProcessBlocksDevice(BeatriceBatch* b, const float* d_in, float* d_out, int channels, int n) {
-  const DeviceScope dev_(b ? b->device : -1);
-  if (!b || !b->ok) return -2;
-  if (b->rb.on) return (!d_in && !d_out && channels == b->rb.channels && n == b->rb.n) ? (rb_step(b) ? 0 : -2) : -1;
-  if (!b->wrap.ready || channels < 1 || channels > 2 || !d_in || !d_out || n < 1 || b->H != 1 || b->io_slots > 0 || b->pipelined || b->tk.on) return -1;
-  const int piece = wrap_max_chunk(b);
-  if (n <= piece) return wrap_chunk(b, d_in, d_out, channels, n) ? 0 : -2;
-  return -1;  // the planar layout [B][channels][n] cannot be cut without copies: callers pass blocks of at most `piece` samples
-}
-int BeatriceBatch_MaxWrapperBlock(const BeatriceBatch* b) { return b && b->ok && b->wrap.ready ? wrap_max_chunk(b) : 0; }
-
-// ---- the same wrapper around the TICK pipeline (throughput form, resident blocks) ------------------------------------------------
-// One call = one host-rate block per stream from slot `call mod n_slots` of d_in: gains and the first resampling direction, the
-// 480-sample accumulation, a model hop into the tick pipeline every time it fills (one tick per hop, at least one tick per
-// call so that a hop is out of the pipeline TickStages() - 1 calls after it went in); then the output half of the call made
-// `delay` = TickStages() - 1 calls ago, into ITS slot of d_out.  Everything that is control is on the host, as in wrap_chunk.
-static void rb_release(BeatriceBatch* b) {
-  BeatriceBatch::ResidentBlocks& r = b->rb;
-  if (r.d_in16) (void)hipFree(r.d_in16);
-  if (r.d_out24) (void)hipFree(r.d_out24);
-  if (r.d_gains) (void)hipFree(r.d_gains);
-  if (r.h_gains) (void)hipHostFree(r.h_gains);
-  if (r.gain_ev) { for (int i = 0; i < r.ring; ++i) if (r.gain_ev[i]) (void)hipEventDestroy(r.gain_ev[i]); delete[] r.gain_ev; }
-  r = BeatriceBatch::ResidentBlocks{};
-}
-static bool rb_step(BeatriceBatch* b) {
-  using namespace wrapn;
-  BeatriceBatch::ResidentBlocks& r = b->rb;
-  const int B = b->B, n = r.n;
-  hipStream_t st = b->stream;
-  WrapPlan& w = b->wrap;
-  const long long call = r.calls;
-  const int ge = (int)(call % r.ring);
-  // this call's gain segments: input half now, output half when its job runs
-  if (call >= r.ring && !hip_ok(hipEventSynchronize(r.gain_ev[ge]), "wrapper gain ring")) return false;
-  GainSeg* seg = r.h_gains + (size_t)ge * 2 * B;
-  for (int s = 0; s < B; ++s) { seg[s] = b->gain_in[s].advance(n, w.rate); seg[B + s] = b->gain_out[s].advance(n, w.rate); }
-  GainSeg* dseg = r.d_gains + (size_t)ge * 2 * B;
-  BHIP_TRY(hipMemcpyAsync(dseg, seg, sizeof(GainSeg) * 2 * B, hipMemcpyHostToDevice, st));
-  BHIP_TRY(hipEventRecord(r.gain_ev[ge], st));
-  const size_t nt = w.taps_down.size();
-  const Dir din = w.to_inner(n);
-  const int m = din.n_out;
-  if (m < 0 || m > kMaxSamples) return false;
-  const Dir dout = w.to_outer(m);
-  if (dout.n_out != n) return false;
-  const float* src = r.d_in + (size_t)(call % r.n_slots) * B * r.channels * n;
-  hipLaunchKernelGGL(wrap_in_kernel, dim3(B), dim3(256), 0, st, src, r.channels, n, b->d_wrap, dseg, b->d_wrap_taps + (din.decimate ? 0 : nt), din,
-                     b->d_wrap_inner, kInnerStride);
-  int ticks = 0;
-  for (int at = 0; at < m;) {  // the 480-sample accumulation; a model hop every time it fills (the per-stream FIFO array holds it)
-    const int take = std::min(kBlock - w.fill, m - at);
-    const int fires = w.fill + take == kBlock ? 1 : 0;
-    hipLaunchKernelGGL(wrap_fifo_kernel, dim3(B), dim3(256), 0, st, b->d_wrap_inner, kInnerStride, b->d_wrap, at, w.fill, take, fires,
-                       r.d_in16 + (size_t)b->io_host * B * B_IN_HOP);
-    if (fires) {
-      if (!tick_run(b, true)) return false;
-      ++ticks;
-      w.fill = 0;
-    } else {
-      w.fill += take;
-    }
-    at += take;
-  }
-  if (ticks == 0 && !tick_run(b, false)) return false;   // the pipeline advances with every call
-  r.jobs.push_back(BeatriceBatch::ResidentBlocks::Job{call, r.t48, dout});
-  r.t48 += m;
-  r.calls = call + 1;
-  bool ok = true;
-  while (ok && !r.jobs.empty() && r.jobs.front().call + r.delay <= call) {
-    ok = rb_post(b, r.jobs.front());
-    r.jobs.pop_front();
-  }
-  b->inflight = true;
-  return ok;
-}
-// d_in / d_out: [n_slots][B][channels][n] planar blocks at the configured host rate (BeatriceBatch_ConfigureWrapper first).
-// Call k (BeatriceBatch_ProcessBlocksDevice(b, NULL, NULL, channels, n)) reads slot k mod n_slots; its output block is in the
-// same slot of d_out BeatriceBatch_ResidentBlocksDelay() calls later (or after BeatriceBatch_Synchronize).  Same samples as
-// the in-order BeatriceBatch_ProcessBlocksDevice.  n_slots > delay + 1.  NULL pointers unbind.
-int BeatriceBatch_BindResidentBlocks(BeatriceBatch* b, const float* d_in, float* d_out, int channels, int n, int n_slots) {
-  const DeviceScope dev_(b ? b->device : -1);
-  if (!b || !b->ok) return -2;
-  BeatriceBatch::ResidentBlocks& r = b->rb;
-  if (r.on) {
-    if (!sync_all(b)) return -2;
-    const int rc = tick_enable(b, false);
-    if (rc) return rc;
-    (void)BeatriceBatch_BindResidentIO(b, nullptr, nullptr, 0);
-    rb_release(b);
-  }
-  if (!d_in && !d_out) return 0;
-  const int stages = b->tk.plan.count();
-  if (!b->wrap.ready || !d_in || !d_out || channels < 1 || channels > 2 || n < 1 || n > wrap_max_chunk(b) || n_slots < stages + 1 || b->H != 1 ||
-      b->io_slots > 0 || b->pipelined || b->tk.on || b->hs.on || b->r48.on)
-    return -1;
-  if (!sync_all(b)) return -2;
-  // model hops a call can fire: ceil(inner samples / 480) + 1; a hop's resident output is read until `delay` calls after the
-  // call in which the NEXT hop fired
-  const int m_max = (int)std::ceil(n * 48000.0 / b->wrap.rate) + 2, hops_per_call = (m_max + wrapn::kBlock - 1) / wrapn::kBlock + 1;
-  r.delay = stages - 1;
-  r.ring = r.delay + 3;
-  r.io_slots = std::max(stages + 1, (r.delay + 2) * hops_per_call + 2);
-  const int B = b->B;
-  bool ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_in16), sizeof(float) * r.io_slots * B * B_IN_HOP), "rb in16") &&
-            hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_out24), sizeof(float) * r.io_slots * B * B_OUT_HOP), "rb out24") &&
-            hip_ok(hipMemset(r.d_in16, 0, sizeof(float) * r.io_slots * B * B_IN_HOP), "rb zero") &&
-            hip_ok(hipMemset(r.d_out24, 0, sizeof(float) * r.io_slots * B * B_OUT_HOP), "rb zero") &&
-            hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_gains), sizeof(wrapn::GainSeg) * r.ring * 2 * B), "rb gains") &&
-            hip_ok(hipHostMalloc(reinterpret_cast<void**>(&r.h_gains), sizeof(wrapn::GainSeg) * r.ring * 2 * B, hipHostMallocDefault), "rb gains host");
-  if (ok) {
-    r.gain_ev = new hipEvent_t[r.ring]();
-    for (int i = 0; i < r.ring && ok; ++i) ok = hip_ok(hipEventCreateWithFlags(&r.gain_ev[i], hipEventDisableTiming), "rb event");
-  }
-  ok = ok && hip_ok(hipDeviceSynchronize(), "rb sync") && BeatriceBatch_BindResidentIO(b, r.d_in16, r.d_out24, r.io_slots) == 0 && tick_enable(b, true) == 0;
-  if (!ok) {
-    (void)tick_enable(b, false);
-    (void)BeatriceBatch_BindResidentIO(b, nullptr, nullptr, 0);
-    rb_release(b);
-    return -2;
-  }
-  r.d_in = d_in; r.d_out = d_out; r.channels = channels; r.n = n; r.n_slots = n_slots; r.on = true;
-  return 0;
-}
-int BeatriceBatch_ResidentBlocksDelay(const BeatriceBatch* b) { return b && b->ok && b->rb.on ? b->rb.delay : -1; }
-int BeatriceBatch_ProcessBlocks(BeatriceBatch* b, const float* in, float* out, int channels, int n) {
-  const DeviceScope dev_(b ? b->device : -1);
-  if (!b || !b->ok) return -2;
-  if (!b->wrap.ready || channels < 1 || channels > 2 || !in || !out || n < 1 || n > wrap_max_chunk(b) || b->H != 1 || b->io_slots > 0 || b->pipelined || b->tk.on) return -1;
-  const size_t cnt = (size_t)b->B * channels * n;
-  float* h_in = b->h_wrap_io;
-  float* h_out = b->h_wrap_io + (size_t)b->B * 2 * wrapn::kMaxSamples;
-  float* d_in = b->d_wrap_io;
-  float* d_out = b->d_wrap_io + (size_t)b->B * 2 * wrapn::kMaxSamples;
-  std::memcpy(h_in, in, sizeof(float) * cnt);
-  bool ok = hip_ok(hipMemcpyAsync(d_in, h_in, sizeof(float) * cnt, hipMemcpyHostToDevice, b->stream), "wrap in");
-  ok = ok && wrap_chunk(b, d_in, d_out, channels, n);
-  ok = ok && hip_ok(hipMemcpyAsync(h_out, d_out, sizeof(float) * cnt, hipMemcpyDeviceToHost, b->stream), "wrap out");
-  ok = hip_ok(hipStreamSynchronize(b->stream), "wrap sync") && ok;
-  b->inflight = false;
-  if (ok) std::memcpy(out, h_out, sizeof(float) * cnt);
-  else std::memset(out, 0, sizeof(float) * cnt);
-  return ok ? 0 : -2;
-}
+#include "batch_wrappers.hip.h"  // 48 kHz and any-rate wrappers, in order and around the ticks
 
 int BeatriceBatch_Synchronize(BeatriceBatch* b) {
   const DeviceScope dev_(b ? b->device : -1);
@@ -1865,165 +1216,7 @@ int BeatriceBatch_EnableGraph(BeatriceBatch* b, int enable) {
   if (!b->use_graph) drop_graph(b);
   return 0;
 }
-// ---- host streaming: the tick pipeline with HOST buffers on either side -----------------------------------------------------
-// The resident I/O slots of the ticks are the batch's PINNED HOST mirrors: the stages that read a hop (f1, fft, pitch head)
-// and the one that writes samples (the tail) go over PCIe themselves -- 160 + 240 KB per tick at 256 streams, spread over
-// hundreds of workgroups that have plenty to overlap it with -- so a call is: memcpy the hop into its slot, launch the
-// tick, record an event, and hand back the step whose tick finished at least two ticks ago (the host then never waits
-// for the device's current work, and two ticks stay queued).  3.07-3.16 M frames/s from and to host memory at 256 streams
-// against 3.2-3.55 M with resident device buffers (before / after the last changes of the tick bodies).  BEATRICE_HIP_HS_COPIES=1 (A/B): device slots with an upload and a
-// download stream beside the ticks instead -- 2.36 M: copy commands and cross-stream waits cost more than PCIe loads.
-static void host_stream_fetch(BeatriceBatch* b) {  // enqueue the download of every step the ticks run so far have completed
-  BeatriceBatch::HostStream& h = b->hs;
-  const long long last_tick = b->tk.tick - 1;
-  const size_t n_out = (size_t)b->B * B_OUT_HOP;
-  for (auto& p : h.pending) {
-    if (p.fetched || p.done_tick > last_tick) continue;
-    if (h.mapped) { p.fetched = true; continue; }  // nothing to download: the last stage wrote host memory
-    // (the event recorded behind the tick just launched: it is at or after the tick that completed this step, also when
-    //  ticks were run by a drain in between, which records none)
-    (void)hipStreamWaitEvent(h.s_out, h.ev_tick[h.rec[0] % h.ev_tick.size()], 0);
-    (void)hipMemcpyAsync(h.h_out + p.slot * n_out, h.d_out + p.slot * n_out, sizeof(float) * n_out, hipMemcpyDeviceToHost, h.s_out);
-    (void)hipEventRecord(h.ev_out[p.slot], h.s_out);
-    p.fetched = true;
-  }
-}
-static bool host_stream_tick(BeatriceBatch* b, bool feeding) {
-  BeatriceBatch::HostStream& h = b->hs;
-  if (!tick_run(b, feeding)) return false;   // (may run a whole drain first: a stage that comes or goes)
-  const long long t = b->tk.tick - 1;        // the tick just launched
-  (void)hipEventRecord(h.ev_tick[t % h.ev_tick.size()], b->stream);
-  h.tick_of_ev[t % h.ev_tick.size()] = t;
-  h.rec[1] = h.rec[0]; h.rec[0] = t;
-  host_stream_fetch(b);
-  return true;
-}
-// the samples of pending step f are in the pinned output mirror
-static bool host_stream_wait(BeatriceBatch* b, const BeatriceBatch::HostStream::Pending& f) {
-  BeatriceBatch::HostStream& h = b->hs;
-  if (!h.mapped) return hip_ok(hipEventSynchronize(h.ev_out[f.slot]), "hs download");
-  const size_t n = h.ev_tick.size();
-  for (long long t = f.done_tick; t <= h.rec[0]; ++t)   // the first event recorded at or behind the tick that completed it
-    if (h.tick_of_ev[t % n] == t) return hip_ok(hipEventSynchronize(h.ev_tick[t % n]), "hs tick done");
-  return false;
-}
-}  // extern "C"
-namespace {
-void host_stream_free(BeatriceBatch* b) {
-  BeatriceBatch::HostStream& h = b->hs;
-  for (hipEvent_t e : h.ev_in) if (e) (void)hipEventDestroy(e);
-  for (hipEvent_t e : h.ev_out) if (e) (void)hipEventDestroy(e);
-  for (hipEvent_t e : h.ev_tick) if (e) (void)hipEventDestroy(e);
-  h.ev_in.clear(); h.ev_out.clear(); h.ev_tick.clear();
-  if (h.s_in) (void)hipStreamDestroy(h.s_in);
-  if (h.s_out) (void)hipStreamDestroy(h.s_out);
-  if (h.d_in) (void)hipFree(h.d_in);
-  if (h.d_out) (void)hipFree(h.d_out);
-  if (h.h_in) (void)hipHostFree(h.h_in);
-  if (h.h_out) (void)hipHostFree(h.h_out);
-  h = BeatriceBatch::HostStream{};
-}
-}  // namespace
-extern "C" {
-int BeatriceBatch_EnableHostStreaming(BeatriceBatch* b, int enable) {
-  const DeviceScope dev_(b ? b->device : -1);
-  if (!b || !b->ok) return -2;
-  BeatriceBatch::HostStream& h = b->hs;
-  if ((enable != 0) == h.on) return 0;
-  if (!enable) {
-    if (!sync_all(b)) return -2;
-    (void)hipStreamSynchronize(h.s_in); (void)hipStreamSynchronize(h.s_out);
-    const int rc = tick_enable(b, false);
-    if (rc) return rc;
-    const int rb = BeatriceBatch_BindResidentIO(b, nullptr, nullptr, 0);
-    host_stream_free(b);
-    return rb;
-  }
-  if (b->H != 1 || b->io_slots > 0 || b->tk.on || b->pipelined) return -1;  // one hop per step; no other binding or pipelining
-  h.n_slots = b->tk.plan.count() + 8;
-  const size_t n_in = (size_t)b->B * B_IN_HOP, n_out = (size_t)b->B * B_OUT_HOP;
-  bool ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&h.d_in), sizeof(float) * n_in * h.n_slots), "hs d_in") &&
-            hip_ok(hipMalloc(reinterpret_cast<void**>(&h.d_out), sizeof(float) * n_out * h.n_slots), "hs d_out") &&
-            hip_ok(hipHostMalloc(reinterpret_cast<void**>(&h.h_in), sizeof(float) * n_in * h.n_slots, hipHostMallocDefault), "hs h_in") &&
-            hip_ok(hipHostMalloc(reinterpret_cast<void**>(&h.h_out), sizeof(float) * n_out * h.n_slots, hipHostMallocDefault), "hs h_out") &&
-            hip_ok(hipMemset(h.d_in, 0, sizeof(float) * n_in * h.n_slots), "hs zero") &&
-            hip_ok(hipStreamCreateWithFlags(&h.s_in, hipStreamNonBlocking), "hs s_in") &&
-            hip_ok(hipStreamCreateWithFlags(&h.s_out, hipStreamNonBlocking), "hs s_out");
-  h.ev_in.assign(h.n_slots, nullptr); h.ev_out.assign(h.n_slots, nullptr); h.ev_tick.assign(tick::kRing, nullptr);
-  for (auto* v : {&h.ev_in, &h.ev_out, &h.ev_tick})
-    for (hipEvent_t& e : *v) ok = ok && hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hs event");
-  h.tick_of_ev.assign(tick::kRing, -1);
-  h.mapped = std::getenv("BEATRICE_HIP_HS_COPIES") == nullptr;   // A/B switch: copies on two more streams instead
-  if (ok && h.mapped) std::memset(h.h_in, 0, sizeof(float) * n_in * h.n_slots);
-  ok = ok && BeatriceBatch_BindResidentIO(b, h.mapped ? h.h_in : h.d_in, h.mapped ? h.h_out : h.d_out, h.n_slots) == 0 && tick_enable(b, true) == 0;
-  if (!ok) { (void)tick_enable(b, false); (void)BeatriceBatch_BindResidentIO(b, nullptr, nullptr, 0); host_stream_free(b); return -2; }
-  h.pending.clear();
-  h.fed = 0;
-  h.rec[0] = h.rec[1] = -1;
-  h.on = true;
-  return 0;
-}
-int BeatriceBatch_HostStreamDelay(const BeatriceBatch* b) { return b ? b->tk.plan.count() + 1 : 0; }
-// in: [B][160] host; out: [B][240] host.  Returns 1 when `out` received the samples of the step fed
-// BeatriceBatch_HostStreamDelay() calls ago, 0 while the pipeline is still filling (out untouched), < 0 on error.
-int BeatriceBatch_StreamFrames(BeatriceBatch* b, const float* in, float* out) {
-  const DeviceScope dev_(b ? b->device : -1);
-  if (!b || !b->ok) return -2;
-  BeatriceBatch::HostStream& h = b->hs;
-  if (!h.on || !in || !out) return -1;
-  const size_t n_in = (size_t)b->B * B_IN_HOP, n_out = (size_t)b->B * B_OUT_HOP;
-  const int slot = b->io_host;  // the slot the tick about to be fed reads and, pipeline depth later, writes
-  if (h.mapped) {
-    // the slot's last readers (stage 9 of the step fed n_slots calls ago) are done: every call since the pipeline filled
-    // has waited for a tick later than theirs before handing back its output
-    std::memcpy(h.h_in + slot * n_in, in, sizeof(float) * n_in);
-    if (!host_stream_tick(b, true)) return -2;
-    h.pending.push_back({h.fed, slot, b->tk.last_feed_tick + b->tk.plan.count() - 1, false});
-    h.fed += 1;
-    const BeatriceBatch::HostStream::Pending& f = h.pending.front();
-    if (!f.fetched || f.done_tick > b->tk.last_feed_tick - 2) return 0;   // keep two ticks queued on the device while the host waits
-    if (!host_stream_wait(b, f)) return -2;
-    std::memcpy(out, h.h_out + f.slot * n_out, sizeof(float) * n_out);
-    h.pending.pop_front();
-    return 1;
-  }
-  if (!hip_ok(hipEventSynchronize(h.ev_in[slot]), "hs in reuse")) return -2;  // the upload that last used this pinned slot (long done)
-  std::memcpy(h.h_in + slot * n_in, in, sizeof(float) * n_in);
-  // every reader of the device slot's old contents is done once the tick before the previous one is (the slot ring is
-  // longer than the deepest reader's stage by more than that)
-  if (h.rec[1] >= 0) (void)hipStreamWaitEvent(h.s_in, h.ev_tick[h.rec[1] % h.ev_tick.size()], 0);
-  bool ok = hip_ok(hipMemcpyAsync(h.d_in + slot * n_in, h.h_in + slot * n_in, sizeof(float) * n_in, hipMemcpyHostToDevice, h.s_in), "hs upload");
-  (void)hipEventRecord(h.ev_in[slot], h.s_in);
-  (void)hipStreamWaitEvent(b->stream, h.ev_in[slot], 0);
-  (void)hipStreamWaitEvent(b->stream, h.ev_out[slot], 0);  // the output slot this step will overwrite has been downloaded
-  ok = ok && host_stream_tick(b, true);
-  if (!ok) return -2;
-  h.pending.push_back({h.fed, slot, b->tk.last_feed_tick + b->tk.plan.count() - 1, false});  // leaves the last stage that many ticks on
-  h.fed += 1;
-  const BeatriceBatch::HostStream::Pending& f = h.pending.front();
-  if (!f.fetched || f.done_tick > b->tk.last_feed_tick - 2) return 0;   // hand back only what was enqueued for download two ticks ago
-  if (!hip_ok(hipEventSynchronize(h.ev_out[f.slot]), "hs download")) return -2;
-  std::memcpy(out, h.h_out + f.slot * n_out, sizeof(float) * n_out);
-  h.pending.pop_front();
-  return 1;
-}
-// After the last StreamFrames: hands back the next step still inside the pipeline (running ticks without input as
-// needed); returns 1 with `out` filled, 0 when nothing is pending.
-int BeatriceBatch_StreamFlush(BeatriceBatch* b, float* out) {
-  const DeviceScope dev_(b ? b->device : -1);
-  if (!b || !b->ok) return -2;
-  BeatriceBatch::HostStream& h = b->hs;
-  if (!h.on || !out) return -1;
-  if (h.pending.empty()) return 0;
-  const size_t n_out = (size_t)b->B * B_OUT_HOP;
-  while (!h.pending.front().fetched)
-    if (!host_stream_tick(b, false)) return -2;
-  const BeatriceBatch::HostStream::Pending f = h.pending.front();
-  if (!host_stream_wait(b, f)) return -2;
-  std::memcpy(out, h.h_out + f.slot * n_out, sizeof(float) * n_out);
-  h.pending.pop_front();
-  return 1;
-}
+#include "batch_host_stream.hip.h"  // BeatriceBatch_StreamFrames
 
 // Throughput mode for callers that enqueue steps ahead (BeatriceBatch_ConvertFramesDevice without waiting,
 // resident I/O): the front end of step t+1 runs on the batch's stream while the waveform generator of step t
@@ -2032,7 +1225,7 @@ int BeatriceBatch_StreamFlush(BeatriceBatch* b, float* out) {
 int BeatriceBatch_EnableTickPipeline(BeatriceBatch* b, int enable) {
   const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
-  if (b->hs.on || b->r48.on) return -1;  // those modes own the tick pipeline: leave them instead
+  if (b->hs.on || b->r48.on || b->rb.on) return -1;  // those modes own the tick pipeline: leave them instead
   return tick_enable(b, enable != 0);
 }
 int BeatriceBatch_TickStages(const BeatriceBatch* b) { return b ? b->tk.plan.count() : 0; }

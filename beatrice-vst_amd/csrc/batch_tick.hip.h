@@ -1,0 +1,343 @@
+// batch_tick.hip.h -- the batch's tick mode: the workgroup table of one tick, the per-tick host work (settings snapshots, step pairs, launch), drain, enable / leave
+// (Part of batch.hip's translation unit: included there, after struct BeatriceBatch and the helpers above it; not a stand-alone header.)
+#pragma once
+
+// ---- tick pipelining (tick.hip.h) ---------------------------------------------------------------------------------
+bool tick_build_table(BeatriceBatch* b) {
+  using namespace tick;
+  State& k = b->tk;
+  auto tb = std::make_unique<Builder>();
+  const PhoneWeights& pw = b->phone_m->w;
+  const PitchWeights& qw = b->pitch_m->w;
+  const WaveWeights& ww = b->wave_m->w;
+  const PhoneState& ps = b->phone;
+  const PitchState& qs = b->pitch;
+  const WaveState& ws = b->wave;
+  const int B = b->B;
+  const Plan pl = k.plan;
+  // measurement aid, MEASUREMENT BUILDS ONLY (tools/debug/build_variant.sh <name> -DBEATRICE_HIP_MEASUREMENT_BUILD; the
+  // product library has no switch that changes results): BEATRICE_HIP_TICK_DROP=<bit mask> leaves groups of bodies out of
+  // the launch
+#ifdef BEATRICE_HIP_MEASUREMENT_BUILD
+  static const int drop = std::getenv("BEATRICE_HIP_TICK_DROP") ? std::atoi(std::getenv("BEATRICE_HIP_TICK_DROP")) : 0;
+#else
+  constexpr int drop = 0;
+#endif
+  auto keep = [](int group) { return ((drop >> group) & 1) == 0; };
+  // (every body takes its step counter from the launch's StepPairs -- a null counter pointer says so, ring.h stepc)
+  auto hp = [&](int) -> const int* { return nullptr; };
+  auto conv = [&](const Ring& in, const Ring& out, const float* w, const float* bias, int stage) { return conv_args(in, out, w, bias, hp(stage), B); };
+  // (workgroups are dispatched in this order: the longest-running bodies first)
+  // ---- longest workgroups first (measured, two per CU): f5 48 us, p1 46, f4 45, rb 42, block halves 41 / 38, tail 36
+  { const ConvArgs a = conv(ps.f[3], ps.f[4], pw.f_w[3], pw.f_b[3], Plan::F5); tb->add<T_F5>(OpF5::info("phone.f5", a), a, OpF5::grid(a), Plan::F5, keep(6), 47); }
+  { const ConvArgs a = conv(qs.spec, qs.p[0], qw.p_w[0], qw.p_b[0], Plan::P1); tb->add<T_P1>(OpP1::info("pitch.p1", a), a, OpP1::grid(a), Plan::P1, keep(2), 34.5); }
+  { const ConvArgs a = conv(ps.f[2], ps.f[3], pw.f_w[2], pw.f_b[2], Plan::F4); tb->add<T_F4>(OpF4::info("phone.f4", a), a, OpF4::grid(a), Plan::F4, keep(6), 37.5); }
+  for (int i = 0; i < 4; ++i) {
+    const ConvArgs a = conv(i == 0 ? ps.f[4] : ps.rb[i - 1], ps.rb[i], pw.rb_w[i], pw.rb_b[i], Plan::RB0 + i);
+    tb->add<T_RB>(OpRB::info("phone.rb", a), a, OpRB::grid(a), Plan::RB0 + i, keep(6), 46);
+  }
+  // conditioned blocks: two row-local chains each
+  for (int blk = 0; blk < B_NBLOCKS; ++blk) {
+    const WaveState::Scratch& sc = ws.scr[blk];  // one scratch set per block: all four blocks are in flight at once
+    const int s0 = pl.blk(blk);
+    const rc::BlockBArgs ba{sc.xa, ws.x[blk + 1], ww.q_w[blk], ww.q_b[blk], ww.o_w[blk], ww.o_b[blk], ws.d_kt[blk], ws.d_v[blk],
+                            b->dev_view<int>(b->off.perm[blk]), b->dev_view<int>(b->off.tile_slot[blk]), hp(s0 + 1)};
+    tb->add<T_BLKB>(LaunchInfo{"wave.blk.b", 2.0 * B * (256.0 * 256 * 2 + 256.0 * 384 * 2), 4.0 * (2.0 * 256 * 256 + 2.0 * 256 * 384 + B * 3.0 * 256)}, ba,
+                    dim3(ws.n_tiles_max, 1), s0 + 1, keep(5), 41.0);
+    if (quads_on(b)) {  // rows without 15 neighbours on their K/V slot: one workgroup per quad (rebuild_tiles decides which rows)
+      const rc::BlockBqArgs bq{sc.xa, ws.x[blk + 1], ww.q_w[blk], ww.q_b[blk], ww.o_w[blk], ww.o_b[blk], ws.d_ktp[blk], ws.d_vp[blk],
+                               b->dev_view<int>(b->off.qperm[blk]), b->dev_view<int>(b->off.qslot[blk]), hp(s0 + 1)};
+      // (a slot leaves at most 7 rows = 2 quads to this list: <= n_slots workgroups of two quads)
+      tb->add<T_BLKBQ>(LaunchInfo{"wave.blk.bq", 0.0, 0.0}, bq, dim3(std::min(2 * ws.n_tiles_max, ws.n_slots), 1), s0 + 1, keep(5), 42.0);
+    }
+  }
+  for (int blk = 0; blk < B_NBLOCKS; ++blk) {
+    const rc::BlockAArgs aa{ws.x[blk], ws.scr[blk].xa, ww.c1_w[blk], ww.c1_b[blk], ww.c2_w[blk], ww.c2_b[blk], hp(pl.blk(blk)), B};
+    switch (blk) {
+      case 0: tb->add<T_BLKA1>(rc::BlockAOp<1>::info(aa), aa, rc::BlockAOp<1>::grid(aa), pl.blk(blk), keep(5), 41); break;
+      case 1: tb->add<T_BLKA2>(rc::BlockAOp<2>::info(aa), aa, rc::BlockAOp<2>::grid(aa), pl.blk(blk), keep(5), 41); break;
+      case 2: tb->add<T_BLKA4>(rc::BlockAOp<4>::info(aa), aa, rc::BlockAOp<4>::grid(aa), pl.blk(blk), keep(5), 41); break;
+      default: tb->add<T_BLKA8>(rc::BlockAOp<8>::info(aa), aa, rc::BlockAOp<8>::grid(aa), pl.blk(blk), keep(5), 41); break;
+    }
+  }
+  if (!pl.split_tail) {
+    TailArgs ta = tail_args(ww, ws); ta.hop = hp(pl.tail()); tb->add<T_TAIL>(tail_info(ws), ta, dim3(B, 1), pl.tail(), keep(4), 41, true);
+  } else {
+    // the tail as three stages, several streams per workgroup (tail_stages.hip.h); same weights, same state block
+    tst::StageArgs t1{}, t2{}, t3{};
+    t1.in = ws.ya2; t1.out = ws.ya3; t2.in = ws.ya3; t2.out = ws.ya4; t3.in = ws.ya4;
+    for (tst::StageArgs* t : {&t1, &t2, &t3}) { t->state = ws.tail.base; t->hop = nullptr; t->B = B; }
+    t1.w[0] = ww.ra_w[1]; t1.b[0] = ww.ra_b[1]; t1.w[1] = ww.rb_w[1]; t1.b[1] = ww.rb_b[1]; t1.w[2] = ww.up_w[2]; t1.b[2] = ww.up_b[2];
+    t2.w[0] = ww.ra_w[2]; t2.b[0] = ww.ra_b[2]; t2.w[1] = ww.rb_w[2]; t2.b[1] = ww.rb_b[2]; t2.w[2] = ww.up_w[3]; t2.b[2] = ww.up_b[3];
+    t3.w[0] = ww.ra_w[3]; t3.b[0] = ww.ra_b[3]; t3.w[1] = ww.rb_w[3]; t3.b[1] = ww.rb_b[3];
+    t3.fin_w = ww.fin_w; t3.fin_b = ww.fin_b; t3.d_out = ws.d_out; t3.io_stride = ws.io_stride;
+    tb->add<T_TAIL1>(tst::T1Op::info(t1), t1, tst::T1Op::grid(t1), pl.tail(), keep(4), 30, true);
+    tb->add<T_TAIL2>(tst::T2Op::info(t2), t2, tst::T2Op::grid(t2), pl.tail() + 1, keep(4), 28, true);
+    tb->add<T_TAIL3>(tst::T3Op::info(t3), t3, tst::T3Op::grid(t3), pl.tail() + 2, keep(4), 16, true);
+  }
+  // ---- everything else, longest workgroups first (they start when the heavy ones above leave their slots)
+  { const ConvArgs a = conv(ps.f[1], ps.f[2], pw.f_w[1], pw.f_b[1], Plan::F3); tb->add<T_F3>(OpF3::info("phone.f3", a), a, OpF3::grid(a), Plan::F3, keep(6), 18); }
+  { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], pl.up1()); tb->add<T_UP1>(OpUP1::info("wave.up1", a), a, OpUP1::grid(a), pl.up1(), keep(7), 36); }
+  { const ConvArgs a = conv(ws.yb1, ws.yc1, ww.rb_w[0], ww.rb_b[0], pl.up1() + 2); tb->add<T_RES1B>(OpRES1B::info("wave.res1b", a), a, OpRES1B::grid(a), pl.up1() + 2, keep(7), 10); }
+  { const ConvArgs a = conv(ws.ya1, ws.yb1, ww.ra_w[0], ww.ra_b[0], pl.up1() + 1); tb->add<T_RES1A>(OpRES1A::info("wave.res1a", a), a, OpRES1A::grid(a), pl.up1() + 1, keep(7), 10); }
+  { const ConvArgs a = conv(ws.yc1, ws.ya2, ww.up_w[1], ww.up_b[1], pl.up1() + 3); tb->add<T_UP2>(OpUP2::info("wave.up2", a), a, OpUP2::grid(a), pl.up1() + 3, keep(7), 12); }
+  { const ConvArgs a = conv(ps.f[0], ps.f[1], pw.f_w[0], pw.f_b[0], Plan::F2); tb->add<T_F2>(OpF2::info("phone.f2", a), a, OpF2::grid(a), Plan::F2, keep(6), 10); }
+  { const GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(Plan::PGRU), B, 0}; tb->add<T_PGRU>(GruOp<256, 256, TICK_GRU_RT>::info("phone.gru", g), g, GruOp<256, 256, TICK_GRU_RT>::grid(g), Plan::PGRU, keep(1), 7.6); }
+  { const ConvArgs a = conv(qs.h, qs.logits, qw.out_w, qw.out_b, Plan::POUT); tb->add<T_POUT>(OpPOUT::info("pitch.out", a), a, OpPOUT::grid(a), Plan::POUT, keep(2), 9.4); }
+  for (int i = 0; i < 2; ++i) {
+    const ConvArgs a = conv(qs.p[i], qs.p[i + 1], qw.p_w[i + 1], qw.p_b[i + 1], Plan::P2 + i);
+    tb->add<T_P23>(OpP23::info("pitch.p23", a), a, OpP23::grid(a), Plan::P2 + i, keep(2), 8);
+  }
+  { const Ring phone_in{ws.d_phone, B_PHONE_CH, 1, ws.front_slots}; ConvArgs a = conv(phone_in, ws.x[0], ww.inp_w, ww.inp_b, Plan::INP); a.res = ws.e; tb->add<T_INP>(OpINP::info("wave.inp", a), a, OpINP::grid(a), Plan::INP, keep(3), 7.7); }
+  { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, 0}; tb->add<T_QGRU>(GruOp<128, 128, TICK_GRU_RT>::info("pitch.gru", g), g, GruOp<128, 128, TICK_GRU_RT>::grid(g), Plan::QGRU, keep(1), 4.6); }
+  { FftArgs a = fft_args(qw, qs); a.hop = hp(Plan::FFT); tb->add<T_FFT>(fft_info(qs), FftArgs2{a, B}, dim3((B + 1) / 2, 1), Plan::FFT, keep(0), 6); }
+  { const ConvArgs a = conv(ps.h, phone_out_ring(ps), pw.out_w, pw.out_b, Plan::OUT); tb->add<T_OUT>(OpOUT::info("phone.out", a), a, OpOUT::grid(a), Plan::OUT, keep(3), 6); }
+  { const VqArgs a{1, ps.raw, phone_vector_ring(ps), hp(Plan::VQ), ps.d_cbT, ps.d_cnorm, ps.d_vqk}; tb->add<T_VQ>(LaunchInfo{"phone.vq", 0, 4.0 * B * 256}, a, dim3(B, 1), Plan::VQ, !ps.skip_vq, 6.0, true); }
+  { PitchHeadArgs a = head_args(qw, qs); a.hop = hp(Plan::HEAD); tb->add<T_HEAD>(head_info(qs), a, dim3((B + 7) / 8, 1), Plan::HEAD, keep(0), 4.7); }
+  { F1Args a = f1_args(pw, ps); a.hop = hp(Plan::F1); a.hop_publish = nullptr; a.hop_publish_wave = nullptr; tb->add<T_F1>(f1_info(ps), F1Args2{a, B}, dim3((B + 1) / 2, 1), Plan::F1, keep(0), 4.5); }
+  { CondArgs a = cond_args(ww, ws); a.hop = hp(Plan::COND); a.hop_next_out = nullptr; tb->add<T_COND>(cond_info(ws), a, dim3((B + 1) / 2, 1), Plan::COND, keep(0), 1.3); }
+  if (!tb->ok) return false;
+  // XCD-aware placement (bodies with many weights pinned to one XCD each, so that the weights stay in that L2) was
+  // measured twice: it cuts the launch's memory-side traffic 4x (rocprofv3 FETCH_SIZE 105 -> 26 MB per tick) and the
+  // pinned workgroups run ~10-25 % shorter, but confining a body to 32 CUs costs more in makespan than that gains
+  // (0.096 vs 0.090 ms per tick): off by default
+  static const bool by_xcd = std::getenv("BEATRICE_HIP_TICK_XCD") != nullptr;
+  if (by_xcd) tb->place_by_xcd();
+  if (std::getenv("BEATRICE_HIP_TICK_TRACE")) {
+    if (k.d_trace) (void)hipFree(k.d_trace);
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&k.d_trace), sizeof(unsigned long long) * 3 * tb->t.total));
+    tb->t.trace = k.d_trace;
+  }
+  BHIP_TRY(hipMemcpy(k.d_table, &tb->t, sizeof(Tab), hipMemcpyHostToDevice));
+  k.table_total = tb->t.total;
+  k.table_flops = tb->flops;
+  k.table_bytes = tb->bytes;
+  // who reads which part of the settings block, and where its private copy lives
+  k.consumers.clear();
+  unsigned char* d = b->settings.d;
+  k.consumers.push_back(Consumer{Plan::VQ, b->off.cbT, b->off.min_q - b->off.cbT, d + b->off.cbT, -1});
+  k.consumers.push_back(Consumer{Plan::HEAD, b->off.min_q, b->off.add_idx - b->off.min_q, d + b->off.min_q, -1});
+  k.consumers.push_back(Consumer{Plan::COND, b->off.add_idx, b->off.front_bytes - b->off.add_idx, d + b->off.add_idx, -1});
+  for (int blk = 0; blk < B_NBLOCKS; ++blk) {
+    const size_t lo = b->off.perm[blk], hi = blk + 1 < B_NBLOCKS ? b->off.perm[blk + 1] : b->off.front_bytes + b->off.wave_bytes;
+    k.consumers.push_back(Consumer{pl.blk(blk) + 1, lo, hi - lo, d + lo, -1});
+  }
+  k.table_dirty = false;
+  return true;
+}
+
+// One tick: every stage advances by one step; `feeding` = a new step enters at stage 0.
+// BEATRICE_HIP_TICK_HOSTPROF=1: host time of tick_run by section, printed when the process ends (measurement aid)
+struct HostProf {
+  static constexpr int N = 5;
+  static bool on() { static const bool v = std::getenv("BEATRICE_HIP_TICK_HOSTPROF") != nullptr; return v; }
+  struct Totals { double us[N] = {}; long long calls = 0; ~Totals() { if (calls) std::fprintf(stderr, "tick_run host us per call: settings/kv %.1f, table %.1f, snapshot upload %.1f, copies %.1f, launch %.1f (%lld calls)\n", us[0] / calls, us[1] / calls, us[2] / calls, us[3] / calls, us[4] / calls, calls); } };
+  static Totals& totals() { static Totals t; return t; }
+  std::chrono::steady_clock::time_point t0;
+  HostProf() { if (on()) { t0 = std::chrono::steady_clock::now(); totals().calls += 1; } }
+  void lap(int i) {
+    if (!on()) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    totals().us[i] += std::chrono::duration<double, std::micro>(t1 - t0).count();
+    t0 = t1;
+  }
+};
+bool tick_run(BeatriceBatch* b, bool feeding) {
+  using namespace tick;
+  State& k = b->tk;
+  HostProf prof;
+  if (feeding) {
+    advance_kv(b);
+    draw_codebooks(b);
+    if (b->vq_dirty) { update_vq_mode(b); b->vq_dirty = false; }   // (drains the pipeline if the k-NN stage comes or goes)
+  }
+  prof.lap(0);
+  if (k.table_dirty && !tick_build_table(b)) return false;
+  prof.lap(1);
+  hipStream_t st = b->stream;
+  Copy upload{nullptr, nullptr, 0};
+  int upload_stage = -1;
+  if (feeding) {
+    bool dirty = b->front_dirty || k.snap_cur < 0;
+    for (bool w : b->wave_dirty) dirty = dirty || w;
+    if (dirty) {  // a new version of the settings: one upload into the next slot of the snapshot ring
+      const int serial = k.snap_next++;
+      const size_t off = 0, len = k.snap_bytes;
+      unsigned char* dst = k.d_snap + (size_t)(serial % kRing) * k.snap_bytes;
+      // through a ring of pinned staging copies, so that the host may run several settings changes ahead of the device
+      // (the batch's two-deep mirror would make every second change wait for the copy of the change before it); the
+      // tick's prologue kernel reads the staging copy straight from host memory (tick.hip.h)
+      const int si = serial % State::kStaging;
+      if (k.stage_pending[si]) { if (!hip_ok(hipEventSynchronize(k.stage_ev[si]), "tick settings staging")) return false; }
+      unsigned char* src = k.h_stage + (size_t)si * k.snap_bytes;
+      std::memcpy(src, b->settings.h + off, len);
+      upload = Copy{dst, src, (int)len};
+      upload_stage = si;
+      k.snap_cur = serial;
+      b->front_dirty = false;
+      for (bool& w : b->wave_dirty) w = false;
+    }
+    const long long u = k.n_fed;
+    k.fed_step[k.tick % kRing] = u;
+    k.snap_of_step[u % kRing] = k.snap_cur;
+    k.hop_of_step[u % kRing] = b->hop_host;
+    k.io_of_step[u % kRing] = b->io_host;
+  } else {
+    k.fed_step[k.tick % kRing] = -1;
+  }
+  prof.lap(2);
+  Prolog p{};
+  p.n_stages = k.plan.count();
+  auto step_at = [&k](int stage) -> long long {
+    const long long t2 = k.tick - stage;
+    return t2 >= 0 ? k.fed_step[t2 % kRing] : -1;
+  };
+  for (int s = 0; s < p.n_stages; ++s) {
+    const long long u = step_at(s);
+    p.hop[s] = u < 0 ? -1 : k.hop_of_step[u % kRing];
+    p.io[s] = u < 0 ? 0 : k.io_of_step[u % kRing];
+  }
+  for (Consumer& c : k.consumers) {
+    const long long u = step_at(c.stage);
+    if (u < 0) continue;
+    const int want = k.snap_of_step[u % kRing];
+    if (want == c.held) continue;
+    p.copy[p.n_copies++] = Copy{c.dst, k.d_snap + (size_t)(want % kRing) * k.snap_bytes + c.off, (int)c.bytes};
+    c.held = want;
+  }
+  if (upload.bytes > 0) {  // first, so that entry order = age; (a consumer never needs the snapshot uploaded in its own tick: none sits at stage 0)
+    for (int i = p.n_copies; i > 0; --i) p.copy[i] = p.copy[i - 1];
+    p.copy[0] = upload;
+    p.n_copies += 1;
+  }
+  if (p.n_copies > 0) {  // (only on ticks where the settings changed or a change arrives at a consumer)
+    int chunks = 0;
+    for (int i = 0; i < p.n_copies; ++i) { p.first_chunk[i] = chunks; chunks += (p.copy[i].bytes + kCopyChunk - 1) / kCopyChunk; }
+    p.first_chunk[p.n_copies] = chunks;
+    hipLaunchKernelGGL(prologue_kernel, dim3(chunks), dim3(256), 0, st, p);
+    if (upload_stage >= 0) {
+      if (!hip_ok(hipEventRecord(k.stage_ev[upload_stage], st), "tick settings event")) return false;
+      k.stage_pending[upload_stage] = true;
+    }
+  }
+  if (b->r48.on && (feeding || b->r48.deferred_slot >= 0)) {
+    // one launch for both ends of the 48 kHz wrapper: the block entering the pipeline -> its 16 kHz hop, straight into the
+    // resident slot; and the step the PREVIOUS tick completed leaves through the up-sampler and the 480-sample FIFO
+    // (resample.h:346-361: the block emitted for step j carries the model output of step j - 1) into the 48 kHz slot of step j
+    BeatriceBatch::Resident48& r = b->r48;
+    Wrap48TickArgs wa{};
+    wa.channels = r.channels; wa.st = b->d_w48; wa.coef_down = b->d_coef_down; wa.coef_up = b->d_coef_up;
+    if (feeding) {
+      wa.n_pre = b->B;
+      wa.in48 = r.d_in48 + (size_t)b->io_host * b->B * r.channels * 480;
+      wa.in16 = r.d_in16 + (size_t)b->io_host * b->B * B_IN_HOP;
+    }
+    if (r.deferred_slot >= 0) {
+      wa.n_post = b->B;
+      wa.out48 = r.d_out48 + (size_t)r.deferred_slot * b->B * r.channels * 480;
+      wa.model_out = r.d_out24 + (size_t)r.deferred_slot * b->B * B_OUT_HOP;
+      r.deferred_slot = -1;
+    }
+    hipLaunchKernelGGL(wrap48_tick_kernel, dim3(wa.n_pre + wa.n_post), dim3(256), 0, st, wa);
+  }
+  prof.lap(3);
+  fuse::StepPairs pairs;
+  for (int s = 0; s < fuse::kMaxStepPairs; ++s) { pairs.hop[s] = s < p.n_stages ? p.hop[s] : -1; pairs.io[s] = s < p.n_stages ? p.io[s] : 0; }
+  fuse::launch_table_w<4>(k.d_table, k.table_total, st, pairs);
+  if (b->r48.on) {  // the step this tick completed: its 48 kHz block is produced by the wrapper launch of the next tick (or of the drain)
+    const long long u = step_at(k.plan.count() - 1);
+    if (u >= 0) b->r48.deferred_slot = k.io_of_step[u % kRing];
+  }
+  if (feeding) {
+    b->last_parity = b->hop_host % 3;
+    b->last_hop = b->hop_host;
+    b->hop_host = hop_next(b->hop_host);
+    b->io_host = (b->io_host + 1) % b->io_slots;
+    b->steps_enqueued += 1;
+    k.n_fed += 1;
+    k.last_feed_tick = k.tick;
+  }
+  prof.lap(4);
+  k.tick += 1;
+  b->inflight = true;
+  return hip_ok(hipGetLastError(), "tick launch");
+}
+// ticks without new input until the last step fed has left the last stage
+// output half of one call of the any-rate wrapper around the ticks (BeatriceBatch_BindResidentBlocks): its block's inner
+// samples gathered from the resident model outputs, second resampling direction, output gain, into the call's slot
+bool rb_post(BeatriceBatch* b, const BeatriceBatch::ResidentBlocks::Job& j) {
+  BeatriceBatch::ResidentBlocks& r = b->rb;
+  const size_t nt = b->wrap.taps_down.size();
+  const int slot = (int)(j.call % r.n_slots), ge = (int)(j.call % r.ring);
+  hipLaunchKernelGGL(wrapn::wrap_post_kernel, dim3(b->B), dim3(256), 0, b->stream, r.d_out24, r.io_slots, b->B, j.t0, b->d_wrap,
+                     r.d_gains + (size_t)ge * 2 * b->B + b->B, b->d_wrap_taps + (j.dout.decimate ? 0 : nt), j.dout,
+                     r.d_out + (size_t)slot * b->B * r.channels * r.n, r.channels);
+  return hip_ok(hipGetLastError(), "wrapper output half");
+}
+bool tick_drain(BeatriceBatch* b) {
+  bool ok = true;
+  if (b->tk.on && b->tk.d_trace && b->tk.last_feed_tick == b->tk.tick - 1 && b->tk.n_fed > b->tk.plan.count()) {
+    // measurement aid: the tick just enqueued had every stage busy; dump its per-workgroup timeline (100 MHz wall clock)
+    std::vector<unsigned long long> tr((size_t)3 * b->tk.table_total);
+    if (hip_ok(hipStreamSynchronize(b->stream), "trace sync") &&
+        hip_ok(hipMemcpy(tr.data(), b->tk.d_trace, tr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost), "trace copy"))
+      if (FILE* f = std::fopen(std::getenv("BEATRICE_HIP_TICK_TRACE"), "w")) {
+        for (size_t i = 0; i < tr.size(); i += 3) std::fprintf(f, "%llu %llu %llu\n", tr[i], tr[i + 1], tr[i + 2]);
+        std::fclose(f);
+      }
+  }
+  while (ok && b->tk.on && b->tk.tick <= b->tk.last_feed_tick + b->tk.plan.count() - 1) ok = tick_run(b, false);
+  if (ok && b->r48.on && b->r48.deferred_slot >= 0) {  // the 48 kHz block of the step the last tick completed
+    BeatriceBatch::Resident48& r = b->r48;
+    Wrap48TickArgs wa{};
+    wa.channels = r.channels; wa.st = b->d_w48; wa.coef_down = b->d_coef_down; wa.coef_up = b->d_coef_up;
+    wa.n_post = b->B;
+    wa.out48 = r.d_out48 + (size_t)r.deferred_slot * b->B * r.channels * 480;
+    wa.model_out = r.d_out24 + (size_t)r.deferred_slot * b->B * B_OUT_HOP;
+    r.deferred_slot = -1;
+    hipLaunchKernelGGL(wrap48_tick_kernel, dim3(wa.n_post), dim3(256), 0, b->stream, wa);
+    ok = hip_ok(hipGetLastError(), "wrap48 flush");
+  }
+  while (ok && b->rb.on && !b->rb.jobs.empty()) {  // every model hop has left the pipeline: the output halves still owed, in order
+    ok = rb_post(b, b->rb.jobs.front());
+    b->rb.jobs.pop_front();
+  }
+  return ok;
+}
+int tick_enable(BeatriceBatch* b, bool on) {
+  using namespace tick;
+  State& k = b->tk;
+  if (on == k.on) return 0;
+  if (on) {
+    // one 10 ms hop per step, resident I/O with enough slots
+    // that a step's input is still there when the pitch head reads it nine ticks on and outputs have somewhere to land
+    if (b->H != 1 || b->B > 4096 || b->io_slots < k.plan.count() + 1) return -1;
+    if (!sync_all(b)) return -2;
+    if (b->pipelined) { drop_graph(b); set_plan(b, 1); }
+    k.snap_bytes = b->off.front_bytes + b->off.wave_bytes;
+    if (!k.d_table) {
+      if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_table), sizeof(Tab)), "tick table") ||
+          !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_snap), k.snap_bytes * kRing), "tick snapshots") ||
+          !hip_ok(hipHostMalloc(reinterpret_cast<void**>(&k.h_stage), k.snap_bytes * State::kStaging, hipHostMallocDefault), "tick staging"))
+        return -2;
+      for (hipEvent_t& e : k.stage_ev) if (!hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "tick staging event")) return -2;
+    }
+    if (!hip_ok(hipDeviceSynchronize(), "tick sync")) return -2;
+    k.tick = 0; k.n_fed = 0; k.last_feed_tick = -1000; k.snap_cur = -1; k.snap_next = 0;
+    for (long long& f : k.fed_step) f = -1;
+    k.table_dirty = true;
+    k.on = true;
+    for (int blk = 0; blk < B_NBLOCKS; ++blk) rebuild_tiles(b, blk);  // (tick mode cuts the attention rows into tiles AND quads)
+    return 0;
+  }
+  if (!sync_all(b)) return -2;  // drains
+  k.on = false;
+  for (int blk = 0; blk < B_NBLOCKS; ++blk) rebuild_tiles(b, blk);
+  // the in-order chain reads its counters from device memory: hand them the host's values
+  const int pair[2] = {b->hop_host, b->io_host};
+  if (!hip_ok(hipMemcpy(b->d_hop_next, pair, sizeof(pair), hipMemcpyHostToDevice), "tick leave")) return -2;
+  b->front_dirty = true;
+  for (bool& w : b->wave_dirty) w = true;
+  return 0;
+}
+

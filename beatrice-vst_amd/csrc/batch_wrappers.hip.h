@@ -1,0 +1,318 @@
+// batch_wrappers.hip.h -- the host-side wrappers of the batch API: 48 kHz blocks (in order and around the ticks), any host rate with gains (in order and around the ticks)
+// (Part of batch.hip's translation unit: included there, after struct BeatriceBatch and the helpers above it; not a stand-alone header.)
+#pragma once
+
+// ---- 48 kHz blocks with the wrapper on the device ----------------------------------------------
+static bool step_48k(BeatriceBatch* b, const float* d_in48, float* d_out48, int channels) {
+  // the FIFO of the reference emits the PREVIOUS block's model output first (resample.h:346-361)
+  hipLaunchKernelGGL(wrap48_post_kernel, dim3(b->B), dim3(256), 0, b->stream, b->d_w48, b->d_coef_up, d_out48, channels);
+  hipLaunchKernelGGL(wrap48_pre_kernel, dim3(b->B), dim3(256), 0, b->stream, d_in48, channels, b->d_w48, b->d_coef_down, b->d_in);
+  if (!step_device(b, nullptr, nullptr)) return false;
+  hipLaunchKernelGGL(wrap48_latch_kernel, dim3((b->B * 240 + 255) / 256), dim3(256), 0, b->stream, b->d_w48, b->wave.d_out, b->B);
+  return hip_ok(hipGetLastError(), "wrap48");
+}
+// Throughput form of the 48 kHz wrapper: n_slots resident 48 kHz blocks per direction, the tick pipeline between them.
+// Block k (BeatriceBatch_ConvertBlocks48kDevice(b, NULL, NULL, channels)) is read from slot k mod n_slots; its converted
+// block lands in the same slot of d_out48 BeatriceBatch_TickStages() - 1 calls later (or after BeatriceBatch_Synchronize).
+// Same samples as the in-order BeatriceBatch_ConvertBlocks48kDevice.  NULL pointers unbind.
+int BeatriceBatch_BindResidentIO48k(BeatriceBatch* b, const float* d_in48, float* d_out48, int channels, int n_slots) {
+  const DeviceScope dev_(b ? b->device : -1);
+  if (!b || !b->ok) return -2;
+  BeatriceBatch::Resident48& r = b->r48;
+  if (r.on) {
+    if (!sync_all(b)) return -2;
+    const int rc = tick_enable(b, false);
+    if (rc) return rc;
+    (void)BeatriceBatch_BindResidentIO(b, nullptr, nullptr, 0);
+    if (r.d_in16) (void)hipFree(r.d_in16);
+    if (r.d_out24) (void)hipFree(r.d_out24);
+    r = BeatriceBatch::Resident48{};
+  }
+  if (!d_in48 && !d_out48) return 0;
+  if (!d_in48 || !d_out48 || channels < 1 || channels > 2 || n_slots < b->tk.plan.count() + 1 || b->H != 1 || b->io_slots > 0 || b->pipelined ||
+      b->tk.on || b->hs.on)
+    return -1;
+  bool ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_in16), sizeof(float) * n_slots * b->B * B_IN_HOP), "r48 in16") &&
+            hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_out24), sizeof(float) * n_slots * b->B * B_OUT_HOP), "r48 out24") &&
+            hip_ok(hipMemset(r.d_in16, 0, sizeof(float) * n_slots * b->B * B_IN_HOP), "r48 zero");
+  ok = ok && BeatriceBatch_BindResidentIO(b, r.d_in16, r.d_out24, n_slots) == 0 && tick_enable(b, true) == 0;
+  if (!ok) {
+    (void)tick_enable(b, false);
+    (void)BeatriceBatch_BindResidentIO(b, nullptr, nullptr, 0);
+    if (r.d_in16) (void)hipFree(r.d_in16);
+    if (r.d_out24) (void)hipFree(r.d_out24);
+    r = BeatriceBatch::Resident48{};
+    return -2;
+  }
+  r.d_in48 = d_in48; r.d_out48 = d_out48; r.channels = channels; r.n_slots = n_slots; r.on = true;
+  return 0;
+}
+int BeatriceBatch_ConvertBlocks48kDevice(BeatriceBatch* b, const float* d_in, float* d_out, int channels) {
+  const DeviceScope dev_(b ? b->device : -1);
+  if (!b || !b->ok) return -2;
+  if (b->r48.on) return (!d_in && !d_out && channels == b->r48.channels) ? (tick_run(b, true) ? 0 : -2) : -1;
+  if (channels < 1 || channels > 2 || !d_in || !d_out || b->H != 1 || b->io_slots > 0 || b->pipelined || b->tk.on) return -1;  // per 10 ms block, in order
+  return step_48k(b, d_in, d_out, channels) ? 0 : -2;
+}
+int BeatriceBatch_ConvertBlocks48k(BeatriceBatch* b, const float* in, float* out, int channels) {
+  const DeviceScope dev_(b ? b->device : -1);
+  if (!b || !b->ok) return -2;
+  if (channels < 1 || channels > 2 || !in || !out || b->H != 1 || b->io_slots > 0 || b->pipelined || b->tk.on) return -1;
+  const size_t n = (size_t)b->B * channels * 480;
+  float* h_in = b->h_io48;
+  float* h_out = b->h_io48 + (size_t)b->B * 2 * 480;
+  float* d_in = b->d_io48;
+  float* d_out = b->d_io48 + (size_t)b->B * 2 * 480;
+  std::memcpy(h_in, in, sizeof(float) * n);
+  bool ok = hip_ok(hipMemcpyAsync(d_in, h_in, sizeof(float) * n, hipMemcpyHostToDevice, b->stream), "in48");
+  ok = ok && step_48k(b, d_in, d_out, channels);
+  ok = ok && hip_ok(hipMemcpyAsync(h_out, d_out, sizeof(float) * n, hipMemcpyDeviceToHost, b->stream), "out48");
+  ok = hip_ok(hipStreamSynchronize(b->stream), "sync") && ok;
+  b->inflight = false;
+  if (ok) std::memcpy(out, h_out, sizeof(float) * n);
+  else std::memset(out, 0, sizeof(float) * n);
+  return ok ? 0 : -2;
+}
+
+// ---- host-rate blocks with the whole wrapper on the device (wrapper.hip.h) -------------------------------------------
+namespace { constexpr int kInnerStride = wrapn::kMaxSamples + 64; }
+int BeatriceBatch_ConfigureWrapper(BeatriceBatch* b, double sample_rate) {
+  const DeviceScope dev_(b ? b->device : -1);
+  if (!b || !b->ok) return -2;
+  if (b->H != 1) return -1;
+  if (!sync_all(b)) return -2;
+  if (!b->wrap.configure(sample_rate)) return -1;  // rate <= 0, or a ratio whose filter history exceeds the state block
+  const int B = b->B;
+  const size_t nt = b->wrap.taps_down.size();
+  bool ok = true;
+  if (!b->d_wrap) {
+    ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_wrap), sizeof(wrapn::StreamState) * B), "wrap state") &&
+         hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_wrap_inner), sizeof(float) * B * kInnerStride), "wrap inner") &&
+         hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_wrap_io), sizeof(float) * B * 4 * wrapn::kMaxSamples), "wrap io") &&
+         hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_wrap_io), sizeof(float) * B * 4 * wrapn::kMaxSamples, hipHostMallocDefault), "wrap io host") &&
+         b->wrap_gains.alloc_host(2 * (size_t)B) &&
+         hip_ok(hipMalloc(reinterpret_cast<void**>(&b->wrap_gains.d), sizeof(wrapn::GainSeg) * 2 * B), "wrap gains");
+    b->gain_in.assign(B, wrapn::GainClock());
+    b->gain_out.assign(B, wrapn::GainClock());
+  }
+  if (b->d_wrap_taps) { (void)hipFree(b->d_wrap_taps); b->d_wrap_taps = nullptr; }
+  ok = ok && hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_wrap_taps), sizeof(float) * 2 * nt), "wrap taps") &&
+       hip_ok(hipMemcpy(b->d_wrap_taps, b->wrap.taps_down.data(), sizeof(float) * nt, hipMemcpyHostToDevice), "taps down") &&
+       hip_ok(hipMemcpy(b->d_wrap_taps + nt, b->wrap.taps_up.data(), sizeof(float) * nt, hipMemcpyHostToDevice), "taps up") &&
+       hip_ok(hipMemset(b->d_wrap, 0, sizeof(wrapn::StreamState) * B), "wrap state0") && hip_ok(hipDeviceSynchronize(), "wrap sync");
+  b->wrap_gains_constant = false;
+  // (a new rate restarts the resampler and the FIFO as the reference's SetSampleRate does; the gains keep their state,
+  //  now ramping at the new rate: reference processor_core_2.cc:421-429)
+  return ok ? 0 : -2;
+}
+// reference ProcessorCore2::SetInputGain / SetOutputGain (processor_core_2.cc:488-496): the target; the ramp follows at 2 dB/ms
+int BeatriceBatch_SetInputGain(BeatriceBatch* b, int stream, double db) {
+  const DeviceScope dev_(b ? b->device : -1);
+  if (!b || !b->ok) return -2;
+  if (stream < -1 || stream >= b->B || b->gain_in.empty()) return -1;
+  for (int s = (stream < 0 ? 0 : stream); s < (stream < 0 ? b->B : stream + 1); ++s) b->gain_in[s].target_db = db;
+  return 0;
+}
+int BeatriceBatch_SetOutputGain(BeatriceBatch* b, int stream, double db) {
+  const DeviceScope dev_(b ? b->device : -1);
+  if (!b || !b->ok) return -2;
+  if (stream < -1 || stream >= b->B || b->gain_out.empty()) return -1;
+  for (int s = (stream < 0 ? 0 : stream); s < (stream < 0 ? b->B : stream + 1); ++s) b->gain_out[s].target_db = db;
+  return 0;
+}
+static bool wrap_chunk(BeatriceBatch* b, const float* d_in, float* d_out, int channels, int n) {
+  using namespace wrapn;
+  const int B = b->B;
+  hipStream_t st = b->stream;
+  WrapPlan& w = b->wrap;
+  // gains: this call's segment per stream; the device copy is refreshed unless it already holds the same constants
+  bool all_constant = true;
+  GainSeg* seg = b->wrap_gains.h;
+  for (int s = 0; s < B; ++s) {
+    const GainSeg gi = b->gain_in[s].advance(n, w.rate), go = b->gain_out[s].advance(n, w.rate);
+    all_constant = all_constant && gi.step == 1.0 && go.step == 1.0 && seg[s].step == 1.0 && seg[B + s].step == 1.0 &&
+                   seg[s].amp0 == gi.amp0 && seg[B + s].amp0 == go.amp0;
+    seg[s] = gi;
+    seg[B + s] = go;
+  }
+  if (!(all_constant && b->wrap_gains_constant)) {
+    const size_t off = 0, len = 2 * (size_t)B;
+    GainSeg* dst = nullptr;
+    if (!b->wrap_gains.push_parts(st, 1, &off, &len, &dst)) return false;
+    b->wrap_gains_constant = all_constant;
+  }
+  const size_t nt = w.taps_down.size();
+  const Dir din = w.to_inner(n);
+  const int m = din.n_out;
+  if (m < 0 || m > kMaxSamples) return false;
+  hipLaunchKernelGGL(wrap_in_kernel, dim3(B), dim3(256), 0, st, d_in, channels, n, b->d_wrap, b->wrap_gains.d, b->d_wrap_taps + (din.decimate ? 0 : nt), din,
+                     b->d_wrap_inner, kInnerStride);
+  for (int at = 0; at < m;) {  // the exact-480 FIFO; a model hop every time it fills
+    const int take = std::min(kBlock - w.fill, m - at);
+    const int fires = w.fill + take == kBlock ? 1 : 0;
+    hipLaunchKernelGGL(wrap_fifo_kernel, dim3(B), dim3(256), 0, st, b->d_wrap_inner, kInnerStride, b->d_wrap, at, w.fill, take, fires, b->d_in);
+    if (fires) {
+      if (!step_device(b, nullptr, nullptr)) return false;
+      hipLaunchKernelGGL(wrap_refill_kernel, dim3((B * kBlock + 255) / 256), dim3(256), 0, st, b->d_wrap, b->wave.d_out, B);
+      w.fill = 0;
+    } else {
+      w.fill += take;
+    }
+    at += take;
+  }
+  const Dir dout = w.to_outer(m);
+  if (dout.n_out != n) return false;  // the two clocks are coupled so that a block comes back with its own length
+  hipLaunchKernelGGL(wrap_out_kernel, dim3(B), dim3(256), 0, st, b->d_wrap_inner, kInnerStride, b->d_wrap, b->wrap_gains.d + B,
+                     b->d_wrap_taps + (dout.decimate ? 0 : nt), dout, d_out, channels);
+  return hip_ok(hipGetLastError(), "wrapper launch");
+}
+static int wrap_max_chunk(const BeatriceBatch* b) {  // host samples per launch so that neither side exceeds the kernels' LDS buffers
+  const double r = b->wrap.rate / 48000.0;
+  return std::max(1, (int)std::floor((wrapn::kMaxSamples - 8) * std::min(1.0, r)));
+}
+// in / out: [B][channels][n] planar at the configured host rate; any n >= 1 (long blocks are processed in pieces)
+int BeatriceBatch_ProcessBlocksDevice(BeatriceBatch* b, const float* d_in, float* d_out, int channels, int n) {
+  const DeviceScope dev_(b ? b->device : -1);
+  if (!b || !b->ok) return -2;
+  if (b->rb.on) return (!d_in && !d_out && channels == b->rb.channels && n == b->rb.n) ? (rb_step(b) ? 0 : -2) : -1;
+  if (!b->wrap.ready || channels < 1 || channels > 2 || !d_in || !d_out || n < 1 || b->H != 1 || b->io_slots > 0 || b->pipelined || b->tk.on) return -1;
+  const int piece = wrap_max_chunk(b);
+  if (n <= piece) return wrap_chunk(b, d_in, d_out, channels, n) ? 0 : -2;
+  return -1;  // the planar layout [B][channels][n] cannot be cut without copies: callers pass blocks of at most `piece` samples
+}
+int BeatriceBatch_MaxWrapperBlock(const BeatriceBatch* b) { return b && b->ok && b->wrap.ready ? wrap_max_chunk(b) : 0; }
+
+// ---- the same wrapper around the TICK pipeline (throughput form, resident blocks) ------------------------------------------------
+// One call = one host-rate block per stream from slot `call mod n_slots` of d_in: gains and the first resampling direction, the
+// 480-sample accumulation, a model hop into the tick pipeline every time it fills (one tick per hop, at least one tick per
+// call so that a hop is out of the pipeline TickStages() - 1 calls after it went in); then the output half of the call made
+// `delay` = TickStages() - 1 calls ago, into ITS slot of d_out.  Everything that is control is on the host, as in wrap_chunk.
+static void rb_release(BeatriceBatch* b) {
+  BeatriceBatch::ResidentBlocks& r = b->rb;
+  if (r.d_in16) (void)hipFree(r.d_in16);
+  if (r.d_out24) (void)hipFree(r.d_out24);
+  if (r.d_gains) (void)hipFree(r.d_gains);
+  if (r.h_gains) (void)hipHostFree(r.h_gains);
+  if (r.gain_ev) { for (int i = 0; i < r.ring; ++i) if (r.gain_ev[i]) (void)hipEventDestroy(r.gain_ev[i]); delete[] r.gain_ev; }
+  r = BeatriceBatch::ResidentBlocks{};
+}
+static bool rb_step(BeatriceBatch* b) {
+  using namespace wrapn;
+  BeatriceBatch::ResidentBlocks& r = b->rb;
+  const int B = b->B, n = r.n;
+  hipStream_t st = b->stream;
+  WrapPlan& w = b->wrap;
+  const long long call = r.calls;
+  const int ge = (int)(call % r.ring);
+  // this call's gain segments: input half now, output half when its job runs
+  if (call >= r.ring && !hip_ok(hipEventSynchronize(r.gain_ev[ge]), "wrapper gain ring")) return false;
+  GainSeg* seg = r.h_gains + (size_t)ge * 2 * B;
+  for (int s = 0; s < B; ++s) { seg[s] = b->gain_in[s].advance(n, w.rate); seg[B + s] = b->gain_out[s].advance(n, w.rate); }
+  GainSeg* dseg = r.d_gains + (size_t)ge * 2 * B;
+  BHIP_TRY(hipMemcpyAsync(dseg, seg, sizeof(GainSeg) * 2 * B, hipMemcpyHostToDevice, st));
+  BHIP_TRY(hipEventRecord(r.gain_ev[ge], st));
+  const size_t nt = w.taps_down.size();
+  const Dir din = w.to_inner(n);
+  const int m = din.n_out;
+  if (m < 0 || m > kMaxSamples) return false;
+  const Dir dout = w.to_outer(m);
+  if (dout.n_out != n) return false;
+  const float* src = r.d_in + (size_t)(call % r.n_slots) * B * r.channels * n;
+  hipLaunchKernelGGL(wrap_in_kernel, dim3(B), dim3(256), 0, st, src, r.channels, n, b->d_wrap, dseg, b->d_wrap_taps + (din.decimate ? 0 : nt), din,
+                     b->d_wrap_inner, kInnerStride);
+  int ticks = 0;
+  for (int at = 0; at < m;) {  // the 480-sample accumulation; a model hop every time it fills (the per-stream FIFO array holds it)
+    const int take = std::min(kBlock - w.fill, m - at);
+    const int fires = w.fill + take == kBlock ? 1 : 0;
+    hipLaunchKernelGGL(wrap_fifo_kernel, dim3(B), dim3(256), 0, st, b->d_wrap_inner, kInnerStride, b->d_wrap, at, w.fill, take, fires,
+                       r.d_in16 + (size_t)b->io_host * B * B_IN_HOP);
+    if (fires) {
+      if (!tick_run(b, true)) return false;
+      ++ticks;
+      w.fill = 0;
+    } else {
+      w.fill += take;
+    }
+    at += take;
+  }
+  if (ticks == 0 && !tick_run(b, false)) return false;   // the pipeline advances with every call
+  r.jobs.push_back(BeatriceBatch::ResidentBlocks::Job{call, r.t48, dout});
+  r.t48 += m;
+  r.calls = call + 1;
+  bool ok = true;
+  while (ok && !r.jobs.empty() && r.jobs.front().call + r.delay <= call) {
+    ok = rb_post(b, r.jobs.front());
+    r.jobs.pop_front();
+  }
+  b->inflight = true;
+  return ok;
+}
+// d_in / d_out: [n_slots][B][channels][n] planar blocks at the configured host rate (BeatriceBatch_ConfigureWrapper first).
+// Call k (BeatriceBatch_ProcessBlocksDevice(b, NULL, NULL, channels, n)) reads slot k mod n_slots; its output block is in the
+// same slot of d_out BeatriceBatch_ResidentBlocksDelay() calls later (or after BeatriceBatch_Synchronize).  Same samples as
+// the in-order BeatriceBatch_ProcessBlocksDevice.  n_slots > delay + 1.  NULL pointers unbind.
+int BeatriceBatch_BindResidentBlocks(BeatriceBatch* b, const float* d_in, float* d_out, int channels, int n, int n_slots) {
+  const DeviceScope dev_(b ? b->device : -1);
+  if (!b || !b->ok) return -2;
+  BeatriceBatch::ResidentBlocks& r = b->rb;
+  if (r.on) {
+    if (!sync_all(b)) return -2;
+    const int rc = tick_enable(b, false);
+    if (rc) return rc;
+    (void)BeatriceBatch_BindResidentIO(b, nullptr, nullptr, 0);
+    rb_release(b);
+  }
+  if (!d_in && !d_out) return 0;
+  const int stages = b->tk.plan.count();
+  if (!b->wrap.ready || !d_in || !d_out || channels < 1 || channels > 2 || n < 1 || n > wrap_max_chunk(b) || n_slots < stages + 1 || b->H != 1 ||
+      b->io_slots > 0 || b->pipelined || b->tk.on || b->hs.on || b->r48.on)
+    return -1;
+  if (!sync_all(b)) return -2;
+  // model hops a call can fire: ceil(inner samples / 480) + 1; a hop's resident output is read until `delay` calls after the
+  // call in which the NEXT hop fired
+  const int m_max = (int)std::ceil(n * 48000.0 / b->wrap.rate) + 2, hops_per_call = (m_max + wrapn::kBlock - 1) / wrapn::kBlock + 1;
+  r.delay = stages - 1;
+  r.ring = r.delay + 3;
+  r.io_slots = std::max(stages + 1, (r.delay + 2) * hops_per_call + 2);
+  const int B = b->B;
+  bool ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_in16), sizeof(float) * r.io_slots * B * B_IN_HOP), "rb in16") &&
+            hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_out24), sizeof(float) * r.io_slots * B * B_OUT_HOP), "rb out24") &&
+            hip_ok(hipMemset(r.d_in16, 0, sizeof(float) * r.io_slots * B * B_IN_HOP), "rb zero") &&
+            hip_ok(hipMemset(r.d_out24, 0, sizeof(float) * r.io_slots * B * B_OUT_HOP), "rb zero") &&
+            hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_gains), sizeof(wrapn::GainSeg) * r.ring * 2 * B), "rb gains") &&
+            hip_ok(hipHostMalloc(reinterpret_cast<void**>(&r.h_gains), sizeof(wrapn::GainSeg) * r.ring * 2 * B, hipHostMallocDefault), "rb gains host");
+  if (ok) {
+    r.gain_ev = new hipEvent_t[r.ring]();
+    for (int i = 0; i < r.ring && ok; ++i) ok = hip_ok(hipEventCreateWithFlags(&r.gain_ev[i], hipEventDisableTiming), "rb event");
+  }
+  ok = ok && hip_ok(hipDeviceSynchronize(), "rb sync") && BeatriceBatch_BindResidentIO(b, r.d_in16, r.d_out24, r.io_slots) == 0 && tick_enable(b, true) == 0;
+  if (!ok) {
+    (void)tick_enable(b, false);
+    (void)BeatriceBatch_BindResidentIO(b, nullptr, nullptr, 0);
+    rb_release(b);
+    return -2;
+  }
+  r.d_in = d_in; r.d_out = d_out; r.channels = channels; r.n = n; r.n_slots = n_slots; r.on = true;
+  return 0;
+}
+int BeatriceBatch_ResidentBlocksDelay(const BeatriceBatch* b) { return b && b->ok && b->rb.on ? b->rb.delay : -1; }
+int BeatriceBatch_ProcessBlocks(BeatriceBatch* b, const float* in, float* out, int channels, int n) {
+  const DeviceScope dev_(b ? b->device : -1);
+  if (!b || !b->ok) return -2;
+  if (!b->wrap.ready || channels < 1 || channels > 2 || !in || !out || n < 1 || n > wrap_max_chunk(b) || b->H != 1 || b->io_slots > 0 || b->pipelined || b->tk.on) return -1;
+  const size_t cnt = (size_t)b->B * channels * n;
+  float* h_in = b->h_wrap_io;
+  float* h_out = b->h_wrap_io + (size_t)b->B * 2 * wrapn::kMaxSamples;
+  float* d_in = b->d_wrap_io;
+  float* d_out = b->d_wrap_io + (size_t)b->B * 2 * wrapn::kMaxSamples;
+  std::memcpy(h_in, in, sizeof(float) * cnt);
+  bool ok = hip_ok(hipMemcpyAsync(d_in, h_in, sizeof(float) * cnt, hipMemcpyHostToDevice, b->stream), "wrap in");
+  ok = ok && wrap_chunk(b, d_in, d_out, channels, n);
+  ok = ok && hip_ok(hipMemcpyAsync(h_out, d_out, sizeof(float) * cnt, hipMemcpyDeviceToHost, b->stream), "wrap out");
+  ok = hip_ok(hipStreamSynchronize(b->stream), "wrap sync") && ok;
+  b->inflight = false;
+  if (ok) std::memcpy(out, h_out, sizeof(float) * cnt);
+  else std::memset(out, 0, sizeof(float) * cnt);
+  return ok ? 0 : -2;
+}
+
