@@ -438,6 +438,8 @@ def bind_batch(abi):
     if getattr(abi, "_batch_bound", False):
         return abi
     for name, (res, args) in _BATCH.items():
+        if os.environ.get("BEATRICE_HIP_LIB") and not hasattr(abi.lib, name):
+            continue   # an older build of the library loaded for an A/B measurement: it simply lacks the newer entry points
         fn = getattr(abi.lib, name)
         fn.restype, fn.argtypes = res, args
         setattr(abi, name, fn)
