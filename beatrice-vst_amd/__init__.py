@@ -386,6 +386,8 @@ _BATCH = {
     "BeatriceBatch_UpdateSpeaker": (C.c_int, [_vp, C.c_int, _f32p, _f32p, _f32p]),
     "BeatriceBatch_SeedLottery": (C.c_int, [_vp, C.c_int, C.c_uint]),
     "BeatriceBatch_MorphSpeaker": (C.c_int, [_vp, C.c_int, _f32p, C.c_int, C.c_uint]),
+    "BeatriceBatch_EnableSilentBlockRule": (C.c_int, [_vp, C.c_int]),
+    "BeatriceBatch_SetSilentStreams": (C.c_int, [_vp, C.c_char_p]),
     "BeatriceBatch_BindResidentBlocks": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int]),
     "BeatriceBatch_ResidentBlocksDelay": (C.c_int, [_vp]),
     "BeatriceBatch_MorphSpeakerStaged": (C.c_int, [_vp, C.c_int, C.c_int, _f32p, C.c_int, C.c_uint]),

@@ -224,6 +224,19 @@ struct BeatriceBatch {
     int deferred_slot = -1;                       // step completed by the last tick, its 48 kHz block not yet produced
   } r48;
   float *d_coef_down = nullptr, *d_coef_up = nullptr, *d_io48 = nullptr, *h_io48 = nullptr;  // io: in [B][2][480] | out [B][2][480]
+  // The shell's silent-block rule per stream (BeatriceBatch_EnableSilentBlockRule; kernels_misc.hip.h freeze_*): streams
+  // flagged for the next 48 kHz block stand still -- model state, wrapper state, key/value installs, codebook lottery
+  struct SilentRule {
+    bool on = false;
+    std::vector<unsigned char> next;    // [B] flags of the step to come (cleared by the step)
+    bool any_next = false;
+    unsigned char *d_flags = nullptr, *h_flags = nullptr;   // [4][B]: a step's flags on the device / their pinned staging (four steps deep)
+    FreezeRing* d_rings = nullptr;
+    int n_rings = 0;
+    float* d_keep = nullptr;            // copies of the single-slot rings, all streams
+    int* d_keep_prev_q = nullptr;       // [B]
+    long long steps = 0;
+  } silent;
   // The any-rate wrapper around the tick pipeline (BeatriceBatch_BindResidentBlocks): host-rate blocks resident on the device,
   // the input half of the chain in front of the ticks, the output half `delay` calls later (wrapper.hip.h wrap_post_kernel)
   struct ResidentBlocks {
@@ -368,6 +381,7 @@ void advance_kv(BeatriceBatch* b) {
   const int H = b->H;
   for (int s = 0; s < b->B; ++s) {
     StreamCfg& c = b->cfg[s];
+    if (b->silent.any_next && b->silent.next[s]) continue;   // a silent block: the reference does not reach its per-hop protocol
     for (int hh = 0; hh < H; ++hh) {  // the hops of this step, each preceded by one block install
       if (c.kv_delay > 0) {
         --c.kv_delay;
@@ -481,6 +495,7 @@ void draw_codebooks(BeatriceBatch* b) {
     StreamCfg& c = b->cfg[s];
     MorphSlot& m = b->morph[c.target_speaker];
     if (!m.active) continue;
+    if (b->silent.any_next && b->silent.next[s]) continue;   // no hop, no draw
     std::mt19937& rng = b->lottery[s];
     float sum = 0.0f;
     for (int i = 0; i < m.n_odds; ++i) sum += m.odds[i];
@@ -629,6 +644,7 @@ int model_ready(Model* m) {
 extern "C" {
 static bool rb_step(BeatriceBatch* b);
 static void rb_release(BeatriceBatch* b);
+static void silent_release(BeatriceBatch* b);
 
 // ---- memory loaders ---------------------------------------------------------------------------
 #define BHIP_MEMORY_LOADER(Name, Obj, KIND, Weights)                                                        \
@@ -823,6 +839,7 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   if (b->r48.d_in16) (void)hipFree(b->r48.d_in16);
   if (b->r48.d_out24) (void)hipFree(b->r48.d_out24);
   rb_release(b);
+  silent_release(b);
   if (b->own_d_out) { b->wave.d_out = b->own_d_out; b->own_d_out = nullptr; }
   if (b->io_mapped) { b->wave.d_out = b->dev_d_out; b->phone.d_in = b->pitch.d_in = b->d_in; b->io_mapped = false; }  // (the modules free what they allocated)
   if (b->module_owned[0]) {  // hand the modules their own arrays back so that destroy() frees what it allocated

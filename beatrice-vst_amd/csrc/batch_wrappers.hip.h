@@ -4,12 +4,86 @@
 
 // ---- 48 kHz blocks with the wrapper on the device ----------------------------------------------
 static bool step_48k(BeatriceBatch* b, const float* d_in48, float* d_out48, int channels) {
+  BeatriceBatch::SilentRule& sr = b->silent;
+  const unsigned char* frozen = nullptr;
+  if (sr.on && sr.any_next) {   // this step's flags travel to the device (a ring of four staging copies: the host runs at most a step ahead)
+    const int e = (int)(sr.steps & 3);
+    unsigned char* h = sr.h_flags + (size_t)e * b->B;
+    std::memcpy(h, sr.next.data(), b->B);
+    unsigned char* d = sr.d_flags + (size_t)e * b->B;
+    BHIP_TRY(hipMemcpyAsync(d, h, b->B, hipMemcpyHostToDevice, b->stream));
+    frozen = d;
+  }
+  if (sr.on) ++sr.steps;
   // the FIFO of the reference emits the PREVIOUS block's model output first (resample.h:346-361)
-  hipLaunchKernelGGL(wrap48_post_kernel, dim3(b->B), dim3(256), 0, b->stream, b->d_w48, b->d_coef_up, d_out48, channels);
-  hipLaunchKernelGGL(wrap48_pre_kernel, dim3(b->B), dim3(256), 0, b->stream, d_in48, channels, b->d_w48, b->d_coef_down, b->d_in);
-  if (!step_device(b, nullptr, nullptr)) return false;
-  hipLaunchKernelGGL(wrap48_latch_kernel, dim3((b->B * 240 + 255) / 256), dim3(256), 0, b->stream, b->d_w48, b->wave.d_out, b->B);
+  hipLaunchKernelGGL(wrap48_post_kernel, dim3(b->B), dim3(256), 0, b->stream, b->d_w48, b->d_coef_up, d_out48, channels, frozen, d_in48);
+  hipLaunchKernelGGL(wrap48_pre_kernel, dim3(b->B), dim3(256), 0, b->stream, d_in48, channels, b->d_w48, b->d_coef_down, b->d_in, frozen);
+  if (frozen)
+    hipLaunchKernelGGL(freeze_save_kernel, dim3(sr.n_rings, b->B), dim3(256), 0, b->stream, sr.d_rings, sr.d_keep, b->B, b->pitch.d_prev_q, sr.d_keep_prev_q);
+  const bool ok = step_device(b, nullptr, nullptr);   // (advance_kv / draw_codebooks skip the flagged streams)
+  if (frozen) {
+    std::fill(sr.next.begin(), sr.next.end(), 0);
+    sr.any_next = false;
+  }
+  if (!ok) return false;
+  if (frozen)
+    hipLaunchKernelGGL(freeze_fix_kernel, dim3(sr.n_rings, b->B), dim3(256), 0, b->stream, sr.d_rings, sr.d_keep, b->B, frozen, b->last_hop,
+                       b->pitch.d_prev_q, sr.d_keep_prev_q);
+  hipLaunchKernelGGL(wrap48_latch_kernel, dim3((b->B * 240 + 255) / 256), dim3(256), 0, b->stream, b->d_w48, b->wave.d_out, b->B, frozen);
   return hip_ok(hipGetLastError(), "wrap48");
+}
+static void silent_release(BeatriceBatch* b) {
+  BeatriceBatch::SilentRule& sr = b->silent;
+  if (sr.d_flags) (void)hipFree(sr.d_flags);
+  if (sr.h_flags) (void)hipHostFree(sr.h_flags);
+  if (sr.d_rings) (void)hipFree(sr.d_rings);
+  if (sr.d_keep) (void)hipFree(sr.d_keep);
+  if (sr.d_keep_prev_q) (void)hipFree(sr.d_keep_prev_q);
+  sr = BeatriceBatch::SilentRule{};
+}
+// The shell's rule "a block whose down-mix is all zeros is not converted" (reference src/vst/processor.cc:204-214), per stream,
+// for the in-order 48 kHz blocks: BeatriceBatch_ConvertBlocks48k (host buffers) finds the silent streams itself, exactly as the
+// shell does (every sample of (L + R) * 0.5, or of L, equal to 0.0f); with device buffers the caller names them for the next
+// block with BeatriceBatch_SetSilentStreams.  A silent stream's output block is its (zero) down-mix on every channel; its model
+// state, its wrapper state (filter histories, the pending 10 ms of the FIFO), its pending key/value installs and its codebook
+// lottery stand still, as if the block had never existed.
+int BeatriceBatch_EnableSilentBlockRule(BeatriceBatch* b, int enable) {
+  const DeviceScope dev_(b ? b->device : -1);
+  if (!b || !b->ok) return -2;
+  BeatriceBatch::SilentRule& sr = b->silent;
+  if (!enable) { if (sr.on) { (void)sync_all(b); silent_release(b); } return 0; }
+  if (sr.on) return 0;
+  if (b->H != 1 || b->pipelined || b->tk.on || b->io_slots > 0) return -1;   // the in-order chain, one block per step
+  if (!sync_all(b)) return -2;
+  std::vector<FreezeRing> rings;
+  size_t keep = 0;
+  for (const RingArena* a : {&b->phone.arena, &b->pitch.arena, &b->wave.arena})
+    for (const Ring* r : a->rings) {
+      FreezeRing f{r->base, r->n * r->C, r->m, 0};
+      if (r->m == 1) { f.keep_off = keep; keep += (size_t)b->B * f.slot_floats; }
+      rings.push_back(f);
+    }
+  sr.n_rings = (int)rings.size();
+  bool ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&sr.d_rings), sizeof(FreezeRing) * rings.size()), "silent rings") &&
+            hip_ok(hipMemcpy(sr.d_rings, rings.data(), sizeof(FreezeRing) * rings.size(), hipMemcpyHostToDevice), "silent rings up") &&
+            hip_ok(hipMalloc(reinterpret_cast<void**>(&sr.d_keep), sizeof(float) * std::max<size_t>(keep, 1)), "silent keep") &&
+            hip_ok(hipMalloc(reinterpret_cast<void**>(&sr.d_keep_prev_q), sizeof(int) * b->B), "silent prev_q") &&
+            hip_ok(hipMalloc(reinterpret_cast<void**>(&sr.d_flags), 4 * (size_t)b->B), "silent flags") &&
+            hip_ok(hipHostMalloc(reinterpret_cast<void**>(&sr.h_flags), 4 * (size_t)b->B, hipHostMallocDefault), "silent flags host");
+  if (!ok) { silent_release(b); return -2; }
+  sr.next.assign(b->B, 0);
+  sr.any_next = false;
+  sr.on = true;
+  drop_graph(b);
+  return 0;
+}
+// streams whose NEXT 48 kHz block is silent by the shell's rule (flags[B], non-zero = silent); cleared by that block
+int BeatriceBatch_SetSilentStreams(BeatriceBatch* b, const unsigned char* flags) {
+  if (!b || !b->ok) return -2;
+  if (!b->silent.on || !flags) return -1;
+  b->silent.any_next = false;
+  for (int s = 0; s < b->B; ++s) { b->silent.next[s] = flags[s] ? 1 : 0; b->silent.any_next = b->silent.any_next || flags[s]; }
+  return 0;
 }
 // Throughput form of the 48 kHz wrapper: n_slots resident 48 kHz blocks per direction, the tick pipeline between them.
 // Block k (BeatriceBatch_ConvertBlocks48kDevice(b, NULL, NULL, channels)) is read from slot k mod n_slots; its converted
@@ -63,6 +137,21 @@ int BeatriceBatch_ConvertBlocks48k(BeatriceBatch* b, const float* in, float* out
   float* h_out = b->h_io48 + (size_t)b->B * 2 * 480;
   float* d_in = b->d_io48;
   float* d_out = b->d_io48 + (size_t)b->B * 2 * 480;
+  if (b->silent.on) {   // the shell's test, per stream: every sample of the down-mix equal to 0.0f
+    BeatriceBatch::SilentRule& sr = b->silent;
+    sr.any_next = false;
+    for (int st = 0; st < b->B; ++st) {
+      const float* src = in + (size_t)st * channels * 480;
+      bool sil = true;
+      for (int i = 0; i < 480 && sil; ++i) {
+        float m = src[i];
+        if (channels >= 2) { m = m + src[480 + i]; m = m * 0.5f; }
+        sil = !(m != 0.0f);
+      }
+      sr.next[st] = sil ? 1 : 0;
+      sr.any_next = sr.any_next || sil;
+    }
+  }
   std::memcpy(h_in, in, sizeof(float) * n);
   bool ok = hip_ok(hipMemcpyAsync(d_in, h_in, sizeof(float) * n, hipMemcpyHostToDevice, b->stream), "in48");
   ok = ok && step_48k(b, d_in, d_out, channels);

@@ -537,9 +537,54 @@ struct Wrap48State {   // per stream, floats
   float fpend[240];    // model output waiting in the 480-sample FIFO (emitted by the NEXT call)
 };
 
+// ---- the shell's silent-block rule per stream (reference src/vst/processor.cc:204-214: a block whose down-mix is all zeros is
+// not converted -- the core is not called, its state and its 10 ms FIFO stand still, the output is that down-mix) ------------
+// A batch advances all of its streams together and indexes every ring by the common step counter, so a stream cannot simply
+// be left out of a step.  Instead the step runs for every stream and the silent ones are put back afterwards: a ring with
+// m >= 2 step slots is ROTATED (slot of step t - k <- slot of step t - k - 1, k = 0 .. m - 2: seen from step t + 1 the
+// stream's history is what it was before the silent block; the slot the step wrote held step t - m, which nothing reads any
+// more), a single-slot ring (state updated in place: the tail's history block; scratch) and the pitch head's previous bin
+// are RESTORED from a copy taken before the step.
+struct FreezeRing { float* base; int slot_floats; int m; unsigned long long keep_off; };   // slot_floats = n C; keep_off: m == 1 only
+static __global__ __launch_bounds__(256) void freeze_save_kernel(const FreezeRing* __restrict__ rings, float* __restrict__ keep, const int B,
+                                                                 const int* __restrict__ prev_q, int* __restrict__ keep_prev_q) {
+  const FreezeRing r = rings[blockIdx.x];
+  const int b = blockIdx.y;
+  if (blockIdx.x == 0 && threadIdx.x == 0) keep_prev_q[b] = prev_q[b];
+  if (r.m != 1) return;
+  const float* src = r.base + (size_t)b * r.slot_floats;
+  float* dst = keep + r.keep_off + (size_t)b * r.slot_floats;
+  for (int i = threadIdx.x; i < r.slot_floats; i += 256) dst[i] = src[i];
+}
+static __global__ __launch_bounds__(256) void freeze_fix_kernel(const FreezeRing* __restrict__ rings, const float* __restrict__ keep, const int B,
+                                                                const unsigned char* __restrict__ frozen, const int hop,
+                                                                int* __restrict__ prev_q, const int* __restrict__ keep_prev_q) {
+  const int b = blockIdx.y;
+  if (!frozen[b]) return;
+  const FreezeRing r = rings[blockIdx.x];
+  if (blockIdx.x == 0 && threadIdx.x == 0) prev_q[b] = keep_prev_q[b];
+  float* base = r.base + (size_t)b * r.slot_floats * r.m;
+  if (r.m == 1) {
+    const float* src = keep + r.keep_off + (size_t)b * r.slot_floats;
+    for (int i = threadIdx.x; i < r.slot_floats; i += 256) base[i] = src[i];
+    return;
+  }
+  const int cur = hop % r.m;
+  for (int i = threadIdx.x; i < r.slot_floats; i += 256) {
+    int d = cur;
+    for (int k = 0; k + 1 < r.m; ++k) {   // (a thread touches element i of every slot only: no cross-thread ordering needed)
+      const int s = d == 0 ? r.m - 1 : d - 1;
+      base[(size_t)d * r.slot_floats + i] = base[(size_t)s * r.slot_floats + i];
+      d = s;
+    }
+  }
+}
+
 // mono = (L + R) * 0.5 (or L), 31-tap low-pass evaluated only at the samples the decimator keeps
+// (frozen != nullptr and frozen[b]: the stream's block is silent by the shell's rule -- nothing of its state moves)
 __device__ __forceinline__ void wrap48_pre_body(const int b, const float* __restrict__ in48, int channels, Wrap48State* __restrict__ st,
-                                                const float* __restrict__ coef_down, float* __restrict__ in16, float* __restrict__ lds) {
+                                                const float* __restrict__ coef_down, float* __restrict__ in16, float* __restrict__ lds,
+                                                const unsigned char* __restrict__ frozen = nullptr) {
   float* g = lds;        // [30 + 480]
   float* cd = lds + 512; // [33]
   const int tid = threadIdx.x;
@@ -559,13 +604,13 @@ __device__ __forceinline__ void wrap48_pre_body(const int b, const float* __rest
     for (int i = 0; i < 31; ++i) acc = acc + g[30 + p - i] * cd[1 + i];
     in16[(size_t)b * 160 + tid] = acc * 1.0f;
   }
-  if (tid < 30) st[b].hist_in[tid] = g[480 + tid];
+  if (tid < 30 && !(frozen && frozen[b])) st[b].hist_in[tid] = g[480 + tid];
 }
 static __global__ __launch_bounds__(256) void wrap48_pre_kernel(const float* __restrict__ in48, int channels,
                                                                 Wrap48State* __restrict__ st, const float* __restrict__ coef_down,
-                                                                float* __restrict__ in16) {
+                                                                float* __restrict__ in16, const unsigned char* __restrict__ frozen = nullptr) {
   __shared__ float lds[512 + 33];
-  wrap48_pre_body(blockIdx.x, in48, channels, st, coef_down, in16, lds);
+  wrap48_pre_body(blockIdx.x, in48, channels, st, coef_down, in16, lds, frozen);
 }
 
 // zero-stuffed previous model output through the 32-tap low-pass; writes every channel.  latch != nullptr: the model
@@ -594,15 +639,27 @@ __device__ __forceinline__ void wrap48_post_body(const int b, Wrap48State* __res
   if (tid < 16) st[b].ztail[tid] = f[16 + 224 + tid];
   if (latch != nullptr && tid < 240) st[b].fpend[tid] = latch[(size_t)b * 240 + tid];
 }
+// (frozen streams: the output block is the block's own down-mix -- zeros -- on every channel, the FIFO stands still)
 static __global__ __launch_bounds__(256) void wrap48_post_kernel(Wrap48State* __restrict__ st, const float* __restrict__ coef_up,
-                                                                 float* __restrict__ out48, int channels) {
+                                                                 float* __restrict__ out48, int channels, const unsigned char* __restrict__ frozen = nullptr,
+                                                                 const float* __restrict__ in48 = nullptr) {
   __shared__ float lds[256 + 33];
+  if (frozen && frozen[blockIdx.x]) {
+    const float* src = in48 + (size_t)blockIdx.x * channels * 480;
+    float* dst = out48 + (size_t)blockIdx.x * channels * 480;
+    for (int n = threadIdx.x; n < 480; n += 256) {
+      float m = src[n];
+      if (channels >= 2) { m = m + src[480 + n]; m = m * 0.5f; }
+      for (int c = 0; c < channels; ++c) dst[c * 480 + n] = m;
+    }
+    return;
+  }
   wrap48_post_body(blockIdx.x, st, coef_up, out48, channels, nullptr, lds);
 }
 
-static __global__ void wrap48_latch_kernel(Wrap48State* __restrict__ st, const float* __restrict__ model_out, int B) {
+static __global__ void wrap48_latch_kernel(Wrap48State* __restrict__ st, const float* __restrict__ model_out, int B, const unsigned char* __restrict__ frozen = nullptr) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < B * 240) st[idx / 240].fpend[idx % 240] = model_out[idx];
+  if (idx < B * 240 && !(frozen && frozen[idx / 240])) st[idx / 240].fpend[idx % 240] = model_out[idx];
 }
 
 // Both ends of the wrapper around one tick of the pipelined batch, one launch: workgroups [0, n_pre) turn the 48 kHz block

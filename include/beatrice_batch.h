@@ -176,6 +176,15 @@ int BeatriceBatch_ConvertBlocks48kDevice(BeatriceBatch* b, const float* d_in, fl
  * appears in the same slot of d_out48 BeatriceBatch_TickStages() - 1 calls later or after BeatriceBatch_Synchronize: the
  * samples of the in-order call, later.  NULL, NULL unbinds (and leaves tick mode). */
 int BeatriceBatch_BindResidentIO48k(BeatriceBatch* b, const float* d_in48, float* d_out48, int channels, int n_slots);
+/* The shell's rule "a block whose down-mix is all zeros is not converted: the core is not called, its state and its 10 ms FIFO
+ * stand still, the output is that down-mix" (reference src/vst/processor.cc:204-214), PER STREAM, for the in-order 48 kHz blocks
+ * (one hop per step, no pipelining).  Enabled, BeatriceBatch_ConvertBlocks48k finds the silent streams of every call itself with
+ * the shell's own test; for BeatriceBatch_ConvertBlocks48kDevice the caller flags them (flags[B], non-zero = silent) before the
+ * call, once per block.  A silent stream's model state, wrapper state, pending key/value installs and codebook lottery stand
+ * still as if the block had never existed (the batch runs the step for every stream and puts the silent ones back: rings rotated,
+ * in-place state restored). */
+int BeatriceBatch_EnableSilentBlockRule(BeatriceBatch* b, int enable);
+int BeatriceBatch_SetSilentStreams(BeatriceBatch* b, const unsigned char* flags);
 
 /* The same wrapper at ANY host rate and block size, with the dB-ramped gains (the whole of the reference's
  * ProcessorCore2::Process, src/common/processor_core_2.cc:24-48, per stream on the device): input gain (gain.h:41-71,
