@@ -350,13 +350,15 @@ int BeatriceBatch_BindResidentBlocks(BeatriceBatch* b, const float* d_in, float*
     if (rc) return rc;
     (void)BeatriceBatch_BindResidentIO(b, nullptr, nullptr, 0);
     rb_release(b);
+    (void)BeatriceBatch_ConfigureWrapper(b, b->wrap.rate);   // the wrapper restarts, as after a sample-rate change (the gains keep their state)
   }
   if (!d_in && !d_out) return 0;
   const int stages = b->tk.plan.count();
   if (!b->wrap.ready || !d_in || !d_out || channels < 1 || channels > 2 || n < 1 || n > wrap_max_chunk(b) || n_slots < stages + 1 || b->H != 1 ||
       b->io_slots > 0 || b->pipelined || b->tk.on || b->hs.on || b->r48.on)
     return -1;
-  if (!sync_all(b)) return -2;
+  // binding restarts the resampler pair and the FIFO (their in-order form keeps processed samples in the FIFO, this one does not)
+  if (BeatriceBatch_ConfigureWrapper(b, b->wrap.rate) != 0) return -2;
   // model hops a call can fire: ceil(inner samples / 480) + 1; a hop's resident output is read until `delay` calls after the
   // call in which the NEXT hop fired
   const int m_max = (int)std::ceil(n * 48000.0 / b->wrap.rate) + 2, hops_per_call = (m_max + wrapn::kBlock - 1) / wrapn::kBlock + 1;

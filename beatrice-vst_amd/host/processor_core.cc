@@ -252,6 +252,7 @@ ErrorCode ProcessorCore2::LoadModel(const std::filesystem::path& model_file) {
   BEATRICE_TRY_READ(Beatrice20rc0_ReadEmbeddingSetterParameters(embedding_setter_, reinterpret_cast<const char*>(path("embedding_setter.bin").c_str())))
   const auto spk = path("speaker_embeddings.bin");
   BEATRICE_TRY_READ(Beatrice20rc0_ReadNSpeakers(reinterpret_cast<const char*>(spk.c_str()), &n_speakers_))
+  if (n_speakers_ < 1) return ErrorCode::kInvalidFileSize;   // (a table without speakers: the morph lottery would draw from an empty range)
   const size_t slots = static_cast<size_t>(n_speakers_) + 1;  // + morph slot, zero-filled
   codebooks_.assign(slots * BEATRICE_20RC0_CODEBOOK_SIZE * BEATRICE_20RC0_PHONE_CHANNELS, 0.0f);
   additive_.assign(slots * BEATRICE_WAVEFORM_GENERATOR_HIDDEN_CHANNELS, 0.0f);

@@ -123,6 +123,7 @@ ErrorCode ProcessorCoreLegacy::LoadModel(const std::filesystem::path& model_file
   BEATRICE_TRY_READ(lib_.read_model[kWaveformGenerator](waveform_generator_, cstr(path("waveform_generator.bin"))))
   const auto spk = path("speaker_embeddings.bin");
   BEATRICE_TRY_READ(lib_.read_n_speakers(cstr(spk), &n_speakers_))
+  if (n_speakers_ < 1) return ErrorCode::kInvalidFileSize;   // (a table without rows: nothing to convert to, and no row to morph from)
   speaker_embeddings_.resize((static_cast<size_t>(n_speakers_) + 1) * kHidden, 0.0f);  // + morph slot
   BEATRICE_TRY_READ(lib_.read_rows(cstr(spk), speaker_embeddings_.data()))
   mean_.Initialize(n_speakers_, kHidden, speaker_embeddings_.data());

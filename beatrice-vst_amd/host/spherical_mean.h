@@ -104,6 +104,7 @@ class SphericalMean {
 
   // un-normalised combination of the ORIGINAL points with the converged coefficients
   void Result(float* out) const {
+    if (index_.empty()) { for (std::size_t l = 0; l < dim_; ++l) out[l] = 0.0f; return; }   // no points at all: nothing to combine
     const float* p0 = &raw_[index_[0] * dim_];
     for (std::size_t l = 0; l < dim_; ++l) out[l] = coef_[0] * p0[l];
     for (std::size_t n = 1; n < active_; ++n) Axpy(coef_[n], &raw_[index_[n] * dim_], out);

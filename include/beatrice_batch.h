@@ -209,7 +209,8 @@ int BeatriceBatch_MaxWrapperBlock(const BeatriceBatch* b);
  * Call k = BeatriceBatch_ProcessBlocksDevice(b, NULL, NULL, channels, n_samples) reads slot k mod n_slots; its output block is in
  * the same slot of d_out BeatriceBatch_ResidentBlocksDelay() (= TickStages() - 1) calls later, or after BeatriceBatch_Synchronize.
  * Gains (BeatriceBatch_SetInputGain / SetOutputGain) and every per-stream setting apply to the call that follows them, as in
- * order.  Same samples as BeatriceBatch_ProcessBlocksDevice in order.  n_slots >= TickStages() + 1.  NULL pointers unbind. */
+ * order.  Same samples as BeatriceBatch_ProcessBlocksDevice in order.  n_slots >= TickStages() + 1.  NULL pointers unbind.
+ * Binding and unbinding restart the wrapper (resampler histories, FIFO) as BeatriceBatch_ConfigureWrapper does; gains keep their state. */
 int BeatriceBatch_BindResidentBlocks(BeatriceBatch* b, const float* d_in, float* d_out, int channels, int n_samples, int n_slots);
 int BeatriceBatch_ResidentBlocksDelay(const BeatriceBatch* b);
 

@@ -208,3 +208,19 @@ def test_proxy_dispatches_on_the_package_version(bv, built, host_path, packages,
     assert np.array_equal(got, want) and np.abs(got).max() > 1e-3
     h.close()
     p.close()
+
+
+def test_a_speaker_table_without_rows_is_refused(bv, built, host_path, packages, tmp_path):
+    """A crafted package whose speaker file holds no row: LoadModel answers kInvalidFileSize and the core stays unloaded
+    (nothing may index an empty table: the morph solver's result, the formant row, the lottery)."""
+    import shutil
+    import struct
+    pkg = tmp_path / "empty"
+    shutil.copytree(packages[1], pkg)
+    (pkg / "speaker_embeddings.bin").write_bytes(struct.pack("<IIII", 0x43525442, 15, 1, 0))
+    h = LegacyHost(host_path, 48000, 1)
+    rc = h.load(str(pkg))
+    assert rc != 0
+    out, codes = h.process(wrapperlib.test_signal(480, 48000, seed=1), 480)
+    assert codes == [9] and not out.any()
+    h.close()
