@@ -85,3 +85,54 @@ def test_tick_soak_vs_oracle(bv, oracle, product, model_dir, B, steps):
     print("tick soak vs ORACLE: %d streams x %d steps, max-abs %g %s" % (B, steps, dev, "bit-identical" if np.array_equal(got, want) else ""))
     assert np.abs(got).max() > 0.05
     assert not bad, "steps beyond tolerance: %s" % bad[:20]
+
+
+def test_ragged_speaker_groups_in_tick_mode_match_oracle(bv, oracle, product, tmp_path):
+    """The attention half's row lists in tick mode (batch.hip rebuild_tiles): a K/V slot's rows fill whole 16-row tiles, a
+    remainder of >= 8 rows is one padded tile, a smaller one goes to pairs of quads (rowchain.hip.h block_bq_body).  53 streams
+    on 7 speakers in groups of 17, 9, 8, 7, 5, 4, 2 and 1 rows -- a full tile + a single row, padded tiles of 9 and 8, quads of
+    4 + 3, 4 + 1, 4, 2 and 1 rows, a pair with an empty second quad -- with speaker switches on the way that move rows between
+    the lists (K/V blocks one per hop: blocks of one stream sit on different slots meanwhile); every stream against the oracle."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import make_model
+    model_dir = str(tmp_path / "m8")
+    os.makedirs(model_dir)
+    make_model.make_model(model_dir, n_speakers=8)
+    groups = [17, 9, 8, 7, 5, 4, 2, 1]
+    speaker_of = [g for g, n in enumerate(groups) for _ in range(n)]
+    B, steps = len(speaker_of), 34
+    audio = np.stack([bv.synth_audio(160 * steps, seed=5100 + s) for s in range(B)]).reshape(B, steps, 160)
+
+    def settings(batch):
+        for s in range(B):
+            batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, s, speaker_of[s])
+            batch.a.BeatriceBatch_SetVQNumNeighbors(batch.h, s, s % 3)
+        batch.a.BeatriceBatch_FlushSpeaker(batch.h, -1)
+
+    def change(batch, k):
+        a, h = batch.a, batch.h
+        if k == 6:      # the single row of speaker 7 joins speaker 0 (17 -> 18 rows: one tile + 2 rows as a quad)
+            a.BeatriceBatch_SetTargetSpeaker(h, B - 1, 0)
+        if k == 13:     # three rows leave the group of nine (9 -> 6: from a padded tile to quads of 4 + 2)
+            for s in (17, 18, 19):
+                a.BeatriceBatch_SetTargetSpeaker(h, s, 6)
+        if k == 21:     # everybody of speaker 3 to speaker 2 (8 + 7 = 15: a padded tile)
+            for s in range(B):
+                if speaker_of[s] == 3:
+                    a.BeatriceBatch_SetTargetSpeaker(h, s, 2)
+
+    def hop_input(k):
+        return audio[:, k]
+
+    m = bv.Models(product, model_dir)
+    batch = bv.Batch(m, B)
+    settings(batch)
+    got = run_tick(bv, batch, steps, hop_input, change=change)
+    batch.close()
+    m.close()
+    sample, want = oracle_leg(bv, oracle, model_dir, B, hop_input, steps, settings, change, list(range(B)))
+    assert np.abs(got).max() > 1e-2
+    bad = [(k, s) for k in range(steps) for s in range(B) if not np.array_equal(got[k, s], want[k, s])]
+    assert not bad, "first differing (step, stream): %s of %d, max-abs %g" % (bad[:4], len(bad), np.abs(got - want).max())
