@@ -67,15 +67,19 @@ PMC_SYMBOL = {
 }
 
 
+# the sources that define the tick launch: its bodies, the table kernel and the table builder (everything they include)
+TICK_LAUNCH_SOURCES = ("tick.hip.h", "fuse.hip.h", "rowchain.hip.h", "tail_stages.hip.h", "wave_tail.hip.h", "chain_layers.hip.h", "conv_gemm.hip.h",
+                       "fused_small.hip.h", "kernels_misc.hip.h", "gemv.hip.h", "spec_math.hip.h", "ring.h", "engine.h", "batch_tick.hip.h")
+
+
 def csrc_sha1():
-    """Fingerprint of the kernel sources (beatrice-vst_amd/csrc): the PMC summaries under profiles/ carry the one they were
-    measured at (tools/pmc_summary.py), and a summary taken at other sources is not quoted."""
-    import glob
+    """Fingerprint of the sources of the tick launch (beatrice-vst_amd/csrc: TICK_LAUNCH_SOURCES): the PMC summaries under
+    profiles/ carry the one they were measured at (tools/pmc_summary.py), and a summary taken at other sources is not quoted."""
     import hashlib
     h = hashlib.sha1()
-    for path in sorted(glob.glob(os.path.join(REPO, "beatrice-vst_amd", "csrc", "*.hip")) + glob.glob(os.path.join(REPO, "beatrice-vst_amd", "csrc", "*.h"))):
-        h.update(os.path.basename(path).encode())
-        h.update(open(path, "rb").read())
+    for name in TICK_LAUNCH_SOURCES:
+        h.update(name.encode())
+        h.update(open(os.path.join(REPO, "beatrice-vst_amd", "csrc", name), "rb").read())
     return h.hexdigest()
 
 
