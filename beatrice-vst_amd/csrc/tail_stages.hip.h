@@ -14,9 +14,18 @@
 // buffers of raw + activated copies) allowing no second stream to fill the gaps.
 // Here a workgroup runs ONE THIRD of the chain for SEVERAL streams: rows = (stream, frame) fill the row tiles
 // (4 x 20 = 80 = 5 tiles, 3 x 80 = 15 tiles, 2 x 240 = 30 tiles), every SIMD gets the same MFMA count, a barrier or an
-// epilogue is paid once per 2-4 streams, and the LDS holds two ping-pong buffers of RAW activations only (lrelu is two VALU
-// operations on the A operand on its way to the MFMA: max(x, 0.1 x), hidden behind the 32-cycle MFMA issue).
-// More stages cost a throughput pipeline nothing (a step's latency grows by two ticks).
+// epilogue is paid once per 2-4 streams.  More stages cost a throughput pipeline nothing (a step's latency grows by two ticks).
+//
+// The cost model that shapes the bodies (tools/microbench/mfma_mix, profiles/r03_notes.md): a SIMD issues ONE instruction
+// stream -- a v_mfma_f32_16x16x4_f32 holds it for 32 cycles, and every VALU instruction beside it costs ~5 cycles, every LDS
+// read ~12, whichever wavefront issues them; nothing overlaps.  A body's time is 32 MFMA + 5 VALU + 12 LDS, so VALU work
+// per MFMA is what to minimise:
+//   * the LDS holds ACTIVATED values only (lrelu applied once per element where it is produced, not once per use as an A
+//     operand: a 64-channel frame is used 12 times); the RAW value a residual connection adds back comes from global memory
+//     (the stage's input ring; a scratch the first residual layer writes for the second), requested before the tile's MFMAs;
+//   * A operands are read at compile-time offsets from one pointer per row tile (lowest tap first: no address arithmetic);
+//   * an epilogue computes (stream, frame) once per four rows (T is a multiple of 4: the four rows a lane owns in a 16 x 16
+//     result tile never straddle streams) and the bias once per layer.
 //
 // Numerics: operation for operation those of wave_tail.hip.h (every K <= 256: one k-ascending MFMA chain per output,
 // bias, then residual), same packed weights, and the SAME per-stream state block (TS_* offsets) for the histories a layer
@@ -57,8 +66,17 @@ struct StageArgs {
   int B;
 };
 
-// LDS buffer of S streams: [S][HP + T][C + 2] raw values; row (s, t), t in [-HP, T).  Stride C + 2: the A-operand read of
-// a wavefront (16 rows x 4 k) hits 32 distinct banks per half (bank = 2 row + k, as in wave_tail.hip.h)
+// lrelu(x) = max(x, 0.1 x), bit for bit MODEL_SPEC's `x > 0 ? x : 0.1 x` (x and 0.1 x have the same sign).  The instruction
+// itself: fmaxf() makes the compiler canonicalise both operands first (two more VALU instructions per value).
+__device__ __forceinline__ float lrelu_max(float x) {
+  float r;
+  const float y = 0.1f * x;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+
+// LDS buffer of S streams: [S][HP + T][C + 2] ACTIVATED values; row (s, t), t in [-HP, T).  Stride C + 2: the A-operand read
+// of a wavefront (16 rows x 4 k) hits 32 distinct banks per half (bank = 2 row + k, as in wave_tail.hip.h)
 template <int C> __host__ __device__ constexpr int cs() { return C + 2; }
 template <int C, int T, int S> __host__ __device__ constexpr int buf_floats() { return S * (HP + T) * cs<C>(); }
 template <int C, int T> __device__ __forceinline__ int row_off(int s, int t) { return (s * (HP + T) + HP + t) * cs<C>(); }
@@ -76,7 +94,10 @@ struct Split {
   static constexpr int CT = POW2 ? 1 : NTL;
 };
 
-template <int K, int NOUT>
+// B fragments of a layer for this wavefront, k-blocks [KB0, KB1).  A layer's fragments are fetched in two halves: the first
+// before the PREVIOUS layer's MFMAs (latency hidden behind them), the second after them -- with 64 channels a layer's
+// fragments are 48 registers, and two whole layers' worth beside the accumulators and the A-operand pipeline spill.
+template <int K, int NOUT, int KB0 = 0, int KB1 = K / 16>
 __device__ __forceinline__ void fetch_b(const float* __restrict__ wpacked, float4 (&bf)[Split<NOUT>::CT][K / 16], int wave, int lane) {
   using SP = Split<NOUT>;
   const int wn = wave % SP::NWN;
@@ -85,45 +106,44 @@ __device__ __forceinline__ void fetch_b(const float* __restrict__ wpacked, float
     const int nt = SP::POW2 ? wn : ct;
     const float4* p = reinterpret_cast<const float4*>(wpacked) + (size_t)nt * (K / 16) * 64 + lane;
 #pragma unroll
-    for (int kb = 0; kb < K / 16; ++kb) bf[ct][kb] = p[(size_t)kb * 64];
+    for (int kb = KB0; kb < KB1; ++kb) bf[ct][kb] = p[(size_t)kb * 64];
   }
 }
 
 #ifndef TST_PIN
 #define TST_PIN 1
 #endif
-// One pass of a layer: NT (1 or 2, compile time) row tiles of 16 that share every B operand.  base[u] = the lane's A address
-// of tile u (row lane & 15 of the tile, k offset lane >> 4); the reduction runs in groups of four MFMA steps (16 k = one B
-// fragment record), the raw A operands of group g + 1 are read from LDS BEFORE the MFMAs of group g issue and the order is
-// pinned (sched_barrier; the asm keeps IR passes from undoing it), lrelu = max(x, 0.1 x) is applied on the way.
+// One pass of a layer: NT (1 or 2, compile time) row tiles of 16 that share every B operand.  ap[u] = the lane's A pointer
+// of tile u: (row lane & 15 of the tile, LOWEST tap, k offset lane >> 4), so that every operand sits at a compile-time,
+// non-negative offset.  The reduction runs in groups of four MFMA steps (16 k = one B fragment record); the A operands of
+// group g + PD are read from LDS before the MFMAs of group g issue, and the order is pinned.
 template <int CIN, int NOUT, int KSZ, int DIL, int NT>
-__device__ __forceinline__ void pass(const float* __restrict__ in, const int (&base)[2], const float4 (&bf)[Split<NOUT>::CT][KSZ * CIN / 16],
+__device__ __forceinline__ void pass(const float* const (&ap)[2], const float4 (&bf)[Split<NOUT>::CT][KSZ * CIN / 16],
                                      tail_f32x4 (&acc)[2][Split<NOUT>::CT]) {
   using SP = Split<NOUT>;
   constexpr int CS = cs<CIN>(), NS = KSZ * CIN / 4, NG = NS / 4;
   static_assert(NS % 4 == 0, "reduction length in blocks of 16");
-  auto a_off = [](int ks) { const int kk = ks * 4, j = kk / CIN, c = kk % CIN; return c - (KSZ - 1 - j) * DIL * CS; };
-  // (two groups ahead: the scheduler places a group's LDS reads at the END of the region they are issued in, behind that
-  //  region's MFMAs, so one group of distance leaves them no time to complete)
-  float xq[2][4][NT];
+  auto a_off = [](int ks) { const int kk = ks * 4, j = kk / CIN, c = kk % CIN; return c + j * DIL * CS; };
+  constexpr int PD = CIN >= 64 ? 1 : 2;   // groups of distance between an operand's read and its use (64 channels: registers are short)
+  float xq[PD][4][NT];
 #pragma unroll
-  for (int q = 0; q < 2; ++q)
+  for (int q = 0; q < PD; ++q)
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int u = 0; u < NT; ++u) xq[q][e][u] = q < NG ? in[base[u] + a_off(q * 4 + e)] : 0.0f;
+      for (int u = 0; u < NT; ++u) xq[q][e][u] = q < NG ? ap[u][a_off(q * 4 + e)] : 0.0f;
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     float ac[4][NT];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int u = 0; u < NT; ++u) ac[e][u] = fmaxf(xq[g & 1][e][u], 0.1f * xq[g & 1][e][u]);  // == lrelu(x) bit for bit
-    if (g + 2 < NG) {
+      for (int u = 0; u < NT; ++u) ac[e][u] = xq[g % PD][e][u];
+    if (g + PD < NG) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int u = 0; u < NT; ++u) xq[g & 1][e][u] = in[base[u] + a_off((g + 2) * 4 + e)];
+        for (int u = 0; u < NT; ++u) xq[g % PD][e][u] = ap[u][a_off((g + PD) * 4 + e)];
     }
 #if TST_PIN
     asm volatile("" ::: "memory");
@@ -140,93 +160,118 @@ __device__ __forceinline__ void pass(const float* __restrict__ in, const int (&b
       }
   }
 }
+
 // One layer over the R = S * T rows of the workgroup: rows = (stream, frame), K = KSZ * CIN from the LDS buffer `in`
-// (taps are row offsets inside a stream's block, history rows included), N = NOUT.  epi(s, t, n, acc) receives the
-// finished chain of output (stream s, frame t, column n); rows >= n_rows are padding (recomputed, never handed out).
-template <int CIN, int NOUT, int KSZ, int DIL, int T, int S, class Epi>
+// (activated values; taps are row offsets inside a stream's block, history rows included), N = NOUT.
+// A lane owns, of each 16 x 16 result tile, four consecutive rows of one column; T is a multiple of 4, so they are frames
+// t0 .. t0 + 3 of ONE stream: pre(s, t0, n, ct, res) may request what the epilogue will need (residual values) before the
+// tile's MFMAs, epi(s, t0, n, ct, acc4, res) receives the four finished chains.  Rows >= n_rows are padding (recomputed from
+// the last row, never handed out).
+// Passes a wavefront makes over a layer's row tiles (two tiles per pass), upper bound
+template <int NOUT, int T, int S> __host__ __device__ constexpr int n_pass() { return ((S * T + 15) / 16 + 2 * Split<NOUT>::NWM - 1) / (2 * Split<NOUT>::NWM); }
+// `res` = four values per (pass, tile of the pass, column tile) that live in REGISTERS across the layer -- and, when the
+// caller hands the same array to the next layer of the same shape (same rows, same columns: the tile-to-wavefront map is
+// the same), across layers: the first residual layer leaves its raw output there and the second one finds its residual
+// without a round trip through memory.  FILL = 1: pre() fills them for every pass before the layer's first MFMA (a pass of a
+// 16- or 32-channel layer is far shorter than a global round trip inside the tick launch); 2: per pass, before that pass's MFMAs
+// (64 channels: registers are short there and a pass is 96 MFMAs long); 0: the caller's values are used as they are.
+template <int CIN, int NOUT, int KSZ, int DIL, int T, int S, int FILL, class Pre, class Epi>
 __device__ __forceinline__ void layer(const float* __restrict__ in, const float4 (&bf)[Split<NOUT>::CT][KSZ * CIN / 16], const int n_rows,
-                                      const int wave, const int lane, Epi epi) {
+                                      const int wave, const int lane, float (&res)[n_pass<NOUT, T, S>()][2][Split<NOUT>::CT][4], Pre pre, Epi epi) {
   using SP = Split<NOUT>;
+  static_assert(T % 4 == 0, "four rows of a lane in one stream");
   constexpr int R = S * T, NRT = (R + 15) / 16;
   const int i = lane & 15, kq = lane >> 4;
-  // (the wavefront index as a SCALAR: the row-tile loop and its "second tile?" test must be scalar branches)
+  // (the wavefront index as a SCALAR: the row-tile loop and its "second tile?" test must be scalar branches -- derived from
+  //  threadIdx.x they are vector conditions, and every MFMA of the second tile ends up under its own exec-mask branch)
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int wn = wave_u % SP::NWN, wm = wave_u / SP::NWN;
-#pragma unroll 1
-  for (int t0 = wm; t0 < NRT; t0 += 2 * SP::NWM) {
+  // what the epilogues will need from global memory (residual values): requested for EVERY pass of this wavefront before its
+  // first MFMA -- a pass of a 16- or 32-channel layer is 12-48 MFMAs, far shorter than a global round trip inside the tick
+  // launch.  (64 channels: per pass, registers are short there and a pass is 96 MFMAs long.)
+  constexpr int NPASS = n_pass<NOUT, T, S>();
+  constexpr bool AHEAD = FILL == 1;
+  auto tile_rows = [&](int tile, int* s, int* t, bool* live) {
+    const int r4 = tile * 16 + kq * 4;
+    *live = r4 < n_rows; *s = r4 / T; *t = r4 % T;
+  };
+  if constexpr (AHEAD) {
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int tile = wm + (2 * p + u) * SP::NWM;
+        int s_, t_; bool live_;
+        tile_rows(tile, &s_, &t_, &live_);
+#pragma unroll
+        for (int ct = 0; ct < SP::CT; ++ct)
+          if (tile < NRT && live_) pre(s_, t_, (SP::POW2 ? wn : ct) * 16 + i, ct, res[p][u][ct]);
+      }
+  }
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    const int t0 = wm + 2 * p * SP::NWM;
+    if (t0 >= NRT) break;
     const bool two = t0 + SP::NWM < NRT;  // a second row tile shares every B operand of this pass
-    int base[2];
+    const float* ap[2];
+    int es[2], et[2];   // (stream, first frame) of the four result rows this lane owns in each tile
+    bool live[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       int r = (t0 + u * SP::NWM) * 16 + i;
       r = r > R - 1 ? R - 1 : r;
-      base[u] = row_off<CIN, T>(r / T, r % T) + kq;
+      ap[u] = in + row_off<CIN, T>(r / T, r % T - (KSZ - 1) * DIL) + kq;
+      tile_rows(t0 + u * SP::NWM, &es[u], &et[u], &live[u]);
+      live[u] = live[u] && (u == 0 || two);
+    }
+    if constexpr (FILL == 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int ct = 0; ct < SP::CT; ++ct)
+          if (live[u]) pre(es[u], et[u], (SP::POW2 ? wn : ct) * 16 + i, ct, res[p][u][ct]);
     }
     tail_f32x4 acc[2][SP::CT];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int ct = 0; ct < SP::CT; ++ct) acc[u][ct] = tail_f32x4{0.f, 0.f, 0.f, 0.f};
-    if (two) pass<CIN, NOUT, KSZ, DIL, 2>(in, base, bf, acc);
-    else pass<CIN, NOUT, KSZ, DIL, 1>(in, base, bf, acc);
+    if (two) pass<CIN, NOUT, KSZ, DIL, 2>(ap, bf, acc);
+    else pass<CIN, NOUT, KSZ, DIL, 1>(ap, bf, acc);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (u == 1 && !two) break;
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int ct = 0; ct < SP::CT; ++ct) {
-        const int n = (SP::POW2 ? wn : ct) * 16 + i;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = (t0 + u * SP::NWM) * 16 + kq * 4 + e;   // D layout of 16x16x4: row = (lane >> 4) * 4 + reg, column = lane & 15
-          if (r < n_rows) epi(r / T, r % T, n, acc[u][ct][e]);
-        }
-      }
-    }
+      for (int ct = 0; ct < SP::CT; ++ct)
+        if (live[u]) epi(es[u], et[u], (SP::POW2 ? wn : ct) * 16 + i, ct, acc[u][ct], res[p][u][ct]);
   }
 }
 
 // ---- global memory <-> LDS, latency-aware.  A workgroup of these stages is a serial chain of phases; inside the tick launch
 // a global round trip takes 1-2 us (the memory system is shared with ~500 other workgroups), so a body may afford very few
-// of them on its critical path: EVERYTHING a stage reads from global memory -- its input frames, its three pieces of the
-// state block, its biases -- is requested in one burst before the first barrier (every thread issues all of its loads, then
-// stores them to LDS), and everything it writes to the state block goes out after the last layer, behind nothing.
+// of them on its critical path: what a stage reads from global memory up front -- its input frames, its pieces of the state
+// block -- is requested in one burst before the first barrier (every thread issues all of its loads, then stores them to
+// LDS), residual values are requested a tile ahead of their use, and the state block is written behind everything else.
 
-// S x N floats (N a multiple of 4, S * N / 4 <= 512: one float4 per thread) of the state block at `ts_off` -> dst[s * N ...]
+// S x N floats (N a multiple of 4, S * N / 4 <= 512: one float4 per thread) of the state block at `ts_off`
 template <int S, int N>
-__device__ __forceinline__ float4 state_load(const float* __restrict__ state, const int ts_off, const int b0, const int B, const int tid, bool* live) {
+__device__ __forceinline__ float4 state_load(const float* __restrict__ state, const int ts_off, const int b0, const int B, const int tid) {
   static_assert(N % 4 == 0 && S * N / 4 <= NTHR, "one float4 per thread");
   const int s = tid / (N / 4), q = tid % (N / 4);
-  *live = tid < S * N / 4 && b0 + s < B;
-  return *live ? *reinterpret_cast<const float4*>(state + (size_t)(b0 + s) * TAIL_STATE_FLOATS + ts_off + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+  return tid < S * N / 4 && b0 + s < B ? *reinterpret_cast<const float4*>(state + (size_t)(b0 + s) * TAIL_STATE_FLOATS + ts_off + 4 * q)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
 }
-// rows [t_first, t_first + ROWS) of every stream's block in `buf` -> the state block
-template <int C, int T, int S, int ROWS>
-__device__ __forceinline__ void state_store_rows(float* __restrict__ state, const int ts_off, const float* __restrict__ buf, const int t_first, const int b0,
-                                                 const int B, const int tid) {
-  constexpr int F2 = C / 2;
-  for (int e = tid; e < S * ROWS * F2; e += NTHR) {
-    const int s = e / (ROWS * F2), q = e % (ROWS * F2), row = q / F2, c2 = q % F2;
-    if (b0 + s < B)
-      *reinterpret_cast<float2*>(state + (size_t)(b0 + s) * TAIL_STATE_FLOATS + ts_off + row * C + 2 * c2) =
-          *reinterpret_cast<const float2*>(buf + row_off<C, T>(s, t_first + row) + 2 * c2);
-  }
-}
-// a stash [S][ROWS][C] (contiguous) -> rows [t_first, t_first + ROWS) of every stream's block (LDS to LDS)
-template <int C, int T, int S, int ROWS>
-__device__ __forceinline__ void stash_to_rows(float* __restrict__ buf, const float* __restrict__ stash, const int t_first, const int tid) {
-  for (int e = tid; e < S * ROWS * C; e += NTHR) {
-    const int s = e / (ROWS * C), q = e % (ROWS * C);
-    buf[row_off<C, T>(s, t_first + q / C) + q % C] = stash[e];
-  }
+__device__ __forceinline__ void store_act4(float* __restrict__ d, const float4 v) {   // (row stride C + 2: 8-byte aligned, not 16)
+  reinterpret_cast<float2*>(d)[0] = make_float2(lrelu_max(v.x), lrelu_max(v.y));
+  reinterpret_cast<float2*>(d)[1] = make_float2(lrelu_max(v.z), lrelu_max(v.w));
 }
 
-// The prologue shared by the three stages: weights of the first layer, the step's input frames -> X rows [-2, T) (history
-// rows from the ring itself, or from the state block at TS_IN -- then the frames that will be the NEXT step's history are
-// stashed in `hin` and reach the state block at the end), the six history rows of the second layer -> Y rows [-6, 0), the
-// history of the third layer -> stash `hc`, and NB bias floats -> `bias_lds`.
-template <int C, int T, int S, int TS_IN, int TS_B, int TS_C, int HC_ROWS, bool IN_FROM_RING_HISTORY, int NB0, int NB1, int NB2>
+// The prologue shared by the three stages: the step's input frames -> X rows [-2, T), activated (history rows from the ring
+// itself, or from the state block at TS_IN -- then the raw frames that will be the NEXT step's history are stashed in `hin`
+// and reach the state block at the end); the six history rows of the second layer -> Y rows [-6, 0); the history of the third
+// layer (HC_ROWS rows) -> `hc`, activated, to be copied into X once the first layer is done with it.
+template <int C, int T, int S, int TS_IN, int TS_B, int TS_C, int HC_ROWS, bool IN_FROM_RING_HISTORY>
 __device__ __forceinline__ void prologue(const StageArgs& a, const int hop, const int b0, float* __restrict__ X, float* __restrict__ Y, float* __restrict__ hin,
-                                         float* __restrict__ hc, float* __restrict__ bias_lds, const int tid) {
+                                         float* __restrict__ hc, const int tid) {
   constexpr int F4 = C / 4, ROWS = T + 2, N = S * ROWS * F4, NIT = (N + NTHR - 1) / NTHR;
   const int pos = ring_pos(a.in, hop);
   float4 v[NIT];
@@ -240,48 +285,115 @@ __device__ __forceinline__ void prologue(const StageArgs& a, const int hop, cons
       else v[it] = *reinterpret_cast<const float4*>(a.state + (size_t)b * TAIL_STATE_FLOATS + TS_IN + (t + 2) * C + 4 * c4);
     }
   }
-  bool live_b, live_c;
-  const float4 hb = state_load<S, 6 * C>(a.state, TS_B, b0, a.B, tid, &live_b);
-  const float4 hcv = state_load<S, HC_ROWS * C>(a.state, TS_C, b0, a.B, tid, &live_c);
-  constexpr int NB = NB0 + NB1 + NB2;
-  static_assert(NB <= NTHR, "biases: one float per thread");
-  float bv = 0.0f;
-  if (tid < NB) bv = tid < NB0 ? a.b[0][tid] : (tid < NB0 + NB1 ? a.b[1][tid - NB0] : a.b[2][tid - NB0 - NB1]);
+  const float4 hb = state_load<S, 6 * C>(a.state, TS_B, b0, a.B, tid);
+  const float4 hcv = state_load<S, HC_ROWS * C>(a.state, TS_C, b0, a.B, tid);
   // ---- every load above is in flight; now the stores
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int e = tid + it * NTHR;
     if (e < N) {
       const int s = e / (ROWS * F4), q = e % (ROWS * F4), t = q / F4 - 2, c4 = q % F4;
-      float* d = X + row_off<C, T>(s, t) + 4 * c4;   // (row stride C + 2: 8-byte aligned, not 16)
-      reinterpret_cast<float2*>(d)[0] = make_float2(v[it].x, v[it].y);
-      reinterpret_cast<float2*>(d)[1] = make_float2(v[it].z, v[it].w);
+      store_act4(X + row_off<C, T>(s, t) + 4 * c4, v[it]);
       if (!IN_FROM_RING_HISTORY && t >= T - 2) *reinterpret_cast<float4*>(hin + (s * 2 + (t - (T - 2))) * C + 4 * c4) = v[it];
     }
   }
   if (tid < S * 6 * C / 4) {   // (zeros past the batch)
     const int s = tid / (6 * C / 4), q = tid % (6 * C / 4);
-    float* d = Y + row_off<C, T>(s, -6 + (4 * q) / C) + (4 * q) % C;
-    reinterpret_cast<float2*>(d)[0] = make_float2(hb.x, hb.y);
-    reinterpret_cast<float2*>(d)[1] = make_float2(hb.z, hb.w);
+    store_act4(Y + row_off<C, T>(s, -6 + (4 * q) / C) + (4 * q) % C, hb);
   }
-  if (tid < S * HC_ROWS * C / 4) *reinterpret_cast<float4*>(hc + 4 * tid) = hcv;
-  if (tid < NB) bias_lds[tid] = bv;
+  if (tid < S * HC_ROWS * C / 4) {
+    float4 w;
+    w.x = lrelu_max(hcv.x); w.y = lrelu_max(hcv.y); w.z = lrelu_max(hcv.z); w.w = lrelu_max(hcv.w);
+    *reinterpret_cast<float4*>(hc + 4 * tid) = w;
+  }
+}
+// a stash [S][ROWS][C] (contiguous) -> rows [t_first, t_first + ROWS) of every stream's block (LDS to LDS)
+template <int C, int T, int S, int ROWS>
+__device__ __forceinline__ void stash_to_rows(float* __restrict__ buf, const float* __restrict__ stash, const int t_first, const int tid) {
+  for (int e = tid; e < S * ROWS * C; e += NTHR) {
+    const int s = e / (ROWS * C), q = e % (ROWS * C);
+    buf[row_off<C, T>(s, t_first + q / C) + q % C] = stash[e];
+  }
+}
+template <int C, int S, int TS_IN>
+__device__ __forceinline__ void hin_to_state(const StageArgs& a, const float* __restrict__ hin, const int b0, const int tid) {
+  for (int e = tid; e < S * 2 * C / 4; e += NTHR) {
+    const int s = e / (2 * C / 4), q = e % (2 * C / 4);
+    if (b0 + s < a.B) *reinterpret_cast<float4*>(a.state + (size_t)(b0 + s) * TAIL_STATE_FLOATS + TS_IN + 4 * q) = *reinterpret_cast<const float4*>(hin + 4 * e);
+  }
+}
+
+// The two residual layers every stage starts with (k3; dilation 1: X -> Y, dilation 3: Y -> X), MODEL_SPEC 4.4.3:
+//   y = x + (conv(lrelu(x)) + bias)      x raw from the stage's input ring, y raw STAYS IN REGISTERS (its last 6 frames -> TS_B)
+//   z = y + (conv(lrelu(y)) + bias)      y raw from those registers; of z only lrelu(z) is used again (-> X) and its last HC_ROWS
+//                                        frames, raw, as the next step's history (-> TS_C)
+// after_a() / between(): called right after the first layer's MFMAs and after the barrier that follows (the caller's fetches of
+// the next layers' weights, see fetch_b).
+template <int C, int T, int S, int TS_B, int TS_C, int HC_ROWS, class AfterA, class Between>
+__device__ __forceinline__ void two_res_layers(const StageArgs& a, const int hop, const int b0, const int n_rows, float* __restrict__ X, float* __restrict__ Y,
+                                               const float* __restrict__ hc, const float4 (&bfa)[Split<C>::CT][3 * C / 16],
+                                               const float4 (&bfb)[Split<C>::CT][3 * C / 16], const int wave, const int lane, const int tid, AfterA after_a, Between between,
+                                               float* __restrict__ yr = nullptr /* C > 32: LDS [S][T][C], the raw y (registers are short at 64 channels) */) {
+  static_assert(Split<C>::CT == 1, "one column tile per wavefront");
+  constexpr bool IN_LDS = C > 32;
+  const int n_lane = (wave % Split<C>::NWN) * 16 + (lane & 15);
+  const float bias_a = a.b[0][n_lane], bias_b = a.b[1][n_lane];
+  const int pos = ring_pos(a.in, hop);
+  float keep[n_pass<C, T, S>()][2][Split<C>::CT][4];
+  layer<C, C, 3, 1, T, S, (C <= 32 ? 1 : 2)>(X, bfa, n_rows, wave, lane, keep,
+    [&](int s, int t0, int n, int, float (&res)[4]) {
+      const float* p = ring_frame(a.in, b0 + s, pos, t0) + n;   // (frames t0 .. t0 + 3 of a step are contiguous in its ring slot)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) res[e] = p[e * C];
+    },
+    [&](int s, int t0, int n, int, const tail_f32x4& acc, float (&res)[4]) {
+      float* yo = Y + row_off<C, T>(s, t0) + n;
+      float* st = a.state + (size_t)(b0 + s) * TAIL_STATE_FLOATS + TS_B + (t0 - (T - 6)) * C + n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float y = res[e] + (acc[e] + bias_a);
+        yo[e * cs<C>()] = lrelu_max(y);
+        if (IN_LDS) yr[((s * T) + t0 + e) * C + n] = y; else res[e] = y;   // the second layer's residual
+        if (t0 + e >= T - 6) st[e * C] = y;
+      }
+    });
+  after_a();
+  TST_STAMP(3);
+  __syncthreads();
+  TST_STAMP(4);
+  between();
+  stash_to_rows<C, T, S, HC_ROWS>(X, hc, -HC_ROWS, tid);
+  layer<C, C, 3, 3, T, S, (IN_LDS ? 2 : 0)>(Y, bfb, n_rows, wave, lane, keep,
+    [&](int s, int t0, int n, int, float (&res)[4]) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) res[e] = yr[((s * T) + t0 + e) * C + n];
+    },
+    [&](int s, int t0, int n, int, const tail_f32x4& acc, float (&res)[4]) {
+      float* xo = X + row_off<C, T>(s, t0) + n;
+      float* st = a.state + (size_t)(b0 + s) * TAIL_STATE_FLOATS + TS_C + (t0 - (T - HC_ROWS)) * C + n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float z = res[e] + (acc[e] + bias_b);
+        xo[e * cs<C>()] = lrelu_max(z);
+        if (t0 + e >= T - HC_ROWS) st[e * C] = z;
+      }
+    });
+  TST_STAMP(5);
+  __syncthreads();
+  TST_STAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The common shape of T1 and T2: two residual convs (k3; dilation 1, 3) over C channels, then the polyphase transposed conv
-// (k2 over input frames, rate UPR, COUT channels) into the next stage's ring.  IN_FROM_RING_HISTORY: the first layer's
-// two history frames come from the input ring itself (T1: the ring of up2 keeps them); otherwise from the state block at
-// TS_IN, which then receives this step's last two input frames (T2).
+// T1 and T2: the two residual layers, then the polyphase transposed conv (k2 over input frames, rate UPR, COUT channels)
+// into the next stage's ring.  IN_FROM_RING_HISTORY: the first layer's two history frames come from the input ring itself
+// (T1: the ring of up2 keeps them); otherwise from the state block at TS_IN (T2).
 template <int C, int T, int S, int COUT, int UPR, int TS_IN, int TS_B, int TS_C, bool IN_FROM_RING_HISTORY>
 __device__ __forceinline__ void res_res_up_body(const StageArgs& a, const int g, float* __restrict__ lds) {
   constexpr int NUP = UPR * COUT;
   float* X = lds;
   float* Y = X + buf_floats<C, T, S>();
-  float* HIN = Y + buf_floats<C, T, S>();   // [S][2][C]
-  float* HC = HIN + S * 2 * C;              // [S][1][C]
-  float* BIAS = HC + S * C;                 // C | C | NUP
+  float* HIN = Y + buf_floats<C, T, S>();   // [S][2][C] raw
+  float* HC = HIN + S * 2 * C;              // [S][1][C] activated
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hop = stepc::step(a.hop);
   if (hop < 0) return;
@@ -293,53 +405,42 @@ __device__ __forceinline__ void res_res_up_body(const StageArgs& a, const int g,
   float4 bfa[Split<C>::CT][3 * C / 16], bfb[Split<C>::CT][3 * C / 16], bfu[Split<NUP>::CT][2 * C / 16];
   TST_STAMP(0);
   fetch_b<3 * C, C>(a.w[0], bfa, wave, lane);
-  prologue<C, T, S, TS_IN, TS_B, TS_C, 1, IN_FROM_RING_HISTORY, C, C, NUP>(a, hop, b0, X, Y, HIN, HC, BIAS, tid);
+  prologue<C, T, S, TS_IN, TS_B, TS_C, 1, IN_FROM_RING_HISTORY>(a, hop, b0, X, Y, HIN, HC, tid);
   TST_STAMP(1);
   __syncthreads();
   TST_STAMP(2);
-  // ---- resA (k3, dilation 1): X -> Y
-  fetch_b<3 * C, C>(a.w[1], bfb, wave, lane);
-  layer<C, C, 3, 1, T, S>(X, bfa, n_rows, wave, lane, [&](int s, int t, int n, float v) {
-    const int o = row_off<C, T>(s, t) + n;
-    Y[o] = X[o] + (v + BIAS[n]);
-  });
-  TST_STAMP(3);
-  __syncthreads();
-  TST_STAMP(4);
-  // ---- resB (k3, dilation 3): Y -> X (X's history row -1 <- the stash: input history of the transposed conv)
-  fetch_b<2 * C, NUP>(a.w[2], bfu, wave, lane);
-  stash_to_rows<C, T, S, 1>(X, HC, -1, tid);
-  layer<C, C, 3, 3, T, S>(Y, bfb, n_rows, wave, lane, [&](int s, int t, int n, float v) {
-    const int o = row_off<C, T>(s, t) + n;
-    X[o] = Y[o] + (v + BIAS[C + n]);
-  });
-  TST_STAMP(5);
-  __syncthreads();
-  TST_STAMP(6);
+  constexpr int KBR = 3 * C / 16, KBU = 2 * C / 16;
+  fetch_b<3 * C, C, 0, KBR / 2>(a.w[1], bfb, wave, lane);
+  two_res_layers<C, T, S, TS_B, TS_C, 1>(a, hop, b0, n_rows, X, Y, HC, bfa, bfb, wave, lane, tid,
+                                         [&] { fetch_b<3 * C, C, KBR / 2, KBR>(a.w[1], bfb, wave, lane); },
+                                         [&] { fetch_b<2 * C, NUP, 0, KBU / 2>(a.w[2], bfu, wave, lane); }, C > 32 ? HC + S * C : nullptr);
+  fetch_b<2 * C, NUP, KBU / 2, KBU>(a.w[2], bfu, wave, lane);
   // ---- transposed conv (polyphase k2): X -> the next stage's ring, frame t UPR + n / COUT, channel n % COUT
   {
+    using SU = Split<NUP>;
+    float bias_u[SU::CT];
+#pragma unroll
+    for (int ct = 0; ct < SU::CT; ++ct) bias_u[ct] = a.b[2][(SU::POW2 ? wave % SU::NWN : ct) * 16 + (lane & 15)];
     const int pos_o = ring_pos(a.out, hop);
-    layer<C, NUP, 2, 1, T, S>(X, bfu, n_rows, wave, lane, [&](int s, int t, int n, float v) {
-      ring_frame(a.out, b0 + s, pos_o, t * UPR + n / COUT)[n % COUT] = v + BIAS[2 * C + n];
-    });
+    float none[n_pass<NUP, T, S>()][2][SU::CT][4];   // (no residual in this layer: never read, costs no registers)
+    layer<C, NUP, 2, 1, T, S, 0>(X, bfu, n_rows, wave, lane, none, [](int, int, int, int, float (&)[4]) {},
+      [&](int s, int t0, int n, int ct, const tail_f32x4& acc, float (&)[4]) {
+        const float bu = bias_u[ct];   // (ct is a compile-time index after unrolling)
+        float* o = ring_frame(a.out, b0 + s, pos_o, t0 * UPR + n / COUT) + n % COUT;   // (output frames of one input frame are UPR apart)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e * UPR * COUT] = acc[e] + bu;
+      });
   }
   TST_STAMP(7);
-  // ---- the histories of the next step -> state block (Y and X still hold this step's resA / resB outputs)
-  state_store_rows<C, T, S, 6>(a.state, TS_B, Y, T - 6, b0, a.B, tid);
-  state_store_rows<C, T, S, 1>(a.state, TS_C, X, T - 1, b0, a.B, tid);
-  if (!IN_FROM_RING_HISTORY)
-    for (int e = tid; e < S * 2 * C / 4; e += NTHR) {
-      const int s = e / (2 * C / 4), q = e % (2 * C / 4);
-      if (b0 + s < a.B) *reinterpret_cast<float4*>(a.state + (size_t)(b0 + s) * TAIL_STATE_FLOATS + TS_IN + 4 * q) = *reinterpret_cast<const float4*>(HIN + 4 * e);
-    }
+  if (!IN_FROM_RING_HISTORY) hin_to_state<C, S, TS_IN>(a, HIN, b0, tid);
   TST_STAMP(8);
 }
 
 constexpr int kT1Streams = 4, kT2Streams = 3, kT3Streams = 2;
-template <int C, int T, int S, int NUP> constexpr int rru_lds() { return 2 * buf_floats<C, T, S>() + S * 3 * C + 2 * C + NUP; }
-constexpr int kT1Lds = rru_lds<64, 20, kT1Streams, 128>();
-constexpr int kT2Lds = rru_lds<32, 80, kT2Streams, 48>();
-constexpr int kT3Lds = 2 * buf_floats<16, 240, kT3Streams>() + kT3Streams * 8 * 16 + 2 * 16 + 7 * 16;
+template <int C, int T, int S, int HC_ROWS> constexpr int stage_lds() { return 2 * buf_floats<C, T, S>() + S * (2 + HC_ROWS) * C + (C > 32 ? S * T * C : 0); }
+constexpr int kT1Lds = stage_lds<64, 20, kT1Streams, 1>();
+constexpr int kT2Lds = stage_lds<32, 80, kT2Streams, 1>();
+constexpr int kT3Lds = stage_lds<16, 240, kT3Streams, 6>() + 7 * 16;
 
 struct T1Op {
   using Args = StageArgs;
@@ -372,10 +473,9 @@ __device__ __forceinline__ void t3_body(const StageArgs& a, const int g, float* 
   constexpr int C = 16, T = 240, S = kT3Streams;
   float* X = lds;
   float* Y = X + buf_floats<C, T, S>();
-  float* HIN = Y + buf_floats<C, T, S>();   // [S][2][C]
-  float* HC = HIN + S * 2 * C;              // [S][6][C]: history of the output conv's input
-  float* BIAS = HC + S * 6 * C;             // C | C
-  float* FW = BIAS + 2 * C;
+  float* HIN = Y + buf_floats<C, T, S>();   // [S][2][C] raw
+  float* HC = HIN + S * 2 * C;              // [S][6][C] activated: history of the output conv's input
+  float* FW = HC + S * 6 * C;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hop = stepc::step(a.hop);
   if (hop < 0) return;
@@ -391,21 +491,11 @@ __device__ __forceinline__ void t3_body(const StageArgs& a, const int g, float* 
   fetch_b<48, 16>(a.w[1], bfb, wave, lane);
   const float fin_b = a.fin_b[0];
   const float fw = tid < 7 * 16 ? a.fin_w[tid] : 0.0f;
-  prologue<C, T, S, TS_YA4, TS_YB4, TS_YC4, 6, false, C, C, 0>(a, hop, b0, X, Y, HIN, HC, BIAS, tid);
+  prologue<C, T, S, TS_YA4, TS_YB4, TS_YC4, 6, false>(a, hop, b0, X, Y, HIN, HC, tid);
   if (tid < 7 * 16) FW[tid] = fw;
   __syncthreads();
-  layer<C, C, 3, 1, T, S>(X, bfa, n_rows, wave, lane, [&](int s, int t, int n, float v) {
-    const int o = row_off<C, T>(s, t) + n;
-    Y[o] = X[o] + (v + BIAS[n]);
-  });
-  __syncthreads();
-  stash_to_rows<C, T, S, 6>(X, HC, -6, tid);
-  layer<C, C, 3, 3, T, S>(Y, bfb, n_rows, wave, lane, [&](int s, int t, int n, float v) {
-    const int o = row_off<C, T>(s, t) + n;
-    X[o] = Y[o] + (v + BIAS[C + n]);
-  });
-  __syncthreads();
-  // ---- output conv: one thread per sample, the operations of wave_tail.hip.h in the same order
+  two_res_layers<C, T, S, TS_YB4, TS_YC4, 6>(a, hop, b0, n_rows, X, Y, HC, bfa, bfb, wave, lane, tid, [] {}, [] {});
+  // ---- output conv over the ACTIVATED frames: one thread per sample, the multiply-adds of wave_tail.hip.h in the same order
   if (tid < S * T) {
     const int s = tid / T, t = tid % T;
     if (b0 + s < a.B) {
@@ -414,16 +504,11 @@ __device__ __forceinline__ void t3_body(const StageArgs& a, const int g, float* 
 #pragma unroll
       for (int j = 0; j < 7; ++j)
 #pragma unroll
-        for (int c = 0; c < 16; ++c) acc = bsp::fma(bsp::lrelu(x[j * cs<C>() + c]), FW[j * 16 + c], acc);
+        for (int c = 0; c < 16; ++c) acc = bsp::fma(x[j * cs<C>() + c], FW[j * 16 + c], acc);
       d_out[(size_t)(b0 + s) * B_OUT_HOP + t] = bsp::tanh(acc + fin_b);
     }
   }
-  state_store_rows<C, T, S, 6>(a.state, TS_YB4, Y, T - 6, b0, a.B, tid);
-  state_store_rows<C, T, S, 6>(a.state, TS_YC4, X, T - 6, b0, a.B, tid);
-  for (int e = tid; e < S * 2 * C / 4; e += NTHR) {
-    const int s = e / (2 * C / 4), q = e % (2 * C / 4);
-    if (b0 + s < a.B) *reinterpret_cast<float4*>(a.state + (size_t)(b0 + s) * TAIL_STATE_FLOATS + TS_YA4 + 4 * q) = *reinterpret_cast<const float4*>(HIN + 4 * e);
-  }
+  hin_to_state<C, S, TS_YA4>(a, HIN, b0, tid);
 }
 struct T3Op {
   using Args = StageArgs;
