@@ -43,6 +43,7 @@ bool RingArena::build(int B_, const std::vector<RingSpec>& specs) {
   size_t total = 0;
   for (const RingSpec& s : specs) {
     if (s.m < 1 || B_HOP_WRAP % s.m != 0) return false;  // the step counter wraps at B_HOP_WRAP = lcm(1..17): every slot count must divide it
+    if ((size_t)B * s.C * s.n * s.m >= ((size_t)1 << 32)) return false;  // ring_frame indexes a ring with 32 bits (ring.h)
     total += ((size_t)B * s.C * s.n * s.m + 63) / 64 * 64;
   }
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&base), total * sizeof(float)));

@@ -28,7 +28,9 @@ __device__ __forceinline__ float* ring_frame(const Ring& r, int b, int pos, int 
   int f = pos + rel;
   const int R = r.n * r.m;
   if (f < 0) f += R;
-  return r.base + ((size_t)b * R + f) * r.C;
+  // 32-bit index arithmetic (a ring holds fewer than 2^32 floats: RingArena::build refuses larger ones): the 64-bit form cost
+  // six to eight VALU instructions per call, and epilogues call this once per output element
+  return r.base + (unsigned)(b * R + f) * (unsigned)r.C;
 }
 
 // The step counter a kernel works on, and the slot of resident I/O buffers that belongs to it.  Ordinary launches read
