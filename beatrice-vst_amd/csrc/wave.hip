@@ -3,9 +3,17 @@
 #include <cstdlib>
 
 #include "chain_layers.hip.h"
+#include "tail_stages.hip.h"  // the tail as three multi-stream kernels (large batches in order; the tick launch has them as bodies)
 #include "rowchain.hip.h"
 
 namespace bhip {
+
+// a tail stage (tail_stages.hip.h) as a launch of its own
+template <class Op>
+static __global__ __launch_bounds__(tst::NTHR, 4) void tail_stage_kernel(const tst::StageArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[Op::LDS_FLOATS];
+  Op::run(a, blockIdx.x, 0, lds);
+}
 
 static const int kBlockDil[B_NBLOCKS] = {1, 2, 4, 8};
 
@@ -192,8 +200,24 @@ static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t
     launch_auto<UP<128, 64, 4, 5 * H>>("wave.up2", conv_args(s.yc1, s.ya2, w.up_w[1], w.up_b[1], s.hop, B), st);
   }
   if (!in_part(7)) return;
-  const TailArgs ta = tail_args(w, s);
-  launch_site(tail_info(s), st, [&] { hipLaunchKernelGGL(wave_tail_kernel<H>, dim3(B), dim3(tail::NTHR), 0, st, ta); });
+  if (rowchain && H == 1 && s.ya3.base != nullptr) {
+    // many streams: the three multi-stream tail stages (tail_stages.hip.h; rows = (stream, frame) fill the MFMA tiles, a third of
+    // the fused kernel's VALU work) as launches of their own -- the same state block, so a batch may change between this,
+    // the fused kernel and the tick launch at any step
+    tst::StageArgs t1{}, t2{}, t3{};
+    t1.in = s.ya2; t1.out = s.ya3; t2.in = s.ya3; t2.out = s.ya4; t3.in = s.ya4;
+    for (tst::StageArgs* t : {&t1, &t2, &t3}) { t->state = s.tail.base; t->hop = s.hop; t->B = B; }
+    t1.w[0] = w.ra_w[1]; t1.b[0] = w.ra_b[1]; t1.w[1] = w.rb_w[1]; t1.b[1] = w.rb_b[1]; t1.w[2] = w.up_w[2]; t1.b[2] = w.up_b[2];
+    t2.w[0] = w.ra_w[2]; t2.b[0] = w.ra_b[2]; t2.w[1] = w.rb_w[2]; t2.b[1] = w.rb_b[2]; t2.w[2] = w.up_w[3]; t2.b[2] = w.up_b[3];
+    t3.w[0] = w.ra_w[3]; t3.b[0] = w.ra_b[3]; t3.w[1] = w.rb_w[3]; t3.b[1] = w.rb_b[3];
+    t3.fin_w = w.fin_w; t3.fin_b = w.fin_b; t3.d_out = s.d_out; t3.io_stride = s.io_stride;
+    launch_site(tst::T1Op::info(t1), st, [&] { hipLaunchKernelGGL(tail_stage_kernel<tst::T1Op>, tst::T1Op::grid(t1), dim3(tst::NTHR), 0, st, t1); });
+    launch_site(tst::T2Op::info(t2), st, [&] { hipLaunchKernelGGL(tail_stage_kernel<tst::T2Op>, tst::T2Op::grid(t2), dim3(tst::NTHR), 0, st, t2); });
+    launch_site(tst::T3Op::info(t3), st, [&] { hipLaunchKernelGGL(tail_stage_kernel<tst::T3Op>, tst::T3Op::grid(t3), dim3(tst::NTHR), 0, st, t3); });
+  } else {
+    const TailArgs ta = tail_args(w, s);
+    launch_site(tail_info(s), st, [&] { hipLaunchKernelGGL(wave_tail_kernel<H>, dim3(B), dim3(tail::NTHR), 0, st, ta); });
+  }
   if (s.advance_hop) MISC_LAUNCH("hop_advance", 0, 4, hop_advance_kernel, dim3(1), dim3(1), s.hop);
 }
 
