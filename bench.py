@@ -434,6 +434,8 @@ def main():
 
     bv = load_pkg()
     product = bv.bind_batch(bv.load_product())
+    if hasattr(product, "BeatriceHip_SetDevice"):   # every object of this rank on this rank's GPU, whatever the thread's current device
+        product.BeatriceHip_SetDevice(local_rank)
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import make_model
 
