@@ -58,6 +58,12 @@ struct ConvArgs {
   int rel_shift;         // added to every input frame offset (-1: read the previous hop's frame)
 };
 
+__device__ __forceinline__ void globalize(ConvArgs& a) {
+  globalize(a.in); globalize(a.out); globalize(a.res);
+  a.w = as_global(a.w); a.bias = as_global(a.bias); a.hop = as_global(a.hop); a.rowscale = as_global(a.rowscale);
+  a.perm = as_global(a.perm); a.tile_slot = as_global(a.tile_slot);
+}
+
 template <int CIN_, int NOUT_, int KSZ_, int STRIDE_, int DIL_, int T_, int PRE_, int ACT_,
           int EPI_, bool RES_, bool GROUPED_ = false>
 struct Layer {

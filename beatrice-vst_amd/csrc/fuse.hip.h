@@ -142,7 +142,13 @@ template <int I, int NTHR, class M, class... Rest>
 __device__ __forceinline__ void run_type(const Banks<M, Rest...>& b, const Span& sp, int id, float* lds) {
   if (sp.type == I) {
     using Op = typename M::op;
-    if (Op::NTHR >= NTHR || (int)threadIdx.x < Op::NTHR) Op::run(b.a[sp.arg], id % sp.gx, id / sp.gx, lds);
+    if (Op::NTHR >= NTHR || (int)threadIdx.x < Op::NTHR) {
+      typename Op::Args a = b.a[sp.arg];   // (uniform: scalar loads)
+#ifdef FUSE_GLOBALIZE   // A/B build switch, OFF: the table's pointers told to be global memory (ring.h as_global) turn the launch's 2 271
+      globalize(a);         // flat loads into global loads with pipelined waits -- and the tick got 4 % SLOWER (profiles/r04_notes.md section 1)
+#endif
+      Op::run(a, id % sp.gx, id / sp.gx, lds);
+    }
   } else {
     if constexpr (sizeof...(Rest) > 0) run_type<I + 1, NTHR, Rest...>(b.rest, sp, id, lds);
   }

@@ -26,6 +26,11 @@ struct GruArgs {
   int t;  // hop within the step: x frame t, previous state = h frame t-1, new state -> h frame t
 };
 
+__device__ __forceinline__ void globalize(GruArgs& a) {
+  globalize(a.x); globalize(a.h);
+  a.wih = as_global(a.wih); a.whh = as_global(a.whh); a.bih = as_global(a.bih); a.bhh = as_global(a.bhh); a.hop = as_global(a.hop);
+}
+
 // RT = row tiles of 16 streams per workgroup: at 2 the wavefront's weight fragments (held in registers for the whole
 // reduction) feed two independent MFMA chains -- half the weight traffic per stream and twice the work per dependent step.
 template <int IN, int H, int RT = 1>
@@ -103,9 +108,9 @@ __device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, c
       const float* g = g6 + t * 6 * 256;
       const float gi_r = g[(0 * 16 + rr_) * 16 + j], gi_z = g[(1 * 16 + rr_) * 16 + j], gi_n = g[(2 * 16 + rr_) * 16 + j];
       const float gh_r = g[(3 * 16 + rr_) * 16 + j], gh_z = g[(4 * 16 + rr_) * 16 + j], gh_n = g[(5 * 16 + rr_) * 16 + j];
-      const float rr = bsp::sigmoid(gi_r + gh_r);
-      const float zz = bsp::sigmoid(gi_z + gh_z);
-      const float nn = bsp::tanh(bsp::fma(rr, gh_n, gi_n));
+      const bsp::f32x2 rz = bsp::sigmoid2(bsp::f32x2{gi_r + gh_r, gi_z + gh_z});   // (packed forms, spec_math.hip.h: the same bits)
+      const float rr = rz.x, zz = rz.y;
+      const float nn = bsp::tanh2(bsp::splat2(bsp::fma(rr, gh_n, gi_n))).x;
       const float hp = hs[r * HS + j0 + j];
       ring_frame(a.h, b0 + r, ph, a.t)[j0 + j] = bsp::fma(zz, hp - nn, nn);
     }
@@ -192,7 +197,11 @@ __device__ __forceinline__ void attn_pv_body(const AttnPvArgs& a, const int bx, 
       mx = bsp::wmax64(mx);
       float s = 0.0f;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) { const float e = bsp::exp(v[rr][i] - mx); s = s + e; es[r * AS + lane + 64 * i] = e; }
+      for (int i = 0; i < 6; i += 2) {
+        const bsp::f32x2 e = bsp::exp2(bsp::f32x2{v[rr][i] - mx, v[rr][i + 1] - mx});
+        s = s + e.x; s = s + e.y;
+        es[r * AS + lane + 64 * i] = e.x; es[r * AS + lane + 64 * (i + 1)] = e.y;
+      }
       const float tot = bsp::wsum64(s);
       if (lane == 0) inv[r] = 1.0f / tot;
     }

@@ -43,6 +43,10 @@ struct F1Args {
   int H;
   size_t io_stride;    // 0, or floats between the slots of a resident multi-step input buffer (batch.hip)
 };
+__device__ __forceinline__ void globalize(F1Args& a) {
+  a.d_in = as_global(a.d_in); globalize(a.audio); globalize(a.out); a.w = as_global(a.w); a.bias = as_global(a.bias);
+  a.hop = as_global(a.hop); a.hop_publish = as_global(a.hop_publish); a.hop_publish_wave = as_global(a.hop_publish_wave);
+}
 // grid (stream, hop-in-step).  Samples before the step come from the audio ring, the rest from d_in.
 constexpr int kF1LdsFloats = 168 + 10 * 64;
 // PACK streams per workgroup, 256 threads each (the tick launch runs 512-thread workgroups: two streams share one).
@@ -92,7 +96,10 @@ __device__ __forceinline__ void phone_f1_body_t(const F1Args& a, const int bx, c
   }
   float* o = ring_frame(out, b, ring_pos(out, hop), hh * 32 + t) + n0;
 #pragma unroll
-  for (int u = 0; u < 8; ++u) o[u] = bsp::gelu(acc[u] + bias[n0 + u]);
+  for (int u = 0; u < 8; u += 2) {   // pairs through the packed gelu (spec_math.hip.h): the same bits, fewer instructions
+    const bsp::f32x2 g = bsp::gelu2(bsp::f32x2{acc[u] + bias[n0 + u], acc[u + 1] + bias[n0 + u + 1]});
+    o[u] = g.x; o[u + 1] = g.y;
+  }
 }
 __device__ __forceinline__ void phone_f1_body(const F1Args& a, const int b, const int hh, float* __restrict__ lds) {
   phone_f1_body_t<1>(a, b, hh, lds, 0);
@@ -109,6 +116,7 @@ struct F1Op {
 };
 // two streams per 512-thread workgroup (H = 1): grid ((n_streams + 1) / 2, 1)
 struct F1Args2 { F1Args a; int n_streams; };
+__device__ __forceinline__ void globalize(F1Args2& a) { globalize(a.a); }
 struct F1Op2 {
   using Args = F1Args2;
   static constexpr int NTHR = 512;
@@ -129,6 +137,9 @@ struct VqArgs {
   const float* const* cnorm;   // per row: [512]
   const int* k;                // per stream
 };
+__device__ __forceinline__ void globalize(VqArgs& a) {
+  globalize(a.raw); globalize(a.out); a.hop = as_global(a.hop); a.cbT = as_global(a.cbT); a.cnorm = as_global(a.cnorm); a.k = as_global(a.k);
+}
 constexpr int kVqLdsFloats = B_PHONE_CH + 8 + 8 + 8;
 __device__ __forceinline__ void phone_vq_body(const VqArgs& a, const int row, float* __restrict__ lds) {
   float* x = lds;                                               // [128]
@@ -140,7 +151,7 @@ __device__ __forceinline__ void phone_vq_body(const VqArgs& a, const int row, fl
   if (hop < 0) return;
   float* out = ring_frame(a.out, b, ring_pos(a.out, hop), row % a.H);
   const int k = a.k[b];
-  const float* cbT = a.cbT[row];
+  const float* cbT = as_global_v(a.cbT[row]);   // (device allocations: global memory)
   if (j < B_PHONE_CH) x[j] = ring_frame(a.raw, b, ring_pos(a.raw, hop), row % a.H)[j];
   if (k <= 0 || cbT == nullptr) {
     if (j < B_PHONE_CH) out[j] = x[j];
@@ -150,7 +161,7 @@ __device__ __forceinline__ void phone_vq_body(const VqArgs& a, const int row, fl
   float dot = 0.0f;
 #pragma unroll 8
   for (int c = 0; c < B_PHONE_CH; ++c) dot = bsp::fma(x[c], cbT[c * B_CODEBOOK + j], dot);
-  float d = bsp::fma(-2.0f, dot, a.cnorm[row][j]);
+  float d = bsp::fma(-2.0f, dot, as_global_v(a.cnorm[row])[j]);
   float acc = 0.0f;
   for (int r = 0; r < k; ++r) {
     float bd = d;
@@ -200,6 +211,10 @@ struct FftArgs {
   int H;
   size_t io_stride;  // see F1Args
 };
+__device__ __forceinline__ void globalize(FftArgs& a) {
+  a.d_in = as_global(a.d_in); globalize(a.audio); globalize(a.spec); a.window = as_global(a.window); a.twiddle = as_global(a.twiddle);
+  a.hop = as_global(a.hop);
+}
 constexpr int kFftLdsFloats = 3 * B_FFT_N;
 // PACK streams per workgroup, 256 threads each (see phone_f1_body_t); the twiddle table is shared
 template <int PACK>
@@ -277,6 +292,7 @@ struct FftOp {
   __device__ static __forceinline__ void run(const Args& a, int bx, int by, float* lds) { pitch_fft_body(a, bx, by, lds); }
 };
 struct FftArgs2 { FftArgs a; int n_streams; };
+__device__ __forceinline__ void globalize(FftArgs2& a) { globalize(a.a); }
 struct FftOp2 {  // two streams per 512-thread workgroup (H = 1): grid ((n_streams + 1) / 2, 1)
   using Args = FftArgs2;
   static constexpr int NTHR = 512;
@@ -311,6 +327,11 @@ struct PitchHeadArgs {
   int q_slots;          // step slots of the three outputs (step t -> slot t mod q_slots): 1, or 2 when the consumer may lag a step
   int B;
 };
+__device__ __forceinline__ void globalize(PitchHeadArgs& a) {
+  globalize(a.logits); globalize(a.h); a.d_in = as_global(a.d_in); a.voi_w = as_global(a.voi_w); a.voi_b = as_global(a.voi_b);
+  a.min_q = as_global(a.min_q); a.max_q = as_global(a.max_q); a.prev_q = as_global(a.prev_q); a.q_raw = as_global(a.q_raw);
+  a.q_out = as_global(a.q_out); a.feat = as_global(a.feat); a.params = as_global(a.params); a.hop = as_global(a.hop);
+}
 
 __device__ inline double pitch_round_half_away(double v) { return v >= 0.0 ? floor(v + 0.5) : -floor(-v + 0.5); }
 
@@ -372,7 +393,11 @@ __device__ __forceinline__ void pitch_head_body(const PitchHeadArgs& a, const in
     mx = bsp::wmax64(mx);
     float s = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) if (i < n_slot) s = s + bsp::exp(v[i] - mx);
+    for (int i = 0; i < 8; i += 2) {   // (pairs through the packed exp; summed in index order as before)
+      const bsp::f32x2 e = bsp::exp2(bsp::f32x2{v[i < 7 ? i : 6] - mx, v[i + 1 < 7 ? i + 1 : 6] - mx});
+      if (i < n_slot) s = s + e.x;
+      if (i + 1 < 7 && i + 1 < n_slot) s = s + e.y;
+    }
     const float f0 = bsp::exp(lg[q] - mx) / bsp::wsum64(s);
     const float* x = a.d_in + (a.io_stride != 0 ? (size_t)stepc::slot(a.hop) * a.io_stride : 0) + row * B_IN_HOP;
     float en = 0.0f;
@@ -430,6 +455,11 @@ struct CondArgs {
   int n_bins;          // rows of pitch_emb: 448, or 384 in the legacy generations -- which also have no formant table
                        // (frm_tab == nullptr): their conditioning is the ONE row add_tab[add_idx] the host hands over per hop
 };
+__device__ __forceinline__ void globalize(CondArgs& a) {
+  a.q = as_global(a.q); a.feat = as_global(a.feat); a.pitch_emb = as_global(a.pitch_emb); a.feat_w = as_global(a.feat_w);
+  a.add_tab = as_global(a.add_tab); a.add_idx = as_global(a.add_idx); a.frm_tab = as_global(a.frm_tab); a.frm_idx = as_global(a.frm_idx);
+  globalize(a.e); a.hop = as_global(a.hop); a.hop_next_out = as_global(a.hop_next_out);
+}
 __device__ __forceinline__ void wave_cond_body(const CondArgs& a, const int row, const int n = threadIdx.x) {
   const int b = row / a.H;
   const int hop = stepc::step(a.hop);

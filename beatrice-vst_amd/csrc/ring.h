@@ -17,6 +17,35 @@ struct Ring {
   int m;  // hop slots
 };
 
+// Pointers that reach a kernel through a table in device memory (the tick launch, fuse.hip.h) are GENERIC to the compiler:
+// it cannot see that they point to global memory and emits flat_load / flat_store -- which count on BOTH vmcnt and lgkmcnt,
+// so every wait for an LDS operand (s_waitcnt lgkmcnt(0): flat and LDS results return out of order) also waits for every
+// weight prefetch in flight.  A round trip through address space 1 tells the compiler what it is (InferAddressSpaces then
+// emits global_load / global_store with their own counter and the ISA shows the intended `s_waitcnt vmcnt(8) lgkmcnt(7)`).
+// MEASURED (round 4, same box, A/B): the tick launch is 4 % SLOWER with it (69.2 vs 66.5 us at 256 streams, 241 vs 232 us at
+// 1 024) -- VGPR spills 48 -> 112 in the table kernel, and the launch is bound by ALU issue, not by exposed latency.  The
+// helpers stay for kernels that take pointers from memory and ARE latency-bound; fuse::run_type uses them only under
+// -DFUSE_GLOBALIZE.
+// (A plain generic -> global -> generic cast is folded away by the front end; the empty asm between the two casts keeps it.
+//  "s": the pointer is wave-uniform and stays in scalar registers -- as_global_v for a pointer that may differ between lanes.)
+template <class T>
+__device__ __forceinline__ T* as_global(T* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);   // (readfirstlane: a no-op for a value already known uniform)
+  const unsigned long long u = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v) |
+                               ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32);
+  __attribute__((address_space(1))) T* g = (__attribute__((address_space(1))) T*)reinterpret_cast<T*>(u);
+  asm("" : "+s"(g));
+  return (T*)g;
+}
+template <class T>
+__device__ __forceinline__ T* as_global_v(T* p) {
+  __attribute__((address_space(1))) T* g = (__attribute__((address_space(1))) T*)p;
+  asm("" : "+v"(g));
+  return (T*)g;
+}
+// globalize(args): every pointer of an argument block through as_global (one overload per block type, next to its struct)
+__device__ __forceinline__ void globalize(Ring& r) { r.base = as_global(r.base); }
+
 __host__ __device__ inline int ring_frames(const Ring& r) { return r.n * r.m; }
 __host__ __device__ inline size_t ring_stream_floats(const Ring& r) { return (size_t)r.n * r.m * r.C; }
 

@@ -180,10 +180,11 @@ __device__ __forceinline__ void mma_segment(f32x4 (&acc)[CG], const float* __res
 }
 
 // A layer over 16 rows: K = NSEG segments of 256 (segment s read from LDS tile seg[s], row stride `as`), N = 16 * 8 * CG
-// columns; wavefront w owns column tiles w, w + 8, ...  epi(row, col, value) receives the ordered sum of the segments.
-template <int NSEG, int CG, class Epi>
+// columns; wavefront w owns column tiles w, w + 8, ...  epi4(first row, col, values) receives the ordered sums of the segments
+// for the four consecutive rows a lane owns of one column (pairs of them go through the packed scalar functions, spec_math.hip.h).
+template <int NSEG, int CG, class Epi4>
 __device__ __forceinline__ void layer256(const float* const (&seg)[NSEG], const int as, const float* __restrict__ w_packed,
-                                         const int wave, const int lane, Epi epi) {
+                                         const int wave, const int lane, Epi4 epi4) {
   constexpr int K = NSEG * 256;
   const float4* wf = reinterpret_cast<const float4*>(w_packed) + (size_t)wave * (K / 16) * 64 + lane;
   const size_t tile_stride = (size_t)NWAVE * (K / 16) * 64;
@@ -201,9 +202,7 @@ __device__ __forceinline__ void layer256(const float* const (&seg)[NSEG], const 
     }
   }
 #pragma unroll
-  for (int c = 0; c < CG; ++c)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) epi((lane >> 4) * 4 + e, (wave + NWAVE * c) * 16 + (lane & 15), tot[c][e]);
+  for (int c = 0; c < CG; ++c) epi4((lane >> 4) * 4, (wave + NWAVE * c) * 16 + (lane & 15), tot[c]);   // rows r0 .. r0 + 3 of one column
 }
 
 // [16 rows][256 channels] from a ring into an LDS tile; row r = frame `rel` of stream sid[r] (zeros when sid[r] < 0)
@@ -229,6 +228,10 @@ struct BlockAArgs {
   const int* hop;
   int B;
 };
+__device__ __forceinline__ void globalize(BlockAArgs& a) {
+  globalize(a.x); globalize(a.xa);
+  a.c1_w = as_global(a.c1_w); a.c1_b = as_global(a.c1_b); a.c2_w = as_global(a.c2_w); a.c2_b = as_global(a.c2_b); a.hop = as_global(a.hop);
+}
 constexpr int kBlockALds = 4 * TILE + 16;
 template <int D>
 __device__ __forceinline__ void block_a_body(const BlockAArgs& a, const int g, float* __restrict__ lds) {
@@ -247,16 +250,25 @@ __device__ __forceinline__ void block_a_body(const BlockAArgs& a, const int g, f
   {
     const float* const seg[3] = {T[0], T[1], T[2]};
     const float* __restrict__ bias = a.c1_b;
-    layer256<3, 2>(seg, AS, a.c1_w, wave, lane, [&](int r, int n, float v) { Hh[r * AS + n] = bsp::gelu(v + bias[n]); });
+    layer256<3, 2>(seg, AS, a.c1_w, wave, lane, [&](int r0, int n, const f32x4& v) {
+      const float bn = bias[n];
+      const bsp::f32x2 g0 = bsp::gelu2(bsp::f32x2{v[0] + bn, v[1] + bn}), g1 = bsp::gelu2(bsp::f32x2{v[2] + bn, v[3] + bn});
+      float* h = Hh + r0 * AS + n;
+      h[0] = g0.x; h[AS] = g0.y; h[2 * AS] = g1.x; h[3 * AS] = g1.y;
+    });
   }
   __syncthreads();
   {
     const float* const seg[1] = {Hh};
     const float* __restrict__ bias = a.c2_b;
     const int pos_o = ring_pos(a.xa, hop);
-    layer256<1, 2>(seg, AS, a.c2_w, wave, lane, [&](int r, int n, float v) {
-      const int b = sid[r];
-      if (b >= 0) ring_frame(a.xa, b, pos_o, 0)[n] = T[2][r * AS + n] + (v + bias[n]);
+    layer256<1, 2>(seg, AS, a.c2_w, wave, lane, [&](int r0, int n, const f32x4& v) {
+      const float bn = bias[n];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int b = sid[r0 + e];
+        if (b >= 0) ring_frame(a.xa, b, pos_o, 0)[n] = T[2][(r0 + e) * AS + n] + (v[e] + bn);
+      }
     });
   }
 }
@@ -289,6 +301,11 @@ struct BlockBArgs {
   const int* tile_slot;            // [n_tiles]
   const int* hop;
 };
+__device__ __forceinline__ void globalize(BlockBArgs& a) {
+  globalize(a.xa); globalize(a.out);
+  a.q_w = as_global(a.q_w); a.q_b = as_global(a.q_b); a.o_w = as_global(a.o_w); a.o_b = as_global(a.o_b);
+  a.kt = as_global(a.kt); a.v = as_global(a.v); a.perm = as_global(a.perm); a.tile_slot = as_global(a.tile_slot); a.hop = as_global(a.hop);
+}
 constexpr int kBlockBLds = 2 * TILE + STILE + 32;
 __device__ __forceinline__ void block_b_body(const BlockBArgs& a, const int g, float* __restrict__ lds) {
   float* XA = lds;
@@ -310,13 +327,20 @@ __device__ __forceinline__ void block_b_body(const BlockBArgs& a, const int g, f
     const float* const seg[1] = {XA};
     const float* __restrict__ bias = a.q_b;
     RC_STAMP(1);
-    layer256<1, 2>(seg, AS, a.q_w, wave, lane, [&](int r, int n, float v) { Q[r * AS + n] = v + bias[n]; });
+    layer256<1, 2>(seg, AS, a.q_w, wave, lane, [&](int r0, int n, const f32x4& v) {
+      const float bn = bias[n];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Q[(r0 + e) * AS + n] = v[e] + bn;
+    });
   }
   __syncthreads();
   RC_STAMP(2);
   {
     const float* const seg[1] = {Q};
-    layer256<1, 3>(seg, AS, a.kt + (size_t)slot * B_HID * B_KV_LEN, wave, lane, [&](int r, int n, float v) { S[r * SS + n] = v * 0.0625f; });
+    layer256<1, 3>(seg, AS, a.kt + (size_t)slot * B_HID * B_KV_LEN, wave, lane, [&](int r0, int n, const f32x4& v) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) S[(r0 + e) * SS + n] = v[e] * 0.0625f;
+    });
   }
   __syncthreads();
   RC_STAMP(3);
@@ -333,7 +357,11 @@ __device__ __forceinline__ void block_b_body(const BlockBArgs& a, const int g, f
     mx = bsp::wmax64(mx);
     float s = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { const float e = bsp::exp(v[i] - mx); s = s + e; S[r * SS + lane + 64 * i] = e; }
+    for (int i = 0; i < 6; i += 2) {   // (pairs through the packed exp: the same bits, half the instructions; the sum in index order as before)
+      const bsp::f32x2 e = bsp::exp2(bsp::f32x2{v[i] - mx, v[i + 1] - mx});
+      s = s + e.x; s = s + e.y;
+      S[r * SS + lane + 64 * i] = e.x; S[r * SS + lane + 64 * (i + 1)] = e.y;
+    }
     const float tot = bsp::wsum64(s);
     if (lane == 0) inv[r] = 1.0f / tot;
   }
@@ -361,9 +389,13 @@ __device__ __forceinline__ void block_b_body(const BlockBArgs& a, const int g, f
     const float* const seg[1] = {Q};
     const float* __restrict__ bias = a.o_b;
     const int pos_o = ring_pos(a.out, hop);
-    layer256<1, 2>(seg, AS, a.o_w, wave, lane, [&](int r, int n, float v) {
-      const int b = sid[r];
-      if (b >= 0) ring_frame(a.out, b, pos_o, 0)[n] = XA[r * AS + n] + (v + bias[n]);
+    layer256<1, 2>(seg, AS, a.o_w, wave, lane, [&](int r0, int n, const f32x4& v) {
+      const float bn = bias[n];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int b = sid[r0 + e];
+        if (b >= 0) ring_frame(a.out, b, pos_o, 0)[n] = XA[(r0 + e) * AS + n] + (v[e] + bn);
+      }
     });
   }
   RC_STAMP(6);
@@ -457,6 +489,11 @@ struct BlockBqArgs {
   const int* qslot;                      // [n_quads] slot or -1 (quad unused)
   const int* hop;
 };
+__device__ __forceinline__ void globalize(BlockBqArgs& a) {
+  globalize(a.xa); globalize(a.out);
+  a.q_w = as_global(a.q_w); a.q_b = as_global(a.q_b); a.o_w = as_global(a.o_w); a.o_b = as_global(a.o_b);
+  a.ktp = as_global(a.ktp); a.vp = as_global(a.vp); a.qperm = as_global(a.qperm); a.qslot = as_global(a.qslot); a.hop = as_global(a.hop);
+}
 constexpr int kBlockBqLds = kBlockBLds;
 __device__ __forceinline__ void block_bq_body(const BlockBqArgs& a, const int g, float* __restrict__ lds) {
   float* XA = lds;
@@ -482,7 +519,11 @@ __device__ __forceinline__ void block_bq_body(const BlockBqArgs& a, const int g,
     const float* const seg[1] = {XA};
     const float* __restrict__ bias = a.q_b;
     RC_STAMP(1);
-    layer256<1, 2>(seg, AS, a.q_w, wave, lane, [&](int r, int n, float v) { Q[r * AS + n] = v + bias[n]; });
+    layer256<1, 2>(seg, AS, a.q_w, wave, lane, [&](int r0, int n, const f32x4& v) {
+      const float bn = bias[n];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Q[(r0 + e) * AS + n] = v[e] + bn;
+    });
   }
   __syncthreads();
   RC_STAMP(2);
@@ -511,7 +552,11 @@ __device__ __forceinline__ void block_bq_body(const BlockBqArgs& a, const int g,
     mx = bsp::wmax64(mx);
     float s = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { const float e = bsp::exp(v[i] - mx); s = s + e; S[r * SS + lane + 64 * i] = e; }
+    for (int i = 0; i < 6; i += 2) {   // (pairs through the packed exp: the same bits, half the instructions; the sum in index order as before)
+      const bsp::f32x2 e = bsp::exp2(bsp::f32x2{v[i] - mx, v[i + 1] - mx});
+      s = s + e.x; s = s + e.y;
+      S[r * SS + lane + 64 * i] = e.x; S[r * SS + lane + 64 * (i + 1)] = e.y;
+    }
     const float tot = bsp::wsum64(s);
     if (lane == 0) inv[r] = 1.0f / tot;
   }
@@ -537,9 +582,13 @@ __device__ __forceinline__ void block_bq_body(const BlockBqArgs& a, const int g,
     const float* const seg[1] = {Q};
     const float* __restrict__ bias = a.o_b;
     const int pos_o = ring_pos(a.out, hop);
-    layer256<1, 2>(seg, AS, a.o_w, wave, lane, [&](int r, int n, float v) {
-      const int b = sid[r];
-      if (b >= 0) ring_frame(a.out, b, pos_o, 0)[n] = XA[r * AS + n] + (v + bias[n]);
+    layer256<1, 2>(seg, AS, a.o_w, wave, lane, [&](int r0, int n, const f32x4& v) {
+      const float bn = bias[n];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int b = sid[r0 + e];
+        if (b >= 0) ring_frame(a.out, b, pos_o, 0)[n] = XA[(r0 + e) * AS + n] + (v[e] + bn);
+      }
     });
   }
   __builtin_amdgcn_s_setprio(0);
@@ -657,24 +706,39 @@ __device__ __forceinline__ void conv_rows_body(const ConvArgs& a, const int bx, 
   const int pos_out = ring_pos(a.out, hop), R_out = a.out.n * a.out.m;
   int pos_res = 0, R_res = 0;
   if constexpr (L::RES) { pos_res = ring_pos(a.res, hop); R_res = a.res.n * a.res.m; }
+  float bias_n[CG];
+#pragma unroll
+  for (int c = 0; c < CG; ++c) {
+    const int nt = wave + NWAVE * c < NTL ? wave + NWAVE * c : NTL - 1;
+    bias_n[c] = L::EPI == EPI_BIAS ? a.bias[(nt_base + nt) * 16 + (lane & 15)] : 0.0f;
+  }
 #pragma unroll
   for (int t = 0; t < RT; ++t)
 #pragma unroll
     for (int c = 0; c < CG; ++c) {
       if (wave + NWAVE * c >= NTL) continue;
       const int n = (nt_base + wave + NWAVE * c) * 16 + (lane & 15);
+      float v[4];
+      int rb[4], rf[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 16 * t + (lane >> 4) * 4 + e;
-        const int b = rb_[r], fr = rb_[ROWS + r];
-        if (b < 0) continue;
-        float v = tot[t][c][e];
-        if constexpr (L::EPI == EPI_BIAS) v = v + a.bias[n];
-        if constexpr (L::EPI == EPI_SCALE) v = v * a.scale;
-        if constexpr (L::EPI == EPI_ROWSCALE) v = v * a.rowscale[b * L::T + fr];
-        if constexpr (L::ACT == ACT_GELU) v = bsp::gelu(v);
-        if constexpr (L::RES) v = a.res.base[((size_t)b * R_res + pos_res) * a.res.C + (size_t)fr * L::NOUT + n] + v;
-        a.out.base[((size_t)b * R_out + pos_out) * a.out.C + (size_t)fr * L::NOUT + n] = v;
+        rb[e] = rb_[r]; rf[e] = rb_[ROWS + r];
+        v[e] = tot[t][c][e];
+        if constexpr (L::EPI == EPI_BIAS) v[e] = v[e] + bias_n[c];
+        if constexpr (L::EPI == EPI_SCALE) v[e] = v[e] * a.scale;
+        if constexpr (L::EPI == EPI_ROWSCALE) v[e] = v[e] * a.rowscale[(rb[e] < 0 ? 0 : rb[e]) * L::T + rf[e]];
+      }
+      if constexpr (L::ACT == ACT_GELU) {   // pairs through the packed scalar functions (spec_math.hip.h): the same bits
+        const bsp::f32x2 g0 = bsp::gelu2(bsp::f32x2{v[0], v[1]}), g1 = bsp::gelu2(bsp::f32x2{v[2], v[3]});
+        v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (rb[e] < 0) continue;
+        // (32-bit index arithmetic: a ring holds fewer than 2^32 floats, RingArena::build)
+        if constexpr (L::RES) v[e] = a.res.base[(unsigned)(rb[e] * R_res + pos_res) * (unsigned)a.res.C + (unsigned)(rf[e] * L::NOUT + n)] + v[e];
+        a.out.base[(unsigned)(rb[e] * R_out + pos_out) * (unsigned)a.out.C + (unsigned)(rf[e] * L::NOUT + n)] = v[e];
       }
     }
 }

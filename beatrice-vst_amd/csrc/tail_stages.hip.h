@@ -65,6 +65,11 @@ struct StageArgs {
   const int* hop;
   int B;
 };
+__device__ __forceinline__ void globalize(StageArgs& a) {
+  globalize(a.in); globalize(a.out); a.state = as_global(a.state);
+  for (int i = 0; i < 3; ++i) { a.w[i] = as_global(a.w[i]); a.b[i] = as_global(a.b[i]); }
+  a.fin_w = as_global(a.fin_w); a.fin_b = as_global(a.fin_b); a.d_out = as_global(a.d_out); a.hop = as_global(a.hop);
+}
 
 // lrelu(x) = max(x, 0.1 x), bit for bit MODEL_SPEC's `x > 0 ? x : 0.1 x` (x and 0.1 x have the same sign).  The instruction
 // itself: fmaxf() makes the compiler canonicalise both operands first (two more VALU instructions per value).
@@ -505,7 +510,7 @@ __device__ __forceinline__ void t3_body(const StageArgs& a, const int g, float* 
       for (int j = 0; j < 7; ++j)
 #pragma unroll
         for (int c = 0; c < 16; ++c) acc = bsp::fma(x[j * cs<C>() + c], FW[j * 16 + c], acc);
-      d_out[(size_t)(b0 + s) * B_OUT_HOP + t] = bsp::tanh(acc + fin_b);
+      d_out[(size_t)(b0 + s) * B_OUT_HOP + t] = bsp::tanh2(bsp::splat2(acc + fin_b)).x;   // (the packed form is the shorter one even for a single value)
     }
   }
   hin_to_state<C, S, TS_YA4>(a, HIN, b0, tid);

@@ -51,6 +51,11 @@ struct TailArgs {
   unsigned long long* stamps;  // tools/microbench/tail_timing.hip: [B][16] wall-clock stamps per phase
 #endif
 };
+__device__ __forceinline__ void globalize(TailArgs& a) {
+  globalize(a.in); a.state = as_global(a.state);
+  for (int i = 0; i < 8; ++i) { a.w[i] = as_global(a.w[i]); a.b[i] = as_global(a.b[i]); }
+  a.fin_w = as_global(a.fin_w); a.fin_b = as_global(a.fin_b); a.d_out = as_global(a.d_out); a.hop = as_global(a.hop);
+}
 #ifdef TAIL_TIMING
 #define TAIL_STAMP(i) do { if (tid == 0) a.stamps[b * 16 + (i)] = wall_clock64(); } while (0)
 // finer split, accumulated over the layers by wavefront 0 (tools/microbench/tail_timing.hip): k = 0 MFMA loop, 1 epilogue,

@@ -54,6 +54,12 @@ int BeatriceHip_SetDevice(int ordinal);
 int BeatriceHip_GetDevice(void);
 int BeatriceBatch_Device(const BeatriceBatch* b);
 
+/* Test support: the packed (two results per instruction) forms of MODEL_SPEC's scalar functions that the kernels use
+ * (csrc/spec_math.hip.h) against their scalar definitions, on the device, for ALL 2^32 float32 bit patterns (NaN excluded).
+ * which: 0 exp, 1 tanh, 2 gelu, 3 sigmoid.  Returns the number of inputs whose results differ in any bit (0 = identical),
+ * *first_bad_bits = the lowest such input (0xffffffff when none); -1 on a HIP failure or an unknown `which`. */
+long long BeatriceHip_MathSelfTest(int which, unsigned* first_bad_bits);
+
 /* Device-resident parameter blobs, for loading a model on several GPUs from ONE file read.
  * kind: 1 phone extractor, 2 pitch estimator, 3 waveform generator, 4 embedding setter; `model` the matching object.
  * BeatriceHip_ModelBlob returns the object's parameter blob as it sits on the device (already in the kernels' packed

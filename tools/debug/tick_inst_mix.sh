@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/tick_inst_mix.txt
 : > $OUT
-for drop in 0 1 2 4 8 16 32 64 128; do
+for drop in ${DROPS:-0 1 2 4 8 16 32 64 128}; do
   rm -rf /tmp/pmc
   BEATRICE_HIP_TICK_DROP=$drop rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_BRANCH --kernel-trace --output-format csv -d /tmp/pmc -o p -- python $ROOT/bench.py --steps 100 --warmup 10 --no-extras > /dev/null 2>&1
   python - "$(find /tmp/pmc -name '*counter_collection.csv' | head -1)" $drop >> $OUT <<'PY'

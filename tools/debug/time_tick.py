@@ -10,7 +10,7 @@ bv = importlib.import_module("beatrice-vst_amd")
 product = bv.bind_batch(bv.load_product())
 tmp = tempfile.TemporaryDirectory(); make_model.make_model(tmp.name, n_speakers=1)
 m = bv.Models(product, tmp.name)
-B, n = 256, 64
+B, n = (int(sys.argv[1]) if len(sys.argv) > 1 else 256), 64
 batch = bv.Batch(m, B)
 d_in = torch.randn((n, B, 160), device="cuda") * 0.1
 d_out = torch.zeros((n, B, 240), device="cuda")
