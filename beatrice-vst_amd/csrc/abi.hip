@@ -255,6 +255,15 @@ void Beatrice20rc0_SetCodebook(Beatrice20rc0_PhoneContext1* ctx, const float* co
   ctx->sel_cbT = hit->d_cbT;
   ctx->sel_cnorm = hit->d_cnorm;
 }
+// SetCodebook recognises a table by its address and a 96-word fingerprint (a per-hop call cannot hash 256 KB).  A caller that
+// rewrites a table IN PLACE in words the fingerprint does not sample (a model reload into the same storage samples all of
+// them with overwhelming probability; a deliberate edit may not) says so here, off the audio thread: entries made from
+// `codebook` (NULL: every entry) are forgotten, and the next SetCodebook of that address uploads the table again.
+extern "C" void BeatriceHip_InvalidateCodebook(Beatrice20rc0_PhoneContext1* ctx, const float* codebook) {
+  if (!ctx || !ctx->ok) return;
+  for (CodebookEntry& e : ctx->pool)
+    if (!codebook || e.host == codebook) { e.host = nullptr; e.print = 0; e.last_use = 0; }
+}
 // ref beatrice.h:243-247; caller processor_core_2.cc:183-185
 void Beatrice20rc0_ExtractPhone1(const Beatrice20rc0_PhoneExtractor* m, const float* input, float* output,
                                  Beatrice20rc0_PhoneContext1* ctx) {

@@ -230,7 +230,11 @@ struct BeatriceBatch {
     bool on = false;
     std::vector<unsigned char> next;    // [B] flags of the step to come (cleared by the step)
     bool any_next = false;
-    unsigned char *d_flags = nullptr, *h_flags = nullptr;   // [4][B]: a step's flags on the device / their pinned staging (four steps deep)
+    bool in_block_step = false;         // the step being enqueued belongs to a 48 kHz block (only those honour `next`)
+    static constexpr int kDepth = 4;
+    unsigned char *d_flags = nullptr, *h_flags = nullptr;   // [kDepth][B]: a step's flags on the device / their pinned staging
+    hipEvent_t flag_ev[kDepth] = {};                        // slot's upload AND the step that reads the device copy are done
+    bool flag_pending[kDepth] = {};
     FreezeRing* d_rings = nullptr;
     int n_rings = 0;
     float* d_keep = nullptr;            // copies of the single-slot rings, all streams
@@ -518,6 +522,7 @@ void draw_codebooks(BeatriceBatch* b) {
 }
 
 bool tick_run(BeatriceBatch* b, bool feeding);
+bool project_speakers(BeatriceBatch* b, int first, int count);
 // Host-buffer steps (BeatriceBatch_ConvertFrames) let the kernels read the pinned input mirror and write the pinned output
 // mirror directly: two copy commands around the chain cost a switch to the copy engine and back each (0.35 -> 0.31 ms per
 // step at 256 streams); every other kind of step uses the device buffers.
@@ -543,6 +548,10 @@ bool step_device(BeatriceBatch* b, const float* d_in, float* d_out) {
   if (b->io_slots > 0 && (d_in || d_out)) return false;  // resident I/O is bound: the step reads and writes its slots
   if (b->io_mapped != b->want_mapped && !set_io_mapped(b, b->want_mapped)) return false;
   if (b->tk.on) return tick_run(b, true);
+  if (b->silent.on && b->silent.any_next && !b->silent.in_block_step) {   // flags name streams of the next 48 kHz BLOCK: any other kind
+    std::fill(b->silent.next.begin(), b->silent.next.end(), 0);           // of step runs for every stream
+    b->silent.any_next = false;
+  }
   advance_kv(b);
   draw_codebooks(b);
   if (b->vq_dirty) { update_vq_mode(b); b->vq_dirty = false; }
@@ -876,7 +885,8 @@ size_t BeatriceBatch_StateBytes(const BeatriceBatch* b) {
 }
 
 // ---- speaker tables -----------------------------------------------------------------------------
-static bool project_speakers(BeatriceBatch* b, int first, int count) {
+namespace {
+bool project_speakers(BeatriceBatch* b, int first, int count) {
   hipStream_t s = b->stream;
   const EmbedWeights& w = b->embed_m->w;
   codebook_prepare(b->d_cb_raw + (size_t)first * B_CODEBOOK * B_PHONE_CH, count,
@@ -889,6 +899,7 @@ static bool project_speakers(BeatriceBatch* b, int first, int count) {
                      b->wave.d_vp[blk] ? b->wave.d_vp[blk] + (size_t)first * B_KV_LEN * B_HID : nullptr);
   return hip_ok(hipStreamSynchronize(s), "project speakers");
 }
+}  // namespace
 
 int BeatriceBatch_SetSpeakerTables(BeatriceBatch* b, int n, const float* codebooks, const float* additive, const float* formant,
                                    const float* kv) {
@@ -1020,8 +1031,12 @@ int BeatriceBatch_MorphSpeakerStaged(BeatriceBatch* b, int slot, int from_slot, 
   if (!b || !b->ok) return -2;
   if (from_slot < 0 || from_slot >= b->max_speakers || from_slot == slot) return -1;
   if (slot >= 0 && slot < b->max_speakers)
-    for (const StreamCfg& c : b->cfg)
+    for (const StreamCfg& c : b->cfg) {
       for (int blk = 0; blk < B_NBLOCKS; ++blk) if (c.kv_slot[blk] == slot) return -3;
+      // ... or is on its way there: installs still pending from an earlier staged call, or a stream that took `slot` by
+      // another route (its additive row and key/value tables would be overwritten under it)
+      if (c.target_speaker == slot || c.additive_speaker == slot) return -3;
+    }
   if (const int rc = morph_into(b, slot, weights, n_weights, seed)) return rc;
   for (int s = 0; s < b->B; ++s) {
     StreamCfg& c = b->cfg[s];
@@ -1170,6 +1185,7 @@ int BeatriceBatch_BindResidentIO(BeatriceBatch* b, const float* d_in, float* d_o
   const bool bind = d_in != nullptr || d_out != nullptr;
   if (bind && (!d_in || !d_out || n_slots < 1)) return -1;
   if (b->tk.on) return -1;  // leave tick mode first
+  if (bind && b->silent.on) return -1;  // the silent-block rule is an in-order mode of the 48 kHz blocks: switch it off first
   if (!set_io_mapped(b, false) || !sync_all(b)) return -2;
   b->io_host = 0;
   drop_graph(b);  // kernel arguments change
@@ -1243,6 +1259,7 @@ int BeatriceBatch_EnableTickPipeline(BeatriceBatch* b, int enable) {
   const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (b->hs.on || b->r48.on || b->rb.on) return -1;  // those modes own the tick pipeline: leave them instead
+  if (enable && b->silent.on) return -1;              // (see BeatriceBatch_EnableSilentBlockRule)
   return tick_enable(b, enable != 0);
 }
 int BeatriceBatch_TickStages(const BeatriceBatch* b) { return b ? b->tk.plan.count() : 0; }
@@ -1276,6 +1293,7 @@ int BeatriceBatch_EnablePipelining(BeatriceBatch* b, int enable) {
   if (b->tk.on) return -1;
   if (!set_io_mapped(b, false) || !sync_all(b)) return -2;
   if (enable < 0 || enable > BeatriceBatch::kMaxStages) return -1;
+  if (enable >= 1 && b->silent.on) return -1;  // (see BeatriceBatch_EnableSilentBlockRule)
   drop_graph(b);  // stages are captured on the streams they will run on
   set_plan(b, enable == 1 ? 2 : enable);  // 1 = the default depth
   for (int s = 1; s < b->n_stages && b->pipelined; ++s)  // every stream takes a hardware queue: only those in use exist

@@ -322,6 +322,26 @@ int tick_enable(BeatriceBatch* b, bool on) {
         return -2;
       for (hipEvent_t& e : k.stage_ev) if (!hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "tick staging event")) return -2;
     }
+    // the plain-order K / V copies the quad bodies read (rowchain.hip.h block_bq_body) exist in tick mode only: ~3 MB per
+    // speaker that the in-order, stage-pipelined and large-batch modes never read
+    if (!b->wave.legacy && !b->wave.d_ktp[0]) {
+      const size_t kvf = (size_t)b->wave.n_slots * B_HID * B_KV_LEN;
+      bool ok = true;
+      for (int blk = 0; blk < B_NBLOCKS && ok; ++blk)
+        ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&b->wave.d_ktp[blk]), sizeof(float) * kvf), "plain K") &&
+             hip_ok(hipMalloc(reinterpret_cast<void**>(&b->wave.d_vp[blk]), sizeof(float) * kvf), "plain V") &&
+             hip_ok(hipMemset(b->wave.d_ktp[blk], 0, sizeof(float) * kvf), "plain K zero") && hip_ok(hipMemset(b->wave.d_vp[blk], 0, sizeof(float) * kvf), "plain V zero");
+      // every entry that may hold a table (real speakers and morph slots): re-projected from the raw embeddings the batch keeps
+      if (ok && b->n_speakers > 0) ok = project_speakers(b, 0, b->max_speakers);
+      if (!ok) {
+        for (int blk = 0; blk < B_NBLOCKS; ++blk) {
+          if (b->wave.d_ktp[blk]) (void)hipFree(b->wave.d_ktp[blk]);
+          if (b->wave.d_vp[blk]) (void)hipFree(b->wave.d_vp[blk]);
+          b->wave.d_ktp[blk] = b->wave.d_vp[blk] = nullptr;
+        }
+        return -2;
+      }
+    }
     if (!hip_ok(hipDeviceSynchronize(), "tick sync")) return -2;
     k.tick = 0; k.n_fed = 0; k.last_feed_tick = -1000; k.snap_cur = -1; k.snap_next = 0;
     for (long long& f : k.fed_step) f = -1;
@@ -332,6 +352,12 @@ int tick_enable(BeatriceBatch* b, bool on) {
   }
   if (!sync_all(b)) return -2;  // drains
   k.on = false;
+  for (int blk = 0; blk < B_NBLOCKS; ++blk) {   // (see above: tick mode's own copies of the K / V tables)
+    if (b->wave.d_ktp[blk]) (void)hipFree(b->wave.d_ktp[blk]);
+    if (b->wave.d_vp[blk]) (void)hipFree(b->wave.d_vp[blk]);
+    b->wave.d_ktp[blk] = b->wave.d_vp[blk] = nullptr;
+  }
+  k.table_dirty = true;
   for (int blk = 0; blk < B_NBLOCKS; ++blk) rebuild_tiles(b, blk);
   // the in-order chain reads its counters from device memory: hand them the host's values
   const int pair[2] = {b->hop_host, b->io_host};

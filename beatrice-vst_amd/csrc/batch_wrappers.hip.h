@@ -6,13 +6,16 @@
 static bool step_48k(BeatriceBatch* b, const float* d_in48, float* d_out48, int channels) {
   BeatriceBatch::SilentRule& sr = b->silent;
   const unsigned char* frozen = nullptr;
-  if (sr.on && sr.any_next) {   // this step's flags travel to the device (a ring of four staging copies: the host runs at most a step ahead)
-    const int e = (int)(sr.steps & 3);
+  int flag_slot = -1;
+  if (sr.on && sr.any_next) {   // this step's flags travel to the device through a ring of staging copies; a slot is reused only
+    const int e = (int)(sr.steps % BeatriceBatch::SilentRule::kDepth);   // after the step that read it has finished (its event)
+    if (sr.flag_pending[e]) { BHIP_TRY(hipEventSynchronize(sr.flag_ev[e])); sr.flag_pending[e] = false; }
     unsigned char* h = sr.h_flags + (size_t)e * b->B;
     std::memcpy(h, sr.next.data(), b->B);
     unsigned char* d = sr.d_flags + (size_t)e * b->B;
     BHIP_TRY(hipMemcpyAsync(d, h, b->B, hipMemcpyHostToDevice, b->stream));
     frozen = d;
+    flag_slot = e;
   }
   if (sr.on) ++sr.steps;
   // the FIFO of the reference emits the PREVIOUS block's model output first (resample.h:346-361)
@@ -20,7 +23,9 @@ static bool step_48k(BeatriceBatch* b, const float* d_in48, float* d_out48, int 
   hipLaunchKernelGGL(wrap48_pre_kernel, dim3(b->B), dim3(256), 0, b->stream, d_in48, channels, b->d_w48, b->d_coef_down, b->d_in, frozen);
   if (frozen)
     hipLaunchKernelGGL(freeze_save_kernel, dim3(sr.n_rings, b->B), dim3(256), 0, b->stream, sr.d_rings, sr.d_keep, b->B, b->pitch.d_prev_q, sr.d_keep_prev_q);
+  sr.in_block_step = true;
   const bool ok = step_device(b, nullptr, nullptr);   // (advance_kv / draw_codebooks skip the flagged streams)
+  sr.in_block_step = false;
   if (frozen) {
     std::fill(sr.next.begin(), sr.next.end(), 0);
     sr.any_next = false;
@@ -30,10 +35,12 @@ static bool step_48k(BeatriceBatch* b, const float* d_in48, float* d_out48, int 
     hipLaunchKernelGGL(freeze_fix_kernel, dim3(sr.n_rings, b->B), dim3(256), 0, b->stream, sr.d_rings, sr.d_keep, b->B, frozen, b->last_hop,
                        b->pitch.d_prev_q, sr.d_keep_prev_q);
   hipLaunchKernelGGL(wrap48_latch_kernel, dim3((b->B * 240 + 255) / 256), dim3(256), 0, b->stream, b->d_w48, b->wave.d_out, b->B, frozen);
+  if (flag_slot >= 0) { BHIP_TRY(hipEventRecord(sr.flag_ev[flag_slot], b->stream)); sr.flag_pending[flag_slot] = true; }
   return hip_ok(hipGetLastError(), "wrap48");
 }
 static void silent_release(BeatriceBatch* b) {
   BeatriceBatch::SilentRule& sr = b->silent;
+  for (hipEvent_t& e : sr.flag_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (sr.d_flags) (void)hipFree(sr.d_flags);
   if (sr.h_flags) (void)hipHostFree(sr.h_flags);
   if (sr.d_rings) (void)hipFree(sr.d_rings);
@@ -68,8 +75,9 @@ int BeatriceBatch_EnableSilentBlockRule(BeatriceBatch* b, int enable) {
             hip_ok(hipMemcpy(sr.d_rings, rings.data(), sizeof(FreezeRing) * rings.size(), hipMemcpyHostToDevice), "silent rings up") &&
             hip_ok(hipMalloc(reinterpret_cast<void**>(&sr.d_keep), sizeof(float) * std::max<size_t>(keep, 1)), "silent keep") &&
             hip_ok(hipMalloc(reinterpret_cast<void**>(&sr.d_keep_prev_q), sizeof(int) * b->B), "silent prev_q") &&
-            hip_ok(hipMalloc(reinterpret_cast<void**>(&sr.d_flags), 4 * (size_t)b->B), "silent flags") &&
-            hip_ok(hipHostMalloc(reinterpret_cast<void**>(&sr.h_flags), 4 * (size_t)b->B, hipHostMallocDefault), "silent flags host");
+            hip_ok(hipMalloc(reinterpret_cast<void**>(&sr.d_flags), BeatriceBatch::SilentRule::kDepth * (size_t)b->B), "silent flags") &&
+            hip_ok(hipHostMalloc(reinterpret_cast<void**>(&sr.h_flags), BeatriceBatch::SilentRule::kDepth * (size_t)b->B, hipHostMallocDefault), "silent flags host");
+  for (hipEvent_t& e : sr.flag_ev) ok = ok && hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "silent flag event");
   if (!ok) { silent_release(b); return -2; }
   sr.next.assign(b->B, 0);
   sr.any_next = false;
@@ -81,6 +89,7 @@ int BeatriceBatch_EnableSilentBlockRule(BeatriceBatch* b, int enable) {
 int BeatriceBatch_SetSilentStreams(BeatriceBatch* b, const unsigned char* flags) {
   if (!b || !b->ok) return -2;
   if (!b->silent.on || !flags) return -1;
+  if (b->H != 1 || b->pipelined || b->tk.on || b->io_slots > 0) return -1;   // (the rule's modes: EnableSilentBlockRule)
   b->silent.any_next = false;
   for (int s = 0; s < b->B; ++s) { b->silent.next[s] = flags[s] ? 1 : 0; b->silent.any_next = b->silent.any_next || flags[s]; }
   return 0;
@@ -104,7 +113,7 @@ int BeatriceBatch_BindResidentIO48k(BeatriceBatch* b, const float* d_in48, float
   }
   if (!d_in48 && !d_out48) return 0;
   if (!d_in48 || !d_out48 || channels < 1 || channels > 2 || n_slots < b->tk.plan.count() + 1 || b->H != 1 || b->io_slots > 0 || b->pipelined ||
-      b->tk.on || b->hs.on)
+      b->tk.on || b->hs.on || b->silent.on)   // (the silent-block rule is an in-order mode: switch it off first)
     return -1;
   bool ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_in16), sizeof(float) * n_slots * b->B * B_IN_HOP), "r48 in16") &&
             hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_out24), sizeof(float) * n_slots * b->B * B_OUT_HOP), "r48 out24") &&
@@ -355,7 +364,7 @@ int BeatriceBatch_BindResidentBlocks(BeatriceBatch* b, const float* d_in, float*
   if (!d_in && !d_out) return 0;
   const int stages = b->tk.plan.count();
   if (!b->wrap.ready || !d_in || !d_out || channels < 1 || channels > 2 || n < 1 || n > wrap_max_chunk(b) || n_slots < stages + 1 || b->H != 1 ||
-      b->io_slots > 0 || b->pipelined || b->tk.on || b->hs.on || b->r48.on)
+      b->io_slots > 0 || b->pipelined || b->tk.on || b->hs.on || b->r48.on || b->silent.on)
     return -1;
   // binding restarts the resampler pair and the FIFO (their in-order form keeps processed samples in the FIFO, this one does not)
   if (BeatriceBatch_ConfigureWrapper(b, b->wrap.rate) != 0) return -2;

@@ -77,12 +77,8 @@ bool WaveState::create(int B_, int H_, int n_slots_, int n_add_, int n_frm_, flo
     BHIP_TRY(hipMemset(d_kt[blk], 0, sizeof(float) * kvf));
     BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_v[blk]), sizeof(float) * kvf));
     BHIP_TRY(hipMemset(d_v[blk], 0, sizeof(float) * kvf));
-    if (pipe_slack && !legacy) {
-      BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_ktp[blk]), sizeof(float) * kvf));
-      BHIP_TRY(hipMemset(d_ktp[blk], 0, sizeof(float) * kvf));
-      BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_vp[blk]), sizeof(float) * kvf));
-      BHIP_TRY(hipMemset(d_vp[blk], 0, sizeof(float) * kvf));
-    }
+    // (the plain-order copies d_ktp / d_vp of these tables belong to tick mode only: the batch allocates and fills them when
+    //  tick mode is entered and frees them when it is left, batch_tick.hip.h tick_enable)
     BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_perm[blk]), sizeof(int) * perm.size()));
     BHIP_TRY(hipMemcpy(d_perm[blk], perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice));
     BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_tile_slot[blk]), sizeof(int) * slot.size()));

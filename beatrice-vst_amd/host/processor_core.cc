@@ -127,6 +127,26 @@ static void ConfigureBridge(RateBridge& b, double sr) {
 StreamingCore::StreamingCore(double sample_rate, int pitch_bins)
     : sample_rate_(sample_rate), pitch_bins_(pitch_bins), gain_in_(sample_rate), gain_out_(sample_rate), fifo_(kBlock, 0.0f) {
   ConfigureBridge(bridge_, sample_rate);
+  ReserveBlocks(kDefaultMaxBlock);
+}
+
+unsigned long long StreamingCore::BufferFingerprint() const {
+  unsigned long long h = 1469598103934665603ull;
+  for (const std::vector<float>* v : {&io_, &work_, &scratch_}) {
+    h = (h ^ reinterpret_cast<unsigned long long>(v->data())) * 1099511628211ull;
+    h = (h ^ static_cast<unsigned long long>(v->capacity())) * 1099511628211ull;
+  }
+  return h;
+}
+void StreamingCore::ReserveBlocks(int max_block) {
+  if (max_block < 1) return;
+  reserved_block_ = std::max(reserved_block_, max_block);
+  // inner (48 kHz) samples a host block can yield: n * 48000 / rate, + the clocks' slack
+  const double ratio = sample_rate_ > 0.0 ? 48000.0 / sample_rate_ : 1.0;
+  const size_t inner = static_cast<size_t>(std::ceil(reserved_block_ * std::max(1.0, ratio))) + 8;
+  io_.reserve(inner);
+  work_.reserve(inner);
+  scratch_.reserve(inner);
 }
 
 ProcessorCore2::ProcessorCore2(double sample_rate)
@@ -313,6 +333,7 @@ ErrorCode StreamingCore::SetSampleRate(double sr) {  // reference processor_core
   if (sr == sample_rate_) return ErrorCode::kSuccess;
   sample_rate_ = sr;
   ConfigureBridge(bridge_, sr);
+  ReserveBlocks(std::max(reserved_block_, kDefaultMaxBlock));
   std::fill(fifo_.begin(), fifo_.end(), 0.0f);
   fifo_fill_ = 0;
   gain_in_.SetSampleRate(sr);
@@ -472,6 +493,8 @@ int BeatriceHost_LoadModel(void* p, const char* toml_path) { return static_cast<
 int BeatriceHost_Process(void* p, const float* in, float* out, int n) { return static_cast<int>(core(p)->Process(in, out, n)); }
 int BeatriceHost_ResetContext(void* p) { return static_cast<int>(core(p)->ResetContext()); }
 int BeatriceHost_SetSampleRate(void* p, double v) { return static_cast<int>(core(p)->SetSampleRate(v)); }
+int BeatriceHost_ReserveBlocks(void* p, int max_block) { if (max_block < 1) return -1; core(p)->ReserveBlocks(max_block); return 0; }
+unsigned long long BeatriceHost_BufferFingerprint(void* p) { return core(p)->BufferFingerprint(); }
 int BeatriceHost_SetTargetSpeaker(void* p, int v) { return static_cast<int>(core(p)->SetTargetSpeaker(v)); }
 int BeatriceHost_SetFormantShift(void* p, double v) { return static_cast<int>(core(p)->SetFormantShift(v)); }
 int BeatriceHost_SetPitchShift(void* p, double v) { return static_cast<int>(core(p)->SetPitchShift(v)); }

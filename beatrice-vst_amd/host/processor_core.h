@@ -117,6 +117,9 @@ class ProcessorCoreBase {
   virtual void SetMorphSeed(std::uint32_t) {}
   virtual int n_speakers() const { return 0; }
   virtual std::vector<int> TakePitchTrace() { return {}; }
+  // (ours, not the reference's: see StreamingCore::ReserveBlocks)
+  virtual void ReserveBlocks(int /*max_block*/) {}
+  virtual unsigned long long BufferFingerprint() const { return 0; }
 };
 
 // The part every generation's core shares (reference processor_core_{0,1,2}.cc hold three copies of it): the guards of
@@ -162,6 +165,17 @@ class StreamingCore : public ProcessorCoreBase {
   std::vector<float> fifo_;  // 480-sample block adapter
   int fifo_fill_ = 0;
   std::vector<float> io_, work_, scratch_;
+  int reserved_block_ = 0;
+
+ public:
+  // The per-block buffers are sized HERE, off the audio thread, for host blocks of up to max_block samples (the VST shell
+  // announces its largest block before processing starts, IAudioProcessor::setupProcessing; the reference pre-sizes its
+  // buffers the same way, src/common/resample.h:303-305): Process() then never allocates.  Called by the constructor and
+  // by SetSampleRate with the default below; a host with larger blocks calls it itself.  A block beyond the reserve still
+  // works (the vectors grow, once).
+  static constexpr int kDefaultMaxBlock = 8192;
+  void ReserveBlocks(int max_block) override;
+  unsigned long long BufferFingerprint() const override;   // test hook: storage addresses and capacities of the per-block buffers
 };
 
 class ProcessorCore2 final : public StreamingCore {

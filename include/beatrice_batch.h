@@ -42,6 +42,11 @@ Beatrice_ErrorCode BeatriceHip_LoadPitchEstimatorFromMemory(Beatrice20rc0_PitchE
 Beatrice_ErrorCode BeatriceHip_LoadWaveformGeneratorFromMemory(Beatrice20rc0_WaveformGenerator* m, const void* bytes, size_t size);
 Beatrice_ErrorCode BeatriceHip_LoadEmbeddingSetterFromMemory(Beatrice20rc0_EmbeddingSetter* m, const void* bytes, size_t size);
 
+/* Beatrice20rc0_SetCodebook (beatrice.h:318-322) is called per hop on the audio thread in morph mode and therefore recognises
+ * a caller-owned table by address + a 96-word sample of its contents.  After rewriting a table IN PLACE (the same address)
+ * call this, off the audio thread, so that the next SetCodebook of it uploads the new contents; NULL forgets every table. */
+void BeatriceHip_InvalidateCodebook(Beatrice20rc0_PhoneContext1* ctx, const float* codebook);
+
 /* Several GPUs in one process (a C++ host with one thread per GPU, examples/node_convert.cc; the reference runs many plugin
  * instances per process, src/vst/factory.cc:21).  Every object of this library -- model objects, contexts, batches --
  * lives on ONE device, fixed when it is created: the calling thread's target device, BeatriceHip_SetDevice(ordinal)

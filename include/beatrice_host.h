@@ -32,6 +32,11 @@ int BeatriceHost_LoadModel(void* core, const char* toml_path);               /* 
 int BeatriceHost_Process(void* core, const float* in, float* out, int n);    /* processor_core_2.cc:24-48 (any n, host rate) */
 int BeatriceHost_ResetContext(void* core);                                   /* :258-291 */
 int BeatriceHost_SetSampleRate(void* core, double v);                        /* :421-429 */
+/* Sizes the per-block buffers for host blocks of up to max_block samples, off the audio thread (the constructor and
+ * SetSampleRate reserve 8192): Process then never allocates -- the reference's rule, src/common/resample.h:303-305.
+ * BufferFingerprint: test hook, changes whenever one of those buffers is reallocated. */
+int BeatriceHost_ReserveBlocks(void* core, int max_block);
+unsigned long long BeatriceHost_BufferFingerprint(void* core);
 int BeatriceHost_SetTargetSpeaker(void* core, int v);                        /* :431-466 */
 int BeatriceHost_SetFormantShift(void* core, double v);                      /* :468-481 */
 int BeatriceHost_SetPitchShift(void* core, double v);

@@ -21,6 +21,8 @@ class Host:
         L.BeatriceHost_ResetContext.argtypes = [C.c_void_p]
         L.BeatriceHost_NumSpeakers.argtypes = [C.c_void_p]
         L.BeatriceHost_TakePitchTrace.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
+        L.BeatriceHost_ReserveBlocks.argtypes = [C.c_void_p, C.c_int]
+        L.BeatriceHost_BufferFingerprint.restype, L.BeatriceHost_BufferFingerprint.argtypes = C.c_ulonglong, [C.c_void_p]
         for name in ("SetSampleRate", "SetFormantShift", "SetPitchShift", "SetInputGain", "SetOutputGain", "SetAverageSourcePitch",
                      "SetIntonationIntensity", "SetPitchCorrection", "SetMinSourcePitch", "SetMaxSourcePitch"):
             getattr(L, "BeatriceHost_" + name).argtypes = [C.c_void_p, C.c_double]

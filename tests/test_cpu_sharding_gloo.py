@@ -160,3 +160,26 @@ def test_speaker_affine_placement():
         sets = [{shard.affine_speaker(rank, world, s, n) for s in range(4 * n)} for rank in range(world)]
         assert sorted(x for st in sets for x in st) == list(range(n)), (world, n)
         assert all(x % world == rank for rank, st in enumerate(sets) for x in st)
+
+
+def test_world_8_partitions_at_the_baseline_config_sizes():
+    """BASELINE.json configs[3] (2048 streams, 64 rotating speakers) and configs[4] (512 stereo streams) over the 8 GPUs of a
+    node: the shards the 8-GPU run will use, checked here so that run needs no code -- 256 / 64 streams per rank, the shards
+    tile the job, and under speaker-affine placement every rank holds 8 speakers x 32 streams, i.e. every key/value slot of a
+    rank fills whole 16-row attention tiles (no padded tile, no quad: the tick launch's fast path)."""
+    shard = _load("beatrice_shard", os.path.join(REPO, "beatrice-vst_amd", "shard.py"))
+    world = 8
+    for total, per_rank in ((2048, 256), (512, 64)):
+        spans = [shard.stream_range(r, world, total) for r in range(world)]
+        assert [h - l for l, h in spans] == [per_rank] * world and spans[0][0] == 0 and spans[-1][1] == total
+    all_speakers = []
+    for rank in range(world):
+        spk = [shard.affine_speaker(rank, world, s, 64) for s in range(256)]
+        counts = {v: spk.count(v) for v in set(spk)}
+        assert len(counts) == 8 and set(counts.values()) == {32} and all(v % world == rank for v in counts)
+        assert all(c % 16 == 0 for c in counts.values())
+        all_speakers += list(counts)
+        # a stream that rotates to the next speaker stays on its rank's set: the rotation step is `world`
+        nxt = [shard.affine_speaker(rank, world, s + 1, 64) for s in range(256)]
+        assert set(nxt) == set(spk)
+    assert sorted(all_speakers) == list(range(64))

@@ -78,6 +78,42 @@ def test_codebook_rewritten_in_place_is_reuploaded(bv, oracle, product, model_di
     assert not np.array_equal(outs["hip"][5], outs["hip"][7])
 
 
+def test_codebook_edited_outside_the_fingerprint_needs_invalidate(bv, oracle, product, model_dir8):
+    """SetCodebook's identity test is address + a 96-word sample (a per-hop call cannot hash 256 KB): an in-place edit that
+    touches none of the sampled words is served from the device copy until the caller says so with
+    BeatriceHip_InvalidateCodebook (off the audio thread) -- after which the PCM equals the oracle's with the edited table."""
+    import ctypes as C
+    n = 512 * 128
+    sampled = set(range(16)) | set(n - 1 - i for i in range(16)) | set((i * 1021 + 389) % n for i in range(64))
+    hops = 10
+    x = bv.synth_audio(160 * hops, seed=33)
+    abi_b = bv.bind_batch(product)
+    outs = {}
+    for name, abi in (("oracle", oracle), ("hip", product)):
+        m = bv.Models(abi, model_dir8)
+        t = m.tables
+        table = np.ascontiguousarray(t.codebooks[3].copy())
+        other = t.codebooks[6].reshape(-1)
+        st = bv.Stream1(m, speaker=0, vq_k=2)
+        out = np.zeros((hops, bv.OUT_HOP), np.float32)
+        for h in range(hops):
+            if h == 5:   # every word the fingerprint does NOT look at takes the other speaker's value
+                flat = table.reshape(-1)
+                keep = {i: flat[i] for i in sampled}
+                flat[:] = other
+                for i, v in keep.items():
+                    flat[i] = v
+                if name == "hip":
+                    abi_b.BeatriceHip_InvalidateCodebook(st.pc, table.ctypes.data_as(C.c_void_p))
+            st.a.SetCodebook(st.pc, bv.fptr(table))
+            out[h] = st.hop(x[h * 160:(h + 1) * 160])
+        st.close()
+        m.close()
+        outs[name] = out
+    assert np.array_equal(outs["oracle"], outs["hip"]), "max-abs %g" % np.abs(outs["oracle"] - outs["hip"]).max()
+    assert not np.array_equal(outs["hip"][4], outs["hip"][6])
+
+
 def test_reloading_parameters_into_the_same_model_objects(bv, oracle, product, model_dir, tmp_path):
     """Read*Parameters on model objects that contexts have already run with (the device blobs are freed and re-allocated):
     the contexts' captured hop graphs are keyed on the blob, so the next hop re-captures instead of replaying kernels that

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 _f32p = C.POINTER(C.c_float)
 
 
-@pytest.mark.parametrize("channels,device_flags", [(2, False), (1, True)])
+@pytest.mark.parametrize("channels,device_flags", [(2, False), (1, True), (2, "ahead")])
 def test_silent_blocks_per_stream_match_the_host_proxy(bv, product, model_dir, channels, device_flags):
     B, blocks, n = 5, 26, 480
     rng = np.random.default_rng(5)
@@ -71,10 +71,15 @@ def test_silent_blocks_per_stream_match_the_host_proxy(bv, product, model_dir, c
     assert a.BeatriceBatch_EnableSilentBlockRule(h, 1) == 0
     got = np.zeros_like(x)
     hip = None
+    ahead = device_flags == "ahead"   # every block enqueued before ONE synchronisation: the flags of 26 steps in flight at once
     if device_flags:
         from tick_driver import Hip
         hip = Hip()
-        d_in, d_out = hip.malloc(B * channels * n * 4), hip.malloc(B * channels * n * 4)
+        per = B * channels * n * 4
+        d_in, d_out = hip.malloc(per * (blocks if ahead else 1)), hip.malloc(per * (blocks if ahead else 1))
+        if ahead:
+            for k in range(blocks):
+                hip.h2d(C.c_void_p(d_in.value + k * per), np.ascontiguousarray(x[:, :, k * n:(k + 1) * n]))
     for k in range(blocks):
         for s in range(B):
             if s in switch and switch[s][0] == k:
@@ -85,6 +90,9 @@ def test_silent_blocks_per_stream_match_the_host_proxy(bv, product, model_dir, c
         if device_flags:   # the caller names the silent streams of the block
             flags = bytes(1 if k in silent[s] else 0 for s in range(B))
             assert a.BeatriceBatch_SetSilentStreams(h, flags) == 0
+            if ahead:
+                assert a.BeatriceBatch_ConvertBlocks48kDevice(h, C.c_void_p(d_in.value + k * per), C.c_void_p(d_out.value + k * per), channels) == 0
+                continue
             hip.h2d(d_in, xin)
             assert a.BeatriceBatch_ConvertBlocks48kDevice(h, d_in, d_out, channels) == 0
             assert a.BeatriceBatch_Synchronize(h) == 0
@@ -92,6 +100,14 @@ def test_silent_blocks_per_stream_match_the_host_proxy(bv, product, model_dir, c
         else:              # host buffers: the library applies the shell's own test
             assert a.BeatriceBatch_ConvertBlocks48k(h, bv.fptr(xin), bv.fptr(out), channels) == 0
         got[:, :, sl] = out
+    if ahead:
+        assert a.BeatriceBatch_Synchronize(h) == 0
+        for k in range(blocks):
+            out = np.zeros((B, channels, n), np.float32)
+            hip.d2h(out, C.c_void_p(d_out.value + k * per))
+            got[:, :, k * n:(k + 1) * n] = out
+    # the rule is a mode of the in-order 48 kHz blocks: the throughput modes refuse while it is on, and it refuses inside them
+    assert a.BeatriceBatch_EnableTickPipeline(h, 1) == -1 and a.BeatriceBatch_EnablePipelining(h, 2) == -1
     assert a.BeatriceBatch_EnableSilentBlockRule(h, 0) == 0
     batch.close()
     m.close()

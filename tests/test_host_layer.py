@@ -109,3 +109,28 @@ def test_reset_context_restarts_the_stream(host_path, model_dir):
     assert np.array_equal(first, fresh)
     assert np.abs(second[4 * block:] - fresh[4 * block:]).max() < 0.5  # same model state; wrapper tails differ early
     h.close(); h2.close()
+
+
+def test_process_never_reallocates_its_block_buffers(host_path, model_dir):
+    """The reference's real-time rule (src/common/resample.h:303-305: buffers are sized when the rate is set, Process does not
+    allocate): the per-block buffers are reserved by the constructor / SetSampleRate / ReserveBlocks, and blocks up to the
+    reserve -- at a rate where the inner stream is LONGER than the host block -- leave their storage where it is."""
+    h = hostlib.Host(host_path, 24000.0)
+    assert h.load(model_dir) == 0
+    fp0 = h.call("BufferFingerprint")
+    x = wrapperlib.test_signal(3 * 8192 + 1000, 24000, seed=7)
+    pos = 0
+    for n in (64, 8192, 1, 8192, 4096, 8192, 999):   # the default reserve is 8192 host samples
+        h.process(x[pos:pos + n], n)
+        pos += n
+        assert h.call("BufferFingerprint") == fp0
+    assert h.call("SetSampleRate", 96000.0) == 0       # a new rate sizes them again (off the audio thread) ...
+    fp1 = h.call("BufferFingerprint")
+    h.process(x[:8192], 8192)
+    assert h.call("BufferFingerprint") == fp1
+    assert h.call("ReserveBlocks", 20000) == 0          # ... and a host with larger blocks says so before processing
+    fp2 = h.call("BufferFingerprint")
+    assert fp2 != fp1
+    h.process(x[:20000], 20000)
+    assert h.call("BufferFingerprint") == fp2
+    h.close()
