@@ -107,6 +107,8 @@ struct PhoneState {
   int out_ch = B_PHONE_CH;    // width of the phone vector (256: legacy generations, which have no codebook step)
   // pipe_slack: one more step slot on every ring a later layer reads, so that each LAYER may run as its own pipeline
   // stage one step behind its producer (batch.hip, tick mode)
+  unsigned long long* d_team_xb = nullptr;   // one stream, one hop per call: the eight convolutions as one team launch (team.hip.h)
+  int* d_team_dead = nullptr;
   bool create(int B, int H, float* shared_in, int out_slots = 1, bool pipe_slack = false, int out_ch = B_PHONE_CH);
   void destroy();
 };
@@ -146,6 +148,8 @@ struct PitchState {
   int* hop_in = nullptr;      // counter the first kernel (FFT) reads
   bool advance_hop = true;    // this module's forward ends with the counter increment
   int bins = B_PITCH_BINS;    // pitch classes (384: legacy generations)
+  unsigned long long* d_team_xb = nullptr;   // (see PhoneState)
+  int* d_team_dead = nullptr;
   bool create(int B, int H, float* shared_in, bool with_params, bool pipe_slack = false, int bins = B_PITCH_BINS);
   void destroy();
 };
@@ -224,6 +228,10 @@ struct WaveState {
   // legacy generations (MODEL_SPEC 6.3, 1-stream ABI only): the phone vector is 256 wide, the pitch embedding has 384 rows, the
   // conditioning vector is ONE additive row handed over per hop (n_frm = 0: no formant table), blocks are c1 + c2 only
   bool legacy = false;
+  // one stream, one hop per call (the 1-stream C-ABI): the layers from the input mix to the stage-2 transposed conv run as ONE
+  // launch of a team of workgroups (team.hip.h); these are its exchange buffers (granules) and its "a wait was given up" flag
+  unsigned long long* d_team_xb = nullptr;
+  int* d_team_dead = nullptr;
   bool create(int B, int H, int n_slots, int n_add, int n_frm, float* shared_phone, int* shared_q, float* shared_feat,
               int front_slots = 1, bool pipe_slack = false, bool legacy = false);
   void destroy();

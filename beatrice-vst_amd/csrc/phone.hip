@@ -1,7 +1,10 @@
 // phone.hip -- content encoder forward pass (MODEL_SPEC 4.1), the body of
 // Beatrice20rc0_ExtractPhone1 (reference lib/beatricelib/beatrice.h:243-247) for B streams and H
 // consecutive hops per step (H = 1: the real-time per-hop path; H > 1: block mode, batch.hip).
+#include <cstdlib>
+
 #include "chain_layers.hip.h"
+#include "team.hip.h"
 
 namespace bhip {
 
@@ -37,6 +40,13 @@ bool PhoneState::create(int B_, int H_, float* shared_in, int out_slots_, bool p
   BHIP_TRY(hipMemset(d_vqk, 0, sizeof(int) * B));
   BHIP_TRY(hipMemset(d_hop, 0, 2 * sizeof(int)));
   hop = d_hop; hop_in = d_hop;
+  if (B == 1 && H == 1) {   // the 1-stream ABI's team launch (team.hip.h); tag 0 = "never written"
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_team_xb), sizeof(unsigned long long) * team::kPhoneGranules));
+    BHIP_TRY(hipMemset(d_team_xb, 0, sizeof(unsigned long long) * team::kPhoneGranules));
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_team_dead), sizeof(int)));
+    BHIP_TRY(hipMemset(d_team_dead, 0, sizeof(int)));
+    BHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(team::phone_team_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, team::kLdsFloats * 4));
+  }
   // hipMemset is asynchronous and runs on the NULL stream, which the (non-blocking) compute streams
   // do not wait for: make every initialisation above visible before the first kernel can start
   BHIP_TRY(hipDeviceSynchronize());
@@ -50,6 +60,9 @@ void PhoneState::destroy() {
   if (d_cnorm) (void)hipFree(d_cnorm);
   if (d_vqk) (void)hipFree(d_vqk);
   if (d_hop) (void)hipFree(d_hop);
+  if (d_team_xb) (void)hipFree(d_team_xb);
+  if (d_team_dead) (void)hipFree(d_team_dead);
+  d_team_xb = nullptr; d_team_dead = nullptr;
   d_in = d_phone = nullptr; d_cbT = d_cnorm = nullptr; d_vqk = d_hop = nullptr;
 }
 
@@ -74,6 +87,20 @@ static void phone_forward_h(const PhoneWeights& w, const PhoneState& s, hipStrea
   const int B = s.B;
   const F1Args fa = f1_args(w, s);
   launch_site(f1_info(s), st, [&] { hipLaunchKernelGGL(phone_f1_kernel, dim3(B, H), dim3(256), 0, st, fa); });
+  static const bool no_team = std::getenv("BEATRICE_HIP_NO_TEAM") != nullptr;
+  if (H == 1 && B == 1 && s.d_team_xb != nullptr && !no_team) {   // one stream: f2 .. f5 and the residual blocks as ONE launch (team.hip.h)
+    using namespace team;
+    PhoneTeamArgs a{};
+    gran_t* g = s.d_team_xb;
+    auto take = [&g](size_t n) { gran_t* p = g; g += n; return p; };
+    a.f[0] = Tensor{s.f[0], nullptr};
+    a.f[1] = Tensor{s.f[1], take(8 * 128)}; a.f[2] = Tensor{s.f[2], take(4 * 256)}; a.f[3] = Tensor{s.f[3], take(2 * 256)}; a.f[4] = Tensor{s.f[4], take(256)};
+    for (int i = 0; i < 4; ++i) { a.rb[i] = Tensor{s.rb[i], take(256)}; a.rb_w[i] = w.rb_w[i]; a.rb_b[i] = w.rb_b[i]; a.f_w[i] = w.f_w[i]; a.f_b[i] = w.f_b[i]; }
+    a.hop = s.hop; a.dead = s.d_team_dead;
+    launch_site(LaunchInfo{"phone.team", 2.0 * (8 * 512.0 * 128 + 4 * 512.0 * 256 + 2 * 1024.0 * 256 + 1024.0 * 256 + 4 * 1280.0 * 256),
+                           4.0 * (512.0 * 128 + 512.0 * 256 + 2 * 1024.0 * 256 + 4 * 1280.0 * 256)},
+                st, [&] { hipLaunchKernelGGL(phone_team_kernel, dim3(NWG), dim3(NTHR), kLdsFloats * 4, st, a); });
+  } else {
   launch_auto<typename PL::F2>("phone.f2", conv_args(s.f[0], s.f[1], w.f_w[0], w.f_b[0], s.hop, B), st);
   launch_auto<typename PL::F3>("phone.f3", conv_args(s.f[1], s.f[2], w.f_w[1], w.f_b[1], s.hop, B), st);
   launch_auto<typename PL::F4>("phone.f4", conv_args(s.f[2], s.f[3], w.f_w[2], w.f_b[2], s.hop, B), st);
@@ -82,6 +109,7 @@ static void phone_forward_h(const PhoneWeights& w, const PhoneState& s, hipStrea
   for (int i = 0; i < 4; ++i) {
     launch_auto<typename PL::RBL>("phone.rb", conv_args(*cur, s.rb[i], w.rb_w[i], w.rb_b[i], s.hop, B), st);
     cur = &s.rb[i];
+  }
   }
   for (int t = 0; t < H; ++t) {  // the recurrence is sequential over the hops of the step
     GruArgs ga{s.rb[3], s.h, w.gru_wih, w.gru_whh, w.gru_bih, w.gru_bhh, s.hop, B, t};

@@ -1,7 +1,10 @@
 // pitch.hip -- pitch estimator forward pass (MODEL_SPEC 4.2), the body of
 // Beatrice20rc0_EstimatePitch1 (reference lib/beatricelib/beatrice.h:266-271) for B streams and H
 // consecutive hops per step.
+#include <cstdlib>
+
 #include "chain_layers.hip.h"
+#include "team.hip.h"
 
 namespace bhip {
 
@@ -46,14 +49,22 @@ bool PitchState::create(int B_, int H_, float* shared_in, bool with_params, bool
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hop), 2 * sizeof(int)));
   BHIP_TRY(hipMemset(d_hop, 0, 2 * sizeof(int)));
   hop = d_hop; hop_in = d_hop;
+  if (B == 1 && H == 1) {   // the 1-stream ABI's team launch (team.hip.h); tag 0 = "never written"
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_team_xb), sizeof(unsigned long long) * team::kPitchGranules));
+    BHIP_TRY(hipMemset(d_team_xb, 0, sizeof(unsigned long long) * team::kPitchGranules));
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_team_dead), sizeof(int)));
+    BHIP_TRY(hipMemset(d_team_dead, 0, sizeof(int)));
+    BHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(team::pitch_team_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, team::kLdsFloats * 4));
+  }
   BHIP_TRY(hipDeviceSynchronize());  // NULL-stream memsets vs non-blocking compute streams
   return true;
 }
 void PitchState::destroy() {
   arena.release();
   if (owns_in && d_in) (void)hipFree(d_in);
-  void* ptrs[] = {d_min_q, d_max_q, d_prev_q, d_q_raw, d_q, d_feat, d_params, d_hop};
+  void* ptrs[] = {d_min_q, d_max_q, d_prev_q, d_q_raw, d_q, d_feat, d_params, d_hop, d_team_xb, d_team_dead};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  d_team_xb = nullptr; d_team_dead = nullptr;
   d_in = d_feat = nullptr; d_min_q = d_max_q = d_prev_q = d_q_raw = d_q = d_hop = nullptr; d_params = nullptr;
 }
 
@@ -67,9 +78,20 @@ static void pitch_forward_h(const PitchWeights& w, const PitchState& s, hipStrea
   const int B = s.B;
   const FftArgs fa = fft_args(w, s);
   launch_site(fft_info(s), st, [&] { hipLaunchKernelGGL(pitch_fft_kernel, dim3(B, H), dim3(256), 0, st, fa); });
-  launch_auto<typename QL::P1>("pitch.p1", conv_args(s.spec, s.p[0], w.p_w[0], w.p_b[0], s.hop, B), st);
-  launch_auto<typename QL::P23>("pitch.p23", conv_args(s.p[0], s.p[1], w.p_w[1], w.p_b[1], s.hop, B), st);
-  launch_auto<typename QL::P23>("pitch.p23", conv_args(s.p[1], s.p[2], w.p_w[2], w.p_b[2], s.hop, B), st);
+  static const bool no_team = std::getenv("BEATRICE_HIP_NO_TEAM") != nullptr;
+  if (H == 1 && B == 1 && s.d_team_xb != nullptr && !no_team) {   // one stream: the three convolutions as ONE launch (team.hip.h)
+    using namespace team;
+    PitchTeamArgs a{};
+    a.spec = Tensor{s.spec, nullptr};
+    for (int i = 0; i < 3; ++i) { a.p[i] = Tensor{s.p[i], s.d_team_xb + 128 * i}; a.p_w[i] = w.p_w[i]; a.p_b[i] = w.p_b[i]; }
+    a.hop = s.hop; a.dead = s.d_team_dead;
+    launch_site(LaunchInfo{"pitch.team", 2.0 * (1536.0 * 128 + 2 * 384.0 * 128), 4.0 * (1536.0 * 128 + 2 * 384.0 * 128)}, st,
+                [&] { hipLaunchKernelGGL(pitch_team_kernel, dim3(kPitchTeamWgs), dim3(NTHR), kLdsFloats * 4, st, a); });
+  } else {
+    launch_auto<typename QL::P1>("pitch.p1", conv_args(s.spec, s.p[0], w.p_w[0], w.p_b[0], s.hop, B), st);
+    launch_auto<typename QL::P23>("pitch.p23", conv_args(s.p[0], s.p[1], w.p_w[1], w.p_b[1], s.hop, B), st);
+    launch_auto<typename QL::P23>("pitch.p23", conv_args(s.p[1], s.p[2], w.p_w[2], w.p_b[2], s.hop, B), st);
+  }
   for (int t = 0; t < H; ++t) {
     GruArgs ga{s.p[2], s.h, w.gru_wih, w.gru_whh, w.gru_bih, w.gru_bhh, s.hop, B, t};
     launch_gru<128, 128>("pitch.gru", ga, st);

@@ -3,6 +3,7 @@
 #include <cstdlib>
 
 #include "chain_layers.hip.h"
+#include "team.hip.h"
 #include "tail_stages.hip.h"  // the tail as three multi-stream kernels (large batches in order; the tick launch has them as bodies)
 #include "rowchain.hip.h"
 
@@ -16,6 +17,7 @@ static __global__ __launch_bounds__(tst::NTHR, 4) void tail_stage_kernel(const t
 }
 
 static const int kBlockDil[B_NBLOCKS] = {1, 2, 4, 8};
+static unsigned long long* g_team_trace = nullptr;   // (BEATRICE_HIP_TEAM_TRACE: one buffer for the process, leaked at exit)
 
 bool WaveState::create(int B_, int H_, int n_slots_, int n_add_, int n_frm_, float* shared_phone, int* shared_q,
                        float* shared_feat, int front_slots_, bool pipe_slack, bool legacy_) {
@@ -87,6 +89,17 @@ bool WaveState::create(int B_, int H_, int n_slots_, int n_add_, int n_frm_, flo
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hop), 2 * sizeof(int)));  // [0] step counter, [1] resident-I/O slot
   BHIP_TRY(hipMemset(d_hop, 0, 2 * sizeof(int)));
   hop = d_hop;
+  if (B == 1 && H == 1 && !legacy) {   // the 1-stream ABI's team launch (team.hip.h); tag 0 = "never written"
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_team_xb), sizeof(unsigned long long) * team::kWaveGranules));
+    BHIP_TRY(hipMemset(d_team_xb, 0, sizeof(unsigned long long) * team::kWaveGranules));
+    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_team_dead), sizeof(int)));
+    BHIP_TRY(hipMemset(d_team_dead, 0, sizeof(int)));
+    BHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(team::wave_team_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, team::kLdsFloats * 4));
+    if (std::getenv("BEATRICE_HIP_TEAM_TRACE")) {   // measurement aid: per-stage stamps of workgroup 0 (BeatriceHip_TeamTraceDump)
+      BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_team_trace), sizeof(unsigned long long) * 1024));
+      BHIP_TRY(hipMemset(g_team_trace, 0, sizeof(unsigned long long) * 1024));
+    }
+  }
   // hipMemset is asynchronous and runs on the NULL stream, which the (non-blocking) compute streams
   // do not wait for: make every initialisation above visible before the first kernel can start
   BHIP_TRY(hipDeviceSynchronize());
@@ -95,6 +108,9 @@ bool WaveState::create(int B_, int H_, int n_slots_, int n_add_, int n_frm_, flo
 void WaveState::destroy() {
   arena.release();
   if (owns_inputs) { if (d_phone) (void)hipFree(d_phone); if (d_q) (void)hipFree(d_q); if (d_feat) (void)hipFree(d_feat); }
+  if (d_team_xb) (void)hipFree(d_team_xb);
+  if (d_team_dead) (void)hipFree(d_team_dead);
+  d_team_xb = nullptr; d_team_dead = nullptr;
   void* ptrs[] = {d_out, d_add_tab, d_frm_tab, d_add_idx, d_frm_idx, d_hop};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int b = 0; b < B_NBLOCKS; ++b) {
@@ -118,6 +134,40 @@ static void launch_c1(const WaveWeights& w, const WaveState& s, int blk, const R
   launch_auto<C1<D, H>>(names[D], conv_args(s.x[blk], h1, w.c1_w[blk], w.c1_b[blk], s.hop, s.B), st);
 }
 
+// One stream, one hop (the 1-stream C-ABI): input mix, the four conditioned blocks and upsampler stage 1 + the stage-2 transposed
+// conv -- 29 layers -- as ONE launch of a team of workgroups (team.hip.h).  BEATRICE_HIP_NO_TEAM=1: the per-layer launches (A/B, parity).
+static bool team_on() {
+  static const bool off = std::getenv("BEATRICE_HIP_NO_TEAM") != nullptr;
+  return !off;
+}
+static void launch_wave_team(const WaveWeights& w, const WaveState& s, hipStream_t st) {
+  using namespace team;
+  const WaveState::Scratch& k = s.scr[0];
+  WaveTeamArgs a{};
+  gran_t* g = s.d_team_xb;
+  auto take = [&g](size_t n) { gran_t* p = g; g += n; return p; };
+  a.phone_in = Ring{s.d_phone, B_PHONE_CH, 1, s.front_slots};
+  a.e = s.e;
+  for (int i = 0; i <= B_NBLOCKS; ++i) a.x[i] = Tensor{s.x[i], take(256)};
+  for (int b = 0; b < B_NBLOCKS; ++b) {
+    a.h1[b] = Tensor{k.h1, take(256)}; a.xa[b] = Tensor{k.xa, take(256)}; a.q[b] = Tensor{k.q, take(256)}; a.o[b] = Tensor{k.o, take(256)};
+    a.sc[b] = Tensor{k.sc, take(384)};
+    a.c1_w[b] = w.c1_w[b]; a.c1_b[b] = w.c1_b[b]; a.c2_w[b] = w.c2_w[b]; a.c2_b[b] = w.c2_b[b];
+    a.q_w[b] = w.q_w[b]; a.q_b[b] = w.q_b[b]; a.o_w[b] = w.o_w[b]; a.o_b[b] = w.o_b[b];
+    a.kt[b] = s.d_kt[b]; a.v[b] = s.d_v[b]; a.tile_slot[b] = s.d_tile_slot[b];
+  }
+  a.ya1 = Tensor{s.ya1, take(640)}; a.yb1 = Tensor{s.yb1, take(640)}; a.yc1 = Tensor{s.yc1, take(640)}; a.ya2 = Tensor{s.ya2, nullptr};
+  a.inp_w = w.inp_w; a.inp_b = w.inp_b;
+  a.up_w[0] = w.up_w[0]; a.up_b[0] = w.up_b[0]; a.up_w[1] = w.up_w[1]; a.up_b[1] = w.up_b[1];
+  a.ra_w = w.ra_w[0]; a.ra_b = w.ra_b[0]; a.rb_w = w.rb_w[0]; a.rb_b = w.rb_b[0];
+  a.hop = s.hop;
+  a.dead = s.d_team_dead;
+  a.stamps = g_team_trace;
+  launch_site(LaunchInfo{"wave.team", 2.0 * (128.0 * 256 + 4 * (768.0 * 256 + 3 * 256.0 * 256 + 2 * 256.0 * 384) + 512.0 * 640 + 2 * 5 * 384.0 * 128 + 5 * 256.0 * 256),
+                         4.0 * (128.0 * 256 + 4 * (768.0 * 256 + 3 * 256.0 * 256 + 2 * 256.0 * 384) + 512.0 * 640 + 2 * 384.0 * 128 + 256.0 * 256)},
+              st, [&] { hipLaunchKernelGGL(wave_team_kernel, dim3(NWG), dim3(NTHR), kLdsFloats * 4, st, a); });
+}
+
 template <int H>
 static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t st, bool cond_done, WavePart part) {
   const int B = s.B, rows = s.B * H;
@@ -127,6 +177,10 @@ static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t
   if (!cond_done) {
     const CondArgs ca = cond_args(w, s);
     launch_site(cond_info(s), st, [&] { hipLaunchKernelGGL(wave_cond_kernel, dim3(rows), dim3(256), 0, st, ca); });
+  }
+  if (H == 1 && B == 1 && s.d_team_xb != nullptr && part.first <= 1 && part.last >= 6 && team_on()) {
+    launch_wave_team(w, s, st);
+    part.first = 7;   // what is left: the fused tail
   }
   if (in_part(1)) {
     const Ring phone_in{s.d_phone, s.legacy ? 256 : B_PHONE_CH, H, s.front_slots};
@@ -221,6 +275,17 @@ static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t
 void wave_cond(const WaveWeights& w, const WaveState& s, hipStream_t st) {
   const CondArgs ca = cond_args(w, s);
   launch_site(cond_info(s), st, [&] { hipLaunchKernelGGL(wave_cond_kernel, dim3(s.B * s.H), dim3(256), 0, st, ca); });
+}
+
+// measurement aid: the stamps of the last team launch (see team.hip.h)
+extern "C" int BeatriceHip_TeamTraceDump(unsigned long long* out, int cap) {
+  if (!g_team_trace || hipDeviceSynchronize() != hipSuccess) return -1;
+  unsigned long long all[1024];
+  if (hipMemcpy(all, g_team_trace, sizeof(all), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  int n = (int)all[1023];
+  n = n < cap ? n : cap;
+  for (int i = 0; i < n; ++i) out[i] = all[i];
+  return n;
 }
 
 void wave_forward(const WaveWeights& w, const WaveState& s, hipStream_t st, bool cond_done, WavePart part) {
