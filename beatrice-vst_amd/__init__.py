@@ -416,6 +416,8 @@ _BATCH = {
     "BeatriceBatch_ProcessBlocks": (C.c_int, [_vp, _f32p, _f32p, C.c_int, C.c_int]),
     "BeatriceBatch_ProcessBlocksDevice": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int]),
     "BeatriceBatch_MaxWrapperBlock": (C.c_int, [_vp]),
+    "BeatriceBatch_ConfigureWrapperRates": (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    "BeatriceBatch_ProcessBlocksRagged": (C.c_int, [_vp, _vp, _vp, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "BeatriceBatch_Synchronize": (C.c_int, [_vp]),
     "BeatriceBatch_BindResidentIO": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "BeatriceBatch_SetStream": (C.c_int, [_vp, _vp]),

@@ -241,6 +241,23 @@ struct BeatriceBatch {
     int* d_keep_prev_q = nullptr;       // [B]
     long long steps = 0;
   } silent;
+  // The any-rate wrapper with clocks PER STREAM (BeatriceBatch_ConfigureWrapperRates / ProcessBlocksRagged; wrapper.hip.h
+  // RagStream): every stream its own host rate, block length and FIFO phase; a stream may sit a call out
+  struct RaggedWrap {
+    bool ready = false;
+    std::vector<wrapn::WrapPlan> classes;          // one per distinct host rate: ratio and tap tables
+    std::vector<int> cls;                          // [B] class of each stream
+    struct Clock { int phase_down, phase_up, fill; };
+    std::vector<Clock> clk;                        // [B] the stream's two resampler clocks and its FIFO fill
+    std::vector<int> taps_down_off, taps_up_off;   // per class: float offsets into d_taps
+    float* d_taps = nullptr;
+    static constexpr int kStage = 4;
+    wrapn::RagStream *d_rs = nullptr, *h_rs = nullptr;   // [kStage][B]: a call's per-stream records, pinned staging and device copy
+    hipEvent_t ev[kStage] = {};
+    bool pending[kStage] = {};
+    long long calls = 0;
+    unsigned char* d_frozen = nullptr;             // [kMaxChunks][B]: per FIFO chunk, the streams that do not fire a hop in it
+  } rw;
   // The any-rate wrapper around the tick pipeline (BeatriceBatch_BindResidentBlocks): host-rate blocks resident on the device,
   // the input half of the chain in front of the ticks, the output half `delay` calls later (wrapper.hip.h wrap_post_kernel)
   struct ResidentBlocks {
@@ -548,7 +565,7 @@ bool step_device(BeatriceBatch* b, const float* d_in, float* d_out) {
   if (b->io_slots > 0 && (d_in || d_out)) return false;  // resident I/O is bound: the step reads and writes its slots
   if (b->io_mapped != b->want_mapped && !set_io_mapped(b, b->want_mapped)) return false;
   if (b->tk.on) return tick_run(b, true);
-  if (b->silent.on && b->silent.any_next && !b->silent.in_block_step) {   // flags name streams of the next 48 kHz BLOCK: any other kind
+  if (b->silent.any_next && !b->silent.in_block_step) {   // flags name streams of the next 48 kHz BLOCK: any other kind
     std::fill(b->silent.next.begin(), b->silent.next.end(), 0);           // of step runs for every stream
     b->silent.any_next = false;
   }
@@ -838,7 +855,9 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   if (!b) return;
   if (b->stream) (void)sync_all(b);
   drop_graph(b);
-  { void* wr[] = {b->d_wrap, b->d_wrap_taps, b->d_wrap_inner, b->d_wrap_io, b->wrap_gains.d}; for (void* p : wr) if (p) (void)hipFree(p); }
+  { void* wr[] = {b->d_wrap, b->d_wrap_taps, b->d_wrap_inner, b->d_wrap_io, b->wrap_gains.d, b->rw.d_taps, b->rw.d_rs, b->rw.d_frozen}; for (void* p : wr) if (p) (void)hipFree(p); }
+  if (b->rw.h_rs) (void)hipHostFree(b->rw.h_rs);
+  for (hipEvent_t e : b->rw.ev) if (e) (void)hipEventDestroy(e);
   if (b->h_wrap_io) (void)hipHostFree(b->h_wrap_io);
   b->wrap_gains.release();
   { void* tk[] = {b->tk.d_table, b->tk.d_snap, b->tk.d_trace}; for (void* p : tk) if (p) (void)hipFree(p); }

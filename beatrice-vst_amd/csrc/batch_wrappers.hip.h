@@ -38,6 +38,7 @@ static bool step_48k(BeatriceBatch* b, const float* d_in48, float* d_out48, int 
   if (flag_slot >= 0) { BHIP_TRY(hipEventRecord(sr.flag_ev[flag_slot], b->stream)); sr.flag_pending[flag_slot] = true; }
   return hip_ok(hipGetLastError(), "wrap48");
 }
+static bool freeze_prepare(BeatriceBatch* b);
 static void silent_release(BeatriceBatch* b) {
   BeatriceBatch::SilentRule& sr = b->silent;
   for (hipEvent_t& e : sr.flag_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
@@ -58,10 +59,23 @@ int BeatriceBatch_EnableSilentBlockRule(BeatriceBatch* b, int enable) {
   const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   BeatriceBatch::SilentRule& sr = b->silent;
-  if (!enable) { if (sr.on) { (void)sync_all(b); silent_release(b); } return 0; }
+  if (!enable) {
+    if (sr.on) { (void)sync_all(b); if (b->rw.ready) sr.on = false; else silent_release(b); }   // (the per-stream wrapper keeps the freeze machinery)
+    return 0;
+  }
   if (sr.on) return 0;
   if (b->H != 1 || b->pipelined || b->tk.on || b->io_slots > 0) return -1;   // the in-order chain, one block per step
   if (!sync_all(b)) return -2;
+  if (!freeze_prepare(b)) { silent_release(b); return -2; }
+  sr.on = true;
+  drop_graph(b);
+  return 0;
+}
+// what a step that leaves some streams standing needs (the silent-block rule of the 48 kHz blocks, and the per-stream clocks of
+// BeatriceBatch_ProcessBlocksRagged): the list of state rings to put back, room for the single-slot ones, the flag staging
+static bool freeze_prepare(BeatriceBatch* b) {
+  BeatriceBatch::SilentRule& sr = b->silent;
+  if (sr.d_rings) return true;
   std::vector<FreezeRing> rings;
   size_t keep = 0;
   for (const RingArena* a : {&b->phone.arena, &b->pitch.arena, &b->wave.arena})
@@ -78,12 +92,10 @@ int BeatriceBatch_EnableSilentBlockRule(BeatriceBatch* b, int enable) {
             hip_ok(hipMalloc(reinterpret_cast<void**>(&sr.d_flags), BeatriceBatch::SilentRule::kDepth * (size_t)b->B), "silent flags") &&
             hip_ok(hipHostMalloc(reinterpret_cast<void**>(&sr.h_flags), BeatriceBatch::SilentRule::kDepth * (size_t)b->B, hipHostMallocDefault), "silent flags host");
   for (hipEvent_t& e : sr.flag_ev) ok = ok && hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "silent flag event");
-  if (!ok) { silent_release(b); return -2; }
+  if (!ok) return false;
   sr.next.assign(b->B, 0);
   sr.any_next = false;
-  sr.on = true;
-  drop_graph(b);
-  return 0;
+  return true;
 }
 // streams whose NEXT 48 kHz block is silent by the shell's rule (flags[B], non-zero = silent); cleared by that block
 int BeatriceBatch_SetSilentStreams(BeatriceBatch* b, const unsigned char* flags) {
@@ -279,6 +291,183 @@ int BeatriceBatch_ProcessBlocksDevice(BeatriceBatch* b, const float* d_in, float
   return -1;  // the planar layout [B][channels][n] cannot be cut without copies: callers pass blocks of at most `piece` samples
 }
 int BeatriceBatch_MaxWrapperBlock(const BeatriceBatch* b) { return b && b->ok && b->wrap.ready ? wrap_max_chunk(b) : 0; }
+
+// ---- clocks per stream: a batch whose streams come from different hosts -------------------------------------------------------------
+// rates[B]: the host rate of every stream (streams of equal rate share their tap tables).  Restarts every stream's resampler
+// pair and FIFO as SetSampleRate does; the gains keep their state.  In-order mode, one hop per step.
+int BeatriceBatch_ConfigureWrapperRates(BeatriceBatch* b, const double* rates) {
+  const DeviceScope dev_(b ? b->device : -1);
+  if (!b || !b->ok) return -2;
+  if (!rates || b->H != 1 || b->pipelined || b->tk.on || b->io_slots > 0) return -1;
+  if (!sync_all(b)) return -2;
+  BeatriceBatch::RaggedWrap& r = b->rw;
+  const int B = b->B;
+  std::vector<wrapn::WrapPlan> classes;
+  std::vector<int> cls(B);
+  for (int s = 0; s < B; ++s) {
+    int c = -1;
+    for (size_t i = 0; i < classes.size(); ++i) if (classes[i].rate == rates[s]) { c = (int)i; break; }
+    if (c < 0) {
+      wrapn::WrapPlan p;
+      if (!p.configure(rates[s])) return -1;
+      classes.push_back(p);
+      c = (int)classes.size() - 1;
+    }
+    cls[s] = c;
+  }
+  // the uniform wrapper's per-stream state, inner buffer, I/O staging and gain mirrors are shared with this mode
+  if (!b->d_wrap) { const int rc = BeatriceBatch_ConfigureWrapper(b, rates[0]); if (rc) return rc; }
+  if (!freeze_prepare(b)) return -2;
+  std::vector<float> taps;
+  r.taps_down_off.clear(); r.taps_up_off.clear();
+  for (const wrapn::WrapPlan& p : classes) {
+    r.taps_down_off.push_back((int)taps.size()); taps.insert(taps.end(), p.taps_down.begin(), p.taps_down.end());
+    r.taps_up_off.push_back((int)taps.size()); taps.insert(taps.end(), p.taps_up.begin(), p.taps_up.end());
+  }
+  if (r.d_taps) { (void)hipFree(r.d_taps); r.d_taps = nullptr; }
+  bool ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_taps), sizeof(float) * taps.size()), "ragged taps") &&
+            hip_ok(hipMemcpy(r.d_taps, taps.data(), sizeof(float) * taps.size(), hipMemcpyHostToDevice), "ragged taps up");
+  if (ok && !r.d_rs) {
+    ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_rs), sizeof(wrapn::RagStream) * r.kStage * B), "ragged records") &&
+         hip_ok(hipHostMalloc(reinterpret_cast<void**>(&r.h_rs), sizeof(wrapn::RagStream) * r.kStage * B, hipHostMallocDefault), "ragged records host") &&
+         hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_frozen), (size_t)wrapn::kMaxChunks * B), "ragged flags");
+    for (hipEvent_t& e : r.ev) ok = ok && hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "ragged event");
+  }
+  ok = ok && hip_ok(hipMemset(b->d_wrap, 0, sizeof(wrapn::StreamState) * B), "ragged state0") && hip_ok(hipDeviceSynchronize(), "ragged sync");
+  if (!ok) return -2;
+  r.classes = classes;
+  r.cls = cls;
+  r.clk.assign(B, BeatriceBatch::RaggedWrap::Clock{0, 0, 0});
+  for (int s = 0; s < B; ++s) r.clk[s] = BeatriceBatch::RaggedWrap::Clock{classes[cls[s]].hi - 1, classes[cls[s]].hi - 1, 0};
+  b->wrap.ready = false;          // (the uniform entry points are off until BeatriceBatch_ConfigureWrapper is called again)
+  b->wrap_gains_constant = false;
+  drop_graph(b);
+  r.ready = true;
+  return 0;
+}
+// One call = for every stream s a block of n_samples[s] host samples at ITS rate (0: the stream sits this call out).  in / out:
+// the streams' planar blocks [channels][n_samples[s]] one after the other.  apply_silent_rule != 0: a block whose down-mix is
+// all zeros is not converted (src/vst/processor.cc:204-214): nothing of that stream moves -- gains, resampler clocks, FIFO,
+// model state, key/value installs, codebook lottery -- and its output block is zeros.  Streams fire their model hops when
+// THEIR 480-sample FIFO fills; a step runs for the streams that fire in it and leaves the others standing.
+int BeatriceBatch_ProcessBlocksRagged(BeatriceBatch* b, const float* in, float* out, int channels, const int* n_samples, int apply_silent_rule) {
+  using namespace wrapn;
+  const DeviceScope dev_(b ? b->device : -1);
+  if (!b || !b->ok) return -2;
+  BeatriceBatch::RaggedWrap& r = b->rw;
+  if (!r.ready || !in || !out || !n_samples || channels < 1 || channels > 2 || b->H != 1 || b->io_slots > 0 || b->pipelined || b->tk.on) return -1;
+  const int B = b->B;
+  hipStream_t st = b->stream;
+  size_t total = 0;
+  for (int s = 0; s < B; ++s) {
+    if (n_samples[s] < 0) return -1;
+    if (n_samples[s] > 0 && n_samples[s] > std::max(1, (int)std::floor((kMaxSamples - 8) * std::min(1.0, r.classes[r.cls[s]].rate / 48000.0)))) return -1;
+    total += (size_t)channels * n_samples[s];
+  }
+  const int e = (int)(r.calls % r.kStage);
+  if (r.pending[e]) { if (!hip_ok(hipEventSynchronize(r.ev[e]), "ragged staging")) return -2; r.pending[e] = false; }
+  RagStream* rs = r.h_rs + (size_t)e * B;
+  GainSeg* seg = b->wrap_gains.h;
+  int max_chunks = 0;
+  size_t off = 0;
+  for (int s = 0; s < B; ++s) {
+    RagStream& q = rs[s];
+    q = RagStream{};
+    const int n = n_samples[s];
+    q.io_off = (long long)off; q.n = n;
+    bool active = n > 0;
+    if (active && apply_silent_rule) {   // the shell's own test on the down-mix
+      const float* src = in + off;
+      bool sil = true;
+      for (int i = 0; i < n && sil; ++i) {
+        float m = src[i];
+        if (channels >= 2) { m = m + src[n + i]; m = m * 0.5f; }
+        sil = !(m != 0.0f);
+      }
+      active = !sil;
+    }
+    off += (size_t)channels * n;
+    q.active = active ? 1 : 0;
+    if (!active) { seg[s] = GainSeg{1.0, 1.0, 1.0}; seg[B + s] = GainSeg{1.0, 1.0, 1.0}; continue; }
+    WrapPlan& p = r.classes[r.cls[s]];
+    BeatriceBatch::RaggedWrap::Clock& c = r.clk[s];
+    p.phase_down = c.phase_down; p.phase_up = c.phase_up; p.fill = c.fill;   // the class's plan does the clock arithmetic on the stream's state
+    seg[s] = b->gain_in[s].advance(n, p.rate);
+    seg[B + s] = b->gain_out[s].advance(n, p.rate);
+    q.din = p.to_inner(n);
+    const int m = q.din.n_out;
+    if (m < 0 || m > kMaxSamples) return -2;
+    int fill = p.fill, nc = 0;
+    for (int at = 0; at < m;) {
+      const int take = std::min(kBlock - fill, m - at);
+      if (nc >= kMaxChunks) return -2;
+      q.at[nc] = (short)at; q.fill[nc] = (short)fill; q.take[nc] = (short)take;
+      q.fires[nc] = fill + take == kBlock ? 1 : 0;
+      fill = q.fires[nc] ? 0 : fill + take;
+      at += take;
+      ++nc;
+    }
+    q.n_chunks = nc;
+    p.fill = fill;
+    q.dout = p.to_outer(m);
+    if (q.dout.n_out != n) return -2;
+    q.taps_in = q.din.decimate ? r.taps_down_off[r.cls[s]] : r.taps_up_off[r.cls[s]];
+    q.taps_out = q.dout.decimate ? r.taps_down_off[r.cls[s]] : r.taps_up_off[r.cls[s]];
+    c.phase_down = p.phase_down; c.phase_up = p.phase_up; c.fill = p.fill;
+    max_chunks = std::max(max_chunks, nc);
+  }
+  // uploads: the per-stream records of this call, the gain segments, the audio
+  RagStream* d_rs = r.d_rs + (size_t)e * B;
+  bool ok = hip_ok(hipMemcpyAsync(d_rs, rs, sizeof(RagStream) * B, hipMemcpyHostToDevice, st), "ragged records up");
+  { const size_t o0 = 0, len = 2 * (size_t)B; GainSeg* dst = nullptr; ok = ok && b->wrap_gains.push_parts(st, 1, &o0, &len, &dst); }
+  b->wrap_gains_constant = false;
+  float* h_in = b->h_wrap_io;
+  float* h_out = b->h_wrap_io + (size_t)B * 2 * kMaxSamples;
+  float* d_in = b->d_wrap_io;
+  float* d_out = b->d_wrap_io + (size_t)B * 2 * kMaxSamples;
+  std::memcpy(h_in, in, sizeof(float) * total);
+  ok = ok && hip_ok(hipMemcpyAsync(d_in, h_in, sizeof(float) * std::max<size_t>(total, 1), hipMemcpyHostToDevice, st), "ragged in");
+  if (!ok) return -2;
+  hipLaunchKernelGGL(wrapr_in_kernel, dim3(B), dim3(256), 0, st, d_in, channels, b->d_wrap, b->wrap_gains.d, r.d_taps, d_rs, b->d_wrap_inner, kInnerStride);
+  BeatriceBatch::SilentRule& sr = b->silent;
+  for (int ci = 0; ci < max_chunks && ok; ++ci) {
+    bool any_fire = false;
+    for (int s = 0; s < B; ++s) {
+      const bool fires = rs[s].active && ci < rs[s].n_chunks && rs[s].fires[ci];
+      sr.next[s] = fires ? 0 : 1;
+      any_fire = any_fire || fires;
+    }
+    unsigned char* d_flags = r.d_frozen + (size_t)ci * B;
+    hipLaunchKernelGGL(wrapr_fifo_kernel, dim3(B), dim3(256), 0, st, b->d_wrap_inner, kInnerStride, b->d_wrap, d_rs, ci, b->d_in, d_flags);
+    if (!any_fire) { std::fill(sr.next.begin(), sr.next.end(), 0); continue; }
+    bool any_frozen = false;
+    for (int s = 0; s < B; ++s) any_frozen = any_frozen || sr.next[s];
+    sr.any_next = any_frozen;
+    if (any_frozen)
+      hipLaunchKernelGGL(freeze_save_kernel, dim3(sr.n_rings, B), dim3(256), 0, st, sr.d_rings, sr.d_keep, B, b->pitch.d_prev_q, sr.d_keep_prev_q);
+    sr.in_block_step = true;
+    ok = step_device(b, nullptr, nullptr);   // (advance_kv / draw_codebooks skip the streams flagged in sr.next)
+    sr.in_block_step = false;
+    std::fill(sr.next.begin(), sr.next.end(), 0);
+    sr.any_next = false;
+    if (!ok) break;
+    if (any_frozen)
+      hipLaunchKernelGGL(freeze_fix_kernel, dim3(sr.n_rings, B), dim3(256), 0, st, sr.d_rings, sr.d_keep, B, d_flags, b->last_hop, b->pitch.d_prev_q, sr.d_keep_prev_q);
+    hipLaunchKernelGGL(wrapr_refill_kernel, dim3((B * kBlock + 255) / 256), dim3(256), 0, st, b->d_wrap, b->wave.d_out, B, d_flags);
+  }
+  if (ok) {
+    hipLaunchKernelGGL(wrapr_out_kernel, dim3(B), dim3(256), 0, st, b->d_wrap_inner, kInnerStride, b->d_wrap, b->wrap_gains.d + B, r.d_taps, d_rs, d_out, channels);
+    ok = hip_ok(hipGetLastError(), "ragged wrapper launch") && hip_ok(hipEventRecord(r.ev[e], st), "ragged event");
+    r.pending[e] = ok;
+  }
+  r.calls += 1;
+  ok = ok && hip_ok(hipMemcpyAsync(h_out, d_out, sizeof(float) * std::max<size_t>(total, 1), hipMemcpyDeviceToHost, st), "ragged out");
+  ok = hip_ok(hipStreamSynchronize(st), "ragged sync") && ok;
+  b->inflight = false;
+  if (ok) std::memcpy(out, h_out, sizeof(float) * total);
+  else std::memset(out, 0, sizeof(float) * total);
+  return ok ? 0 : -2;
+}
 
 // ---- the same wrapper around the TICK pipeline (throughput form, resident blocks) ------------------------------------------------
 // One call = one host-rate block per stream from slot `call mod n_slots` of d_in: gains and the first resampling direction, the

@@ -198,6 +198,125 @@ static __global__ void wrap_refill_kernel(StreamState* __restrict__ st, const fl
   st[b].fifo[i] = (i & 1) ? 0.0f : out24[(size_t)b * 240 + (i >> 1)];
 }
 
+// ---- the same chain with clocks PER STREAM (BeatriceBatch_ConfigureWrapperRates / ProcessBlocksRagged): every stream has its
+// own host rate, its own block length per call and its own place in the 480-sample FIFO -- what the reference gives every
+// plugin instance (src/common/resample.h:401-438, processor_core_2.h:28) -- and may sit a call out altogether (no block, or
+// a block the shell's rule calls silent: src/vst/processor.cc:204-214).  Control stays on the host, now per stream; the
+// kernels read a per-stream record instead of one set of arguments.
+constexpr int kMaxChunks = 12;   // FIFO pieces one call can cut a stream's inner samples into: ceil(4096 / 480) + 2
+struct RagStream {
+  Dir din, dout;                 // this call's two directions (n_in == 0: the stream sits the call out)
+  long long io_off;              // floats from the start of the call's buffers to this stream's planar block [channels][n]
+  int n;                         // host samples of the block
+  int taps_in, taps_out;         // float offsets of the two tables in the batch's tap buffer
+  int n_chunks;
+  short at[kMaxChunks], fill[kMaxChunks], take[kMaxChunks];   // chunk i: inner samples [at, at + take) <-> FIFO [fill, fill + take)
+  unsigned char fires[kMaxChunks];
+  int active;                    // 0: nothing of this stream moves in this call (its output block is zeros)
+};
+
+static __global__ __launch_bounds__(256) void wrapr_in_kernel(const float* __restrict__ in, const int channels, StreamState* __restrict__ st,
+                                                              const GainSeg* __restrict__ gain, const float* __restrict__ taps_all,
+                                                              const RagStream* __restrict__ rs, float* __restrict__ inner, const int stride) {
+  __shared__ float x[kMaxHist + kMaxSamples];
+  __shared__ double amp[kMaxSamples];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const RagStream r = rs[b];
+  if (!r.active) return;
+  const Dir d = r.din;
+  const int n = r.n;
+  const float* src = in + r.io_off;
+  const float* taps = taps_all + r.taps_in;
+  float* hist = d.decimate ? st[b].hist_high : st[b].hist_low;
+  const GainSeg g = gain[b];
+  if (tid == 0 && g.step != 1.0) {
+    double a = g.amp0;
+    for (int i = 0; i < n; ++i) {
+      if (g.step > 1.0) { if (a < g.goal) a = fmin(a * g.step, g.goal); }
+      else if (a > g.goal) a = fmax(a * g.step, g.goal);
+      amp[i] = a;
+    }
+  }
+  for (int i = tid; i < d.hist; i += 256) x[i] = hist[i];
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    float m = src[i];
+    if (channels >= 2) { m = m + src[n + i]; m = m * 0.5f; }
+    const double a = g.step != 1.0 ? amp[i] : g.amp0;
+    x[d.hist + i] = (float)(m * a);
+  }
+  __syncthreads();
+  for (int o = tid; o < d.n_out; o += 256) inner[(size_t)b * stride + o] = resample_one(d, x, taps, o);
+  __syncthreads();
+  for (int i = tid; i < d.hist; i += 256) hist[i] = x[n + i];
+}
+static __global__ __launch_bounds__(256) void wrapr_out_kernel(const float* __restrict__ inner, const int stride, StreamState* __restrict__ st,
+                                                               const GainSeg* __restrict__ gain, const float* __restrict__ taps_all,
+                                                               const RagStream* __restrict__ rs, float* __restrict__ out, const int channels) {
+  __shared__ float x[kMaxHist + kMaxSamples];
+  __shared__ double amp[kMaxSamples];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const RagStream r = rs[b];
+  float* dst = out + r.io_off;
+  if (!r.active) {   // the stream sat the call out: its block comes back as silence (the shell hands the zero block through)
+    for (int i = tid; i < channels * r.n; i += 256) dst[i] = 0.0f;
+    return;
+  }
+  const Dir d = r.dout;
+  const int n = d.n_out;
+  const float* taps = taps_all + r.taps_out;
+  float* hist = d.decimate ? st[b].hist_high_out : st[b].hist_low_out;
+  const GainSeg g = gain[b];
+  if (tid == 0 && g.step != 1.0) {
+    double a = g.amp0;
+    for (int i = 0; i < n; ++i) {
+      if (g.step > 1.0) { if (a < g.goal) a = fmin(a * g.step, g.goal); }
+      else if (a > g.goal) a = fmax(a * g.step, g.goal);
+      amp[i] = a;
+    }
+  }
+  for (int i = tid; i < d.hist; i += 256) x[i] = hist[i];
+  for (int i = tid; i < d.n_in; i += 256) x[d.hist + i] = inner[(size_t)b * stride + i];
+  __syncthreads();
+  for (int o = tid; o < n; o += 256) {
+    const float y = resample_one(d, x, taps, o);
+    const double a = g.step != 1.0 ? amp[o] : g.amp0;
+    const float v = (float)(y * a);
+    for (int c = 0; c < channels; ++c) dst[c * n + o] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < d.hist; i += 256) hist[i] = x[d.n_in + i];
+}
+// chunk `ci` of every stream that has one; frozen[b] = 1 for the streams that do NOT complete a 480-block in this chunk (the
+// model step that follows stands still for them); in16: the step's input
+static __global__ __launch_bounds__(256) void wrapr_fifo_kernel(float* __restrict__ inner, const int stride, StreamState* __restrict__ st,
+                                                                const RagStream* __restrict__ rs, const int ci, float* __restrict__ in16,
+                                                                unsigned char* __restrict__ frozen) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const RagStream& r = rs[b];
+  const bool has = r.active && ci < r.n_chunks;
+  const bool fires = has && r.fires[ci];
+  if (frozen != nullptr && tid == 0) frozen[b] = fires ? 0 : 1;
+  if (!has) return;
+  const int at = r.at[ci], fill = r.fill[ci], take = r.take[ci];
+  float* f = st[b].fifo;
+  for (int i = tid; i < take; i += 256) {
+    const float fresh = inner[(size_t)b * stride + at + i];
+    inner[(size_t)b * stride + at + i] = f[fill + i];
+    f[fill + i] = fresh;
+  }
+  if (!fires) return;
+  __syncthreads();
+  for (int i = tid; i < 160; i += 256) in16[(size_t)b * 160 + i] = f[3 * i + 2];
+}
+static __global__ void wrapr_refill_kernel(StreamState* __restrict__ st, const float* __restrict__ out24, const int B, const unsigned char* __restrict__ frozen) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * kBlock) return;
+  const int b = idx / kBlock, i = idx % kBlock;
+  if (frozen[b]) return;
+  st[b].fifo[i] = (i & 1) ? 0.0f : out24[(size_t)b * 240 + (i >> 1)];
+}
+
 // ---- host side: the clocks and the tables -------------------------------------------------------------------------
 // smallest-denominator search on the Stern-Brocot tree, parts < 1000 (reference resample.h:25-46)
 inline void simple_fraction(double ratio, int* numer, int* denom) {

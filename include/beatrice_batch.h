@@ -215,6 +215,18 @@ int BeatriceBatch_SetOutputGain(BeatriceBatch* b, int stream, double gain_db);
 int BeatriceBatch_ProcessBlocks(BeatriceBatch* b, const float* in, float* out, int channels, int n_samples);
 int BeatriceBatch_ProcessBlocksDevice(BeatriceBatch* b, const float* d_in, float* d_out, int channels, int n_samples);
 int BeatriceBatch_MaxWrapperBlock(const BeatriceBatch* b);
+/* The same wrapper with clocks PER STREAM -- what the reference gives every plugin instance (src/common/resample.h:401-438,
+ * processor_core_2.h:28): a batch whose streams come from hosts at different rates and block sizes.
+ * BeatriceBatch_ConfigureWrapperRates: rates[B], the host rate of each stream (restarts every stream's resampler pair and FIFO;
+ * gains keep their state; the uniform entry points above are off until BeatriceBatch_ConfigureWrapper is called again).
+ * BeatriceBatch_ProcessBlocksRagged: for every stream s one block of n_samples[s] samples at its rate (0: the stream sits the
+ * call out); in / out (host): the streams' planar blocks [channels][n_samples[s]] one after the other.  A stream fires a model
+ * hop whenever ITS 480-sample FIFO fills; a model step runs for the streams that fire in it, the others stand still.
+ * apply_silent_rule != 0: the shell's rule per stream (src/vst/processor.cc:204-214): a block whose down-mix is all zeros is
+ * not converted -- gains, resampler clocks, FIFO, model state, key/value installs and codebook lottery of that stream do not
+ * move, its output block is zeros.  In-order mode.  Bit-identical to one reference wrapper per stream. */
+int BeatriceBatch_ConfigureWrapperRates(BeatriceBatch* b, const double* rates);
+int BeatriceBatch_ProcessBlocksRagged(BeatriceBatch* b, const float* in, float* out, int channels, const int* n_samples, int apply_silent_rule);
 /* Throughput form of the any-rate wrapper: the TICK pipeline between resident host-rate blocks (as BeatriceBatch_BindResidentIO48k
  * is for 48 kHz / 0 dB).  d_in / d_out: [n_slots][B][channels][n_samples] planar, at the rate of BeatriceBatch_ConfigureWrapper.
  * Call k = BeatriceBatch_ProcessBlocksDevice(b, NULL, NULL, channels, n_samples) reads slot k mod n_slots; its output block is in
