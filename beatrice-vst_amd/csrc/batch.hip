@@ -855,6 +855,9 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   if (!b) return;
   if (b->stream) (void)sync_all(b);
   drop_graph(b);
+  if (b->tk.d_hopv) (void)hipFree(b->tk.d_hopv);
+  if (b->tk.h_hopv) (void)hipHostFree(b->tk.h_hopv);
+  for (hipEvent_t e : b->tk.hv_ev) if (e) (void)hipEventDestroy(e);
   { void* wr[] = {b->d_wrap, b->d_wrap_taps, b->d_wrap_inner, b->d_wrap_io, b->wrap_gains.d, b->rw.d_taps, b->rw.d_rs, b->rw.d_frozen}; for (void* p : wr) if (p) (void)hipFree(p); }
   if (b->rw.h_rs) (void)hipHostFree(b->rw.h_rs);
   for (hipEvent_t e : b->rw.ev) if (e) (void)hipEventDestroy(e);

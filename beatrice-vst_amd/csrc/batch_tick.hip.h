@@ -185,6 +185,39 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
   } else {
     k.fed_step[k.tick % kRing] = -1;
   }
+  // ragged steps: the flags of BeatriceBatch_SetSilentStreams name the streams that sit THIS step out
+  Copy hv_upload{nullptr, nullptr, 0};
+  int hv_stage = -1;
+  if (feeding) {
+    BeatriceBatch::SilentRule& sr = b->silent;
+    if (!k.ragged && sr.on && sr.any_next) {   // the first stream to stand still: from here on every stream has its own counter
+      if (!k.d_hopv) {
+        k.row = (b->B + 3) & ~3;
+        if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_hopv), sizeof(int) * kRing * k.row), "tick hopv") ||
+            !hip_ok(hipHostMalloc(reinterpret_cast<void**>(&k.h_hopv), sizeof(int) * State::kStaging * k.row, hipHostMallocDefault), "tick hopv staging"))
+          return false;
+        for (hipEvent_t& e : k.hv_ev) if (!hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "tick hopv event")) return false;
+      }
+      k.hop_s.assign(b->B, b->hop_host);
+      k.ragged = true;
+    }
+    const long long u = k.n_fed;
+    k.step_ragged[u % kRing] = k.ragged;
+    if (k.ragged) {
+      const int si = (int)(u % State::kStaging);
+      if (k.hv_pending[si]) { if (!hip_ok(hipEventSynchronize(k.hv_ev[si]), "tick hopv staging")) return false; k.hv_pending[si] = false; }
+      int* h = k.h_hopv + (size_t)si * k.row;
+      for (int s = 0; s < b->B; ++s) {
+        const bool out = sr.any_next && sr.next[s];
+        h[s] = out ? -1 : k.hop_s[s];
+        if (!out) k.hop_s[s] = hop_next(k.hop_s[s]);
+      }
+      for (int s = b->B; s < k.row; ++s) h[s] = -1;
+      hv_upload = Copy{reinterpret_cast<unsigned char*>(k.d_hopv + (size_t)(u % kRing) * k.row), reinterpret_cast<const unsigned char*>(h), (int)(sizeof(int) * k.row)};
+      hv_stage = si;
+    }
+    if (sr.any_next) { std::fill(sr.next.begin(), sr.next.end(), 0); sr.any_next = false; }
+  }
   prof.lap(2);
   Prolog p{};
   p.n_stages = k.plan.count();
@@ -210,6 +243,7 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
     p.copy[0] = upload;
     p.n_copies += 1;
   }
+  if (hv_upload.bytes > 0) p.copy[p.n_copies++] = hv_upload;   // (read by stage 0 of the launch that follows: the prologue runs before it)
   if (p.n_copies > 0) {  // (only on ticks where the settings changed or a change arrives at a consumer)
     int chunks = 0;
     for (int i = 0; i < p.n_copies; ++i) { p.first_chunk[i] = chunks; chunks += (p.copy[i].bytes + kCopyChunk - 1) / kCopyChunk; }
@@ -218,6 +252,10 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
     if (upload_stage >= 0) {
       if (!hip_ok(hipEventRecord(k.stage_ev[upload_stage], st), "tick settings event")) return false;
       k.stage_pending[upload_stage] = true;
+    }
+    if (hv_stage >= 0) {
+      if (!hip_ok(hipEventRecord(k.hv_ev[hv_stage], st), "tick hopv event")) return false;
+      k.hv_pending[hv_stage] = true;
     }
   }
   if (b->r48.on && (feeding || b->r48.deferred_slot >= 0)) {
@@ -242,8 +280,14 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
   }
   prof.lap(3);
   fuse::StepPairs pairs;
-  for (int s = 0; s < fuse::kMaxStepPairs; ++s) { pairs.hop[s] = s < p.n_stages ? p.hop[s] : -1; pairs.io[s] = s < p.n_stages ? p.io[s] : 0; }
-  fuse::launch_table_w<4>(k.d_table, k.table_total, st, pairs);
+  pairs.hopv = k.ragged ? k.d_hopv : nullptr;
+  pairs.n_streams = k.row;
+  for (int s = 0; s < fuse::kMaxStepPairs; ++s) {
+    pairs.hop[s] = s < p.n_stages ? p.hop[s] : -1; pairs.io[s] = s < p.n_stages ? p.io[s] : 0;
+    const long long u = s < p.n_stages ? step_at(s) : -1;
+    pairs.hv[s] = u >= 0 && k.step_ragged[u % kRing] ? (int)(u % kRing) : -1;
+  }
+  fuse::launch_table_w<4>(k.d_table, k.table_total, st, pairs, k.ragged);   // (the second instance of the launch once a stream has sat a step out)
   if (b->r48.on) {  // the step this tick completed: its 48 kHz block is produced by the wrapper launch of the next tick (or of the drain)
     const long long u = step_at(k.plan.count() - 1);
     if (u >= 0) b->r48.deferred_slot = k.io_of_step[u % kRing];
@@ -344,14 +388,21 @@ int tick_enable(BeatriceBatch* b, bool on) {
     }
     if (!hip_ok(hipDeviceSynchronize(), "tick sync")) return -2;
     k.tick = 0; k.n_fed = 0; k.last_feed_tick = -1000; k.snap_cur = -1; k.snap_next = 0;
+    k.ragged = false;
+    for (bool& r : k.step_ragged) r = false;
     for (long long& f : k.fed_step) f = -1;
     k.table_dirty = true;
     k.on = true;
     for (int blk = 0; blk < B_NBLOCKS; ++blk) rebuild_tiles(b, blk);  // (tick mode cuts the attention rows into tiles AND quads)
     return 0;
   }
+  if (k.ragged) {   // streams that have sat steps out are at counters of their own: the in-order chain (one counter for all) cannot take them over
+    for (int s = 0; s < b->B; ++s) if (k.hop_s[s] != b->hop_host) return -1;
+  }
   if (!sync_all(b)) return -2;  // drains
   k.on = false;
+  k.ragged = false;
+  if (b->silent.on && !b->silent.d_rings) b->silent.on = false;   // (the rule was enabled for tick mode only)
   for (int blk = 0; blk < B_NBLOCKS; ++blk) {   // (see above: tick mode's own copies of the K / V tables)
     if (b->wave.d_ktp[blk]) (void)hipFree(b->wave.d_ktp[blk]);
     if (b->wave.d_vp[blk]) (void)hipFree(b->wave.d_vp[blk]);

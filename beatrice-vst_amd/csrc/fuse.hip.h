@@ -115,7 +115,9 @@ constexpr int kMaxSpans = 64;
 // a workgroup looks its body's stage up and leaves the pair in LDS for the body (stepc, ring.h); a stage whose counter is
 // negative has no step in this launch and its workgroups leave at once.
 constexpr int kMaxStepPairs = 32;
-struct StepPairs { int hop[kMaxStepPairs], io[kMaxStepPairs]; };
+// hv / hopv / n_streams: ragged steps (ring.h stepc::hopv) -- stage s reads its per-stream counters at hopv + hv[s] * n_streams
+// (hv[s] < 0 or hopv null: every stream is at hop[s])
+struct StepPairs { int hop[kMaxStepPairs], io[kMaxStepPairs], hv[kMaxStepPairs]; const int* hopv; int n_streams; };
 template <class... Ms> struct Banks;
 template <> struct Banks<> {};
 template <class M, class... Rest>
@@ -138,7 +140,7 @@ struct MaxM<M, Rest...> {
   static constexpr int LDS = M::op::LDS_FLOATS > MaxM<Rest...>::LDS ? M::op::LDS_FLOATS : MaxM<Rest...>::LDS;
 };
 
-template <int I, int NTHR, class M, class... Rest>
+template <int I, int NTHR, bool RAG, class M, class... Rest>
 __device__ __forceinline__ void run_type(const Banks<M, Rest...>& b, const Span& sp, int id, float* lds) {
   if (sp.type == I) {
     using Op = typename M::op;
@@ -147,22 +149,24 @@ __device__ __forceinline__ void run_type(const Banks<M, Rest...>& b, const Span&
 #ifdef FUSE_GLOBALIZE   // A/B build switch, OFF: the table's pointers told to be global memory (ring.h as_global) turn the launch's 2 271
       globalize(a);         // flat loads into global loads with pipelined waits -- and the tick got 4 % SLOWER (profiles/r04_notes.md section 1)
 #endif
-      Op::run(a, id % sp.gx, id / sp.gx, lds);
+      Op::template run_t<RAG>(a, id % sp.gx, id / sp.gx, lds);
     }
   } else {
-    if constexpr (sizeof...(Rest) > 0) run_type<I + 1, NTHR, Rest...>(b.rest, sp, id, lds);
+    if constexpr (sizeof...(Rest) > 0) run_type<I + 1, NTHR, RAG, Rest...>(b.rest, sp, id, lds);
   }
 }
 
-template <int MINW, class... Ms>
+template <int MINW, bool RAG, class... Ms>
 __device__ __forceinline__ void table_body(const Table<Ms...>* __restrict__ t, const StepPairs& pairs);
 template <class... Ms>
-__global__ __launch_bounds__(MaxM<Ms...>::NTHR) void table_kernel(const Table<Ms...>* __restrict__ t, const StepPairs pairs) { table_body<0, Ms...>(t, pairs); }
+__global__ __launch_bounds__(MaxM<Ms...>::NTHR) void table_kernel(const Table<Ms...>* __restrict__ t, const StepPairs pairs) { table_body<0, false, Ms...>(t, pairs); }
 // the same with a register budget: MINW = minimum wavefronts per SIMD the launch wants resident (HIP's second
 // __launch_bounds__ parameter): 4 with 512-thread workgroups = two workgroups per CU = at most 128 VGPRs
-template <int MINW, class... Ms>
-__global__ __launch_bounds__(MaxM<Ms...>::NTHR, MINW) void table_kernel_w(const Table<Ms...>* __restrict__ t, const StepPairs pairs) { table_body<MINW, Ms...>(t, pairs); }
-template <int MINW, class... Ms>
+// RAG: the launch of RAGGED steps (streams that sit steps out; ring.h stepc::hopv) -- a second instance of every body that works with
+// per-row step counters; the common launch (RAG = false) contains none of that
+template <int MINW, bool RAG, class... Ms>
+__global__ __launch_bounds__(MaxM<Ms...>::NTHR, MINW) void table_kernel_w(const Table<Ms...>* __restrict__ t, const StepPairs pairs) { table_body<MINW, RAG, Ms...>(t, pairs); }
+template <int MINW, bool RAG, class... Ms>
 __device__ __forceinline__ void table_body(const Table<Ms...>* __restrict__ t, const StepPairs& pairs) {
   __shared__ __attribute__((aligned(16))) float lds[MaxM<Ms...>::LDS > 0 ? MaxM<Ms...>::LDS : 1];
   const int lane = threadIdx.x & 63;
@@ -180,7 +184,10 @@ __device__ __forceinline__ void table_body(const Table<Ms...>* __restrict__ t, c
   const int stage = (sp.arg >> 16) & 0xff;
   const int step = pairs.hop[stage];
   if (step < 0) return;    // fill / drain: this stage has no step in this launch
-  if (threadIdx.x == 0) { stepc::pair[0] = step; stepc::pair[1] = pairs.io[stage]; }
+  if (threadIdx.x == 0) {
+    stepc::pair[0] = step; stepc::pair[1] = pairs.io[stage];
+    if constexpr (RAG) stepc::hopv = pairs.hopv != nullptr && pairs.hv[stage] >= 0 ? pairs.hopv + (size_t)pairs.hv[stage] * pairs.n_streams : nullptr;
+  }
   __syncthreads();
   unsigned long long* const trace = t->trace;
   const unsigned long long t0 = trace ? wall_clock64() : 0;
@@ -189,7 +196,7 @@ __device__ __forceinline__ void table_body(const Table<Ms...>* __restrict__ t, c
   const int local = id - sp.first;
   const int body_wg = (sp.arg & 0x1000) ? local * 8 + ((sp.arg >> 8) & 15) : local;
   sp.arg &= 0xff;
-  run_type<0, MaxM<Ms...>::NTHR, Ms...>(t->banks, sp, body_wg, lds);
+  run_type<0, MaxM<Ms...>::NTHR, RAG, Ms...>(t->banks, sp, body_wg, lds);
   if (trace && threadIdx.x == 0) {
     trace[3 * (size_t)blockIdx.x] = t0; trace[3 * (size_t)blockIdx.x + 1] = wall_clock64(); trace[3 * (size_t)blockIdx.x + 2] = (unsigned long long)sp.type | ((__builtin_readcyclecounter() - c0) << 8);
   }
@@ -200,10 +207,11 @@ static inline void launch_table(const Table<Ms...>* d_table, int total, hipStrea
   hipLaunchKernelGGL((table_kernel<Ms...>), dim3(total), dim3(MaxM<Ms...>::NTHR), 0, stream, d_table, pairs);
 }
 template <int MINW, class... Ms>
-static inline void launch_table_w(const Table<Ms...>* d_table, int total, hipStream_t stream, const StepPairs& pairs) {
+static inline void launch_table_w(const Table<Ms...>* d_table, int total, hipStream_t stream, const StepPairs& pairs, const bool ragged = false) {
   // measurement aid: BEATRICE_HIP_TICK_PAD_LDS=<bytes> of dynamic LDS on top of the static block (e.g. to allow one workgroup per CU only)
   static const int pad = std::getenv("BEATRICE_HIP_TICK_PAD_LDS") ? std::atoi(std::getenv("BEATRICE_HIP_TICK_PAD_LDS")) : 0;
-  hipLaunchKernelGGL((table_kernel_w<MINW, Ms...>), dim3(total), dim3(MaxM<Ms...>::NTHR), pad, stream, d_table, pairs);
+  if (ragged) hipLaunchKernelGGL((table_kernel_w<MINW, true, Ms...>), dim3(total), dim3(MaxM<Ms...>::NTHR), pad, stream, d_table, pairs);
+  else hipLaunchKernelGGL((table_kernel_w<MINW, false, Ms...>), dim3(total), dim3(MaxM<Ms...>::NTHR), pad, stream, d_table, pairs);
 }
 
 // host side: fill a Table<Ms...>.  add<I>() appends one body of type I (its index in Ms...); bodies run in the order added

@@ -33,7 +33,7 @@ __device__ __forceinline__ void globalize(GruArgs& a) {
 
 // RT = row tiles of 16 streams per workgroup: at 2 the wavefront's weight fragments (held in registers for the whole
 // reduction) feed two independent MFMA chains -- half the weight traffic per stream and twice the work per dependent step.
-template <int IN, int H, int RT = 1>
+template <int IN, int H, int RT = 1, bool RAG = false>
 __device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, const int by, float* __restrict__ lds) {
   constexpr int XS = IN + 2, HS = H + 2;  // lds: 16 RT * XS + 16 RT * HS + RT * 6 * 256 floats
   constexpr int ROWS = 16 * RT;
@@ -55,19 +55,26 @@ __device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, c
   }
   const int hop = stepc::step(a.hop);
   if (hop < 0) return;
+  const bool rag = stepc::rag_t<RAG>();   // (tick launch, ragged steps: every row at its stream's own counter, -1 = the stream sits the step out)
   const int px = ring_pos(a.x, hop), ph = ring_pos(a.h, hop);
   // A tiles -> LDS
   for (int e = tid; e < ROWS * (IN / 4); e += 384) {
     const int r = e / (IN / 4), q = e % (IN / 4);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (b0 + r < a.B) v = *reinterpret_cast<const float4*>(ring_frame(a.x, b0 + r, px, a.t) + 4 * q);
+    if (b0 + r < a.B) {
+      const int hr = rag ? stepc::hopv[b0 + r] : hop;
+      if (hr >= 0) v = *reinterpret_cast<const float4*>(ring_frame(a.x, b0 + r, rag ? ring_pos(a.x, hr) : px, a.t) + 4 * q);
+    }
     float2* d = reinterpret_cast<float2*>(&xs[r * XS + 4 * q]);
     d[0] = make_float2(v.x, v.y); d[1] = make_float2(v.z, v.w);
   }
   for (int e = tid; e < ROWS * (H / 4); e += 384) {
     const int r = e / (H / 4), q = e % (H / 4);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (b0 + r < a.B) v = *reinterpret_cast<const float4*>(ring_frame(a.h, b0 + r, ph, a.t - 1) + 4 * q);
+    if (b0 + r < a.B) {
+      const int hr = rag ? stepc::hopv[b0 + r] : hop;
+      if (hr >= 0) v = *reinterpret_cast<const float4*>(ring_frame(a.h, b0 + r, rag ? ring_pos(a.h, hr) : ph, a.t - 1) + 4 * q);
+    }
     float2* d = reinterpret_cast<float2*>(&hs[r * HS + 4 * q]);
     d[0] = make_float2(v.x, v.y); d[1] = make_float2(v.z, v.w);
   }
@@ -104,7 +111,8 @@ __device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, c
   __syncthreads();
   for (int idx = tid; idx < ROWS * 16; idx += 384) {
     const int r = idx >> 4, j = idx & 15, t = r >> 4, rr_ = r & 15;
-    if (b0 + r < a.B) {
+    const int hr = b0 + r < a.B ? (rag ? stepc::hopv[b0 + r] : hop) : -1;
+    if (hr >= 0) {
       const float* g = g6 + t * 6 * 256;
       const float gi_r = g[(0 * 16 + rr_) * 16 + j], gi_z = g[(1 * 16 + rr_) * 16 + j], gi_n = g[(2 * 16 + rr_) * 16 + j];
       const float gh_r = g[(3 * 16 + rr_) * 16 + j], gh_z = g[(4 * 16 + rr_) * 16 + j], gh_n = g[(5 * 16 + rr_) * 16 + j];
@@ -112,7 +120,7 @@ __device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, c
       const float rr = rz.x, zz = rz.y;
       const float nn = bsp::tanh2(bsp::splat2(bsp::fma(rr, gh_n, gi_n))).x;
       const float hp = hs[r * HS + j0 + j];
-      ring_frame(a.h, b0 + r, ph, a.t)[j0 + j] = bsp::fma(zz, hp - nn, nn);
+      ring_frame(a.h, b0 + r, rag ? ring_pos(a.h, hr) : ph, a.t)[j0 + j] = bsp::fma(zz, hp - nn, nn);
     }
   }
 }
@@ -133,6 +141,7 @@ struct GruOp {
     return bhip::LaunchInfo{name, 2.0 * a.B * (IN + H) * 3.0 * H, 4.0 * ((IN + H) * 3.0 * H + a.B * (IN + 2.0 * H))};
   }
   __device__ static __forceinline__ void run(const GruArgs& a, int bx, int by, float* lds) { gru_fused_body<IN, H, RT>(a, bx, by, lds); }
+  template <bool RAG> __device__ static __forceinline__ void run_t(const GruArgs& a, int bx, int by, float* lds) { gru_fused_body<IN, H, RT, RAG>(a, bx, by, lds); }
 };
 
 // (RT = 2 as a launch of its own measured slower at 8192 streams -- 140 vs 113 us: 78 KB of LDS leave two workgroups

@@ -51,15 +51,17 @@ __device__ __forceinline__ void globalize(F1Args& a) {
 constexpr int kF1LdsFloats = 168 + 10 * 64;
 // PACK streams per workgroup, 256 threads each (the tick launch runs 512-thread workgroups: two streams share one).
 // n_streams bounds the stream index when PACK > 1 (every thread still reaches the barrier).
-template <int PACK>
+template <int PACK, bool RAG = false>
 __device__ __forceinline__ void phone_f1_body_t(const F1Args& a, const int bx, const int hh, float* __restrict__ lds, const int n_streams) {
   const int tid = threadIdx.x & 255, part = PACK > 1 ? (int)(threadIdx.x >> 8) : 0;
   float* x = lds + 168 * part;     // [5 + 160] per stream
   float* ws = lds + 168 * PACK;    // [10][64], shared
   const int b = bx * PACK + part;
-  const bool live = PACK == 1 || b < n_streams;
-  const int hop = stepc::step(a.hop), H = a.H;
-  if (hop < 0) return;
+  const bool in_batch = PACK == 1 || b < n_streams;
+  const int step = stepc::step(a.hop), H = a.H;
+  if (step < 0) return;
+  const int hop = in_batch ? stepc::of_t<RAG>(step, b) : -1;   // (a stream that sits the step out: -1)
+  const bool live = hop >= 0;
   const int io = a.io_stride != 0 ? stepc::slot(a.hop) : 0;
   if (a.hop_publish != nullptr && b == 0 && hh == 0 && tid == 0) {
     a.hop_publish[0] = hop; a.hop_publish[1] = io;
@@ -70,7 +72,7 @@ __device__ __forceinline__ void phone_f1_body_t(const F1Args& a, const int bx, c
   const float* __restrict__ d_in = a.d_in + (size_t)io * a.io_stride;
   const float* __restrict__ w = a.w;
   const float* __restrict__ bias = a.bias;
-  const int pos = ring_pos(audio, hop);
+  const int pos = live ? ring_pos(audio, hop) : 0;
   const float* src = d_in + (size_t)b * H * B_IN_HOP;
   for (int i = threadIdx.x; i < 10 * 64; i += 256 * PACK) ws[i] = w[i];
   if (live && tid < 5) {
@@ -122,6 +124,7 @@ struct F1Op2 {
   static constexpr int NTHR = 512;
   static constexpr int LDS_FLOATS = 2 * 168 + 10 * 64;
   __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { phone_f1_body_t<2>(a.a, bx, 0, lds, a.n_streams); }
+  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) { phone_f1_body_t<2, RAG>(a.a, bx, 0, lds, a.n_streams); }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -141,14 +144,17 @@ __device__ __forceinline__ void globalize(VqArgs& a) {
   globalize(a.raw); globalize(a.out); a.hop = as_global(a.hop); a.cbT = as_global(a.cbT); a.cnorm = as_global(a.cnorm); a.k = as_global(a.k);
 }
 constexpr int kVqLdsFloats = B_PHONE_CH + 8 + 8 + 8;
+template <bool RAG = false>
 __device__ __forceinline__ void phone_vq_body(const VqArgs& a, const int row, float* __restrict__ lds) {
   float* x = lds;                                               // [128]
   float* red_d = lds + B_PHONE_CH;                              // [8]
   int* red_j = reinterpret_cast<int*>(lds + B_PHONE_CH + 8);    // [8]
   int& winner = *reinterpret_cast<int*>(lds + B_PHONE_CH + 16);
   const int b = row / a.H, j = threadIdx.x, lane = j & 63, wave = j >> 6;
-  const int hop = stepc::step(a.hop);
-  if (hop < 0) return;
+  const int step = stepc::step(a.hop);
+  if (step < 0) return;
+  const int hop = stepc::of_t<RAG>(step, b);
+  if (hop < 0) return;   // (the stream sits this step out)
   float* out = ring_frame(a.out, b, ring_pos(a.out, hop), row % a.H);
   const int k = a.k[b];
   const float* cbT = as_global_v(a.cbT[row]);   // (device allocations: global memory)
@@ -198,6 +204,7 @@ struct VqOp {
   static constexpr int NTHR = 512;
   static constexpr int LDS_FLOATS = kVqLdsFloats;
   __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { phone_vq_body(a, bx, lds); }
+  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) { phone_vq_body<RAG>(a, bx, lds); }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -217,22 +224,24 @@ __device__ __forceinline__ void globalize(FftArgs& a) {
 }
 constexpr int kFftLdsFloats = 3 * B_FFT_N;
 // PACK streams per workgroup, 256 threads each (see phone_f1_body_t); the twiddle table is shared
-template <int PACK>
+template <int PACK, bool RAG = false>
 __device__ __forceinline__ void pitch_fft_body_t(const FftArgs& a, const int bx, const int hh, float* __restrict__ lds, const int n_streams) {
   const int tid = threadIdx.x & 255, part = PACK > 1 ? (int)(threadIdx.x >> 8) : 0;
   float* re = lds + 2 * B_FFT_N * part;
   float* im = re + B_FFT_N;
   float* tw = lds + 2 * B_FFT_N * PACK;
   const int b = bx * PACK + part;
-  const bool live = PACK == 1 || b < n_streams;
-  const int hop = stepc::step(a.hop), H = a.H;
-  if (hop < 0) return;
+  const bool in_batch = PACK == 1 || b < n_streams;
+  const int step = stepc::step(a.hop), H = a.H;
+  if (step < 0) return;
+  const int hop = in_batch ? stepc::of_t<RAG>(step, b) : -1;   // (a stream that sits the step out: -1)
+  const bool live = hop >= 0;
   const Ring& audio = a.audio;
   const Ring& spec = a.spec;
   const float* __restrict__ d_in = a.d_in + (a.io_stride != 0 ? (size_t)stepc::slot(a.hop) * a.io_stride : 0);
   const float* __restrict__ window = a.window;
   const float* __restrict__ twiddle = a.twiddle;
-  const int pos = ring_pos(audio, hop);
+  const int pos = live ? ring_pos(audio, hop) : 0;
   const float* src = d_in + (size_t)b * H * B_IN_HOP;
   for (int i = threadIdx.x; i < B_FFT_N; i += 256 * PACK) tw[i] = twiddle[i];
   if (live)
@@ -298,6 +307,7 @@ struct FftOp2 {  // two streams per 512-thread workgroup (H = 1): grid ((n_strea
   static constexpr int NTHR = 512;
   static constexpr int LDS_FLOATS = 5 * B_FFT_N;
   __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { pitch_fft_body_t<2>(a.a, bx, 0, lds, a.n_streams); }
+  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) { pitch_fft_body_t<2, RAG>(a.a, bx, 0, lds, a.n_streams); }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -358,9 +368,12 @@ __device__ inline int pitch_transform_device(int q, const PitchParams& p) {
   return qi < 1 ? 1 : (qi > B_PITCH_BINS - 1 ? B_PITCH_BINS - 1 : qi);
 }
 
+template <bool RAG = false>
 __device__ __forceinline__ void pitch_head_body(const PitchHeadArgs& a, const int b, const int l = threadIdx.x) {
-  const int hop = stepc::step(a.hop);
-  if (hop < 0) return;
+  const int step = stepc::step(a.hop);
+  if (step < 0) return;
+  const int hop = stepc::of_t<RAG>(step, b);
+  if (hop < 0) return;   // (the stream sits this step out: previous bin, outputs and slots stay as they are)
   const size_t qoff = (size_t)(hop % a.q_slots) * a.B * a.H;
   const int pos_l = ring_pos(a.logits, hop);
   int lo = a.min_q[b], hi = a.max_q[b];
@@ -433,6 +446,10 @@ struct HeadOp8 {  // one wavefront per stream, eight streams per 512-thread work
     const int b = bx * 8 + (int)(threadIdx.x >> 6);
     if (b < a.B) pitch_head_body(a, b, (int)(threadIdx.x & 63));
   }
+  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float*) {
+    const int b = bx * 8 + (int)(threadIdx.x >> 6);
+    if (b < a.B) pitch_head_body<RAG>(a, b, (int)(threadIdx.x & 63));
+  }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -460,10 +477,13 @@ __device__ __forceinline__ void globalize(CondArgs& a) {
   a.add_tab = as_global(a.add_tab); a.add_idx = as_global(a.add_idx); a.frm_tab = as_global(a.frm_tab); a.frm_idx = as_global(a.frm_idx);
   globalize(a.e); a.hop = as_global(a.hop); a.hop_next_out = as_global(a.hop_next_out);
 }
+template <bool RAG = false>
 __device__ __forceinline__ void wave_cond_body(const CondArgs& a, const int row, const int n = threadIdx.x) {
   const int b = row / a.H;
-  const int hop = stepc::step(a.hop);
-  if (hop < 0) return;
+  const int step = stepc::step(a.hop);
+  if (step < 0) return;
+  const int hop = stepc::of_t<RAG>(step, b);
+  if (hop < 0) return;   // (the stream sits this step out)
   const size_t qoff = (size_t)(hop % a.q_slots) * a.B * a.H;
   int q = a.q[qoff + row];
   q = q < 0 ? 0 : (q > a.n_bins - 1 ? a.n_bins - 1 : q);
@@ -476,7 +496,7 @@ __device__ __forceinline__ void wave_cond_body(const CondArgs& a, const int row,
   ring_frame(a.e, b, ring_pos(a.e, hop), row % a.H)[n] = (a.pitch_emb[(size_t)q * B_HID + n] + fp) + c;
   if (a.hop_next_out != nullptr && row == 0 && n == 0) {
     const int io = a.io_slots > 0 ? stepc::slot(a.hop) : 0;
-    a.hop_next_out[0] = hop_next(hop);
+    a.hop_next_out[0] = hop_next(step);
     a.hop_next_out[1] = a.io_slots > 0 ? (io + 1 >= a.io_slots ? 0 : io + 1) : 0;
   }
 }
@@ -494,6 +514,10 @@ struct CondOp2 {  // two rows per 512-thread workgroup: grid ((rows + 1) / 2, 1)
   __device__ static __forceinline__ void run(const Args& a, int bx, int, float*) {
     const int row = bx * 2 + (int)(threadIdx.x >> 8);
     if (row < a.B * a.H) wave_cond_body(a, row, (int)(threadIdx.x & 255));
+  }
+  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float*) {
+    const int row = bx * 2 + (int)(threadIdx.x >> 8);
+    if (row < a.B * a.H) wave_cond_body<RAG>(a, row, (int)(threadIdx.x & 255));
   }
 };
 

@@ -70,11 +70,33 @@ __device__ __forceinline__ float* ring_frame(const Ring& r, int b, int pos, int 
 // (stepc::immediate(hop); addresses below kImmediateTop are never mapped), again without a dependent load.
 namespace stepc {
 __shared__ int pair[2];
+// The tick launch with RAGGED steps (streams that sit a step out: the shell's silent-block rule per stream, batch.hip): this
+// stage's per-stream step counters [B] -- stream b is at hopv[b], or -1 when it takes no part in the step -- left here by the table
+// kernel beside `pair`; nullptr while every stream is at the step's common counter.  Only meaningful where args.hop is null.
+__shared__ const int* hopv;
 constexpr unsigned long long kImmediateTop = 1ull << 28;
 inline const int* immediate(int hop) { return reinterpret_cast<const int*>(static_cast<unsigned long long>(hop + 2)); }
 __device__ __forceinline__ int step(const int* p) {
   const unsigned long long v = reinterpret_cast<unsigned long long>(p);
   return v == 0 ? pair[0] : (v < kImmediateTop ? (int)v - 2 : *p);
+}
+// the step counter of stream b in this step: the common one, or the stream's own (-1: absent) in a ragged tick step
+__device__ __forceinline__ int of(const int* p, const int hop, const int b) {
+  if (reinterpret_cast<unsigned long long>(p) != 0) return hop;
+  const int* v = hopv;
+  return v != nullptr ? v[b] : hop;
+}
+__device__ __forceinline__ bool ragged(const int* p) { return reinterpret_cast<unsigned long long>(p) == 0 && hopv != nullptr; }
+// The same as compile-time variants: the tick launch exists twice (fuse::table_kernel_w<.., RAG>), and only the RAG = true one --
+// launched once a stream has sat a step out -- pays for per-row counters; with RAG = false these fold to `hop` / `false` and
+// the bodies are exactly what they were (the common path measured 3.5 % slower with run-time tests).
+template <bool RAG> __device__ __forceinline__ int of_t(const int hop, const int b) {
+  if constexpr (RAG) { const int* v = hopv; return v != nullptr ? v[b] : hop; }
+  else return hop;
+}
+template <bool RAG> __device__ __forceinline__ bool rag_t() {
+  if constexpr (RAG) return hopv != nullptr;
+  else return false;
 }
 __device__ __forceinline__ int slot(const int* p) {
   const unsigned long long v = reinterpret_cast<unsigned long long>(p);

@@ -206,14 +206,16 @@ __device__ __forceinline__ void layer256(const float* const (&seg)[NSEG], const 
 }
 
 // [16 rows][256 channels] from a ring into an LDS tile; row r = frame `rel` of stream sid[r] (zeros when sid[r] < 0)
+// (rowhop: LDS [16], the rows' own step counters in a ragged tick step -- sid[] is then already -1 for streams that sit it out --
+//  or nullptr: every row at `pos`)
 __device__ __forceinline__ void load_tile(float* __restrict__ dst, const Ring& ring, const int* sid /* LDS, [16] */, const int pos, const int rel,
-                                          const int tid) {
+                                          const int tid, const int* rowhop = nullptr) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int idx = tid + i * NTHR, r = idx >> 6, q = idx & 63;
     const int b = sid[r];
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (b >= 0) v = *reinterpret_cast<const float4*>(ring_frame(ring, b, pos, rel) + 4 * q);
+    if (b >= 0) v = *reinterpret_cast<const float4*>(ring_frame(ring, b, rowhop != nullptr ? ring_pos(ring, rowhop[r]) : pos, rel) + 4 * q);
     float2* d = reinterpret_cast<float2*>(dst + r * AS + 4 * q);
     d[0] = make_float2(v.x, v.y);
     d[1] = make_float2(v.z, v.w);
@@ -232,20 +234,27 @@ __device__ __forceinline__ void globalize(BlockAArgs& a) {
   globalize(a.x); globalize(a.xa);
   a.c1_w = as_global(a.c1_w); a.c1_b = as_global(a.c1_b); a.c2_w = as_global(a.c2_w); a.c2_b = as_global(a.c2_b); a.hop = as_global(a.hop);
 }
-constexpr int kBlockALds = 4 * TILE + 16;
-template <int D>
+constexpr int kBlockALds = 4 * TILE + 32;   // + sid[16], rowhop[16]
+template <int D, bool RAG = false>
 __device__ __forceinline__ void block_a_body(const BlockAArgs& a, const int g, float* __restrict__ lds) {
   float* T[3] = {lds, lds + TILE, lds + 2 * TILE};  // taps t-2D, t-D, t
   float* Hh = lds + 3 * TILE;
   int* sid = reinterpret_cast<int*>(lds + 4 * TILE);
+  int* rowhop_ = sid + 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hop = stepc::step(a.hop);
   if (hop < 0) return;
-  if (tid < 16) sid[tid] = g * 16 + tid < a.B ? g * 16 + tid : -1;
+  const int* rowhop = stepc::rag_t<RAG>() ? rowhop_ : nullptr;   // (ragged tick step: rows at their streams' own counters)
+  if (tid < 16) {
+    const int b = g * 16 + tid < a.B ? g * 16 + tid : -1;
+    const int hr = b >= 0 ? stepc::of_t<RAG>(hop, b) : -1;
+    sid[tid] = hr >= 0 ? b : -1;
+    rowhop_[tid] = hr >= 0 ? hr : 0;
+  }
   __syncthreads();
   const int pos = ring_pos(a.x, hop);
 #pragma unroll
-  for (int j = 0; j < 3; ++j) load_tile(T[j], a.x, sid, pos, -(2 - j) * D, tid);
+  for (int j = 0; j < 3; ++j) load_tile(T[j], a.x, sid, pos, -(2 - j) * D, tid, rowhop);
   __syncthreads();
   {
     const float* const seg[3] = {T[0], T[1], T[2]};
@@ -267,7 +276,7 @@ __device__ __forceinline__ void block_a_body(const BlockAArgs& a, const int g, f
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int b = sid[r0 + e];
-        if (b >= 0) ring_frame(a.xa, b, pos_o, 0)[n] = T[2][(r0 + e) * AS + n] + (v[e] + bn);
+        if (b >= 0) ring_frame(a.xa, b, rowhop != nullptr ? ring_pos(a.xa, rowhop[r0 + e]) : pos_o, 0)[n] = T[2][(r0 + e) * AS + n] + (v[e] + bn);
       }
     });
   }
@@ -283,6 +292,7 @@ struct BlockAOp {
   }
   static constexpr double wg_cost() { return 20.0; }
   __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { block_a_body<D>(a, bx, lds); }
+  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) { block_a_body<D, RAG>(a, bx, lds); }
 };
 template <int D>
 static __global__ __launch_bounds__(NTHR, 4) void block_a_kernel(const BlockAArgs a) {
@@ -306,7 +316,8 @@ __device__ __forceinline__ void globalize(BlockBArgs& a) {
   a.q_w = as_global(a.q_w); a.q_b = as_global(a.q_b); a.o_w = as_global(a.o_w); a.o_b = as_global(a.o_b);
   a.kt = as_global(a.kt); a.v = as_global(a.v); a.perm = as_global(a.perm); a.tile_slot = as_global(a.tile_slot); a.hop = as_global(a.hop);
 }
-constexpr int kBlockBLds = 2 * TILE + STILE + 32;
+constexpr int kBlockBLds = 2 * TILE + STILE + 48;   // + inv[16], sid[16], rowhop[16]
+template <bool RAG = false>
 __device__ __forceinline__ void block_b_body(const BlockBArgs& a, const int g, float* __restrict__ lds) {
   float* XA = lds;
   float* Q = lds + TILE;           // q, later o
@@ -319,9 +330,16 @@ __device__ __forceinline__ void block_b_body(const BlockBArgs& a, const int g, f
   const int slot = a.tile_slot[g];
   if (slot < 0) return;
   RC_STAMP(0);
-  if (tid < 16) sid[tid] = a.perm[g * 16 + tid];
+  int* rowhop_ = sid + 16;
+  const int* rowhop = stepc::rag_t<RAG>() ? rowhop_ : nullptr;
+  if (tid < 16) {
+    const int b = a.perm[g * 16 + tid];
+    const int hr = b >= 0 ? stepc::of_t<RAG>(hop, b) : -1;
+    sid[tid] = hr >= 0 ? b : -1;
+    rowhop_[tid] = hr >= 0 ? hr : 0;
+  }
   __syncthreads();
-  load_tile(XA, a.xa, sid, ring_pos(a.xa, hop), 0, tid);
+  load_tile(XA, a.xa, sid, ring_pos(a.xa, hop), 0, tid, rowhop);
   __syncthreads();
   {
     const float* const seg[1] = {XA};
@@ -394,7 +412,7 @@ __device__ __forceinline__ void block_b_body(const BlockBArgs& a, const int g, f
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int b = sid[r0 + e];
-        if (b >= 0) ring_frame(a.out, b, pos_o, 0)[n] = XA[(r0 + e) * AS + n] + (v[e] + bn);
+        if (b >= 0) ring_frame(a.out, b, rowhop != nullptr ? ring_pos(a.out, rowhop[r0 + e]) : pos_o, 0)[n] = XA[(r0 + e) * AS + n] + (v[e] + bn);
       }
     });
   }
@@ -406,6 +424,7 @@ struct BlockBOp {
   static constexpr int LDS_FLOATS = kBlockBLds;
   static constexpr double wg_cost() { return 24.0; }
   __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { block_b_body(a, bx, lds); }
+  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) { block_b_body<RAG>(a, bx, lds); }
 };
 static __global__ __launch_bounds__(NTHR, 4) void block_b_kernel(const BlockBArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[kBlockBLds];
@@ -495,6 +514,7 @@ __device__ __forceinline__ void globalize(BlockBqArgs& a) {
   a.ktp = as_global(a.ktp); a.vp = as_global(a.vp); a.qperm = as_global(a.qperm); a.qslot = as_global(a.qslot); a.hop = as_global(a.hop);
 }
 constexpr int kBlockBqLds = kBlockBLds;
+template <bool RAG = false>
 __device__ __forceinline__ void block_bq_body(const BlockBqArgs& a, const int g, float* __restrict__ lds) {
   float* XA = lds;
   float* Q = lds + TILE;           // q, later o
@@ -511,9 +531,16 @@ __device__ __forceinline__ void block_bq_body(const BlockBqArgs& a, const int g,
   // co-resident workgroup (zero-sum for the SIMD, profiles/r03_notes.md section 2, but it shortens the launch's tail).
   __builtin_amdgcn_s_setprio(3);
   RC_STAMP(0);
-  if (tid < 16) sid[tid] = tid < 8 ? a.qperm[g * 8 + tid] : -1;   // rows 8..15 of the tile stay empty
+  int* rowhop_ = sid + 16;
+  const int* rowhop = stepc::rag_t<RAG>() ? rowhop_ : nullptr;
+  if (tid < 16) {   // rows 8..15 of the tile stay empty
+    const int b = tid < 8 ? a.qperm[g * 8 + tid] : -1;
+    const int hr = b >= 0 ? stepc::of_t<RAG>(hop, b) : -1;
+    sid[tid] = hr >= 0 ? b : -1;
+    rowhop_[tid] = hr >= 0 ? hr : 0;
+  }
   __syncthreads();
-  load_tile(XA, a.xa, sid, ring_pos(a.xa, hop), 0, tid);
+  load_tile(XA, a.xa, sid, ring_pos(a.xa, hop), 0, tid, rowhop);
   __syncthreads();
   {
     const float* const seg[1] = {XA};
@@ -587,7 +614,7 @@ __device__ __forceinline__ void block_bq_body(const BlockBqArgs& a, const int g,
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int b = sid[r0 + e];
-        if (b >= 0) ring_frame(a.out, b, pos_o, 0)[n] = XA[(r0 + e) * AS + n] + (v[e] + bn);
+        if (b >= 0) ring_frame(a.out, b, rowhop != nullptr ? ring_pos(a.out, rowhop[r0 + e]) : pos_o, 0)[n] = XA[(r0 + e) * AS + n] + (v[e] + bn);
       }
     });
   }
@@ -600,6 +627,7 @@ struct BlockBqOp {
   static constexpr int LDS_FLOATS = kBlockBqLds;
   static constexpr double wg_cost() { return 30.0; }
   __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { block_bq_body(a, bx, lds); }
+  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) { block_bq_body<RAG>(a, bx, lds); }
 };
 // ---------------------------------------------------------------------------------------------------------------------
 // Any conv_gemm Layer for ONE tile of 16 rows and ALL its output columns: the A operand streams through two LDS tiles
@@ -609,10 +637,10 @@ struct BlockBqOp {
 // a tick this replaces conv_gemm's 64-wide k-chunks (two barriers and an exposed load latency per 16 MFMA steps):
 // phone.rb (K = 1280): 65 -> 46 us per workgroup with two workgroups per CU.
 constexpr int kConvRowsLds = 2 * TILE + 32;
-template <int RT> constexpr int conv_rows_lds() { return 2 * RT * TILE + 32 * RT; }
+template <int RT> constexpr int conv_rows_lds() { return 2 * RT * TILE + 48 * RT; }   // + per row: stream, frame, the stream's step counter
 // COLS = output columns per workgroup (0 = all): a wide layer can be cut into column slabs, one workgroup each (grid y).
 // RT = row tiles of 16 per workgroup: at 2 every weight fragment feeds two MFMAs (half the weight traffic per row).
-template <class L, int COLS = 0, int RT = 1>
+template <class L, int COLS = 0, int RT = 1, bool RAG = false>
 __device__ __forceinline__ void conv_rows_body(const ConvArgs& a, const int bx, const int by, float* __restrict__ lds) {
   constexpr int NCOL = COLS > 0 ? COLS : L::NOUT;
   static_assert(L::NOUT % NCOL == 0 && NCOL % 16 == 0, "column slabs");
@@ -627,10 +655,14 @@ __device__ __forceinline__ void conv_rows_body(const ConvArgs& a, const int bx, 
   const int hop = stepc::step(a.hop);
   if (hop < 0) return;
   const int M = a.B * L::T;
+  const bool rag = stepc::rag_t<RAG>();   // (ragged tick step: every row at its stream's own counter; absent streams' rows drop out)
   if (tid < ROWS) {
     const int m = bx * ROWS + tid;
-    rb_[tid] = m < M ? m / L::T : -1;
+    const int b = m < M ? m / L::T : -1;
+    const int hr = b >= 0 ? stepc::of_t<RAG>(hop, b) : -1;
+    rb_[tid] = hr >= 0 ? b : -1;
     rb_[ROWS + tid] = m < M ? m % L::T : 0;
+    rb_[2 * ROWS + tid] = hr >= 0 ? hr : 0;
   }
   __syncthreads();
   const int pos_in = ring_pos(a.in, hop);
@@ -648,7 +680,8 @@ __device__ __forceinline__ void conv_rows_body(const ConvArgs& a, const int bx, 
     for (int i = 0; i < 2 * RT; ++i) {
       nx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (live && pb[i] >= 0)
-        nx[i] = *reinterpret_cast<const float4*>(ring_frame(a.in, pb[i], pos_in, (pt[i] + 1) * L::STRIDE - 1 - (L::KSZ - 1 - j) * L::DIL + a.rel_shift) + c);
+        nx[i] = *reinterpret_cast<const float4*>(ring_frame(a.in, pb[i], rag ? ring_pos(a.in, rb_[2 * ROWS + r0 + 8 * i]) : pos_in,   // (ragged: worked out per load, no register held for it in the common case)
+                                                            (pt[i] + 1) * L::STRIDE - 1 - (L::KSZ - 1 - j) * L::DIL + a.rel_shift) + c);
     }
   };
   auto store_seg = [&](float* dst) {
@@ -736,9 +769,15 @@ __device__ __forceinline__ void conv_rows_body(const ConvArgs& a, const int bx, 
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if (rb[e] < 0) continue;
+        int po = pos_out, pr = pos_res;
+        if (rag) {
+          const int hr = rb_[2 * ROWS + 16 * t + (lane >> 4) * 4 + e];
+          po = ring_pos(a.out, hr);
+          if constexpr (L::RES) pr = ring_pos(a.res, hr);
+        }
         // (32-bit index arithmetic: a ring holds fewer than 2^32 floats, RingArena::build)
-        if constexpr (L::RES) v[e] = a.res.base[(unsigned)(rb[e] * R_res + pos_res) * (unsigned)a.res.C + (unsigned)(rf[e] * L::NOUT + n)] + v[e];
-        a.out.base[(unsigned)(rb[e] * R_out + pos_out) * (unsigned)a.out.C + (unsigned)(rf[e] * L::NOUT + n)] = v[e];
+        if constexpr (L::RES) v[e] = a.res.base[(unsigned)(rb[e] * R_res + pr) * (unsigned)a.res.C + (unsigned)(rf[e] * L::NOUT + n)] + v[e];
+        a.out.base[(unsigned)(rb[e] * R_out + po) * (unsigned)a.out.C + (unsigned)(rf[e] * L::NOUT + n)] = v[e];
       }
     }
 }
@@ -750,6 +789,7 @@ struct ConvRowsOp {
   static inline dim3 grid(const ConvArgs& a) { return dim3((a.B * L::T + 16 * RT - 1) / (16 * RT), COLS > 0 ? L::NOUT / COLS : 1); }
   static inline bhip::LaunchInfo info(const char* name, const ConvArgs& a) { return ConvOp<L, TileCfg<1, 1, 1, 2, 1>>::info(name, a); }
   __device__ static __forceinline__ void run(const ConvArgs& a, int bx, int by, float* lds) { conv_rows_body<L, COLS, RT>(a, bx, by, lds); }
+  template <bool RAG> __device__ static __forceinline__ void run_t(const ConvArgs& a, int bx, int by, float* lds) { conv_rows_body<L, COLS, RT, RAG>(a, bx, by, lds); }
 };
 
 // the same body as a launch of its own (the in-order chain at large batches, wave.hip)

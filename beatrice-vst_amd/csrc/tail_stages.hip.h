@@ -85,6 +85,8 @@ __device__ __forceinline__ float lrelu_max(float x) {
 template <int C> __host__ __device__ constexpr int cs() { return C + 2; }
 template <int C, int T, int S> __host__ __device__ constexpr int buf_floats() { return S * (HP + T) * cs<C>(); }
 template <int C, int T> __device__ __forceinline__ int row_off(int s, int t) { return (s * (HP + T) + HP + t) * cs<C>(); }
+// LDS of a stage (floats): two activation buffers, the raw-input and third-layer-history stashes, the raw y of the 64-channel stage, the streams' step counters
+template <int C, int T, int S, int HC_ROWS> constexpr int stage_lds() { return 2 * buf_floats<C, T, S>() + S * (2 + HC_ROWS) * C + (C > 32 ? S * T * C : 0) + 8; }   // (+ 8: the streams' step counters)
 
 // Work split of a layer over the 8 wavefronts: NWN column groups x NWM row groups.  A wavefront keeps the B fragments of its
 // CT column tiles in registers (1, or all of them when the tile count is not a power of two) and walks the row tiles
@@ -258,12 +260,35 @@ __device__ __forceinline__ void layer(const float* __restrict__ in, const float4
 // LDS), residual values are requested a tile ahead of their use, and the state block is written behind everything else.
 
 // S x N floats (N a multiple of 4, S * N / 4 <= 512: one float4 per thread) of the state block at `ts_off`
-template <int S, int N>
-__device__ __forceinline__ float4 state_load(const float* __restrict__ state, const int ts_off, const int b0, const int B, const int tid) {
+// (shop: LDS [S], the step counter of each of the workgroup's streams, -1 = past the batch or sitting this step out)
+// is stream s of the workgroup there in this step?  (RAG = false, the common launch: "inside the batch", no memory access)
+template <bool RAG>
+__device__ __forceinline__ bool live_s(const int* shop, const int b0, const int s, const int B) {
+  if constexpr (RAG) return shop[s] >= 0;
+  else return b0 + s < B;
+}
+template <int S, int N, bool RAG>
+__device__ __forceinline__ float4 state_load(const float* __restrict__ state, const int ts_off, const int b0, const int* shop, const int B, const int tid) {
   static_assert(N % 4 == 0 && S * N / 4 <= NTHR, "one float4 per thread");
   const int s = tid / (N / 4), q = tid % (N / 4);
-  return tid < S * N / 4 && b0 + s < B ? *reinterpret_cast<const float4*>(state + (size_t)(b0 + s) * TAIL_STATE_FLOATS + ts_off + 4 * q)
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+  return tid < S * N / 4 && live_s<RAG>(shop, b0, s, B) ? *reinterpret_cast<const float4*>(state + (size_t)(b0 + s) * TAIL_STATE_FLOATS + ts_off + 4 * q)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+// the streams of a workgroup: their step counters (the common one; their own in a ragged tick step; -1 where there is no stream)
+template <int S, bool RAG>
+__device__ __forceinline__ void stream_hops(const StageArgs& a, const int hop, const int b0, int* shop) {
+  if constexpr (RAG) {
+    if (threadIdx.x < S) {
+      const int b = b0 + (int)threadIdx.x;
+      shop[threadIdx.x] = b < a.B ? stepc::of_t<RAG>(hop, b) : -1;
+    }
+    __syncthreads();
+  }
+}
+template <bool RAG>
+__device__ __forceinline__ int stream_pos(const Ring& ring, const int pos, const int* shop, const int s) {
+  if constexpr (RAG) return stepc::hopv != nullptr ? ring_pos(ring, shop[s]) : pos;
+  else return pos;
 }
 __device__ __forceinline__ void store_act4(float* __restrict__ d, const float4 v) {   // (row stride C + 2: 8-byte aligned, not 16)
   reinterpret_cast<float2*>(d)[0] = make_float2(lrelu_max(v.x), lrelu_max(v.y));
@@ -274,9 +299,9 @@ __device__ __forceinline__ void store_act4(float* __restrict__ d, const float4 v
 // itself, or from the state block at TS_IN -- then the raw frames that will be the NEXT step's history are stashed in `hin`
 // and reach the state block at the end); the six history rows of the second layer -> Y rows [-6, 0); the history of the third
 // layer (HC_ROWS rows) -> `hc`, activated, to be copied into X once the first layer is done with it.
-template <int C, int T, int S, int TS_IN, int TS_B, int TS_C, int HC_ROWS, bool IN_FROM_RING_HISTORY>
+template <int C, int T, int S, int TS_IN, int TS_B, int TS_C, int HC_ROWS, bool IN_FROM_RING_HISTORY, bool RAG>
 __device__ __forceinline__ void prologue(const StageArgs& a, const int hop, const int b0, float* __restrict__ X, float* __restrict__ Y, float* __restrict__ hin,
-                                         float* __restrict__ hc, const int tid) {
+                                         float* __restrict__ hc, const int tid, const int* shop) {
   constexpr int F4 = C / 4, ROWS = T + 2, N = S * ROWS * F4, NIT = (N + NTHR - 1) / NTHR;
   const int pos = ring_pos(a.in, hop);
   float4 v[NIT];
@@ -285,13 +310,13 @@ __device__ __forceinline__ void prologue(const StageArgs& a, const int hop, cons
     const int e = tid + it * NTHR;
     const int s = e / (ROWS * F4), q = e % (ROWS * F4), t = q / F4 - 2, c4 = q % F4, b = b0 + s;
     v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e < N && b < a.B) {
-      if (IN_FROM_RING_HISTORY || t >= 0) v[it] = *reinterpret_cast<const float4*>(ring_frame(a.in, b, pos, t) + 4 * c4);
+    if (e < N && live_s<RAG>(shop, b0, s, a.B)) {
+      if (IN_FROM_RING_HISTORY || t >= 0) v[it] = *reinterpret_cast<const float4*>(ring_frame(a.in, b, stream_pos<RAG>(a.in, pos, shop, s), t) + 4 * c4);
       else v[it] = *reinterpret_cast<const float4*>(a.state + (size_t)b * TAIL_STATE_FLOATS + TS_IN + (t + 2) * C + 4 * c4);
     }
   }
-  const float4 hb = state_load<S, 6 * C>(a.state, TS_B, b0, a.B, tid);
-  const float4 hcv = state_load<S, HC_ROWS * C>(a.state, TS_C, b0, a.B, tid);
+  const float4 hb = state_load<S, 6 * C, RAG>(a.state, TS_B, b0, shop, a.B, tid);
+  const float4 hcv = state_load<S, HC_ROWS * C, RAG>(a.state, TS_C, b0, shop, a.B, tid);
   // ---- every load above is in flight; now the stores
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -320,11 +345,11 @@ __device__ __forceinline__ void stash_to_rows(float* __restrict__ buf, const flo
     buf[row_off<C, T>(s, t_first + q / C) + q % C] = stash[e];
   }
 }
-template <int C, int S, int TS_IN>
-__device__ __forceinline__ void hin_to_state(const StageArgs& a, const float* __restrict__ hin, const int b0, const int tid) {
+template <int C, int S, int TS_IN, bool RAG>
+__device__ __forceinline__ void hin_to_state(const StageArgs& a, const float* __restrict__ hin, const int b0, const int tid, const int* shop) {
   for (int e = tid; e < S * 2 * C / 4; e += NTHR) {
     const int s = e / (2 * C / 4), q = e % (2 * C / 4);
-    if (b0 + s < a.B) *reinterpret_cast<float4*>(a.state + (size_t)(b0 + s) * TAIL_STATE_FLOATS + TS_IN + 4 * q) = *reinterpret_cast<const float4*>(hin + 4 * e);
+    if (live_s<RAG>(shop, b0, s, a.B)) *reinterpret_cast<float4*>(a.state + (size_t)(b0 + s) * TAIL_STATE_FLOATS + TS_IN + 4 * q) = *reinterpret_cast<const float4*>(hin + 4 * e);
   }
 }
 
@@ -334,11 +359,11 @@ __device__ __forceinline__ void hin_to_state(const StageArgs& a, const float* __
 //                                        frames, raw, as the next step's history (-> TS_C)
 // after_a() / between(): called right after the first layer's MFMAs and after the barrier that follows (the caller's fetches of
 // the next layers' weights, see fetch_b).
-template <int C, int T, int S, int TS_B, int TS_C, int HC_ROWS, class AfterA, class Between>
+template <int C, int T, int S, int TS_B, int TS_C, int HC_ROWS, bool RAG, class AfterA, class Between>
 __device__ __forceinline__ void two_res_layers(const StageArgs& a, const int hop, const int b0, const int n_rows, float* __restrict__ X, float* __restrict__ Y,
                                                const float* __restrict__ hc, const float4 (&bfa)[Split<C>::CT][3 * C / 16],
                                                const float4 (&bfb)[Split<C>::CT][3 * C / 16], const int wave, const int lane, const int tid, AfterA after_a, Between between,
-                                               float* __restrict__ yr = nullptr /* C > 32: LDS [S][T][C], the raw y (registers are short at 64 channels) */) {
+                                               const int* shop, float* __restrict__ yr = nullptr /* C > 32: LDS [S][T][C], the raw y (registers are short at 64 channels) */) {
   static_assert(Split<C>::CT == 1, "one column tile per wavefront");
   constexpr bool IN_LDS = C > 32;
   const int n_lane = (wave % Split<C>::NWN) * 16 + (lane & 15);
@@ -347,7 +372,10 @@ __device__ __forceinline__ void two_res_layers(const StageArgs& a, const int hop
   float keep[n_pass<C, T, S>()][2][Split<C>::CT][4];
   layer<C, C, 3, 1, T, S, (C <= 32 ? 1 : 2)>(X, bfa, n_rows, wave, lane, keep,
     [&](int s, int t0, int n, int, float (&res)[4]) {
-      const float* p = ring_frame(a.in, b0 + s, pos, t0) + n;   // (frames t0 .. t0 + 3 of a step are contiguous in its ring slot)
+      if constexpr (RAG) {
+        if (shop[s] < 0) { res[0] = res[1] = res[2] = res[3] = 0.0f; return; }   // (a stream that sits the step out: its rows compute on zeros, nothing of it is written)
+      }
+      const float* p = ring_frame(a.in, b0 + s, stream_pos<RAG>(a.in, pos, shop, s), t0) + n;   // (frames t0 .. t0 + 3 of a step are contiguous in its ring slot)
 #pragma unroll
       for (int e = 0; e < 4; ++e) res[e] = p[e * C];
     },
@@ -359,7 +387,7 @@ __device__ __forceinline__ void two_res_layers(const StageArgs& a, const int hop
         const float y = res[e] + (acc[e] + bias_a);
         yo[e * cs<C>()] = lrelu_max(y);
         if (IN_LDS) yr[((s * T) + t0 + e) * C + n] = y; else res[e] = y;   // the second layer's residual
-        if (t0 + e >= T - 6) st[e * C] = y;
+        if (t0 + e >= T - 6 && (!RAG || shop[s] >= 0)) st[e * C] = y;
       }
     });
   after_a();
@@ -380,7 +408,7 @@ __device__ __forceinline__ void two_res_layers(const StageArgs& a, const int hop
       for (int e = 0; e < 4; ++e) {
         const float z = res[e] + (acc[e] + bias_b);
         xo[e * cs<C>()] = lrelu_max(z);
-        if (t0 + e >= T - HC_ROWS) st[e * C] = z;
+        if (t0 + e >= T - HC_ROWS && (!RAG || shop[s] >= 0)) st[e * C] = z;
       }
     });
   TST_STAMP(5);
@@ -392,7 +420,7 @@ __device__ __forceinline__ void two_res_layers(const StageArgs& a, const int hop
 // T1 and T2: the two residual layers, then the polyphase transposed conv (k2 over input frames, rate UPR, COUT channels)
 // into the next stage's ring.  IN_FROM_RING_HISTORY: the first layer's two history frames come from the input ring itself
 // (T1: the ring of up2 keeps them); otherwise from the state block at TS_IN (T2).
-template <int C, int T, int S, int COUT, int UPR, int TS_IN, int TS_B, int TS_C, bool IN_FROM_RING_HISTORY>
+template <int C, int T, int S, int COUT, int UPR, int TS_IN, int TS_B, int TS_C, bool IN_FROM_RING_HISTORY, bool RAG = false>
 __device__ __forceinline__ void res_res_up_body(const StageArgs& a, const int g, float* __restrict__ lds) {
   constexpr int NUP = UPR * COUT;
   float* X = lds;
@@ -407,18 +435,20 @@ __device__ __forceinline__ void res_res_up_body(const StageArgs& a, const int g,
 #endif
   const int b0 = g * S;
   const int n_rows = (a.B - b0 < S ? a.B - b0 : S) * T;
+  int* shop = reinterpret_cast<int*>(lds + stage_lds<C, T, S, 1>() - 8);
   float4 bfa[Split<C>::CT][3 * C / 16], bfb[Split<C>::CT][3 * C / 16], bfu[Split<NUP>::CT][2 * C / 16];
   TST_STAMP(0);
   fetch_b<3 * C, C>(a.w[0], bfa, wave, lane);
-  prologue<C, T, S, TS_IN, TS_B, TS_C, 1, IN_FROM_RING_HISTORY>(a, hop, b0, X, Y, HIN, HC, tid);
+  stream_hops<S, RAG>(a, hop, b0, shop);
+  prologue<C, T, S, TS_IN, TS_B, TS_C, 1, IN_FROM_RING_HISTORY, RAG>(a, hop, b0, X, Y, HIN, HC, tid, shop);
   TST_STAMP(1);
   __syncthreads();
   TST_STAMP(2);
   constexpr int KBR = 3 * C / 16, KBU = 2 * C / 16;
   fetch_b<3 * C, C, 0, KBR / 2>(a.w[1], bfb, wave, lane);
-  two_res_layers<C, T, S, TS_B, TS_C, 1>(a, hop, b0, n_rows, X, Y, HC, bfa, bfb, wave, lane, tid,
+  two_res_layers<C, T, S, TS_B, TS_C, 1, RAG>(a, hop, b0, n_rows, X, Y, HC, bfa, bfb, wave, lane, tid,
                                          [&] { fetch_b<3 * C, C, KBR / 2, KBR>(a.w[1], bfb, wave, lane); },
-                                         [&] { fetch_b<2 * C, NUP, 0, KBU / 2>(a.w[2], bfu, wave, lane); }, C > 32 ? HC + S * C : nullptr);
+                                         [&] { fetch_b<2 * C, NUP, 0, KBU / 2>(a.w[2], bfu, wave, lane); }, shop, C > 32 ? HC + S * C : nullptr);
   fetch_b<2 * C, NUP, KBU / 2, KBU>(a.w[2], bfu, wave, lane);
   // ---- transposed conv (polyphase k2): X -> the next stage's ring, frame t UPR + n / COUT, channel n % COUT
   {
@@ -431,18 +461,18 @@ __device__ __forceinline__ void res_res_up_body(const StageArgs& a, const int g,
     layer<C, NUP, 2, 1, T, S, 0>(X, bfu, n_rows, wave, lane, none, [](int, int, int, int, float (&)[4]) {},
       [&](int s, int t0, int n, int ct, const tail_f32x4& acc, float (&)[4]) {
         const float bu = bias_u[ct];   // (ct is a compile-time index after unrolling)
-        float* o = ring_frame(a.out, b0 + s, pos_o, t0 * UPR + n / COUT) + n % COUT;   // (output frames of one input frame are UPR apart)
+        if constexpr (RAG) { if (shop[s] < 0) return; }
+        float* o = ring_frame(a.out, b0 + s, stream_pos<RAG>(a.out, pos_o, shop, s), t0 * UPR + n / COUT) + n % COUT;   // (output frames of one input frame are UPR apart)
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e * UPR * COUT] = acc[e] + bu;
       });
   }
   TST_STAMP(7);
-  if (!IN_FROM_RING_HISTORY) hin_to_state<C, S, TS_IN>(a, HIN, b0, tid);
+  if (!IN_FROM_RING_HISTORY) hin_to_state<C, S, TS_IN, RAG>(a, HIN, b0, tid, shop);
   TST_STAMP(8);
 }
 
 constexpr int kT1Streams = 4, kT2Streams = 3, kT3Streams = 2;
-template <int C, int T, int S, int HC_ROWS> constexpr int stage_lds() { return 2 * buf_floats<C, T, S>() + S * (2 + HC_ROWS) * C + (C > 32 ? S * T * C : 0); }
 constexpr int kT1Lds = stage_lds<64, 20, kT1Streams, 1>();
 constexpr int kT2Lds = stage_lds<32, 80, kT2Streams, 1>();
 constexpr int kT3Lds = stage_lds<16, 240, kT3Streams, 6>() + 7 * 16;
@@ -458,6 +488,9 @@ struct T1Op {
   __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) {
     res_res_up_body<64, 20, kT1Streams, 32, 4, 0, TS_YB2, TS_YC2, true>(a, bx, lds);
   }
+  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) {
+    res_res_up_body<64, 20, kT1Streams, 32, 4, 0, TS_YB2, TS_YC2, true, RAG>(a, bx, lds);
+  }
 };
 struct T2Op {
   using Args = StageArgs;
@@ -470,17 +503,21 @@ struct T2Op {
   __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) {
     res_res_up_body<32, 80, kT2Streams, 16, 3, TS_YA3, TS_YB3, TS_YC3, false>(a, bx, lds);
   }
+  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) {
+    res_res_up_body<32, 80, kT2Streams, 16, 3, TS_YA3, TS_YB3, TS_YC3, false, RAG>(a, bx, lds);
+  }
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
 // T3: res4a, res4b (16 channels, 240 frames per stream) and the output conv: lrelu, Conv1d(16 -> 1, k7), tanh.
+template <bool RAG = false>
 __device__ __forceinline__ void t3_body(const StageArgs& a, const int g, float* __restrict__ lds) {
   constexpr int C = 16, T = 240, S = kT3Streams;
   float* X = lds;
   float* Y = X + buf_floats<C, T, S>();
   float* HIN = Y + buf_floats<C, T, S>();   // [S][2][C] raw
   float* HC = HIN + S * 2 * C;              // [S][6][C] activated: history of the output conv's input
-  float* FW = HC + S * 6 * C;
+  float* FW = HC + S * 6 * C + 8;   // (behind the streams' step counters)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hop = stepc::step(a.hop);
   if (hop < 0) return;
@@ -491,19 +528,21 @@ __device__ __forceinline__ void t3_body(const StageArgs& a, const int g, float* 
   float* __restrict__ d_out = a.d_out + (size_t)io * a.io_stride;
   const int b0 = g * S;
   const int n_rows = (a.B - b0 < S ? a.B - b0 : S) * T;
+  int* shop = reinterpret_cast<int*>(lds + stage_lds<C, T, S, 6>() - 8);
+  stream_hops<S, RAG>(a, hop, b0, shop);
   float4 bfa[1][3], bfb[1][3];
   fetch_b<48, 16>(a.w[0], bfa, wave, lane);
   fetch_b<48, 16>(a.w[1], bfb, wave, lane);
   const float fin_b = a.fin_b[0];
   const float fw = tid < 7 * 16 ? a.fin_w[tid] : 0.0f;
-  prologue<C, T, S, TS_YA4, TS_YB4, TS_YC4, 6, false>(a, hop, b0, X, Y, HIN, HC, tid);
+  prologue<C, T, S, TS_YA4, TS_YB4, TS_YC4, 6, false, RAG>(a, hop, b0, X, Y, HIN, HC, tid, shop);
   if (tid < 7 * 16) FW[tid] = fw;
   __syncthreads();
-  two_res_layers<C, T, S, TS_YB4, TS_YC4, 6>(a, hop, b0, n_rows, X, Y, HC, bfa, bfb, wave, lane, tid, [] {}, [] {});
+  two_res_layers<C, T, S, TS_YB4, TS_YC4, 6, RAG>(a, hop, b0, n_rows, X, Y, HC, bfa, bfb, wave, lane, tid, [] {}, [] {}, shop);
   // ---- output conv over the ACTIVATED frames: one thread per sample, the multiply-adds of wave_tail.hip.h in the same order
   if (tid < S * T) {
     const int s = tid / T, t = tid % T;
-    if (b0 + s < a.B) {
+    if (live_s<RAG>(shop, b0, s, a.B)) {
       float acc = 0.0f;
       const float* x = X + row_off<C, T>(s, t - 6);
 #pragma unroll
@@ -513,7 +552,7 @@ __device__ __forceinline__ void t3_body(const StageArgs& a, const int g, float* 
       d_out[(size_t)(b0 + s) * B_OUT_HOP + t] = bsp::tanh2(bsp::splat2(acc + fin_b)).x;   // (the packed form is the shorter one even for a single value)
     }
   }
-  hin_to_state<C, S, TS_YA4>(a, HIN, b0, tid);
+  hin_to_state<C, S, TS_YA4, RAG>(a, HIN, b0, tid, shop);
 }
 struct T3Op {
   using Args = StageArgs;
@@ -524,6 +563,7 @@ struct T3Op {
     return bhip::LaunchInfo{"wave.tail3", 2.0 * a.B * macs, 4.0 * (2.0 * 48 * 16 + 112.0 + a.B * (240.0 * 16 + 240 + 2 * 14 * 16))};
   }
   __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { t3_body(a, bx, lds); }
+  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) { t3_body<RAG>(a, bx, lds); }
 };
 
 }  // namespace tst

@@ -156,6 +156,17 @@ struct State {
   int snap_cur = -1, snap_next = 0;
   std::vector<Consumer> consumers;
   Plan plan;
+  // Ragged steps (the shell's silent-block rule per stream, BeatriceBatch_SetSilentStreams in tick mode): a stream that sits a
+  // step out does not advance -- so every stream has its OWN step counter from then on, and a step carries the counters of its
+  // streams (-1: absent) through the stages, like its settings: [kRing][row] on the device, staged through pinned copies.
+  bool ragged = false;
+  int row = 0;                        // ints per step (B rounded up to a multiple of 4: the prologue copies 16-byte pieces)
+  std::vector<int> hop_s;             // [B] the streams' counters on the host
+  int* d_hopv = nullptr;              // [kRing][row]
+  int* h_hopv = nullptr;              // [kStaging][row] pinned
+  hipEvent_t hv_ev[kStaging] = {};
+  bool hv_pending[kStaging] = {};
+  bool step_ragged[kRing] = {};       // step u (at [u % kRing]) carries per-stream counters
 };
 
 }  // namespace tick

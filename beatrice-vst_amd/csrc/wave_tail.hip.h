@@ -367,4 +367,5 @@ struct TailOp {
   static constexpr int NTHR = tail::NTHR;
   static constexpr int LDS_FLOATS = kTailLdsFloats;
   __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { wave_tail_body<H>(a, bx, lds); }
+  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) { wave_tail_body<H>(a, bx, lds); }   // (not a stage of ragged ticks: the tail runs as three stages there)
 };

@@ -1,0 +1,82 @@
+"""the shell's silent-block rule PER STREAM in the throughput mode.  In tick mode every stage of one launch works on
+a different step, so a stream that sits a step out cannot be "put back" afterwards as the in-order chain does: instead the step
+carries the step counter of each of its streams (-1: absent) through all 28 stages, every body addresses its rings with the
+row's own counter and leaves absent rows alone (csrc/ring.h stepc::hopv, batch_tick.hip.h).  Reference per stream: one Stream1
+on the ORACLE driven through the reference's per-hop protocol, whose hop is simply not called for the steps the stream sits out
+(the shell does not call the core for a silent block, src/vst/processor.cc:204-214) -- state, pending key/value installs and
+k-NN settings wait."""
+import numpy as np
+import pytest
+
+from oracle_batch import OracleBatch
+from tick_driver import run_tick
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,steps", [(7, 70), (40, 45)])
+def test_streams_that_sit_steps_out_in_tick_mode_match_the_oracle(bv, oracle, product, model_dir, B, steps):
+    rng = np.random.default_rng(11 + B)
+    x = np.stack([bv.synth_audio(160 * steps, seed=7300 + s) for s in range(B)]).reshape(B, steps, 160)
+    # which steps each stream sits out: none for some, single steps, long runs, the very first steps, ...
+    out = {s: set() for s in range(B)}
+    for s in range(B):
+        kind = s % 5
+        if kind == 1:
+            out[s] = {5, 6, 7, 30}
+        elif kind == 2:
+            out[s] = {0, 1, 2} | set(range(20, 36))
+        elif kind == 3:
+            out[s] = set(int(k) for k in rng.choice(steps, size=steps // 4, replace=False))
+        elif kind == 4:
+            out[s] = {steps - 1, steps - 2, 11}
+    switch = {1: (5, 2), 2: (19, 0), 3: (9, 1), 4: (11, 2), 6: (33, 1)}   # stream -> (before step, speaker): some right before absent steps
+    sample = list(range(B)) if B <= 8 else sorted(set([0, 1, 2, 3, 4, 16, 17, 18, 31, 33, 39]))
+
+    # ---- reference: one oracle stream per sampled stream (tests/oracle_batch.py: the batch's defaults and setters on independent
+    # Stream1 objects); a step a stream sits out is a hop that is never made
+    ob = OracleBatch(bv, oracle, model_dir, B, sample=sample)
+    for s in range(B):
+        ob.a.BeatriceBatch_SetTargetSpeaker(None, s, s % 3)
+        ob.a.BeatriceBatch_SetVQNumNeighbors(None, s, s % 3)
+    ob.a.BeatriceBatch_FlushSpeaker(None, -1)
+    want = np.zeros((steps, B, 240), np.float32)
+    for k in range(steps):
+        for s in ob.sample:
+            if s in switch and switch[s][0] == k:
+                ob.a.BeatriceBatch_SetTargetSpeaker(None, s, switch[s][1])
+            if k not in out[s]:
+                want[k, s] = ob.st[s]["s1"].hop(x[s, k])
+    sample = ob.sample
+    ob.close()
+
+    # ---- product: tick mode, flags name the streams that sit the next step out
+    m = bv.Models(product, model_dir)
+    batch = bv.Batch(m, B)
+    a, h = batch.a, batch.h
+    for s in range(B):
+        a.BeatriceBatch_SetTargetSpeaker(h, s, s % 3)
+        a.BeatriceBatch_SetVQNumNeighbors(h, s, s % 3)
+    a.BeatriceBatch_FlushSpeaker(h, -1)
+    enabled = []
+
+    def change(batch_, k):
+        if not enabled:   # (tick mode is on by now: the rule is enabled inside it)
+            assert a.BeatriceBatch_EnableSilentBlockRule(h, 1) == 0
+            enabled.append(1)
+        for s in range(B):
+            if s in switch and switch[s][0] == k:
+                a.BeatriceBatch_SetTargetSpeaker(h, s, switch[s][1])
+        flags = bytes(1 if k in out[s] else 0 for s in range(B))
+        if any(flags):
+            assert a.BeatriceBatch_SetSilentStreams(h, flags) == 0
+
+    got = run_tick(bv, batch, steps, lambda k: x[:, k], change=change, chunk=13, leave=False)
+    batch.close()
+    m.close()
+    assert np.abs(want).max() > 0.05
+    for s in sample:
+        for k in range(steps):
+            if k in out[s]:
+                continue
+            assert np.array_equal(got[k, s], want[k, s]), "stream %d step %d: max-abs %g" % (s, k, np.abs(got[k, s] - want[k, s]).max())

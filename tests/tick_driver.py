@@ -24,7 +24,7 @@ class Hip:
         self.lib.hipFree(p)
 
 
-def run_tick(bv, batch, steps, hop_input, change=None, slots=None, chunk=None):
+def run_tick(bv, batch, steps, hop_input, change=None, slots=None, chunk=None, leave=True):
     """Feeds `steps` steps through tick mode and returns their samples [steps][B][240].
 
     hop_input(k) -> [B][160] is step k's input; change(batch, k) runs before step k is fed (settings travel with the step).
@@ -58,8 +58,11 @@ def run_tick(bv, batch, steps, hop_input, change=None, slots=None, chunk=None):
             for k in range(k0, k0 + n):
                 got[k] = out[k % slots]
             k0 += n
-        assert a.BeatriceBatch_EnableTickPipeline(h, 0) == 0
-        assert a.BeatriceBatch_BindResidentIO(h, None, None, 0) == 0
+        if leave:   # (a batch whose streams have sat steps out stays in tick mode: their step counters have diverged)
+            assert a.BeatriceBatch_EnableTickPipeline(h, 0) == 0
+            assert a.BeatriceBatch_BindResidentIO(h, None, None, 0) == 0
+        else:
+            assert a.BeatriceBatch_EnableTickPipeline(h, 0) == -1
     finally:
         hip.free(d_in)
         hip.free(d_out)
