@@ -222,6 +222,7 @@ struct BeatriceBatch {
     float* d_out48 = nullptr;        // [n_slots][B][channels][480]
     float *d_in16 = nullptr, *d_out24 = nullptr;  // [n_slots][B][160], [n_slots][B][240]: the resident I/O of the ticks
     int deferred_slot = -1;                       // step completed by the last tick, its 48 kHz block not yet produced
+    long long deferred_step = -1;                 // ... and which step that was (its per-stream counters name its silent streams)
   } r48;
   float *d_coef_down = nullptr, *d_coef_up = nullptr, *d_io48 = nullptr, *h_io48 = nullptr;  // io: in [B][2][480] | out [B][2][480]
   // The shell's silent-block rule per stream (BeatriceBatch_EnableSilentBlockRule; kernels_misc.hip.h freeze_*): streams

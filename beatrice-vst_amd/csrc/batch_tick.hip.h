@@ -265,15 +265,19 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
     BeatriceBatch::Resident48& r = b->r48;
     Wrap48TickArgs wa{};
     wa.channels = r.channels; wa.st = b->d_w48; wa.coef_down = b->d_coef_down; wa.coef_up = b->d_coef_up;
+    auto counters_of = [&k](long long u) -> const int* { return u >= 0 && k.step_ragged[u % kRing] ? k.d_hopv + (size_t)(u % kRing) * k.row : nullptr; };
     if (feeding) {
       wa.n_pre = b->B;
       wa.in48 = r.d_in48 + (size_t)b->io_host * b->B * r.channels * 480;
       wa.in16 = r.d_in16 + (size_t)b->io_host * b->B * B_IN_HOP;
+      wa.hv_pre = counters_of(k.n_fed);   // (the step being fed; its row was written by the prologue launch above)
     }
     if (r.deferred_slot >= 0) {
       wa.n_post = b->B;
       wa.out48 = r.d_out48 + (size_t)r.deferred_slot * b->B * r.channels * 480;
       wa.model_out = r.d_out24 + (size_t)r.deferred_slot * b->B * B_OUT_HOP;
+      wa.hv_post = counters_of(r.deferred_step);
+      wa.in48_post = r.d_in48 + (size_t)r.deferred_slot * b->B * r.channels * 480;
       r.deferred_slot = -1;
     }
     hipLaunchKernelGGL(wrap48_tick_kernel, dim3(wa.n_pre + wa.n_post), dim3(256), 0, st, wa);
@@ -290,7 +294,7 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
   fuse::launch_table_w<4>(k.d_table, k.table_total, st, pairs, k.ragged);   // (the second instance of the launch once a stream has sat a step out)
   if (b->r48.on) {  // the step this tick completed: its 48 kHz block is produced by the wrapper launch of the next tick (or of the drain)
     const long long u = step_at(k.plan.count() - 1);
-    if (u >= 0) b->r48.deferred_slot = k.io_of_step[u % kRing];
+    if (u >= 0) { b->r48.deferred_slot = k.io_of_step[u % kRing]; b->r48.deferred_step = u; }
   }
   if (feeding) {
     b->last_parity = b->hop_host % 3;
@@ -338,6 +342,8 @@ bool tick_drain(BeatriceBatch* b) {
     wa.n_post = b->B;
     wa.out48 = r.d_out48 + (size_t)r.deferred_slot * b->B * r.channels * 480;
     wa.model_out = r.d_out24 + (size_t)r.deferred_slot * b->B * B_OUT_HOP;
+    wa.hv_post = r.deferred_step >= 0 && b->tk.step_ragged[r.deferred_step % tick::kRing] ? b->tk.d_hopv + (size_t)(r.deferred_step % tick::kRing) * b->tk.row : nullptr;
+    wa.in48_post = r.d_in48 + (size_t)r.deferred_slot * b->B * r.channels * 480;
     r.deferred_slot = -1;
     hipLaunchKernelGGL(wrap48_tick_kernel, dim3(wa.n_post), dim3(256), 0, b->stream, wa);
     ok = hip_ok(hipGetLastError(), "wrap48 flush");

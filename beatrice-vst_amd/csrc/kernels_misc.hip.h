@@ -725,10 +725,30 @@ struct Wrap48TickArgs {
   const float *coef_down, *coef_up;
   const float* in48; float* in16;          // pre: slot of the step fed by this tick
   float* out48; const float* model_out;    // post: slot of the step completed by the previous tick
+  // ragged steps (the silent-block rule per stream): the step counters of the entering / the completed step's streams, -1 =
+  // the stream's block is silent (pre: its filter history stands still; post: its output block is its own zero down-mix,
+  // FIFO and latch untouched); null: every stream takes part
+  const int *hv_pre, *hv_post;
+  const float* in48_post;                  // the completed step's own input block (read for silent streams only)
 };
 static __global__ __launch_bounds__(256) void wrap48_tick_kernel(const Wrap48TickArgs a) {
   __shared__ float lds[512 + 33];
   const int w = blockIdx.x;
-  if (w < a.n_pre) wrap48_pre_body(w, a.in48, a.channels, a.st, a.coef_down, a.in16, lds);
-  else wrap48_post_body(w - a.n_pre, a.st, a.coef_up, a.out48, a.channels, a.model_out, lds);
+  if (w < a.n_pre) {
+    if (a.hv_pre != nullptr && a.hv_pre[w] < 0) return;   // (its 16 kHz hop is not read either: the model sits the step out)
+    wrap48_pre_body(w, a.in48, a.channels, a.st, a.coef_down, a.in16, lds);
+  } else {
+    const int b = w - a.n_pre;
+    if (a.hv_post != nullptr && a.hv_post[b] < 0) {
+      const float* src = a.in48_post + (size_t)b * a.channels * 480;
+      float* dst = a.out48 + (size_t)b * a.channels * 480;
+      for (int n = threadIdx.x; n < 480; n += 256) {
+        float m = src[n];
+        if (a.channels >= 2) { m = m + src[480 + n]; m = m * 0.5f; }
+        for (int c = 0; c < a.channels; ++c) dst[c * 480 + n] = m;
+      }
+      return;
+    }
+    wrap48_post_body(b, a.st, a.coef_up, a.out48, a.channels, a.model_out, lds);
+  }
 }

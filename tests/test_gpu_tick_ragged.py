@@ -80,3 +80,86 @@ def test_streams_that_sit_steps_out_in_tick_mode_match_the_oracle(bv, oracle, pr
             if k in out[s]:
                 continue
             assert np.array_equal(got[k, s], want[k, s]), "stream %d step %d: max-abs %g" % (s, k, np.abs(got[k, s] - want[k, s]).max())
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+def test_silent_48k_blocks_per_stream_around_the_tick_pipeline(bv, product, model_dir, channels):
+    """The same rule where the shell applies it: 48 kHz blocks, here resident on the device with the tick pipeline between the two
+    halves of the wrapper (BeatriceBatch_BindResidentIO48k).  Reference per stream: ProcessorProxy::ProcessChannels of the host
+    layer on the ORACLE core (the rule as the shell has it: the block is handed back, nothing moves)."""
+    import ctypes as C
+    import wrapperlib
+    from test_host_proxy import K_MODEL, K_VOICE, K_VQ, Proxy
+    from tick_driver import Hip
+    _f32p = C.POINTER(C.c_float)
+    B, blocks, n = 6, 44, 480
+    x = np.zeros((B, channels, blocks * n), np.float32)
+    for s in range(B):
+        for c in range(channels):
+            x[s, c] = (0.7 if c else 1.0) * wrapperlib.test_signal(blocks * n, 48000, seed=5200 + 5 * s + c)
+    silent = {0: {3, 4, 5, 11}, 1: {0, 1, 9, 20, 21}, 2: set(), 3: set(range(6, 19)), 4: {2, 13, 14, 43}, 5: {30}}
+    for s, ks in silent.items():
+        for k in ks:
+            x[s, :, k * n:(k + 1) * n] = 0.0
+    switch = {0: (3, 2), 1: (8, 0), 3: (5, 1), 4: (13, 2)}
+    want = np.zeros_like(x)
+    for s in range(B):
+        p = Proxy(48000.0)
+        assert p.call("SetString", K_MODEL, (model_dir + "/model.toml").encode()) == 0
+        p.call("SetInt", K_VOICE, s % 3)
+        p.call("SetNumber", K_VQ, float(s % 3))
+        for k in range(blocks):
+            if s in switch and switch[s][0] == k:
+                p.call("SetInt", K_VOICE, switch[s][1])
+            sl = slice(k * n, (k + 1) * n)
+            in0 = np.ascontiguousarray(x[s, 0, sl])
+            in1 = np.ascontiguousarray(x[s, 1, sl]) if channels == 2 else None
+            o0, o1 = np.zeros(n, np.float32), np.zeros(n, np.float32)
+            flag = p.call("ProcessChannels", in0.ctypes.data_as(_f32p), in1.ctypes.data_as(_f32p) if in1 is not None else None,
+                          o0.ctypes.data_as(_f32p), o1.ctypes.data_as(_f32p) if channels == 2 else None, n)
+            assert flag == (1 if k in silent[s] else 0)
+            want[s, 0, sl] = o0
+            if channels == 2:
+                want[s, 1, sl] = o1
+        p.close()
+
+    m = bv.Models(product, model_dir)
+    batch = bv.Batch(m, B)
+    a, h = batch.a, batch.h
+    for s in range(B):
+        a.BeatriceBatch_SetTargetSpeaker(h, s, s % 3)
+        a.BeatriceBatch_SetVQNumNeighbors(h, s, s % 3)
+    hip = Hip()
+    slots = a.BeatriceBatch_TickStages(h) + 3
+    d_in, d_out = hip.malloc(slots * B * channels * n * 4), hip.malloc(slots * B * channels * n * 4)
+    assert a.BeatriceBatch_BindResidentIO48k(h, d_in, d_out, channels, slots) == 0
+    assert a.BeatriceBatch_EnableSilentBlockRule(h, 1) == 0
+    got = np.zeros_like(x)
+    k0 = 0
+    while k0 < blocks:
+        cnt = min(11, blocks - k0)
+        buf = np.zeros((slots, B, channels, n), np.float32)
+        for k in range(k0, k0 + cnt):
+            buf[k % slots] = x[:, :, k * n:(k + 1) * n]
+        hip.h2d(d_in, buf)
+        for k in range(k0, k0 + cnt):
+            for s in range(B):
+                if s in switch and switch[s][0] == k:
+                    a.BeatriceBatch_SetTargetSpeaker(h, s, switch[s][1])
+            flags = bytes(1 if k in silent[s] else 0 for s in range(B))
+            if any(flags):
+                assert a.BeatriceBatch_SetSilentStreams(h, flags) == 0
+            assert a.BeatriceBatch_ConvertBlocks48kDevice(h, None, None, channels) == 0
+        assert a.BeatriceBatch_Synchronize(h) == 0
+        out = np.zeros((slots, B, channels, n), np.float32)
+        hip.d2h(out, d_out)
+        for k in range(k0, k0 + cnt):
+            got[:, :, k * n:(k + 1) * n] = out[k % slots]
+        k0 += cnt
+    batch.close()
+    m.close()
+    hip.free(d_in); hip.free(d_out)
+    assert np.abs(want).max() > 1e-3
+    for s in range(B):
+        d = np.abs(got[s] - want[s])
+        assert np.array_equal(got[s], want[s]), "stream %d: max-abs %g, first differing block %d" % (s, d.max(), int(np.argmax(d.max(axis=0) > 0)) // n)
