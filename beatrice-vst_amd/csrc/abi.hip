@@ -408,6 +408,13 @@ Beatrice20rc0_WaveformContext1* Beatrice20rc0_CreateWaveformContext1(void) {
           hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(float) * (in_floats + B_OUT_HOP), hipHostMallocDefault), "hipHostMalloc");
   c->st.hop = reinterpret_cast<int*>(c->d_inputs + B_PHONE_CH + 4 + 1);
   c->st.advance_hop = false;
+  // The hop's 240 samples: written by the last kernel straight into the pinned block the host reads (posted writes over PCIe,
+  // flushed when the kernel ends) instead of a device buffer + one more copy command per call.  BEATRICE_HIP_OUT_COPY=1: the copy.
+  if (c->ok && std::getenv("BEATRICE_HIP_OUT_COPY") == nullptr) {
+    c->dev_d_out = c->st.d_out;
+    c->st.d_out = c->h_io + in_floats;
+    c->out_mapped = true;
+  }
   return c;
 }
 void Beatrice20rc0_DestroyWaveformContext1(Beatrice20rc0_WaveformContext1* c) {
@@ -415,6 +422,7 @@ void Beatrice20rc0_DestroyWaveformContext1(Beatrice20rc0_WaveformContext1* c) {
   const DeviceScope dev_(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->hop_graph.drop();
+  if (c->out_mapped) { c->st.d_out = c->dev_d_out; c->out_mapped = false; }
   c->st.destroy();
   if (c->d_inputs) (void)hipFree(c->d_inputs);
   if (c->h_io) (void)hipHostFree(c->h_io);
@@ -439,7 +447,7 @@ void Beatrice20rc0_GenerateWaveform1(const Beatrice20rc0_WaveformGenerator* m, c
   bool ok = run_hop(ctx->hop_graph, m->blob.d, 0, ctx->stream, [&] {
     (void)hipMemcpyAsync(ctx->d_inputs, h_in, sizeof(float) * in_floats, hipMemcpyHostToDevice, ctx->stream);
     wave_forward(m->w, ctx->st, ctx->stream);
-    (void)hipMemcpyAsync(h_out, ctx->st.d_out, sizeof(float) * B_OUT_HOP, hipMemcpyDeviceToHost, ctx->stream);
+    if (!ctx->out_mapped) (void)hipMemcpyAsync(h_out, ctx->st.d_out, sizeof(float) * B_OUT_HOP, hipMemcpyDeviceToHost, ctx->stream);
   });
   ok = wait_stream(ctx->stream) && ok;
   if (ok) std::memcpy(output, h_out, sizeof(float) * B_OUT_HOP);

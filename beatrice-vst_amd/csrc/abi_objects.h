@@ -105,6 +105,8 @@ struct Beatrice20rc0_WaveformContext1 {
   hipStream_t stream = nullptr;
   float* d_inputs = nullptr;  // device: 128 phone | 4 feat | 1 bin | step counter
   float* h_io = nullptr;      // pinned: inputs | 240 out
+  float* dev_d_out = nullptr; // the module's own device output buffer while the tail writes the pinned block itself (out_mapped)
+  bool out_mapped = false;
   int hop_count = 0;
   bhip::HopGraph hop_graph;
   bool ok = false;
