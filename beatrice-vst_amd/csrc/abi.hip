@@ -408,9 +408,10 @@ Beatrice20rc0_WaveformContext1* Beatrice20rc0_CreateWaveformContext1(void) {
           hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(float) * (in_floats + B_OUT_HOP), hipHostMallocDefault), "hipHostMalloc");
   c->st.hop = reinterpret_cast<int*>(c->d_inputs + B_PHONE_CH + 4 + 1);
   c->st.advance_hop = false;
-  // The hop's 240 samples: written by the last kernel straight into the pinned block the host reads (posted writes over PCIe,
-  // flushed when the kernel ends) instead of a device buffer + one more copy command per call.  BEATRICE_HIP_OUT_COPY=1: the copy.
-  if (c->ok && std::getenv("BEATRICE_HIP_OUT_COPY") == nullptr) {
+  // Measurement switch BEATRICE_HIP_OUT_MAPPED=1: the hop's 240 samples written by the last kernel straight into the pinned block
+  // the host reads (posted writes over PCIe, flushed when the kernel ends) instead of a device buffer + one more copy command
+  // per call -- measured neutral (p50 281-285 us either way, round 4), so the copy stays the default
+  if (c->ok && std::getenv("BEATRICE_HIP_OUT_MAPPED") != nullptr) {
     c->dev_d_out = c->st.d_out;
     c->st.d_out = c->h_io + in_floats;
     c->out_mapped = true;
