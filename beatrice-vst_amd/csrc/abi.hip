@@ -299,6 +299,7 @@ void Beatrice20rc0_ExtractPhone1(const Beatrice20rc0_PhoneExtractor* m, const fl
   }
   bool ok = run_hop(ctx->hop_graph[variant], m->blob.d, variant, ctx->stream, enqueue);
   ok = wait_stream(ctx->stream) && ok;
+  ok = ok && !(ctx->st.d_team_dead && *ctx->st.d_team_dead);   // (a team launch that gave a wait up: zeros, as for any internal failure)
   if (ok) std::memcpy(output, h_out, sizeof(float) * B_PHONE_CH);
 }
 
@@ -377,6 +378,7 @@ void Beatrice20rc0_EstimatePitch1(const Beatrice20rc0_PitchEstimator* m, const f
     (void)hipMemcpyAsync(h_q, ctx->st.d_q_raw, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
   });
   ok = wait_stream(ctx->stream) && ok;
+  ok = ok && !(ctx->st.d_team_dead && *ctx->st.d_team_dead);
   if (ok) { *out_q = *h_q; std::memcpy(out_feat, h_feat, sizeof(float) * 4); }
 }
 
@@ -451,6 +453,7 @@ void Beatrice20rc0_GenerateWaveform1(const Beatrice20rc0_WaveformGenerator* m, c
     if (!ctx->out_mapped) (void)hipMemcpyAsync(h_out, ctx->st.d_out, sizeof(float) * B_OUT_HOP, hipMemcpyDeviceToHost, ctx->stream);
   });
   ok = wait_stream(ctx->stream) && ok;
+  ok = ok && !(ctx->st.d_team_dead && *ctx->st.d_team_dead);
   if (ok) std::memcpy(output, h_out, sizeof(float) * B_OUT_HOP);
 }
 

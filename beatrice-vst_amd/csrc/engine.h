@@ -108,7 +108,7 @@ struct PhoneState {
   // pipe_slack: one more step slot on every ring a later layer reads, so that each LAYER may run as its own pipeline
   // stage one step behind its producer (batch.hip, tick mode)
   unsigned long long* d_team_xb = nullptr;   // one stream, one hop per call: the eight convolutions as one team launch (team.hip.h)
-  int* d_team_dead = nullptr;
+  int* d_team_dead = nullptr;   // pinned host word: set by a team launch that gave a wait up (the call then returns zeros)
   bool create(int B, int H, float* shared_in, int out_slots = 1, bool pipe_slack = false, int out_ch = B_PHONE_CH);
   void destroy();
 };
@@ -149,7 +149,7 @@ struct PitchState {
   bool advance_hop = true;    // this module's forward ends with the counter increment
   int bins = B_PITCH_BINS;    // pitch classes (384: legacy generations)
   unsigned long long* d_team_xb = nullptr;   // (see PhoneState)
-  int* d_team_dead = nullptr;
+  int* d_team_dead = nullptr;   // pinned host word: set by a team launch that gave a wait up (the call then returns zeros)
   bool create(int B, int H, float* shared_in, bool with_params, bool pipe_slack = false, int bins = B_PITCH_BINS);
   void destroy();
 };
@@ -231,7 +231,7 @@ struct WaveState {
   // one stream, one hop per call (the 1-stream C-ABI): the layers from the input mix to the stage-2 transposed conv run as ONE
   // launch of a team of workgroups (team.hip.h); these are its exchange buffers (granules) and its "a wait was given up" flag
   unsigned long long* d_team_xb = nullptr;
-  int* d_team_dead = nullptr;
+  int* d_team_dead = nullptr;   // pinned host word: set by a team launch that gave a wait up (the call then returns zeros)
   bool create(int B, int H, int n_slots, int n_add, int n_frm, float* shared_phone, int* shared_q, float* shared_feat,
               int front_slots = 1, bool pipe_slack = false, bool legacy = false);
   void destroy();

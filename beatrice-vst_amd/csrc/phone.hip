@@ -43,8 +43,9 @@ bool PhoneState::create(int B_, int H_, float* shared_in, int out_slots_, bool p
   if (B == 1 && H == 1) {   // the 1-stream ABI's team launch (team.hip.h); tag 0 = "never written"
     BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_team_xb), sizeof(unsigned long long) * team::kPhoneGranules));
     BHIP_TRY(hipMemset(d_team_xb, 0, sizeof(unsigned long long) * team::kPhoneGranules));
-    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_team_dead), sizeof(int)));
-    BHIP_TRY(hipMemset(d_team_dead, 0, sizeof(int)));
+    // (pinned host memory, written by the kernel only when a wait was given up: the host reads it after every call for free)
+    BHIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d_team_dead), sizeof(int), hipHostMallocDefault));
+    *d_team_dead = 0;
     BHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(team::phone_team_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, team::kLdsFloats * 4));
   }
   // hipMemset is asynchronous and runs on the NULL stream, which the (non-blocking) compute streams
@@ -61,7 +62,7 @@ void PhoneState::destroy() {
   if (d_vqk) (void)hipFree(d_vqk);
   if (d_hop) (void)hipFree(d_hop);
   if (d_team_xb) (void)hipFree(d_team_xb);
-  if (d_team_dead) (void)hipFree(d_team_dead);
+  if (d_team_dead) (void)hipHostFree(d_team_dead);
   d_team_xb = nullptr; d_team_dead = nullptr;
   d_in = d_phone = nullptr; d_cbT = d_cnorm = nullptr; d_vqk = d_hop = nullptr;
 }

@@ -52,8 +52,9 @@ bool PitchState::create(int B_, int H_, float* shared_in, bool with_params, bool
   if (B == 1 && H == 1) {   // the 1-stream ABI's team launch (team.hip.h); tag 0 = "never written"
     BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_team_xb), sizeof(unsigned long long) * team::kPitchGranules));
     BHIP_TRY(hipMemset(d_team_xb, 0, sizeof(unsigned long long) * team::kPitchGranules));
-    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_team_dead), sizeof(int)));
-    BHIP_TRY(hipMemset(d_team_dead, 0, sizeof(int)));
+    // (pinned host memory, written by the kernel only when a wait was given up: the host reads it after every call for free)
+    BHIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d_team_dead), sizeof(int), hipHostMallocDefault));
+    *d_team_dead = 0;
     BHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(team::pitch_team_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, team::kLdsFloats * 4));
   }
   BHIP_TRY(hipDeviceSynchronize());  // NULL-stream memsets vs non-blocking compute streams
@@ -62,8 +63,9 @@ bool PitchState::create(int B_, int H_, float* shared_in, bool with_params, bool
 void PitchState::destroy() {
   arena.release();
   if (owns_in && d_in) (void)hipFree(d_in);
-  void* ptrs[] = {d_min_q, d_max_q, d_prev_q, d_q_raw, d_q, d_feat, d_params, d_hop, d_team_xb, d_team_dead};
+  void* ptrs[] = {d_min_q, d_max_q, d_prev_q, d_q_raw, d_q, d_feat, d_params, d_hop, d_team_xb};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (d_team_dead) (void)hipHostFree(d_team_dead);
   d_team_xb = nullptr; d_team_dead = nullptr;
   d_in = d_feat = nullptr; d_min_q = d_max_q = d_prev_q = d_q_raw = d_q = d_hop = nullptr; d_params = nullptr;
 }

@@ -92,8 +92,9 @@ bool WaveState::create(int B_, int H_, int n_slots_, int n_add_, int n_frm_, flo
   if (B == 1 && H == 1 && !legacy) {   // the 1-stream ABI's team launch (team.hip.h); tag 0 = "never written"
     BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_team_xb), sizeof(unsigned long long) * team::kWaveGranules));
     BHIP_TRY(hipMemset(d_team_xb, 0, sizeof(unsigned long long) * team::kWaveGranules));
-    BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_team_dead), sizeof(int)));
-    BHIP_TRY(hipMemset(d_team_dead, 0, sizeof(int)));
+    // (pinned host memory, written by the kernel only when a wait was given up: the host reads it after every call for free)
+    BHIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d_team_dead), sizeof(int), hipHostMallocDefault));
+    *d_team_dead = 0;
     BHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(team::wave_team_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, team::kLdsFloats * 4));
     if (std::getenv("BEATRICE_HIP_TEAM_TRACE")) {   // measurement aid: per-stage stamps of workgroup 0 (BeatriceHip_TeamTraceDump)
       BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_team_trace), sizeof(unsigned long long) * 1024));
@@ -109,7 +110,7 @@ void WaveState::destroy() {
   arena.release();
   if (owns_inputs) { if (d_phone) (void)hipFree(d_phone); if (d_q) (void)hipFree(d_q); if (d_feat) (void)hipFree(d_feat); }
   if (d_team_xb) (void)hipFree(d_team_xb);
-  if (d_team_dead) (void)hipFree(d_team_dead);
+  if (d_team_dead) (void)hipHostFree(d_team_dead);
   d_team_xb = nullptr; d_team_dead = nullptr;
   void* ptrs[] = {d_out, d_add_tab, d_frm_tab, d_add_idx, d_frm_idx, d_hop};
   for (void* p : ptrs) if (p) (void)hipFree(p);

@@ -16,6 +16,9 @@ d_in = torch.randn((n, B, 160), device="cuda") * 0.1
 d_out = torch.zeros((n, B, 240), device="cuda")
 assert product.BeatriceBatch_BindResidentIO(batch.h, d_in.data_ptr(), d_out.data_ptr(), n) == 0
 assert product.BeatriceBatch_EnableTickPipeline(batch.h, 1) == 0
+if len(sys.argv) > 2 and sys.argv[2] == "ragged":   # the second instance of the launch: one step with a tenth of the streams sitting it out
+    assert product.BeatriceBatch_EnableSilentBlockRule(batch.h, 1) == 0
+    assert product.BeatriceBatch_SetSilentStreams(batch.h, bytes(1 if s % 10 == 3 else 0 for s in range(B))) == 0
 for _ in range(60):
     product.BeatriceBatch_ConvertFramesDevice(batch.h, None, None)
 us, fl, by = ctypes.c_float(0), ctypes.c_double(0), ctypes.c_double(0)
