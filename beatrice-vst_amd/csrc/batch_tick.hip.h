@@ -3,7 +3,7 @@
 #pragma once
 
 // ---- tick pipelining (tick.hip.h) ---------------------------------------------------------------------------------
-bool tick_build_table(BeatriceBatch* b) {
+bool tick_build_table(BeatriceBatch* b, const bool sparse = false) {
   using namespace tick;
   State& k = b->tk;
   auto tb = std::make_unique<Builder>();
@@ -29,12 +29,22 @@ bool tick_build_table(BeatriceBatch* b) {
   auto conv = [&](const Ring& in, const Ring& out, const float* w, const float* bias, int stage) { return conv_args(in, out, w, bias, hp(stage), B); };
   // (workgroups are dispatched in this order: the longest-running bodies first)
   // ---- longest workgroups first (measured, two per CU): f5 48 us, p1 46, f4 45, rb 42, block halves 41 / 38, tail 36
-  { const ConvArgs a = conv(ps.f[3], ps.f[4], pw.f_w[3], pw.f_b[3], Plan::F5); tb->add<T_F5>(OpF5::info("phone.f5", a), a, OpF5::grid(a), Plan::F5, keep(6), 47); }
-  { const ConvArgs a = conv(qs.spec, qs.p[0], qw.p_w[0], qw.p_b[0], Plan::P1); tb->add<T_P1>(OpP1::info("pitch.p1", a), a, OpP1::grid(a), Plan::P1, keep(2), 34.5); }
-  { const ConvArgs a = conv(ps.f[2], ps.f[3], pw.f_w[2], pw.f_b[2], Plan::F4); tb->add<T_F4>(OpF4::info("phone.f4", a), a, OpF4::grid(a), Plan::F4, keep(6), 37.5); }
-  for (int i = 0; i < 4; ++i) {
-    const ConvArgs a = conv(i == 0 ? ps.f[4] : ps.rb[i - 1], ps.rb[i], pw.rb_w[i], pw.rb_b[i], Plan::RB0 + i);
-    tb->add<T_RB>(OpRB::info("phone.rb", a), a, OpRB::grid(a), Plan::RB0 + i, keep(6), 46);
+  if (!sparse) {
+    { const ConvArgs a = conv(ps.f[3], ps.f[4], pw.f_w[3], pw.f_b[3], Plan::F5); tb->add<T_F5>(OpF5::info("phone.f5", a), a, OpF5::grid(a), Plan::F5, keep(6), 47); }
+    { const ConvArgs a = conv(qs.spec, qs.p[0], qw.p_w[0], qw.p_b[0], Plan::P1); tb->add<T_P1>(OpP1::info("pitch.p1", a), a, OpP1::grid(a), Plan::P1, keep(2), 34.5); }
+    { const ConvArgs a = conv(ps.f[2], ps.f[3], pw.f_w[2], pw.f_b[2], Plan::F4); tb->add<T_F4>(OpF4::info("phone.f4", a), a, OpF4::grid(a), Plan::F4, keep(6), 37.5); }
+    for (int i = 0; i < 4; ++i) {
+      const ConvArgs a = conv(i == 0 ? ps.f[4] : ps.rb[i - 1], ps.rb[i], pw.rb_w[i], pw.rb_b[i], Plan::RB0 + i);
+      tb->add<T_RB>(OpRB::info("phone.rb", a), a, OpRB::grid(a), Plan::RB0 + i, keep(6), 46);
+    }
+  } else {   // (the sparse table: one row tile per workgroup, tick.hip.h)
+    { const ConvArgs a = conv(ps.f[3], ps.f[4], pw.f_w[3], pw.f_b[3], Plan::F5); tb->add<T_F5S>(OpF5s::info("phone.f5", a), a, OpF5s::grid(a), Plan::F5, keep(6), 47); }
+    { const ConvArgs a = conv(qs.spec, qs.p[0], qw.p_w[0], qw.p_b[0], Plan::P1); tb->add<T_P1S>(OpP1s::info("pitch.p1", a), a, OpP1s::grid(a), Plan::P1, keep(2), 34.5); }
+    { const ConvArgs a = conv(ps.f[2], ps.f[3], pw.f_w[2], pw.f_b[2], Plan::F4); tb->add<T_F4S>(OpF4s::info("phone.f4", a), a, OpF4s::grid(a), Plan::F4, keep(6), 37.5); }
+    for (int i = 0; i < 4; ++i) {
+      const ConvArgs a = conv(i == 0 ? ps.f[4] : ps.rb[i - 1], ps.rb[i], pw.rb_w[i], pw.rb_b[i], Plan::RB0 + i);
+      tb->add<T_RBS>(OpRBs::info("phone.rb", a), a, OpRBs::grid(a), Plan::RB0 + i, keep(6), 46);
+    }
   }
   // conditioned blocks: two row-local chains each
   for (int blk = 0; blk < B_NBLOCKS; ++blk) {
@@ -71,13 +81,19 @@ bool tick_build_table(BeatriceBatch* b) {
     t2.w[0] = ww.ra_w[2]; t2.b[0] = ww.ra_b[2]; t2.w[1] = ww.rb_w[2]; t2.b[1] = ww.rb_b[2]; t2.w[2] = ww.up_w[3]; t2.b[2] = ww.up_b[3];
     t3.w[0] = ww.ra_w[3]; t3.b[0] = ww.ra_b[3]; t3.w[1] = ww.rb_w[3]; t3.b[1] = ww.rb_b[3];
     t3.fin_w = ww.fin_w; t3.fin_b = ww.fin_b; t3.d_out = ws.d_out; t3.io_stride = ws.io_stride;
-    tb->add<T_TAIL1>(tst::T1Op::info(t1), t1, tst::T1Op::grid(t1), pl.tail(), keep(4), 30, true);
-    tb->add<T_TAIL2>(tst::T2Op::info(t2), t2, tst::T2Op::grid(t2), pl.tail() + 1, keep(4), 28, true);
+    if (!sparse) {
+      tb->add<T_TAIL1>(tst::T1Op::info(t1), t1, tst::T1Op::grid(t1), pl.tail(), keep(4), 30, true);
+      tb->add<T_TAIL2>(tst::T2Op::info(t2), t2, tst::T2Op::grid(t2), pl.tail() + 1, keep(4), 28, true);
+    } else {   // (never occupied while the sparse table is in use; kept so that the two tables hold the same stages)
+      tb->add<T_TAIL1S>(T1s::info(t1), t1, T1s::grid(t1), pl.tail(), keep(4), 30, true);
+      tb->add<T_TAIL2S>(T2s::info(t2), t2, T2s::grid(t2), pl.tail() + 1, keep(4), 28, true);
+    }
     tb->add<T_TAIL3>(tst::T3Op::info(t3), t3, tst::T3Op::grid(t3), pl.tail() + 2, keep(4), 16, true);
   }
   // ---- everything else, longest workgroups first (they start when the heavy ones above leave their slots)
   { const ConvArgs a = conv(ps.f[1], ps.f[2], pw.f_w[1], pw.f_b[1], Plan::F3); tb->add<T_F3>(OpF3::info("phone.f3", a), a, OpF3::grid(a), Plan::F3, keep(6), 18); }
-  { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], pl.up1()); tb->add<T_UP1>(OpUP1::info("wave.up1", a), a, OpUP1::grid(a), pl.up1(), keep(7), 36); }
+  if (!sparse) { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], pl.up1()); tb->add<T_UP1>(OpUP1::info("wave.up1", a), a, OpUP1::grid(a), pl.up1(), keep(7), 36); }
+  else { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], pl.up1()); tb->add<T_UP1S>(OpUP1s::info("wave.up1", a), a, OpUP1s::grid(a), pl.up1(), keep(7), 36); }
   { const ConvArgs a = conv(ws.yb1, ws.yc1, ww.rb_w[0], ww.rb_b[0], pl.up1() + 2); tb->add<T_RES1B>(OpRES1B::info("wave.res1b", a), a, OpRES1B::grid(a), pl.up1() + 2, keep(7), 10); }
   { const ConvArgs a = conv(ws.ya1, ws.yb1, ww.ra_w[0], ww.ra_b[0], pl.up1() + 1); tb->add<T_RES1A>(OpRES1A::info("wave.res1a", a), a, OpRES1A::grid(a), pl.up1() + 1, keep(7), 10); }
   { const ConvArgs a = conv(ws.yc1, ws.ya2, ww.up_w[1], ww.up_b[1], pl.up1() + 3); tb->add<T_UP2>(OpUP2::info("wave.up2", a), a, OpUP2::grid(a), pl.up1() + 3, keep(7), 12); }
@@ -107,6 +123,12 @@ bool tick_build_table(BeatriceBatch* b) {
     if (k.d_trace) (void)hipFree(k.d_trace);
     BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&k.d_trace), sizeof(unsigned long long) * 3 * tb->t.total));
     tb->t.trace = k.d_trace;
+  }
+  if (sparse) {
+    tb->t.trace = nullptr;
+    BHIP_TRY(hipMemcpy(k.d_table_sparse, &tb->t, sizeof(Tab), hipMemcpyHostToDevice));
+    k.table_sparse_total = tb->t.total;
+    return true;
   }
   BHIP_TRY(hipMemcpy(k.d_table, &tb->t, sizeof(Tab), hipMemcpyHostToDevice));
   k.table_total = tb->t.total;
@@ -152,7 +174,7 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
     if (b->vq_dirty) { update_vq_mode(b); b->vq_dirty = false; }   // (drains the pipeline if the k-NN stage comes or goes)
   }
   prof.lap(0);
-  if (k.table_dirty && !tick_build_table(b)) return false;
+  if (k.table_dirty && !(tick_build_table(b, true) && tick_build_table(b, false))) return false;   // (the full table last: it clears table_dirty)
   prof.lap(1);
   hipStream_t st = b->stream;
   Copy upload{nullptr, nullptr, 0};
@@ -291,7 +313,14 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
     const long long u = s < p.n_stages ? step_at(s) : -1;
     pairs.hv[s] = u >= 0 && k.step_ragged[u % kRing] ? (int)(u % kRing) : -1;
   }
-  fuse::launch_table_w<4>(k.d_table, k.table_total, st, pairs, k.ragged);   // (the second instance of the launch once a stream has sat a step out)
+  // The sparse table (tick.hip.h) while only front-end stages have a step -- the first ticks of a fill: measured per tick on a
+  // 20-step run (tools/debug/fill_drain.sh) 31 us against 42-45; from the first conditioned block on, and in the drain, the
+  // half-size bodies LOSE (51-54 us against 45-48; two streams per tail workgroup 39 against 37), so there the full table runs
+  int highest = -1;
+  for (int s = 0; s < p.n_stages; ++s) if (p.hop[s] >= 0) highest = s;
+  static const bool no_sparse = std::getenv("BEATRICE_HIP_TICK_NO_SPARSE") != nullptr;   // A/B switch for measurements
+  const bool sparse = highest >= 0 && highest < Plan::BLK0 && !no_sparse;
+  fuse::launch_table_w<4>(sparse ? k.d_table_sparse : k.d_table, sparse ? k.table_sparse_total : k.table_total, st, pairs, k.ragged);   // (ragged: the second instance of the launch, once a stream has sat a step out)
   if (b->r48.on) {  // the step this tick completed: its 48 kHz block is produced by the wrapper launch of the next tick (or of the drain)
     const long long u = step_at(k.plan.count() - 1);
     if (u >= 0) { b->r48.deferred_slot = k.io_of_step[u % kRing]; b->r48.deferred_step = u; }
@@ -367,6 +396,7 @@ int tick_enable(BeatriceBatch* b, bool on) {
     k.snap_bytes = b->off.front_bytes + b->off.wave_bytes;
     if (!k.d_table) {
       if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_table), sizeof(Tab)), "tick table") ||
+          !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_table_sparse), sizeof(Tab)), "tick sparse table") ||
           !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_snap), k.snap_bytes * kRing), "tick snapshots") ||
           !hip_ok(hipHostMalloc(reinterpret_cast<void**>(&k.h_stage), k.snap_bytes * State::kStaging, hipHostMallocDefault), "tick staging"))
         return -2;

@@ -473,40 +473,45 @@ __device__ __forceinline__ void res_res_up_body(const StageArgs& a, const int g,
 }
 
 constexpr int kT1Streams = 4, kT2Streams = 3, kT3Streams = 2;
-constexpr int kT1Lds = stage_lds<64, 20, kT1Streams, 1>();
-constexpr int kT2Lds = stage_lds<32, 80, kT2Streams, 1>();
-constexpr int kT3Lds = stage_lds<16, 240, kT3Streams, 6>() + 7 * 16;
-
-struct T1Op {
+// S = streams per workgroup.  The tick launch's table for FULL ticks uses 4 (T1) and 3 (T2): fewer, fuller workgroups; its table
+// for the sparse ticks of fill and drain uses 2: half as long, and a sparse launch lasts as long as its longest workgroup
+// (profiles/r04_notes.md section 4).  Same arithmetic, same state block, same rings: interchangeable from one tick to the next.
+template <int S = kT1Streams>
+struct T1OpS {
   using Args = StageArgs;
-  static constexpr int NTHR = tst::NTHR, LDS_FLOATS = kT1Lds;
-  static inline dim3 grid(const Args& a) { return dim3((a.B + kT1Streams - 1) / kT1Streams, 1); }
+  static constexpr int NTHR = tst::NTHR, LDS_FLOATS = stage_lds<64, 20, S, 1>();
+  static inline dim3 grid(const Args& a) { return dim3((a.B + S - 1) / S, 1); }
   static inline bhip::LaunchInfo info(const Args& a) {
     const double macs = 2.0 * 20 * 192 * 64 + 20.0 * 128 * 128;
     return bhip::LaunchInfo{"wave.tail1", 2.0 * a.B * macs, 4.0 * (2.0 * 192 * 64 + 128.0 * 128 + a.B * (22.0 * 64 + 80 * 32 + 2 * 7 * 64))};
   }
   __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) {
-    res_res_up_body<64, 20, kT1Streams, 32, 4, 0, TS_YB2, TS_YC2, true>(a, bx, lds);
+    res_res_up_body<64, 20, S, 32, 4, 0, TS_YB2, TS_YC2, true>(a, bx, lds);
   }
   template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) {
-    res_res_up_body<64, 20, kT1Streams, 32, 4, 0, TS_YB2, TS_YC2, true, RAG>(a, bx, lds);
+    res_res_up_body<64, 20, S, 32, 4, 0, TS_YB2, TS_YC2, true, RAG>(a, bx, lds);
   }
 };
-struct T2Op {
+using T1Op = T1OpS<kT1Streams>;
+template <int S = kT2Streams>
+struct T2OpS {
   using Args = StageArgs;
-  static constexpr int NTHR = tst::NTHR, LDS_FLOATS = kT2Lds;
-  static inline dim3 grid(const Args& a) { return dim3((a.B + kT2Streams - 1) / kT2Streams, 1); }
+  static constexpr int NTHR = tst::NTHR, LDS_FLOATS = stage_lds<32, 80, S, 1>();
+  static inline dim3 grid(const Args& a) { return dim3((a.B + S - 1) / S, 1); }
   static inline bhip::LaunchInfo info(const Args& a) {
     const double macs = 2.0 * 80 * 96 * 32 + 80.0 * 64 * 48;
     return bhip::LaunchInfo{"wave.tail2", 2.0 * a.B * macs, 4.0 * (2.0 * 96 * 32 + 64.0 * 48 + a.B * (80.0 * 32 + 240 * 16 + 2 * 9 * 32))};
   }
   __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) {
-    res_res_up_body<32, 80, kT2Streams, 16, 3, TS_YA3, TS_YB3, TS_YC3, false>(a, bx, lds);
+    res_res_up_body<32, 80, S, 16, 3, TS_YA3, TS_YB3, TS_YC3, false>(a, bx, lds);
   }
   template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) {
-    res_res_up_body<32, 80, kT2Streams, 16, 3, TS_YA3, TS_YB3, TS_YC3, false, RAG>(a, bx, lds);
+    res_res_up_body<32, 80, S, 16, 3, TS_YA3, TS_YB3, TS_YC3, false, RAG>(a, bx, lds);
   }
 };
+using T2Op = T2OpS<kT2Streams>;
+constexpr int kT1Lds = T1Op::LDS_FLOATS, kT2Lds = T2Op::LDS_FLOATS;
+constexpr int kT3Lds = stage_lds<16, 240, kT3Streams, 6>() + 7 * 16;
 
 // ---------------------------------------------------------------------------------------------------------------------
 // T3: res4a, res4b (16 channels, 240 frames per stream) and the output conv: lrelu, Conv1d(16 -> 1, k7), tanh.

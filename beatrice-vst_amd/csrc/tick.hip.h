@@ -100,10 +100,23 @@ using OpUP1 = rc::ConvRowsOp<UP<256, 128, 5, 1>, 128, TICK_MID_RT>;   // 640 col
 using OpRES1A = rc::ConvRowsOp<RES<128, 1, 5>, 0, TICK_MID_RT>;
 using OpRES1B = rc::ConvRowsOp<RES<128, 3, 5>, 0, TICK_MID_RT>;
 using OpUP2 = rc::ConvRowsOp<UP<128, 64, 4, 5>, 0, TICK_MID_RT>;
+// The SPARSE table (the first ticks of a fill, while only front-end stages have a step): the bodies whose workgroups last longest
+// in half-size pieces -- one row tile per convolution workgroup (and two streams per tail workgroup, unused: see tick_run).  A
+// partly filled launch lasts as long as its longest workgroup and has idle slots to spare, so shorter workgroups in larger
+// numbers are what it wants (in a full tick they cost ~3 %: twice the weight traffic per row, more prologues).  Same arithmetic,
+// same rings: a tick may use either table.
+using OpF4s = rc::ConvRowsOp<PL::F4, TICK_RB_COLS, 1>;
+using OpF5s = rc::ConvRowsOp<PL::F5, TICK_RB_COLS, 1>;
+using OpRBs = rc::ConvRowsOp<PL::RBL, TICK_RB_COLS, 1>;
+using OpP1s = rc::ConvRowsOp<QL1::P1, 0, 1>;
+using OpUP1s = rc::ConvRowsOp<UP<256, 128, 5, 1>, 128, 1>;
+using T1s = tst::T1OpS<2>;
+using T2s = tst::T2OpS<2>;
 
 enum BodyType {
   T_F1, T_FFT, T_F2, T_F3, T_F4, T_F5, T_P1, T_RB, T_P23, T_POUT, T_HEAD, T_OUT, T_COND, T_INP, T_UP1, T_RES1A, T_RES1B, T_UP2,
-  T_QGRU, T_PGRU, T_VQ, T_TAIL, T_TAIL1, T_TAIL2, T_TAIL3, T_BLKA1, T_BLKA2, T_BLKA4, T_BLKA8, T_BLKB, T_BLKBQ, T_COUNT
+  T_QGRU, T_PGRU, T_VQ, T_TAIL, T_TAIL1, T_TAIL2, T_TAIL3, T_BLKA1, T_BLKA2, T_BLKA4, T_BLKA8, T_BLKB, T_BLKBQ,
+  T_F4S, T_F5S, T_RBS, T_P1S, T_UP1S, T_TAIL1S, T_TAIL2S, T_COUNT
 };
 #define TICK_TYPES                                                                                                            \
     fuse::Many<F1Op2, 1>, fuse::Many<FftOp2, 1>, fuse::Many<OpF2, 1>, fuse::Many<OpF3, 1>, fuse::Many<OpF4, 1>, fuse::Many<OpF5, 1>, \
@@ -111,7 +124,8 @@ enum BodyType {
     fuse::Many<OpOUT, 1>, fuse::Many<CondOp2, 1>, fuse::Many<OpINP, 1>, fuse::Many<OpUP1, 1>, fuse::Many<OpRES1A, 1>,               \
     fuse::Many<OpRES1B, 1>, fuse::Many<OpUP2, 1>, fuse::Many<GruOp<128, 128, TICK_GRU_RT>, 1>, fuse::Many<GruOp<256, 256, TICK_GRU_RT>, 1>,                  \
     fuse::Many<VqOp, 1>, fuse::Many<TailOp<1>, 1>, fuse::Many<tst::T1Op, 1>, fuse::Many<tst::T2Op, 1>, fuse::Many<tst::T3Op, 1>, fuse::Many<rc::BlockAOp<1>, 1>, fuse::Many<rc::BlockAOp<2>, 1>,                 \
-    fuse::Many<rc::BlockAOp<4>, 1>, fuse::Many<rc::BlockAOp<8>, 1>, fuse::Many<rc::BlockBOp, 4>, fuse::Many<rc::BlockBqOp, 4>
+    fuse::Many<rc::BlockAOp<4>, 1>, fuse::Many<rc::BlockAOp<8>, 1>, fuse::Many<rc::BlockBOp, 4>, fuse::Many<rc::BlockBqOp, 4>,                     \
+    fuse::Many<OpF4s, 1>, fuse::Many<OpF5s, 1>, fuse::Many<OpRBs, 4>, fuse::Many<OpP1s, 1>, fuse::Many<OpUP1s, 1>, fuse::Many<T1s, 1>, fuse::Many<T2s, 1>
 using Tab = fuse::Table<TICK_TYPES>;
 using Builder = fuse::TableBuilder<TICK_TYPES>;
 
@@ -141,6 +155,8 @@ struct State {
   bool on = false;
   Tab* d_table = nullptr;
   int table_total = 0;
+  Tab* d_table_sparse = nullptr;     // the same stages with the long bodies in half-size pieces (fill and drain ticks)
+  int table_sparse_total = 0;
   double table_flops = 0, table_bytes = 0;  // algorithmic work of one full tick (sum over the bodies)
   unsigned long long* d_trace = nullptr;  // BEATRICE_HIP_TICK_TRACE=<file>: per-workgroup timeline of the last full tick
   bool table_dirty = true;
