@@ -289,6 +289,11 @@ bool sync_all(BeatriceBatch* b) {
   for (int s = 1; s < BeatriceBatch::kMaxStages; ++s)
     if (b->stage_stream_own[s]) ok = hip_ok(hipStreamSynchronize(b->stage_stream_own[s]), "sync stage") && ok;
   b->inflight = false;
+  if (b->tk.h_link_dead && *b->tk.h_link_dead) {   // a GRU cell of a tick gave up waiting for the cell of the hop before (tick.hip.h): results are void
+    std::fprintf(stderr, "beatrice_hip: tick launch: a linked GRU cell timed out\n");
+    b->ok = false;
+    ok = false;
+  }
   return ok;
 }
 // Experiment switch: BEATRICE_HIP_CUMASK="lo-hi;lo-hi;..." gives the stream of stage 0, 1, ... a CU mask (CU index
@@ -746,7 +751,7 @@ BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* pho
   ok = ok && hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_in), sizeof(float) * B * H * B_IN_HOP), "d_in") &&
        hip_ok(hipMemset(b->d_in, 0, sizeof(float) * B * H * B_IN_HOP), "d_in0");
   // the front end's outputs (phone vector, conditioning mix) have three step slots: see `pipelined`
-  const bool slack = H == 1;  // rings sized so that every layer can be its own pipeline stage (tick.hip.h)
+  const bool slack = H <= tick::kMaxHops;  // rings sized so that every layer can be its own pipeline stage (tick.hip.h)
   ok = ok && b->phone.create(B, H, b->d_in, 3, slack) && b->pitch.create(B, H, b->d_in, true, slack) &&
        b->wave.create(B, H, S, S, 9, b->phone.d_phone, b->pitch.d_q, b->pitch.d_feat, 3, slack);
   b->wave.q_slots = b->pitch.q_slots;
@@ -864,7 +869,8 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   for (hipEvent_t e : b->rw.ev) if (e) (void)hipEventDestroy(e);
   if (b->h_wrap_io) (void)hipHostFree(b->h_wrap_io);
   b->wrap_gains.release();
-  { void* tk[] = {b->tk.d_table, b->tk.d_table_sparse, b->tk.d_snap, b->tk.d_trace}; for (void* p : tk) if (p) (void)hipFree(p); }
+  { void* tk[] = {b->tk.d_table, b->tk.d_table_sparse, b->tk.d_snap, b->tk.d_trace, b->tk.d_link_q, b->tk.d_link_p}; for (void* p : tk) if (p) (void)hipFree(p); }
+  if (b->tk.h_link_dead) (void)hipHostFree(b->tk.h_link_dead);
   if (b->tk.h_stage) (void)hipHostFree(b->tk.h_stage);
   for (hipEvent_t e : b->tk.stage_ev) if (e) (void)hipEventDestroy(e);
   host_stream_free(b);

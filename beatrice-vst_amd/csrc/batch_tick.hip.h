@@ -3,10 +3,19 @@
 #pragma once
 
 // ---- tick pipelining (tick.hip.h) ---------------------------------------------------------------------------------
-bool tick_build_table(BeatriceBatch* b, const bool sparse = false) {
+template <int H>
+bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
   using namespace tick;
+  using O = Ops<H>;
+  using Tab = typename O::Tab;
+  using OpF2 = typename O::OpF2; using OpF3 = typename O::OpF3; using OpF4 = typename O::OpF4; using OpF5 = typename O::OpF5; using OpRB = typename O::OpRB;
+  using OpOUT = typename O::OpOUT; using OpP1 = typename O::OpP1; using OpP23 = typename O::OpP23; using OpPOUT = typename O::OpPOUT; using OpINP = typename O::OpINP;
+  using OpUP1 = typename O::OpUP1; using OpRES1A = typename O::OpRES1A; using OpRES1B = typename O::OpRES1B; using OpUP2 = typename O::OpUP2;
+  using OpF4s = typename O::OpF4s; using OpF5s = typename O::OpF5s; using OpRBs = typename O::OpRBs; using OpP1s = typename O::OpP1s; using OpUP1s = typename O::OpUP1s;
+  using T1 = typename O::T1; using T2 = typename O::T2; using T3 = typename O::T3; using T1s = typename O::T1s; using T2s = typename O::T2s;
+  using GruQ = typename O::GruQ; using GruP = typename O::GruP; using GruQ1 = typename O::GruQ1; using GruP1 = typename O::GruP1;
   State& k = b->tk;
-  auto tb = std::make_unique<Builder>();
+  auto tb = std::make_unique<typename O::Builder>();
   const PhoneWeights& pw = b->phone_m->w;
   const PitchWeights& qw = b->pitch_m->w;
   const WaveWeights& ww = b->wave_m->w;
@@ -28,22 +37,27 @@ bool tick_build_table(BeatriceBatch* b, const bool sparse = false) {
   auto hp = [&](int) -> const int* { return nullptr; };
   auto conv = [&](const Ring& in, const Ring& out, const float* w, const float* bias, int stage) { return conv_args(in, out, w, bias, hp(stage), B); };
   // (workgroups are dispatched in this order: the longest-running bodies first)
+  if constexpr (H > 1) {   // the GRU cells of the step's FIRST hop: ahead of every other body, so that the cells of the second hop
+                           // (below, behind the launch's first round) find their states published when they start
+    { const GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(Plan::PGRU), B, 0, k.d_link_p, nullptr, k.h_link_dead}; tb->template add<T_PGRU>(GruP::info("phone.gru", g), g, GruP::grid(g), Plan::PGRU, keep(1), 7.6); }
+    { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, 0, k.d_link_q, nullptr, k.h_link_dead}; tb->template add<T_QGRU>(GruQ::info("pitch.gru", g), g, GruQ::grid(g), Plan::QGRU, keep(1), 4.6); }
+  }
   // ---- longest workgroups first (measured, two per CU): f5 48 us, p1 46, f4 45, rb 42, block halves 41 / 38, tail 36
   if (!sparse) {
-    { const ConvArgs a = conv(ps.f[3], ps.f[4], pw.f_w[3], pw.f_b[3], Plan::F5); tb->add<T_F5>(OpF5::info("phone.f5", a), a, OpF5::grid(a), Plan::F5, keep(6), 47); }
-    { const ConvArgs a = conv(qs.spec, qs.p[0], qw.p_w[0], qw.p_b[0], Plan::P1); tb->add<T_P1>(OpP1::info("pitch.p1", a), a, OpP1::grid(a), Plan::P1, keep(2), 34.5); }
-    { const ConvArgs a = conv(ps.f[2], ps.f[3], pw.f_w[2], pw.f_b[2], Plan::F4); tb->add<T_F4>(OpF4::info("phone.f4", a), a, OpF4::grid(a), Plan::F4, keep(6), 37.5); }
+    { const ConvArgs a = conv(ps.f[3], ps.f[4], pw.f_w[3], pw.f_b[3], Plan::F5); tb->template add<T_F5>(OpF5::info("phone.f5", a), a, OpF5::grid(a), Plan::F5, keep(6), 47); }
+    { const ConvArgs a = conv(qs.spec, qs.p[0], qw.p_w[0], qw.p_b[0], Plan::P1); tb->template add<T_P1>(OpP1::info("pitch.p1", a), a, OpP1::grid(a), Plan::P1, keep(2), 34.5); }
+    { const ConvArgs a = conv(ps.f[2], ps.f[3], pw.f_w[2], pw.f_b[2], Plan::F4); tb->template add<T_F4>(OpF4::info("phone.f4", a), a, OpF4::grid(a), Plan::F4, keep(6), 37.5); }
     for (int i = 0; i < 4; ++i) {
       const ConvArgs a = conv(i == 0 ? ps.f[4] : ps.rb[i - 1], ps.rb[i], pw.rb_w[i], pw.rb_b[i], Plan::RB0 + i);
-      tb->add<T_RB>(OpRB::info("phone.rb", a), a, OpRB::grid(a), Plan::RB0 + i, keep(6), 46);
+      tb->template add<T_RB>(OpRB::info("phone.rb", a), a, OpRB::grid(a), Plan::RB0 + i, keep(6), 46);
     }
   } else {   // (the sparse table: one row tile per workgroup, tick.hip.h)
-    { const ConvArgs a = conv(ps.f[3], ps.f[4], pw.f_w[3], pw.f_b[3], Plan::F5); tb->add<T_F5S>(OpF5s::info("phone.f5", a), a, OpF5s::grid(a), Plan::F5, keep(6), 47); }
-    { const ConvArgs a = conv(qs.spec, qs.p[0], qw.p_w[0], qw.p_b[0], Plan::P1); tb->add<T_P1S>(OpP1s::info("pitch.p1", a), a, OpP1s::grid(a), Plan::P1, keep(2), 34.5); }
-    { const ConvArgs a = conv(ps.f[2], ps.f[3], pw.f_w[2], pw.f_b[2], Plan::F4); tb->add<T_F4S>(OpF4s::info("phone.f4", a), a, OpF4s::grid(a), Plan::F4, keep(6), 37.5); }
+    { const ConvArgs a = conv(ps.f[3], ps.f[4], pw.f_w[3], pw.f_b[3], Plan::F5); tb->template add<T_F5S>(OpF5s::info("phone.f5", a), a, OpF5s::grid(a), Plan::F5, keep(6), 47); }
+    { const ConvArgs a = conv(qs.spec, qs.p[0], qw.p_w[0], qw.p_b[0], Plan::P1); tb->template add<T_P1S>(OpP1s::info("pitch.p1", a), a, OpP1s::grid(a), Plan::P1, keep(2), 34.5); }
+    { const ConvArgs a = conv(ps.f[2], ps.f[3], pw.f_w[2], pw.f_b[2], Plan::F4); tb->template add<T_F4S>(OpF4s::info("phone.f4", a), a, OpF4s::grid(a), Plan::F4, keep(6), 37.5); }
     for (int i = 0; i < 4; ++i) {
       const ConvArgs a = conv(i == 0 ? ps.f[4] : ps.rb[i - 1], ps.rb[i], pw.rb_w[i], pw.rb_b[i], Plan::RB0 + i);
-      tb->add<T_RBS>(OpRBs::info("phone.rb", a), a, OpRBs::grid(a), Plan::RB0 + i, keep(6), 46);
+      tb->template add<T_RBS>(OpRBs::info("phone.rb", a), a, OpRBs::grid(a), Plan::RB0 + i, keep(6), 46);
     }
   }
   // conditioned blocks: two row-local chains each
@@ -52,26 +66,26 @@ bool tick_build_table(BeatriceBatch* b, const bool sparse = false) {
     const int s0 = pl.blk(blk);
     const rc::BlockBArgs ba{sc.xa, ws.x[blk + 1], ww.q_w[blk], ww.q_b[blk], ww.o_w[blk], ww.o_b[blk], ws.d_kt[blk], ws.d_v[blk],
                             b->dev_view<int>(b->off.perm[blk]), b->dev_view<int>(b->off.tile_slot[blk]), hp(s0 + 1)};
-    tb->add<T_BLKB>(LaunchInfo{"wave.blk.b", 2.0 * B * (256.0 * 256 * 2 + 256.0 * 384 * 2), 4.0 * (2.0 * 256 * 256 + 2.0 * 256 * 384 + B * 3.0 * 256)}, ba,
+    tb->template add<T_BLKB>(LaunchInfo{"wave.blk.b", 2.0 * B * H * (256.0 * 256 * 2 + 256.0 * 384 * 2), 4.0 * (2.0 * 256 * 256 + 2.0 * 256 * 384 + B * H * 3.0 * 256)}, ba,
                     dim3(ws.n_tiles_max, 1), s0 + 1, keep(5), 41.0);
     if (quads_on(b)) {  // rows without 15 neighbours on their K/V slot: one workgroup per quad (rebuild_tiles decides which rows)
       const rc::BlockBqArgs bq{sc.xa, ws.x[blk + 1], ww.q_w[blk], ww.q_b[blk], ww.o_w[blk], ww.o_b[blk], ws.d_ktp[blk], ws.d_vp[blk],
                                b->dev_view<int>(b->off.qperm[blk]), b->dev_view<int>(b->off.qslot[blk]), hp(s0 + 1)};
       // (a slot leaves at most 7 rows = 2 quads to this list: <= n_slots workgroups of two quads)
-      tb->add<T_BLKBQ>(LaunchInfo{"wave.blk.bq", 0.0, 0.0}, bq, dim3(std::min(2 * ws.n_tiles_max, ws.n_slots), 1), s0 + 1, keep(5), 42.0);
+      tb->template add<T_BLKBQ>(LaunchInfo{"wave.blk.bq", 0.0, 0.0}, bq, dim3(std::min(2 * ws.n_tiles_max, ws.n_slots), 1), s0 + 1, keep(5), 42.0);
     }
   }
   for (int blk = 0; blk < B_NBLOCKS; ++blk) {
     const rc::BlockAArgs aa{ws.x[blk], ws.scr[blk].xa, ww.c1_w[blk], ww.c1_b[blk], ww.c2_w[blk], ww.c2_b[blk], hp(pl.blk(blk)), B};
     switch (blk) {
-      case 0: tb->add<T_BLKA1>(rc::BlockAOp<1>::info(aa), aa, rc::BlockAOp<1>::grid(aa), pl.blk(blk), keep(5), 41); break;
-      case 1: tb->add<T_BLKA2>(rc::BlockAOp<2>::info(aa), aa, rc::BlockAOp<2>::grid(aa), pl.blk(blk), keep(5), 41); break;
-      case 2: tb->add<T_BLKA4>(rc::BlockAOp<4>::info(aa), aa, rc::BlockAOp<4>::grid(aa), pl.blk(blk), keep(5), 41); break;
-      default: tb->add<T_BLKA8>(rc::BlockAOp<8>::info(aa), aa, rc::BlockAOp<8>::grid(aa), pl.blk(blk), keep(5), 41); break;
+      case 0: tb->template add<T_BLKA1>(rc::BlockAOp<1, H>::info(aa), aa, rc::BlockAOp<1, H>::grid(aa), pl.blk(blk), keep(5), 41); break;
+      case 1: tb->template add<T_BLKA2>(rc::BlockAOp<2, H>::info(aa), aa, rc::BlockAOp<2, H>::grid(aa), pl.blk(blk), keep(5), 41); break;
+      case 2: tb->template add<T_BLKA4>(rc::BlockAOp<4, H>::info(aa), aa, rc::BlockAOp<4, H>::grid(aa), pl.blk(blk), keep(5), 41); break;
+      default: tb->template add<T_BLKA8>(rc::BlockAOp<8, H>::info(aa), aa, rc::BlockAOp<8, H>::grid(aa), pl.blk(blk), keep(5), 41); break;
     }
   }
   if (!pl.split_tail) {
-    TailArgs ta = tail_args(ww, ws); ta.hop = hp(pl.tail()); tb->add<T_TAIL>(tail_info(ws), ta, dim3(B, 1), pl.tail(), keep(4), 41, true);
+    TailArgs ta = tail_args(ww, ws); ta.hop = hp(pl.tail()); tb->template add<T_TAIL>(tail_info(ws), ta, dim3(B, 1), pl.tail(), keep(4), 41, true);
   } else {
     // the tail as three stages, several streams per workgroup (tail_stages.hip.h); same weights, same state block
     tst::StageArgs t1{}, t2{}, t3{};
@@ -82,36 +96,38 @@ bool tick_build_table(BeatriceBatch* b, const bool sparse = false) {
     t3.w[0] = ww.ra_w[3]; t3.b[0] = ww.ra_b[3]; t3.w[1] = ww.rb_w[3]; t3.b[1] = ww.rb_b[3];
     t3.fin_w = ww.fin_w; t3.fin_b = ww.fin_b; t3.d_out = ws.d_out; t3.io_stride = ws.io_stride;
     if (!sparse) {
-      tb->add<T_TAIL1>(tst::T1Op::info(t1), t1, tst::T1Op::grid(t1), pl.tail(), keep(4), 30, true);
-      tb->add<T_TAIL2>(tst::T2Op::info(t2), t2, tst::T2Op::grid(t2), pl.tail() + 1, keep(4), 28, true);
+      tb->template add<T_TAIL1>(T1::info(t1), t1, T1::grid(t1), pl.tail(), keep(4), 30, true);
+      tb->template add<T_TAIL2>(T2::info(t2), t2, T2::grid(t2), pl.tail() + 1, keep(4), 28, true);
     } else {   // (never occupied while the sparse table is in use; kept so that the two tables hold the same stages)
-      tb->add<T_TAIL1S>(T1s::info(t1), t1, T1s::grid(t1), pl.tail(), keep(4), 30, true);
-      tb->add<T_TAIL2S>(T2s::info(t2), t2, T2s::grid(t2), pl.tail() + 1, keep(4), 28, true);
+      tb->template add<T_TAIL1S>(T1s::info(t1), t1, T1s::grid(t1), pl.tail(), keep(4), 30, true);
+      tb->template add<T_TAIL2S>(T2s::info(t2), t2, T2s::grid(t2), pl.tail() + 1, keep(4), 28, true);
     }
-    tb->add<T_TAIL3>(tst::T3Op::info(t3), t3, tst::T3Op::grid(t3), pl.tail() + 2, keep(4), 16, true);
+    tb->template add<T_TAIL3>(T3::info(t3), t3, T3::grid(t3), pl.tail() + 2, keep(4), 16, true);
   }
   // ---- everything else, longest workgroups first (they start when the heavy ones above leave their slots)
-  { const ConvArgs a = conv(ps.f[1], ps.f[2], pw.f_w[1], pw.f_b[1], Plan::F3); tb->add<T_F3>(OpF3::info("phone.f3", a), a, OpF3::grid(a), Plan::F3, keep(6), 18); }
-  if (!sparse) { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], pl.up1()); tb->add<T_UP1>(OpUP1::info("wave.up1", a), a, OpUP1::grid(a), pl.up1(), keep(7), 36); }
-  else { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], pl.up1()); tb->add<T_UP1S>(OpUP1s::info("wave.up1", a), a, OpUP1s::grid(a), pl.up1(), keep(7), 36); }
-  { const ConvArgs a = conv(ws.yb1, ws.yc1, ww.rb_w[0], ww.rb_b[0], pl.up1() + 2); tb->add<T_RES1B>(OpRES1B::info("wave.res1b", a), a, OpRES1B::grid(a), pl.up1() + 2, keep(7), 10); }
-  { const ConvArgs a = conv(ws.ya1, ws.yb1, ww.ra_w[0], ww.ra_b[0], pl.up1() + 1); tb->add<T_RES1A>(OpRES1A::info("wave.res1a", a), a, OpRES1A::grid(a), pl.up1() + 1, keep(7), 10); }
-  { const ConvArgs a = conv(ws.yc1, ws.ya2, ww.up_w[1], ww.up_b[1], pl.up1() + 3); tb->add<T_UP2>(OpUP2::info("wave.up2", a), a, OpUP2::grid(a), pl.up1() + 3, keep(7), 12); }
-  { const ConvArgs a = conv(ps.f[0], ps.f[1], pw.f_w[0], pw.f_b[0], Plan::F2); tb->add<T_F2>(OpF2::info("phone.f2", a), a, OpF2::grid(a), Plan::F2, keep(6), 10); }
-  { const GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(Plan::PGRU), B, 0}; tb->add<T_PGRU>(GruOp<256, 256, TICK_GRU_RT>::info("phone.gru", g), g, GruOp<256, 256, TICK_GRU_RT>::grid(g), Plan::PGRU, keep(1), 7.6); }
-  { const ConvArgs a = conv(qs.h, qs.logits, qw.out_w, qw.out_b, Plan::POUT); tb->add<T_POUT>(OpPOUT::info("pitch.out", a), a, OpPOUT::grid(a), Plan::POUT, keep(2), 9.4); }
+  { const ConvArgs a = conv(ps.f[1], ps.f[2], pw.f_w[1], pw.f_b[1], Plan::F3); tb->template add<T_F3>(OpF3::info("phone.f3", a), a, OpF3::grid(a), Plan::F3, keep(6), 18); }
+  if (!sparse) { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], pl.up1()); tb->template add<T_UP1>(OpUP1::info("wave.up1", a), a, OpUP1::grid(a), pl.up1(), keep(7), 36); }
+  else { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], pl.up1()); tb->template add<T_UP1S>(OpUP1s::info("wave.up1", a), a, OpUP1s::grid(a), pl.up1(), keep(7), 36); }
+  { const ConvArgs a = conv(ws.yb1, ws.yc1, ww.rb_w[0], ww.rb_b[0], pl.up1() + 2); tb->template add<T_RES1B>(OpRES1B::info("wave.res1b", a), a, OpRES1B::grid(a), pl.up1() + 2, keep(7), 10); }
+  { const ConvArgs a = conv(ws.ya1, ws.yb1, ww.ra_w[0], ww.ra_b[0], pl.up1() + 1); tb->template add<T_RES1A>(OpRES1A::info("wave.res1a", a), a, OpRES1A::grid(a), pl.up1() + 1, keep(7), 10); }
+  { const ConvArgs a = conv(ws.yc1, ws.ya2, ww.up_w[1], ww.up_b[1], pl.up1() + 3); tb->template add<T_UP2>(OpUP2::info("wave.up2", a), a, OpUP2::grid(a), pl.up1() + 3, keep(7), 12); }
+  { const ConvArgs a = conv(ps.f[0], ps.f[1], pw.f_w[0], pw.f_b[0], Plan::F2); tb->template add<T_F2>(OpF2::info("phone.f2", a), a, OpF2::grid(a), Plan::F2, keep(6), 10); }
+  if constexpr (H == 1) { const GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(Plan::PGRU), B, 0}; tb->template add<T_PGRU>(GruP::info("phone.gru", g), g, GruP::grid(g), Plan::PGRU, keep(1), 7.6); }
+  else { const GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(Plan::PGRU), B, 1, nullptr, k.d_link_p, k.h_link_dead}; tb->template add<T_PGRU1>(GruP1::info("phone.gru", g), g, GruP1::grid(g), Plan::PGRU, keep(1), 7.6); }
+  { const ConvArgs a = conv(qs.h, qs.logits, qw.out_w, qw.out_b, Plan::POUT); tb->template add<T_POUT>(OpPOUT::info("pitch.out", a), a, OpPOUT::grid(a), Plan::POUT, keep(2), 9.4); }
   for (int i = 0; i < 2; ++i) {
     const ConvArgs a = conv(qs.p[i], qs.p[i + 1], qw.p_w[i + 1], qw.p_b[i + 1], Plan::P2 + i);
-    tb->add<T_P23>(OpP23::info("pitch.p23", a), a, OpP23::grid(a), Plan::P2 + i, keep(2), 8);
+    tb->template add<T_P23>(OpP23::info("pitch.p23", a), a, OpP23::grid(a), Plan::P2 + i, keep(2), 8);
   }
-  { const Ring phone_in{ws.d_phone, B_PHONE_CH, 1, ws.front_slots}; ConvArgs a = conv(phone_in, ws.x[0], ww.inp_w, ww.inp_b, Plan::INP); a.res = ws.e; tb->add<T_INP>(OpINP::info("wave.inp", a), a, OpINP::grid(a), Plan::INP, keep(3), 7.7); }
-  { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, 0}; tb->add<T_QGRU>(GruOp<128, 128, TICK_GRU_RT>::info("pitch.gru", g), g, GruOp<128, 128, TICK_GRU_RT>::grid(g), Plan::QGRU, keep(1), 4.6); }
-  { FftArgs a = fft_args(qw, qs); a.hop = hp(Plan::FFT); tb->add<T_FFT>(fft_info(qs), FftArgs2{a, B}, dim3((B + 1) / 2, 1), Plan::FFT, keep(0), 6); }
-  { const ConvArgs a = conv(ps.h, phone_out_ring(ps), pw.out_w, pw.out_b, Plan::OUT); tb->add<T_OUT>(OpOUT::info("phone.out", a), a, OpOUT::grid(a), Plan::OUT, keep(3), 6); }
-  { const VqArgs a{1, ps.raw, phone_vector_ring(ps), hp(Plan::VQ), ps.d_cbT, ps.d_cnorm, ps.d_vqk}; tb->add<T_VQ>(LaunchInfo{"phone.vq", 0, 4.0 * B * 256}, a, dim3(B, 1), Plan::VQ, !ps.skip_vq, 6.0, true); }
-  { PitchHeadArgs a = head_args(qw, qs); a.hop = hp(Plan::HEAD); tb->add<T_HEAD>(head_info(qs), a, dim3((B + 7) / 8, 1), Plan::HEAD, keep(0), 4.7); }
-  { F1Args a = f1_args(pw, ps); a.hop = hp(Plan::F1); a.hop_publish = nullptr; a.hop_publish_wave = nullptr; tb->add<T_F1>(f1_info(ps), F1Args2{a, B}, dim3((B + 1) / 2, 1), Plan::F1, keep(0), 4.5); }
-  { CondArgs a = cond_args(ww, ws); a.hop = hp(Plan::COND); a.hop_next_out = nullptr; tb->add<T_COND>(cond_info(ws), a, dim3((B + 1) / 2, 1), Plan::COND, keep(0), 1.3); }
+  { const Ring phone_in{ws.d_phone, B_PHONE_CH, H, ws.front_slots}; ConvArgs a = conv(phone_in, ws.x[0], ww.inp_w, ww.inp_b, Plan::INP); a.res = ws.e; tb->template add<T_INP>(OpINP::info("wave.inp", a), a, OpINP::grid(a), Plan::INP, keep(3), 7.7); }
+  if constexpr (H == 1) { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, 0}; tb->template add<T_QGRU>(GruQ::info("pitch.gru", g), g, GruQ::grid(g), Plan::QGRU, keep(1), 4.6); }
+  else { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, 1, nullptr, k.d_link_q, k.h_link_dead}; tb->template add<T_QGRU1>(GruQ1::info("pitch.gru", g), g, GruQ1::grid(g), Plan::QGRU, keep(1), 4.6); }
+  { FftArgs a = fft_args(qw, qs); a.hop = hp(Plan::FFT); tb->template add<T_FFT>(fft_info(qs), FftArgs2{a, B}, dim3((B + 1) / 2, H), Plan::FFT, keep(0), 6); }
+  { const ConvArgs a = conv(ps.h, phone_out_ring(ps), pw.out_w, pw.out_b, Plan::OUT); tb->template add<T_OUT>(OpOUT::info("phone.out", a), a, OpOUT::grid(a), Plan::OUT, keep(3), 6); }
+  { const VqArgs a{H, ps.raw, phone_vector_ring(ps), hp(Plan::VQ), ps.d_cbT, ps.d_cnorm, ps.d_vqk}; tb->template add<T_VQ>(LaunchInfo{"phone.vq", 0, 4.0 * B * H * 256}, a, dim3(B * H, 1), Plan::VQ, !ps.skip_vq, 6.0, true); }
+  { PitchHeadArgs a = head_args(qw, qs); a.hop = hp(Plan::HEAD); tb->template add<T_HEAD>(head_info(qs), a, dim3((B + 7) / 8, 1), Plan::HEAD, keep(0), 4.7); }
+  { F1Args a = f1_args(pw, ps); a.hop = hp(Plan::F1); a.hop_publish = nullptr; a.hop_publish_wave = nullptr; tb->template add<T_F1>(f1_info(ps), F1Args2{a, B}, dim3((B + 1) / 2, H), Plan::F1, keep(0), 4.5); }
+  { CondArgs a = cond_args(ww, ws); a.hop = hp(Plan::COND); a.hop_next_out = nullptr; tb->template add<T_COND>(cond_info(ws), a, dim3((B * H + 1) / 2, 1), Plan::COND, keep(0), 1.3); }
   if (!tb->ok) return false;
   // XCD-aware placement (bodies with many weights pinned to one XCD each, so that the weights stay in that L2) was
   // measured twice: it cuts the launch's memory-side traffic 4x (rocprofv3 FETCH_SIZE 105 -> 26 MB per tick) and the
@@ -146,6 +162,21 @@ bool tick_build_table(BeatriceBatch* b, const bool sparse = false) {
   }
   k.table_dirty = false;
   return true;
+}
+bool tick_build_table(BeatriceBatch* b, const bool sparse = false) {
+  switch (b->H) {
+    case 1: return tick_build_table_h<1>(b, sparse);
+    case 2: return tick_build_table_h<2>(b, sparse);
+    default: return false;
+  }
+}
+// the launch of one tick: the table kernel of the batch's hops per step
+static void tick_launch(BeatriceBatch* b, const bool sparse, hipStream_t st, const fuse::StepPairs& pairs) {
+  tick::State& k = b->tk;
+  const void* t = sparse ? k.d_table_sparse : k.d_table;
+  const int total = sparse ? k.table_sparse_total : k.table_total;
+  if (b->H == 1) fuse::launch_table_w<4>(static_cast<const tick::Ops<1>::Tab*>(t), total, st, pairs, k.ragged);   // (ragged: the second instance of the launch, once a stream has sat a step out)
+  else fuse::launch_table_w<4, false>(static_cast<const tick::Ops<2>::Tab*>(t), total, st, pairs, false);   // (no ragged steps at several hops per step: EnableSilentBlockRule refuses)
 }
 
 // One tick: every stage advances by one step; `feeding` = a new step enters at stage 0.
@@ -320,7 +351,7 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
   for (int s = 0; s < p.n_stages; ++s) if (p.hop[s] >= 0) highest = s;
   static const bool no_sparse = std::getenv("BEATRICE_HIP_TICK_NO_SPARSE") != nullptr;   // A/B switch for measurements
   const bool sparse = highest >= 0 && highest < Plan::BLK0 && !no_sparse;
-  fuse::launch_table_w<4>(sparse ? k.d_table_sparse : k.d_table, sparse ? k.table_sparse_total : k.table_total, st, pairs, k.ragged);   // (ragged: the second instance of the launch, once a stream has sat a step out)
+  tick_launch(b, sparse, st, pairs);
   if (b->r48.on) {  // the step this tick completed: its 48 kHz block is produced by the wrapper launch of the next tick (or of the drain)
     const long long u = step_at(k.plan.count() - 1);
     if (u >= 0) { b->r48.deferred_slot = k.io_of_step[u % kRing]; b->r48.deferred_step = u; }
@@ -390,17 +421,27 @@ int tick_enable(BeatriceBatch* b, bool on) {
   if (on) {
     // one 10 ms hop per step, resident I/O with enough slots
     // that a step's input is still there when the pitch head reads it nine ticks on and outputs have somewhere to land
-    if (b->H != 1 || b->B > 4096 || b->io_slots < k.plan.count() + 1) return -1;
+    if (b->H > kMaxHops || b->B > 4096 || b->io_slots < k.plan.count() + 1) return -1;
     if (!sync_all(b)) return -2;
     if (b->pipelined) { drop_graph(b); set_plan(b, 1); }
     k.snap_bytes = b->off.front_bytes + b->off.wave_bytes;
     if (!k.d_table) {
-      if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_table), sizeof(Tab)), "tick table") ||
-          !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_table_sparse), sizeof(Tab)), "tick sparse table") ||
+      const size_t tab_bytes = std::max(sizeof(Ops<1>::Tab), sizeof(Ops<2>::Tab));
+      if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_table), tab_bytes), "tick table") ||
+          !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_table_sparse), tab_bytes), "tick sparse table") ||
           !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_snap), k.snap_bytes * kRing), "tick snapshots") ||
           !hip_ok(hipHostMalloc(reinterpret_cast<void**>(&k.h_stage), k.snap_bytes * State::kStaging, hipHostMallocDefault), "tick staging"))
         return -2;
       for (hipEvent_t& e : k.stage_ev) if (!hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "tick staging event")) return -2;
+    }
+    if (b->H > 1 && !k.d_link_p) {   // the granules between the GRU cells of a step's hops (tick.hip.h); tag 0 = never written
+      const size_t nq = (size_t)b->B * 128, np = (size_t)b->B * 256;
+      if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_link_q), sizeof(unsigned long long) * nq), "tick gru link") ||
+          !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_link_p), sizeof(unsigned long long) * np), "tick gru link") ||
+          !hip_ok(hipMemset(k.d_link_q, 0, sizeof(unsigned long long) * nq), "tick gru link") || !hip_ok(hipMemset(k.d_link_p, 0, sizeof(unsigned long long) * np), "tick gru link") ||
+          !hip_ok(hipHostMalloc(reinterpret_cast<void**>(&k.h_link_dead), sizeof(int), hipHostMallocDefault), "tick gru link flag"))
+        return -2;
+      *k.h_link_dead = 0;
     }
     // the plain-order K / V copies the quad bodies read (rowchain.hip.h block_bq_body) exist in tick mode only: ~3 MB per
     // speaker that the in-order, stage-pipelined and large-batch modes never read

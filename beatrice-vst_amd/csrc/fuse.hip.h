@@ -206,12 +206,15 @@ template <class... Ms>
 static inline void launch_table(const Table<Ms...>* d_table, int total, hipStream_t stream, const StepPairs& pairs) {
   hipLaunchKernelGGL((table_kernel<Ms...>), dim3(total), dim3(MaxM<Ms...>::NTHR), 0, stream, d_table, pairs);
 }
-template <int MINW, class... Ms>
+// WITH_RAGGED = false: the launch has no ragged instance (its caller never passes ragged = true)
+template <int MINW, bool WITH_RAGGED = true, class... Ms>
 static inline void launch_table_w(const Table<Ms...>* d_table, int total, hipStream_t stream, const StepPairs& pairs, const bool ragged = false) {
   // measurement aid: BEATRICE_HIP_TICK_PAD_LDS=<bytes> of dynamic LDS on top of the static block (e.g. to allow one workgroup per CU only)
   static const int pad = std::getenv("BEATRICE_HIP_TICK_PAD_LDS") ? std::atoi(std::getenv("BEATRICE_HIP_TICK_PAD_LDS")) : 0;
-  if (ragged) hipLaunchKernelGGL((table_kernel_w<MINW, true, Ms...>), dim3(total), dim3(MaxM<Ms...>::NTHR), pad, stream, d_table, pairs);
-  else hipLaunchKernelGGL((table_kernel_w<MINW, false, Ms...>), dim3(total), dim3(MaxM<Ms...>::NTHR), pad, stream, d_table, pairs);
+  if constexpr (WITH_RAGGED) {
+    if (ragged) { hipLaunchKernelGGL((table_kernel_w<MINW, true, Ms...>), dim3(total), dim3(MaxM<Ms...>::NTHR), pad, stream, d_table, pairs); return; }
+  }
+  hipLaunchKernelGGL((table_kernel_w<MINW, false, Ms...>), dim3(total), dim3(MaxM<Ms...>::NTHR), pad, stream, d_table, pairs);
 }
 
 // host side: fill a Table<Ms...>.  add<I>() appends one body of type I (its index in Ms...); bodies run in the order added

@@ -24,16 +24,40 @@ struct GruArgs {
   const int* hop;
   int B;
   int t;  // hop within the step: x frame t, previous state = h frame t-1, new state -> h frame t
+  // Hops of one step linked INSIDE a launch (the tick launch with several hops per stage, tick.hip.h; null elsewhere): the cell
+  // of hop t publishes its state as tagged granules [B][H] of {value, step tag} (one 8-byte agent-scope store each: the data
+  // carries its own flag, no fence), the cell of hop t + 1 -- workgroups LATER in the launch's dispatch order -- polls them.
+  unsigned long long* link_out;
+  const unsigned long long* link_in;
+  int* link_dead;   // pinned host word, set when a wait was given up (a bug must not hang the GPU)
 };
+namespace glink {
+constexpr int kSpinLimit = 2000000;   // polls before a workgroup gives up: ~1 s
+__device__ __forceinline__ void publish(unsigned long long* g, const float v, const int tag) {
+  __hip_atomic_store(g, ((unsigned long long)(unsigned)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float acquire(const unsigned long long* g, const int tag, int* dead) {
+  unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int spins = 0;
+  while ((int)(v >> 32) != tag) {
+    if (++spins > kSpinLimit) { *dead = 1; return 0.0f; }
+    __builtin_amdgcn_s_sleep(2);
+    v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return __uint_as_float((unsigned)v);
+}
+}  // namespace glink
 
 __device__ __forceinline__ void globalize(GruArgs& a) {
   globalize(a.x); globalize(a.h);
   a.wih = as_global(a.wih); a.whh = as_global(a.whh); a.bih = as_global(a.bih); a.bhh = as_global(a.bhh); a.hop = as_global(a.hop);
+  a.link_out = as_global(a.link_out); a.link_in = as_global(a.link_in);
 }
 
 // RT = row tiles of 16 streams per workgroup: at 2 the wavefront's weight fragments (held in registers for the whole
 // reduction) feed two independent MFMA chains -- half the weight traffic per stream and twice the work per dependent step.
-template <int IN, int H, int RT = 1, bool RAG = false>
+// LINK: bit 0 = publish the new state as granules (a.link_out), bit 1 = take the previous state from granules (a.link_in)
+template <int IN, int H, int RT = 1, bool RAG = false, int LINK = 0>
 __device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, const int by, float* __restrict__ lds) {
   constexpr int XS = IN + 2, HS = H + 2;  // lds: 16 RT * XS + 16 RT * HS + RT * 6 * 256 floats
   constexpr int ROWS = 16 * RT;
@@ -73,7 +97,16 @@ __device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, c
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (b0 + r < a.B) {
       const int hr = rag ? stepc::hopv[b0 + r] : hop;
-      if (hr >= 0) v = *reinterpret_cast<const float4*>(ring_frame(a.h, b0 + r, rag ? ring_pos(a.h, hr) : ph, a.t - 1) + 4 * q);
+      if constexpr ((LINK & 2) != 0) {   // the state the cell of the hop before published in THIS launch
+        const unsigned long long* g = a.link_in + (size_t)(b0 + r) * H + 4 * q;
+        unsigned long long gv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gv[i] = __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float f[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = (int)(gv[i] >> 32) == hop + 1 ? __uint_as_float((unsigned)gv[i]) : glink::acquire(g + i, hop + 1, a.link_dead);
+        v = make_float4(f[0], f[1], f[2], f[3]);
+      } else if (hr >= 0) v = *reinterpret_cast<const float4*>(ring_frame(a.h, b0 + r, rag ? ring_pos(a.h, hr) : ph, a.t - 1) + 4 * q);
     }
     float2* d = reinterpret_cast<float2*>(&hs[r * HS + 4 * q]);
     d[0] = make_float2(v.x, v.y); d[1] = make_float2(v.z, v.w);
@@ -120,7 +153,9 @@ __device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, c
       const float rr = rz.x, zz = rz.y;
       const float nn = bsp::tanh2(bsp::splat2(bsp::fma(rr, gh_n, gi_n))).x;
       const float hp = hs[r * HS + j0 + j];
-      ring_frame(a.h, b0 + r, rag ? ring_pos(a.h, hr) : ph, a.t)[j0 + j] = bsp::fma(zz, hp - nn, nn);
+      const float hv = bsp::fma(zz, hp - nn, nn);
+      ring_frame(a.h, b0 + r, rag ? ring_pos(a.h, hr) : ph, a.t)[j0 + j] = hv;
+      if constexpr ((LINK & 1) != 0) glink::publish(a.link_out + (size_t)(b0 + r) * H + j0 + j, hv, hop + 1);
     }
   }
 }
@@ -131,7 +166,7 @@ static __global__ __launch_bounds__(384) void gru_fused_kernel(const GruArgs a) 
   gru_fused_body<IN, H, RT>(a, blockIdx.x, blockIdx.y, lds);
 }
 
-template <int IN, int H, int RT = 1>
+template <int IN, int H, int RT = 1, int LINK = 0>
 struct GruOp {
   using Args = GruArgs;
   static constexpr int NTHR = 384;
@@ -140,8 +175,8 @@ struct GruOp {
   static inline bhip::LaunchInfo info(const char* name, const GruArgs& a) {
     return bhip::LaunchInfo{name, 2.0 * a.B * (IN + H) * 3.0 * H, 4.0 * ((IN + H) * 3.0 * H + a.B * (IN + 2.0 * H))};
   }
-  __device__ static __forceinline__ void run(const GruArgs& a, int bx, int by, float* lds) { gru_fused_body<IN, H, RT>(a, bx, by, lds); }
-  template <bool RAG> __device__ static __forceinline__ void run_t(const GruArgs& a, int bx, int by, float* lds) { gru_fused_body<IN, H, RT, RAG>(a, bx, by, lds); }
+  __device__ static __forceinline__ void run(const GruArgs& a, int bx, int by, float* lds) { gru_fused_body<IN, H, RT, false, LINK>(a, bx, by, lds); }
+  template <bool RAG> __device__ static __forceinline__ void run_t(const GruArgs& a, int bx, int by, float* lds) { gru_fused_body<IN, H, RT, RAG, LINK>(a, bx, by, lds); }
 };
 
 // (RT = 2 as a launch of its own measured slower at 8192 streams -- 140 vs 113 us: 78 KB of LDS leave two workgroups

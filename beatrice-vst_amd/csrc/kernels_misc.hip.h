@@ -123,8 +123,9 @@ struct F1Op2 {
   using Args = F1Args2;
   static constexpr int NTHR = 512;
   static constexpr int LDS_FLOATS = 2 * 168 + 10 * 64;
-  __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { phone_f1_body_t<2>(a.a, bx, 0, lds, a.n_streams); }
-  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) { phone_f1_body_t<2, RAG>(a.a, bx, 0, lds, a.n_streams); }
+  // (grid y = hop within the step: ((n_streams + 1) / 2, H))
+  __device__ static __forceinline__ void run(const Args& a, int bx, int by, float* lds) { phone_f1_body_t<2>(a.a, bx, by, lds, a.n_streams); }
+  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int by, float* lds) { phone_f1_body_t<2, RAG>(a.a, bx, by, lds, a.n_streams); }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -306,8 +307,8 @@ struct FftOp2 {  // two streams per 512-thread workgroup (H = 1): grid ((n_strea
   using Args = FftArgs2;
   static constexpr int NTHR = 512;
   static constexpr int LDS_FLOATS = 5 * B_FFT_N;
-  __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { pitch_fft_body_t<2>(a.a, bx, 0, lds, a.n_streams); }
-  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) { pitch_fft_body_t<2, RAG>(a.a, bx, 0, lds, a.n_streams); }
+  __device__ static __forceinline__ void run(const Args& a, int bx, int by, float* lds) { pitch_fft_body_t<2>(a.a, bx, by, lds, a.n_streams); }
+  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int by, float* lds) { pitch_fft_body_t<2, RAG>(a.a, bx, by, lds, a.n_streams); }
 };
 
 // ---------------------------------------------------------------------------------------------

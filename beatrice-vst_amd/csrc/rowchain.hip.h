@@ -208,6 +208,8 @@ __device__ __forceinline__ void layer256(const float* const (&seg)[NSEG], const 
 // [16 rows][256 channels] from a ring into an LDS tile; row r = frame `rel` of stream sid[r] (zeros when sid[r] < 0)
 // (rowhop: LDS [16], the rows' own step counters in a ragged tick step -- sid[] is then already -1 for streams that sit it out --
 //  or nullptr: every row at `pos`)
+// HOPS = hops per step: sid[r] is then the ROW (stream * HOPS + hop in step) and the row's frame is `rel + hop in step`
+template <int HOPS = 1>
 __device__ __forceinline__ void load_tile(float* __restrict__ dst, const Ring& ring, const int* sid /* LDS, [16] */, const int pos, const int rel,
                                           const int tid, const int* rowhop = nullptr) {
 #pragma unroll
@@ -215,7 +217,7 @@ __device__ __forceinline__ void load_tile(float* __restrict__ dst, const Ring& r
     const int idx = tid + i * NTHR, r = idx >> 6, q = idx & 63;
     const int b = sid[r];
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (b >= 0) v = *reinterpret_cast<const float4*>(ring_frame(ring, b, rowhop != nullptr ? ring_pos(ring, rowhop[r]) : pos, rel) + 4 * q);
+    if (b >= 0) v = *reinterpret_cast<const float4*>(ring_frame(ring, b / HOPS, rowhop != nullptr ? ring_pos(ring, rowhop[r]) : pos, rel + b % HOPS) + 4 * q);
     float2* d = reinterpret_cast<float2*>(dst + r * AS + 4 * q);
     d[0] = make_float2(v.x, v.y);
     d[1] = make_float2(v.z, v.w);
@@ -235,7 +237,7 @@ __device__ __forceinline__ void globalize(BlockAArgs& a) {
   a.c1_w = as_global(a.c1_w); a.c1_b = as_global(a.c1_b); a.c2_w = as_global(a.c2_w); a.c2_b = as_global(a.c2_b); a.hop = as_global(a.hop);
 }
 constexpr int kBlockALds = 4 * TILE + 32;   // + sid[16], rowhop[16]
-template <int D, bool RAG = false>
+template <int D, bool RAG = false, int HOPS = 1>
 __device__ __forceinline__ void block_a_body(const BlockAArgs& a, const int g, float* __restrict__ lds) {
   float* T[3] = {lds, lds + TILE, lds + 2 * TILE};  // taps t-2D, t-D, t
   float* Hh = lds + 3 * TILE;
@@ -246,15 +248,15 @@ __device__ __forceinline__ void block_a_body(const BlockAArgs& a, const int g, f
   if (hop < 0) return;
   const int* rowhop = stepc::rag_t<RAG>() ? rowhop_ : nullptr;   // (ragged tick step: rows at their streams' own counters)
   if (tid < 16) {
-    const int b = g * 16 + tid < a.B ? g * 16 + tid : -1;
-    const int hr = b >= 0 ? stepc::of_t<RAG>(hop, b) : -1;
+    const int b = g * 16 + tid < a.B * HOPS ? g * 16 + tid : -1;   // (the row: stream * HOPS + hop in step)
+    const int hr = b >= 0 ? stepc::of_t<RAG>(hop, b / HOPS) : -1;
     sid[tid] = hr >= 0 ? b : -1;
     rowhop_[tid] = hr >= 0 ? hr : 0;
   }
   __syncthreads();
   const int pos = ring_pos(a.x, hop);
 #pragma unroll
-  for (int j = 0; j < 3; ++j) load_tile(T[j], a.x, sid, pos, -(2 - j) * D, tid, rowhop);
+  for (int j = 0; j < 3; ++j) load_tile<HOPS>(T[j], a.x, sid, pos, -(2 - j) * D, tid, rowhop);
   __syncthreads();
   {
     const float* const seg[3] = {T[0], T[1], T[2]};
@@ -276,23 +278,23 @@ __device__ __forceinline__ void block_a_body(const BlockAArgs& a, const int g, f
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int b = sid[r0 + e];
-        if (b >= 0) ring_frame(a.xa, b, rowhop != nullptr ? ring_pos(a.xa, rowhop[r0 + e]) : pos_o, 0)[n] = T[2][(r0 + e) * AS + n] + (v[e] + bn);
+        if (b >= 0) ring_frame(a.xa, b / HOPS, rowhop != nullptr ? ring_pos(a.xa, rowhop[r0 + e]) : pos_o, b % HOPS)[n] = T[2][(r0 + e) * AS + n] + (v[e] + bn);
       }
     });
   }
 }
-template <int D>
+template <int D, int HOPS = 1>
 struct BlockAOp {
   using Args = BlockAArgs;
   static constexpr int NTHR = rc::NTHR;
   static constexpr int LDS_FLOATS = kBlockALds;
-  static inline dim3 grid(const Args& a) { return dim3((a.B + 15) / 16, 1); }
+  static inline dim3 grid(const Args& a) { return dim3((a.B * HOPS + 15) / 16, 1); }
   static inline bhip::LaunchInfo info(const Args& a) {
-    return bhip::LaunchInfo{"wave.blk.a", 2.0 * a.B * (768.0 + 256.0) * 256.0, 4.0 * ((768.0 + 256.0) * 256.0 + a.B * 5.0 * 256.0)};
+    return bhip::LaunchInfo{"wave.blk.a", 2.0 * a.B * HOPS * (768.0 + 256.0) * 256.0, 4.0 * ((768.0 + 256.0) * 256.0 + a.B * HOPS * 5.0 * 256.0)};
   }
   static constexpr double wg_cost() { return 20.0; }
-  __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { block_a_body<D>(a, bx, lds); }
-  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) { block_a_body<D, RAG>(a, bx, lds); }
+  __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { block_a_body<D, false, HOPS>(a, bx, lds); }
+  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) { block_a_body<D, RAG, HOPS>(a, bx, lds); }
 };
 template <int D>
 static __global__ __launch_bounds__(NTHR, 4) void block_a_kernel(const BlockAArgs a) {
@@ -317,7 +319,7 @@ __device__ __forceinline__ void globalize(BlockBArgs& a) {
   a.kt = as_global(a.kt); a.v = as_global(a.v); a.perm = as_global(a.perm); a.tile_slot = as_global(a.tile_slot); a.hop = as_global(a.hop);
 }
 constexpr int kBlockBLds = 2 * TILE + STILE + 48;   // + inv[16], sid[16], rowhop[16]
-template <bool RAG = false>
+template <bool RAG = false, int HOPS = 1>
 __device__ __forceinline__ void block_b_body(const BlockBArgs& a, const int g, float* __restrict__ lds) {
   float* XA = lds;
   float* Q = lds + TILE;           // q, later o
@@ -333,13 +335,13 @@ __device__ __forceinline__ void block_b_body(const BlockBArgs& a, const int g, f
   int* rowhop_ = sid + 16;
   const int* rowhop = stepc::rag_t<RAG>() ? rowhop_ : nullptr;
   if (tid < 16) {
-    const int b = a.perm[g * 16 + tid];
-    const int hr = b >= 0 ? stepc::of_t<RAG>(hop, b) : -1;
+    const int b = a.perm[g * 16 + tid];   // (the row: stream * HOPS + hop in step)
+    const int hr = b >= 0 ? stepc::of_t<RAG>(hop, b / HOPS) : -1;
     sid[tid] = hr >= 0 ? b : -1;
     rowhop_[tid] = hr >= 0 ? hr : 0;
   }
   __syncthreads();
-  load_tile(XA, a.xa, sid, ring_pos(a.xa, hop), 0, tid, rowhop);
+  load_tile<HOPS>(XA, a.xa, sid, ring_pos(a.xa, hop), 0, tid, rowhop);
   __syncthreads();
   {
     const float* const seg[1] = {XA};
@@ -412,20 +414,22 @@ __device__ __forceinline__ void block_b_body(const BlockBArgs& a, const int g, f
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int b = sid[r0 + e];
-        if (b >= 0) ring_frame(a.out, b, rowhop != nullptr ? ring_pos(a.out, rowhop[r0 + e]) : pos_o, 0)[n] = XA[(r0 + e) * AS + n] + (v[e] + bn);
+        if (b >= 0) ring_frame(a.out, b / HOPS, rowhop != nullptr ? ring_pos(a.out, rowhop[r0 + e]) : pos_o, b % HOPS)[n] = XA[(r0 + e) * AS + n] + (v[e] + bn);
       }
     });
   }
   RC_STAMP(6);
 }
-struct BlockBOp {
+template <int HOPS = 1>
+struct BlockBOpH {
   using Args = BlockBArgs;
   static constexpr int NTHR = rc::NTHR;
   static constexpr int LDS_FLOATS = kBlockBLds;
   static constexpr double wg_cost() { return 24.0; }
-  __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { block_b_body(a, bx, lds); }
-  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) { block_b_body<RAG>(a, bx, lds); }
+  __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { block_b_body<false, HOPS>(a, bx, lds); }
+  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) { block_b_body<RAG, HOPS>(a, bx, lds); }
 };
+using BlockBOp = BlockBOpH<1>;
 static __global__ __launch_bounds__(NTHR, 4) void block_b_kernel(const BlockBArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[kBlockBLds];
   block_b_body(a, blockIdx.x, lds);
@@ -514,7 +518,7 @@ __device__ __forceinline__ void globalize(BlockBqArgs& a) {
   a.ktp = as_global(a.ktp); a.vp = as_global(a.vp); a.qperm = as_global(a.qperm); a.qslot = as_global(a.qslot); a.hop = as_global(a.hop);
 }
 constexpr int kBlockBqLds = kBlockBLds;
-template <bool RAG = false>
+template <bool RAG = false, int HOPS = 1>
 __device__ __forceinline__ void block_bq_body(const BlockBqArgs& a, const int g, float* __restrict__ lds) {
   float* XA = lds;
   float* Q = lds + TILE;           // q, later o
@@ -535,12 +539,12 @@ __device__ __forceinline__ void block_bq_body(const BlockBqArgs& a, const int g,
   const int* rowhop = stepc::rag_t<RAG>() ? rowhop_ : nullptr;
   if (tid < 16) {   // rows 8..15 of the tile stay empty
     const int b = tid < 8 ? a.qperm[g * 8 + tid] : -1;
-    const int hr = b >= 0 ? stepc::of_t<RAG>(hop, b) : -1;
+    const int hr = b >= 0 ? stepc::of_t<RAG>(hop, b / HOPS) : -1;
     sid[tid] = hr >= 0 ? b : -1;
     rowhop_[tid] = hr >= 0 ? hr : 0;
   }
   __syncthreads();
-  load_tile(XA, a.xa, sid, ring_pos(a.xa, hop), 0, tid, rowhop);
+  load_tile<HOPS>(XA, a.xa, sid, ring_pos(a.xa, hop), 0, tid, rowhop);
   __syncthreads();
   {
     const float* const seg[1] = {XA};
@@ -614,21 +618,23 @@ __device__ __forceinline__ void block_bq_body(const BlockBqArgs& a, const int g,
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int b = sid[r0 + e];
-        if (b >= 0) ring_frame(a.out, b, rowhop != nullptr ? ring_pos(a.out, rowhop[r0 + e]) : pos_o, 0)[n] = XA[(r0 + e) * AS + n] + (v[e] + bn);
+        if (b >= 0) ring_frame(a.out, b / HOPS, rowhop != nullptr ? ring_pos(a.out, rowhop[r0 + e]) : pos_o, b % HOPS)[n] = XA[(r0 + e) * AS + n] + (v[e] + bn);
       }
     });
   }
   __builtin_amdgcn_s_setprio(0);
   RC_STAMP(6);
 }
-struct BlockBqOp {
+template <int HOPS = 1>
+struct BlockBqOpH {
   using Args = BlockBqArgs;
   static constexpr int NTHR = rc::NTHR;
   static constexpr int LDS_FLOATS = kBlockBqLds;
   static constexpr double wg_cost() { return 30.0; }
-  __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { block_bq_body(a, bx, lds); }
-  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) { block_bq_body<RAG>(a, bx, lds); }
+  __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { block_bq_body<false, HOPS>(a, bx, lds); }
+  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) { block_bq_body<RAG, HOPS>(a, bx, lds); }
 };
+using BlockBqOp = BlockBqOpH<1>;
 // ---------------------------------------------------------------------------------------------------------------------
 // Any conv_gemm Layer for ONE tile of 16 rows and ALL its output columns: the A operand streams through two LDS tiles
 // one 256-long reduction segment at a time (gathered from the input ring exactly as conv_gemm does, next segment's
@@ -791,6 +797,16 @@ struct ConvRowsOp {
   __device__ static __forceinline__ void run(const ConvArgs& a, int bx, int by, float* lds) { conv_rows_body<L, COLS, RT>(a, bx, by, lds); }
   template <bool RAG> __device__ static __forceinline__ void run_t(const ConvArgs& a, int bx, int by, float* lds) { conv_rows_body<L, COLS, RT, RAG>(a, bx, by, lds); }
 };
+
+// a body type that is never added to a table (keeps the type lists of the tick launch the same length at every hops-per-step)
+struct NopOp {
+  struct Args { int unused; };
+  static constexpr int NTHR = 64;
+  static constexpr int LDS_FLOATS = 0;
+  __device__ static __forceinline__ void run(const Args&, int, int, float*) {}
+  template <bool RAG> __device__ static __forceinline__ void run_t(const Args&, int, int, float*) {}
+};
+__device__ __forceinline__ void globalize(NopOp::Args&) {}
 
 // the same body as a launch of its own (the in-order chain at large batches, wave.hip)
 template <class L, int COLS, int RT>

@@ -476,48 +476,54 @@ constexpr int kT1Streams = 4, kT2Streams = 3, kT3Streams = 2;
 // S = streams per workgroup.  The tick launch's table for FULL ticks uses 4 (T1) and 3 (T2): fewer, fuller workgroups; its table
 // for the sparse ticks of fill and drain uses 2: half as long, and a sparse launch lasts as long as its longest workgroup
 // (profiles/r04_notes.md section 4).  Same arithmetic, same state block, same rings: interchangeable from one tick to the next.
-template <int S = kT1Streams>
+// HOPS = hops per step (tick mode with several hops per stage, tick.hip.h): a stream's frames of a step are HOPS times as many --
+// the same bodies with T = HOPS x the per-hop count (the histories a layer keeps across steps do not depend on T).
+template <int S = kT1Streams, int HOPS = 1>
 struct T1OpS {
   using Args = StageArgs;
-  static constexpr int NTHR = tst::NTHR, LDS_FLOATS = stage_lds<64, 20, S, 1>();
+  static constexpr int T = 20 * HOPS;
+  static constexpr int NTHR = tst::NTHR, LDS_FLOATS = stage_lds<64, T, S, 1>();
   static inline dim3 grid(const Args& a) { return dim3((a.B + S - 1) / S, 1); }
   static inline bhip::LaunchInfo info(const Args& a) {
-    const double macs = 2.0 * 20 * 192 * 64 + 20.0 * 128 * 128;
-    return bhip::LaunchInfo{"wave.tail1", 2.0 * a.B * macs, 4.0 * (2.0 * 192 * 64 + 128.0 * 128 + a.B * (22.0 * 64 + 80 * 32 + 2 * 7 * 64))};
+    const double macs = 2.0 * T * 192 * 64 + 1.0 * T * 128 * 128;
+    return bhip::LaunchInfo{"wave.tail1", 2.0 * a.B * macs, 4.0 * (2.0 * 192 * 64 + 128.0 * 128 + a.B * ((T + 2.0) * 64 + 4 * T * 32 + 2 * 7 * 64))};
   }
   __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) {
-    res_res_up_body<64, 20, S, 32, 4, 0, TS_YB2, TS_YC2, true>(a, bx, lds);
+    res_res_up_body<64, T, S, 32, 4, 0, TS_YB2, TS_YC2, true>(a, bx, lds);
   }
   template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) {
-    res_res_up_body<64, 20, S, 32, 4, 0, TS_YB2, TS_YC2, true, RAG>(a, bx, lds);
+    res_res_up_body<64, T, S, 32, 4, 0, TS_YB2, TS_YC2, true, RAG>(a, bx, lds);
   }
 };
 using T1Op = T1OpS<kT1Streams>;
-template <int S = kT2Streams>
+template <int S = kT2Streams, int HOPS = 1>
 struct T2OpS {
   using Args = StageArgs;
-  static constexpr int NTHR = tst::NTHR, LDS_FLOATS = stage_lds<32, 80, S, 1>();
+  static constexpr int T = 80 * HOPS;
+  static constexpr int NTHR = tst::NTHR, LDS_FLOATS = stage_lds<32, T, S, 1>();
   static inline dim3 grid(const Args& a) { return dim3((a.B + S - 1) / S, 1); }
   static inline bhip::LaunchInfo info(const Args& a) {
-    const double macs = 2.0 * 80 * 96 * 32 + 80.0 * 64 * 48;
-    return bhip::LaunchInfo{"wave.tail2", 2.0 * a.B * macs, 4.0 * (2.0 * 96 * 32 + 64.0 * 48 + a.B * (80.0 * 32 + 240 * 16 + 2 * 9 * 32))};
+    const double macs = 2.0 * T * 96 * 32 + 1.0 * T * 64 * 48;
+    return bhip::LaunchInfo{"wave.tail2", 2.0 * a.B * macs, 4.0 * (2.0 * 96 * 32 + 64.0 * 48 + a.B * (1.0 * T * 32 + 3 * T * 16 + 2 * 9 * 32))};
   }
   __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) {
-    res_res_up_body<32, 80, S, 16, 3, TS_YA3, TS_YB3, TS_YC3, false>(a, bx, lds);
+    res_res_up_body<32, T, S, 16, 3, TS_YA3, TS_YB3, TS_YC3, false>(a, bx, lds);
   }
   template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) {
-    res_res_up_body<32, 80, S, 16, 3, TS_YA3, TS_YB3, TS_YC3, false, RAG>(a, bx, lds);
+    res_res_up_body<32, T, S, 16, 3, TS_YA3, TS_YB3, TS_YC3, false, RAG>(a, bx, lds);
   }
 };
 using T2Op = T2OpS<kT2Streams>;
 constexpr int kT1Lds = T1Op::LDS_FLOATS, kT2Lds = T2Op::LDS_FLOATS;
-constexpr int kT3Lds = stage_lds<16, 240, kT3Streams, 6>() + 7 * 16;
+template <int S, int HOPS> constexpr int t3_lds() { return stage_lds<16, 240 * HOPS, S, 6>() + 7 * 16; }
+constexpr int kT3Lds = t3_lds<kT3Streams, 1>();
 
 // ---------------------------------------------------------------------------------------------------------------------
 // T3: res4a, res4b (16 channels, 240 frames per stream) and the output conv: lrelu, Conv1d(16 -> 1, k7), tanh.
-template <bool RAG = false>
+template <bool RAG = false, int S = kT3Streams, int HOPS = 1>
 __device__ __forceinline__ void t3_body(const StageArgs& a, const int g, float* __restrict__ lds) {
-  constexpr int C = 16, T = 240, S = kT3Streams;
+  constexpr int C = 16, T = 240 * HOPS;
+  static_assert(S * T <= NTHR, "one thread per output sample");
   float* X = lds;
   float* Y = X + buf_floats<C, T, S>();
   float* HIN = Y + buf_floats<C, T, S>();   // [S][2][C] raw
@@ -554,21 +560,24 @@ __device__ __forceinline__ void t3_body(const StageArgs& a, const int g, float* 
       for (int j = 0; j < 7; ++j)
 #pragma unroll
         for (int c = 0; c < 16; ++c) acc = bsp::fma(x[j * cs<C>() + c], FW[j * 16 + c], acc);
-      d_out[(size_t)(b0 + s) * B_OUT_HOP + t] = bsp::tanh2(bsp::splat2(acc + fin_b)).x;   // (the packed form is the shorter one even for a single value)
+      d_out[(size_t)(b0 + s) * T + t] = bsp::tanh2(bsp::splat2(acc + fin_b)).x;   // (the packed form is the shorter one even for a single value)
     }
   }
   hin_to_state<C, S, TS_YA4, RAG>(a, HIN, b0, tid, shop);
 }
-struct T3Op {
+template <int S = kT3Streams, int HOPS = 1>
+struct T3OpS {
   using Args = StageArgs;
-  static constexpr int NTHR = tst::NTHR, LDS_FLOATS = kT3Lds;
-  static inline dim3 grid(const Args& a) { return dim3((a.B + kT3Streams - 1) / kT3Streams, 1); }
+  static constexpr int T = 240 * HOPS;
+  static constexpr int NTHR = tst::NTHR, LDS_FLOATS = t3_lds<S, HOPS>();
+  static inline dim3 grid(const Args& a) { return dim3((a.B + S - 1) / S, 1); }
   static inline bhip::LaunchInfo info(const Args& a) {
-    const double macs = 2.0 * 240 * 48 * 16 + 240.0 * 112;
-    return bhip::LaunchInfo{"wave.tail3", 2.0 * a.B * macs, 4.0 * (2.0 * 48 * 16 + 112.0 + a.B * (240.0 * 16 + 240 + 2 * 14 * 16))};
+    const double macs = 2.0 * T * 48 * 16 + 1.0 * T * 112;
+    return bhip::LaunchInfo{"wave.tail3", 2.0 * a.B * macs, 4.0 * (2.0 * 48 * 16 + 112.0 + a.B * (1.0 * T * 16 + T + 2 * 14 * 16))};
   }
-  __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { t3_body(a, bx, lds); }
-  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) { t3_body<RAG>(a, bx, lds); }
+  __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { t3_body<false, S, HOPS>(a, bx, lds); }
+  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) { t3_body<RAG, S, HOPS>(a, bx, lds); }
 };
+using T3Op = T3OpS<kT3Streams, 1>;
 
 }  // namespace tst

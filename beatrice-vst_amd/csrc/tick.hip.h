@@ -23,6 +23,8 @@
 //     byte range a consumer stage reads from its step's snapshot into that stage's private arrays at the tick the step
 //     arrives there (consumers: k-NN, pitch head, conditioning mix, the attention half of each block).
 #pragma once
+#include <type_traits>
+
 #include "chain_layers.hip.h"
 #include "fuse.hip.h"
 #include "rowchain.hip.h"
@@ -67,71 +69,93 @@ using namespace wave_layers;
 #ifndef TICK_RB_COLS
 #define TICK_RB_COLS 128
 #endif
-using PL = PhoneLayers<1>;
-using QL1 = PitchLayers<1>;
 #ifndef TICK_GRU_RT
 #define TICK_GRU_RT 2
 #endif
 #ifndef TICK_MID_RT
 #define TICK_MID_RT 2
 #endif
-using OpF2 = rc::ConvRowsOp<PL::F2, 0, TICK_MID_RT>;
 // (phone.f3 with ONE row tile: it runs in the launch's second round, where short workgroups matter more than traffic --
 //  32 workgroups of 28 us end the launch later than 64 of 18 us: 3.45 -> 3.55 M frames/s at 256 streams)
 #ifndef TICK_F3_RT
 #define TICK_F3_RT 1
 #endif
-using OpF3 = rc::ConvRowsOp<PL::F3, 0, TICK_F3_RT>;
 #ifndef TICK_RB_RT
 #define TICK_RB_RT 2
 #endif
-using OpF4 = rc::ConvRowsOp<PL::F4, TICK_RB_COLS, TICK_RB_RT>;
-using OpF5 = rc::ConvRowsOp<PL::F5, TICK_RB_COLS, TICK_RB_RT>;
-using OpRB = rc::ConvRowsOp<PL::RBL, TICK_RB_COLS, TICK_RB_RT>;
-using OpOUT = rc::ConvRowsOp<PL::OUTL>;
 #ifndef TICK_P1_RT
 #define TICK_P1_RT TICK_MID_RT
 #endif
-using OpP1 = rc::ConvRowsOp<QL1::P1, 0, TICK_P1_RT>;
-using OpP23 = rc::ConvRowsOp<QL1::P23>;
-using OpPOUT = rc::ConvRowsOp<QL1::POUT>;
-using OpINP = rc::ConvRowsOp<INP<1>>;
-using OpUP1 = rc::ConvRowsOp<UP<256, 128, 5, 1>, 128, TICK_MID_RT>;   // 640 columns: five slabs
-using OpRES1A = rc::ConvRowsOp<RES<128, 1, 5>, 0, TICK_MID_RT>;
-using OpRES1B = rc::ConvRowsOp<RES<128, 3, 5>, 0, TICK_MID_RT>;
-using OpUP2 = rc::ConvRowsOp<UP<128, 64, 4, 5>, 0, TICK_MID_RT>;
-// The SPARSE table (the first ticks of a fill, while only front-end stages have a step): the bodies whose workgroups last longest
-// in half-size pieces -- one row tile per convolution workgroup (and two streams per tail workgroup, unused: see tick_run).  A
-// partly filled launch lasts as long as its longest workgroup and has idle slots to spare, so shorter workgroups in larger
-// numbers are what it wants (in a full tick they cost ~3 %: twice the weight traffic per row, more prologues).  Same arithmetic,
-// same rings: a tick may use either table.
-using OpF4s = rc::ConvRowsOp<PL::F4, TICK_RB_COLS, 1>;
-using OpF5s = rc::ConvRowsOp<PL::F5, TICK_RB_COLS, 1>;
-using OpRBs = rc::ConvRowsOp<PL::RBL, TICK_RB_COLS, 1>;
-using OpP1s = rc::ConvRowsOp<QL1::P1, 0, 1>;
-using OpUP1s = rc::ConvRowsOp<UP<256, 128, 5, 1>, 128, 1>;
-using T1s = tst::T1OpS<2>;
-using T2s = tst::T2OpS<2>;
 
 enum BodyType {
   T_F1, T_FFT, T_F2, T_F3, T_F4, T_F5, T_P1, T_RB, T_P23, T_POUT, T_HEAD, T_OUT, T_COND, T_INP, T_UP1, T_RES1A, T_RES1B, T_UP2,
   T_QGRU, T_PGRU, T_VQ, T_TAIL, T_TAIL1, T_TAIL2, T_TAIL3, T_BLKA1, T_BLKA2, T_BLKA4, T_BLKA8, T_BLKB, T_BLKBQ,
-  T_F4S, T_F5S, T_RBS, T_P1S, T_UP1S, T_TAIL1S, T_TAIL2S, T_COUNT
+  T_F4S, T_F5S, T_RBS, T_P1S, T_UP1S, T_TAIL1S, T_TAIL2S, T_QGRU1, T_PGRU1, T_COUNT
 };
-#define TICK_TYPES                                                                                                            \
-    fuse::Many<F1Op2, 1>, fuse::Many<FftOp2, 1>, fuse::Many<OpF2, 1>, fuse::Many<OpF3, 1>, fuse::Many<OpF4, 1>, fuse::Many<OpF5, 1>, \
-    fuse::Many<OpP1, 1>, fuse::Many<OpRB, 4>, fuse::Many<OpP23, 2>, fuse::Many<OpPOUT, 1>, fuse::Many<HeadOp8, 1>,                  \
-    fuse::Many<OpOUT, 1>, fuse::Many<CondOp2, 1>, fuse::Many<OpINP, 1>, fuse::Many<OpUP1, 1>, fuse::Many<OpRES1A, 1>,               \
-    fuse::Many<OpRES1B, 1>, fuse::Many<OpUP2, 1>, fuse::Many<GruOp<128, 128, TICK_GRU_RT>, 1>, fuse::Many<GruOp<256, 256, TICK_GRU_RT>, 1>,                  \
-    fuse::Many<VqOp, 1>, fuse::Many<TailOp<1>, 1>, fuse::Many<tst::T1Op, 1>, fuse::Many<tst::T2Op, 1>, fuse::Many<tst::T3Op, 1>, fuse::Many<rc::BlockAOp<1>, 1>, fuse::Many<rc::BlockAOp<2>, 1>,                 \
-    fuse::Many<rc::BlockAOp<4>, 1>, fuse::Many<rc::BlockAOp<8>, 1>, fuse::Many<rc::BlockBOp, 4>, fuse::Many<rc::BlockBqOp, 4>,                     \
-    fuse::Many<OpF4s, 1>, fuse::Many<OpF5s, 1>, fuse::Many<OpRBs, 4>, fuse::Many<OpP1s, 1>, fuse::Many<OpUP1s, 1>, fuse::Many<T1s, 1>, fuse::Many<T2s, 1>
-using Tab = fuse::Table<TICK_TYPES>;
-using Builder = fuse::TableBuilder<TICK_TYPES>;
+// The bodies of a tick with H hops per stage (H = 1: a step is one 10 ms hop of every stream; H = 2: two -- every stage then
+// works on twice the rows per weight fragment and per launch, and a launch's fixed costs are paid once per two hops; the two
+// recurrent layers run their two hops one after the other inside a workgroup).  Same layer types as the in-order chain at H hops
+// per step: rows are (stream, frame of the step), the recurrences (GRU, pitch head, the tail's histories) run in frame order.
+template <int H>
+struct Ops {
+  using PL = PhoneLayers<H>;
+  using QL1 = PitchLayers<H>;
+  using OpF2 = rc::ConvRowsOp<typename PL::F2, 0, TICK_MID_RT>;
+  using OpF3 = rc::ConvRowsOp<typename PL::F3, 0, TICK_F3_RT>;
+  using OpF4 = rc::ConvRowsOp<typename PL::F4, TICK_RB_COLS, TICK_RB_RT>;
+  using OpF5 = rc::ConvRowsOp<typename PL::F5, TICK_RB_COLS, TICK_RB_RT>;
+  using OpRB = rc::ConvRowsOp<typename PL::RBL, TICK_RB_COLS, TICK_RB_RT>;
+  using OpOUT = rc::ConvRowsOp<typename PL::OUTL>;
+  using OpP1 = rc::ConvRowsOp<typename QL1::P1, 0, TICK_P1_RT>;
+  using OpP23 = rc::ConvRowsOp<typename QL1::P23>;
+  using OpPOUT = rc::ConvRowsOp<typename QL1::POUT>;
+  using OpINP = rc::ConvRowsOp<INP<H>>;
+  using OpUP1 = rc::ConvRowsOp<UP<256, 128, 5, H>, 128, TICK_MID_RT>;   // 640 columns: five slabs
+  using OpRES1A = rc::ConvRowsOp<RES<128, 1, 5 * H>, 0, TICK_MID_RT>;
+  using OpRES1B = rc::ConvRowsOp<RES<128, 3, 5 * H>, 0, TICK_MID_RT>;
+  using OpUP2 = rc::ConvRowsOp<UP<128, 64, 4, 5 * H>, 0, TICK_MID_RT>;
+  // The SPARSE table (the first ticks of a fill, while only front-end stages have a step): the bodies whose workgroups last longest
+  // in half-size pieces -- one row tile per convolution workgroup (and half the streams per tail workgroup, unused: see tick_run).  A
+  // partly filled launch lasts as long as its longest workgroup and has idle slots to spare, so shorter workgroups in larger
+  // numbers are what it wants (in a full tick they cost ~3 %: twice the weight traffic per row, more prologues).  Same arithmetic,
+  // same rings: a tick may use either table.
+  using OpF4s = rc::ConvRowsOp<typename PL::F4, TICK_RB_COLS, 1>;
+  using OpF5s = rc::ConvRowsOp<typename PL::F5, TICK_RB_COLS, 1>;
+  using OpRBs = rc::ConvRowsOp<typename PL::RBL, TICK_RB_COLS, 1>;
+  using OpP1s = rc::ConvRowsOp<typename QL1::P1, 0, 1>;
+  using OpUP1s = rc::ConvRowsOp<UP<256, 128, 5, H>, 128, 1>;
+  // the tail's stages: streams per workgroup so that a workgroup holds the same number of rows at every H (80 / 240 / 480; H = 2: T2 160)
+  using T1 = tst::T1OpS<(H == 1 ? tst::kT1Streams : 4 / H), H>;
+  using T2 = tst::T2OpS<(H == 1 ? tst::kT2Streams : 1), H>;
+  using T3 = tst::T3OpS<(H == 1 ? tst::kT3Streams : 1), H>;
+  using T1s = tst::T1OpS<(H == 1 ? 2 : 1), H>;
+  using T2s = tst::T2OpS<(H == 1 ? 2 : 1), H>;
+  // The GRUs: the column-split cell (fused_small.hip.h; 32 streams x 16 hidden units per workgroup, a weight fragment held in
+  // registers).  Hop t of a step needs the whole state vector of hop t - 1: with two hops per step the cell of hop 0 PUBLISHES
+  // its state as tagged granules and the cell of hop 1 -- a second set of workgroups of the SAME launch and stage, later in
+  // dispatch order (tick_build_table) -- polls them (GruArgs::link_*): the one place where workgroups of a tick wait for each other.
+  static_assert(H <= 2, "one link per GRU");
+  using GruQ = GruOp<128, 128, TICK_GRU_RT, (H > 1 ? 1 : 0)>;
+  using GruP = GruOp<256, 256, TICK_GRU_RT, (H > 1 ? 1 : 0)>;
+  using GruQ1 = std::conditional_t<H == 1, rc::NopOp, GruOp<128, 128, TICK_GRU_RT, 2>>;
+  using GruP1 = std::conditional_t<H == 1, rc::NopOp, GruOp<256, 256, TICK_GRU_RT, 2>>;
+  template <class... Ms> struct List { using Tab = fuse::Table<Ms...>; using Builder = fuse::TableBuilder<Ms...>; };
+  using L = List<
+      fuse::Many<F1Op2, 1>, fuse::Many<FftOp2, 1>, fuse::Many<OpF2, 1>, fuse::Many<OpF3, 1>, fuse::Many<OpF4, 1>, fuse::Many<OpF5, 1>,
+      fuse::Many<OpP1, 1>, fuse::Many<OpRB, 4>, fuse::Many<OpP23, 2>, fuse::Many<OpPOUT, 1>, fuse::Many<HeadOp8, 1>,
+      fuse::Many<OpOUT, 1>, fuse::Many<CondOp2, 1>, fuse::Many<OpINP, 1>, fuse::Many<OpUP1, 1>, fuse::Many<OpRES1A, 1>,
+      fuse::Many<OpRES1B, 1>, fuse::Many<OpUP2, 1>, fuse::Many<GruQ, 1>, fuse::Many<GruP, 1>,
+      fuse::Many<VqOp, 1>, fuse::Many<TailOp<H>, 1>, fuse::Many<T1, 1>, fuse::Many<T2, 1>, fuse::Many<T3, 1>, fuse::Many<rc::BlockAOp<1, H>, 1>, fuse::Many<rc::BlockAOp<2, H>, 1>,
+      fuse::Many<rc::BlockAOp<4, H>, 1>, fuse::Many<rc::BlockAOp<8, H>, 1>, fuse::Many<rc::BlockBOpH<H>, 4>, fuse::Many<rc::BlockBqOpH<H>, 4>,
+      fuse::Many<OpF4s, 1>, fuse::Many<OpF5s, 1>, fuse::Many<OpRBs, 4>, fuse::Many<OpP1s, 1>, fuse::Many<OpUP1s, 1>, fuse::Many<T1s, 1>, fuse::Many<T2s, 1>,
+      fuse::Many<GruQ1, 1>, fuse::Many<GruP1, 1>>;
+  using Tab = typename L::Tab;
+  using Builder = typename L::Builder;
+};
 
 // Stage of each body.  Front end: the in-order chain's launch order, the pitch estimator zipped into the content
 // encoder's stages from the fourth launch on (its spectrum ring then has its reader one stage later, like every other
-// ring).  A conditioned block is two stages (rowchain.hip.h).
+// ring).  A conditioned block is two stages (rowchain.hip.h).  The same plan at every number of hops per step.
 struct Plan {
   static constexpr int F1 = 0, F2 = 1, F3 = 2, F4 = 3, FFT = 3, F5 = 4, P1 = 4, RB0 = 5, P2 = 5, QGRU = 7, POUT = 8, PGRU = 9, HEAD = 9,
                        OUT = 10, COND = 10, VQ = 11, INP = 12, BLK0 = 13;
@@ -142,6 +166,7 @@ struct Plan {
   bool split_tail = true;
   int count() const { return tail() + (split_tail ? 3 : 1); }
 };
+constexpr int kMaxHops = 2;   // hops per stage per tick the launch is built for (Ops<1>, Ops<2>)
 static_assert(Plan::BLK0 + Plan::per_block * B_NBLOCKS + 7 <= kMaxStages && kMaxStages + 2 <= kRing && kMaxStages <= fuse::kMaxStepPairs, "stage bookkeeping");
 
 struct Consumer {  // a kernel that reads per-stream settings: its private copy of a byte range of the settings block
@@ -153,9 +178,9 @@ struct Consumer {  // a kernel that reads per-stream settings: its private copy 
 
 struct State {
   bool on = false;
-  Tab* d_table = nullptr;
+  void* d_table = nullptr;           // Ops<H>::Tab on the device
   int table_total = 0;
-  Tab* d_table_sparse = nullptr;     // the same stages with the long bodies in half-size pieces (fill and drain ticks)
+  void* d_table_sparse = nullptr;    // the same stages with the long bodies in half-size pieces (fill and drain ticks)
   int table_sparse_total = 0;
   double table_flops = 0, table_bytes = 0;  // algorithmic work of one full tick (sum over the bodies)
   unsigned long long* d_trace = nullptr;  // BEATRICE_HIP_TICK_TRACE=<file>: per-workgroup timeline of the last full tick
@@ -183,6 +208,10 @@ struct State {
   hipEvent_t hv_ev[kStaging] = {};
   bool hv_pending[kStaging] = {};
   bool step_ragged[kRing] = {};       // step u (at [u % kRing]) carries per-stream counters
+  // several hops per step: the granules that link the GRU cells of a step's hops inside a launch (fused_small.hip.h GruArgs::link_*)
+  unsigned long long* d_link_q = nullptr;   // [B][128]
+  unsigned long long* d_link_p = nullptr;   // [B][256]
+  int* h_link_dead = nullptr;               // pinned: a cell gave a wait up
 };
 
 }  // namespace tick

@@ -362,6 +362,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
     ap.add_argument("--speakers", type=int, default=None)
+    ap.add_argument("--hops-per-step", type=int, default=None, choices=(1, 2),
+                    help="10 ms hops of every stream per step (tick pipeline: hops per stage per launch); default 2 for configs 2 and 3 "
+                         "with the tick pipeline, 1 otherwise")
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4),
                     help="BASELINE.json configs index: 2 = 256 streams/GPU, 1 speaker (default, the headline); "
                          "3 = 256 streams/GPU, 64 rotating speakers, VQ k=4; 4 = 64 streams/GPU, 48 kHz stereo, wrapper on the device")
@@ -450,6 +453,11 @@ def main():
         a.streams = a.total_streams // world
         scaling = "strong"
     B = a.streams
+    if a.hops_per_step is None:
+        a.hops_per_step = 2 if (a.config in (2, 3) and a.pipeline == "tick" and not a.copy_io) else 1
+    H = a.hops_per_step
+    if H > 1 and (a.config == 4 or a.pipeline != "tick" or a.copy_io):
+        raise SystemExit("--hops-per-step 2 is the tick pipeline's form (configs 2 and 3, resident I/O)")
     tmp = tempfile.TemporaryDirectory()
     model_dir = tmp.name
     if rank == 0:
@@ -468,7 +476,7 @@ def main():
                                                            model_dir, rank, world, dist, torch)
     if rank == 0:
         m.tables = bv.SpeakerTables(product, model_dir)
-    batch = bv.Batch(m, B, max_speakers=a.speakers + 1, upload_tables=(rank == 0))
+    batch = bv.Batch(m, B, max_speakers=a.speakers + 1, hops_per_step=H, upload_tables=(rank == 0))
     table_bytes, table_path = shard.share_speaker_tables(product, batch.h, a.speakers + 1, rank, world, dist, torch,
                                                          host_tables=m.tables if rank == 0 else None)
     bcast_bytes += table_bytes
@@ -488,14 +496,14 @@ def main():
     if a.config == 3:
         product.BeatriceBatch_SetVQNumNeighbors(batch.h, -1, 4)
 
-    # synthetic audio, resident on the device: 64 hops x B streams, cycled
+    # synthetic audio, resident on the device: 64 steps (of H hops) x B streams, cycled
     n_cycle = 64
-    audio = np.stack([bv.synth_audio(160 * n_cycle, seed=rank * 100000 + s, silence_gap=(s % 10 == 3)) for s in range(B)])  # (every tenth stream: 0.5 s of digital silence)
-    audio = np.ascontiguousarray(audio.reshape(B, n_cycle, 160).transpose(1, 0, 2))
+    audio = np.stack([bv.synth_audio(160 * H * n_cycle, seed=rank * 100000 + s, silence_gap=(s % 10 == 3)) for s in range(B)])  # (every tenth stream: 0.5 s of digital silence)
+    audio = np.ascontiguousarray(audio.reshape(B, n_cycle, H * 160).transpose(1, 0, 2))
     d_audio = torch.from_numpy(audio).cuda()
     resident = a.config != 4 and not a.copy_io
-    d_out = torch.zeros((n_cycle if resident else 1, B, 240), dtype=torch.float32, device="cuda")
-    base, hop_bytes = d_audio.data_ptr(), B * 160 * 4
+    d_out = torch.zeros((n_cycle if resident else 1, B, H * 240), dtype=torch.float32, device="cuda")
+    base, hop_bytes = d_audio.data_ptr(), B * H * 160 * 4
     a.pipeline_request = a.pipeline
     tick48 = False
     if a.config == 4 or a.pipeline == "off":
@@ -533,9 +541,10 @@ def main():
 
     def step(i):
         if a.config == 3 and i > 0:  # every stream moves to the next speaker every 200 hops, staggered by stream index
-            for s in switchers[i % 200]:
-                current_speaker[s] = (current_speaker[s] + 1) % a.speakers
-                product.BeatriceBatch_SetTargetSpeaker(batch.h, s, current_speaker[s])
+            for hop in range(i * H, (i + 1) * H):   # (settings travel with the step: the switches of its hops, before it)
+                for s in switchers[hop % 200]:
+                    current_speaker[s] = (current_speaker[s] + 1) % a.speakers
+                    product.BeatriceBatch_SetTargetSpeaker(batch.h, s, current_speaker[s])
         if a.config == 4 and tick48:
             rc = product.BeatriceBatch_ConvertBlocks48kDevice(batch.h, None, None, 2)
         elif a.config == 4:
@@ -577,31 +586,32 @@ def main():
     out_rms = float((d_out48 if a.config == 4 else d_out).float().pow(2).mean().sqrt().item())
 
     if rank == 0:
-        frames = world * B * a.steps
+        frames = world * B * a.steps * H
         res = {
             "metric": "audio frames/sec (24 kHz out, 10 ms hop)", "value": round(frames / elapsed, 1), "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": {2: "BASELINE.json configs[2]: %d concurrent streams per GPU, %d speaker(s), 10 ms hop "
-                                       "(160 in @16 kHz -> 240 out @24 kHz), synthetic weights of MODEL_SPEC v1" % (B, a.speakers),
+                                       "(160 in @16 kHz -> 240 out @24 kHz), synthetic weights of MODEL_SPEC v1; a step = %d consecutive hop(s) of every stream" % (B, a.speakers, H),
                                     3: "BASELINE.json configs[3] per-GPU share: %d streams, %d speakers, every stream switches "
                                        "speaker every 200 hops (K/V blocks one per hop), VQ k=4" % (B, a.speakers),
                                     4: "BASELINE.json configs[4] per-GPU share: %d streams of 48 kHz stereo, downmix + resample "
                                        "wrapper on the device, 480-sample blocks" % B}[a.config],
-                       "streams_per_gpu": B, "speakers": a.speakers, "hipgraph": not a.no_graph, "device_warm_ms": a.device_warm_ms,
+                       "streams_per_gpu": B, "speakers": a.speakers, "hops_per_step": H, "frames_per_step": world * B * H, "hipgraph": not a.no_graph, "device_warm_ms": a.device_warm_ms,
                        "pipelining": ("tick: every layer of the chain its own pipeline stage (%d stages), one launch per tick on one HIP "
-                                      "stream, stage s works on the step fed s ticks earlier; steps enqueued without waiting; the timed "
-                                      "region includes the %d ticks that drain the pipeline" % (product.BeatriceBatch_TickStages(batch.h), product.BeatriceBatch_TickStages(batch.h) - 1)) if (tick or tick48)
+                                      "stream, stage s works on the step fed s ticks earlier (%d hop(s) of every stream per stage per launch); "
+                                      "steps enqueued without waiting; the timed region includes the %d ticks that drain the pipeline"
+                                      % (product.BeatriceBatch_TickStages(batch.h), H, product.BeatriceBatch_TickStages(batch.h) - 1)) if (tick or tick48)
                                      else ("%d stages of the chain on %d HIP streams; stage s of step t+1 overlaps stage s+1 of step t, "
                                       "steps enqueued without waiting; GPU_MAX_HW_QUEUES=%s" % (pipelined, pipelined, os.environ.get("GPU_MAX_HW_QUEUES"))) if pipelined
                                      else "off: one stream, in order",
                        "io": "resident 48 kHz stereo blocks, 64 per stream cycled, bound as I/O slots; resamplers and FIFO on the device either side of the tick pipeline" if tick48
-                             else "resident device buffers, 64 hops per stream cycled, bound as I/O slots (no per-step copy)" if resident
+                             else "resident device buffers, 64 steps per stream cycled, bound as I/O slots (no per-step copy)" if resident
                              else "resident device buffers, one device-to-device copy in and out per step",
                        "parallelism": "streams sharded over %d GPU(s), no per-hop collective; load: one file read on rank 0, "
                                       "%d bytes of parameters (%s) and speaker tables (%s) broadcast over RCCL" % (world, bcast_bytes, load_path, table_path),
                        "placement": a.placement if a.config == 3 else "n/a"},
-            "x_realtime_per_stream": round(a.steps / elapsed / 100.0, 2), "output_rms": round(out_rms, 4),
+            "x_realtime_per_stream": round(a.steps * H / elapsed / 100.0, 2), "output_rms": round(out_rms, 4),
             "host_enqueue_ms_per_step": round(1e3 * enqueue_s / a.steps, 4),
         }
         tick_roof = None
@@ -630,8 +640,8 @@ def main():
                              "traffic": pmc_traffic("tick", B), "traffic_unit": "bytes per launch (PMC, profiles/)",
                              "algorithmic_bytes": int(by.value), "algorithmic_flops": int(fl.value),
                              "kernel": "tick launch (fuse::table_kernel_w: one workgroup-table launch holding every stage of the "
-                                       "chain, %d stages each on its own step)" % stages,
-                             "launches_per_hop": 1, "mean_us_per_launch": round(us.value, 2), "launch_us_per_call": calls,
+                                       "chain, %d stages each on its own step of %d hop(s) per stream)" % (stages, H),
+                             "launches_per_hop": 1.0 / H, "hops_per_launch": H, "mean_us_per_launch": round(us.value, 2), "launch_us_per_call": calls,
                              "share_of_chain": round(us.value * 1e-3 / (1e3 * elapsed / a.steps), 3) if a.steps >= 200 else None}
                 summary = pmc_summary_file()
                 tick_roof["traffic_measured_at"] = ({"csrc_sha1": summary["csrc_sha1"], "commit": summary.get("commit")} if summary else
@@ -646,12 +656,20 @@ def main():
                 for i in range(600):
                     step(i)
                 product.BeatriceBatch_Synchronize(batch.h)
-                res["steady_state"] = {"steps": 600, "frames_per_s": round(B * 600 / (time.perf_counter() - t1), 1),
+                res["steady_state"] = {"steps": 600, "frames_per_s": round(B * H * 600 / (time.perf_counter() - t1), 1),
                                        "note": "same loop, 600 steps: fill and drain (%d ticks) amortised" % (stages - 1)}
         if not a.no_extras:
             # per-kernel timing with HIP events on the library's own stream (eager, 10 launches per bracket), chain in order
             if tick:
                 product.BeatriceBatch_EnableTickPipeline(batch.h, 0)
+            if H > 1:   # the per-kernel table below is of the in-order chain at ONE hop per step: a batch of its own
+                batch.close()
+                batch = bv.Batch(m, B, max_speakers=a.speakers + 1)
+                for s_ in range(B):
+                    product.BeatriceBatch_SetTargetSpeaker(batch.h, s_, current_speaker[s_])
+                product.BeatriceBatch_FlushSpeaker(batch.h, -1)
+                if a.config == 3:
+                    product.BeatriceBatch_SetVQNumNeighbors(batch.h, -1, 4)
             rows = batch.profile_kernels(repeats=10)
             for r in rows:
                 r["total_us"] = r["mean_us"] * r["launches"]
@@ -682,8 +700,8 @@ def main():
             chain_flops = sum(r["flops"] * r["launches"] for r in rows)
             res["chain"] = {"launches_per_hop": sum(r["launches"] for r in rows),
                             "sum_kernel_us": round(total_us, 1), "gflop_per_step": round(chain_flops / 1e9, 3),
-                            "tflops_end_to_end": round(chain_flops / (elapsed / a.steps) / 1e12, 2),
-                            "mfma_frac_end_to_end": round(chain_flops / (elapsed / a.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                            "tflops_end_to_end": round(chain_flops * H / (elapsed / a.steps) / 1e12, 2),
+                            "mfma_frac_end_to_end": round(chain_flops * H / (elapsed / a.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                             "state_bytes_per_stream": int(product.BeatriceBatch_StateBytes(batch.h)) // B}
             res["kernels"] = [{"name": r["name"], "n": r["launches"], "us": round(r["mean_us"], 2)}
                               for r in sorted(rows, key=lambda r: -r["total_us"])[:12]]

@@ -1,0 +1,114 @@
+"""Tick pipelining with TWO hops per stage per tick (a batch created with BeatriceBatch_CreateBlock(..., 2) in tick mode):
+a step is two consecutive 10 ms hops of every stream, every stage of the launch works on twice the rows, the two recurrent
+layers run their hops one after the other inside a workgroup.  Must give the samples of the in-order chain at one hop per step bit for bit -- with settings
+that change between steps (speaker switches installing one K/V block per HOP, k-NN, pitch and formant settings), across
+drains, and on the way back to the in-order chain."""
+import itertools
+
+import numpy as np
+import pytest
+
+from test_gpu_resident_io import Hip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,steps", [(24, 40), (5, 34), (256, 36), (1, 33), (37, 70)])
+def test_tick_two_hops_per_step_matches_in_order_chain(bv, product, model_dir, B, steps):
+    H = 2
+    hip = Hip()
+    m = bv.Models(product, model_dir)
+    bv.bind_batch(product)
+    tail_steps = 3   # after the pipelined part: the in-order chain (two hops per step) on the same streams
+    total = steps + tail_steps
+    audio = np.stack([bv.synth_audio(160 * H * total, seed=8100 + s) for s in range(B)])  # [B][total*320]
+
+    def settings(batch):
+        for s in range(B):
+            batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, s, s % 3)
+            batch.a.BeatriceBatch_SetVQNumNeighbors(batch.h, s, s % 3)
+        batch.a.BeatriceBatch_FlushSpeaker(batch.h, -1)
+
+    def change(batch, k):   # before STEP k (hops 2 k, 2 k + 1)
+        a, h = batch.a, batch.h
+        if k % 4 == 1:
+            s = (7 * k) % B
+            a.BeatriceBatch_SetTargetSpeaker(h, s, (k + s) % 3)            # K/V blocks follow, one per hop
+            a.BeatriceBatch_SetFormantShift(h, (s + 1) % B, float(k % 5) - 2.0)
+            a.BeatriceBatch_SetPitchShift(h, (s + 2) % B, float(k % 7) - 3.0)
+        if k % 9 == 5:
+            a.BeatriceBatch_SetVQNumNeighbors(h, (3 * k) % B, k % 5)
+        if k == 21:
+            assert a.BeatriceBatch_ResetStream(h, 2 % B) == 0
+        if k == 27:
+            a.BeatriceBatch_SetMinSourcePitch(h, 0, 50.0)
+            a.BeatriceBatch_SetPitchCorrection(h, 1 % B, 0.6)
+
+    # reference: the in-order chain, one hop per step, the script applied before every second hop
+    ref_batch = bv.Batch(m, B)
+    settings(ref_batch)
+    ref = np.zeros((total, B, H * 240), np.float32)
+    for k in range(total):
+        change(ref_batch, k)
+        for hh in range(H):
+            j = k * H + hh
+            ref[k][:, hh * 240:(hh + 1) * 240] = ref_batch.convert(audio[:, j * 160:(j + 1) * 160])
+    ref_batch.close()
+
+    batch = bv.Batch(m, B, hops_per_step=H)
+    settings(batch)
+    a, h = batch.a, batch.h
+    stages = a.BeatriceBatch_TickStages(h)
+    assert stages == 28
+    slots = stages + 5
+    d_in, d_out = hip.malloc(slots * B * H * 160 * 4), hip.malloc(slots * B * H * 240 * 4)
+    assert a.BeatriceBatch_BindResidentIO(h, d_in, d_out, slots) == 0
+    assert a.BeatriceBatch_EnableTickPipeline(h, 1) == 0
+    assert a.BeatriceBatch_EnableSilentBlockRule(h, 1) == -1     # (per-stream step counters: one hop per step only)
+    got = np.zeros_like(ref)
+    k0 = 0
+    for chunk in itertools.cycle((slots, 7, slots - 3)):
+        n = min(chunk, steps - k0)
+        if n <= 0:
+            break
+        buf = np.zeros((slots, B, H * 160), np.float32)
+        hip.d2h(buf, d_in)
+        for k in range(k0, k0 + n):
+            buf[k % slots] = audio[:, k * H * 160:(k + 1) * H * 160]
+        hip.h2d(d_in, buf)
+        for k in range(k0, k0 + n):
+            change(batch, k)
+            assert a.BeatriceBatch_ConvertFramesDevice(h, None, None) == 0
+        assert a.BeatriceBatch_Synchronize(h) == 0
+        out = np.zeros((slots, B, H * 240), np.float32)
+        hip.d2h(out, d_out)
+        for k in range(k0, k0 + n):
+            got[k] = out[k % slots]
+        k0 += n
+    # back to the in-order chain: same streams, same slots, state carried over
+    assert a.BeatriceBatch_EnableTickPipeline(h, 0) == 0
+    buf = np.zeros((slots, B, H * 160), np.float32)
+    for k in range(steps, total):
+        buf[k % slots] = audio[:, k * H * 160:(k + 1) * H * 160]
+    hip.h2d(d_in, buf)
+    for k in range(steps, total):
+        change(batch, k)
+        assert a.BeatriceBatch_ConvertFramesDevice(h, None, None) == 0
+    assert a.BeatriceBatch_Synchronize(h) == 0
+    out = np.zeros((slots, B, H * 240), np.float32)
+    hip.d2h(out, d_out)
+    for k in range(steps, total):
+        got[k] = out[k % slots]
+    batch.close()
+    m.close()
+    hip.free(d_in); hip.free(d_out)
+    bad = [k for k in range(total) if not np.array_equal(ref[k], got[k])]
+    if bad:
+        k = bad[0]
+        rows = sorted(set(np.argwhere(ref[k] != got[k])[:, 0].tolist()))
+        cols = np.argwhere(ref[k] != got[k])[:, 1]
+        print("first differing step %d: streams %s, samples %d..%d" % (k, rows[:16], cols.min(), cols.max()))
+    print("tick pipeline, 2 hops per step, B=%d, %d stages, %d steps: %s" % (B, stages, steps, "bit-identical" if not bad else
+          "steps that differ: %s, max-abs %g" % (bad[:12], np.abs(ref - got).max())))
+    assert np.abs(got).max() > 0.05
+    assert not bad

@@ -11,9 +11,10 @@ product = bv.bind_batch(bv.load_product())
 tmp = tempfile.TemporaryDirectory(); make_model.make_model(tmp.name, n_speakers=1)
 m = bv.Models(product, tmp.name)
 B, n = (int(sys.argv[1]) if len(sys.argv) > 1 else 256), 64
-batch = bv.Batch(m, B)
-d_in = torch.randn((n, B, 160), device="cuda") * 0.1
-d_out = torch.zeros((n, B, 240), device="cuda")
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 1   # hops per step (third argument; the second: "ragged" or "-")
+batch = bv.Batch(m, B, hops_per_step=H)
+d_in = torch.randn((n, B, H * 160), device="cuda") * 0.1
+d_out = torch.zeros((n, B, H * 240), device="cuda")
 assert product.BeatriceBatch_BindResidentIO(batch.h, d_in.data_ptr(), d_out.data_ptr(), n) == 0
 assert product.BeatriceBatch_EnableTickPipeline(batch.h, 1) == 0
 if len(sys.argv) > 2 and sys.argv[2] == "ragged":   # the second instance of the launch: one step with a tenth of the streams sitting it out
@@ -30,4 +31,7 @@ t0 = time.perf_counter()
 for _ in range(400):
     product.BeatriceBatch_ConvertFramesDevice(batch.h, None, None)
 torch.cuda.synchronize()
-print("loop without drain: %.2f us per tick" % ((time.perf_counter() - t0) / 400 * 1e6))
+dt = (time.perf_counter() - t0) / 400 * 1e6
+print("loop without drain: %.2f us per tick of %d hop(s) x %d streams = %.3f M frames/s" % (dt, H, B, H * B / dt))
+if os.environ.get("BEATRICE_HIP_TICK_TRACE"):   # the drain dumps the per-workgroup timeline of the last full tick
+    product.BeatriceBatch_Synchronize(batch.h)
