@@ -200,6 +200,92 @@ static __global__ __launch_bounds__(512) void phone_vq_kernel(const VqArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[kVqLdsFloats];
   phone_vq_body(a, blockIdx.x, lds);
 }
+// The same for the NH hops of a step in ONE workgroup (the tick launch with several hops per stage): a lookup is bound by the
+// 256 KB of codebook a workgroup pulls through its CU's L1, and the hops of a stream almost always share their codebook -- then
+// every codebook element is read once and feeds NH distances.  Per row the operations of phone_vq_body, in its order.
+template <bool RAG, int NH>
+__device__ __forceinline__ void phone_vq_rows_body(const VqArgs& a, const int b, float* __restrict__ lds) {
+  float* x = lds;                                                    // [NH][128]
+  float* red_d = lds + NH * B_PHONE_CH;                              // [8]
+  int* red_j = reinterpret_cast<int*>(lds + NH * B_PHONE_CH + 8);    // [8]
+  int& winner = *reinterpret_cast<int*>(lds + NH * B_PHONE_CH + 16);
+  const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
+  const int step = stepc::step(a.hop);
+  if (step < 0) return;
+  const int hop = stepc::of_t<RAG>(step, b);
+  if (hop < 0) return;
+  const int k = a.k[b];
+  const float* cb[NH];
+  bool same = true;
+#pragma unroll
+  for (int h = 0; h < NH; ++h) { cb[h] = as_global_v(a.cbT[b * NH + h]); same = same && cb[h] == cb[0]; }
+  if (j < B_PHONE_CH) {
+#pragma unroll
+    for (int h = 0; h < NH; ++h) x[h * B_PHONE_CH + j] = ring_frame(a.raw, b, ring_pos(a.raw, hop), h)[j];
+  }
+  __syncthreads();
+  float dot[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) dot[h] = 0.0f;
+  if (k > 0 && same && cb[0] != nullptr) {
+#pragma unroll 16
+    for (int c = 0; c < B_PHONE_CH; ++c) {
+      const float v = cb[0][c * B_CODEBOOK + j];
+#pragma unroll
+      for (int h = 0; h < NH; ++h) dot[h] = bsp::fma(x[h * B_PHONE_CH + c], v, dot[h]);
+    }
+  } else if (k > 0) {
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+      if (cb[h] != nullptr) {
+#pragma unroll 8
+        for (int c = 0; c < B_PHONE_CH; ++c) dot[h] = bsp::fma(x[h * B_PHONE_CH + c], cb[h][c * B_CODEBOOK + j], dot[h]);
+      }
+  }
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    float* out = ring_frame(a.out, b, ring_pos(a.out, hop), h);
+    if (k <= 0 || cb[h] == nullptr) {   // (uniform over the workgroup)
+      if (j < B_PHONE_CH) out[j] = x[h * B_PHONE_CH + j];
+      continue;
+    }
+    float d = bsp::fma(-2.0f, dot[h], as_global_v(a.cnorm[b * NH + h])[j]);
+    float acc = 0.0f;
+    for (int r = 0; r < k; ++r) {
+      float bd = d;
+      int bj = j;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const float od = __shfl_xor(bd, off, 64);
+        const int oj = __shfl_xor(bj, off, 64);
+        if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
+      }
+      if (lane == 0) { red_d[wave] = bd; red_j[wave] = bj; }
+      __syncthreads();
+      if (j == 0) {
+        float wd = red_d[0];
+        int wj = red_j[0];
+        for (int w = 1; w < 8; ++w)
+          if (red_d[w] < wd || (red_d[w] == wd && red_j[w] < wj)) { wd = red_d[w]; wj = red_j[w]; }
+        winner = wj;
+      }
+      __syncthreads();
+      const int wj = winner;
+      if (j == wj) d = __builtin_huge_valf();
+      if (j < B_PHONE_CH) acc = acc + cb[h][j * B_CODEBOOK + wj];
+      __syncthreads();
+    }
+    if (j < B_PHONE_CH) out[j] = acc / (float)k;
+  }
+}
+template <int NH>
+struct VqRowsOp {   // grid (streams, 1)
+  using Args = VqArgs;
+  static constexpr int NTHR = 512;
+  static constexpr int LDS_FLOATS = NH * B_PHONE_CH + 24;
+  __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { phone_vq_rows_body<false, NH>(a, bx, lds); }
+  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) { phone_vq_rows_body<RAG, NH>(a, bx, lds); }
+};
 struct VqOp {
   using Args = VqArgs;
   static constexpr int NTHR = 512;

@@ -139,13 +139,14 @@ struct Ops {
   using GruP = GruOp<256, 256, TICK_GRU_RT, (H > 1 ? 1 : 0)>;
   using GruQ1 = std::conditional_t<H == 1, rc::NopOp, GruOp<128, 128, TICK_GRU_RT, 2>>;
   using GruP1 = std::conditional_t<H == 1, rc::NopOp, GruOp<256, 256, TICK_GRU_RT, 2>>;
+  using Vq = std::conditional_t<H == 1, VqOp, VqRowsOp<H>>;   // (several hops: a stream's rows in one workgroup, the codebook read once)
   template <class... Ms> struct List { using Tab = fuse::Table<Ms...>; using Builder = fuse::TableBuilder<Ms...>; };
   using L = List<
       fuse::Many<F1Op2, 1>, fuse::Many<FftOp2, 1>, fuse::Many<OpF2, 1>, fuse::Many<OpF3, 1>, fuse::Many<OpF4, 1>, fuse::Many<OpF5, 1>,
       fuse::Many<OpP1, 1>, fuse::Many<OpRB, 4>, fuse::Many<OpP23, 2>, fuse::Many<OpPOUT, 1>, fuse::Many<HeadOp8, 1>,
       fuse::Many<OpOUT, 1>, fuse::Many<CondOp2, 1>, fuse::Many<OpINP, 1>, fuse::Many<OpUP1, 1>, fuse::Many<OpRES1A, 1>,
       fuse::Many<OpRES1B, 1>, fuse::Many<OpUP2, 1>, fuse::Many<GruQ, 1>, fuse::Many<GruP, 1>,
-      fuse::Many<VqOp, 1>, fuse::Many<TailOp<H>, 1>, fuse::Many<T1, 1>, fuse::Many<T2, 1>, fuse::Many<T3, 1>, fuse::Many<rc::BlockAOp<1, H>, 1>, fuse::Many<rc::BlockAOp<2, H>, 1>,
+      fuse::Many<Vq, 1>, fuse::Many<TailOp<H>, 1>, fuse::Many<T1, 1>, fuse::Many<T2, 1>, fuse::Many<T3, 1>, fuse::Many<rc::BlockAOp<1, H>, 1>, fuse::Many<rc::BlockAOp<2, H>, 1>,
       fuse::Many<rc::BlockAOp<4, H>, 1>, fuse::Many<rc::BlockAOp<8, H>, 1>, fuse::Many<rc::BlockBOpH<H>, 4>, fuse::Many<rc::BlockBqOpH<H>, 4>,
       fuse::Many<OpF4s, 1>, fuse::Many<OpF5s, 1>, fuse::Many<OpRBs, 4>, fuse::Many<OpP1s, 1>, fuse::Many<OpUP1s, 1>, fuse::Many<T1s, 1>, fuse::Many<T2s, 1>,
       fuse::Many<GruQ1, 1>, fuse::Many<GruP1, 1>>;
