@@ -112,3 +112,50 @@ def test_tick_two_hops_per_step_matches_in_order_chain(bv, product, model_dir, B
           "steps that differ: %s, max-abs %g" % (bad[:12], np.abs(ref - got).max())))
     assert np.abs(got).max() > 0.05
     assert not bad
+
+
+def test_tick_two_hops_per_step_with_a_morph_slot(bv, product, model_dir):
+    """A morphed speaker draws a codebook per stream and HOP (processor_core_2.cc:94-121): the two hops of a step may then use
+    different codebooks (the k-NN body's separate-codebook path), and the draws must come in the order of one hop per step."""
+    H, B, steps = 2, 12, 40
+    hip = Hip()
+    m = bv.Models(product, model_dir)
+    bv.bind_batch(product)
+    n = m.tables.n_speakers
+    audio = np.stack([bv.synth_audio(160 * H * steps, seed=8300 + s) for s in range(B)])
+    w = np.zeros(n, np.float32)
+    w[:3] = (0.5, 0.3, 0.2)
+
+    def setup(batch):
+        a, h = batch.a, batch.h
+        assert a.BeatriceBatch_MorphSpeaker(h, n, bv.fptr(w), n, 1234) == 0
+        for s in range(B):
+            a.BeatriceBatch_SetTargetSpeaker(h, s, n if s % 2 == 0 else s % n)
+            a.BeatriceBatch_SetVQNumNeighbors(h, s, 1 + s % 3)
+        a.BeatriceBatch_FlushSpeaker(h, -1)
+
+    ref_batch = bv.Batch(m, B)
+    setup(ref_batch)
+    ref = np.stack([ref_batch.convert(np.ascontiguousarray(audio[:, k * 160:(k + 1) * 160])) for k in range(H * steps)])   # [hops][B][240]
+    ref_batch.close()
+    ref = ref.reshape(steps, H, B, 240).transpose(0, 2, 1, 3).reshape(steps, B, H * 240)
+
+    batch = bv.Batch(m, B, hops_per_step=H)
+    setup(batch)
+    a, h = batch.a, batch.h
+    slots = steps
+    d_in, d_out = hip.malloc(slots * B * H * 160 * 4), hip.malloc(slots * B * H * 240 * 4)
+    hip.h2d(d_in, np.ascontiguousarray(audio.reshape(B, steps, H * 160).transpose(1, 0, 2)))
+    assert a.BeatriceBatch_BindResidentIO(h, d_in, d_out, slots) == 0
+    assert a.BeatriceBatch_EnableTickPipeline(h, 1) == 0
+    for k in range(steps):
+        assert a.BeatriceBatch_ConvertFramesDevice(h, None, None) == 0
+    assert a.BeatriceBatch_Synchronize(h) == 0
+    got = np.zeros((slots, B, H * 240), np.float32)
+    hip.d2h(got, d_out)
+    bad = [(k, int(s_)) for k in range(steps) for s_ in np.nonzero(np.abs(got[k] - ref[k]).max(axis=1))[0]]
+    assert not bad, "differing (step, stream): %s" % bad[:30]
+    assert np.abs(ref).max() > 0.05
+    hip.free(d_in); hip.free(d_out)
+    batch.close()
+    m.close()
