@@ -8,13 +8,14 @@ import itertools
 import numpy as np
 import pytest
 
+from oracle_batch import oracle_leg, pick_streams, scripted_streams
 from test_gpu_resident_io import Hip
 
 pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("B,steps", [(24, 40), (5, 34), (256, 36), (1, 33), (37, 70)])
-def test_tick_two_hops_per_step_matches_in_order_chain(bv, product, model_dir, B, steps):
+def test_tick_two_hops_per_step_matches_in_order_chain(bv, oracle, product, model_dir, B, steps):
     H = 2
     hip = Hip()
     m = bv.Models(product, model_dir)
@@ -112,6 +113,15 @@ def test_tick_two_hops_per_step_matches_in_order_chain(bv, product, model_dir, B
           "steps that differ: %s, max-abs %g" % (bad[:12], np.abs(ref - got).max())))
     assert np.abs(got).max() > 0.05
     assert not bad
+    # the ORACLE leg: a sample of the streams as independent oracle streams driven by the same script through the reference
+    # protocol, one hop at a time (the script's changes precede a step = every second hop)
+    sample = sorted(set(pick_streams(B, 6)) | set(scripted_streams(B, total, change, 6)))
+    sample, want = oracle_leg(bv, oracle, model_dir, B, lambda k: audio[:, k * 160:(k + 1) * 160], total * H, settings,
+                              lambda ob, hop: change(ob, hop // H) if hop % H == 0 else None, sample)
+    want = want.reshape(total, H, len(sample), 240).transpose(0, 2, 1, 3).reshape(total, len(sample), H * 240)
+    dev = float(np.abs(got[:, sample] - want).max())
+    print("tick pipeline (2 hops per step) vs ORACLE, streams %s, %d steps: max-abs %g" % (sample, total, dev))
+    assert dev <= 1e-4
 
 
 def test_tick_two_hops_per_step_with_a_morph_slot(bv, product, model_dir):

@@ -25,23 +25,23 @@ class Hip:
 
 
 def run_tick(bv, batch, steps, hop_input, change=None, slots=None, chunk=None, leave=True):
-    """Feeds `steps` steps through tick mode and returns their samples [steps][B][240].
+    """Feeds `steps` steps through tick mode and returns their samples [steps][B][H * 240] (H = the batch's hops per step).
 
-    hop_input(k) -> [B][160] is step k's input; change(batch, k) runs before step k is fed (settings travel with the step).
+    hop_input(k) -> [B][H * 160] is step k's input; change(batch, k) runs before step k is fed (settings travel with the step).
     The resident I/O has `slots` slots (default: stages + 6) used round-robin as the library does (step k <-> slot k mod
     slots); steps are fed `chunk` (<= slots) at a time without waiting, then the pipeline is drained and the chunk read back,
     so the ring wraps many times over a long run."""
     hip = Hip()
-    a, h, B = batch.a, batch.h, batch.B
+    a, h, B, H = batch.a, batch.h, batch.B, batch.H
     stages = a.BeatriceBatch_TickStages(h)
     slots = slots or stages + 6
     chunk = min(chunk or slots, slots)
-    d_in, d_out = hip.malloc(slots * B * 160 * 4), hip.malloc(slots * B * 240 * 4)
+    d_in, d_out = hip.malloc(slots * B * H * 160 * 4), hip.malloc(slots * B * H * 240 * 4)
     try:
         assert a.BeatriceBatch_BindResidentIO(h, d_in, d_out, slots) == 0
         assert a.BeatriceBatch_EnableTickPipeline(h, 1) == 0
-        got = np.zeros((steps, B, 240), np.float32)
-        buf = np.zeros((slots, B, 160), np.float32)
+        got = np.zeros((steps, B, H * 240), np.float32)
+        buf = np.zeros((slots, B, H * 160), np.float32)
         k0 = 0
         while k0 < steps:
             n = min(chunk, steps - k0)
@@ -53,7 +53,7 @@ def run_tick(bv, batch, steps, hop_input, change=None, slots=None, chunk=None, l
                     change(batch, k)
                 assert a.BeatriceBatch_ConvertFramesDevice(h, None, None) == 0
             assert a.BeatriceBatch_Synchronize(h) == 0
-            out = np.zeros((slots, B, 240), np.float32)
+            out = np.zeros((slots, B, H * 240), np.float32)
             hip.d2h(out, d_out)
             for k in range(k0, k0 + n):
                 got[k] = out[k % slots]
