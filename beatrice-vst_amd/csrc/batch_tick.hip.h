@@ -133,8 +133,8 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
   // measured twice: it cuts the launch's memory-side traffic 4x (rocprofv3 FETCH_SIZE 105 -> 26 MB per tick) and the
   // pinned workgroups run ~10-25 % shorter, but confining a body to 32 CUs costs more in makespan than that gains
   // (0.096 vs 0.090 ms per tick): off by default
-  static const bool by_xcd = std::getenv("BEATRICE_HIP_TICK_XCD") != nullptr;
-  if (by_xcd) tb->place_by_xcd();
+  static const int by_xcd = std::getenv("BEATRICE_HIP_TICK_XCD") ? std::atoi(std::getenv("BEATRICE_HIP_TICK_XCD")) : 0;   // 2, 4: groups of XCDs; anything else: 8
+  if (by_xcd) tb->place_by_xcd(by_xcd == 2 || by_xcd == 4 ? by_xcd : 8);
   if (std::getenv("BEATRICE_HIP_TICK_TRACE")) {
     if (k.d_trace) (void)hipFree(k.d_trace);
     BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&k.d_trace), sizeof(unsigned long long) * 3 * tb->t.total));

@@ -172,8 +172,8 @@ __device__ __forceinline__ void table_body(const Table<Ms...>* __restrict__ t, c
   const int lane = threadIdx.x & 63;
   // XCD-aware layout: workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only), and the table gives
   // every XCD its own contiguous run of body indices, so that a body's weights are fetched into ONE XCD's L2 and stay there
-  const int per = t->per_xcd;
-  const int id = per > 0 ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int per = t->per_xcd, groups = t->pad > 0 ? t->pad : 8;   // (groups: 8 = one XCD per body; 2 / 4 = XCDs of equal index modulo 2 / 4)
+  const int id = per > 0 ? (int)(blockIdx.x % groups) * per + (int)(blockIdx.x / groups) : (int)blockIdx.x;
   // (unused entries hold first = INT_MAX)
   const int4 mine = reinterpret_cast<const int4*>(t->span)[lane];
   const int idx = __popcll(__ballot(mine.x <= id)) - 1;
@@ -194,7 +194,7 @@ __device__ __forceinline__ void table_body(const Table<Ms...>* __restrict__ t, c
   const unsigned long long c0 = trace ? __builtin_readcyclecounter() : 0;   // shader clock (the wall clock is 100 MHz): their ratio = the clock the launch ran at
   // (a body spread over the XCDs is eight spans; span k owns the body's workgroups k, k + 8, ...: arg bits 8-11 = k, bit 12 set)
   const int local = id - sp.first;
-  const int body_wg = (sp.arg & 0x1000) ? local * 8 + ((sp.arg >> 8) & 15) : local;
+  const int body_wg = (sp.arg & 0x1000) ? local * groups + ((sp.arg >> 8) & 15) : local;
   sp.arg &= 0xff;
   run_type<0, MaxM<Ms...>::NTHR, RAG, Ms...>(t->banks, sp, body_wg, lds);
   if (trace && threadIdx.x == 0) {
@@ -241,11 +241,13 @@ struct TableBuilder {
   // `spread` (many workgroups, few weights) is dealt round-robin over all eight.  XCD x owns the index range
   // [x * per_xcd, (x + 1) * per_xcd), padded with indices that do nothing.  Launch 8 * per_xcd workgroups.
   bool spread[kMaxSpans] = {};
-  void place_by_xcd() {
+  // G = groups of XCDs: 8 = every XCD its own bodies; 2 / 4 = the XCDs of equal index modulo G share a body (a body then has
+  // half / a quarter of the chip, and its weights are fetched by 4 / 2 L2s instead of 8)
+  void place_by_xcd(const int G = 8) {
     const int n = t.n_spans;
     int n_out = 0;
-    for (int i = 0; i < n; ++i) n_out += spread[i] ? 8 : 1;
-    if (n == 0 || n_out + 8 > kMaxSpans) return;
+    for (int i = 0; i < n; ++i) n_out += spread[i] ? G : 1;
+    if (n == 0 || n_out + G > kMaxSpans || (G != 2 && G != 4 && G != 8)) return;
     int order[kMaxSpans];
     for (int i = 0; i < n; ++i) order[i] = i;
     for (int i = 0; i < n; ++i)
@@ -254,18 +256,18 @@ struct TableBuilder {
     double load[8] = {};
     int len[8] = {}, owner[kMaxSpans];
     for (int i = 0; i < n; ++i)
-      if (spread[i]) for (int x = 0; x < 8; ++x) { load[x] += cost[i] / 8; len[x] += (n_wg[i] - x + 7) / 8; }
+      if (spread[i]) for (int x = 0; x < G; ++x) { load[x] += cost[i] / G; len[x] += (n_wg[i] - x + G - 1) / G; }
     for (int oi = 0; oi < n; ++oi) {
       const int i = order[oi];
       if (spread[i]) continue;
       int best = 0;
-      for (int x = 1; x < 8; ++x) if (load[x] < load[best]) best = x;
+      for (int x = 1; x < G; ++x) if (load[x] < load[best]) best = x;
       owner[i] = best;
       load[best] += cost[i];
       len[best] += n_wg[i];
     }
     int per = 1;
-    for (int x = 0; x < 8; ++x) per = len[x] > per ? len[x] : per;
+    for (int x = 0; x < G; ++x) per = len[x] > per ? len[x] : per;
     Span old[kMaxSpans];
     for (int i = 0; i < n; ++i) old[i] = t.span[i];
     // inside an XCD: the bodies whose workgroups run longest first (they set the launch's makespan)
@@ -274,12 +276,12 @@ struct TableBuilder {
       for (int j = i + 1; j < n; ++j)
         if (cost[order[j]] / n_wg[order[j]] > cost[order[i]] / n_wg[order[i]]) { const int x = order[i]; order[i] = order[j]; order[j] = x; }
     int out = 0;
-    for (int x = 0; x < 8; ++x) {
+    for (int x = 0; x < G; ++x) {
       int at = x * per;
       for (int oi = 0; oi < n; ++oi) {
         const int i = order[oi];
         if (spread[i]) {
-          const int cnt = (n_wg[i] - x + 7) / 8;
+          const int cnt = (n_wg[i] - x + G - 1) / G;
           if (cnt <= 0) continue;
           t.span[out] = old[i];
           t.span[out].first = at;
@@ -298,7 +300,8 @@ struct TableBuilder {
     for (int i = out; i < kMaxSpans; ++i) t.span[i] = Span{0x7fffffff, 1, -1, 0};
     t.n_spans = out;
     t.per_xcd = per;
-    t.total = 8 * per;
+    t.total = G * per;
+    t.pad = G;
   }
   template <int I, class Args>
   void add(const bhip::LaunchInfo& info, const Args& a, dim3 grid, int stage, bool on = true, double wg_cost = 1.0, bool spread_over_xcds = false) {
