@@ -73,6 +73,56 @@ def test_config3_256_streams_64_rotating_speakers(bv, oracle, product, model_dir
     assert dev <= TOL
 
 
+def test_config3_shape_through_the_tick_pipeline_two_hops_per_step(bv, oracle, product, model_dir64):
+    """The form bench.py --config 3 times: 256 streams on the 64-speaker table in tick mode with two hops per stage per launch
+    (a speaker's rows then fill half an attention tile; while its streams switch, the rest are quads), every stream rotating,
+    k-NN 4 -- every stream against an independent oracle stream."""
+    from tick_driver import run_tick
+    B, S, H, steps = 256, 64, 2, 9
+    hops = H * steps
+    audio = np.stack([bv.synth_audio(160 * hops, seed=4500 + s) for s in range(B)])
+    start = [s % S for s in range(B)]
+    switch_at = [1 + (s % 5) for s in range(B)]          # step index: the switch precedes the step's first hop
+
+    mo = bv.Models(oracle, model_dir64)
+
+    def one_stream(s):
+        st = bv.Stream1(mo, speaker=start[s], vq_k=4)
+        out = np.zeros((hops, bv.OUT_HOP), np.float32)
+        for h in range(hops):
+            if h == H * switch_at[s]:
+                st.set_target_speaker((start[s] + 1) % S)
+            out[h] = st.hop(audio[s, h * 160:(h + 1) * 160])
+        st.close()
+        return out
+
+    with ThreadPoolExecutor(_workers()) as pool:
+        ref = np.stack(list(pool.map(one_stream, range(B))), axis=0)   # [B][hops][240]
+    mo.close()
+    ref = ref.reshape(B, steps, H * 240).transpose(1, 0, 2)            # [steps][B][480]
+
+    m = bv.Models(bv.bind_batch(product), model_dir64)
+    batch = bv.Batch(m, B, hops_per_step=H)
+    a, hnd = batch.a, batch.h
+    for s in range(B):
+        a.BeatriceBatch_SetTargetSpeaker(hnd, s, start[s])
+    a.BeatriceBatch_FlushSpeaker(hnd, -1)
+    a.BeatriceBatch_SetVQNumNeighbors(hnd, -1, 4)
+
+    def change(bt, k):
+        for s in range(B):
+            if k == switch_at[s]:
+                bt.a.BeatriceBatch_SetTargetSpeaker(bt.h, s, (start[s] + 1) % S)
+
+    got = run_tick(bv, batch, steps, lambda k: audio[:, k * H * 160:(k + 1) * H * 160], change)
+    batch.close()
+    m.close()
+    dev = float(np.abs(ref - got).max())
+    print("configs[3] shape in tick mode, two hops per step: max-abs %g %s" % (dev, "bit-identical" if np.array_equal(ref, got) else ""))
+    assert np.abs(got).max() > 0.05
+    assert dev <= TOL
+
+
 def test_config4_64_stereo_streams_48k(bv, oracle, product, model_dir):
     B, blocks = 64, 12
     x = np.zeros((B, 2, 480 * blocks), np.float32)
