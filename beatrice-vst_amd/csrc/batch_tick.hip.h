@@ -317,20 +317,20 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
     // (resample.h:346-361: the block emitted for step j carries the model output of step j - 1) into the 48 kHz slot of step j
     BeatriceBatch::Resident48& r = b->r48;
     Wrap48TickArgs wa{};
-    wa.channels = r.channels; wa.st = b->d_w48; wa.coef_down = b->d_coef_down; wa.coef_up = b->d_coef_up;
+    wa.channels = r.channels; wa.st = b->d_w48; wa.coef_down = b->d_coef_down; wa.coef_up = b->d_coef_up; wa.H = b->H;
     auto counters_of = [&k](long long u) -> const int* { return u >= 0 && k.step_ragged[u % kRing] ? k.d_hopv + (size_t)(u % kRing) * k.row : nullptr; };
     if (feeding) {
       wa.n_pre = b->B;
-      wa.in48 = r.d_in48 + (size_t)b->io_host * b->B * r.channels * 480;
-      wa.in16 = r.d_in16 + (size_t)b->io_host * b->B * B_IN_HOP;
+      wa.in48 = r.d_in48 + (size_t)b->io_host * b->B * b->H * r.channels * 480;
+      wa.in16 = r.d_in16 + (size_t)b->io_host * b->B * b->H * B_IN_HOP;
       wa.hv_pre = counters_of(k.n_fed);   // (the step being fed; its row was written by the prologue launch above)
     }
     if (r.deferred_slot >= 0) {
       wa.n_post = b->B;
-      wa.out48 = r.d_out48 + (size_t)r.deferred_slot * b->B * r.channels * 480;
-      wa.model_out = r.d_out24 + (size_t)r.deferred_slot * b->B * B_OUT_HOP;
+      wa.out48 = r.d_out48 + (size_t)r.deferred_slot * b->B * b->H * r.channels * 480;
+      wa.model_out = r.d_out24 + (size_t)r.deferred_slot * b->B * b->H * B_OUT_HOP;
       wa.hv_post = counters_of(r.deferred_step);
-      wa.in48_post = r.d_in48 + (size_t)r.deferred_slot * b->B * r.channels * 480;
+      wa.in48_post = r.d_in48 + (size_t)r.deferred_slot * b->B * b->H * r.channels * 480;
       r.deferred_slot = -1;
     }
     hipLaunchKernelGGL(wrap48_tick_kernel, dim3(wa.n_pre + wa.n_post), dim3(256), 0, st, wa);
@@ -398,12 +398,12 @@ bool tick_drain(BeatriceBatch* b) {
   if (ok && b->r48.on && b->r48.deferred_slot >= 0) {  // the 48 kHz block of the step the last tick completed
     BeatriceBatch::Resident48& r = b->r48;
     Wrap48TickArgs wa{};
-    wa.channels = r.channels; wa.st = b->d_w48; wa.coef_down = b->d_coef_down; wa.coef_up = b->d_coef_up;
+    wa.channels = r.channels; wa.st = b->d_w48; wa.coef_down = b->d_coef_down; wa.coef_up = b->d_coef_up; wa.H = b->H;
     wa.n_post = b->B;
-    wa.out48 = r.d_out48 + (size_t)r.deferred_slot * b->B * r.channels * 480;
-    wa.model_out = r.d_out24 + (size_t)r.deferred_slot * b->B * B_OUT_HOP;
+    wa.out48 = r.d_out48 + (size_t)r.deferred_slot * b->B * b->H * r.channels * 480;
+    wa.model_out = r.d_out24 + (size_t)r.deferred_slot * b->B * b->H * B_OUT_HOP;
     wa.hv_post = r.deferred_step >= 0 && b->tk.step_ragged[r.deferred_step % tick::kRing] ? b->tk.d_hopv + (size_t)(r.deferred_step % tick::kRing) * b->tk.row : nullptr;
-    wa.in48_post = r.d_in48 + (size_t)r.deferred_slot * b->B * r.channels * 480;
+    wa.in48_post = r.d_in48 + (size_t)r.deferred_slot * b->B * b->H * r.channels * 480;
     r.deferred_slot = -1;
     hipLaunchKernelGGL(wrap48_tick_kernel, dim3(wa.n_post), dim3(256), 0, b->stream, wa);
     ok = hip_ok(hipGetLastError(), "wrap48 flush");

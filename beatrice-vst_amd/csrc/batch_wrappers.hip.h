@@ -132,12 +132,13 @@ int BeatriceBatch_BindResidentIO48k(BeatriceBatch* b, const float* d_in48, float
     r = BeatriceBatch::Resident48{};
   }
   if (!d_in48 && !d_out48) return 0;
-  if (!d_in48 || !d_out48 || channels < 1 || channels > 2 || n_slots < b->tk.plan.count() + 1 || b->H != 1 || b->io_slots > 0 || b->pipelined ||
+  if (!d_in48 || !d_out48 || channels < 1 || channels > 2 || n_slots < b->tk.plan.count() + 1 || b->H > tick::kMaxHops || b->io_slots > 0 || b->pipelined ||
       b->tk.on || b->hs.on || b->silent.on)   // (the silent-block rule is an in-order mode: switch it off first)
     return -1;
-  bool ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_in16), sizeof(float) * n_slots * b->B * B_IN_HOP), "r48 in16") &&
-            hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_out24), sizeof(float) * n_slots * b->B * B_OUT_HOP), "r48 out24") &&
-            hip_ok(hipMemset(r.d_in16, 0, sizeof(float) * n_slots * b->B * B_IN_HOP), "r48 zero");
+  // (with H hops per step a slot holds H blocks per stream, [B][H][channels][480], and a call converts them all)
+  bool ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_in16), sizeof(float) * n_slots * b->B * b->H * B_IN_HOP), "r48 in16") &&
+            hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_out24), sizeof(float) * n_slots * b->B * b->H * B_OUT_HOP), "r48 out24") &&
+            hip_ok(hipMemset(r.d_in16, 0, sizeof(float) * n_slots * b->B * b->H * B_IN_HOP), "r48 zero");
   ok = ok && BeatriceBatch_BindResidentIO(b, r.d_in16, r.d_out24, n_slots) == 0 && tick_enable(b, true) == 0;
   if (!ok) {
     (void)tick_enable(b, false);

@@ -723,13 +723,15 @@ static __global__ __launch_bounds__(256) void freeze_fix_kernel(const FreezeRing
 
 // mono = (L + R) * 0.5 (or L), 31-tap low-pass evaluated only at the samples the decimator keeps
 // (frozen != nullptr and frozen[b]: the stream's block is silent by the shell's rule -- nothing of its state moves)
+// (row: the block's index in in48 / in16 -- the stream, or (stream, hop in step) with several blocks per step; b: the stream's state)
 __device__ __forceinline__ void wrap48_pre_body(const int b, const float* __restrict__ in48, int channels, Wrap48State* __restrict__ st,
                                                 const float* __restrict__ coef_down, float* __restrict__ in16, float* __restrict__ lds,
-                                                const unsigned char* __restrict__ frozen = nullptr) {
+                                                const unsigned char* __restrict__ frozen = nullptr, int row = -1) {
+  if (row < 0) row = b;
   float* g = lds;        // [30 + 480]
   float* cd = lds + 512; // [33]
   const int tid = threadIdx.x;
-  const float* src = in48 + (size_t)b * channels * 480;
+  const float* src = in48 + (size_t)row * channels * 480;
   if (tid < 33) cd[tid] = coef_down[tid];
   if (tid < 30) g[tid] = st[b].hist_in[tid];
   for (int i = tid; i < 480; i += 256) {
@@ -743,7 +745,7 @@ __device__ __forceinline__ void wrap48_pre_body(const int b, const float* __rest
     float acc = 0.0f;
 #pragma unroll
     for (int i = 0; i < 31; ++i) acc = acc + g[30 + p - i] * cd[1 + i];
-    in16[(size_t)b * 160 + tid] = acc * 1.0f;
+    in16[(size_t)row * 160 + tid] = acc * 1.0f;
   }
   if (tid < 30 && !(frozen && frozen[b])) st[b].hist_in[tid] = g[480 + tid];
 }
@@ -758,7 +760,8 @@ static __global__ __launch_bounds__(256) void wrap48_pre_kernel(const float* __r
 // output of this step ([B][240]) then takes the FIFO's place for the next block (what wrap48_latch_kernel does).
 __device__ __forceinline__ void wrap48_post_body(const int b, Wrap48State* __restrict__ st, const float* __restrict__ coef_up,
                                                  float* __restrict__ out48, int channels, const float* __restrict__ latch,
-                                                 float* __restrict__ lds) {
+                                                 float* __restrict__ lds, int row = -1) {
+  if (row < 0) row = b;
   float* f = lds;         // [16 + 240]
   float* cu = lds + 256;  // [33]
   const int tid = threadIdx.x;
@@ -766,7 +769,7 @@ __device__ __forceinline__ void wrap48_post_body(const int b, Wrap48State* __res
   if (tid < 16) f[tid] = st[b].ztail[tid];
   if (tid < 240) f[16 + tid] = st[b].fpend[tid];
   __syncthreads();
-  float* dst = out48 + (size_t)b * channels * 480;
+  float* dst = out48 + (size_t)row * channels * 480;
   for (int n = tid; n < 480; n += 256) {
     float acc = 0.0f;
 #pragma unroll
@@ -778,7 +781,7 @@ __device__ __forceinline__ void wrap48_post_body(const int b, Wrap48State* __res
   }
   __syncthreads();
   if (tid < 16) st[b].ztail[tid] = f[16 + 224 + tid];
-  if (latch != nullptr && tid < 240) st[b].fpend[tid] = latch[(size_t)b * 240 + tid];
+  if (latch != nullptr && tid < 240) st[b].fpend[tid] = latch[(size_t)row * 240 + tid];
 }
 // (frozen streams: the output block is the block's own down-mix -- zeros -- on every channel, the FIFO stands still)
 static __global__ __launch_bounds__(256) void wrap48_post_kernel(Wrap48State* __restrict__ st, const float* __restrict__ coef_up,
@@ -817,13 +820,17 @@ struct Wrap48TickArgs {
   // FIFO and latch untouched); null: every stream takes part
   const int *hv_pre, *hv_post;
   const float* in48_post;                  // the completed step's own input block (read for silent streams only)
+  int H;                                   // blocks per stream and step (a batch with several hops per step): rows are (stream, hop), in order
 };
 static __global__ __launch_bounds__(256) void wrap48_tick_kernel(const Wrap48TickArgs a) {
   __shared__ float lds[512 + 33];
   const int w = blockIdx.x;
   if (w < a.n_pre) {
     if (a.hv_pre != nullptr && a.hv_pre[w] < 0) return;   // (its 16 kHz hop is not read either: the model sits the step out)
-    wrap48_pre_body(w, a.in48, a.channels, a.st, a.coef_down, a.in16, lds);
+    for (int hh = 0; hh < a.H; ++hh) {   // (the filter history goes from block to block through the state: written and read by the same threads)
+      if (hh > 0) __syncthreads();
+      wrap48_pre_body(w, a.in48, a.channels, a.st, a.coef_down, a.in16, lds, nullptr, w * a.H + hh);
+    }
   } else {
     const int b = w - a.n_pre;
     if (a.hv_post != nullptr && a.hv_post[b] < 0) {
@@ -836,6 +843,9 @@ static __global__ __launch_bounds__(256) void wrap48_tick_kernel(const Wrap48Tic
       }
       return;
     }
-    wrap48_post_body(b, a.st, a.coef_up, a.out48, a.channels, a.model_out, lds);
+    for (int hh = 0; hh < a.H; ++hh) {
+      if (hh > 0) __syncthreads();
+      wrap48_post_body(b, a.st, a.coef_up, a.out48, a.channels, a.model_out, lds, b * a.H + hh);
+    }
   }
 }

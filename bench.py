@@ -454,10 +454,10 @@ def main():
         scaling = "strong"
     B = a.streams
     if a.hops_per_step is None:
-        a.hops_per_step = 2 if (a.config in (2, 3) and a.pipeline == "tick" and not a.copy_io) else 1
+        a.hops_per_step = 2 if (a.pipeline == "tick" and not a.copy_io) else 1
     H = a.hops_per_step
-    if H > 1 and (a.config == 4 or a.pipeline != "tick" or a.copy_io):
-        raise SystemExit("--hops-per-step 2 is the tick pipeline's form (configs 2 and 3, resident I/O)")
+    if H > 1 and (a.pipeline != "tick" or a.copy_io):
+        raise SystemExit("--hops-per-step 2 is the tick pipeline's form (resident I/O)")
     tmp = tempfile.TemporaryDirectory()
     model_dir = tmp.name
     if rank == 0:
@@ -523,14 +523,16 @@ def main():
         pipelined = 0
 
     if a.config == 4:  # 48 kHz stereo blocks, resident: [n_cycle][B][2][480]
-        a48 = np.stack([np.stack([bv.synth_audio(480 * n_cycle, seed=rank * 100000 + 2 * s + c, sr=48000) for c in range(2)])
+        a48 = np.stack([np.stack([bv.synth_audio(480 * H * n_cycle, seed=rank * 100000 + 2 * s + c, sr=48000) for c in range(2)])
                         for s in range(B)])
-        a48 = np.ascontiguousarray(a48.reshape(B, 2, n_cycle, 480).transpose(2, 0, 1, 3))
+        a48 = np.ascontiguousarray(a48.reshape(B, 2, n_cycle, H, 480).transpose(2, 0, 3, 1, 4))   # [n_cycle][B][H][2][480]
         d_audio48 = torch.from_numpy(a48).cuda()
-        d_out48 = torch.zeros((n_cycle, B, 2, 480), dtype=torch.float32, device="cuda")
-        base48, blk_bytes = d_audio48.data_ptr(), B * 2 * 480 * 4
+        d_out48 = torch.zeros((n_cycle, B, H, 2, 480), dtype=torch.float32, device="cuda")
+        base48, blk_bytes = d_audio48.data_ptr(), B * H * 2 * 480 * 4
         # throughput form: the 64 resident 48 kHz blocks are the slots, the tick pipeline runs between the two resamplers
         tick48 = a.pipeline_request == "tick" and product.BeatriceBatch_BindResidentIO48k(batch.h, d_audio48.data_ptr(), d_out48.data_ptr(), 2, n_cycle) == 0
+        if H > 1 and not tick48:
+            raise SystemExit("configs[4] with two blocks per step needs the 48 kHz wrapper around the tick pipeline")
 
     if product.BeatriceBatch_Prepare(batch.h):  # graph capture now, not inside the first (possibly timed) steps
         raise SystemExit("Prepare failed")
@@ -596,7 +598,7 @@ def main():
                                     3: "BASELINE.json configs[3] per-GPU share: %d streams, %d speakers, every stream switches "
                                        "speaker every 200 hops (K/V blocks one per hop), VQ k=4" % (B, a.speakers),
                                     4: "BASELINE.json configs[4] per-GPU share: %d streams of 48 kHz stereo, downmix + resample "
-                                       "wrapper on the device, 480-sample blocks" % B}[a.config],
+                                       "wrapper on the device, 480-sample blocks, %d block(s) per stream and step" % (B, H)}[a.config],
                        "streams_per_gpu": B, "speakers": a.speakers, "hops_per_step": H, "frames_per_step": world * B * H, "hipgraph": not a.no_graph, "device_warm_ms": a.device_warm_ms,
                        "pipelining": ("tick: every layer of the chain its own pipeline stage (%d stages), one launch per tick on one HIP "
                                       "stream, stage s works on the step fed s ticks earlier (%d hop(s) of every stream per stage per launch); "

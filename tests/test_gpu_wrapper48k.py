@@ -175,3 +175,72 @@ def test_48k_wrapper_around_the_tick_pipeline_matches_in_order(bv, oracle, produ
     hip.free(d_in); hip.free(d_out)
     batch.close()
     m.close()
+
+
+@pytest.mark.parametrize("B,channels,steps", [(5, 2, 36), (64, 2, 24), (3, 1, 33)])
+def test_48k_wrapper_around_the_tick_pipeline_two_blocks_per_step(bv, product, model_dir, B, channels, steps):
+    """The same with a batch of two hops per step: a slot holds two consecutive 480-sample blocks per stream
+    ([B][2][channels][480]), every call converts both -- the resamplers and the FIFO run block after block inside the wrapper
+    launch.  Must equal the in-order device wrapper (one block per call; oracle-checked above) block for block; settings move
+    between steps."""
+    from test_gpu_resident_io import Hip
+    hip = Hip()
+    H = 2
+    blocks = H * steps
+    x = np.stack([np.stack([wrapperlib.test_signal(480 * blocks, 48000, seed=900 + 7 * s + c) for c in range(channels)])
+                  for s in range(B)]).astype(np.float32)                      # [B][ch][blocks*480]
+    m = bv.Models(product, model_dir)
+
+    def settings(batch):
+        for s in range(B):
+            batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, s, s % 3)
+            batch.a.BeatriceBatch_SetVQNumNeighbors(batch.h, s, s % 2)
+        batch.a.BeatriceBatch_FlushSpeaker(batch.h, -1)
+
+    def change(batch, k):   # before step k
+        if k % 5 == 3:
+            batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, (3 * k) % B, (k + 1) % 3)
+            batch.a.BeatriceBatch_SetPitchShift(batch.h, (5 * k) % B, float(k % 5) - 2.0)
+
+    ref_batch = bv.Batch(m, B)
+    settings(ref_batch)
+    want = []
+    for k in range(blocks):
+        if k % H == 0:
+            change(ref_batch, k // H)
+        want.append(ref_batch.convert48k(np.ascontiguousarray(x[:, :, 480 * k:480 * (k + 1)]), channels).copy())
+    ref_batch.close()
+
+    batch = bv.Batch(m, B, hops_per_step=H)
+    settings(batch)
+    a, h = batch.a, batch.h
+    slots = a.BeatriceBatch_TickStages(h) + 4
+    blk = B * H * channels * 480
+    d_in, d_out = hip.malloc(slots * blk * 4), hip.malloc(slots * blk * 4)
+    assert a.BeatriceBatch_BindResidentIO48k(h, d_in, d_out, channels, slots) == 0
+    got = [None] * blocks
+    k0 = 0
+    while k0 < steps:
+        n = min(slots if k0 == 0 else 7, steps - k0)
+        buf = np.zeros((slots, B, H, channels, 480), np.float32)
+        for k in range(k0, k0 + n):
+            for hh in range(H):
+                buf[k % slots, :, hh] = x[:, :, 480 * (H * k + hh):480 * (H * k + hh + 1)]
+        hip.h2d(d_in, buf)
+        for k in range(k0, k0 + n):
+            change(batch, k)
+            assert a.BeatriceBatch_ConvertBlocks48kDevice(h, None, None, channels) == 0
+        assert a.BeatriceBatch_Synchronize(h) == 0
+        out = np.zeros((slots, B, H, channels, 480), np.float32)
+        hip.d2h(out, d_out)
+        for k in range(k0, k0 + n):
+            for hh in range(H):
+                got[H * k + hh] = out[k % slots, :, hh].copy()
+        k0 += n
+    bad = [k for k in range(blocks) if not np.array_equal(got[k], want[k])]
+    assert not bad, "blocks that differ: %s" % bad[:20]
+    assert max(float(np.abs(w).max()) for w in want) > 1e-3
+    assert a.BeatriceBatch_BindResidentIO48k(h, None, None, 0, 0) == 0
+    batch.close()
+    m.close()
+    hip.free(d_in); hip.free(d_out)
