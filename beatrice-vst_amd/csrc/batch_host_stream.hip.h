@@ -13,7 +13,7 @@
 static void host_stream_fetch(BeatriceBatch* b) {  // enqueue the download of every step the ticks run so far have completed
   BeatriceBatch::HostStream& h = b->hs;
   const long long last_tick = b->tk.tick - 1;
-  const size_t n_out = (size_t)b->B * B_OUT_HOP;
+  const size_t n_out = (size_t)b->B * b->H * B_OUT_HOP;
   for (auto& p : h.pending) {
     if (p.fetched || p.done_tick > last_tick) continue;
     if (h.mapped) { p.fetched = true; continue; }  // nothing to download: the last stage wrote host memory
@@ -76,9 +76,9 @@ int BeatriceBatch_EnableHostStreaming(BeatriceBatch* b, int enable) {
     host_stream_free(b);
     return rb;
   }
-  if (b->H != 1 || b->io_slots > 0 || b->tk.on || b->pipelined) return -1;  // one hop per step; no other binding or pipelining
+  if (b->H > tick::kMaxHops || b->io_slots > 0 || b->tk.on || b->pipelined) return -1;  // one or two hops per step (buffers are [B][H x 160] -> [B][H x 240]); no other binding or pipelining
   h.n_slots = b->tk.plan.count() + 8;
-  const size_t n_in = (size_t)b->B * B_IN_HOP, n_out = (size_t)b->B * B_OUT_HOP;
+  const size_t n_in = (size_t)b->B * b->H * B_IN_HOP, n_out = (size_t)b->B * b->H * B_OUT_HOP;
   bool ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&h.d_in), sizeof(float) * n_in * h.n_slots), "hs d_in") &&
             hip_ok(hipMalloc(reinterpret_cast<void**>(&h.d_out), sizeof(float) * n_out * h.n_slots), "hs d_out") &&
             hip_ok(hipHostMalloc(reinterpret_cast<void**>(&h.h_in), sizeof(float) * n_in * h.n_slots, hipHostMallocDefault), "hs h_in") &&
@@ -108,7 +108,7 @@ int BeatriceBatch_StreamFrames(BeatriceBatch* b, const float* in, float* out) {
   if (!b || !b->ok) return -2;
   BeatriceBatch::HostStream& h = b->hs;
   if (!h.on || !in || !out) return -1;
-  const size_t n_in = (size_t)b->B * B_IN_HOP, n_out = (size_t)b->B * B_OUT_HOP;
+  const size_t n_in = (size_t)b->B * b->H * B_IN_HOP, n_out = (size_t)b->B * b->H * B_OUT_HOP;
   const int slot = b->io_host;  // the slot the tick about to be fed reads and, pipeline depth later, writes
   if (h.mapped) {
     // the slot's last readers (stage 9 of the step fed n_slots calls ago) are done: every call since the pipeline filled
@@ -152,7 +152,7 @@ int BeatriceBatch_StreamFlush(BeatriceBatch* b, float* out) {
   BeatriceBatch::HostStream& h = b->hs;
   if (!h.on || !out) return -1;
   if (h.pending.empty()) return 0;
-  const size_t n_out = (size_t)b->B * B_OUT_HOP;
+  const size_t n_out = (size_t)b->B * b->H * B_OUT_HOP;
   while (!h.pending.front().fetched)
     if (!host_stream_tick(b, false)) return -2;
   const BeatriceBatch::HostStream::Pending f = h.pending.front();

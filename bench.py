@@ -321,6 +321,25 @@ def host_buffer_rate(bv, models, product, streams, steps=200):
                                                  "delay_steps": int(product.BeatriceBatch_HostStreamDelay(batch.h))}
         product.BeatriceBatch_EnableHostStreaming(batch.h, 0)
     batch.close()
+    # ... and with two hops per step ([B][320] in, [B][480] out per call)
+    batch = bv.Batch(models, streams, hops_per_step=2)
+    product.BeatriceBatch_FlushSpeaker(batch.h, -1)
+    x2 = [np.ascontiguousarray(np.concatenate([xs[(2 * i) % 8], xs[(2 * i + 1) % 8]], axis=1)) for i in range(4)]
+    out2 = np.zeros((streams, 480), np.float32)
+    if product.BeatriceBatch_EnableHostStreaming(batch.h, 1) == 0:
+        n = 300
+        for timed in (False, True):
+            t0 = time.perf_counter()
+            got = 0
+            for i in range(n):
+                got += product.BeatriceBatch_StreamFrames(batch.h, bv.fptr(x2[i % 4]), bv.fptr(out2))
+            while product.BeatriceBatch_StreamFlush(batch.h, bv.fptr(out2)) == 1:
+                got += 1
+            dt = time.perf_counter() - t0
+        res["streamed_through_tick_pipeline_two_hops_per_step"] = {"frames_per_s": round(2 * streams * n / dt, 1), "ms_per_step": round(dt / n * 1e3, 4),
+                                                                   "steps": n, "steps_returned": got}
+        product.BeatriceBatch_EnableHostStreaming(batch.h, 0)
+    batch.close()
     return res
 
 

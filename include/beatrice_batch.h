@@ -268,7 +268,8 @@ void* BeatriceBatch_GetWaveStream(const BeatriceBatch* b);
  * frames/s; 64 speakers on 256 streams: 2.30 -> 3.01 M), same samples as one hop per step, settings still apply per step and
  * key/value installs per hop.  The 48 kHz wrapper around the ticks takes such a batch too (BeatriceBatch_BindResidentIO48k: a slot
  * then holds two consecutive blocks per stream, [B][2][channels][480], and a call converts both: 64 stereo streams 1.41 -> 2.27 M
- * frames/s); the silent-block rule, BindResidentBlocks and EnableHostStreaming need one hop per step. */
+ * frames/s), and so does host streaming (BeatriceBatch_StreamFrames then takes [B][320] and returns [B][480]: 3.30 -> 3.52 M frames/s
+ * from and to host memory); the silent-block rule and BindResidentBlocks need one hop per step. */
 int BeatriceBatch_EnableTickPipeline(BeatriceBatch* b, int enable);
 int BeatriceBatch_TickStages(const BeatriceBatch* b);
 /* Host streaming: tick pipelining for callers whose audio lives in HOST memory (offline conversion of files, a network

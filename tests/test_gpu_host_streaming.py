@@ -75,3 +75,63 @@ def test_streamed_host_buffers_match_in_order_chain(bv, oracle, product, model_d
     assert a.BeatriceBatch_EnableHostStreaming(h, 0) == 0
     batch.close()
     m.close()
+
+
+@pytest.mark.parametrize("B,steps", [(7, 60), (256, 45)])
+def test_streamed_host_buffers_two_hops_per_step(bv, product, model_dir, B, steps):
+    """Host streaming with a batch of two hops per step: a call takes [B][320] and hands back [B][480] (the tick pipeline with two
+    hops per stage per launch underneath).  Must equal the in-order chain at one hop per step, the script applied before a step."""
+    H = 2
+    m = bv.Models(product, model_dir)
+    bv.bind_batch(product)
+    audio = np.stack([bv.synth_audio(160 * H * steps, seed=4700 + s) for s in range(B)])
+
+    def settings(batch):
+        for s in range(B):
+            batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, s, s % 3)
+            batch.a.BeatriceBatch_SetVQNumNeighbors(batch.h, s, s % 4)
+        batch.a.BeatriceBatch_FlushSpeaker(batch.h, -1)
+
+    def change(batch, k):
+        if k % 11 == 3:
+            batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, (5 * k) % B, (k + 1) % 3)
+            batch.a.BeatriceBatch_SetPitchShift(batch.h, (3 * k) % B, float(k % 5) - 2.0)
+        if k == 29:
+            assert batch.a.BeatriceBatch_ResetStream(batch.h, 2 % B) == 0   # drains
+
+    ref_batch = bv.Batch(m, B)
+    settings(ref_batch)
+    ref = np.zeros((steps, B, H * 240), np.float32)
+    for k in range(steps):
+        change(ref_batch, k)
+        for hh in range(H):
+            j = H * k + hh
+            ref[k][:, hh * 240:(hh + 1) * 240] = ref_batch.convert(np.ascontiguousarray(audio[:, j * 160:(j + 1) * 160]))
+    ref_batch.close()
+
+    batch = bv.Batch(m, B, hops_per_step=H)
+    settings(batch)
+    a, h = batch.a, batch.h
+    out = np.zeros((B, H * 240), np.float32)
+    assert a.BeatriceBatch_EnableHostStreaming(h, 1) == 0
+    got = []
+    for k in range(steps):
+        change(batch, k)
+        x = np.ascontiguousarray(audio[:, k * H * 160:(k + 1) * H * 160])
+        rc = a.BeatriceBatch_StreamFrames(h, bv.fptr(x), bv.fptr(out))
+        assert rc in (0, 1)
+        if rc == 1:
+            got.append(out.copy())
+    while True:
+        rc = a.BeatriceBatch_StreamFlush(h, bv.fptr(out))
+        assert rc in (0, 1)
+        if rc == 0:
+            break
+        got.append(out.copy())
+    assert len(got) == steps
+    bad = [(k, int(s_)) for k in range(steps) for s_ in np.nonzero(np.abs(got[k] - ref[k]).max(axis=1))[0]]
+    assert not bad, "differing (step, stream): %s" % bad[:40]
+    assert np.abs(ref).max() > 0.05
+    assert a.BeatriceBatch_EnableHostStreaming(h, 0) == 0
+    batch.close()
+    m.close()
