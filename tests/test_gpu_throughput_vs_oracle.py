@@ -11,42 +11,49 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4   # north_star's bound on output PCM; observed 0.0
 
 
-def test_bench_workload_in_tick_mode_matches_oracle(bv, oracle, product, model_dir):
+@pytest.mark.parametrize("H", [2, 1])
+def test_bench_workload_in_tick_mode_matches_oracle(bv, oracle, product, model_dir, H):
     """bench.py's headline: BASELINE.json configs[2] -- 256 streams, 1 speaker, k-NN 0, every tenth stream with 0.5 s of
-    digital silence, 64 resident hops per stream cycled as I/O slots, steps enqueued without waiting.  100 steps (the slot
-    ring wraps), a sample of 12 streams (silence-gap streams 3, 13, 253 among them) against independent oracle streams."""
+    digital silence, 64 resident steps per stream cycled as I/O slots, steps of H hops (2: the bench's default) enqueued without
+    waiting.  100 steps (the slot ring wraps), a sample of 12 streams (silence-gap streams 3, 13, 253 among them) against
+    independent oracle streams."""
     B, n_cycle, steps = 256, 64, 100
-    audio = np.stack([bv.synth_audio(160 * n_cycle, seed=s, silence_gap=(s % 10 == 3)) for s in range(B)]).reshape(B, n_cycle, 160)
+    audio = np.stack([bv.synth_audio(160 * H * n_cycle, seed=s, silence_gap=(s % 10 == 3)) for s in range(B)]).reshape(B, n_cycle * H, 160)
 
     def settings(batch):
         batch.a.BeatriceBatch_SetTargetSpeaker(batch.h, -1, 0)
         batch.a.BeatriceBatch_FlushSpeaker(batch.h, -1)
 
-    def hop_input(k):
-        return audio[:, k % n_cycle]
+    def hop_input(j):   # hop j of the run
+        return audio[:, j % (n_cycle * H)]
+
+    def step_input(k):
+        return np.concatenate([hop_input(k * H + hh) for hh in range(H)], axis=1)
 
     m = bv.Models(product, model_dir)
-    batch = bv.Batch(m, B)
+    batch = bv.Batch(m, B, hops_per_step=H)
     settings(batch)
-    got = run_tick(bv, batch, steps, hop_input, slots=n_cycle)
+    got = run_tick(bv, batch, steps, step_input, slots=n_cycle)
     batch.close()
     m.close()
     assert np.all(np.abs(got).reshape(steps, B, -1).max(axis=(0, 2)) > 1e-3)     # every stream produces sound
     sample = [0, 3, 13, 15, 16, 31, 32, 127, 128, 253, 254, 255]
-    sample, want = oracle_leg(bv, oracle, model_dir, B, hop_input, steps, settings, lambda b, k: None, sample)
+    sample, want = oracle_leg(bv, oracle, model_dir, B, hop_input, steps * H, settings, lambda b, k: None, sample)
+    want = want.reshape(steps, H, len(sample), 240).transpose(0, 2, 1, 3).reshape(steps, len(sample), H * 240)
     dev = float(np.abs(got[:, sample] - want).max())
-    print("bench workload, tick mode vs ORACLE: %d streams x %d steps, max-abs %g %s"
-          % (len(sample), steps, dev, "bit-identical" if np.array_equal(got[:, sample], want) else ""))
+    print("bench workload, tick mode (%d hop(s) per step) vs ORACLE: %d streams x %d steps, max-abs %g %s"
+          % (H, len(sample), steps, dev, "bit-identical" if np.array_equal(got[:, sample], want) else ""))
     assert dev <= TOL
 
 
-@pytest.mark.parametrize("B,steps", [(8, 330)])
-def test_tick_soak_vs_oracle(bv, oracle, product, model_dir, B, steps):
+@pytest.mark.parametrize("B,steps,H", [(8, 330, 1), (8, 330, 2)])
+def test_tick_soak_vs_oracle(bv, oracle, product, model_dir, B, steps, H):
     """Soak: every stream of a small batch for 330 hops in tick mode against independent oracle streams driven through the
     reference protocol (processor_core_2.cc:50-256; a switch installs one K/V block per hop, :179-181): speaker switches
     throughout, k-NN on / off / changed, formant and pitch settings, pitch range, two stream resets -- early, in the middle and
     near the end, so that every ring of the pipeline has wrapped several times when they arrive."""
-    audio = np.stack([bv.synth_audio(160 * steps, seed=7700 + s, silence_gap=(s == 5)) for s in range(B)]).reshape(B, steps, 160)
+    # (H = 2: two hops per stage per launch; the script then precedes a STEP, i.e. every second hop of the oracle streams)
+    audio = np.stack([bv.synth_audio(160 * H * steps, seed=7700 + s, silence_gap=(s == 5)) for s in range(B)]).reshape(B, steps * H, 160)
 
     def settings(batch):
         for s in range(B):
@@ -74,12 +81,14 @@ def test_tick_soak_vs_oracle(bv, oracle, product, model_dir, B, steps):
             a.BeatriceBatch_SetTargetSpeaker(h, -1, 2)                                # everyone, near the end
 
     m = bv.Models(product, model_dir)
-    batch = bv.Batch(m, B)
+    batch = bv.Batch(m, B, hops_per_step=H)
     settings(batch)
-    got = run_tick(bv, batch, steps, lambda k: audio[:, k], change, chunk=29)          # (chunks of 29: drains land everywhere)
+    got = run_tick(bv, batch, steps, lambda k: audio[:, k * H:(k + 1) * H].reshape(B, H * 160), change, chunk=29)          # (chunks of 29: drains land everywhere)
     batch.close()
     m.close()
-    sample, want = oracle_leg(bv, oracle, model_dir, B, lambda k: audio[:, k], steps, settings, change, list(range(B)))
+    sample, want = oracle_leg(bv, oracle, model_dir, B, lambda j: audio[:, j], steps * H, settings,
+                              lambda ob, j: change(ob, j // H) if j % H == 0 else None, list(range(B)))
+    want = want.reshape(steps, H, B, 240).transpose(0, 2, 1, 3).reshape(steps, B, H * 240)
     bad = sorted({int(k) for k in np.nonzero(np.abs(got - want).reshape(steps, -1).max(axis=1) > TOL)[0]})
     dev = float(np.abs(got - want).max())
     print("tick soak vs ORACLE: %d streams x %d steps, max-abs %g %s" % (B, steps, dev, "bit-identical" if np.array_equal(got, want) else ""))
