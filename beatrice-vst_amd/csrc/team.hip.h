@@ -191,7 +191,7 @@ __device__ __forceinline__ void stage(const StageArgs& a, const int hop, const i
   const int pos_out = ring_pos(a.out.ring, hop);
   int pos_res = 0;
   if constexpr (L::RES) pos_res = ring_pos(a.res.ring, hop);
-  bool first = true;
+  bool first = true, next_tile_in_pre = false;
   for (int tile = wg; tile < NT8; tile += NWG) {
     // ---- this tile's weights: every load issued now (registers), stored to LDS once the inputs are in -- the round trip
     // hides behind the wait for the producers.  Record (16-column tile, k-block): 64 lanes x float4, lane slot 16 kq + (n & 15),
@@ -199,7 +199,7 @@ __device__ __forceinline__ void stage(const StageArgs& a, const int hop, const i
     stamp(st, wg);
     const int n0 = tile * COLS;
     float4 wr[MAX_P][2];
-    if (first && pre.ok) {
+    if ((first && pre.ok) || next_tile_in_pre) {   // requested during the stage before / during this stage's previous tile
 #pragma unroll
       for (int s = 0; s < P; ++s) { wr[s][0] = pre.r[s][0]; wr[s][1] = pre.r[s][1]; }
     } else {
@@ -235,9 +235,13 @@ __device__ __forceinline__ void stage(const StageArgs& a, const int hop, const i
     stamp(st, wg);
     if (tile + NWG >= NT8) {   // this workgroup's last tile of the stage: the next stage's weights travel during its chains
       pre.ok = false;
+      next_tile_in_pre = false;
       if constexpr (!std::is_same<LN, NoLayer>::value) {
         if (wg < LN::NOUT / COLS) { load_w<LN>(w_next, wg, pre.r); pre.ok = true; }
       }
+    } else {                   // a layer wider than the team (attention scores, up1): the next tile's weights, likewise
+      load_w<L>(a.w, tile + NWG, pre.r);
+      next_tile_in_pre = true;
     }
     // ---- the chains: lane (c, pair) = column c, (row m, segment s).  Pairs are dealt to the four wavefronts round-robin
     // (pair = wavefront + 4 j), so that with two segments of different lengths (K = 384) a wavefront's lanes all run the same length
