@@ -10,9 +10,10 @@ product = bv.bind_batch(bv.load_product())
 tmp = tempfile.TemporaryDirectory(); make_model.make_model(tmp.name, n_speakers=1)
 m = bv.Models(product, tmp.name)
 B, n, steps = 256, 64, int(sys.argv[1]) if len(sys.argv) > 1 else 20
-batch = bv.Batch(m, B)
-d_in = torch.randn((n, B, 160), device="cuda") * 0.1
-d_out = torch.zeros((n, B, 240), device="cuda")
+H = int(os.environ.get("FD_HOPS", "2"))   # hops per step
+batch = bv.Batch(m, B, hops_per_step=H)
+d_in = torch.randn((n, B, H * 160), device="cuda") * 0.1
+d_out = torch.zeros((n, B, H * 240), device="cuda")
 assert product.BeatriceBatch_BindResidentIO(batch.h, d_in.data_ptr(), d_out.data_ptr(), n) == 0
 assert product.BeatriceBatch_EnableTickPipeline(batch.h, 1) == 0
 x = torch.randn((4096, 4096), device="cuda")
