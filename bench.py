@@ -632,6 +632,7 @@ def main():
                        "parallelism": "streams sharded over %d GPU(s), no per-hop collective; load: one file read on rank 0, "
                                       "%d bytes of parameters (%s) and speaker tables (%s) broadcast over RCCL" % (world, bcast_bytes, load_path, table_path),
                        "placement": a.placement if a.config == 3 else "n/a"},
+            "ms_per_hop": round(1e3 * elapsed / (a.steps * H), 4),   # (of all streams: ms_per_step / hops_per_step)
             "x_realtime_per_stream": round(a.steps * H / elapsed / 100.0, 2), "output_rms": round(out_rms, 4),
             "host_enqueue_ms_per_step": round(1e3 * enqueue_s / a.steps, 4),
         }
@@ -735,6 +736,8 @@ def main():
                 res["hop_synchronous_frames_per_s"] = res["hop_synchronous"]["frames_per_s"]
                 res["saturation"] = saturation(bv, m, product)
                 res["saturation"]["tick_pipelined"] = tick_rate(bv, m, product, torch, 1024, res["chain"]["gflop_per_step"] * 1e9 / B)
+                if tick and H > 1 and a.config == 2:   # the same run at ONE hop per step (the headline's definition up to round 3): same K, fill and drain inside
+                    res["one_hop_per_step"] = tick_rate(bv, m, product, torch, B, res["chain"]["gflop_per_step"] * 1e9 / B, steps=a.steps)
                 res["block_mode"] = block_mode(bv, m, product, B)
                 res["morph"] = morph_timing(bv, product)
                 res["host_buffer_variant"] = host_buffer_rate(bv, m, product, B)
