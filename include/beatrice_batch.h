@@ -185,7 +185,9 @@ int BeatriceBatch_ConvertBlocks48kDevice(BeatriceBatch* b, const float* d_in, fl
  * the tick pipeline between them (the batch allocates its own 16 / 24 kHz slots).  While bound, block k --
  * BeatriceBatch_ConvertBlocks48kDevice(b, NULL, NULL, channels) -- is taken from slot k mod n_slots, and its converted block
  * appears in the same slot of d_out48 BeatriceBatch_TickStages() - 1 calls later or after BeatriceBatch_Synchronize: the
- * samples of the in-order call, later.  NULL, NULL unbinds (and leaves tick mode). */
+ * samples of the in-order call, later.  NULL, NULL unbinds (and leaves tick mode).
+ * On a batch with two hops per step (BeatriceBatch_CreateBlock(..., 2)) a slot holds two consecutive blocks per stream,
+ * [n_slots][B][2][channels][480], and every call converts both (the samples of two in-order calls). */
 int BeatriceBatch_BindResidentIO48k(BeatriceBatch* b, const float* d_in48, float* d_out48, int channels, int n_slots);
 /* The shell's rule "a block whose down-mix is all zeros is not converted: the core is not called, its state and its 10 ms FIFO
  * stand still, the output is that down-mix" (reference src/vst/processor.cc:204-214), PER STREAM, for the in-order 48 kHz blocks
