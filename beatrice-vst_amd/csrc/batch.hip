@@ -1316,6 +1316,18 @@ int BeatriceBatch_TimeTickLaunch(BeatriceBatch* b, int ticks, float* us_per_laun
   if (bytes) *bytes = b->tk.table_bytes;
   return 0;
 }
+#ifdef BEATRICE_HIP_MEASUREMENT_BUILD
+// MEASUREMENT BUILDS ONLY: from the next tick on the launch holds only the bodies whose tick::BodyType bit is set in `mask`
+// (the other stages' outputs go stale: instruction counters and timings per body type, never results)
+extern "C" int BeatriceBatchMeas_TickOnlyTypes(BeatriceBatch* b, unsigned long long mask) {
+  const DeviceScope dev_(b ? b->device : -1);
+  if (!b || !b->ok || !b->tk.on) return -1;
+  if (!hip_ok(hipStreamSynchronize(b->stream), "meas sync")) return -2;
+  g_tick_only_types = mask;
+  b->tk.table_dirty = true;
+  return 0;
+}
+#endif
 int BeatriceBatch_EnablePipelining(BeatriceBatch* b, int enable) {
   const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;

@@ -3,6 +3,11 @@
 #pragma once
 
 // ---- tick pipelining (tick.hip.h) ---------------------------------------------------------------------------------
+#ifdef BEATRICE_HIP_MEASUREMENT_BUILD
+// MEASUREMENT BUILDS ONLY (results are wrong by construction): the tick launch with only the body TYPES of this mask (tick::BodyType
+// bit numbers), for per-body instruction counters (tools/debug/tick_inst_by_body.py); BeatriceBatchMeas_TickOnlyTypes below
+static unsigned long long g_tick_only_types = ~0ull;
+#endif
 template <int H>
 bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
   using namespace tick;
@@ -33,6 +38,9 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
   constexpr int drop = 0;
 #endif
   auto keep = [](int group) { return ((drop >> group) & 1) == 0; };
+#ifdef BEATRICE_HIP_MEASUREMENT_BUILD
+  tb->only = g_tick_only_types;
+#endif
   // (every body takes its step counter from the launch's StepPairs -- a null counter pointer says so, ring.h stepc)
   auto hp = [&](int) -> const int* { return nullptr; };
   auto conv = [&](const Ring& in, const Ring& out, const float* w, const float* bias, int stage) { return conv_args(in, out, w, bias, hp(stage), B); };

@@ -236,6 +236,7 @@ struct TableBuilder {
   TableBuilder() { for (Span& sp : t.span) sp = Span{0x7fffffff, 1, -1, 0}; }
   bool ok = true;
   double flops = 0, bytes = 0;
+  unsigned long long only = ~0ull;   // measurement builds (batch_tick.hip.h): bit I clear = bodies of type I are left out of the table
   // Re-lays the bodies out for an 8-XCD chip.  A pinned body goes whole to ONE XCD (longest first, to the XCD with the
   // least work so far), so that its weights are fetched into one L2 and stay there from tick to tick; a body marked
   // `spread` (many workgroups, few weights) is dealt round-robin over all eight.  XCD x owns the index range
@@ -305,7 +306,7 @@ struct TableBuilder {
   }
   template <int I, class Args>
   void add(const bhip::LaunchInfo& info, const Args& a, dim3 grid, int stage, bool on = true, double wg_cost = 1.0, bool spread_over_xcds = false) {
-    if (!on) return;
+    if (!on || ((only >> I) & 1) == 0) return;
     using BA = BankAt<I, Banks<Ms...>>;
     if (t.n_spans >= kMaxSpans || used[I] >= BA::cap) { ok = false; return; }
     BA::get(t.banks)[used[I]] = a;

@@ -136,7 +136,25 @@ unsigned long long StreamingCore::BufferFingerprint() const {
     h = (h ^ reinterpret_cast<unsigned long long>(v->data())) * 1099511628211ull;
     h = (h ^ static_cast<unsigned long long>(v->capacity())) * 1099511628211ull;
   }
+  // (every other container the per-hop path writes: the pitch-trace ring)
+  h = (h ^ reinterpret_cast<unsigned long long>(pitch_trace_.data())) * 1099511628211ull;
+  h = (h ^ static_cast<unsigned long long>(pitch_trace_.capacity())) * 1099511628211ull;
   return h;
+}
+void StreamingCore::EnablePitchTrace(int capacity) {
+  pitch_trace_.assign(static_cast<size_t>(capacity > 0 ? capacity : 0), 0);
+  pitch_trace_.shrink_to_fit();
+  trace_count_ = 0;
+}
+std::vector<int> StreamingCore::TakePitchTrace() {
+  std::vector<int> t;
+  const unsigned long long cap = pitch_trace_.size();
+  if (cap == 0) return t;
+  const unsigned long long n = trace_count_ < cap ? trace_count_ : cap;
+  t.reserve(static_cast<size_t>(n));
+  for (unsigned long long i = trace_count_ - n; i < trace_count_; ++i) t.push_back(pitch_trace_[static_cast<size_t>(i % cap)]);
+  trace_count_ = 0;
+  return t;
 }
 void StreamingCore::ReserveBlocks(int max_block) {
   if (max_block < 1) return;
@@ -225,7 +243,7 @@ void ProcessorCore2::Hop(const float* in160, float* out240) {
   float feature[4];
   Beatrice20rc0_EstimatePitch1(pitch_estimator_, in160, &q, feature, pitch_context_);
   q = TransformPitch(q);
-  pitch_trace_.push_back(q);
+  RecordPitch(q);
   Beatrice20rc0_GenerateWaveform1(waveform_generator_, phone, &q, feature, out240, waveform_context_);
 }
 
@@ -514,6 +532,7 @@ int BeatriceHost_SetSpeakerMorphingWeights(void* p, const float* weights, int n)
 }
 void BeatriceHost_SetMorphSeed(void* p, unsigned seed) { core(p)->SetMorphSeed(seed); }
 int BeatriceHost_NumSpeakers(void* p) { return core(p)->n_speakers(); }
+void BeatriceHost_EnablePitchTrace(void* p, int capacity) { core(p)->EnablePitchTrace(capacity); }
 int BeatriceHost_TakePitchTrace(void* p, int* out, int cap) {
   const auto t = core(p)->TakePitchTrace();
   const int n = static_cast<int>(t.size()) < cap ? static_cast<int>(t.size()) : cap;

@@ -117,6 +117,7 @@ class ProcessorCoreBase {
   virtual void SetMorphSeed(std::uint32_t) {}
   virtual int n_speakers() const { return 0; }
   virtual std::vector<int> TakePitchTrace() { return {}; }
+  virtual void EnablePitchTrace(int /*capacity*/) {}
   // (ours, not the reference's: see StreamingCore::ReserveBlocks)
   virtual void ReserveBlocks(int /*max_block*/) {}
   virtual unsigned long long BufferFingerprint() const { return 0; }
@@ -138,8 +139,11 @@ class StreamingCore : public ProcessorCoreBase {
   ErrorCode SetPitchCorrection(double pitch_correction) override;
   ErrorCode SetPitchCorrectionType(int pitch_correction_type) override;
   int n_speakers() const override { return n_speakers_; }
-  // test hook: bins handed to GenerateWaveform1 since the last call (pitch transform output)
-  std::vector<int> TakePitchTrace() override { std::vector<int> t; t.swap(pitch_trace_); return t; }
+  // test hook, OFF unless a test enables it: the bins handed to GenerateWaveform1 (pitch transform output) in a ring of fixed
+  // capacity allocated by EnablePitchTrace -- the per-hop path only writes a slot (no allocation on the audio thread,
+  // src/common/resample.h:303-305); TakePitchTrace returns the newest <= capacity entries in order and empties the ring
+  void EnablePitchTrace(int capacity) override;
+  std::vector<int> TakePitchTrace() override;
 
  protected:
   bool IsLoaded() const { return !model_file_.empty(); }
@@ -155,9 +159,15 @@ class StreamingCore : public ProcessorCoreBase {
   int target_speaker_ = 0, n_speakers_ = 0, pitch_correction_type_ = 0;
   double formant_shift_ = 0.0, pitch_shift_ = 0.0, average_source_pitch_ = 52.0, intonation_intensity_ = 1.0;
   double pitch_correction_ = 0.0, min_source_pitch_ = 33.125, max_source_pitch_ = 80.875;
-  std::vector<int> pitch_trace_;
+  void RecordPitch(int q) {
+    if (pitch_trace_.empty()) return;
+    pitch_trace_[static_cast<size_t>(trace_count_ % pitch_trace_.size())] = q;
+    ++trace_count_;
+  }
 
  private:
+  std::vector<int> pitch_trace_;      // ring, size = capacity (0: tracing off)
+  unsigned long long trace_count_ = 0;  // entries written since the last TakePitchTrace
   void Block480(const float* in480, float* out480);
   void Reblock(const float* in, float* out, int n);
   RateBridge bridge_;

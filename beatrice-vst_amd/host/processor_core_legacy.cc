@@ -88,7 +88,7 @@ void ProcessorCoreLegacy::Hop(const float* in160, float* out240) {
   float feature[4];
   lib_.estimate_pitch(pitch_estimator_, in160, &q, feature, pitch_context_);
   q = TransformPitch(q);
-  pitch_trace_.push_back(q);
+  RecordPitch(q);
   const size_t target = static_cast<size_t>(target_speaker_);
   // morphing: one solver update per hop; the slot follows it until it has converged (:121-130)
   if (target_speaker_ == n_speakers_ && !mean_.Update()) mean_.Result(speaker_embeddings_.data() + target * kHidden);

@@ -52,7 +52,11 @@ int BeatriceHost_SetVQNumNeighbors(void* core, int v);
 int BeatriceHost_SetSpeakerMorphingWeights(void* core, const float* weights, int n);  /* :507-532 */
 void BeatriceHost_SetMorphSeed(void* core, unsigned seed);                   /* the reference seeds from random_device; tests need a fixed lottery */
 int BeatriceHost_NumSpeakers(void* core);
-int BeatriceHost_TakePitchTrace(void* core, int* out, int cap);              /* test hook: quantised pitch per hop */
+/* Test hook, off by default: EnablePitchTrace(capacity) allocates a ring of `capacity` entries (off the audio thread; 0 = off
+ * again); while on, every hop writes its transformed pitch bin into the ring (no allocation per hop).  TakePitchTrace copies
+ * the newest <= min(cap, capacity) entries since the last call, oldest first, and returns how many the ring held. */
+void BeatriceHost_EnablePitchTrace(void* core, int capacity);
+int BeatriceHost_TakePitchTrace(void* core, int* out, int cap);
 /* weighted spherical mean as the morph branch runs it (spherical_average.h:80-444); returns updates performed */
 int BeatriceHost_SphericalMean(int dim, int n_points, const float* points, const float* weights, const int* order, int limit,
                                int max_updates, float* out);

@@ -11,7 +11,7 @@ _f32p = C.POINTER(C.c_float)
 
 
 class Host:
-    def __init__(self, path, sample_rate):
+    def __init__(self, path, sample_rate, pitch_trace=4096):
         self.lib = C.CDLL(path)
         L = self.lib
         L.BeatriceHost_Create.restype, L.BeatriceHost_Create.argtypes = C.c_void_p, [C.c_double]
@@ -21,6 +21,7 @@ class Host:
         L.BeatriceHost_ResetContext.argtypes = [C.c_void_p]
         L.BeatriceHost_NumSpeakers.argtypes = [C.c_void_p]
         L.BeatriceHost_TakePitchTrace.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
+        L.BeatriceHost_EnablePitchTrace.restype, L.BeatriceHost_EnablePitchTrace.argtypes = None, [C.c_void_p, C.c_int]
         L.BeatriceHost_ReserveBlocks.argtypes = [C.c_void_p, C.c_int]
         L.BeatriceHost_BufferFingerprint.restype, L.BeatriceHost_BufferFingerprint.argtypes = C.c_ulonglong, [C.c_void_p]
         for name in ("SetSampleRate", "SetFormantShift", "SetPitchShift", "SetInputGain", "SetOutputGain", "SetAverageSourcePitch",
@@ -29,6 +30,8 @@ class Host:
         for name in ("SetTargetSpeaker", "SetPitchCorrectionType", "SetVQNumNeighbors"):
             getattr(L, "BeatriceHost_" + name).argtypes = [C.c_void_p, C.c_int]
         self.h = L.BeatriceHost_Create(float(sample_rate))
+        if pitch_trace:   # (the library's default is off: a ring of this capacity, allocated here, off the audio path)
+            L.BeatriceHost_EnablePitchTrace(self.h, pitch_trace)
 
     def call(self, name, *args):
         return getattr(self.lib, "BeatriceHost_" + name)(self.h, *args)

@@ -115,9 +115,9 @@ def test_process_never_reallocates_its_block_buffers(host_path, model_dir):
     """The reference's real-time rule (src/common/resample.h:303-305: buffers are sized when the rate is set, Process does not
     allocate): the per-block buffers are reserved by the constructor / SetSampleRate / ReserveBlocks, and blocks up to the
     reserve -- at a rate where the inner stream is LONGER than the host block -- leave their storage where it is."""
-    h = hostlib.Host(host_path, 24000.0)
+    h = hostlib.Host(host_path, 24000.0, pitch_trace=16)   # (the test hook's ring: 16 entries, far fewer than the hops below)
     assert h.load(model_dir) == 0
-    fp0 = h.call("BufferFingerprint")
+    fp0 = h.call("BufferFingerprint")   # covers io / work / scratch AND the pitch-trace ring: every container the per-hop path writes
     x = wrapperlib.test_signal(3 * 8192 + 1000, 24000, seed=7)
     pos = 0
     for n in (64, 8192, 1, 8192, 4096, 8192, 999):   # the default reserve is 8192 host samples
@@ -133,4 +133,12 @@ def test_process_never_reallocates_its_block_buffers(host_path, model_dir):
     assert fp2 != fp1
     h.process(x[:20000], 20000)
     assert h.call("BufferFingerprint") == fp2
+    # the trace ring held its 16 newest hops of the > 100 processed and never grew; with the hook off nothing is recorded
+    assert len(h.pitch_trace()) == 16
+    h.close()
+    h = hostlib.Host(host_path, 24000.0, pitch_trace=0)
+    assert h.load(model_dir) == 0
+    fp = h.call("BufferFingerprint")
+    h.process(x[:8192], 512)
+    assert h.pitch_trace() == [] and h.call("BufferFingerprint") == fp
     h.close()

@@ -48,6 +48,7 @@ class LegacyHost(hostlib.Host):
         self.lib.BeatriceHost_SetSpeakerMorphingWeights.argtypes = [C.c_void_p, _f32p, C.c_int]
         self.lib.BeatriceHost_GetVersion.argtypes = [C.c_void_p]
         self.h = self.lib.BeatriceHost_CreateVersion(float(sample_rate), version)
+        self.lib.BeatriceHost_EnablePitchTrace(self.h, 4096)
 
 
 def spherical_mean(lib, points, weights, updates):
