@@ -44,14 +44,59 @@ __device__ unsigned long long* g_rc_stamps;   // [workgroups][16]
 namespace rc {
 
 constexpr int NTHR = 512, NWAVE = 8;
-constexpr int AS = B_HID + 2;        // LDS row stride of a 256-channel tile: A-operand reads (row l&15, k l>>4) hit 32 distinct banks
+// LDS tiles of activations [16 rows][K] hold every 16-long k-block K-PERMUTED: logical k = 16 b + 4 j + q sits at position
+// 16 b + 4 q + j (kpos), so that the four values a lane feeds to the four MFMAs of a k-block (k = q, 4 + q, 8 + q, 12 + q for the
+// lane's q = l >> 4) are ONE ds_read_b128 instead of four ds_read_b32 (round 5; profiles/r05_notes.md).  Row stride = K + 8
+// floats: stride / 4 = 2 (mod 16) makes the 16-byte slots of each of ds_read_b128's four lane groups ({0-3, 12-15, 20-27}, ...:
+// rows 0-3 and 12-15 at one q, rows 4-11 at q + 1) all distinct -- conflict-free (with K + 4 rows 11 and 12 would collide).
+#ifndef RC_KPERM
+#define RC_KPERM 1   // A/B build switch: 0 = tiles in logical k order, four ds_read_b32 per k-block (rounds 2-4), row stride K + 2
+#endif
+constexpr bool KPERM = RC_KPERM != 0;
+constexpr int AS = B_HID + (KPERM ? 8 : 2);        // LDS row stride of a 256-channel tile
 constexpr int TILE = 16 * AS;        // floats of one [16][256] tile
-constexpr int SS = B_KV_LEN + 2;     // row stride of the score tile
+constexpr int SS = B_KV_LEN + (KPERM ? 8 : 2);     // row stride of the score tile
 constexpr int STILE = 16 * SS;
+__host__ __device__ constexpr int kpos(int k) { return KPERM ? ((k & ~15) | ((k & 3) << 2) | ((k >> 2) & 3)) : k; }
+constexpr int KSTEP = KPERM ? 4 : 1;   // distance of columns n, n + 1 of a lane's four inside a tile row
+// Which 16-byte piece (row r, floats 4 q .. 4 q + 3) of a [rows][256] tile a thread gathers: wave-load W (64 threads) and lane ln.
+// Logical tiles: one row per wave-load.  k-permuted tiles: FOUR rows x 16 pieces per wave-load -- a piece is stored as four
+// ds_write_b32 at p, p + 4, p + 8, p + 12, and 64 pieces of ONE row would hit 8 of the 32 banks (4-way, twice the time); rows
+// are 8 banks apart, so four rows x 16 pieces are 2-way, which costs a ds_write_b32 nothing (MI355X_MICROARCH.md, LDS)
+#ifndef RC_WMAP
+#define RC_WMAP RC_KPERM
+#endif
+template <int ROWGROUPS /* rows / 4 */>
+__device__ __forceinline__ void piece_of(const int W, const int ln, int* r, int* q) {
+  if constexpr (RC_WMAP != 0) { *r = 4 * (W % ROWGROUPS) + (ln >> 4); *q = 16 * (W / ROWGROUPS) + (ln & 15); }
+  else { *r = W; *q = ln; }
+}
+// a lane's operand base inside a tile row: its q = l >> 4
+__device__ __forceinline__ int lane_koff(const int lane) { return KPERM ? 4 * (lane >> 4) : (lane >> 4); }
+// the four values k = q, 4 + q, 8 + q, 12 + q of k-block kb for this lane (p = row base + lane_koff)
+__device__ __forceinline__ float4 lds_kblock(const float* __restrict__ p, const int kb) {
+  if constexpr (KPERM) return *reinterpret_cast<const float4*>(p + kb * 16);
+  else { const float* q = p + kb * 16; return make_float4(q[0], q[4], q[8], q[12]); }
+}
+// Results come TRANSPOSED out of the matrix unit: the weights are the MFMA's A operand, the activations its B operand (bit for
+// bit the same chains: tools/microbench/mfma_swap.hip), so a lane owns FOUR CONSECUTIVE COLUMNS n0 .. n0 + 3 of ONE row (row =
+// l & 15, n0 = 16 tile + 4 (l >> 4)) -- one row lookup, one 16-byte bias / residual load and one 16-byte store per accumulator,
+// where the other orientation (four rows of one column) paid all of that per element.  In a k-permuted LDS tile those four
+// columns are the elements p, p + 4, p + 8, p + 12 with p = kpos(n0).
+__device__ __forceinline__ void store_perm4(float* __restrict__ row, const int n0, const float v0, const float v1, const float v2, const float v3) {
+  if constexpr (KPERM) {
+    float* d = row + kpos(n0);
+    d[0] = v0; d[4] = v1; d[8] = v2; d[12] = v3;
+  } else {   // (row stride K + 2: 8-byte aligned)
+    float2* d = reinterpret_cast<float2*>(row + n0);
+    d[0] = make_float2(v0, v1); d[1] = make_float2(v2, v3);
+  }
+}
 
-// One reduction segment (KB k-blocks of 16) for CG column tiles of this wavefront: acc[c] += A[16 x 16 KB] . W.
-// `a` = this lane's A base in LDS (row l&15, k l>>4 of the segment's first k); `wf` = this lane's float4 of column
-// tile 0 / k-block 0 of the segment; consecutive column tiles of the wavefront are `tile_stride` float4 apart.
+// One reduction segment (KB k-blocks of 16) for CG column tiles of this wavefront: acc[c] += (A[16 x 16 KB] . W)^T.
+// `a` = this lane's activation base in the k-permuted LDS tile (row l & 15, position 4 (l >> 4) of the segment's first
+// k-block: 16-byte aligned); `wf` = this lane's float4 of column tile 0 / k-block 0 of the segment; consecutive column tiles
+// of the wavefront are `tile_stride` float4 apart.  acc[c][e] = row l & 15, column 16 tile_c + 4 (l >> 4) + e.
 // B fragments are fetched four k-blocks ahead of their use (an L2 round trip is ~200-500 cycles, a k-block is
 // 4 CG MFMAs = 128 CG cycles of the SIMD's matrix pipe; eight ahead measured 2 % better than four at two column tiles).
 // Software pipeline, pinned: left alone the compiler SINKS the prefetch loads to just in front of their first use (to save
@@ -81,7 +126,7 @@ __device__ __forceinline__ void mma_segment_p(f32x4 (&acc)[CG], const float* __r
   for (int d = 0; d < D; ++d)
 #pragma unroll
     for (int c = 0; c < CG; ++c) bq[d][c] = wf[c][(size_t)d * 64];
-  float an[4] = {a[0], a[4], a[8], a[12]};   // A operand of the k-block to come (one k-block ahead: LDS latency behind 4 CG MFMAs)
+  float4 an = lds_kblock(a, 0);   // activations of the k-block to come (one k-block ahead: LDS latency behind 4 CG MFMAs), one ds_read_b128
 #pragma unroll
   for (int kb = 0; kb < KB; kb += D) {
 #pragma unroll
@@ -89,24 +134,21 @@ __device__ __forceinline__ void mma_segment_p(f32x4 (&acc)[CG], const float* __r
       float4 cur[CG];
 #pragma unroll
       for (int c = 0; c < CG; ++c) cur[c] = bq[d][c];
-      const float a0 = an[0], a1 = an[1], a2 = an[2], a3 = an[3];
+      const float4 x = an;
       if (kb + d + D < KB) {
 #pragma unroll
         for (int c = 0; c < CG; ++c) bq[d][c] = wf[c][(size_t)ABL_KB(kb + d + D) * 64];
       }
-      if (kb + d + 1 < KB) {
-        const float* ap = a + (kb + d + 1) * 16;
-        an[0] = ap[0]; an[1] = ap[4]; an[2] = ap[8]; an[3] = ap[12];
-      }
+      if (kb + d + 1 < KB) an = lds_kblock(a, kb + d + 1);
       pin_pipeline();
 #pragma unroll
-      for (int c = 0; c < CG; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, cur[c].x, acc[c], 0, 0, 0);
+      for (int c = 0; c < CG; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[c].x, x.x, acc[c], 0, 0, 0);
 #pragma unroll
-      for (int c = 0; c < CG; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, cur[c].y, acc[c], 0, 0, 0);
+      for (int c = 0; c < CG; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[c].y, x.y, acc[c], 0, 0, 0);
 #pragma unroll
-      for (int c = 0; c < CG; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, cur[c].z, acc[c], 0, 0, 0);
+      for (int c = 0; c < CG; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[c].z, x.z, acc[c], 0, 0, 0);
 #pragma unroll
-      for (int c = 0; c < CG; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, cur[c].w, acc[c], 0, 0, 0);
+      for (int c = 0; c < CG; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[c].w, x.w, acc[c], 0, 0, 0);
     }
   }
 }
@@ -123,12 +165,9 @@ __device__ __forceinline__ void mma_segment_rt(f32x4 (&acc)[RT][CG], const float
   for (int d = 0; d < D; ++d)
 #pragma unroll
     for (int c = 0; c < CG; ++c) bq[d][c] = wf[c][(size_t)d * 64];
-  float an[RT][4];
+  float4 an[RT];
 #pragma unroll
-  for (int t = 0; t < RT; ++t) {
-    const float* ap = a + t * a_tile_stride;
-    an[t][0] = ap[0]; an[t][1] = ap[4]; an[t][2] = ap[8]; an[t][3] = ap[12];
-  }
+  for (int t = 0; t < RT; ++t) an[t] = lds_kblock(a + t * a_tile_stride, 0);
 #pragma unroll
   for (int kb = 0; kb < KB; kb += D) {
 #pragma unroll
@@ -136,37 +175,34 @@ __device__ __forceinline__ void mma_segment_rt(f32x4 (&acc)[RT][CG], const float
       float4 cur[CG];
 #pragma unroll
       for (int c = 0; c < CG; ++c) cur[c] = bq[d][c];
-      float av[RT][4];
+      float4 av[RT];
 #pragma unroll
-      for (int t = 0; t < RT; ++t) { av[t][0] = an[t][0]; av[t][1] = an[t][1]; av[t][2] = an[t][2]; av[t][3] = an[t][3]; }
+      for (int t = 0; t < RT; ++t) av[t] = an[t];
       if (kb + d + D < KB) {
 #pragma unroll
         for (int c = 0; c < CG; ++c) bq[d][c] = wf[c][(size_t)ABL_KB(kb + d + D) * 64];
       }
       if (kb + d + 1 < KB) {
 #pragma unroll
-        for (int t = 0; t < RT; ++t) {
-          const float* ap = a + t * a_tile_stride + (kb + d + 1) * 16;
-          an[t][0] = ap[0]; an[t][1] = ap[4]; an[t][2] = ap[8]; an[t][3] = ap[12];
-        }
+        for (int t = 0; t < RT; ++t) an[t] = lds_kblock(a + t * a_tile_stride, kb + d + 1);
       }
       pin_pipeline();
 #pragma unroll
       for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int c = 0; c < CG; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][0], cur[c].x, acc[t][c], 0, 0, 0);
+        for (int c = 0; c < CG; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[c].x, av[t].x, acc[t][c], 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int c = 0; c < CG; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][1], cur[c].y, acc[t][c], 0, 0, 0);
+        for (int c = 0; c < CG; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[c].y, av[t].y, acc[t][c], 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int c = 0; c < CG; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][2], cur[c].z, acc[t][c], 0, 0, 0);
+        for (int c = 0; c < CG; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[c].z, av[t].z, acc[t][c], 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int c = 0; c < CG; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][3], cur[c].w, acc[t][c], 0, 0, 0);
+        for (int c = 0; c < CG; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[c].w, av[t].w, acc[t][c], 0, 0, 0);
     }
   }
 }
@@ -180,8 +216,8 @@ __device__ __forceinline__ void mma_segment(f32x4 (&acc)[CG], const float* __res
 }
 
 // A layer over 16 rows: K = NSEG segments of 256 (segment s read from LDS tile seg[s], row stride `as`), N = 16 * 8 * CG
-// columns; wavefront w owns column tiles w, w + 8, ...  epi4(first row, col, values) receives the ordered sums of the segments
-// for the four consecutive rows a lane owns of one column (pairs of them go through the packed scalar functions, spec_math.hip.h).
+// columns; wavefront w owns column tiles w, w + 8, ...  epi4(row, first column, values) receives the ordered sums of the segments
+// for the four consecutive columns a lane owns of one row (pairs of them go through the packed scalar functions, spec_math.hip.h).
 template <int NSEG, int CG, class Epi4>
 __device__ __forceinline__ void layer256(const float* const (&seg)[NSEG], const int as, const float* __restrict__ w_packed,
                                          const int wave, const int lane, Epi4 epi4) {
@@ -194,7 +230,7 @@ __device__ __forceinline__ void layer256(const float* const (&seg)[NSEG], const 
     f32x4 acc[CG];
 #pragma unroll
     for (int c = 0; c < CG; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    mma_segment<CG, 16>(acc, seg[s] + (lane & 15) * as + (lane >> 4), wf + (size_t)s * 16 * 64, tile_stride);
+    mma_segment<CG, 16>(acc, seg[s] + (lane & 15) * as + lane_koff(lane), wf + (size_t)s * 16 * 64, tile_stride);
 #pragma unroll
     for (int c = 0; c < CG; ++c) {
       if (s == 0) tot[c] = acc[c];
@@ -202,10 +238,10 @@ __device__ __forceinline__ void layer256(const float* const (&seg)[NSEG], const 
     }
   }
 #pragma unroll
-  for (int c = 0; c < CG; ++c) epi4((lane >> 4) * 4, (wave + NWAVE * c) * 16 + (lane & 15), tot[c]);   // rows r0 .. r0 + 3 of one column
+  for (int c = 0; c < CG; ++c) epi4(lane & 15, (wave + NWAVE * c) * 16 + (lane >> 4) * 4, tot[c]);   // columns n0 .. n0 + 3 of one row
 }
 
-// [16 rows][256 channels] from a ring into an LDS tile; row r = frame `rel` of stream sid[r] (zeros when sid[r] < 0)
+// [16 rows][256 channels] from a ring into a k-permuted LDS tile; row r = frame `rel` of stream sid[r] (zeros when sid[r] < 0)
 // (rowhop: LDS [16], the rows' own step counters in a ragged tick step -- sid[] is then already -1 for streams that sit it out --
 //  or nullptr: every row at `pos`)
 // HOPS = hops per step: sid[r] is then the ROW (stream * HOPS + hop in step) and the row's frame is `rel + hop in step`
@@ -214,13 +250,13 @@ __device__ __forceinline__ void load_tile(float* __restrict__ dst, const Ring& r
                                           const int tid, const int* rowhop = nullptr) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int idx = tid + i * NTHR, r = idx >> 6, q = idx & 63;
+    const int idx = tid + i * NTHR;
+    int r, q;
+    piece_of<4>(idx >> 6, idx & 63, &r, &q);
     const int b = sid[r];
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (b >= 0) v = *reinterpret_cast<const float4*>(ring_frame(ring, b / HOPS, rowhop != nullptr ? ring_pos(ring, rowhop[r]) : pos, rel + b % HOPS) + 4 * q);
-    float2* d = reinterpret_cast<float2*>(dst + r * AS + 4 * q);
-    d[0] = make_float2(v.x, v.y);
-    d[1] = make_float2(v.z, v.w);
+    store_perm4(dst + r * AS, 4 * q, v.x, v.y, v.z, v.w);
   }
 }
 
@@ -261,11 +297,10 @@ __device__ __forceinline__ void block_a_body(const BlockAArgs& a, const int g, f
   {
     const float* const seg[3] = {T[0], T[1], T[2]};
     const float* __restrict__ bias = a.c1_b;
-    layer256<3, 2>(seg, AS, a.c1_w, wave, lane, [&](int r0, int n, const f32x4& v) {
-      const float bn = bias[n];
-      const bsp::f32x2 g0 = bsp::gelu2(bsp::f32x2{v[0] + bn, v[1] + bn}), g1 = bsp::gelu2(bsp::f32x2{v[2] + bn, v[3] + bn});
-      float* h = Hh + r0 * AS + n;
-      h[0] = g0.x; h[AS] = g0.y; h[2 * AS] = g1.x; h[3 * AS] = g1.y;
+    layer256<3, 2>(seg, AS, a.c1_w, wave, lane, [&](int r, int n0, const f32x4& v) {
+      const float4 bn = *reinterpret_cast<const float4*>(bias + n0);
+      const bsp::f32x2 g0 = bsp::gelu2(bsp::f32x2{v[0] + bn.x, v[1] + bn.y}), g1 = bsp::gelu2(bsp::f32x2{v[2] + bn.z, v[3] + bn.w});
+      store_perm4(Hh + r * AS, n0, g0.x, g0.y, g1.x, g1.y);
     });
   }
   __syncthreads();
@@ -273,13 +308,13 @@ __device__ __forceinline__ void block_a_body(const BlockAArgs& a, const int g, f
     const float* const seg[1] = {Hh};
     const float* __restrict__ bias = a.c2_b;
     const int pos_o = ring_pos(a.xa, hop);
-    layer256<1, 2>(seg, AS, a.c2_w, wave, lane, [&](int r0, int n, const f32x4& v) {
-      const float bn = bias[n];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int b = sid[r0 + e];
-        if (b >= 0) ring_frame(a.xa, b / HOPS, rowhop != nullptr ? ring_pos(a.xa, rowhop[r0 + e]) : pos_o, b % HOPS)[n] = T[2][(r0 + e) * AS + n] + (v[e] + bn);
-      }
+    layer256<1, 2>(seg, AS, a.c2_w, wave, lane, [&](int r, int n0, const f32x4& v) {
+      const int b = sid[r];
+      if (b < 0) return;
+      const float4 bn = *reinterpret_cast<const float4*>(bias + n0);
+      const float* x = T[2] + r * AS + kpos(n0);   // the residual: this row's raw input, columns n0 .. n0 + 3
+      *reinterpret_cast<float4*>(ring_frame(a.xa, b / HOPS, rowhop != nullptr ? ring_pos(a.xa, rowhop[r]) : pos_o, b % HOPS) + n0) =
+          make_float4(x[0] + (v[0] + bn.x), x[KSTEP] + (v[1] + bn.y), x[2 * KSTEP] + (v[2] + bn.z), x[3 * KSTEP] + (v[3] + bn.w));
     });
   }
 }
@@ -347,30 +382,30 @@ __device__ __forceinline__ void block_b_body(const BlockBArgs& a, const int g, f
     const float* const seg[1] = {XA};
     const float* __restrict__ bias = a.q_b;
     RC_STAMP(1);
-    layer256<1, 2>(seg, AS, a.q_w, wave, lane, [&](int r0, int n, const f32x4& v) {
-      const float bn = bias[n];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) Q[(r0 + e) * AS + n] = v[e] + bn;
+    layer256<1, 2>(seg, AS, a.q_w, wave, lane, [&](int r, int n0, const f32x4& v) {
+      const float4 bn = *reinterpret_cast<const float4*>(bias + n0);
+      store_perm4(Q + r * AS, n0, v[0] + bn.x, v[1] + bn.y, v[2] + bn.z, v[3] + bn.w);
     });
   }
   __syncthreads();
   RC_STAMP(2);
   {
     const float* const seg[1] = {Q};
-    layer256<1, 3>(seg, AS, a.kt + (size_t)slot * B_HID * B_KV_LEN, wave, lane, [&](int r0, int n, const f32x4& v) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) S[(r0 + e) * SS + n] = v[e] * 0.0625f;
+    layer256<1, 3>(seg, AS, a.kt + (size_t)slot * B_HID * B_KV_LEN, wave, lane, [&](int r, int n0, const f32x4& v) {
+      store_perm4(S + r * SS, n0, v[0] * 0.0625f, v[1] * 0.0625f, v[2] * 0.0625f, v[3] * 0.0625f);
     });
   }
   __syncthreads();
   RC_STAMP(3);
-  // softmax statistics, two rows per wavefront (MODEL_SPEC 4.4.2; same operations as attn_pv_kernel)
+  // softmax statistics, two rows per wavefront (MODEL_SPEC 4.4.2; same operations as attn_pv_kernel); lane l owns the LOGICAL
+  // keys l, l + 64, ... of a row (the order of the sums is the spec's), which sit at kpos(l) + 64 i in the k-permuted tile
+  const int lp = kpos(lane);
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr) {
     const int r = wave * 2 + rr;
     float v[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) v[i] = S[r * SS + lane + 64 * i];
+    for (int i = 0; i < 6; ++i) v[i] = S[r * SS + lp + 64 * i];
     float mx = -__builtin_huge_valf();
 #pragma unroll
     for (int i = 0; i < 6; ++i) mx = fmaxf(mx, v[i]);
@@ -380,7 +415,7 @@ __device__ __forceinline__ void block_b_body(const BlockBArgs& a, const int g, f
     for (int i = 0; i < 6; i += 2) {   // (pairs through the packed exp: the same bits, half the instructions; the sum in index order as before)
       const bsp::f32x2 e = bsp::exp2(bsp::f32x2{v[i] - mx, v[i + 1] - mx});
       s = s + e.x; s = s + e.y;
-      S[r * SS + lane + 64 * i] = e.x; S[r * SS + lane + 64 * (i + 1)] = e.y;
+      S[r * SS + lp + 64 * i] = e.x; S[r * SS + lp + 64 * (i + 1)] = e.y;
     }
     const float tot = bsp::wsum64(s);
     if (lane == 0) inv[r] = 1.0f / tot;
@@ -390,18 +425,16 @@ __device__ __forceinline__ void block_b_body(const BlockBArgs& a, const int g, f
   {  // o = (segment 0 + segment 1) * (1 / sum): K = 384 = 256 + 128, V packed [384][256]
     const float4* wf = reinterpret_cast<const float4*>(a.v + (size_t)slot * B_KV_LEN * B_HID) + (size_t)wave * (B_KV_LEN / 16) * 64 + lane;
     const size_t tile_stride = (size_t)NWAVE * (B_KV_LEN / 16) * 64;
-    const float* ap = S + (lane & 15) * SS + (lane >> 4);
+    const float* ap = S + (lane & 15) * SS + lane_koff(lane);
     f32x4 acc0[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, acc1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     mma_segment<2, 16>(acc0, ap, wf, tile_stride);
     mma_segment<2, 8>(acc1, ap + 256, wf + (size_t)16 * 64, tile_stride);
+    const int r = lane & 15;
+    const float ir = inv[r];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = (lane >> 4) * 4 + e, n = (wave + NWAVE * c) * 16 + (lane & 15);
-        const float v = acc0[c][e] + acc1[c][e];
-        Q[r * AS + n] = v * inv[r];
-      }
+      store_perm4(Q + r * AS, (wave + NWAVE * c) * 16 + (lane >> 4) * 4, (acc0[c][0] + acc1[c][0]) * ir, (acc0[c][1] + acc1[c][1]) * ir,
+                  (acc0[c][2] + acc1[c][2]) * ir, (acc0[c][3] + acc1[c][3]) * ir);
   }
   __syncthreads();
   RC_STAMP(5);
@@ -409,13 +442,13 @@ __device__ __forceinline__ void block_b_body(const BlockBArgs& a, const int g, f
     const float* const seg[1] = {Q};
     const float* __restrict__ bias = a.o_b;
     const int pos_o = ring_pos(a.out, hop);
-    layer256<1, 2>(seg, AS, a.o_w, wave, lane, [&](int r0, int n, const f32x4& v) {
-      const float bn = bias[n];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int b = sid[r0 + e];
-        if (b >= 0) ring_frame(a.out, b / HOPS, rowhop != nullptr ? ring_pos(a.out, rowhop[r0 + e]) : pos_o, b % HOPS)[n] = XA[(r0 + e) * AS + n] + (v[e] + bn);
-      }
+    layer256<1, 2>(seg, AS, a.o_w, wave, lane, [&](int r, int n0, const f32x4& v) {
+      const int b = sid[r];
+      if (b < 0) return;
+      const float4 bn = *reinterpret_cast<const float4*>(bias + n0);
+      const float* x = XA + r * AS + kpos(n0);   // the residual: this row of xa, columns n0 .. n0 + 3
+      *reinterpret_cast<float4*>(ring_frame(a.out, b / HOPS, rowhop != nullptr ? ring_pos(a.out, rowhop[r]) : pos_o, b % HOPS) + n0) =
+          make_float4(x[0] + (v[0] + bn.x), x[KSTEP] + (v[1] + bn.y), x[2 * KSTEP] + (v[2] + bn.z), x[3 * KSTEP] + (v[3] + bn.w));
     });
   }
   RC_STAMP(6);
@@ -550,10 +583,11 @@ __device__ __forceinline__ void block_bq_body(const BlockBqArgs& a, const int g,
     const float* const seg[1] = {XA};
     const float* __restrict__ bias = a.q_b;
     RC_STAMP(1);
-    layer256<1, 2>(seg, AS, a.q_w, wave, lane, [&](int r0, int n, const f32x4& v) {
-      const float bn = bias[n];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) Q[(r0 + e) * AS + n] = v[e] + bn;
+    // (q in LOGICAL column order: the quad products below read a row's k in sequence; XA above and o below are k-permuted tiles)
+    layer256<1, 2>(seg, AS, a.q_w, wave, lane, [&](int r, int n0, const f32x4& v) {
+      const float4 bn = *reinterpret_cast<const float4*>(bias + n0);
+      float2* d = reinterpret_cast<float2*>(Q + r * AS + n0);
+      d[0] = make_float2(v[0] + bn.x, v[1] + bn.y); d[1] = make_float2(v[2] + bn.z, v[3] + bn.w);
     });
   }
   __syncthreads();
@@ -604,7 +638,7 @@ __device__ __forceinline__ void block_bq_body(const BlockBqArgs& a, const int g,
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float v = acc0[0][r] + acc1[0][r];
-      Q[(quad * 4 + r) * AS + n] = v * inv[quad * 4 + r];
+      Q[(quad * 4 + r) * AS + kpos(n)] = v * inv[quad * 4 + r];   // (o: the output layer's k-permuted operand tile)
     }
   }
   __syncthreads();
@@ -613,13 +647,13 @@ __device__ __forceinline__ void block_bq_body(const BlockBqArgs& a, const int g,
     const float* const seg[1] = {Q};
     const float* __restrict__ bias = a.o_b;
     const int pos_o = ring_pos(a.out, hop);
-    layer256<1, 2>(seg, AS, a.o_w, wave, lane, [&](int r0, int n, const f32x4& v) {
-      const float bn = bias[n];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int b = sid[r0 + e];
-        if (b >= 0) ring_frame(a.out, b / HOPS, rowhop != nullptr ? ring_pos(a.out, rowhop[r0 + e]) : pos_o, b % HOPS)[n] = XA[(r0 + e) * AS + n] + (v[e] + bn);
-      }
+    layer256<1, 2>(seg, AS, a.o_w, wave, lane, [&](int r, int n0, const f32x4& v) {
+      const int b = sid[r];
+      if (b < 0) return;
+      const float4 bn = *reinterpret_cast<const float4*>(bias + n0);
+      const float* x = XA + r * AS + kpos(n0);   // the residual: this row of xa, columns n0 .. n0 + 3
+      *reinterpret_cast<float4*>(ring_frame(a.out, b / HOPS, rowhop != nullptr ? ring_pos(a.out, rowhop[r]) : pos_o, b % HOPS) + n0) =
+          make_float4(x[0] + (v[0] + bn.x), x[KSTEP] + (v[1] + bn.y), x[2 * KSTEP] + (v[2] + bn.z), x[3 * KSTEP] + (v[3] + bn.w));
     });
   }
   __builtin_amdgcn_s_setprio(0);
@@ -672,21 +706,23 @@ __device__ __forceinline__ void conv_rows_body(const ConvArgs& a, const int bx, 
   }
   __syncthreads();
   const int pos_in = ring_pos(a.in, hop);
-  // this thread's 2 RT 16-byte pieces of a segment: rows r0 + 8 i, piece q
-  const int q = tid & 63, r0 = tid >> 6;
-  int pb[2 * RT], pt[2 * RT];
+  // this thread's 2 RT 16-byte pieces of a segment: (row pr[i], piece pq[i]), wave-load wave + 8 i (piece_of)
+  int pr[2 * RT], pq[2 * RT], pb[2 * RT], pt[2 * RT];
 #pragma unroll
-  for (int i = 0; i < 2 * RT; ++i) { pb[i] = rb_[r0 + 8 * i]; pt[i] = rb_[ROWS + r0 + 8 * i]; }
+  for (int i = 0; i < 2 * RT; ++i) {
+    piece_of<4 * RT>(wave + NWAVE * i, lane, &pr[i], &pq[i]);
+    pb[i] = rb_[pr[i]]; pt[i] = rb_[ROWS + pr[i]];
+  }
   float4 nx[2 * RT];
   auto load_seg = [&](int s) {
-    const int kk = s * 256 + 4 * q;
-    const bool live = kk < K;
-    const int j = live ? kk / L::CIN : 0, c = live ? kk % L::CIN : 0;
 #pragma unroll
     for (int i = 0; i < 2 * RT; ++i) {
+      const int kk = s * 256 + 4 * pq[i];
+      const bool live = kk < K;
+      const int j = live ? kk / L::CIN : 0, c = live ? kk % L::CIN : 0;
       nx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (live && pb[i] >= 0)
-        nx[i] = *reinterpret_cast<const float4*>(ring_frame(a.in, pb[i], rag ? ring_pos(a.in, rb_[2 * ROWS + r0 + 8 * i]) : pos_in,   // (ragged: worked out per load, no register held for it in the common case)
+        nx[i] = *reinterpret_cast<const float4*>(ring_frame(a.in, pb[i], rag ? ring_pos(a.in, rb_[2 * ROWS + pr[i]]) : pos_in,   // (ragged: worked out per load, no register held for it in the common case)
                                                             (pt[i] + 1) * L::STRIDE - 1 - (L::KSZ - 1 - j) * L::DIL + a.rel_shift) + c);
     }
   };
@@ -695,9 +731,7 @@ __device__ __forceinline__ void conv_rows_body(const ConvArgs& a, const int bx, 
     for (int i = 0; i < 2 * RT; ++i) {
       float4 v = nx[i];
       if constexpr (L::PRE == PRE_LRELU) { v.x = bsp::lrelu(v.x); v.y = bsp::lrelu(v.y); v.z = bsp::lrelu(v.z); v.w = bsp::lrelu(v.w); }
-      float2* d = reinterpret_cast<float2*>(dst + (r0 + 8 * i) * AS + 4 * q);   // (row 16 t + r of the slot = row r of its tile t: tiles are contiguous)
-      d[0] = make_float2(v.x, v.y);
-      d[1] = make_float2(v.z, v.w);
+      store_perm4(dst + pr[i] * AS, 4 * pq[i], v.x, v.y, v.z, v.w);   // (row 16 t + r of the slot = row r of its tile t: tiles are contiguous)
     }
   };
   const float4* wfc[CG];
@@ -721,7 +755,7 @@ __device__ __forceinline__ void conv_rows_body(const ConvArgs& a, const int bx, 
     const float4* wfs[CG];
 #pragma unroll
     for (int c = 0; c < CG; ++c) wfs[c] = wfc[c] + (size_t)s * 16 * 64;
-    const float* ap = slot[s & 1] + (lane & 15) * AS + (lane >> 4);
+    const float* ap = slot[s & 1] + (lane & 15) * AS + lane_koff(lane);
     if constexpr (RT == 1) {
       if (s + 1 < P) mma_segment_p<CG, 16>(acc[0], ap, wfs);
       else mma_segment_p<CG, LAST / 16>(acc[0], ap, wfs);
@@ -741,51 +775,52 @@ __device__ __forceinline__ void conv_rows_body(const ConvArgs& a, const int bx, 
       __syncthreads();
     }
   }
-  // epilogue: conv_gemm's, operation for operation
+  // epilogue: conv_gemm's, operation for operation; a lane owns columns n0 .. n0 + 3 of ONE row per accumulator (the transposed
+  // form, top of this file): one row lookup, 16-byte bias / residual loads and one 16-byte store
   const int pos_out = ring_pos(a.out, hop), R_out = a.out.n * a.out.m;
   int pos_res = 0, R_res = 0;
   if constexpr (L::RES) { pos_res = ring_pos(a.res, hop); R_res = a.res.n * a.res.m; }
-  float bias_n[CG];
+  float4 bias_n[CG];
 #pragma unroll
   for (int c = 0; c < CG; ++c) {
     const int nt = wave + NWAVE * c < NTL ? wave + NWAVE * c : NTL - 1;
-    bias_n[c] = L::EPI == EPI_BIAS ? a.bias[(nt_base + nt) * 16 + (lane & 15)] : 0.0f;
+    bias_n[c] = L::EPI == EPI_BIAS ? *reinterpret_cast<const float4*>(a.bias + (nt_base + nt) * 16 + (lane >> 4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #pragma unroll
-  for (int t = 0; t < RT; ++t)
+  for (int t = 0; t < RT; ++t) {
+    const int r = 16 * t + (lane & 15);
+    const int rb = rb_[r], rf = rb_[ROWS + r];
+    int po = pos_out, pr = pos_res;
+    if (rag) {
+      const int hr = rb_[2 * ROWS + r];
+      po = ring_pos(a.out, hr);
+      if constexpr (L::RES) pr = ring_pos(a.res, hr);
+    }
+    float rs = 1.0f;
+    if constexpr (L::EPI == EPI_ROWSCALE) rs = a.rowscale[(rb < 0 ? 0 : rb) * L::T + rf];
 #pragma unroll
     for (int c = 0; c < CG; ++c) {
       if (wave + NWAVE * c >= NTL) continue;
-      const int n = (nt_base + wave + NWAVE * c) * 16 + (lane & 15);
+      const int n0 = (nt_base + wave + NWAVE * c) * 16 + (lane >> 4) * 4;
       float v[4];
-      int rb[4], rf[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 16 * t + (lane >> 4) * 4 + e;
-        rb[e] = rb_[r]; rf[e] = rb_[ROWS + r];
-        v[e] = tot[t][c][e];
-        if constexpr (L::EPI == EPI_BIAS) v[e] = v[e] + bias_n[c];
-        if constexpr (L::EPI == EPI_SCALE) v[e] = v[e] * a.scale;
-        if constexpr (L::EPI == EPI_ROWSCALE) v[e] = v[e] * a.rowscale[(rb[e] < 0 ? 0 : rb[e]) * L::T + rf[e]];
-      }
+      for (int e = 0; e < 4; ++e) v[e] = tot[t][c][e];
+      if constexpr (L::EPI == EPI_BIAS) { v[0] = v[0] + bias_n[c].x; v[1] = v[1] + bias_n[c].y; v[2] = v[2] + bias_n[c].z; v[3] = v[3] + bias_n[c].w; }
+      if constexpr (L::EPI == EPI_SCALE) { for (int e = 0; e < 4; ++e) v[e] = v[e] * a.scale; }
+      if constexpr (L::EPI == EPI_ROWSCALE) { for (int e = 0; e < 4; ++e) v[e] = v[e] * rs; }
       if constexpr (L::ACT == ACT_GELU) {   // pairs through the packed scalar functions (spec_math.hip.h): the same bits
         const bsp::f32x2 g0 = bsp::gelu2(bsp::f32x2{v[0], v[1]}), g1 = bsp::gelu2(bsp::f32x2{v[2], v[3]});
         v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (rb[e] < 0) continue;
-        int po = pos_out, pr = pos_res;
-        if (rag) {
-          const int hr = rb_[2 * ROWS + 16 * t + (lane >> 4) * 4 + e];
-          po = ring_pos(a.out, hr);
-          if constexpr (L::RES) pr = ring_pos(a.res, hr);
-        }
-        // (32-bit index arithmetic: a ring holds fewer than 2^32 floats, RingArena::build)
-        if constexpr (L::RES) v[e] = a.res.base[(unsigned)(rb[e] * R_res + pr) * (unsigned)a.res.C + (unsigned)(rf[e] * L::NOUT + n)] + v[e];
-        a.out.base[(unsigned)(rb[e] * R_out + po) * (unsigned)a.out.C + (unsigned)(rf[e] * L::NOUT + n)] = v[e];
+      if (rb < 0) continue;
+      // (32-bit index arithmetic: a ring holds fewer than 2^32 floats, RingArena::build)
+      if constexpr (L::RES) {
+        const float4 x = *reinterpret_cast<const float4*>(a.res.base + ((unsigned)(rb * R_res + pr) * (unsigned)a.res.C + (unsigned)(rf * L::NOUT + n0)));
+        v[0] = x.x + v[0]; v[1] = x.y + v[1]; v[2] = x.z + v[2]; v[3] = x.w + v[3];
       }
+      *reinterpret_cast<float4*>(a.out.base + ((unsigned)(rb * R_out + po) * (unsigned)a.out.C + (unsigned)(rf * L::NOUT + n0))) = make_float4(v[0], v[1], v[2], v[3]);
     }
+  }
 }
 template <class L, int COLS = 0, int RT = 1>
 struct ConvRowsOp {
