@@ -19,6 +19,7 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
   using OpF4s = typename O::OpF4s; using OpF5s = typename O::OpF5s; using OpRBs = typename O::OpRBs; using OpP1s = typename O::OpP1s; using OpUP1s = typename O::OpUP1s;
   using T1 = typename O::T1; using T2 = typename O::T2; using T3 = typename O::T3; using T1s = typename O::T1s; using T2s = typename O::T2s;
   using GruQ = typename O::GruQ; using GruP = typename O::GruP; using GruQ1 = typename O::GruQ1; using GruP1 = typename O::GruP1;
+  using GruQm = typename O::GruQm; using GruPm = typename O::GruPm;
   State& k = b->tk;
   auto tb = std::make_unique<typename O::Builder>();
   const PhoneWeights& pw = b->phone_m->w;
@@ -45,11 +46,41 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
   auto hp = [&](int) -> const int* { return nullptr; };
   auto conv = [&](const Ring& in, const Ring& out, const float* w, const float* bias, int stage) { return conv_args(in, out, w, bias, hp(stage), B); };
   // (workgroups are dispatched in this order: the longest-running bodies first)
-  if constexpr (H > 1) {   // the GRU cells of the step's FIRST hop: ahead of every other body, so that the cells of the second hop
-                           // (below, behind the launch's first round) find their states published when they start
-    { const GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(Plan::PGRU), B, 0, k.d_link_p, nullptr, k.h_link_dead}; tb->template add<T_PGRU>(GruP::info("phone.gru", g), g, GruP::grid(g), Plan::PGRU, keep(1), 7.6); }
-    { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, 0, k.d_link_q, nullptr, k.h_link_dead}; tb->template add<T_QGRU>(GruQ::info("pitch.gru", g), g, GruQ::grid(g), Plan::QGRU, keep(1), 4.6); }
-  }
+  // The GRU cells of a step's hops, linked inside the launch (tick.hip.h): hop 0 publishes into link 0, hop t polls link t - 1 and
+  // publishes into link t, the last hop only polls.  A cell must find its predecessor's states published when it starts (it holds a
+  // slot while it waits), so the hops sit far apart in dispatch order: hop 0 ahead of every other body, the later ones at the points
+  // marked gru_at() below, each behind at least one more round of the launch's workgroups.
+  auto link_p = [&](int t) { return k.d_link_p + (size_t)t * B * 256; };
+  auto link_q = [&](int t) { return k.d_link_q + (size_t)t * B * 128; };
+  auto add_pgru = [&](int t) {
+    if constexpr (H > 1) {
+      GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(Plan::PGRU), B, t, t + 1 < H ? link_p(t) : nullptr, t > 0 ? link_p(t - 1) : nullptr, k.h_link_dead};
+      if (t == 0) tb->template add<T_PGRU>(GruP::info("phone.gru", g), g, GruP::grid(g), Plan::PGRU, keep(1), 7.6);
+      else if (t == H - 1) tb->template add<T_PGRU1>(GruP1::info("phone.gru", g), g, GruP1::grid(g), Plan::PGRU, keep(1), 7.6);
+      else if constexpr (H > 2) tb->template add<T_PGRUM>(GruPm::info("phone.gru", g), g, GruPm::grid(g), Plan::PGRU, keep(1), 7.6);
+    }
+  };
+  auto add_qgru = [&](int t) {
+    if constexpr (H > 1) {
+      GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, t, t + 1 < H ? link_q(t) : nullptr, t > 0 ? link_q(t - 1) : nullptr, k.h_link_dead};
+      if (t == 0) tb->template add<T_QGRU>(GruQ::info("pitch.gru", g), g, GruQ::grid(g), Plan::QGRU, keep(1), 4.6);
+      else if (t == H - 1) tb->template add<T_QGRU1>(GruQ1::info("pitch.gru", g), g, GruQ1::grid(g), Plan::QGRU, keep(1), 4.6);
+      else if constexpr (H > 2) tb->template add<T_QGRUM>(GruQm::info("pitch.gru", g), g, GruQm::grid(g), Plan::QGRU, keep(1), 4.6);
+    }
+  };
+  // gru_at(point): the hops placed at insertion point 0 (behind the conditioned blocks), 1 (behind the tail), 2 / 3 (where the second
+  // hop of a two-hop step has always been: behind phone.f2 / wave.inp).  H = 2: hop 1 at 2 (phone) and 3 (pitch); H = 4: hops 1, 2 at
+  // 0, 1 and hop 3 at 2 / 3
+  auto gru_at = [&](int point) {
+    if constexpr (H == 2) { if (point == 2) add_pgru(1); if (point == 3) add_qgru(1); }
+    if constexpr (H == 4) {
+      if (point == 0) { add_pgru(1); add_qgru(1); }
+      if (point == 1) { add_pgru(2); add_qgru(2); }
+      if (point == 2) add_pgru(3);
+      if (point == 3) add_qgru(3);
+    }
+  };
+  add_pgru(0); add_qgru(0);
   // ---- longest workgroups first (measured, two per CU): f5 48 us, p1 46, f4 45, rb 42, block halves 41 / 38, tail 36
   if (!sparse) {
     { const ConvArgs a = conv(ps.f[3], ps.f[4], pw.f_w[3], pw.f_b[3], Plan::F5); tb->template add<T_F5>(OpF5::info("phone.f5", a), a, OpF5::grid(a), Plan::F5, keep(6), 47); }
@@ -92,6 +123,7 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
       default: tb->template add<T_BLKA8>(rc::BlockAOp<8, H>::info(aa), aa, rc::BlockAOp<8, H>::grid(aa), pl.blk(blk), keep(5), 41); break;
     }
   }
+  gru_at(0);
   if (!pl.split_tail) {
     TailArgs ta = tail_args(ww, ws); ta.hop = hp(pl.tail()); tb->template add<T_TAIL>(tail_info(ws), ta, dim3(B, 1), pl.tail(), keep(4), 41, true);
   } else {
@@ -112,7 +144,11 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
     }
     tb->template add<T_TAIL3>(T3::info(t3), t3, T3::grid(t3), pl.tail() + 2, keep(4), 16, true);
   }
+  gru_at(1);
   // ---- everything else, longest workgroups first (they start when the heavy ones above leave their slots)
+  // (the pitch head: few workgroups that walk a step's hops one after the other -- 10 us per workgroup at two hops per step, 21 at four;
+  //  at the end of the table, where its instruction count would put it, it ENDED the launch: round 5's timelines, profiles/r05_notes.md)
+  { PitchHeadArgs a = head_args(qw, qs); a.hop = hp(Plan::HEAD); tb->template add<T_HEAD>(head_info(qs), a, dim3((B + 7) / 8, 1), Plan::HEAD, keep(0), 4.7 * H); }
   { const ConvArgs a = conv(ps.f[1], ps.f[2], pw.f_w[1], pw.f_b[1], Plan::F3); tb->template add<T_F3>(OpF3::info("phone.f3", a), a, OpF3::grid(a), Plan::F3, keep(6), 18); }
   if (!sparse) { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], pl.up1()); tb->template add<T_UP1>(OpUP1::info("wave.up1", a), a, OpUP1::grid(a), pl.up1(), keep(7), 36); }
   else { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], pl.up1()); tb->template add<T_UP1S>(OpUP1s::info("wave.up1", a), a, OpUP1s::grid(a), pl.up1(), keep(7), 36); }
@@ -121,7 +157,7 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
   { const ConvArgs a = conv(ws.yc1, ws.ya2, ww.up_w[1], ww.up_b[1], pl.up1() + 3); tb->template add<T_UP2>(OpUP2::info("wave.up2", a), a, OpUP2::grid(a), pl.up1() + 3, keep(7), 12); }
   { const ConvArgs a = conv(ps.f[0], ps.f[1], pw.f_w[0], pw.f_b[0], Plan::F2); tb->template add<T_F2>(OpF2::info("phone.f2", a), a, OpF2::grid(a), Plan::F2, keep(6), 10); }
   if constexpr (H == 1) { const GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(Plan::PGRU), B, 0}; tb->template add<T_PGRU>(GruP::info("phone.gru", g), g, GruP::grid(g), Plan::PGRU, keep(1), 7.6); }
-  else { const GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(Plan::PGRU), B, 1, nullptr, k.d_link_p, k.h_link_dead}; tb->template add<T_PGRU1>(GruP1::info("phone.gru", g), g, GruP1::grid(g), Plan::PGRU, keep(1), 7.6); }
+  gru_at(2);
   { const ConvArgs a = conv(qs.h, qs.logits, qw.out_w, qw.out_b, Plan::POUT); tb->template add<T_POUT>(OpPOUT::info("pitch.out", a), a, OpPOUT::grid(a), Plan::POUT, keep(2), 9.4); }
   for (int i = 0; i < 2; ++i) {
     const ConvArgs a = conv(qs.p[i], qs.p[i + 1], qw.p_w[i + 1], qw.p_b[i + 1], Plan::P2 + i);
@@ -129,11 +165,10 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
   }
   { const Ring phone_in{ws.d_phone, B_PHONE_CH, H, ws.front_slots}; ConvArgs a = conv(phone_in, ws.x[0], ww.inp_w, ww.inp_b, Plan::INP); a.res = ws.e; tb->template add<T_INP>(OpINP::info("wave.inp", a), a, OpINP::grid(a), Plan::INP, keep(3), 7.7); }
   if constexpr (H == 1) { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, 0}; tb->template add<T_QGRU>(GruQ::info("pitch.gru", g), g, GruQ::grid(g), Plan::QGRU, keep(1), 4.6); }
-  else { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, 1, nullptr, k.d_link_q, k.h_link_dead}; tb->template add<T_QGRU1>(GruQ1::info("pitch.gru", g), g, GruQ1::grid(g), Plan::QGRU, keep(1), 4.6); }
+  gru_at(3);
   { FftArgs a = fft_args(qw, qs); a.hop = hp(Plan::FFT); tb->template add<T_FFT>(fft_info(qs), FftArgs2{a, B}, dim3((B + 1) / 2, H), Plan::FFT, keep(0), 6); }
   { const ConvArgs a = conv(ps.h, phone_out_ring(ps), pw.out_w, pw.out_b, Plan::OUT); tb->template add<T_OUT>(OpOUT::info("phone.out", a), a, OpOUT::grid(a), Plan::OUT, keep(3), 6); }
   { const VqArgs a{H, ps.raw, phone_vector_ring(ps), hp(Plan::VQ), ps.d_cbT, ps.d_cnorm, ps.d_vqk}; tb->template add<T_VQ>(LaunchInfo{"phone.vq", 0, 4.0 * B * H * 256}, a, dim3(B, 1), Plan::VQ, !ps.skip_vq, 6.0, true); }
-  { PitchHeadArgs a = head_args(qw, qs); a.hop = hp(Plan::HEAD); tb->template add<T_HEAD>(head_info(qs), a, dim3((B + 7) / 8, 1), Plan::HEAD, keep(0), 4.7); }
   { F1Args a = f1_args(pw, ps); a.hop = hp(Plan::F1); a.hop_publish = nullptr; a.hop_publish_wave = nullptr; tb->template add<T_F1>(f1_info(ps), F1Args2{a, B}, dim3((B + 1) / 2, H), Plan::F1, keep(0), 4.5); }
   { CondArgs a = cond_args(ww, ws); a.hop = hp(Plan::COND); a.hop_next_out = nullptr; tb->template add<T_COND>(cond_info(ws), a, dim3((B * H + 1) / 2, 1), Plan::COND, keep(0), 1.3); }
   if (!tb->ok) return false;
@@ -175,6 +210,7 @@ bool tick_build_table(BeatriceBatch* b, const bool sparse = false) {
   switch (b->H) {
     case 1: return tick_build_table_h<1>(b, sparse);
     case 2: return tick_build_table_h<2>(b, sparse);
+    case 4: return tick_build_table_h<4>(b, sparse);
     default: return false;
   }
 }
@@ -184,7 +220,8 @@ static void tick_launch(BeatriceBatch* b, const bool sparse, hipStream_t st, con
   const void* t = sparse ? k.d_table_sparse : k.d_table;
   const int total = sparse ? k.table_sparse_total : k.table_total;
   if (b->H == 1) fuse::launch_table_w<4>(static_cast<const tick::Ops<1>::Tab*>(t), total, st, pairs, k.ragged);   // (ragged: the second instance of the launch, once a stream has sat a step out)
-  else fuse::launch_table_w<4, false>(static_cast<const tick::Ops<2>::Tab*>(t), total, st, pairs, false);   // (no ragged steps at several hops per step: EnableSilentBlockRule refuses)
+  else if (b->H == 2) fuse::launch_table_w<4, false>(static_cast<const tick::Ops<2>::Tab*>(t), total, st, pairs, false);   // (no ragged steps at several hops per step: EnableSilentBlockRule refuses)
+  else fuse::launch_table_w<4, false>(static_cast<const tick::Ops<4>::Tab*>(t), total, st, pairs, false);
 }
 
 // One tick: every stage advances by one step; `feeding` = a new step enters at stage 0.
@@ -358,7 +395,9 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
   int highest = -1;
   for (int s = 0; s < p.n_stages; ++s) if (p.hop[s] >= 0) highest = s;
   static const bool no_sparse = std::getenv("BEATRICE_HIP_TICK_NO_SPARSE") != nullptr;   // A/B switch for measurements
-  const bool sparse = highest >= 0 && highest < Plan::BLK0 && !no_sparse;
+  // (one hop per step only: at two hops per step it measured no difference, at four the half-size bodies cost 1 % of a 20-step run --
+  //  5 196 against 5 138 us of launches, profiles/r05_notes.md)
+  const bool sparse = highest >= 0 && highest < Plan::BLK0 && !no_sparse && b->H == 1;
   tick_launch(b, sparse, st, pairs);
   if (b->r48.on) {  // the step this tick completed: its 48 kHz block is produced by the wrapper launch of the next tick (or of the drain)
     const long long u = step_at(k.plan.count() - 1);
@@ -429,12 +468,12 @@ int tick_enable(BeatriceBatch* b, bool on) {
   if (on) {
     // one 10 ms hop per step, resident I/O with enough slots
     // that a step's input is still there when the pitch head reads it nine ticks on and outputs have somewhere to land
-    if (b->H > kMaxHops || b->B > 4096 || b->io_slots < k.plan.count() + 1) return -1;
+    if ((b->H != 1 && b->H != 2 && b->H != 4) || b->B > 4096 || b->io_slots < k.plan.count() + 1) return -1;
     if (!sync_all(b)) return -2;
     if (b->pipelined) { drop_graph(b); set_plan(b, 1); }
     k.snap_bytes = b->off.front_bytes + b->off.wave_bytes;
     if (!k.d_table) {
-      const size_t tab_bytes = std::max(sizeof(Ops<1>::Tab), sizeof(Ops<2>::Tab));
+      const size_t tab_bytes = std::max(std::max(sizeof(Ops<1>::Tab), sizeof(Ops<2>::Tab)), sizeof(Ops<4>::Tab));
       if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_table), tab_bytes), "tick table") ||
           !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_table_sparse), tab_bytes), "tick sparse table") ||
           !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_snap), k.snap_bytes * kRing), "tick snapshots") ||
@@ -443,7 +482,7 @@ int tick_enable(BeatriceBatch* b, bool on) {
       for (hipEvent_t& e : k.stage_ev) if (!hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "tick staging event")) return -2;
     }
     if (b->H > 1 && !k.d_link_p) {   // the granules between the GRU cells of a step's hops (tick.hip.h); tag 0 = never written
-      const size_t nq = (size_t)b->B * 128, np = (size_t)b->B * 256;
+      const size_t nq = (size_t)(b->H - 1) * b->B * 128, np = (size_t)(b->H - 1) * b->B * 256;
       if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_link_q), sizeof(unsigned long long) * nq), "tick gru link") ||
           !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_link_p), sizeof(unsigned long long) * np), "tick gru link") ||
           !hip_ok(hipMemset(k.d_link_q, 0, sizeof(unsigned long long) * nq), "tick gru link") || !hip_ok(hipMemset(k.d_link_p, 0, sizeof(unsigned long long) * np), "tick gru link") ||

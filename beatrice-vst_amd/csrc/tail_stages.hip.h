@@ -299,9 +299,13 @@ __device__ __forceinline__ void store_act4(float* __restrict__ d, const float4 v
 // itself, or from the state block at TS_IN -- then the raw frames that will be the NEXT step's history are stashed in `hin`
 // and reach the state block at the end); the six history rows of the second layer -> Y rows [-6, 0); the history of the third
 // layer (HC_ROWS rows) -> `hc`, activated, to be copied into X once the first layer is done with it.
+// A step cut into SUB-STEPS (NSUB > 1: the tick launch at four hops per step, where a stream's 320 / 960 frames of a step do not fit
+// the LDS): the body runs the sub-steps of T frames one after the other, `fb` = the sub-step's first frame inside the step.  Only
+// the FIRST sub-step takes the layers' histories from the state block -- the later ones find them in LDS, where carry_histories()
+// left them (the input's two history frames are simply the ring's frames fb - 2, fb - 1) -- and only the LAST one writes them back.
 template <int C, int T, int S, int TS_IN, int TS_B, int TS_C, int HC_ROWS, bool IN_FROM_RING_HISTORY, bool RAG>
 __device__ __forceinline__ void prologue(const StageArgs& a, const int hop, const int b0, float* __restrict__ X, float* __restrict__ Y, float* __restrict__ hin,
-                                         float* __restrict__ hc, const int tid, const int* shop) {
+                                         float* __restrict__ hc, const int tid, const int* shop, const int fb = 0, const bool first = true, const bool last = true) {
   constexpr int F4 = C / 4, ROWS = T + 2, N = S * ROWS * F4, NIT = (N + NTHR - 1) / NTHR;
   const int pos = ring_pos(a.in, hop);
   float4 v[NIT];
@@ -311,12 +315,15 @@ __device__ __forceinline__ void prologue(const StageArgs& a, const int hop, cons
     const int s = e / (ROWS * F4), q = e % (ROWS * F4), t = q / F4 - 2, c4 = q % F4, b = b0 + s;
     v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e < N && live_s<RAG>(shop, b0, s, a.B)) {
-      if (IN_FROM_RING_HISTORY || t >= 0) v[it] = *reinterpret_cast<const float4*>(ring_frame(a.in, b, stream_pos<RAG>(a.in, pos, shop, s), t) + 4 * c4);
+      if (IN_FROM_RING_HISTORY || t + fb >= 0) v[it] = *reinterpret_cast<const float4*>(ring_frame(a.in, b, stream_pos<RAG>(a.in, pos, shop, s), t + fb) + 4 * c4);
       else v[it] = *reinterpret_cast<const float4*>(a.state + (size_t)b * TAIL_STATE_FLOATS + TS_IN + (t + 2) * C + 4 * c4);
     }
   }
-  const float4 hb = state_load<S, 6 * C, RAG>(a.state, TS_B, b0, shop, a.B, tid);
-  const float4 hcv = state_load<S, HC_ROWS * C, RAG>(a.state, TS_C, b0, shop, a.B, tid);
+  float4 hb = make_float4(0.f, 0.f, 0.f, 0.f), hcv = hb;
+  if (first) {
+    hb = state_load<S, 6 * C, RAG>(a.state, TS_B, b0, shop, a.B, tid);
+    hcv = state_load<S, HC_ROWS * C, RAG>(a.state, TS_C, b0, shop, a.B, tid);
+  }
   // ---- every load above is in flight; now the stores
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -324,17 +331,34 @@ __device__ __forceinline__ void prologue(const StageArgs& a, const int hop, cons
     if (e < N) {
       const int s = e / (ROWS * F4), q = e % (ROWS * F4), t = q / F4 - 2, c4 = q % F4;
       store_act4(X + row_off<C, T>(s, t) + 4 * c4, v[it]);
-      if (!IN_FROM_RING_HISTORY && t >= T - 2) *reinterpret_cast<float4*>(hin + (s * 2 + (t - (T - 2))) * C + 4 * c4) = v[it];
+      if (!IN_FROM_RING_HISTORY && last && t >= T - 2) *reinterpret_cast<float4*>(hin + (s * 2 + (t - (T - 2))) * C + 4 * c4) = v[it];
     }
   }
-  if (tid < S * 6 * C / 4) {   // (zeros past the batch)
-    const int s = tid / (6 * C / 4), q = tid % (6 * C / 4);
-    store_act4(Y + row_off<C, T>(s, -6 + (4 * q) / C) + (4 * q) % C, hb);
+  if (first) {
+    if (tid < S * 6 * C / 4) {   // (zeros past the batch)
+      const int s = tid / (6 * C / 4), q = tid % (6 * C / 4);
+      store_act4(Y + row_off<C, T>(s, -6 + (4 * q) / C) + (4 * q) % C, hb);
+    }
+    if (tid < S * HC_ROWS * C / 4) {
+      float4 w;
+      w.x = lrelu_max(hcv.x); w.y = lrelu_max(hcv.y); w.z = lrelu_max(hcv.z); w.w = lrelu_max(hcv.w);
+      *reinterpret_cast<float4*>(hc + 4 * tid) = w;
+    }
   }
-  if (tid < S * HC_ROWS * C / 4) {
-    float4 w;
-    w.x = lrelu_max(hcv.x); w.y = lrelu_max(hcv.y); w.z = lrelu_max(hcv.z); w.w = lrelu_max(hcv.w);
-    *reinterpret_cast<float4*>(hc + 4 * tid) = w;
+}
+// between two sub-steps: what the next one's prologue would have read from the state block, taken from this one's LDS buffers --
+// the second layer's six history rows = the last six rows of Y (activated y), the third layer's HC_ROWS = the last rows of X
+// (activated z).  The caller brackets it with barriers (every wavefront is done with X and Y; nobody has started the next prologue).
+template <int C, int T, int S, int HC_ROWS>
+__device__ __forceinline__ void carry_histories(float* __restrict__ X, float* __restrict__ Y, float* __restrict__ hc, const int tid) {
+  static_assert(T >= 12, "history rows and their sources do not overlap");
+  for (int e = tid; e < S * 6 * C; e += NTHR) {
+    const int s = e / (6 * C), q = e % (6 * C);
+    Y[row_off<C, T>(s, -6 + q / C) + q % C] = Y[row_off<C, T>(s, T - 6 + q / C) + q % C];
+  }
+  for (int e = tid; e < S * HC_ROWS * C; e += NTHR) {
+    const int s = e / (HC_ROWS * C), q = e % (HC_ROWS * C);
+    hc[e] = X[row_off<C, T>(s, T - HC_ROWS + q / C) + q % C];
   }
 }
 // a stash [S][ROWS][C] (contiguous) -> rows [t_first, t_first + ROWS) of every stream's block (LDS to LDS)
@@ -363,7 +387,8 @@ template <int C, int T, int S, int TS_B, int TS_C, int HC_ROWS, bool RAG, class 
 __device__ __forceinline__ void two_res_layers(const StageArgs& a, const int hop, const int b0, const int n_rows, float* __restrict__ X, float* __restrict__ Y,
                                                const float* __restrict__ hc, const float4 (&bfa)[Split<C>::CT][3 * C / 16],
                                                const float4 (&bfb)[Split<C>::CT][3 * C / 16], const int wave, const int lane, const int tid, AfterA after_a, Between between,
-                                               const int* shop, float* __restrict__ yr = nullptr /* C > 32: LDS [S][T][C], the raw y (registers are short at 64 channels) */) {
+                                               const int* shop, float* __restrict__ yr = nullptr /* C > 32: LDS [S][T][C], the raw y (registers are short at 64 channels) */,
+                                               const int fb = 0 /* sub-steps: first frame inside the step */, const bool last = true /* the step's last sub-step: histories -> state block */) {
   static_assert(Split<C>::CT == 1, "one column tile per wavefront");
   constexpr bool IN_LDS = C > 32;
   const int n_lane = (wave % Split<C>::NWN) * 16 + (lane & 15);
@@ -375,7 +400,7 @@ __device__ __forceinline__ void two_res_layers(const StageArgs& a, const int hop
       if constexpr (RAG) {
         if (shop[s] < 0) { res[0] = res[1] = res[2] = res[3] = 0.0f; return; }   // (a stream that sits the step out: its rows compute on zeros, nothing of it is written)
       }
-      const float* p = ring_frame(a.in, b0 + s, stream_pos<RAG>(a.in, pos, shop, s), t0) + n;   // (frames t0 .. t0 + 3 of a step are contiguous in its ring slot)
+      const float* p = ring_frame(a.in, b0 + s, stream_pos<RAG>(a.in, pos, shop, s), t0 + fb) + n;   // (frames t0 .. t0 + 3 of a step are contiguous in its ring slot)
 #pragma unroll
       for (int e = 0; e < 4; ++e) res[e] = p[e * C];
     },
@@ -387,7 +412,7 @@ __device__ __forceinline__ void two_res_layers(const StageArgs& a, const int hop
         const float y = res[e] + (acc[e] + bias_a);
         yo[e * cs<C>()] = lrelu_max(y);
         if (IN_LDS) yr[((s * T) + t0 + e) * C + n] = y; else res[e] = y;   // the second layer's residual
-        if (t0 + e >= T - 6 && (!RAG || shop[s] >= 0)) st[e * C] = y;
+        if (last && t0 + e >= T - 6 && (!RAG || shop[s] >= 0)) st[e * C] = y;
       }
     });
   after_a();
@@ -408,7 +433,7 @@ __device__ __forceinline__ void two_res_layers(const StageArgs& a, const int hop
       for (int e = 0; e < 4; ++e) {
         const float z = res[e] + (acc[e] + bias_b);
         xo[e * cs<C>()] = lrelu_max(z);
-        if (t0 + e >= T - HC_ROWS && (!RAG || shop[s] >= 0)) st[e * C] = z;
+        if (last && t0 + e >= T - HC_ROWS && (!RAG || shop[s] >= 0)) st[e * C] = z;
       }
     });
   TST_STAMP(5);
@@ -420,8 +445,9 @@ __device__ __forceinline__ void two_res_layers(const StageArgs& a, const int hop
 // T1 and T2: the two residual layers, then the polyphase transposed conv (k2 over input frames, rate UPR, COUT channels)
 // into the next stage's ring.  IN_FROM_RING_HISTORY: the first layer's two history frames come from the input ring itself
 // (T1: the ring of up2 keeps them); otherwise from the state block at TS_IN (T2).
-template <int C, int T, int S, int COUT, int UPR, int TS_IN, int TS_B, int TS_C, bool IN_FROM_RING_HISTORY, bool RAG = false>
+template <int C, int T, int S, int COUT, int UPR, int TS_IN, int TS_B, int TS_C, bool IN_FROM_RING_HISTORY, bool RAG = false, int NSUB = 1>
 __device__ __forceinline__ void res_res_up_body(const StageArgs& a, const int g, float* __restrict__ lds) {
+  // (T = frames per SUB-step; the step has NSUB * T frames per stream, prologue())
   constexpr int NUP = UPR * COUT;
   float* X = lds;
   float* Y = X + buf_floats<C, T, S>();
@@ -436,38 +462,50 @@ __device__ __forceinline__ void res_res_up_body(const StageArgs& a, const int g,
   const int b0 = g * S;
   const int n_rows = (a.B - b0 < S ? a.B - b0 : S) * T;
   int* shop = reinterpret_cast<int*>(lds + stage_lds<C, T, S, 1>() - 8);
-  float4 bfa[Split<C>::CT][3 * C / 16], bfb[Split<C>::CT][3 * C / 16], bfu[Split<NUP>::CT][2 * C / 16];
-  TST_STAMP(0);
-  fetch_b<3 * C, C>(a.w[0], bfa, wave, lane);
   stream_hops<S, RAG>(a, hop, b0, shop);
-  prologue<C, T, S, TS_IN, TS_B, TS_C, 1, IN_FROM_RING_HISTORY, RAG>(a, hop, b0, X, Y, HIN, HC, tid, shop);
-  TST_STAMP(1);
-  __syncthreads();
-  TST_STAMP(2);
-  constexpr int KBR = 3 * C / 16, KBU = 2 * C / 16;
-  fetch_b<3 * C, C, 0, KBR / 2>(a.w[1], bfb, wave, lane);
-  two_res_layers<C, T, S, TS_B, TS_C, 1, RAG>(a, hop, b0, n_rows, X, Y, HC, bfa, bfb, wave, lane, tid,
-                                         [&] { fetch_b<3 * C, C, KBR / 2, KBR>(a.w[1], bfb, wave, lane); },
-                                         [&] { fetch_b<2 * C, NUP, 0, KBU / 2>(a.w[2], bfu, wave, lane); }, shop, C > 32 ? HC + S * C : nullptr);
-  fetch_b<2 * C, NUP, KBU / 2, KBU>(a.w[2], bfu, wave, lane);
-  // ---- transposed conv (polyphase k2): X -> the next stage's ring, frame t UPR + n / COUT, channel n % COUT
-  {
-    using SU = Split<NUP>;
-    float bias_u[SU::CT];
+#pragma unroll 1
+  for (int sub = 0; sub < NSUB; ++sub) {
+    const int fb = NSUB > 1 ? sub * T : 0;
+    const bool first = NSUB == 1 || sub == 0, last = NSUB == 1 || sub == NSUB - 1;
+    float4 bfa[Split<C>::CT][3 * C / 16], bfb[Split<C>::CT][3 * C / 16], bfu[Split<NUP>::CT][2 * C / 16];
+    TST_STAMP(0);
+    fetch_b<3 * C, C>(a.w[0], bfa, wave, lane);
+    prologue<C, T, S, TS_IN, TS_B, TS_C, 1, IN_FROM_RING_HISTORY, RAG>(a, hop, b0, X, Y, HIN, HC, tid, shop, fb, first, last);
+    TST_STAMP(1);
+    __syncthreads();
+    TST_STAMP(2);
+    constexpr int KBR = 3 * C / 16, KBU = 2 * C / 16;
+    fetch_b<3 * C, C, 0, KBR / 2>(a.w[1], bfb, wave, lane);
+    two_res_layers<C, T, S, TS_B, TS_C, 1, RAG>(a, hop, b0, n_rows, X, Y, HC, bfa, bfb, wave, lane, tid,
+                                           [&] { fetch_b<3 * C, C, KBR / 2, KBR>(a.w[1], bfb, wave, lane); },
+                                           [&] { fetch_b<2 * C, NUP, 0, KBU / 2>(a.w[2], bfu, wave, lane); }, shop, C > 32 ? HC + S * C : nullptr, fb, last);
+    fetch_b<2 * C, NUP, KBU / 2, KBU>(a.w[2], bfu, wave, lane);
+    // ---- transposed conv (polyphase k2): X -> the next stage's ring, frame t UPR + n / COUT, channel n % COUT
+    {
+      using SU = Split<NUP>;
+      float bias_u[SU::CT];
 #pragma unroll
-    for (int ct = 0; ct < SU::CT; ++ct) bias_u[ct] = a.b[2][(SU::POW2 ? wave % SU::NWN : ct) * 16 + (lane & 15)];
-    const int pos_o = ring_pos(a.out, hop);
-    float none[n_pass<NUP, T, S>()][2][SU::CT][4];   // (no residual in this layer: never read, costs no registers)
-    layer<C, NUP, 2, 1, T, S, 0>(X, bfu, n_rows, wave, lane, none, [](int, int, int, int, float (&)[4]) {},
-      [&](int s, int t0, int n, int ct, const tail_f32x4& acc, float (&)[4]) {
-        const float bu = bias_u[ct];   // (ct is a compile-time index after unrolling)
-        if constexpr (RAG) { if (shop[s] < 0) return; }
-        float* o = ring_frame(a.out, b0 + s, stream_pos<RAG>(a.out, pos_o, shop, s), t0 * UPR + n / COUT) + n % COUT;   // (output frames of one input frame are UPR apart)
+      for (int ct = 0; ct < SU::CT; ++ct) bias_u[ct] = a.b[2][(SU::POW2 ? wave % SU::NWN : ct) * 16 + (lane & 15)];
+      const int pos_o = ring_pos(a.out, hop);
+      float none[n_pass<NUP, T, S>()][2][SU::CT][4];   // (no residual in this layer: never read, costs no registers)
+      layer<C, NUP, 2, 1, T, S, 0>(X, bfu, n_rows, wave, lane, none, [](int, int, int, int, float (&)[4]) {},
+        [&](int s, int t0, int n, int ct, const tail_f32x4& acc, float (&)[4]) {
+          const float bu = bias_u[ct];   // (ct is a compile-time index after unrolling)
+          if constexpr (RAG) { if (shop[s] < 0) return; }
+          float* o = ring_frame(a.out, b0 + s, stream_pos<RAG>(a.out, pos_o, shop, s), (t0 + fb) * UPR + n / COUT) + n % COUT;   // (output frames of one input frame are UPR apart)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e * UPR * COUT] = acc[e] + bu;
-      });
+          for (int e = 0; e < 4; ++e) o[e * UPR * COUT] = acc[e] + bu;
+        });
+    }
+    TST_STAMP(7);
+    if constexpr (NSUB > 1) {
+      if (!last) {
+        __syncthreads();
+        carry_histories<C, T, S, 1>(X, Y, HC, tid);
+        __syncthreads();
+      }
+    }
   }
-  TST_STAMP(7);
   if (!IN_FROM_RING_HISTORY) hin_to_state<C, S, TS_IN, RAG>(a, HIN, b0, tid, shop);
   TST_STAMP(8);
 }
@@ -496,21 +534,24 @@ struct T1OpS {
   }
 };
 using T1Op = T1OpS<kT1Streams>;
-template <int S = kT2Streams, int HOPS = 1>
+// NSUB: the step's 80 HOPS frames per stream in NSUB sub-steps, one after the other inside the workgroup (res_res_up_body)
+template <int S = kT2Streams, int HOPS = 1, int NSUB = 1>
 struct T2OpS {
   using Args = StageArgs;
-  static constexpr int T = 80 * HOPS;
-  static constexpr int NTHR = tst::NTHR, LDS_FLOATS = stage_lds<32, T, S, 1>();
+  static_assert(HOPS % NSUB == 0, "whole hops per sub-step");
+  static constexpr int T = 80 * HOPS;          // frames per stream and step
+  static constexpr int TSUB = T / NSUB;        // ... per sub-step: what the LDS holds
+  static constexpr int NTHR = tst::NTHR, LDS_FLOATS = stage_lds<32, TSUB, S, 1>();
   static inline dim3 grid(const Args& a) { return dim3((a.B + S - 1) / S, 1); }
   static inline bhip::LaunchInfo info(const Args& a) {
     const double macs = 2.0 * T * 96 * 32 + 1.0 * T * 64 * 48;
     return bhip::LaunchInfo{"wave.tail2", 2.0 * a.B * macs, 4.0 * (2.0 * 96 * 32 + 64.0 * 48 + a.B * (1.0 * T * 32 + 3 * T * 16 + 2 * 9 * 32))};
   }
   __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) {
-    res_res_up_body<32, T, S, 16, 3, TS_YA3, TS_YB3, TS_YC3, false>(a, bx, lds);
+    res_res_up_body<32, TSUB, S, 16, 3, TS_YA3, TS_YB3, TS_YC3, false, false, NSUB>(a, bx, lds);
   }
   template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) {
-    res_res_up_body<32, T, S, 16, 3, TS_YA3, TS_YB3, TS_YC3, false, RAG>(a, bx, lds);
+    res_res_up_body<32, TSUB, S, 16, 3, TS_YA3, TS_YB3, TS_YC3, false, RAG, NSUB>(a, bx, lds);
   }
 };
 using T2Op = T2OpS<kT2Streams>;
@@ -520,9 +561,10 @@ constexpr int kT3Lds = t3_lds<kT3Streams, 1>();
 
 // ---------------------------------------------------------------------------------------------------------------------
 // T3: res4a, res4b (16 channels, 240 frames per stream) and the output conv: lrelu, Conv1d(16 -> 1, k7), tanh.
-template <bool RAG = false, int S = kT3Streams, int HOPS = 1>
+template <bool RAG = false, int S = kT3Streams, int HOPS = 1, int NSUB = 1>
 __device__ __forceinline__ void t3_body(const StageArgs& a, const int g, float* __restrict__ lds) {
-  constexpr int C = 16, T = 240 * HOPS;
+  static_assert(HOPS % NSUB == 0, "whole hops per sub-step");
+  constexpr int C = 16, T = 240 * HOPS / NSUB;   // T = frames per SUB-step (prologue()): what the LDS holds
   static_assert(S * T <= NTHR, "one thread per output sample");
   float* X = lds;
   float* Y = X + buf_floats<C, T, S>();
@@ -546,37 +588,49 @@ __device__ __forceinline__ void t3_body(const StageArgs& a, const int g, float* 
   fetch_b<48, 16>(a.w[1], bfb, wave, lane);
   const float fin_b = a.fin_b[0];
   const float fw = tid < 7 * 16 ? a.fin_w[tid] : 0.0f;
-  prologue<C, T, S, TS_YA4, TS_YB4, TS_YC4, 6, false, RAG>(a, hop, b0, X, Y, HIN, HC, tid, shop);
-  if (tid < 7 * 16) FW[tid] = fw;
-  __syncthreads();
-  two_res_layers<C, T, S, TS_YB4, TS_YC4, 6, RAG>(a, hop, b0, n_rows, X, Y, HC, bfa, bfb, wave, lane, tid, [] {}, [] {}, shop);
-  // ---- output conv over the ACTIVATED frames: one thread per sample, the multiply-adds of wave_tail.hip.h in the same order
-  if (tid < S * T) {
-    const int s = tid / T, t = tid % T;
-    if (live_s<RAG>(shop, b0, s, a.B)) {
-      float acc = 0.0f;
-      const float* x = X + row_off<C, T>(s, t - 6);
+#pragma unroll 1
+  for (int sub = 0; sub < NSUB; ++sub) {
+    const int fb = NSUB > 1 ? sub * T : 0;
+    const bool first = NSUB == 1 || sub == 0, last = NSUB == 1 || sub == NSUB - 1;
+    prologue<C, T, S, TS_YA4, TS_YB4, TS_YC4, 6, false, RAG>(a, hop, b0, X, Y, HIN, HC, tid, shop, fb, first, last);
+    if (first && tid < 7 * 16) FW[tid] = fw;
+    __syncthreads();
+    two_res_layers<C, T, S, TS_YB4, TS_YC4, 6, RAG>(a, hop, b0, n_rows, X, Y, HC, bfa, bfb, wave, lane, tid, [] {}, [] {}, shop, nullptr, fb, last);
+    // ---- output conv over the ACTIVATED frames: one thread per sample, the multiply-adds of wave_tail.hip.h in the same order
+    if (tid < S * T) {
+      const int s = tid / T, t = tid % T;
+      if (live_s<RAG>(shop, b0, s, a.B)) {
+        float acc = 0.0f;
+        const float* x = X + row_off<C, T>(s, t - 6);
 #pragma unroll
-      for (int j = 0; j < 7; ++j)
+        for (int j = 0; j < 7; ++j)
 #pragma unroll
-        for (int c = 0; c < 16; ++c) acc = bsp::fma(x[j * cs<C>() + c], FW[j * 16 + c], acc);
-      d_out[(size_t)(b0 + s) * T + t] = bsp::tanh2(bsp::splat2(acc + fin_b)).x;   // (the packed form is the shorter one even for a single value)
+          for (int c = 0; c < 16; ++c) acc = bsp::fma(x[j * cs<C>() + c], FW[j * 16 + c], acc);
+        d_out[(size_t)(b0 + s) * (T * NSUB) + fb + t] = bsp::tanh2(bsp::splat2(acc + fin_b)).x;   // (the packed form is the shorter one even for a single value)
+      }
+    }
+    if constexpr (NSUB > 1) {
+      if (!last) {
+        __syncthreads();
+        carry_histories<C, T, S, 6>(X, Y, HC, tid);
+        __syncthreads();
+      }
     }
   }
   hin_to_state<C, S, TS_YA4, RAG>(a, HIN, b0, tid, shop);
 }
-template <int S = kT3Streams, int HOPS = 1>
+template <int S = kT3Streams, int HOPS = 1, int NSUB = 1>
 struct T3OpS {
   using Args = StageArgs;
   static constexpr int T = 240 * HOPS;
-  static constexpr int NTHR = tst::NTHR, LDS_FLOATS = t3_lds<S, HOPS>();
+  static constexpr int NTHR = tst::NTHR, LDS_FLOATS = t3_lds<S, HOPS / NSUB>();
   static inline dim3 grid(const Args& a) { return dim3((a.B + S - 1) / S, 1); }
   static inline bhip::LaunchInfo info(const Args& a) {
     const double macs = 2.0 * T * 48 * 16 + 1.0 * T * 112;
     return bhip::LaunchInfo{"wave.tail3", 2.0 * a.B * macs, 4.0 * (2.0 * 48 * 16 + 112.0 + a.B * (1.0 * T * 16 + T + 2 * 14 * 16))};
   }
-  __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { t3_body<false, S, HOPS>(a, bx, lds); }
-  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) { t3_body<RAG, S, HOPS>(a, bx, lds); }
+  __device__ static __forceinline__ void run(const Args& a, int bx, int, float* lds) { t3_body<false, S, HOPS, NSUB>(a, bx, lds); }
+  template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int, float* lds) { t3_body<RAG, S, HOPS, NSUB>(a, bx, lds); }
 };
 using T3Op = T3OpS<kT3Streams, 1>;
 

@@ -90,7 +90,7 @@ using namespace wave_layers;
 enum BodyType {
   T_F1, T_FFT, T_F2, T_F3, T_F4, T_F5, T_P1, T_RB, T_P23, T_POUT, T_HEAD, T_OUT, T_COND, T_INP, T_UP1, T_RES1A, T_RES1B, T_UP2,
   T_QGRU, T_PGRU, T_VQ, T_TAIL, T_TAIL1, T_TAIL2, T_TAIL3, T_BLKA1, T_BLKA2, T_BLKA4, T_BLKA8, T_BLKB, T_BLKBQ,
-  T_F4S, T_F5S, T_RBS, T_P1S, T_UP1S, T_TAIL1S, T_TAIL2S, T_QGRU1, T_PGRU1, T_COUNT
+  T_F4S, T_F5S, T_RBS, T_P1S, T_UP1S, T_TAIL1S, T_TAIL2S, T_QGRU1, T_PGRU1, T_QGRUM, T_PGRUM, T_COUNT
 };
 // The bodies of a tick with H hops per stage (H = 1: a step is one 10 ms hop of every stream; H = 2: two -- every stage then
 // works on twice the rows per weight fragment and per launch, and a launch's fixed costs are paid once per two hops; the two
@@ -124,21 +124,28 @@ struct Ops {
   using OpRBs = rc::ConvRowsOp<typename PL::RBL, TICK_RB_COLS, 1>;
   using OpP1s = rc::ConvRowsOp<typename QL1::P1, 0, 1>;
   using OpUP1s = rc::ConvRowsOp<UP<256, 128, 5, H>, 128, 1>;
-  // the tail's stages: streams per workgroup so that a workgroup holds the same number of rows at every H (80 / 240 / 480; H = 2: T2 160)
-  using T1 = tst::T1OpS<(H == 1 ? tst::kT1Streams : 4 / H), H>;
-  using T2 = tst::T2OpS<(H == 1 ? tst::kT2Streams : 1), H>;
-  using T3 = tst::T3OpS<(H == 1 ? tst::kT3Streams : 1), H>;
+  // the tail's stages: streams per workgroup so that a workgroup holds the same number of rows at every H (80 / 240 / 480; H = 2: T2 160).
+  // H = 4: a stream's 320 / 960 frames of a step do not fit the LDS -- T2 and T3 run the step as two sub-steps of two hops, one after
+  // the other inside the workgroup, the layers' histories carried in LDS (tail_stages.hip.h prologue / carry_histories)
+  static constexpr int NSUB = H > 2 ? H / 2 : 1;
+  using T1 = tst::T1OpS<(H == 1 ? tst::kT1Streams : (H == 2 ? 2 : 1)), H>;
+  using T2 = tst::T2OpS<(H == 1 ? tst::kT2Streams : 1), H, NSUB>;
+  using T3 = tst::T3OpS<(H == 1 ? tst::kT3Streams : 1), H, NSUB>;
   using T1s = tst::T1OpS<(H == 1 ? 2 : 1), H>;
-  using T2s = tst::T2OpS<(H == 1 ? 2 : 1), H>;
+  using T2s = tst::T2OpS<(H == 1 ? 2 : 1), H, NSUB>;
   // The GRUs: the column-split cell (fused_small.hip.h; 32 streams x 16 hidden units per workgroup, a weight fragment held in
-  // registers).  Hop t of a step needs the whole state vector of hop t - 1: with two hops per step the cell of hop 0 PUBLISHES
-  // its state as tagged granules and the cell of hop 1 -- a second set of workgroups of the SAME launch and stage, later in
+  // registers).  Hop t of a step needs the whole state vector of hop t - 1: with several hops per step the cell of hop t PUBLISHES
+  // its state as tagged granules and the cell of hop t + 1 -- another set of workgroups of the SAME launch and stage, later in
   // dispatch order (tick_build_table) -- polls them (GruArgs::link_*): the one place where workgroups of a tick wait for each other.
-  static_assert(H <= 2, "one link per GRU");
+  // GruQ / GruP: hop 0 (publishes when H > 1); GruQm / GruPm: hops 1 .. H - 2 (poll and publish; H = 4: two of each, every link
+  // its own granule array); GruQ1 / GruP1: the last hop (polls)
+  static_assert(H <= 4, "link arrays: tick::State");
   using GruQ = GruOp<128, 128, TICK_GRU_RT, (H > 1 ? 1 : 0)>;
   using GruP = GruOp<256, 256, TICK_GRU_RT, (H > 1 ? 1 : 0)>;
   using GruQ1 = std::conditional_t<H == 1, rc::NopOp, GruOp<128, 128, TICK_GRU_RT, 2>>;
   using GruP1 = std::conditional_t<H == 1, rc::NopOp, GruOp<256, 256, TICK_GRU_RT, 2>>;
+  using GruQm = std::conditional_t<H <= 2, rc::NopOp, GruOp<128, 128, TICK_GRU_RT, 3>>;
+  using GruPm = std::conditional_t<H <= 2, rc::NopOp, GruOp<256, 256, TICK_GRU_RT, 3>>;
   using Vq = std::conditional_t<H == 1, VqOp, VqRowsOp<H>>;   // (several hops: a stream's rows in one workgroup, the codebook read once)
   template <class... Ms> struct List { using Tab = fuse::Table<Ms...>; using Builder = fuse::TableBuilder<Ms...>; };
   using L = List<
@@ -149,7 +156,7 @@ struct Ops {
       fuse::Many<Vq, 1>, fuse::Many<TailOp<H>, 1>, fuse::Many<T1, 1>, fuse::Many<T2, 1>, fuse::Many<T3, 1>, fuse::Many<rc::BlockAOp<1, H>, 1>, fuse::Many<rc::BlockAOp<2, H>, 1>,
       fuse::Many<rc::BlockAOp<4, H>, 1>, fuse::Many<rc::BlockAOp<8, H>, 1>, fuse::Many<rc::BlockBOpH<H>, 4>, fuse::Many<rc::BlockBqOpH<H>, 4>,
       fuse::Many<OpF4s, 1>, fuse::Many<OpF5s, 1>, fuse::Many<OpRBs, 4>, fuse::Many<OpP1s, 1>, fuse::Many<OpUP1s, 1>, fuse::Many<T1s, 1>, fuse::Many<T2s, 1>,
-      fuse::Many<GruQ1, 1>, fuse::Many<GruP1, 1>>;
+      fuse::Many<GruQ1, 1>, fuse::Many<GruP1, 1>, fuse::Many<GruQm, 2>, fuse::Many<GruPm, 2>>;
   using Tab = typename L::Tab;
   using Builder = typename L::Builder;
 };
@@ -167,7 +174,7 @@ struct Plan {
   bool split_tail = true;
   int count() const { return tail() + (split_tail ? 3 : 1); }
 };
-constexpr int kMaxHops = 2;   // hops per stage per tick the launch is built for (Ops<1>, Ops<2>)
+constexpr int kMaxHops = 4;   // hops per stage per tick the launch is built for (Ops<1>, Ops<2>, Ops<4>)
 static_assert(Plan::BLK0 + Plan::per_block * B_NBLOCKS + 7 <= kMaxStages && kMaxStages + 2 <= kRing && kMaxStages <= fuse::kMaxStepPairs, "stage bookkeeping");
 
 struct Consumer {  // a kernel that reads per-stream settings: its private copy of a byte range of the settings block
@@ -210,8 +217,8 @@ struct State {
   bool hv_pending[kStaging] = {};
   bool step_ragged[kRing] = {};       // step u (at [u % kRing]) carries per-stream counters
   // several hops per step: the granules that link the GRU cells of a step's hops inside a launch (fused_small.hip.h GruArgs::link_*)
-  unsigned long long* d_link_q = nullptr;   // [B][128]
-  unsigned long long* d_link_p = nullptr;   // [B][256]
+  unsigned long long* d_link_q = nullptr;   // [H - 1][B][128]: link t = hop t's state for hop t + 1
+  unsigned long long* d_link_p = nullptr;   // [H - 1][B][256]
   int* h_link_dead = nullptr;               // pinned: a cell gave a wait up
 };
 

@@ -381,7 +381,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
     ap.add_argument("--speakers", type=int, default=None)
-    ap.add_argument("--hops-per-step", type=int, default=None, choices=(1, 2),
+    ap.add_argument("--hops-per-step", type=int, default=None, choices=(1, 2, 4),
                     help="10 ms hops of every stream per step (tick pipeline: hops per stage per launch); default 2 for configs 2 and 3 "
                          "with the tick pipeline, 1 otherwise")
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4),

@@ -1,6 +1,7 @@
-"""Tick pipelining with TWO hops per stage per tick (a batch created with BeatriceBatch_CreateBlock(..., 2) in tick mode):
-a step is two consecutive 10 ms hops of every stream, every stage of the launch works on twice the rows, the two recurrent
-layers run their hops one after the other inside a workgroup.  Must give the samples of the in-order chain at one hop per step bit for bit -- with settings
+"""Tick pipelining with TWO or FOUR hops per stage per tick (a batch created with BeatriceBatch_CreateBlock(..., 2 / 4) in tick
+mode): a step is H consecutive 10 ms hops of every stream, every stage of the launch works on H times the rows, the cells of the
+two recurrent layers are linked hop to hop inside the launch (H - 1 links of tagged granules), at H = 4 the 32- and 16-channel tail
+stages run a step as two sub-steps.  Must give the samples of the in-order chain at one hop per step bit for bit -- with settings
 that change between steps (speaker switches installing one K/V block per HOP, k-NN, pitch and formant settings), across
 drains, and on the way back to the in-order chain."""
 import itertools
@@ -14,9 +15,10 @@ from test_gpu_resident_io import Hip
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("B,steps", [(24, 40), (5, 34), (256, 36), (1, 33), (37, 70)])
-def test_tick_two_hops_per_step_matches_in_order_chain(bv, oracle, product, model_dir, B, steps):
-    H = 2
+# (1 024 / 4 096 streams: more first-hop GRU cells than the chip has workgroup slots -- the links rest on dispatch order = index order)
+@pytest.mark.parametrize("H,B,steps", [(2, 24, 40), (2, 5, 34), (2, 256, 36), (2, 1, 33), (2, 37, 70), (4, 24, 40), (4, 5, 34), (4, 256, 36), (4, 1, 33), (4, 37, 50),
+                                       (2, 1024, 30), (4, 1024, 30), (2, 4096, 30)])
+def test_tick_two_hops_per_step_matches_in_order_chain(bv, oracle, product, model_dir, H, B, steps):
     hip = Hip()
     m = bv.Models(product, model_dir)
     bv.bind_batch(product)
@@ -30,7 +32,7 @@ def test_tick_two_hops_per_step_matches_in_order_chain(bv, oracle, product, mode
             batch.a.BeatriceBatch_SetVQNumNeighbors(batch.h, s, s % 3)
         batch.a.BeatriceBatch_FlushSpeaker(batch.h, -1)
 
-    def change(batch, k):   # before STEP k (hops 2 k, 2 k + 1)
+    def change(batch, k):   # before STEP k (hops H k .. H k + H - 1)
         a, h = batch.a, batch.h
         if k % 4 == 1:
             s = (7 * k) % B
@@ -45,7 +47,7 @@ def test_tick_two_hops_per_step_matches_in_order_chain(bv, oracle, product, mode
             a.BeatriceBatch_SetMinSourcePitch(h, 0, 50.0)
             a.BeatriceBatch_SetPitchCorrection(h, 1 % B, 0.6)
 
-    # reference: the in-order chain, one hop per step, the script applied before every second hop
+    # reference: the in-order chain, one hop per step, the script applied before every H-th hop
     ref_batch = bv.Batch(m, B)
     settings(ref_batch)
     ref = np.zeros((total, B, H * 240), np.float32)
@@ -109,7 +111,7 @@ def test_tick_two_hops_per_step_matches_in_order_chain(bv, oracle, product, mode
         rows = sorted(set(np.argwhere(ref[k] != got[k])[:, 0].tolist()))
         cols = np.argwhere(ref[k] != got[k])[:, 1]
         print("first differing step %d: streams %s, samples %d..%d" % (k, rows[:16], cols.min(), cols.max()))
-    print("tick pipeline, 2 hops per step, B=%d, %d stages, %d steps: %s" % (B, stages, steps, "bit-identical" if not bad else
+    print("tick pipeline, %d hops per step, B=%d, %d stages, %d steps: %s" % (H, B, stages, steps, "bit-identical" if not bad else
           "steps that differ: %s, max-abs %g" % (bad[:12], np.abs(ref - got).max())))
     assert np.abs(got).max() > 0.05
     assert not bad
@@ -120,14 +122,15 @@ def test_tick_two_hops_per_step_matches_in_order_chain(bv, oracle, product, mode
                               lambda ob, hop: change(ob, hop // H) if hop % H == 0 else None, sample)
     want = want.reshape(total, H, len(sample), 240).transpose(0, 2, 1, 3).reshape(total, len(sample), H * 240)
     dev = float(np.abs(got[:, sample] - want).max())
-    print("tick pipeline (2 hops per step) vs ORACLE, streams %s, %d steps: max-abs %g" % (sample, total, dev))
+    print("tick pipeline (%d hops per step) vs ORACLE, streams %s, %d steps: max-abs %g" % (H, sample, total, dev))
     assert dev <= 1e-4
 
 
-def test_tick_two_hops_per_step_with_a_morph_slot(bv, product, model_dir):
-    """A morphed speaker draws a codebook per stream and HOP (processor_core_2.cc:94-121): the two hops of a step may then use
+@pytest.mark.parametrize("H", [2, 4])
+def test_tick_two_hops_per_step_with_a_morph_slot(bv, product, model_dir, H):
+    """A morphed speaker draws a codebook per stream and HOP (processor_core_2.cc:94-121): the hops of a step may then use
     different codebooks (the k-NN body's separate-codebook path), and the draws must come in the order of one hop per step."""
-    H, B, steps = 2, 12, 40
+    B, steps = 12, 40
     hip = Hip()
     m = bv.Models(product, model_dir)
     bv.bind_batch(product)

@@ -15,10 +15,10 @@ bv = importlib.import_module("beatrice-vst_amd")
 
 # tick::BodyType (csrc/tick.hip.h), in order
 TYPES = ("F1 FFT F2 F3 F4 F5 P1 RB P23 POUT HEAD OUT COND INP UP1 RES1A RES1B UP2 QGRU PGRU VQ TAIL TAIL1 TAIL2 TAIL3 "
-         "BLKA1 BLKA2 BLKA4 BLKA8 BLKB BLKBQ F4S F5S RBS P1S UP1S TAIL1S TAIL2S QGRU1 PGRU1").split()
+         "BLKA1 BLKA2 BLKA4 BLKA8 BLKB BLKBQ F4S F5S RBS P1S UP1S TAIL1S TAIL2S QGRU1 PGRU1 QGRUM PGRUM").split()
 GROUPS = [("all", None), ("f1", ["F1"]), ("fft", ["FFT"]), ("f2", ["F2"]), ("f3", ["F3"]), ("f4", ["F4"]), ("f5", ["F5"]), ("p1", ["P1"]),
           ("rb x4", ["RB"]), ("p23 x2", ["P23"]), ("pout", ["POUT"]), ("head", ["HEAD"]), ("out", ["OUT"]), ("cond", ["COND"]), ("inp", ["INP"]),
-          ("up1", ["UP1"]), ("res1a", ["RES1A"]), ("res1b", ["RES1B"]), ("up2", ["UP2"]), ("qgru", ["QGRU", "QGRU1"]), ("pgru", ["PGRU", "PGRU1"]),
+          ("up1", ["UP1"]), ("res1a", ["RES1A"]), ("res1b", ["RES1B"]), ("up2", ["UP2"]), ("qgru", ["QGRU", "QGRU1", "QGRUM"]), ("pgru", ["PGRU", "PGRU1", "PGRUM"]),
           ("tail1", ["TAIL1"]), ("tail2", ["TAIL2"]), ("tail3", ["TAIL3"]), ("blk.a x4", ["BLKA1", "BLKA2", "BLKA4", "BLKA8"]), ("blk.b x4", ["BLKB", "BLKBQ"]),
           ("all again", None)]
 N_FILL, N_MEAS = 30, 8
