@@ -55,17 +55,17 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
   auto add_pgru = [&](int t) {
     if constexpr (H > 1) {
       GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(Plan::PGRU), B, t, t + 1 < H ? link_p(t) : nullptr, t > 0 ? link_p(t - 1) : nullptr, k.h_link_dead};
-      if (t == 0) tb->template add<T_PGRU>(GruP::info("phone.gru", g), g, GruP::grid(g), Plan::PGRU, keep(1), 7.6);
-      else if (t == H - 1) tb->template add<T_PGRU1>(GruP1::info("phone.gru", g), g, GruP1::grid(g), Plan::PGRU, keep(1), 7.6);
-      else if constexpr (H > 2) tb->template add<T_PGRUM>(GruPm::info("phone.gru", g), g, GruPm::grid(g), Plan::PGRU, keep(1), 7.6);
+      if (t == 0) tb->template add<T_PGRU>(GruP::info("phone.gru", g), g, GruP::grid(g), Plan::PGRU, keep(1), 19);
+      else if (t == H - 1) tb->template add<T_PGRU1>(GruP1::info("phone.gru", g), g, GruP1::grid(g), Plan::PGRU, keep(1), 19);
+      else if constexpr (H > 2) tb->template add<T_PGRUM>(GruPm::info("phone.gru", g), g, GruPm::grid(g), Plan::PGRU, keep(1), 19);
     }
   };
   auto add_qgru = [&](int t) {
     if constexpr (H > 1) {
       GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, t, t + 1 < H ? link_q(t) : nullptr, t > 0 ? link_q(t - 1) : nullptr, k.h_link_dead};
-      if (t == 0) tb->template add<T_QGRU>(GruQ::info("pitch.gru", g), g, GruQ::grid(g), Plan::QGRU, keep(1), 4.6);
-      else if (t == H - 1) tb->template add<T_QGRU1>(GruQ1::info("pitch.gru", g), g, GruQ1::grid(g), Plan::QGRU, keep(1), 4.6);
-      else if constexpr (H > 2) tb->template add<T_QGRUM>(GruQm::info("pitch.gru", g), g, GruQm::grid(g), Plan::QGRU, keep(1), 4.6);
+      if (t == 0) tb->template add<T_QGRU>(GruQ::info("pitch.gru", g), g, GruQ::grid(g), Plan::QGRU, keep(1), 12);
+      else if (t == H - 1) tb->template add<T_QGRU1>(GruQ1::info("pitch.gru", g), g, GruQ1::grid(g), Plan::QGRU, keep(1), 12);
+      else if constexpr (H > 2) tb->template add<T_QGRUM>(GruQm::info("pitch.gru", g), g, GruQm::grid(g), Plan::QGRU, keep(1), 12);
     }
   };
   // gru_at(point): the hops placed at insertion point 0 (behind the conditioned blocks), 1 (behind the tail), 2 / 3 (where the second
@@ -83,20 +83,20 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
   add_pgru(0); add_qgru(0);
   // ---- longest workgroups first (measured, two per CU): f5 48 us, p1 46, f4 45, rb 42, block halves 41 / 38, tail 36
   if (!sparse) {
-    { const ConvArgs a = conv(ps.f[3], ps.f[4], pw.f_w[3], pw.f_b[3], Plan::F5); tb->template add<T_F5>(OpF5::info("phone.f5", a), a, OpF5::grid(a), Plan::F5, keep(6), 47); }
-    { const ConvArgs a = conv(qs.spec, qs.p[0], qw.p_w[0], qw.p_b[0], Plan::P1); tb->template add<T_P1>(OpP1::info("pitch.p1", a), a, OpP1::grid(a), Plan::P1, keep(2), 34.5); }
-    { const ConvArgs a = conv(ps.f[2], ps.f[3], pw.f_w[2], pw.f_b[2], Plan::F4); tb->template add<T_F4>(OpF4::info("phone.f4", a), a, OpF4::grid(a), Plan::F4, keep(6), 37.5); }
+    { const ConvArgs a = conv(ps.f[3], ps.f[4], pw.f_w[3], pw.f_b[3], Plan::F5); tb->template add<T_F5>(OpF5::info("phone.f5", a), a, OpF5::grid(a), Plan::F5, keep(6), 30); }
+    { const ConvArgs a = conv(qs.spec, qs.p[0], qw.p_w[0], qw.p_b[0], Plan::P1); tb->template add<T_P1>(OpP1::info("pitch.p1", a), a, OpP1::grid(a), Plan::P1, keep(2), 41); }
+    { const ConvArgs a = conv(ps.f[2], ps.f[3], pw.f_w[2], pw.f_b[2], Plan::F4); tb->template add<T_F4>(OpF4::info("phone.f4", a), a, OpF4::grid(a), Plan::F4, keep(6), 28); }
     for (int i = 0; i < 4; ++i) {
       const ConvArgs a = conv(i == 0 ? ps.f[4] : ps.rb[i - 1], ps.rb[i], pw.rb_w[i], pw.rb_b[i], Plan::RB0 + i);
-      tb->template add<T_RB>(OpRB::info("phone.rb", a), a, OpRB::grid(a), Plan::RB0 + i, keep(6), 46);
+      tb->template add<T_RB>(OpRB::info("phone.rb", a), a, OpRB::grid(a), Plan::RB0 + i, keep(6), 39);
     }
   } else {   // (the sparse table: one row tile per workgroup, tick.hip.h)
-    { const ConvArgs a = conv(ps.f[3], ps.f[4], pw.f_w[3], pw.f_b[3], Plan::F5); tb->template add<T_F5S>(OpF5s::info("phone.f5", a), a, OpF5s::grid(a), Plan::F5, keep(6), 47); }
-    { const ConvArgs a = conv(qs.spec, qs.p[0], qw.p_w[0], qw.p_b[0], Plan::P1); tb->template add<T_P1S>(OpP1s::info("pitch.p1", a), a, OpP1s::grid(a), Plan::P1, keep(2), 34.5); }
-    { const ConvArgs a = conv(ps.f[2], ps.f[3], pw.f_w[2], pw.f_b[2], Plan::F4); tb->template add<T_F4S>(OpF4s::info("phone.f4", a), a, OpF4s::grid(a), Plan::F4, keep(6), 37.5); }
+    { const ConvArgs a = conv(ps.f[3], ps.f[4], pw.f_w[3], pw.f_b[3], Plan::F5); tb->template add<T_F5S>(OpF5s::info("phone.f5", a), a, OpF5s::grid(a), Plan::F5, keep(6), 30); }
+    { const ConvArgs a = conv(qs.spec, qs.p[0], qw.p_w[0], qw.p_b[0], Plan::P1); tb->template add<T_P1S>(OpP1s::info("pitch.p1", a), a, OpP1s::grid(a), Plan::P1, keep(2), 41); }
+    { const ConvArgs a = conv(ps.f[2], ps.f[3], pw.f_w[2], pw.f_b[2], Plan::F4); tb->template add<T_F4S>(OpF4s::info("phone.f4", a), a, OpF4s::grid(a), Plan::F4, keep(6), 28); }
     for (int i = 0; i < 4; ++i) {
       const ConvArgs a = conv(i == 0 ? ps.f[4] : ps.rb[i - 1], ps.rb[i], pw.rb_w[i], pw.rb_b[i], Plan::RB0 + i);
-      tb->template add<T_RBS>(OpRBs::info("phone.rb", a), a, OpRBs::grid(a), Plan::RB0 + i, keep(6), 46);
+      tb->template add<T_RBS>(OpRBs::info("phone.rb", a), a, OpRBs::grid(a), Plan::RB0 + i, keep(6), 39);
     }
   }
   // conditioned blocks: two row-local chains each
@@ -106,7 +106,7 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
     const rc::BlockBArgs ba{sc.xa, ws.x[blk + 1], ww.q_w[blk], ww.q_b[blk], ww.o_w[blk], ww.o_b[blk], ws.d_kt[blk], ws.d_v[blk],
                             b->dev_view<int>(b->off.perm[blk]), b->dev_view<int>(b->off.tile_slot[blk]), hp(s0 + 1)};
     tb->template add<T_BLKB>(LaunchInfo{"wave.blk.b", 2.0 * B * H * (256.0 * 256 * 2 + 256.0 * 384 * 2), 4.0 * (2.0 * 256 * 256 + 2.0 * 256 * 384 + B * H * 3.0 * 256)}, ba,
-                    dim3(ws.n_tiles_max, 1), s0 + 1, keep(5), 41.0);
+                    dim3(ws.n_tiles_max, 1), s0 + 1, keep(5), 43.0);
     if (quads_on(b)) {  // rows without 15 neighbours on their K/V slot: one workgroup per quad (rebuild_tiles decides which rows)
       const rc::BlockBqArgs bq{sc.xa, ws.x[blk + 1], ww.q_w[blk], ww.q_b[blk], ww.o_w[blk], ww.o_b[blk], ws.d_ktp[blk], ws.d_vp[blk],
                                b->dev_view<int>(b->off.qperm[blk]), b->dev_view<int>(b->off.qslot[blk]), hp(s0 + 1)};
@@ -117,10 +117,10 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
   for (int blk = 0; blk < B_NBLOCKS; ++blk) {
     const rc::BlockAArgs aa{ws.x[blk], ws.scr[blk].xa, ww.c1_w[blk], ww.c1_b[blk], ww.c2_w[blk], ww.c2_b[blk], hp(pl.blk(blk)), B};
     switch (blk) {
-      case 0: tb->template add<T_BLKA1>(rc::BlockAOp<1, H>::info(aa), aa, rc::BlockAOp<1, H>::grid(aa), pl.blk(blk), keep(5), 41); break;
-      case 1: tb->template add<T_BLKA2>(rc::BlockAOp<2, H>::info(aa), aa, rc::BlockAOp<2, H>::grid(aa), pl.blk(blk), keep(5), 41); break;
-      case 2: tb->template add<T_BLKA4>(rc::BlockAOp<4, H>::info(aa), aa, rc::BlockAOp<4, H>::grid(aa), pl.blk(blk), keep(5), 41); break;
-      default: tb->template add<T_BLKA8>(rc::BlockAOp<8, H>::info(aa), aa, rc::BlockAOp<8, H>::grid(aa), pl.blk(blk), keep(5), 41); break;
+      case 0: tb->template add<T_BLKA1>(rc::BlockAOp<1, H>::info(aa), aa, rc::BlockAOp<1, H>::grid(aa), pl.blk(blk), keep(5), 38); break;
+      case 1: tb->template add<T_BLKA2>(rc::BlockAOp<2, H>::info(aa), aa, rc::BlockAOp<2, H>::grid(aa), pl.blk(blk), keep(5), 38); break;
+      case 2: tb->template add<T_BLKA4>(rc::BlockAOp<4, H>::info(aa), aa, rc::BlockAOp<4, H>::grid(aa), pl.blk(blk), keep(5), 38); break;
+      default: tb->template add<T_BLKA8>(rc::BlockAOp<8, H>::info(aa), aa, rc::BlockAOp<8, H>::grid(aa), pl.blk(blk), keep(5), 38); break;
     }
   }
   gru_at(0);
@@ -136,48 +136,83 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
     t3.w[0] = ww.ra_w[3]; t3.b[0] = ww.ra_b[3]; t3.w[1] = ww.rb_w[3]; t3.b[1] = ww.rb_b[3];
     t3.fin_w = ww.fin_w; t3.fin_b = ww.fin_b; t3.d_out = ws.d_out; t3.io_stride = ws.io_stride;
     if (!sparse) {
-      tb->template add<T_TAIL1>(T1::info(t1), t1, T1::grid(t1), pl.tail(), keep(4), 30, true);
-      tb->template add<T_TAIL2>(T2::info(t2), t2, T2::grid(t2), pl.tail() + 1, keep(4), 28, true);
+      tb->template add<T_TAIL1>(T1::info(t1), t1, T1::grid(t1), pl.tail(), keep(4), 28, true);
+      tb->template add<T_TAIL2>(T2::info(t2), t2, T2::grid(t2), pl.tail() + 1, keep(4), 11.5 * H, true);
     } else {   // (never occupied while the sparse table is in use; kept so that the two tables hold the same stages)
-      tb->template add<T_TAIL1S>(T1s::info(t1), t1, T1s::grid(t1), pl.tail(), keep(4), 30, true);
-      tb->template add<T_TAIL2S>(T2s::info(t2), t2, T2s::grid(t2), pl.tail() + 1, keep(4), 28, true);
+      tb->template add<T_TAIL1S>(T1s::info(t1), t1, T1s::grid(t1), pl.tail(), keep(4), 28, true);
+      tb->template add<T_TAIL2S>(T2s::info(t2), t2, T2s::grid(t2), pl.tail() + 1, keep(4), 11.5 * H, true);
     }
-    tb->template add<T_TAIL3>(T3::info(t3), t3, T3::grid(t3), pl.tail() + 2, keep(4), 16, true);
+    tb->template add<T_TAIL3>(T3::info(t3), t3, T3::grid(t3), pl.tail() + 2, keep(4), 6.5 * H, true);
   }
   gru_at(1);
   // ---- everything else, longest workgroups first (they start when the heavy ones above leave their slots)
   // (the pitch head: few workgroups that walk a step's hops one after the other -- 10 us per workgroup at two hops per step, 21 at four;
   //  at the end of the table, where its instruction count would put it, it ENDED the launch: round 5's timelines, profiles/r05_notes.md)
-  { PitchHeadArgs a = head_args(qw, qs); a.hop = hp(Plan::HEAD); tb->template add<T_HEAD>(head_info(qs), a, dim3((B + 7) / 8, 1), Plan::HEAD, keep(0), 4.7 * H); }
-  { const ConvArgs a = conv(ps.f[1], ps.f[2], pw.f_w[1], pw.f_b[1], Plan::F3); tb->template add<T_F3>(OpF3::info("phone.f3", a), a, OpF3::grid(a), Plan::F3, keep(6), 18); }
-  if (!sparse) { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], pl.up1()); tb->template add<T_UP1>(OpUP1::info("wave.up1", a), a, OpUP1::grid(a), pl.up1(), keep(7), 36); }
-  else { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], pl.up1()); tb->template add<T_UP1S>(OpUP1s::info("wave.up1", a), a, OpUP1s::grid(a), pl.up1(), keep(7), 36); }
-  { const ConvArgs a = conv(ws.yb1, ws.yc1, ww.rb_w[0], ww.rb_b[0], pl.up1() + 2); tb->template add<T_RES1B>(OpRES1B::info("wave.res1b", a), a, OpRES1B::grid(a), pl.up1() + 2, keep(7), 10); }
-  { const ConvArgs a = conv(ws.ya1, ws.yb1, ww.ra_w[0], ww.ra_b[0], pl.up1() + 1); tb->template add<T_RES1A>(OpRES1A::info("wave.res1a", a), a, OpRES1A::grid(a), pl.up1() + 1, keep(7), 10); }
-  { const ConvArgs a = conv(ws.yc1, ws.ya2, ww.up_w[1], ww.up_b[1], pl.up1() + 3); tb->template add<T_UP2>(OpUP2::info("wave.up2", a), a, OpUP2::grid(a), pl.up1() + 3, keep(7), 12); }
-  { const ConvArgs a = conv(ps.f[0], ps.f[1], pw.f_w[0], pw.f_b[0], Plan::F2); tb->template add<T_F2>(OpF2::info("phone.f2", a), a, OpF2::grid(a), Plan::F2, keep(6), 10); }
-  if constexpr (H == 1) { const GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(Plan::PGRU), B, 0}; tb->template add<T_PGRU>(GruP::info("phone.gru", g), g, GruP::grid(g), Plan::PGRU, keep(1), 7.6); }
+  { PitchHeadArgs a = head_args(qw, qs); a.hop = hp(Plan::HEAD); tb->template add<T_HEAD>(head_info(qs), a, dim3((B + 7) / 8, 1), Plan::HEAD, keep(0), 7.5 * H); }
+  { const ConvArgs a = conv(ps.f[1], ps.f[2], pw.f_w[1], pw.f_b[1], Plan::F3); tb->template add<T_F3>(OpF3::info("phone.f3", a), a, OpF3::grid(a), Plan::F3, keep(6), 15); }
+  if (!sparse) { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], pl.up1()); tb->template add<T_UP1>(OpUP1::info("wave.up1", a), a, OpUP1::grid(a), pl.up1(), keep(7), 14); }
+  else { const ConvArgs a = conv(ws.x[4], ws.ya1, ww.up_w[0], ww.up_b[0], pl.up1()); tb->template add<T_UP1S>(OpUP1s::info("wave.up1", a), a, OpUP1s::grid(a), pl.up1(), keep(7), 14); }
+  { const ConvArgs a = conv(ws.yb1, ws.yc1, ww.rb_w[0], ww.rb_b[0], pl.up1() + 2); tb->template add<T_RES1B>(OpRES1B::info("wave.res1b", a), a, OpRES1B::grid(a), pl.up1() + 2, keep(7), 13); }
+  { const ConvArgs a = conv(ws.ya1, ws.yb1, ww.ra_w[0], ww.ra_b[0], pl.up1() + 1); tb->template add<T_RES1A>(OpRES1A::info("wave.res1a", a), a, OpRES1A::grid(a), pl.up1() + 1, keep(7), 13); }
+  { const ConvArgs a = conv(ws.yc1, ws.ya2, ww.up_w[1], ww.up_b[1], pl.up1() + 3); tb->template add<T_UP2>(OpUP2::info("wave.up2", a), a, OpUP2::grid(a), pl.up1() + 3, keep(7), 13); }
+  { const ConvArgs a = conv(ps.f[0], ps.f[1], pw.f_w[0], pw.f_b[0], Plan::F2); tb->template add<T_F2>(OpF2::info("phone.f2", a), a, OpF2::grid(a), Plan::F2, keep(6), 15); }
+  if constexpr (H == 1) { const GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(Plan::PGRU), B, 0}; tb->template add<T_PGRU>(GruP::info("phone.gru", g), g, GruP::grid(g), Plan::PGRU, keep(1), 19); }
   gru_at(2);
-  { const ConvArgs a = conv(qs.h, qs.logits, qw.out_w, qw.out_b, Plan::POUT); tb->template add<T_POUT>(OpPOUT::info("pitch.out", a), a, OpPOUT::grid(a), Plan::POUT, keep(2), 9.4); }
+  { const ConvArgs a = conv(qs.h, qs.logits, qw.out_w, qw.out_b, Plan::POUT); tb->template add<T_POUT>(OpPOUT::info("pitch.out", a), a, OpPOUT::grid(a), Plan::POUT, keep(2), 11); }
   for (int i = 0; i < 2; ++i) {
     const ConvArgs a = conv(qs.p[i], qs.p[i + 1], qw.p_w[i + 1], qw.p_b[i + 1], Plan::P2 + i);
-    tb->template add<T_P23>(OpP23::info("pitch.p23", a), a, OpP23::grid(a), Plan::P2 + i, keep(2), 8);
+    tb->template add<T_P23>(OpP23::info("pitch.p23", a), a, OpP23::grid(a), Plan::P2 + i, keep(2), 10);
   }
-  { const Ring phone_in{ws.d_phone, B_PHONE_CH, H, ws.front_slots}; ConvArgs a = conv(phone_in, ws.x[0], ww.inp_w, ww.inp_b, Plan::INP); a.res = ws.e; tb->template add<T_INP>(OpINP::info("wave.inp", a), a, OpINP::grid(a), Plan::INP, keep(3), 7.7); }
-  if constexpr (H == 1) { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, 0}; tb->template add<T_QGRU>(GruQ::info("pitch.gru", g), g, GruQ::grid(g), Plan::QGRU, keep(1), 4.6); }
+  { const Ring phone_in{ws.d_phone, B_PHONE_CH, H, ws.front_slots}; ConvArgs a = conv(phone_in, ws.x[0], ww.inp_w, ww.inp_b, Plan::INP); a.res = ws.e; tb->template add<T_INP>(OpINP::info("wave.inp", a), a, OpINP::grid(a), Plan::INP, keep(3), 7.5); }
+  if constexpr (H == 1) { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, 0}; tb->template add<T_QGRU>(GruQ::info("pitch.gru", g), g, GruQ::grid(g), Plan::QGRU, keep(1), 12); }
   gru_at(3);
-  { FftArgs a = fft_args(qw, qs); a.hop = hp(Plan::FFT); tb->template add<T_FFT>(fft_info(qs), FftArgs2{a, B}, dim3((B + 1) / 2, H), Plan::FFT, keep(0), 6); }
-  { const ConvArgs a = conv(ps.h, phone_out_ring(ps), pw.out_w, pw.out_b, Plan::OUT); tb->template add<T_OUT>(OpOUT::info("phone.out", a), a, OpOUT::grid(a), Plan::OUT, keep(3), 6); }
+  { FftArgs a = fft_args(qw, qs); a.hop = hp(Plan::FFT); tb->template add<T_FFT>(fft_info(qs), FftArgs2{a, B}, dim3((B + 1) / 2, H), Plan::FFT, keep(0), 8.7); }
+  { const ConvArgs a = conv(ps.h, phone_out_ring(ps), pw.out_w, pw.out_b, Plan::OUT); tb->template add<T_OUT>(OpOUT::info("phone.out", a), a, OpOUT::grid(a), Plan::OUT, keep(3), 4.5); }
   { const VqArgs a{H, ps.raw, phone_vector_ring(ps), hp(Plan::VQ), ps.d_cbT, ps.d_cnorm, ps.d_vqk}; tb->template add<T_VQ>(LaunchInfo{"phone.vq", 0, 4.0 * B * H * 256}, a, dim3(B, 1), Plan::VQ, !ps.skip_vq, 6.0, true); }
-  { F1Args a = f1_args(pw, ps); a.hop = hp(Plan::F1); a.hop_publish = nullptr; a.hop_publish_wave = nullptr; tb->template add<T_F1>(f1_info(ps), F1Args2{a, B}, dim3((B + 1) / 2, H), Plan::F1, keep(0), 4.5); }
-  { CondArgs a = cond_args(ww, ws); a.hop = hp(Plan::COND); a.hop_next_out = nullptr; tb->template add<T_COND>(cond_info(ws), a, dim3((B * H + 1) / 2, 1), Plan::COND, keep(0), 1.3); }
+  { F1Args a = f1_args(pw, ps); a.hop = hp(Plan::F1); a.hop_publish = nullptr; a.hop_publish_wave = nullptr; tb->template add<T_F1>(f1_info(ps), F1Args2{a, B}, dim3((B + 1) / 2, H), Plan::F1, keep(0), 3.7); }
+  { CondArgs a = cond_args(ww, ws); a.hop = hp(Plan::COND); a.hop_next_out = nullptr; tb->template add<T_COND>(cond_info(ws), a, dim3((B * H + 1) / 2, 1), Plan::COND, keep(0), 1.5); }
   if (!tb->ok) return false;
-  // XCD-aware placement (bodies with many weights pinned to one XCD each, so that the weights stay in that L2) was
-  // measured twice: it cuts the launch's memory-side traffic 4x (rocprofv3 FETCH_SIZE 105 -> 26 MB per tick) and the
-  // pinned workgroups run ~10-25 % shorter, but confining a body to 32 CUs costs more in makespan than that gains
-  // (0.096 vs 0.090 ms per tick): off by default
-  static const int by_xcd = std::getenv("BEATRICE_HIP_TICK_XCD") ? std::atoi(std::getenv("BEATRICE_HIP_TICK_XCD")) : 0;   // 2, 4: groups of XCDs; anything else: 8
-  if (by_xcd) tb->place_by_xcd(by_xcd == 2 || by_xcd == 4 ? by_xcd : 8);
+  // (XCD-aware placement -- bodies with many weights pinned to one XCD, or to the XCDs of equal index modulo 2 / 4, so that their weights
+  //  stay in fewer L2s -- was measured in rounds 2 and 4: memory-side traffic / 4, the launch 4-8 % slower; the switch went with the
+  //  span lookup in round 5, the builder's place_by_xcd() documents the layout)
+  // Dispatch order by workgroup (fuse::WgDesc, one descriptor per workgroup read by a scalar load): BEATRICE_HIP_TICK_ORDER=0 (default):
+  // the bodies in the order added above, every body a contiguous run; 1: the short, latency-bound workgroups dealt among the long
+  // MFMA-dense ones (TableBuilder::interleave; _RESERVE=<percent of the light time kept for the end of the launch>) -- measured, slower
+  static const int order_mode = std::getenv("BEATRICE_HIP_TICK_ORDER") ? std::atoi(std::getenv("BEATRICE_HIP_TICK_ORDER")) : 0;
+  static const double order_reserve = (std::getenv("BEATRICE_HIP_TICK_RESERVE") ? std::atoi(std::getenv("BEATRICE_HIP_TICK_RESERVE")) : 15) / 100.0;
+  {
+    using TB = typename O::Builder;
+    std::vector<fuse::WgDesc> desc;
+    if (order_mode != 0) {
+      int klass[fuse::kMaxSpans];
+      for (int i = 0; i < tb->t.n_spans; ++i) {
+        const int type = tb->t.span[i].type, bank = tb->t.span[i].arg & 0xff;
+        switch (type) {
+          case T_PGRU: case T_QGRU: klass[i] = H > 1 ? TB::kFirst : TB::kLight; break;
+          case T_PGRU1: case T_QGRU1: klass[i] = TB::kAt + 1000 * (H - 1) / H; break;
+          case T_PGRUM: case T_QGRUM: klass[i] = TB::kAt + 1000 * (1 + bank) / H; break;
+          case T_F4: case T_F5: case T_P1: case T_RB: case T_F4S: case T_F5S: case T_P1S: case T_RBS:
+          case T_BLKA1: case T_BLKA2: case T_BLKA4: case T_BLKA8: case T_BLKB: case T_BLKBQ:
+          case T_TAIL: case T_TAIL1: case T_TAIL2: case T_TAIL3: case T_TAIL1S: case T_TAIL2S: klass[i] = TB::kDense; break;
+          default: klass[i] = TB::kLight; break;
+        }
+      }
+      desc = tb->interleave(klass, order_reserve);
+    } else {
+      desc = tb->in_span_order();
+    }
+    if ((int)desc.size() != tb->t.total) return false;
+    fuse::WgDesc*& d_desc = sparse ? k.d_desc_sparse : k.d_desc;
+    size_t& cap = sparse ? k.desc_sparse_cap : k.desc_cap;
+    if (desc.size() > cap) {
+      if (d_desc) (void)hipFree(d_desc);
+      d_desc = nullptr;
+      cap = 0;
+      BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_desc), sizeof(fuse::WgDesc) * desc.size()));
+      cap = desc.size();
+    }
+    if (!desc.empty()) BHIP_TRY(hipMemcpy(d_desc, desc.data(), sizeof(fuse::WgDesc) * desc.size(), hipMemcpyHostToDevice));
+  }
   if (std::getenv("BEATRICE_HIP_TICK_TRACE")) {
     if (k.d_trace) (void)hipFree(k.d_trace);
     BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&k.d_trace), sizeof(unsigned long long) * 3 * tb->t.total));
@@ -218,10 +253,11 @@ bool tick_build_table(BeatriceBatch* b, const bool sparse = false) {
 static void tick_launch(BeatriceBatch* b, const bool sparse, hipStream_t st, const fuse::StepPairs& pairs) {
   tick::State& k = b->tk;
   const void* t = sparse ? k.d_table_sparse : k.d_table;
+  const fuse::WgDesc* desc = sparse ? k.d_desc_sparse : k.d_desc;
   const int total = sparse ? k.table_sparse_total : k.table_total;
-  if (b->H == 1) fuse::launch_table_w<4>(static_cast<const tick::Ops<1>::Tab*>(t), total, st, pairs, k.ragged);   // (ragged: the second instance of the launch, once a stream has sat a step out)
-  else if (b->H == 2) fuse::launch_table_w<4, false>(static_cast<const tick::Ops<2>::Tab*>(t), total, st, pairs, false);   // (no ragged steps at several hops per step: EnableSilentBlockRule refuses)
-  else fuse::launch_table_w<4, false>(static_cast<const tick::Ops<4>::Tab*>(t), total, st, pairs, false);
+  if (b->H == 1) fuse::launch_table_w<4>(static_cast<const tick::Ops<1>::Tab*>(t), desc, total, st, pairs, k.ragged);   // (ragged: the second instance of the launch, once a stream has sat a step out)
+  else if (b->H == 2) fuse::launch_table_w<4, false>(static_cast<const tick::Ops<2>::Tab*>(t), desc, total, st, pairs, false);   // (no ragged steps at several hops per step: EnableSilentBlockRule refuses)
+  else fuse::launch_table_w<4, false>(static_cast<const tick::Ops<4>::Tab*>(t), desc, total, st, pairs, false);
 }
 
 // One tick: every stage advances by one step; `feeding` = a new step enters at stage 0.
@@ -468,7 +504,7 @@ int tick_enable(BeatriceBatch* b, bool on) {
   if (on) {
     // one 10 ms hop per step, resident I/O with enough slots
     // that a step's input is still there when the pitch head reads it nine ticks on and outputs have somewhere to land
-    if ((b->H != 1 && b->H != 2 && b->H != 4) || b->B > 4096 || b->io_slots < k.plan.count() + 1) return -1;
+    if ((b->H != 1 && b->H != 2 && b->H != 4) || b->B > 4096 || b->io_slots < k.plan.count() + 1 || b->io_slots > stepc::kImmediateMaxSlot + 1) return -1;   // (the slot index travels in 12 bits of an immediate, ring.h stepc)
     if (!sync_all(b)) return -2;
     if (b->pipelined) { drop_graph(b); set_plan(b, 1); }
     k.snap_bytes = b->off.front_bytes + b->off.wave_bytes;

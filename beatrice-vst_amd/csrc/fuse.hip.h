@@ -15,7 +15,10 @@
 
 #include <cstdlib>
 
+#include <algorithm>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "engine.h"
 #include "ring.h"
@@ -125,6 +128,11 @@ struct Banks<M, Rest...> {
   typename M::op::Args a[M::cap];
   Banks<Rest...> rest;
 };
+// One workgroup of a launch whose dispatch ORDER is free (Table::desc): body type, argument block | stage << 16 (as Span::arg),
+// the workgroup's index inside its body, the body's grid x-extent.  With a descriptor per workgroup the bodies need not be
+// contiguous runs of indices: TableBuilder::interleave() deals the short, latency-bound workgroups among the long MFMA-dense
+// ones, so that a compute unit mostly hosts one of each instead of two of a kind (profiles/r05_notes.md).
+struct WgDesc { int type, arg, local, gx; };
 template <class... Ms>
 struct Table {
   int n_spans, total, per_xcd, pad;  // per_xcd > 0: XCD-aware layout, see TableBuilder::place_by_xcd
@@ -141,80 +149,73 @@ struct MaxM<M, Rest...> {
 };
 
 template <int I, int NTHR, bool RAG, class M, class... Rest>
-__device__ __forceinline__ void run_type(const Banks<M, Rest...>& b, const Span& sp, int id, float* lds) {
+__device__ __forceinline__ void run_type(const Banks<M, Rest...>& b, const Span& sp, int id, float* lds, const int* hop_imm) {
   if (sp.type == I) {
     using Op = typename M::op;
     if (Op::NTHR >= NTHR || (int)threadIdx.x < Op::NTHR) {
       typename Op::Args a = b.a[sp.arg];   // (uniform: scalar loads)
+      if constexpr (!RAG) stepc::set_hop(a, hop_imm, 0);   // the stage's {step counter, I/O slot} as an immediate (ring.h stepc)
 #ifdef FUSE_GLOBALIZE   // A/B build switch, OFF: the table's pointers told to be global memory (ring.h as_global) turn the launch's 2 271
       globalize(a);         // flat loads into global loads with pipelined waits -- and the tick got 4 % SLOWER (profiles/r04_notes.md section 1)
 #endif
       Op::template run_t<RAG>(a, id % sp.gx, id / sp.gx, lds);
     }
   } else {
-    if constexpr (sizeof...(Rest) > 0) run_type<I + 1, NTHR, RAG, Rest...>(b.rest, sp, id, lds);
+    if constexpr (sizeof...(Rest) > 0) run_type<I + 1, NTHR, RAG, Rest...>(b.rest, sp, id, lds, hop_imm);
   }
 }
 
 template <int MINW, bool RAG, class... Ms>
-__device__ __forceinline__ void table_body(const Table<Ms...>* __restrict__ t, const StepPairs& pairs);
-template <class... Ms>
-__global__ __launch_bounds__(MaxM<Ms...>::NTHR) void table_kernel(const Table<Ms...>* __restrict__ t, const StepPairs pairs) { table_body<0, false, Ms...>(t, pairs); }
+__device__ __forceinline__ void table_body(const Table<Ms...>* __restrict__ t, const WgDesc* __restrict__ desc, const StepPairs& pairs);
 // the same with a register budget: MINW = minimum wavefronts per SIMD the launch wants resident (HIP's second
 // __launch_bounds__ parameter): 4 with 512-thread workgroups = two workgroups per CU = at most 128 VGPRs
 // RAG: the launch of RAGGED steps (streams that sit steps out; ring.h stepc::hopv) -- a second instance of every body that works with
 // per-row step counters; the common launch (RAG = false) contains none of that
+// desc: the launch's workgroups in dispatch order, a KERNEL ARGUMENT of its own (`const ... __restrict__`): the compiler then reads a
+// workgroup's descriptor with one scalar load that depends on nothing but the kernel arguments.  (Round 4 found the body by a vector
+// load of the span table + ballot + readlane behind a dependent scalar load of the table's header; a descriptor pointer stored INSIDE
+// the table is a plain pointer to the compiler -- the descriptor then comes through a flat load into VGPRs and the whole type dispatch
+// turns into vector compares and exec masks: 226 spills, the tick 7-12 % slower, profiles/r05_notes.md.)
 template <int MINW, bool RAG, class... Ms>
-__global__ __launch_bounds__(MaxM<Ms...>::NTHR, MINW) void table_kernel_w(const Table<Ms...>* __restrict__ t, const StepPairs pairs) { table_body<MINW, RAG, Ms...>(t, pairs); }
+__global__ __launch_bounds__(MaxM<Ms...>::NTHR, MINW) void table_kernel_w(const Table<Ms...>* __restrict__ t, const WgDesc* __restrict__ desc, const StepPairs pairs) { table_body<MINW, RAG, Ms...>(t, desc, pairs); }
 template <int MINW, bool RAG, class... Ms>
-__device__ __forceinline__ void table_body(const Table<Ms...>* __restrict__ t, const StepPairs& pairs) {
+__device__ __forceinline__ void table_body(const Table<Ms...>* __restrict__ t, const WgDesc* __restrict__ desc, const StepPairs& pairs) {
   __shared__ __attribute__((aligned(16))) float lds[MaxM<Ms...>::LDS > 0 ? MaxM<Ms...>::LDS : 1];
-  const int lane = threadIdx.x & 63;
-  // XCD-aware layout: workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only), and the table gives
-  // every XCD its own contiguous run of body indices, so that a body's weights are fetched into ONE XCD's L2 and stay there
-  const int per = t->per_xcd, groups = t->pad > 0 ? t->pad : 8;   // (groups: 8 = one XCD per body; 2 / 4 = XCDs of equal index modulo 2 / 4)
-  const int id = per > 0 ? (int)(blockIdx.x % groups) * per + (int)(blockIdx.x / groups) : (int)blockIdx.x;
-  // (unused entries hold first = INT_MAX)
-  const int4 mine = reinterpret_cast<const int4*>(t->span)[lane];
-  const int idx = __popcll(__ballot(mine.x <= id)) - 1;
+  const WgDesc d = desc[blockIdx.x];
   Span sp;
-  sp.first = __builtin_amdgcn_readlane(mine.x, idx); sp.gx = __builtin_amdgcn_readlane(mine.y, idx);
-  sp.type = __builtin_amdgcn_readlane(mine.z, idx); sp.arg = __builtin_amdgcn_readlane(mine.w, idx);
+  sp.first = 0; sp.gx = d.gx; sp.type = d.type; sp.arg = d.arg;
   if (sp.type < 0) return;  // filler index
   const int stage = (sp.arg >> 16) & 0xff;
   const int step = pairs.hop[stage];
   if (step < 0) return;    // fill / drain: this stage has no step in this launch
-  if (threadIdx.x == 0) {
-    stepc::pair[0] = step; stepc::pair[1] = pairs.io[stage];
-    if constexpr (RAG) stepc::hopv = pairs.hopv != nullptr && pairs.hv[stage] >= 0 ? pairs.hopv + (size_t)pairs.hv[stage] * pairs.n_streams : nullptr;
+  const int io = pairs.io[stage];
+  if constexpr (RAG) {   // (ragged steps: the bodies take the pair, and their streams' own counters, from LDS)
+    if (threadIdx.x == 0) {
+      stepc::pair[0] = step; stepc::pair[1] = io;
+      stepc::hopv = pairs.hopv != nullptr && pairs.hv[stage] >= 0 ? pairs.hopv + (size_t)pairs.hv[stage] * pairs.n_streams : nullptr;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   unsigned long long* const trace = t->trace;
   const unsigned long long t0 = trace ? wall_clock64() : 0;
   const unsigned long long c0 = trace ? __builtin_readcyclecounter() : 0;   // shader clock (the wall clock is 100 MHz): their ratio = the clock the launch ran at
-  // (a body spread over the XCDs is eight spans; span k owns the body's workgroups k, k + 8, ...: arg bits 8-11 = k, bit 12 set)
-  const int local = id - sp.first;
-  const int body_wg = (sp.arg & 0x1000) ? local * groups + ((sp.arg >> 8) & 15) : local;
+  const int body_wg = d.local;
   sp.arg &= 0xff;
-  run_type<0, MaxM<Ms...>::NTHR, RAG, Ms...>(t->banks, sp, body_wg, lds);
+  run_type<0, MaxM<Ms...>::NTHR, RAG, Ms...>(t->banks, sp, body_wg, lds, stepc::immediate(step, io));
   if (trace && threadIdx.x == 0) {
     trace[3 * (size_t)blockIdx.x] = t0; trace[3 * (size_t)blockIdx.x + 1] = wall_clock64(); trace[3 * (size_t)blockIdx.x + 2] = (unsigned long long)sp.type | ((__builtin_readcyclecounter() - c0) << 8);
   }
 }
 
-template <class... Ms>
-static inline void launch_table(const Table<Ms...>* d_table, int total, hipStream_t stream, const StepPairs& pairs) {
-  hipLaunchKernelGGL((table_kernel<Ms...>), dim3(total), dim3(MaxM<Ms...>::NTHR), 0, stream, d_table, pairs);
-}
 // WITH_RAGGED = false: the launch has no ragged instance (its caller never passes ragged = true)
 template <int MINW, bool WITH_RAGGED = true, class... Ms>
-static inline void launch_table_w(const Table<Ms...>* d_table, int total, hipStream_t stream, const StepPairs& pairs, const bool ragged = false) {
+static inline void launch_table_w(const Table<Ms...>* d_table, const WgDesc* d_desc, int total, hipStream_t stream, const StepPairs& pairs, const bool ragged = false) {
   // measurement aid: BEATRICE_HIP_TICK_PAD_LDS=<bytes> of dynamic LDS on top of the static block (e.g. to allow one workgroup per CU only)
   static const int pad = std::getenv("BEATRICE_HIP_TICK_PAD_LDS") ? std::atoi(std::getenv("BEATRICE_HIP_TICK_PAD_LDS")) : 0;
   if constexpr (WITH_RAGGED) {
-    if (ragged) { hipLaunchKernelGGL((table_kernel_w<MINW, true, Ms...>), dim3(total), dim3(MaxM<Ms...>::NTHR), pad, stream, d_table, pairs); return; }
+    if (ragged) { hipLaunchKernelGGL((table_kernel_w<MINW, true, Ms...>), dim3(total), dim3(MaxM<Ms...>::NTHR), pad, stream, d_table, d_desc, pairs); return; }
   }
-  hipLaunchKernelGGL((table_kernel_w<MINW, false, Ms...>), dim3(total), dim3(MaxM<Ms...>::NTHR), pad, stream, d_table, pairs);
+  hipLaunchKernelGGL((table_kernel_w<MINW, false, Ms...>), dim3(total), dim3(MaxM<Ms...>::NTHR), pad, stream, d_table, d_desc, pairs);
 }
 
 // host side: fill a Table<Ms...>.  add<I>() appends one body of type I (its index in Ms...); bodies run in the order added
@@ -303,6 +304,56 @@ struct TableBuilder {
     t.per_xcd = per;
     t.total = G * per;
     t.pad = G;
+  }
+  // Dispatch order by workgroup (Table::desc).  klass[i] of span i (in the order added):
+  //   kFirst  -- ahead of everything (the first hop's GRU cells: later hops poll what they publish);
+  //   kDense  -- long, MFMA-dense workgroups, kept in the order added (longest first);
+  //   kLight  -- short workgroups that are mostly memory round trips: dealt among the dense ones in proportion to estimated time
+  //              (cost[]), the last `reserve` of their time kept for the end of the launch, where short workgroups pack the ragged edge;
+  //   kAt + f -- the whole span once the dense workgroups before it hold fraction f / 1000 of the dense time (linked GRU cells of
+  //              later hops: each behind at least one more round of the launch's workgroups).
+  static constexpr int kFirst = -1, kDense = -2, kLight = -3, kAt = 0;
+  // the workgroups in the order the bodies were added (every body a contiguous run)
+  std::vector<WgDesc> in_span_order() const {
+    std::vector<WgDesc> out;
+    for (int i = 0; i < t.n_spans; ++i)
+      for (int w = 0; w < n_wg[i]; ++w) out.push_back(WgDesc{t.span[i].type, t.span[i].arg, w, t.span[i].gx});
+    return out;
+  }
+  std::vector<WgDesc> interleave(const int* klass, const double reserve) const {
+    struct Item { int span, local; double c; };
+    std::vector<Item> first, dense, light;
+    std::vector<std::pair<double, int>> at;   // (fraction, span)
+    for (int i = 0; i < t.n_spans; ++i) {
+      const double c = n_wg[i] > 0 ? cost[i] / n_wg[i] : 0.0;
+      if (klass[i] >= kAt) { at.push_back({klass[i] / 1000.0, i}); continue; }
+      std::vector<Item>& dst = klass[i] == kFirst ? first : (klass[i] == kDense ? dense : light);
+      for (int w = 0; w < n_wg[i]; ++w) dst.push_back(Item{i, w, c});
+    }
+    std::sort(at.begin(), at.end());
+    double total_d = 0, total_l = 0;
+    for (const Item& x : dense) total_d += x.c;
+    for (const Item& x : light) total_l += x.c;
+    // the light workgroups that wait for the end: from the back of the list (the shortest bodies) up to `reserve` of the light time
+    size_t n_main = light.size();
+    for (double held = 0; n_main > 0 && held + light[n_main - 1].c <= reserve * total_l; --n_main) held += light[n_main - 1].c;
+    double main_l = 0;
+    for (size_t j = 0; j < n_main; ++j) main_l += light[j].c;
+    std::vector<WgDesc> out;
+    auto emit = [&](const Item& x) { const Span& sp = t.span[x.span]; out.push_back(WgDesc{sp.type, sp.arg, x.local, sp.gx}); };
+    auto emit_span = [&](int i) { for (int w = 0; w < n_wg[i]; ++w) emit(Item{i, w, 0}); };
+    for (const Item& x : first) emit(x);
+    double cum_d = 0, cum_l = 0;
+    size_t jl = 0, ja = 0;
+    for (const Item& x : dense) {
+      while (ja < at.size() && cum_d >= at[ja].first * total_d) emit_span(at[ja++].second);
+      emit(x);
+      cum_d += x.c;
+      while (jl < n_main && cum_l < main_l * (cum_d / (total_d > 0 ? total_d : 1.0))) { emit(light[jl]); cum_l += light[jl].c; ++jl; }
+    }
+    while (ja < at.size()) emit_span(at[ja++].second);
+    for (; jl < light.size(); ++jl) emit(light[jl]);
+    return out;
   }
   template <int I, class Args>
   void add(const bhip::LaunchInfo& info, const Args& a, dim3 grid, int stage, bool on = true, double wg_cost = 1.0, bool spread_over_xcds = false) {

@@ -66,19 +66,26 @@ __device__ __forceinline__ float* ring_frame(const Ring& r, int b, int pos, int 
 // the pair from device memory (args.hop); in the batch's tick launch (tick.hip.h) the table kernel takes every stage's
 // pair from its kernel arguments and leaves it in LDS for the body it dispatches to -- no dependent global load at the
 // start of a workgroup, no separate launch to publish the counters: there args.hop is null.
-// Third form, for the 1-stream calls whose host tracks the counter: the VALUE travels in the pointer bits
-// (stepc::immediate(hop); addresses below kImmediateTop are never mapped), again without a dependent load.
+// Third form: the VALUE travels in the pointer bits (stepc::immediate(hop[, slot]): bits 0-23 = counter + 2, bits 24-35 = I/O slot;
+// the pointers in question are the library's own device allocations, never below kImmediateTop = 64 GB), again without a dependent load -- the 1-stream calls whose host tracks
+// the counter, and since round 5 the COMMON tick launch: the table kernel puts the stage's pair into the body's argument block, so a
+// workgroup starts without the LDS write + barrier that published the pair (only the launch of RAGGED steps still leaves `hopv`,
+// and the pair, in LDS).
 namespace stepc {
 __shared__ int pair[2];
 // The tick launch with RAGGED steps (streams that sit a step out: the shell's silent-block rule per stream, batch.hip): this
 // stage's per-stream step counters [B] -- stream b is at hopv[b], or -1 when it takes no part in the step -- left here by the table
 // kernel beside `pair`; nullptr while every stream is at the step's common counter.  Only meaningful where args.hop is null.
 __shared__ const int* hopv;
-constexpr unsigned long long kImmediateTop = 1ull << 28;
-inline const int* immediate(int hop) { return reinterpret_cast<const int*>(static_cast<unsigned long long>(hop + 2)); }
+constexpr unsigned long long kImmediateTop = 1ull << 36;
+constexpr int kImmediateMaxSlot = 4095;
+constexpr unsigned kImmediateHopMask = 0xffffffu;   // (the counter wraps at B_HOP_WRAP = lcm(1..17) = 12 252 240 < 2^24 - 2)
+__host__ __device__ inline const int* immediate(int hop, int slot = 0) {
+  return reinterpret_cast<const int*>(static_cast<unsigned long long>((unsigned)(hop + 2)) | (static_cast<unsigned long long>((unsigned)slot) << 24));
+}
 __device__ __forceinline__ int step(const int* p) {
   const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-  return v == 0 ? pair[0] : (v < kImmediateTop ? (int)v - 2 : *p);
+  return v == 0 ? pair[0] : (v < kImmediateTop ? (int)((unsigned)v & kImmediateHopMask) - 2 : *p);
 }
 // the step counter of stream b in this step: the common one, or the stream's own (-1: absent) in a ragged tick step
 __device__ __forceinline__ int of(const int* p, const int hop, const int b) {
@@ -100,6 +107,10 @@ template <bool RAG> __device__ __forceinline__ bool rag_t() {
 }
 __device__ __forceinline__ int slot(const int* p) {
   const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-  return v == 0 ? pair[1] : (v < kImmediateTop ? 0 : p[1]);
+  return v == 0 ? pair[1] : (v < kImmediateTop ? (int)(v >> 24) : p[1]);
 }
+// the `hop` member of a body's argument block (some blocks nest the kernel's own: F1Args2 { F1Args a; ... })
+template <class A> __device__ __forceinline__ auto set_hop(A& a, const int* p, int) -> decltype((void)(a.hop = p)) { a.hop = p; }
+template <class A> __device__ __forceinline__ auto set_hop(A& a, const int* p, long) -> decltype((void)(a.a.hop = p)) { a.a.hop = p; }
+template <class A> __device__ __forceinline__ void set_hop(A&, const int*, ...) {}
 }  // namespace stepc

@@ -113,19 +113,31 @@ __device__ __forceinline__ void pin_pipeline() {
   __builtin_amdgcn_sched_barrier(0);    // machine scheduler: nothing crosses
 #endif
 }
-template <int CG, int KB>
-__device__ __forceinline__ void mma_segment_p(f32x4 (&acc)[CG], const float* __restrict__ a, const float4* const (&wf)[CG]) {
 #ifndef RC_PREFETCH
 #define RC_PREFETCH 8
 #endif
-  constexpr int D = CG <= 2 ? RC_PREFETCH : (CG <= 3 ? 4 : 2);  // prefetch depth in k-blocks (registers: D * CG float4)
+// prefetch depth of a segment in k-blocks (registers: D * CG float4)
+template <int RT, int CG> __host__ __device__ constexpr int seg_depth() { return RT == 1 ? (CG <= 2 ? RC_PREFETCH : (CG <= 3 ? 4 : 2)) : (RT * CG <= 2 ? 8 : 4); }
+// the first seg_depth() k-blocks of a segment's weight fragments, requested by the CALLER ahead of time (a body's first segment: the
+// request goes out before the body gathers its rows, so that the two round trips overlap instead of following each other)
+template <int RT, int CG> struct SegHead { float4 v[seg_depth<RT, CG>()][CG]; };
+template <int RT, int CG>
+__device__ __forceinline__ void seg_head_load(SegHead<RT, CG>& h, const float4* const (&wf)[CG]) {
+#pragma unroll
+  for (int d = 0; d < seg_depth<RT, CG>(); ++d)
+#pragma unroll
+    for (int c = 0; c < CG; ++c) h.v[d][c] = wf[c][(size_t)d * 64];
+}
+template <int CG, int KB, bool HEAD = false>
+__device__ __forceinline__ void mma_segment_p(f32x4 (&acc)[CG], const float* __restrict__ a, const float4* const (&wf)[CG], const SegHead<1, CG>* head = nullptr) {
+  constexpr int D = seg_depth<1, CG>();
   static_assert(KB % D == 0, "segment length");
   float4 bq[D][CG];
   pin_pipeline();   // (the segment's first loads stay behind what precedes it: hoisted over an epilogue they only add register pressure)
 #pragma unroll
   for (int d = 0; d < D; ++d)
 #pragma unroll
-    for (int c = 0; c < CG; ++c) bq[d][c] = wf[c][(size_t)d * 64];
+    for (int c = 0; c < CG; ++c) { if constexpr (HEAD) bq[d][c] = head->v[d][c]; else bq[d][c] = wf[c][(size_t)d * 64]; }
   float4 an = lds_kblock(a, 0);   // activations of the k-block to come (one k-block ahead: LDS latency behind 4 CG MFMAs), one ds_read_b128
 #pragma unroll
   for (int kb = 0; kb < KB; kb += D) {
@@ -154,17 +166,17 @@ __device__ __forceinline__ void mma_segment_p(f32x4 (&acc)[CG], const float* __r
 }
 // The same for RT row tiles of 16 that share every B fragment (a1 = a0 + one LDS tile): acc[t][c] += A_t . W_c.
 // A fragment then feeds RT MFMAs: half the weight traffic per multiply-add at RT = 2.
-template <int RT, int CG, int KB>
+template <int RT, int CG, int KB, bool HEAD = false>
 __device__ __forceinline__ void mma_segment_rt(f32x4 (&acc)[RT][CG], const float* __restrict__ a, const int a_tile_stride,
-                                               const float4* const (&wf)[CG]) {
-  constexpr int D = RT * CG <= 2 ? 8 : 4;  // prefetch depth in k-blocks (registers: D * CG float4)
+                                               const float4* const (&wf)[CG], const SegHead<RT, CG>* head = nullptr) {
+  constexpr int D = seg_depth<RT, CG>();
   static_assert(KB % D == 0, "segment length");
   float4 bq[D][CG];
   pin_pipeline();
 #pragma unroll
   for (int d = 0; d < D; ++d)
 #pragma unroll
-    for (int c = 0; c < CG; ++c) bq[d][c] = wf[c][(size_t)d * 64];
+    for (int c = 0; c < CG; ++c) { if constexpr (HEAD) bq[d][c] = head->v[d][c]; else bq[d][c] = wf[c][(size_t)d * 64]; }
   float4 an[RT];
 #pragma unroll
   for (int t = 0; t < RT; ++t) an[t] = lds_kblock(a + t * a_tile_stride, 0);
@@ -694,6 +706,19 @@ __device__ __forceinline__ void conv_rows_body(const ConvArgs& a, const int bx, 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hop = stepc::step(a.hop);
   if (hop < 0) return;
+  // the first thing a workgroup does: request the first weight fragments of its first segment -- that round trip then runs beside the
+  // row table's barrier and the row gather instead of behind them (a short body is mostly such round trips, profiles/r05_notes.md)
+  const float4* wfc[CG];
+#pragma unroll
+  for (int c = 0; c < CG; ++c) {
+    const int nt = wave + NWAVE * c < NTL ? wave + NWAVE * c : NTL - 1;  // surplus tiles of a ragged layer recompute the last one
+    wfc[c] = reinterpret_cast<const float4*>(a.w) + (size_t)(nt_base + nt) * (K / 16) * 64 + lane;
+  }
+#ifndef RC_SEG_HEAD
+#define RC_SEG_HEAD 0   // A/B switch, OFF: 1 = the first segment's first weight fragments requested before the row gather -- measured 256 streams x 2 hops 118.1 -> 120.5 us (slower), x 4 hops 237.4 -> 236.4, x 1 hop unchanged (profiles/r05_notes.md)
+#endif
+  SegHead<RT, CG> head;
+  if constexpr (RC_SEG_HEAD != 0) seg_head_load<RT, CG>(head, wfc);
   const int M = a.B * L::T;
   const bool rag = stepc::rag_t<RAG>();   // (ragged tick step: every row at its stream's own counter; absent streams' rows drop out)
   if (tid < ROWS) {
@@ -734,12 +759,6 @@ __device__ __forceinline__ void conv_rows_body(const ConvArgs& a, const int bx, 
       store_perm4(dst + pr[i] * AS, 4 * pq[i], v.x, v.y, v.z, v.w);   // (row 16 t + r of the slot = row r of its tile t: tiles are contiguous)
     }
   };
-  const float4* wfc[CG];
-#pragma unroll
-  for (int c = 0; c < CG; ++c) {
-    const int nt = wave + NWAVE * c < NTL ? wave + NWAVE * c : NTL - 1;  // surplus tiles of a ragged layer recompute the last one
-    wfc[c] = reinterpret_cast<const float4*>(a.w) + (size_t)(nt_base + nt) * (K / 16) * 64 + lane;
-  }
   load_seg(0);
   store_seg(slot[0]);
   __syncthreads();
@@ -756,7 +775,15 @@ __device__ __forceinline__ void conv_rows_body(const ConvArgs& a, const int bx, 
 #pragma unroll
     for (int c = 0; c < CG; ++c) wfs[c] = wfc[c] + (size_t)s * 16 * 64;
     const float* ap = slot[s & 1] + (lane & 15) * AS + lane_koff(lane);
-    if constexpr (RT == 1) {
+    if (RC_SEG_HEAD != 0 && s == 0) {   // (s is a compile-time index after unrolling)
+      if constexpr (RT == 1) {
+        if constexpr (P > 1) mma_segment_p<CG, 16, true>(acc[0], ap, wfs, &head);
+        else mma_segment_p<CG, LAST / 16, true>(acc[0], ap, wfs, &head);
+      } else {
+        if constexpr (P > 1) mma_segment_rt<RT, CG, 16, true>(acc, ap, TILE, wfs, &head);
+        else mma_segment_rt<RT, CG, LAST / 16, true>(acc, ap, TILE, wfs, &head);
+      }
+    } else if constexpr (RT == 1) {
       if (s + 1 < P) mma_segment_p<CG, 16>(acc[0], ap, wfs);
       else mma_segment_p<CG, LAST / 16>(acc[0], ap, wfs);
     } else {

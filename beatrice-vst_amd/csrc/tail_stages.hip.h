@@ -462,14 +462,11 @@ __device__ __forceinline__ void res_res_up_body(const StageArgs& a, const int g,
   const int b0 = g * S;
   const int n_rows = (a.B - b0 < S ? a.B - b0 : S) * T;
   int* shop = reinterpret_cast<int*>(lds + stage_lds<C, T, S, 1>() - 8);
-  stream_hops<S, RAG>(a, hop, b0, shop);
-#pragma unroll 1
-  for (int sub = 0; sub < NSUB; ++sub) {
-    const int fb = NSUB > 1 ? sub * T : 0;
-    const bool first = NSUB == 1 || sub == 0, last = NSUB == 1 || sub == NSUB - 1;
+  auto sub_step = [&](const int fb, const bool first, const bool last) {
     float4 bfa[Split<C>::CT][3 * C / 16], bfb[Split<C>::CT][3 * C / 16], bfu[Split<NUP>::CT][2 * C / 16];
     TST_STAMP(0);
     fetch_b<3 * C, C>(a.w[0], bfa, wave, lane);
+    if (first) stream_hops<S, RAG>(a, hop, b0, shop);
     prologue<C, T, S, TS_IN, TS_B, TS_C, 1, IN_FROM_RING_HISTORY, RAG>(a, hop, b0, X, Y, HIN, HC, tid, shop, fb, first, last);
     TST_STAMP(1);
     __syncthreads();
@@ -505,6 +502,11 @@ __device__ __forceinline__ void res_res_up_body(const StageArgs& a, const int g,
         __syncthreads();
       }
     }
+  };
+  if constexpr (NSUB == 1) sub_step(0, true, true);
+  else {
+#pragma unroll 1
+    for (int sub = 0; sub < NSUB; ++sub) sub_step(sub * T, sub == 0, sub == NSUB - 1);
   }
   if (!IN_FROM_RING_HISTORY) hin_to_state<C, S, TS_IN, RAG>(a, HIN, b0, tid, shop);
   TST_STAMP(8);

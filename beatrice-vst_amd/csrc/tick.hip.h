@@ -191,6 +191,9 @@ struct State {
   void* d_table_sparse = nullptr;    // the same stages with the long bodies in half-size pieces (fill and drain ticks)
   int table_sparse_total = 0;
   double table_flops = 0, table_bytes = 0;  // algorithmic work of one full tick (sum over the bodies)
+  fuse::WgDesc* d_desc = nullptr;    // dispatch order of the full / the sparse table by workgroup (tick_build_table_h)
+  fuse::WgDesc* d_desc_sparse = nullptr;
+  size_t desc_cap = 0, desc_sparse_cap = 0;
   unsigned long long* d_trace = nullptr;  // BEATRICE_HIP_TICK_TRACE=<file>: per-workgroup timeline of the last full tick
   bool table_dirty = true;
   unsigned char* d_snap = nullptr;  // [kRing][snap_bytes] settings snapshots

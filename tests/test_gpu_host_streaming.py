@@ -77,11 +77,11 @@ def test_streamed_host_buffers_match_in_order_chain(bv, oracle, product, model_d
     m.close()
 
 
-@pytest.mark.parametrize("B,steps", [(7, 60), (256, 45)])
-def test_streamed_host_buffers_two_hops_per_step(bv, product, model_dir, B, steps):
-    """Host streaming with a batch of two hops per step: a call takes [B][320] and hands back [B][480] (the tick pipeline with two
-    hops per stage per launch underneath).  Must equal the in-order chain at one hop per step, the script applied before a step."""
-    H = 2
+@pytest.mark.parametrize("H,B,steps", [(2, 7, 60), (2, 256, 45), (4, 7, 50), (4, 256, 36)])
+def test_streamed_host_buffers_two_hops_per_step(bv, oracle, product, model_dir, H, B, steps):
+    """Host streaming with a batch of two or four hops per step: a call takes [B][H x 160] and hands back [B][H x 240] (the tick
+    pipeline with H hops per stage per launch underneath).  Must equal the in-order chain at one hop per step, the script applied
+    before a step -- and a sample of the streams the ORACLE driven through the reference protocol."""
     m = bv.Models(product, model_dir)
     bv.bind_batch(product)
     audio = np.stack([bv.synth_audio(160 * H * steps, seed=4700 + s) for s in range(B)])
@@ -135,3 +135,12 @@ def test_streamed_host_buffers_two_hops_per_step(bv, product, model_dir, B, step
     assert a.BeatriceBatch_EnableHostStreaming(h, 0) == 0
     batch.close()
     m.close()
+    # the ORACLE leg: sampled streams as independent oracle streams, one hop at a time, the script before every H-th hop
+    from oracle_batch import oracle_leg, pick_streams, scripted_streams
+    sample = sorted(set(pick_streams(B, 6)) | set(scripted_streams(B, steps, change, 6)))
+    sample, want = oracle_leg(bv, oracle, model_dir, B, lambda j: audio[:, j * 160:(j + 1) * 160], steps * H, settings,
+                              lambda ob, hop: change(ob, hop // H) if hop % H == 0 else None, sample)
+    want = want.reshape(steps, H, len(sample), 240).transpose(0, 2, 1, 3).reshape(steps, len(sample), H * 240)
+    dev = float(np.abs(np.stack(got)[:, sample] - want).max())
+    print("host streaming (%d hops per call) vs ORACLE, streams %s, %d steps: max-abs %g" % (H, sample, steps, dev))
+    assert dev <= 1e-4

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from oracle_batch import oracle_leg, pick_streams, scripted_streams
+from test_gpu_morph_device import host_lib  # noqa: F401  (fixture: the host solver for the oracle leg of the morph test)
 from test_gpu_resident_io import Hip
 
 pytestmark = pytest.mark.gpu
@@ -127,7 +128,7 @@ def test_tick_two_hops_per_step_matches_in_order_chain(bv, oracle, product, mode
 
 
 @pytest.mark.parametrize("H", [2, 4])
-def test_tick_two_hops_per_step_with_a_morph_slot(bv, product, model_dir, H):
+def test_tick_two_hops_per_step_with_a_morph_slot(bv, oracle, product, host_lib, model_dir, H):
     """A morphed speaker draws a codebook per stream and HOP (processor_core_2.cc:94-121): the hops of a step may then use
     different codebooks (the k-NN body's separate-codebook path), and the draws must come in the order of one hop per step."""
     B, steps = 12, 40
@@ -172,3 +173,38 @@ def test_tick_two_hops_per_step_with_a_morph_slot(bv, product, model_dir, H):
     hip.free(d_in); hip.free(d_out)
     batch.close()
     m.close()
+    # the ORACLE leg: every stream as an independent oracle stream -- the morph entry of the caller-owned tables filled by the host
+    # solver, one codebook drawn per morphing stream and hop from that stream's own engine (std::mt19937(seed + stream)), as
+    # tests/test_gpu_morph_device.py::test_morph_end_to_end does it
+    from test_gpu_morph_device import _host_entry, _mt_draws
+    mo = bv.Models(oracle, model_dir)
+    t = mo.tables
+    add, kv, pruned, order = _host_entry(host_lib, t, n, list(w))
+    t.additive[n] = add
+    t.kv[n] = kv
+    odds = pruned[order[:8]]
+    total = np.float32(0)
+    for v in odds:
+        total = np.float32(total + v)
+    draws = {s_: _mt_draws(1234 + s_) for s_ in range(B)}
+    streams = [bv.Stream1(mo, speaker=(n if s_ % 2 == 0 else s_ % n), vq_k=1 + s_ % 3) for s_ in range(B)]
+    want = np.zeros((H * steps, B, 240), np.float32)
+    for j in range(H * steps):
+        for s_ in range(0, B, 2):   # the morphing streams
+            r = np.float32(next(draws[s_]) * total)
+            idx = int(order[0])
+            for i in range(len(odds)):
+                r = np.float32(r - odds[i])
+                if r < 0:
+                    idx = int(order[i])
+                    break
+            streams[s_].a.SetCodebook(streams[s_].pc, bv.fptr(t.codebooks[idx]))
+        for s_ in range(B):
+            want[j, s_] = streams[s_].hop(audio[s_, j * 160:(j + 1) * 160])
+    for st in streams:
+        st.close()
+    mo.close()
+    want = want.reshape(steps, H, B, 240).transpose(0, 2, 1, 3).reshape(steps, B, H * 240)
+    dev = float(np.abs(got - want).max())
+    print("tick pipeline (%d hops per step) with a morph slot vs ORACLE: max-abs %g" % (H, dev))
+    assert dev <= 1e-4

@@ -54,6 +54,60 @@ def test_device_wrapper_48k_matches_host_chain(bv, oracle, product, model_dir, B
     assert dev <= 1e-4
 
 
+def oracle_leg_48k(bv, oracle, model_dir, B, channels, x, blocks, settings, change_block, got, n_pick=4):
+    """The ORACLE leg of the 48 kHz tests: a sample of the streams as the host chain -- the ref-pinned wrapper oracle around an
+    independent oracle stream, `change_block(script, k)` applied before block k; a reset restarts the stream's wrapper too
+    (SetSampleRate semantics).  got[k] = [B][channels][480].  Returns (sample, max-abs)."""
+    import ctypes as C
+    from oracle_batch import OracleBatch, pick_streams, scripted_streams
+    sample = sorted(set(pick_streams(B, n_pick)) | set(scripted_streams(B, blocks, change_block, n_pick)))
+    ob = OracleBatch(bv, oracle, model_dir, B, sample=sample)
+    settings(ob)
+    wl = wrapperlib.oracle_wrapper()
+    wrappers, callbacks = {}, {}
+
+    def make_wrapper(s):
+        def hop(in160, out240, _u, s=s):
+            o = ob.st[s]["s1"].hop(np.ctypeslib.as_array(in160, (160,)).copy())
+            C.memmove(out240, o.ctypes.data, 240 * 4)
+        if s in wrappers:
+            wl.f_destroy(wrappers[s])
+        callbacks[s] = wrapperlib.HOP_FN(hop)
+        wrappers[s] = wl.f_create(48000.0, callbacks[s], None)
+
+    class Script:   # what the script sees: the oracle streams, plus the wrapper restart that goes with a stream reset
+        def __init__(self):
+            self.h, self.a = None, self
+
+        def BeatriceBatch_ResetStream(self, h_, stream):
+            rc = ob.a.BeatriceBatch_ResetStream(h_, stream)
+            if stream in wrappers:
+                make_wrapper(stream)
+            return rc
+
+        def __getattr__(self, name):
+            return getattr(ob.a, name)
+
+    script = Script()
+    for s_ in ob.sample:
+        make_wrapper(s_)
+    dev = 0.0
+    for k in range(blocks):
+        change_block(script, k)
+        for s_ in ob.sample:
+            blk_in = x[s_, :, 480 * k:480 * (k + 1)]
+            mono = np.ascontiguousarray(blk_in[0] if channels == 1 else ((blk_in[0] + blk_in[1]) * np.float32(0.5)).astype(np.float32))
+            y = np.zeros(480, np.float32)
+            assert wl.f_process(wrappers[s_], bv.fptr(mono), bv.fptr(y), 480) == 0
+            for c in range(channels):
+                dev = max(dev, float(np.abs(got[k][s_, c] - y).max()))
+    for s_ in ob.sample:
+        wl.f_destroy(wrappers[s_])
+    sample = list(ob.sample)
+    ob.close()
+    return sample, dev
+
+
 @pytest.mark.parametrize("B,channels,blocks", [(5, 2, 70), (64, 2, 45)])
 def test_48k_wrapper_around_the_tick_pipeline_matches_in_order(bv, oracle, product, model_dir, B, channels, blocks):
     """BeatriceBatch_BindResidentIO48k: resident 48 kHz slots, the tick pipeline in between; block k's converted samples
@@ -119,55 +173,8 @@ def test_48k_wrapper_around_the_tick_pipeline_matches_in_order(bv, oracle, produ
     for k in range(blocks):
         assert np.array_equal(got[k], want[k]), "block %d differs" % k
     assert a.BeatriceBatch_BindResidentIO48k(h, None, None, 0, 0) == 0
-    # the ORACLE leg: a sample of the streams as the host chain -- the ref-pinned wrapper oracle around an independent oracle
-    # stream, the same script applied before each block; a reset restarts the stream's wrapper too (SetSampleRate semantics)
-    import ctypes as C
-    from oracle_batch import OracleBatch, pick_streams, scripted_streams
-    sample = sorted(set(pick_streams(B, 4)) | set(scripted_streams(B, blocks, change, 4)))
-    ob = OracleBatch(bv, oracle, model_dir, B, sample=sample)
-    settings(ob)
-    wl = wrapperlib.oracle_wrapper()
-    wrappers, callbacks = {}, {}
-
-    def make_wrapper(s):
-        def hop(in160, out240, _u, s=s):
-            o = ob.st[s]["s1"].hop(np.ctypeslib.as_array(in160, (160,)).copy())
-            C.memmove(out240, o.ctypes.data, 240 * 4)
-        if s in wrappers:
-            wl.f_destroy(wrappers[s])
-        callbacks[s] = wrapperlib.HOP_FN(hop)
-        wrappers[s] = wl.f_create(48000.0, callbacks[s], None)
-
-    class Script:   # what `change` sees: the oracle streams, plus the wrapper restart that goes with a stream reset
-        def __init__(self):
-            self.h, self.a = None, self
-
-        def BeatriceBatch_ResetStream(self, h_, stream):
-            rc = ob.a.BeatriceBatch_ResetStream(h_, stream)
-            if stream in wrappers:
-                make_wrapper(stream)
-            return rc
-
-        def __getattr__(self, name):
-            return getattr(ob.a, name)
-
-    script = Script()
-    for s_ in ob.sample:
-        make_wrapper(s_)
-    dev = 0.0
-    for k in range(blocks):
-        change(script, k)
-        for s_ in ob.sample:
-            blk_in = x[s_, :, 480 * k:480 * (k + 1)]
-            mono = np.ascontiguousarray(blk_in[0] if channels == 1 else ((blk_in[0] + blk_in[1]) * np.float32(0.5)).astype(np.float32))
-            y = np.zeros(480, np.float32)
-            assert wl.f_process(wrappers[s_], bv.fptr(mono), bv.fptr(y), 480) == 0
-            for c in range(channels):
-                dev = max(dev, float(np.abs(got[k][s_, c] - y).max()))
-    for s_ in ob.sample:
-        wl.f_destroy(wrappers[s_])
-    ob.close()
-    print("48k wrapper around the tick pipeline vs ORACLE host chain, streams %s, %d blocks: max-abs %g" % (ob.sample, blocks, dev))
+    sample, dev = oracle_leg_48k(bv, oracle, model_dir, B, channels, x, blocks, settings, change, got)
+    print("48k wrapper around the tick pipeline vs ORACLE host chain, streams %s, %d blocks: max-abs %g" % (sample, blocks, dev))
     assert dev <= 1e-4
     # in order again on the same streams (wrapper and model state carried over)
     y = batch.convert48k(np.ascontiguousarray(x[:, :, :480]), channels)
@@ -177,15 +184,14 @@ def test_48k_wrapper_around_the_tick_pipeline_matches_in_order(bv, oracle, produ
     m.close()
 
 
-@pytest.mark.parametrize("B,channels,steps", [(5, 2, 36), (64, 2, 24), (3, 1, 33)])
-def test_48k_wrapper_around_the_tick_pipeline_two_blocks_per_step(bv, product, model_dir, B, channels, steps):
-    """The same with a batch of two hops per step: a slot holds two consecutive 480-sample blocks per stream
-    ([B][2][channels][480]), every call converts both -- the resamplers and the FIFO run block after block inside the wrapper
-    launch.  Must equal the in-order device wrapper (one block per call; oracle-checked above) block for block; settings move
-    between steps."""
+@pytest.mark.parametrize("H,B,channels,steps", [(2, 5, 2, 36), (2, 64, 2, 24), (2, 3, 1, 33), (4, 5, 2, 33), (4, 64, 2, 16), (4, 3, 1, 30)])
+def test_48k_wrapper_around_the_tick_pipeline_two_blocks_per_step(bv, oracle, product, model_dir, H, B, channels, steps):
+    """The same with a batch of two or four hops per step: a slot holds H consecutive 480-sample blocks per stream
+    ([B][H][channels][480]), every call converts them all -- the resamplers and the FIFO run block after block inside the wrapper
+    launch.  Must equal the in-order device wrapper (one block per call) block for block, and a sample of the streams the ORACLE
+    host chain (this is the mode `bench.py --config 4` times); settings move between steps."""
     from test_gpu_resident_io import Hip
     hip = Hip()
-    H = 2
     blocks = H * steps
     x = np.stack([np.stack([wrapperlib.test_signal(480 * blocks, 48000, seed=900 + 7 * s + c) for c in range(channels)])
                   for s in range(B)]).astype(np.float32)                      # [B][ch][blocks*480]
@@ -244,3 +250,7 @@ def test_48k_wrapper_around_the_tick_pipeline_two_blocks_per_step(bv, product, m
     batch.close()
     m.close()
     hip.free(d_in); hip.free(d_out)
+    sample, dev = oracle_leg_48k(bv, oracle, model_dir, B, channels, x, blocks, settings,
+                                 lambda script, kb: change(script, kb // H) if kb % H == 0 else None, got)
+    print("48k wrapper around the tick pipeline, %d blocks per step, vs ORACLE host chain, streams %s, %d blocks: max-abs %g" % (H, sample, blocks, dev))
+    assert dev <= 1e-4
