@@ -395,6 +395,7 @@ _BATCH = {
     "BeatriceBatch_MorphSpeakerStaged": (C.c_int, [_vp, C.c_int, C.c_int, _f32p, C.c_int, C.c_uint]),
     "BeatriceBatch_GetSpeakerEmbeddings": (C.c_int, [_vp, C.c_int, _f32p, _f32p]),
     "BeatriceBatch_SetTargetSpeaker": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "BeatriceBatch_SetTargetSpeakers": (C.c_int, [_vp, C.c_int, _i32p, _i32p]),
     "BeatriceBatch_FlushSpeaker": (C.c_int, [_vp, C.c_int]),
     "BeatriceBatch_SetFormantShift": (C.c_int, [_vp, C.c_int, C.c_double]),
     "BeatriceBatch_SetVQNumNeighbors": (C.c_int, [_vp, C.c_int, C.c_int]),

@@ -1115,6 +1115,25 @@ int BeatriceBatch_SetTargetSpeaker(BeatriceBatch* b, int stream, int speaker) {
   if (r == 0) { b->pending_kv = 0; for (const StreamCfg& c : b->cfg) if (c.kv_set_count < B_NBLOCKS) ++b->pending_kv; }
   return r;
 }
+// The same for n (stream, speaker) pairs in one call -- a server that moves many streams before a step (BASELINE.json configs[3]:
+// 64 rotating speakers) pays the bookkeeping of the pending key/value installs once, not once per stream.  All or nothing: an
+// invalid pair changes nothing.
+int BeatriceBatch_SetTargetSpeakers(BeatriceBatch* b, int n, const int* streams, const int* speakers) {
+  const DeviceScope dev_(b ? b->device : -1);
+  if (!b || !b->ok) return -2;
+  if (n < 0 || (n > 0 && (!streams || !speakers))) return -1;
+  for (int i = 0; i < n; ++i)
+    if (streams[i] < 0 || streams[i] >= b->B || speakers[i] < 0 || speakers[i] >= b->max_speakers) return -1;
+  for (int i = 0; i < n; ++i) {
+    StreamCfg& c = b->cfg[streams[i]];
+    c.target_speaker = speakers[i]; c.codebook_speaker = speakers[i]; c.additive_speaker = speakers[i]; c.kv_set_count = 0; c.kv_delay = 0;
+    for (int& cr : c.codebook_row) cr = speakers[i];
+    sync_stream_arrays(b, streams[i]);
+  }
+  b->pending_kv = 0;
+  for (const StreamCfg& c : b->cfg) if (c.kv_set_count < B_NBLOCKS) ++b->pending_kv;
+  return 0;
+}
 // processor_core_2.cc:270,414: `while (SetKeyValueSpeakerEmbedding());`
 int BeatriceBatch_FlushSpeaker(BeatriceBatch* b, int stream) {
   const DeviceScope dev_(b ? b->device : -1);

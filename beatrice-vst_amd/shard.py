@@ -192,3 +192,13 @@ def max_over_ranks(value, world, dist, torch, device):
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_over_ranks(value, world, dist, torch, device):
+    """every rank's value, in rank order (all ranks receive the list)"""
+    if world == 1:
+        return [value]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]

@@ -187,14 +187,15 @@ def saturation(bv, models, product, streams=8192, steps=30):
             "best_gemm_tflops": round(max(r["flops"] / (r["mean_us"] * 1e-6) / 1e12 for r in rows), 2)}
 
 
-def tick_rate(bv, models, product, torch, streams, flops_per_stream_hop, steps=150):
-    """Tick pipelining at a larger batch (resident noise input, 64 slots, fill and drain inside the timed region)."""
+def tick_rate(bv, models, product, torch, streams, flops_per_stream_hop, steps=150, hops=1):
+    """Tick pipelining at another batch size / number of hops per step (resident noise input, 64 slots, fill and drain inside the
+    timed region)."""
     import time
     n_cycle = 64
-    batch = bv.Batch(models, streams)
+    batch = bv.Batch(models, streams, hops_per_step=hops)
     product.BeatriceBatch_FlushSpeaker(batch.h, -1)
-    d_in = torch.randn((n_cycle, streams, 160), dtype=torch.float32, device="cuda") * 0.1
-    d_out = torch.zeros((n_cycle, streams, 240), dtype=torch.float32, device="cuda")
+    d_in = torch.randn((n_cycle, streams, hops * 160), dtype=torch.float32, device="cuda") * 0.1
+    d_out = torch.zeros((n_cycle, streams, hops * 240), dtype=torch.float32, device="cuda")
     out = None
     if product.BeatriceBatch_BindResidentIO(batch.h, d_in.data_ptr(), d_out.data_ptr(), n_cycle) == 0 and \
             product.BeatriceBatch_EnableTickPipeline(batch.h, 1) == 0:
@@ -205,8 +206,8 @@ def tick_rate(bv, models, product, torch, streams, flops_per_stream_hop, steps=1
                 product.BeatriceBatch_ConvertFramesDevice(batch.h, None, None)
             product.BeatriceBatch_Synchronize(batch.h)
             dt = time.perf_counter() - t0
-        fps = streams * steps / dt
-        out = {"streams": streams, "steps": steps, "frames_per_s": round(fps, 1), "ms_per_step": round(dt / steps * 1e3, 4),
+        fps = streams * hops * steps / dt
+        out = {"streams": streams, "hops_per_step": hops, "steps": steps, "frames_per_s": round(fps, 1), "ms_per_step": round(dt / steps * 1e3, 4),
                "tflops_end_to_end": round(fps * flops_per_stream_hop / 1e12, 2),
                "mfma_frac_end_to_end": round(fps * flops_per_stream_hop / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
         product.BeatriceBatch_EnableTickPipeline(batch.h, 0)
@@ -382,8 +383,8 @@ def main():
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
     ap.add_argument("--speakers", type=int, default=None)
     ap.add_argument("--hops-per-step", type=int, default=None, choices=(1, 2, 4),
-                    help="10 ms hops of every stream per step (tick pipeline: hops per stage per launch); default 2 for configs 2 and 3 "
-                         "with the tick pipeline, 1 otherwise")
+                    help="10 ms hops of every stream per step (tick pipeline: hops per stage per launch); default 4 with the tick "
+                         "pipeline (round 4: 2; rounds 1-3: 1 -- the same run at those definitions is in the line), 1 otherwise")
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4),
                     help="BASELINE.json configs index: 2 = 256 streams/GPU, 1 speaker (default, the headline); "
                          "3 = 256 streams/GPU, 64 rotating speakers, VQ k=4; 4 = 64 streams/GPU, 48 kHz stereo, wrapper on the device")
@@ -473,10 +474,10 @@ def main():
         scaling = "strong"
     B = a.streams
     if a.hops_per_step is None:
-        a.hops_per_step = 2 if (a.pipeline == "tick" and not a.copy_io) else 1
+        a.hops_per_step = 4 if (a.pipeline == "tick" and not a.copy_io) else 1
     H = a.hops_per_step
     if H > 1 and (a.pipeline != "tick" or a.copy_io):
-        raise SystemExit("--hops-per-step 2 is the tick pipeline's form (resident I/O)")
+        raise SystemExit("--hops-per-step 2 / 4 is the tick pipeline's form (resident I/O)")
     tmp = tempfile.TemporaryDirectory()
     model_dir = tmp.name
     if rank == 0:
@@ -562,10 +563,14 @@ def main():
 
     def step(i):
         if a.config == 3 and i > 0:  # every stream moves to the next speaker every 200 hops, staggered by stream index
+            moved = []
             for hop in range(i * H, (i + 1) * H):   # (settings travel with the step: the switches of its hops, before it)
                 for s in switchers[hop % 200]:
                     current_speaker[s] = (current_speaker[s] + 1) % a.speakers
-                    product.BeatriceBatch_SetTargetSpeaker(batch.h, s, current_speaker[s])
+                    moved.append(s)
+            if moved:   # one call for all of the step's switches
+                n_mv = len(moved)
+                product.BeatriceBatch_SetTargetSpeakers(batch.h, n_mv, (ctypes.c_int * n_mv)(*moved), (ctypes.c_int * n_mv)(*[current_speaker[s] for s in moved]))
         if a.config == 4 and tick48:
             rc = product.BeatriceBatch_ConvertBlocks48kDevice(batch.h, None, None, 2)
         elif a.config == 4:
@@ -601,9 +606,18 @@ def main():
         raise SystemExit("Synchronize failed")
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    own_elapsed = elapsed
     if world > 1:
         dist.barrier()
         elapsed = shard.max_over_ranks(elapsed, world, dist, torch, "cuda")
+    per_rank_elapsed = shard.gather_over_ranks(own_elapsed, world, dist, torch, "cuda") if world > 1 else [own_elapsed]
+    # the host's own work per step, measured where the device cannot push back: 12 steps (fewer than the 16 settings snapshots the
+    # library lets the host run ahead) into a drained pipeline, enqueue time only
+    t_probe = time.perf_counter()
+    for i in range(12):
+        step(a.warmup + a.steps + i)
+    host_work_s = (time.perf_counter() - t_probe) / 12
+    product.BeatriceBatch_Synchronize(batch.h)
     out_rms = float((d_out48 if a.config == 4 else d_out).float().pow(2).mean().sqrt().item())
 
     if rank == 0:
@@ -634,7 +648,9 @@ def main():
                        "placement": a.placement if a.config == 3 else "n/a"},
             "ms_per_hop": round(1e3 * elapsed / (a.steps * H), 4),   # (of all streams: ms_per_step / hops_per_step)
             "x_realtime_per_stream": round(a.steps * H / elapsed / 100.0, 2), "output_rms": round(out_rms, 4),
-            "host_enqueue_ms_per_step": round(1e3 * enqueue_s / a.steps, 4),
+            "host_enqueue_ms_per_step": round(1e3 * enqueue_s / a.steps, 4),   # (includes waiting for the device once the host is 16 settings snapshots ahead)
+            "host_work_ms_per_step": round(1e3 * host_work_s, 4),               # (12 steps into a drained pipeline: the host's own work)
+            "per_rank_frames_per_s": [round(B * a.steps * H / e, 1) for e in per_rank_elapsed],   # (a straggler shows; `value` uses the MAX-reduced time)
         }
         tick_roof = None
         if tick48:  # configs[4]: the wrapper kernels run beside each tick launch; per-kernel figures below are of the chain in order
@@ -644,7 +660,7 @@ def main():
             # one pair of HIP events on the batch's stream (BeatriceBatch_TimeTickLaunch)
             stages = product.BeatriceBatch_TickStages(batch.h)
             for i in range(stages + 2):
-                step(a.warmup + a.steps + i)
+                step(a.warmup + a.steps + 12 + i)
             us, fl, by = ctypes.c_float(0), ctypes.c_double(0), ctypes.c_double(0)
             # (clocks and caches settle over a few hundred ticks after the refill above -- 83 -> 81 -> 79 -> 77 us over four calls on
             #  an idle-cooled device, tools/debug/time_tick.py -- so the figure is the mean of the last three of eight calls of 64
@@ -736,8 +752,11 @@ def main():
                 res["hop_synchronous_frames_per_s"] = res["hop_synchronous"]["frames_per_s"]
                 res["saturation"] = saturation(bv, m, product)
                 res["saturation"]["tick_pipelined"] = tick_rate(bv, m, product, torch, 1024, res["chain"]["gflop_per_step"] * 1e9 / B)
-                if tick and H > 1 and a.config == 2:   # the same run at ONE hop per step (the headline's definition up to round 3): same K, fill and drain inside
+                if tick and H > 1 and a.config == 2:   # the same K steps at the headline's earlier definitions: ONE hop per step (rounds 1-3), TWO (round 4); fill and drain inside
                     res["one_hop_per_step"] = tick_rate(bv, m, product, torch, B, res["chain"]["gflop_per_step"] * 1e9 / B, steps=a.steps)
+                    if H > 2:
+                        res["two_hops_per_step"] = tick_rate(bv, m, product, torch, B, res["chain"]["gflop_per_step"] * 1e9 / B, steps=a.steps, hops=2)
+                        res["same_hop_count_at_two_hops_per_step"] = tick_rate(bv, m, product, torch, B, res["chain"]["gflop_per_step"] * 1e9 / B, steps=a.steps * H // 2, hops=2)
                 res["block_mode"] = block_mode(bv, m, product, B)
                 res["morph"] = morph_timing(bv, product)
                 res["host_buffer_variant"] = host_buffer_rate(bv, m, product, B)

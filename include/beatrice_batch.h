@@ -143,6 +143,9 @@ int BeatriceBatch_MorphSpeakerStaged(BeatriceBatch* b, int slot, int from_slot, 
 int BeatriceBatch_GetSpeakerEmbeddings(BeatriceBatch* b, int speaker, float* additive, float* key_value);
 
 int BeatriceBatch_SetTargetSpeaker(BeatriceBatch* b, int stream, int speaker);
+/* n (stream, speaker) pairs at once (the same effect as n calls of BeatriceBatch_SetTargetSpeaker, processor_core_2.cc:431-466 per
+ * stream; all or nothing: -1 and no change when any pair is out of range). */
+int BeatriceBatch_SetTargetSpeakers(BeatriceBatch* b, int n, const int* streams, const int* speakers);
 int BeatriceBatch_FlushSpeaker(BeatriceBatch* b, int stream); /* install all pending K/V blocks now */
 int BeatriceBatch_SetFormantShift(BeatriceBatch* b, int stream, double formant_shift);
 int BeatriceBatch_SetVQNumNeighbors(BeatriceBatch* b, int stream, int k);
