@@ -299,7 +299,11 @@ void Beatrice20rc0_ExtractPhone1(const Beatrice20rc0_PhoneExtractor* m, const fl
   }
   bool ok = run_hop(ctx->hop_graph[variant], m->blob.d, variant, ctx->stream, enqueue);
   ok = wait_stream(ctx->stream) && ok;
-  ok = ok && !(ctx->st.d_team_dead && *ctx->st.d_team_dead);   // (a team launch that gave a wait up: zeros, as for any internal failure)
+  if (team_timed_out(ctx->st)) {   // a team launch gave a wait up: zeros for this call (as for any internal failure), the per-layer launches from the next one on (engine.h team_recover)
+    ok = false;
+    team_recover(ctx->st, ctx->stream);
+    for (HopGraph& g : ctx->hop_graph) g.drop();   // (they hold the team launch)
+  }
   if (ok) std::memcpy(output, h_out, sizeof(float) * B_PHONE_CH);
 }
 
@@ -378,7 +382,12 @@ void Beatrice20rc0_EstimatePitch1(const Beatrice20rc0_PitchEstimator* m, const f
     (void)hipMemcpyAsync(h_q, ctx->st.d_q_raw, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
   });
   ok = wait_stream(ctx->stream) && ok;
-  ok = ok && !(ctx->st.d_team_dead && *ctx->st.d_team_dead);
+  if (team_timed_out(ctx->st)) {
+    ok = false;
+    team_recover(ctx->st, ctx->stream);
+    (void)hipMemsetAsync(ctx->st.d_prev_q, 0, sizeof(int), ctx->stream);   // (the one piece of the stream's state outside the rings)
+    ctx->hop_graph.drop();
+  }
   if (ok) { *out_q = *h_q; std::memcpy(out_feat, h_feat, sizeof(float) * 4); }
 }
 
@@ -453,8 +462,21 @@ void Beatrice20rc0_GenerateWaveform1(const Beatrice20rc0_WaveformGenerator* m, c
     if (!ctx->out_mapped) (void)hipMemcpyAsync(h_out, ctx->st.d_out, sizeof(float) * B_OUT_HOP, hipMemcpyDeviceToHost, ctx->stream);
   });
   ok = wait_stream(ctx->stream) && ok;
-  ok = ok && !(ctx->st.d_team_dead && *ctx->st.d_team_dead);
+  if (team_timed_out(ctx->st)) {
+    ok = false;
+    team_recover(ctx->st, ctx->stream);
+    ctx->hop_graph.drop();
+  }
   if (ok) std::memcpy(output, h_out, sizeof(float) * B_OUT_HOP);
+}
+
+// Test hook: makes the context's NEXT GenerateWaveform1 behave as if its team launch had timed out (engine.h team_recover) -- that
+// call returns zeros, the context's rings restart from silence and the following calls run the per-layer launches.  -1: the
+// context has no team launch.
+int BeatriceHip_InjectTeamTimeout(Beatrice20rc0_WaveformContext1* ctx) {
+  if (!ctx || !ctx->ok || !ctx->st.d_team_dead || ctx->st.team_off) return -1;
+  *ctx->st.d_team_dead = 1;
+  return 0;
 }
 
 // ================================ embedding setter =============================================

@@ -283,12 +283,22 @@ hipStream_t stage_stream(const BeatriceBatch* b, int s) { return b->pipelined &&
 hipStream_t wave_stream(const BeatriceBatch* b) { return stage_stream(b, b->n_stages - 1); }  // where a step's output appears
 bool tick_drain(BeatriceBatch* b);
 void host_stream_free(BeatriceBatch* b);
+void drop_graph(BeatriceBatch* b);
 bool sync_all(BeatriceBatch* b) {
   bool ok = !b->tk.on || tick_drain(b);  // steps still inside the tick pipeline come out first
   ok = hip_ok(hipStreamSynchronize(b->stream), "sync") && ok;
   for (int s = 1; s < BeatriceBatch::kMaxStages; ++s)
     if (b->stage_stream_own[s]) ok = hip_ok(hipStreamSynchronize(b->stage_stream_own[s]), "sync stage") && ok;
   b->inflight = false;
+  // a one-stream batch runs the modules' team launches (team.hip.h): a timeout voids the steps since the last synchronisation; the
+  // stream restarts from silence on the per-layer launches (engine.h team_recover)
+  if (team_timed_out(b->phone) || team_timed_out(b->pitch) || team_timed_out(b->wave)) {
+    std::fprintf(stderr, "beatrice_hip: a team launch timed out; the batch's stream was reset and continues on the per-layer launches\n");
+    team_recover(b->phone, b->stream); team_recover(b->pitch, b->stream); team_recover(b->wave, b->stream);
+    (void)hipMemsetAsync(b->pitch.d_prev_q, 0, sizeof(int) * b->B, b->stream);
+    drop_graph(b);
+    ok = false;
+  }
   if (b->tk.h_link_dead && *b->tk.h_link_dead) {   // a GRU cell of a tick gave up waiting for the cell of the hop before (tick.hip.h): results are void
     std::fprintf(stderr, "beatrice_hip: tick launch: a linked GRU cell timed out\n");
     b->ok = false;
@@ -869,7 +879,7 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   for (hipEvent_t e : b->rw.ev) if (e) (void)hipEventDestroy(e);
   if (b->h_wrap_io) (void)hipHostFree(b->h_wrap_io);
   b->wrap_gains.release();
-  { void* tk[] = {b->tk.d_table, b->tk.d_table_sparse, b->tk.d_snap, b->tk.d_trace, b->tk.d_link_q, b->tk.d_link_p, b->tk.d_desc, b->tk.d_desc_sparse}; for (void* p : tk) if (p) (void)hipFree(p); }
+  { void* tk[] = {b->tk.d_table, b->tk.d_table_sparse, b->tk.d_snap, b->tk.d_trace, b->tk.d_link_q, b->tk.d_link_p, b->tk.d_desc, b->tk.d_desc_sparse, b->tk.d_ring_table, b->tk.d_shift}; for (void* p : tk) if (p) (void)hipFree(p); }
   if (b->tk.h_link_dead) (void)hipHostFree(b->tk.h_link_dead);
   if (b->tk.h_stage) (void)hipHostFree(b->tk.h_stage);
   for (hipEvent_t e : b->tk.stage_ev) if (e) (void)hipEventDestroy(e);

@@ -453,6 +453,45 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
   b->inflight = true;
   return hip_ok(hipGetLastError(), "tick launch");
 }
+// Ragged steps leave every stream at a step counter of its own; at a DRAINED point (no step inside the pipeline) the batch is brought
+// back to one counter: the rings of every stream that lags are rotated forward by its deficit (ring_rotate_kernel), after which all
+// streams stand at the batch's counter -- the common launch runs again (the ragged instance costs +16 %), and the in-order chain,
+// which has one counter for all streams, can take the batch over (leaving tick mode used to be refused for good).
+static bool tick_relevel(BeatriceBatch* b) {
+  using namespace tick;
+  State& k = b->tk;
+  if (!k.ragged) return true;
+  std::vector<int> shift(b->B, 0);
+  bool any = false;
+  for (int s = 0; s < b->B; ++s) {
+    int d = b->hop_host - k.hop_s[s];
+    if (d < 0) d += B_HOP_WRAP;
+    shift[s] = d;
+    any = any || d != 0;
+  }
+  if (any) {
+    if (!k.d_ring_table) {
+      std::vector<FreezeRing> rings;
+      for (const RingArena* a : {&b->phone.arena, &b->pitch.arena, &b->wave.arena})
+        for (const Ring* r : a->rings) {
+          if (r->m > kMaxRotateSlots) return false;
+          rings.push_back(FreezeRing{r->base, r->n * r->C, r->m, 0});
+        }
+      k.n_ring_table = (int)rings.size();
+      if (!hip_ok(hipMalloc(&k.d_ring_table, sizeof(FreezeRing) * rings.size()), "ring table") ||
+          !hip_ok(hipMemcpy(k.d_ring_table, rings.data(), sizeof(FreezeRing) * rings.size(), hipMemcpyHostToDevice), "ring table up") ||
+          !hip_ok(hipMalloc(reinterpret_cast<void**>(&k.d_shift), sizeof(int) * b->B), "ring shifts"))
+        return false;
+    }
+    if (!hip_ok(hipMemcpyAsync(k.d_shift, shift.data(), sizeof(int) * b->B, hipMemcpyHostToDevice, b->stream), "ring shifts up")) return false;   // (pageable source: staged before the call returns)
+    hipLaunchKernelGGL(ring_rotate_kernel, dim3(k.n_ring_table, b->B), dim3(256), 0, b->stream, static_cast<const FreezeRing*>(k.d_ring_table), k.d_shift);
+    if (!hip_ok(hipGetLastError(), "ring rotate")) return false;
+  }
+  k.hop_s.assign(b->B, b->hop_host);
+  k.ragged = false;
+  for (bool& r : k.step_ragged) r = false;
+  return true;
+}
 // ticks without new input until the last step fed has left the last stage
 // output half of one call of the any-rate wrapper around the ticks (BeatriceBatch_BindResidentBlocks): its block's inner
 // samples gathered from the resident model outputs, second resampling direction, output gain, into the call's slot
@@ -495,6 +534,7 @@ bool tick_drain(BeatriceBatch* b) {
     ok = rb_post(b, b->rb.jobs.front());
     b->rb.jobs.pop_front();
   }
+  if (ok && b->tk.on && b->tk.ragged) ok = tick_relevel(b);   // (nothing is in flight: back to one counter and the common launch)
   return ok;
 }
 int tick_enable(BeatriceBatch* b, bool on) {
@@ -556,12 +596,9 @@ int tick_enable(BeatriceBatch* b, bool on) {
     for (int blk = 0; blk < B_NBLOCKS; ++blk) rebuild_tiles(b, blk);  // (tick mode cuts the attention rows into tiles AND quads)
     return 0;
   }
-  if (k.ragged) {   // streams that have sat steps out are at counters of their own: the in-order chain (one counter for all) cannot take them over
-    for (int s = 0; s < b->B; ++s) if (k.hop_s[s] != b->hop_host) return -1;
-  }
-  if (!sync_all(b)) return -2;  // drains
+  if (!sync_all(b)) return -2;  // drains; streams that have sat steps out come back to the batch's counter (tick_relevel)
+  if (k.ragged) return -2;
   k.on = false;
-  k.ragged = false;
   if (b->silent.on && !b->silent.d_rings) b->silent.on = false;   // (the rule was enabled for tick mode only)
   for (int blk = 0; blk < B_NBLOCKS; ++blk) {   // (see above: tick mode's own copies of the K / V tables)
     if (b->wave.d_ktp[blk]) (void)hipFree(b->wave.d_ktp[blk]);

@@ -60,6 +60,16 @@ bool RingArena::build(int B_, const std::vector<RingSpec>& specs) {
   }
   return true;
 }
+bool team_capacity_ok(const void* kernel, int n_workgroups, int threads, size_t dynamic_lds_bytes) {
+  int per_cu = 0, dev = 0;
+  hipDeviceProp_t prop{};
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, dynamic_lds_bytes) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+      hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return (long long)per_cu * prop.multiProcessorCount >= n_workgroups;
+}
 bool RingArena::zero_all(hipStream_t s) const {
   BHIP_TRY(hipMemsetAsync(base, 0, floats * sizeof(float), s));
   return true;

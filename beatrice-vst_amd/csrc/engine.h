@@ -67,6 +67,27 @@ struct RingArena {
 //   pitch: [0] step counter, [1] lowest bin, [2] highest bin
 constexpr int kMailboxWords = 8;
 
+// ---- team launches (team.hip.h): every workgroup of the launch spin-waits on granules other workgroups of the SAME launch write,
+// so all of them must be resident at once.  (a) At create time a context only gets a team launch when the device can hold the whole
+// team (occupancy x compute units >= workgroups: a partitioned or CU-masked GPU may not).  (b) Residency can still fail at run time
+// -- other processes' kernels between the team's workgroups -- and the bounded spins then give up and raise the context's pinned
+// flag: team_recover() clears it, zeroes the granules and the context's rings (the stream restarts from silence, like a new
+// context) and switches the context to the per-layer launches for good; the call that hit the timeout returns zeros (the ABI's
+// answer to any internal failure), the following ones work.
+bool team_capacity_ok(const void* kernel, int n_workgroups, int threads, size_t dynamic_lds_bytes);
+template <class State>
+bool team_timed_out(const State& st) { return st.d_team_dead != nullptr && *st.d_team_dead != 0; }
+template <class State>
+bool team_recover(State& st, hipStream_t s) {   // (call with the stream idle)
+  if (!team_timed_out(st)) return false;
+  *st.d_team_dead = 0;
+  st.team_off = true;
+  if (st.d_team_xb && st.team_granules) (void)hipMemsetAsync(st.d_team_xb, 0, sizeof(unsigned long long) * st.team_granules, s);
+  (void)st.arena.zero_all(s);
+  (void)hipStreamSynchronize(s);
+  return true;
+}
+
 // ---- phone extractor ---------------------------------------------------------------------------
 struct PhoneWeights {
   const float *f1_w, *f1_b;
@@ -109,6 +130,8 @@ struct PhoneState {
   // stage one step behind its producer (batch.hip, tick mode)
   unsigned long long* d_team_xb = nullptr;   // one stream, one hop per call: the eight convolutions as one team launch (team.hip.h)
   int* d_team_dead = nullptr;   // pinned host word: set by a team launch that gave a wait up (the call then returns zeros)
+  size_t team_granules = 0;
+  bool team_off = false;        // set by team_recover(): this context runs the per-layer launches from then on
   bool create(int B, int H, float* shared_in, int out_slots = 1, bool pipe_slack = false, int out_ch = B_PHONE_CH);
   void destroy();
 };
@@ -150,6 +173,8 @@ struct PitchState {
   int bins = B_PITCH_BINS;    // pitch classes (384: legacy generations)
   unsigned long long* d_team_xb = nullptr;   // (see PhoneState)
   int* d_team_dead = nullptr;   // pinned host word: set by a team launch that gave a wait up (the call then returns zeros)
+  size_t team_granules = 0;
+  bool team_off = false;
   bool create(int B, int H, float* shared_in, bool with_params, bool pipe_slack = false, int bins = B_PITCH_BINS);
   void destroy();
 };
@@ -232,6 +257,8 @@ struct WaveState {
   // launch of a team of workgroups (team.hip.h); these are its exchange buffers (granules) and its "a wait was given up" flag
   unsigned long long* d_team_xb = nullptr;
   int* d_team_dead = nullptr;   // pinned host word: set by a team launch that gave a wait up (the call then returns zeros)
+  size_t team_granules = 0;
+  bool team_off = false;
   bool create(int B, int H, int n_slots, int n_add, int n_frm, float* shared_phone, int* shared_q, float* shared_feat,
               int front_slots = 1, bool pipe_slack = false, bool legacy = false);
   void destroy();

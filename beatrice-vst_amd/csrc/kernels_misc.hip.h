@@ -721,6 +721,25 @@ static __global__ __launch_bounds__(256) void freeze_fix_kernel(const FreezeRing
   }
 }
 
+// Streams of a batch back to ONE step counter (tick mode with ragged steps, at a drained point): stream b has sat shift[b] steps out
+// in total, i.e. its rings are indexed by a counter that lags the batch's by shift[b].  Every slot of every ring moves forward by
+// shift[b] (mod the ring's slot count): what the stream wrote at its own step h then sits where the common counter h + shift[b]
+// points, so the next step at the common counter finds the stream's whole history in the right places.  Single-slot rings are not
+// indexed by the counter.  Grid (rings, streams); a thread moves element i of every slot (no cross-thread ordering needed).
+constexpr int kMaxRotateSlots = 64;
+static __global__ __launch_bounds__(256) void ring_rotate_kernel(const FreezeRing* __restrict__ rings, const int* __restrict__ shift) {
+  const FreezeRing r = rings[blockIdx.x];
+  const int b = blockIdx.y;
+  const int d = r.m > 1 ? shift[b] % r.m : 0;
+  if (d == 0) return;
+  float* base = r.base + (size_t)b * r.slot_floats * r.m;
+  for (int i = threadIdx.x; i < r.slot_floats; i += 256) {
+    float v[kMaxRotateSlots];
+    for (int j = 0; j < r.m; ++j) v[j] = base[(size_t)j * r.slot_floats + i];
+    for (int j = 0; j < r.m; ++j) { const int t = j + d >= r.m ? j + d - r.m : j + d; base[(size_t)t * r.slot_floats + i] = v[j]; }
+  }
+}
+
 // mono = (L + R) * 0.5 (or L), 31-tap low-pass evaluated only at the samples the decimator keeps
 // (frozen != nullptr and frozen[b]: the stream's block is silent by the shell's rule -- nothing of its state moves)
 // (row: the block's index in in48 / in16 -- the stream, or (stream, hop in step) with several blocks per step; b: the stream's state)

@@ -188,6 +188,7 @@ void extract_phone(const LPhoneModel* m, const float* input, float* output, LPho
     (void)hipMemcpyAsync(h_out, ctx->st.d_phone, sizeof(float) * kLPhoneCh, hipMemcpyDeviceToHost, ctx->stream);
   });
   ok = wait_stream(ctx->stream) && ok;
+  if (team_timed_out(ctx->st)) { ok = false; team_recover(ctx->st, ctx->stream); ctx->graph.drop(); }   // (engine.h: zeros for this call, the per-layer launches from the next one on)
   if (ok) std::memcpy(output, h_out, sizeof(float) * kLPhoneCh);
 }
 // ref beatrice.h:88-93 / 157-162; caller processor_core_1.cc:54-57
@@ -210,6 +211,7 @@ void estimate_pitch(const LPitchModel* m, const float* input, int* out_q, float*
     (void)hipMemcpyAsync(h_q, ctx->st.d_q_raw, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
   });
   ok = wait_stream(ctx->stream) && ok;
+  if (team_timed_out(ctx->st)) { ok = false; team_recover(ctx->st, ctx->stream); (void)hipMemsetAsync(ctx->st.d_prev_q, 0, sizeof(int), ctx->stream); ctx->graph.drop(); }
   if (ok) { *out_q = *h_q; std::memcpy(out_feat, h_feat, sizeof(float) * 4); }
 }
 // ref beatrice.h:112-120 / 181-189; caller processor_core_1.cc:139-142
@@ -232,6 +234,7 @@ void generate_waveform(const LWaveModel* m, const float* phone, const int* q, co
     (void)hipMemcpyAsync(h_out, ctx->st.d_out, sizeof(float) * B_OUT_HOP, hipMemcpyDeviceToHost, ctx->stream);
   });
   ok = wait_stream(ctx->stream) && ok;
+  if (team_timed_out(ctx->st)) { ok = false; team_recover(ctx->st, ctx->stream); ctx->graph.drop(); }
   if (ok) std::memcpy(output, h_out, sizeof(float) * B_OUT_HOP);
 }
 

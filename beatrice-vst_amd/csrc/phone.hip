@@ -40,13 +40,16 @@ bool PhoneState::create(int B_, int H_, float* shared_in, int out_slots_, bool p
   BHIP_TRY(hipMemset(d_vqk, 0, sizeof(int) * B));
   BHIP_TRY(hipMemset(d_hop, 0, 2 * sizeof(int)));
   hop = d_hop; hop_in = d_hop;
-  if (B == 1 && H == 1) {   // the 1-stream ABI's team launch (team.hip.h); tag 0 = "never written"
+  team_off = false;
+  if (B == 1 && H == 1 && hipFuncSetAttribute(reinterpret_cast<const void*>(team::phone_team_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, team::kLdsFloats * 4) == hipSuccess &&
+      team_capacity_ok(reinterpret_cast<const void*>(team::phone_team_kernel), team::NWG, team::NTHR, team::kLdsFloats * 4)) {
+    // the 1-stream ABI's team launch (team.hip.h), where the device can hold the whole team at once; tag 0 = "never written"
+    team_granules = team::kPhoneGranules;
     BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_team_xb), sizeof(unsigned long long) * team::kPhoneGranules));
     BHIP_TRY(hipMemset(d_team_xb, 0, sizeof(unsigned long long) * team::kPhoneGranules));
     // (pinned host memory, written by the kernel only when a wait was given up: the host reads it after every call for free)
     BHIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d_team_dead), sizeof(int), hipHostMallocDefault));
     *d_team_dead = 0;
-    BHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(team::phone_team_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, team::kLdsFloats * 4));
   }
   // hipMemset is asynchronous and runs on the NULL stream, which the (non-blocking) compute streams
   // do not wait for: make every initialisation above visible before the first kernel can start
@@ -89,7 +92,7 @@ static void phone_forward_h(const PhoneWeights& w, const PhoneState& s, hipStrea
   const F1Args fa = f1_args(w, s);
   launch_site(f1_info(s), st, [&] { hipLaunchKernelGGL(phone_f1_kernel, dim3(B, H), dim3(256), 0, st, fa); });
   static const bool no_team = std::getenv("BEATRICE_HIP_NO_TEAM") != nullptr;
-  if (H == 1 && B == 1 && s.d_team_xb != nullptr && !no_team) {   // one stream: f2 .. f5 and the residual blocks as ONE launch (team.hip.h)
+  if (H == 1 && B == 1 && s.d_team_xb != nullptr && !no_team && !s.team_off) {   // one stream: f2 .. f5 and the residual blocks as ONE launch (team.hip.h)
     using namespace team;
     PhoneTeamArgs a{};
     gran_t* g = s.d_team_xb;

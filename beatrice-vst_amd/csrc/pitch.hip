@@ -49,13 +49,16 @@ bool PitchState::create(int B_, int H_, float* shared_in, bool with_params, bool
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hop), 2 * sizeof(int)));
   BHIP_TRY(hipMemset(d_hop, 0, 2 * sizeof(int)));
   hop = d_hop; hop_in = d_hop;
-  if (B == 1 && H == 1) {   // the 1-stream ABI's team launch (team.hip.h); tag 0 = "never written"
+  team_off = false;
+  if (B == 1 && H == 1 && hipFuncSetAttribute(reinterpret_cast<const void*>(team::pitch_team_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, team::kLdsFloats * 4) == hipSuccess &&
+      team_capacity_ok(reinterpret_cast<const void*>(team::pitch_team_kernel), team::kPitchTeamWgs, team::NTHR, team::kLdsFloats * 4)) {
+    // the 1-stream ABI's team launch (team.hip.h), where the device can hold the whole team at once; tag 0 = "never written"
+    team_granules = team::kPitchGranules;
     BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_team_xb), sizeof(unsigned long long) * team::kPitchGranules));
     BHIP_TRY(hipMemset(d_team_xb, 0, sizeof(unsigned long long) * team::kPitchGranules));
     // (pinned host memory, written by the kernel only when a wait was given up: the host reads it after every call for free)
     BHIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d_team_dead), sizeof(int), hipHostMallocDefault));
     *d_team_dead = 0;
-    BHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(team::pitch_team_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, team::kLdsFloats * 4));
   }
   BHIP_TRY(hipDeviceSynchronize());  // NULL-stream memsets vs non-blocking compute streams
   return true;
@@ -81,7 +84,7 @@ static void pitch_forward_h(const PitchWeights& w, const PitchState& s, hipStrea
   const FftArgs fa = fft_args(w, s);
   launch_site(fft_info(s), st, [&] { hipLaunchKernelGGL(pitch_fft_kernel, dim3(B, H), dim3(256), 0, st, fa); });
   static const bool no_team = std::getenv("BEATRICE_HIP_NO_TEAM") != nullptr;
-  if (H == 1 && B == 1 && s.d_team_xb != nullptr && !no_team) {   // one stream: the three convolutions as ONE launch (team.hip.h)
+  if (H == 1 && B == 1 && s.d_team_xb != nullptr && !no_team && !s.team_off) {   // one stream: the three convolutions as ONE launch (team.hip.h)
     using namespace team;
     PitchTeamArgs a{};
     a.spec = Tensor{s.spec, nullptr};

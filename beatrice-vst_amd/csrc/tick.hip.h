@@ -219,6 +219,10 @@ struct State {
   hipEvent_t hv_ev[kStaging] = {};
   bool hv_pending[kStaging] = {};
   bool step_ragged[kRing] = {};       // step u (at [u % kRing]) carries per-stream counters
+  // back to one counter at a drained point (batch_tick.hip.h tick_relevel): the table of the batch's rings, the streams' deficits
+  void* d_ring_table = nullptr;       // FreezeRing [n_ring_table]
+  int n_ring_table = 0;
+  int* d_shift = nullptr;             // [B]
   // several hops per step: the granules that link the GRU cells of a step's hops inside a launch (fused_small.hip.h GruArgs::link_*)
   unsigned long long* d_link_q = nullptr;   // [H - 1][B][128]: link t = hop t's state for hop t + 1
   unsigned long long* d_link_p = nullptr;   // [H - 1][B][256]

@@ -89,13 +89,16 @@ bool WaveState::create(int B_, int H_, int n_slots_, int n_add_, int n_frm_, flo
   BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hop), 2 * sizeof(int)));  // [0] step counter, [1] resident-I/O slot
   BHIP_TRY(hipMemset(d_hop, 0, 2 * sizeof(int)));
   hop = d_hop;
-  if (B == 1 && H == 1 && !legacy) {   // the 1-stream ABI's team launch (team.hip.h); tag 0 = "never written"
+  team_off = false;
+  if (B == 1 && H == 1 && !legacy && hipFuncSetAttribute(reinterpret_cast<const void*>(team::wave_team_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, team::kLdsFloats * 4) == hipSuccess &&
+      team_capacity_ok(reinterpret_cast<const void*>(team::wave_team_kernel), team::NWG, team::NTHR, team::kLdsFloats * 4)) {
+    // the 1-stream ABI's team launch (team.hip.h), where the device can hold the whole team at once; tag 0 = "never written"
+    team_granules = team::kWaveGranules;
     BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_team_xb), sizeof(unsigned long long) * team::kWaveGranules));
     BHIP_TRY(hipMemset(d_team_xb, 0, sizeof(unsigned long long) * team::kWaveGranules));
     // (pinned host memory, written by the kernel only when a wait was given up: the host reads it after every call for free)
     BHIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d_team_dead), sizeof(int), hipHostMallocDefault));
     *d_team_dead = 0;
-    BHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(team::wave_team_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, team::kLdsFloats * 4));
     if (std::getenv("BEATRICE_HIP_TEAM_TRACE")) {   // measurement aid: per-stage stamps of workgroup 0 (BeatriceHip_TeamTraceDump)
       BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_team_trace), sizeof(unsigned long long) * 1024));
       BHIP_TRY(hipMemset(g_team_trace, 0, sizeof(unsigned long long) * 1024));
@@ -179,7 +182,7 @@ static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t
     const CondArgs ca = cond_args(w, s);
     launch_site(cond_info(s), st, [&] { hipLaunchKernelGGL(wave_cond_kernel, dim3(rows), dim3(256), 0, st, ca); });
   }
-  if (H == 1 && B == 1 && s.d_team_xb != nullptr && part.first <= 1 && part.last >= 6 && team_on()) {
+  if (H == 1 && B == 1 && s.d_team_xb != nullptr && !s.team_off && part.first <= 1 && part.last >= 6 && team_on()) {
     launch_wave_team(w, s, st);
     part.first = 7;   // what is left: the fused tail
   }

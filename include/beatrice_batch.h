@@ -46,6 +46,10 @@ Beatrice_ErrorCode BeatriceHip_LoadEmbeddingSetterFromMemory(Beatrice20rc0_Embed
  * a caller-owned table by address + a 96-word sample of its contents.  After rewriting a table IN PLACE (the same address)
  * call this, off the audio thread, so that the next SetCodebook of it uploads the new contents; NULL forgets every table. */
 void BeatriceHip_InvalidateCodebook(Beatrice20rc0_PhoneContext1* ctx, const float* codebook);
+/* Test hook for the recovery path of the 1-stream team launches (a launch whose workgroups could not all become resident gives its
+ * waits up after ~0.3 s instead of hanging the GPU): the context's next GenerateWaveform1 returns zeros, its state restarts from
+ * silence, and from then on the context runs one launch per layer.  -1: the context has no team launch. */
+int BeatriceHip_InjectTeamTimeout(Beatrice20rc0_WaveformContext1* ctx);
 
 /* Several GPUs in one process (a C++ host with one thread per GPU, examples/node_convert.cc; the reference runs many plugin
  * instances per process, src/vst/factory.cc:21).  Every object of this library -- model objects, contexts, batches --
@@ -189,8 +193,8 @@ int BeatriceBatch_ConvertBlocks48kDevice(BeatriceBatch* b, const float* d_in, fl
  * BeatriceBatch_ConvertBlocks48kDevice(b, NULL, NULL, channels) -- is taken from slot k mod n_slots, and its converted block
  * appears in the same slot of d_out48 BeatriceBatch_TickStages() - 1 calls later or after BeatriceBatch_Synchronize: the
  * samples of the in-order call, later.  NULL, NULL unbinds (and leaves tick mode).
- * On a batch with two hops per step (BeatriceBatch_CreateBlock(..., 2)) a slot holds two consecutive blocks per stream,
- * [n_slots][B][2][channels][480], and every call converts both (the samples of two in-order calls). */
+ * On a batch with H = 2 or 4 hops per step (BeatriceBatch_CreateBlock(..., H)) a slot holds H consecutive blocks per stream,
+ * [n_slots][B][H][channels][480], and every call converts them all (the samples of H in-order calls). */
 int BeatriceBatch_BindResidentIO48k(BeatriceBatch* b, const float* d_in48, float* d_out48, int channels, int n_slots);
 /* The shell's rule "a block whose down-mix is all zeros is not converted: the core is not called, its state and its 10 ms FIFO
  * stand still, the output is that down-mix" (reference src/vst/processor.cc:204-214), PER STREAM, for the in-order 48 kHz blocks
@@ -198,7 +202,14 @@ int BeatriceBatch_BindResidentIO48k(BeatriceBatch* b, const float* d_in48, float
  * the shell's own test; for BeatriceBatch_ConvertBlocks48kDevice the caller flags them (flags[B], non-zero = silent) before the
  * call, once per block.  A silent stream's model state, wrapper state, pending key/value installs and codebook lottery stand
  * still as if the block had never existed (the batch runs the step for every stream and puts the silent ones back: rings rotated,
- * in-place state restored). */
+ * in-place state restored).
+ * In TICK MODE (BeatriceBatch_EnableTickPipeline, or the 48 kHz blocks around the ticks, BeatriceBatch_BindResidentIO48k; one hop
+ * per step): enable the rule after entering the mode; the streams flagged with BeatriceBatch_SetSilentStreams sit the NEXT step out --
+ * the step carries each stream's own step counter through the pipeline, a second instance of the launch runs from then on.  At
+ * every drained point (BeatriceBatch_Synchronize, leaving the mode) the streams are brought back to the batch's one counter
+ * (their rings rotated by the steps they missed), so the common launch runs again and BeatriceBatch_EnableTickPipeline(b, 0) /
+ * BeatriceBatch_BindResidentIO48k(b, NULL, NULL, ..) succeed as on any batch.  Returns -1 for a batch of several hops per step,
+ * under host streaming or resident wrapper blocks, and (in order) with resident I/O or stage pipelining. */
 int BeatriceBatch_EnableSilentBlockRule(BeatriceBatch* b, int enable);
 int BeatriceBatch_SetSilentStreams(BeatriceBatch* b, const unsigned char* flags);
 

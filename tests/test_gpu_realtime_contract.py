@@ -155,3 +155,33 @@ def test_reloading_parameters_into_the_same_model_objects(bv, oracle, product, m
     print("parameters reloaded into live model objects: max-abs %g" % dev)
     assert np.abs(outs["hip"][7:]).max() > 1e-3
     assert dev <= 1e-4
+
+
+def test_team_launch_timeout_recovers(bv, oracle, product, model_dir):
+    """The 1-stream calls run each module's convolutions as ONE launch of a team of workgroups that wait for each other; where the
+    team cannot become resident its bounded waits give up.  The call that hit the timeout returns zeros (beatrice.h's contract for
+    any internal failure), the context's rings restart from silence and every later call runs one launch per layer -- it does not
+    stay silent for good.  The waveform generator has a finite memory, so a few hops after the (injected) timeout the
+    samples equal those of an uninterrupted oracle stream bit for bit again."""
+    bv.bind_batch(product)
+    hops, at = 70, 9
+    x = bv.synth_audio(160 * hops, seed=77)
+    mo = bv.Models(oracle, model_dir)
+    so = bv.Stream1(mo, speaker=1, vq_k=2)
+    want = np.array([so.hop(x[i * 160:(i + 1) * 160]) for i in range(hops)])
+    so.close(); mo.close()
+    m = bv.Models(product, model_dir)
+    s = bv.Stream1(m, speaker=1, vq_k=2)
+    got = []
+    for i in range(hops):
+        if i == at:
+            assert product.BeatriceHip_InjectTeamTimeout(s.wc) == 0
+        got.append(s.hop(x[i * 160:(i + 1) * 160]))
+    assert product.BeatriceHip_InjectTeamTimeout(s.wc) == -1      # the context has left the team launch for good
+    s.close(); m.close()
+    got = np.array(got)
+    assert np.array_equal(got[:at], want[:at])
+    assert not got[at].any()                                       # the failed call: zeros
+    assert np.abs(got[at + 1:at + 4]).max() > 0                    # ... and sound again right after
+    settled = at + 40                                              # (dilated convolutions reach 16 frames back, the tail a few more)
+    assert np.array_equal(got[settled:], want[settled:]), "max-abs %g" % np.abs(got[settled:] - want[settled:]).max()

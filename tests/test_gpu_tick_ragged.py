@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("B,steps", [(7, 70), (40, 45)])
 def test_streams_that_sit_steps_out_in_tick_mode_match_the_oracle(bv, oracle, product, model_dir, B, steps):
     rng = np.random.default_rng(11 + B)
-    x = np.stack([bv.synth_audio(160 * steps, seed=7300 + s) for s in range(B)]).reshape(B, steps, 160)
+    tail = 6   # hops in order after the pipelined part: streams that sat steps out are brought back to one step counter when the batch leaves tick mode
+    x = np.stack([bv.synth_audio(160 * (steps + tail), seed=7300 + s) for s in range(B)]).reshape(B, steps + tail, 160)
     # which steps each stream sits out: none for some, single steps, long runs, the very first steps, ...
     out = {s: set() for s in range(B)}
     for s in range(B):
@@ -48,6 +49,10 @@ def test_streams_that_sit_steps_out_in_tick_mode_match_the_oracle(bv, oracle, pr
             if k not in out[s]:
                 want[k, s] = ob.st[s]["s1"].hop(x[s, k])
     sample = ob.sample
+    want_tail = np.zeros((tail, B, 240), np.float32)
+    for k in range(tail):
+        for s in sample:
+            want_tail[k, s] = ob.st[s]["s1"].hop(x[s, steps + k])
     ob.close()
 
     # ---- product: tick mode, flags name the streams that sit the next step out
@@ -71,9 +76,14 @@ def test_streams_that_sit_steps_out_in_tick_mode_match_the_oracle(bv, oracle, pr
         if any(flags):
             assert a.BeatriceBatch_SetSilentStreams(h, flags) == 0
 
-    got = run_tick(bv, batch, steps, lambda k: x[:, k], change=change, chunk=13, leave=False)
+    got = run_tick(bv, batch, steps, lambda k: x[:, k], change=change, chunk=13)   # (every drain brings the streams back to one counter: ring_rotate_kernel)
+    # ... and leaves tick mode: the in-order chain (ONE counter for all streams) takes the batch over
+    assert a.BeatriceBatch_EnableSilentBlockRule(h, 0) == 0
+    got_tail = np.stack([batch.convert(np.ascontiguousarray(x[:, steps + k])) for k in range(tail)])
     batch.close()
     m.close()
+    for s in sample:
+        assert np.array_equal(got_tail[:, s], want_tail[:, s]), "in order after tick mode, stream %d: max-abs %g" % (s, np.abs(got_tail[:, s] - want_tail[:, s]).max())
     assert np.abs(want).max() > 0.05
     for s in sample:
         for k in range(steps):

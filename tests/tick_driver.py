@@ -58,11 +58,9 @@ def run_tick(bv, batch, steps, hop_input, change=None, slots=None, chunk=None, l
             for k in range(k0, k0 + n):
                 got[k] = out[k % slots]
             k0 += n
-        if leave:   # (a batch whose streams have sat steps out stays in tick mode: their step counters have diverged)
+        if leave:   # (streams that have sat steps out come back to the batch's step counter at every drained point)
             assert a.BeatriceBatch_EnableTickPipeline(h, 0) == 0
             assert a.BeatriceBatch_BindResidentIO(h, None, None, 0) == 0
-        else:
-            assert a.BeatriceBatch_EnableTickPipeline(h, 0) == -1
     finally:
         hip.free(d_in)
         hip.free(d_out)
