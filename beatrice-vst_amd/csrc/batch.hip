@@ -250,6 +250,8 @@ struct BeatriceBatch {
     std::vector<int> cls;                          // [B] class of each stream
     struct Clock { int phase_down, phase_up, fill; };
     std::vector<Clock> clk;                        // [B] the stream's two resampler clocks and its FIFO fill
+    std::vector<Clock> clk_undo;                   // what ProcessBlocksRagged restores when a call is refused half-way through its plan
+    std::vector<wrapn::GainClock> gain_undo_in, gain_undo_out;
     std::vector<int> taps_down_off, taps_up_off;   // per class: float offsets into d_taps
     float* d_taps = nullptr;
     static constexpr int kStage = 4;

@@ -379,6 +379,12 @@ int BeatriceBatch_ProcessBlocksRagged(BeatriceBatch* b, const float* in, float* 
   GainSeg* seg = b->wrap_gains.h;
   int max_chunks = 0;
   size_t off = 0;
+  // (all or nothing: the host-side clocks of the streams planned so far go back to where they were when a later stream's plan does
+  //  not fit -- otherwise host and device state of those streams would part ways)
+  r.clk_undo = r.clk;
+  r.gain_undo_in.assign(b->gain_in.begin(), b->gain_in.end());
+  r.gain_undo_out.assign(b->gain_out.begin(), b->gain_out.end());
+  auto refuse = [&]() { r.clk = r.clk_undo; std::copy(r.gain_undo_in.begin(), r.gain_undo_in.end(), b->gain_in.begin()); std::copy(r.gain_undo_out.begin(), r.gain_undo_out.end(), b->gain_out.begin()); return -2; };
   for (int s = 0; s < B; ++s) {
     RagStream& q = rs[s];
     q = RagStream{};
@@ -405,11 +411,11 @@ int BeatriceBatch_ProcessBlocksRagged(BeatriceBatch* b, const float* in, float* 
     seg[B + s] = b->gain_out[s].advance(n, p.rate);
     q.din = p.to_inner(n);
     const int m = q.din.n_out;
-    if (m < 0 || m > kMaxSamples) return -2;
+    if (m < 0 || m > kMaxSamples) return refuse();
     int fill = p.fill, nc = 0;
     for (int at = 0; at < m;) {
       const int take = std::min(kBlock - fill, m - at);
-      if (nc >= kMaxChunks) return -2;
+      if (nc >= kMaxChunks) return refuse();
       q.at[nc] = (short)at; q.fill[nc] = (short)fill; q.take[nc] = (short)take;
       q.fires[nc] = fill + take == kBlock ? 1 : 0;
       fill = q.fires[nc] ? 0 : fill + take;
@@ -419,7 +425,7 @@ int BeatriceBatch_ProcessBlocksRagged(BeatriceBatch* b, const float* in, float* 
     q.n_chunks = nc;
     p.fill = fill;
     q.dout = p.to_outer(m);
-    if (q.dout.n_out != n) return -2;
+    if (q.dout.n_out != n) return refuse();
     q.taps_in = q.din.decimate ? r.taps_down_off[r.cls[s]] : r.taps_up_off[r.cls[s]];
     q.taps_out = q.dout.decimate ? r.taps_down_off[r.cls[s]] : r.taps_up_off[r.cls[s]];
     c.phase_down = p.phase_down; c.phase_up = p.phase_up; c.fill = p.fill;
