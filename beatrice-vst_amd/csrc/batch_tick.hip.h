@@ -180,6 +180,7 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
   // MFMA-dense ones (TableBuilder::interleave; _RESERVE=<percent of the light time kept for the end of the launch>) -- measured, slower
   static const int order_mode = std::getenv("BEATRICE_HIP_TICK_ORDER") ? std::atoi(std::getenv("BEATRICE_HIP_TICK_ORDER")) : 0;
   static const double order_reserve = (std::getenv("BEATRICE_HIP_TICK_RESERVE") ? std::atoi(std::getenv("BEATRICE_HIP_TICK_RESERVE")) : 15) / 100.0;
+  static const int halves_mode = std::getenv("BEATRICE_HIP_TICK_HALVES") ? std::atoi(std::getenv("BEATRICE_HIP_TICK_HALVES")) : 2;   // 0: every body on all XCDs; 2 (default): halves; 4: quarters
   {
     using TB = typename O::Builder;
     std::vector<fuse::WgDesc> desc;
@@ -198,20 +199,42 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
         }
       }
       desc = tb->interleave(klass, order_reserve);
+    } else if (halves_mode != 0) {   // the bodies with the weights, each on one half of the chip (TableBuilder::two_halves)
+      bool pinned[fuse::kMaxSpans];
+      int group[fuse::kMaxSpans];
+      for (int i = 0; i < tb->t.n_spans; ++i) {
+        group[i] = -1;
+        switch (tb->t.span[i].type) {
+          case T_PGRU: case T_PGRU1: case T_PGRUM: pinned[i] = true; group[i] = 0; break;
+          case T_QGRU: case T_QGRU1: case T_QGRUM: pinned[i] = true; group[i] = 1; break;
+          case T_F2: case T_F3: case T_F4: case T_F5: case T_P1: case T_RB: case T_F4S: case T_F5S: case T_P1S: case T_RBS:
+          case T_BLKA1: case T_BLKA2: case T_BLKA4: case T_BLKA8: case T_BLKB: case T_BLKBQ:
+          case T_UP1: case T_UP1S: case T_RES1A: case T_RES1B: case T_UP2: case T_POUT: case T_P23: case T_INP: case T_OUT: pinned[i] = true; break;
+          default: pinned[i] = false; break;   // (the tail stages and the per-stream bodies: hardly any weights)
+        }
+      }
+      desc = tb->two_halves(pinned, group, halves_mode == 4 ? 4 : 2);
     } else {
       desc = tb->in_span_order();
     }
-    if ((int)desc.size() != tb->t.total) return false;
-    fuse::WgDesc*& d_desc = sparse ? k.d_desc_sparse : k.d_desc;
-    size_t& cap = sparse ? k.desc_sparse_cap : k.desc_cap;
-    if (desc.size() > cap) {
-      if (d_desc) (void)hipFree(d_desc);
-      d_desc = nullptr;
-      cap = 0;
-      BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_desc), sizeof(fuse::WgDesc) * desc.size()));
-      cap = desc.size();
+    auto upload = [&](const std::vector<fuse::WgDesc>& v, fuse::WgDesc*& d_desc, size_t& cap) {
+      if (v.size() > cap) {
+        if (d_desc) (void)hipFree(d_desc);
+        d_desc = nullptr;
+        cap = 0;
+        BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_desc), sizeof(fuse::WgDesc) * v.size()));
+        cap = v.size();
+      }
+      if (!v.empty()) BHIP_TRY(hipMemcpy(d_desc, v.data(), sizeof(fuse::WgDesc) * v.size(), hipMemcpyHostToDevice));
+      return true;
+    };
+    if (!sparse) {   // (the order of partly filled ticks: tick_launch)
+      const std::vector<fuse::WgDesc> plain = tb->in_span_order();
+      if (!upload(plain, k.d_desc_plain, k.desc_plain_cap)) return false;
+      k.table_total_plain = (int)plain.size();
     }
-    if (!desc.empty()) BHIP_TRY(hipMemcpy(d_desc, desc.data(), sizeof(fuse::WgDesc) * desc.size(), hipMemcpyHostToDevice));
+    tb->t.total = (int)desc.size();   // (two_halves may add filler indices)
+    if (!upload(desc, sparse ? k.d_desc_sparse : k.d_desc, sparse ? k.desc_sparse_cap : k.desc_cap)) return false;
   }
   if (std::getenv("BEATRICE_HIP_TICK_TRACE")) {
     if (k.d_trace) (void)hipFree(k.d_trace);
@@ -250,11 +273,13 @@ bool tick_build_table(BeatriceBatch* b, const bool sparse = false) {
   }
 }
 // the launch of one tick: the table kernel of the batch's hops per step
-static void tick_launch(BeatriceBatch* b, const bool sparse, hipStream_t st, const fuse::StepPairs& pairs) {
+static void tick_launch(BeatriceBatch* b, const bool sparse, const bool full, hipStream_t st, const fuse::StepPairs& pairs) {
   tick::State& k = b->tk;
   const void* t = sparse ? k.d_table_sparse : k.d_table;
-  const fuse::WgDesc* desc = sparse ? k.d_desc_sparse : k.d_desc;
-  const int total = sparse ? k.table_sparse_total : k.table_total;
+  // full = every stage has a step: the order that confines the bodies with the weights to halves of the chip; a partly filled tick
+  // (fill, drain) runs the same table in plain span order
+  const fuse::WgDesc* desc = sparse ? k.d_desc_sparse : (full ? k.d_desc : k.d_desc_plain);
+  const int total = sparse ? k.table_sparse_total : (full ? k.table_total : k.table_total_plain);
   if (b->H == 1) fuse::launch_table_w<4>(static_cast<const tick::Ops<1>::Tab*>(t), desc, total, st, pairs, k.ragged);   // (ragged: the second instance of the launch, once a stream has sat a step out)
   else if (b->H == 2) fuse::launch_table_w<4, false>(static_cast<const tick::Ops<2>::Tab*>(t), desc, total, st, pairs, false);   // (no ragged steps at several hops per step: EnableSilentBlockRule refuses)
   else fuse::launch_table_w<4, false>(static_cast<const tick::Ops<4>::Tab*>(t), desc, total, st, pairs, false);
@@ -434,7 +459,9 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
   // (one hop per step only: at two hops per step it measured no difference, at four the half-size bodies cost 1 % of a 20-step run --
   //  5 196 against 5 138 us of launches, profiles/r05_notes.md)
   const bool sparse = highest >= 0 && highest < Plan::BLK0 && !no_sparse && b->H == 1;
-  tick_launch(b, sparse, st, pairs);
+  int occupied = 0;
+  for (int s = 0; s < p.n_stages; ++s) occupied += p.hop[s] >= 0 ? 1 : 0;
+  tick_launch(b, sparse, occupied == p.n_stages, st, pairs);
   if (b->r48.on) {  // the step this tick completed: its 48 kHz block is produced by the wrapper launch of the next tick (or of the drain)
     const long long u = step_at(k.plan.count() - 1);
     if (u >= 0) { b->r48.deferred_slot = k.io_of_step[u % kRing]; b->r48.deferred_step = u; }

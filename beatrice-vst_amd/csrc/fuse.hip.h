@@ -320,6 +320,48 @@ struct TableBuilder {
       for (int w = 0; w < n_wg[i]; ++w) out.push_back(WgDesc{t.span[i].type, t.span[i].arg, w, t.span[i].gx});
     return out;
   }
+  // Two HALVES of the chip.  Workgroup i of a launch runs on XCD i % 8 (observed; used for speed only), so the indices with
+  // i % 8 < 4 and those with i % 8 >= 4 are two queues, four XCDs each.  A body flagged `pinned` goes whole into ONE queue (the
+  // one with less estimated time so far, cost[]; spans that name the same `group` >= 0 share a queue: the linked GRU cells of a
+  // step's hops), so its weights pass through four of the eight L2s instead of all of them; the other bodies are dealt to both
+  // queues, more to the one that is behind.  Order inside a queue = the order added.  The launch's memory-side traffic falls by
+  // half the pinned bodies' weights x 8 (profiles/r05_notes.md); what it may cost is balance: the two halves no longer share one
+  // queue of work.
+  std::vector<WgDesc> two_halves(const bool* pinned, const int* group, const int NQ = 2 /* queues: 2 halves or 4 quarters of the chip */) const {
+    struct Item { int span, local; };
+    std::vector<Item> q[4];
+    double load[4] = {0, 0, 0, 0};
+    int group_q[kMaxSpans];
+    for (int& g : group_q) g = -1;
+    auto lightest = [&]() { int h = 0; for (int x = 1; x < NQ; ++x) if (load[x] < load[h]) h = x; return h; };
+    for (int i = 0; i < t.n_spans; ++i) {
+      const double c = n_wg[i] > 0 ? cost[i] / n_wg[i] : 0.0;
+      if (pinned[i]) {
+        int h = lightest();
+        if (group[i] >= 0 && group[i] < kMaxSpans) { if (group_q[group[i]] >= 0) h = group_q[group[i]]; else group_q[group[i]] = h; }
+        for (int w = 0; w < n_wg[i]; ++w) q[h].push_back(Item{i, w});
+        load[h] += cost[i];
+      } else {
+        for (int w = 0; w < n_wg[i]; ++w) { const int h = lightest(); q[h].push_back(Item{i, w}); load[h] += c; }
+      }
+    }
+    std::vector<WgDesc> out;
+    auto emit = [&](const Item& x) { const Span& sp = t.span[x.span]; out.push_back(WgDesc{sp.type, sp.arg, x.local, sp.gx}); };
+    size_t at[4] = {0, 0, 0, 0};
+    auto all_have = [&]() { for (int h = 0; h < NQ; ++h) if (at[h] >= q[h].size()) return false; return true; };
+    while (all_have()) {   // 8 / NQ consecutive indices (= XCDs) for each queue in turn
+      for (int h = 0; h < NQ; ++h)
+        for (int j = 0; j < 8 / NQ; ++j) {
+          if (at[h] < q[h].size()) emit(q[h][at[h]++]);
+          else out.push_back(WgDesc{-1, 0, 0, 1});   // (a filler index: that slot's turn passes)
+        }
+    }
+    for (bool more = true; more;) {   // (the longer queues' rests go to all eight XCDs, round-robin)
+      more = false;
+      for (int h = 0; h < NQ; ++h) if (at[h] < q[h].size()) { emit(q[h][at[h]++]); more = true; }
+    }
+    return out;
+  }
   std::vector<WgDesc> interleave(const int* klass, const double reserve) const {
     struct Item { int span, local; double c; };
     std::vector<Item> first, dense, light;

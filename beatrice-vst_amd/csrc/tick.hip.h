@@ -194,6 +194,11 @@ struct State {
   fuse::WgDesc* d_desc = nullptr;    // dispatch order of the full / the sparse table by workgroup (tick_build_table_h)
   fuse::WgDesc* d_desc_sparse = nullptr;
   size_t desc_cap = 0, desc_sparse_cap = 0;
+  // the full table's workgroups in plain span order (every body on all eight XCDs): the order of PARTLY FILLED ticks -- with few stages
+  // occupied a body confined to half the chip leaves the other half idle (a 20-step run: 3.78 -> 3.51 M frames/s with the halves everywhere)
+  fuse::WgDesc* d_desc_plain = nullptr;
+  size_t desc_plain_cap = 0;
+  int table_total_plain = 0;
   unsigned long long* d_trace = nullptr;  // BEATRICE_HIP_TICK_TRACE=<file>: per-workgroup timeline of the last full tick
   bool table_dirty = true;
   unsigned char* d_snap = nullptr;  // [kRing][snap_bytes] settings snapshots
