@@ -174,7 +174,7 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
   if (!tb->ok) return false;
   // (XCD-aware placement -- bodies with many weights pinned to one XCD, or to the XCDs of equal index modulo 2 / 4, so that their weights
   //  stay in fewer L2s -- was measured in rounds 2 and 4: memory-side traffic / 4, the launch 4-8 % slower; the switch went with the
-  //  span lookup in round 5, the builder's place_by_xcd() documents the layout)
+  //  span lookup in round 5.  Its successor is TableBuilder::two_halves below: the same idea at the granularity that costs nothing)
   // Dispatch order by workgroup (fuse::WgDesc, one descriptor per workgroup read by a scalar load): BEATRICE_HIP_TICK_ORDER=0 (default):
   // the bodies in the order added above, every body a contiguous run; 1: the short, latency-bound workgroups dealt among the long
   // MFMA-dense ones (TableBuilder::interleave; _RESERVE=<percent of the light time kept for the end of the launch>) -- measured, slower

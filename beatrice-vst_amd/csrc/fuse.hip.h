@@ -135,7 +135,7 @@ struct Banks<M, Rest...> {
 struct WgDesc { int type, arg, local, gx; };
 template <class... Ms>
 struct Table {
-  int n_spans, total, per_xcd, pad;  // per_xcd > 0: XCD-aware layout, see TableBuilder::place_by_xcd
+  int n_spans, total, unused0, unused1;
   unsigned long long* trace;         // measurement aid (may be null): per workgroup {start, end} wall clock + body type
   Span span[kMaxSpans];  // 16 bytes each: a wavefront fetches all of them with one load, lane i = body i
   Banks<Ms...> banks;
@@ -232,80 +232,13 @@ template <class... Ms>
 struct TableBuilder {
   Table<Ms...> t{};
   int used[sizeof...(Ms)] = {};
-  double cost[kMaxSpans] = {};  // estimated time of the body's workgroups (relative), for place_by_xcd
+  double cost[kMaxSpans] = {};  // estimated time of the body's workgroups (us, from the launch's timelines): what two_halves / interleave balance
   int n_wg[kMaxSpans] = {};
   TableBuilder() { for (Span& sp : t.span) sp = Span{0x7fffffff, 1, -1, 0}; }
   bool ok = true;
   double flops = 0, bytes = 0;
   unsigned long long only = ~0ull;   // measurement builds (batch_tick.hip.h): bit I clear = bodies of type I are left out of the table
-  // Re-lays the bodies out for an 8-XCD chip.  A pinned body goes whole to ONE XCD (longest first, to the XCD with the
-  // least work so far), so that its weights are fetched into one L2 and stay there from tick to tick; a body marked
-  // `spread` (many workgroups, few weights) is dealt round-robin over all eight.  XCD x owns the index range
-  // [x * per_xcd, (x + 1) * per_xcd), padded with indices that do nothing.  Launch 8 * per_xcd workgroups.
-  bool spread[kMaxSpans] = {};
-  // G = groups of XCDs: 8 = every XCD its own bodies; 2 / 4 = the XCDs of equal index modulo G share a body (a body then has
-  // half / a quarter of the chip, and its weights are fetched by 4 / 2 L2s instead of 8)
-  void place_by_xcd(const int G = 8) {
-    const int n = t.n_spans;
-    int n_out = 0;
-    for (int i = 0; i < n; ++i) n_out += spread[i] ? G : 1;
-    if (n == 0 || n_out + G > kMaxSpans || (G != 2 && G != 4 && G != 8)) return;
-    int order[kMaxSpans];
-    for (int i = 0; i < n; ++i) order[i] = i;
-    for (int i = 0; i < n; ++i)
-      for (int j = i + 1; j < n; ++j)
-        if (cost[order[j]] > cost[order[i]]) { const int x = order[i]; order[i] = order[j]; order[j] = x; }
-    double load[8] = {};
-    int len[8] = {}, owner[kMaxSpans];
-    for (int i = 0; i < n; ++i)
-      if (spread[i]) for (int x = 0; x < G; ++x) { load[x] += cost[i] / G; len[x] += (n_wg[i] - x + G - 1) / G; }
-    for (int oi = 0; oi < n; ++oi) {
-      const int i = order[oi];
-      if (spread[i]) continue;
-      int best = 0;
-      for (int x = 1; x < G; ++x) if (load[x] < load[best]) best = x;
-      owner[i] = best;
-      load[best] += cost[i];
-      len[best] += n_wg[i];
-    }
-    int per = 1;
-    for (int x = 0; x < G; ++x) per = len[x] > per ? len[x] : per;
-    Span old[kMaxSpans];
-    for (int i = 0; i < n; ++i) old[i] = t.span[i];
-    // inside an XCD: the bodies whose workgroups run longest first (they set the launch's makespan)
-    for (int i = 0; i < n; ++i) order[i] = i;
-    for (int i = 0; i < n; ++i)
-      for (int j = i + 1; j < n; ++j)
-        if (cost[order[j]] / n_wg[order[j]] > cost[order[i]] / n_wg[order[i]]) { const int x = order[i]; order[i] = order[j]; order[j] = x; }
-    int out = 0;
-    for (int x = 0; x < G; ++x) {
-      int at = x * per;
-      for (int oi = 0; oi < n; ++oi) {
-        const int i = order[oi];
-        if (spread[i]) {
-          const int cnt = (n_wg[i] - x + G - 1) / G;
-          if (cnt <= 0) continue;
-          t.span[out] = old[i];
-          t.span[out].first = at;
-          t.span[out].arg = old[i].arg | (x << 8) | 0x1000;
-          at += cnt;
-          ++out;
-        } else if (owner[i] == x) {
-          t.span[out] = old[i];
-          t.span[out].first = at;
-          at += n_wg[i];
-          ++out;
-        }
-      }
-      if (at < (x + 1) * per) t.span[out++] = Span{at, 1, -1, 0};  // filler: these indices exit at once
-    }
-    for (int i = out; i < kMaxSpans; ++i) t.span[i] = Span{0x7fffffff, 1, -1, 0};
-    t.n_spans = out;
-    t.per_xcd = per;
-    t.total = G * per;
-    t.pad = G;
-  }
-  // Dispatch order by workgroup (Table::desc).  klass[i] of span i (in the order added):
+  // Dispatch order by workgroup (the launch's WgDesc list).  klass[i] of span i (in the order added):
   //   kFirst  -- ahead of everything (the first hop's GRU cells: later hops poll what they publish);
   //   kDense  -- long, MFMA-dense workgroups, kept in the order added (longest first);
   //   kLight  -- short workgroups that are mostly memory round trips: dealt among the dense ones in proportion to estimated time
@@ -407,7 +340,6 @@ struct TableBuilder {
     sp.first = t.total; sp.gx = (int)grid.x > 0 ? (int)grid.x : 1; sp.type = I; sp.arg = used[I]++ | (stage << 16);
     n_wg[t.n_spans] = (int)(grid.x * grid.y);
     cost[t.n_spans] = wg_cost * n_wg[t.n_spans];
-    spread[t.n_spans] = spread_over_xcds;
     ++t.n_spans;
     t.total += (int)(grid.x * grid.y);
     flops += info.flops; bytes += info.bytes;
