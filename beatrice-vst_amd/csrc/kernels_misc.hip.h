@@ -309,14 +309,42 @@ __device__ __forceinline__ void globalize(FftArgs& a) {
   a.d_in = as_global(a.d_in); globalize(a.audio); globalize(a.spec); a.window = as_global(a.window); a.twiddle = as_global(a.twiddle);
   a.hop = as_global(a.hop);
 }
-constexpr int kFftLdsFloats = 3 * B_FFT_N;
+// Round 5: the same butterflies (MODEL_SPEC 4.2.1, operation for operation, the same twiddle table: bit-identical), scheduled as FIVE
+// passes of two stages each instead of ten passes through LDS.  A thread owns the four elements {base + m h1} of a pass (h1 = 4^p)
+// and runs the stage-h1 and the stage-2 h1 butterflies on them in registers.  Pass 0 takes its elements straight from the audio
+// (element 4 t + m of the bit-reversed order is the sample at rev8(t) + 256 rev2(m)): the bit-reversal scatter into LDS -- whose 1 024
+// stores landed on one bank in groups of 32, half of the tick launch's LDS bank conflicts, profiles/r05_tick_inst_by_body.txt -- is
+// gone; pass 4 leaves bins t and t + 256 in registers for the log-power.  Four LDS exchanges and barriers instead of eleven; LDS
+// indices are padded by 4 floats per 16 (fft_at): the strided accesses of passes 1 and 2 then spread over all banks.
+constexpr int kFftArr = B_FFT_N + 4 * (B_FFT_N / 16);   // one padded array of 1 024 floats
+constexpr int kFftLdsFloats = 2 * kFftArr + B_FFT_N;
+__device__ __forceinline__ int fft_at(const int i) { return i + 4 * (i >> 4); }
+__device__ __forceinline__ void fft_bfly(float& ar, float& ai, float& br, float& bi, const float wr, const float wi) {
+  const float tr = bsp::fma(-wi, bi, wr * br);
+  const float ti = bsp::fma(wi, br, wr * bi);
+  const float xr = ar, xi = ai;
+  ar = xr + tr; ai = xi + ti;
+  br = xr - tr; bi = xi - ti;
+}
+// stages h1 and 2 h1 on the four elements i_m = base + m h1 (j1 = base & (h1 - 1)); tw = the table (cos, -sin)(2 pi k / 1024) in LDS
+__device__ __forceinline__ void fft_two_stages(float (&xr)[4], float (&xi)[4], const float* __restrict__ tw, const int h1, const int low) {
+  const int s1 = (B_FFT_N / 2) / h1;               // twiddle step of stage h1: N / (2 h1)
+  const float w1r = tw[2 * (low * s1)], w1i = tw[2 * (low * s1) + 1];
+  fft_bfly(xr[0], xi[0], xr[1], xi[1], w1r, w1i);
+  fft_bfly(xr[2], xi[2], xr[3], xi[3], w1r, w1i);
+  const int s2 = s1 >> 1;                          // stage 2 h1: j = low (elements 0, 2) and low + h1 (elements 1, 3)
+  const float war = tw[2 * (low * s2)], wai = tw[2 * (low * s2) + 1];
+  const float wbr = tw[2 * ((low + h1) * s2)], wbi = tw[2 * ((low + h1) * s2) + 1];
+  fft_bfly(xr[0], xi[0], xr[2], xi[2], war, wai);
+  fft_bfly(xr[1], xi[1], xr[3], xi[3], wbr, wbi);
+}
 // PACK streams per workgroup, 256 threads each (see phone_f1_body_t); the twiddle table is shared
 template <int PACK, bool RAG = false>
 __device__ __forceinline__ void pitch_fft_body_t(const FftArgs& a, const int bx, const int hh, float* __restrict__ lds, const int n_streams) {
   const int tid = threadIdx.x & 255, part = PACK > 1 ? (int)(threadIdx.x >> 8) : 0;
-  float* re = lds + 2 * B_FFT_N * part;
-  float* im = re + B_FFT_N;
-  float* tw = lds + 2 * B_FFT_N * PACK;
+  float* re = lds + 2 * kFftArr * part;
+  float* im = re + kFftArr;
+  float* tw = lds + 2 * kFftArr * PACK;
   const int b = bx * PACK + part;
   const bool in_batch = PACK == 1 || b < n_streams;
   const int step = stepc::step(a.hop), H = a.H;
@@ -331,47 +359,50 @@ __device__ __forceinline__ void pitch_fft_body_t(const FftArgs& a, const int bx,
   const int pos = live ? ring_pos(audio, hop) : 0;
   const float* src = d_in + (size_t)b * H * B_IN_HOP;
   for (int i = threadIdx.x; i < B_FFT_N; i += 256 * PACK) tw[i] = twiddle[i];
-  if (live)
-    for (int i = tid; i < B_FFT_N; i += 256) {
-      const int si = hh * B_IN_HOP + i - B_PITCH_HIST;  // sample index relative to the start of the step
-      float s;
-      if (si < 0) {
-        s = *ring_frame(audio, b, pos, si);
-      } else {
-        s = src[si];
-        if (i >= B_PITCH_HIST) *ring_frame(audio, b, pos, si) = s;  // each hop block appends its own 160 samples
-      }
-      const int rev = (int)(__brev((unsigned)i) >> 22);
-      re[rev] = s * window[i];
-      im[rev] = 0.0f;
-    }
-  __syncthreads();
-  for (int half = 1; half < B_FFT_N; half <<= 1) {
-    const int step = B_FFT_N / (2 * half);
-    if (live) {
+  float xr[4] = {0.f, 0.f, 0.f, 0.f}, xi[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    // the frame: 864 samples of history + this hop's 160; sample index relative to the start of the step: negative = the ring,
+    // otherwise the step's input (earlier hops of the step included).  Element m of this thread = position r8 + 256 rev2(m).
+    const int r8 = (int)(__brev((unsigned)tid) >> 24);
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int bf = tid + u * 256;
-        const int j = bf & (half - 1);
-        const int ia = ((bf - j) << 1) + j, ib = ia + half;
-        const float wr = tw[2 * (j * step)], wi = tw[2 * (j * step) + 1];
-        const float br = re[ib], bi = im[ib];
-        const float tr = bsp::fma(-wi, bi, wr * br);
-        const float ti = bsp::fma(wi, br, wr * bi);
-        const float ar = re[ia], ai = im[ia];
-        re[ia] = ar + tr; im[ia] = ai + ti;
-        re[ib] = ar - tr; im[ib] = ai - ti;
+    for (int m = 0; m < 4; ++m) {
+      const int i = r8 + 256 * ((m >> 1) | ((m & 1) << 1));
+      const int si = hh * B_IN_HOP + i - B_PITCH_HIST;
+      const float s = si < 0 ? *ring_frame(audio, b, pos, si) : src[si];
+      xr[m] = s * window[i];
+    }
+    if (tid < B_IN_HOP) *ring_frame(audio, b, pos, hh * B_IN_HOP + tid) = src[hh * B_IN_HOP + tid];   // each hop block appends its own 160 samples
+  }
+  __syncthreads();   // (the twiddles are in LDS)
+  if (live) {
+    fft_two_stages(xr, xi, tw, 1, 0);
+    // elements 4 t .. 4 t + 3: one 16-byte store per array (fft_at keeps groups of 16 together)
+    *reinterpret_cast<float4*>(re + fft_at(4 * tid)) = make_float4(xr[0], xr[1], xr[2], xr[3]);
+    *reinterpret_cast<float4*>(im + fft_at(4 * tid)) = make_float4(xi[0], xi[1], xi[2], xi[3]);
+  }
+#pragma unroll
+  for (int p = 1; p < 5; ++p) {
+    constexpr int kH1[5] = {1, 4, 16, 64, 256};
+    const int h1 = kH1[p];
+    __syncthreads();   // (the pass before has written; inside a pass a thread reads and writes its own four elements only)
+    if (live) {
+      const int low = tid & (h1 - 1), base = ((tid >> (2 * p)) << (2 * p + 2)) + low;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { xr[m] = re[fft_at(base + m * h1)]; xi[m] = im[fft_at(base + m * h1)]; }
+      fft_two_stages(xr, xi, tw, h1, low);
+      if (p < 4) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { re[fft_at(base + m * h1)] = xr[m]; im[fft_at(base + m * h1)] = xi[m]; }
       }
     }
-    __syncthreads();
   }
   if (!live) return;
+  // after the last pass this thread holds bins t + 256 m; the feature wants bins 0 .. 511
   float* o = ring_frame(spec, b, ring_pos(spec, hop), hh);
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    const int k = tid + u * 256;
-    const float pw = bsp::fma(im[k], im[k], re[k] * re[k]);
-    o[k] = 0.5f * bsp::log(pw + 1e-5f);
+    const float pw = bsp::fma(xi[u], xi[u], xr[u] * xr[u]);
+    o[tid + u * 256] = 0.5f * bsp::log(pw + 1e-5f);
   }
 }
 __device__ __forceinline__ void pitch_fft_body(const FftArgs& a, const int b, const int hh, float* __restrict__ lds) {
@@ -392,7 +423,7 @@ __device__ __forceinline__ void globalize(FftArgs2& a) { globalize(a.a); }
 struct FftOp2 {  // two streams per 512-thread workgroup (H = 1): grid ((n_streams + 1) / 2, 1)
   using Args = FftArgs2;
   static constexpr int NTHR = 512;
-  static constexpr int LDS_FLOATS = 5 * B_FFT_N;
+  static constexpr int LDS_FLOATS = 4 * kFftArr + B_FFT_N;
   __device__ static __forceinline__ void run(const Args& a, int bx, int by, float* lds) { pitch_fft_body_t<2>(a.a, bx, by, lds, a.n_streams); }
   template <bool RAG> __device__ static __forceinline__ void run_t(const Args& a, int bx, int by, float* lds) { pitch_fft_body_t<2, RAG>(a.a, bx, by, lds, a.n_streams); }
 };

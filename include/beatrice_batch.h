@@ -276,16 +276,17 @@ void* BeatriceBatch_GetWaveStream(const BeatriceBatch* b);
  * ticks as the only synchronisation.  Same samples, bit for bit; a step's output lands
  * in its resident-I/O slot BeatriceBatch_TickStages() - 1 ticks after its input was fed, and BeatriceBatch_Synchronize
  * drains the pipeline (that many ticks without new input).  Settings changed between steps apply to exactly the step
- * they precede.  Requirements (-1 otherwise): one or two hops per step, at most 4096 streams (tested to 600, measured to 4096), resident I/O bound with more slots
- * than stages, and the caller must leave a step's INPUT slot untouched for BeatriceBatch_TickStages() further steps.
+ * they precede.  Requirements (-1 otherwise): one, two or four hops per step, at most 4096 streams (tested to 4096), resident I/O bound with more slots
+ * than stages and at most 4096 of them, and the caller must leave a step's INPUT slot untouched for BeatriceBatch_TickStages() further steps.
  * The host-buffer, 48 kHz and profiling entry points return -1 while it is on.
- * Two hops per step (a batch from BeatriceBatch_CreateBlock(..., 2); slots of [B][320] in, [B][480] out): every stage works on
- * both hops of its step in one launch -- the fixed cost of a launch is paid once per two hops (256 streams: 3.84 -> 4.20 M
- * frames/s; 64 speakers on 256 streams: 2.30 -> 3.01 M), same samples as one hop per step, settings still apply per step and
- * key/value installs per hop.  The 48 kHz wrapper around the ticks takes such a batch too (BeatriceBatch_BindResidentIO48k: a slot
- * then holds two consecutive blocks per stream, [B][2][channels][480], and a call converts both: 64 stereo streams 1.41 -> 2.27 M
- * frames/s), and so does host streaming (BeatriceBatch_StreamFrames then takes [B][320] and returns [B][480]: 3.30 -> 3.52 M frames/s
- * from and to host memory); the silent-block rule and BindResidentBlocks need one hop per step. */
+ * H = 2 or 4 hops per step (a batch from BeatriceBatch_CreateBlock(..., H); slots of [B][H * 160] in, [B][H * 240] out): every stage
+ * works on all hops of its step in one launch -- the fixed cost of a launch is paid once per H hops, and a short run has fewer
+ * partly filled launches per hop (256 streams, 20 steps + drain: 2.72 / 3.44 / 3.9 M frames/s at 1 / 2 / 4 hops per step; steady
+ * 3.8 / 4.35 / 4.38 M; 64 speakers on 256 streams: 2.30 / 3.01 / 3.45 M), same samples as one hop per step, settings still apply
+ * per step and key/value installs per hop.  The 48 kHz wrapper around the ticks takes such a batch too
+ * (BeatriceBatch_BindResidentIO48k: a slot then holds H consecutive blocks per stream, [B][H][channels][480], and a call converts
+ * them all: 64 stereo streams 1.41 / 2.32 / 2.9 M frames/s), and so does host streaming (BeatriceBatch_StreamFrames then takes
+ * [B][H * 160] and returns [B][H * 240]); the silent-block rule and BindResidentBlocks need one hop per step. */
 int BeatriceBatch_EnableTickPipeline(BeatriceBatch* b, int enable);
 int BeatriceBatch_TickStages(const BeatriceBatch* b);
 /* Host streaming: tick pipelining for callers whose audio lives in HOST memory (offline conversion of files, a network

@@ -223,3 +223,39 @@ def test_device_blob_sharing_roundtrip(bv, product, model_dir):
     assert np.abs(outs[0]).max() > 0.01
     assert np.array_equal(outs[0], outs[1]), "objects filled device-to-device differ from file-loaded ones"
     assert np.array_equal(o2[0], o2[1]) and np.array_equal(o2[0], outs[0])
+
+
+def test_set_target_speakers_equals_one_call_per_stream(bv, product, model_dir):
+    """BeatriceBatch_SetTargetSpeakers(b, n, streams, speakers) = n calls of BeatriceBatch_SetTargetSpeaker (key/value blocks follow one
+    per hop either way, processor_core_2.cc:431-466); an out-of-range pair refuses the whole call and changes nothing."""
+    import ctypes as C
+    B, hops = 12, 14
+    x = np.stack([bv.synth_audio(160 * hops, seed=6100 + s) for s in range(B)]).reshape(B, hops, 160)
+    moves = {3: [(0, 2), (5, 1), (11, 0)], 4: [(5, 2)], 9: [(s, (s + 1) % 3) for s in range(B)]}
+    m = bv.Models(bv.bind_batch(product), model_dir)
+    outs = []
+    for batched in (False, True):
+        batch = bv.Batch(m, B)
+        a, h = batch.a, batch.h
+        for s in range(B):
+            a.BeatriceBatch_SetTargetSpeaker(h, s, s % 3)
+            a.BeatriceBatch_SetVQNumNeighbors(h, s, 1 + s % 2)
+        a.BeatriceBatch_FlushSpeaker(h, -1)
+        got = []
+        for k in range(hops):
+            mv = moves.get(k, [])
+            if mv and batched:
+                n = len(mv)
+                st, sp = (C.c_int * n)(*[p[0] for p in mv]), (C.c_int * n)(*[p[1] for p in mv])
+                bad_st = (C.c_int * n)(*([p[0] for p in mv[:-1]] + [B]))          # last stream out of range: nothing may change
+                assert a.BeatriceBatch_SetTargetSpeakers(h, n, bad_st, sp) == -1
+                assert a.BeatriceBatch_SetTargetSpeakers(h, n, st, sp) == 0
+            else:
+                for s, spk in mv:
+                    assert a.BeatriceBatch_SetTargetSpeaker(h, s, spk) == 0
+            got.append(batch.convert(np.ascontiguousarray(x[:, k])).copy())
+        batch.close()
+        outs.append(np.stack(got))
+    m.close()
+    assert np.abs(outs[0]).max() > 0.05
+    assert np.array_equal(outs[0], outs[1])
