@@ -120,11 +120,16 @@ static void capture_hop(HopGraph& g, const void* blob, int variant, hipStream_t 
 // Runs `enqueue` through the context's captured graph; captures it first when there is none for this parameter blob /
 // variant.  The key is the DEVICE BLOB the captured kernels read (not the model object's address): Read*Parameters on the
 // same object frees and re-allocates the blob, and a graph holding the old pointers must not be replayed.
-// BEATRICE_HIP_NO_HOP_GRAPH=1: plain launches (measurements).
+// Round 5: PLAIN LAUNCHES are the default.  With each module's convolutions in one team launch a call is 4-6 kernels + 2-3 copies,
+// and replaying them as a hipGraph measures ~10 us per hop SLOWER than enqueuing them (p50 285 vs 275 us over three A/B rounds,
+// profiles/r05_notes.md section 10; with 49 kernels per hop, rounds 1-3, the graph won).  BEATRICE_HIP_HOP_GRAPH=1: the graphs.
+static bool hop_graphs() {
+  static const bool on = std::getenv("BEATRICE_HIP_HOP_GRAPH") != nullptr && std::getenv("BEATRICE_HIP_NO_HOP_GRAPH") == nullptr;
+  return on;
+}
 template <class F>
 static bool run_hop(HopGraph& g, const void* blob, int variant, hipStream_t s, F enqueue) {
-  static const bool eager = std::getenv("BEATRICE_HIP_NO_HOP_GRAPH") != nullptr;
-  if (eager || hop_immediate()) { enqueue(); return hip_ok(hipGetLastError(), "hop launch"); }
+  if (!hop_graphs() || hop_immediate()) { enqueue(); return hip_ok(hipGetLastError(), "hop launch"); }
   if (g.blob != blob || g.variant != variant || (!g.exec && !g.eager)) capture_hop(g, blob, variant, s, enqueue);
   if (!g.exec) { enqueue(); return hip_ok(hipGetLastError(), "hop launch"); }
   BHIP_TRY(hipGraphLaunch(g.exec, s));
@@ -291,7 +296,7 @@ void Beatrice20rc0_ExtractPhone1(const Beatrice20rc0_PhoneExtractor* m, const fl
   // Both variants (k-NN launch present / absent) are captured at the first hop with a given parameter blob, so that a
   // later SetVQNumNeighbors toggle on the audio thread finds its graph ready instead of spending 1-2 ms on a capture.
   HopGraph& other = ctx->hop_graph[variant ^ 1];
-  if (other.blob != m->blob.d && !hop_immediate() && std::getenv("BEATRICE_HIP_NO_HOP_GRAPH") == nullptr) {
+  if (other.blob != m->blob.d && !hop_immediate() && hop_graphs()) {
     const bool keep = ctx->st.skip_vq;
     ctx->st.skip_vq = !keep;
     capture_hop(other, m->blob.d, variant ^ 1, ctx->stream, enqueue);

@@ -129,3 +129,38 @@ def test_end_to_end_protocol(bv, oracle, product, model_dir):
     d = _maxabs(res["o"], res["p"])
     print("end-to-end max-abs", d, "bit-identical" if np.array_equal(res["o"], res["p"]) else "")
     assert d <= TOL
+
+
+def test_hop_graph_variant_matches_oracle(model_dir):
+    """The per-hop calls enqueue plain launches by default (round 5: ~10 us per hop faster than replaying them as a hipGraph now that
+    a call is a handful of kernels); BEATRICE_HIP_HOP_GRAPH=1 replays captured graphs (read once per process: hence a subprocess).
+    Both must give the oracle's samples, with a k-NN toggle in mid-stream (the graph variant captures both forms up front)."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import importlib.util, os, sys\n"
+        "import numpy as np\n"
+        "repo, model_dir = sys.argv[1], sys.argv[2]\n"
+        "spec = importlib.util.spec_from_file_location('bv', os.path.join(repo, 'beatrice-vst_amd', '__init__.py'))\n"
+        "bv = importlib.util.module_from_spec(spec); sys.modules['bv'] = bv; spec.loader.exec_module(bv)\n"
+        "x = bv.synth_audio(160 * 30, seed=21)\n"
+        "outs = {}\n"
+        "for name, abi in (('o', bv.Abi(os.path.join(repo, 'oracle', 'libbeatrice_oracle.so'))), ('p', bv.load_product())):\n"
+        "    m = bv.Models(abi, model_dir)\n"
+        "    s = bv.Stream1(m, speaker=1, vq_k=0)\n"
+        "    got = []\n"
+        "    for i in range(30):\n"
+        "        if i == 11: abi.SetVQNumNeighbors(s.pc, 3)\n"
+        "        if i == 20: abi.SetVQNumNeighbors(s.pc, 0)\n"
+        "        got.append(s.hop(x[i * 160:(i + 1) * 160]))\n"
+        "    s.close(); m.close()\n"
+        "    outs[name] = np.array(got)\n"
+        "assert np.abs(outs['p']).max() > 1e-3\n"
+        "print('max-abs', float(np.abs(outs['o'] - outs['p']).max()))\n"
+        "assert np.array_equal(outs['o'], outs['p'])\n")
+    for mode in ({}, {"BEATRICE_HIP_HOP_GRAPH": "1"}):
+        env = dict(os.environ, **mode)
+        r = subprocess.run([sys.executable, "-c", code, repo, model_dir], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, (mode, r.stdout[-500:], r.stderr[-1500:])
