@@ -383,8 +383,12 @@ void Beatrice20rc0_EstimatePitch1(const Beatrice20rc0_PitchEstimator* m, const f
   bool ok = run_hop(ctx->hop_graph, m->blob.d, 0, ctx->stream, [&] {
     (void)hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * (B_IN_HOP + kMailboxWords), hipMemcpyHostToDevice, ctx->stream);
     pitch_forward(m->w, ctx->st, ctx->stream);
-    (void)hipMemcpyAsync(h_feat, ctx->st.d_feat, sizeof(float) * 4, hipMemcpyDeviceToHost, ctx->stream);
-    (void)hipMemcpyAsync(h_q, ctx->st.d_q_raw, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (ctx->st.q_raw_in_feat) {   // (h_q = h_feat + 4, d_q_raw = d_feat + 4: one copy for the five result words)
+      (void)hipMemcpyAsync(h_feat, ctx->st.d_feat, sizeof(float) * 5, hipMemcpyDeviceToHost, ctx->stream);
+    } else {
+      (void)hipMemcpyAsync(h_feat, ctx->st.d_feat, sizeof(float) * 4, hipMemcpyDeviceToHost, ctx->stream);
+      (void)hipMemcpyAsync(h_q, ctx->st.d_q_raw, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    }
   });
   ok = wait_stream(ctx->stream) && ok;
   if (team_timed_out(ctx->st)) {

@@ -171,6 +171,7 @@ struct PitchState {
   int* hop_in = nullptr;      // counter the first kernel (FFT) reads
   bool advance_hop = true;    // this module's forward ends with the counter increment
   int bins = B_PITCH_BINS;    // pitch classes (384: legacy generations)
+  bool q_raw_in_feat = false;   // d_q_raw = d_feat + 4 (create())
   unsigned long long* d_team_xb = nullptr;   // (see PhoneState)
   int* d_team_dead = nullptr;   // pinned host word: set by a team launch that gave a wait up (the call then returns zeros)
   size_t team_granules = 0;

@@ -207,8 +207,12 @@ void estimate_pitch(const LPitchModel* m, const float* input, int* out_q, float*
   bool ok = run_graph(ctx->graph, m->blob.d, ctx->stream, [&] {
     (void)hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * (B_IN_HOP + kMailboxWords), hipMemcpyHostToDevice, ctx->stream);
     pitch_forward(m->w, ctx->st, ctx->stream);
-    (void)hipMemcpyAsync(h_feat, ctx->st.d_feat, sizeof(float) * 4, hipMemcpyDeviceToHost, ctx->stream);
-    (void)hipMemcpyAsync(h_q, ctx->st.d_q_raw, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (ctx->st.q_raw_in_feat) {
+      (void)hipMemcpyAsync(h_feat, ctx->st.d_feat, sizeof(float) * 5, hipMemcpyDeviceToHost, ctx->stream);
+    } else {
+      (void)hipMemcpyAsync(h_feat, ctx->st.d_feat, sizeof(float) * 4, hipMemcpyDeviceToHost, ctx->stream);
+      (void)hipMemcpyAsync(h_q, ctx->st.d_q_raw, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    }
   });
   ok = wait_stream(ctx->stream) && ok;
   if (team_timed_out(ctx->st)) { ok = false; team_recover(ctx->st, ctx->stream); (void)hipMemsetAsync(ctx->st.d_prev_q, 0, sizeof(int), ctx->stream); ctx->graph.drop(); }

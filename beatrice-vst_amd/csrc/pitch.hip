@@ -31,13 +31,18 @@ bool PitchState::create(int B_, int H_, float* shared_in, bool with_params, bool
     BHIP_TRY(hipMalloc(reinterpret_cast<void**>(p), sizeof(int) * B));
     BHIP_TRY(hipMemset(*p, 0, sizeof(int) * B));
   }
+  // (one stream, one hop per call -- the 1-stream ABI: the raw bin sits right behind the four features, so that EstimatePitch1 fetches
+  //  its five result words with ONE copy command instead of two)
+  q_raw_in_feat = B == 1 && H == 1 && q_slots == 1;
+  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_feat), sizeof(float) * (4 * B * H * q_slots + 4)));
+  BHIP_TRY(hipMemset(d_feat, 0, sizeof(float) * (4 * B * H * q_slots + 4)));
+  if (q_raw_in_feat) d_q_raw = reinterpret_cast<int*>(d_feat + 4);
   int** per_row[] = {&d_q_raw, &d_q};
   for (int** p : per_row) {
+    if (p == &d_q_raw && q_raw_in_feat) continue;
     BHIP_TRY(hipMalloc(reinterpret_cast<void**>(p), sizeof(int) * B * H * q_slots));
     BHIP_TRY(hipMemset(*p, 0, sizeof(int) * B * H * q_slots));
   }
-  BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_feat), sizeof(float) * 4 * B * H * q_slots));
-  BHIP_TRY(hipMemset(d_feat, 0, sizeof(float) * 4 * B * H * q_slots));
   std::vector<int> lo(B, 1), hi(B, bins - 1);
   BHIP_TRY(hipMemcpy(d_min_q, lo.data(), sizeof(int) * B, hipMemcpyHostToDevice));
   BHIP_TRY(hipMemcpy(d_max_q, hi.data(), sizeof(int) * B, hipMemcpyHostToDevice));
@@ -66,7 +71,7 @@ bool PitchState::create(int B_, int H_, float* shared_in, bool with_params, bool
 void PitchState::destroy() {
   arena.release();
   if (owns_in && d_in) (void)hipFree(d_in);
-  void* ptrs[] = {d_min_q, d_max_q, d_prev_q, d_q_raw, d_q, d_feat, d_params, d_hop, d_team_xb};
+  void* ptrs[] = {d_min_q, d_max_q, d_prev_q, q_raw_in_feat ? nullptr : d_q_raw, d_q, d_feat, d_params, d_hop, d_team_xb};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (d_team_dead) (void)hipHostFree(d_team_dead);
   d_team_xb = nullptr; d_team_dead = nullptr;
