@@ -199,7 +199,7 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
         }
       }
       desc = tb->interleave(klass, order_reserve);
-    } else if (halves_mode != 0) {   // the bodies with the weights, each on one half of the chip (TableBuilder::two_halves)
+    } else if (halves_mode != 0 && !sparse) {   // the bodies with the weights, each on one half of the chip (TableBuilder::two_halves); the sparse table only ever runs partly filled ticks
       bool pinned[fuse::kMaxSpans];
       int group[fuse::kMaxSpans];
       for (int i = 0; i < tb->t.n_spans; ++i) {

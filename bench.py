@@ -648,6 +648,10 @@ def main():
                        "placement": a.placement if a.config == 3 else "n/a"},
             "ms_per_hop": round(1e3 * elapsed / (a.steps * H), 4),   # (of all streams: ms_per_step / hops_per_step)
             "x_realtime_per_stream": round(a.steps * H / elapsed / 100.0, 2), "output_rms": round(out_rms, 4),
+            # what "N concurrent streams" means in this mode: a throughput (offline / faster-than-real-time) pipeline -- a step's samples
+            # appear n_stages - 1 launches after its input, with n_stages steps of H hops of every stream in flight
+            "in_flight": ({"steps": int(product.BeatriceBatch_TickStages(batch.h)), "audio_ms_per_stream": int(product.BeatriceBatch_TickStages(batch.h)) * H * 10,
+                           "wall_ms": round(int(product.BeatriceBatch_TickStages(batch.h)) * 1e3 * elapsed / a.steps, 3)} if (tick or tick48) else None),
             "host_enqueue_ms_per_step": round(1e3 * enqueue_s / a.steps, 4),   # (includes waiting for the device once the host is 16 settings snapshots ahead)
             "host_work_ms_per_step": round(1e3 * host_work_s, 4),               # (12 steps into a drained pipeline: the host's own work)
             "per_rank_frames_per_s": [round(B * a.steps * H / e, 1) for e in per_rank_elapsed],   # (a straggler shows; `value` uses the MAX-reduced time)
