@@ -881,7 +881,7 @@ void BeatriceBatch_Destroy(BeatriceBatch* b) {
   for (hipEvent_t e : b->rw.ev) if (e) (void)hipEventDestroy(e);
   if (b->h_wrap_io) (void)hipHostFree(b->h_wrap_io);
   b->wrap_gains.release();
-  { void* tk[] = {b->tk.d_table, b->tk.d_table_sparse, b->tk.d_snap, b->tk.d_trace, b->tk.d_link_q, b->tk.d_link_p, b->tk.d_desc, b->tk.d_desc_sparse, b->tk.d_desc_plain, b->tk.d_ring_table, b->tk.d_shift}; for (void* p : tk) if (p) (void)hipFree(p); }
+  { void* tk[] = {b->tk.d_table, b->tk.d_table_sparse, b->tk.d_snap, b->tk.d_trace, b->tk.d_link_q, b->tk.d_link_p, b->tk.d_desc, b->tk.d_desc_sparse, b->tk.d_desc_plain, b->tk.d_desc_ranges, b->tk.d_ring_table, b->tk.d_shift}; for (void* p : tk) if (p) (void)hipFree(p); }
   if (b->tk.h_link_dead) (void)hipHostFree(b->tk.h_link_dead);
   if (b->tk.h_stage) (void)hipHostFree(b->tk.h_stage);
   for (hipEvent_t e : b->tk.stage_ev) if (e) (void)hipEventDestroy(e);

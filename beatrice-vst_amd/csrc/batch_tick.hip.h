@@ -232,6 +232,22 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
       const std::vector<fuse::WgDesc> plain = tb->in_span_order();
       if (!upload(plain, k.d_desc_plain, k.desc_plain_cap)) return false;
       k.table_total_plain = (int)plain.size();
+      // the fill / drain shapes without the empty stages' workgroups (tick::State::d_desc_ranges)
+      for (auto& row : k.range_n) for (int& n : row) n = 0;
+      const int n_stages = pl.count();
+      if (plain.size() <= 16384 && n_stages <= kMaxStages) {
+        std::vector<fuse::WgDesc> all;
+        for (int shape = 0; shape < 2; ++shape)
+          for (int s0 = 0; s0 < n_stages; ++s0) {
+            k.range_off[shape][s0] = all.size();
+            for (const fuse::WgDesc& d : plain) {
+              const int stage = (d.arg >> 16) & 0xff;
+              if (shape == 0 ? stage <= s0 : stage >= s0) all.push_back(d);
+            }
+            k.range_n[shape][s0] = (int)(all.size() - k.range_off[shape][s0]);
+          }
+        if (!upload(all, k.d_desc_ranges, k.desc_ranges_cap)) return false;
+      }
     }
     tb->t.total = (int)desc.size();   // (two_halves may add filler indices)
     if (!upload(desc, sparse ? k.d_desc_sparse : k.d_desc, sparse ? k.desc_sparse_cap : k.desc_cap)) return false;
@@ -277,9 +293,22 @@ static void tick_launch(BeatriceBatch* b, const bool sparse, const bool full, hi
   tick::State& k = b->tk;
   const void* t = sparse ? k.d_table_sparse : k.d_table;
   // full = every stage has a step: the order that confines the bodies with the weights to halves of the chip; a partly filled tick
-  // (fill, drain) runs the same table in plain span order
+  // (fill, drain) runs the same table in plain span order -- without the workgroups of its empty stages where the occupied stages
+  // are 0 .. k or k .. last (tick::State::d_desc_ranges)
   const fuse::WgDesc* desc = sparse ? k.d_desc_sparse : (full ? k.d_desc : k.d_desc_plain);
-  const int total = sparse ? k.table_sparse_total : (full ? k.table_total : k.table_total_plain);
+  int total = sparse ? k.table_sparse_total : (full ? k.table_total : k.table_total_plain);
+  static const bool no_ranges = std::getenv("BEATRICE_HIP_TICK_NO_RANGES") != nullptr;   // A/B switch for measurements
+  if (!sparse && !full && !no_ranges && k.d_desc_ranges != nullptr) {
+    const int n_stages = k.plan.count();
+    int lo = n_stages, hi = -1, occupied = 0;
+    for (int s = 0; s < n_stages; ++s) if (pairs.hop[s] >= 0) { lo = s < lo ? s : lo; hi = s; ++occupied; }
+    if (occupied > 0 && occupied == hi - lo + 1) {
+      const int shape = lo == 0 ? 0 : (hi == n_stages - 1 ? 1 : -1);
+      const int at = shape == 0 ? hi : lo;
+      if (shape >= 0 && k.range_n[shape][at] > 0) { desc = k.d_desc_ranges + k.range_off[shape][at]; total = k.range_n[shape][at]; }
+    }
+  }
+  if (total <= 0) return;
   if (b->H == 1) fuse::launch_table_w<4>(static_cast<const tick::Ops<1>::Tab*>(t), desc, total, st, pairs, k.ragged);   // (ragged: the second instance of the launch, once a stream has sat a step out)
   else if (b->H == 2) fuse::launch_table_w<4, false>(static_cast<const tick::Ops<2>::Tab*>(t), desc, total, st, pairs, false);   // (no ragged steps at several hops per step: EnableSilentBlockRule refuses)
   else fuse::launch_table_w<4, false>(static_cast<const tick::Ops<4>::Tab*>(t), desc, total, st, pairs, false);

@@ -199,6 +199,14 @@ struct State {
   fuse::WgDesc* d_desc_plain = nullptr;
   size_t desc_plain_cap = 0;
   int table_total_plain = 0;
+  // ... and the same order with the workgroups of EMPTY stages left out, for the two shapes a fill and a drain go through: stages
+  // 0 .. k occupied (range_off[0][k]) and stages k .. last occupied (range_off[1][k]).  A partly filled launch otherwise dispatches
+  // every stage's workgroups only for most of them to leave at once -- thousands of slot turns per launch in a run of few steps.
+  // One buffer; n = 0: not built (very large batches) or the tick's occupied stages are no such range -> the plain list.
+  fuse::WgDesc* d_desc_ranges = nullptr;
+  size_t desc_ranges_cap = 0;
+  size_t range_off[2][kMaxStages] = {};
+  int range_n[2][kMaxStages] = {};
   unsigned long long* d_trace = nullptr;  // BEATRICE_HIP_TICK_TRACE=<file>: per-workgroup timeline of the last full tick
   bool table_dirty = true;
   unsigned char* d_snap = nullptr;  // [kRing][snap_bytes] settings snapshots
