@@ -268,11 +268,17 @@ struct BeatriceBatch {
     int channels = 0, n = 0, n_slots = 0, io_slots = 0, delay = 0, ring = 0;
     const float* d_in = nullptr;   // [n_slots][B][channels][n]
     float* d_out = nullptr;        // [n_slots][B][channels][n]
-    float *d_in16 = nullptr, *d_out24 = nullptr;   // [io_slots][B][160], [io_slots][B][240]: the resident I/O of the ticks
+    float *d_in16 = nullptr, *d_out24 = nullptr;   // [io_slots][B][H][160], [io_slots][B][H][240]: the resident I/O of the ticks
     wrapn::GainSeg *d_gains = nullptr, *h_gains = nullptr;   // [ring][2][B]: a call's input | output segments, until its output half has run
     hipEvent_t* gain_ev = nullptr;                           // [ring]: upload of ring entry done
     long long calls = 0, t48 = 0;                            // calls so far; 48 kHz samples fed so far
-    struct Job { long long call, t0; wrapn::Dir dout; };
+    long long hops_fired = 0;                                // model hops the FIFO has fired; hop k = hop k % H of step k / H
+    int H = 1;                                               // hops per step of the batch
+    long long hops_fed() const { return hops_fired / H * H; }   // ... of which the hops of full steps are inside (or through) the ticks
+    struct Job {
+      long long call, t0; wrapn::Dir dout;
+      long long last_hop() const { return (t0 + dout.n_in - 1) / wrapn::kBlock - 1; }   // the newest model hop its samples come from (wrap_post_kernel)
+    };
     std::deque<Job> jobs;                                    // calls whose output half is still to run, oldest first
   } rb;
 };

@@ -555,7 +555,7 @@ bool rb_post(BeatriceBatch* b, const BeatriceBatch::ResidentBlocks::Job& j) {
   BeatriceBatch::ResidentBlocks& r = b->rb;
   const size_t nt = b->wrap.taps_down.size();
   const int slot = (int)(j.call % r.n_slots), ge = (int)(j.call % r.ring);
-  hipLaunchKernelGGL(wrapn::wrap_post_kernel, dim3(b->B), dim3(256), 0, b->stream, r.d_out24, r.io_slots, b->B, j.t0, b->d_wrap,
+  hipLaunchKernelGGL(wrapn::wrap_post_kernel, dim3(b->B), dim3(256), 0, b->stream, r.d_out24, r.io_slots, b->B, b->H, j.t0, b->d_wrap,
                      r.d_gains + (size_t)ge * 2 * b->B + b->B, b->d_wrap_taps + (j.dout.decimate ? 0 : nt), j.dout,
                      r.d_out + (size_t)slot * b->B * r.channels * r.n, r.channels);
   return hip_ok(hipGetLastError(), "wrapper output half");
@@ -586,7 +586,10 @@ bool tick_drain(BeatriceBatch* b) {
     hipLaunchKernelGGL(wrap48_tick_kernel, dim3(wa.n_post), dim3(256), 0, b->stream, wa);
     ok = hip_ok(hipGetLastError(), "wrap48 flush");
   }
-  while (ok && b->rb.on && !b->rb.jobs.empty()) {  // every model hop has left the pipeline: the output halves still owed, in order
+  // every model hop that entered the pipeline has left it: the output halves still owed, in order.  With several hops per step
+  // the hops of a step that is not full yet have not entered: the calls that end on them stay owed until later calls fill the
+  // step (BeatriceBatch_ResidentBlocksOwed)
+  while (ok && b->rb.on && !b->rb.jobs.empty() && b->rb.jobs.front().last_hop() < b->rb.hops_fed()) {
     ok = rb_post(b, b->rb.jobs.front());
     b->rb.jobs.pop_front();
   }

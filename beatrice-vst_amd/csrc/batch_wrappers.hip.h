@@ -198,7 +198,7 @@ namespace { constexpr int kInnerStride = wrapn::kMaxSamples + 64; }
 int BeatriceBatch_ConfigureWrapper(BeatriceBatch* b, double sample_rate) {
   const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
-  if (b->H != 1) return -1;
+  if (b->H != 1 && b->H != 2 && b->H != 4) return -1;   // (several hops per step: for BeatriceBatch_BindResidentBlocks, the wrapper around the ticks)
   if (!sync_all(b)) return -2;
   if (!b->wrap.configure(sample_rate)) return -1;  // rate <= 0, or a ratio whose filter history exceeds the state block
   const int B = b->B;
@@ -269,7 +269,7 @@ static bool wrap_chunk(BeatriceBatch* b, const float* d_in, float* d_out, int ch
   for (int at = 0; at < m;) {  // the exact-480 FIFO; a model hop every time it fills
     const int take = std::min(kBlock - w.fill, m - at);
     const int fires = w.fill + take == kBlock ? 1 : 0;
-    hipLaunchKernelGGL(wrap_fifo_kernel, dim3(B), dim3(256), 0, st, b->d_wrap_inner, kInnerStride, b->d_wrap, at, w.fill, take, fires, b->d_in);
+    hipLaunchKernelGGL(wrap_fifo_kernel, dim3(B), dim3(256), 0, st, b->d_wrap_inner, kInnerStride, b->d_wrap, at, w.fill, take, fires, b->d_in, B_IN_HOP);
     if (fires) {
       if (!step_device(b, nullptr, nullptr)) return false;
       hipLaunchKernelGGL(wrap_refill_kernel, dim3((B * kBlock + 255) / 256), dim3(256), 0, st, b->d_wrap, b->wave.d_out, B);
@@ -498,6 +498,16 @@ static void rb_release(BeatriceBatch* b) {
   if (r.gain_ev) { for (int i = 0; i < r.ring; ++i) if (r.gain_ev[i]) (void)hipEventDestroy(r.gain_ev[i]); delete[] r.gain_ev; }
   r = BeatriceBatch::ResidentBlocks{};
 }
+// Calls after which a call's output block is out: TickStages() - 1 ticks behind the tick that fed its newest hop (every call runs
+// at least one tick); with H hops per step that hop waits until up to H - 1 further hops have filled its step, each call bringing at
+// least m_lo inner samples (the two clocks make a call's count vary by one).  -1: blocks too short to bound it (H > 1 only).
+static int rb_delay(const BeatriceBatch* b, int n) {
+  const int stages = b->tk.plan.count();
+  if (b->H == 1) return stages - 1;
+  const long long m_lo = (long long)std::floor(n * 48000.0 / b->wrap.rate) - 1;
+  if (m_lo < 1) return -1;
+  return stages - 1 + (int)(((long long)(b->H - 1) * wrapn::kBlock + m_lo - 1) / m_lo);
+}
 static bool rb_step(BeatriceBatch* b) {
   using namespace wrapn;
   BeatriceBatch::ResidentBlocks& r = b->rb;
@@ -526,11 +536,16 @@ static bool rb_step(BeatriceBatch* b) {
   for (int at = 0; at < m;) {  // the 480-sample accumulation; a model hop every time it fills (the per-stream FIFO array holds it)
     const int take = std::min(kBlock - w.fill, m - at);
     const int fires = w.fill + take == kBlock ? 1 : 0;
+    // (the hop's place: hop hops_fired % H of the step that goes in next, slot io_host)
+    const int H = r.H, h = (int)(r.hops_fired % H);
     hipLaunchKernelGGL(wrap_fifo_kernel, dim3(B), dim3(256), 0, st, b->d_wrap_inner, kInnerStride, b->d_wrap, at, w.fill, take, fires,
-                       r.d_in16 + (size_t)b->io_host * B * B_IN_HOP);
+                       r.d_in16 + ((size_t)b->io_host * B * H + h) * B_IN_HOP, H * B_IN_HOP);
     if (fires) {
-      if (!tick_run(b, true)) return false;
-      ++ticks;
+      ++r.hops_fired;
+      if (h == H - 1) {   // the step is full: into the pipeline
+        if (!tick_run(b, true)) return false;
+        ++ticks;
+      }
       w.fill = 0;
     } else {
       w.fill += take;
@@ -542,7 +557,9 @@ static bool rb_step(BeatriceBatch* b) {
   r.t48 += m;
   r.calls = call + 1;
   bool ok = true;
-  while (ok && !r.jobs.empty() && r.jobs.front().call + r.delay <= call) {
+  // (after `delay` calls a call's hops are out -- at several hops per step under the bind-time bound on the calls that fill a step;
+  // calls that a drained point left owed come out here too, in order)
+  while (ok && !r.jobs.empty() && r.jobs.front().call + r.delay <= call && r.jobs.front().last_hop() < r.hops_fed()) {
     ok = rb_post(b, r.jobs.front());
     r.jobs.pop_front();
   }
@@ -567,22 +584,28 @@ int BeatriceBatch_BindResidentBlocks(BeatriceBatch* b, const float* d_in, float*
   }
   if (!d_in && !d_out) return 0;
   const int stages = b->tk.plan.count();
-  if (!b->wrap.ready || !d_in || !d_out || channels < 1 || channels > 2 || n < 1 || n > wrap_max_chunk(b) || n_slots < stages + 1 || b->H != 1 ||
+  const int H = b->H;
+  if (!b->wrap.ready || !d_in || !d_out || channels < 1 || channels > 2 || n < 1 || n > wrap_max_chunk(b) || (H != 1 && H != 2 && H != 4) ||
       b->io_slots > 0 || b->pipelined || b->tk.on || b->hs.on || b->r48.on || b->silent.on)
     return -1;
+  const int delay = rb_delay(b, n);
+  if (delay < 0 || n_slots < delay + 2) return -1;
   // binding restarts the resampler pair and the FIFO (their in-order form keeps processed samples in the FIFO, this one does not)
   if (BeatriceBatch_ConfigureWrapper(b, b->wrap.rate) != 0) return -2;
   // model hops a call can fire: ceil(inner samples / 480) + 1; a hop's resident output is read until `delay` calls after the
   // call in which the NEXT hop fired
+  // call in which the NEXT hop fired.  With H hops per step a slot holds a step: the hops of (delay + 2) calls are that many / H steps.
   const int m_max = (int)std::ceil(n * 48000.0 / b->wrap.rate) + 2, hops_per_call = (m_max + wrapn::kBlock - 1) / wrapn::kBlock + 1;
-  r.delay = stages - 1;
+  r.delay = delay;
   r.ring = r.delay + 3;
-  r.io_slots = std::max(stages + 1, (r.delay + 2) * hops_per_call + 2);
+  r.H = H;
+  r.io_slots = std::max(stages + 1, H == 1 ? (r.delay + 2) * hops_per_call + 2 : ((r.delay + 2) * hops_per_call + H - 1) / H + 3);
+  if (r.io_slots > stepc::kImmediateMaxSlot + 1) { r = BeatriceBatch::ResidentBlocks{}; return -1; }   // (tick mode's limit on resident slots)
   const int B = b->B;
-  bool ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_in16), sizeof(float) * r.io_slots * B * B_IN_HOP), "rb in16") &&
-            hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_out24), sizeof(float) * r.io_slots * B * B_OUT_HOP), "rb out24") &&
-            hip_ok(hipMemset(r.d_in16, 0, sizeof(float) * r.io_slots * B * B_IN_HOP), "rb zero") &&
-            hip_ok(hipMemset(r.d_out24, 0, sizeof(float) * r.io_slots * B * B_OUT_HOP), "rb zero") &&
+  bool ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_in16), sizeof(float) * r.io_slots * B * H * B_IN_HOP), "rb in16") &&
+            hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_out24), sizeof(float) * r.io_slots * B * H * B_OUT_HOP), "rb out24") &&
+            hip_ok(hipMemset(r.d_in16, 0, sizeof(float) * r.io_slots * B * H * B_IN_HOP), "rb zero") &&
+            hip_ok(hipMemset(r.d_out24, 0, sizeof(float) * r.io_slots * B * H * B_OUT_HOP), "rb zero") &&
             hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_gains), sizeof(wrapn::GainSeg) * r.ring * 2 * B), "rb gains") &&
             hip_ok(hipHostMalloc(reinterpret_cast<void**>(&r.h_gains), sizeof(wrapn::GainSeg) * r.ring * 2 * B, hipHostMallocDefault), "rb gains host");
   if (ok) {
@@ -600,6 +623,8 @@ int BeatriceBatch_BindResidentBlocks(BeatriceBatch* b, const float* d_in, float*
   return 0;
 }
 int BeatriceBatch_ResidentBlocksDelay(const BeatriceBatch* b) { return b && b->ok && b->rb.on ? b->rb.delay : -1; }
+int BeatriceBatch_ResidentBlocksDelayFor(const BeatriceBatch* b, int n) { return b && b->ok && b->wrap.ready && n >= 1 ? rb_delay(b, n) : -1; }
+int BeatriceBatch_ResidentBlocksOwed(const BeatriceBatch* b) { return b && b->ok && b->rb.on ? (int)b->rb.jobs.size() : -1; }
 int BeatriceBatch_ProcessBlocks(BeatriceBatch* b, const float* in, float* out, int channels, int n) {
   const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;

@@ -139,7 +139,8 @@ static __global__ __launch_bounds__(256) void wrap_out_kernel(const float* __res
 // model hop t / 480 - 1 (zeros before the first hop; reference resample.h:343-363, 380-394) -- so the block's inner samples
 // [t0, t0 + m) are gathered straight from the resident model outputs (hop k in slot k mod io_slots) once those hops have
 // left the pipeline, and go through the second resampling direction and the output gain exactly as in wrap_out_kernel.
-static __global__ __launch_bounds__(256) void wrap_post_kernel(const float* __restrict__ out24 /* [io_slots][B][240] */, const int io_slots, const int B,
+// H hops per step (a batch of BeatriceBatch_CreateBlock): hop k is hop k % H of step k / H, in slot (k / H) mod io_slots.
+static __global__ __launch_bounds__(256) void wrap_post_kernel(const float* __restrict__ out24 /* [io_slots][B][H][240] */, const int io_slots, const int B, const int H,
                                                                const long long t0, StreamState* __restrict__ st, const GainSeg* __restrict__ gain,
                                                                const float* __restrict__ taps, const Dir d, float* __restrict__ out, const int channels) {
   __shared__ float x[kMaxHist + kMaxSamples];
@@ -160,7 +161,7 @@ static __global__ __launch_bounds__(256) void wrap_post_kernel(const float* __re
     const long long t = t0 + i;
     const long long k = t / kBlock - 1;
     const int off = (int)(t % kBlock);
-    x[d.hist + i] = (k < 0 || (off & 1)) ? 0.0f : out24[((size_t)(k % io_slots) * B + b) * 240 + (off >> 1)];
+    x[d.hist + i] = (k < 0 || (off & 1)) ? 0.0f : out24[(((size_t)((k / H) % io_slots) * B + b) * H + (int)(k % H)) * 240 + (off >> 1)];
   }
   __syncthreads();
   float* dst = out + (size_t)b * channels * n;
@@ -176,9 +177,10 @@ static __global__ __launch_bounds__(256) void wrap_post_kernel(const float* __re
 
 // The exact-480 FIFO (reference resample.h:343-363): samples [at, at + take) of the 48 kHz stream swap places with
 // FIFO positions [fill, fill + take) -- the stream gets what the previous block left there (its processed output), the
-// FIFO gets the new input.  When that completes the block (fires != 0) every third sample goes to the model's input.
+// FIFO gets the new input.  When that completes the block (fires != 0) every third sample goes to the model's input
+// (in16: the hop's place in the first stream's row of the step's slot, row16 floats per stream: 160 x hops per step).
 static __global__ __launch_bounds__(256) void wrap_fifo_kernel(float* __restrict__ inner, const int stride, StreamState* __restrict__ st, const int at,
-                                                               const int fill, const int take, const int fires, float* __restrict__ in16) {
+                                                               const int fill, const int take, const int fires, float* __restrict__ in16, const int row16) {
   const int b = blockIdx.x, tid = threadIdx.x;
   float* f = st[b].fifo;
   for (int i = tid; i < take; i += 256) {
@@ -188,7 +190,7 @@ static __global__ __launch_bounds__(256) void wrap_fifo_kernel(float* __restrict
   }
   if (!fires) return;
   __syncthreads();
-  for (int i = tid; i < 160; i += 256) in16[(size_t)b * 160 + i] = f[3 * i + 2];
+  for (int i = tid; i < 160; i += 256) in16[(size_t)b * row16 + i] = f[3 * i + 2];
 }
 // the model's 240 samples, zero-stuffed, become the FIFO's content (reference resample.h:390-393)
 static __global__ void wrap_refill_kernel(StreamState* __restrict__ st, const float* __restrict__ out24, const int B) {

@@ -72,6 +72,10 @@ TICK_LAUNCH_SOURCES = ("tick.hip.h", "fuse.hip.h", "rowchain.hip.h", "tail_stage
                        "fused_small.hip.h", "kernels_misc.hip.h", "gemv.hip.h", "spec_math.hip.h", "ring.h", "engine.h", "batch_tick.hip.h")
 
 
+# the PMC passes (tools/profile_round.sh, tools/pmc_restamp.sh) run this bench with its defaults: four hops per step
+PMC_PASS_HOPS_PER_STEP = 4
+
+
 def csrc_sha1():
     """Fingerprint of the sources of the tick launch (beatrice-vst_amd/csrc: TICK_LAUNCH_SOURCES): the PMC summaries under
     profiles/ carry the one they were measured at (tools/pmc_summary.py), and a summary taken at other sources is not quoted."""
@@ -680,7 +684,7 @@ def main():
                 tick_roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                              # (the PMC passes of tools/profile_round.sh run the default workload: quoted for that one only)
-                             "traffic": pmc_traffic("tick", B) if (a.config == 2 and a.speakers == 1 and H == 2) else None,
+                             "traffic": pmc_traffic("tick", B) if (a.config == 2 and a.speakers == 1 and H == PMC_PASS_HOPS_PER_STEP) else None,
                              "traffic_unit": "bytes per launch (PMC, profiles/)",
                              "algorithmic_bytes": int(by.value), "algorithmic_flops": int(fl.value),
                              "kernel": "tick launch (fuse::table_kernel_w: one workgroup-table launch holding every stage of the "

@@ -224,7 +224,8 @@ int BeatriceBatch_SetSilentStreams(BeatriceBatch* b, const unsigned char* flags)
  * one-stream form of that rule is ProcessorProxy::ProcessChannels, beatrice_host.h); n may change from call to call, up to
  * BeatriceBatch_MaxWrapperBlock(b) (4088 samples at the higher of the two rates).  A model hop runs whenever 480 samples
  * at 48 kHz have accumulated (0, 1 or several times per call).  Bit-identical to the host chain.  One 10 ms hop per step
- * batches only, pipelining off. */
+ * batches only, pipelining off (a batch of several hops per step takes BeatriceBatch_ConfigureWrapper for
+ * BeatriceBatch_BindResidentBlocks, below; the in-order calls return -1 on it). */
 int BeatriceBatch_ConfigureWrapper(BeatriceBatch* b, double host_sample_rate);
 int BeatriceBatch_SetInputGain(BeatriceBatch* b, int stream, double gain_db);
 int BeatriceBatch_SetOutputGain(BeatriceBatch* b, int stream, double gain_db);
@@ -249,9 +250,20 @@ int BeatriceBatch_ProcessBlocksRagged(BeatriceBatch* b, const float* in, float* 
  * the same slot of d_out BeatriceBatch_ResidentBlocksDelay() (= TickStages() - 1) calls later, or after BeatriceBatch_Synchronize.
  * Gains (BeatriceBatch_SetInputGain / SetOutputGain) and every per-stream setting apply to the call that follows them, as in
  * order.  Same samples as BeatriceBatch_ProcessBlocksDevice in order.  n_slots >= TickStages() + 1.  NULL pointers unbind.
- * Binding and unbinding restart the wrapper (resampler histories, FIFO) as BeatriceBatch_ConfigureWrapper does; gains keep their state. */
+ * Binding and unbinding restart the wrapper (resampler histories, FIFO) as BeatriceBatch_ConfigureWrapper does; gains keep their state.
+ * On a batch with H = 2 or 4 hops per step (BeatriceBatch_CreateBlock(..., H); BeatriceBatch_ConfigureWrapper accepts it for this
+ * entry point only): the model hops the FIFOs fire are collected H at a time -- hop k of the batch is hop k mod H of step k / H --
+ * and a step enters the pipeline when it is full, so every tick launch carries H hops per stream as in plain tick mode.  A call's
+ * block is then out once the step of its newest hop has filled and passed the ticks: BeatriceBatch_ResidentBlocksDelay() =
+ * TickStages() - 1 + the calls that bring (H - 1) x 480 inner samples (ask BeatriceBatch_ResidentBlocksDelayFor(b, n_samples) before
+ * binding: n_slots >= that + 2; -1 for blocks shorter than two inner samples).  BeatriceBatch_Synchronize completes the calls whose
+ * hops' steps are full; the last calls, which end on a step still filling, stay owed (BeatriceBatch_ResidentBlocksOwed, 0 at one
+ * hop per step) until later calls fill it -- an offline caller ends a file with that many blocks of silence.  Same samples as one
+ * hop per step. */
 int BeatriceBatch_BindResidentBlocks(BeatriceBatch* b, const float* d_in, float* d_out, int channels, int n_samples, int n_slots);
 int BeatriceBatch_ResidentBlocksDelay(const BeatriceBatch* b);
+int BeatriceBatch_ResidentBlocksDelayFor(const BeatriceBatch* b, int n_samples);
+int BeatriceBatch_ResidentBlocksOwed(const BeatriceBatch* b);
 
 /* Execution control: use an externally owned hipStream_t (e.g. the framework's current stream);
  * replay the per-hop kernel chain from a captured hipGraph (default on). */
@@ -286,7 +298,8 @@ void* BeatriceBatch_GetWaveStream(const BeatriceBatch* b);
  * per step and key/value installs per hop.  The 48 kHz wrapper around the ticks takes such a batch too
  * (BeatriceBatch_BindResidentIO48k: a slot then holds H consecutive blocks per stream, [B][H][channels][480], and a call converts
  * them all: 64 stereo streams 1.41 / 2.32 / 2.9 M frames/s), and so does host streaming (BeatriceBatch_StreamFrames then takes
- * [B][H * 160] and returns [B][H * 240]); the silent-block rule and BindResidentBlocks need one hop per step. */
+ * [B][H * 160] and returns [B][H * 240]) and the any-rate wrapper around the ticks (BeatriceBatch_BindResidentBlocks: a step enters the
+ * pipeline when the FIFOs have fired H hops); the silent-block rule needs one hop per step. */
 int BeatriceBatch_EnableTickPipeline(BeatriceBatch* b, int enable);
 int BeatriceBatch_TickStages(const BeatriceBatch* b);
 /* Host streaming: tick pipelining for callers whose audio lives in HOST memory (offline conversion of files, a network
