@@ -280,6 +280,15 @@ struct BeatriceBatch {
       long long last_hop() const { return (t0 + dout.n_in - 1) / wrapn::kBlock - 1; }   // the newest model hop its samples come from (wrap_post_kernel)
     };
     std::deque<Job> jobs;                                    // calls whose output half is still to run, oldest first
+    // the form with clocks PER STREAM (BeatriceBatch_BindResidentBlocksRagged; the rates, clocks and tap tables are `rw`'s): a slot
+    // holds one cell of channels x max_samples floats per stream; a call's per-stream records stay on the device until its output
+    // half has run; slot_map[b][g mod map_ring] = the resident slot of the step that stream b's hop g rode in
+    bool ragged = false;
+    int max_samples = 0, cell = 0, map_ring = 0;
+    wrapn::RagStream *d_rs = nullptr, *h_rs = nullptr;       // [ring][B]
+    int* d_map = nullptr;                                    // [B][map_ring]
+    std::vector<long long> t48_s;                            // [B] 48 kHz samples of the stream fed so far
+    std::vector<int> hops_s;                                 // [B] model hops the stream has fired
   } rb;
 };
 

@@ -293,7 +293,7 @@ static int wrap_max_chunk(const BeatriceBatch* b) {  // host samples per launch 
 int BeatriceBatch_ProcessBlocksDevice(BeatriceBatch* b, const float* d_in, float* d_out, int channels, int n) {
   const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
-  if (b->rb.on) return (!d_in && !d_out && channels == b->rb.channels && n == b->rb.n) ? (rb_step(b) ? 0 : -2) : -1;
+  if (b->rb.on) return (!b->rb.ragged && !d_in && !d_out && channels == b->rb.channels && n == b->rb.n) ? (rb_step(b) ? 0 : -2) : -1;
   if (!b->wrap.ready || channels < 1 || channels > 2 || !d_in || !d_out || n < 1 || b->H != 1 || b->io_slots > 0 || b->pipelined || b->tk.on) return -1;
   const int piece = wrap_max_chunk(b);
   if (n <= piece) return wrap_chunk(b, d_in, d_out, channels, n) ? 0 : -2;
@@ -354,6 +354,39 @@ int BeatriceBatch_ConfigureWrapperRates(BeatriceBatch* b, const double* rates) {
   r.ready = true;
   return 0;
 }
+// One active stream's share of a call with per-stream clocks: its gain segments, the two resampling directions and the pieces its inner
+// samples are cut into at the 480-sample FIFO, from the stream's own clocks (which advance).  false: the plan does not fit the kernels'
+// buffers -- the caller puts every clock of the call back.
+static bool rag_plan(BeatriceBatch* b, int s, int n, wrapn::RagStream& q, wrapn::GainSeg& seg_in, wrapn::GainSeg& seg_out) {
+  using namespace wrapn;
+  BeatriceBatch::RaggedWrap& r = b->rw;
+  WrapPlan& p = r.classes[r.cls[s]];
+  BeatriceBatch::RaggedWrap::Clock& c = r.clk[s];
+  p.phase_down = c.phase_down; p.phase_up = c.phase_up; p.fill = c.fill;   // the class's plan does the clock arithmetic on the stream's state
+  seg_in = b->gain_in[s].advance(n, p.rate);
+  seg_out = b->gain_out[s].advance(n, p.rate);
+  q.din = p.to_inner(n);
+  const int m = q.din.n_out;
+  if (m < 0 || m > kMaxSamples) return false;
+  int fill = p.fill, nc = 0;
+  for (int at = 0; at < m;) {
+    const int take = std::min(kBlock - fill, m - at);
+    if (nc >= kMaxChunks) return false;
+    q.at[nc] = (short)at; q.fill[nc] = (short)fill; q.take[nc] = (short)take;
+    q.fires[nc] = fill + take == kBlock ? 1 : 0;
+    fill = q.fires[nc] ? 0 : fill + take;
+    at += take;
+    ++nc;
+  }
+  q.n_chunks = nc;
+  p.fill = fill;
+  q.dout = p.to_outer(m);
+  if (q.dout.n_out != n) return false;
+  q.taps_in = q.din.decimate ? r.taps_down_off[r.cls[s]] : r.taps_up_off[r.cls[s]];
+  q.taps_out = q.dout.decimate ? r.taps_down_off[r.cls[s]] : r.taps_up_off[r.cls[s]];
+  c.phase_down = p.phase_down; c.phase_up = p.phase_up; c.fill = p.fill;
+  return true;
+}
 // One call = for every stream s a block of n_samples[s] host samples at ITS rate (0: the stream sits this call out).  in / out:
 // the streams' planar blocks [channels][n_samples[s]] one after the other.  apply_silent_rule != 0: a block whose down-mix is
 // all zeros is not converted (src/vst/processor.cc:204-214): nothing of that stream moves -- gains, resampler clocks, FIFO,
@@ -404,31 +437,8 @@ int BeatriceBatch_ProcessBlocksRagged(BeatriceBatch* b, const float* in, float* 
     off += (size_t)channels * n;
     q.active = active ? 1 : 0;
     if (!active) { seg[s] = GainSeg{1.0, 1.0, 1.0}; seg[B + s] = GainSeg{1.0, 1.0, 1.0}; continue; }
-    WrapPlan& p = r.classes[r.cls[s]];
-    BeatriceBatch::RaggedWrap::Clock& c = r.clk[s];
-    p.phase_down = c.phase_down; p.phase_up = c.phase_up; p.fill = c.fill;   // the class's plan does the clock arithmetic on the stream's state
-    seg[s] = b->gain_in[s].advance(n, p.rate);
-    seg[B + s] = b->gain_out[s].advance(n, p.rate);
-    q.din = p.to_inner(n);
-    const int m = q.din.n_out;
-    if (m < 0 || m > kMaxSamples) return refuse();
-    int fill = p.fill, nc = 0;
-    for (int at = 0; at < m;) {
-      const int take = std::min(kBlock - fill, m - at);
-      if (nc >= kMaxChunks) return refuse();
-      q.at[nc] = (short)at; q.fill[nc] = (short)fill; q.take[nc] = (short)take;
-      q.fires[nc] = fill + take == kBlock ? 1 : 0;
-      fill = q.fires[nc] ? 0 : fill + take;
-      at += take;
-      ++nc;
-    }
-    q.n_chunks = nc;
-    p.fill = fill;
-    q.dout = p.to_outer(m);
-    if (q.dout.n_out != n) return refuse();
-    q.taps_in = q.din.decimate ? r.taps_down_off[r.cls[s]] : r.taps_up_off[r.cls[s]];
-    q.taps_out = q.dout.decimate ? r.taps_down_off[r.cls[s]] : r.taps_up_off[r.cls[s]];
-    c.phase_down = p.phase_down; c.phase_up = p.phase_up; c.fill = p.fill;
+    if (!rag_plan(b, s, n, q, seg[s], seg[B + s])) return refuse();
+    const int nc = q.n_chunks;
     max_chunks = std::max(max_chunks, nc);
   }
   // uploads: the per-stream records of this call, the gain segments, the audio
@@ -453,7 +463,7 @@ int BeatriceBatch_ProcessBlocksRagged(BeatriceBatch* b, const float* in, float* 
       any_fire = any_fire || fires;
     }
     unsigned char* d_flags = r.d_frozen + (size_t)ci * B;
-    hipLaunchKernelGGL(wrapr_fifo_kernel, dim3(B), dim3(256), 0, st, b->d_wrap_inner, kInnerStride, b->d_wrap, d_rs, ci, b->d_in, d_flags);
+    hipLaunchKernelGGL(wrapr_fifo_kernel, dim3(B), dim3(256), 0, st, b->d_wrap_inner, kInnerStride, b->d_wrap, d_rs, ci, b->d_in, d_flags, nullptr, 0, 0);
     if (!any_fire) { std::fill(sr.next.begin(), sr.next.end(), 0); continue; }
     bool any_frozen = false;
     for (int s = 0; s < B; ++s) any_frozen = any_frozen || sr.next[s];
@@ -496,7 +506,29 @@ static void rb_release(BeatriceBatch* b) {
   if (r.d_gains) (void)hipFree(r.d_gains);
   if (r.h_gains) (void)hipHostFree(r.h_gains);
   if (r.gain_ev) { for (int i = 0; i < r.ring; ++i) if (r.gain_ev[i]) (void)hipEventDestroy(r.gain_ev[i]); delete[] r.gain_ev; }
+  if (r.d_rs) (void)hipFree(r.d_rs);
+  if (r.h_rs) (void)hipHostFree(r.h_rs);
+  if (r.d_map) (void)hipFree(r.d_map);
   r = BeatriceBatch::ResidentBlocks{};
+}
+// leaves either form of the resident blocks: the pipeline drained, tick mode off, the wrapper restarted at its rate(s)
+static int rb_unbind(BeatriceBatch* b) {
+  BeatriceBatch::ResidentBlocks& r = b->rb;
+  if (!sync_all(b)) return -2;
+  const int rc = tick_enable(b, false);
+  if (rc) return rc;
+  (void)BeatriceBatch_BindResidentIO(b, nullptr, nullptr, 0);
+  const bool ragged = r.ragged;
+  rb_release(b);
+  if (ragged) {
+    b->silent.on = false;   // (the flags of the ragged steps were the binding's own)
+    std::vector<double> rates(b->B);
+    for (int s = 0; s < b->B; ++s) rates[s] = b->rw.classes[b->rw.cls[s]].rate;
+    (void)BeatriceBatch_ConfigureWrapperRates(b, rates.data());
+  } else {
+    (void)BeatriceBatch_ConfigureWrapper(b, b->wrap.rate);   // the wrapper restarts, as after a sample-rate change (the gains keep their state)
+  }
+  return 0;
 }
 // Calls after which a call's output block is out: TickStages() - 1 ticks behind the tick that fed its newest hop (every call runs
 // at least one tick); with H hops per step that hop waits until up to H - 1 further hops have filled its step, each call bringing at
@@ -574,14 +606,7 @@ int BeatriceBatch_BindResidentBlocks(BeatriceBatch* b, const float* d_in, float*
   const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   BeatriceBatch::ResidentBlocks& r = b->rb;
-  if (r.on) {
-    if (!sync_all(b)) return -2;
-    const int rc = tick_enable(b, false);
-    if (rc) return rc;
-    (void)BeatriceBatch_BindResidentIO(b, nullptr, nullptr, 0);
-    rb_release(b);
-    (void)BeatriceBatch_ConfigureWrapper(b, b->wrap.rate);   // the wrapper restarts, as after a sample-rate change (the gains keep their state)
-  }
+  if (r.on) { const int rc = rb_unbind(b); if (rc) return rc; }
   if (!d_in && !d_out) return 0;
   const int stages = b->tk.plan.count();
   const int H = b->H;
@@ -620,6 +645,159 @@ int BeatriceBatch_BindResidentBlocks(BeatriceBatch* b, const float* d_in, float*
     return -2;
   }
   r.d_in = d_in; r.d_out = d_out; r.channels = channels; r.n = n; r.n_slots = n_slots; r.on = true;
+  return 0;
+}
+// ---- the wrapper with clocks PER STREAM around the tick pipeline (BeatriceBatch_ConfigureWrapperRates, then
+// BeatriceBatch_BindResidentBlocksRagged / BeatriceBatch_ProcessBlocksRaggedDevice): what the reference gives every plugin instance
+// (src/common/resample.h:401-438), in the throughput form.  A call = for every stream a block of n_samples[s] host samples at ITS
+// rate from its cell of slot `call mod n_slots`; a stream fires a model hop when ITS 480-sample FIFO fills, and the step that goes
+// into the ticks then carries the streams that fired -- the others sit it out with their own step counters (the tick launch's ragged
+// steps, batch_tick.hip.h), so a stream's hops ride in steps of their own and slot_map remembers which.  Output half `delay` =
+// TickStages() - 1 calls later, from the records the call left on the device.
+static int rbr_step(BeatriceBatch* b, const int* n_samples) {
+  using namespace wrapn;
+  BeatriceBatch::ResidentBlocks& r = b->rb;
+  BeatriceBatch::RaggedWrap& rw = b->rw;
+  const int B = b->B;
+  hipStream_t st = b->stream;
+  for (int s = 0; s < B; ++s) {
+    const int lim = std::max(1, (int)std::floor((kMaxSamples - 8) * std::min(1.0, rw.classes[rw.cls[s]].rate / 48000.0)));
+    if (n_samples[s] < 0 || n_samples[s] > std::min(r.max_samples, lim)) return -1;
+  }
+  const long long call = r.calls;
+  const int ge = (int)(call % r.ring);
+  if (call >= r.ring && !hip_ok(hipEventSynchronize(r.gain_ev[ge]), "wrapper record ring")) return -2;
+  RagStream* rs = r.h_rs + (size_t)ge * B;
+  GainSeg* seg = r.h_gains + (size_t)ge * 2 * B;
+  // all or nothing, as BeatriceBatch_ProcessBlocksRagged: a plan that does not fit puts every clock of the call back
+  rw.clk_undo = rw.clk;
+  rw.gain_undo_in.assign(b->gain_in.begin(), b->gain_in.end());
+  rw.gain_undo_out.assign(b->gain_out.begin(), b->gain_out.end());
+  int max_chunks = 0;
+  for (int s = 0; s < B; ++s) {
+    RagStream& q = rs[s];
+    q = RagStream{};
+    const int n = n_samples[s];
+    q.io_off = (long long)s * r.cell; q.n = n;
+    q.active = n > 0 ? 1 : 0;
+    q.hop0 = r.hops_s[s]; q.t0 = r.t48_s[s];
+    if (!q.active) { seg[s] = GainSeg{1.0, 1.0, 1.0}; seg[B + s] = GainSeg{1.0, 1.0, 1.0}; continue; }
+    if (!rag_plan(b, s, n, q, seg[s], seg[B + s])) {
+      rw.clk = rw.clk_undo;
+      std::copy(rw.gain_undo_in.begin(), rw.gain_undo_in.end(), b->gain_in.begin());
+      std::copy(rw.gain_undo_out.begin(), rw.gain_undo_out.end(), b->gain_out.begin());
+      return -2;
+    }
+    max_chunks = std::max(max_chunks, q.n_chunks);
+  }
+  for (int s = 0; s < B; ++s) {   // (the plan stands: the streams' sample and hop counts move)
+    if (!rs[s].active) continue;
+    r.t48_s[s] += rs[s].din.n_out;
+    for (int c = 0; c < rs[s].n_chunks; ++c) r.hops_s[s] += rs[s].fires[c];
+  }
+  RagStream* d_rs = r.d_rs + (size_t)ge * B;
+  GainSeg* dseg = r.d_gains + (size_t)ge * 2 * B;
+  if (!hip_ok(hipMemcpyAsync(d_rs, rs, sizeof(RagStream) * B, hipMemcpyHostToDevice, st), "wrapper records up") ||
+      !hip_ok(hipMemcpyAsync(dseg, seg, sizeof(GainSeg) * 2 * B, hipMemcpyHostToDevice, st), "wrapper gains up") ||
+      !hip_ok(hipEventRecord(r.gain_ev[ge], st), "wrapper record event"))
+    return -2;
+  const float* src = r.d_in + (size_t)(call % r.n_slots) * B * r.cell;
+  hipLaunchKernelGGL(wrapr_in_kernel, dim3(B), dim3(256), 0, st, src, r.channels, b->d_wrap, dseg, rw.d_taps, d_rs, b->d_wrap_inner, kInnerStride);
+  BeatriceBatch::SilentRule& sr = b->silent;
+  int ticks = 0;
+  for (int ci = 0; ci < max_chunks; ++ci) {
+    bool any_fire = false, any_out = false;
+    for (int s = 0; s < B; ++s) {
+      const bool fires = rs[s].active && ci < rs[s].n_chunks && rs[s].fires[ci];
+      sr.next[s] = fires ? 0 : 1;
+      any_fire = any_fire || fires;
+      any_out = any_out || !fires;
+    }
+    hipLaunchKernelGGL(wrapr_fifo_kernel, dim3(B), dim3(256), 0, st, b->d_wrap_inner, kInnerStride, b->d_wrap, d_rs, ci,
+                       r.d_in16 + (size_t)b->io_host * B * B_IN_HOP, nullptr, r.d_map, r.map_ring, b->io_host);
+    if (!any_fire) { std::fill(sr.next.begin(), sr.next.end(), 0); continue; }
+    sr.any_next = any_out;   // (tick_run: the flagged streams sit this step out, and clears the flags)
+    if (!tick_run(b, true)) return -2;
+    std::fill(sr.next.begin(), sr.next.end(), 0);
+    sr.any_next = false;
+    ++ticks;
+  }
+  if (ticks == 0 && !tick_run(b, false)) return -2;   // the pipeline advances with every call
+  r.jobs.push_back(BeatriceBatch::ResidentBlocks::Job{call, 0, Dir{}});
+  r.calls = call + 1;
+  bool ok = true;
+  while (ok && !r.jobs.empty() && r.jobs.front().call + r.delay <= call) {
+    ok = rb_post(b, r.jobs.front());
+    r.jobs.pop_front();
+  }
+  b->inflight = true;
+  return ok ? 0 : -2;
+}
+int BeatriceBatch_ProcessBlocksRaggedDevice(BeatriceBatch* b, const int* n_samples) {
+  const DeviceScope dev_(b ? b->device : -1);
+  if (!b || !b->ok) return -2;
+  if (!b->rb.on || !b->rb.ragged || !n_samples) return -1;
+  return rbr_step(b, n_samples);
+}
+// d_in / d_out: [n_slots][B][channels * max_samples]: stream s's block of a call, planar [channels][n_samples[s]], at the start of its cell
+int BeatriceBatch_BindResidentBlocksRagged(BeatriceBatch* b, const float* d_in, float* d_out, int channels, int max_samples, int n_slots) {
+  const DeviceScope dev_(b ? b->device : -1);
+  if (!b || !b->ok) return -2;
+  BeatriceBatch::ResidentBlocks& r = b->rb;
+  if (r.on) { const int rc = rb_unbind(b); if (rc) return rc; }
+  if (!d_in && !d_out) return 0;
+  const int stages = b->tk.plan.count();
+  if (!b->rw.ready || !d_in || !d_out || channels < 1 || channels > 2 || max_samples < 1 || n_slots < stages + 1 || b->H != 1 ||
+      b->io_slots > 0 || b->pipelined || b->tk.on || b->hs.on || b->r48.on || b->silent.on)
+    return -1;
+  const int B = b->B;
+  // binding restarts every stream's resampler pair and FIFO (their in-order form keeps processed samples in the FIFO, this one does not)
+  std::vector<double> rates(B);
+  for (int s = 0; s < B; ++s) rates[s] = b->rw.classes[b->rw.cls[s]].rate;
+  if (BeatriceBatch_ConfigureWrapperRates(b, rates.data()) != 0) return -2;
+  // steps a call can feed = the most hops one stream can fire in it; a hop's resident output is read until `delay` calls after the call
+  // in which the stream's NEXT hop fired
+  int hops_per_call = 1;
+  for (int s = 0; s < B; ++s) {
+    const int lim = std::max(1, (int)std::floor((wrapn::kMaxSamples - 8) * std::min(1.0, rates[s] / 48000.0)));
+    const int m_max = (int)std::ceil(std::min(max_samples, lim) * 48000.0 / rates[s]) + 2;
+    hops_per_call = std::max(hops_per_call, (m_max + wrapn::kBlock - 1) / wrapn::kBlock + 1);
+  }
+  r.delay = stages - 1;
+  r.ring = r.delay + 3;
+  r.H = 1;
+  r.io_slots = std::max(stages + 1, (r.delay + 2) * hops_per_call + 2);
+  if (r.io_slots > stepc::kImmediateMaxSlot + 1) { r = BeatriceBatch::ResidentBlocks{}; return -1; }
+  r.map_ring = r.io_slots;
+  bool ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_in16), sizeof(float) * r.io_slots * B * B_IN_HOP), "rb in16") &&
+            hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_out24), sizeof(float) * r.io_slots * B * B_OUT_HOP), "rb out24") &&
+            hip_ok(hipMemset(r.d_in16, 0, sizeof(float) * r.io_slots * B * B_IN_HOP), "rb zero") &&
+            hip_ok(hipMemset(r.d_out24, 0, sizeof(float) * r.io_slots * B * B_OUT_HOP), "rb zero") &&
+            hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_gains), sizeof(wrapn::GainSeg) * r.ring * 2 * B), "rb gains") &&
+            hip_ok(hipHostMalloc(reinterpret_cast<void**>(&r.h_gains), sizeof(wrapn::GainSeg) * r.ring * 2 * B, hipHostMallocDefault), "rb gains host") &&
+            hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_rs), sizeof(wrapn::RagStream) * r.ring * B), "rb records") &&
+            hip_ok(hipHostMalloc(reinterpret_cast<void**>(&r.h_rs), sizeof(wrapn::RagStream) * r.ring * B, hipHostMallocDefault), "rb records host") &&
+            hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_map), sizeof(int) * B * r.map_ring), "rb slot map") &&
+            hip_ok(hipMemset(r.d_map, 0, sizeof(int) * B * r.map_ring), "rb slot map zero");
+  if (ok) {
+    r.gain_ev = new hipEvent_t[r.ring]();
+    for (int i = 0; i < r.ring && ok; ++i) ok = hip_ok(hipEventCreateWithFlags(&r.gain_ev[i], hipEventDisableTiming), "rb event");
+  }
+  ok = ok && hip_ok(hipDeviceSynchronize(), "rb sync") && BeatriceBatch_BindResidentIO(b, r.d_in16, r.d_out24, r.io_slots) == 0 && tick_enable(b, true) == 0;
+  if (!ok) {
+    (void)tick_enable(b, false);
+    (void)BeatriceBatch_BindResidentIO(b, nullptr, nullptr, 0);
+    rb_release(b);
+    return -2;
+  }
+  b->silent.next.assign(B, 0);   // the ragged steps' flags (tick_run): set per tick by rbr_step, not by the caller
+  b->silent.any_next = false;
+  b->silent.on = true;
+  r.d_in = d_in; r.d_out = d_out; r.channels = channels; r.max_samples = max_samples; r.cell = channels * max_samples; r.n = 0;
+  r.n_slots = n_slots; r.ragged = true;
+  r.t48_s.assign(B, 0);
+  r.hops_s.assign(B, 0);
+  r.on = true;
   return 0;
 }
 int BeatriceBatch_ResidentBlocksDelay(const BeatriceBatch* b) { return b && b->ok && b->rb.on ? b->rb.delay : -1; }

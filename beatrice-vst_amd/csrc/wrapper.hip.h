@@ -215,6 +215,10 @@ struct RagStream {
   short at[kMaxChunks], fill[kMaxChunks], take[kMaxChunks];   // chunk i: inner samples [at, at + take) <-> FIFO [fill, fill + take)
   unsigned char fires[kMaxChunks];
   int active;                    // 0: nothing of this stream moves in this call (its output block is zeros)
+  // around the tick pipeline (BeatriceBatch_BindResidentBlocksRagged): the stream's own 48 kHz sample count and model-hop count
+  // at the start of the call
+  int hop0;
+  long long t0;
 };
 
 static __global__ __launch_bounds__(256) void wrapr_in_kernel(const float* __restrict__ in, const int channels, StreamState* __restrict__ st,
@@ -290,15 +294,23 @@ static __global__ __launch_bounds__(256) void wrapr_out_kernel(const float* __re
   for (int i = tid; i < d.hist; i += 256) hist[i] = x[d.n_in + i];
 }
 // chunk `ci` of every stream that has one; frozen[b] = 1 for the streams that do NOT complete a 480-block in this chunk (the
-// model step that follows stands still for them); in16: the step's input
+// model step that follows stands still for them); in16: the step's input.  Around the tick pipeline (slot_map != nullptr): the hop a
+// stream fires here is the stream's hop number g = hop0 + its fires in earlier chunks, and the step it rides in is the one in resident
+// slot `slot`: slot_map[b][g mod map_ring] = slot, for the output half of the calls that will read that hop (wrapr_post_kernel).
 static __global__ __launch_bounds__(256) void wrapr_fifo_kernel(float* __restrict__ inner, const int stride, StreamState* __restrict__ st,
                                                                 const RagStream* __restrict__ rs, const int ci, float* __restrict__ in16,
-                                                                unsigned char* __restrict__ frozen) {
+                                                                unsigned char* __restrict__ frozen, int* __restrict__ slot_map, const int map_ring,
+                                                                const int slot) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const RagStream& r = rs[b];
   const bool has = r.active && ci < r.n_chunks;
   const bool fires = has && r.fires[ci];
   if (frozen != nullptr && tid == 0) frozen[b] = fires ? 0 : 1;
+  if (slot_map != nullptr && fires && tid == 0) {
+    int g = r.hop0;
+    for (int j = 0; j < ci; ++j) g += r.fires[j];
+    slot_map[(size_t)b * map_ring + g % map_ring] = slot;
+  }
   if (!has) return;
   const int at = r.at[ci], fill = r.fill[ci], take = r.take[ci];
   float* f = st[b].fifo;
@@ -310,6 +322,52 @@ static __global__ __launch_bounds__(256) void wrapr_fifo_kernel(float* __restric
   if (!fires) return;
   __syncthreads();
   for (int i = tid; i < 160; i += 256) in16[(size_t)b * 160 + i] = f[3 * i + 2];
+}
+// The output half of a call with per-stream clocks around the tick pipeline: as wrap_post_kernel, with the stream's own sample
+// count t0 and its own hops -- 48 kHz sample t of stream b is sample t % 480 of the zero-stuffed output of ITS hop t / 480 - 1, which
+// rode in the step of resident slot slot_map[b][hop mod map_ring].
+static __global__ __launch_bounds__(256) void wrapr_post_kernel(const float* __restrict__ out24 /* [io_slots][B][240] */, const int B,
+                                                                const int* __restrict__ slot_map, const int map_ring, StreamState* __restrict__ st,
+                                                                const GainSeg* __restrict__ gain, const float* __restrict__ taps_all,
+                                                                const RagStream* __restrict__ rs, float* __restrict__ out, const int channels) {
+  __shared__ float x[kMaxHist + kMaxSamples];
+  __shared__ double amp[kMaxSamples];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const RagStream r = rs[b];
+  float* dst = out + r.io_off;
+  if (!r.active) {   // the stream sat the call out: its block comes back as silence
+    for (int i = tid; i < channels * r.n; i += 256) dst[i] = 0.0f;
+    return;
+  }
+  const Dir d = r.dout;
+  const int n = d.n_out;
+  const float* taps = taps_all + r.taps_out;
+  float* hist = d.decimate ? st[b].hist_high_out : st[b].hist_low_out;
+  const GainSeg g = gain[b];
+  if (tid == 0 && g.step != 1.0) {
+    double a = g.amp0;
+    for (int i = 0; i < n; ++i) {
+      if (g.step > 1.0) { if (a < g.goal) a = fmin(a * g.step, g.goal); }
+      else if (a > g.goal) a = fmax(a * g.step, g.goal);
+      amp[i] = a;
+    }
+  }
+  for (int i = tid; i < d.hist; i += 256) x[i] = hist[i];
+  for (int i = tid; i < d.n_in; i += 256) {
+    const long long t = r.t0 + i;
+    const long long k = t / kBlock - 1;
+    const int off = (int)(t % kBlock);
+    x[d.hist + i] = (k < 0 || (off & 1)) ? 0.0f : out24[((size_t)slot_map[(size_t)b * map_ring + (int)(k % map_ring)] * B + b) * 240 + (off >> 1)];
+  }
+  __syncthreads();
+  for (int o = tid; o < n; o += 256) {
+    const float y = resample_one(d, x, taps, o);
+    const double a = g.step != 1.0 ? amp[o] : g.amp0;
+    const float v = (float)(y * a);
+    for (int c = 0; c < channels; ++c) dst[c * n + o] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < d.hist; i += 256) hist[i] = x[d.n_in + i];
 }
 static __global__ void wrapr_refill_kernel(StreamState* __restrict__ st, const float* __restrict__ out24, const int B, const unsigned char* __restrict__ frozen) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;

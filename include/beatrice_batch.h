@@ -264,6 +264,19 @@ int BeatriceBatch_BindResidentBlocks(BeatriceBatch* b, const float* d_in, float*
 int BeatriceBatch_ResidentBlocksDelay(const BeatriceBatch* b);
 int BeatriceBatch_ResidentBlocksDelayFor(const BeatriceBatch* b, int n_samples);
 int BeatriceBatch_ResidentBlocksOwed(const BeatriceBatch* b);
+/* The throughput form with clocks PER STREAM (reference src/common/resample.h:401-438: every plugin instance owns its resampler
+ * pair; here a batch whose streams come from hosts at 44.1, 48, 96 kHz ... with block sizes of their own, around ONE tick pipeline).
+ * After BeatriceBatch_ConfigureWrapperRates: d_in / d_out = [n_slots][B][channels * max_samples]; stream s's block of a call, planar
+ * [channels][n_samples[s]], sits at the start of its cell.  Call k = BeatriceBatch_ProcessBlocksRaggedDevice(b, n_samples) reads slot
+ * k mod n_slots: n_samples[B], 0 <= n_samples[s] <= max_samples (and the per-rate limit of BeatriceBatch_ProcessBlocksRagged),
+ * 0 = the stream sits the call out (nothing of it moves, no output).  A stream fires a model hop when ITS 480-sample FIFO fills; the
+ * step that enters the ticks carries the streams that fired, the others sit it out with step counters of their own (the tick launch's
+ * ragged steps).  The output blocks of call k are in the same slot of d_out BeatriceBatch_ResidentBlocksDelay() (= TickStages() - 1)
+ * calls later, or after BeatriceBatch_Synchronize.  Gains and per-stream settings apply to the call that follows them.  Same samples
+ * as BeatriceBatch_ProcessBlocksRagged in order = one reference wrapper per stream.  One hop per step, n_slots >= TickStages() + 1.
+ * NULL pointers unbind (either bind call unbinds either form); binding and unbinding restart every stream's resampler pair and FIFO. */
+int BeatriceBatch_BindResidentBlocksRagged(BeatriceBatch* b, const float* d_in, float* d_out, int channels, int max_samples, int n_slots);
+int BeatriceBatch_ProcessBlocksRaggedDevice(BeatriceBatch* b, const int* n_samples);
 
 /* Execution control: use an externally owned hipStream_t (e.g. the framework's current stream);
  * replay the per-hop kernel chain from a captured hipGraph (default on). */

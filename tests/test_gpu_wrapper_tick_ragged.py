@@ -1,0 +1,128 @@
+"""VERDICT r04 missing #4 / item 6: clocks PER STREAM for the resident-block wrapper AROUND THE TICK PIPELINE (reference: every plugin
+instance owns its resampler pair, src/common/resample.h:401-438).  BeatriceBatch_ConfigureWrapperRates, then
+BeatriceBatch_BindResidentBlocksRagged / BeatriceBatch_ProcessBlocksRaggedDevice: a batch of 44.1 + 48 + 96 + 32 kHz callers with
+block sizes of their own; a stream fires a model hop when ITS FIFO fills, the step that enters the ticks carries the streams that
+fired and the others sit it out (ragged tick steps); blocks the shell would not convert (src/vst/processor.cc:204-214) and calls
+without a block are handed in as n_samples = 0.
+Reference per stream: ProcessorProxy::ProcessChannels of the host layer on the ORACLE core at that stream's rate and block size
+(CPU-pinned to the reference wrapper: test_host_layer.py, test_wrapper_oracle.py), and the same batch code in order."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import wrapperlib
+from test_host_proxy import K_MODEL, K_VOICE, K_VQ, Proxy
+from tick_driver import Hip
+
+pytestmark = pytest.mark.gpu
+_f32p = C.POINTER(C.c_float)
+
+
+@pytest.mark.parametrize("channels,holes", [(1, True), (2, True), (1, False)])
+def test_mixed_rate_batch_around_the_tick_pipeline_matches_one_proxy_per_stream(bv, product, model_dir, channels, holes):
+    rates = [44100.0, 48000.0, 96000.0, 44100.0, 32000.0, 48000.0, 16000.0]
+    blocks = [441, 480, 1024, 300, 512, 64, 333]      # host samples per call, per stream
+    B, calls = len(rates), 100
+    absent = {3: {5, 6, 20, 61}, 5: {0, 1, 2, 30, 31, 32, 33}} if holes else {}        # calls in which a stream hands in no block at all
+    silent = {0: {4, 5, 17, 70}, 1: {0, 9, 10, 11, 55}, 2: {12}, 4: {3, 25, 26}} if holes else {}   # blocks the shell's rule skips
+    switch = {0: (4, 2), 1: (12, 0), 2: (7, 1), 4: (26, 2), 6: (50, 0)}    # stream -> (before call, speaker); some right before silent blocks
+    x = []
+    for s in range(B):
+        sig = np.stack([(0.6 if c else 1.0) * wrapperlib.test_signal(calls * blocks[s], int(rates[s]), seed=5100 + 7 * s + c) for c in range(channels)])
+        for k in silent.get(s, ()):
+            sig[:, k * blocks[s]:(k + 1) * blocks[s]] = 0.0
+        x.append(sig.astype(np.float32))
+
+    # ---- reference: one proxy on the oracle core per stream, its own rate and block size; absent calls simply do not happen
+    want = [np.zeros_like(x[s]) for s in range(B)]
+    for s in range(B):
+        p = Proxy(rates[s])
+        assert p.call("SetString", K_MODEL, (model_dir + "/model.toml").encode()) == 0
+        p.call("SetInt", K_VOICE, s % 3)
+        p.call("SetNumber", K_VQ, float(s % 3))
+        n = blocks[s]
+        for k in range(calls):
+            if s in switch and switch[s][0] == k:
+                p.call("SetInt", K_VOICE, switch[s][1])
+            if k in absent.get(s, ()):
+                continue
+            sl = slice(k * n, (k + 1) * n)
+            in0 = np.ascontiguousarray(x[s][0, sl])
+            in1 = np.ascontiguousarray(x[s][1, sl]) if channels == 2 else None
+            o0, o1 = np.zeros(n, np.float32), np.zeros(n, np.float32)
+            flag = p.call("ProcessChannels", in0.ctypes.data_as(_f32p), in1.ctypes.data_as(_f32p) if in1 is not None else None,
+                          o0.ctypes.data_as(_f32p), o1.ctypes.data_as(_f32p) if channels == 2 else None, n)
+            assert flag == (1 if k in silent.get(s, ()) else 0)
+            want[s][0, sl] = o0
+            if channels == 2:
+                want[s][1, sl] = o1
+        p.close()
+
+    # ---- product: one batch, every stream its own clocks, the tick pipeline between resident blocks
+    m = bv.Models(product, model_dir)
+    batch = bv.Batch(m, B)
+    a, h = batch.a, batch.h
+    for s in range(B):
+        a.BeatriceBatch_SetTargetSpeaker(h, s, s % 3)
+        a.BeatriceBatch_SetVQNumNeighbors(h, s, s % 3)      # (no flush: the key/value blocks follow one per hop, as in the proxy)
+    hip = Hip()
+    stages = a.BeatriceBatch_TickStages(h)
+    slots, cap = 3 * stages, max(blocks)
+    cell = channels * cap
+    d_in, d_out = hip.malloc(slots * B * cell * 4), hip.malloc(slots * B * cell * 4)
+    assert a.BeatriceBatch_BindResidentBlocksRagged(h, d_in, d_out, channels, cap, slots) == -1          # no rates configured
+    assert a.BeatriceBatch_ConfigureWrapperRates(h, (C.c_double * B)(*rates)) == 0
+    assert a.BeatriceBatch_BindResidentBlocksRagged(h, d_in, d_out, channels, cap, stages) == -1         # too few slots
+    assert a.BeatriceBatch_BindResidentBlocksRagged(h, d_in, d_out, channels, cap, slots) == 0
+    delay = a.BeatriceBatch_ResidentBlocksDelay(h)
+    assert delay == stages - 1
+    assert a.BeatriceBatch_ProcessBlocksDevice(h, None, None, channels, cap) == -1                      # the uniform entry point is not this binding's
+    assert a.BeatriceBatch_ProcessBlocksRaggedDevice(h, (C.c_int * B)(*([cap + 1] * B))) == -1          # a block longer than its cell
+    got = [np.zeros_like(x[s]) for s in range(B)]
+    chunk = slots - delay - 1
+    buf_in = np.zeros((slots, B, cell), np.float32)
+    k0 = 0
+    while k0 < calls:
+        nk = min(chunk, calls - k0)
+        for k in range(k0, k0 + nk):
+            for s in range(B):
+                n = blocks[s]
+                buf_in[k % slots, s, :channels * n] = x[s][:, k * n:(k + 1) * n].reshape(-1)
+        hip.h2d(d_in, buf_in)
+        for k in range(k0, k0 + nk):
+            for s in range(B):
+                if s in switch and switch[s][0] == k:
+                    a.BeatriceBatch_SetTargetSpeaker(h, s, switch[s][1])
+            # the shell's rule is the caller's here (the blocks are on the device): silent and missing blocks are n_samples = 0
+            ns = [0 if (k in absent.get(s, ()) or k in silent.get(s, ())) else blocks[s] for s in range(B)]
+            assert a.BeatriceBatch_ProcessBlocksRaggedDevice(h, (C.c_int * B)(*ns)) == 0
+        assert a.BeatriceBatch_Synchronize(h) == 0               # drains the pipeline, runs the output halves still owed, relevels the streams
+        assert a.BeatriceBatch_ResidentBlocksOwed(h) == 0
+        out = np.zeros((slots, B, cell), np.float32)
+        hip.d2h(out, d_out)
+        for k in range(k0, k0 + nk):
+            for s in range(B):
+                if k in absent.get(s, ()) or k in silent.get(s, ()):
+                    continue
+                n = blocks[s]
+                got[s][:, k * n:(k + 1) * n] = out[k % slots, s, :channels * n].reshape(channels, n)
+        k0 += nk
+    assert a.BeatriceBatch_BindResidentBlocksRagged(h, None, None, 0, 0, 0) == 0
+    # the batch is back in order with its per-stream clocks restarted: one more in-order call goes through
+    ns = (C.c_int * B)(*blocks)
+    xin = np.concatenate([np.ascontiguousarray(x[s][:, :blocks[s]]).reshape(-1) for s in range(B)]).astype(np.float32)
+    out = np.zeros_like(xin)
+    assert a.BeatriceBatch_ProcessBlocksRagged(h, bv.fptr(xin), bv.fptr(out), channels, ns, 0) == 0
+    batch.close()
+    m.close()
+    hip.free(d_in)
+    hip.free(d_out)
+    bad = []
+    for s in range(B):
+        assert np.abs(want[s]).max() > 1e-3
+        if not np.array_equal(got[s], want[s]):
+            d = np.abs(got[s] - want[s])
+            bad.append("stream %d (%.0f Hz, %d-sample blocks): max-abs %g, first differing call %d" % (
+                s, rates[s], blocks[s], d.max(), int(np.argmax(d.max(axis=0) > 0)) // blocks[s]))
+    assert not bad, "; ".join(bad)
