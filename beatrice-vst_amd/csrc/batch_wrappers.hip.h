@@ -530,15 +530,18 @@ static int rb_unbind(BeatriceBatch* b) {
   }
   return 0;
 }
-// Calls after which a call's output block is out: TickStages() - 1 ticks behind the tick that fed its newest hop (every call runs
-// at least one tick); with H hops per step that hop waits until up to H - 1 further hops have filled its step, each call bringing at
-// least m_lo inner samples (the two clocks make a call's count vary by one).  -1: blocks too short to bound it (H > 1 only).
+// Calls after which a call's output block is out.  One hop per step: every call runs at least one tick, so TickStages() - 1 calls
+// behind the call that fed its newest hop.  H hops per step: ticks run only when a step is full (an idle tick per call would carry a
+// quarter-filled pipeline and cost what a full one does) -- the newest hop waits until up to H - 1 further hops have filled its step
+// and TickStages() - 1 further steps have gone in behind it, each call bringing at least m_lo inner samples (the two clocks make a
+// call's count vary by one).  -1: blocks too short to bound it (H > 1 only).
 static int rb_delay(const BeatriceBatch* b, int n) {
   const int stages = b->tk.plan.count();
   if (b->H == 1) return stages - 1;
   const long long m_lo = (long long)std::floor(n * 48000.0 / b->wrap.rate) - 1;
   if (m_lo < 1) return -1;
-  return stages - 1 + (int)(((long long)(b->H - 1) * wrapn::kBlock + m_lo - 1) / m_lo);
+  const long long hops = (long long)(b->H - 1) + (long long)(stages - 1) * b->H;
+  return (int)((hops * wrapn::kBlock + m_lo - 1) / m_lo);
 }
 static bool rb_step(BeatriceBatch* b) {
   using namespace wrapn;
@@ -584,7 +587,7 @@ static bool rb_step(BeatriceBatch* b) {
     }
     at += take;
   }
-  if (ticks == 0 && !tick_run(b, false)) return false;   // the pipeline advances with every call
+  if (ticks == 0 && r.H == 1 && !tick_run(b, false)) return false;   // one hop per step: the pipeline advances with every call
   r.jobs.push_back(BeatriceBatch::ResidentBlocks::Job{call, r.t48, dout});
   r.t48 += m;
   r.calls = call + 1;

@@ -253,12 +253,13 @@ int BeatriceBatch_ProcessBlocksRagged(BeatriceBatch* b, const float* in, float* 
  * Binding and unbinding restart the wrapper (resampler histories, FIFO) as BeatriceBatch_ConfigureWrapper does; gains keep their state.
  * On a batch with H = 2 or 4 hops per step (BeatriceBatch_CreateBlock(..., H); BeatriceBatch_ConfigureWrapper accepts it for this
  * entry point only): the model hops the FIFOs fire are collected H at a time -- hop k of the batch is hop k mod H of step k / H --
- * and a step enters the pipeline when it is full, so every tick launch carries H hops per stream as in plain tick mode.  A call's
- * block is then out once the step of its newest hop has filled and passed the ticks: BeatriceBatch_ResidentBlocksDelay() =
- * TickStages() - 1 + the calls that bring (H - 1) x 480 inner samples (ask BeatriceBatch_ResidentBlocksDelayFor(b, n_samples) before
- * binding: n_slots >= that + 2; -1 for blocks shorter than two inner samples).  BeatriceBatch_Synchronize completes the calls whose
- * hops' steps are full; the last calls, which end on a step still filling, stay owed (BeatriceBatch_ResidentBlocksOwed, 0 at one
- * hop per step) until later calls fill it -- an offline caller ends a file with that many blocks of silence.  Same samples as one
+ * and a step enters the pipeline when it is full, so every tick launch carries H hops per stream as in plain tick mode; ticks run
+ * only then (no idle tick per call).  A call's block is out once the step of its newest hop has filled and TickStages() - 1 further
+ * steps have gone in behind it: BeatriceBatch_ResidentBlocksDelay() = the calls that bring ((H - 1) + (TickStages() - 1) x H) x 480
+ * inner samples (ask BeatriceBatch_ResidentBlocksDelayFor(b, n_samples) before binding: n_slots >= that + 2; -1 for blocks shorter
+ * than two inner samples).  BeatriceBatch_Synchronize drains the ticks and completes the calls whose hops' steps are full; the last
+ * calls, which end on a step still filling, stay owed (BeatriceBatch_ResidentBlocksOwed, 0 at one hop per step) until later calls
+ * fill it -- an offline caller ends a file with that many blocks of silence.  Same samples as one
  * hop per step. */
 int BeatriceBatch_BindResidentBlocks(BeatriceBatch* b, const float* d_in, float* d_out, int channels, int n_samples, int n_slots);
 int BeatriceBatch_ResidentBlocksDelay(const BeatriceBatch* b);
