@@ -273,6 +273,8 @@ struct BeatriceBatch {
     hipEvent_t* gain_ev = nullptr;                           // [ring]: upload of ring entry done
     long long calls = 0, t48 = 0;                            // calls so far; 48 kHz samples fed so far
     long long hops_fired = 0;                                // model hops the FIFO has fired; hop k = hop k % H of step k / H
+    long long hops_done = 0;                                 // hops of the steps fed by the end of the previous call
+    std::vector<char> ev_recorded;                           // [ring] gain_ev[i] marks the output half that read ring entry i last
     int H = 1;                                               // hops per step of the batch
     long long hops_fed() const { return hops_fired / H * H; }   // ... of which the hops of full steps are inside (or through) the ticks
     struct Job {

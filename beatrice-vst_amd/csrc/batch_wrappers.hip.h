@@ -541,60 +541,81 @@ static int rb_delay(const BeatriceBatch* b, int n) {
   const long long m_lo = (long long)std::floor(n * 48000.0 / b->wrap.rate) - 1;
   if (m_lo < 1) return -1;
   const long long hops = (long long)(b->H - 1) + (long long)(stages - 1) * b->H;
-  return (int)((hops * wrapn::kBlock + m_lo - 1) / m_lo);
+  return (int)((hops * wrapn::kBlock + m_lo - 1) / m_lo) + 1;   // (+ 1: the output half rides in the launch of the call after)
 }
 static bool rb_step(BeatriceBatch* b) {
   using namespace wrapn;
   BeatriceBatch::ResidentBlocks& r = b->rb;
-  const int B = b->B, n = r.n;
+  const int B = b->B, n = r.n, H = r.H;
   hipStream_t st = b->stream;
   WrapPlan& w = b->wrap;
   const long long call = r.calls;
   const int ge = (int)(call % r.ring);
-  // this call's gain segments: input half now, output half when its job runs
-  if (call >= r.ring && !hip_ok(hipEventSynchronize(r.gain_ev[ge]), "wrapper gain ring")) return false;
+  // this call's gain segments: input half now, output half when its job runs.  The kernels read them where they are written (pinned
+  // memory): the entry is free again once the output half that read it last has run
+  if (r.ev_recorded[ge]) { if (!hip_ok(hipEventSynchronize(r.gain_ev[ge]), "wrapper gain ring")) return false; r.ev_recorded[ge] = 0; }
   GainSeg* seg = r.h_gains + (size_t)ge * 2 * B;
   for (int s = 0; s < B; ++s) { seg[s] = b->gain_in[s].advance(n, w.rate); seg[B + s] = b->gain_out[s].advance(n, w.rate); }
-  GainSeg* dseg = r.d_gains + (size_t)ge * 2 * B;
-  BHIP_TRY(hipMemcpyAsync(dseg, seg, sizeof(GainSeg) * 2 * B, hipMemcpyHostToDevice, st));
-  BHIP_TRY(hipEventRecord(r.gain_ev[ge], st));
   const size_t nt = w.taps_down.size();
-  const Dir din = w.to_inner(n);
-  const int m = din.n_out;
+  WrapCallArgs a{};
+  a.din = w.to_inner(n);
+  const int m = a.din.n_out;
   if (m < 0 || m > kMaxSamples) return false;
   const Dir dout = w.to_outer(m);
   if (dout.n_out != n) return false;
-  const float* src = r.d_in + (size_t)(call % r.n_slots) * B * r.channels * n;
-  hipLaunchKernelGGL(wrap_in_kernel, dim3(B), dim3(256), 0, st, src, r.channels, n, b->d_wrap, dseg, b->d_wrap_taps + (din.decimate ? 0 : nt), din,
-                     b->d_wrap_inner, kInnerStride);
-  int ticks = 0;
-  for (int at = 0; at < m;) {  // the 480-sample accumulation; a model hop every time it fills (the per-stream FIFO array holds it)
+  a.src = r.d_in + (size_t)(call % r.n_slots) * B * r.channels * n;
+  a.channels = r.channels; a.n = n; a.st = b->d_wrap; a.gain_in = seg; a.taps_in = b->d_wrap_taps + (a.din.decimate ? 0 : nt);
+  a.inner = b->d_wrap_inner; a.stride = kInnerStride; a.in16 = r.d_in16; a.row16 = H * B_IN_HOP; a.B = B; a.H = H;
+  // the 480-sample accumulation; a model hop every time it fills (the per-stream FIFO array holds it), into its place: hop
+  // hops_fired % H of the step that goes in next -- the steps this call fills take the resident slots from io_host on
+  int steps = 0, slot = b->io_host;
+  for (int at = 0; at < m;) {
     const int take = std::min(kBlock - w.fill, m - at);
     const int fires = w.fill + take == kBlock ? 1 : 0;
-    // (the hop's place: hop hops_fired % H of the step that goes in next, slot io_host)
-    const int H = r.H, h = (int)(r.hops_fired % H);
-    hipLaunchKernelGGL(wrap_fifo_kernel, dim3(B), dim3(256), 0, st, b->d_wrap_inner, kInnerStride, b->d_wrap, at, w.fill, take, fires,
-                       r.d_in16 + ((size_t)b->io_host * B * H + h) * B_IN_HOP, H * B_IN_HOP);
+    if (a.n_chunks >= kMaxChunks) return false;
+    const int c = a.n_chunks++;
+    a.at[c] = (short)at; a.fill[c] = (short)w.fill; a.take[c] = (short)take; a.fires[c] = (unsigned char)fires;
+    a.in16_off[c] = (long long)((size_t)slot * B * H + (size_t)(r.hops_fired % H)) * B_IN_HOP;
     if (fires) {
       ++r.hops_fired;
-      if (h == H - 1) {   // the step is full: into the pipeline
-        if (!tick_run(b, true)) return false;
-        ++ticks;
-      }
+      if (r.hops_fired % H == 0) { ++steps; slot = (slot + 1) % r.io_slots; }   // the step is full
       w.fill = 0;
     } else {
       w.fill += take;
     }
     at += take;
   }
-  if (ticks == 0 && r.H == 1 && !tick_run(b, false)) return false;   // one hop per step: the pipeline advances with every call
+  // several hops per step: the output half of the oldest call that is due rides in this launch (its hops left the ticks with the
+  // previous call at the latest: `delay` counts this call)
+  const BeatriceBatch::ResidentBlocks::Job* due = nullptr;
+  if (H > 1 && !r.jobs.empty() && r.jobs.front().call + r.delay <= call && r.jobs.front().last_hop() < r.hops_done) due = &r.jobs.front();
+  int due_ge = -1;
+  if (due) {
+    due_ge = (int)(due->call % r.ring);
+    a.n_post = B; a.out24 = r.d_out24; a.io_slots = r.io_slots; a.t0 = due->t0; a.gain_out = r.h_gains + (size_t)due_ge * 2 * B + B;
+    a.taps_out = b->d_wrap_taps + (due->dout.decimate ? 0 : nt); a.dout = due->dout;
+    a.out = r.d_out + (size_t)(due->call % r.n_slots) * B * r.channels * n;
+  }
+  hipLaunchKernelGGL(wrap_call_kernel, dim3(B + a.n_post), dim3(256), 0, st, a);
+  if (due) {
+    if (!hip_ok(hipEventRecord(r.gain_ev[due_ge], st), "wrapper gain event")) return false;
+    r.ev_recorded[due_ge] = 1;
+    r.jobs.pop_front();
+  }
+  // (never more than one call comes due per call under the bind-time bound; should the queue have fallen behind, the rest follow here)
+  while (H > 1 && !r.jobs.empty() && r.jobs.front().call + r.delay <= call && r.jobs.front().last_hop() < r.hops_done) {
+    if (!rb_post(b, r.jobs.front())) return false;
+    r.jobs.pop_front();
+  }
+  for (int i = 0; i < steps; ++i) if (!tick_run(b, true)) return false;   // the full steps: into the pipeline
+  if (steps == 0 && H == 1 && !tick_run(b, false)) return false;          // one hop per step: the pipeline advances with every call
+  r.hops_done = r.hops_fed();
   r.jobs.push_back(BeatriceBatch::ResidentBlocks::Job{call, r.t48, dout});
   r.t48 += m;
   r.calls = call + 1;
-  bool ok = true;
-  // (after `delay` calls a call's hops are out -- at several hops per step under the bind-time bound on the calls that fill a step;
-  // calls that a drained point left owed come out here too, in order)
-  while (ok && !r.jobs.empty() && r.jobs.front().call + r.delay <= call && r.jobs.front().last_hop() < r.hops_fed()) {
+  bool ok = hip_ok(hipGetLastError(), "wrapper launch");
+  // one hop per step: after `delay` calls a call's hops are out, its output half runs behind this call's tick
+  while (ok && H == 1 && !r.jobs.empty() && r.jobs.front().call + r.delay <= call) {
     ok = rb_post(b, r.jobs.front());
     r.jobs.pop_front();
   }
@@ -634,11 +655,11 @@ int BeatriceBatch_BindResidentBlocks(BeatriceBatch* b, const float* d_in, float*
             hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_out24), sizeof(float) * r.io_slots * B * H * B_OUT_HOP), "rb out24") &&
             hip_ok(hipMemset(r.d_in16, 0, sizeof(float) * r.io_slots * B * H * B_IN_HOP), "rb zero") &&
             hip_ok(hipMemset(r.d_out24, 0, sizeof(float) * r.io_slots * B * H * B_OUT_HOP), "rb zero") &&
-            hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_gains), sizeof(wrapn::GainSeg) * r.ring * 2 * B), "rb gains") &&
             hip_ok(hipHostMalloc(reinterpret_cast<void**>(&r.h_gains), sizeof(wrapn::GainSeg) * r.ring * 2 * B, hipHostMallocDefault), "rb gains host");
   if (ok) {
     r.gain_ev = new hipEvent_t[r.ring]();
     for (int i = 0; i < r.ring && ok; ++i) ok = hip_ok(hipEventCreateWithFlags(&r.gain_ev[i], hipEventDisableTiming), "rb event");
+    r.ev_recorded.assign(r.ring, 0);
   }
   ok = ok && hip_ok(hipDeviceSynchronize(), "rb sync") && BeatriceBatch_BindResidentIO(b, r.d_in16, r.d_out24, r.io_slots) == 0 && tick_enable(b, true) == 0;
   if (!ok) {

@@ -26,6 +26,7 @@ namespace wrapn {
 constexpr int kTapsPerOutput = 32;   // filter length in low-rate samples (reference resample.h:415)
 constexpr int kBlock = 480;          // 10 ms at 48 kHz
 constexpr int kMaxSamples = 4096;    // largest host block per call
+constexpr int kMaxChunks = 12;      // FIFO pieces one call can cut its inner samples into: ceil(4096 / 480) + 2
 constexpr int kMaxHist = kTapsPerOutput * 8 + 1;   // history of the high-rate side: 32 * hi / lo + 1, host rates up to 384 kHz
 
 struct GainSeg { double amp0, goal, step; };   // per stream and call: amplitude before the first sample, goal, per-sample factor
@@ -72,12 +73,10 @@ __device__ __forceinline__ float resample_one(const Dir& d, const float* __restr
 }
 
 // host block -> 48 kHz: downmix, input gain, first resampling direction.  One workgroup per stream.
-static __global__ __launch_bounds__(256) void wrap_in_kernel(const float* __restrict__ in, const int channels, const int n, StreamState* __restrict__ st,
-                                                             const GainSeg* __restrict__ gain, const float* __restrict__ taps, const Dir d,
-                                                             float* __restrict__ inner /* [B][stride] */, const int stride) {
-  __shared__ float x[kMaxHist + kMaxSamples];
-  __shared__ double amp[kMaxSamples];
-  const int b = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void wrap_in_body(float* __restrict__ x /* LDS [kMaxHist + kMaxSamples] */, double* __restrict__ amp /* LDS [kMaxSamples] */,
+                                             const int b, const int tid, const float* __restrict__ in, const int channels, const int n,
+                                             StreamState* __restrict__ st, const GainSeg* __restrict__ gain, const float* __restrict__ taps, const Dir& d,
+                                             float* __restrict__ inner /* [B][stride] */, const int stride) {
   const float* src = in + (size_t)b * channels * n;
   float* hist = d.decimate ? st[b].hist_high : st[b].hist_low;
   const GainSeg g = gain[b];
@@ -101,6 +100,13 @@ static __global__ __launch_bounds__(256) void wrap_in_kernel(const float* __rest
   for (int o = tid; o < d.n_out; o += 256) inner[(size_t)b * stride + o] = resample_one(d, x, taps, o);
   __syncthreads();
   for (int i = tid; i < d.hist; i += 256) hist[i] = x[n + i];  // the newest `hist` samples
+}
+static __global__ __launch_bounds__(256) void wrap_in_kernel(const float* __restrict__ in, const int channels, const int n, StreamState* __restrict__ st,
+                                                             const GainSeg* __restrict__ gain, const float* __restrict__ taps, const Dir d,
+                                                             float* __restrict__ inner /* [B][stride] */, const int stride) {
+  __shared__ float x[kMaxHist + kMaxSamples];
+  __shared__ double amp[kMaxSamples];
+  wrap_in_body(x, amp, blockIdx.x, threadIdx.x, in, channels, n, st, gain, taps, d, inner, stride);
 }
 
 // 48 kHz -> host block: second direction, output gain, every channel
@@ -140,12 +146,11 @@ static __global__ __launch_bounds__(256) void wrap_out_kernel(const float* __res
 // [t0, t0 + m) are gathered straight from the resident model outputs (hop k in slot k mod io_slots) once those hops have
 // left the pipeline, and go through the second resampling direction and the output gain exactly as in wrap_out_kernel.
 // H hops per step (a batch of BeatriceBatch_CreateBlock): hop k is hop k % H of step k / H, in slot (k / H) mod io_slots.
-static __global__ __launch_bounds__(256) void wrap_post_kernel(const float* __restrict__ out24 /* [io_slots][B][H][240] */, const int io_slots, const int B, const int H,
-                                                               const long long t0, StreamState* __restrict__ st, const GainSeg* __restrict__ gain,
-                                                               const float* __restrict__ taps, const Dir d, float* __restrict__ out, const int channels) {
-  __shared__ float x[kMaxHist + kMaxSamples];
-  __shared__ double amp[kMaxSamples];
-  const int b = blockIdx.x, tid = threadIdx.x, n = d.n_out;
+__device__ __forceinline__ void wrap_post_body(float* __restrict__ x, double* __restrict__ amp, const int b, const int tid,
+                                               const float* __restrict__ out24 /* [io_slots][B][H][240] */, const int io_slots, const int B, const int H,
+                                               const long long t0, StreamState* __restrict__ st, const GainSeg* __restrict__ gain,
+                                               const float* __restrict__ taps, const Dir& d, float* __restrict__ out, const int channels) {
+  const int n = d.n_out;
   float* hist = d.decimate ? st[b].hist_high_out : st[b].hist_low_out;
   const GainSeg g = gain[b];
   if (tid == 0 && g.step != 1.0) {
@@ -174,14 +179,20 @@ static __global__ __launch_bounds__(256) void wrap_post_kernel(const float* __re
   __syncthreads();
   for (int i = tid; i < d.hist; i += 256) hist[i] = x[d.n_in + i];
 }
+static __global__ __launch_bounds__(256) void wrap_post_kernel(const float* __restrict__ out24 /* [io_slots][B][H][240] */, const int io_slots, const int B, const int H,
+                                                               const long long t0, StreamState* __restrict__ st, const GainSeg* __restrict__ gain,
+                                                               const float* __restrict__ taps, const Dir d, float* __restrict__ out, const int channels) {
+  __shared__ float x[kMaxHist + kMaxSamples];
+  __shared__ double amp[kMaxSamples];
+  wrap_post_body(x, amp, blockIdx.x, threadIdx.x, out24, io_slots, B, H, t0, st, gain, taps, d, out, channels);
+}
 
 // The exact-480 FIFO (reference resample.h:343-363): samples [at, at + take) of the 48 kHz stream swap places with
 // FIFO positions [fill, fill + take) -- the stream gets what the previous block left there (its processed output), the
 // FIFO gets the new input.  When that completes the block (fires != 0) every third sample goes to the model's input
 // (in16: the hop's place in the first stream's row of the step's slot, row16 floats per stream: 160 x hops per step).
-static __global__ __launch_bounds__(256) void wrap_fifo_kernel(float* __restrict__ inner, const int stride, StreamState* __restrict__ st, const int at,
-                                                               const int fill, const int take, const int fires, float* __restrict__ in16, const int row16) {
-  const int b = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void wrap_fifo_body(const int b, const int tid, float* __restrict__ inner, const int stride, StreamState* __restrict__ st, const int at,
+                                               const int fill, const int take, const int fires, float* __restrict__ in16, const int row16) {
   float* f = st[b].fifo;
   for (int i = tid; i < take; i += 256) {
     const float fresh = inner[(size_t)b * stride + at + i];
@@ -191,6 +202,48 @@ static __global__ __launch_bounds__(256) void wrap_fifo_kernel(float* __restrict
   if (!fires) return;
   __syncthreads();
   for (int i = tid; i < 160; i += 256) in16[(size_t)b * row16 + i] = f[3 * i + 2];
+}
+static __global__ __launch_bounds__(256) void wrap_fifo_kernel(float* __restrict__ inner, const int stride, StreamState* __restrict__ st, const int at,
+                                                               const int fill, const int take, const int fires, float* __restrict__ in16, const int row16) {
+  wrap_fifo_body(blockIdx.x, threadIdx.x, inner, stride, st, at, fill, take, fires, in16, row16);
+}
+// One launch per call of the wrapper around the tick pipeline (BeatriceBatch_BindResidentBlocks): workgroups [0, B) run the call's
+// input half -- gains, first resampling direction, then every piece the 480-sample FIFO cuts the inner samples into, each fired hop
+// straight into its place of its step's resident slot (the pieces only move wrapper state: none depends on a tick) --, workgroups
+// [B, 2 B) the output half of the call made `delay` calls ago (n_post = 0: none is due).  The gain segments are read where the host
+// wrote them (pinned memory): no copy command.  Three to four launches and a copy per call were serial with the tick launch before.
+struct WrapCallArgs {
+  const float* src; int channels, n;
+  StreamState* st;
+  const GainSeg* gain_in;
+  const float* taps_in; Dir din;
+  float* inner; int stride;
+  int n_chunks;
+  short at[kMaxChunks], fill[kMaxChunks], take[kMaxChunks];
+  unsigned char fires[kMaxChunks];
+  long long in16_off[kMaxChunks];   // floats from in16 to the hop's place in the first stream's row of its slot
+  float* in16; int row16;
+  int n_post;
+  const float* out24; int io_slots, B, H;
+  long long t0;
+  const GainSeg* gain_out;
+  const float* taps_out; Dir dout;
+  float* out;
+};
+static __global__ __launch_bounds__(256) void wrap_call_kernel(const WrapCallArgs a) {
+  __shared__ float x[kMaxHist + kMaxSamples];
+  __shared__ double amp[kMaxSamples];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < a.B) {
+    const int b = blockIdx.x;
+    wrap_in_body(x, amp, b, tid, a.src, a.channels, a.n, a.st, a.gain_in, a.taps_in, a.din, a.inner, a.stride);
+    for (int c = 0; c < a.n_chunks; ++c) {
+      __syncthreads();   // (the pieces follow each other in the stream's inner samples and its FIFO)
+      wrap_fifo_body(b, tid, a.inner, a.stride, a.st, a.at[c], a.fill[c], a.take[c], a.fires[c], a.in16 + a.in16_off[c], a.row16);
+    }
+  } else {
+    wrap_post_body(x, amp, (int)blockIdx.x - a.B, tid, a.out24, a.io_slots, a.B, a.H, a.t0, a.st, a.gain_out, a.taps_out, a.dout, a.out, a.channels);
+  }
 }
 // the model's 240 samples, zero-stuffed, become the FIFO's content (reference resample.h:390-393)
 static __global__ void wrap_refill_kernel(StreamState* __restrict__ st, const float* __restrict__ out24, const int B) {
@@ -205,7 +258,6 @@ static __global__ void wrap_refill_kernel(StreamState* __restrict__ st, const fl
 // plugin instance (src/common/resample.h:401-438, processor_core_2.h:28) -- and may sit a call out altogether (no block, or
 // a block the shell's rule calls silent: src/vst/processor.cc:204-214).  Control stays on the host, now per stream; the
 // kernels read a per-stream record instead of one set of arguments.
-constexpr int kMaxChunks = 12;   // FIFO pieces one call can cut a stream's inner samples into: ceil(4096 / 480) + 2
 struct RagStream {
   Dir din, dout;                 // this call's two directions (n_in == 0: the stream sits the call out)
   long long io_off;              // floats from the start of the call's buffers to this stream's planar block [channels][n]

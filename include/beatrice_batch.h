@@ -256,7 +256,7 @@ int BeatriceBatch_ProcessBlocksRagged(BeatriceBatch* b, const float* in, float* 
  * and a step enters the pipeline when it is full, so every tick launch carries H hops per stream as in plain tick mode; ticks run
  * only then (no idle tick per call).  A call's block is out once the step of its newest hop has filled and TickStages() - 1 further
  * steps have gone in behind it: BeatriceBatch_ResidentBlocksDelay() = the calls that bring ((H - 1) + (TickStages() - 1) x H) x 480
- * inner samples (ask BeatriceBatch_ResidentBlocksDelayFor(b, n_samples) before binding: n_slots >= that + 2; -1 for blocks shorter
+ * inner samples, + 1 (the output half rides in the next call's launch: one launch per call beside the tick launches) (ask BeatriceBatch_ResidentBlocksDelayFor(b, n_samples) before binding: n_slots >= that + 2; -1 for blocks shorter
  * than two inner samples).  BeatriceBatch_Synchronize drains the ticks and completes the calls whose hops' steps are full; the last
  * calls, which end on a step still filling, stay owed (BeatriceBatch_ResidentBlocksOwed, 0 at one hop per step) until later calls
  * fill it -- an offline caller ends a file with that many blocks of silence.  Same samples as one
