@@ -269,8 +269,8 @@ struct BeatriceBatch {
     const float* d_in = nullptr;   // [n_slots][B][channels][n]
     float* d_out = nullptr;        // [n_slots][B][channels][n]
     float *d_in16 = nullptr, *d_out24 = nullptr;   // [io_slots][B][H][160], [io_slots][B][H][240]: the resident I/O of the ticks
-    wrapn::GainSeg *d_gains = nullptr, *h_gains = nullptr;   // [ring][2][B]: a call's input | output segments, until its output half has run
-    hipEvent_t* gain_ev = nullptr;                           // [ring]: upload of ring entry done
+    wrapn::GainSeg* h_gains = nullptr;                       // [ring][2][B] pinned: a call's input | output segments, read by the kernels in place
+    hipEvent_t* gain_ev = nullptr;                           // [ring]: the output half that read ring entry i has run
     long long calls = 0, t48 = 0;                            // calls so far; 48 kHz samples fed so far
     long long hops_fired = 0;                                // model hops the FIFO has fired; hop k = hop k % H of step k / H
     long long hops_done = 0;                                 // hops of the steps fed by the end of the previous call
@@ -287,7 +287,7 @@ struct BeatriceBatch {
     // half has run; slot_map[b][g mod map_ring] = the resident slot of the step that stream b's hop g rode in
     bool ragged = false;
     int max_samples = 0, cell = 0, map_ring = 0;
-    wrapn::RagStream *d_rs = nullptr, *h_rs = nullptr;       // [ring][B]
+    wrapn::RagStream* h_rs = nullptr;                        // [ring][B] pinned, read by the kernels in place
     int* d_map = nullptr;                                    // [B][map_ring]
     std::vector<long long> t48_s;                            // [B] 48 kHz samples of the stream fed so far
     std::vector<int> hops_s;                                 // [B] model hops the stream has fired

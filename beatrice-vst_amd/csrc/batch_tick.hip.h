@@ -557,15 +557,15 @@ bool rb_post(BeatriceBatch* b, const BeatriceBatch::ResidentBlocks::Job& j) {
   const int slot = (int)(j.call % r.n_slots), ge = (int)(j.call % r.ring);
   if (r.ragged)   // clocks per stream: the call's records name every stream's directions, sample count and block
     hipLaunchKernelGGL(wrapn::wrapr_post_kernel, dim3(b->B), dim3(256), 0, b->stream, r.d_out24, b->B, r.d_map, r.map_ring, b->d_wrap,
-                       r.d_gains + (size_t)ge * 2 * b->B + b->B, b->rw.d_taps, r.d_rs + (size_t)ge * b->B,
+                       r.h_gains + (size_t)ge * 2 * b->B + b->B, b->rw.d_taps, r.h_rs + (size_t)ge * b->B,
                        r.d_out + (size_t)slot * b->B * r.cell, r.channels);
-  else {   // (the gain segments where the host wrote them: pinned memory; the event frees the ring entry for the host)
+  else   // (the gain segments where the host wrote them: pinned memory)
     hipLaunchKernelGGL(wrapn::wrap_post_kernel, dim3(b->B), dim3(256), 0, b->stream, r.d_out24, r.io_slots, b->B, b->H, j.t0, b->d_wrap,
                        r.h_gains + (size_t)ge * 2 * b->B + b->B, b->d_wrap_taps + (j.dout.decimate ? 0 : nt), j.dout,
                        r.d_out + (size_t)slot * b->B * r.channels * r.n, r.channels);
-    if (!hip_ok(hipEventRecord(r.gain_ev[ge], b->stream), "wrapper gain event")) return false;
-    r.ev_recorded[ge] = 1;
-  }
+  // (the event frees the ring entry for the host)
+  if (!hip_ok(hipEventRecord(r.gain_ev[ge], b->stream), "wrapper gain event")) return false;
+  r.ev_recorded[ge] = 1;
   return hip_ok(hipGetLastError(), "wrapper output half");
 }
 bool tick_drain(BeatriceBatch* b) {

@@ -503,10 +503,8 @@ static void rb_release(BeatriceBatch* b) {
   BeatriceBatch::ResidentBlocks& r = b->rb;
   if (r.d_in16) (void)hipFree(r.d_in16);
   if (r.d_out24) (void)hipFree(r.d_out24);
-  if (r.d_gains) (void)hipFree(r.d_gains);
   if (r.h_gains) (void)hipHostFree(r.h_gains);
   if (r.gain_ev) { for (int i = 0; i < r.ring; ++i) if (r.gain_ev[i]) (void)hipEventDestroy(r.gain_ev[i]); delete[] r.gain_ev; }
-  if (r.d_rs) (void)hipFree(r.d_rs);
   if (r.h_rs) (void)hipHostFree(r.h_rs);
   if (r.d_map) (void)hipFree(r.d_map);
   r = BeatriceBatch::ResidentBlocks{};
@@ -690,7 +688,9 @@ static int rbr_step(BeatriceBatch* b, const int* n_samples) {
   }
   const long long call = r.calls;
   const int ge = (int)(call % r.ring);
-  if (call >= r.ring && !hip_ok(hipEventSynchronize(r.gain_ev[ge]), "wrapper record ring")) return -2;
+  // (records and gain segments are read by the kernels where they are written, pinned memory: the ring entry is free again once the
+  //  output half that read it last has run)
+  if (r.ev_recorded[ge]) { if (!hip_ok(hipEventSynchronize(r.gain_ev[ge]), "wrapper record ring")) return -2; r.ev_recorded[ge] = 0; }
   RagStream* rs = r.h_rs + (size_t)ge * B;
   GainSeg* seg = r.h_gains + (size_t)ge * 2 * B;
   // all or nothing, as BeatriceBatch_ProcessBlocksRagged: a plan that does not fit puts every clock of the call back
@@ -719,27 +719,31 @@ static int rbr_step(BeatriceBatch* b, const int* n_samples) {
     r.t48_s[s] += rs[s].din.n_out;
     for (int c = 0; c < rs[s].n_chunks; ++c) r.hops_s[s] += rs[s].fires[c];
   }
-  RagStream* d_rs = r.d_rs + (size_t)ge * B;
-  GainSeg* dseg = r.d_gains + (size_t)ge * 2 * B;
-  if (!hip_ok(hipMemcpyAsync(d_rs, rs, sizeof(RagStream) * B, hipMemcpyHostToDevice, st), "wrapper records up") ||
-      !hip_ok(hipMemcpyAsync(dseg, seg, sizeof(GainSeg) * 2 * B, hipMemcpyHostToDevice, st), "wrapper gains up") ||
-      !hip_ok(hipEventRecord(r.gain_ev[ge], st), "wrapper record event"))
-    return -2;
-  const float* src = r.d_in + (size_t)(call % r.n_slots) * B * r.cell;
-  hipLaunchKernelGGL(wrapr_in_kernel, dim3(B), dim3(256), 0, st, src, r.channels, b->d_wrap, dseg, rw.d_taps, d_rs, b->d_wrap_inner, kInnerStride);
+  // one launch for every stream's input half and FIFO pieces; piece c belongs to the c-th step this call feeds (if any stream fires in
+  // it), which takes the next resident slot
+  WraprCallArgs a{};
+  a.in = r.d_in + (size_t)(call % r.n_slots) * B * r.cell; a.channels = r.channels; a.st = b->d_wrap; a.gain = seg; a.taps_all = rw.d_taps;
+  a.rs = rs; a.inner = b->d_wrap_inner; a.stride = kInnerStride; a.in16 = r.d_in16; a.B = B; a.slot_map = r.d_map; a.map_ring = r.map_ring;
+  bool fire_at[kMaxChunks] = {};
+  {
+    int slot = b->io_host;
+    for (int ci = 0; ci < max_chunks; ++ci) {
+      for (int s = 0; s < B && !fire_at[ci]; ++s) fire_at[ci] = rs[s].active && ci < rs[s].n_chunks && rs[s].fires[ci];
+      a.slot[ci] = slot;
+      if (fire_at[ci]) slot = (slot + 1) % r.io_slots;
+    }
+  }
+  hipLaunchKernelGGL(wrapr_call_kernel, dim3(B), dim3(256), 0, st, a);
   BeatriceBatch::SilentRule& sr = b->silent;
   int ticks = 0;
   for (int ci = 0; ci < max_chunks; ++ci) {
-    bool any_fire = false, any_out = false;
+    if (!fire_at[ci]) continue;
+    bool any_out = false;
     for (int s = 0; s < B; ++s) {
       const bool fires = rs[s].active && ci < rs[s].n_chunks && rs[s].fires[ci];
       sr.next[s] = fires ? 0 : 1;
-      any_fire = any_fire || fires;
       any_out = any_out || !fires;
     }
-    hipLaunchKernelGGL(wrapr_fifo_kernel, dim3(B), dim3(256), 0, st, b->d_wrap_inner, kInnerStride, b->d_wrap, d_rs, ci,
-                       r.d_in16 + (size_t)b->io_host * B * B_IN_HOP, nullptr, r.d_map, r.map_ring, b->io_host);
-    if (!any_fire) { std::fill(sr.next.begin(), sr.next.end(), 0); continue; }
     sr.any_next = any_out;   // (tick_run: the flagged streams sit this step out, and clears the flags)
     if (!tick_run(b, true)) return -2;
     std::fill(sr.next.begin(), sr.next.end(), 0);
@@ -797,15 +801,14 @@ int BeatriceBatch_BindResidentBlocksRagged(BeatriceBatch* b, const float* d_in, 
             hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_out24), sizeof(float) * r.io_slots * B * B_OUT_HOP), "rb out24") &&
             hip_ok(hipMemset(r.d_in16, 0, sizeof(float) * r.io_slots * B * B_IN_HOP), "rb zero") &&
             hip_ok(hipMemset(r.d_out24, 0, sizeof(float) * r.io_slots * B * B_OUT_HOP), "rb zero") &&
-            hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_gains), sizeof(wrapn::GainSeg) * r.ring * 2 * B), "rb gains") &&
             hip_ok(hipHostMalloc(reinterpret_cast<void**>(&r.h_gains), sizeof(wrapn::GainSeg) * r.ring * 2 * B, hipHostMallocDefault), "rb gains host") &&
-            hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_rs), sizeof(wrapn::RagStream) * r.ring * B), "rb records") &&
             hip_ok(hipHostMalloc(reinterpret_cast<void**>(&r.h_rs), sizeof(wrapn::RagStream) * r.ring * B, hipHostMallocDefault), "rb records host") &&
             hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_map), sizeof(int) * B * r.map_ring), "rb slot map") &&
             hip_ok(hipMemset(r.d_map, 0, sizeof(int) * B * r.map_ring), "rb slot map zero");
   if (ok) {
     r.gain_ev = new hipEvent_t[r.ring]();
     for (int i = 0; i < r.ring && ok; ++i) ok = hip_ok(hipEventCreateWithFlags(&r.gain_ev[i], hipEventDisableTiming), "rb event");
+    r.ev_recorded.assign(r.ring, 0);
   }
   ok = ok && hip_ok(hipDeviceSynchronize(), "rb sync") && BeatriceBatch_BindResidentIO(b, r.d_in16, r.d_out24, r.io_slots) == 0 && tick_enable(b, true) == 0;
   if (!ok) {

@@ -273,13 +273,9 @@ struct RagStream {
   long long t0;
 };
 
-static __global__ __launch_bounds__(256) void wrapr_in_kernel(const float* __restrict__ in, const int channels, StreamState* __restrict__ st,
-                                                              const GainSeg* __restrict__ gain, const float* __restrict__ taps_all,
-                                                              const RagStream* __restrict__ rs, float* __restrict__ inner, const int stride) {
-  __shared__ float x[kMaxHist + kMaxSamples];
-  __shared__ double amp[kMaxSamples];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const RagStream r = rs[b];
+__device__ __forceinline__ void wrapr_in_body(float* __restrict__ x, double* __restrict__ amp, const int b, const int tid, const float* __restrict__ in,
+                                              const int channels, StreamState* __restrict__ st, const GainSeg* __restrict__ gain,
+                                              const float* __restrict__ taps_all, const RagStream& r, float* __restrict__ inner, const int stride) {
   if (!r.active) return;
   const Dir d = r.din;
   const int n = r.n;
@@ -307,6 +303,14 @@ static __global__ __launch_bounds__(256) void wrapr_in_kernel(const float* __res
   for (int o = tid; o < d.n_out; o += 256) inner[(size_t)b * stride + o] = resample_one(d, x, taps, o);
   __syncthreads();
   for (int i = tid; i < d.hist; i += 256) hist[i] = x[n + i];
+}
+static __global__ __launch_bounds__(256) void wrapr_in_kernel(const float* __restrict__ in, const int channels, StreamState* __restrict__ st,
+                                                              const GainSeg* __restrict__ gain, const float* __restrict__ taps_all,
+                                                              const RagStream* __restrict__ rs, float* __restrict__ inner, const int stride) {
+  __shared__ float x[kMaxHist + kMaxSamples];
+  __shared__ double amp[kMaxSamples];
+  const RagStream r = rs[blockIdx.x];
+  wrapr_in_body(x, amp, blockIdx.x, threadIdx.x, in, channels, st, gain, taps_all, r, inner, stride);
 }
 static __global__ __launch_bounds__(256) void wrapr_out_kernel(const float* __restrict__ inner, const int stride, StreamState* __restrict__ st,
                                                                const GainSeg* __restrict__ gain, const float* __restrict__ taps_all,
@@ -349,12 +353,9 @@ static __global__ __launch_bounds__(256) void wrapr_out_kernel(const float* __re
 // model step that follows stands still for them); in16: the step's input.  Around the tick pipeline (slot_map != nullptr): the hop a
 // stream fires here is the stream's hop number g = hop0 + its fires in earlier chunks, and the step it rides in is the one in resident
 // slot `slot`: slot_map[b][g mod map_ring] = slot, for the output half of the calls that will read that hop (wrapr_post_kernel).
-static __global__ __launch_bounds__(256) void wrapr_fifo_kernel(float* __restrict__ inner, const int stride, StreamState* __restrict__ st,
-                                                                const RagStream* __restrict__ rs, const int ci, float* __restrict__ in16,
-                                                                unsigned char* __restrict__ frozen, int* __restrict__ slot_map, const int map_ring,
-                                                                const int slot) {
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const RagStream& r = rs[b];
+__device__ __forceinline__ void wrapr_fifo_body(const int b, const int tid, float* __restrict__ inner, const int stride, StreamState* __restrict__ st,
+                                                const RagStream& r, const int ci, float* __restrict__ in16, unsigned char* __restrict__ frozen,
+                                                int* __restrict__ slot_map, const int map_ring, const int slot) {
   const bool has = r.active && ci < r.n_chunks;
   const bool fires = has && r.fires[ci];
   if (frozen != nullptr && tid == 0) frozen[b] = fires ? 0 : 1;
@@ -374,6 +375,39 @@ static __global__ __launch_bounds__(256) void wrapr_fifo_kernel(float* __restric
   if (!fires) return;
   __syncthreads();
   for (int i = tid; i < 160; i += 256) in16[(size_t)b * 160 + i] = f[3 * i + 2];
+}
+static __global__ __launch_bounds__(256) void wrapr_fifo_kernel(float* __restrict__ inner, const int stride, StreamState* __restrict__ st,
+                                                                const RagStream* __restrict__ rs, const int ci, float* __restrict__ in16,
+                                                                unsigned char* __restrict__ frozen, int* __restrict__ slot_map, const int map_ring,
+                                                                const int slot) {
+  wrapr_fifo_body(blockIdx.x, threadIdx.x, inner, stride, st, rs[blockIdx.x], ci, in16, frozen, slot_map, map_ring, slot);
+}
+// One launch for the input half of a call with per-stream clocks around the tick pipeline: a stream's gains and first resampling
+// direction, then every piece ITS FIFO cuts its inner samples into (the pieces only move wrapper state; the steps they fill are fed
+// after the launch); piece c of any stream belongs to the call's c-th step, whose resident slot is slot[c].  Records and gain segments
+// are read where the host wrote them (pinned memory).
+struct WraprCallArgs {
+  const float* in; int channels;
+  StreamState* st;
+  const GainSeg* gain;
+  const float* taps_all;
+  const RagStream* rs;
+  float* inner; int stride;
+  float* in16; int B;
+  int slot[kMaxChunks];
+  int* slot_map; int map_ring;
+};
+static __global__ __launch_bounds__(256) void wrapr_call_kernel(const WraprCallArgs a) {
+  __shared__ float x[kMaxHist + kMaxSamples];
+  __shared__ double amp[kMaxSamples];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const RagStream r = a.rs[b];
+  if (!r.active) return;
+  wrapr_in_body(x, amp, b, tid, a.in, a.channels, a.st, a.gain, a.taps_all, r, a.inner, a.stride);
+  for (int c = 0; c < r.n_chunks; ++c) {
+    __syncthreads();
+    wrapr_fifo_body(b, tid, a.inner, a.stride, a.st, r, c, a.in16 + (size_t)a.slot[c] * a.B * 160, nullptr, a.slot_map, a.map_ring, a.slot[c]);
+  }
 }
 // The output half of a call with per-stream clocks around the tick pipeline: as wrap_post_kernel, with the stream's own sample
 // count t0 and its own hops -- 48 kHz sample t of stream b is sample t % 480 of the zero-stuffed output of ITS hop t / 480 - 1, which
