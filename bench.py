@@ -348,6 +348,57 @@ def host_buffer_rate(bv, models, product, streams, steps=200):
     return res
 
 
+def wrapper_around_ticks(bv, models, product, torch, streams, calls=400):
+    """The reference's whole per-instance wrapper (any host rate, gains, FIFO: processor_core_2.cc:24-48) around the tick pipeline with
+    resident host-rate blocks: 44.1 kHz callers with 10 ms blocks on a batch of four hops per step (BeatriceBatch_BindResidentBlocks), and
+    callers at four different rates with clocks per stream (BeatriceBatch_BindResidentBlocksRagged, one hop per step).  Drain inside
+    the timed region; frames = 10 ms model hops."""
+    import ctypes as C
+    res = {}
+    sr, block, H = 44100, 441, 4
+    batch = bv.Batch(models, streams, hops_per_step=H)
+    product.BeatriceBatch_FlushSpeaker(batch.h, -1)
+    if product.BeatriceBatch_ConfigureWrapper(batch.h, float(sr)) == 0:
+        delay = int(product.BeatriceBatch_ResidentBlocksDelayFor(batch.h, block))
+        slots = delay + 8
+        d_in = (0.1 * torch.randn((slots, streams, 1, block), device="cuda")).contiguous()
+        d_out = torch.zeros_like(d_in)
+        if product.BeatriceBatch_BindResidentBlocks(batch.h, d_in.data_ptr(), d_out.data_ptr(), 1, block, slots) == 0:
+            for timed in (False, True):
+                t0 = time.perf_counter()
+                for _ in range(calls):
+                    product.BeatriceBatch_ProcessBlocksDevice(batch.h, None, None, 1, block)
+                product.BeatriceBatch_Synchronize(batch.h)
+                dt = time.perf_counter() - t0
+            res["uniform_44k1_four_hops_per_step"] = {"frames_per_s": round(streams * calls * block * 100.0 / sr / dt, 1), "ms_per_call": round(dt / calls * 1e3, 4),
+                                                      "calls": calls, "block": block, "delay_calls": delay}
+            product.BeatriceBatch_BindResidentBlocks(batch.h, None, None, 0, 0, 0)
+        del d_in, d_out
+    batch.close()
+    rates = [(44100.0, 441), (48000.0, 480), (96000.0, 960), (32000.0, 320)]
+    batch = bv.Batch(models, streams)
+    product.BeatriceBatch_FlushSpeaker(batch.h, -1)
+    rs = (C.c_double * streams)(*[rates[s % 4][0] for s in range(streams)])
+    ns = (C.c_int * streams)(*[rates[s % 4][1] for s in range(streams)])
+    if product.BeatriceBatch_ConfigureWrapperRates(batch.h, rs) == 0:
+        slots, cap = int(product.BeatriceBatch_TickStages(batch.h)) + 8, 960
+        d_in = (0.1 * torch.randn((slots, streams, cap), device="cuda")).contiguous()
+        d_out = torch.zeros_like(d_in)
+        if product.BeatriceBatch_BindResidentBlocksRagged(batch.h, d_in.data_ptr(), d_out.data_ptr(), 1, cap, slots) == 0:
+            for timed in (False, True):
+                t0 = time.perf_counter()
+                for _ in range(calls):
+                    product.BeatriceBatch_ProcessBlocksRaggedDevice(batch.h, ns)
+                product.BeatriceBatch_Synchronize(batch.h)
+                dt = time.perf_counter() - t0
+            res["clocks_per_stream_four_rates"] = {"frames_per_s": round(streams * calls / dt, 1), "ms_per_call": round(dt / calls * 1e3, 4), "calls": calls,
+                                                   "rates": [r for r, _ in rates]}
+            product.BeatriceBatch_BindResidentBlocksRagged(batch.h, None, None, 0, 0, 0)
+        del d_in, d_out
+    batch.close()
+    return res
+
+
 def hop_synchronous(bv, models, product, streams, steps=300):
     """The same chain with pipelining off: every step complete before the next starts (what a real-time server that
     receives one hop per stream every 10 ms runs); its step time is the latency of a 256-stream hop."""
@@ -768,6 +819,7 @@ def main():
                 res["block_mode"] = block_mode(bv, m, product, B)
                 res["morph"] = morph_timing(bv, product)
                 res["host_buffer_variant"] = host_buffer_rate(bv, m, product, B)
+                res["any_rate_wrapper_around_ticks"] = wrapper_around_ticks(bv, m, product, torch, B)
                 res["latency_b1"] = latency_b1(bv, product, model_dir)
                 res["cpu_baseline"] = cpu_baseline(bv, model_dir, a.cpu_seconds)
                 peaks = measured_peaks()
