@@ -63,6 +63,54 @@ def test_batches_do_not_leak(bv, product, model_dir):
     assert before - after <= 8 << 20
 
 
+def test_wrapper_bindings_around_the_ticks_do_not_leak(bv, product, model_dir):
+    """The resident-block wrappers around the tick pipeline (uniform clocks at 1 / 2 / 4 hops per step, clocks per stream): bound, run,
+    unbound or destroyed while still bound, for ever."""
+    import ctypes as C
+    from tick_driver import Hip
+    m = bv.Models(product, model_dir)
+    hip = Hip()
+    B, block = 8, 441
+
+    def cycle(i):
+        H = (1, 2, 4, 1)[i % 4]
+        ragged = i % 4 == 3
+        batch = bv.Batch(m, B, hops_per_step=H)
+        a, h = batch.a, batch.h
+        if ragged:
+            assert a.BeatriceBatch_ConfigureWrapperRates(h, (C.c_double * B)(*([44100.0, 48000.0] * (B // 2)))) == 0
+            slots = a.BeatriceBatch_TickStages(h) + 4
+        else:
+            assert a.BeatriceBatch_ConfigureWrapper(h, 44100.0) == 0
+            slots = a.BeatriceBatch_ResidentBlocksDelayFor(h, block) + 4
+        d_in, d_out = hip.malloc(slots * B * 480 * 4), hip.malloc(slots * B * 480 * 4)
+        assert hip.lib.hipMemset(d_in, 0, C.c_size_t(slots * B * 480 * 4)) == 0
+        if ragged:
+            assert a.BeatriceBatch_BindResidentBlocksRagged(h, d_in, d_out, 1, 480, slots) == 0
+            for _ in range(6):
+                assert a.BeatriceBatch_ProcessBlocksRaggedDevice(h, (C.c_int * B)(*([441, 480] * (B // 2)))) == 0
+        else:
+            assert a.BeatriceBatch_BindResidentBlocks(h, d_in, d_out, 1, block, slots) == 0
+            for _ in range(6):
+                assert a.BeatriceBatch_ProcessBlocksDevice(h, None, None, 1, block) == 0
+        assert a.BeatriceBatch_Synchronize(h) == 0
+        if i % 2 == 0:   # every other batch is destroyed while still bound
+            assert (a.BeatriceBatch_BindResidentBlocksRagged(h, None, None, 0, 0, 0) if ragged else a.BeatriceBatch_BindResidentBlocks(h, None, None, 0, 0, 0)) == 0
+        batch.close()
+        hip.free(d_in)
+        hip.free(d_out)
+
+    for i in range(4):
+        cycle(i)
+    before = _free_bytes()
+    for i in range(16):
+        cycle(i)
+    after = _free_bytes()
+    m.close()
+    print("free device memory: %.1f MB -> %.1f MB" % (before / 2**20, after / 2**20))
+    assert before - after <= 8 << 20
+
+
 def test_unhealthy_objects_fail_softly(bv, product, model_dir):
     """Calls on objects that could not be built must not crash: error code from the batch, zeros from the
     void per-hop calls ('Errors')."""
