@@ -90,9 +90,13 @@ static void phone_forward_h(const PhoneWeights& w, const PhoneState& s, hipStrea
   using PL = PhoneLayers<H>;
   const int B = s.B;
   const F1Args fa = f1_args(w, s);
-  launch_site(f1_info(s), st, [&] { hipLaunchKernelGGL(phone_f1_kernel, dim3(B, H), dim3(256), 0, st, fa); });
   static const bool no_team = std::getenv("BEATRICE_HIP_NO_TEAM") != nullptr;
-  if (H == 1 && B == 1 && s.d_team_xb != nullptr && !no_team && !s.team_off) {   // one stream: f2 .. f5 and the residual blocks as ONE launch (team.hip.h)
+  static const bool no_team_head = std::getenv("BEATRICE_HIP_NO_TEAM_HEAD") != nullptr;   // A/B switch: f1 as a launch of its own again
+  const bool use_team = H == 1 && B == 1 && s.d_team_xb != nullptr && !no_team && !s.team_off;
+  // the 1-stream ABI's contexts (one counter, nothing to publish): f1 runs at the head of the team launch (team.hip.h with_f1)
+  const bool f1_in_team = use_team && !no_team_head && fa.hop == s.hop && fa.hop_publish == nullptr && fa.io_stride == 0;
+  if (!f1_in_team) launch_site(f1_info(s), st, [&] { hipLaunchKernelGGL(phone_f1_kernel, dim3(B, H), dim3(256), 0, st, fa); });
+  if (use_team) {   // one stream: f2 .. f5 and the residual blocks as ONE launch (team.hip.h)
     using namespace team;
     PhoneTeamArgs a{};
     gran_t* g = s.d_team_xb;
@@ -101,6 +105,7 @@ static void phone_forward_h(const PhoneWeights& w, const PhoneState& s, hipStrea
     a.f[1] = Tensor{s.f[1], take(8 * 128)}; a.f[2] = Tensor{s.f[2], take(4 * 256)}; a.f[3] = Tensor{s.f[3], take(2 * 256)}; a.f[4] = Tensor{s.f[4], take(256)};
     for (int i = 0; i < 4; ++i) { a.rb[i] = Tensor{s.rb[i], take(256)}; a.rb_w[i] = w.rb_w[i]; a.rb_b[i] = w.rb_b[i]; a.f_w[i] = w.f_w[i]; a.f_b[i] = w.f_b[i]; }
     a.hop = s.hop; a.dead = s.d_team_dead;
+    a.with_f1 = f1_in_team ? 1 : 0; a.f1 = fa;
     launch_site(LaunchInfo{"phone.team", 2.0 * (8 * 512.0 * 128 + 4 * 512.0 * 256 + 2 * 1024.0 * 256 + 1024.0 * 256 + 4 * 1280.0 * 256),
                            4.0 * (512.0 * 128 + 512.0 * 256 + 2 * 1024.0 * 256 + 4 * 1280.0 * 256)},
                 st, [&] { hipLaunchKernelGGL(phone_team_kernel, dim3(NWG), dim3(NTHR), kLdsFloats * 4, st, a); });

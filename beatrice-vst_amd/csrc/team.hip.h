@@ -300,6 +300,8 @@ struct WaveTeamArgs {
   const int* hop;
   int* dead;                                      // device flag: a wait was given up (outputs are garbage; the host reports failure)
   unsigned long long* stamps;                     // measurement aid, normally null
+  int with_cond;                                  // the conditioning mix (wave.cond: 256 sums per hop) at the head of the launch, by every
+  CondArgs cond;                                  // workgroup redundantly (see PhoneTeamArgs::with_f1): one launch fewer per hop
 };
 
 template <int D, class LNEXT>   // LNEXT: the layer that follows the block (the next block's dilated conv, or the first transposed conv)
@@ -367,6 +369,11 @@ static __global__ __launch_bounds__(NTHR) void wave_team_kernel(const WaveTeamAr
   __shared__ int dead;
   if (threadIdx.x == 0) dead = 0;
   __syncthreads();
+  if (a.with_cond) {
+    wave_cond_body(a.cond, 0);
+    __threadfence();   // (e goes to its ring with plain stores and is read with plain loads by the first stage's epilogue)
+    __syncthreads();
+  }
   StageArgs s{};
   // x0 = Linear(phone) + e
   s.in = Tensor{a.phone_in, nullptr}; s.res = Tensor{a.e, nullptr}; s.out = a.x[0]; s.w = a.inp_w; s.bias = a.inp_b;
@@ -398,6 +405,12 @@ struct PhoneTeamArgs {
   const float *f_w[4], *f_b[4], *rb_w[4], *rb_b[4];
   const int* hop;
   int* dead;
+  // with_f1: the module's first layer (phone.f1: Conv1d(1 -> 64) on the hop's audio, VALU work of a few microseconds) runs at the
+  // head of the launch instead of as a launch of its own -- by EVERY workgroup of the team, redundantly: each then reads the f[0]
+  // frames (and the audio ring) it wrote itself, all write the same bits, nothing is exchanged, and a launch boundary (~3 us of
+  // dependent-launch gap + the launch) is gone from the hop
+  int with_f1;
+  F1Args f1;
 };
 static __global__ __launch_bounds__(NTHR) void phone_team_kernel(const PhoneTeamArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -410,6 +423,11 @@ static __global__ __launch_bounds__(NTHR) void phone_team_kernel(const PhoneTeam
   __shared__ int dead;
   if (threadIdx.x == 0) dead = 0;
   __syncthreads();
+  if (a.with_f1) {
+    phone_f1_body(a.f1, 0, 0, lds);
+    __threadfence();   // (the frames go to the ring with plain stores and are gathered with plain loads below)
+    __syncthreads();
+  }
   StageArgs s{};
   s.in = a.f[0]; s.out = a.f[1]; s.w = a.f_w[0]; s.bias = a.f_b[0];
   Pre pre;

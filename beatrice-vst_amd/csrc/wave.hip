@@ -144,7 +144,7 @@ static bool team_on() {
   static const bool off = std::getenv("BEATRICE_HIP_NO_TEAM") != nullptr;
   return !off;
 }
-static void launch_wave_team(const WaveWeights& w, const WaveState& s, hipStream_t st) {
+static void launch_wave_team(const WaveWeights& w, const WaveState& s, hipStream_t st, const CondArgs* cond) {
   using namespace team;
   const WaveState::Scratch& k = s.scr[0];
   WaveTeamArgs a{};
@@ -167,6 +167,7 @@ static void launch_wave_team(const WaveWeights& w, const WaveState& s, hipStream
   a.hop = s.hop;
   a.dead = s.d_team_dead;
   a.stamps = g_team_trace;
+  if (cond != nullptr) { a.with_cond = 1; a.cond = *cond; }   // (the conditioning mix at the head of the launch)
   launch_site(LaunchInfo{"wave.team", 2.0 * (128.0 * 256 + 4 * (768.0 * 256 + 3 * 256.0 * 256 + 2 * 256.0 * 384) + 512.0 * 640 + 2 * 5 * 384.0 * 128 + 5 * 256.0 * 256),
                          4.0 * (128.0 * 256 + 4 * (768.0 * 256 + 3 * 256.0 * 256 + 2 * 256.0 * 384) + 512.0 * 640 + 2 * 384.0 * 128 + 256.0 * 256)},
               st, [&] { hipLaunchKernelGGL(wave_team_kernel, dim3(NWG), dim3(NTHR), kLdsFloats * 4, st, a); });
@@ -178,12 +179,14 @@ static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t
   const WaveState::Scratch& k = s.scr[part.scratch];
   auto in_part = [&part](int seg) { return seg >= part.first && seg <= part.last; };
   ConvArgs a;
-  if (!cond_done) {
-    const CondArgs ca = cond_args(w, s);
-    launch_site(cond_info(s), st, [&] { hipLaunchKernelGGL(wave_cond_kernel, dim3(rows), dim3(256), 0, st, ca); });
-  }
-  if (H == 1 && B == 1 && s.d_team_xb != nullptr && !s.team_off && part.first <= 1 && part.last >= 6 && team_on()) {
-    launch_wave_team(w, s, st);
+  const bool use_team = H == 1 && B == 1 && s.d_team_xb != nullptr && !s.team_off && part.first <= 1 && part.last >= 6 && team_on();
+  const CondArgs ca = cond_args(w, s);
+  static const bool no_team_head = std::getenv("BEATRICE_HIP_NO_TEAM_HEAD") != nullptr;   // A/B switch: wave.cond as a launch of its own again
+  // the 1-stream ABI's contexts (one counter, no pair to hand on): the conditioning mix runs at the head of the team launch
+  const bool cond_in_team = use_team && !cond_done && !no_team_head && ca.hop == s.hop && ca.hop_next_out == nullptr;
+  if (!cond_done && !cond_in_team) launch_site(cond_info(s), st, [&] { hipLaunchKernelGGL(wave_cond_kernel, dim3(rows), dim3(256), 0, st, ca); });
+  if (use_team) {
+    launch_wave_team(w, s, st, cond_in_team ? &ca : nullptr);
     part.first = 7;   // what is left: the fused tail
   }
   if (in_part(1)) {
