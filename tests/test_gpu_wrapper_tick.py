@@ -15,9 +15,13 @@ pytestmark = pytest.mark.gpu
                                                    (32000, 1000, 2, 3, 1), (16000, 333, 1, 2, 1),
                                                    # several hops per step: a step enters the ticks when the FIFOs have fired H hops
                                                    (48000, 480, 2, 4, 2), (44100, 441, 1, 5, 2), (96000, 960, 1, 3, 4), (44100, 64, 1, 3, 2),
-                                                   (32000, 1000, 2, 3, 4), (16000, 333, 1, 2, 2), (44100, 441, 1, 3, 4)])
+                                                   (32000, 1000, 2, 3, 4), (16000, 333, 1, 2, 2), (44100, 441, 1, 3, 4),
+                                                   (44100, 441, 1, 3, -4)])   # (H < 0: |H| hops per step over a long run, every ring of the binding wraps)
 def test_any_rate_wrapper_around_the_tick_pipeline(bv, oracle, product, model_dir, sr, block, channels, B, H):
+    long_run, H = H < 0, abs(H)
     n_blocks = max(40, int(0.45 * sr) // block)            # longer than the pipeline is deep, whatever the block size
+    if long_run:
+        n_blocks = 1200
     total = block * n_blocks
     x = np.zeros((B, channels, total), np.float32)
     for s in range(B):

@@ -19,13 +19,17 @@ pytestmark = pytest.mark.gpu
 _f32p = C.POINTER(C.c_float)
 
 
-@pytest.mark.parametrize("channels,holes", [(1, True), (2, True), (1, False)])
-def test_mixed_rate_batch_around_the_tick_pipeline_matches_one_proxy_per_stream(bv, product, model_dir, channels, holes):
+@pytest.mark.parametrize("channels,holes,calls", [(1, True, 100), (2, True, 100), (1, False, 100),
+                                                  (1, True, 1300)])   # (the long run: every ring of the binding wraps many times)
+def test_mixed_rate_batch_around_the_tick_pipeline_matches_one_proxy_per_stream(bv, product, model_dir, channels, holes, calls):
     rates = [44100.0, 48000.0, 96000.0, 44100.0, 32000.0, 48000.0, 16000.0]
     blocks = [441, 480, 1024, 300, 512, 64, 333]      # host samples per call, per stream
-    B, calls = len(rates), 100
+    B = len(rates)
     absent = {3: {5, 6, 20, 61}, 5: {0, 1, 2, 30, 31, 32, 33}} if holes else {}        # calls in which a stream hands in no block at all
     silent = {0: {4, 5, 17, 70}, 1: {0, 9, 10, 11, 55}, 2: {12}, 4: {3, 25, 26}} if holes else {}   # blocks the shell's rule skips
+    if calls > 200:   # holes all along the long run
+        absent = {3: {k for k in range(calls) if k % 37 in (5, 6)}, 5: {k for k in range(calls) if k % 101 < 4}}
+        silent = {0: {k for k in range(calls) if k % 53 in (4, 5)}, 1: {k for k in range(calls) if k % 29 == 0}, 4: {k for k in range(calls) if k % 97 in (3, 25, 26)}}
     switch = {0: (4, 2), 1: (12, 0), 2: (7, 1), 4: (26, 2), 6: (50, 0)}    # stream -> (before call, speaker); some right before silent blocks
     x = []
     for s in range(B):
