@@ -50,11 +50,14 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
   // publishes into link t, the last hop only polls.  A cell must find its predecessor's states published when it starts (it holds a
   // slot while it waits), so the hops sit far apart in dispatch order: hop 0 ahead of every other body, the later ones at the points
   // marked gru_at() below, each behind at least one more round of the launch's workgroups.
+  // (GruArgs::passes: two row groups per workgroup from 512 streams on; BEATRICE_HIP_GRU_PASSES overrides, for measurements)
+  static const int gru_passes_env = std::getenv("BEATRICE_HIP_GRU_PASSES") ? std::atoi(std::getenv("BEATRICE_HIP_GRU_PASSES")) : 0;
+  const int gru_passes = gru_passes_env > 0 ? gru_passes_env : (B >= 512 ? 2 : 1);
   auto link_p = [&](int t) { return k.d_link_p + (size_t)t * B * 256; };
   auto link_q = [&](int t) { return k.d_link_q + (size_t)t * B * 128; };
   auto add_pgru = [&](int t) {
     if constexpr (H > 1) {
-      GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(Plan::PGRU), B, t, t + 1 < H ? link_p(t) : nullptr, t > 0 ? link_p(t - 1) : nullptr, k.h_link_dead};
+      GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(Plan::PGRU), B, t, t + 1 < H ? link_p(t) : nullptr, t > 0 ? link_p(t - 1) : nullptr, k.h_link_dead, gru_passes};
       if (t == 0) tb->template add<T_PGRU>(GruP::info("phone.gru", g), g, GruP::grid(g), Plan::PGRU, keep(1), 19);
       else if (t == H - 1) tb->template add<T_PGRU1>(GruP1::info("phone.gru", g), g, GruP1::grid(g), Plan::PGRU, keep(1), 19);
       else if constexpr (H > 2) tb->template add<T_PGRUM>(GruPm::info("phone.gru", g), g, GruPm::grid(g), Plan::PGRU, keep(1), 19);
@@ -62,7 +65,7 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
   };
   auto add_qgru = [&](int t) {
     if constexpr (H > 1) {
-      GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, t, t + 1 < H ? link_q(t) : nullptr, t > 0 ? link_q(t - 1) : nullptr, k.h_link_dead};
+      GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, t, t + 1 < H ? link_q(t) : nullptr, t > 0 ? link_q(t - 1) : nullptr, k.h_link_dead, gru_passes};
       if (t == 0) tb->template add<T_QGRU>(GruQ::info("pitch.gru", g), g, GruQ::grid(g), Plan::QGRU, keep(1), 12);
       else if (t == H - 1) tb->template add<T_QGRU1>(GruQ1::info("pitch.gru", g), g, GruQ1::grid(g), Plan::QGRU, keep(1), 12);
       else if constexpr (H > 2) tb->template add<T_QGRUM>(GruQm::info("pitch.gru", g), g, GruQm::grid(g), Plan::QGRU, keep(1), 12);
@@ -156,7 +159,7 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
   { const ConvArgs a = conv(ws.ya1, ws.yb1, ww.ra_w[0], ww.ra_b[0], pl.up1() + 1); tb->template add<T_RES1A>(OpRES1A::info("wave.res1a", a), a, OpRES1A::grid(a), pl.up1() + 1, keep(7), 13); }
   { const ConvArgs a = conv(ws.yc1, ws.ya2, ww.up_w[1], ww.up_b[1], pl.up1() + 3); tb->template add<T_UP2>(OpUP2::info("wave.up2", a), a, OpUP2::grid(a), pl.up1() + 3, keep(7), 13); }
   { const ConvArgs a = conv(ps.f[0], ps.f[1], pw.f_w[0], pw.f_b[0], Plan::F2); tb->template add<T_F2>(OpF2::info("phone.f2", a), a, OpF2::grid(a), Plan::F2, keep(6), 15); }
-  if constexpr (H == 1) { const GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(Plan::PGRU), B, 0}; tb->template add<T_PGRU>(GruP::info("phone.gru", g), g, GruP::grid(g), Plan::PGRU, keep(1), 19); }
+  if constexpr (H == 1) { const GruArgs g{ps.rb[3], ps.h, pw.gru_wih, pw.gru_whh, pw.gru_bih, pw.gru_bhh, hp(Plan::PGRU), B, 0, nullptr, nullptr, nullptr, gru_passes}; tb->template add<T_PGRU>(GruP::info("phone.gru", g), g, GruP::grid(g), Plan::PGRU, keep(1), 19); }
   gru_at(2);
   { const ConvArgs a = conv(qs.h, qs.logits, qw.out_w, qw.out_b, Plan::POUT); tb->template add<T_POUT>(OpPOUT::info("pitch.out", a), a, OpPOUT::grid(a), Plan::POUT, keep(2), 11); }
   for (int i = 0; i < 2; ++i) {
@@ -164,7 +167,7 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
     tb->template add<T_P23>(OpP23::info("pitch.p23", a), a, OpP23::grid(a), Plan::P2 + i, keep(2), 10);
   }
   { const Ring phone_in{ws.d_phone, B_PHONE_CH, H, ws.front_slots}; ConvArgs a = conv(phone_in, ws.x[0], ww.inp_w, ww.inp_b, Plan::INP); a.res = ws.e; tb->template add<T_INP>(OpINP::info("wave.inp", a), a, OpINP::grid(a), Plan::INP, keep(3), 7.5); }
-  if constexpr (H == 1) { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, 0}; tb->template add<T_QGRU>(GruQ::info("pitch.gru", g), g, GruQ::grid(g), Plan::QGRU, keep(1), 12); }
+  if constexpr (H == 1) { const GruArgs g{qs.p[2], qs.h, qw.gru_wih, qw.gru_whh, qw.gru_bih, qw.gru_bhh, hp(Plan::QGRU), B, 0, nullptr, nullptr, nullptr, gru_passes}; tb->template add<T_QGRU>(GruQ::info("pitch.gru", g), g, GruQ::grid(g), Plan::QGRU, keep(1), 12); }
   gru_at(3);
   { FftArgs a = fft_args(qw, qs); a.hop = hp(Plan::FFT); tb->template add<T_FFT>(fft_info(qs), FftArgs2{a, B}, dim3((B + 1) / 2, H), Plan::FFT, keep(0), 8.7); }
   { const ConvArgs a = conv(ps.h, phone_out_ring(ps), pw.out_w, pw.out_b, Plan::OUT); tb->template add<T_OUT>(OpOUT::info("phone.out", a), a, OpOUT::grid(a), Plan::OUT, keep(3), 4.5); }

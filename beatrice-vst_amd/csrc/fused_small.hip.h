@@ -30,6 +30,11 @@ struct GruArgs {
   unsigned long long* link_out;
   const unsigned long long* link_in;
   int* link_dead;   // pinned host word, set when a wait was given up (a bug must not hang the GPU)
+  // Row groups a workgroup walks one after the other with its column tile's weights kept in registers (0 or 1: one group per
+  // workgroup).  A cell's weights pass a compute unit once per 16 RT rows; with two groups per workgroup once per 32 RT -- at
+  // 1 024 streams x 4 hops the tick launch 947 -> 921 us, at 256 streams no gain (fewer, longer workgroups in the linked chains), so
+  // the tick table asks for it from 512 streams on (profiles/r05_notes.md section 15).
+  int passes;
 };
 namespace glink {
 constexpr int kSpinLimit = 2000000;   // polls before a workgroup gives up: ~1 s
@@ -66,7 +71,7 @@ __device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, c
   float* g6 = hs + ROWS * HS;  // [tile][src][gate][16][16]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int src = wave / 3, gate = wave % 3;
-  const int b0 = bx * ROWS, j0 = by * 16;
+  const int j0 = by * 16;
 
   // B fragment of this wave: packed weights, column tile (gate*H + j0)/16, all k-blocks
   constexpr int KB_X = IN / 16, KB_H = H / 16;
@@ -81,6 +86,11 @@ __device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, c
   if (hop < 0) return;
   const bool rag = stepc::rag_t<RAG>();   // (tick launch, ragged steps: every row at its stream's own counter, -1 = the stream sits the step out)
   const int px = ring_pos(a.x, hop), ph = ring_pos(a.h, hop);
+  const int passes = a.passes > 1 ? a.passes : 1;   // (GruArgs::passes: row groups walked with the weights above kept in registers)
+#pragma unroll 1
+  for (int pass = 0; pass < passes; ++pass) {
+  const int b0 = (bx * passes + pass) * ROWS;
+  if (pass > 0) { if (b0 >= a.B) break; __syncthreads(); }   // (the tiles and the gate block are reused)
   // A tiles -> LDS
   for (int e = tid; e < ROWS * (IN / 4); e += 384) {
     const int r = e / (IN / 4), q = e % (IN / 4);
@@ -158,6 +168,7 @@ __device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, c
       if constexpr ((LINK & 1) != 0) glink::publish(a.link_out + (size_t)(b0 + r) * H + j0 + j, hv, hop + 1);
     }
   }
+  }
 }
 
 template <int IN, int H, int RT = 1>
@@ -171,7 +182,7 @@ struct GruOp {
   using Args = GruArgs;
   static constexpr int NTHR = 384;
   static constexpr int LDS_FLOATS = RT * (16 * (IN + 2) + 16 * (H + 2) + 6 * 256);
-  static inline dim3 grid(const GruArgs& a) { return dim3((a.B + 16 * RT - 1) / (16 * RT), H / 16); }
+  static inline dim3 grid(const GruArgs& a) { const int rows = 16 * RT * (a.passes > 1 ? a.passes : 1); return dim3((a.B + rows - 1) / rows, H / 16); }
   static inline bhip::LaunchInfo info(const char* name, const GruArgs& a) {
     return bhip::LaunchInfo{name, 2.0 * a.B * (IN + H) * 3.0 * H, 4.0 * ((IN + H) * 3.0 * H + a.B * (IN + 2.0 * H))};
   }
