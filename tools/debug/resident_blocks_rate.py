@@ -87,6 +87,10 @@ def ragged():
     hip.free(d_out)
 
 
+if os.environ.get("BLOCK"):   # e.g. BLOCK=64 RATE=48000: DAW-sized blocks (several calls per model hop)
+    for H in (1, 2, 4):
+        uniform(int(os.environ.get("RATE", "48000")), int(os.environ["BLOCK"]), H)
+    sys.exit(0)
 for H in (1, 2, 4):
     uniform(44100, 441, H)
 uniform(48000, 480, 4)
