@@ -72,6 +72,17 @@ __device__ __forceinline__ float resample_one(const Dir& d, const float* __restr
   return acc;
 }
 
+// The direction's tap table for this workgroup: staged into LDS when it fits (44.1 <-> 48 kHz: 5 121 floats).  A thread's output walks
+// 32 taps hi apart in ascending order, each one a dependent round trip to global memory otherwise -- ~0.4 us each, 13 of the 15 us of
+// a wrapper launch (profiles/r05_notes.md section 16).  Same values, same order.  Visible after the caller's next barrier.
+constexpr int kTapsLds = 7168;
+__device__ __forceinline__ const float* stage_taps(const Dir& d, const float* __restrict__ taps, const int tid) {
+  __shared__ float tl[kTapsLds];
+  if (d.n_taps > kTapsLds) return taps;
+  for (int i = tid; i < d.n_taps; i += 256) tl[i] = taps[i];
+  return tl;
+}
+
 // host block -> 48 kHz: downmix, input gain, first resampling direction.  One workgroup per stream.
 __device__ __forceinline__ void wrap_in_body(float* __restrict__ x /* LDS [kMaxHist + kMaxSamples] */, double* __restrict__ amp /* LDS [kMaxSamples] */,
                                              const int b, const int tid, const float* __restrict__ in, const int channels, const int n,
@@ -88,6 +99,7 @@ __device__ __forceinline__ void wrap_in_body(float* __restrict__ x /* LDS [kMaxH
       amp[i] = a;
     }
   }
+  const float* tl_ = stage_taps(d, taps, tid);
   for (int i = tid; i < d.hist; i += 256) x[i] = hist[i];
   __syncthreads();
   for (int i = tid; i < n; i += 256) {
@@ -97,7 +109,7 @@ __device__ __forceinline__ void wrap_in_body(float* __restrict__ x /* LDS [kMaxH
     x[d.hist + i] = (float)(m * a);
   }
   __syncthreads();
-  for (int o = tid; o < d.n_out; o += 256) inner[(size_t)b * stride + o] = resample_one(d, x, taps, o);
+  for (int o = tid; o < d.n_out; o += 256) inner[(size_t)b * stride + o] = resample_one(d, x, tl_, o);
   __syncthreads();
   for (int i = tid; i < d.hist; i += 256) hist[i] = x[n + i];  // the newest `hist` samples
 }
@@ -126,12 +138,13 @@ static __global__ __launch_bounds__(256) void wrap_out_kernel(const float* __res
       amp[i] = a;
     }
   }
+  const float* tl_ = stage_taps(d, taps, tid);
   for (int i = tid; i < d.hist; i += 256) x[i] = hist[i];
   for (int i = tid; i < d.n_in; i += 256) x[d.hist + i] = inner[(size_t)b * stride + i];
   __syncthreads();
   float* dst = out + (size_t)b * channels * n;
   for (int o = tid; o < n; o += 256) {
-    const float y = resample_one(d, x, taps, o);
+    const float y = resample_one(d, x, tl_, o);
     const double a = g.step != 1.0 ? amp[o] : g.amp0;
     const float v = (float)(y * a);
     for (int c = 0; c < channels; ++c) dst[c * n + o] = v;
@@ -161,6 +174,7 @@ __device__ __forceinline__ void wrap_post_body(float* __restrict__ x, double* __
       amp[i] = a;
     }
   }
+  const float* tl_ = stage_taps(d, taps, tid);
   for (int i = tid; i < d.hist; i += 256) x[i] = hist[i];
   for (int i = tid; i < d.n_in; i += 256) {
     const long long t = t0 + i;
@@ -171,7 +185,7 @@ __device__ __forceinline__ void wrap_post_body(float* __restrict__ x, double* __
   __syncthreads();
   float* dst = out + (size_t)b * channels * n;
   for (int o = tid; o < n; o += 256) {
-    const float y = resample_one(d, x, taps, o);
+    const float y = resample_one(d, x, tl_, o);
     const double a = g.step != 1.0 ? amp[o] : g.amp0;
     const float v = (float)(y * a);
     for (int c = 0; c < channels; ++c) dst[c * n + o] = v;
@@ -291,6 +305,7 @@ __device__ __forceinline__ void wrapr_in_body(float* __restrict__ x, double* __r
       amp[i] = a;
     }
   }
+  const float* tl_ = stage_taps(d, taps, tid);
   for (int i = tid; i < d.hist; i += 256) x[i] = hist[i];
   __syncthreads();
   for (int i = tid; i < n; i += 256) {
@@ -300,7 +315,7 @@ __device__ __forceinline__ void wrapr_in_body(float* __restrict__ x, double* __r
     x[d.hist + i] = (float)(m * a);
   }
   __syncthreads();
-  for (int o = tid; o < d.n_out; o += 256) inner[(size_t)b * stride + o] = resample_one(d, x, taps, o);
+  for (int o = tid; o < d.n_out; o += 256) inner[(size_t)b * stride + o] = resample_one(d, x, tl_, o);
   __syncthreads();
   for (int i = tid; i < d.hist; i += 256) hist[i] = x[n + i];
 }
@@ -337,11 +352,12 @@ static __global__ __launch_bounds__(256) void wrapr_out_kernel(const float* __re
       amp[i] = a;
     }
   }
+  const float* tl_ = stage_taps(d, taps, tid);
   for (int i = tid; i < d.hist; i += 256) x[i] = hist[i];
   for (int i = tid; i < d.n_in; i += 256) x[d.hist + i] = inner[(size_t)b * stride + i];
   __syncthreads();
   for (int o = tid; o < n; o += 256) {
-    const float y = resample_one(d, x, taps, o);
+    const float y = resample_one(d, x, tl_, o);
     const double a = g.step != 1.0 ? amp[o] : g.amp0;
     const float v = (float)(y * a);
     for (int c = 0; c < channels; ++c) dst[c * n + o] = v;
@@ -438,6 +454,7 @@ static __global__ __launch_bounds__(256) void wrapr_post_kernel(const float* __r
       amp[i] = a;
     }
   }
+  const float* tl_ = stage_taps(d, taps, tid);
   for (int i = tid; i < d.hist; i += 256) x[i] = hist[i];
   for (int i = tid; i < d.n_in; i += 256) {
     const long long t = r.t0 + i;
@@ -447,7 +464,7 @@ static __global__ __launch_bounds__(256) void wrapr_post_kernel(const float* __r
   }
   __syncthreads();
   for (int o = tid; o < n; o += 256) {
-    const float y = resample_one(d, x, taps, o);
+    const float y = resample_one(d, x, tl_, o);
     const double a = g.step != 1.0 ? amp[o] : g.amp0;
     const float v = (float)(y * a);
     for (int c = 0; c < channels; ++c) dst[c * n + o] = v;
