@@ -872,15 +872,73 @@ struct Wrap48TickArgs {
   const float* in48_post;                  // the completed step's own input block (read for silent streams only)
   int H;                                   // blocks per stream and step (a batch with several hops per step): rows are (stream, hop), in order
 };
+// The step's H blocks of a stream, in order, operation for operation wrap48_pre_body / wrap48_post_body -- with what goes from one
+// block to the next (the decimator's 30 samples of history; the up-sampler's 16-sample tail and the latched model output) carried in
+// registers instead of through the state in global memory: a store -> load round trip per block was the launch's critical path at
+// four blocks per step.
+__device__ __forceinline__ void wrap48_pre_blocks(const int b, const Wrap48TickArgs& a, float* __restrict__ lds) {
+  float* g = lds;        // [30 + 480]
+  float* cd = lds + 512; // [33]
+  const int tid = threadIdx.x;
+  if (tid < 33) cd[tid] = a.coef_down[tid];
+  float hk = tid < 30 ? a.st[b].hist_in[tid] : 0.0f;
+  for (int hh = 0; hh < a.H; ++hh) {
+    const int row = b * a.H + hh;
+    const float* src = a.in48 + (size_t)row * a.channels * 480;
+    if (hh > 0) __syncthreads();
+    if (tid < 30) g[tid] = hk;
+    for (int i = tid; i < 480; i += 256) {
+      float m = src[i];
+      if (a.channels >= 2) { m = m + src[480 + i]; m = m * 0.5f; }
+      g[30 + i] = m;
+    }
+    __syncthreads();
+    if (tid < 160) {
+      const int p = 3 * tid + 2;
+      float acc = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 31; ++i) acc = acc + g[30 + p - i] * cd[1 + i];
+      a.in16[(size_t)row * 160 + tid] = acc * 1.0f;
+    }
+    if (tid < 30) hk = g[480 + tid];
+  }
+  if (tid < 30) a.st[b].hist_in[tid] = hk;
+}
+__device__ __forceinline__ void wrap48_post_blocks(const int b, const Wrap48TickArgs& a, float* __restrict__ lds) {
+  float* f = lds;         // [16 + 240]
+  float* cu = lds + 256;  // [33]
+  const int tid = threadIdx.x;
+  if (tid < 33) cu[tid] = a.coef_up[tid];
+  float zt = tid < 16 ? a.st[b].ztail[tid] : 0.0f;
+  float fp = tid < 240 ? a.st[b].fpend[tid] : 0.0f;
+  for (int hh = 0; hh < a.H; ++hh) {
+    const int row = b * a.H + hh;
+    if (hh > 0) __syncthreads();
+    if (tid < 16) f[tid] = zt;
+    if (tid < 240) f[16 + tid] = fp;
+    __syncthreads();
+    float* dst = a.out48 + (size_t)row * a.channels * 480;
+    for (int n = tid; n < 480; n += 256) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const int m = n - i;                     // index into the zero-stuffed stream; odd positions are zero
+        if ((m & 1) == 0) acc = acc + f[16 + (m >> 1)] * cu[i];
+      }
+      for (int c = 0; c < a.channels; ++c) dst[c * 480 + n] = acc;
+    }
+    if (tid < 16) zt = f[16 + 224 + tid];
+    if (tid < 240) fp = a.model_out[(size_t)row * 240 + tid];   // this block's model output is the next block's FIFO content
+  }
+  if (tid < 16) a.st[b].ztail[tid] = zt;
+  if (tid < 240) a.st[b].fpend[tid] = fp;
+}
 static __global__ __launch_bounds__(256) void wrap48_tick_kernel(const Wrap48TickArgs a) {
   __shared__ float lds[512 + 33];
   const int w = blockIdx.x;
   if (w < a.n_pre) {
     if (a.hv_pre != nullptr && a.hv_pre[w] < 0) return;   // (its 16 kHz hop is not read either: the model sits the step out)
-    for (int hh = 0; hh < a.H; ++hh) {   // (the filter history goes from block to block through the state: written and read by the same threads)
-      if (hh > 0) __syncthreads();
-      wrap48_pre_body(w, a.in48, a.channels, a.st, a.coef_down, a.in16, lds, nullptr, w * a.H + hh);
-    }
+    wrap48_pre_blocks(w, a, lds);
   } else {
     const int b = w - a.n_pre;
     if (a.hv_post != nullptr && a.hv_post[b] < 0) {
@@ -893,9 +951,6 @@ static __global__ __launch_bounds__(256) void wrap48_tick_kernel(const Wrap48Tic
       }
       return;
     }
-    for (int hh = 0; hh < a.H; ++hh) {
-      if (hh > 0) __syncthreads();
-      wrap48_post_body(b, a.st, a.coef_up, a.out48, a.channels, a.model_out, lds, b * a.H + hh);
-    }
+    wrap48_post_blocks(b, a, lds);
   }
 }
