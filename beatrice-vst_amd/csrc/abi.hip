@@ -92,7 +92,7 @@ bool wait_stream(hipStream_t s) {
 // BEATRICE_HIP_HOP_IMMEDIATE=1: the step counter of a call travels in the kernels' arguments (stepc::immediate) instead of
 // the mailbox in device memory; the launches are then plain ones (arguments change every call).
 static bool hop_immediate() {
-  static const bool on = std::getenv("BEATRICE_HIP_HOP_IMMEDIATE") != nullptr;
+  static const bool on = bhip::meas_env("BEATRICE_HIP_HOP_IMMEDIATE") != nullptr;
   return on;
 }
 // Captures `enqueue` (copies + kernels on `s`) into g for this parameter blob / variant; nothing runs.  On any failure the
@@ -124,7 +124,7 @@ static void capture_hop(HopGraph& g, const void* blob, int variant, hipStream_t 
 // and replaying them as a hipGraph measures ~10 us per hop SLOWER than enqueuing them (p50 285 vs 275 us over three A/B rounds,
 // profiles/r05_notes.md section 10; with 49 kernels per hop, rounds 1-3, the graph won).  BEATRICE_HIP_HOP_GRAPH=1: the graphs.
 static bool hop_graphs() {
-  static const bool on = std::getenv("BEATRICE_HIP_HOP_GRAPH") != nullptr && std::getenv("BEATRICE_HIP_NO_HOP_GRAPH") == nullptr;
+  static const bool on = std::getenv("BEATRICE_HIP_HOP_GRAPH") != nullptr;
   return on;
 }
 template <class F>
@@ -431,7 +431,7 @@ Beatrice20rc0_WaveformContext1* Beatrice20rc0_CreateWaveformContext1(void) {
   // Measurement switch BEATRICE_HIP_OUT_MAPPED=1: the hop's 240 samples written by the last kernel straight into the pinned block
   // the host reads (posted writes over PCIe, flushed when the kernel ends) instead of a device buffer + one more copy command
   // per call -- measured neutral (p50 281-285 us either way, round 4), so the copy stays the default
-  if (c->ok && std::getenv("BEATRICE_HIP_OUT_MAPPED") != nullptr) {
+  if (c->ok && bhip::meas_env("BEATRICE_HIP_OUT_MAPPED") != nullptr) {
     c->dev_d_out = c->st.d_out;
     c->st.d_out = c->h_io + in_floats;
     c->out_mapped = true;

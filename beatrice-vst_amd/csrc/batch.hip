@@ -265,6 +265,8 @@ struct BeatriceBatch {
   // the input half of the chain in front of the ticks, the output half `delay` calls later (wrapper.hip.h wrap_post_kernel)
   struct ResidentBlocks {
     bool on = false;
+    bool dead = false;   // a call of the uniform form failed after the host's clocks had advanced (rb_step): host and device wrapper state no
+                         // longer agree, every further call is refused with -2 until the binding is released
     int channels = 0, n = 0, n_slots = 0, io_slots = 0, delay = 0, ring = 0;
     const float* d_in = nullptr;   // [n_slots][B][channels][n]
     float* d_out = nullptr;        // [n_slots][B][channels][n]
@@ -363,7 +365,7 @@ void settle(BeatriceBatch* b) {
 // Tick mode splits the attention rows of a step between two kinds of workgroup (rowchain.hip.h): 16-row tiles that share a
 // K/V slot (block_b_body) and quads of <= 4 rows (block_bq_body).  BEATRICE_HIP_TICK_NO_QUADS: A/B switch for measurements.
 bool quads_on(const BeatriceBatch* b) {
-  static const bool no_quads = std::getenv("BEATRICE_HIP_TICK_NO_QUADS") != nullptr;
+  static const bool no_quads = bhip::meas_env("BEATRICE_HIP_TICK_NO_QUADS") != nullptr;
   return b->tk.on && b->wave.d_ktp[0] != nullptr && !no_quads;
 }
 void rebuild_tiles(BeatriceBatch* b, int blk) {
@@ -480,7 +482,7 @@ bool push_settings(BeatriceBatch* b, int parity /* slot: step & 3 */) {
 // content encoder's (front.hip); elsewhere the modules run one after the other.  (Running them as parallel
 // graph branches was measured and buys nothing on ROCm 7.2 / MI355X, profiles/r01_notes.md.)
 void enqueue_front(BeatriceBatch* b, hipStream_t st) {
-  static const bool no_pairs = std::getenv("BEATRICE_HIP_NO_PAIRS") != nullptr;  // A/B switch for measurements
+  static const bool no_pairs = bhip::meas_env("BEATRICE_HIP_NO_PAIRS") != nullptr;  // A/B switch for measurements
   if (!no_pairs && front_forward(b->phone_m->w, b->phone, b->pitch_m->w, b->pitch, b->wave_m->w, b->wave, st)) return;
   phone_forward(b->phone_m->w, b->phone, st);
   pitch_forward(b->pitch_m->w, b->pitch, st);

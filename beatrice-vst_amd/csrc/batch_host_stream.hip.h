@@ -90,7 +90,7 @@ int BeatriceBatch_EnableHostStreaming(BeatriceBatch* b, int enable) {
   for (auto* v : {&h.ev_in, &h.ev_out, &h.ev_tick})
     for (hipEvent_t& e : *v) ok = ok && hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hs event");
   h.tick_of_ev.assign(tick::kRing, -1);
-  h.mapped = std::getenv("BEATRICE_HIP_HS_COPIES") == nullptr;   // A/B switch: copies on two more streams instead
+  h.mapped = bhip::meas_env("BEATRICE_HIP_HS_COPIES") == nullptr;   // A/B switch: copies on two more streams instead
   if (ok && h.mapped) std::memset(h.h_in, 0, sizeof(float) * n_in * h.n_slots);
   ok = ok && BeatriceBatch_BindResidentIO(b, h.mapped ? h.h_in : h.d_in, h.mapped ? h.h_out : h.d_out, h.n_slots) == 0 && tick_enable(b, true) == 0;
   if (!ok) { (void)tick_enable(b, false); (void)BeatriceBatch_BindResidentIO(b, nullptr, nullptr, 0); host_stream_free(b); return -2; }

@@ -34,7 +34,7 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
   // product library has no switch that changes results): BEATRICE_HIP_TICK_DROP=<bit mask> leaves groups of bodies out of
   // the launch
 #ifdef BEATRICE_HIP_MEASUREMENT_BUILD
-  static const int drop = std::getenv("BEATRICE_HIP_TICK_DROP") ? std::atoi(std::getenv("BEATRICE_HIP_TICK_DROP")) : 0;
+  static const int drop = bhip::meas_env("BEATRICE_HIP_TICK_DROP") ? std::atoi(bhip::meas_env("BEATRICE_HIP_TICK_DROP")) : 0;
 #else
   constexpr int drop = 0;
 #endif
@@ -51,7 +51,7 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
   // slot while it waits), so the hops sit far apart in dispatch order: hop 0 ahead of every other body, the later ones at the points
   // marked gru_at() below, each behind at least one more round of the launch's workgroups.
   // (GruArgs::passes: two row groups per workgroup from 512 streams on; BEATRICE_HIP_GRU_PASSES overrides, for measurements)
-  static const int gru_passes_env = std::getenv("BEATRICE_HIP_GRU_PASSES") ? std::atoi(std::getenv("BEATRICE_HIP_GRU_PASSES")) : 0;
+  static const int gru_passes_env = bhip::meas_env("BEATRICE_HIP_GRU_PASSES") ? std::atoi(bhip::meas_env("BEATRICE_HIP_GRU_PASSES")) : 0;
   const int gru_passes = gru_passes_env > 0 ? gru_passes_env : (B >= 512 ? 2 : 1);
   auto link_p = [&](int t) { return k.d_link_p + (size_t)t * B * 256; };
   auto link_q = [&](int t) { return k.d_link_q + (size_t)t * B * 128; };
@@ -178,31 +178,14 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
   // (XCD-aware placement -- bodies with many weights pinned to one XCD, or to the XCDs of equal index modulo 2 / 4, so that their weights
   //  stay in fewer L2s -- was measured in rounds 2 and 4: memory-side traffic / 4, the launch 4-8 % slower; the switch went with the
   //  span lookup in round 5.  Its successor is TableBuilder::two_halves below: the same idea at the granularity that costs nothing)
-  // Dispatch order by workgroup (fuse::WgDesc, one descriptor per workgroup read by a scalar load): BEATRICE_HIP_TICK_ORDER=0 (default):
-  // the bodies in the order added above, every body a contiguous run; 1: the short, latency-bound workgroups dealt among the long
-  // MFMA-dense ones (TableBuilder::interleave; _RESERVE=<percent of the light time kept for the end of the launch>) -- measured, slower
-  static const int order_mode = std::getenv("BEATRICE_HIP_TICK_ORDER") ? std::atoi(std::getenv("BEATRICE_HIP_TICK_ORDER")) : 0;
-  static const double order_reserve = (std::getenv("BEATRICE_HIP_TICK_RESERVE") ? std::atoi(std::getenv("BEATRICE_HIP_TICK_RESERVE")) : 15) / 100.0;
-  static const int halves_mode = std::getenv("BEATRICE_HIP_TICK_HALVES") ? std::atoi(std::getenv("BEATRICE_HIP_TICK_HALVES")) : 2;   // 0: every body on all XCDs; 2 (default): halves; 4: quarters
+  // Dispatch order by workgroup (fuse::WgDesc, one descriptor per workgroup read by a scalar load): the bodies in the order added above,
+  // every body a contiguous run.  (Round 5 also measured the short workgroups dealt AMONG the long MFMA-dense ones: 7.7 % slower,
+  // profiles/r05_notes.md section 4; round 6 the short ones as a KERNEL OF THEIR OWN at twice the occupancy, beside or behind the dense
+  // one: 8-12 % slower, profiles/r06_notes.md section 1, tools/experiments/r06_two_kernel_tick.patch.)
+  static const int halves_mode = bhip::meas_env("BEATRICE_HIP_TICK_HALVES") ? std::atoi(bhip::meas_env("BEATRICE_HIP_TICK_HALVES")) : 2;   // 0: every body on all XCDs; 2 (default): halves; 4: quarters
   {
-    using TB = typename O::Builder;
     std::vector<fuse::WgDesc> desc;
-    if (order_mode != 0) {
-      int klass[fuse::kMaxSpans];
-      for (int i = 0; i < tb->t.n_spans; ++i) {
-        const int type = tb->t.span[i].type, bank = tb->t.span[i].arg & 0xff;
-        switch (type) {
-          case T_PGRU: case T_QGRU: klass[i] = H > 1 ? TB::kFirst : TB::kLight; break;
-          case T_PGRU1: case T_QGRU1: klass[i] = TB::kAt + 1000 * (H - 1) / H; break;
-          case T_PGRUM: case T_QGRUM: klass[i] = TB::kAt + 1000 * (1 + bank) / H; break;
-          case T_F4: case T_F5: case T_P1: case T_RB: case T_F4S: case T_F5S: case T_P1S: case T_RBS:
-          case T_BLKA1: case T_BLKA2: case T_BLKA4: case T_BLKA8: case T_BLKB: case T_BLKBQ:
-          case T_TAIL: case T_TAIL1: case T_TAIL2: case T_TAIL3: case T_TAIL1S: case T_TAIL2S: klass[i] = TB::kDense; break;
-          default: klass[i] = TB::kLight; break;
-        }
-      }
-      desc = tb->interleave(klass, order_reserve);
-    } else if (halves_mode != 0 && !sparse) {   // the bodies with the weights, each on one half of the chip (TableBuilder::two_halves); the sparse table only ever runs partly filled ticks
+    if (halves_mode != 0 && !sparse) {   // the bodies with the weights, each on one half of the chip (TableBuilder::two_halves); the sparse table only ever runs partly filled ticks
       bool pinned[fuse::kMaxSpans];
       int group[fuse::kMaxSpans];
       for (int i = 0; i < tb->t.n_spans; ++i) {
@@ -255,7 +238,7 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
     tb->t.total = (int)desc.size();   // (two_halves may add filler indices)
     if (!upload(desc, sparse ? k.d_desc_sparse : k.d_desc, sparse ? k.desc_sparse_cap : k.desc_cap)) return false;
   }
-  if (std::getenv("BEATRICE_HIP_TICK_TRACE")) {
+  if (bhip::meas_env("BEATRICE_HIP_TICK_TRACE")) {
     if (k.d_trace) (void)hipFree(k.d_trace);
     BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&k.d_trace), sizeof(unsigned long long) * 3 * tb->t.total));
     tb->t.trace = k.d_trace;
@@ -300,7 +283,7 @@ static void tick_launch(BeatriceBatch* b, const bool sparse, const bool full, hi
   // are 0 .. k or k .. last (tick::State::d_desc_ranges)
   const fuse::WgDesc* desc = sparse ? k.d_desc_sparse : (full ? k.d_desc : k.d_desc_plain);
   int total = sparse ? k.table_sparse_total : (full ? k.table_total : k.table_total_plain);
-  static const bool no_ranges = std::getenv("BEATRICE_HIP_TICK_NO_RANGES") != nullptr;   // A/B switch for measurements
+  static const bool no_ranges = bhip::meas_env("BEATRICE_HIP_TICK_NO_RANGES") != nullptr;   // A/B switch for measurements
   if (!sparse && !full && !no_ranges && k.d_desc_ranges != nullptr) {
     const int n_stages = k.plan.count();
     int lo = n_stages, hi = -1, occupied = 0;
@@ -321,7 +304,7 @@ static void tick_launch(BeatriceBatch* b, const bool sparse, const bool full, hi
 // BEATRICE_HIP_TICK_HOSTPROF=1: host time of tick_run by section, printed when the process ends (measurement aid)
 struct HostProf {
   static constexpr int N = 5;
-  static bool on() { static const bool v = std::getenv("BEATRICE_HIP_TICK_HOSTPROF") != nullptr; return v; }
+  static bool on() { static const bool v = bhip::meas_env("BEATRICE_HIP_TICK_HOSTPROF") != nullptr; return v; }
   struct Totals { double us[N] = {}; long long calls = 0; ~Totals() { if (calls) std::fprintf(stderr, "tick_run host us per call: settings/kv %.1f, table %.1f, snapshot upload %.1f, copies %.1f, launch %.1f (%lld calls)\n", us[0] / calls, us[1] / calls, us[2] / calls, us[3] / calls, us[4] / calls, calls); } };
   static Totals& totals() { static Totals t; return t; }
   std::chrono::steady_clock::time_point t0;
@@ -487,7 +470,7 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
   // half-size bodies LOSE (51-54 us against 45-48; two streams per tail workgroup 39 against 37), so there the full table runs
   int highest = -1;
   for (int s = 0; s < p.n_stages; ++s) if (p.hop[s] >= 0) highest = s;
-  static const bool no_sparse = std::getenv("BEATRICE_HIP_TICK_NO_SPARSE") != nullptr;   // A/B switch for measurements
+  static const bool no_sparse = bhip::meas_env("BEATRICE_HIP_TICK_NO_SPARSE") != nullptr;   // A/B switch for measurements
   // (one hop per step only: at two hops per step it measured no difference, at four the half-size bodies cost 1 % of a 20-step run --
   //  5 196 against 5 138 us of launches, profiles/r05_notes.md)
   const bool sparse = highest >= 0 && highest < Plan::BLK0 && !no_sparse && b->H == 1;
@@ -578,7 +561,7 @@ bool tick_drain(BeatriceBatch* b) {
     std::vector<unsigned long long> tr((size_t)3 * b->tk.table_total);
     if (hip_ok(hipStreamSynchronize(b->stream), "trace sync") &&
         hip_ok(hipMemcpy(tr.data(), b->tk.d_trace, tr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost), "trace copy"))
-      if (FILE* f = std::fopen(std::getenv("BEATRICE_HIP_TICK_TRACE"), "w")) {
+      if (FILE* f = std::fopen(bhip::meas_env("BEATRICE_HIP_TICK_TRACE"), "w")) {
         for (size_t i = 0; i < tr.size(); i += 3) std::fprintf(f, "%llu %llu %llu\n", tr[i], tr[i + 1], tr[i + 2]);
         std::fclose(f);
       }

@@ -59,6 +59,10 @@ int BeatriceBatch_EnableSilentBlockRule(BeatriceBatch* b, int enable) {
   const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   BeatriceBatch::SilentRule& sr = b->silent;
+  // a resident-block binding around the ticks owns the rule's flags while it is bound (BindResidentBlocksRagged names the streams
+  // whose FIFO did not fire through silent.next; switching the rule off underneath it would advance every stream on every fired
+  // step while the key/value installs and the codebook lottery still skip the flagged ones -- ADVICE r05): refused in both directions
+  if (b->rb.on) return -1;
   if (!enable) {
     if (sr.on) { (void)sync_all(b); if (b->rw.ready) sr.on = false; else silent_release(b); }   // (the per-stream wrapper keeps the freeze machinery)
     return 0;
@@ -293,7 +297,12 @@ static int wrap_max_chunk(const BeatriceBatch* b) {  // host samples per launch 
 int BeatriceBatch_ProcessBlocksDevice(BeatriceBatch* b, const float* d_in, float* d_out, int channels, int n) {
   const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
-  if (b->rb.on) return (!b->rb.ragged && !d_in && !d_out && channels == b->rb.channels && n == b->rb.n) ? (rb_step(b) ? 0 : -2) : -1;
+  if (b->rb.on) {
+    if (b->rb.ragged || d_in || d_out || channels != b->rb.channels || n != b->rb.n) return -1;
+    if (b->rb.dead) return -2;
+    if (!rb_step(b)) { b->rb.dead = true; return -2; }   // (rb_step advances gain clocks, resampler phases and the FIFO before its checks: a failed call leaves the binding unusable, not silently skewed)
+    return 0;
+  }
   if (!b->wrap.ready || channels < 1 || channels > 2 || !d_in || !d_out || n < 1 || b->H != 1 || b->io_slots > 0 || b->pipelined || b->tk.on) return -1;
   const int piece = wrap_max_chunk(b);
   if (n <= piece) return wrap_chunk(b, d_in, d_out, channels, n) ? 0 : -2;

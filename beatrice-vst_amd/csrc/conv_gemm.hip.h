@@ -19,6 +19,7 @@
 // reads (ds_read_b32, lane -> [row l&15][k l>>4]) are bank-conflict free (A stride KC+2 -> banks
 // 2*i + k distinct over a 32-lane group).  W never touches LDS: see "PRE-PACKED" below.
 #pragma once
+#include "meas_env.h"
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -474,7 +475,7 @@ static inline void launch_auto(const char* name, const ConvArgs& a, hipStream_t 
   // 6.5-6.8 -- a single 256-long chain per lane pays the same serial memory round trips as the MFMA kernel and has no
   // second wavefront to hide them -- but layers with three or more reduction segments win (the segments run as
   // parallel lanes): k5 residual blocks 5.8 vs 7.4, k3 dilated convs 5.5-6.0 vs 6.6-6.9, the pitch estimator's first layer 6.7 vs 7.8
-  static const bool no_gemv = std::getenv("BEATRICE_HIP_NO_GEMV") != nullptr;  // A/B switch for measurements
+  static const bool no_gemv = bhip::meas_env("BEATRICE_HIP_NO_GEMV") != nullptr;  // A/B switch for measurements
   if constexpr (!L::GROUPED && L::P >= 3 && L::T == 1) {
     if (!no_gemv && a.B <= 2) { gemv::launch<L>(name, a, s); return; }
   }

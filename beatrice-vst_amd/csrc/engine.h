@@ -8,12 +8,14 @@
 //              sequence is capturable into a hipGraph).
 // The 1-stream C-ABI (abi.hip) wraps these with B = 1; the batched ABI (batch.hip) with B = N.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
 #include <vector>
 
 #include "kernels_misc.hip.h"
+#include "meas_env.h"
 #include "ring.h"
 
 namespace bhip {
@@ -69,8 +71,10 @@ constexpr int kMailboxWords = 8;
 
 // ---- team launches (team.hip.h): every workgroup of the launch spin-waits on granules other workgroups of the SAME launch write,
 // so all of them must be resident at once.  (a) At create time a context only gets a team launch when the device can hold the whole
-// team (occupancy x compute units >= workgroups: a partitioned or CU-masked GPU may not).  (b) Residency can still fail at run time
-// -- other processes' kernels between the team's workgroups -- and the bounded spins then give up and raise the context's pinned
+// team (occupancy x hipDeviceProp's compute-unit count >= workgroups: this catches a PARTITION of the GPU, whose device reports fewer
+// compute units; it does NOT see CU masks -- HSA_CU_MASK, a stream's CU mask -- or compute units held by other processes).
+// (b) Residency can therefore still fail at run time -- a masked GPU, other processes' kernels between the team's workgroups --: the
+// first call then spins until the bounded waits give up (~0.3-1 s, once), and the bounded spins then give up and raise the context's pinned
 // flag: team_recover() clears it, zeroes the granules and the context's rings (the stream restarts from silence, like a new
 // context) and switches the context to the per-layer launches for good; the call that hit the timeout returns zeros (the ABI's
 // answer to any internal failure), the following ones work.

@@ -11,6 +11,7 @@
 //
 // Who shares launches: the pitch estimator's launches ride in the content encoder's (front.hip).
 #pragma once
+#include "meas_env.h"
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -129,9 +130,8 @@ struct Banks<M, Rest...> {
   Banks<Rest...> rest;
 };
 // One workgroup of a launch whose dispatch ORDER is free (Table::desc): body type, argument block | stage << 16 (as Span::arg),
-// the workgroup's index inside its body, the body's grid x-extent.  With a descriptor per workgroup the bodies need not be
-// contiguous runs of indices: TableBuilder::interleave() deals the short, latency-bound workgroups among the long MFMA-dense
-// ones, so that a compute unit mostly hosts one of each instead of two of a kind (profiles/r05_notes.md).
+// the workgroup's index inside its body, the body's grid x-extent.  With a descriptor per workgroup the order is free:
+// TableBuilder::two_halves() puts every body with weights on one half of the chip.
 struct WgDesc { int type, arg, local, gx; };
 template <class... Ms>
 struct Table {
@@ -210,8 +210,7 @@ __device__ __forceinline__ void table_body(const Table<Ms...>* __restrict__ t, c
 // WITH_RAGGED = false: the launch has no ragged instance (its caller never passes ragged = true)
 template <int MINW, bool WITH_RAGGED = true, class... Ms>
 static inline void launch_table_w(const Table<Ms...>* d_table, const WgDesc* d_desc, int total, hipStream_t stream, const StepPairs& pairs, const bool ragged = false) {
-  // measurement aid: BEATRICE_HIP_TICK_PAD_LDS=<bytes> of dynamic LDS on top of the static block (e.g. to allow one workgroup per CU only)
-  static const int pad = std::getenv("BEATRICE_HIP_TICK_PAD_LDS") ? std::atoi(std::getenv("BEATRICE_HIP_TICK_PAD_LDS")) : 0;
+  constexpr int pad = 0;   // (dynamic LDS on top of the static block: none.  Round 2 measured one workgroup per CU this way: slower)
   if constexpr (WITH_RAGGED) {
     if (ragged) { hipLaunchKernelGGL((table_kernel_w<MINW, true, Ms...>), dim3(total), dim3(MaxM<Ms...>::NTHR), pad, stream, d_table, d_desc, pairs); return; }
   }
@@ -232,20 +231,12 @@ template <class... Ms>
 struct TableBuilder {
   Table<Ms...> t{};
   int used[sizeof...(Ms)] = {};
-  double cost[kMaxSpans] = {};  // estimated time of the body's workgroups (us, from the launch's timelines): what two_halves / interleave balance
+  double cost[kMaxSpans] = {};  // estimated time of the body's workgroups (us, from the launch's timelines): what two_halves balances
   int n_wg[kMaxSpans] = {};
   TableBuilder() { for (Span& sp : t.span) sp = Span{0x7fffffff, 1, -1, 0}; }
   bool ok = true;
   double flops = 0, bytes = 0;
   unsigned long long only = ~0ull;   // measurement builds (batch_tick.hip.h): bit I clear = bodies of type I are left out of the table
-  // Dispatch order by workgroup (the launch's WgDesc list).  klass[i] of span i (in the order added):
-  //   kFirst  -- ahead of everything (the first hop's GRU cells: later hops poll what they publish);
-  //   kDense  -- long, MFMA-dense workgroups, kept in the order added (longest first);
-  //   kLight  -- short workgroups that are mostly memory round trips: dealt among the dense ones in proportion to estimated time
-  //              (cost[]), the last `reserve` of their time kept for the end of the launch, where short workgroups pack the ragged edge;
-  //   kAt + f -- the whole span once the dense workgroups before it hold fraction f / 1000 of the dense time (linked GRU cells of
-  //              later hops: each behind at least one more round of the launch's workgroups).
-  static constexpr int kFirst = -1, kDense = -2, kLight = -3, kAt = 0;
   // the workgroups in the order the bodies were added (every body a contiguous run)
   std::vector<WgDesc> in_span_order() const {
     std::vector<WgDesc> out;
@@ -293,41 +284,6 @@ struct TableBuilder {
       more = false;
       for (int h = 0; h < NQ; ++h) if (at[h] < q[h].size()) { emit(q[h][at[h]++]); more = true; }
     }
-    return out;
-  }
-  std::vector<WgDesc> interleave(const int* klass, const double reserve) const {
-    struct Item { int span, local; double c; };
-    std::vector<Item> first, dense, light;
-    std::vector<std::pair<double, int>> at;   // (fraction, span)
-    for (int i = 0; i < t.n_spans; ++i) {
-      const double c = n_wg[i] > 0 ? cost[i] / n_wg[i] : 0.0;
-      if (klass[i] >= kAt) { at.push_back({klass[i] / 1000.0, i}); continue; }
-      std::vector<Item>& dst = klass[i] == kFirst ? first : (klass[i] == kDense ? dense : light);
-      for (int w = 0; w < n_wg[i]; ++w) dst.push_back(Item{i, w, c});
-    }
-    std::sort(at.begin(), at.end());
-    double total_d = 0, total_l = 0;
-    for (const Item& x : dense) total_d += x.c;
-    for (const Item& x : light) total_l += x.c;
-    // the light workgroups that wait for the end: from the back of the list (the shortest bodies) up to `reserve` of the light time
-    size_t n_main = light.size();
-    for (double held = 0; n_main > 0 && held + light[n_main - 1].c <= reserve * total_l; --n_main) held += light[n_main - 1].c;
-    double main_l = 0;
-    for (size_t j = 0; j < n_main; ++j) main_l += light[j].c;
-    std::vector<WgDesc> out;
-    auto emit = [&](const Item& x) { const Span& sp = t.span[x.span]; out.push_back(WgDesc{sp.type, sp.arg, x.local, sp.gx}); };
-    auto emit_span = [&](int i) { for (int w = 0; w < n_wg[i]; ++w) emit(Item{i, w, 0}); };
-    for (const Item& x : first) emit(x);
-    double cum_d = 0, cum_l = 0;
-    size_t jl = 0, ja = 0;
-    for (const Item& x : dense) {
-      while (ja < at.size() && cum_d >= at[ja].first * total_d) emit_span(at[ja++].second);
-      emit(x);
-      cum_d += x.c;
-      while (jl < n_main && cum_l < main_l * (cum_d / (total_d > 0 ? total_d : 1.0))) { emit(light[jl]); cum_l += light[jl].c; ++jl; }
-    }
-    while (ja < at.size()) emit_span(at[ja++].second);
-    for (; jl < light.size(); ++jl) emit(light[jl]);
     return out;
   }
   template <int I, class Args>

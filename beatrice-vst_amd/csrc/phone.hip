@@ -90,8 +90,8 @@ static void phone_forward_h(const PhoneWeights& w, const PhoneState& s, hipStrea
   using PL = PhoneLayers<H>;
   const int B = s.B;
   const F1Args fa = f1_args(w, s);
-  static const bool no_team = std::getenv("BEATRICE_HIP_NO_TEAM") != nullptr;
-  static const bool no_team_head = std::getenv("BEATRICE_HIP_NO_TEAM_HEAD") != nullptr;   // A/B switch: f1 as a launch of its own again
+  static const bool no_team = bhip::meas_env("BEATRICE_HIP_NO_TEAM") != nullptr;
+  static const bool no_team_head = bhip::meas_env("BEATRICE_HIP_NO_TEAM_HEAD") != nullptr;   // A/B switch: f1 as a launch of its own again
   const bool use_team = H == 1 && B == 1 && s.d_team_xb != nullptr && !no_team && !s.team_off;
   // the 1-stream ABI's contexts (one counter, nothing to publish): f1 runs at the head of the team launch (team.hip.h with_f1)
   const bool f1_in_team = use_team && !no_team_head && fa.hop == s.hop && fa.hop_publish == nullptr && fa.io_stride == 0;

@@ -88,7 +88,7 @@ static void pitch_forward_h(const PitchWeights& w, const PitchState& s, hipStrea
   const int B = s.B;
   const FftArgs fa = fft_args(w, s);
   launch_site(fft_info(s), st, [&] { hipLaunchKernelGGL(pitch_fft_kernel, dim3(B, H), dim3(256), 0, st, fa); });
-  static const bool no_team = std::getenv("BEATRICE_HIP_NO_TEAM") != nullptr;
+  static const bool no_team = bhip::meas_env("BEATRICE_HIP_NO_TEAM") != nullptr;
   if (H == 1 && B == 1 && s.d_team_xb != nullptr && !no_team && !s.team_off) {   // one stream: the three convolutions as ONE launch (team.hip.h)
     using namespace team;
     PitchTeamArgs a{};

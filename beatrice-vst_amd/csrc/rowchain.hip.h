@@ -15,6 +15,7 @@
 // segment one k-ascending MFMA chain, segments added in order, then bias / scale / activation / residual in the same
 // order as conv_gemm's epilogue; softmax as attn_pv_kernel), so results are bit-identical.
 #pragma once
+#include "meas_env.h"
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -893,7 +894,7 @@ static inline void launch_many_rows(const char* name, const ConvArgs& a, hipStre
   constexpr int LAST = L::K - 256 * (L::P - 1);
   constexpr bool ok = !L::GROUPED && L::K % 16 == 0 && LAST % 64 == 0 && L::NOUT % 16 == 0;
   if constexpr (ok) {
-    static const bool off = std::getenv("BEATRICE_HIP_NO_CONVROWS") != nullptr;
+    static const bool off = bhip::meas_env("BEATRICE_HIP_NO_CONVROWS") != nullptr;
     if (!off) {
       constexpr int COLS = (L::NOUT % 128 == 0 && (L::NOUT > 256 || (L::NOUT == 256 && L::K >= 768))) ? 128 : 0;
       rc::launch_conv_rows<L, COLS, 2>(name, a, s);

@@ -99,7 +99,7 @@ bool WaveState::create(int B_, int H_, int n_slots_, int n_add_, int n_frm_, flo
     // (pinned host memory, written by the kernel only when a wait was given up: the host reads it after every call for free)
     BHIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d_team_dead), sizeof(int), hipHostMallocDefault));
     *d_team_dead = 0;
-    if (std::getenv("BEATRICE_HIP_TEAM_TRACE")) {   // measurement aid: per-stage stamps of workgroup 0 (BeatriceHip_TeamTraceDump)
+    if (bhip::meas_env("BEATRICE_HIP_TEAM_TRACE")) {   // measurement aid: per-stage stamps of workgroup 0 (BeatriceHip_TeamTraceDump)
       BHIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_team_trace), sizeof(unsigned long long) * 1024));
       BHIP_TRY(hipMemset(g_team_trace, 0, sizeof(unsigned long long) * 1024));
     }
@@ -141,7 +141,7 @@ static void launch_c1(const WaveWeights& w, const WaveState& s, int blk, const R
 // One stream, one hop (the 1-stream C-ABI): input mix, the four conditioned blocks and upsampler stage 1 + the stage-2 transposed
 // conv -- 29 layers -- as ONE launch of a team of workgroups (team.hip.h).  BEATRICE_HIP_NO_TEAM=1: the per-layer launches (A/B, parity).
 static bool team_on() {
-  static const bool off = std::getenv("BEATRICE_HIP_NO_TEAM") != nullptr;
+  static const bool off = bhip::meas_env("BEATRICE_HIP_NO_TEAM") != nullptr;
   return !off;
 }
 static void launch_wave_team(const WaveWeights& w, const WaveState& s, hipStream_t st, const CondArgs* cond) {
@@ -181,7 +181,7 @@ static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t
   ConvArgs a;
   const bool use_team = H == 1 && B == 1 && s.d_team_xb != nullptr && !s.team_off && part.first <= 1 && part.last >= 6 && team_on();
   const CondArgs ca = cond_args(w, s);
-  static const bool no_team_head = std::getenv("BEATRICE_HIP_NO_TEAM_HEAD") != nullptr;   // A/B switch: wave.cond as a launch of its own again
+  static const bool no_team_head = bhip::meas_env("BEATRICE_HIP_NO_TEAM_HEAD") != nullptr;   // A/B switch: wave.cond as a launch of its own again
   // the 1-stream ABI's contexts (one counter, no pair to hand on): the conditioning mix runs at the head of the team launch
   const bool cond_in_team = use_team && !cond_done && !no_team_head && ca.hop == s.hop && ca.hop_next_out == nullptr;
   if (!cond_done && !cond_in_team) launch_site(cond_info(s), st, [&] { hipLaunchKernelGGL(wave_cond_kernel, dim3(rows), dim3(256), 0, st, ca); });
@@ -200,7 +200,7 @@ static void wave_forward_h(const WaveWeights& w, const WaveState& s, hipStream_t
   // per-layer launches win while a launch cannot fill the chip (256 streams: 0.293 vs 0.413 ms per step), the row-local
   // kernels once 16 streams per workgroup do (8192 streams: 84-89 TFLOP/s per block half against 34-61 for the six
   // layers; 3.40 -> 3.82 M frames/s); even at 2048.  BEATRICE_HIP_ROWCHAIN=1 / =0 forces one or the other (measurements, parity tests).
-  static const char* const rc_env = std::getenv("BEATRICE_HIP_ROWCHAIN");
+  static const char* const rc_env = bhip::meas_env("BEATRICE_HIP_ROWCHAIN");
   const bool rowchain = rc_env != nullptr ? rc_env[0] != '0' : B >= 2048;
   for (int blk = 0; blk < B_NBLOCKS; ++blk) {
     if (!in_part(2 + blk)) continue;

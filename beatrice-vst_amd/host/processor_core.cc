@@ -535,9 +535,10 @@ int BeatriceHost_NumSpeakers(void* p) { return core(p)->n_speakers(); }
 void BeatriceHost_EnablePitchTrace(void* p, int capacity) { core(p)->EnablePitchTrace(capacity); }
 int BeatriceHost_TakePitchTrace(void* p, int* out, int cap) {
   const auto t = core(p)->TakePitchTrace();
-  const int n = static_cast<int>(t.size()) < cap ? static_cast<int>(t.size()) : cap;
-  for (int i = 0; i < n; ++i) out[i] = t[i];
-  return static_cast<int>(t.size());
+  const int held = static_cast<int>(t.size());
+  const int n = held < cap ? held : (cap > 0 ? cap : 0);
+  for (int i = 0; i < n; ++i) out[i] = t[held - n + i];   // the NEWEST n entries, oldest of them first (beatrice_host.h)
+  return held;
 }
 }
 

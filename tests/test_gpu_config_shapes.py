@@ -73,12 +73,13 @@ def test_config3_256_streams_64_rotating_speakers(bv, oracle, product, model_dir
     assert dev <= TOL
 
 
-def test_config3_shape_through_the_tick_pipeline_two_hops_per_step(bv, oracle, product, model_dir64):
-    """The form bench.py --config 3 times: 256 streams on the 64-speaker table in tick mode with two hops per stage per launch
-    (a speaker's rows then fill half an attention tile; while its streams switch, the rest are quads), every stream rotating,
-    k-NN 4 -- every stream against an independent oracle stream."""
+@pytest.mark.parametrize("H", [4, 2])
+def test_config3_shape_through_the_tick_pipeline(bv, oracle, product, model_dir64, H):
+    """The form bench.py --config 3 times: 256 streams on the 64-speaker table in tick mode with H hops per stage per launch
+    (4: the bench's default -- a speaker's 4 streams x 4 hops are exactly one full 16-row attention tile; 2: half a tile; while
+    its streams switch, the rest are quads), every stream rotating, k-NN 4 -- every stream against an independent oracle stream."""
     from tick_driver import run_tick
-    B, S, H, steps = 256, 64, 2, 9
+    B, S, steps = 256, 64, 9
     hops = H * steps
     audio = np.stack([bv.synth_audio(160 * hops, seed=4500 + s) for s in range(B)])
     start = [s % S for s in range(B)]
@@ -118,7 +119,7 @@ def test_config3_shape_through_the_tick_pipeline_two_hops_per_step(bv, oracle, p
     batch.close()
     m.close()
     dev = float(np.abs(ref - got).max())
-    print("configs[3] shape in tick mode, two hops per step: max-abs %g %s" % (dev, "bit-identical" if np.array_equal(ref, got) else ""))
+    print("configs[3] shape in tick mode, %d hops per step: max-abs %g %s" % (H, dev, "bit-identical" if np.array_equal(ref, got) else ""))
     assert np.abs(got).max() > 0.05
     assert dev <= TOL
 

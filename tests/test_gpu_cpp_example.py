@@ -33,6 +33,26 @@ def test_cpp_host_program_matches_python_driven_chain(bv, product, model_dir, tm
     assert np.array_equal(got, want)
 
 
+def test_latency_loop_program_equals_its_oracle_build(model_dir, built):
+    """examples/latency_b1 (the C++ loop bench.py's `latency_b1` runs: the reference's three per-hop calls, clock_gettime) against the
+    same source linked to the oracle: the running checksum of one output sample per hop over 600 hops must be EQUAL (bit-identical
+    PCM), the report must parse, and no hop of a healthy run takes longer than the 10 ms budget."""
+    import json
+    exe, ora = os.path.join(REPO, "examples", "latency_b1"), os.path.join(REPO, "oracle", "latency_b1_on_oracle")
+    assert os.path.exists(exe), "examples/latency_b1 was not built (make -C beatrice-vst_amd)"
+    assert os.path.exists(ora), "oracle/latency_b1_on_oracle was not built (make -C oracle)"
+    lines = []
+    for prog in (exe, ora):
+        r = subprocess.run([prog, model_dir, "600", "50", "2", "--histogram"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    hip, cpu = lines
+    print("latency loop, 600 hops: HIP p50 %.1f us p99 %.1f max %.1f | oracle p50 %.1f us" % (hip["p50_us"], hip["p99_us"], hip["max_us"], cpu["p50_us"]))
+    assert hip["last_hop_peak"] > 1e-3
+    assert hip["checksum"] == cpu["checksum"] and hip["last_hop_peak"] == cpu["last_hop_peak"]
+    assert hip["hops_over_10ms"] == 0
+
+
 @pytest.mark.parametrize("speaker,k,placement", [(2, 3, "range"), (-1, 2, "range"), (-1, 0, "speaker")])
 def test_node_host_program_matches_single_batch(bv, product, model_dir, tmp_path, speaker, k, placement):
     """examples/node_convert: the C++ host of one node (one thread + one batch per GPU, model read once on GPU 0, parameter

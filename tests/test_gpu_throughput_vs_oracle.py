@@ -11,12 +11,13 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4   # north_star's bound on output PCM; observed 0.0
 
 
-@pytest.mark.parametrize("H", [2, 1])
+@pytest.mark.parametrize("H", [4, 2, 1])
 def test_bench_workload_in_tick_mode_matches_oracle(bv, oracle, product, model_dir, H):
     """bench.py's headline: BASELINE.json configs[2] -- 256 streams, 1 speaker, k-NN 0, every tenth stream with 0.5 s of
-    digital silence, 64 resident steps per stream cycled as I/O slots, steps of H hops (2: the bench's default) enqueued without
-    waiting.  100 steps (the slot ring wraps), a sample of 12 streams (silence-gap streams 3, 13, 253 among them) against
-    independent oracle streams."""
+    digital silence, 64 resident steps per stream cycled as I/O slots, steps of H hops (4: the bench's default,
+    `bench.DEFAULT_HOPS_PER_STEP_TICK`; tests/test_cpu_bench_defaults_are_tested.py keeps test and bench in step) enqueued
+    without waiting.  100 steps (the slot ring wraps), a sample of 12 streams (silence-gap streams 3, 13, 253 among them)
+    against independent oracle streams."""
     B, n_cycle, steps = 256, 64, 100
     audio = np.stack([bv.synth_audio(160 * H * n_cycle, seed=s, silence_gap=(s % 10 == 3)) for s in range(B)]).reshape(B, n_cycle * H, 160)
 
@@ -46,13 +47,14 @@ def test_bench_workload_in_tick_mode_matches_oracle(bv, oracle, product, model_d
     assert dev <= TOL
 
 
-@pytest.mark.parametrize("B,steps,H", [(8, 330, 1), (8, 330, 2)])
+@pytest.mark.parametrize("B,steps,H", [(8, 330, 4), (8, 330, 1), (8, 330, 2)])
 def test_tick_soak_vs_oracle(bv, oracle, product, model_dir, B, steps, H):
     """Soak: every stream of a small batch for 330 hops in tick mode against independent oracle streams driven through the
     reference protocol (processor_core_2.cc:50-256; a switch installs one K/V block per hop, :179-181): speaker switches
     throughout, k-NN on / off / changed, formant and pitch settings, pitch range, two stream resets -- early, in the middle and
     near the end, so that every ring of the pipeline has wrapped several times when they arrive."""
-    # (H = 2: two hops per stage per launch; the script then precedes a STEP, i.e. every second hop of the oracle streams)
+    # (H = 2 / 4: that many hops per stage per launch -- 4 is the bench's default --; the script then precedes a STEP, i.e. every H-th hop of
+    #  the oracle streams)
     audio = np.stack([bv.synth_audio(160 * H * steps, seed=7700 + s, silence_gap=(s == 5)) for s in range(B)]).reshape(B, steps * H, 160)
 
     def settings(batch):

@@ -102,6 +102,7 @@ def test_any_rate_wrapper_around_the_tick_pipeline(bv, oracle, product, model_di
     assert a.BeatriceBatch_BindResidentBlocks(h, d_in, d_out, channels, block, slots) == 0
     delay = a.BeatriceBatch_ResidentBlocksDelay(h)
     assert delay == want_delay
+    assert a.BeatriceBatch_EnableSilentBlockRule(h, 0) == -1 and a.BeatriceBatch_EnableSilentBlockRule(h, 1) == -1   # not under a binding
     # several hops per step: the last calls end on a step that is still filling and stay owed at a drained point; blocks of silence
     # behind the material bring them out (the wrapper oracle is not asked about those)
     n_real, n_blocks = n_blocks, n_blocks + (0 if H == 1 else delay - (stages - 1) + 1)

@@ -82,6 +82,9 @@ def test_mixed_rate_batch_around_the_tick_pipeline_matches_one_proxy_per_stream(
     delay = a.BeatriceBatch_ResidentBlocksDelay(h)
     assert delay == stages - 1
     assert a.BeatriceBatch_ProcessBlocksDevice(h, None, None, channels, cap) == -1                      # the uniform entry point is not this binding's
+    # the binding owns the silent-rule flags (its "this stream's FIFO did not fire" marks): the rule cannot be switched under it, in
+    # either direction -- switching it off used to be accepted and silently advanced every stream on every fired step
+    assert a.BeatriceBatch_EnableSilentBlockRule(h, 0) == -1 and a.BeatriceBatch_EnableSilentBlockRule(h, 1) == -1
     assert a.BeatriceBatch_ProcessBlocksRaggedDevice(h, (C.c_int * B)(*([cap + 1] * B))) == -1          # a block longer than its cell
     got = [np.zeros_like(x[s]) for s in range(B)]
     chunk = slots - delay - 1

@@ -1,9 +1,10 @@
 """Summarise a BEATRICE_HIP_TICK_TRACE dump: per body type, workgroup count and duration; makespan; slot utilisation."""
 import sys
 import numpy as np
-NAMES = "f1 fft f2 f3 f4 f5 p1 rb p23 pout head out cond inp up1 res1a res1b up2 qgru pgru vq tail tail1 tail2 tail3 blkA1 blkA2 blkA4 blkA8 blkB blkBq f4s f5s rbs p1s up1s tail1s tail2s qgru1 pgru1 qgrum pgrum".split()
+NAMES = "f1 fft f2 f3 f4 f5 p1 rb p23 pout head out cond inp up1 res1a res1b up2 qgru pgru vq tail tail1 tail2 tail3 blkA1 blkA2 blkA4 blkA8 blkB blkBq f4s f5s rbs p1s up1s tail1s tail2s qgru1 pgru1 qgrum pgrum f2l f3l p23l poutl outl inpl up1l res1al res1bl up2l".split()
 d = np.loadtxt(sys.argv[1], dtype=np.uint64).astype(np.int64)
 d = d[d[:, 1] > 0]
+d = d[np.abs(d[:, 0] - np.median(d[:, 0])) < 100000]   # (entries of workgroups that left at once keep an older tick's stamps: beyond 1 ms of the median start)
 t0 = d[:, 0].min()
 start, end, typ = (d[:, 0] - t0) / 100.0, (d[:, 1] - t0) / 100.0, d[:, 2] & 255   # 100 MHz -> us
 cyc = d[:, 2] >> 8
