@@ -1251,6 +1251,8 @@ int BeatriceBatch_ResetStream(BeatriceBatch* b, int stream) {
 int BeatriceBatch_ConvertFramesDevice(BeatriceBatch* b, const float* d_in, float* d_out) {
   const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
+  if (b->io_slots > 0 && (d_in || d_out)) return -1;   // resident I/O is bound: NULL, NULL (the step reads and writes its slot)
+  if (b->hs.on || b->r48.on || b->rb.on) return -1;     // host streaming and the wrappers around the ticks feed the pipeline through their own entry points
   return step_device(b, d_in, d_out) ? 0 : -2;
 }
 // Resident I/O: the caller keeps n_slots steps of input and output on the device,
@@ -1349,6 +1351,7 @@ int BeatriceBatch_TimeTickLaunch(BeatriceBatch* b, int ticks, float* us_per_laun
   const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (!b->tk.on || ticks < 1 || ticks > 64 || !us_per_launch) return -1;
+  if (b->hs.on || b->r48.on || b->rb.on) return -1;   // plain tick mode only (those modes feed the pipeline through their own entry points)
   // ONE pair of events around `ticks` back-to-back launches (an event pair per launch adds two commands between
   // consecutive launches and reads ~5 us long against rocprofv3's kernel durations); the figure includes the boundary
   // between two ticks, which belongs to the launch's cost
@@ -1493,6 +1496,7 @@ int BeatriceBatch_ProfileKernels(BeatriceBatch* b, int repeats, int max_entries,
 int BeatriceBatch_TimeSteps(BeatriceBatch* b, int steps, float* ms) {
   const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok || steps < 1 || !ms) return b && b->ok ? -1 : -2;
+  if (b->hs.on || b->r48.on || b->rb.on) return -1;   // (as BeatriceBatch_ConvertFramesDevice: those modes feed the pipeline through their own entry points)
   bool ok = sync_all(b) && hip_ok(hipEventRecord(b->ev0, b->stream), "ev0");
   for (int i = 0; i < steps && ok; ++i) ok = step_device(b, nullptr, nullptr);
   ok = ok && hip_ok(hipEventRecord(b->ev1, wave_stream(b)), "ev1") && hip_ok(hipEventSynchronize(b->ev1), "evsync") &&

@@ -76,7 +76,7 @@ int BeatriceBatch_EnableHostStreaming(BeatriceBatch* b, int enable) {
     host_stream_free(b);
     return rb;
   }
-  if (b->H > tick::kMaxHops || b->io_slots > 0 || b->tk.on || b->pipelined) return -1;  // one or two hops per step (buffers are [B][H x 160] -> [B][H x 240]); no other binding or pipelining
+  if (b->H > tick::kMaxHops || b->io_slots > 0 || b->tk.on || b->pipelined || b->silent.on) return -1;   // (the in-order silent-block rule: switch it off first)  // one or two hops per step (buffers are [B][H x 160] -> [B][H x 240]); no other binding or pipelining
   h.n_slots = b->tk.plan.count() + 8;
   const size_t n_in = (size_t)b->B * b->H * B_IN_HOP, n_out = (size_t)b->B * b->H * B_OUT_HOP;
   bool ok = hip_ok(hipMalloc(reinterpret_cast<void**>(&h.d_in), sizeof(float) * n_in * h.n_slots), "hs d_in") &&

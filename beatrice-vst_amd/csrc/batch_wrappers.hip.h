@@ -203,6 +203,7 @@ int BeatriceBatch_ConfigureWrapper(BeatriceBatch* b, double sample_rate) {
   const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;
   if (b->H != 1 && b->H != 2 && b->H != 4) return -1;   // (several hops per step: for BeatriceBatch_BindResidentBlocks, the wrapper around the ticks)
+  if (b->rb.on) return -1;                              // resident blocks are bound: the binding restarts the wrapper itself when it is made and released
   if (!sync_all(b)) return -2;
   if (!b->wrap.configure(sample_rate)) return -1;  // rate <= 0, or a ratio whose filter history exceeds the state block
   const int B = b->B;

@@ -629,20 +629,34 @@ def main():
     if product.BeatriceBatch_Prepare(batch.h):  # graph capture now, not inside the first (possibly timed) steps
         raise SystemExit("Prepare failed")
 
-    # (schedule of configs[3]'s speaker switches, worked out before the timed loop: stream s switches at steps congruent to
-    #  -(s * 200 // B) modulo 200)
+    # configs[3]'s speaker switches: stream s moves to the next speaker every 200 hops, staggered by stream index (it switches at hops
+    # congruent to -(s * 200 // B) modulo 200).  The whole run's schedule is worked out BEFORE the timed loop as one (streams, speakers) array
+    # pair per step -- what a server's control plane hands over --, so that a step's host work is one BeatriceBatch_SetTargetSpeakers call
+    # (settings travel with the step: the switches of its hops, before it)
     switchers = [[s for s in range(B) if (r + s * 200 // B) % 200 == 0] for r in range(200)]
+    schedule = []
+
+    def schedule_until(n_steps):
+        while len(schedule) < n_steps:
+            i = len(schedule)
+            moved = []
+            if a.config == 3 and i > 0:
+                for hop in range(i * H, (i + 1) * H):
+                    for s in switchers[hop % 200]:
+                        current_speaker[s] = (current_speaker[s] + 1) % a.speakers
+                        moved.append(s)
+            n_mv = len(moved)
+            schedule.append((n_mv, (ctypes.c_int * n_mv)(*moved), (ctypes.c_int * n_mv)(*[current_speaker[s] for s in moved])) if n_mv else None)
+
+    if a.config == 3:
+        schedule_until(a.warmup + a.steps + 700)
 
     def step(i):
-        if a.config == 3 and i > 0:  # every stream moves to the next speaker every 200 hops, staggered by stream index
-            moved = []
-            for hop in range(i * H, (i + 1) * H):   # (settings travel with the step: the switches of its hops, before it)
-                for s in switchers[hop % 200]:
-                    current_speaker[s] = (current_speaker[s] + 1) % a.speakers
-                    moved.append(s)
-            if moved:   # one call for all of the step's switches
-                n_mv = len(moved)
-                product.BeatriceBatch_SetTargetSpeakers(batch.h, n_mv, (ctypes.c_int * n_mv)(*moved), (ctypes.c_int * n_mv)(*[current_speaker[s] for s in moved]))
+        if a.config == 3:
+            if i >= len(schedule):
+                schedule_until(i + 1)
+            if schedule[i] is not None:   # one call for all of the step's switches
+                product.BeatriceBatch_SetTargetSpeakers(batch.h, *schedule[i])
         if a.config == 4 and tick48:
             rc = product.BeatriceBatch_ConvertBlocks48kDevice(batch.h, None, None, 2)
         elif a.config == 4:

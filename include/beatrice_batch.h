@@ -78,6 +78,66 @@ long long BeatriceHip_MathSelfTest(int which, unsigned* first_bad_bits);
 int BeatriceHip_ModelBlob(int kind, void* model, int allocate, void** d_ptr, size_t* n_bytes);
 int BeatriceHip_ModelBlobReady(int kind, void* model);
 
+/* ---------------------------------------------------------------------------------------------------------------------------------------
+ * MODES.  A batch is in exactly one of the modes below; the table says which entry point works in which (ok), which is refused with -1
+ * (-), and at which hops per step H (BeatriceBatch_CreateBlock) the mode exists.  A refused call changes NOTHING: no drain, no clock, no
+ * flag -- tests/test_gpu_mode_matrix.py asks every "-" cell of this table between steps and compares the batch, bit for bit, with one that
+ * never asked.  The "ok" cells are the -m gpu parity tests against the oracle.  Settings (BeatriceBatch_Set*, ResetStream, Morph*,
+ * SetInputGain / SetOutputGain once a wrapper is configured) work in every mode and apply to the step / call that follows them.
+ *
+ *   mode (how it is entered)                                        H           its entry point per step / call
+ *   A  in order            (a new batch)                            1 2 4 8     ConvertFrames, ConvertFramesDevice
+ *   B  stage pipelining    (EnablePipelining(2..4))                 1 2 4 8     ConvertFrames, ConvertFramesDevice
+ *   C  resident I/O        (BindResidentIO)                         1 2 4 8     ConvertFramesDevice(NULL, NULL)
+ *   D  tick mode           (C + EnableTickPipeline(1))              1 2 4       ConvertFramesDevice(NULL, NULL)
+ *   E  host streaming      (EnableHostStreaming(1))                 1 2 4       StreamFrames / StreamFlush
+ *   F  48 kHz blocks around the ticks (BindResidentIO48k)           1 2 4       ConvertBlocks48kDevice(NULL, NULL)
+ *   G  resident blocks around the ticks, one set of clocks
+ *                          (ConfigureWrapper + BindResidentBlocks)  1 2 4       ProcessBlocksDevice(NULL, NULL, channels, n)
+ *   P  ... with clocks per stream
+ *                          (ConfigureWrapperRates + BindResidentBlocksRagged)  1   ProcessBlocksRaggedDevice
+ *   S  A with the silent-block rule (EnableSilentBlockRule(1))      1           ConvertBlocks48k[Device]
+ *
+ *   entry point                          A        B     C     D        E     F        G     P     S
+ *   ConvertFrames (host buffers)         ok       ok    -     -        -     -        -     -     ok
+ *   ConvertFramesDevice(d_in, d_out)     ok       ok    -     -        -     -        -     -     ok
+ *   ConvertFramesDevice(NULL, NULL)      ok       ok    ok    ok       -     -        -     -     ok
+ *   ConvertBlocks48k, ..Device(ptrs)     ok, H=1  -     -     -        -     -        -     -     ok
+ *   ConvertBlocks48kDevice(NULL, NULL)   -        -     -     -        -     ok       -     -     -
+ *   ProcessBlocks, ..Device(ptrs)        ok (1)   -     -     -        -     -        -     -     - (1)
+ *   ProcessBlocksDevice(NULL, NULL)      -        -     -     -        -     -        ok    -     -
+ *   ProcessBlocksRagged                  ok (2)   -     -     -        -     -        -     -     - (2)
+ *   ProcessBlocksRaggedDevice            -        -     -     -        -     -        -     ok    -
+ *   StreamFrames / StreamFlush           -        -     -     -        ok    -        -     -     -
+ *   EnableSilentBlockRule(1)             ok, H=1  -     -     ok, H=1  -     ok, H=1  -     -     ok
+ *   EnableSilentBlockRule(0)             ok       ok    ok    ok       ok    ok       -     -     ok
+ *   SetSilentStreams                     - (3)    -     -     - (3)    -     - (3)    -     -     ok
+ *   EnablePipelining(n)                  ok       ok    ok    -        -     -        -     -     - (n >= 1)
+ *   EnableTickPipeline(1)                -        -     ok(4) ok       -     -        -     -     -
+ *   EnableTickPipeline(0)                ok       ok    ok    ok       -     -        -     -     ok
+ *   EnableHostStreaming(1)               ok       -     -     -        ok    -        -     -     -
+ *   BindResidentIO (bind)                ok       ok    ok    -        -     -        -     -     -
+ *   BindResidentIO (NULL, NULL)          ok       ok    ok    -        -     -        -     -     ok
+ *   BindResidentIO48k (bind)             ok       -     -     -        -     ok (5)   -     -     -
+ *   BindResidentBlocks (bind)            ok (1)   -     -     -        -     -        ok(5) ok(5) -
+ *   BindResidentBlocksRagged (bind)      ok (2)   -     -     -        -     -        ok(5) ok(5) -
+ *   Bind...(NULL, NULL) of F / G / P     ok       ok    ok    ok       ok    leaves F leaves G / P      ok
+ *   ConfigureWrapper                     ok       ok    ok    ok       ok    ok       -     -     ok
+ *   ConfigureWrapperRates                ok, H=1  -     -     -        -     -        -     -     ok
+ *   ProfileKernels                       ok       ok    ok    -        -     -        -     -     ok
+ *   TimeSteps                            ok       ok    ok    ok       -     -        -     -     ok
+ *   TimeTickLaunch                       -        -     -     ok       -     -        -     -     -
+ *
+ *   (1) once BeatriceBatch_ConfigureWrapper has been called (-1 before); one hop per step for the in-order calls, H = 1 / 2 / 4 for the binding.
+ *   (2) once BeatriceBatch_ConfigureWrapperRates has been called (-1 before); one hop per step.
+ *   (3) ok once the rule is enabled in that mode (D, F: one hop per step; the flagged streams sit the NEXT step out).
+ *   (4) with more resident slots than BeatriceBatch_TickStages() and at most 4096 of them, B <= 4096, H = 1 / 2 / 4.
+ *   (5) a bind call on a batch that is already in F / G / P first LEAVES that mode (drains, restarts the wrapper), then binds anew.
+ *
+ * Environment variables the library reads: BEATRICE_HIP_DEBUG (print HIP errors to stderr), BEATRICE_HIP_CUMASK ("lo-hi;lo-hi;..": CU masks
+ * of the stage-pipelining streams), BEATRICE_HIP_HOP_GRAPH (the 1-stream calls replayed as hipGraphs).  Nothing else: the A/B switches of
+ * profiles/r0*_notes.md exist in measurement builds only (tools/debug/build_variant.sh <name> -DBEATRICE_HIP_MEASUREMENT_BUILD).
+ * --------------------------------------------------------------------------------------------------------------------------------------- */
 /* n_streams concurrent streams; speaker tables may hold up to max_speakers entries
  * (n_speakers + 1 when the caller keeps the reference's extra "morph" slot). */
 BeatriceBatch* BeatriceBatch_Create(const Beatrice20rc0_PhoneExtractor* phone, const Beatrice20rc0_PitchEstimator* pitch,
