@@ -395,6 +395,7 @@ _BATCH = {
     "BeatriceBatch_ResidentBlocksDelay": (C.c_int, [_vp]),
     "BeatriceBatch_ResidentBlocksDelayFor": (C.c_int, [_vp, C.c_int]),
     "BeatriceBatch_ResidentBlocksOwed": (C.c_int, [_vp]),
+    "BeatriceBatch_FlushResidentBlocks": (C.c_int, [_vp]),
     "BeatriceBatch_BindResidentBlocksRagged": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int]),
     "BeatriceBatch_ProcessBlocksRaggedDevice": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "BeatriceBatch_MorphSpeakerStaged": (C.c_int, [_vp, C.c_int, C.c_int, _f32p, C.c_int, C.c_uint]),

@@ -284,6 +284,7 @@ struct BeatriceBatch {
       long long last_hop() const { return (t0 + dout.n_in - 1) / wrapn::kBlock - 1; }   // the newest model hop its samples come from (wrap_post_kernel)
     };
     std::deque<Job> jobs;                                    // calls whose output half is still to run, oldest first
+    float* d_zero = nullptr;                                 // [B][channels][n] zeros: the input of the calls BeatriceBatch_FlushResidentBlocks makes up
     // the form with clocks PER STREAM (BeatriceBatch_BindResidentBlocksRagged; the rates, clocks and tap tables are `rw`'s): a slot
     // holds one cell of channels x max_samples floats per stream; a call's per-stream records stay on the device until its output
     // half has run; slot_map[b][g mod map_ring] = the resident slot of the step that stream b's hop g rode in
@@ -705,7 +706,7 @@ int model_ready(Model* m) {
 }  // namespace
 
 extern "C" {
-static bool rb_step(BeatriceBatch* b);
+static bool rb_step(BeatriceBatch* b, bool synthetic = false);
 static void rb_release(BeatriceBatch* b);
 static void silent_release(BeatriceBatch* b);
 

@@ -127,6 +127,10 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
     }
   }
   gru_at(0);
+  // (the k-NN lookup: one workgroup per stream walks the step's hops against the stream's codebook -- 35 us at four hops per step with
+  //  64 speakers' codebooks in play.  At the end of the table, where round 2 had put it by its one-hop cost, it ENDED the launch: 256
+  //  workgroups alone on the chip from 229 to 283 us of configs[3]'s tick, profiles/r06_notes.md section 3.  Present only while some stream has k > 0)
+  { const VqArgs a{H, ps.raw, phone_vector_ring(ps), hp(Plan::VQ), ps.d_cbT, ps.d_cnorm, ps.d_vqk}; tb->template add<T_VQ>(LaunchInfo{"phone.vq", 0, 4.0 * B * H * 256}, a, dim3(B, 1), Plan::VQ, !ps.skip_vq, 9.0 * H, true); }
   if (!pl.split_tail) {
     TailArgs ta = tail_args(ww, ws); ta.hop = hp(pl.tail()); tb->template add<T_TAIL>(tail_info(ws), ta, dim3(B, 1), pl.tail(), keep(4), 41, true);
   } else {
@@ -171,7 +175,6 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
   gru_at(3);
   { FftArgs a = fft_args(qw, qs); a.hop = hp(Plan::FFT); tb->template add<T_FFT>(fft_info(qs), FftArgs2{a, B}, dim3((B + 1) / 2, H), Plan::FFT, keep(0), 8.7); }
   { const ConvArgs a = conv(ps.h, phone_out_ring(ps), pw.out_w, pw.out_b, Plan::OUT); tb->template add<T_OUT>(OpOUT::info("phone.out", a), a, OpOUT::grid(a), Plan::OUT, keep(3), 4.5); }
-  { const VqArgs a{H, ps.raw, phone_vector_ring(ps), hp(Plan::VQ), ps.d_cbT, ps.d_cnorm, ps.d_vqk}; tb->template add<T_VQ>(LaunchInfo{"phone.vq", 0, 4.0 * B * H * 256}, a, dim3(B, 1), Plan::VQ, !ps.skip_vq, 6.0, true); }
   { F1Args a = f1_args(pw, ps); a.hop = hp(Plan::F1); a.hop_publish = nullptr; a.hop_publish_wave = nullptr; tb->template add<T_F1>(f1_info(ps), F1Args2{a, B}, dim3((B + 1) / 2, H), Plan::F1, keep(0), 3.7); }
   { CondArgs a = cond_args(ww, ws); a.hop = hp(Plan::COND); a.hop_next_out = nullptr; tb->template add<T_COND>(cond_info(ws), a, dim3((B * H + 1) / 2, 1), Plan::COND, keep(0), 1.5); }
   if (!tb->ok) return false;

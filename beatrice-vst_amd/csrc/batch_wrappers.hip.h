@@ -517,6 +517,7 @@ static void rb_release(BeatriceBatch* b) {
   if (r.gain_ev) { for (int i = 0; i < r.ring; ++i) if (r.gain_ev[i]) (void)hipEventDestroy(r.gain_ev[i]); delete[] r.gain_ev; }
   if (r.h_rs) (void)hipHostFree(r.h_rs);
   if (r.d_map) (void)hipFree(r.d_map);
+  if (r.d_zero) (void)hipFree(r.d_zero);
   r = BeatriceBatch::ResidentBlocks{};
 }
 // leaves either form of the resident blocks: the pipeline drained, tick mode off, the wrapper restarted at its rate(s)
@@ -551,7 +552,9 @@ static int rb_delay(const BeatriceBatch* b, int n) {
   const long long hops = (long long)(b->H - 1) + (long long)(stages - 1) * b->H;
   return (int)((hops * wrapn::kBlock + m_lo - 1) / m_lo) + 1;   // (+ 1: the output half rides in the launch of the call after)
 }
-static bool rb_step(BeatriceBatch* b) {
+// synthetic: a call BeatriceBatch_FlushResidentBlocks makes up -- a block of zeros that is no call of the caller's: it reads no slot, owes no
+// output block and does not count (the call counter stands), but moves the wrapper and fires hops as a block of silence would
+static bool rb_step(BeatriceBatch* b, const bool synthetic) {
   using namespace wrapn;
   BeatriceBatch::ResidentBlocks& r = b->rb;
   const int B = b->B, n = r.n, H = r.H;
@@ -571,7 +574,7 @@ static bool rb_step(BeatriceBatch* b) {
   if (m < 0 || m > kMaxSamples) return false;
   const Dir dout = w.to_outer(m);
   if (dout.n_out != n) return false;
-  a.src = r.d_in + (size_t)(call % r.n_slots) * B * r.channels * n;
+  a.src = synthetic ? r.d_zero : r.d_in + (size_t)(call % r.n_slots) * B * r.channels * n;
   a.channels = r.channels; a.n = n; a.st = b->d_wrap; a.gain_in = seg; a.taps_in = b->d_wrap_taps + (a.din.decimate ? 0 : nt);
   a.inner = b->d_wrap_inner; a.stride = kInnerStride; a.in16 = r.d_in16; a.row16 = H * B_IN_HOP; a.B = B; a.H = H;
   // the 480-sample accumulation; a model hop every time it fills (the per-stream FIFO array holds it), into its place: hop
@@ -618,9 +621,9 @@ static bool rb_step(BeatriceBatch* b) {
   for (int i = 0; i < steps; ++i) if (!tick_run(b, true)) return false;   // the full steps: into the pipeline
   if (steps == 0 && H == 1 && !tick_run(b, false)) return false;          // one hop per step: the pipeline advances with every call
   r.hops_done = r.hops_fed();
-  r.jobs.push_back(BeatriceBatch::ResidentBlocks::Job{call, r.t48, dout});
+  if (!synthetic) r.jobs.push_back(BeatriceBatch::ResidentBlocks::Job{call, r.t48, dout});
   r.t48 += m;
-  r.calls = call + 1;
+  if (!synthetic) r.calls = call + 1;
   bool ok = hip_ok(hipGetLastError(), "wrapper launch");
   // one hop per step: after `delay` calls a call's hops are out, its output half runs behind this call's tick
   while (ok && H == 1 && !r.jobs.empty() && r.jobs.front().call + r.delay <= call) {
@@ -839,6 +842,37 @@ int BeatriceBatch_BindResidentBlocksRagged(BeatriceBatch* b, const float* d_in, 
 }
 int BeatriceBatch_ResidentBlocksDelay(const BeatriceBatch* b) { return b && b->ok && b->rb.on ? b->rb.delay : -1; }
 int BeatriceBatch_ResidentBlocksDelayFor(const BeatriceBatch* b, int n) { return b && b->ok && b->wrap.ready && n >= 1 ? rb_delay(b, n) : -1; }
+// End of the material: every call made so far gets its output block as if silence had followed (several hops per step: the step still filling
+// is completed with hops of silence -- no caller slot is read or written for them), then the binding starts over as a new one does.
+int BeatriceBatch_FlushResidentBlocks(BeatriceBatch* b) {
+  const DeviceScope dev_(b ? b->device : -1);
+  if (!b || !b->ok) return -2;
+  BeatriceBatch::ResidentBlocks& r = b->rb;
+  if (!r.on) return -1;
+  if (r.dead) return -2;
+  if (!sync_all(b)) return -2;           // (one hop per step and clocks per stream: everything is out now)
+  if (r.jobs.empty()) return 0;
+  if (r.ragged || r.H == 1) return -2;   // (cannot be: nothing stays owed there)
+  if (!r.d_zero) {
+    const size_t bytes = sizeof(float) * b->B * r.channels * r.n;
+    if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&r.d_zero), bytes), "rb zeros") || !hip_ok(hipMemset(r.d_zero, 0, bytes), "rb zeros")) return -2;
+  }
+  for (int guard = 0; !r.jobs.empty() && guard < 64 * r.H; ++guard) {
+    const long long fed = r.hops_fed();
+    if (!hip_ok(hipStreamSynchronize(b->stream), "flush sync") || !rb_step(b, true)) { r.dead = true; return -2; }   // (the made-up calls share one gain ring entry: one at a time)
+    if (r.hops_fed() > fed && !sync_all(b)) return -2;   // a step went in: drained, the output halves of everything fed have run
+  }
+  if (!r.jobs.empty()) { r.dead = true; return -2; }
+  // the binding starts over: resampler pair and FIFO as after BeatriceBatch_BindResidentBlocks (the gains keep their state), call 0 reads slot 0
+  r.on = false;
+  const int rc = BeatriceBatch_ConfigureWrapper(b, b->wrap.rate);
+  r.on = true;
+  if (rc != 0) { r.dead = true; return -2; }
+  r.calls = 0; r.t48 = 0; r.hops_fired = 0; r.hops_done = 0;
+  std::fill(r.ev_recorded.begin(), r.ev_recorded.end(), 0);
+  b->io_host = 0;   // (hop k of the binding rides in resident slot (k / H) mod io_slots: wrap_post_kernel)
+  return 0;
+}
 int BeatriceBatch_ResidentBlocksOwed(const BeatriceBatch* b) { return b && b->ok && b->rb.on ? (int)b->rb.jobs.size() : -1; }
 int BeatriceBatch_ProcessBlocks(BeatriceBatch* b, const float* in, float* out, int channels, int n) {
   const DeviceScope dev_(b ? b->device : -1);

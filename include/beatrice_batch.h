@@ -106,6 +106,7 @@ int BeatriceHip_ModelBlobReady(int kind, void* model);
  *   ConvertBlocks48kDevice(NULL, NULL)   -        -     -     -        -     ok       -     -     -
  *   ProcessBlocks, ..Device(ptrs)        ok (1)   -     -     -        -     -        -     -     - (1)
  *   ProcessBlocksDevice(NULL, NULL)      -        -     -     -        -     -        ok    -     -
+ *   FlushResidentBlocks                  -        -     -     -        -     -        ok    ok    -
  *   ProcessBlocksRagged                  ok (2)   -     -     -        -     -        -     -     - (2)
  *   ProcessBlocksRaggedDevice            -        -     -     -        -     -        -     ok    -
  *   StreamFrames / StreamFlush           -        -     -     -        ok    -        -     -     -
@@ -319,12 +320,19 @@ int BeatriceBatch_ProcessBlocksRagged(BeatriceBatch* b, const float* in, float* 
  * inner samples, + 1 (the output half rides in the next call's launch: one launch per call beside the tick launches) (ask BeatriceBatch_ResidentBlocksDelayFor(b, n_samples) before binding: n_slots >= that + 2; -1 for blocks shorter
  * than two inner samples).  BeatriceBatch_Synchronize drains the ticks and completes the calls whose hops' steps are full; the last
  * calls, which end on a step still filling, stay owed (BeatriceBatch_ResidentBlocksOwed, 0 at one hop per step) until later calls
- * fill it -- an offline caller ends a file with that many blocks of silence.  Same samples as one
+ * fill it -- an offline caller ends a file with BeatriceBatch_FlushResidentBlocks (or with that many blocks of silence).  Same samples as one
  * hop per step. */
 int BeatriceBatch_BindResidentBlocks(BeatriceBatch* b, const float* d_in, float* d_out, int channels, int n_samples, int n_slots);
 int BeatriceBatch_ResidentBlocksDelay(const BeatriceBatch* b);
 int BeatriceBatch_ResidentBlocksDelayFor(const BeatriceBatch* b, int n_samples);
 int BeatriceBatch_ResidentBlocksOwed(const BeatriceBatch* b);
+/* End of the material (reference src/common/resample.h:331-364: the FIFO hands a block's samples out one block later -- whatever follows):
+ * every call made so far gets its output block, as if blocks of silence had followed -- the library completes the step that is still filling
+ * with hops of silence itself (no caller slot is read or written for them), drains the pipeline, runs the output halves still owed --, then
+ * the binding STARTS OVER as a new one does: resampler pair and FIFO restarted (the gains keep their state), the next call is call 0 and reads
+ * slot 0; the streams' model state carries on.  BeatriceBatch_ResidentBlocksOwed() is 0 afterwards.  With nothing owed (always so at one hop
+ * per step and with clocks per stream) it is BeatriceBatch_Synchronize and the binding is left as it is.  -1 without a binding. */
+int BeatriceBatch_FlushResidentBlocks(BeatriceBatch* b);
 /* The throughput form with clocks PER STREAM (reference src/common/resample.h:401-438: every plugin instance owns its resampler
  * pair; here a batch whose streams come from hosts at 44.1, 48, 96 kHz ... with block sizes of their own, around ONE tick pipeline).
  * After BeatriceBatch_ConfigureWrapperRates: d_in / d_out = [n_slots][B][channels * max_samples]; stream s's block of a call, planar

@@ -86,12 +86,13 @@ PROBES = {
     "ConfigureWrapperRates": lambda c: c.a.BeatriceBatch_ConfigureWrapperRates(c.h, (C.c_double * B)(*([44100.0] * B))),
     "ProfileKernels": lambda c: c.a.BeatriceBatch_ProfileKernels(c.h, 1, 4, C.create_string_buffer(4 * 64), c.bv.iptr(np.zeros(4, np.int32)), (C.c_double * 4)(), (C.c_double * 4)(), (C.c_double * 4)()),
     "TimeTickLaunch": lambda c: c.a.BeatriceBatch_TimeTickLaunch(c.h, 1, C.byref(C.c_float(0)), None, None),
+    "FlushResidentBlocks": lambda c: c.a.BeatriceBatch_FlushResidentBlocks(c.h),
     "TimeSteps": lambda c: c.a.BeatriceBatch_TimeSteps(c.h, 1, c.bv.fptr(np.zeros(1, np.float32))),
 }
 
 # ---- the table of include/beatrice_batch.h: mode -> entry points that refuse with -1 (H: only at that many hops per step) ------------------
 _WRAPPERS_IN_ORDER = ["ConvertBlocks48k", "ConvertBlocks48kDevice(ptrs)", "ProcessBlocks", "ProcessBlocksDevice(ptrs)", "ProcessBlocksRagged"]
-_NOT_MINE = ["ConvertBlocks48kDevice(NULL)", "ProcessBlocksDevice(NULL)", "ProcessBlocksRaggedDevice", "StreamFrames", "TimeTickLaunch"]
+_NOT_MINE = ["ConvertBlocks48kDevice(NULL)", "ProcessBlocksDevice(NULL)", "ProcessBlocksRaggedDevice", "StreamFrames", "TimeTickLaunch", "FlushResidentBlocks"]
 _BINDS = ["BindResidentIO48k(bind)", "BindResidentBlocks(bind)", "BindResidentBlocksRagged(bind)"]
 _HOST_AND_PTRS = ["ConvertFrames", "ConvertFramesDevice(ptrs)"]
 _OWNS_TICKS = _HOST_AND_PTRS + ["ConvertFramesDevice(NULL)", "TimeSteps", "EnablePipelining(2)", "EnableTickPipeline(1)", "EnableTickPipeline(0)", "BindResidentIO(bind)", "BindResidentIO(unbind)",
@@ -104,15 +105,15 @@ MATRIX = {
                  "H>1": ["ConvertBlocks48k", "ConvertBlocks48kDevice(ptrs)", "EnableSilentBlockRule(1)", "ConfigureWrapperRates"]},
     "stage_pipelining": {"all": _NOT_MINE + _WRAPPERS_IN_ORDER + _BINDS + ["SetSilentStreams", "EnableSilentBlockRule(1)", "EnableTickPipeline(1)", "EnableHostStreaming(1)", "ConfigureWrapperRates"]},
     "resident_io": {"all": _NOT_MINE + _WRAPPERS_IN_ORDER + _BINDS + _HOST_AND_PTRS + ["SetSilentStreams", "EnableSilentBlockRule(1)", "EnableHostStreaming(1)", "ConfigureWrapperRates"]},
-    "tick": {"all": _NOT_MINE[:-1] + _WRAPPERS_IN_ORDER + _BINDS + _HOST_AND_PTRS + ["SetSilentStreams", "EnablePipelining(2)", "EnableHostStreaming(1)", "BindResidentIO(bind)", "BindResidentIO(unbind)",
+    "tick": {"all": [p for p in _NOT_MINE if p != "TimeTickLaunch"] + _WRAPPERS_IN_ORDER + _BINDS + _HOST_AND_PTRS + ["SetSilentStreams", "EnablePipelining(2)", "EnableHostStreaming(1)", "BindResidentIO(bind)", "BindResidentIO(unbind)",
                                                                                     "ConfigureWrapperRates", "ProfileKernels"],
              "H>1": ["EnableSilentBlockRule(1)"]},
     "host_streaming": {"all": [p for p in _NOT_MINE if p != "StreamFrames"] + _BINDS + _OWNS_TICKS + ["EnableSilentBlockRule(1)"]},
     "blocks48k_around_ticks": {"all": [p for p in _NOT_MINE if p != "ConvertBlocks48kDevice(NULL)"] + ["BindResidentBlocks(bind)", "BindResidentBlocksRagged(bind)", "EnableHostStreaming(1)"] + _OWNS_TICKS,
                                "H>1": ["EnableSilentBlockRule(1)"]},
-    "resident_blocks": {"all": [p for p in _NOT_MINE if p != "ProcessBlocksDevice(NULL)"] + ["BindResidentIO48k(bind)", "EnableHostStreaming(1)", "EnableSilentBlockRule(1)", "EnableSilentBlockRule(0)",
+    "resident_blocks": {"all": [p for p in _NOT_MINE if p not in ("ProcessBlocksDevice(NULL)", "FlushResidentBlocks")] + ["BindResidentIO48k(bind)", "EnableHostStreaming(1)", "EnableSilentBlockRule(1)", "EnableSilentBlockRule(0)",
                                                                                                                       "ConfigureWrapper"] + _OWNS_TICKS},
-    "resident_blocks_per_stream_clocks": {"all": [p for p in _NOT_MINE if p != "ProcessBlocksRaggedDevice"] + ["BindResidentIO48k(bind)", "EnableHostStreaming(1)", "EnableSilentBlockRule(1)",
+    "resident_blocks_per_stream_clocks": {"all": [p for p in _NOT_MINE if p not in ("ProcessBlocksRaggedDevice", "FlushResidentBlocks")] + ["BindResidentIO48k(bind)", "EnableHostStreaming(1)", "EnableSilentBlockRule(1)",
                                                                                                                                         "EnableSilentBlockRule(0)", "ConfigureWrapper"] + _OWNS_TICKS},
     # the in-order silent-block rule of the 48 kHz blocks (one hop per step)
     "silent_rule_in_order": {"all": _NOT_MINE + _BINDS + ["EnableHostStreaming(1)", "EnablePipelining(2)", "EnableTickPipeline(1)", "BindResidentIO(bind)", "ProcessBlocks", "ProcessBlocksDevice(ptrs)", "ProcessBlocksRagged"]},

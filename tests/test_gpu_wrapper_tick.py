@@ -16,8 +16,11 @@ pytestmark = pytest.mark.gpu
                                                    # several hops per step: a step enters the ticks when the FIFOs have fired H hops
                                                    (48000, 480, 2, 4, 2), (44100, 441, 1, 5, 2), (96000, 960, 1, 3, 4), (44100, 64, 1, 3, 2),
                                                    (32000, 1000, 2, 3, 4), (16000, 333, 1, 2, 2), (44100, 441, 1, 3, 4),
-                                                   (44100, 441, 1, 3, -4)])   # (H < 0: |H| hops per step over a long run, every ring of the binding wraps)
+                                                   (44100, 441, 1, 3, -4),    # (H < 0: |H| hops per step over a long run, every ring of the binding wraps)
+                                                   # (H + 100: the material ends with BeatriceBatch_FlushResidentBlocks instead of blocks of silence from the caller)
+                                                   (44100, 441, 1, 3, 104), (48000, 480, 2, 4, 102), (44100, 64, 1, 3, 102), (32000, 1000, 2, 3, 104)])
 def test_any_rate_wrapper_around_the_tick_pipeline(bv, oracle, product, model_dir, sr, block, channels, B, H):
+    use_flush, H = H > 100, H % 100 if H > 100 else H
     long_run, H = H < 0, abs(H)
     n_blocks = max(40, int(0.45 * sr) // block)            # longer than the pipeline is deep, whatever the block size
     if long_run:
@@ -105,7 +108,7 @@ def test_any_rate_wrapper_around_the_tick_pipeline(bv, oracle, product, model_di
     assert a.BeatriceBatch_EnableSilentBlockRule(h, 0) == -1 and a.BeatriceBatch_EnableSilentBlockRule(h, 1) == -1   # not under a binding
     # several hops per step: the last calls end on a step that is still filling and stay owed at a drained point; blocks of silence
     # behind the material bring them out (the wrapper oracle is not asked about those)
-    n_real, n_blocks = n_blocks, n_blocks + (0 if H == 1 else delay - (stages - 1) + 1)
+    n_real, n_blocks = n_blocks, n_blocks + (0 if H == 1 or use_flush else delay - (stages - 1) + 1)
     x = np.concatenate([x, np.zeros((B, channels, block * (n_blocks - n_real)), np.float32)], axis=2)
     got = np.zeros_like(x)
     have = 0                                                 # calls whose output block has been collected
@@ -128,6 +131,9 @@ def test_any_rate_wrapper_around_the_tick_pipeline(bv, oracle, product, model_di
                 if (pos == switch_at if H == 1 else k == switch_call) and s in switch_to:
                     a.BeatriceBatch_SetTargetSpeaker(h, s, switch_to[s])
             assert a.BeatriceBatch_ProcessBlocksDevice(h, None, None, channels, block) == 0
+        if use_flush and k0 + nk == n_blocks:                    # the end of the material: nothing stays owed, no silence from the caller
+            assert a.BeatriceBatch_FlushResidentBlocks(h) == 0
+            assert a.BeatriceBatch_ResidentBlocksOwed(h) == 0
         assert a.BeatriceBatch_Synchronize(h) == 0               # drains the pipeline and runs the output halves still owed
         owed = a.BeatriceBatch_ResidentBlocksOwed(h)
         assert owed == 0 if H == 1 else 0 <= owed <= delay - (stages - 1) + 1
@@ -139,6 +145,18 @@ def test_any_rate_wrapper_around_the_tick_pipeline(bv, oracle, product, model_di
         k0 += nk
     assert have >= n_real
     got, x = got[:, :, :n_real * block], x[:, :, :n_real * block]
+    if use_flush:   # the binding has started over: call 0 reads slot 0 again, the first block out is the FIFO's silence, then sound; a second flush ends it
+        buf_in[:min(slots, n_real)] = x[:, :, :min(slots, n_real) * block].reshape(B, channels, -1, block).transpose(2, 0, 1, 3)
+        hip.h2d(d_in, buf_in)
+        n_more = min(slots - 1, 3 * H + 5)
+        for k in range(n_more):
+            assert a.BeatriceBatch_ProcessBlocksDevice(h, None, None, channels, block) == 0
+        assert a.BeatriceBatch_FlushResidentBlocks(h) == 0 and a.BeatriceBatch_ResidentBlocksOwed(h) == 0
+        again = np.zeros((slots, B, channels, block), np.float32)
+        hip.d2h(again, d_out)
+        assert np.isfinite(again[:n_more]).all() and np.abs(again[1:n_more]).max() > 1e-4
+        if block * 48000 <= 480 * sr:
+            assert np.abs(again[0]).max() == 0.0               # (at most 10 ms: nothing but the restarted FIFO's zeros)
     assert a.BeatriceBatch_BindResidentBlocks(h, None, None, 0, 0, 0) == 0
     batch.close()
     m.close()

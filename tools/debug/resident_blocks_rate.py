@@ -91,6 +91,9 @@ if os.environ.get("BLOCK"):   # e.g. BLOCK=64 RATE=48000: DAW-sized blocks (seve
     for H in (1, 2, 4):
         uniform(int(os.environ.get("RATE", "48000")), int(os.environ["BLOCK"]), H)
     sys.exit(0)
+if os.environ.get("ONLY_H"):   # one case (for a kernel trace)
+    uniform(44100, 441, int(os.environ["ONLY_H"]))
+    sys.exit(0)
 for H in (1, 2, 4):
     uniform(44100, 441, H)
 uniform(48000, 480, 4)

@@ -8,11 +8,17 @@ torch.cuda.init()
 import make_model
 bv = importlib.import_module("beatrice-vst_amd")
 product = bv.bind_batch(bv.load_product())
-tmp = tempfile.TemporaryDirectory(); make_model.make_model(tmp.name, n_speakers=1)
+S = int(sys.argv[4]) if len(sys.argv) > 4 else 1   # speakers (fourth argument): stream s on speaker s mod S, k-NN 4 when S > 1 (configs[3]'s shape, no switches)
+tmp = tempfile.TemporaryDirectory(); make_model.make_model(tmp.name, n_speakers=S)
 m = bv.Models(product, tmp.name)
 B, n = (int(sys.argv[1]) if len(sys.argv) > 1 else 256), 64
 H = int(sys.argv[3]) if len(sys.argv) > 3 else 1   # hops per step (third argument; the second: "ragged" or "-")
 batch = bv.Batch(m, B, hops_per_step=H)
+if S > 1:
+    for s_ in range(B):
+        product.BeatriceBatch_SetTargetSpeaker(batch.h, s_, s_ % S)
+    product.BeatriceBatch_FlushSpeaker(batch.h, -1)
+    product.BeatriceBatch_SetVQNumNeighbors(batch.h, -1, 4)
 d_in = torch.randn((n, B, H * 160), device="cuda") * 0.1
 d_out = torch.zeros((n, B, H * 240), device="cuda")
 assert product.BeatriceBatch_BindResidentIO(batch.h, d_in.data_ptr(), d_out.data_ptr(), n) == 0
