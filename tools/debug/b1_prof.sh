@@ -1,12 +1,12 @@
 #!/bin/bash
-# rocprofv3 kernel trace of the 1-stream C-ABI (eager launches: rocprofv3 does not survive the per-call graphs).
+# rocprofv3 kernel trace of the 1-stream C-ABI (plain launches, the default since round 5; BEATRICE_HIP_HOP_GRAPH=1 = the per-call graphs, which rocprofv3 does not survive).
 # Output: gpurun_out/$1/{kernel_stats_B1.csv, b1_gaps.txt}
 out=gpurun_out/${1:-b1}
 mkdir -p $out
 export TMPDIR=/tmp
-python tools/debug/b1_hops.py 2000 > $out/b1_graph.txt 2>&1
-BEATRICE_HIP_NO_HOP_GRAPH=1 python tools/debug/b1_hops.py 2000 > $out/b1_eager.txt 2>&1
-BEATRICE_HIP_NO_HOP_GRAPH=1 rocprofv3 --kernel-trace --stats -d $out/prof -o b1 --output-format csv -- python tools/debug/b1_hops.py 400 > $out/b1_under_rocprof.txt 2>&1
+BEATRICE_HIP_HOP_GRAPH=1 timeout 200 python tools/debug/b1_hops.py 2000 > $out/b1_graph.txt 2>&1
+timeout 200 python tools/debug/b1_hops.py 2000 > $out/b1_eager.txt 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d $out/prof -o b1 --output-format csv -- python tools/debug/b1_hops.py 400 > $out/b1_under_rocprof.txt 2>&1
 cp $(find $out/prof -name '*kernel_stats.csv' | head -1) $out/kernel_stats_B1.csv
 python - "$(find $out/prof -name '*kernel_trace.csv' | head -1)" > $out/b1_gaps.txt <<'PY'
 import csv, sys, collections

@@ -14,10 +14,16 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 
-python "$ROOT/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
+timeout 900 python "$ROOT/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -c 400 "$OUT/bench.err"
+# the driver's own flags, five times on this box (a 20-step run is 5 ms of launches and follows the box's clocks: VERDICT r05 item 3 asks for the median)
+for i in 1 2 3 4 5; do timeout 300 python "$ROOT/bench.py" --steps 20 --warmup 5 --no-extras > "$OUT/bench_driver_flags_steps20_run$i.json" 2> /dev/null; done
+timeout 600 python "$ROOT/bench.py" --steps 20 --warmup 5 > "$OUT/bench_driver_flags_steps20.json" 2> /dev/null
+timeout 300 python "$ROOT/bench.py" --config 3 --no-extras > "$OUT/bench_config3.json" 2> /dev/null
+timeout 300 python "$ROOT/bench.py" --config 4 --no-extras > "$OUT/bench_config4.json" 2> /dev/null
+timeout 300 python "$ROOT/bench.py" --streams 1024 --no-extras > "$OUT/bench_B1024.json" 2> /dev/null
 
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o k -- \
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o k -- \
   python "$ROOT/bench.py" --no-extras --steps 300 --warmup 20 > "$OUT/bench_under_rocprof.json" 2> /dev/null
 STATS=$(find "$OUT/prof" -name 'k_kernel_stats.csv' | head -1)
 [ -n "$STATS" ] && cp "$STATS" "$OUT/kernel_stats_B256_tick.csv"
@@ -32,22 +38,16 @@ print("tick launches %d: mean of all %.2f us; full ticks (>= 0.9 x third quartil
          len(d) - len(full), (sum(d) - sum(full)) / max(1, len(d) - len(full)) / 1e3))
 PY
 rm -rf "$OUT/prof"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o k -- \
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o k -- \
   python "$ROOT/bench.py" --no-extras --pipeline off --steps 200 --warmup 20 > /dev/null 2>&1
 STATS=$(find "$OUT/prof" -name 'k_kernel_stats.csv' | head -1)
 [ -n "$STATS" ] && cp "$STATS" "$OUT/kernel_stats_B256_in_order.csv"
-rm -rf "$OUT/prof"
-# the same chain with the conditioned blocks as two row-local kernels each (evidence for profiles/r02_notes.md)
-BEATRICE_HIP_ROWCHAIN=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o k -- \
-  python "$ROOT/bench.py" --no-extras --pipeline off --steps 200 --warmup 20 > "$OUT/bench_in_order_rowchain.json" 2> /dev/null
-STATS=$(find "$OUT/prof" -name 'k_kernel_stats.csv' | head -1)
-[ -n "$STATS" ] && cp "$STATS" "$OUT/kernel_stats_B256_in_order_rowchain.csv"
 rm -rf "$OUT/prof"
 # configs[1]: the 1-stream C-ABI, eager launches (rocprofv3 does not survive the per-call graphs)
 ( cd "$ROOT" && bash tools/debug/b1_prof.sh "$TAG/b1" > /dev/null 2>&1 )
 
 for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
-  rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- \
+  timeout 600 rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- \
     python "$ROOT/bench.py" --no-extras --steps 200 --warmup 5 > /dev/null 2>&1
   CSV=$(find "$OUT/pmc_$C" -name 'pmc_counter_collection.csv' | head -1)
   mkdir -p "$OUT/pmc_r1_$C"
