@@ -369,6 +369,9 @@ _BATCH = {
     "BeatriceHip_MathSelfTest": (C.c_longlong, [C.c_int, C.POINTER(C.c_uint)]),
     "BeatriceHip_InvalidateCodebook": (None, [_vp, _vp]),
     "BeatriceHip_InjectTeamTimeout": (C.c_int, [_vp]),
+    "BeatriceHip_InjectTeamTimeoutPhone": (C.c_int, [_vp]),
+    "BeatriceHip_InjectTeamTimeoutPitch": (C.c_int, [_vp]),
+    "BeatriceBatch_InjectTeamTimeout": (C.c_int, [_vp]),
     "BeatriceHip_ModelBlob": (C.c_int, [C.c_int, _vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "BeatriceHip_ModelBlobReady": (C.c_int, [C.c_int, _vp]),
     "BeatriceBatch_Create": (_vp, [_vp, _vp, _vp, _vp, C.c_int, C.c_int]),

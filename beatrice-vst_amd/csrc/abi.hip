@@ -487,6 +487,17 @@ int BeatriceHip_InjectTeamTimeout(Beatrice20rc0_WaveformContext1* ctx) {
   *ctx->st.d_team_dead = 1;
   return 0;
 }
+// the same for the other two modules' contexts (their recovery paths: ExtractPhone1 / EstimatePitch1 above)
+int BeatriceHip_InjectTeamTimeoutPhone(Beatrice20rc0_PhoneContext1* ctx) {
+  if (!ctx || !ctx->ok || !ctx->st.d_team_dead || ctx->st.team_off) return -1;
+  *ctx->st.d_team_dead = 1;
+  return 0;
+}
+int BeatriceHip_InjectTeamTimeoutPitch(Beatrice20rc0_PitchContext1* ctx) {
+  if (!ctx || !ctx->ok || !ctx->st.d_team_dead || ctx->st.team_off) return -1;
+  *ctx->st.d_team_dead = 1;
+  return 0;
+}
 
 // ================================ embedding setter =============================================
 // ref beatrice.h:309-311

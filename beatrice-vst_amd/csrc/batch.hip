@@ -316,8 +316,10 @@ bool sync_all(BeatriceBatch* b) {
   // stream restarts from silence on the per-layer launches (engine.h team_recover)
   if (team_timed_out(b->phone) || team_timed_out(b->pitch) || team_timed_out(b->wave)) {
     std::fprintf(stderr, "beatrice_hip: a team launch timed out; the batch's stream was reset and continues on the per-layer launches\n");
+    // (each module recovers for itself: the one whose team gave a wait up restarts from silence, the others' state is valid and stays)
+    const bool pitch_too = team_timed_out(b->pitch);
     team_recover(b->phone, b->stream); team_recover(b->pitch, b->stream); team_recover(b->wave, b->stream);
-    (void)hipMemsetAsync(b->pitch.d_prev_q, 0, sizeof(int) * b->B, b->stream);
+    if (pitch_too) (void)hipMemsetAsync(b->pitch.d_prev_q, 0, sizeof(int) * b->B, b->stream);   // (the one piece of the pitch estimator's state outside its rings)
     drop_graph(b);
     ok = false;
   }
@@ -1306,6 +1308,12 @@ int BeatriceBatch_ConvertFrames(BeatriceBatch* b, const float* in, float* out) {
 }
 #include "batch_wrappers.hip.h"  // 48 kHz and any-rate wrappers, in order and around the ticks
 
+// Test hook (beatrice_batch.h): the wave module's team launch of a one-stream batch "times out" at the next synchronisation (sync_all's recovery path)
+int BeatriceBatch_InjectTeamTimeout(BeatriceBatch* b) {
+  if (!b || !b->ok || !b->wave.d_team_dead || b->wave.team_off) return -1;
+  *b->wave.d_team_dead = 1;
+  return 0;
+}
 int BeatriceBatch_Synchronize(BeatriceBatch* b) {
   const DeviceScope dev_(b ? b->device : -1);
   if (!b || !b->ok) return -2;

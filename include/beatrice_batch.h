@@ -50,6 +50,11 @@ void BeatriceHip_InvalidateCodebook(Beatrice20rc0_PhoneContext1* ctx, const floa
  * waits up after ~0.3 s instead of hanging the GPU): the context's next GenerateWaveform1 returns zeros, its state restarts from
  * silence, and from then on the context runs one launch per layer.  -1: the context has no team launch. */
 int BeatriceHip_InjectTeamTimeout(Beatrice20rc0_WaveformContext1* ctx);
+/* ... and for the content encoder's and the pitch estimator's contexts (the next ExtractPhone1 / EstimatePitch1 returns zeros, the context restarts from
+ * silence like a new one and runs one launch per layer from then on), and for a ONE-STREAM batch, whose in-order chain uses the same team launches (the
+ * steps since the last BeatriceBatch_Synchronize are void: it returns -2 once, the stream restarts from silence, the batch stays usable).  -1: no team launch. */
+int BeatriceHip_InjectTeamTimeoutPhone(Beatrice20rc0_PhoneContext1* ctx);
+int BeatriceHip_InjectTeamTimeoutPitch(Beatrice20rc0_PitchContext1* ctx);
 
 /* Several GPUs in one process (a C++ host with one thread per GPU, examples/node_convert.cc; the reference runs many plugin
  * instances per process, src/vst/factory.cc:21).  Every object of this library -- model objects, contexts, batches --
@@ -154,6 +159,7 @@ BeatriceBatch* BeatriceBatch_CreateBlock(const Beatrice20rc0_PhoneExtractor* pho
                                          int n_streams, int max_speakers, int hops_per_step);
 void BeatriceBatch_Destroy(BeatriceBatch* b);
 int BeatriceBatch_IsHealthy(const BeatriceBatch* b);
+int BeatriceBatch_InjectTeamTimeout(BeatriceBatch* b);   /* test hook, see BeatriceHip_InjectTeamTimeout */
 int BeatriceBatch_NumStreams(const BeatriceBatch* b);
 int BeatriceBatch_HopsPerStep(const BeatriceBatch* b);
 /* bytes of per-stream activation history (all rings of all three modules) held for the n_streams streams */

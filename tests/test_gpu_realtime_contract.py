@@ -185,3 +185,97 @@ def test_team_launch_timeout_recovers(bv, oracle, product, model_dir):
     assert np.abs(got[at + 1:at + 4]).max() > 0                    # ... and sound again right after
     settled = at + 40                                              # (dilated convolutions reach 16 frames back, the tail a few more)
     assert np.array_equal(got[settled:], want[settled:]), "max-abs %g" % np.abs(got[settled:] - want[settled:]).max()
+
+
+@pytest.mark.parametrize("which", ["phone", "pitch"])
+def test_team_launch_timeout_recovers_in_the_other_modules(bv, oracle, product, model_dir, which):
+    """The same recovery in ExtractPhone1 and EstimatePitch1 (only the waveform context had an injection test): the call that hit
+    the (injected) timeout returns zeros, the context restarts FROM SILENCE -- rings, GRU state, the pitch estimator's previous bin -- and runs one
+    launch per layer from then on.  Both modules remember for ever (a GRU), so the yardstick after the timeout is a NEW oracle context that starts
+    with the hop after it: bit for bit from its first hop on."""
+    bv.bind_batch(product)
+    hops, at = 30, 8
+    x = bv.synth_audio(160 * hops, seed=78)
+
+    def run(abi, models, inject):
+        pc, tc = abi.CreatePhoneContext1(), abi.CreatePitchContext1()
+        t = models.tables
+        abi.SetCodebook(pc, bv.fptr(t.codebooks[1]))
+        abi.SetVQNumNeighbors(pc, 2)
+        abi.SetMinQuantizedPitch(tc, 1)
+        abi.SetMaxQuantizedPitch(tc, 383)
+        out = []
+        for i in range(hops):
+            if inject is not None and i == inject:
+                if which == "phone":
+                    assert product.BeatriceHip_InjectTeamTimeoutPhone(pc) == 0
+                else:
+                    assert product.BeatriceHip_InjectTeamTimeoutPitch(tc) == 0
+            h = np.ascontiguousarray(x[i * 160:(i + 1) * 160])
+            if which == "phone":
+                v = np.zeros(bv.PHONE_CH, np.float32)
+                abi.ExtractPhone1(models.phone, bv.fptr(h), bv.fptr(v), pc)
+                out.append(v)
+            else:
+                q, f = np.zeros(1, np.int32), np.zeros(4, np.float32)
+                abi.EstimatePitch1(models.pitch, bv.fptr(h), bv.iptr(q), bv.fptr(f), tc)
+                out.append(np.concatenate([q.astype(np.float32), f]))
+        if inject is not None:
+            assert (product.BeatriceHip_InjectTeamTimeoutPhone(pc) if which == "phone" else product.BeatriceHip_InjectTeamTimeoutPitch(tc)) == -1   # per-layer launches for good
+        abi.DestroyPhoneContext1(pc)
+        abi.DestroyPitchContext1(tc)
+        return np.array(out)
+
+    m = bv.Models(product, model_dir)
+    got = run(product, m, at)
+    m.close()
+    mo = bv.Models(oracle, model_dir)
+    want_before = run(oracle, mo, None)
+    x_keep, x = x, x[160 * (at + 1):]
+    hops_keep, hops = hops, hops - at - 1
+    want_after = run(oracle, mo, None)          # a new context that starts with the hop after the timeout
+    x, hops = x_keep, hops_keep
+    mo.close()
+    assert np.array_equal(got[:at], want_before[:at])
+    if which == "phone":
+        assert not got[at].any()                                    # the failed call: zeros
+    else:
+        assert got[at][0] == 1.0 and not got[at][1:].any()           # ... the pitch estimator's: the lowest valid bin, zero features (csrc/abi.hip)
+    assert np.abs(got[at + 1:]).max() > 0
+    assert np.array_equal(got[at + 1:], want_after), "max-abs %g" % np.abs(got[at + 1:] - want_after).max()
+
+
+def test_team_launch_timeout_in_a_one_stream_batch(bv, oracle, product, model_dir):
+    """A batch of ONE stream runs its in-order chain on the modules' team launches; a timeout there voids the steps since the last
+    synchronisation (ConvertFrames reports -2 once and hands out zeros), the module whose team gave up -- here the waveform generator's -- restarts
+    from silence on the per-layer launches, the other modules' state stays, and the batch stays usable: once the waveform generator's finite memory
+    (dilated convolutions, the tail's histories) has passed, the samples equal the UNINTERRUPTED oracle stream's bit for bit again."""
+    a = bv.bind_batch(product)
+    hops, at = 90, 6
+    x = bv.synth_audio(160 * hops, seed=79)
+    m = bv.Models(product, model_dir)
+    batch = bv.Batch(m, 1)
+    got = []
+    for i in range(hops):
+        if i == at:
+            rc = a.BeatriceBatch_InjectTeamTimeout(batch.h)
+            if rc == -1:
+                pytest.skip("this device runs the one-stream batch without team launches")
+            out = np.zeros((1, 240), np.float32)
+            assert a.BeatriceBatch_ConvertFrames(batch.h, bv.fptr(np.ascontiguousarray(x[i * 160:(i + 1) * 160])), bv.fptr(out)) == -2
+            assert not out.any()
+            got.append(out[0])
+            continue
+        got.append(batch.convert(x[None, i * 160:(i + 1) * 160])[0])
+    assert a.BeatriceBatch_InjectTeamTimeout(batch.h) == -1
+    assert a.BeatriceBatch_IsHealthy(batch.h)
+    batch.close(); m.close()
+    got = np.array(got)
+    mo = bv.Models(oracle, model_dir)
+    so = bv.Stream1(mo, speaker=0)
+    want = np.array([so.hop(x[i * 160:(i + 1) * 160]) for i in range(hops)])
+    so.close(); mo.close()
+    assert np.array_equal(got[:at], want[:at])
+    assert np.abs(got[at + 1:at + 4]).max() > 0                    # sound again right after
+    settled = at + 45
+    assert np.array_equal(got[settled:], want[settled:]), "max-abs %g" % np.abs(got[settled:] - want[settled:]).max()
