@@ -457,7 +457,7 @@ bool tick_run(BeatriceBatch* b, bool feeding) {
       wa.in48_post = r.d_in48 + (size_t)r.deferred_slot * b->B * b->H * r.channels * 480;
       r.deferred_slot = -1;
     }
-    hipLaunchKernelGGL(wrap48_tick_kernel, dim3(wa.n_pre + wa.n_post), dim3(256), 0, st, wa);
+    hipLaunchKernelGGL(wrap48_tick_kernel, dim3(wrap48_tick_grid(wa)), dim3(256), 0, st, wa);
   }
   prof.lap(3);
   fuse::StepPairs pairs;
@@ -580,7 +580,7 @@ bool tick_drain(BeatriceBatch* b) {
     wa.hv_post = r.deferred_step >= 0 && b->tk.step_ragged[r.deferred_step % tick::kRing] ? b->tk.d_hopv + (size_t)(r.deferred_step % tick::kRing) * b->tk.row : nullptr;
     wa.in48_post = r.d_in48 + (size_t)r.deferred_slot * b->B * b->H * r.channels * 480;
     r.deferred_slot = -1;
-    hipLaunchKernelGGL(wrap48_tick_kernel, dim3(wa.n_post), dim3(256), 0, b->stream, wa);
+    hipLaunchKernelGGL(wrap48_tick_kernel, dim3(wrap48_tick_grid(wa)), dim3(256), 0, b->stream, wa);
     ok = hip_ok(hipGetLastError(), "wrap48 flush");
   }
   // every model hop that entered the pipeline has left it: the output halves still owed, in order.  With several hops per step

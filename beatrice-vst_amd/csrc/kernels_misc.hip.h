@@ -933,9 +933,91 @@ __device__ __forceinline__ void wrap48_post_blocks(const int b, const Wrap48Tick
   if (tid < 16) a.st[b].ztail[tid] = zt;
   if (tid < 240) a.st[b].fpend[tid] = fp;
 }
+// Round 6: the blocks of a step side by side.  What one block hands the next is a function of the step's INPUTS alone -- the decimator's history
+// = the last 30 down-mixed samples of the block before, the up-sampler's FIFO = the model output of the hop before, its 16-sample tail = the end of
+// the FIFO content before that -- so a workgroup can fetch it instead of waiting for a neighbour: one workgroup per (stream, block) for the input half,
+// and for the output half one per block except that blocks 0 and 1 share one (both read the state the launch found; that workgroup also writes the
+// state the launch leaves, from the inputs, after it has read the old one).  Operation for operation the bodies above: the same samples.  A step's
+// wrapper launch was a chain of H blocks per workgroup (18 us at four blocks, 128 workgroups on 256 compute units): now of one or two.
+__device__ __forceinline__ float wrap48_mono(const float* __restrict__ src, const int channels, const int i) {
+  float m = src[i];
+  if (channels >= 2) { m = m + src[480 + i]; m = m * 0.5f; }
+  return m;
+}
+__device__ __forceinline__ void wrap48_pre_block_par(const int b, const int hh, const Wrap48TickArgs& a, float* __restrict__ lds) {
+  float* g = lds;        // [30 + 480]
+  float* cd = lds + 512; // [33]
+  const int tid = threadIdx.x;
+  const int row = b * a.H + hh;
+  const float* src = a.in48 + (size_t)row * a.channels * 480;
+  if (tid < 33) cd[tid] = a.coef_down[tid];
+  if (tid < 30) g[tid] = hh == 0 ? a.st[b].hist_in[tid] : wrap48_mono(src - (size_t)a.channels * 480, a.channels, 450 + tid);
+  for (int i = tid; i < 480; i += 256) g[30 + i] = wrap48_mono(src, a.channels, i);
+  __syncthreads();
+  if (tid < 160) {
+    const int p = 3 * tid + 2;
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 31; ++i) acc = acc + g[30 + p - i] * cd[1 + i];
+    a.in16[(size_t)row * 160 + tid] = acc * 1.0f;
+  }
+  // (the history the launch leaves: the end of the step's LAST block; written by the one workgroup that read the old one, behind that read)
+  if (hh == 0 && tid < 30) a.st[b].hist_in[tid] = wrap48_mono(a.in48 + (size_t)(b * a.H + a.H - 1) * a.channels * 480, a.channels, 450 + tid);
+}
+__device__ __forceinline__ void wrap48_post_blocks_par(const int b, const int h0, const int nb, const Wrap48TickArgs& a, float* __restrict__ lds) {
+  float* f = lds;         // [16 + 240]
+  float* cu = lds + 256;  // [33]
+  const int tid = threadIdx.x;
+  if (tid < 33) cu[tid] = a.coef_up[tid];
+  const float* mo = a.model_out + (size_t)b * a.H * 240;   // the step's model outputs of this stream, hop after hop
+  float zt = 0.0f, fp = 0.0f;
+  if (h0 == 0) {
+    if (tid < 16) zt = a.st[b].ztail[tid];
+    if (tid < 240) fp = a.st[b].fpend[tid];
+  } else {   // (h0 >= 2: blocks 0 and 1 are one workgroup's)
+    if (tid < 16) zt = mo[(size_t)(h0 - 2) * 240 + 224 + tid];
+    if (tid < 240) fp = mo[(size_t)(h0 - 1) * 240 + tid];
+  }
+  for (int hh = h0; hh < h0 + nb; ++hh) {
+    const int row = b * a.H + hh;
+    if (hh > h0) __syncthreads();
+    if (tid < 16) f[tid] = zt;
+    if (tid < 240) f[16 + tid] = fp;
+    __syncthreads();
+    float* dst = a.out48 + (size_t)row * a.channels * 480;
+    for (int n = tid; n < 480; n += 256) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const int m = n - i;                     // index into the zero-stuffed stream; odd positions are zero
+        if ((m & 1) == 0) acc = acc + f[16 + (m >> 1)] * cu[i];
+      }
+      for (int c = 0; c < a.channels; ++c) dst[c * 480 + n] = acc;
+    }
+    if (tid < 16) zt = f[16 + 224 + tid];
+    if (tid < 240) fp = mo[(size_t)hh * 240 + tid];
+  }
+  if (h0 == 0) {   // the state the launch leaves (the old one was read above, by these threads)
+    if (tid < 16) a.st[b].ztail[tid] = mo[(size_t)(a.H - 2) * 240 + 224 + tid];
+    if (tid < 240) a.st[b].fpend[tid] = mo[(size_t)(a.H - 1) * 240 + tid];
+  }
+}
+// workgroups of the launch: H > 1 without ragged steps = the side-by-side form (H per stream for the input half, H - 1 for the output half)
+static inline int wrap48_tick_grid(const Wrap48TickArgs& a) {
+  const bool par = a.H > 1 && a.hv_pre == nullptr && a.hv_post == nullptr;
+  return par ? a.n_pre * a.H + a.n_post * (a.H - 1) : a.n_pre + a.n_post;
+}
 static __global__ __launch_bounds__(256) void wrap48_tick_kernel(const Wrap48TickArgs a) {
   __shared__ float lds[512 + 33];
-  const int w = blockIdx.x;
+  int w = blockIdx.x;
+  if (a.H > 1 && a.hv_pre == nullptr && a.hv_post == nullptr) {
+    const int npre = a.n_pre * a.H;
+    if (w < npre) { wrap48_pre_block_par(w / a.H, w % a.H, a, lds); return; }
+    w -= npre;
+    const int b = w / (a.H - 1), j = w % (a.H - 1);
+    wrap48_post_blocks_par(b, j == 0 ? 0 : j + 1, j == 0 ? 2 : 1, a, lds);
+    return;
+  }
   if (w < a.n_pre) {
     if (a.hv_pre != nullptr && a.hv_pre[w] < 0) return;   // (its 16 kHz hop is not read either: the model sits the step out)
     wrap48_pre_blocks(w, a, lds);
