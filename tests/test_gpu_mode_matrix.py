@@ -118,8 +118,9 @@ MATRIX = {
     # the in-order silent-block rule of the 48 kHz blocks (one hop per step)
     "silent_rule_in_order": {"all": _NOT_MINE + _BINDS + ["EnableHostStreaming(1)", "EnablePipelining(2)", "EnableTickPipeline(1)", "BindResidentIO(bind)", "ProcessBlocks", "ProcessBlocksDevice(ptrs)", "ProcessBlocksRagged"]},
 }
-MODES_AT = [("in_order", 1), ("in_order", 2), ("in_order", 4), ("stage_pipelining", 1), ("resident_io", 1), ("resident_io", 4), ("tick", 1), ("tick", 2), ("tick", 4),
-            ("host_streaming", 1), ("host_streaming", 4), ("blocks48k_around_ticks", 1), ("blocks48k_around_ticks", 4), ("resident_blocks", 1), ("resident_blocks", 4),
+MODES_AT = [("in_order", 1), ("in_order", 2), ("in_order", 4), ("stage_pipelining", 1), ("stage_pipelining", 2), ("resident_io", 1), ("resident_io", 2), ("resident_io", 4),
+            ("tick", 1), ("tick", 2), ("tick", 4), ("host_streaming", 1), ("host_streaming", 2), ("host_streaming", 4), ("blocks48k_around_ticks", 1),
+            ("blocks48k_around_ticks", 2), ("blocks48k_around_ticks", 4), ("resident_blocks", 1), ("resident_blocks", 2), ("resident_blocks", 4),
             ("resident_blocks_per_stream_clocks", 1), ("silent_rule_in_order", 1)]
 
 
