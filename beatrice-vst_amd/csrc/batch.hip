@@ -438,11 +438,17 @@ void sync_stream_arrays(BeatriceBatch* b, int s) {
 void advance_kv(BeatriceBatch* b) {
   if (b->pending_kv == 0 && !b->kv_transient) return;
   bool dirty[B_NBLOCKS] = {false, false, false, false};
-  bool advanced = false;
+  bool advanced = false, mixed_left = false;
   const int H = b->H;
   for (int s = 0; s < b->B; ++s) {
     StreamCfg& c = b->cfg[s];
-    if (b->silent.any_next && b->silent.next[s]) continue;   // a silent block: the reference does not reach its per-hop protocol
+    if (b->silent.any_next && b->silent.next[s]) {   // a silent block: the reference does not reach its per-hop protocol
+      // (several hops per step: a switch that completed INSIDE the stream's last step left its rows on mixed key/value entries -- hop 0 had
+      //  one new block, hop 1 two ... --; they are brought to the settled entries in the stream's next step, so the pass must come back for it)
+      for (int hh = 0; hh < H && H > 1 && !mixed_left; ++hh)
+        for (int blk = 0; blk < B_NBLOCKS; ++blk) mixed_left = mixed_left || b->row_slot[blk][(size_t)s * H + hh] != c.kv_slot[blk];
+      continue;
+    }
     for (int hh = 0; hh < H; ++hh) {  // the hops of this step, each preceded by one block install
       if (c.kv_delay > 0) {
         --c.kv_delay;
@@ -460,7 +466,7 @@ void advance_kv(BeatriceBatch* b) {
   int still = 0;
   for (const StreamCfg& c : b->cfg) if (c.kv_set_count < B_NBLOCKS) ++still;
   b->pending_kv = still;
-  b->kv_transient = advanced && H > 1;
+  b->kv_transient = (advanced && H > 1) || mixed_left;
   for (int blk = 0; blk < B_NBLOCKS; ++blk) if (dirty[blk]) rebuild_tiles(b, blk);
 }
 

@@ -298,9 +298,10 @@ static void tick_launch(BeatriceBatch* b, const bool sparse, const bool full, hi
     }
   }
   if (total <= 0) return;
-  if (b->H == 1) fuse::launch_table_w<4>(static_cast<const tick::Ops<1>::Tab*>(t), desc, total, st, pairs, k.ragged);   // (ragged: the second instance of the launch, once a stream has sat a step out)
-  else if (b->H == 2) fuse::launch_table_w<4, false>(static_cast<const tick::Ops<2>::Tab*>(t), desc, total, st, pairs, false);   // (no ragged steps at several hops per step: EnableSilentBlockRule refuses)
-  else fuse::launch_table_w<4, false>(static_cast<const tick::Ops<4>::Tab*>(t), desc, total, st, pairs, false);
+  // (k.ragged: the second instance of the launch, once a stream has sat a step out -- at several hops per step a stream sits a WHOLE step out)
+  if (b->H == 1) fuse::launch_table_w<4>(static_cast<const tick::Ops<1>::Tab*>(t), desc, total, st, pairs, k.ragged);
+  else if (b->H == 2) fuse::launch_table_w<4>(static_cast<const tick::Ops<2>::Tab*>(t), desc, total, st, pairs, k.ragged);
+  else fuse::launch_table_w<4>(static_cast<const tick::Ops<4>::Tab*>(t), desc, total, st, pairs, k.ragged);
 }
 
 // One tick: every stage advances by one step; `feeding` = a new step enters at stage 0.

@@ -107,7 +107,9 @@ __device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, c
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (b0 + r < a.B) {
       const int hr = rag ? stepc::hopv[b0 + r] : hop;
-      if constexpr ((LINK & 2) != 0) {   // the state the cell of the hop before published in THIS launch
+      if (hr < 0) {
+        // (ragged step: the stream sits the step out -- nothing was published for it and nothing is read; zeros in the tile)
+      } else if constexpr ((LINK & 2) != 0) {   // the state the cell of the hop before published in THIS launch
         const unsigned long long* g = a.link_in + (size_t)(b0 + r) * H + 4 * q;
         unsigned long long gv[4];
 #pragma unroll
@@ -116,7 +118,7 @@ __device__ __forceinline__ void gru_fused_body(const GruArgs& a, const int bx, c
 #pragma unroll
         for (int i = 0; i < 4; ++i) f[i] = (int)(gv[i] >> 32) == hop + 1 ? __uint_as_float((unsigned)gv[i]) : glink::acquire(g + i, hop + 1, a.link_dead);
         v = make_float4(f[0], f[1], f[2], f[3]);
-      } else if (hr >= 0) v = *reinterpret_cast<const float4*>(ring_frame(a.h, b0 + r, rag ? ring_pos(a.h, hr) : ph, a.t - 1) + 4 * q);
+      } else v = *reinterpret_cast<const float4*>(ring_frame(a.h, b0 + r, rag ? ring_pos(a.h, hr) : ph, a.t - 1) + 4 * q);
     }
     float2* d = reinterpret_cast<float2*>(&hs[r * HS + 4 * q]);
     d[0] = make_float2(v.x, v.y); d[1] = make_float2(v.z, v.w);

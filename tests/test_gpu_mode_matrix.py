@@ -106,8 +106,7 @@ MATRIX = {
     "stage_pipelining": {"all": _NOT_MINE + _WRAPPERS_IN_ORDER + _BINDS + ["SetSilentStreams", "EnableSilentBlockRule(1)", "EnableTickPipeline(1)", "EnableHostStreaming(1)", "ConfigureWrapperRates"]},
     "resident_io": {"all": _NOT_MINE + _WRAPPERS_IN_ORDER + _BINDS + _HOST_AND_PTRS + ["SetSilentStreams", "EnableSilentBlockRule(1)", "EnableHostStreaming(1)", "ConfigureWrapperRates"]},
     "tick": {"all": [p for p in _NOT_MINE if p != "TimeTickLaunch"] + _WRAPPERS_IN_ORDER + _BINDS + _HOST_AND_PTRS + ["SetSilentStreams", "EnablePipelining(2)", "EnableHostStreaming(1)", "BindResidentIO(bind)", "BindResidentIO(unbind)",
-                                                                                    "ConfigureWrapperRates", "ProfileKernels"],
-             "H>1": ["EnableSilentBlockRule(1)"]},
+                                                                                    "ConfigureWrapperRates", "ProfileKernels"]},
     "host_streaming": {"all": [p for p in _NOT_MINE if p != "StreamFrames"] + _BINDS + _OWNS_TICKS + ["EnableSilentBlockRule(1)"]},
     "blocks48k_around_ticks": {"all": [p for p in _NOT_MINE if p != "ConvertBlocks48kDevice(NULL)"] + ["BindResidentBlocks(bind)", "BindResidentBlocksRagged(bind)", "EnableHostStreaming(1)"] + _OWNS_TICKS,
                                "H>1": ["EnableSilentBlockRule(1)"]},

@@ -68,7 +68,7 @@ def test_tick_two_hops_per_step_matches_in_order_chain(bv, oracle, product, mode
     d_in, d_out = hip.malloc(slots * B * H * 160 * 4), hip.malloc(slots * B * H * 240 * 4)
     assert a.BeatriceBatch_BindResidentIO(h, d_in, d_out, slots) == 0
     assert a.BeatriceBatch_EnableTickPipeline(h, 1) == 0
-    assert a.BeatriceBatch_EnableSilentBlockRule(h, 1) == -1     # (per-stream step counters: one hop per step only)
+    assert a.BeatriceBatch_EnableSilentBlockRule(h, 1) == 0 and a.BeatriceBatch_EnableSilentBlockRule(h, 0) == 0   # (round 6: whole steps sat out, tests/test_gpu_tick_ragged.py)
     got = np.zeros_like(ref)
     k0 = 0
     for chunk in itertools.cycle((slots, 7, slots - 3)):
