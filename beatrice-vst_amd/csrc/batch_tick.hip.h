@@ -188,20 +188,20 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
   static const int halves_mode = bhip::meas_env("BEATRICE_HIP_TICK_HALVES") ? std::atoi(bhip::meas_env("BEATRICE_HIP_TICK_HALVES")) : 2;   // 0: every body on all XCDs; 2 (default): halves; 4: quarters
   {
     std::vector<fuse::WgDesc> desc;
-    if (halves_mode != 0 && !sparse) {   // the bodies with the weights, each on one half of the chip (TableBuilder::two_halves); the sparse table only ever runs partly filled ticks
-      bool pinned[fuse::kMaxSpans];
-      int group[fuse::kMaxSpans];
-      for (int i = 0; i < tb->t.n_spans; ++i) {
-        group[i] = -1;
-        switch (tb->t.span[i].type) {
-          case T_PGRU: case T_PGRU1: case T_PGRUM: pinned[i] = true; group[i] = 0; break;
-          case T_QGRU: case T_QGRU1: case T_QGRUM: pinned[i] = true; group[i] = 1; break;
-          case T_F2: case T_F3: case T_F4: case T_F5: case T_P1: case T_RB: case T_F4S: case T_F5S: case T_P1S: case T_RBS:
-          case T_BLKA1: case T_BLKA2: case T_BLKA4: case T_BLKA8: case T_BLKB: case T_BLKBQ:
-          case T_UP1: case T_UP1S: case T_RES1A: case T_RES1B: case T_UP2: case T_POUT: case T_P23: case T_INP: case T_OUT: pinned[i] = true; break;
-          default: pinned[i] = false; break;   // (the tail stages and the per-stream bodies: hardly any weights)
-        }
+    bool pinned[fuse::kMaxSpans];
+    int group[fuse::kMaxSpans];
+    for (int i = 0; i < tb->t.n_spans; ++i) {   // the bodies with the weights, each on one half of the chip (TableBuilder::two_halves)
+      group[i] = -1;
+      switch (tb->t.span[i].type) {
+        case T_PGRU: case T_PGRU1: case T_PGRUM: pinned[i] = true; group[i] = 0; break;
+        case T_QGRU: case T_QGRU1: case T_QGRUM: pinned[i] = true; group[i] = 1; break;
+        case T_F2: case T_F3: case T_F4: case T_F5: case T_P1: case T_RB: case T_F4S: case T_F5S: case T_P1S: case T_RBS:
+        case T_BLKA1: case T_BLKA2: case T_BLKA4: case T_BLKA8: case T_BLKB: case T_BLKBQ:
+        case T_UP1: case T_UP1S: case T_RES1A: case T_RES1B: case T_UP2: case T_POUT: case T_P23: case T_INP: case T_OUT: pinned[i] = true; break;
+        default: pinned[i] = false; break;   // (the tail stages and the per-stream bodies: hardly any weights)
       }
+    }
+    if (halves_mode != 0 && !sparse) {   // (the sparse table only ever runs partly filled ticks)
       desc = tb->two_halves(pinned, group, halves_mode == 4 ? 4 : 2);
     } else {
       desc = tb->in_span_order();
@@ -224,14 +224,23 @@ bool tick_build_table_h(BeatriceBatch* b, const bool sparse) {
       // the fill / drain shapes without the empty stages' workgroups (tick::State::d_desc_ranges)
       for (auto& row : k.range_n) for (int& n : row) n = 0;
       const int n_stages = pl.count();
+      // ... and, from kRangeHalvesFrom occupied stages on, in the halves order worked out for exactly the stages they hold (round 6: a
+      // nearly full tick gains from the halves what a full one does; profiles/r06_notes.md section 9)
+      static const int range_halves_from = bhip::meas_env("BEATRICE_HIP_TICK_RANGE_HALVES") ? std::atoi(bhip::meas_env("BEATRICE_HIP_TICK_RANGE_HALVES")) : kRangeHalvesFrom;
       if (plain.size() <= 16384 && n_stages <= kMaxStages) {
         std::vector<fuse::WgDesc> all;
         for (int shape = 0; shape < 2; ++shape)
           for (int s0 = 0; s0 < n_stages; ++s0) {
             k.range_off[shape][s0] = all.size();
-            for (const fuse::WgDesc& d : plain) {
-              const int stage = (d.arg >> 16) & 0xff;
-              if (shape == 0 ? stage <= s0 : stage >= s0) all.push_back(d);
+            const int occupied = shape == 0 ? s0 + 1 : n_stages - s0;
+            if (halves_mode != 0 && occupied >= range_halves_from) {
+              const std::vector<fuse::WgDesc> part = shape == 0 ? tb->two_halves(pinned, group, 2, 0, s0) : tb->two_halves(pinned, group, 2, s0, 255);
+              all.insert(all.end(), part.begin(), part.end());
+            } else {
+              for (const fuse::WgDesc& d : plain) {
+                const int stage = (d.arg >> 16) & 0xff;
+                if (shape == 0 ? stage <= s0 : stage >= s0) all.push_back(d);
+              }
             }
             k.range_n[shape][s0] = (int)(all.size() - k.range_off[shape][s0]);
           }

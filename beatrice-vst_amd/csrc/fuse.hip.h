@@ -251,7 +251,9 @@ struct TableBuilder {
   // queues, more to the one that is behind.  Order inside a queue = the order added.  The launch's memory-side traffic falls by
   // half the pinned bodies' weights x 8 (profiles/r05_notes.md); what it may cost is balance: the two halves no longer share one
   // queue of work.
-  std::vector<WgDesc> two_halves(const bool* pinned, const int* group, const int NQ = 2 /* queues: 2 halves or 4 quarters of the chip */) const {
+  // stage_lo .. stage_hi: only the bodies of these stages (a partly filled tick's list, balanced over the halves for what it holds)
+  std::vector<WgDesc> two_halves(const bool* pinned, const int* group, const int NQ = 2 /* queues: 2 halves or 4 quarters of the chip */,
+                                 const int stage_lo = 0, const int stage_hi = 255) const {
     struct Item { int span, local; };
     std::vector<Item> q[4];
     double load[4] = {0, 0, 0, 0};
@@ -259,6 +261,8 @@ struct TableBuilder {
     for (int& g : group_q) g = -1;
     auto lightest = [&]() { int h = 0; for (int x = 1; x < NQ; ++x) if (load[x] < load[h]) h = x; return h; };
     for (int i = 0; i < t.n_spans; ++i) {
+      const int stage = (t.span[i].arg >> 16) & 0xff;
+      if (stage < stage_lo || stage > stage_hi) continue;
       const double c = n_wg[i] > 0 ? cost[i] / n_wg[i] : 0.0;
       if (pinned[i]) {
         int h = lightest();

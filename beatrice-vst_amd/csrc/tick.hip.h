@@ -32,6 +32,7 @@
 
 namespace tick {
 
+constexpr int kRangeHalvesFrom = 99;   // a partly filled tick with at least this many occupied stages runs in its own halves order (99: none does)
 constexpr int kMaxStages = 32, kRing = 64, kMaxCopies = 16;  // (copies: 7 consumers + the snapshot upload)
 
 struct Copy { unsigned char* dst; const unsigned char* src; int bytes; };

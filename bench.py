@@ -473,8 +473,8 @@ def main():
                     help="device-to-device copy of each hop into / out of the library's own buffers instead of "
                          "binding the resident audio buffers (BeatriceBatch_BindResidentIO)")
     ap.add_argument("--device-warm-ms", type=float, default=1000.0,
-                    help="milliseconds of unrelated GPU work (torch matmuls) before the warm-up steps, so that a run of a few milliseconds "
-                         "does not execute at an idle device's clocks (+5 %% at 20 and at 300 steps); 0 = off; stated in config")
+                    help="milliseconds of the workload's own steps (untimed, drained) before the warm-up steps, so that a run of a few milliseconds "
+                         "executes at the clocks of a device that has been converting, not at an idle one's (+5 %% at 20 steps); 0 = off; stated in config")
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / B=1 latency / kernel profile")
     ap.add_argument("--total-streams", type=int, default=None,
                     help="strong scaling: this many streams in total, split evenly over the GPUs (default: --streams per GPU, weak scaling)")
@@ -651,7 +651,11 @@ def main():
     if a.config == 3:
         schedule_until(a.warmup + a.steps + 700)
 
-    def step(i):
+    fed = [0]   # steps fed so far (the resident ring's slot and configs[3]'s switch schedule follow it)
+
+    def step(_unused=None):
+        i = fed[0]
+        fed[0] += 1
         if a.config == 3:
             if i >= len(schedule):
                 schedule_until(i + 1)
@@ -668,15 +672,19 @@ def main():
         if rc:
             raise SystemExit("Convert* failed: %d" % rc)
 
-    if a.device_warm_ms > 0:  # bring the GPU out of its idle power state with unrelated work (stated in `config`): a run of
-        # a few milliseconds otherwise executes at the clocks of an idle device (tools/debug/time_tick.py)
-        wa = torch.randn((2048, 2048), device="cuda")
+    if a.device_warm_ms > 0:
+        # Bring the GPU to the clocks of a server that has been converting for a while: the workload's OWN steps, untimed, drained, before the W warm-up
+        # steps (stated in `config`).  A run of a few milliseconds otherwise executes at whatever clocks the device was left at: 20 steps + drain
+        # measured 3.59 M frames/s after 50 ms of idling, 3.96-4.09 M after a second of torch matmuls with synchronisation gaps (rounds 3-5's
+        # warm-up), 4.15-4.19 M after 300 of its own steps (tools/debug/clock_state_probe.py, profiles/r06_notes.md section 9).
         t_end = time.perf_counter() + a.device_warm_ms * 1e-3
         while time.perf_counter() < t_end:
-            for _ in range(8):
-                wa = (wa @ wa).clamp_(-1.0, 1.0)
-            torch.cuda.synchronize()
-        del wa
+            for _ in range(64):
+                step()
+            product.BeatriceBatch_Synchronize(batch.h)
+        torch.cuda.synchronize()
+        if a.config == 3:
+            schedule_until(fed[0] + a.warmup + a.steps + 700)
     for i in range(a.warmup):
         step(i)
     product.BeatriceBatch_Synchronize(batch.h)
@@ -718,7 +726,7 @@ def main():
                                        "speaker every 200 hops (K/V blocks one per hop), VQ k=4" % (B, a.speakers),
                                     4: "BASELINE.json configs[4] per-GPU share: %d streams of 48 kHz stereo, downmix + resample "
                                        "wrapper on the device, 480-sample blocks, %d block(s) per stream and step" % (B, H)}[a.config],
-                       "streams_per_gpu": B, "speakers": a.speakers, "hops_per_step": H, "frames_per_step": world * B * H, "hipgraph": not a.no_graph, "device_warm_ms": a.device_warm_ms,
+                       "streams_per_gpu": B, "speakers": a.speakers, "hops_per_step": H, "frames_per_step": world * B * H, "hipgraph": not a.no_graph, "device_warm_ms": a.device_warm_ms, "device_warm": "the workload's own steps for device_warm_ms, untimed and drained, before the warm-up steps",
                        "pipelining": ("tick: every layer of the chain its own pipeline stage (%d stages), one launch per tick on one HIP "
                                       "stream, stage s works on the step fed s ticks earlier (%d hop(s) of every stream per stage per launch); "
                                       "steps enqueued without waiting; the timed region includes the %d ticks that drain the pipeline"

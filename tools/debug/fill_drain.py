@@ -20,5 +20,10 @@ x = torch.randn((4096, 4096), device="cuda")
 for rep in range(3):
     for _ in range(30): y = x @ x          # keep the clocks up between the runs
     torch.cuda.synchronize()
-    for _ in range(steps): product.BeatriceBatch_ConvertFramesDevice(batch.h, None, None)
-    product.BeatriceBatch_Synchronize(batch.h)
+    import time
+    ts = [time.perf_counter()]
+    for _ in range(steps):
+        product.BeatriceBatch_ConvertFramesDevice(batch.h, None, None); ts.append(time.perf_counter())
+    product.BeatriceBatch_Synchronize(batch.h); ts.append(time.perf_counter())
+    if os.environ.get("FD_HOSTTIMES") and rep == 2:
+        print("host us per feed:", " ".join("%.0f" % ((b - a) * 1e6) for a, b in zip(ts[:-2], ts[1:-1])), "| drain %.0f | whole %.0f" % ((ts[-1] - ts[-2]) * 1e6, (ts[-1] - ts[0]) * 1e6), flush=True)
