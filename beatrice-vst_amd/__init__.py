@@ -371,6 +371,7 @@ _BATCH = {
     "BeatriceHip_InjectTeamTimeout": (C.c_int, [_vp]),
     "BeatriceHip_InjectTeamTimeoutPhone": (C.c_int, [_vp]),
     "BeatriceHip_InjectTeamTimeoutPitch": (C.c_int, [_vp]),
+    "BeatriceHip_PitchSpeculation": (C.c_int, [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "BeatriceBatch_InjectTeamTimeout": (C.c_int, [_vp]),
     "BeatriceHip_ModelBlob": (C.c_int, [C.c_int, _vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "BeatriceHip_ModelBlobReady": (C.c_int, [C.c_int, _vp]),

@@ -14,7 +14,9 @@
 #include <cstring>
 #include <fstream>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "abi_objects.h"
@@ -136,6 +138,92 @@ static bool run_hop(HopGraph& g, const void* blob, int variant, hipStream_t s, F
   return true;
 }
 
+// ---- The pitch call runs BESIDE the phone call (pre-execution) ----------------------------------------------------------------------
+// The reference's hop is ExtractPhone1(x) -> EstimatePitch1(x) -> GenerateWaveform1 (processor_core_2.cc:184,188,253): two independent
+// modules over the SAME 160 samples, one after the other because a CPU has nothing to gain from anything else.  Here the two are device
+// work on two streams, and the per-hop latency is the sum of what could overlap.  So, once a pitch context has been seen to be called
+// right after a phone context with the same samples (same thread), the phone call also enqueues the pitch context's hop for ITS input on
+// the pitch context's own stream, and returns when the phone features are there, as always.  EstimatePitch1 then finds its hop done or
+// under way: if it arrives with the same 160 samples, bin range, estimator and parameters, it waits for that hop and hands out its
+// results; if anything differs, the pre-executed hop is dropped and the call runs as it always did.
+// Dropping is exact: a hop writes slot `hop` of the context's rings (rewritten by the real hop), the previous bin (put back from
+// committed_prev_q) and this hop's granule tags of the team launch (the real hop then runs the per-layer launches, redo_plain: the same
+// values, tests/test_gpu_realtime_contract.py).  The hop counter only moves when a hop counts.  A context whose pre-executions keep being
+// dropped stops getting them (spec_off).  BEATRICE_HIP_NO_SPECULATION=1 turns the whole mechanism off (include/beatrice_batch.h).
+namespace {
+std::shared_mutex g_pair_mu;   // the pairing pointers and the registries below (shared: a phone call enqueuing; exclusive: create / destroy / pair)
+std::unordered_set<const void*> g_live_phone, g_live_pitch_models;
+thread_local Beatrice20rc0_PhoneContext1* t_last_phone = nullptr;   // the phone context this thread called last (a candidate partner)
+}
+static bool speculation_on() {
+  static const bool on = std::getenv("BEATRICE_HIP_NO_SPECULATION") == nullptr;
+  return on && !hop_graphs() && !hop_immediate();
+}
+// the hop's input and mailbox (counter | lowest bin | highest bin) into the pinned block; the counter is NOT advanced here
+static void pitch_stage(Beatrice20rc0_PitchContext1* ctx, const float* input) {
+  float* h_in = ctx->h_io;
+  std::memcpy(h_in, input, sizeof(float) * B_IN_HOP);
+  int* mb = reinterpret_cast<int*>(h_in + B_IN_HOP);
+  mb[0] = ctx->hop_count; mb[1] = ctx->min_q; mb[2] = ctx->max_q;
+}
+// input copy, the module's kernels, result copy on the context's stream; plain: the per-layer launches instead of the team launch
+static void pitch_enqueue(const Beatrice20rc0_PitchEstimator* m, Beatrice20rc0_PitchContext1* ctx, const bool plain) {
+  float* h_in = ctx->h_io;
+  float* h_feat = ctx->h_io + B_IN_HOP + kMailboxWords;
+  int* h_q = reinterpret_cast<int*>(ctx->h_io + B_IN_HOP + kMailboxWords + 4);
+  (void)hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * (B_IN_HOP + kMailboxWords), hipMemcpyHostToDevice, ctx->stream);
+  const bool team_was_off = ctx->st.team_off;
+  if (plain) ctx->st.team_off = true;   // (for this one hop; the caller holds the context)
+  pitch_forward(m->w, ctx->st, ctx->stream);
+  ctx->st.team_off = team_was_off;
+  if (ctx->st.q_raw_in_feat) {   // (h_q = h_feat + 4, d_q_raw = d_feat + 4: one copy for the five result words)
+    (void)hipMemcpyAsync(h_feat, ctx->st.d_feat, sizeof(float) * 5, hipMemcpyDeviceToHost, ctx->stream);
+  } else {
+    (void)hipMemcpyAsync(h_feat, ctx->st.d_feat, sizeof(float) * 4, hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipMemcpyAsync(h_q, ctx->st.d_q_raw, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+  }
+}
+// a pre-executed hop that does not count (the stream is idle): the previous bin back, the hop's tags are used up
+static void spec_drop(Beatrice20rc0_PitchContext1* ctx) {
+  int* h_prev = reinterpret_cast<int*>(ctx->h_io + B_IN_HOP + kMailboxWords + 6);
+  *h_prev = ctx->committed_prev_q;
+  (void)hipMemcpyAsync(ctx->st.d_prev_q, h_prev, sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+  ctx->redo_plain = true;
+  ++ctx->spec_misses;
+  if (++ctx->spec_strikes >= 8) ctx->spec_off = true;
+}
+// called by ExtractPhone1 with its own work enqueued and not yet waited for: the partner's hop for the same samples
+static void spec_launch(Beatrice20rc0_PhoneContext1* phone) {
+  t_last_phone = phone;
+  if (!phone->paired_pitch) return;
+  std::shared_lock<std::shared_mutex> g(g_pair_mu);
+  Beatrice20rc0_PitchContext1* q = phone->paired_pitch;
+  if (!q || !q->ok || q->device != phone->device || !q->spec_mu.try_lock()) return;
+  std::lock_guard<std::mutex> own(q->spec_mu, std::adopt_lock);
+  if (q->spec_pending) {   // the last one was never asked for
+    (void)wait_stream(q->stream);
+    q->spec_pending = false;
+    if (team_timed_out(q->st)) { team_recover(q->st, q->stream); (void)hipMemsetAsync(q->st.d_prev_q, 0, sizeof(int), q->stream); q->committed_prev_q = 0; q->redo_plain = false; ++q->spec_misses; }
+    else spec_drop(q);
+  }
+  const Beatrice20rc0_PitchEstimator* m = q->spec_model;
+  if (q->spec_off || !m || !g_live_pitch_models.count(m) || !m->loaded || m->device != q->device || m->generation != q->spec_generation) return;
+  pitch_stage(q, phone->h_io);
+  q->spec_min_q = q->min_q; q->spec_max_q = q->max_q;
+  pitch_enqueue(m, q, q->redo_plain);
+  q->spec_launch_ok = hipGetLastError() == hipSuccess;   // (a hop whose launches failed is never claimed)
+  q->spec_pending = true;
+}
+// EstimatePitch1 without a partner yet: was this thread's last phone call given the same samples?
+static void spec_learn(Beatrice20rc0_PitchContext1* ctx, const float* input) {
+  Beatrice20rc0_PhoneContext1* p = t_last_phone;
+  if (!p || ctx->paired_phone || ctx->spec_off) return;
+  std::unique_lock<std::shared_mutex> g(g_pair_mu);
+  if (!g_live_phone.count(p) || !p->ok || p->device != ctx->device || p->paired_pitch || std::memcmp(p->h_io, input, sizeof(float) * B_IN_HOP) != 0) return;
+  p->paired_pitch = ctx;
+  ctx->paired_phone = p;
+}
+
 // the same for callers in other translation units (legacy.hip)
 bool run_hop_graph(HopGraph& g, const void* blob, int variant, hipStream_t s, void (*enqueue)(void*), void* ctx) {
   return run_hop(g, blob, variant, s, [&] { enqueue(ctx); });
@@ -188,10 +276,16 @@ Beatrice20rc0_PhoneContext1* Beatrice20rc0_CreatePhoneContext1(void) {
   }
   c->st.advance_hop = false;
   c->st.skip_vq = true;  // k = 0 until SetVQNumNeighbors says otherwise
+  { std::unique_lock<std::shared_mutex> g(g_pair_mu); g_live_phone.insert(c); }
   return c;
 }
 void Beatrice20rc0_DestroyPhoneContext1(Beatrice20rc0_PhoneContext1* c) {
   if (!c) return;
+  {
+    std::unique_lock<std::shared_mutex> g(g_pair_mu);
+    g_live_phone.erase(c);
+    if (c->paired_pitch) { c->paired_pitch->paired_phone = nullptr; c->paired_pitch = nullptr; }
+  }
   const DeviceScope dev_(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (HopGraph& g : c->hop_graph) g.drop();
@@ -303,6 +397,7 @@ void Beatrice20rc0_ExtractPhone1(const Beatrice20rc0_PhoneExtractor* m, const fl
     ctx->st.skip_vq = keep;
   }
   bool ok = run_hop(ctx->hop_graph[variant], m->blob.d, variant, ctx->stream, enqueue);
+  if (speculation_on()) spec_launch(ctx);   // the partner pitch context's hop for the same samples, beside this one ("pre-execution" above)
   ok = wait_stream(ctx->stream) && ok;
   if (team_timed_out(ctx->st)) {   // a team launch gave a wait up: zeros for this call (as for any internal failure), the per-layer launches from the next one on (engine.h team_recover)
     ok = false;
@@ -314,9 +409,15 @@ void Beatrice20rc0_ExtractPhone1(const Beatrice20rc0_PhoneExtractor* m, const fl
 
 // ================================ pitch estimator ==============================================
 // ref beatrice.h:249-251
-Beatrice20rc0_PitchEstimator* Beatrice20rc0_CreatePitchEstimator(void) { return new Beatrice20rc0_PitchEstimator(); }
+Beatrice20rc0_PitchEstimator* Beatrice20rc0_CreatePitchEstimator(void) {
+  auto* m = new Beatrice20rc0_PitchEstimator();
+  std::unique_lock<std::shared_mutex> g(g_pair_mu);
+  g_live_pitch_models.insert(m);
+  return m;
+}
 void Beatrice20rc0_DestroyPitchEstimator(Beatrice20rc0_PitchEstimator* m) {
   if (!m) return;
+  { std::unique_lock<std::shared_mutex> g(g_pair_mu); g_live_pitch_models.erase(m); }   // (no pre-execution starts with it from here on; hipFree below waits for those under way)
   const DeviceScope dev_(m->device);
   m->blob.release();
   delete m;
@@ -325,7 +426,10 @@ void Beatrice20rc0_DestroyPitchEstimator(Beatrice20rc0_PitchEstimator* m) {
 Beatrice_ErrorCode Beatrice20rc0_ReadPitchEstimatorParameters(Beatrice20rc0_PitchEstimator* m, const char* path) {
   std::vector<float> host;
   const Beatrice_ErrorCode e = read_model_file(path, KIND_PITCH, (long)PitchWeights::n_floats(), &host);
-  return e ? e : install(m, host);
+  if (e) return e;
+  std::unique_lock<std::shared_mutex> g(g_pair_mu);   // (a pre-executed hop is claimed only by the parameters it ran with)
+  ++m->generation;
+  return install(m, host);
 }
 // ref beatrice.h:252-253
 Beatrice20rc0_PitchContext1* Beatrice20rc0_CreatePitchContext1(void) {
@@ -344,6 +448,10 @@ Beatrice20rc0_PitchContext1* Beatrice20rc0_CreatePitchContext1(void) {
 }
 void Beatrice20rc0_DestroyPitchContext1(Beatrice20rc0_PitchContext1* c) {
   if (!c) return;
+  {
+    std::unique_lock<std::shared_mutex> g(g_pair_mu);   // (no phone call is enqueuing here while this is held)
+    if (c->paired_phone) { c->paired_phone->paired_pitch = nullptr; c->paired_phone = nullptr; }
+  }
   const DeviceScope dev_(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->hop_graph.drop();
@@ -370,34 +478,59 @@ void Beatrice20rc0_EstimatePitch1(const Beatrice20rc0_PitchEstimator* m, const f
   std::memset(out_feat, 0, sizeof(float) * 4);
   if (!m || !m->loaded || !ctx || !ctx->ok || m->device != ctx->device) return;
   const DeviceScope dev_(ctx->device);
+  std::lock_guard<std::mutex> own(ctx->spec_mu);
   float* h_in = ctx->h_io;
   float* h_feat = ctx->h_io + B_IN_HOP + kMailboxWords;
   int* h_q = reinterpret_cast<int*>(ctx->h_io + B_IN_HOP + kMailboxWords + 4);
-  std::memcpy(h_in, input, sizeof(float) * B_IN_HOP);
-  {  // mailbox: counter | lowest bin | highest bin
-    int* mb = reinterpret_cast<int*>(h_in + B_IN_HOP);
-    mb[0] = ctx->hop_count; mb[1] = ctx->min_q; mb[2] = ctx->max_q;
-  }
-  if (hop_immediate()) ctx->st.hop = ctx->st.hop_in = const_cast<int*>(stepc::immediate(ctx->hop_count));
-  ctx->hop_count = hop_next(ctx->hop_count);
-  bool ok = run_hop(ctx->hop_graph, m->blob.d, 0, ctx->stream, [&] {
-    (void)hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * (B_IN_HOP + kMailboxWords), hipMemcpyHostToDevice, ctx->stream);
-    pitch_forward(m->w, ctx->st, ctx->stream);
-    if (ctx->st.q_raw_in_feat) {   // (h_q = h_feat + 4, d_q_raw = d_feat + 4: one copy for the five result words)
-      (void)hipMemcpyAsync(h_feat, ctx->st.d_feat, sizeof(float) * 5, hipMemcpyDeviceToHost, ctx->stream);
+  bool ok = false, have = false;
+  if (ctx->spec_pending) {   // the phone call before this one enqueued this hop for ITS samples (pre-execution, above)
+    ctx->spec_pending = false;
+    ok = wait_stream(ctx->stream);
+    have = ctx->spec_launch_ok && ok && m == ctx->spec_model && m->generation == ctx->spec_generation && ctx->min_q == ctx->spec_min_q && ctx->max_q == ctx->spec_max_q &&
+           std::memcmp(input, h_in, sizeof(float) * B_IN_HOP) == 0;
+    if (have) {
+      ctx->redo_plain = false;
+      if ((++ctx->spec_hits & 255) == 0 && ctx->spec_strikes > 0) --ctx->spec_strikes;
+    } else if (team_timed_out(ctx->st)) {   // (the hop that does not count gave a wait up: the context restarts as after any time-out, then runs this hop)
+      team_recover(ctx->st, ctx->stream);
+      (void)hipMemsetAsync(ctx->st.d_prev_q, 0, sizeof(int), ctx->stream);
+      ctx->committed_prev_q = 0;
+      ctx->redo_plain = false;
+      ++ctx->spec_misses;
     } else {
-      (void)hipMemcpyAsync(h_feat, ctx->st.d_feat, sizeof(float) * 4, hipMemcpyDeviceToHost, ctx->stream);
-      (void)hipMemcpyAsync(h_q, ctx->st.d_q_raw, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+      spec_drop(ctx);
     }
-  });
-  ok = wait_stream(ctx->stream) && ok;
+  }
+  if (!have) {
+    pitch_stage(ctx, input);
+    if (hop_immediate()) ctx->st.hop = ctx->st.hop_in = const_cast<int*>(stepc::immediate(ctx->hop_count));
+    const bool plain = ctx->redo_plain;
+    ok = run_hop(ctx->hop_graph, m->blob.d, 0, ctx->stream, [&] { pitch_enqueue(m, ctx, plain); });
+    ok = wait_stream(ctx->stream) && ok;
+    ctx->redo_plain = false;
+    ctx->spec_model = m;
+    ctx->spec_generation = m->generation;
+    if (speculation_on() && !ctx->paired_phone) spec_learn(ctx, input);
+  }
+  ctx->hop_count = hop_next(ctx->hop_count);
   if (team_timed_out(ctx->st)) {
     ok = false;
     team_recover(ctx->st, ctx->stream);
     (void)hipMemsetAsync(ctx->st.d_prev_q, 0, sizeof(int), ctx->stream);   // (the one piece of the stream's state outside the rings)
     ctx->hop_graph.drop();
+    ctx->committed_prev_q = 0;
+  } else if (ok) {
+    ctx->committed_prev_q = *h_q;
   }
   if (ok) { *out_q = *h_q; std::memcpy(out_feat, h_feat, sizeof(float) * 4); }
+}
+// Counters of the pre-execution for tests and tools: hops claimed / dropped so far; returns 1 while the context has a partner and gets pre-executions, else 0.
+int BeatriceHip_PitchSpeculation(Beatrice20rc0_PitchContext1* ctx, long long* claimed, long long* dropped) {
+  if (!ctx || !ctx->ok) return -1;
+  std::lock_guard<std::mutex> own(ctx->spec_mu);
+  if (claimed) *claimed = ctx->spec_hits;
+  if (dropped) *dropped = ctx->spec_misses;
+  return ctx->paired_phone != nullptr && !ctx->spec_off && speculation_on() ? 1 : 0;
 }
 
 // ================================ waveform generator ===========================================

@@ -2,6 +2,7 @@
 // implementation.  Shared by abi.hip (1-stream ABI) and batch.hip (batched extension).
 #pragma once
 #include <cstdint>
+#include <mutex>
 #include <vector>
 
 #include "beatrice_abi.h"
@@ -40,7 +41,8 @@ constexpr int kCodebookPool = 12;  // >= the 8 speakers a morph can draw from (r
 
 // model objects: immutable after Read*Parameters, shareable between contexts and threads
 struct Beatrice20rc0_PhoneExtractor { int device = bhip::target_device(); bhip::DeviceBlob blob; bhip::PhoneWeights w{}; bool loaded = false; };
-struct Beatrice20rc0_PitchEstimator { int device = bhip::target_device(); bhip::DeviceBlob blob; bhip::PitchWeights w{}; bool loaded = false; };
+struct Beatrice20rc0_PitchEstimator { int device = bhip::target_device(); bhip::DeviceBlob blob; bhip::PitchWeights w{}; bool loaded = false;
+                                      unsigned generation = 0; /* counts Read*Parameters: a pre-executed hop (abi.hip) is only claimed by the parameters it ran with */ };
 struct Beatrice20rc0_WaveformGenerator { int device = bhip::target_device(); bhip::DeviceBlob blob; bhip::WaveWeights w{}; bool loaded = false; };
 struct Beatrice20rc0_EmbeddingSetter { int device = bhip::target_device(); bhip::DeviceBlob blob; bhip::EmbedWeights w{}; bool loaded = false; };
 
@@ -86,6 +88,7 @@ struct Beatrice20rc0_PhoneContext1 {
   unsigned long long use_clock = 0;
   void* own_sel[3] = {nullptr, nullptr, nullptr};  // the state's own (unused) selector arrays, handed back before destroy()
   bhip::HopGraph hop_graph[2];  // [k-NN launch present]: both captured at the first hop with a given parameter blob
+  struct Beatrice20rc0_PitchContext1* paired_pitch = nullptr;   // the pitch context whose call follows this context's with the same input (abi.hip: pre-execution)
   bool ok = false;
 };
 struct Beatrice20rc0_PitchContext1 {
@@ -97,6 +100,21 @@ struct Beatrice20rc0_PitchContext1 {
   int min_q = 1, max_q = BEATRICE_20RC0_PITCH_BINS - 1;  // travel with the input copy
   void* own_sel[2] = {nullptr, nullptr};
   bhip::HopGraph hop_graph;
+  // Pre-execution (abi.hip, "the pitch call runs beside the phone call"): the hop a paired phone context's call enqueued here for the
+  // input it was given; EstimatePitch1 claims it when it arrives with the same 160 samples, bin range and parameters, and runs the hop
+  // itself otherwise.  spec_mu: held by EstimatePitch1 for its duration and by the phone call while it enqueues here.
+  std::mutex spec_mu;
+  struct Beatrice20rc0_PhoneContext1* paired_phone = nullptr;
+  const Beatrice20rc0_PitchEstimator* spec_model = nullptr;   // the estimator of the last EstimatePitch1 (what a pre-execution runs with)
+  unsigned spec_generation = 0;
+  bool spec_pending = false;   // a pre-executed hop is on the stream / in h_io, unclaimed
+  bool spec_launch_ok = false;
+  int spec_min_q = 0, spec_max_q = 0;
+  bool redo_plain = false;     // this hop's granule tags were used by a pre-execution that was not claimed: the hop runs the per-layer launches
+  int committed_prev_q = 0;    // raw bin of the last hop that counted (what d_prev_q holds before the next one)
+  int spec_strikes = 0;        // unclaimed pre-executions (decays with claimed ones); too many: no more for this context
+  bool spec_off = false;
+  long long spec_hits = 0, spec_misses = 0;
   bool ok = false;
 };
 struct Beatrice20rc0_WaveformContext1 {

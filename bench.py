@@ -427,23 +427,28 @@ def latency_b1(model_dir, hops=100000, warm=2000, paced_hops=1500):
     around the reference's three per-hop calls with clock_gettime; no interpreter between the clock and the calls), in a process
     of its own.  100 000 hops back to back: p50 / p99 / p99.9 / max, the counts of hops over 1 ms and over the 10 ms budget and how
     many of those coincide with the OS preempting the thread; then `paced_hops` hops arriving every 10 ms on a SCHED_FIFO thread --
-    what a DAW's audio callback sees, the GPU idle between hops -- as `paced_10ms`."""
+    what a DAW's audio callback sees, the GPU idle between hops -- as `paced_10ms`.  Round 6: the pitch estimator's hop runs beside the phone call
+    (pitch_hops_claimed; include/beatrice_batch.h BeatriceHip_PitchSpeculation); `calls_one_by_one` is the same loop with that switched off."""
     import subprocess
     exe = os.path.join(REPO, "examples", "latency_b1")
     if not os.path.exists(exe):
         raise RuntimeError("examples/latency_b1 was not built (make -C beatrice-vst_amd)")
 
-    def run(*args):
-        r = subprocess.run([exe, model_dir] + [str(a) for a in args], capture_output=True, text=True, timeout=900)
+    def run(*args, env=None):
+        r = subprocess.run([exe, model_dir] + [str(a) for a in args], capture_output=True, text=True, timeout=900, env=dict(os.environ, **(env or {})))
         if r.returncode != 0:
             raise RuntimeError("examples/latency_b1 failed (%d): %s" % (r.returncode, r.stderr[-500:]))
         return json.loads(r.stdout.strip().splitlines()[-1])
 
     out = run(hops, warm, 0, "--histogram")
+    # the same loop with the pitch estimator's hop NOT started inside the phone call (csrc/abi.hip "pre-execution"; rounds 1-5's figure)
+    plain = run(min(hops, 20000), warm, 0, "--histogram", env={"BEATRICE_HIP_NO_SPECULATION": "1"})
+    out["calls_one_by_one"] = {k: plain[k] for k in ("hops", "p50_us", "p99_us", "p999_us", "max_us", "per_call_p50_us", "pitch_hops_claimed", "checksum")}
+    out["calls_one_by_one"]["note"] = "BEATRICE_HIP_NO_SPECULATION=1: EstimatePitch1 runs its hop itself, after ExtractPhone1 has returned"
     if paced_hops > 0:
         paced = run(paced_hops, 100, 0, "--histogram", "--period-us", 10000, "--rt")
         out["paced_10ms"] = {k: paced[k] for k in ("workload", "period_us", "realtime_thread", "hops", "p50_us", "p99_us", "p999_us", "max_us", "hops_over_1ms",
-                                                    "hops_over_10ms", "involuntary_context_switches", "per_call_p50_us")}
+                                                    "hops_over_10ms", "involuntary_context_switches", "per_call_p50_us", "pitch_hops_claimed")}
     return out
 
 

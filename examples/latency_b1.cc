@@ -19,6 +19,7 @@
 // whole real-time budget), the index of the slowest hop and the ten slowest hops with their positions (a periodic cause shows as a
 // pattern), mean and frames per second; and with --histogram the per-call split (phone / pitch / waveform medians).
 // Built by `make -C beatrice-vst_amd` into examples/latency_b1; run by bench.py (latency_b1) and tests/test_gpu_cpp_example.py.
+#include <dlfcn.h>
 #include <sched.h>
 #include <sys/mman.h>
 #include <sys/resource.h>
@@ -199,6 +200,13 @@ int main(int argc, char** argv) {
     std::printf(", \"per_call_p50_us\": {\"ExtractPhone1\": %.1f, \"EstimatePitch1\": %.1f, \"GenerateWaveform1\": %.1f}, "
                 "\"per_call_p99_us\": {\"ExtractPhone1\": %.1f, \"EstimatePitch1\": %.1f, \"GenerateWaveform1\": %.1f}",
                 pct(t_phone, 0.5), pct(t_pitch, 0.5), pct(t_wave, 0.5), pct(t_phone, 0.99), pct(t_pitch, 0.99), pct(t_wave, 0.99));
+  }
+  {  // hops of the pitch estimator that ran beside the phone call and were claimed by EstimatePitch1 (include/beatrice_batch.h BeatriceHip_PitchSpeculation;
+     // looked up at run time: the oracle build of this tool has no such entry)
+    using Fn = int (*)(Beatrice20rc0_PitchContext1*, long long*, long long*);
+    long long claimed = 0, dropped = 0;
+    if (Fn fn = reinterpret_cast<Fn>(dlsym(RTLD_DEFAULT, "BeatriceHip_PitchSpeculation"))) (void)fn(tc, &claimed, &dropped);
+    std::printf(", \"pitch_hops_claimed\": %lld, \"pitch_hops_dropped\": %lld", claimed, dropped);
   }
   std::printf(", \"last_hop_peak\": %.6g, \"checksum\": %.9g}\n", peak, checksum);
 

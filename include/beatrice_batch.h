@@ -55,6 +55,14 @@ int BeatriceHip_InjectTeamTimeout(Beatrice20rc0_WaveformContext1* ctx);
  * steps since the last BeatriceBatch_Synchronize are void: it returns -2 once, the stream restarts from silence, the batch stays usable).  -1: no team launch. */
 int BeatriceHip_InjectTeamTimeoutPhone(Beatrice20rc0_PhoneContext1* ctx);
 int BeatriceHip_InjectTeamTimeoutPitch(Beatrice20rc0_PitchContext1* ctx);
+/* The pitch call beside the phone call.  The reference's hop calls ExtractPhone1 and EstimatePitch1 one after the other on the SAME 160 samples
+ * (src/common/processor_core_2.cc:184,188); the two modules are independent.  Once a pitch context has been called right after a phone context with
+ * the same samples (same thread), that phone context's calls also start the pitch context's hop for their input on the pitch context's own stream;
+ * EstimatePitch1 claims that hop when it arrives with the same samples, bin range, estimator and parameters, and otherwise drops it and runs as it
+ * always did -- results and state are the same to the bit either way (csrc/abi.hip, tests/test_gpu_pitch_beside_phone.py).  This entry reads the
+ * counters: hops claimed / dropped so far (either pointer may be NULL); returns 1 while the context has a partner and gets such hops, 0 if not, -1 on
+ * a bad context.  BEATRICE_HIP_NO_SPECULATION=1 in the environment turns the mechanism off. */
+int BeatriceHip_PitchSpeculation(Beatrice20rc0_PitchContext1* ctx, long long* claimed, long long* dropped);
 
 /* Several GPUs in one process (a C++ host with one thread per GPU, examples/node_convert.cc; the reference runs many plugin
  * instances per process, src/vst/factory.cc:21).  Every object of this library -- model objects, contexts, batches --
@@ -142,7 +150,8 @@ int BeatriceHip_ModelBlobReady(int kind, void* model);
  *   (5) a bind call on a batch that is already in F / G / P first LEAVES that mode (drains, restarts the wrapper), then binds anew.
  *
  * Environment variables the library reads: BEATRICE_HIP_DEBUG (print HIP errors to stderr), BEATRICE_HIP_CUMASK ("lo-hi;lo-hi;..": CU masks
- * of the stage-pipelining streams), BEATRICE_HIP_HOP_GRAPH (the 1-stream calls replayed as hipGraphs).  Nothing else: the A/B switches of
+ * of the stage-pipelining streams), BEATRICE_HIP_HOP_GRAPH (the 1-stream calls replayed as hipGraphs), BEATRICE_HIP_NO_SPECULATION (no pitch hop beside
+ * the phone call, BeatriceHip_PitchSpeculation above).  Nothing else: the A/B switches of
  * profiles/r0*_notes.md exist in measurement builds only (tools/debug/build_variant.sh <name> -DBEATRICE_HIP_MEASUREMENT_BUILD).
  * --------------------------------------------------------------------------------------------------------------------------------------- */
 /* n_streams concurrent streams; speaker tables may hold up to max_speakers entries
