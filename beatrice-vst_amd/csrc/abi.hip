@@ -138,6 +138,59 @@ static bool run_hop(HopGraph& g, const void* blob, int variant, hipStream_t s, F
   return true;
 }
 
+// ---- Completion of a per-hop call without a call into the runtime -----------------------------------------------------------------------
+// Every call's LAST kernel writes the call's results into the pinned block the host reads and then, behind a system-scope fence, the call's
+// sequence word (sent down with the input copy) -- the waveform generator's tail and the pitch estimator's head do it themselves, the phone
+// vector goes through publish_kernel below, in the place of the copy command.  The host polls that word in its own memory.  Round 1's poll of
+// hipStreamQuery returned a few microseconds after the last copy command had landed AND had the runtime retire the call's commands on the
+// critical path (~1.5 us each: 10 us for a finished stream of seven); that bookkeeping now happens inside the next call's enqueues, beside
+// device work.  A word that does not arrive (a failed launch, a device fault) ends in the stream wait every call had before.
+static __global__ __launch_bounds__(256) void publish_kernel(const float* __restrict__ src, float* __restrict__ dst, const int n, const int* __restrict__ seq, int* flag) {
+  const int t = threadIdx.x;
+  if (t < n) { dst[t] = src[t]; __threadfence_system(); }
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(flag, *seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+static bool flag_wait(const int* flag_word, const int seq, hipStream_t s) {
+  const volatile int* flag = flag_word;
+  for (long spins = 0; spins < 300000; ++spins) {
+    if (*flag == seq) return true;
+    __builtin_ia32_pause();
+  }
+  return wait_stream(s) && *flag == seq;
+}
+
+// The bookkeeping left behind, done where it costs nothing: a call that has enqueued its work and has 40-130 us of device time to wait for first asks the runtime
+// about the OTHER contexts' streams this thread completed calls on (hipStreamQuery on a finished stream retires its commands).  Left entirely to the enqueues the
+// runtime catches up in bursts -- every 32-64 hops a few hops 30-45 us longer (p99 233 -> 250 us; profiles/r06_notes.md section 10).
+namespace {
+std::shared_mutex g_pair_mu;   // the registries below and the pairing pointers of the pre-execution (shared: a call looking at them; exclusive: create / destroy / pair)
+std::unordered_set<hipStream_t> g_live_streams;
+thread_local hipStream_t t_dirty[8];
+thread_local int t_n_dirty = 0;
+}
+static void mark_dirty(hipStream_t s) {
+  for (int i = 0; i < t_n_dirty; ++i) if (t_dirty[i] == s) return;
+  if (t_n_dirty < 8) t_dirty[t_n_dirty++] = s;
+}
+static void housekeep(hipStream_t own) {
+  if (t_n_dirty == 0) return;
+  std::shared_lock<std::shared_mutex> g(g_pair_mu);
+  int kept = 0;
+  for (int i = 0; i < t_n_dirty; ++i) {
+    const hipStream_t s = t_dirty[i];
+    if (s != own) {
+      if (!g_live_streams.count(s)) continue;                  // (its context is gone)
+      if (hipStreamQuery(s) != hipErrorNotReady) continue;     // retired (or failed: its own calls will see that)
+    }
+    t_dirty[kept++] = s;
+  }
+  t_n_dirty = kept;
+  (void)hipGetLastError();   // (hipErrorNotReady is not this call's failure)
+}
+static void stream_born(hipStream_t s) { if (s) { std::unique_lock<std::shared_mutex> g(g_pair_mu); g_live_streams.insert(s); } }
+static void stream_gone(hipStream_t s) { if (s) { std::unique_lock<std::shared_mutex> g(g_pair_mu); g_live_streams.erase(s); } }
+
 // ---- The pitch call runs BESIDE the phone call (pre-execution) ----------------------------------------------------------------------
 // The reference's hop is ExtractPhone1(x) -> EstimatePitch1(x) -> GenerateWaveform1 (processor_core_2.cc:184,188,253): two independent
 // modules over the SAME 160 samples, one after the other because a CPU has nothing to gain from anything else.  Here the two are device
@@ -151,8 +204,7 @@ static bool run_hop(HopGraph& g, const void* blob, int variant, hipStream_t s, F
 // values, tests/test_gpu_realtime_contract.py).  The hop counter only moves when a hop counts.  A context whose pre-executions keep being
 // dropped stops getting them (spec_off).  BEATRICE_HIP_NO_SPECULATION=1 turns the whole mechanism off (include/beatrice_batch.h).
 namespace {
-std::shared_mutex g_pair_mu;   // the pairing pointers and the registries below (shared: a phone call enqueuing; exclusive: create / destroy / pair)
-std::unordered_set<const void*> g_live_phone, g_live_pitch_models;
+std::unordered_set<const void*> g_live_phone, g_live_pitch_models;   // (behind g_pair_mu)
 thread_local Beatrice20rc0_PhoneContext1* t_last_phone = nullptr;   // the phone context this thread called last (a candidate partner)
 }
 static bool speculation_on() {
@@ -165,23 +217,20 @@ static void pitch_stage(Beatrice20rc0_PitchContext1* ctx, const float* input) {
   std::memcpy(h_in, input, sizeof(float) * B_IN_HOP);
   int* mb = reinterpret_cast<int*>(h_in + B_IN_HOP);
   mb[0] = ctx->hop_count; mb[1] = ctx->min_q; mb[2] = ctx->max_q;
+  mb[3] = ++ctx->seq;   // (comes back as the last word the head kernel writes into the pinned result block: pitch_wait)
 }
 // input copy, the module's kernels, result copy on the context's stream; plain: the per-layer launches instead of the team launch
 static void pitch_enqueue(const Beatrice20rc0_PitchEstimator* m, Beatrice20rc0_PitchContext1* ctx, const bool plain) {
   float* h_in = ctx->h_io;
-  float* h_feat = ctx->h_io + B_IN_HOP + kMailboxWords;
-  int* h_q = reinterpret_cast<int*>(ctx->h_io + B_IN_HOP + kMailboxWords + 4);
   (void)hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * (B_IN_HOP + kMailboxWords), hipMemcpyHostToDevice, ctx->stream);
   const bool team_was_off = ctx->st.team_off;
   if (plain) ctx->st.team_off = true;   // (for this one hop; the caller holds the context)
   pitch_forward(m->w, ctx->st, ctx->stream);
   ctx->st.team_off = team_was_off;
-  if (ctx->st.q_raw_in_feat) {   // (h_q = h_feat + 4, d_q_raw = d_feat + 4: one copy for the five result words)
-    (void)hipMemcpyAsync(h_feat, ctx->st.d_feat, sizeof(float) * 5, hipMemcpyDeviceToHost, ctx->stream);
-  } else {
-    (void)hipMemcpyAsync(h_feat, ctx->st.d_feat, sizeof(float) * 4, hipMemcpyDeviceToHost, ctx->stream);
-    (void)hipMemcpyAsync(h_q, ctx->st.d_q_raw, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-  }
+  // (no result copy: the head kernel writes the four features, the raw bin and then the call's sequence word into the pinned block itself, PitchState::h_result)
+}
+static bool pitch_wait(Beatrice20rc0_PitchContext1* ctx) {   // (flag_wait above: the head kernel's sequence word)
+  return flag_wait(reinterpret_cast<const int*>(ctx->h_io + B_IN_HOP + kMailboxWords) + 5, ctx->seq, ctx->stream);
 }
 // a pre-executed hop that does not count (the stream is idle): the previous bin back, the hop's tags are used up
 static void spec_drop(Beatrice20rc0_PitchContext1* ctx) {
@@ -201,7 +250,7 @@ static void spec_launch(Beatrice20rc0_PhoneContext1* phone) {
   if (!q || !q->ok || q->device != phone->device || !q->spec_mu.try_lock()) return;
   std::lock_guard<std::mutex> own(q->spec_mu, std::adopt_lock);
   if (q->spec_pending) {   // the last one was never asked for
-    (void)wait_stream(q->stream);
+    (void)(q->spec_launch_ok ? pitch_wait(q) : wait_stream(q->stream));
     q->spec_pending = false;
     if (team_timed_out(q->st)) { team_recover(q->st, q->stream); (void)hipMemsetAsync(q->st.d_prev_q, 0, sizeof(int), q->stream); q->committed_prev_q = 0; q->redo_plain = false; ++q->spec_misses; }
     else spec_drop(q);
@@ -255,7 +304,7 @@ Beatrice20rc0_PhoneContext1* Beatrice20rc0_CreatePhoneContext1(void) {
   const DeviceScope dev_(c->device);
   constexpr size_t kCbFloats = (size_t)B_CODEBOOK * B_PHONE_CH, kSlotFloats = kCbFloats + B_CODEBOOK;
   c->ok = make_stream(&c->stream) && c->st.create(1, 1, nullptr) &&
-          hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(float) * (B_IN_HOP + kMailboxWords + B_PHONE_CH), hipHostMallocDefault),
+          hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(float) * (B_IN_HOP + kMailboxWords + B_PHONE_CH + 1), hipHostMallocDefault),
                  "hipHostMalloc") &&
           hip_ok(hipMalloc(reinterpret_cast<void**>(&c->d_pool), sizeof(float) * kSlotFloats * kCodebookPool), "cb pool") &&
           hip_ok(hipMalloc(reinterpret_cast<void**>(&c->d_cb_stage), sizeof(float) * 2 * kCbFloats), "cb stage") &&
@@ -263,6 +312,7 @@ Beatrice20rc0_PhoneContext1* Beatrice20rc0_CreatePhoneContext1(void) {
           hip_ok(hipEventCreateWithFlags(&c->stage_done[0], hipEventDisableTiming), "ev") &&
           hip_ok(hipEventCreateWithFlags(&c->stage_done[1], hipEventDisableTiming), "ev");
   if (c->ok) {
+    std::memset(c->h_io, 0, sizeof(float) * (B_IN_HOP + kMailboxWords + B_PHONE_CH + 1));
     for (int i = 0; i < kCodebookPool; ++i) {
       c->pool[i].d_cbT = c->d_pool + (size_t)i * kSlotFloats;
       c->pool[i].d_cnorm = c->pool[i].d_cbT + kCbFloats;
@@ -277,6 +327,7 @@ Beatrice20rc0_PhoneContext1* Beatrice20rc0_CreatePhoneContext1(void) {
   c->st.advance_hop = false;
   c->st.skip_vq = true;  // k = 0 until SetVQNumNeighbors says otherwise
   { std::unique_lock<std::shared_mutex> g(g_pair_mu); g_live_phone.insert(c); }
+  stream_born(c->stream);
   return c;
 }
 void Beatrice20rc0_DestroyPhoneContext1(Beatrice20rc0_PhoneContext1* c) {
@@ -284,6 +335,7 @@ void Beatrice20rc0_DestroyPhoneContext1(Beatrice20rc0_PhoneContext1* c) {
   {
     std::unique_lock<std::shared_mutex> g(g_pair_mu);
     g_live_phone.erase(c);
+    g_live_streams.erase(c->stream);
     if (c->paired_pitch) { c->paired_pitch->paired_phone = nullptr; c->paired_pitch = nullptr; }
   }
   const DeviceScope dev_(c->device);
@@ -378,13 +430,14 @@ void Beatrice20rc0_ExtractPhone1(const Beatrice20rc0_PhoneExtractor* m, const fl
     mb[1] = ctx->sel_cbT ? ctx->vq_k : 0;
     std::memcpy(mb + 2, &ctx->sel_cbT, sizeof(float*));
     std::memcpy(mb + 4, &ctx->sel_cnorm, sizeof(float*));
+    mb[6] = ++ctx->seq;   // (comes back behind the phone vector: flag_wait)
   }
   if (hop_immediate()) ctx->st.hop = ctx->st.hop_in = const_cast<int*>(stepc::immediate(ctx->hop_count));
   ctx->hop_count = hop_next(ctx->hop_count);
   auto enqueue = [&] {
     (void)hipMemcpyAsync(ctx->st.d_in, h_in, sizeof(float) * (B_IN_HOP + kMailboxWords), hipMemcpyHostToDevice, ctx->stream);
     phone_forward(m->w, ctx->st, ctx->stream);
-    (void)hipMemcpyAsync(h_out, ctx->st.d_phone, sizeof(float) * B_PHONE_CH, hipMemcpyDeviceToHost, ctx->stream);
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->st.d_phone, h_out, B_PHONE_CH, ctx->st.hop_mailbox + 6, reinterpret_cast<int*>(h_out + B_PHONE_CH));
   };
   const int variant = ctx->st.skip_vq ? 0 : 1;
   // Both variants (k-NN launch present / absent) are captured at the first hop with a given parameter blob, so that a
@@ -396,9 +449,14 @@ void Beatrice20rc0_ExtractPhone1(const Beatrice20rc0_PhoneExtractor* m, const fl
     capture_hop(other, m->blob.d, variant ^ 1, ctx->stream, enqueue);
     ctx->st.skip_vq = keep;
   }
+  // the partner pitch context's hop for the same samples, beside this one ("pre-execution" above): enqueued right behind this call's team launch, whose
+  // ~45 us cover the host time of those launches and of this call's remaining ones
+  if (speculation_on()) { ctx->st.after_convs = [](void* c) { spec_launch(static_cast<Beatrice20rc0_PhoneContext1*>(c)); }; ctx->st.after_convs_arg = ctx; }
   bool ok = run_hop(ctx->hop_graph[variant], m->blob.d, variant, ctx->stream, enqueue);
-  if (speculation_on()) spec_launch(ctx);   // the partner pitch context's hop for the same samples, beside this one ("pre-execution" above)
-  ok = wait_stream(ctx->stream) && ok;
+  ctx->st.after_convs = nullptr;
+  housekeep(ctx->stream);
+  ok = (ok ? flag_wait(reinterpret_cast<const int*>(h_out + B_PHONE_CH), ctx->seq, ctx->stream) : wait_stream(ctx->stream)) && ok;
+  mark_dirty(ctx->stream);
   if (team_timed_out(ctx->st)) {   // a team launch gave a wait up: zeros for this call (as for any internal failure), the per-layer launches from the next one on (engine.h team_recover)
     ok = false;
     team_recover(ctx->st, ctx->stream);
@@ -442,8 +500,11 @@ Beatrice20rc0_PitchContext1* Beatrice20rc0_CreatePitchContext1(void) {
     c->own_sel[0] = c->st.d_min_q; c->own_sel[1] = c->st.d_max_q;
     c->st.d_min_q = c->st.hop_mailbox + 1;
     c->st.d_max_q = c->st.hop_mailbox + 2;
+    std::memset(c->h_io, 0, sizeof(float) * (B_IN_HOP + kMailboxWords + 8));
+    c->st.h_result = c->h_io + B_IN_HOP + kMailboxWords;   // the head kernel writes the results and the call's sequence word here itself (pitch_wait)
   }
   c->st.advance_hop = false;
+  stream_born(c->stream);
   return c;
 }
 void Beatrice20rc0_DestroyPitchContext1(Beatrice20rc0_PitchContext1* c) {
@@ -451,6 +512,7 @@ void Beatrice20rc0_DestroyPitchContext1(Beatrice20rc0_PitchContext1* c) {
   {
     std::unique_lock<std::shared_mutex> g(g_pair_mu);   // (no phone call is enqueuing here while this is held)
     if (c->paired_phone) { c->paired_phone->paired_pitch = nullptr; c->paired_phone = nullptr; }
+    g_live_streams.erase(c->stream);
   }
   const DeviceScope dev_(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -485,7 +547,7 @@ void Beatrice20rc0_EstimatePitch1(const Beatrice20rc0_PitchEstimator* m, const f
   bool ok = false, have = false;
   if (ctx->spec_pending) {   // the phone call before this one enqueued this hop for ITS samples (pre-execution, above)
     ctx->spec_pending = false;
-    ok = wait_stream(ctx->stream);
+    ok = ctx->spec_launch_ok ? pitch_wait(ctx) : wait_stream(ctx->stream);
     have = ctx->spec_launch_ok && ok && m == ctx->spec_model && m->generation == ctx->spec_generation && ctx->min_q == ctx->spec_min_q && ctx->max_q == ctx->spec_max_q &&
            std::memcmp(input, h_in, sizeof(float) * B_IN_HOP) == 0;
     if (have) {
@@ -506,13 +568,15 @@ void Beatrice20rc0_EstimatePitch1(const Beatrice20rc0_PitchEstimator* m, const f
     if (hop_immediate()) ctx->st.hop = ctx->st.hop_in = const_cast<int*>(stepc::immediate(ctx->hop_count));
     const bool plain = ctx->redo_plain;
     ok = run_hop(ctx->hop_graph, m->blob.d, 0, ctx->stream, [&] { pitch_enqueue(m, ctx, plain); });
-    ok = wait_stream(ctx->stream) && ok;
+    housekeep(ctx->stream);
+    ok = (ok ? pitch_wait(ctx) : wait_stream(ctx->stream)) && ok;
     ctx->redo_plain = false;
     ctx->spec_model = m;
     ctx->spec_generation = m->generation;
     if (speculation_on() && !ctx->paired_phone) spec_learn(ctx, input);
   }
   ctx->hop_count = hop_next(ctx->hop_count);
+  mark_dirty(ctx->stream);
   if (team_timed_out(ctx->st)) {
     ok = false;
     team_recover(ctx->st, ctx->stream);
@@ -553,26 +617,28 @@ Beatrice_ErrorCode Beatrice20rc0_ReadWaveformGeneratorParameters(Beatrice20rc0_W
 Beatrice20rc0_WaveformContext1* Beatrice20rc0_CreateWaveformContext1(void) {
   auto* c = new Beatrice20rc0_WaveformContext1();
   const DeviceScope dev_(c->device);
-  const size_t in_floats = B_PHONE_CH + 4 + 1 + 1;  // ... | step counter
+  const size_t in_floats = B_PHONE_CH + 4 + 1 + 1 + 1;  // ... | step counter | sequence word
   c->ok = make_stream(&c->stream) &&
           hip_ok(hipMalloc(reinterpret_cast<void**>(&c->d_inputs), sizeof(float) * in_floats), "inputs") &&
           hip_ok(hipMemset(c->d_inputs, 0, sizeof(float) * in_floats), "inputs0") &&
           c->st.create(1, 1, 1, 1, 1, c->d_inputs, reinterpret_cast<int*>(c->d_inputs + B_PHONE_CH + 4), c->d_inputs + B_PHONE_CH) &&
-          hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(float) * (in_floats + B_OUT_HOP), hipHostMallocDefault), "hipHostMalloc");
+          hip_ok(hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(float) * (in_floats + B_OUT_HOP + 1), hipHostMallocDefault), "hipHostMalloc");
   c->st.hop = reinterpret_cast<int*>(c->d_inputs + B_PHONE_CH + 4 + 1);
   c->st.advance_hop = false;
-  // Measurement switch BEATRICE_HIP_OUT_MAPPED=1: the hop's 240 samples written by the last kernel straight into the pinned block
-  // the host reads (posted writes over PCIe, flushed when the kernel ends) instead of a device buffer + one more copy command
-  // per call -- measured neutral (p50 281-285 us either way, round 4), so the copy stays the default
-  if (c->ok && bhip::meas_env("BEATRICE_HIP_OUT_MAPPED") != nullptr) {
+  if (c->ok) {   // the tail kernel writes the hop's 240 samples straight into the pinned block, then the call's sequence word behind them (flag_wait)
+    std::memset(c->h_io, 0, sizeof(float) * (in_floats + B_OUT_HOP + 1));
     c->dev_d_out = c->st.d_out;
     c->st.d_out = c->h_io + in_floats;
+    c->st.h_flag = reinterpret_cast<int*>(c->h_io + in_floats + B_OUT_HOP);
+    c->st.d_seq = reinterpret_cast<const int*>(c->d_inputs + B_PHONE_CH + 4 + 2);
     c->out_mapped = true;
   }
+  stream_born(c->stream);
   return c;
 }
 void Beatrice20rc0_DestroyWaveformContext1(Beatrice20rc0_WaveformContext1* c) {
   if (!c) return;
+  stream_gone(c->stream);
   const DeviceScope dev_(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->hop_graph.drop();
@@ -589,21 +655,24 @@ void Beatrice20rc0_GenerateWaveform1(const Beatrice20rc0_WaveformGenerator* m, c
   std::memset(output, 0, sizeof(float) * B_OUT_HOP);
   if (!m || !m->loaded || !ctx || !ctx->ok || m->device != ctx->device) return;
   const DeviceScope dev_(ctx->device);
-  const size_t in_floats = B_PHONE_CH + 4 + 1 + 1;
+  const size_t in_floats = B_PHONE_CH + 4 + 1 + 1 + 1;
   float* h_in = ctx->h_io;
   float* h_out = ctx->h_io + in_floats;
   std::memcpy(h_in, phone, sizeof(float) * B_PHONE_CH);
   std::memcpy(h_in + B_PHONE_CH, feat, sizeof(float) * 4);
   std::memcpy(h_in + B_PHONE_CH + 4, q, sizeof(int));
   std::memcpy(h_in + B_PHONE_CH + 5, &ctx->hop_count, sizeof(int));
+  ++ctx->seq;
+  std::memcpy(h_in + B_PHONE_CH + 6, &ctx->seq, sizeof(int));
   if (hop_immediate()) ctx->st.hop = const_cast<int*>(stepc::immediate(ctx->hop_count));
   ctx->hop_count = hop_next(ctx->hop_count);
   bool ok = run_hop(ctx->hop_graph, m->blob.d, 0, ctx->stream, [&] {
     (void)hipMemcpyAsync(ctx->d_inputs, h_in, sizeof(float) * in_floats, hipMemcpyHostToDevice, ctx->stream);
-    wave_forward(m->w, ctx->st, ctx->stream);
-    if (!ctx->out_mapped) (void)hipMemcpyAsync(h_out, ctx->st.d_out, sizeof(float) * B_OUT_HOP, hipMemcpyDeviceToHost, ctx->stream);
+    wave_forward(m->w, ctx->st, ctx->stream);   // (its last kernel writes h_out and the sequence word)
   });
-  ok = wait_stream(ctx->stream) && ok;
+  housekeep(ctx->stream);
+  ok = (ok ? flag_wait(ctx->st.h_flag, ctx->seq, ctx->stream) : wait_stream(ctx->stream)) && ok;
+  mark_dirty(ctx->stream);
   if (team_timed_out(ctx->st)) {
     ok = false;
     team_recover(ctx->st, ctx->stream);

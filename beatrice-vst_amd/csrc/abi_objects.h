@@ -71,6 +71,7 @@ struct Beatrice20rc0_PhoneContext1 {
   hipStream_t stream = nullptr;
   float* h_io = nullptr;  // pinned: 160 in | mailbox (step counter, k, codebook pointers) | 128 out
   int hop_count = 0;      // hops done; travels to the device with the input copy (no launch spent on counting)
+  int seq = 0;            // calls enqueued: mailbox word 6, written behind the phone vector in the pinned block when it is there (abi.hip flag_wait)
   // k-NN settings travel with the input copy too (mailbox words behind the audio: counter | k | cbT* | cnorm*), so
   // SetVQNumNeighbors / SetCodebook issue no device call of their own
   int vq_k = 0;
@@ -95,9 +96,10 @@ struct Beatrice20rc0_PitchContext1 {
   int device = bhip::target_device();
   bhip::PitchState st;
   hipStream_t stream = nullptr;
-  float* h_io = nullptr;  // pinned: 160 in | mailbox (step counter, bin range) | 4 feat | 1 bin
+  float* h_io = nullptr;  // pinned: 160 in | mailbox (step counter, bin range, sequence) | 4 feat | 1 bin | sequence echo | previous-bin staging
   int hop_count = 0;
   int min_q = 1, max_q = BEATRICE_20RC0_PITCH_BINS - 1;  // travel with the input copy
+  int seq = 0;            // calls enqueued so far: mailbox word 3, echoed by the head kernel into the pinned result block when the hop's results are there
   void* own_sel[2] = {nullptr, nullptr};
   bhip::HopGraph hop_graph;
   // Pre-execution (abi.hip, "the pitch call runs beside the phone call"): the hop a paired phone context's call enqueued here for the
@@ -123,9 +125,10 @@ struct Beatrice20rc0_WaveformContext1 {
   hipStream_t stream = nullptr;
   float* d_inputs = nullptr;  // device: 128 phone | 4 feat | 1 bin | step counter
   float* h_io = nullptr;      // pinned: inputs | 240 out
-  float* dev_d_out = nullptr; // the module's own device output buffer while the tail writes the pinned block itself (out_mapped)
+  float* dev_d_out = nullptr; // the module's own device output buffer (the tail writes the pinned block itself: out_mapped)
   bool out_mapped = false;
   int hop_count = 0;
+  int seq = 0;                // calls enqueued: travels with the inputs, written behind the 240 samples by the tail kernel (abi.hip flag_wait)
   bhip::HopGraph hop_graph;
   bool ok = false;
 };

@@ -53,7 +53,8 @@ static inline LaunchInfo fft_info(const PitchState& s) {
 }
 static inline PitchHeadArgs head_args(const PitchWeights& w, const PitchState& s) {
   return PitchHeadArgs{s.H, s.logits, s.h, s.d_in, w.voi_w, w.voi_b, s.d_min_q, s.d_max_q, s.d_prev_q,
-                       s.d_q_raw, s.d_q, s.d_feat, s.d_params, s.hop, s.io_stride, s.q_slots, s.B};
+                       s.d_q_raw, s.d_q, s.d_feat, s.d_params, s.hop, s.io_stride, s.q_slots, s.B,
+                       s.B == 1 && s.H == 1 && s.hop_mailbox != nullptr ? s.h_result : nullptr};
 }
 static inline LaunchInfo head_info(const PitchState& s) {
   return LaunchInfo{"pitch.head", 25.0 * s.B * s.H * 448, 4.0 * s.B * s.H * (448 + 160 + 128 + 8)};
@@ -69,6 +70,7 @@ static inline LaunchInfo cond_info(const WaveState& s) {
 static inline TailArgs tail_args(const WaveWeights& w, const WaveState& s) {
   TailArgs ta{};
   ta.in = s.ya2; ta.state = s.tail.base; ta.fin_w = w.fin_w; ta.fin_b = w.fin_b; ta.d_out = s.d_out; ta.hop = s.hop; ta.io_stride = s.io_stride;
+  if (s.B == 1 && s.H == 1) { ta.host_flag = s.h_flag; ta.seq = s.d_seq; }
   ta.w[0] = w.ra_w[1]; ta.b[0] = w.ra_b[1]; ta.w[1] = w.rb_w[1]; ta.b[1] = w.rb_b[1];
   ta.w[2] = w.up_w[2]; ta.b[2] = w.up_b[2]; ta.w[3] = w.ra_w[2]; ta.b[3] = w.ra_b[2]; ta.w[4] = w.rb_w[2]; ta.b[4] = w.rb_b[2];
   ta.w[5] = w.up_w[3]; ta.b[5] = w.up_b[3]; ta.w[6] = w.ra_w[3]; ta.b[6] = w.ra_b[3]; ta.w[7] = w.rb_w[3]; ta.b[7] = w.rb_b[3];

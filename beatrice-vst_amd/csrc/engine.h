@@ -129,6 +129,8 @@ struct PhoneState {
   int* hop_publish_wave = nullptr;  // batch: ... and to the waveform generator's counter pair [counter & 1]
   bool advance_hop = true;    // this module's forward ends with the counter increment
   bool skip_vq = false;       // no stream uses the codebook: phone.out writes d_phone, no k-NN launch
+  void (*after_convs)(void*) = nullptr;   // 1-stream ABI: called once the convolutions (the team launch) are enqueued, before the GRU cell's launch --
+  void* after_convs_arg = nullptr;        // where abi.hip enqueues the partner pitch context's hop (its launches go out while the team launch runs)
   int out_ch = B_PHONE_CH;    // width of the phone vector (256: legacy generations, which have no codebook step)
   // pipe_slack: one more step slot on every ring a later layer reads, so that each LAYER may run as its own pipeline
   // stage one step behind its producer (batch.hip, tick mode)
@@ -176,6 +178,7 @@ struct PitchState {
   bool advance_hop = true;    // this module's forward ends with the counter increment
   int bins = B_PITCH_BINS;    // pitch classes (384: legacy generations)
   bool q_raw_in_feat = false;   // d_q_raw = d_feat + 4 (create())
+  float* h_result = nullptr;    // 1-stream ABI: pinned host block the head kernel writes [4 feat | raw bin | sequence word] into itself (kernels_misc.hip.h PitchHeadArgs::host_out)
   unsigned long long* d_team_xb = nullptr;   // (see PhoneState)
   int* d_team_dead = nullptr;   // pinned host word: set by a team launch that gave a wait up (the call then returns zeros)
   size_t team_granules = 0;
@@ -233,6 +236,8 @@ struct WaveState {
   int q_slots = 1;  // step slots of d_q / d_feat (PitchState::q_slots when shared)
   bool owns_inputs = false;
   float* d_out = nullptr;  // [B][H*240]
+  int* h_flag = nullptr;         // 1-stream ABI: d_out is a pinned host block and the tail kernel writes *d_seq here once the samples are (wave_tail.hip.h TailArgs::host_flag)
+  const int* d_seq = nullptr;
   // conditioning tables and per-stream selectors
   float* d_add_tab = nullptr; int n_add = 0;  // [n_add][256] projected additive embeddings
   float* d_frm_tab = nullptr; int n_frm = 0;  // [n_frm][256] projected formant embeddings

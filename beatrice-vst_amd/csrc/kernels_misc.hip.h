@@ -454,6 +454,8 @@ struct PitchHeadArgs {
   size_t io_stride;     // see F1Args (d_in is read for the frame energy)
   int q_slots;          // step slots of the three outputs (step t -> slot t mod q_slots): 1, or 2 when the consumer may lag a step
   int B;
+  float* host_out;      // 1-stream ABI (B = 1, H = 1) or null: pinned host block [4 feat | raw bin | sequence word]; the kernel writes the results there itself and the
+                        // call's sequence word (mailbox word 3 behind the audio) LAST, behind a system-scope fence: the host polls that word, no copy command, no stream query
 };
 __device__ __forceinline__ void globalize(PitchHeadArgs& a) {
   globalize(a.logits); globalize(a.h); a.d_in = as_global(a.d_in); a.voi_w = as_global(a.voi_w); a.voi_b = as_global(a.voi_b);
@@ -544,10 +546,19 @@ __device__ __forceinline__ void pitch_head_body(const PitchHeadArgs& a, const in
       f[0] = f0; f[1] = f1; f[2] = dq; f[3] = f3;
       a.q_raw[qoff + row] = q;
       a.q_out[qoff + row] = a.params ? pitch_transform_device(q, a.params[b]) : q;
+      if (a.host_out != nullptr) {   // (one stream, one hop per step)
+        a.host_out[0] = f0; a.host_out[1] = f1; a.host_out[2] = dq; a.host_out[3] = f3;
+        reinterpret_cast<int*>(a.host_out)[4] = q;
+      }
     }
     prev = q;
   }
   if (l == 0) a.prev_q[b] = prev;
+  if (l == 0 && a.host_out != nullptr) {
+    const int seq = reinterpret_cast<const int*>(a.d_in + B_IN_HOP)[3];
+    __threadfence_system();
+    __hip_atomic_store(reinterpret_cast<int*>(a.host_out) + 5, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 static __global__ __launch_bounds__(64) void pitch_head_kernel(const PitchHeadArgs a) { pitch_head_body(a, blockIdx.x); }
 struct HeadOp {

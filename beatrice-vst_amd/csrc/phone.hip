@@ -120,6 +120,7 @@ static void phone_forward_h(const PhoneWeights& w, const PhoneState& s, hipStrea
     cur = &s.rb[i];
   }
   }
+  if (s.after_convs != nullptr) s.after_convs(s.after_convs_arg);
   for (int t = 0; t < H; ++t) {  // the recurrence is sequential over the hops of the step
     GruArgs ga{s.rb[3], s.h, w.gru_wih, w.gru_whh, w.gru_bih, w.gru_bhh, s.hop, B, t};
     launch_gru<256, 256>("phone.gru", ga, st);

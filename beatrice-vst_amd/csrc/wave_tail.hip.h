@@ -47,6 +47,8 @@ struct TailArgs {
   float* d_out;  // [B][H*240]
   const int* hop;
   size_t io_stride;   // 0, or floats between the slots of a resident multi-step output buffer (slot = hop[1])
+  int* host_flag;     // 1-stream ABI or null: d_out is then a pinned host block, and this word behind it gets the call's sequence word (*seq) once the 240 samples
+  const int* seq;     // are written (system-scope fence): the host polls it -- no copy command, no stream query (csrc/abi.hip flag_wait)
 #ifdef TAIL_TIMING
   unsigned long long* stamps;  // tools/microbench/tail_timing.hip: [B][16] wall-clock stamps per phase
 #endif
@@ -345,8 +347,10 @@ __device__ __forceinline__ void wave_tail_body(const TailArgs& a, const int b, f
 #pragma unroll
       for (int c = 0; c < 16; ++c) acc = bsp::fma(bsp::lrelu(R2[(tid + j) * 18 + c]), FW[j * 16 + c], acc);
     d_out[((size_t)b * H + hh) * B_OUT_HOP + tid] = bsp::tanh(acc + a.fin_b[0]);
+    if (a.host_flag != nullptr) __threadfence_system();
   }
   __syncthreads();
+  if (a.host_flag != nullptr && tid == 0) __hip_atomic_store(a.host_flag, *a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // (the state below is the next call's business)
   { float* tmp = SI_; SI_ = SO_; SO_ = tmp; }  // this hop's histories are the next hop's state
   }  // hops of the step
   for (int e = tid; e < TAIL_STATE_FLOATS; e += NTHR) st[e] = SI_[e];

@@ -56,12 +56,15 @@ int main(int argc, char** argv) {
   int speaker = 0, pos = 0;
   bool split = false, want_rt = false;
   long period_us = 0;
-  std::string in_path;
+  double gap_us = 0.0;   // --gap-us G: the host idles G microseconds between ExtractPhone1 and EstimatePitch1 (a measurement aid: is the pitch hop done by then?)
+  std::string in_path, dump_path;   // --dump <file>: every timed hop's microseconds (and with --histogram the three calls'), one line per hop
   for (int i = 2; i < argc; ++i) {
     if (!std::strcmp(argv[i], "--histogram")) { split = true; continue; }
     if (!std::strcmp(argv[i], "--in") && i + 1 < argc) { in_path = argv[++i]; continue; }
     if (!std::strcmp(argv[i], "--period-us") && i + 1 < argc) { period_us = std::atol(argv[++i]); continue; }
     if (!std::strcmp(argv[i], "--rt")) { want_rt = true; continue; }
+    if (!std::strcmp(argv[i], "--gap-us") && i + 1 < argc) { gap_us = std::atof(argv[++i]); continue; }
+    if (!std::strcmp(argv[i], "--dump") && i + 1 < argc) { dump_path = argv[++i]; continue; }
     const long v = std::atol(argv[i]);
     if (pos == 0) hops = v; else if (pos == 1) warm = v; else if (pos == 2) speaker = (int)v;
     ++pos;
@@ -156,7 +159,8 @@ int main(int argc, char** argv) {
     int q = 0;
     const double t0 = now_us();
     Beatrice20rc0_ExtractPhone1(pe, in, phone, pc);
-    const double t1 = split ? now_us() : 0.0;
+    double t1 = split ? now_us() : 0.0;
+    if (gap_us > 0.0) { const double until = now_us() + gap_us; while (now_us() < until) {} t1 = now_us(); }
     Beatrice20rc0_EstimatePitch1(pt, in, &q, feat, tc);
     const double t2 = split ? now_us() : 0.0;
     q = q < 1 ? 1 : (q > 447 ? 447 : q);   // (identity pitch transform: intonation 1, shift 0, no correction -- :190-252 clamps to [1, 447])
@@ -176,6 +180,15 @@ int main(int argc, char** argv) {
   }
   double peak = 0.0;
   for (float v : out) peak = std::max(peak, (double)std::fabs(v));
+  if (!dump_path.empty()) {
+    if (FILE* f = std::fopen(dump_path.c_str(), "w")) {
+      for (long i = 0; i < hops; ++i) {
+        if (split) std::fprintf(f, "%.1f %.1f %.1f %.1f\n", lat[i], t_phone[i], t_pitch[i], t_wave[i]);
+        else std::fprintf(f, "%.1f\n", lat[i]);
+      }
+      std::fclose(f);
+    }
+  }
 
   std::vector<long> order((size_t)hops);
   for (long i = 0; i < hops; ++i) order[i] = i;
