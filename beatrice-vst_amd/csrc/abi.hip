@@ -175,7 +175,8 @@ static void mark_dirty(hipStream_t s) {
 }
 static void housekeep(hipStream_t own) {
   if (t_n_dirty == 0) return;
-  std::shared_lock<std::shared_mutex> g(g_pair_mu);
+  std::shared_lock<std::shared_mutex> g(g_pair_mu, std::try_to_lock);   // (an audio thread never waits for a create / destroy / reload elsewhere: next call then)
+  if (!g.owns_lock()) return;
   int kept = 0;
   for (int i = 0; i < t_n_dirty; ++i) {
     const hipStream_t s = t_dirty[i];
@@ -245,7 +246,8 @@ static void spec_drop(Beatrice20rc0_PitchContext1* ctx) {
 static void spec_launch(Beatrice20rc0_PhoneContext1* phone) {
   t_last_phone = phone;
   if (!phone->paired_pitch) return;
-  std::shared_lock<std::shared_mutex> g(g_pair_mu);
+  std::shared_lock<std::shared_mutex> g(g_pair_mu, std::try_to_lock);   // (held exclusively while an estimator is reloaded or a context comes or goes: no pre-execution for this hop)
+  if (!g.owns_lock()) return;
   Beatrice20rc0_PitchContext1* q = phone->paired_pitch;
   if (!q || !q->ok || q->device != phone->device || !q->spec_mu.try_lock()) return;
   std::lock_guard<std::mutex> own(q->spec_mu, std::adopt_lock);
@@ -267,8 +269,8 @@ static void spec_launch(Beatrice20rc0_PhoneContext1* phone) {
 static void spec_learn(Beatrice20rc0_PitchContext1* ctx, const float* input) {
   Beatrice20rc0_PhoneContext1* p = t_last_phone;
   if (!p || ctx->paired_phone || ctx->spec_off) return;
-  std::unique_lock<std::shared_mutex> g(g_pair_mu);
-  if (!g_live_phone.count(p) || !p->ok || p->device != ctx->device || p->paired_pitch || std::memcmp(p->h_io, input, sizeof(float) * B_IN_HOP) != 0) return;
+  std::unique_lock<std::shared_mutex> g(g_pair_mu, std::try_to_lock);   // (busy: the next hop will do)
+  if (!g.owns_lock() || !g_live_phone.count(p) || !p->ok || p->device != ctx->device || p->paired_pitch || std::memcmp(p->h_io, input, sizeof(float) * B_IN_HOP) != 0) return;
   p->paired_pitch = ctx;
   ctx->paired_phone = p;
 }
