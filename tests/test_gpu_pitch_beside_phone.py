@@ -235,7 +235,8 @@ def test_instances_on_threads_of_their_own(bv, oracle, product, model_dir):
         res[abi is product] = outs
     for t in range(n):
         same(res[True][t], res[False][t])
-    assert all(s == (1, hops - 1, 0) for s in st), st
+    # (the registry lock is only ever TRIED on a per-hop call: while another thread pairs its contexts, a hop goes without its pre-execution)
+    assert all(s[0] == 1 and s[2] == 0 and hops - 10 <= s[1] <= hops - 1 for s in st), st
 
 
 def test_phone_and_pitch_calls_of_one_instance_on_two_threads(bv, oracle, product, model_dir):

@@ -54,6 +54,11 @@ for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   [ -n "$CSV" ] && cp "$CSV" "$OUT/pmc_r1_$C/pmc_counter_collection.csv"
 done
 python "$ROOT/tools/pmc_summary.py" "$OUT" "$OUT/pmc_traffic.json"
+# the bench line once more, now that a PMC pass at THESE kernel sources exists (bench.py quotes roofline.traffic only from a summary whose csrc_sha1 is the tree's):
+# the summary goes where bench.py looks (profiles/, under the round's name) on this box; the caller copies it there in the repo as well
+ROUND=$(echo "$TAG" | cut -c1-3)
+cp "$OUT/pmc_traffic.json" "$ROOT/profiles/${ROUND}_pmc_traffic.json"
+timeout 900 python "$ROOT/bench.py" > "$OUT/bench_with_traffic.json" 2> /dev/null
 # keep the merge-back small: raw traces stay on the box
 rm -rf "$OUT/prof" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES"
 for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
