@@ -69,8 +69,8 @@ int BeatriceBatch_EnableSilentBlockRule(BeatriceBatch* b, int enable) {
   }
   if (sr.on) return 0;
   if (b->tk.on) {   // tick mode (plain resident I/O): the flagged streams sit the next STEP out -- their step counters stand still and
-    if (b->hs.on || b->rb.on || (b->H != 1 && b->r48.on)) return -1;   // travel with every step from then on (batch_tick.hip.h, ragged steps); with the 48 kHz
-                                                        // wrapper around the ticks (BindResidentIO48k) that is the shell's rule on its blocks
+    if (b->hs.on || b->rb.on) return -1;   // travel with every step from then on (batch_tick.hip.h, ragged steps); with the 48 kHz wrapper around the ticks
+                                            // (BindResidentIO48k) that is the shell's rule on its blocks -- at two / four blocks per step on a stream's WHOLE step
     sr.next.assign(b->B, 0);
     sr.any_next = false;
     sr.on = true;
@@ -113,7 +113,7 @@ static bool freeze_prepare(BeatriceBatch* b) {
 int BeatriceBatch_SetSilentStreams(BeatriceBatch* b, const unsigned char* flags) {
   if (!b || !b->ok) return -2;
   if (!b->silent.on || !flags) return -1;
-  if ((b->H != 1 && !(b->tk.on && !b->r48.on)) || b->pipelined || (!b->tk.on && b->io_slots > 0) || (b->tk.on && (b->hs.on || b->rb.on))) return -1;   // (the rule's modes: EnableSilentBlockRule)
+  if ((b->H != 1 && !b->tk.on) || b->pipelined || (!b->tk.on && b->io_slots > 0) || (b->tk.on && (b->hs.on || b->rb.on))) return -1;   // (the rule's modes: EnableSilentBlockRule)
   b->silent.any_next = false;
   for (int s = 0; s < b->B; ++s) { b->silent.next[s] = flags[s] ? 1 : 0; b->silent.any_next = b->silent.any_next || flags[s]; }
   return 0;

@@ -1034,13 +1034,15 @@ static __global__ __launch_bounds__(256) void wrap48_tick_kernel(const Wrap48Tic
     wrap48_pre_blocks(w, a, lds);
   } else {
     const int b = w - a.n_pre;
-    if (a.hv_post != nullptr && a.hv_post[b] < 0) {
-      const float* src = a.in48_post + (size_t)b * a.channels * 480;
-      float* dst = a.out48 + (size_t)b * a.channels * 480;
-      for (int n = threadIdx.x; n < 480; n += 256) {
-        float m = src[n];
-        if (a.channels >= 2) { m = m + src[480 + n]; m = m * 0.5f; }
-        for (int c = 0; c < a.channels; ++c) dst[c * 480 + n] = m;
+    if (a.hv_post != nullptr && a.hv_post[b] < 0) {   // (the stream sat the step out: every block of it)
+      for (int hh = 0; hh < a.H; ++hh) {
+        const float* src = a.in48_post + ((size_t)b * a.H + hh) * a.channels * 480;
+        float* dst = a.out48 + ((size_t)b * a.H + hh) * a.channels * 480;
+        for (int n = threadIdx.x; n < 480; n += 256) {
+          float m = src[n];
+          if (a.channels >= 2) { m = m + src[480 + n]; m = m * 0.5f; }
+          for (int c = 0; c < a.channels; ++c) dst[c * 480 + n] = m;
+        }
       }
       return;
     }

@@ -123,7 +123,7 @@ int BeatriceHip_ModelBlobReady(int kind, void* model);
  *   ProcessBlocksRagged                  ok (2)   -     -     -        -     -        -     -     - (2)
  *   ProcessBlocksRaggedDevice            -        -     -     -        -     -        -     ok    -
  *   StreamFrames / StreamFlush           -        -     -     -        ok    -        -     -     -
- *   EnableSilentBlockRule(1)             ok, H=1  -     -     ok (6)   -     ok, H=1  -     -     ok
+ *   EnableSilentBlockRule(1)             ok, H=1  -     -     ok (6)   -     ok (6)   -     -     ok
  *   EnableSilentBlockRule(0)             ok       ok    ok    ok       ok    ok       -     -     ok
  *   SetSilentStreams                     - (3)    -     -     - (3)    -     - (3)    -     -     ok
  *   EnablePipelining(n)                  ok       ok    ok    -        -     -        -     -     - (n >= 1)
@@ -144,9 +144,10 @@ int BeatriceHip_ModelBlobReady(int kind, void* model);
  *
  *   (1) once BeatriceBatch_ConfigureWrapper has been called (-1 before); one hop per step for the in-order calls, H = 1 / 2 / 4 for the binding.
  *   (2) once BeatriceBatch_ConfigureWrapperRates has been called (-1 before); one hop per step.
- *   (3) ok once the rule is enabled in that mode (D: any H; F: one hop per step; the flagged streams sit the NEXT step out).
+ *   (3) ok once the rule is enabled in that mode (D, F: any H; the flagged streams sit the NEXT step out).
  *   (4) with more resident slots than BeatriceBatch_TickStages() and at most 4096 of them, B <= 4096, H = 1 / 2 / 4.
- *   (6) at H = 2 / 4 a flagged stream sits a WHOLE step (its H hops) out; the shell's per-block rule inside a multi-hop step (F) is not built.
+ *   (6) at H = 2 / 4 a flagged stream sits a WHOLE step (its H hops / its H 48 kHz blocks) out: the caller flags a stream whose blocks of the step are ALL silent.  One
+ *       silent block among sounding ones of the same step cannot be skipped there (it is converted as the sounding ones are) -- the shell's per-block rule needs one hop per step.
  *   (5) a bind call on a batch that is already in F / G / P first LEAVES that mode (drains, restarts the wrapper), then binds anew.
  *
  * Environment variables the library reads: BEATRICE_HIP_DEBUG (print HIP errors to stderr), BEATRICE_HIP_CUMASK ("lo-hi;lo-hi;..": CU masks
@@ -285,9 +286,10 @@ int BeatriceBatch_BindResidentIO48k(BeatriceBatch* b, const float* d_in48, float
  * the step carries each stream's own step counter through the pipeline, a second instance of the launch runs from then on.  At
  * every drained point (BeatriceBatch_Synchronize, leaving the mode) the streams are brought back to the batch's one counter
  * (their rings rotated by the steps they missed), so the common launch runs again and BeatriceBatch_EnableTickPipeline(b, 0) /
- * BeatriceBatch_BindResidentIO48k(b, NULL, NULL, ..) succeed as on any batch.  A batch of several hops per step takes the rule in PLAIN tick
- * mode (round 6): a flagged stream then sits a whole step -- its H hops -- out.  Returns -1 for the 48 kHz blocks around the ticks at several hops
- * per step (the shell's rule is per block there), under host streaming or resident wrapper blocks, and (in order) with resident I/O or stage pipelining. */
+ * BeatriceBatch_BindResidentIO48k(b, NULL, NULL, ..) succeed as on any batch.  A batch of several hops per step takes the rule in tick mode
+ * as well (round 6; plain or with the 48 kHz blocks around the ticks): a flagged stream then sits a WHOLE step -- its H hops, its H 48 kHz blocks, which come back as
+ * their own down-mix -- out; a single silent block among sounding ones of a step is converted like them (the shell's per-block rule: one hop per step).
+ * Returns -1 under host streaming or resident wrapper blocks, and (in order) with resident I/O, stage pipelining or several hops per step. */
 int BeatriceBatch_EnableSilentBlockRule(BeatriceBatch* b, int enable);
 int BeatriceBatch_SetSilentStreams(BeatriceBatch* b, const unsigned char* flags);
 

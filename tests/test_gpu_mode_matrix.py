@@ -108,8 +108,7 @@ MATRIX = {
     "tick": {"all": [p for p in _NOT_MINE if p != "TimeTickLaunch"] + _WRAPPERS_IN_ORDER + _BINDS + _HOST_AND_PTRS + ["SetSilentStreams", "EnablePipelining(2)", "EnableHostStreaming(1)", "BindResidentIO(bind)", "BindResidentIO(unbind)",
                                                                                     "ConfigureWrapperRates", "ProfileKernels"]},
     "host_streaming": {"all": [p for p in _NOT_MINE if p != "StreamFrames"] + _BINDS + _OWNS_TICKS + ["EnableSilentBlockRule(1)"]},
-    "blocks48k_around_ticks": {"all": [p for p in _NOT_MINE if p != "ConvertBlocks48kDevice(NULL)"] + ["BindResidentBlocks(bind)", "BindResidentBlocksRagged(bind)", "EnableHostStreaming(1)"] + _OWNS_TICKS,
-                               "H>1": ["EnableSilentBlockRule(1)"]},
+    "blocks48k_around_ticks": {"all": [p for p in _NOT_MINE if p != "ConvertBlocks48kDevice(NULL)"] + ["BindResidentBlocks(bind)", "BindResidentBlocksRagged(bind)", "EnableHostStreaming(1)"] + _OWNS_TICKS},
     "resident_blocks": {"all": [p for p in _NOT_MINE if p not in ("ProcessBlocksDevice(NULL)", "FlushResidentBlocks")] + ["BindResidentIO48k(bind)", "EnableHostStreaming(1)", "EnableSilentBlockRule(1)", "EnableSilentBlockRule(0)",
                                                                                                                       "ConfigureWrapper"] + _OWNS_TICKS},
     "resident_blocks_per_stream_clocks": {"all": [p for p in _NOT_MINE if p not in ("ProcessBlocksRaggedDevice", "FlushResidentBlocks")] + ["BindResidentIO48k(bind)", "EnableHostStreaming(1)", "EnableSilentBlockRule(1)",

@@ -95,26 +95,32 @@ def test_streams_that_sit_steps_out_in_tick_mode_match_the_oracle(bv, oracle, pr
     assert not bad_tail, "in order after tick mode, (stream, step, max-abs): %s" % bad_tail[:12]
 
 
-@pytest.mark.parametrize("channels", [1, 2])
-def test_silent_48k_blocks_per_stream_around_the_tick_pipeline(bv, product, model_dir, channels):
+@pytest.mark.parametrize("channels,H", [(1, 1), (2, 1), (2, 2), (1, 4), (2, 4)])
+def test_silent_48k_blocks_per_stream_around_the_tick_pipeline(bv, product, model_dir, channels, H):
     """The same rule where the shell applies it: 48 kHz blocks, here resident on the device with the tick pipeline between the two
     halves of the wrapper (BeatriceBatch_BindResidentIO48k).  Reference per stream: ProcessorProxy::ProcessChannels of the host
-    layer on the ORACLE core (the rule as the shell has it: the block is handed back, nothing moves)."""
+    layer on the ORACLE core (the rule as the shell has it: the block is handed back, nothing moves).
+    H = 2, 4 (round 6): a batch of several blocks per step -- a flagged stream sits a WHOLE step out, so the silent blocks here come in whole steps
+    (to the reference each of them is a silent block like any other); speaker switches fall on step boundaries, where a batch applies them."""
     import ctypes as C
     import wrapperlib
     from test_host_proxy import K_MODEL, K_VOICE, K_VQ, Proxy
     from tick_driver import Hip
     _f32p = C.POINTER(C.c_float)
-    B, blocks, n = 6, 44, 480
+    B, n = 6, 480
+    steps = 44 if H == 1 else (26 if H == 2 else 16)
+    blocks = steps * H
     x = np.zeros((B, channels, blocks * n), np.float32)
     for s in range(B):
         for c in range(channels):
             x[s, c] = (0.7 if c else 1.0) * wrapperlib.test_signal(blocks * n, 48000, seed=5200 + 5 * s + c)
-    silent = {0: {3, 4, 5, 11}, 1: {0, 1, 9, 20, 21}, 2: set(), 3: set(range(6, 19)), 4: {2, 13, 14, 43}, 5: {30}}
+    silent_steps = ({0: {3, 4, 5, 11}, 1: {0, 1, 9, 20, 21}, 2: set(), 3: set(range(6, 19)), 4: {2, 13, 14, 43}, 5: {30}} if H == 1 else
+                    {0: {3, 4, 11}, 1: {0, 1, 9}, 2: set(), 3: set(range(5, 12)), 4: {2, 13, 14, steps - 1}, 5: {7}})
+    silent = {s: {st * H + hh for st in ks if st < steps for hh in range(H)} for s, ks in silent_steps.items()}
     for s, ks in silent.items():
         for k in ks:
             x[s, :, k * n:(k + 1) * n] = 0.0
-    switch = {0: (3, 2), 1: (8, 0), 3: (5, 1), 4: (13, 2)}
+    switch = {0: (3 * H, 2), 1: (8 * H, 0), 3: (5 * H, 1), 4: (13 * H, 2)}
     want = np.zeros_like(x)
     for s in range(B):
         p = Proxy(48000.0)
@@ -137,38 +143,41 @@ def test_silent_48k_blocks_per_stream_around_the_tick_pipeline(bv, product, mode
         p.close()
 
     m = bv.Models(product, model_dir)
-    batch = bv.Batch(m, B)
+    batch = bv.Batch(m, B, hops_per_step=H)
     a, h = batch.a, batch.h
     for s in range(B):
         a.BeatriceBatch_SetTargetSpeaker(h, s, s % 3)
         a.BeatriceBatch_SetVQNumNeighbors(h, s, s % 3)
     hip = Hip()
     slots = a.BeatriceBatch_TickStages(h) + 3
-    d_in, d_out = hip.malloc(slots * B * channels * n * 4), hip.malloc(slots * B * channels * n * 4)
+    d_in, d_out = hip.malloc(slots * B * H * channels * n * 4), hip.malloc(slots * B * H * channels * n * 4)
     assert a.BeatriceBatch_BindResidentIO48k(h, d_in, d_out, channels, slots) == 0
     assert a.BeatriceBatch_EnableSilentBlockRule(h, 1) == 0
     got = np.zeros_like(x)
+    xs = x.reshape(B, channels, steps, H, n).transpose(2, 0, 3, 1, 4)   # [step][B][H][channels][n]: a step's resident slot
+    gs = np.zeros_like(xs)
     k0 = 0
-    while k0 < blocks:
-        cnt = min(11, blocks - k0)
-        buf = np.zeros((slots, B, channels, n), np.float32)
+    while k0 < steps:
+        cnt = min(11, steps - k0)
+        buf = np.zeros((slots, B, H, channels, n), np.float32)
         for k in range(k0, k0 + cnt):
-            buf[k % slots] = x[:, :, k * n:(k + 1) * n]
+            buf[k % slots] = xs[k]
         hip.h2d(d_in, buf)
         for k in range(k0, k0 + cnt):
             for s in range(B):
-                if s in switch and switch[s][0] == k:
+                if s in switch and switch[s][0] == k * H:
                     a.BeatriceBatch_SetTargetSpeaker(h, s, switch[s][1])
-            flags = bytes(1 if k in silent[s] else 0 for s in range(B))
+            flags = bytes(1 if k * H in silent[s] else 0 for s in range(B))
             if any(flags):
                 assert a.BeatriceBatch_SetSilentStreams(h, flags) == 0
             assert a.BeatriceBatch_ConvertBlocks48kDevice(h, None, None, channels) == 0
         assert a.BeatriceBatch_Synchronize(h) == 0
-        out = np.zeros((slots, B, channels, n), np.float32)
+        out = np.zeros((slots, B, H, channels, n), np.float32)
         hip.d2h(out, d_out)
         for k in range(k0, k0 + cnt):
-            got[:, :, k * n:(k + 1) * n] = out[k % slots]
+            gs[k] = out[k % slots]
         k0 += cnt
+    got = np.ascontiguousarray(gs.transpose(1, 3, 0, 2, 4)).reshape(B, channels, blocks * n)
     batch.close()
     m.close()
     hip.free(d_in); hip.free(d_out)
